@@ -1,0 +1,179 @@
+"""Synthetic (u, i, ctx, r) tuple generator of BASELINE.md section 3, shaped the way
+DataDAO.readData (reference src/carskit/data/processor/DataDAO.java:198-354) would hand the tuples to
+a recommender: inner ids in first-seen order, duplicates collapsed (last write wins, :342), tuples in
+the CRS order of the (user-item pair x context) rating matrix that MatrixIterator yields.
+
+Pure numpy, deterministic for a given seed (PCG64).  No reference code involved."""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+DEFAULT_SEED = 20260927
+
+
+@dataclass
+class RatingData:
+    n_users: int
+    n_items: int
+    n_conds: int          # number of context conditions (columns >= 3 of the binary format)
+    n_dims: int           # context dimensions = active conditions per rating
+    u: np.ndarray         # int32 [n]  inner user id of each tuple, CRS order
+    j: np.ndarray         # int32 [n]  inner item id
+    ctx: np.ndarray       # int32 [n]  inner context-combination id
+    r: np.ndarray         # float64 [n]
+    ctx_ptr: np.ndarray   # int32 [n_ctx+1]
+    ctx_conds: np.ndarray  # int32 [nnz]  ascending condition ids of each context combination
+    min_rate: float = 1.0
+    max_rate: float = 5.0
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n(self):
+        return int(self.r.shape[0])
+
+    @property
+    def n_ctx(self):
+        return int(self.ctx_ptr.shape[0] - 1)
+
+    def subset(self, idx):
+        """Tuples idx (ascending positions keep CRS order); id spaces unchanged."""
+        idx = np.asarray(idx)
+        return RatingData(self.n_users, self.n_items, self.n_conds, self.n_dims, self.u[idx], self.j[idx],
+                          self.ctx[idx], self.r[idx], self.ctx_ptr, self.ctx_conds, self.min_rate, self.max_rate,
+                          dict(self.meta))
+
+
+def _first_seen_ids(keys):
+    """Map each key to the rank of its first occurrence (DataDAO: id = map size on first sight)."""
+    uniq, first, inv = np.unique(keys, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")
+    rank = np.empty(len(uniq), dtype=np.int64)
+    rank[order] = np.arange(len(uniq), dtype=np.int64)
+    return rank[inv], len(uniq)
+
+
+def generate(n_users, n_items, n_dims, conds_per_dim, n_ratings, seed=DEFAULT_SEED, item_zipf=None,
+             latent_k=8, noise=0.5):
+    """Generate ~n_ratings tuples (fewer after duplicate removal).
+
+    u, i uniform (or items Zipf(item_zipf)); one active condition per dimension, uniform; integer
+    ratings 1..5 from a latent_k model plus N(0, noise)."""
+    rng = np.random.default_rng(seed)
+    n = int(n_ratings)
+    raw_u = rng.integers(0, n_users, n, dtype=np.int64)
+    if item_zipf:
+        w = 1.0 / np.arange(1, n_items + 1, dtype=np.float64) ** float(item_zipf)
+        cdf = np.cumsum(w)
+        cdf /= cdf[-1]
+        raw_i = np.searchsorted(cdf, rng.random(n)).astype(np.int64)
+        raw_i = rng.permutation(n_items)[raw_i]
+    else:
+        raw_i = rng.integers(0, n_items, n, dtype=np.int64)
+    raw_c = rng.integers(0, conds_per_dim, (n_dims, n), dtype=np.int64) if n_dims else np.zeros((0, n), np.int64)
+    ckey = np.zeros(n, dtype=np.int64)
+    for d in range(n_dims):
+        ckey = ckey * conds_per_dim + raw_c[d]
+    n_ckeys = max(1, conds_per_dim ** n_dims)
+
+    # ratings from a small latent model (chunked to bound memory)
+    zu = rng.standard_normal((n_users, latent_k)).astype(np.float32)
+    zi = rng.standard_normal((n_items, latent_k)).astype(np.float32)
+    zc = rng.standard_normal(n_ckeys if n_ckeys < (1 << 24) else 1).astype(np.float32) * 0.3
+    r = np.empty(n, dtype=np.float64)
+    step = 1 << 22
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        dot = np.einsum("nk,nk->n", zu[raw_u[s:e]], zi[raw_i[s:e]]) / np.sqrt(latent_k)
+        cb = zc[ckey[s:e]] if zc.shape[0] > 1 else 0.0
+        val = 3.0 + dot + cb + noise * rng.standard_normal(e - s).astype(np.float32)
+        r[s:e] = np.clip(np.rint(val), 1, 5)
+    del zu, zi
+
+    # duplicates of (u, i, ctx): the LAST line wins (dataTable.put overwrites, DataDAO.java:342)
+    trip = (raw_u * n_items + raw_i) * n_ckeys + ckey
+    rev = np.arange(n - 1, -1, -1)
+    _, last_rev = np.unique(trip[rev], return_index=True)
+    last_pos = rev[last_rev]                       # stream position of the surviving line per triple
+    keep_val = r[last_pos]
+    # the triple keeps the ids of its FIRST appearance; find the first position of each triple
+    _, first_pos = np.unique(trip, return_index=True)  # same sorted-unique order as above
+    order = np.argsort(first_pos, kind="stable")
+    pos = first_pos[order]
+    r = keep_val[order]
+    raw_u, raw_i, ckey = raw_u[pos], raw_i[pos], ckey[pos]
+    n = len(r)
+
+    # first-seen inner ids (over the de-duplicated stream; every id's first sight is a first-appearance line)
+    u, nu = _first_seen_ids(raw_u)
+    i, ni = _first_seen_ids(raw_i)
+    ui, n_ui = _first_seen_ids(raw_u * n_items + raw_i)
+    ctx, n_ctx = _first_seen_ids(ckey)
+
+    # condition ids: column d*conds_per_dim + c; the context key lists them in ascending column order
+    ctx_first = np.empty(n_ctx, dtype=np.int64)
+    ctx_first[ctx[::-1]] = np.arange(n - 1, -1, -1)  # first stream position of each ctx id
+    ck = ckey[ctx_first]
+    conds = np.zeros((n_ctx, n_dims), dtype=np.int32)
+    for d in range(n_dims - 1, -1, -1):
+        conds[:, d] = d * conds_per_dim + (ck % conds_per_dim)
+        ck = ck // conds_per_dim
+    ctx_ptr = (np.arange(n_ctx + 1, dtype=np.int64) * n_dims).astype(np.int32)
+    ctx_conds = conds.reshape(-1)
+
+    # CRS order: user-item pair id ascending, then context id ascending
+    order = np.lexsort((ctx, ui))
+    return RatingData(int(nu), int(ni), int(n_dims * conds_per_dim), int(n_dims), u[order].astype(np.int32),
+                      i[order].astype(np.int32), ctx[order].astype(np.int32), r[order], ctx_ptr, ctx_conds, 1.0, 5.0,
+                      {"seed": seed, "n_ui": int(n_ui), "requested": int(n_ratings), "item_zipf": item_zipf})
+
+
+def split(data, test_ratio=0.2, seed=DEFAULT_SEED + 1):
+    """Seeded 80/20 split (NOT the reference's RNG); both parts keep CRS order and the id spaces."""
+    rng = np.random.default_rng(seed)
+    mask = rng.random(data.n) < test_ratio
+    idx = np.arange(data.n)
+    return data.subset(idx[~mask]), data.subset(idx[mask])
+
+
+def to_2d(data):
+    """DataDAO.toTraditionalSparseMatrix (reference DataDAO.java:1241-1257): user x item matrix whose
+    value is the mean over contexts of each (user, item) pair, iterated user ascending, item ascending.
+    Returns (u, j, r) int32/int32/float64 in that CRS order."""
+    key = data.u.astype(np.int64) * data.n_items + data.j
+    uniq, inv = np.unique(key, return_inverse=True)
+    sums = np.zeros(len(uniq))
+    cnts = np.zeros(len(uniq))
+    # sequential accumulation order within a pair = CRS order of the contextual matrix
+    np.add.at(sums, inv, data.r)
+    np.add.at(cnts, inv, 1.0)
+    return (uniq // data.n_items).astype(np.int32), (uniq % data.n_items).astype(np.int32), sums / cnts
+
+
+def java_float(x):
+    """(double)(float)x : hyper-parameters are parsed as Java float (IterativeRecommender.java:36-40)."""
+    return float(np.float32(x))
+
+
+def init_state(model, data, k, seed=DEFAULT_SEED + 2, dtype=np.float64):
+    """Initial parameter arrays in the reference's shapes and distributions (P,Q ~ N(0,0.1) then the
+    model's bias containers in source order; icBias/ucBias of CAMF_CI/CU ~ U(0,1)); the stream is numpy's,
+    not librec's unseeded java.util.Random -- parity runs inject these arrays on both sides."""
+    rng = np.random.default_rng(seed)
+    g = lambda *s: (0.1 * rng.standard_normal(s)).astype(dtype)
+    st = {"P": g(data.n_users, k), "Q": g(data.n_items, k)}
+    if model in ("BiasedMF", "CAMF_C"):
+        st["userBias"], st["itemBias"] = g(data.n_users), g(data.n_items)
+        if model == "CAMF_C":
+            st["condBias"] = g(data.n_conds)
+    elif model == "CAMF_CI":
+        st["userBias"] = g(data.n_users)
+        st["icBias"] = rng.random((data.n_items, data.n_conds)).astype(dtype)
+    elif model == "CAMF_CU":
+        st["itemBias"] = g(data.n_items)
+        st["ucBias"] = rng.random((data.n_users, data.n_conds)).astype(dtype)
+    elif model == "CAMF_CUCI":
+        st["ucBias"] = g(data.n_users, data.n_conds)
+        st["icBias"] = g(data.n_items, data.n_conds)
+    else:
+        raise ValueError(model)
+    return st

@@ -1,0 +1,49 @@
+"""Shared helpers for the test-suite (problem builders, oracle adapters)."""
+import numpy as np
+
+from carskit_amd import synth
+from oracle import oracle_np
+
+MODELS = ["BiasedMF", "CAMF_C", "CAMF_CI", "CAMF_CU", "CAMF_CUCI"]
+
+# setting.conf defaults as the doubles the reference computes with (Java float -> double)
+REG = synth.java_float(1e-4)
+REGC = synth.java_float(1e-3)
+LR = synth.java_float(2e-2)
+
+
+def small_data(n_users=23, n_items=11, n_dims=2, conds_per_dim=3, n=300, seed=7, item_zipf=None):
+    return synth.generate(n_users, n_items, n_dims, conds_per_dim, n, seed=seed, item_zipf=item_zipf)
+
+
+def tuples_for(model, data):
+    """(u, j, ctx, r) arrays in the order the model's buildModel iterates."""
+    if model == "BiasedMF":
+        u, j, r = synth.to_2d(data)
+        return u, j, np.zeros(len(r), np.int32), r
+    return data.u, data.j, data.ctx, data.r
+
+
+def np_model(model, data, k, state, gm, regU=REG, regI=REG, regB=REG, regC=REGC):
+    conds = [data.ctx_conds[data.ctx_ptr[c]:data.ctx_ptr[c + 1]].tolist() for c in range(data.n_ctx)]
+    m = oracle_np.MODELS[model](k, data.n_users, data.n_items, data.n_conds, conds, gm, regU, regI, regB, regC)
+    for name, a in state.items():
+        setattr(m, name, np.asarray(a, dtype=np.float64).tolist())
+    return m
+
+
+def np_state(m):
+    out = {}
+    for name in ("P", "Q", "userBias", "itemBias", "condBias", "ucBias", "icBias"):
+        v = getattr(m, name)
+        if v is not None:
+            out[name] = np.array(v, dtype=np.float64)
+    return out
+
+
+def c_oracle(model, data, k, state, gm, regU=REG, regI=REG, regB=REG, regC=REGC):
+    from oracle import oracle_c
+    u, j, ctx, r = tuples_for(model, data)
+    st = {n: np.array(a, dtype=np.float64, copy=True) for n, a in state.items()}
+    return oracle_c.Oracle(model, k, data.n_users, data.n_items, data.n_conds, u, j, ctx, r, data.ctx_ptr,
+                           data.ctx_conds, st, gm, regU, regI, regB, regC)
