@@ -1,0 +1,247 @@
+"""ctypes binding of libcarskit_mi355x.so (include/carskit_mi355x.h).
+
+This is the only way Python reaches the compute path; there is no Python or CPU fallback.  If the
+shared library is missing (not built) loading raises; without a HIP device cmi_create fails with
+CMI_E_NO_DEVICE and `Instance(...)` raises `CmiError`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcarskit_mi355x.so")
+
+OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NUMERIC, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+MODEL_IDS = {"BiasedMF": 0, "CAMF_C": 1, "CAMF_CI": 2, "CAMF_CU": 3, "CAMF_CUCI": 4}
+STATE_IDS = {"P": 0, "Q": 1, "userBias": 2, "itemBias": 3, "condBias": 4, "ucBias": 5, "icBias": 6}
+MODEL_STATES = {
+    "BiasedMF": ("P", "Q", "userBias", "itemBias"),
+    "CAMF_C": ("P", "Q", "userBias", "itemBias", "condBias"),
+    "CAMF_CI": ("P", "Q", "userBias", "icBias"),
+    "CAMF_CU": ("P", "Q", "itemBias", "ucBias"),
+    "CAMF_CUCI": ("P", "Q", "ucBias", "icBias"),
+}
+# the state keyed by item (replicated and reconciled across GPUs when tuples are sharded by user)
+ITEM_SIDE = {"Q", "itemBias", "icBias", "condBias"}
+
+FLAG_STATE_F64 = 0x1
+FLAG_SCHED_SERIAL = 0x2
+FLAG_STRICT = 0x4
+FLAG_RELAX_COND = 0x8
+FLAG_NO_GRAPH = 0x10
+
+# every symbol include/carskit_mi355x.h declares: (name, restype, argtypes)
+_vp, _i64, _i32, _dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+SYMBOLS = [
+    ("cmi_abi_version", C.c_int, []),
+    ("cmi_device_count", C.c_int, []),
+    ("cmi_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.POINTER(_vp)]),
+    ("cmi_destroy", C.c_int, [_vp]),
+    ("cmi_last_error", C.c_char_p, [_vp]),
+    ("cmi_set_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    ("cmi_set_state", C.c_int, [_vp, C.c_int, _vp, _i64, C.c_int]),
+    ("cmi_get_state", C.c_int, [_vp, C.c_int, _vp, _i64, C.c_int]),
+    ("cmi_set_hparams", C.c_int, [_vp, _dbl, _dbl, _dbl, _dbl, _dbl]),
+    ("cmi_train_epoch", C.c_int, [_vp, _dbl, C.POINTER(_dbl)]),
+    ("cmi_train", C.c_int, [_vp, C.c_int, _dbl, _dbl, C.c_int, _dbl, C.c_int, _vp, _vp, C.POINTER(C.c_int),
+                            C.POINTER(_dbl)]),
+    ("cmi_predict_batch", C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, _dbl, _dbl, _vp]),
+    ("cmi_eval_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, C.POINTER(_i64)]),
+    ("cmi_state_device_ptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(C.c_int)]),
+    ("cmi_stream", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("cmi_synchronize", C.c_int, [_vp]),
+    ("cmi_train_epoch_async", C.c_int, [_vp, _dbl]),
+    ("cmi_last_loss", C.c_int, [_vp, C.POINTER(_dbl)]),
+    ("cmi_schedule_info", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("cmi_last_epoch_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
+    ("cmi_level_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, _vp, _vp, _i64, C.POINTER(_i64)]),
+]
+
+_LIB = None
+
+
+class CmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libcarskit_mi355x error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load the C-ABI library (raises OSError if it has not been built)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError("%s not found: build it with `python __graft_entry__.py` or `make -C carskit_amd/csrc` "
+                          "(there is no Python/CPU fallback for the compute path)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def device_count():
+    return lib().cmi_device_count()
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def level_schedule(u, j, n_users, n_items, order=0):
+    """Host-only: (perm, level_off) of the dependency-level schedule (see cmi_level_schedule)."""
+    u = np.ascontiguousarray(u, dtype=np.int32)
+    j = np.ascontiguousarray(j, dtype=np.int32)
+    n = len(u)
+    nl = _i64()
+    rc = lib().cmi_level_schedule(n, _p(u), _p(j), n_users, n_items, order, None, None, 0, C.byref(nl))
+    if rc != OK:
+        raise CmiError(rc, "cmi_level_schedule")
+    perm = np.empty(n, dtype=np.int32)
+    off = np.empty(nl.value + 1, dtype=np.int64)
+    rc = lib().cmi_level_schedule(n, _p(u), _p(j), n_users, n_items, order, _p(perm), _p(off), len(off), C.byref(nl))
+    if rc != OK:
+        raise CmiError(rc, "cmi_level_schedule")
+    return perm, off
+
+
+class Instance:
+    """One recommender instance on one GPU (a `cmi_handle`)."""
+
+    def __init__(self, model, k, n_users, n_items, n_conds, device=0, flags=0):
+        self.L = lib()
+        self.model = model if isinstance(model, str) else {v: n for n, v in MODEL_IDS.items()}[model]
+        self.k, self.n_users, self.n_items, self.n_conds = k, n_users, n_items, n_conds
+        self.flags = flags
+        self.h = _vp()
+        rc = self.L.cmi_create(MODEL_IDS[self.model], k, n_users, n_items, n_conds, device, flags, C.byref(self.h))
+        if rc != OK:
+            self.h = None
+            raise CmiError(rc, self.L.cmi_last_error(None).decode())
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise CmiError(rc, self.L.cmi_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cmi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- data ---------------------------------------------------------------------------------------
+    def set_ratings(self, u, j, ctx, r, ctx_ptr=None, ctx_conds=None):
+        c32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        u, j, ctx, ctx_ptr, ctx_conds = c32(u), c32(j), c32(ctx), c32(ctx_ptr), c32(ctx_conds)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        n_ctx = 0 if ctx_ptr is None else len(ctx_ptr) - 1
+        self._chk(self.L.cmi_set_ratings(self.h, len(r), _p(u), _p(j), _p(ctx), _p(r), n_ctx, _p(ctx_ptr),
+                                         _p(ctx_conds)))
+
+    def set_state(self, name, arr):
+        a = np.ascontiguousarray(arr)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float64)
+        self._chk(self.L.cmi_set_state(self.h, STATE_IDS[name], _p(a), a.size, 1 if a.dtype == np.float64 else 0))
+
+    def set_states(self, state):
+        for name, arr in state.items():
+            if arr is not None:
+                self.set_state(name, arr)
+
+    def state_shape(self, name):
+        return {"P": (self.n_users, self.k), "Q": (self.n_items, self.k), "userBias": (self.n_users,),
+                "itemBias": (self.n_items,), "condBias": (self.n_conds,), "ucBias": (self.n_users, self.n_conds),
+                "icBias": (self.n_items, self.n_conds)}[name]
+
+    def get_state(self, name, dtype=np.float64):
+        out = np.empty(self.state_shape(name), dtype=dtype)
+        self._chk(self.L.cmi_get_state(self.h, STATE_IDS[name], _p(out), out.size, 1 if dtype == np.float64 else 0))
+        return out
+
+    def get_states(self, dtype=np.float64):
+        return {name: self.get_state(name, dtype) for name in MODEL_STATES[self.model]}
+
+    def set_hparams(self, regU, regI, regB, regC, global_mean):
+        self._chk(self.L.cmi_set_hparams(self.h, regU, regI, regB, regC, global_mean))
+
+    # -- training -----------------------------------------------------------------------------------
+    def train_epoch(self, lrate):
+        loss = _dbl()
+        self._chk(self.L.cmi_train_epoch(self.h, lrate, C.byref(loss)))
+        return loss.value
+
+    def train_epoch_async(self, lrate):
+        self._chk(self.L.cmi_train_epoch_async(self.h, lrate))
+
+    def last_loss(self):
+        loss = _dbl()
+        self._chk(self.L.cmi_last_loss(self.h, C.byref(loss)))
+        return loss.value
+
+    def train(self, num_iters, init_lrate, max_lrate=-1.0, bold_driver=False, decay=-1.0, early_stop=0):
+        losses, lrs = np.zeros(num_iters), np.zeros(num_iters)
+        n, final = C.c_int(0), _dbl(0)
+        rc = self.L.cmi_train(self.h, num_iters, init_lrate, max_lrate, int(bold_driver), decay, early_stop,
+                              _p(losses), _p(lrs), C.byref(n), C.byref(final))
+        self.iters_run, self.final_lrate = n.value, final.value
+        self._chk(rc)
+        return losses[:n.value], lrs[:n.value]
+
+    def synchronize(self):
+        self._chk(self.L.cmi_synchronize(self.h))
+
+    def last_epoch_ms(self):
+        ms = C.c_float()
+        self._chk(self.L.cmi_last_epoch_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def schedule_info(self):
+        info = (_i64 * 6)()
+        self._chk(self.L.cmi_schedule_info(self.h, info))
+        return dict(zip(("levels", "max_level", "tuples", "dmax", "state_bytes", "tuple_bytes"), list(info)))
+
+    def stream(self):
+        s = _vp()
+        self._chk(self.L.cmi_stream(self.h, C.byref(s)))
+        return s.value
+
+    def state_device_ptr(self, name):
+        ptr, cnt, dt = _vp(), _i64(), C.c_int()
+        self._chk(self.L.cmi_state_device_ptr(self.h, STATE_IDS[name], C.byref(ptr), C.byref(cnt), C.byref(dt)))
+        return ptr.value, cnt.value, (np.float64 if dt.value else np.float32)
+
+    # -- inference ----------------------------------------------------------------------------------
+    def predict(self, u, j, ctx=None, bound=None):
+        c32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        u, j, ctx = c32(u), c32(j), c32(ctx)
+        out = np.empty(len(u))
+        lo, hi = bound if bound else (0.0, 0.0)
+        self._chk(self.L.cmi_predict_batch(self.h, len(u), _p(u), _p(j), _p(ctx), 1 if bound else 0, lo, hi, _p(out)))
+        return out
+
+    def eval_ratings(self, u, j, ctx, r, min_rate, max_rate):
+        c32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        u, j, ctx = c32(u), c32(j), c32(ctx)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        out, cnt = np.zeros(5), _i64()
+        self._chk(self.L.cmi_eval_ratings(self.h, len(r), _p(u), _p(j), _p(ctx), _p(r), min_rate, max_rate, _p(out),
+                                          C.byref(cnt)))
+        res = dict(zip(("MAE", "RMSE", "NMAE", "rMAE", "rRMSE"), out.tolist()))
+        res["n"] = cnt.value
+        return res

@@ -1,0 +1,710 @@
+// cmi_api.cpp -- implementation of include/carskit_mi355x.h: instance handle, device memory,
+// schedule construction, hipGraph capture of the per-level launches, the isConverged/updateLRate
+// loop, predict/eval.  Compiled by hipcc together with mf_sgd_kernels.hip into libcarskit_mi355x.so.
+// There is deliberately no CPU code path for any compute entry point.
+#include "../../include/carskit_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "level_schedule.hpp"
+#include "mf_sgd_kernels.hpp"
+
+using namespace cmi;
+
+struct cmi_instance {
+    int model = 0, k = 0, n_users = 0, n_items = 0, n_conds = 0, device = 0;
+    unsigned flags = 0;
+    bool f64 = false, serial = false, strict = false, relax = false, use_graph = true, fast = false;
+    std::string err;
+    hipStream_t stream = nullptr;
+    void *state[CMI_STATE_COUNT] = {};
+    int64_t state_count[CMI_STATE_COUNT] = {};
+    // tuple stream (schedule order)
+    int64_t n = 0;
+    int dmax = 0;
+    int32_t n_ctx = 0;
+    int32_t *d_su = nullptr, *d_sj = nullptr, *d_sconds = nullptr, *d_ctx_ptr = nullptr, *d_ctx_conds = nullptr;
+    void *d_sr = nullptr;
+    int64_t ctx_nnz = 0;
+    std::vector<int64_t> level_off, slot_off;
+    int64_t n_slots = 0, max_level = 0, tuple_bytes = 0;
+    double *d_loss_part = nullptr, *d_scratch = nullptr, *d_loss = nullptr;
+    HParams *d_hp = nullptr;
+    HParams hp{0, 0, 0, 0, 0, 0};
+    double *h_loss = nullptr; // pinned
+    hipGraphExec_t graph_exec = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_ratings = false, epoch_timed = false;
+    double last_loss = 0.0;
+};
+
+static thread_local std::string g_create_err;
+
+#define CMI_FAIL(h, code, ...)                                                                          \
+    do {                                                                                                \
+        char buf_[512];                                                                                 \
+        snprintf(buf_, sizeof buf_, __VA_ARGS__);                                                       \
+        (h)->err = buf_;                                                                                \
+        return (code);                                                                                  \
+    } while (0)
+
+#define CMI_HIP(h, expr)                                                                                \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) CMI_FAIL(h, CMI_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+static bool model_has(int model, int which) {
+    switch (which) {
+    case CMI_STATE_P:
+    case CMI_STATE_Q: return true;
+    case CMI_STATE_USER_BIAS: return model == CMI_MODEL_BIASEDMF || model == CMI_MODEL_CAMF_C || model == CMI_MODEL_CAMF_CI;
+    case CMI_STATE_ITEM_BIAS: return model == CMI_MODEL_BIASEDMF || model == CMI_MODEL_CAMF_C || model == CMI_MODEL_CAMF_CU;
+    case CMI_STATE_COND_BIAS: return model == CMI_MODEL_CAMF_C;
+    case CMI_STATE_UC_BIAS: return model == CMI_MODEL_CAMF_CU || model == CMI_MODEL_CAMF_CUCI;
+    case CMI_STATE_IC_BIAS: return model == CMI_MODEL_CAMF_CI || model == CMI_MODEL_CAMF_CUCI;
+    }
+    return false;
+}
+
+static int64_t state_elems(const cmi_instance *h, int which) {
+    switch (which) {
+    case CMI_STATE_P: return (int64_t)h->n_users * h->k;
+    case CMI_STATE_Q: return (int64_t)h->n_items * h->k;
+    case CMI_STATE_USER_BIAS: return h->n_users;
+    case CMI_STATE_ITEM_BIAS: return h->n_items;
+    case CMI_STATE_COND_BIAS: return h->n_conds;
+    case CMI_STATE_UC_BIAS: return (int64_t)h->n_users * h->n_conds;
+    case CMI_STATE_IC_BIAS: return (int64_t)h->n_items * h->n_conds;
+    }
+    return 0;
+}
+
+static size_t esize(const cmi_instance *h) { return h->f64 ? 8 : 4; }
+
+extern "C" int cmi_abi_version(void) { return CMI_ABI_VERSION; }
+
+extern "C" int cmi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *cmi_last_error(cmi_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+static void free_ratings(cmi_instance *h) {
+    if (h->graph_exec) {
+        hipGraphExecDestroy(h->graph_exec);
+        h->graph_exec = nullptr;
+    }
+    void *ptrs[] = {h->d_su, h->d_sj, h->d_sconds, h->d_ctx_ptr, h->d_ctx_conds, h->d_sr, h->d_loss_part};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    h->d_su = h->d_sj = h->d_sconds = h->d_ctx_ptr = h->d_ctx_conds = nullptr;
+    h->d_sr = nullptr;
+    h->d_loss_part = nullptr;
+    h->have_ratings = false;
+    h->n = 0;
+}
+
+extern "C" int cmi_destroy(cmi_handle h) {
+    if (!h) return CMI_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    free_ratings(h);
+    for (void *&p : h->state)
+        if (p) {
+            hipFree(p);
+            p = nullptr;
+        }
+    if (h->d_scratch) hipFree(h->d_scratch);
+    if (h->d_loss) hipFree(h->d_loss);
+    if (h->d_hp) hipFree(h->d_hp);
+    if (h->h_loss) hipHostFree(h->h_loss);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return CMI_OK;
+}
+
+extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_conds, int device, unsigned flags,
+                          cmi_handle *out) {
+    if (out) *out = nullptr;
+    if (!out || model < 0 || model > CMI_MODEL_CAMF_CUCI || k <= 0 || n_users <= 0 || n_items <= 0 || n_conds < 0) {
+        g_create_err = "cmi_create: invalid argument";
+        return CMI_E_INVALID;
+    }
+    int ndev = cmi_device_count();
+    if (ndev <= 0) {
+        g_create_err = "cmi_create: no HIP device visible (libcarskit_mi355x has no CPU fallback)";
+        return CMI_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_err = "cmi_create: device index out of range";
+        return CMI_E_INVALID;
+    }
+    if ((flags & CMI_FLAG_RELAX_COND) && model != CMI_MODEL_CAMF_C) {
+        g_create_err = "cmi_create: CMI_FLAG_RELAX_COND applies to CAMF_C only";
+        return CMI_E_INVALID;
+    }
+    if (model == CMI_MODEL_CAMF_C && !(flags & (CMI_FLAG_SCHED_SERIAL | CMI_FLAG_RELAX_COND))) {
+        g_create_err =
+            "cmi_create: CAMF_C updates the shared condBias vector on every tuple, so no order-exact parallel "
+            "schedule exists; pass CMI_FLAG_SCHED_SERIAL (exact) or CMI_FLAG_RELAX_COND (atomics, not order-exact)";
+        return CMI_E_UNSUPPORTED;
+    }
+    cmi_instance *h = new cmi_instance();
+    h->model = model;
+    h->k = k;
+    h->n_users = n_users;
+    h->n_items = n_items;
+    h->n_conds = n_conds;
+    h->device = device;
+    h->flags = flags;
+    h->f64 = flags & CMI_FLAG_STATE_F64;
+    h->serial = flags & CMI_FLAG_SCHED_SERIAL;
+    h->strict = flags & CMI_FLAG_STRICT;
+    h->relax = flags & CMI_FLAG_RELAX_COND;
+    h->use_graph = !(flags & CMI_FLAG_NO_GRAPH);
+    const char *step = "";
+    hipError_t e = hipSuccess;
+#define TRY(x)                                                                                          \
+    if (e == hipSuccess) {                                                                              \
+        step = #x;                                                                                      \
+        e = (x);                                                                                        \
+    }
+    TRY(hipSetDevice(device));
+    TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    TRY(hipEventCreate(&h->ev0));
+    TRY(hipEventCreate(&h->ev1));
+    for (int w = 0; w < CMI_STATE_COUNT; ++w) {
+        if (!model_has(model, w)) continue;
+        h->state_count[w] = state_elems(h, w);
+        size_t bytes = (size_t)h->state_count[w] * esize(h);
+        if (bytes == 0) continue;
+        TRY(hipMalloc(&h->state[w], bytes));
+        TRY(hipMemsetAsync(h->state[w], 0, bytes, h->stream));
+    }
+    TRY(hipMalloc((void **)&h->d_scratch, 256 * sizeof(double)));
+    TRY(hipMalloc((void **)&h->d_loss, sizeof(double)));
+    TRY(hipMalloc((void **)&h->d_hp, sizeof(HParams)));
+    TRY(hipHostMalloc((void **)&h->h_loss, sizeof(double), hipHostMallocDefault));
+    TRY(hipStreamSynchronize(h->stream));
+#undef TRY
+    if (e != hipSuccess) {
+        g_create_err = std::string("cmi_create: ") + step + " failed: " + hipGetErrorString(e);
+        cmi_destroy(h);
+        return CMI_E_HIP;
+    }
+    *out = h;
+    return CMI_OK;
+}
+
+extern "C" int cmi_set_hparams(cmi_handle h, double regU, double regI, double regB, double regC, double global_mean) {
+    if (!h) return CMI_E_INVALID;
+    h->hp.regU = regU;
+    h->hp.regI = regI;
+    h->hp.regB = regB;
+    h->hp.regC = regC;
+    h->hp.gm = global_mean;
+    return CMI_OK;
+}
+
+// ---- state copy-in / copy-back -------------------------------------------------------------------
+
+static int check_state_args(cmi_instance *h, int which, const void *p, int64_t count, int dtype) {
+    if (which < 0 || which >= CMI_STATE_COUNT || !p || (dtype != CMI_DTYPE_F32 && dtype != CMI_DTYPE_F64))
+        CMI_FAIL(h, CMI_E_INVALID, "state: invalid argument");
+    if (!model_has(h->model, which)) CMI_FAIL(h, CMI_E_INVALID, "state %d does not exist in model %d", which, h->model);
+    if (count != h->state_count[which])
+        CMI_FAIL(h, CMI_E_INVALID, "state %d: count %lld != expected %lld", which, (long long)count,
+                 (long long)h->state_count[which]);
+    return CMI_OK;
+}
+
+extern "C" int cmi_set_state(cmi_handle h, int which, const void *src, int64_t count, int dtype) {
+    if (!h) return CMI_E_INVALID;
+    if (int rc = check_state_args(h, which, src, count, dtype)) return rc;
+    if (count == 0) return CMI_OK;
+    CMI_HIP(h, hipSetDevice(h->device));
+    const bool src_f64 = dtype == CMI_DTYPE_F64;
+    if (src_f64 == h->f64) {
+        CMI_HIP(h, hipMemcpyAsync(h->state[which], src, (size_t)count * esize(h), hipMemcpyHostToDevice, h->stream));
+        CMI_HIP(h, hipStreamSynchronize(h->stream));
+        return CMI_OK;
+    }
+    void *stage = nullptr;
+    const size_t sb = (size_t)count * (src_f64 ? 8 : 4);
+    CMI_HIP(h, hipMalloc(&stage, sb));
+    hipError_t e = hipMemcpyAsync(stage, src, sb, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = launch_convert(stage, src_f64, h->state[which], h->f64, count, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(stage);
+    CMI_HIP(h, e);
+    return CMI_OK;
+}
+
+extern "C" int cmi_get_state(cmi_handle h, int which, void *dst, int64_t count, int dtype) {
+    if (!h) return CMI_E_INVALID;
+    if (int rc = check_state_args(h, which, dst, count, dtype)) return rc;
+    if (count == 0) return CMI_OK;
+    CMI_HIP(h, hipSetDevice(h->device));
+    const bool dst_f64 = dtype == CMI_DTYPE_F64;
+    if (dst_f64 == h->f64) {
+        CMI_HIP(h, hipMemcpyAsync(dst, h->state[which], (size_t)count * esize(h), hipMemcpyDeviceToHost, h->stream));
+        CMI_HIP(h, hipStreamSynchronize(h->stream));
+        return CMI_OK;
+    }
+    void *stage = nullptr;
+    const size_t db = (size_t)count * (dst_f64 ? 8 : 4);
+    CMI_HIP(h, hipMalloc(&stage, db));
+    hipError_t e = launch_convert(h->state[which], h->f64, stage, dst_f64, count, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, stage, db, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(stage);
+    CMI_HIP(h, e);
+    return CMI_OK;
+}
+
+extern "C" int cmi_state_device_ptr(cmi_handle h, int which, void **ptr, int64_t *count, int *dtype) {
+    if (!h || which < 0 || which >= CMI_STATE_COUNT) return CMI_E_INVALID;
+    if (!model_has(h->model, which)) CMI_FAIL(h, CMI_E_INVALID, "state %d does not exist in model %d", which, h->model);
+    if (ptr) *ptr = h->state[which];
+    if (count) *count = h->state_count[which];
+    if (dtype) *dtype = h->f64 ? CMI_DTYPE_F64 : CMI_DTYPE_F32;
+    return CMI_OK;
+}
+
+// ---- ratings + schedule ----------------------------------------------------------------------------
+
+template <typename V>
+static hipError_t upload(void **dst, const std::vector<V> &v, hipStream_t s) {
+    *dst = nullptr;
+    if (v.empty()) return hipSuccess;
+    hipError_t e = hipMalloc(dst, v.size() * sizeof(V));
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice, s);
+}
+
+extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
+                               const double *r, int32_t n_ctx, const int32_t *ctx_ptr, const int32_t *ctx_conds) {
+    if (!h) return CMI_E_INVALID;
+    const bool contextual = h->model != CMI_MODEL_BIASEDMF;
+    if (n < 0 || (n > 0 && (!u || !j || !r))) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: null tuple arrays");
+    if (contextual && (n_ctx < 0 || !ctx_ptr || (n > 0 && !ctx) || (n_ctx > 0 && ctx_ptr[n_ctx] > 0 && !ctx_conds)))
+        CMI_FAIL(h, CMI_E_INVALID, "set_ratings: context table required for model %d", h->model);
+    CMI_HIP(h, hipSetDevice(h->device));
+    CMI_HIP(h, hipStreamSynchronize(h->stream));
+    free_ratings(h);
+
+    // validate ids (the reference would throw ArrayIndexOutOfBounds inside the loop)
+    int dmax = 0;
+    if (contextual) {
+        if (ctx_ptr[0] != 0) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: ctx_ptr[0] != 0");
+        for (int32_t c = 0; c < n_ctx; ++c) {
+            const int32_t len = ctx_ptr[c + 1] - ctx_ptr[c];
+            if (len < 0) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: ctx_ptr not monotone at %d", c);
+            if (len > dmax) dmax = len;
+        }
+        for (int32_t q = 0; q < ctx_ptr[n_ctx]; ++q)
+            if (ctx_conds[q] < 0 || ctx_conds[q] >= h->n_conds)
+                CMI_FAIL(h, CMI_E_INVALID, "set_ratings: condition id %d out of range [0,%d)", ctx_conds[q], h->n_conds);
+    }
+    for (int64_t t = 0; t < n; ++t) {
+        if (u[t] < 0 || u[t] >= h->n_users) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: user id %d out of range at tuple %lld", u[t], (long long)t);
+        if (j[t] < 0 || j[t] >= h->n_items) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: item id %d out of range at tuple %lld", j[t], (long long)t);
+        if (contextual && (ctx[t] < 0 || ctx[t] >= n_ctx)) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: context id %d out of range at tuple %lld", ctx[t], (long long)t);
+    }
+    if (n >= ((int64_t)1 << 31)) CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: more than 2^31-1 tuples per instance");
+
+    h->n = n;
+    h->n_ctx = contextual ? n_ctx : 0;
+    h->dmax = dmax;
+    LaunchCfg cfg{h->model, h->strict, h->relax};
+    h->fast = !h->serial && has_fast_path(h->k, dmax, h->f64, cfg);
+
+    // schedule
+    LevelSchedule sch;
+    if (h->serial) {
+        sch.level_off = {0, n};
+        sch.max_level = n;
+    } else {
+        int order = LEVEL_ORDER_CRS;
+        if (const char *env = getenv("CMI_LEVEL_ORDER")) {
+            if (!strcmp(env, "item")) order = LEVEL_ORDER_ITEM;
+            else if (!strcmp(env, "user")) order = LEVEL_ORDER_USER;
+        }
+        if (!build_level_schedule(n, u, j, h->n_users, h->n_items, order, sch))
+            CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: schedule construction failed");
+    }
+    h->level_off = sch.level_off;
+    h->max_level = sch.max_level;
+    const int64_t n_levels = (int64_t)h->level_off.size() - 1;
+    h->slot_off.assign((size_t)n_levels + 1, 0);
+    for (int64_t l = 0; l < n_levels; ++l) {
+        const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
+        const int blocks = h->serial ? 0 : (h->fast ? level_blocks_f32_fast(h->k, cnt) : level_blocks_generic(cnt));
+        h->slot_off[(size_t)l + 1] = h->slot_off[(size_t)l] + blocks;
+    }
+    h->n_slots = h->slot_off[(size_t)n_levels];
+
+    // tuple stream in schedule order, conditions pre-expanded to [n x dmax] (-1 padded) so the kernels
+    // need no ctx -> condition-list indirection
+    std::vector<int32_t> su((size_t)n), sj((size_t)n), sconds((size_t)n * (size_t)dmax);
+    std::vector<float> sr32;
+    std::vector<double> sr64;
+    if (h->f64) sr64.resize((size_t)n);
+    else sr32.resize((size_t)n);
+    for (int64_t s = 0; s < n; ++s) {
+        const int64_t t = h->serial ? s : sch.perm[(size_t)s];
+        su[(size_t)s] = u[t];
+        sj[(size_t)s] = j[t];
+        if (h->f64) sr64[(size_t)s] = r[t];
+        else sr32[(size_t)s] = (float)r[t];
+        if (dmax > 0) {
+            int32_t *row = &sconds[(size_t)s * (size_t)dmax];
+            const int32_t b = ctx_ptr[ctx[t]], e = ctx_ptr[ctx[t] + 1];
+            int d = 0;
+            for (int32_t q = b; q < e; ++q) row[d++] = ctx_conds[q];
+            for (; d < dmax; ++d) row[d] = -1;
+        }
+    }
+    hipError_t e = upload((void **)&h->d_su, su, h->stream);
+    if (e == hipSuccess) e = upload((void **)&h->d_sj, sj, h->stream);
+    if (e == hipSuccess) e = upload((void **)&h->d_sconds, sconds, h->stream);
+    if (e == hipSuccess) e = h->f64 ? upload(&h->d_sr, sr64, h->stream) : upload(&h->d_sr, sr32, h->stream);
+    if (e == hipSuccess && contextual) {
+        std::vector<int32_t> cp(ctx_ptr, ctx_ptr + n_ctx + 1), cc(ctx_conds, ctx_conds + ctx_ptr[n_ctx]);
+        h->ctx_nnz = (int64_t)cc.size();
+        e = upload((void **)&h->d_ctx_ptr, cp, h->stream);
+        if (e == hipSuccess) e = upload((void **)&h->d_ctx_conds, cc, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // cp/cc are locals
+    }
+    if (e == hipSuccess && h->n_slots > 0) e = hipMalloc((void **)&h->d_loss_part, (size_t)h->n_slots * sizeof(double));
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        free_ratings(h);
+        CMI_FAIL(h, CMI_E_HIP, "set_ratings: upload failed: %s", hipGetErrorString(e));
+    }
+    h->tuple_bytes = n * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax);
+    h->have_ratings = true;
+    return CMI_OK;
+}
+
+extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[6]) {
+    if (!h || !info) return CMI_E_INVALID;
+    if (!h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "schedule_info: call cmi_set_ratings first");
+    info[0] = (int64_t)h->level_off.size() - 1;
+    info[1] = h->max_level;
+    info[2] = h->n;
+    info[3] = h->dmax;
+    int64_t sb = 0;
+    for (int w = 0; w < CMI_STATE_COUNT; ++w) sb += h->state_count[w] * (int64_t)esize(h);
+    info[4] = sb;
+    info[5] = h->tuple_bytes;
+    return CMI_OK;
+}
+
+// ---- training -------------------------------------------------------------------------------------
+
+template <typename T>
+static SgdArgs<T> make_args(cmi_instance *h) {
+    SgdArgs<T> a;
+    a.P = (T *)h->state[CMI_STATE_P];
+    a.Q = (T *)h->state[CMI_STATE_Q];
+    a.userBias = (T *)h->state[CMI_STATE_USER_BIAS];
+    a.itemBias = (T *)h->state[CMI_STATE_ITEM_BIAS];
+    a.condBias = (T *)h->state[CMI_STATE_COND_BIAS];
+    a.ucBias = (T *)h->state[CMI_STATE_UC_BIAS];
+    a.icBias = (T *)h->state[CMI_STATE_IC_BIAS];
+    a.su = h->d_su;
+    a.sj = h->d_sj;
+    a.sr = (const T *)h->d_sr;
+    a.sconds = h->d_sconds;
+    a.hp = h->d_hp;
+    a.loss_part = h->d_loss_part;
+    a.k = h->k;
+    a.n_conds = h->n_conds;
+    a.dmax = h->dmax;
+    return a;
+}
+
+// enqueue every level of one epoch + the loss reduction on h->stream
+static hipError_t enqueue_levels(cmi_instance *h) {
+    LaunchCfg cfg{h->model, h->strict, h->relax};
+    hipError_t e = hipSuccess;
+    const int64_t n_levels = (int64_t)h->level_off.size() - 1;
+    if (h->serial) {
+        if (h->f64) return launch_serial<double>(make_args<double>(h), cfg, h->n, h->d_loss, h->stream);
+        return launch_serial<float>(make_args<float>(h), cfg, h->n, h->d_loss, h->stream);
+    }
+    if (h->f64) {
+        const SgdArgs<double> a = make_args<double>(h);
+        for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l)
+            e = launch_level_generic<double>(a, cfg, h->level_off[(size_t)l],
+                                             (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]),
+                                             h->slot_off[(size_t)l], h->stream);
+    } else {
+        const SgdArgs<float> a = make_args<float>(h);
+        for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l) {
+            const int64_t b = h->level_off[(size_t)l];
+            const int cnt = (int)(h->level_off[(size_t)l + 1] - b);
+            e = h->fast ? launch_level_fast_f32(a, cfg, b, cnt, h->slot_off[(size_t)l], h->stream)
+                        : launch_level_generic<float>(a, cfg, b, cnt, h->slot_off[(size_t)l], h->stream);
+        }
+    }
+    if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);
+    return e;
+}
+
+static int enqueue_epoch(cmi_instance *h, double lrate) {
+    if (!h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "train: call cmi_set_ratings first");
+    CMI_HIP(h, hipSetDevice(h->device));
+    h->hp.lr = lrate;
+    CMI_HIP(h, launch_set_hparams(h->d_hp, h->hp, h->stream));
+    if (h->n == 0) {
+        CMI_HIP(h, hipMemsetAsync(h->d_loss, 0, sizeof(double), h->stream));
+        h->epoch_timed = false;
+        return CMI_OK;
+    }
+    const bool graph = h->use_graph && !h->serial;
+    if (graph && !h->graph_exec) {
+        hipGraph_t g = nullptr;
+        CMI_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = enqueue_levels(h);
+        hipError_t e2 = hipStreamEndCapture(h->stream, &g);
+        if (e != hipSuccess || e2 != hipSuccess) {
+            if (g) hipGraphDestroy(g);
+            CMI_FAIL(h, CMI_E_HIP, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        }
+        e = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) {
+            h->graph_exec = nullptr;
+            CMI_FAIL(h, CMI_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        }
+    }
+    CMI_HIP(h, hipEventRecord(h->ev0, h->stream));
+    if (graph) CMI_HIP(h, hipGraphLaunch(h->graph_exec, h->stream));
+    else CMI_HIP(h, enqueue_levels(h));
+    CMI_HIP(h, hipEventRecord(h->ev1, h->stream));
+    h->epoch_timed = true;
+    return CMI_OK;
+}
+
+extern "C" int cmi_train_epoch_async(cmi_handle h, double lrate) {
+    if (!h) return CMI_E_INVALID;
+    return enqueue_epoch(h, lrate);
+}
+
+extern "C" int cmi_last_loss(cmi_handle h, double *loss_out) {
+    if (!h || !loss_out) return CMI_E_INVALID;
+    CMI_HIP(h, hipSetDevice(h->device));
+    CMI_HIP(h, hipMemcpyAsync(h->h_loss, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CMI_HIP(h, hipStreamSynchronize(h->stream));
+    h->last_loss = *h->h_loss;
+    *loss_out = h->last_loss;
+    return CMI_OK;
+}
+
+extern "C" int cmi_train_epoch(cmi_handle h, double lrate, double *loss_out) {
+    if (!h) return CMI_E_INVALID;
+    if (int rc = enqueue_epoch(h, lrate)) return rc;
+    double loss = 0.0;
+    if (int rc = cmi_last_loss(h, &loss)) return rc;
+    if (loss_out) *loss_out = loss;
+    return CMI_OK;
+}
+
+// IterativeRecommender.isConverged + updateLRate (IterativeRecommender.java:145-229), host side.
+extern "C" int cmi_train(cmi_handle h, int num_iters, double init_lrate, double max_lrate, int bold_driver,
+                         double decay, int early_stop, double *losses, double *lrates, int *iters_run,
+                         double *final_lrate) {
+    if (!h) return CMI_E_INVALID;
+    if (early_stop != 0 && early_stop != 1) CMI_FAIL(h, CMI_E_UNSUPPORTED, "train: early_stop must be 0 (none) or 1 (loss)");
+    double lr = init_lrate, last_loss = 0.0, measure = 0.0, last_measure = 0.0;
+    int it = 0;
+    if (iters_run) *iters_run = 0;
+    for (it = 1; it <= num_iters; ++it) {
+        double loss = 0.0;
+        if (lrates) lrates[it - 1] = lr;
+        if (int rc = cmi_train_epoch(h, lr, &loss)) return rc;
+        if (losses) losses[it - 1] = loss;
+        if (iters_run) *iters_run = it;
+        if (early_stop == 1) {
+            measure = loss;
+            last_measure = last_loss;
+        }
+        const float delta_measure = (float)(last_measure - measure);
+        if (std::isnan(loss) || std::isinf(loss)) {
+            if (final_lrate) *final_lrate = lr;
+            CMI_FAIL(h, CMI_E_NUMERIC, "Loss = NaN or Infinity at iteration %d: current settings do not fit the recommender", it);
+        }
+        const bool converged = std::fabs(loss) < 1e-5 || (delta_measure > 0 && delta_measure < 1e-5);
+        if (!converged && lr > 0) {
+            if (bold_driver && it > 1) lr = std::fabs(last_loss) > std::fabs(loss) ? lr * 1.05 : lr * 0.5;
+            else if (decay > 0 && decay < 1) lr *= decay;
+            if (max_lrate > 0 && lr > max_lrate) lr = max_lrate;
+        }
+        last_loss = loss;
+        last_measure = measure;
+        if (converged) break;
+    }
+    if (final_lrate) *final_lrate = lr;
+    return CMI_OK;
+}
+
+extern "C" int cmi_stream(cmi_handle h, void **stream) {
+    if (!h || !stream) return CMI_E_INVALID;
+    *stream = (void *)h->stream;
+    return CMI_OK;
+}
+
+extern "C" int cmi_synchronize(cmi_handle h) {
+    if (!h) return CMI_E_INVALID;
+    CMI_HIP(h, hipSetDevice(h->device));
+    CMI_HIP(h, hipStreamSynchronize(h->stream));
+    return CMI_OK;
+}
+
+extern "C" int cmi_last_epoch_ms(cmi_handle h, float *ms) {
+    if (!h || !ms) return CMI_E_INVALID;
+    if (!h->epoch_timed) CMI_FAIL(h, CMI_E_INVALID, "last_epoch_ms: no epoch has run");
+    CMI_HIP(h, hipSetDevice(h->device));
+    CMI_HIP(h, hipEventSynchronize(h->ev1));
+    CMI_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return CMI_OK;
+}
+
+// ---- predict / evalRatings -------------------------------------------------------------------------
+
+template <typename T>
+static hipError_t run_eval(cmi_instance *h, int64_t n, const int32_t *du, const int32_t *dj, const int32_t *dctx,
+                           const double *dr, double *dpreds, double *dpart, int bound, double lo, double hi,
+                           double min_rate) {
+    EvalArgs<T> a;
+    a.P = (const T *)h->state[CMI_STATE_P];
+    a.Q = (const T *)h->state[CMI_STATE_Q];
+    a.userBias = (const T *)h->state[CMI_STATE_USER_BIAS];
+    a.itemBias = (const T *)h->state[CMI_STATE_ITEM_BIAS];
+    a.condBias = (const T *)h->state[CMI_STATE_COND_BIAS];
+    a.ucBias = (const T *)h->state[CMI_STATE_UC_BIAS];
+    a.icBias = (const T *)h->state[CMI_STATE_IC_BIAS];
+    a.u = du;
+    a.j = dj;
+    a.ctx = dctx;
+    a.r = dr;
+    a.ctx_ptr = h->d_ctx_ptr;
+    a.ctx_conds = h->d_ctx_conds;
+    a.preds = dpreds;
+    a.part = dpart;
+    a.gm = h->hp.gm;
+    a.lo = lo;
+    a.hi = hi;
+    a.min_rate = min_rate;
+    a.k = h->k;
+    a.n_conds = h->n_conds;
+    a.bound = bound;
+    a.model = h->model;
+    return launch_eval<T>(a, n, h->stream);
+}
+
+static int eval_common(cmi_instance *h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
+                       const double *r, int bound, double lo, double hi, double min_rate, double *preds_out,
+                       double sums[5]) {
+    const bool contextual = h->model != CMI_MODEL_BIASEDMF;
+    if (n < 0 || (n > 0 && (!u || !j))) CMI_FAIL(h, CMI_E_INVALID, "eval: null tuple arrays");
+    if (contextual && n > 0 && !ctx) CMI_FAIL(h, CMI_E_INVALID, "eval: ctx required for model %d", h->model);
+    if (contextual && !h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "eval: the context table comes from cmi_set_ratings; call it first");
+    for (int64_t t = 0; t < n; ++t) {
+        if (u[t] < 0 || u[t] >= h->n_users || j[t] < 0 || j[t] >= h->n_items)
+            CMI_FAIL(h, CMI_E_INVALID, "eval: user/item id out of range at tuple %lld", (long long)t);
+        if (contextual && (ctx[t] < 0 || ctx[t] >= h->n_ctx))
+            CMI_FAIL(h, CMI_E_INVALID, "eval: context id %d out of range at tuple %lld", ctx[t], (long long)t);
+    }
+    for (int c = 0; c < 5; ++c) sums[c] = 0.0;
+    if (n == 0) return CMI_OK;
+    CMI_HIP(h, hipSetDevice(h->device));
+    int32_t *du = nullptr, *dj = nullptr, *dctx = nullptr;
+    double *dr = nullptr, *dpreds = nullptr, *dpart = nullptr;
+    const int blocks = eval_blocks(n);
+    std::vector<double> part((size_t)blocks * 5);
+    hipError_t e = hipMalloc((void **)&du, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&dj, (size_t)n * 4);
+    if (e == hipSuccess && contextual) e = hipMalloc((void **)&dctx, (size_t)n * 4);
+    if (e == hipSuccess && r) e = hipMalloc((void **)&dr, (size_t)n * 8);
+    if (e == hipSuccess && preds_out) e = hipMalloc((void **)&dpreds, (size_t)n * 8);
+    if (e == hipSuccess && r) e = hipMalloc((void **)&dpart, part.size() * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(du, u, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dj, j, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && contextual) e = hipMemcpyAsync(dctx, ctx, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && r) e = hipMemcpyAsync(dr, r, (size_t)n * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess)
+        e = h->f64 ? run_eval<double>(h, n, du, dj, dctx, dr, dpreds, dpart, bound, lo, hi, min_rate)
+                   : run_eval<float>(h, n, du, dj, dctx, dr, dpreds, dpart, bound, lo, hi, min_rate);
+    if (e == hipSuccess && preds_out) e = hipMemcpyAsync(preds_out, dpreds, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && r) e = hipMemcpyAsync(part.data(), dpart, part.size() * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    void *ptrs[] = {du, dj, dctx, dr, dpreds, dpart};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    CMI_HIP(h, e);
+    if (r)
+        for (int b = 0; b < blocks; ++b)
+            for (int c = 0; c < 5; ++c) sums[c] += part[(size_t)b * 5 + c];
+    return CMI_OK;
+}
+
+extern "C" int cmi_predict_batch(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
+                                 int bound, double lo, double hi, double *out) {
+    if (!h) return CMI_E_INVALID;
+    if (n > 0 && !out) CMI_FAIL(h, CMI_E_INVALID, "predict_batch: null output");
+    double sums[5];
+    return eval_common(h, n, u, j, ctx, nullptr, bound, lo, hi, 1.0, out, sums);
+}
+
+extern "C" int cmi_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
+                                const double *r, double min_rate, double max_rate, double *out, int64_t *count) {
+    if (!h) return CMI_E_INVALID;
+    if (!out || (n > 0 && !r)) CMI_FAIL(h, CMI_E_INVALID, "eval_ratings: null argument");
+    double sums[5];
+    if (int rc = eval_common(h, n, u, j, ctx, r, 1, min_rate, max_rate, min_rate, nullptr, sums)) return rc;
+    const double cnt = sums[4];
+    const double mae = sums[0] / cnt;
+    out[0] = mae;
+    out[1] = std::sqrt(sums[1] / cnt);
+    out[2] = mae / (max_rate - min_rate);
+    out[3] = sums[2] / cnt;
+    out[4] = std::sqrt(sums[3] / cnt);
+    if (count) *count = (int64_t)cnt;
+    return CMI_OK;
+}
+
+// ---- host-only schedule export ------------------------------------------------------------------------
+
+extern "C" int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
+                                  int order, int32_t *perm, int64_t *level_off, int64_t level_cap,
+                                  int64_t *n_levels) {
+    if (n < 0 || (n > 0 && (!u || !j)) || n_users <= 0 || n_items <= 0 || !n_levels || order < 0 || order > 2)
+        return CMI_E_INVALID;
+    for (int64_t t = 0; t < n; ++t)
+        if (u[t] < 0 || u[t] >= n_users || j[t] < 0 || j[t] >= n_items) return CMI_E_INVALID;
+    LevelSchedule sch;
+    if (!build_level_schedule(n, u, j, n_users, n_items, order, sch)) return CMI_E_UNSUPPORTED;
+    *n_levels = sch.n_levels();
+    if (level_off) {
+        if (level_cap < sch.n_levels() + 1) return CMI_E_INVALID;
+        for (size_t i = 0; i < sch.level_off.size(); ++i) level_off[i] = sch.level_off[i];
+    }
+    if (perm)
+        for (int64_t s = 0; s < n; ++s) perm[s] = sch.perm[(size_t)s];
+    return CMI_OK;
+}

@@ -1,0 +1,68 @@
+// level_schedule.cpp -- host-side integer preprocessing that turns the reference's sequential
+// visiting order into a parallel schedule WITHOUT changing the result.
+//
+// The reference walks the training tuples one by one in CRS order (librec MatrixIterator; e.g.
+// CAMF_CI.java:80 `for (MatrixEntry me : trainMatrix)`).  Update t reads and writes only state keyed
+// by its user u_t (P[u], userBias[u], ucBias[u,*]) and by its item j_t (Q[j], itemBias[j],
+// icBias[j,*]).  Two tuples with different users AND different items touch disjoint state, so they
+// commute exactly.  Hence the only ordering that matters is, per user and per item, the CRS order
+// of the tuples containing it.  Define
+//     level(t) = 1 + max(level(previous tuple with the same user), level(previous tuple with the
+//                same item)),   0 predecessors -> level 1.
+// Tuples of one level are pairwise independent; running levels 1,2,3,... in sequence with all
+// tuples of a level in parallel yields, for every state element, the same sequence of updates
+// with the same operands as the sequential walk -- bit-identical at equal precision.
+// (CAMF_C's condBias is shared by every tuple, so for CAMF_C no such schedule exists; see
+// CMI_FLAG_SCHED_SERIAL / CMI_FLAG_RELAX_COND.)
+#include "level_schedule.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+namespace cmi {
+
+bool build_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
+                          int within_level_order, LevelSchedule &out) {
+    out.perm.clear();
+    out.level_off.clear();
+    out.max_level = 0;
+    if (n <= 0) {
+        out.level_off.push_back(0);
+        return true;
+    }
+    if (n >= (int64_t)1 << 31) return false;
+    std::vector<int32_t> last_u((size_t)n_users, 0), last_j((size_t)n_items, 0), level((size_t)n);
+    int32_t n_levels = 0;
+    for (int64_t t = 0; t < n; ++t) {
+        const int32_t a = last_u[(size_t)u[t]], b = last_j[(size_t)j[t]];
+        const int32_t l = (a > b ? a : b) + 1;
+        last_u[(size_t)u[t]] = l;
+        last_j[(size_t)j[t]] = l;
+        level[(size_t)t] = l;
+        if (l > n_levels) n_levels = l;
+    }
+    // stable counting sort by level: inside a level the CRS order is kept
+    out.level_off.assign((size_t)n_levels + 1, 0);
+    for (int64_t t = 0; t < n; ++t) out.level_off[(size_t)level[(size_t)t]]++;
+    for (int32_t l = 1; l <= n_levels; ++l) {
+        out.max_level = std::max(out.max_level, out.level_off[(size_t)l]);
+        out.level_off[(size_t)l] += out.level_off[(size_t)l - 1];
+    }
+    out.perm.resize((size_t)n);
+    {
+        std::vector<int64_t> cur(out.level_off.begin(), out.level_off.end() - 1);
+        for (int64_t t = 0; t < n; ++t) out.perm[(size_t)cur[(size_t)level[(size_t)t] - 1]++] = (int32_t)t;
+    }
+    // Tuples of a level are independent, so their order inside the level is free: sorting by item
+    // (or user) id only changes which rows neighbouring lanes touch (memory locality), not the result.
+    if (within_level_order != LEVEL_ORDER_CRS) {
+        const int32_t *key = within_level_order == LEVEL_ORDER_ITEM ? j : u;
+        for (int32_t l = 0; l < n_levels; ++l) {
+            auto b = out.perm.begin() + out.level_off[(size_t)l], e = out.perm.begin() + out.level_off[(size_t)l + 1];
+            std::sort(b, e, [key](int32_t x, int32_t y) { return key[x] != key[y] ? key[x] < key[y] : x < y; });
+        }
+    }
+    return true;
+}
+
+} // namespace cmi

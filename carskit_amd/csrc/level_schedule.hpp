@@ -1,0 +1,21 @@
+// level_schedule.hpp -- see level_schedule.cpp
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+namespace cmi {
+
+enum { LEVEL_ORDER_CRS = 0, LEVEL_ORDER_ITEM = 1, LEVEL_ORDER_USER = 2 };
+
+struct LevelSchedule {
+    std::vector<int32_t> perm;       // schedule position -> CRS tuple index
+    std::vector<int64_t> level_off;  // n_levels+1 offsets into perm
+    int64_t max_level = 0;           // largest level size
+    int64_t n_levels() const { return (int64_t)level_off.size() - 1; }
+};
+
+// false if n does not fit the int32 permutation
+bool build_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
+                          int within_level_order, LevelSchedule &out);
+
+} // namespace cmi

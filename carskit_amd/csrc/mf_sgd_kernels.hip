@@ -1,0 +1,612 @@
+// mf_sgd_kernels.hip -- hand-written gfx950 (MI355X, CDNA4) kernels for the CARSKit SGD inner loop.
+//
+// What one update is (reference: src/carskit/alg/cars/adaptation/dependent/dev/CAMF_CI.java:79-123
+// and its siblings CAMF_C/CAMF_CU/CAMF_CUCI, src/carskit/alg/baseline/cf/BiasedMF.java:62-98):
+//     pred = gm [+ bu] [+ bj] + <P[u],Q[j]> + sum_c contextBias(c)      e = r - pred
+//     bias  += lr * (e - reg * bias)            for every bias entry the model touches
+//     P[u]  += lr * (e * Q[j] - regU * P[u])    Q[j] += lr * (e * P[u] - regI * Q[j])   (old values)
+// i.e. a gather of two k-vectors and a handful of scalars, a dot product, and an AXPY scatter:
+// ~10k flop against ~16k bytes.  HBM-bound, no dense contraction -> no MFMA; the work is coalesced
+// 16-byte-per-lane row traffic, DPP row reductions for the dot, and keeping enough tuples in flight.
+//
+// Three kernel families:
+//   sgd_level_fast_f32  fp32 state, k in {64,128,256}: 16 lanes per tuple (4 tuples per wave64), each lane
+//                       owns k/16 factors as float4s -> every row load/store instruction moves whole 256-B
+//                       segments; the dot is reduced inside a DPP row (row_ror 8/4/2/1, pure VALU).
+//   sgd_level_generic   any k / fp64 state / strict order: one wave64 per tuple, lane-strided factors.
+//   sgd_serial          one wave64 walks every tuple in the reference's order (exact for all models).
+// A "level" is a set of tuples that share no user and no item; their updates commute exactly, so
+// running levels back-to-back reproduces the reference's sequential result (see level_schedule.cpp).
+//
+// Built with -ffp-contract=off: the JVM never fuses a*b+c, and the strict fp64 path is bit-compared
+// with the CPU oracle.
+#include "mf_sgd_kernels.hpp"
+
+namespace cmi {
+
+// ---------------------------------------------------------------------------------------------
+// cross-lane helpers
+// ---------------------------------------------------------------------------------------------
+
+// DPP row_ror:n -- lane l of each 16-lane row reads lane (l - n) mod 16 of the same row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+
+// Sum over the 16 lanes of a DPP row; every lane ends with the bit-identical total (the rotation
+// tree pairs the same operands in every lane, and fp add is commutative).
+__device__ __forceinline__ float row_sum16(float x) {
+    x += dpp_f32<0x128>(x); // row_ror:8
+    x += dpp_f32<0x124>(x); // row_ror:4
+    x += dpp_f32<0x122>(x); // row_ror:2
+    x += dpp_f32<0x121>(x); // row_ror:1
+    return x;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum64(T x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+
+template <int MODEL>
+struct Traits {
+    static constexpr bool has_bu = MODEL == BIASEDMF || MODEL == CAMF_C || MODEL == CAMF_CI;
+    static constexpr bool has_bj = MODEL == BIASEDMF || MODEL == CAMF_C || MODEL == CAMF_CU;
+    static constexpr bool has_bc = MODEL == CAMF_C;
+    static constexpr bool has_ic = MODEL == CAMF_CI || MODEL == CAMF_CUCI;
+    static constexpr bool has_uc = MODEL == CAMF_CU || MODEL == CAMF_CUCI;
+};
+
+// ---------------------------------------------------------------------------------------------
+// fast path: fp32 state, K = 64*VPL, 16 lanes per tuple
+// ---------------------------------------------------------------------------------------------
+
+template <int MODEL, int VPL>
+__global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int64_t begin, int count,
+                                                          int64_t slot0, int relax_cond) {
+    using M = Traits<MODEL>;
+    constexpr int K = 64 * VPL;
+    __shared__ double s_loss[16];
+    const int tid = threadIdx.x;
+    const int l16 = tid & 15;
+    const int gib = tid >> 4;
+    const int g = blockIdx.x * 16 + gib;
+    double gloss = 0.0;
+
+    if (g < count) {
+        const int64_t t = begin + g;
+        const int uu = a.su[t];
+        const int jj = a.sj[t];
+        const float rr = a.sr[t];
+        int cond = -1;
+        if (MODEL != BIASEDMF && l16 < a.dmax) cond = a.sconds[t * a.dmax + l16];
+
+        float4 *prow = reinterpret_cast<float4 *>(a.P + (size_t)uu * K) + l16;
+        float4 *qrow = reinterpret_cast<float4 *>(a.Q + (size_t)jj * K) + l16;
+        float4 p[VPL], q[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) p[v] = prow[v * 16];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) q[v] = qrow[v * 16];
+
+        float bu = 0.f, bj = 0.f, bc = 0.f, bic = 0.f, buc = 0.f;
+        if (M::has_bu) bu = a.userBias[uu];
+        if (M::has_bj) bj = a.itemBias[jj];
+        float *pic = nullptr, *puc = nullptr;
+        if (cond >= 0) {
+            if (M::has_bc) bc = a.condBias[cond];
+            if (M::has_ic) {
+                pic = a.icBias + (size_t)jj * a.n_conds + cond;
+                bic = *pic;
+            }
+            if (M::has_uc) {
+                puc = a.ucBias + (size_t)uu * a.n_conds + cond;
+                buc = *puc;
+            }
+        }
+
+        const HParams hp = *a.hp;
+        const float lr = (float)hp.lr, regU = (float)hp.regU, regI = (float)hp.regI, regB = (float)hp.regB,
+                    regC = (float)hp.regC, gm = (float)hp.gm;
+
+        float part = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            part += p[v].x * q[v].x;
+            part += p[v].y * q[v].y;
+            part += p[v].z * q[v].z;
+            part += p[v].w * q[v].w;
+        }
+        const float dot = row_sum16(part);
+
+        float pred = gm;
+        if (M::has_bu) pred += bu;
+        if (M::has_bj) pred += bj;
+        pred += dot;
+        if (MODEL != BIASEDMF) {
+            float term = 0.f; // lane d carries the deviation of the tuple's d-th condition
+            if (M::has_bc) term = bc;
+            if (M::has_ic && M::has_uc) term = bic + buc;
+            else if (M::has_ic) term = bic;
+            else if (M::has_uc) term = buc;
+            pred += row_sum16(term);
+        }
+        const float e = rr - pred;
+
+        // scalar biases: lane 0 of the group owns the store
+        if (l16 == 0) {
+            if (M::has_bu) a.userBias[uu] = bu + lr * (e - regB * bu);
+            if (M::has_bj) a.itemBias[jj] = bj + lr * (e - regB * bj);
+        }
+        float ctx_loss = 0.f;
+        if (cond >= 0) {
+            if (M::has_bc) {
+                // condBias is shared by (nearly) every tuple: only reachable with CMI_FLAG_RELAX_COND
+                if (relax_cond) atomicAdd(a.condBias + cond, lr * (e - regC * bc));
+                ctx_loss = bc; // reference quirk: plain sum, weighted by regB below (CAMF_C.java:110,115)
+            }
+            if (M::has_ic) {
+                *pic = bic + lr * (e - regC * bic);
+                ctx_loss += bic * bic;
+            }
+            if (M::has_uc) {
+                *puc = buc + lr * (e - regC * buc);
+                ctx_loss += buc * buc;
+            }
+        }
+
+        float lsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            float4 pn, qn;
+#define CMI_UPD(c)                                                                                       \
+    pn.c = p[v].c + lr * (e * q[v].c - regU * p[v].c);                                                   \
+    qn.c = q[v].c + lr * (e * p[v].c - regI * q[v].c);                                                   \
+    lsum += (regU * p[v].c) * p[v].c + (regI * q[v].c) * q[v].c;
+            CMI_UPD(x) CMI_UPD(y) CMI_UPD(z) CMI_UPD(w)
+#undef CMI_UPD
+            prow[v * 16] = pn;
+            qrow[v * 16] = qn;
+        }
+
+        const float reg_loss = row_sum16(lsum);
+        const float ctx_sum = (MODEL != BIASEDMF) ? row_sum16(ctx_loss) : 0.f;
+        if (l16 == 0) {
+            double l = (double)e * (double)e;
+            if (M::has_bu) l += (double)regB * bu * bu;
+            if (M::has_bj) l += (double)regB * bj * bj;
+            if (M::has_bc) l += (double)regB * ctx_sum;
+            else if (MODEL != BIASEDMF) l += (double)regC * ctx_sum;
+            gloss = l + (double)reg_loss;
+        }
+    }
+
+    if (l16 == 0) s_loss[gib] = gloss;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += s_loss[i];
+        a.loss_part[slot0 + blockIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic path: one wave64 per tuple, any k, T in {float,double}, optional strict order
+// ---------------------------------------------------------------------------------------------
+
+// Applies one update.  `loss` is the running sum the contributions are added to, in the
+// reference's order when STRICT (loss += e*e; bias terms in source order; then one add per factor).
+template <typename T, int MODEL, bool STRICT>
+__device__ __forceinline__ double sgd_one(const SgdArgs<T> &a, const HParams &hp, int uu, int jj, T rr,
+                                          const int32_t *conds, int lane, double loss, bool relax_cond) {
+    using M = Traits<MODEL>;
+    const int k = a.k;
+    T *pu = a.P + (size_t)uu * k;
+    T *qj = a.Q + (size_t)jj * k;
+    const T lr = (T)hp.lr, regU = (T)hp.regU, regI = (T)hp.regI, regB = (T)hp.regB, regC = (T)hp.regC,
+            gm = (T)hp.gm;
+
+    // DenseMatrix.rowMult: s = 0; s += m[f]*n[f], f ascending (librec jar)
+    T dot = 0;
+    if (STRICT) {
+        for (int c0 = 0; c0 < k; c0 += 64) {
+            const int f = c0 + lane;
+            const T prod = f < k ? pu[f] * qj[f] : (T)0;
+            const int m = (k - c0) < 64 ? (k - c0) : 64;
+            for (int l = 0; l < m; ++l) dot += __shfl(prod, l, 64);
+        }
+    } else {
+        T part = 0;
+        for (int f = lane; f < k; f += 64) part += pu[f] * qj[f];
+        dot = wave_sum64(part);
+    }
+
+    // predict(): every lane evaluates the same scalar expression in the reference's add order
+    T bu = 0, bj = 0;
+    if (M::has_bu) bu = a.userBias[uu];
+    if (M::has_bj) bj = a.itemBias[jj];
+    T pred = gm;
+    if (M::has_bu) pred += bu;
+    if (M::has_bj) pred += bj;
+    pred += dot;
+    if (MODEL != BIASEDMF) {
+        for (int d = 0; d < a.dmax; ++d) {
+            const int cond = conds[d];
+            if (cond < 0) break;
+            if (M::has_bc) pred += a.condBias[cond];
+            if (M::has_ic && M::has_uc)
+                pred += a.icBias[(size_t)jj * a.n_conds + cond] + a.ucBias[(size_t)uu * a.n_conds + cond];
+            else if (M::has_ic)
+                pred += a.icBias[(size_t)jj * a.n_conds + cond];
+            else if (M::has_uc)
+                pred += a.ucBias[(size_t)uu * a.n_conds + cond];
+        }
+    }
+    const T e = rr - pred;
+    loss += (double)(e * e);
+
+    if (M::has_bu) {
+        if (lane == 0) a.userBias[uu] = bu + lr * (e - regB * bu);
+        loss += (double)((regB * bu) * bu);
+    }
+    if (M::has_bj) {
+        if (lane == 0) a.itemBias[jj] = bj + lr * (e - regB * bj);
+        loss += (double)((regB * bj) * bj);
+    }
+    if (MODEL != BIASEDMF) {
+        T s_ic = 0, s_uc = 0, s_bc = 0;
+        for (int d = 0; d < a.dmax; ++d) {
+            const int cond = conds[d];
+            if (cond < 0) break;
+            if (M::has_bc) {
+                T *cell = a.condBias + cond;
+                const T bc = *cell;
+                s_bc += bc;
+                if (lane == 0) {
+                    if (relax_cond) atomicAdd(cell, lr * (e - regC * bc));
+                    else *cell = bc + lr * (e - regC * bc);
+                }
+            }
+            if (M::has_uc) {
+                T *cell = a.ucBias + (size_t)uu * a.n_conds + cond;
+                const T b = *cell;
+                s_uc += b * b;
+                if (lane == 0) *cell = b + lr * (e - regC * b);
+            }
+            if (M::has_ic) {
+                T *cell = a.icBias + (size_t)jj * a.n_conds + cond;
+                const T b = *cell;
+                s_ic += b * b;
+                if (lane == 0) *cell = b + lr * (e - regC * b);
+            }
+        }
+        if (M::has_bc) loss += (double)(regB * s_bc);                   // CAMF_C.java:115
+        else if (M::has_ic && M::has_uc) loss += (double)(regC * s_ic + regC * s_uc); // CAMF_CUCI.java:111
+        else if (M::has_ic) loss += (double)(regC * s_ic);
+        else loss += (double)(regC * s_uc);
+    }
+
+    // factor loop: puf, qjf both read before either is written
+    if (STRICT) {
+        for (int c0 = 0; c0 < k; c0 += 64) {
+            const int f = c0 + lane;
+            T term = 0;
+            if (f < k) {
+                const T p = pu[f], q = qj[f];
+                pu[f] = p + lr * (e * q - regU * p);
+                qj[f] = q + lr * (e * p - regI * q);
+                term = (regU * p) * p + (regI * q) * q;
+            }
+            const int m = (k - c0) < 64 ? (k - c0) : 64;
+            for (int l = 0; l < m; ++l) loss += (double)__shfl(term, l, 64);
+        }
+    } else {
+        T part = 0;
+        for (int f = lane; f < k; f += 64) {
+            const T p = pu[f], q = qj[f];
+            pu[f] = p + lr * (e * q - regU * p);
+            qj[f] = q + lr * (e * p - regI * q);
+            part += (regU * p) * p + (regI * q) * q;
+        }
+        loss += wave_sum64((double)part);
+    }
+    return loss;
+}
+
+template <typename T, int MODEL, bool STRICT>
+__global__ __launch_bounds__(256) void sgd_level_generic(SgdArgs<T> a, int64_t begin, int count, int64_t slot0,
+                                                         int relax_cond) {
+    __shared__ double s_loss[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + wave;
+    double gl = 0.0;
+    if (g < count) {
+        const int64_t t = begin + g;
+        const HParams hp = *a.hp;
+        gl = sgd_one<T, MODEL, STRICT>(a, hp, a.su[t], a.sj[t], a.sr[t], a.sconds + t * a.dmax, lane, 0.0,
+                                       relax_cond != 0);
+    }
+    if (lane == 0) s_loss[wave] = gl;
+    __syncthreads();
+    if (threadIdx.x == 0) a.loss_part[slot0 + blockIdx.x] = ((s_loss[0] + s_loss[1]) + s_loss[2]) + s_loss[3];
+}
+
+// One wavefront, tuples strictly in stream order: the reference's single-threaded semantics.
+// Same-wave stores and later loads of the same address stay ordered in the vector memory pipeline.
+template <typename T, int MODEL, bool STRICT>
+__global__ __launch_bounds__(64) void sgd_serial(SgdArgs<T> a, int64_t n, double *loss_out) {
+    const int lane = threadIdx.x;
+    const HParams hp = *a.hp;
+    double loss = 0.0;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t t = base + lane;
+        int mu = 0, mj = 0;
+        T mr = 0;
+        if (t < n) {
+            mu = a.su[t];
+            mj = a.sj[t];
+            mr = a.sr[t];
+        }
+        const int m = (n - base) < 64 ? (int)(n - base) : 64;
+        for (int i = 0; i < m; ++i) {
+            const int uu = __shfl(mu, i, 64), jj = __shfl(mj, i, 64);
+            const T rr = __shfl(mr, i, 64);
+            loss = sgd_one<T, MODEL, STRICT>(a, hp, uu, jj, rr, a.sconds + (base + i) * a.dmax, lane, loss, false);
+        }
+    }
+    if (lane == 0) loss_out[0] = loss * 0.5;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small utility kernels
+// ---------------------------------------------------------------------------------------------
+
+__global__ void set_hparams_kernel(HParams *dst, HParams v) { *dst = v; }
+
+// Fixed-shape two-stage reduction: the result depends only on (n_slots), never on timing.
+__global__ __launch_bounds__(256) void reduce_loss_stage1(const double *part, int64_t n, double *scratch) {
+    __shared__ double s[256];
+    const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t b = (int64_t)blockIdx.x * chunk;
+    const int64_t e = (b + chunk) < n ? (b + chunk) : n;
+    double acc = 0.0;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) acc += part[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scratch[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(256) void reduce_loss_stage2(const double *scratch, int nblk, double *loss_out) {
+    __shared__ double s[256];
+    s[threadIdx.x] = (int)threadIdx.x < nblk ? scratch[threadIdx.x] : 0.0;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_out[0] = s[0] * 0.5;
+}
+
+template <typename S, typename D>
+__global__ void convert_kernel(const S *src, D *dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (D)src[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// predict / evalRatings (Recommender.java:306-317, 504-594): fp64 arithmetic over the stored state
+// ---------------------------------------------------------------------------------------------
+
+template <typename T>
+__global__ __launch_bounds__(256) void eval_kernel(EvalArgs<T> a, int64_t n) {
+    __shared__ double s_part[4][5];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    double s_abs = 0, s_sq = 0, s_rabs = 0, s_rsq = 0, s_cnt = 0;
+    const int k = a.k;
+    const int model = a.model;
+    const bool has_bu = model == BIASEDMF || model == CAMF_C || model == CAMF_CI;
+    const bool has_bj = model == BIASEDMF || model == CAMF_C || model == CAMF_CU;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n; t += stride) {
+        const int uu = a.u[t], jj = a.j[t];
+        const T *pu = a.P + (size_t)uu * k;
+        const T *qj = a.Q + (size_t)jj * k;
+        double part = 0.0;
+        for (int f = lane; f < k; f += 64) part += (double)pu[f] * (double)qj[f];
+        const double dot = wave_sum64(part);
+        double pred = a.gm;
+        if (has_bu) pred += (double)a.userBias[uu];
+        if (has_bj) pred += (double)a.itemBias[jj];
+        pred += dot;
+        if (model != BIASEDMF) {
+            const int c = a.ctx[t];
+            for (int q = a.ctx_ptr[c]; q < a.ctx_ptr[c + 1]; ++q) {
+                const int cond = a.ctx_conds[q];
+                if (model == CAMF_C) pred += (double)a.condBias[cond];
+                else if (model == CAMF_CI) pred += (double)a.icBias[(size_t)jj * a.n_conds + cond];
+                else if (model == CAMF_CU) pred += (double)a.ucBias[(size_t)uu * a.n_conds + cond];
+                else pred += (double)a.icBias[(size_t)jj * a.n_conds + cond] + (double)a.ucBias[(size_t)uu * a.n_conds + cond];
+            }
+        }
+        if (a.bound) {
+            if (pred > a.hi) pred = a.hi;
+            if (pred < a.lo) pred = a.lo;
+        }
+        if (a.preds && lane == 0) a.preds[t] = pred;
+        if (a.r && !isnan(pred)) {
+            const double rate = a.r[t];
+            const double rpred = floor(pred / a.min_rate + 0.5) * a.min_rate; // Math.round(x)*minRate
+            const double err = fabs(rate - pred), rerr = fabs(rate - rpred);
+            s_abs += err;
+            s_sq += err * err;
+            s_rabs += rerr;
+            s_rsq += rerr * rerr;
+            s_cnt += 1.0;
+        }
+    }
+    if (a.part) {
+        if (lane == 0) {
+            s_part[wave][0] = s_abs;
+            s_part[wave][1] = s_sq;
+            s_part[wave][2] = s_rabs;
+            s_part[wave][3] = s_rsq;
+            s_part[wave][4] = s_cnt;
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            const int c = threadIdx.x;
+            a.part[(size_t)blockIdx.x * 5 + c] = ((s_part[0][c] + s_part[1][c]) + s_part[2][c]) + s_part[3][c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+
+int level_blocks_f32_fast(int, int count) { return (count + 15) / 16; }
+int level_blocks_generic(int count) { return (count + 3) / 4; }
+
+bool has_fast_path(int k, int dmax, bool f64, const LaunchCfg &cfg) {
+    if (f64 || cfg.strict) return false;
+    if (!(k == 64 || k == 128 || k == 256)) return false;
+    if (dmax > 16) return false;
+    return true;
+}
+
+template <int MODEL>
+static hipError_t launch_fast_model(const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,
+                                    int64_t slot0, hipStream_t s) {
+    const dim3 grid(level_blocks_f32_fast(a.k, count)), block(256);
+    const int relax = cfg.relax_cond ? 1 : 0;
+    switch (a.k) {
+    case 64: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 1>), grid, block, 0, s, a, begin, count, slot0, relax); break;
+    case 128: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 2>), grid, block, 0, s, a, begin, count, slot0, relax); break;
+    case 256: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 4>), grid, block, 0, s, a, begin, count, slot0, relax); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,
+                                 int64_t slot0, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    switch (cfg.model) {
+    case BIASEDMF: return launch_fast_model<BIASEDMF>(a, cfg, begin, count, slot0, s);
+    case CAMF_C: return launch_fast_model<CAMF_C>(a, cfg, begin, count, slot0, s);
+    case CAMF_CI: return launch_fast_model<CAMF_CI>(a, cfg, begin, count, slot0, s);
+    case CAMF_CU: return launch_fast_model<CAMF_CU>(a, cfg, begin, count, slot0, s);
+    case CAMF_CUCI: return launch_fast_model<CAMF_CUCI>(a, cfg, begin, count, slot0, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <typename T, int MODEL>
+static hipError_t launch_generic_model(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t begin, int count,
+                                       int64_t slot0, hipStream_t s) {
+    const dim3 grid(level_blocks_generic(count)), block(256);
+    const int relax = cfg.relax_cond ? 1 : 0;
+    if (cfg.strict)
+        hipLaunchKernelGGL((sgd_level_generic<T, MODEL, true>), grid, block, 0, s, a, begin, count, slot0, relax);
+    else
+        hipLaunchKernelGGL((sgd_level_generic<T, MODEL, false>), grid, block, 0, s, a, begin, count, slot0, relax);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_level_generic(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t begin, int count, int64_t slot0,
+                                hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    switch (cfg.model) {
+    case BIASEDMF: return launch_generic_model<T, BIASEDMF>(a, cfg, begin, count, slot0, s);
+    case CAMF_C: return launch_generic_model<T, CAMF_C>(a, cfg, begin, count, slot0, s);
+    case CAMF_CI: return launch_generic_model<T, CAMF_CI>(a, cfg, begin, count, slot0, s);
+    case CAMF_CU: return launch_generic_model<T, CAMF_CU>(a, cfg, begin, count, slot0, s);
+    case CAMF_CUCI: return launch_generic_model<T, CAMF_CUCI>(a, cfg, begin, count, slot0, s);
+    }
+    return hipErrorInvalidValue;
+}
+template hipError_t launch_level_generic<float>(const SgdArgs<float> &, const LaunchCfg &, int64_t, int, int64_t,
+                                                hipStream_t);
+template hipError_t launch_level_generic<double>(const SgdArgs<double> &, const LaunchCfg &, int64_t, int, int64_t,
+                                                 hipStream_t);
+
+template <typename T, int MODEL>
+static hipError_t launch_serial_model(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t n, double *loss_out,
+                                      hipStream_t s) {
+    if (cfg.strict)
+        hipLaunchKernelGGL((sgd_serial<T, MODEL, true>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else
+        hipLaunchKernelGGL((sgd_serial<T, MODEL, false>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_serial(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t n, double *loss_out, hipStream_t s) {
+    switch (cfg.model) {
+    case BIASEDMF: return launch_serial_model<T, BIASEDMF>(a, cfg, n, loss_out, s);
+    case CAMF_C: return launch_serial_model<T, CAMF_C>(a, cfg, n, loss_out, s);
+    case CAMF_CI: return launch_serial_model<T, CAMF_CI>(a, cfg, n, loss_out, s);
+    case CAMF_CU: return launch_serial_model<T, CAMF_CU>(a, cfg, n, loss_out, s);
+    case CAMF_CUCI: return launch_serial_model<T, CAMF_CUCI>(a, cfg, n, loss_out, s);
+    }
+    return hipErrorInvalidValue;
+}
+template hipError_t launch_serial<float>(const SgdArgs<float> &, const LaunchCfg &, int64_t, double *, hipStream_t);
+template hipError_t launch_serial<double>(const SgdArgs<double> &, const LaunchCfg &, int64_t, double *, hipStream_t);
+
+hipError_t launch_set_hparams(HParams *dst, HParams v, hipStream_t s) {
+    hipLaunchKernelGGL(set_hparams_kernel, dim3(1), dim3(1), 0, s, dst, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_loss(const double *loss_part, int64_t n_slots, double *scratch, double *loss_out,
+                              hipStream_t s) {
+    int nblk = (int)((n_slots + 4095) / 4096);
+    if (nblk < 1) nblk = 1;
+    if (nblk > 256) nblk = 256;
+    hipLaunchKernelGGL(reduce_loss_stage1, dim3(nblk), dim3(256), 0, s, loss_part, n_slots, scratch);
+    hipLaunchKernelGGL(reduce_loss_stage2, dim3(1), dim3(256), 0, s, scratch, nblk, loss_out);
+    return hipGetLastError();
+}
+
+int eval_blocks(int64_t n) {
+    int64_t b = (n + 3) / 4;
+    if (b < 1) b = 1;
+    if (b > 4096) b = 4096;
+    return (int)b;
+}
+
+template <typename T>
+hipError_t launch_eval(const EvalArgs<T> &a, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(eval_kernel<T>, dim3(eval_blocks(n)), dim3(256), 0, s, a, n);
+    return hipGetLastError();
+}
+template hipError_t launch_eval<float>(const EvalArgs<float> &, int64_t, hipStream_t);
+template hipError_t launch_eval<double>(const EvalArgs<double> &, int64_t, hipStream_t);
+
+hipError_t launch_convert(const void *src, int src_f64, void *dst, int dst_f64, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (src_f64 && dst_f64)
+        hipLaunchKernelGGL((convert_kernel<double, double>), grid, block, 0, s, (const double *)src, (double *)dst, n);
+    else if (src_f64 && !dst_f64)
+        hipLaunchKernelGGL((convert_kernel<double, float>), grid, block, 0, s, (const double *)src, (float *)dst, n);
+    else if (!src_f64 && dst_f64)
+        hipLaunchKernelGGL((convert_kernel<float, double>), grid, block, 0, s, (const float *)src, (double *)dst, n);
+    else
+        hipLaunchKernelGGL((convert_kernel<float, float>), grid, block, 0, s, (const float *)src, (float *)dst, n);
+    return hipGetLastError();
+}
+
+} // namespace cmi

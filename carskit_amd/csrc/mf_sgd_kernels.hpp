@@ -1,0 +1,78 @@
+// mf_sgd_kernels.hpp -- launch interface between the C-ABI host code (cmi_api.cpp) and the gfx950
+// kernels (mf_sgd_kernels.hip).  Internal header; the public surface is include/carskit_mi355x.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cmi {
+
+enum Model { BIASEDMF = 0, CAMF_C = 1, CAMF_CI = 2, CAMF_CU = 3, CAMF_CUCI = 4 };
+
+// Device-resident hyper-parameters, rewritten before every epoch by set_hparams (so a captured
+// hipGraph of level launches can be replayed with a new learning rate).
+struct HParams {
+    double lr, regU, regI, regB, regC, gm;
+};
+
+// Everything a training kernel needs; T = element type of the model state in HBM.
+template <typename T>
+struct SgdArgs {
+    T *P, *Q;                  // [n_users x k], [n_items x k] row-major, row = k contiguous elements
+    T *userBias, *itemBias;    // [n_users], [n_items]
+    T *condBias;               // [n_conds]
+    T *ucBias, *icBias;        // [n_users x n_conds], [n_items x n_conds]
+    const int32_t *su, *sj;    // tuple stream in SCHEDULE order (levels concatenated)
+    const T *sr;               // ratings, same order
+    const int32_t *sconds;     // [n x dmax] condition ids of each tuple, -1 padded
+    const HParams *hp;
+    double *loss_part;         // one slot per workgroup of the epoch (deterministic reduction)
+    int32_t k, n_conds, dmax;
+};
+
+struct LaunchCfg {
+    int model;
+    bool strict;     // left-to-right dot (DenseMatrix.rowMult order) + reference loss order
+    bool relax_cond; // CAMF_C: condBias through atomics
+};
+
+// number of workgroups a level of `count` tuples occupies (= loss_part slots it writes)
+int level_blocks_f32_fast(int k, int count);
+int level_blocks_generic(int count);
+bool has_fast_path(int k, int dmax, bool f64, const LaunchCfg &cfg);
+
+// one dependency level: tuples [begin, begin+count) of the schedule run concurrently
+hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,
+                                 int64_t slot0, hipStream_t s);
+template <typename T>
+hipError_t launch_level_generic(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t begin, int count, int64_t slot0,
+                                hipStream_t s);
+// one wavefront walks tuples [0, n) in order (the reference's sequential semantics); loss -> loss_out[0] (already *0.5)
+template <typename T>
+hipError_t launch_serial(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t n, double *loss_out, hipStream_t s);
+
+hipError_t launch_set_hparams(HParams *dst, HParams v, hipStream_t s);
+// loss_out[0] = 0.5 * sum(loss_part[0..n_slots)) in a fixed order; scratch holds >= 256 doubles
+hipError_t launch_reduce_loss(const double *loss_part, int64_t n_slots, double *scratch, double *loss_out,
+                              hipStream_t s);
+
+// predict / evalRatings
+template <typename T>
+struct EvalArgs {
+    const T *P, *Q, *userBias, *itemBias, *condBias, *ucBias, *icBias;
+    const int32_t *u, *j, *ctx;       // n tuples (ctx may be null for BiasedMF)
+    const double *r;                  // may be null (predict only)
+    const int32_t *ctx_ptr, *ctx_conds;
+    double *preds;                    // may be null
+    double *part;                     // [blocks x 5] partial sums (abs, sq, rabs, rsq, count); may be null
+    double gm, lo, hi, min_rate;
+    int32_t k, n_conds, bound, model;
+};
+int eval_blocks(int64_t n);
+template <typename T>
+hipError_t launch_eval(const EvalArgs<T> &a, int64_t n, hipStream_t s);
+
+// dtype conversion for cmi_set_state / cmi_get_state staging
+hipError_t launch_convert(const void *src, int src_f64, void *dst, int dst_f64, int64_t n, hipStream_t s);
+
+} // namespace cmi

@@ -1,0 +1,168 @@
+/*
+ * carskit_mi355x.h -- C ABI of libcarskit_mi355x.so: the MI355X (gfx950) replacement for the
+ * per-rating SGD inner loop of buildModel() in CARSKit's BiasedMF / CAMF_C / CAMF_CI / CAMF_CU /
+ * CAMF_CUCI recommenders, plus the numeric part of evalRatings().
+ *
+ * The reference (irecsys/CARSKit v0.4.0) is Java and has no FFI of its own; this is the surface a
+ * JNI shim (see INTEGRATION.md and java/) binds.  Every entry point names the reference code it
+ * stands in for (paths relative to the reference root).  Plain pointers and sizes only; the
+ * caller owns every host buffer; the library owns the device copies.
+ *
+ * Threading: a handle is an independent recommender instance bound to one GPU; different handles
+ * may be used from different threads concurrently (the reference runs one Java thread per CV
+ * fold, src/carskit/main/CARSKit.java:395-412).  One handle must not be used from two threads at
+ * once.  No process-global state.
+ *
+ * Errors: every function returns CMI_OK (0) or a negative CMI_E_* code; cmi_last_error() gives
+ * the message (the reference throws checked Exceptions, src/carskit/generic/Recommender.java:319;
+ * the JNI shim turns a non-zero status into a RuntimeException).  There is NO CPU fallback: without
+ * a HIP device every compute entry point fails with CMI_E_NO_DEVICE.
+ */
+#ifndef CARSKIT_MI355X_H
+#define CARSKIT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMI_ABI_VERSION 1
+
+/* status codes */
+#define CMI_OK 0
+#define CMI_E_INVALID (-1)    /* bad argument / bad call order */
+#define CMI_E_NO_DEVICE (-2)  /* no HIP device (no CPU fallback exists) */
+#define CMI_E_HIP (-3)        /* a HIP runtime call failed */
+#define CMI_E_NUMERIC (-4)    /* loss became NaN/Inf (IterativeRecommender.java:181-184) */
+#define CMI_E_UNSUPPORTED (-5)
+
+/* recommender kinds = the `recommender=` names the reference's factory switch maps to the classes
+ * this library accelerates (src/carskit/main/CARSKit.java:461,700-707) */
+#define CMI_MODEL_BIASEDMF 0  /* src/carskit/alg/baseline/cf/BiasedMF.java */
+#define CMI_MODEL_CAMF_C 1    /* src/carskit/alg/cars/adaptation/dependent/dev/CAMF_C.java */
+#define CMI_MODEL_CAMF_CI 2   /* .../dev/CAMF_CI.java */
+#define CMI_MODEL_CAMF_CU 3   /* .../dev/CAMF_CU.java */
+#define CMI_MODEL_CAMF_CUCI 4 /* .../dev/CAMF_CUCI.java */
+
+/* state containers = the model fields a subclass must leave consistent
+ * (IterativeRecommender.java:56-64, CAMF.java:40-42) */
+#define CMI_STATE_P 0         /* DenseMatrix P        numUsers x k */
+#define CMI_STATE_Q 1         /* DenseMatrix Q        numItems x k */
+#define CMI_STATE_USER_BIAS 2 /* DenseVector userBias numUsers */
+#define CMI_STATE_ITEM_BIAS 3 /* DenseVector itemBias numItems */
+#define CMI_STATE_COND_BIAS 4 /* DenseVector condBias numConditions         (CAMF_C) */
+#define CMI_STATE_UC_BIAS 5   /* DenseMatrix ucBias   numUsers x numConditions (CAMF_CU, CAMF_CUCI) */
+#define CMI_STATE_IC_BIAS 6   /* DenseMatrix icBias   numItems x numConditions (CAMF_CI, CAMF_CUCI) */
+#define CMI_STATE_COUNT 7
+
+/* host buffer element types for cmi_set_state / cmi_get_state */
+#define CMI_DTYPE_F32 0
+#define CMI_DTYPE_F64 1
+
+/* cmi_create flags */
+#define CMI_FLAG_STATE_F64 0x1u  /* keep the model in fp64 on the GPU (reference precision); default fp32 */
+#define CMI_FLAG_SCHED_SERIAL 0x2u /* one wavefront walks the tuples in the reference's CRS order (exact for
+                                      every model incl. CAMF_C; slow).  Default: dependency-level schedule --
+                                      tuples that share no user and no item commute exactly, so the result equals
+                                      the sequential order at equal precision while whole levels run in parallel */
+#define CMI_FLAG_STRICT 0x4u     /* generic kernel + strictly left-to-right dot product (DenseMatrix.rowMult
+                                      order) and, under SCHED_SERIAL, the reference's running-sum order for `loss`:
+                                      with STATE_F64 the model (and under SERIAL the loss) is bit-identical to the
+                                      Java arithmetic */
+#define CMI_FLAG_RELAX_COND 0x8u /* CAMF_C only, level schedule: condBias updates of one level are applied with
+                                      atomics instead of in CRS order (NOT order-exact; report the RMSE band) */
+#define CMI_FLAG_NO_GRAPH 0x10u  /* launch the per-level kernels eagerly instead of replaying a hipGraph */
+
+typedef struct cmi_instance *cmi_handle;
+
+/* library / device probes (no reference counterpart) */
+int cmi_abi_version(void);
+int cmi_device_count(void); /* 0 when no HIP device is visible; never fails */
+
+/* new Recommender(trainMatrix, testMatrix, fold) + initModel() container allocation
+ * (Recommender.java:180-275, IterativeRecommender.java:232-247, CAMF_CI.java:51-63 ...).
+ * State is zero until cmi_set_state: the library never draws random numbers (the reference's
+ * init stream is unseedable), the host injects the arrays. */
+int cmi_create(int model, int k, int n_users, int n_items, int n_conds, int device, unsigned flags,
+               cmi_handle *out);
+int cmi_destroy(cmi_handle h);
+/* message of the last failure on this handle; h == NULL: last cmi_create failure on this thread */
+const char *cmi_last_error(cmi_handle h);
+
+/* The training matrix: what `for (MatrixEntry me : trainMatrix)` yields, flattened
+ * (CAMF_CI.java:80-86; librec SparseMatrix CSR arrays + DataDAO.getUserIdFromUI/getItemIdFromUI,
+ * src/carskit/data/processor/DataDAO.java:1038-1046).  n tuples in CRS order: u[t], j[t] inner
+ * user/item ids, ctx[t] context-combination id, r[t] rating.  ctx_ptr/ctx_conds (n_ctx+1 / nnz) is
+ * ContextRecommender.getConditions (src/carskit/generic/ContextRecommender.java:53-61) as CSR.
+ * BiasedMF: the 2-D `train` matrix (BiasedMF.java:62-66); ctx, ctx_ptr, ctx_conds may be NULL.
+ * Builds the execution schedule (host integer work) and uploads. */
+int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
+                    const double *r, int32_t n_ctx, const int32_t *ctx_ptr, const int32_t *ctx_conds);
+
+/* copy-in at buildModel() entry / copy-back at exit of one model container (row-major, count
+ * elements = rows*cols).  Converts between the host dtype and the device state dtype. */
+int cmi_set_state(cmi_handle h, int which, const void *src, int64_t count, int dtype);
+int cmi_get_state(cmi_handle h, int which, void *dst, int64_t count, int dtype);
+
+/* regU/regI/regB/regC (IterativeRecommender.java:40,94-98: Java floats promoted to double) and
+ * globalMean (Recommender.java:265) */
+int cmi_set_hparams(cmi_handle h, double regU, double regI, double regB, double regC, double global_mean);
+
+/* One pass of the `for (MatrixEntry me : trainMatrix) {...}` body + `loss *= 0.5`
+ * (e.g. CAMF_CI.java:79-123) with learning rate lrate; *loss_out = the epoch's loss.  The host keeps
+ * calling isConverged() itself (the Java drop-in does exactly this). */
+int cmi_train_epoch(cmi_handle h, double lrate, double *loss_out);
+
+/* Whole buildModel(): up to num_iters epochs with IterativeRecommender.isConverged/updateLRate
+ * (IterativeRecommender.java:145-229) evaluated between epochs.  early_stop: 0 none, 1 loss.
+ * losses/lrates (num_iters each, may be NULL) receive the per-epoch loss and the rate used;
+ * *iters_run the number of epochs executed; *final_lrate (may be NULL) the lRate field afterwards.
+ * NaN/Inf loss -> CMI_E_NUMERIC (the reference calls System.exit(-1)). */
+int cmi_train(cmi_handle h, int num_iters, double init_lrate, double max_lrate, int bold_driver, double decay,
+              int early_stop, double *losses, double *lrates, int *iters_run, double *final_lrate);
+
+/* predict(u, j, c, bound) for n tuples (Recommender.java:306-317 + the model's predict());
+ * bound != 0 clamps to [lo, hi].  ctx may be NULL for BiasedMF. */
+int cmi_predict_batch(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, int bound,
+                      double lo, double hi, double *out);
+
+/* numeric part of Recommender.evalRatings (Recommender.java:504-594) over n test tuples whose ctx
+ * ids index the SAME ctx_ptr/ctx_conds table given to cmi_set_ratings.
+ * out[0]=MAE out[1]=RMSE out[2]=NMAE out[3]=rMAE out[4]=rRMSE; *count = tuples with non-NaN prediction */
+int cmi_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
+                     const double *r, double min_rate, double max_rate, double *out, int64_t *count);
+
+/* ---- plumbing for the host layer (multi-GPU exchange, measurement); no reference counterpart ---- */
+
+/* device pointer of a state container (element type per CMI_FLAG_STATE_F64), so the host can run its
+ * epoch-boundary exchange (RCCL all-reduce of item-side deltas) in place */
+int cmi_state_device_ptr(cmi_handle h, int which, void **ptr, int64_t *count, int *dtype);
+/* the HIP stream (hipStream_t) all of this handle's work is enqueued on */
+int cmi_stream(cmi_handle h, void **stream);
+int cmi_synchronize(cmi_handle h);
+/* enqueue one epoch without reading the loss back (pair with cmi_synchronize / cmi_last_loss) */
+int cmi_train_epoch_async(cmi_handle h, double lrate);
+int cmi_last_loss(cmi_handle h, double *loss_out);
+/* schedule facts: info[0]=levels (kernel launches per epoch), info[1]=largest level, info[2]=tuples,
+ * info[3]=max conditions per tuple (D), info[4]=state bytes on device, info[5]=tuple-stream bytes on device */
+int cmi_schedule_info(cmi_handle h, int64_t info[6]);
+/* GPU time of the most recent epoch's kernels measured with HIP events on cmi_stream() */
+int cmi_last_epoch_ms(cmi_handle h, float *ms);
+
+/* ---- host-only integer preprocessing (runs without a GPU) ------------------------------------- */
+
+/* The dependency-level schedule the default mode executes (carskit_amd/csrc/level_schedule.cpp):
+ * level(t) = 1 + max(level of the previous tuple with the same user, ... same item).  It replaces the
+ * reference's implicit "one tuple after another" order (librec MatrixIterator, CAMF_CI.java:80) by the
+ * weakest order that yields the identical result.  perm[n]: schedule position -> CRS tuple index;
+ * level_off[0..*n_levels]: offsets of the levels in perm (level_cap = capacity of level_off, must be
+ * >= *n_levels + 1; pass level_off = NULL to only count).  order: 0 keep CRS order inside a level,
+ * 1 sort by item id, 2 sort by user id (tuples of one level commute, so this is free). */
+int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int order,
+                       int32_t *perm, int64_t *level_off, int64_t level_cap, int64_t *n_levels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

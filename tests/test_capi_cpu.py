@@ -1,0 +1,101 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/carskit_mi355x.h
+declares, refuses to compute without a GPU (no CPU fallback), and the host-only level scheduler
+produces a valid, minimal, order-preserving schedule."""
+import os
+import re
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from carskit_amd import capi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_all_exported():
+    hdr = open(os.path.join(ROOT, "include", "carskit_mi355x.h")).read()
+    declared = set(re.findall(r"\b(cmi_[a-z_0-9]+)\s*\(", hdr))
+    bound = {name for name, _, _ in capi.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    L = capi.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.cmi_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(capi.CmiError) as ei:
+        capi.Instance("CAMF_CI", 8, 10, 10, 4)
+    assert ei.value.code == capi.E_NO_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_package_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "carskit_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the CPU oracle", ""), os.path.join(dirpath, f)
+
+
+def _check_schedule(u, j, nu, ni, order):
+    perm, off = capi.level_schedule(u, j, nu, ni, order)
+    n = len(u)
+    assert sorted(perm.tolist()) == list(range(n))          # a permutation
+    assert off[0] == 0 and off[-1] == n and np.all(np.diff(off) > 0 if n else True)
+    level_of = np.empty(n, dtype=np.int64)
+    for l in range(len(off) - 1):
+        seg = perm[off[l]:off[l + 1]]
+        level_of[seg] = l
+        # tuples of one level share no user and no item -> they commute
+        assert len(set(u[seg].tolist())) == len(seg)
+        assert len(set(j[seg].tolist())) == len(seg)
+    # per user and per item the levels strictly increase along the CRS order
+    for key in (u, j):
+        last = {}
+        for t in range(n):
+            k = int(key[t])
+            if k in last:
+                assert level_of[t] > last[k]
+            last[k] = level_of[t]
+    # minimality: level(t) = 1 + max(level of predecessors) (longest dependency chain)
+    lu, lj = {}, {}
+    for t in range(n):
+        want = max(lu.get(int(u[t]), -1), lj.get(int(j[t]), -1)) + 1
+        assert level_of[t] == want
+        lu[int(u[t])] = lj[int(j[t])] = want
+    return perm, off
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_level_schedule_small(order):
+    d = synth.generate(37, 13, 2, 3, 600, seed=order + 1)
+    perm, off = _check_schedule(d.u, d.j, d.n_users, d.n_items, order)
+    if order == 0:  # CRS order kept inside a level
+        for l in range(len(off) - 1):
+            assert np.all(np.diff(perm[off[l]:off[l + 1]]) > 0)
+
+
+@settings(max_examples=40, deadline=None)
+@given(nu=st.integers(1, 9), ni=st.integers(1, 9), n=st.integers(0, 80), seed=st.integers(0, 1000),
+       order=st.integers(0, 2))
+def test_level_schedule_property(nu, ni, n, seed, order):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, nu, n).astype(np.int32)
+    j = rng.integers(0, ni, n).astype(np.int32)
+    _check_schedule(u, j, nu, ni, order)
+
+
+def test_level_schedule_rejects_bad_ids():
+    with pytest.raises(capi.CmiError):
+        capi.level_schedule(np.array([0, 5], np.int32), np.array([0, 0], np.int32), 3, 2)
+
+
+def test_level_schedule_zipf_chain():
+    """A hot item serialises its tuples: #levels >= its degree."""
+    d = synth.generate(200, 50, 1, 2, 3000, seed=4, item_zipf=1.3)
+    _, off = capi.level_schedule(d.u, d.j, d.n_users, d.n_items)
+    assert len(off) - 1 >= np.bincount(d.j).max()

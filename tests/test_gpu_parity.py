@@ -1,0 +1,227 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bars (written where they are asserted):
+  * fp64 state + strict order, serial schedule : model state AND per-epoch loss bit-identical
+  * fp64 state + strict order, level schedule  : model state bit-identical, loss to 1e-12 relative
+  * fp64 state, default (tree-reduced dot)      : RMSE/MAE within 1e-9
+  * fp32 state (the throughput configuration)   : RMSE/MAE within 1e-5 (BASELINE.json north_star)
+"""
+import numpy as np
+import pytest
+
+from carskit_amd import capi, synth
+from oracle import oracle_c
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+F64, SERIAL, STRICT, RELAX, NOGRAPH = (capi.FLAG_STATE_F64, capi.FLAG_SCHED_SERIAL, capi.FLAG_STRICT,
+                                       capi.FLAG_RELAX_COND, capi.FLAG_NO_GRAPH)
+
+
+def make_pair(model, data, k, flags, seed=5, regs=None):
+    """(oracle, gpu instance) over the same tuples and the same injected initial state."""
+    regU, regI, regB, regC = regs or (util.REG, util.REG, util.REG, util.REGC)
+    state = synth.init_state(model, data, k, seed=seed)
+    gm = oracle_c.global_mean(data.r)
+    orc = util.c_oracle(model, data, k, state, gm, regU, regI, regB, regC)
+    u, j, ctx, r = util.tuples_for(model, data)
+    inst = capi.Instance(model, k, data.n_users, data.n_items, data.n_conds, flags=flags)
+    inst.set_hparams(regU, regI, regB, regC, gm)
+    if model == "BiasedMF":
+        inst.set_ratings(u, j, None, r)
+    else:
+        inst.set_ratings(u, j, ctx, r, data.ctx_ptr, data.ctx_conds)
+    inst.set_states(state)
+    return orc, inst
+
+
+def assert_state_equal(orc, inst, exact=True, atol=0.0):
+    for name, a in inst.get_states().items():
+        ref = orc.state[name].reshape(a.shape)
+        if exact:
+            assert np.array_equal(ref, a), name
+        else:
+            assert np.max(np.abs(ref - a)) <= atol, (name, np.max(np.abs(ref - a)))
+
+
+@pytest.mark.parametrize("model", util.MODELS)
+@pytest.mark.parametrize("k", [3, 10, 64, 70])
+def test_serial_strict_f64_bit_exact(model, k):
+    data = util.small_data(n_users=60, n_items=25, n=900, seed=21)
+    orc, inst = make_pair(model, data, k, F64 | SERIAL | STRICT)
+    o_losses, o_lrs, _ = orc.build_model(6, util.LR, bold_driver=True)
+    g_losses, g_lrs = inst.train(6, util.LR, bold_driver=True)
+    assert g_losses.tolist() == o_losses.tolist()      # bit-identical epoch losses
+    assert g_lrs.tolist() == o_lrs.tolist()            # hence identical bold-driver trajectory
+    assert_state_equal(orc, inst, exact=True)
+
+
+@pytest.mark.parametrize("model", [m for m in util.MODELS if m != "CAMF_C"])
+@pytest.mark.parametrize("k", [5, 64, 130])
+@pytest.mark.parametrize("graph", [True, False])
+def test_level_strict_f64_state_bit_exact(model, k, graph):
+    data = util.small_data(n_users=300, n_items=40, n=4000, seed=22)
+    orc, inst = make_pair(model, data, k, F64 | STRICT | (0 if graph else NOGRAPH))
+    lr = util.LR
+    for _ in range(4):
+        lo = orc.epoch(lr)
+        lg = inst.train_epoch(lr)
+        assert abs(lo - lg) <= 1e-12 * abs(lo)          # loss: same terms, different (fixed) summation tree
+    assert_state_equal(orc, inst, exact=True)           # state: the level schedule commutes exactly
+    assert inst.schedule_info()["levels"] >= np.bincount(data.j).max()
+
+
+@pytest.mark.parametrize("model", [m for m in util.MODELS if m != "CAMF_C"])
+def test_level_f64_default(model):
+    data = util.small_data(n_users=400, n_items=60, n_dims=3, conds_per_dim=4, n=8000, seed=23)
+    train, test = synth.split(data, 0.2)
+    orc, inst = make_pair(model, train, 64, F64)
+    o_losses, _, _ = orc.build_model(10, util.LR, bold_driver=True)
+    g_losses, _ = inst.train(10, util.LR, bold_driver=True)
+    np.testing.assert_allclose(g_losses, o_losses, rtol=1e-11)
+    tu, tj, tctx, tr = util.tuples_for(model, test) if model != "BiasedMF" else (test.u, test.j, None, test.r)
+    oe = orc.eval_ratings(tu, tj, tctx, tr, 1.0, 5.0)
+    ge = inst.eval_ratings(tu, tj, tctx, tr, 1.0, 5.0)
+    assert oe["n"] == ge["n"]
+    for key in ("MAE", "RMSE", "NMAE", "rMAE", "rRMSE"):
+        assert abs(oe[key] - ge[key]) <= 1e-9, key       # fp64 bar
+    assert_state_equal(orc, inst, exact=False, atol=1e-12)
+
+
+@pytest.mark.parametrize("model", [m for m in util.MODELS if m != "CAMF_C"])
+@pytest.mark.parametrize("k", [10, 64, 128, 256])
+def test_level_f32_rmse_within_1e5(model, k):
+    """The throughput configuration: fp32 state, DPP-reduced dot, dependency-level schedule."""
+    data = util.small_data(n_users=3000, n_items=400, n_dims=4, conds_per_dim=4, n=60000, seed=24)
+    train, test = synth.split(data, 0.2)
+    orc, inst = make_pair(model, train, k, 0)
+    iters = 20
+    o_losses, o_lrs, _ = orc.build_model(iters, util.LR, bold_driver=True)
+    g_losses, g_lrs = inst.train(iters, util.LR, bold_driver=True)
+    assert g_lrs.tolist() == o_lrs.tolist()             # same bold-driver decisions
+    np.testing.assert_allclose(g_losses, o_losses, rtol=2e-5)
+    tu, tj, tctx, tr = (test.u, test.j, test.ctx, test.r)
+    if model == "BiasedMF":
+        tctx = None
+    oe = orc.eval_ratings(tu, tj, tctx, tr, 1.0, 5.0)
+    ge = inst.eval_ratings(tu, tj, tctx, tr, 1.0, 5.0)
+    assert abs(oe["RMSE"] - ge["RMSE"]) <= 1e-5          # north_star tolerance, fp32
+    assert abs(oe["MAE"] - ge["MAE"]) <= 1e-5
+    ot = orc.eval_ratings(*util.tuples_for(model, train), 1.0, 5.0)
+    gt = inst.eval_ratings(*util.tuples_for(model, train), 1.0, 5.0) if model != "BiasedMF" else \
+        inst.eval_ratings(*util.tuples_for(model, train)[:2], None, util.tuples_for(model, train)[3], 1.0, 5.0)
+    assert abs(ot["RMSE"] - gt["RMSE"]) <= 1e-5
+
+
+def test_camf_c_serial_f32_and_relaxed_band():
+    """CAMF_C (config C2 shape: k=64): the serial schedule is order-exact; the relaxed level schedule is
+    NOT order-exact and is only held to an RMSE band, which this test prints."""
+    data = util.small_data(n_users=500, n_items=200, n_dims=4, conds_per_dim=3, n=12000, seed=25)
+    train, test = synth.split(data, 0.2)
+    orc, inst = make_pair("CAMF_C", train, 64, SERIAL)
+    o_losses, o_lrs, _ = orc.build_model(15, util.LR, bold_driver=True)
+    g_losses, g_lrs = inst.train(15, util.LR, bold_driver=True)
+    assert g_lrs.tolist() == o_lrs.tolist()
+    oe = orc.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
+    ge = inst.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
+    assert abs(oe["RMSE"] - ge["RMSE"]) <= 1e-5 and abs(oe["MAE"] - ge["MAE"]) <= 1e-5
+    _, rel = make_pair("CAMF_C", train, 64, RELAX)
+    rel.train(15, util.LR, bold_driver=True)
+    re_ = rel.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
+    print("CAMF_C relaxed-condBias band: dRMSE=%.3e dMAE=%.3e" % (re_["RMSE"] - oe["RMSE"], re_["MAE"] - oe["MAE"]))
+    assert abs(re_["RMSE"] - oe["RMSE"]) <= 5e-2
+
+
+def test_predict_batch_and_bounds():
+    data = util.small_data(n_users=50, n_items=20, n=500, seed=26)
+    orc, inst = make_pair("CAMF_CUCI", data, 16, F64)
+    orc.epoch(util.LR)
+    inst.train_epoch(util.LR)
+    want = np.array([orc.predict(int(u), int(j), int(c)) for u, j, c in zip(data.u, data.j, data.ctx)])
+    got = inst.predict(data.u, data.j, data.ctx)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    got_b = inst.predict(data.u, data.j, data.ctx, bound=(2.0, 4.0))
+    np.testing.assert_allclose(got_b, np.clip(want, 2.0, 4.0), rtol=0, atol=1e-12)
+
+
+def test_ragged_and_empty_contexts():
+    """Contexts with different numbers of active conditions, including none (an ill-formed binary file
+    can produce them; getConditions would return that many ids)."""
+    rng = np.random.default_rng(3)
+    nu, ni, nc, n = 40, 15, 7, 700
+    ctx_lists = [[], [0], [1, 4], [0, 2, 5], [3, 4, 5, 6], [6]]
+    ctx_ptr = np.cumsum([0] + [len(c) for c in ctx_lists]).astype(np.int32)
+    ctx_conds = np.array([c for cl in ctx_lists for c in cl], dtype=np.int32)
+    data = synth.RatingData(nu, ni, nc, 4, rng.integers(0, nu, n).astype(np.int32),
+                            rng.integers(0, ni, n).astype(np.int32),
+                            rng.integers(0, len(ctx_lists), n).astype(np.int32),
+                            rng.integers(1, 6, n).astype(np.float64), ctx_ptr, ctx_conds)
+    for model in ("CAMF_CI", "CAMF_CU", "CAMF_CUCI"):
+        for flags in (F64 | STRICT, F64 | SERIAL | STRICT):
+            orc, inst = make_pair(model, data, 6, flags)
+            for _ in range(3):
+                orc.epoch(util.LR)
+                inst.train_epoch(util.LR)
+            assert_state_equal(orc, inst, exact=True)
+    orc, inst = make_pair("CAMF_CI", data, 64, 0)        # fp32 fast path with padded condition lanes
+    for _ in range(3):
+        lo, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
+        assert abs(lo - lg) <= 1e-5 * abs(lo)
+    assert_state_equal(orc, inst, exact=False, atol=2e-5)
+
+
+def test_edge_cases_and_errors():
+    data = util.small_data(n_users=10, n_items=5, n=40, seed=27)
+    # empty training set: loss 0, state untouched
+    inst = capi.Instance("CAMF_CI", 8, data.n_users, data.n_items, data.n_conds, flags=F64)
+    inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+    inst.set_ratings(data.u[:0], data.j[:0], data.ctx[:0], data.r[:0], data.ctx_ptr, data.ctx_conds)
+    st = synth.init_state("CAMF_CI", data, 8)
+    inst.set_states(st)
+    assert inst.train_epoch(0.01) == 0.0
+    assert np.array_equal(inst.get_state("P"), st["P"])
+    # single tuple
+    orc, one = make_pair("CAMF_CU", data.subset(np.array([0])), 8, F64 | STRICT)
+    assert orc.epoch(util.LR) == one.train_epoch(util.LR)
+    assert_state_equal(orc, one, exact=True)
+    # call-order and range errors are reported, not crashed on
+    bad = capi.Instance("CAMF_CI", 8, data.n_users, data.n_items, data.n_conds)
+    with pytest.raises(capi.CmiError):
+        bad.train_epoch(0.01)                               # no ratings yet
+    with pytest.raises(capi.CmiError):
+        bad.set_ratings(data.u + 1000, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
+    with pytest.raises(capi.CmiError):
+        bad.set_state("itemBias", np.zeros(data.n_items))   # CAMF_CI has no itemBias
+    with pytest.raises(capi.CmiError):
+        bad.set_state("P", np.zeros(3))                     # wrong size
+    with pytest.raises(capi.CmiError) as ei:
+        capi.Instance("CAMF_C", 8, 4, 4, 4)                 # no exact parallel schedule for CAMF_C
+    assert ei.value.code == capi.E_UNSUPPORTED
+
+
+def test_nan_loss_is_an_error():
+    data = util.small_data(n_users=30, n_items=10, n=400, seed=28)
+    _, inst = make_pair("CAMF_CI", data, 8, F64)
+    with pytest.raises(capi.CmiError) as ei:
+        inst.train(50, 50.0, bold_driver=False)              # absurd learning rate diverges
+    assert ei.value.code == capi.E_NUMERIC
+
+
+def test_level_order_is_free():
+    """Tuples inside a level commute: a different within-level order gives the bit-identical model."""
+    import os
+    data = util.small_data(n_users=800, n_items=90, n=9000, seed=29)
+    outs = []
+    for order in ("crs", "item", "user"):
+        os.environ["CMI_LEVEL_ORDER"] = order
+        try:
+            _, inst = make_pair("CAMF_CI", data, 128, 0)
+            for _ in range(3):
+                inst.train_epoch(util.LR)
+            outs.append(inst.get_states(np.float32))
+        finally:
+            os.environ.pop("CMI_LEVEL_ORDER", None)
+    for other in outs[1:]:
+        for name in outs[0]:
+            assert np.array_equal(outs[0][name], other[name]), name
