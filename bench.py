@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- rating-updates/sec of the CAMF_CI k=128 SGD hot path on MI355X (BASELINE.json metric).
+
+A "step" is one epoch of buildModel(): one pass of the fused gather-dot-AXPY update over every training
+tuple, through the C ABI (libcarskit_mi355x.so), with tuples and model already resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|northstar|small]
+
+N>1 is launched by the driver through torch.distributed.run (one rank per GPU): tuples are sharded by
+user (each rank owns its own users and their ratings: weak scaling, per-GPU work fixed), the item-side
+state (Q, icBias) is replicated and its per-epoch deltas are summed with an RCCL all-reduce
+(carskit_amd/dist.py).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from carskit_amd import capi, synth  # noqa: E402
+
+# name -> (model, k, users, items, dims, conds/dim, ratings) ; per GPU
+WORKLOADS = {
+    # BASELINE.json configs[2]: the configuration the metric is quoted on that fits one GPU
+    "c3": ("CAMF_CI", 128, 1_000_000, 100_000, 4, 8, 50_000_000),
+    # BASELINE.json north_star target sentence: 10M users / 1M items / 64 conditions
+    "northstar": ("CAMF_CI", 128, 10_000_000, 1_000_000, 4, 16, 200_000_000),
+    "small": ("CAMF_CI", 128, 100_000, 10_000, 4, 8, 5_000_000),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def algorithmic_bytes(model, k, d):
+    """B = 16 + 4D + 16k + 8S + 8DT (fp32 state, int32 ids, compulsory traffic, no reuse)."""
+    s, t = {"BiasedMF": (2, 0), "CAMF_C": (2, 1), "CAMF_CI": (1, 1), "CAMF_CU": (1, 1), "CAMF_CUCI": (0, 2)}[model]
+    return 16 + 4 * d + 16 * k + 8 * s + 8 * d * t
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(model, k, data, state, gm, regs, lr, budget_tuples):
+    """The oracle (order-exact fp64 restatement of the Java loop, 1 thread) on a prefix of the same tuples."""
+    from oracle import oracle_c
+    m = min(data.n, budget_tuples)
+    st = {n: np.asarray(a, dtype=np.float64) for n, a in state.items()}
+    orc = oracle_c.Oracle(model, k, data.n_users, data.n_items, data.n_conds, data.u[:m], data.j[:m], data.ctx[:m],
+                          data.r[:m], data.ctx_ptr, data.ctx_conds, st, gm, *regs)
+    t0 = time.perf_counter()
+    orc.epoch(lr)
+    dt = time.perf_counter() - t0
+    return {"value": m / dt, "unit": "rating-updates/s", "cores": 1, "kind": "port",
+            "sample": "1 epoch over the first %d tuples of the same workload, fp64 order-exact C restatement of the "
+                      "Java loop, single thread (host has %d cores; the reference loop is single-threaded per fold)"
+                      % (m, os.cpu_count() or 0), "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tuples", type=int, default=20_000_000)
+    ap.add_argument("--flags", type=int, default=0, help="extra cmi_create flags (e.g. 16 = no hipGraph)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one rank per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    model, k, n_users, n_items, n_dims, cpd, n_ratings = WORKLOADS[args.workload]
+    t0 = time.perf_counter()
+    # every rank owns its own users (seeded by rank); items and contexts are the shared, replicated side
+    data = synth.generate_fast(n_users, n_items, n_dims, cpd, n_ratings, seed=synth.DEFAULT_SEED + 1000 * rank)
+    log("rank %d: generated %d tuples (%d users, %d items, %d contexts) in %.1fs"
+        % (rank, data.n, data.n_users, data.n_items, data.n_ctx, time.perf_counter() - t0))
+    regs = (synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-3))
+    lr = synth.java_float(0.02)
+    gm = float(data.r.sum() / np.count_nonzero(data.r))
+    t0 = time.perf_counter()
+    state = synth.init_state(model, data, k, seed=synth.DEFAULT_SEED + 2 + (0 if world == 1 else 0), dtype=np.float32)
+    if world > 1:
+        # item-side state must start identical on every rank; user-side differs per rank
+        rng_u = np.random.default_rng(synth.DEFAULT_SEED + 7 + rank)
+        state["P"] = (0.1 * rng_u.standard_normal(state["P"].shape)).astype(np.float32)
+        state["userBias"] = (0.1 * rng_u.standard_normal(state["userBias"].shape)).astype(np.float32)
+    log("rank %d: init state in %.1fs" % (rank, time.perf_counter() - t0))
+
+    t0 = time.perf_counter()
+    inst = capi.Instance(model, k, data.n_users, n_items, data.n_conds, device=local_rank, flags=args.flags)
+    inst.set_hparams(*regs, gm)
+    inst.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
+    inst.set_states(state)
+    info = inst.schedule_info()
+    log("rank %d: schedule + upload in %.1fs: %s" % (rank, time.perf_counter() - t0, info))
+
+    trainer = None
+    if world > 1:
+        from carskit_amd import dist as cdist
+        trainer = cdist.ShardedEpochRunner(inst, dist)
+
+    def step():
+        if trainer is not None:
+            return trainer.epoch(lr)
+        return inst.train_epoch(lr)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        inst.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    gpu_ms = []
+    loss = None
+    for _ in range(args.steps):
+        loss = step()
+        gpu_ms.append(inst.last_epoch_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([float(data.n)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot)
+        total_tuples = float(tot.item())
+    else:
+        total_tuples = float(data.n)
+
+    if rank == 0:
+        bytes_per_update = algorithmic_bytes(model, k, n_dims)
+        kern_ms = float(np.mean(gpu_ms))          # HIP events on the instance stream around one epoch's launches
+        launches = info["levels"]
+        achieved = data.n * bytes_per_update / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "SGD rating-updates/sec, CAMF_CI k=128",
+            "value": total_tuples * args.steps / elapsed,
+            "unit": "rating-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s k=%d, %d users x %d items x %d conditions (%d dims), %d ratings per GPU, "
+                                   "lr 0.02f reg 1e-4f regC 1e-3f, order-exact dependency-level schedule"
+                                   % (args.workload, model, k, data.n_users, n_items, data.n_conds, n_dims, data.n),
+                       "levels_per_epoch": launches, "final_loss": loss,
+                       "parallelism": "1 GPU" if world == 1 else "user-sharded x%d + RCCL all-reduce of item-side deltas" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sgd_level_fast_f32<CAMF_CI,2>", "bytes_per_update": bytes_per_update,
+                         "launches_per_epoch": launches,
+                         "avg_launch_us": kern_ms * 1e3 / launches,
+                         "bytes_per_launch": data.n * bytes_per_update / launches},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(model, k, data, state, gm, regs, lr, args.cpu_tuples)
+            except Exception as e:  # the oracle is only the reported baseline, never the product path
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

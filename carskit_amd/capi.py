@@ -29,7 +29,6 @@ ITEM_SIDE = {"Q", "itemBias", "icBias", "condBias"}
 FLAG_STATE_F64 = 0x1
 FLAG_SCHED_SERIAL = 0x2
 FLAG_STRICT = 0x4
-FLAG_RELAX_COND = 0x8
 FLAG_NO_GRAPH = 0x10
 
 # every symbol include/carskit_mi355x.h declares: (name, restype, argtypes)

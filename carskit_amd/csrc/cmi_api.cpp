@@ -21,7 +21,7 @@ using namespace cmi;
 struct cmi_instance {
     int model = 0, k = 0, n_users = 0, n_items = 0, n_conds = 0, device = 0;
     unsigned flags = 0;
-    bool f64 = false, serial = false, strict = false, relax = false, use_graph = true, fast = false;
+    bool f64 = false, serial = false, strict = false, use_graph = true, fast = false;
     std::string err;
     hipStream_t stream = nullptr;
     void *state[CMI_STATE_COUNT] = {};
@@ -151,14 +151,10 @@ extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_cond
         g_create_err = "cmi_create: device index out of range";
         return CMI_E_INVALID;
     }
-    if ((flags & CMI_FLAG_RELAX_COND) && model != CMI_MODEL_CAMF_C) {
-        g_create_err = "cmi_create: CMI_FLAG_RELAX_COND applies to CAMF_C only";
-        return CMI_E_INVALID;
-    }
-    if (model == CMI_MODEL_CAMF_C && !(flags & (CMI_FLAG_SCHED_SERIAL | CMI_FLAG_RELAX_COND))) {
+    if (model == CMI_MODEL_CAMF_C && !(flags & CMI_FLAG_SCHED_SERIAL)) {
         g_create_err =
-            "cmi_create: CAMF_C updates the shared condBias vector on every tuple, so no order-exact parallel "
-            "schedule exists; pass CMI_FLAG_SCHED_SERIAL (exact) or CMI_FLAG_RELAX_COND (atomics, not order-exact)";
+            "cmi_create: CAMF_C updates the shared condBias vector on every tuple, so its tuples do not commute and "
+            "no order-exact level schedule exists; pass CMI_FLAG_SCHED_SERIAL";
         return CMI_E_UNSUPPORTED;
     }
     cmi_instance *h = new cmi_instance();
@@ -172,7 +168,6 @@ extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_cond
     h->f64 = flags & CMI_FLAG_STATE_F64;
     h->serial = flags & CMI_FLAG_SCHED_SERIAL;
     h->strict = flags & CMI_FLAG_STRICT;
-    h->relax = flags & CMI_FLAG_RELAX_COND;
     h->use_graph = !(flags & CMI_FLAG_NO_GRAPH);
     const char *step = "";
     hipError_t e = hipSuccess;
@@ -328,7 +323,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     h->n = n;
     h->n_ctx = contextual ? n_ctx : 0;
     h->dmax = dmax;
-    LaunchCfg cfg{h->model, h->strict, h->relax};
+    LaunchCfg cfg{h->model, h->strict};
     h->fast = !h->serial && has_fast_path(h->k, dmax, h->f64, cfg);
 
     // schedule
@@ -439,7 +434,7 @@ static SgdArgs<T> make_args(cmi_instance *h) {
 
 // enqueue every level of one epoch + the loss reduction on h->stream
 static hipError_t enqueue_levels(cmi_instance *h) {
-    LaunchCfg cfg{h->model, h->strict, h->relax};
+    LaunchCfg cfg{h->model, h->strict};
     hipError_t e = hipSuccess;
     const int64_t n_levels = (int64_t)h->level_off.size() - 1;
     if (h->serial) {

@@ -13,7 +13,7 @@
 // tuples of a level in parallel yields, for every state element, the same sequence of updates
 // with the same operands as the sequential walk -- bit-identical at equal precision.
 // (CAMF_C's condBias is shared by every tuple, so for CAMF_C no such schedule exists; see
-// CMI_FLAG_SCHED_SERIAL / CMI_FLAG_RELAX_COND.)
+// CMI_FLAG_SCHED_SERIAL.)
 #include "level_schedule.hpp"
 
 #include <algorithm>

@@ -66,8 +66,9 @@ struct Traits {
 
 template <int MODEL, int VPL>
 __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int64_t begin, int count,
-                                                          int64_t slot0, int relax_cond) {
+                                                          int64_t slot0) {
     using M = Traits<MODEL>;
+    static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
     constexpr int K = 64 * VPL;
     __shared__ double s_loss[16];
     const int tid = threadIdx.x;
@@ -92,12 +93,11 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
 #pragma unroll
         for (int v = 0; v < VPL; ++v) q[v] = qrow[v * 16];
 
-        float bu = 0.f, bj = 0.f, bc = 0.f, bic = 0.f, buc = 0.f;
+        float bu = 0.f, bj = 0.f, bic = 0.f, buc = 0.f;
         if (M::has_bu) bu = a.userBias[uu];
         if (M::has_bj) bj = a.itemBias[jj];
         float *pic = nullptr, *puc = nullptr;
         if (cond >= 0) {
-            if (M::has_bc) bc = a.condBias[cond];
             if (M::has_ic) {
                 pic = a.icBias + (size_t)jj * a.n_conds + cond;
                 bic = *pic;
@@ -128,7 +128,6 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
         pred += dot;
         if (MODEL != BIASEDMF) {
             float term = 0.f; // lane d carries the deviation of the tuple's d-th condition
-            if (M::has_bc) term = bc;
             if (M::has_ic && M::has_uc) term = bic + buc;
             else if (M::has_ic) term = bic;
             else if (M::has_uc) term = buc;
@@ -143,11 +142,6 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
         }
         float ctx_loss = 0.f;
         if (cond >= 0) {
-            if (M::has_bc) {
-                // condBias is shared by (nearly) every tuple: only reachable with CMI_FLAG_RELAX_COND
-                if (relax_cond) atomicAdd(a.condBias + cond, lr * (e - regC * bc));
-                ctx_loss = bc; // reference quirk: plain sum, weighted by regB below (CAMF_C.java:110,115)
-            }
             if (M::has_ic) {
                 *pic = bic + lr * (e - regC * bic);
                 ctx_loss += bic * bic;
@@ -178,8 +172,7 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
             double l = (double)e * (double)e;
             if (M::has_bu) l += (double)regB * bu * bu;
             if (M::has_bj) l += (double)regB * bj * bj;
-            if (M::has_bc) l += (double)regB * ctx_sum;
-            else if (MODEL != BIASEDMF) l += (double)regC * ctx_sum;
+            if (MODEL != BIASEDMF) l += (double)regC * ctx_sum;
             gloss = l + (double)reg_loss;
         }
     }
@@ -202,7 +195,7 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
 // reference's order when STRICT (loss += e*e; bias terms in source order; then one add per factor).
 template <typename T, int MODEL, bool STRICT>
 __device__ __forceinline__ double sgd_one(const SgdArgs<T> &a, const HParams &hp, int uu, int jj, T rr,
-                                          const int32_t *conds, int lane, double loss, bool relax_cond) {
+                                          const int32_t *conds, int lane, double loss) {
     using M = Traits<MODEL>;
     const int k = a.k;
     T *pu = a.P + (size_t)uu * k;
@@ -266,10 +259,7 @@ __device__ __forceinline__ double sgd_one(const SgdArgs<T> &a, const HParams &hp
                 T *cell = a.condBias + cond;
                 const T bc = *cell;
                 s_bc += bc;
-                if (lane == 0) {
-                    if (relax_cond) atomicAdd(cell, lr * (e - regC * bc));
-                    else *cell = bc + lr * (e - regC * bc);
-                }
+                if (lane == 0) *cell = bc + lr * (e - regC * bc);
             }
             if (M::has_uc) {
                 T *cell = a.ucBias + (size_t)uu * a.n_conds + cond;
@@ -318,8 +308,7 @@ __device__ __forceinline__ double sgd_one(const SgdArgs<T> &a, const HParams &hp
 }
 
 template <typename T, int MODEL, bool STRICT>
-__global__ __launch_bounds__(256) void sgd_level_generic(SgdArgs<T> a, int64_t begin, int count, int64_t slot0,
-                                                         int relax_cond) {
+__global__ __launch_bounds__(256) void sgd_level_generic(SgdArgs<T> a, int64_t begin, int count, int64_t slot0) {
     __shared__ double s_loss[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + wave;
@@ -327,8 +316,7 @@ __global__ __launch_bounds__(256) void sgd_level_generic(SgdArgs<T> a, int64_t b
     if (g < count) {
         const int64_t t = begin + g;
         const HParams hp = *a.hp;
-        gl = sgd_one<T, MODEL, STRICT>(a, hp, a.su[t], a.sj[t], a.sr[t], a.sconds + t * a.dmax, lane, 0.0,
-                                       relax_cond != 0);
+        gl = sgd_one<T, MODEL, STRICT>(a, hp, a.su[t], a.sj[t], a.sr[t], a.sconds + t * a.dmax, lane, 0.0);
     }
     if (lane == 0) s_loss[wave] = gl;
     __syncthreads();
@@ -355,7 +343,7 @@ __global__ __launch_bounds__(64) void sgd_serial(SgdArgs<T> a, int64_t n, double
         for (int i = 0; i < m; ++i) {
             const int uu = __shfl(mu, i, 64), jj = __shfl(mj, i, 64);
             const T rr = __shfl(mr, i, 64);
-            loss = sgd_one<T, MODEL, STRICT>(a, hp, uu, jj, rr, a.sconds + (base + i) * a.dmax, lane, loss, false);
+            loss = sgd_one<T, MODEL, STRICT>(a, hp, uu, jj, rr, a.sconds + (base + i) * a.dmax, lane, loss);
         }
     }
     if (lane == 0) loss_out[0] = loss * 0.5;
@@ -486,11 +474,10 @@ template <int MODEL>
 static hipError_t launch_fast_model(const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,
                                     int64_t slot0, hipStream_t s) {
     const dim3 grid(level_blocks_f32_fast(a.k, count)), block(256);
-    const int relax = cfg.relax_cond ? 1 : 0;
     switch (a.k) {
-    case 64: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 1>), grid, block, 0, s, a, begin, count, slot0, relax); break;
-    case 128: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 2>), grid, block, 0, s, a, begin, count, slot0, relax); break;
-    case 256: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 4>), grid, block, 0, s, a, begin, count, slot0, relax); break;
+    case 64: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 1>), grid, block, 0, s, a, begin, count, slot0); break;
+    case 128: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 2>), grid, block, 0, s, a, begin, count, slot0); break;
+    case 256: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 4>), grid, block, 0, s, a, begin, count, slot0); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -501,7 +488,6 @@ hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, 
     if (count <= 0) return hipSuccess;
     switch (cfg.model) {
     case BIASEDMF: return launch_fast_model<BIASEDMF>(a, cfg, begin, count, slot0, s);
-    case CAMF_C: return launch_fast_model<CAMF_C>(a, cfg, begin, count, slot0, s);
     case CAMF_CI: return launch_fast_model<CAMF_CI>(a, cfg, begin, count, slot0, s);
     case CAMF_CU: return launch_fast_model<CAMF_CU>(a, cfg, begin, count, slot0, s);
     case CAMF_CUCI: return launch_fast_model<CAMF_CUCI>(a, cfg, begin, count, slot0, s);
@@ -513,11 +499,10 @@ template <typename T, int MODEL>
 static hipError_t launch_generic_model(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t begin, int count,
                                        int64_t slot0, hipStream_t s) {
     const dim3 grid(level_blocks_generic(count)), block(256);
-    const int relax = cfg.relax_cond ? 1 : 0;
     if (cfg.strict)
-        hipLaunchKernelGGL((sgd_level_generic<T, MODEL, true>), grid, block, 0, s, a, begin, count, slot0, relax);
+        hipLaunchKernelGGL((sgd_level_generic<T, MODEL, true>), grid, block, 0, s, a, begin, count, slot0);
     else
-        hipLaunchKernelGGL((sgd_level_generic<T, MODEL, false>), grid, block, 0, s, a, begin, count, slot0, relax);
+        hipLaunchKernelGGL((sgd_level_generic<T, MODEL, false>), grid, block, 0, s, a, begin, count, slot0);
     return hipGetLastError();
 }
 

@@ -32,8 +32,7 @@ struct SgdArgs {
 
 struct LaunchCfg {
     int model;
-    bool strict;     // left-to-right dot (DenseMatrix.rowMult order) + reference loss order
-    bool relax_cond; // CAMF_C: condBias through atomics
+    bool strict; // left-to-right dot (DenseMatrix.rowMult order) + reference loss order
 };
 
 // number of workgroups a level of `count` tuples occupies (= loss_part slots it writes)

@@ -127,6 +127,93 @@ def generate(n_users, n_items, n_dims, conds_per_dim, n_ratings, seed=DEFAULT_SE
                       {"seed": seed, "n_ui": int(n_ui), "requested": int(n_ratings), "item_zipf": item_zipf})
 
 
+def _mix64(x, key):
+    """SplitMix64-style finaliser on uint64 arrays (wrap-around arithmetic)."""
+    x = (x + np.uint64(key)) * np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(30)
+    x *= np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+    return x
+
+
+def _distinct_indices(n, domain, seed):
+    """n distinct pseudo-random integers in [0, domain): a 4-round Feistel permutation of 0..n-1 over the
+    enclosing power-of-four domain, cycle-walked back into range (sampling without replacement, O(n))."""
+    bits = max(2, int(domain - 1).bit_length())
+    bits += bits & 1
+    hb = np.uint64(bits // 2)
+    mask = np.uint64((1 << (bits // 2)) - 1)
+    keys = [int(k) for k in np.random.default_rng(seed).integers(1, 1 << 62, 4)]
+
+    def perm(x):
+        left, right = x >> hb, x & mask
+        for k in keys:
+            left, right = right, left ^ (_mix64(right, k) & mask)
+        return (left << hb) | right
+
+    with np.errstate(over="ignore"):
+        v = perm(np.arange(n, dtype=np.uint64))
+        bad = np.flatnonzero(v >= np.uint64(domain))
+        while len(bad):
+            v[bad] = perm(v[bad])
+            bad = bad[v[bad] >= np.uint64(domain)]
+    return v.astype(np.int64)
+
+
+def _first_seen_dense(raw, size):
+    """First-seen inner ids for keys drawn from a small dense range [0, size): O(n) scatter instead of a sort."""
+    n = len(raw)
+    first = np.full(size, n, dtype=np.int64)
+    first[raw[::-1]] = np.arange(n - 1, -1, -1, dtype=np.int64)  # repeated index: last write wins = first sight
+    seen = np.flatnonzero(first < n)
+    order = seen[np.argsort(first[seen], kind="stable")]
+    rank = np.full(size, -1, dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    return rank[raw], len(order), first[order]
+
+
+def generate_fast(n_users, n_items, n_dims, conds_per_dim, n_ratings, seed=DEFAULT_SEED, latent_k=8, noise=0.5):
+    """Large-scale variant of generate() for uniform users/items: the (user, item) pairs are sampled WITHOUT
+    replacement (distributionally what "sample, then drop duplicates" gives), so no (u,i,ctx) duplicate can
+    occur, every pair's id is its stream position and the CRS order IS the stream order -- no 50M-element sorts.
+    Same output contract as generate()."""
+    n = int(n_ratings)
+    if n > n_users * n_items:
+        raise ValueError("more ratings than (user, item) pairs")
+    rng = np.random.default_rng(seed)
+    pair = _distinct_indices(n, n_users * n_items, seed + 17)
+    raw_u, raw_i = pair // n_items, pair % n_items
+    del pair
+    n_ckeys = max(1, conds_per_dim ** n_dims)
+    ckey = rng.integers(0, n_ckeys, n, dtype=np.int64)
+
+    zu = rng.standard_normal((n_users, latent_k)).astype(np.float32)
+    zi = rng.standard_normal((n_items, latent_k)).astype(np.float32)
+    zc = rng.standard_normal(n_ckeys).astype(np.float32) * 0.3
+    r = np.empty(n, dtype=np.float64)
+    step = 1 << 22
+    inv = np.float32(1.0 / np.sqrt(latent_k))
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        dot = np.einsum("nk,nk->n", zu[raw_u[s:e]], zi[raw_i[s:e]]) * inv
+        val = 3.0 + dot + zc[ckey[s:e]] + noise * rng.standard_normal(e - s, dtype=np.float32)
+        r[s:e] = np.clip(np.rint(val), 1, 5)
+    del zu, zi
+
+    u, nu, _ = _first_seen_dense(raw_u, n_users)
+    i, ni, _ = _first_seen_dense(raw_i, n_items)
+    ctx, n_ctx, ctx_first = _first_seen_dense(ckey, n_ckeys)
+    ck = ckey[ctx_first]
+    conds = np.zeros((n_ctx, n_dims), dtype=np.int32)
+    for d in range(n_dims - 1, -1, -1):
+        conds[:, d] = d * conds_per_dim + (ck % conds_per_dim)
+        ck = ck // conds_per_dim
+    ctx_ptr = (np.arange(n_ctx + 1, dtype=np.int64) * n_dims).astype(np.int32)
+    return RatingData(int(nu), int(ni), int(n_dims * conds_per_dim), int(n_dims), u.astype(np.int32),
+                      i.astype(np.int32), ctx.astype(np.int32), r, ctx_ptr, conds.reshape(-1), 1.0, 5.0,
+                      {"seed": seed, "n_ui": n, "requested": n, "item_zipf": None, "generator": "fast"})
+
+
 def split(data, test_ratio=0.2, seed=DEFAULT_SEED + 1):
     """Seeded 80/20 split (NOT the reference's RNG); both parts keep CRS order and the id spaces."""
     rng = np.random.default_rng(seed)

@@ -60,7 +60,8 @@ extern "C" {
 #define CMI_DTYPE_F32 0
 #define CMI_DTYPE_F64 1
 
-/* cmi_create flags */
+/* cmi_create flags.  CAMF_C updates the condBias vector shared by every tuple, so its tuples do not
+ * commute and it requires CMI_FLAG_SCHED_SERIAL (cmi_create returns CMI_E_UNSUPPORTED otherwise). */
 #define CMI_FLAG_STATE_F64 0x1u  /* keep the model in fp64 on the GPU (reference precision); default fp32 */
 #define CMI_FLAG_SCHED_SERIAL 0x2u /* one wavefront walks the tuples in the reference's CRS order (exact for
                                       every model incl. CAMF_C; slow).  Default: dependency-level schedule --
@@ -70,8 +71,6 @@ extern "C" {
                                       order) and, under SCHED_SERIAL, the reference's running-sum order for `loss`:
                                       with STATE_F64 the model (and under SERIAL the loss) is bit-identical to the
                                       Java arithmetic */
-#define CMI_FLAG_RELAX_COND 0x8u /* CAMF_C only, level schedule: condBias updates of one level are applied with
-                                      atomics instead of in CRS order (NOT order-exact; report the RMSE band) */
 #define CMI_FLAG_NO_GRAPH 0x10u  /* launch the per-level kernels eagerly instead of replaying a hipGraph */
 
 typedef struct cmi_instance *cmi_handle;

@@ -15,8 +15,7 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
-F64, SERIAL, STRICT, RELAX, NOGRAPH = (capi.FLAG_STATE_F64, capi.FLAG_SCHED_SERIAL, capi.FLAG_STRICT,
-                                       capi.FLAG_RELAX_COND, capi.FLAG_NO_GRAPH)
+F64, SERIAL, STRICT, NOGRAPH = (capi.FLAG_STATE_F64, capi.FLAG_SCHED_SERIAL, capi.FLAG_STRICT, capi.FLAG_NO_GRAPH)
 
 
 def make_pair(model, data, k, flags, seed=5, regs=None):
@@ -114,9 +113,9 @@ def test_level_f32_rmse_within_1e5(model, k):
     assert abs(ot["RMSE"] - gt["RMSE"]) <= 1e-5
 
 
-def test_camf_c_serial_f32_and_relaxed_band():
-    """CAMF_C (config C2 shape: k=64): the serial schedule is order-exact; the relaxed level schedule is
-    NOT order-exact and is only held to an RMSE band, which this test prints."""
+def test_camf_c_serial_f32():
+    """CAMF_C (config C2 shape: k=64, fp32): condBias is shared by every tuple, so only the serial
+    schedule is order-exact."""
     data = util.small_data(n_users=500, n_items=200, n_dims=4, conds_per_dim=3, n=12000, seed=25)
     train, test = synth.split(data, 0.2)
     orc, inst = make_pair("CAMF_C", train, 64, SERIAL)
@@ -126,11 +125,6 @@ def test_camf_c_serial_f32_and_relaxed_band():
     oe = orc.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
     ge = inst.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
     assert abs(oe["RMSE"] - ge["RMSE"]) <= 1e-5 and abs(oe["MAE"] - ge["MAE"]) <= 1e-5
-    _, rel = make_pair("CAMF_C", train, 64, RELAX)
-    rel.train(15, util.LR, bold_driver=True)
-    re_ = rel.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
-    print("CAMF_C relaxed-condBias band: dRMSE=%.3e dMAE=%.3e" % (re_["RMSE"] - oe["RMSE"], re_["MAE"] - oe["MAE"]))
-    assert abs(re_["RMSE"] - oe["RMSE"]) <= 5e-2
 
 
 def test_predict_batch_and_bounds():
