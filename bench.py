@@ -42,6 +42,17 @@ def algorithmic_bytes(model, k, d):
     return 16 + 4 * d + 16 * k + 8 * s + 8 * d * t
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/<round>_<workload>_pmc.json, written
+    by tools/pmc_summary.py from FETCH_SIZE/WRITE_SIZE runs of this same command); None if not collected."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % workload)))
+    if not cands:
+        return None, None
+    d = json.load(open(cands[-1]))
+    return d.get("hbm_bytes_per_launch"), os.path.relpath(cands[-1], ROOT)
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
@@ -157,6 +168,7 @@ def main():
         kern_ms = float(np.mean(gpu_ms))          # HIP events on the instance stream around one epoch's launches
         launches = info["levels"]
         achieved = data.n * bytes_per_update / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(args.workload)
         out = {
             "metric": "SGD rating-updates/sec, CAMF_CI k=128",
             "value": total_tuples * args.steps / elapsed,
@@ -171,7 +183,7 @@ def main():
                        "levels_per_epoch": launches, "final_loss": loss,
                        "parallelism": "1 GPU" if world == 1 else "user-sharded x%d + RCCL all-reduce of item-side deltas" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "sgd_level_fast_f32<CAMF_CI,2>", "bytes_per_update": bytes_per_update,
                          "launches_per_epoch": launches,
                          "avg_launch_us": kern_ms * 1e3 / launches,

@@ -1,0 +1,144 @@
+"""Multi-GPU host layer: user-sharded data-parallel epochs with an item-side delta exchange.
+
+The reference path is one sequential loop (no collective exists to translate).  The algorithm shards
+naturally BY USER: P[u], userBias[u], ucBias[u,*] are then touched by exactly one rank, while the
+item-side containers (Q, itemBias, icBias) are replicated.  One epoch =
+
+    every rank:  local SGD epoch over its own tuples (order-exact level schedule, cmi_train_epoch_async)
+    exchange:    delta_r = itemside_r - itemside_at_epoch_start ;  all-reduce(sum) ;
+                 itemside = itemside_at_epoch_start + sum_r delta_r          (one flat bucket, RCCL over xGMI)
+    loss:        all-reduce(sum) of the per-rank epoch losses (feeds the host's bold-driver / isConverged)
+
+With world_size == 1 this is exactly the single-GPU path.  With more ranks it is NOT the reference's
+sequential semantics (W local SGD streams merged per epoch), so multi-GPU accuracy is reported as an RMSE
+band against the 1-GPU result; the 1-GPU order-exact path stays the parity anchor.
+
+The runner is written against a tiny engine protocol so the exchange algebra can be tested on CPU with
+torch.distributed's gloo backend (tests/test_dist_gloo.py drives it with the CPU oracle as the engine);
+the product engine is GpuEngine over a capi.Instance and there is no CPU engine in this package.
+"""
+import numpy as np
+
+from . import capi
+
+ITEM_SIDE = {
+    "BiasedMF": ("Q", "itemBias"),
+    "CAMF_CI": ("Q", "icBias"),
+    "CAMF_CU": ("Q", "itemBias"),
+    "CAMF_CUCI": ("Q", "icBias"),
+    # CAMF_C also shares condBias; it is serial-only on one GPU and is not sharded
+}
+
+
+class _DevArray:
+    """Expose a raw device pointer through __cuda_array_interface__ so torch can alias it (zero copy)."""
+
+    def __init__(self, ptr, count, np_dtype):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": np.dtype(np_dtype).str,
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class GpuEngine:
+    """Engine over one capi.Instance: the item-side containers are aliased as torch tensors in place."""
+
+    def __init__(self, inst, device_index):
+        import torch
+        self.inst = inst
+        self.torch = torch
+        self.device = torch.device("cuda", device_index)
+        self.item = {}
+        for name in ITEM_SIDE[inst.model]:
+            ptr, cnt, dt = inst.state_device_ptr(name)
+            self.item[name] = torch.as_tensor(_DevArray(ptr, cnt, dt), device=self.device)
+
+    def epoch_local(self, lr):
+        self.inst.train_epoch_async(lr)
+        loss = self.inst.last_loss()          # synchronises the instance stream
+        return loss
+
+    def item_state(self):
+        return self.item
+
+    def before_exchange(self):
+        self.inst.synchronize()               # kernels of the epoch are done before torch touches the state
+
+    def after_exchange(self):
+        self.torch.cuda.synchronize(self.device)  # exchange finished before the next epoch's kernels start
+
+
+class ShardedEpochRunner:
+    def __init__(self, engine_or_inst, dist, device_index=None, group=None, always_exchange=False):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.group = group
+        if isinstance(engine_or_inst, capi.Instance):
+            if device_index is None:
+                device_index = torch.cuda.current_device()
+            engine_or_inst = GpuEngine(engine_or_inst, device_index)
+        self.engine = engine_or_inst
+        item = self.engine.item_state()
+        self.names = list(item)
+        total = sum(t.numel() for t in item.values())
+        any_t = next(iter(item.values()))
+        self.bucket = torch.empty(total, dtype=any_t.dtype, device=any_t.device)
+        self.start = {n: t.clone() for n, t in item.items()}   # item-side state at epoch start
+        self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+        self.always_exchange = always_exchange and dist is not None and dist.is_initialized()
+
+    def epoch(self, lr):
+        """One global epoch; returns the global loss (sum over ranks)."""
+        torch, dist = self.torch, self.dist
+        loss = self.engine.epoch_local(lr)
+        if self.world == 1 and not self.always_exchange:
+            return loss
+        if hasattr(self.engine, "before_exchange"):
+            self.engine.before_exchange()
+        item = self.engine.item_state()
+        off = 0
+        for n in self.names:
+            x = item[n].view(-1)
+            torch.sub(x, self.start[n].view(-1), out=self.bucket[off:off + x.numel()])
+            off += x.numel()
+        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for n in self.names:
+            x = item[n].view(-1)
+            torch.add(self.start[n].view(-1), self.bucket[off:off + x.numel()], out=x)
+            self.start[n].view(-1).copy_(x)
+            off += x.numel()
+        lt = torch.tensor([loss], dtype=torch.float64, device=self.bucket.device)
+        dist.all_reduce(lt, op=dist.ReduceOp.SUM, group=self.group)
+        if hasattr(self.engine, "after_exchange"):
+            self.engine.after_exchange()
+        return float(lt.item())
+
+
+def shard_by_user(data, rank, world):
+    """Tuples of the users owned by `rank`: contiguous user-id ranges cut so that every rank gets about the same
+    number of ratings; CRS order is kept; user ids are re-based to the shard (local id = global id - start).
+    Returns (RatingData shard, (user_start, user_end))."""
+    from .synth import RatingData
+    deg = np.bincount(data.u, minlength=data.n_users).astype(np.int64)
+    cum = np.concatenate([[0], np.cumsum(deg)])
+    if data.n_users < world:
+        raise ValueError("fewer users than ranks")
+    cuts = [0]
+    for r in range(1, world):
+        c = int(np.searchsorted(cum, data.n * r / world, side="left"))
+        cuts.append(min(max(c, cuts[-1] + 1), data.n_users - (world - r)))  # >= 1 user per rank
+    cuts.append(data.n_users)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    idx = np.flatnonzero((data.u >= lo) & (data.u < hi))
+    return (RatingData(hi - lo, data.n_items, data.n_conds, data.n_dims, (data.u[idx] - lo).astype(np.int32),
+                       data.j[idx], data.ctx[idx], data.r[idx], data.ctx_ptr, data.ctx_conds, data.min_rate,
+                       data.max_rate, dict(data.meta)), (lo, hi))
+
+
+def global_mean(dist, r, device=None):
+    """SparseMatrix.getGlobalAvg over the union of all ranks' training tuples (sum / #non-zero)."""
+    import torch
+    v = torch.tensor([float(np.sum(r)), float(np.count_nonzero(r))], dtype=torch.float64, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(v)
+    return float(v[0].item() / v[1].item())

@@ -219,3 +219,40 @@ def test_level_order_is_free():
     for other in outs[1:]:
         for name in outs[0]:
             assert np.array_equal(outs[0][name], other[name]), name
+
+
+def test_dist_gpu_engine_aliases_device_state_and_exchange_is_identity_at_world1():
+    """carskit_amd.dist on a real GPU: the item-side containers are aliased as torch tensors through
+    cmi_state_device_ptr (zero copy), and with one rank the RCCL exchange is the identity."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as tdist
+    from carskit_amd import dist as cdist
+    data = util.small_data(n_users=400, n_items=50, n=5000, seed=33)
+    _, a = make_pair("CAMF_CI", data, 128, 0)
+    _, b = make_pair("CAMF_CI", data, 128, 0)
+    eng = cdist.GpuEngine(a, 0)
+    q = eng.item["Q"]
+    assert q.is_cuda and q.numel() == data.n_items * 128
+    assert np.array_equal(q.cpu().numpy().reshape(data.n_items, 128), a.get_state("Q", np.float32))
+    q[:128] += 1.0                                          # torch writes land in the library's buffer
+    torch.cuda.synchronize()
+    assert np.array_equal(a.get_state("Q", np.float32)[0], b.get_state("Q", np.float32)[0] + 1.0)
+    q[:128] -= 1.0
+    torch.cuda.synchronize()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        runner = cdist.ShardedEpochRunner(a, tdist, device_index=0, always_exchange=True)
+        for _ in range(3):
+            la, lb = runner.epoch(util.LR), b.train_epoch(util.LR)
+            assert la == lb
+        for name in ("P", "Q", "userBias", "icBias"):
+            assert np.array_equal(a.get_state(name, np.float32), b.get_state(name, np.float32)), name
+    finally:
+        tdist.destroy_process_group()
