@@ -30,6 +30,7 @@ FLAG_STATE_F64 = 0x1
 FLAG_SCHED_SERIAL = 0x2
 FLAG_STRICT = 0x4
 FLAG_NO_GRAPH = 0x10
+FLAG_SCHED_FLOW = 0x20
 
 # every symbol include/carskit_mi355x.h declares: (name, restype, argtypes)
 _vp, _i64, _i32, _dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
@@ -56,6 +57,7 @@ SYMBOLS = [
     ("cmi_schedule_info", C.c_int, [_vp, C.POINTER(_i64)]),
     ("cmi_last_epoch_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("cmi_level_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, _vp, _vp, _i64, C.POINTER(_i64)]),
+    ("cmi_flow_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
 ]
 
 _LIB = None
@@ -106,6 +108,23 @@ def level_schedule(u, j, n_users, n_items, order=0):
     if rc != OK:
         raise CmiError(rc, "cmi_level_schedule")
     return perm, off
+
+
+def flow_schedule(u, j, n_users, n_items):
+    """Host-only: (perm with -1 padding, seq_u, seq_j) of the dataflow schedule (see cmi_flow_schedule)."""
+    u = np.ascontiguousarray(u, dtype=np.int32)
+    j = np.ascontiguousarray(j, dtype=np.int32)
+    ns = _i64()
+    rc = lib().cmi_flow_schedule(len(u), _p(u), _p(j), n_users, n_items, None, None, None, 0, C.byref(ns))
+    if rc != OK:
+        raise CmiError(rc, "cmi_flow_schedule")
+    perm = np.empty(ns.value, dtype=np.int32)
+    su, sj = np.empty(ns.value, dtype=np.uint32), np.empty(ns.value, dtype=np.uint32)
+    rc = lib().cmi_flow_schedule(len(u), _p(u), _p(j), n_users, n_items, _p(perm), _p(su), _p(sj), ns.value,
+                                 C.byref(ns))
+    if rc != OK:
+        raise CmiError(rc, "cmi_flow_schedule")
+    return perm, su, sj
 
 
 class Instance:
@@ -211,9 +230,12 @@ class Instance:
         return ms.value
 
     def schedule_info(self):
-        info = (_i64 * 6)()
+        info = (_i64 * 8)()
         self._chk(self.L.cmi_schedule_info(self.h, info))
-        return dict(zip(("levels", "max_level", "tuples", "dmax", "state_bytes", "tuple_bytes"), list(info)))
+        d = dict(zip(("levels", "max_level", "tuples", "dmax", "state_bytes", "tuple_bytes", "kind", "flow_blocks"),
+                     list(info)))
+        d["kind"] = ("level", "serial", "flow")[d["kind"]]
+        return d
 
     def stream(self):
         s = _vp()

@@ -21,7 +21,7 @@ using namespace cmi;
 struct cmi_instance {
     int model = 0, k = 0, n_users = 0, n_items = 0, n_conds = 0, device = 0;
     unsigned flags = 0;
-    bool f64 = false, serial = false, strict = false, use_graph = true, fast = false;
+    bool f64 = false, serial = false, strict = false, use_graph = true, fast = false, want_flow = false, flow = false;
     std::string err;
     hipStream_t stream = nullptr;
     void *state[CMI_STATE_COUNT] = {};
@@ -32,9 +32,13 @@ struct cmi_instance {
     int32_t n_ctx = 0;
     int32_t *d_su = nullptr, *d_sj = nullptr, *d_sconds = nullptr, *d_ctx_ptr = nullptr, *d_ctx_conds = nullptr;
     void *d_sr = nullptr;
+    uint32_t *d_seq_u = nullptr, *d_seq_j = nullptr, *d_ver_u = nullptr, *d_ver_j = nullptr;
+    int32_t *d_flow_err = nullptr;
+    int64_t n_chunks = 0;
+    int flow_blocks = 0;
     int64_t ctx_nnz = 0;
     std::vector<int64_t> level_off, slot_off;
-    int64_t n_slots = 0, max_level = 0, tuple_bytes = 0;
+    int64_t n_slots = 0, max_level = 0, tuple_bytes = 0, sched_levels = 0;
     double *d_loss_part = nullptr, *d_scratch = nullptr, *d_loss = nullptr;
     HParams *d_hp = nullptr;
     HParams hp{0, 0, 0, 0, 0, 0};
@@ -104,10 +108,14 @@ static void free_ratings(cmi_instance *h) {
         hipGraphExecDestroy(h->graph_exec);
         h->graph_exec = nullptr;
     }
-    void *ptrs[] = {h->d_su, h->d_sj, h->d_sconds, h->d_ctx_ptr, h->d_ctx_conds, h->d_sr, h->d_loss_part};
+    void *ptrs[] = {h->d_su, h->d_sj, h->d_sconds, h->d_ctx_ptr, h->d_ctx_conds, h->d_sr, h->d_loss_part,
+                    h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err};
     for (void *p : ptrs)
         if (p) hipFree(p);
     h->d_su = h->d_sj = h->d_sconds = h->d_ctx_ptr = h->d_ctx_conds = nullptr;
+    h->d_seq_u = h->d_seq_j = h->d_ver_u = h->d_ver_j = nullptr;
+    h->d_flow_err = nullptr;
+    h->flow = false;
     h->d_sr = nullptr;
     h->d_loss_part = nullptr;
     h->have_ratings = false;
@@ -169,6 +177,7 @@ extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_cond
     h->serial = flags & CMI_FLAG_SCHED_SERIAL;
     h->strict = flags & CMI_FLAG_STRICT;
     h->use_graph = !(flags & CMI_FLAG_NO_GRAPH);
+    h->want_flow = flags & CMI_FLAG_SCHED_FLOW;
     const char *step = "";
     hipError_t e = hipSuccess;
 #define TRY(x)                                                                                          \
@@ -328,44 +337,81 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
 
     // schedule
     LevelSchedule sch;
-    if (h->serial) {
-        sch.level_off = {0, n};
-        sch.max_level = n;
-    } else {
-        int order = LEVEL_ORDER_CRS;
-        if (const char *env = getenv("CMI_LEVEL_ORDER")) {
-            if (!strcmp(env, "item")) order = LEVEL_ORDER_ITEM;
-            else if (!strcmp(env, "user")) order = LEVEL_ORDER_USER;
+    FlowSchedule fsch;
+    h->flow = false;
+    h->flow_blocks = 0;
+    if (h->want_flow && h->fast && n > 0) {
+        h->flow_blocks = flow_grid_blocks(h->device, h->k);
+        if (h->flow_blocks > 0) {
+            if (!build_flow_schedule(n, u, j, h->n_users, h->n_items, fsch))
+                CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: dataflow schedule construction failed");
+            h->flow = true;
         }
-        if (!build_level_schedule(n, u, j, h->n_users, h->n_items, order, sch))
-            CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: schedule construction failed");
     }
-    h->level_off = sch.level_off;
-    h->max_level = sch.max_level;
-    const int64_t n_levels = (int64_t)h->level_off.size() - 1;
-    h->slot_off.assign((size_t)n_levels + 1, 0);
-    for (int64_t l = 0; l < n_levels; ++l) {
-        const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
-        const int blocks = h->serial ? 0 : (h->fast ? level_blocks_f32_fast(h->k, cnt) : level_blocks_generic(cnt));
-        h->slot_off[(size_t)l + 1] = h->slot_off[(size_t)l] + blocks;
+    if (h->flow) {
+        h->level_off = {0, (int64_t)fsch.perm.size()};
+        h->max_level = fsch.max_level;
+        h->n_chunks = fsch.n_chunks();
+        h->slot_off = {0, (int64_t)h->flow_blocks * 4};
+        h->n_slots = (int64_t)h->flow_blocks * 4;
+        h->sched_levels = fsch.n_levels;
+    } else {
+        if (h->serial) {
+            sch.level_off = {0, n};
+            sch.max_level = n;
+        } else {
+            int order = LEVEL_ORDER_CRS;
+            if (const char *env = getenv("CMI_LEVEL_ORDER")) {
+                if (!strcmp(env, "item")) order = LEVEL_ORDER_ITEM;
+                else if (!strcmp(env, "user")) order = LEVEL_ORDER_USER;
+            }
+            if (!build_level_schedule(n, u, j, h->n_users, h->n_items, order, sch))
+                CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: schedule construction failed");
+        }
+        if (const char *env = getenv("CMI_DEBUG_MERGE_LEVELS")) { // TIMING EXPERIMENT ONLY: wrong results
+            const int m = atoi(env);
+            if (m > 1) {
+                std::vector<int64_t> lo;
+                for (size_t i = 0; i + 1 < sch.level_off.size(); i += (size_t)m) lo.push_back(sch.level_off[i]);
+                lo.push_back(sch.level_off.back());
+                sch.level_off = lo;
+            }
+        }
+        h->level_off = sch.level_off;
+        h->max_level = sch.max_level;
+        const int64_t n_levels = (int64_t)h->level_off.size() - 1;
+        h->sched_levels = n_levels;
+        h->slot_off.assign((size_t)n_levels + 1, 0);
+        for (int64_t l = 0; l < n_levels; ++l) {
+            const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
+            const int blocks = h->serial ? 0 : (h->fast ? level_blocks_f32_fast(h->k, cnt) : level_blocks_generic(cnt));
+            h->slot_off[(size_t)l + 1] = h->slot_off[(size_t)l] + blocks;
+        }
+        h->n_slots = h->slot_off[(size_t)n_levels];
     }
-    h->n_slots = h->slot_off[(size_t)n_levels];
 
     // tuple stream in schedule order, conditions pre-expanded to [n x dmax] (-1 padded) so the kernels
-    // need no ctx -> condition-list indirection
-    std::vector<int32_t> su((size_t)n), sj((size_t)n), sconds((size_t)n * (size_t)dmax);
+    // need no ctx -> condition-list indirection.  The dataflow schedule has padding slots (user id -1).
+    const int64_t ns = h->flow ? (int64_t)fsch.perm.size() : n;
+    std::vector<int32_t> su((size_t)ns), sj((size_t)ns), sconds((size_t)ns * (size_t)dmax);
     std::vector<float> sr32;
     std::vector<double> sr64;
-    if (h->f64) sr64.resize((size_t)n);
-    else sr32.resize((size_t)n);
-    for (int64_t s = 0; s < n; ++s) {
-        const int64_t t = h->serial ? s : sch.perm[(size_t)s];
+    if (h->f64) sr64.resize((size_t)ns);
+    else sr32.resize((size_t)ns);
+    for (int64_t s = 0; s < ns; ++s) {
+        const int64_t t = h->flow ? fsch.perm[(size_t)s] : (h->serial ? s : sch.perm[(size_t)s]);
+        int32_t *row = dmax > 0 ? &sconds[(size_t)s * (size_t)dmax] : nullptr;
+        if (t < 0) { // padding slot
+            su[(size_t)s] = -1;
+            sj[(size_t)s] = 0;
+            for (int d = 0; d < dmax; ++d) row[d] = -1;
+            continue;
+        }
         su[(size_t)s] = u[t];
         sj[(size_t)s] = j[t];
         if (h->f64) sr64[(size_t)s] = r[t];
         else sr32[(size_t)s] = (float)r[t];
         if (dmax > 0) {
-            int32_t *row = &sconds[(size_t)s * (size_t)dmax];
             const int32_t b = ctx_ptr[ctx[t]], e = ctx_ptr[ctx[t] + 1];
             int d = 0;
             for (int32_t q = b; q < e; ++q) row[d++] = ctx_conds[q];
@@ -376,6 +422,14 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     if (e == hipSuccess) e = upload((void **)&h->d_sj, sj, h->stream);
     if (e == hipSuccess) e = upload((void **)&h->d_sconds, sconds, h->stream);
     if (e == hipSuccess) e = h->f64 ? upload(&h->d_sr, sr64, h->stream) : upload(&h->d_sr, sr32, h->stream);
+    if (e == hipSuccess && h->flow) {
+        e = upload((void **)&h->d_seq_u, fsch.seq_u, h->stream);
+        if (e == hipSuccess) e = upload((void **)&h->d_seq_j, fsch.seq_j, h->stream);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_ver_u, (size_t)h->n_users * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_ver_j, (size_t)h->n_items * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_flow_err, 4);
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_flow_err, 0, 4, h->stream);
+    }
     if (e == hipSuccess && contextual) {
         std::vector<int32_t> cp(ctx_ptr, ctx_ptr + n_ctx + 1), cc(ctx_conds, ctx_conds + ctx_ptr[n_ctx]);
         h->ctx_nnz = (int64_t)cc.size();
@@ -389,15 +443,16 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         free_ratings(h);
         CMI_FAIL(h, CMI_E_HIP, "set_ratings: upload failed: %s", hipGetErrorString(e));
     }
-    h->tuple_bytes = n * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax);
+    h->n = n;
+    h->tuple_bytes = ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + (h->flow ? 8 : 0));
     h->have_ratings = true;
     return CMI_OK;
 }
 
-extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[6]) {
+extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[8]) {
     if (!h || !info) return CMI_E_INVALID;
     if (!h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "schedule_info: call cmi_set_ratings first");
-    info[0] = (int64_t)h->level_off.size() - 1;
+    info[0] = h->sched_levels;
     info[1] = h->max_level;
     info[2] = h->n;
     info[3] = h->dmax;
@@ -405,6 +460,8 @@ extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[6]) {
     for (int w = 0; w < CMI_STATE_COUNT; ++w) sb += h->state_count[w] * (int64_t)esize(h);
     info[4] = sb;
     info[5] = h->tuple_bytes;
+    info[6] = h->flow ? 2 : (h->serial ? 1 : 0);
+    info[7] = h->flow ? h->flow_blocks : 0;
     return CMI_OK;
 }
 
@@ -429,6 +486,8 @@ static SgdArgs<T> make_args(cmi_instance *h) {
     a.k = h->k;
     a.n_conds = h->n_conds;
     a.dmax = h->dmax;
+    a.store_mode = 0;
+    if (const char *env = getenv("CMI_LEVEL_STORE")) a.store_mode = atoi(env);
     return a;
 }
 
@@ -440,6 +499,15 @@ static hipError_t enqueue_levels(cmi_instance *h) {
     if (h->serial) {
         if (h->f64) return launch_serial<double>(make_args<double>(h), cfg, h->n, h->d_loss, h->stream);
         return launch_serial<float>(make_args<float>(h), cfg, h->n, h->d_loss, h->stream);
+    }
+    if (h->flow) {
+        FlowArgs fa{h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->n_chunks, 0};
+        if (const char *env = getenv("CMI_FLOW_DEBUG")) fa.debug = atoi(env);
+        e = hipMemsetAsync(h->d_ver_u, 0, (size_t)h->n_users * 4, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_ver_j, 0, (size_t)h->n_items * 4, h->stream);
+        if (e == hipSuccess) e = launch_flow_f32(make_args<float>(h), fa, cfg, h->flow_blocks, h->stream);
+        if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);
+        return e;
     }
     if (h->f64) {
         const SgdArgs<double> a = make_args<double>(h);
@@ -470,7 +538,7 @@ static int enqueue_epoch(cmi_instance *h, double lrate) {
         h->epoch_timed = false;
         return CMI_OK;
     }
-    const bool graph = h->use_graph && !h->serial;
+    const bool graph = h->use_graph && !h->serial && !h->flow;
     if (graph && !h->graph_exec) {
         hipGraph_t g = nullptr;
         CMI_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -504,7 +572,10 @@ extern "C" int cmi_last_loss(cmi_handle h, double *loss_out) {
     if (!h || !loss_out) return CMI_E_INVALID;
     CMI_HIP(h, hipSetDevice(h->device));
     CMI_HIP(h, hipMemcpyAsync(h->h_loss, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    int32_t flow_err = 0;
+    if (h->flow) CMI_HIP(h, hipMemcpyAsync(&flow_err, h->d_flow_err, 4, hipMemcpyDeviceToHost, h->stream));
     CMI_HIP(h, hipStreamSynchronize(h->stream));
+    if (flow_err) CMI_FAIL(h, CMI_E_HIP, "dataflow epoch stalled: a tuple waited past its bound for a predecessor (model state is invalid)");
     h->last_loss = *h->h_loss;
     *loss_out = h->last_loss;
     return CMI_OK;
@@ -701,5 +772,23 @@ extern "C" int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j,
     }
     if (perm)
         for (int64_t s = 0; s < n; ++s) perm[s] = sch.perm[(size_t)s];
+    return CMI_OK;
+}
+
+extern "C" int cmi_flow_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
+                                 int32_t *perm, uint32_t *seq_u, uint32_t *seq_j, int64_t cap, int64_t *n_slots) {
+    if (n < 0 || (n > 0 && (!u || !j)) || n_users <= 0 || n_items <= 0 || !n_slots) return CMI_E_INVALID;
+    for (int64_t t = 0; t < n; ++t)
+        if (u[t] < 0 || u[t] >= n_users || j[t] < 0 || j[t] >= n_items) return CMI_E_INVALID;
+    FlowSchedule f;
+    if (!build_flow_schedule(n, u, j, n_users, n_items, f)) return CMI_E_UNSUPPORTED;
+    *n_slots = (int64_t)f.perm.size();
+    if (!perm) return CMI_OK;
+    if (cap < *n_slots || !seq_u || !seq_j) return CMI_E_INVALID;
+    for (size_t s = 0; s < f.perm.size(); ++s) {
+        perm[s] = f.perm[s];
+        seq_u[s] = f.seq_u[s];
+        seq_j[s] = f.seq_j[s];
+    }
     return CMI_OK;
 }

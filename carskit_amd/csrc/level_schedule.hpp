@@ -14,6 +14,17 @@ struct LevelSchedule {
     int64_t n_levels() const { return (int64_t)level_off.size() - 1; }
 };
 
+// Dataflow variant of the same schedule (see build_flow_schedule in level_schedule.cpp).
+struct FlowSchedule {
+    std::vector<int32_t> perm;   // padded schedule position -> CRS tuple index, -1 = padding slot
+    std::vector<uint32_t> seq_u; // per position: how many earlier tuples of the epoch share its user
+    std::vector<uint32_t> seq_j; // ... its item
+    int64_t n_levels = 0, max_level = 0;
+    int64_t n_chunks() const { return (int64_t)perm.size() / 16; }
+};
+bool build_flow_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
+                         FlowSchedule &out);
+
 // false if n does not fit the int32 permutation
 bool build_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
                           int within_level_order, LevelSchedule &out);

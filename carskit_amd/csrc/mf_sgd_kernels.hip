@@ -22,6 +22,8 @@
 // with the CPU oracle.
 #include "mf_sgd_kernels.hpp"
 
+#include <cstdlib>
+
 namespace cmi {
 
 // ---------------------------------------------------------------------------------------------
@@ -60,11 +62,24 @@ struct Traits {
     static constexpr bool has_uc = MODEL == CAMF_CU || MODEL == CAMF_CUCI;
 };
 
+// 16-byte row stores with an explicit cache policy (stores have no outputs, so inline asm is safe here)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_row_wt(float4 *p, float4 v) {
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void st_row_nt(float4 *p, float4 v) {
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(x) : "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
 // fast path: fp32 state, K = 64*VPL, 16 lanes per tuple
 // ---------------------------------------------------------------------------------------------
 
-template <int MODEL, int VPL>
+// TPG = tuples each 16-lane group processes CONCURRENTLY (all their loads are issued before the first use):
+// more bytes in flight per wave and 1/TPG as many workgroups to dispatch per level.
+template <int MODEL, int VPL, int TPG>
 __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int64_t begin, int count,
                                                           int64_t slot0) {
     using M = Traits<MODEL>;
@@ -74,81 +89,102 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
     const int tid = threadIdx.x;
     const int l16 = tid & 15;
     const int gib = tid >> 4;
-    const int g = blockIdx.x * 16 + gib;
+    const int g0 = blockIdx.x * (16 * TPG) + gib; // tuple i of this group: g0 + 16*i (keeps the stream loads coalesced)
     double gloss = 0.0;
 
-    if (g < count) {
-        const int64_t t = begin + g;
-        const int uu = a.su[t];
-        const int jj = a.sj[t];
-        const float rr = a.sr[t];
-        int cond = -1;
-        if (MODEL != BIASEDMF && l16 < a.dmax) cond = a.sconds[t * a.dmax + l16];
-
-        float4 *prow = reinterpret_cast<float4 *>(a.P + (size_t)uu * K) + l16;
-        float4 *qrow = reinterpret_cast<float4 *>(a.Q + (size_t)jj * K) + l16;
-        float4 p[VPL], q[VPL];
+    bool live[TPG];
+    int uu[TPG], jj[TPG], cond[TPG];
+    float rr[TPG];
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) p[v] = prow[v * 16];
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) q[v] = qrow[v * 16];
+    for (int i = 0; i < TPG; ++i) {
+        const int g = g0 + 16 * i;
+        live[i] = g < count;
+        uu[i] = jj[i] = 0;
+        rr[i] = 0.f;
+        cond[i] = -1;
+        if (live[i]) {
+            const int64_t t = begin + g;
+            uu[i] = a.su[t];
+            jj[i] = a.sj[t];
+            rr[i] = a.sr[t];
+            if (MODEL != BIASEDMF && l16 < a.dmax) cond[i] = a.sconds[t * a.dmax + l16];
+        }
+    }
 
-        float bu = 0.f, bj = 0.f, bic = 0.f, buc = 0.f;
-        if (M::has_bu) bu = a.userBias[uu];
-        if (M::has_bj) bj = a.itemBias[jj];
-        float *pic = nullptr, *puc = nullptr;
-        if (cond >= 0) {
-            if (M::has_ic) {
-                pic = a.icBias + (size_t)jj * a.n_conds + cond;
-                bic = *pic;
-            }
-            if (M::has_uc) {
-                puc = a.ucBias + (size_t)uu * a.n_conds + cond;
-                buc = *puc;
+    float4 *prow[TPG], *qrow[TPG];
+    float4 p[TPG][VPL], q[TPG][VPL];
+    float bu[TPG], bj[TPG], bic[TPG], buc[TPG];
+    float *pic[TPG], *puc[TPG];
+#pragma unroll
+    for (int i = 0; i < TPG; ++i) {
+        prow[i] = reinterpret_cast<float4 *>(a.P + (size_t)uu[i] * K) + l16;
+        qrow[i] = reinterpret_cast<float4 *>(a.Q + (size_t)jj[i] * K) + l16;
+        bu[i] = bj[i] = bic[i] = buc[i] = 0.f;
+        pic[i] = puc[i] = nullptr;
+        if (live[i]) {
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) p[i][v] = prow[i][v * 16];
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) q[i][v] = qrow[i][v * 16];
+            if (M::has_bu) bu[i] = a.userBias[uu[i]];
+            if (M::has_bj) bj[i] = a.itemBias[jj[i]];
+            if (cond[i] >= 0) {
+                if (M::has_ic) {
+                    pic[i] = a.icBias + (size_t)jj[i] * a.n_conds + cond[i];
+                    bic[i] = *pic[i];
+                }
+                if (M::has_uc) {
+                    puc[i] = a.ucBias + (size_t)uu[i] * a.n_conds + cond[i];
+                    buc[i] = *puc[i];
+                }
             }
         }
+    }
 
-        const HParams hp = *a.hp;
-        const float lr = (float)hp.lr, regU = (float)hp.regU, regI = (float)hp.regI, regB = (float)hp.regB,
-                    regC = (float)hp.regC, gm = (float)hp.gm;
+    const HParams hp = *a.hp;
+    const float lr = (float)hp.lr, regU = (float)hp.regU, regI = (float)hp.regI, regB = (float)hp.regB,
+                regC = (float)hp.regC, gm = (float)hp.gm;
 
+#pragma unroll
+    for (int i = 0; i < TPG; ++i) {
+        if (!live[i]) continue; // group-uniform
         float part = 0.f;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
-            part += p[v].x * q[v].x;
-            part += p[v].y * q[v].y;
-            part += p[v].z * q[v].z;
-            part += p[v].w * q[v].w;
+            part += p[i][v].x * q[i][v].x;
+            part += p[i][v].y * q[i][v].y;
+            part += p[i][v].z * q[i][v].z;
+            part += p[i][v].w * q[i][v].w;
         }
         const float dot = row_sum16(part);
 
         float pred = gm;
-        if (M::has_bu) pred += bu;
-        if (M::has_bj) pred += bj;
+        if (M::has_bu) pred += bu[i];
+        if (M::has_bj) pred += bj[i];
         pred += dot;
         if (MODEL != BIASEDMF) {
             float term = 0.f; // lane d carries the deviation of the tuple's d-th condition
-            if (M::has_ic && M::has_uc) term = bic + buc;
-            else if (M::has_ic) term = bic;
-            else if (M::has_uc) term = buc;
+            if (M::has_ic && M::has_uc) term = bic[i] + buc[i];
+            else if (M::has_ic) term = bic[i];
+            else if (M::has_uc) term = buc[i];
             pred += row_sum16(term);
         }
-        const float e = rr - pred;
+        const float e = rr[i] - pred;
 
         // scalar biases: lane 0 of the group owns the store
         if (l16 == 0) {
-            if (M::has_bu) a.userBias[uu] = bu + lr * (e - regB * bu);
-            if (M::has_bj) a.itemBias[jj] = bj + lr * (e - regB * bj);
+            if (M::has_bu) a.userBias[uu[i]] = bu[i] + lr * (e - regB * bu[i]);
+            if (M::has_bj) a.itemBias[jj[i]] = bj[i] + lr * (e - regB * bj[i]);
         }
         float ctx_loss = 0.f;
-        if (cond >= 0) {
+        if (cond[i] >= 0) {
             if (M::has_ic) {
-                *pic = bic + lr * (e - regC * bic);
-                ctx_loss += bic * bic;
+                *pic[i] = bic[i] + lr * (e - regC * bic[i]);
+                ctx_loss += bic[i] * bic[i];
             }
             if (M::has_uc) {
-                *puc = buc + lr * (e - regC * buc);
-                ctx_loss += buc * buc;
+                *puc[i] = buc[i] + lr * (e - regC * buc[i]);
+                ctx_loss += buc[i] * buc[i];
             }
         }
 
@@ -157,23 +193,23 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
         for (int v = 0; v < VPL; ++v) {
             float4 pn, qn;
 #define CMI_UPD(c)                                                                                       \
-    pn.c = p[v].c + lr * (e * q[v].c - regU * p[v].c);                                                   \
-    qn.c = q[v].c + lr * (e * p[v].c - regI * q[v].c);                                                   \
-    lsum += (regU * p[v].c) * p[v].c + (regI * q[v].c) * q[v].c;
+    pn.c = p[i][v].c + lr * (e * q[i][v].c - regU * p[i][v].c);                                          \
+    qn.c = q[i][v].c + lr * (e * p[i][v].c - regI * q[i][v].c);                                          \
+    lsum += (regU * p[i][v].c) * p[i][v].c + (regI * q[i][v].c) * q[i][v].c;
             CMI_UPD(x) CMI_UPD(y) CMI_UPD(z) CMI_UPD(w)
 #undef CMI_UPD
-            prow[v * 16] = pn;
-            qrow[v * 16] = qn;
+            prow[i][v * 16] = pn;
+            qrow[i][v * 16] = qn;
         }
 
         const float reg_loss = row_sum16(lsum);
         const float ctx_sum = (MODEL != BIASEDMF) ? row_sum16(ctx_loss) : 0.f;
         if (l16 == 0) {
             double l = (double)e * (double)e;
-            if (M::has_bu) l += (double)regB * bu * bu;
-            if (M::has_bj) l += (double)regB * bj * bj;
+            if (M::has_bu) l += (double)regB * bu[i] * bu[i];
+            if (M::has_bj) l += (double)regB * bj[i] * bj[i];
             if (MODEL != BIASEDMF) l += (double)regC * ctx_sum;
-            gloss = l + (double)reg_loss;
+            gloss += l + (double)reg_loss;
         }
     }
 
@@ -185,6 +221,210 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
         for (int i = 0; i < 16; ++i) s += s_loss[i];
         a.loss_part[slot0 + blockIdx.x] = s;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dataflow path: one persistent launch per epoch, levels overlap (fp32 state, K = 64*VPL)
+// ---------------------------------------------------------------------------------------------
+//
+// Same arithmetic and lane layout as sgd_level_fast_f32, but instead of a kernel boundary after every
+// dependency level each tuple waits for exactly its own two predecessors: ver_u[u] / ver_j[j] count the
+// tuples of that user / item retired so far in this epoch, and the tuple at schedule position p may run
+// once they equal seq_u[p] / seq_j[p].  Because model rows now travel between workgroups (and XCDs, whose
+// L2s are not coherent with each other) INSIDE a launch, every access to model state is device-coherent:
+//   * row loads/stores are `global_load/store_dwordx4 ... sc0 sc1` (L1 bypass + write-through),
+//   * the producer drains its stores (`s_waitcnt vmcnt(0)`) before publishing the new version with a
+//     relaxed agent-scope store; the consumer polls the version with relaxed agent-scope loads and only
+//     then issues its row loads.
+// The tuple stream itself is read-only and uses plain loads.  Waves never synchronise with each other
+// (no __syncthreads): a wave owns 4 tuples of one level per step and accumulates its loss in registers.
+// Every spin is bounded; on overflow the kernel raises *error and carries on (the host reports it).
+
+__device__ __forceinline__ f32x4 ld_row_coherent(const f32x4 *p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void st_row_coherent(f32x4 *p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ float ld_f32_coherent(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_f32_coherent(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define CMI_FLOW_SPIN_LIMIT (1u << 22)
+
+template <int MODEL, int VPL>
+__global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs fa) {
+    using M = Traits<MODEL>;
+    static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
+    constexpr int K = 64 * VPL;
+    const int tid = threadIdx.x;
+    const int l16 = tid & 15;
+    const int gib = tid >> 4;
+    const int wave = tid >> 6;
+    double wloss = 0.0; // this wave's loss over all its tuples (fixed order: static chunk assignment)
+
+    const HParams hp = *a.hp;
+    const float lr = (float)hp.lr, regU = (float)hp.regU, regI = (float)hp.regI, regB = (float)hp.regB,
+                regC = (float)hp.regC, gm = (float)hp.gm;
+
+    for (int64_t chunk = blockIdx.x; chunk < fa.n_chunks; chunk += gridDim.x) {
+        const int64_t pos = chunk * 16 + gib;
+        const int uu = a.su[pos];
+        const int jj = a.sj[pos];
+        const bool live = uu >= 0;
+        float rr = 0.f;
+        int cond = -1;
+        uint32_t want_u = 0, want_j = 0;
+        if (live) {
+            rr = a.sr[pos];
+            want_u = fa.seq_u[pos];
+            want_j = fa.seq_j[pos];
+            if (MODEL != BIASEDMF && l16 < a.dmax) cond = a.sconds[pos * a.dmax + l16];
+        }
+
+        // wait until both predecessors have retired (usually true on the first poll)
+        bool ready = !live || (fa.debug & 1);
+        unsigned spins = 0;
+        while (true) {
+            if (!ready) {
+                const uint32_t vu = __hip_atomic_load(fa.ver_u + uu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t vj = __hip_atomic_load(fa.ver_j + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = (vu == want_u) && (vj == want_j);
+            }
+            if (__all(ready)) break;
+            if (++spins > CMI_FLOW_SPIN_LIMIT) {
+                if ((tid & 63) == 0) atomicExch(fa.error, 1);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+
+        double gloss = 0.0;
+        if (live) {
+            f32x4 *prow = reinterpret_cast<f32x4 *>(a.P + (size_t)uu * K) + l16;
+            f32x4 *qrow = reinterpret_cast<f32x4 *>(a.Q + (size_t)jj * K) + l16;
+            f32x4 p[VPL], q[VPL];
+            if (fa.debug & 4) {
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) p[v] = prow[v * 16];
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) q[v] = qrow[v * 16];
+            } else {
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) p[v] = ld_row_coherent(prow + v * 16);
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) q[v] = ld_row_coherent(qrow + v * 16);
+            }
+
+            float bu = 0.f, bj = 0.f, bic = 0.f, buc = 0.f;
+            if (M::has_bu) bu = ld_f32_coherent(a.userBias + uu);
+            if (M::has_bj) bj = ld_f32_coherent(a.itemBias + jj);
+            float *pic = nullptr, *puc = nullptr;
+            if (cond >= 0) {
+                if (M::has_ic) {
+                    pic = a.icBias + (size_t)jj * a.n_conds + cond;
+                    bic = ld_f32_coherent(pic);
+                }
+                if (M::has_uc) {
+                    puc = a.ucBias + (size_t)uu * a.n_conds + cond;
+                    buc = ld_f32_coherent(puc);
+                }
+            }
+            // the asm loads are invisible to the compiler's waitcnt pass: wait here, and tie the registers
+            // to the wait so no use can be scheduled above it
+            if (VPL == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(q[0])::"memory");
+            if (VPL == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(p[VPL > 1 ? 1 : 0]), "+v"(q[0]), "+v"(q[VPL > 1 ? 1 : 0])::"memory");
+            if (VPL == 4)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(p[0]), "+v"(p[VPL > 1 ? 1 : 0]), "+v"(p[VPL > 2 ? 2 : 0]), "+v"(p[VPL > 3 ? 3 : 0]),
+                               "+v"(q[0]), "+v"(q[VPL > 1 ? 1 : 0]), "+v"(q[VPL > 2 ? 2 : 0]), "+v"(q[VPL > 3 ? 3 : 0])::"memory");
+
+            float part = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                part += p[v].x * q[v].x;
+                part += p[v].y * q[v].y;
+                part += p[v].z * q[v].z;
+                part += p[v].w * q[v].w;
+            }
+            const float dot = row_sum16(part);
+
+            float pred = gm;
+            if (M::has_bu) pred += bu;
+            if (M::has_bj) pred += bj;
+            pred += dot;
+            if (MODEL != BIASEDMF) {
+                float term = 0.f;
+                if (M::has_ic && M::has_uc) term = bic + buc;
+                else if (M::has_ic) term = bic;
+                else if (M::has_uc) term = buc;
+                pred += row_sum16(term);
+            }
+            const float e = rr - pred;
+
+            if (l16 == 0) {
+                if (M::has_bu) st_f32_coherent(a.userBias + uu, bu + lr * (e - regB * bu));
+                if (M::has_bj) st_f32_coherent(a.itemBias + jj, bj + lr * (e - regB * bj));
+            }
+            float ctx_loss = 0.f;
+            if (cond >= 0) {
+                if (M::has_ic) {
+                    st_f32_coherent(pic, bic + lr * (e - regC * bic));
+                    ctx_loss += bic * bic;
+                }
+                if (M::has_uc) {
+                    st_f32_coherent(puc, buc + lr * (e - regC * buc));
+                    ctx_loss += buc * buc;
+                }
+            }
+
+            float lsum = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                f32x4 pn, qn;
+#define CMI_UPD(c)                                                                                       \
+    pn.c = p[v].c + lr * (e * q[v].c - regU * p[v].c);                                                   \
+    qn.c = q[v].c + lr * (e * p[v].c - regI * q[v].c);                                                   \
+    lsum += (regU * p[v].c) * p[v].c + (regI * q[v].c) * q[v].c;
+                CMI_UPD(x) CMI_UPD(y) CMI_UPD(z) CMI_UPD(w)
+#undef CMI_UPD
+                if (fa.debug & 4) {
+                    prow[v * 16] = pn;
+                    qrow[v * 16] = qn;
+                } else {
+                    st_row_coherent(prow + v * 16, pn);
+                    st_row_coherent(qrow + v * 16, qn);
+                }
+            }
+
+            const float reg_loss = row_sum16(lsum);
+            const float ctx_sum = (MODEL != BIASEDMF) ? row_sum16(ctx_loss) : 0.f;
+            if (l16 == 0) {
+                double l = (double)e * (double)e;
+                if (M::has_bu) l += (double)regB * bu * bu;
+                if (M::has_bj) l += (double)regB * bj * bj;
+                if (MODEL != BIASEDMF) l += (double)regC * ctx_sum;
+                gloss = l + (double)reg_loss;
+            }
+        }
+
+        // retire: all of this wave's state stores are written through before the versions move
+        if (!(fa.debug & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (live && l16 == 0) {
+            __hip_atomic_store(fa.ver_u + uu, want_u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fa.ver_j + jj, want_j + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the four tuple losses of this wave, fixed order
+        const double g0 = __shfl(gloss, 0, 64), g1 = __shfl(gloss, 16, 64), g2 = __shfl(gloss, 32, 64),
+                     g3 = __shfl(gloss, 48, 64);
+        wloss += ((g0 + g1) + g2) + g3;
+    }
+    if ((tid & 63) == 0) a.loss_part[(int64_t)blockIdx.x * 4 + wave] = wloss;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -460,7 +700,17 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs<T> a, int64_t n) {
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 
-int level_blocks_f32_fast(int, int count) { return (count + 15) / 16; }
+static int g_fast_tpg = -1;
+static int fast_tpg() { // tuples per 16-lane group (CMI_LEVEL_TPG overrides for experiments)
+    if (g_fast_tpg < 0) {
+        int v = 2;
+        if (const char *env = getenv("CMI_LEVEL_TPG")) v = atoi(env);
+        g_fast_tpg = (v == 1 || v == 2 || v == 4) ? v : 2;
+    }
+    return g_fast_tpg;
+}
+
+int level_blocks_f32_fast(int, int count) { return (count + 16 * fast_tpg() - 1) / (16 * fast_tpg()); }
 int level_blocks_generic(int count) { return (count + 3) / 4; }
 
 bool has_fast_path(int k, int dmax, bool f64, const LaunchCfg &cfg) {
@@ -470,17 +720,27 @@ bool has_fast_path(int k, int dmax, bool f64, const LaunchCfg &cfg) {
     return true;
 }
 
-template <int MODEL>
-static hipError_t launch_fast_model(const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,
-                                    int64_t slot0, hipStream_t s) {
-    const dim3 grid(level_blocks_f32_fast(a.k, count)), block(256);
+template <int MODEL, int TPG>
+static hipError_t launch_fast_model_tpg(const SgdArgs<float> &a, int64_t begin, int count, int64_t slot0,
+                                        hipStream_t s) {
+    const dim3 grid((count + 16 * TPG - 1) / (16 * TPG)), block(256);
     switch (a.k) {
-    case 64: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 1>), grid, block, 0, s, a, begin, count, slot0); break;
-    case 128: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 2>), grid, block, 0, s, a, begin, count, slot0); break;
-    case 256: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 4>), grid, block, 0, s, a, begin, count, slot0); break;
+    case 64: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 1, TPG>), grid, block, 0, s, a, begin, count, slot0); break;
+    case 128: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 2, TPG>), grid, block, 0, s, a, begin, count, slot0); break;
+    case 256: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 4, TPG>), grid, block, 0, s, a, begin, count, slot0); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+template <int MODEL>
+static hipError_t launch_fast_model(const SgdArgs<float> &a, const LaunchCfg &, int64_t begin, int count,
+                                    int64_t slot0, hipStream_t s) {
+    switch (fast_tpg()) {
+    case 1: return launch_fast_model_tpg<MODEL, 1>(a, begin, count, slot0, s);
+    case 4: return launch_fast_model_tpg<MODEL, 4>(a, begin, count, slot0, s);
+    default: return launch_fast_model_tpg<MODEL, 2>(a, begin, count, slot0, s);
+    }
 }
 
 hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,
@@ -493,6 +753,53 @@ hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, 
     case CAMF_CUCI: return launch_fast_model<CAMF_CUCI>(a, cfg, begin, count, slot0, s);
     }
     return hipErrorInvalidValue;
+}
+
+
+template <int MODEL>
+static hipError_t launch_flow_model(const SgdArgs<float> &a, const FlowArgs &fa, int grid_blocks, hipStream_t s) {
+    const dim3 grid(grid_blocks), block(256);
+    switch (a.k) {
+    case 64: hipLaunchKernelGGL((sgd_flow_f32<MODEL, 1>), grid, block, 0, s, a, fa); break;
+    case 128: hipLaunchKernelGGL((sgd_flow_f32<MODEL, 2>), grid, block, 0, s, a, fa); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_flow_f32(const SgdArgs<float> &a, const FlowArgs &fa, const LaunchCfg &cfg, int grid_blocks,
+                           hipStream_t s) {
+    if (fa.n_chunks <= 0) return hipSuccess;
+    switch (cfg.model) {
+    case BIASEDMF: return launch_flow_model<BIASEDMF>(a, fa, grid_blocks, s);
+    case CAMF_CI: return launch_flow_model<CAMF_CI>(a, fa, grid_blocks, s);
+    case CAMF_CU: return launch_flow_model<CAMF_CU>(a, fa, grid_blocks, s);
+    case CAMF_CUCI: return launch_flow_model<CAMF_CUCI>(a, fa, grid_blocks, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// The flow kernel needs every workgroup co-resident (waiting workgroups must not keep runnable ones off the
+// chip).  Size the grid from the occupancy query with a safety margin (MI355X_MICROARCH.md: the API can
+// over-report by one block per CU for SGPR-heavy kernels) and never above 4 blocks per CU: 4 x 16 tuples x
+// 256 CUs x ~2 KB in flight already exceeds what the HBM latency-bandwidth product needs.
+int flow_grid_blocks(int device, int k) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+    int per_cu = 0;
+    hipError_t e = hipErrorInvalidValue;
+    if (k == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_flow_f32<CAMF_CUCI, 1>, 256, 0);
+    if (k == 128) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_flow_f32<CAMF_CUCI, 2>, 256, 0);
+    // k == 256 is not offered yet: with eight 16-byte asm loads in flight the register allocator may copy a
+    // destination before the hand-placed wait (observed: NaN) -> falls back to the level schedule
+    if (e != hipSuccess || per_cu < 2) return 0;
+    int use = per_cu - 1;
+    if (use > 4) use = 4;
+    if (const char *env = getenv("CMI_FLOW_BLOCKS_PER_CU")) {
+        const int v = atoi(env);
+        if (v >= 1 && v < per_cu) use = v;
+    }
+    return use * prop.multiProcessorCount;
 }
 
 template <typename T, int MODEL>

@@ -28,6 +28,7 @@ struct SgdArgs {
     const HParams *hp;
     double *loss_part;         // one slot per workgroup of the epoch (deterministic reduction)
     int32_t k, n_conds, dmax;
+    int32_t store_mode;        // row stores of the level kernel: 0 plain (write-back L2), 1 sc0 sc1 write-through, 2 nt
 };
 
 struct LaunchCfg {
@@ -46,6 +47,18 @@ hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, 
 template <typename T>
 hipError_t launch_level_generic(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t begin, int count, int64_t slot0,
                                 hipStream_t s);
+// Dataflow epoch: ONE persistent launch walks the padded schedule; tuples wait on per-row version counters.
+struct FlowArgs {
+    const uint32_t *seq_u, *seq_j; // per padded position: version the tuple must observe
+    uint32_t *ver_u, *ver_j;       // per user / per item: tuples retired this epoch (zeroed before the launch)
+    int32_t *error;                // set to 1 if a wait exceeded its bound (schedule stalled)
+    int64_t n_chunks;              // padded positions / 16
+    int32_t debug;                 // timing experiments only (CMI_FLOW_DEBUG): 1 skip waits, 2 skip store drain, 4 plain row traffic
+};
+int flow_grid_blocks(int device, int k);       // fully co-resident grid size for the flow kernel (0 = unsupported)
+hipError_t launch_flow_f32(const SgdArgs<float> &a, const FlowArgs &fa, const LaunchCfg &cfg, int grid_blocks,
+                           hipStream_t s);
+
 // one wavefront walks tuples [0, n) in order (the reference's sequential semantics); loss -> loss_out[0] (already *0.5)
 template <typename T>
 hipError_t launch_serial(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t n, double *loss_out, hipStream_t s);

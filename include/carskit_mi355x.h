@@ -71,6 +71,12 @@ extern "C" {
                                       order) and, under SCHED_SERIAL, the reference's running-sum order for `loss`:
                                       with STATE_F64 the model (and under SERIAL the loss) is bit-identical to the
                                       Java arithmetic */
+#define CMI_FLAG_SCHED_FLOW 0x20u /* same dependency levels, but ONE persistent launch per epoch in which every tuple
+                                      waits only for its own two predecessors (per-row version counters, device-coherent
+                                      row traffic): adjacent levels overlap.  Same result as the level schedule, bit for
+                                      bit.  EXPERIMENTAL (round 1: correct but slower than the level launches, see
+                                      DESIGN.md); fp32 state, k in {64,128}; silently falls back to the level schedule
+                                      otherwise (cmi_schedule_info reports which one runs) */
 #define CMI_FLAG_NO_GRAPH 0x10u  /* launch the per-level kernels eagerly instead of replaying a hipGraph */
 
 typedef struct cmi_instance *cmi_handle;
@@ -144,8 +150,10 @@ int cmi_synchronize(cmi_handle h);
 int cmi_train_epoch_async(cmi_handle h, double lrate);
 int cmi_last_loss(cmi_handle h, double *loss_out);
 /* schedule facts: info[0]=levels (kernel launches per epoch), info[1]=largest level, info[2]=tuples,
- * info[3]=max conditions per tuple (D), info[4]=state bytes on device, info[5]=tuple-stream bytes on device */
-int cmi_schedule_info(cmi_handle h, int64_t info[6]);
+ * info[3]=max conditions per tuple (D), info[4]=state bytes on device, info[5]=tuple-stream bytes on device,
+ * info[6]=schedule kind actually running (0 level launches, 1 serial, 2 dataflow), info[7]=workgroups of the
+ * dataflow launch (0 otherwise) */
+int cmi_schedule_info(cmi_handle h, int64_t info[8]);
 /* GPU time of the most recent epoch's kernels measured with HIP events on cmi_stream() */
 int cmi_last_epoch_ms(cmi_handle h, float *ms);
 
@@ -160,6 +168,13 @@ int cmi_last_epoch_ms(cmi_handle h, float *ms);
  * 1 sort by item id, 2 sort by user id (tuples of one level commute, so this is free). */
 int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int order,
                        int32_t *perm, int64_t *level_off, int64_t level_cap, int64_t *n_levels);
+
+/* The padded dataflow form of the same schedule (CMI_FLAG_SCHED_FLOW; level_schedule.cpp): call with
+ * perm = NULL to get *n_slots, then with arrays of that capacity.  perm[s] = CRS tuple index or -1 for a
+ * padding slot (every level is padded to a multiple of 16 slots); seq_u[s] / seq_j[s] = number of earlier
+ * tuples (CRS order) with the same user / item = the row version the tuple waits for. */
+int cmi_flow_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
+                      int32_t *perm, uint32_t *seq_u, uint32_t *seq_j, int64_t cap, int64_t *n_slots);
 
 #ifdef __cplusplus
 }

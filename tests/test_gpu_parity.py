@@ -16,6 +16,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 F64, SERIAL, STRICT, NOGRAPH = (capi.FLAG_STATE_F64, capi.FLAG_SCHED_SERIAL, capi.FLAG_STRICT, capi.FLAG_NO_GRAPH)
+FLOW = capi.FLAG_SCHED_FLOW
 
 
 def make_pair(model, data, k, flags, seed=5, regs=None):
@@ -236,11 +237,13 @@ def test_dist_gpu_engine_aliases_device_state_and_exchange_is_identity_at_world1
     q = eng.item["Q"]
     assert q.is_cuda and q.numel() == data.n_items * 128
     assert np.array_equal(q.cpu().numpy().reshape(data.n_items, 128), a.get_state("Q", np.float32))
-    q[:128] += 1.0                                          # torch writes land in the library's buffer
+    saved = q[:128].clone()
+    q[:128] = 7.0                                           # torch writes land in the library's buffer
     torch.cuda.synchronize()
-    assert np.array_equal(a.get_state("Q", np.float32)[0], b.get_state("Q", np.float32)[0] + 1.0)
-    q[:128] -= 1.0
+    assert np.all(a.get_state("Q", np.float32)[0] == 7.0)
+    q[:128] = saved
     torch.cuda.synchronize()
+    assert np.array_equal(a.get_state("Q", np.float32), b.get_state("Q", np.float32))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -256,3 +259,42 @@ def test_dist_gpu_engine_aliases_device_state_and_exchange_is_identity_at_world1
             assert np.array_equal(a.get_state(name, np.float32), b.get_state(name, np.float32)), name
     finally:
         tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", [m for m in util.MODELS if m != "CAMF_C"])
+@pytest.mark.parametrize("k", [64, 128])
+def test_flow_schedule_bit_identical_to_level_schedule(model, k):
+    """The dataflow launch (levels overlapped, per-row version counters, device-coherent row traffic) must give
+    the bit-identical fp32 model and loss trajectory as one launch per level: any stale cross-XCD read or a
+    missed dependency changes bits."""
+    data = util.small_data(n_users=20000, n_items=1500, n_dims=4, conds_per_dim=4, n=400000, seed=41)
+    _, lvl = make_pair(model, data, k, 0)
+    _, flw = make_pair(model, data, k, FLOW)
+    assert flw.schedule_info()["kind"] == "flow" and lvl.schedule_info()["kind"] == "level"
+    assert flw.schedule_info()["levels"] == lvl.schedule_info()["levels"]
+    l_losses, l_lrs = lvl.train(8, util.LR, bold_driver=True)
+    f_losses, f_lrs = flw.train(8, util.LR, bold_driver=True)
+    np.testing.assert_allclose(f_losses, l_losses, rtol=1e-12)   # same terms, different fixed summation tree
+    assert f_lrs.tolist() == l_lrs.tolist()
+    a, b = lvl.get_states(np.float32), flw.get_states(np.float32)
+    for name in a:
+        assert np.array_equal(a[name], b[name]), name
+
+
+def test_flow_schedule_hot_item_and_fallback():
+    """Zipf items: long dependency chains, tiny levels -> many waits; still bit-identical.  Unsupported shapes
+    (fp64 state, k=10) fall back to the level schedule."""
+    data = util.small_data(n_users=5000, n_items=300, n_dims=2, conds_per_dim=3, n=60000, seed=42, item_zipf=1.2)
+    _, lvl = make_pair("CAMF_CI", data, 64, 0)
+    _, flw = make_pair("CAMF_CI", data, 64, FLOW)
+    for _ in range(3):
+        a, b = lvl.train_epoch(util.LR), flw.train_epoch(util.LR)
+        assert abs(a - b) <= 1e-12 * abs(a)
+    for name, arr in lvl.get_states(np.float32).items():
+        assert np.array_equal(arr, flw.get_state(name, np.float32)), name
+    _, fb = make_pair("CAMF_CI", data, 10, FLOW)
+    assert fb.schedule_info()["kind"] == "level"
+    _, fb256 = make_pair("CAMF_CI", data, 256, FLOW)
+    assert fb256.schedule_info()["kind"] == "level"
+    _, fb64 = make_pair("CAMF_CI", data, 64, FLOW | F64)
+    assert fb64.schedule_info()["kind"] == "level"
