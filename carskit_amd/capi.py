@@ -58,6 +58,22 @@ SYMBOLS = [
     ("cmi_last_epoch_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("cmi_level_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, _vp, _vp, _i64, C.POINTER(_i64)]),
     ("cmi_flow_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
+    ("cmi_fm_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.POINTER(_vp)]),
+    ("cmi_fm_destroy", C.c_int, [_vp]),
+    ("cmi_fm_last_error", C.c_char_p, [_vp]),
+    ("cmi_fm_set_hparams", C.c_int, [_vp, _dbl, _dbl, _i64]),
+    ("cmi_fm_set_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    ("cmi_fm_set_model", C.c_int, [_vp, _dbl, _vp, _vp]),
+    ("cmi_fm_get_model", C.c_int, [_vp, C.POINTER(_dbl), _vp, _vp]),
+    ("cmi_fm_init", C.c_int, [_vp]),
+    ("cmi_fm_sweep", C.c_int, [_vp]),
+    ("cmi_fm_train", C.c_int, [_vp, C.c_int]),
+    ("cmi_fm_predict_batch", C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, _dbl, _dbl, _vp]),
+    ("cmi_fm_synchronize", C.c_int, [_vp]),
+    ("cmi_fm_num_phases", C.c_int, [_vp]),
+    ("cmi_fm_phase_reduce", C.c_int, [_vp, C.c_int]),
+    ("cmi_fm_phase_buffer", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64)]),
+    ("cmi_fm_phase_apply", C.c_int, [_vp, C.c_int]),
 ]
 
 _LIB = None
@@ -266,3 +282,86 @@ class Instance:
         res = dict(zip(("MAE", "RMSE", "NMAE", "rMAE", "rRMSE"), out.tolist()))
         res["n"] = cnt.value
         return res
+
+
+class FMInstance:
+    """The reference's FM recommender on one GPU (a `cmi_fm_handle`)."""
+
+    def __init__(self, k, n_users, n_items, n_conds, n_ctx_dims, device=0, flags=0):
+        self.L = lib()
+        self.k, self.n_users, self.n_items, self.n_conds = k, n_users, n_items, n_conds
+        self.p = n_users + n_items + n_conds
+        self.h = _vp()
+        rc = self.L.cmi_fm_create(k, n_users, n_items, n_conds, n_ctx_dims, device, flags, C.byref(self.h))
+        if rc != OK:
+            self.h = None
+            raise CmiError(rc, self.L.cmi_fm_last_error(None).decode())
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise CmiError(rc, self.L.cmi_fm_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cmi_fm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_hparams(self, regLw, regLf, global_size=0):
+        self._chk(self.L.cmi_fm_set_hparams(self.h, regLw, regLf, global_size))
+
+    def set_ratings(self, u, j, ctx, r):
+        c32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        u, j, ctx = c32(u), c32(j), c32(ctx)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        self._chk(self.L.cmi_fm_set_ratings(self.h, len(r), _p(u), _p(j), _p(ctx), _p(r)))
+
+    def set_model(self, w0, w, V):
+        w = np.ascontiguousarray(w, dtype=np.float64).reshape(self.p)
+        V = np.ascontiguousarray(V, dtype=np.float64).reshape(self.p, self.k)
+        self._chk(self.L.cmi_fm_set_model(self.h, float(w0), _p(w), _p(V)))
+
+    def get_model(self):
+        w0, w, V = _dbl(), np.empty(self.p), np.empty((self.p, self.k))
+        self._chk(self.L.cmi_fm_get_model(self.h, C.byref(w0), _p(w), _p(V)))
+        return w0.value, w, V
+
+    def init(self):
+        self._chk(self.L.cmi_fm_init(self.h))
+
+    def sweep(self):
+        self._chk(self.L.cmi_fm_sweep(self.h))
+        self._chk(self.L.cmi_fm_synchronize(self.h))
+
+    def train(self, num_iters):
+        self._chk(self.L.cmi_fm_train(self.h, num_iters))
+
+    def num_phases(self):
+        return self.L.cmi_fm_num_phases(self.h)
+
+    def phase_reduce(self, phase):
+        self._chk(self.L.cmi_fm_phase_reduce(self.h, phase))
+
+    def phase_buffer(self, phase):
+        ptr, cnt = _vp(), _i64()
+        self._chk(self.L.cmi_fm_phase_buffer(self.h, phase, C.byref(ptr), C.byref(cnt)))
+        return ptr.value, cnt.value
+
+    def phase_apply(self, phase):
+        self._chk(self.L.cmi_fm_phase_apply(self.h, phase))
+
+    def synchronize(self):
+        self._chk(self.L.cmi_fm_synchronize(self.h))
+
+    def predict(self, u, j, ctx, bound=None):
+        c32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        u, j, ctx = c32(u), c32(j), c32(ctx)
+        out = np.empty(len(u))
+        lo, hi = bound if bound else (0.0, 0.0)
+        self._chk(self.L.cmi_fm_predict_batch(self.h, len(u), _p(u), _p(j), _p(ctx), 1 if bound else 0, lo, hi, _p(out)))
+        return out

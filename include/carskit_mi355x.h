@@ -157,6 +157,50 @@ int cmi_schedule_info(cmi_handle h, int64_t info[8]);
 /* GPU time of the most recent epoch's kernels measured with HIP events on cmi_stream() */
 int cmi_last_epoch_ms(cmi_handle h, float *ms);
 
+/* ---- FM: src/carskit/alg/cars/adaptation/dependent/FM.java (ALS / coordinate-descent sweep, not SGD) ---------
+ * Separate handle type: the state is (w0, w[p], V[p x k]) with p = numUsers+numItems+numConditions
+ * (FM.java:57-74) plus the per-rating errors[] and Q[][] of buildModel() (FM.java:117-146).  fp64 on the
+ * device (the reference's precision).  The reference's quirks are kept: the context feature of a rating is
+ * index numUsers+numItems+c with c the CONTEXT-COMBINATION id and value 1/numContextDims, present only if
+ * c < numConditions (FM.java:81-86); denominators add the regulariser once per rating (FM.java:181,201); the
+ * error/Q update of a factor uses x_il (FM.java:209-210).  Sums are tree-reduced (not the Java's sequential
+ * order): model within ~1e-12 of the reference arithmetic, RMSE within 1e-9.  `loss` (FM.java:218) is never
+ * read by the reference and is not computed. */
+typedef struct cmi_fm_instance *cmi_fm_handle;
+
+/* new FM(train, test, fold) + initModel() allocation (FM.java:49-74) */
+int cmi_fm_create(int k, int n_users, int n_items, int n_conds, int n_ctx_dims, int device, unsigned flags,
+                  cmi_fm_handle *out);
+int cmi_fm_destroy(cmi_fm_handle h);
+const char *cmi_fm_last_error(cmi_fm_handle h);
+/* -lw / -lf of the `FM=` line (FM.java:53-54; Java floats promoted) and `size` = trainMatrix.size() over ALL
+ * ranks (FM.java:64; <= 0 means the local tuple count) */
+int cmi_fm_set_hparams(cmi_fm_handle h, double regLw, double regLf, int64_t global_size);
+/* training tuples as `trainMatrix.iterator()` yields them (FM.java:118-127); ctx = context-combination id */
+int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
+                       const double *r);
+/* w0, w (p), V (p x k row-major): injected initial model / trained model (FM.java:65-70) */
+int cmi_fm_set_model(cmi_fm_handle h, double w0, const double *w, const double *V);
+int cmi_fm_get_model(cmi_fm_handle h, double *w0, double *w, double *V);
+/* the pre-pass of buildModel(): errors[] and Q[][] from the current model (FM.java:117-146) */
+int cmi_fm_init(cmi_fm_handle h);
+/* one iteration of the `for (iter ...)` loop (FM.java:148-218) on one GPU */
+int cmi_fm_sweep(cmi_fm_handle h);
+/* whole buildModel(): cmi_fm_init + num_iters sweeps (the reference has no early stop for FM) */
+int cmi_fm_train(cmi_fm_handle h, int num_iters);
+/* FM.predict (FM.java:93-113) (+ bounding, Recommender.java:306-317) */
+int cmi_fm_predict_batch(cmi_fm_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
+                         int bound, double lo, double hi, double *out);
+int cmi_fm_synchronize(cmi_fm_handle h);
+/* multi-GPU plumbing (no reference counterpart): a sweep is cmi_fm_num_phases() phases (0: w0; 1-3: w of the
+ * user / item / context-feature field; 4+3f+field: column f of V).  phase_reduce leaves the local partial sums
+ * [num(count/2) | den(count/2)] in a device buffer the host may all-reduce (ratings sharded across ranks),
+ * phase_apply consumes it.  reduce+apply over all phases == cmi_fm_sweep. */
+int cmi_fm_num_phases(cmi_fm_handle h);
+int cmi_fm_phase_reduce(cmi_fm_handle h, int phase);
+int cmi_fm_phase_buffer(cmi_fm_handle h, int phase, void **dev_ptr, int64_t *count);
+int cmi_fm_phase_apply(cmi_fm_handle h, int phase);
+
 /* ---- host-only integer preprocessing (runs without a GPU) ------------------------------------- */
 
 /* The dependency-level schedule the default mode executes (carskit_amd/csrc/level_schedule.cpp):

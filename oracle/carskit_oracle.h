@@ -113,6 +113,24 @@ double orc_jrandom_next_gaussian(orc_jrandom *g);
 void orc_init_gaussian(orc_jrandom *g, double *a, int64_t n, double mean, double sigma);
 void orc_init_uniform(orc_jrandom *g, double *a, int64_t n, double range);
 
+/* ---- FM (src/carskit/alg/cars/adaptation/dependent/FM.java), see carskit_oracle_fm.c ---------------- */
+typedef struct {
+    int32_t k, n_users, n_items, n_conds, n_ctx_dims;
+    int32_t p;             /* n_users + n_items + n_conds (FM.java:62) */
+    int64_t size;          /* training tuples, CRS order */
+    const int32_t *u, *j, *ctx;
+    const double *r;
+    double w0;
+    double *w;             /* p */
+    double *V;             /* p x k row-major */
+    double *Q;             /* size x k row-major (FM.java:72) */
+    double *errors;        /* size */
+    double regLw, regLf;   /* Java floats promoted (FM.java:53-54) */
+} orc_fm;
+double orc_fm_predict(const orc_fm *m, int32_t u, int32_t j, int32_t c);
+void orc_fm_init(orc_fm *m);
+double orc_fm_sweep(orc_fm *m);
+
 #ifdef __cplusplus
 }
 #endif

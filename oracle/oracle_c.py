@@ -35,6 +35,16 @@ class OrcSchedule(C.Structure):
     ]
 
 
+class OrcFM(C.Structure):
+    _fields_ = [
+        ("k", C.c_int32), ("n_users", C.c_int32), ("n_items", C.c_int32), ("n_conds", C.c_int32),
+        ("n_ctx_dims", C.c_int32), ("p", C.c_int32), ("size", C.c_int64),
+        ("u", C.c_void_p), ("j", C.c_void_p), ("ctx", C.c_void_p), ("r", C.c_void_p),
+        ("w0", C.c_double), ("w", C.c_void_p), ("V", C.c_void_p), ("Q", C.c_void_p), ("errors", C.c_void_p),
+        ("regLw", C.c_double), ("regLf", C.c_double),
+    ]
+
+
 class OrcJRandom(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("nextNextGaussian", C.c_double), ("haveNextNextGaussian", C.c_int32)]
 
@@ -73,6 +83,11 @@ def lib():
         L.orc_jrandom_next_gaussian.argtypes = [C.POINTER(OrcJRandom)]
         L.orc_init_gaussian.argtypes = [C.POINTER(OrcJRandom), C.c_void_p, C.c_int64, C.c_double, C.c_double]
         L.orc_init_uniform.argtypes = [C.POINTER(OrcJRandom), C.c_void_p, C.c_int64, C.c_double]
+        L.orc_fm_predict.restype = C.c_double
+        L.orc_fm_predict.argtypes = [C.POINTER(OrcFM), C.c_int32, C.c_int32, C.c_int32]
+        L.orc_fm_init.argtypes = [C.POINTER(OrcFM)]
+        L.orc_fm_sweep.restype = C.c_double
+        L.orc_fm_sweep.argtypes = [C.POINTER(OrcFM)]
         _LIB = L
     return _LIB
 
@@ -165,3 +180,35 @@ class JRandom:
         a = np.zeros(shape)
         self.L.orc_init_uniform(C.byref(self.g), _p(a), a.size, rng)
         return a
+
+
+class FMOracle:
+    """The reference's FM over flat arrays (w, V are updated in place; w0 lives in self.m.w0)."""
+
+    def __init__(self, k, n_users, n_items, n_conds, n_ctx_dims, u, j, ctx, r, w0, w, V, regLw, regLf):
+        self.L = lib()
+        self.u = np.ascontiguousarray(u, dtype=np.int32)
+        self.j = np.ascontiguousarray(j, dtype=np.int32)
+        self.ctx = np.ascontiguousarray(ctx, dtype=np.int32)
+        self.r = np.ascontiguousarray(r, dtype=np.float64)
+        p = n_users + n_items + n_conds
+        self.w = np.array(w, dtype=np.float64).reshape(p)
+        self.V = np.array(V, dtype=np.float64).reshape(p, k)
+        n = len(self.r)
+        self.Q = np.zeros((n, k))
+        self.errors = np.zeros(n)
+        self.m = OrcFM(k, n_users, n_items, n_conds, n_ctx_dims, p, n, _p(self.u), _p(self.j), _p(self.ctx),
+                       _p(self.r), w0, _p(self.w), _p(self.V), _p(self.Q), _p(self.errors), regLw, regLf)
+
+    @property
+    def w0(self):
+        return self.m.w0
+
+    def init(self):
+        self.L.orc_fm_init(C.byref(self.m))
+
+    def sweep(self):
+        return self.L.orc_fm_sweep(C.byref(self.m))
+
+    def predict(self, u, j, c):
+        return self.L.orc_fm_predict(C.byref(self.m), u, j, c)

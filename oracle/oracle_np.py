@@ -303,3 +303,91 @@ def eval_ratings(model, tuples, min_rate, max_rate):
     mae = sa / n
     return {"MAE": mae, "RMSE": math.sqrt(ss / n), "NMAE": mae / (max_rate - min_rate), "rMAE": sra / n,
             "rRMSE": math.sqrt(srs / n), "n": n}
+
+
+class FM:
+    """Second restatement of the reference's FM (src/carskit/alg/cars/adaptation/dependent/FM.java:57-220):
+    dense feature matrix, dense loops, exactly as the Java is written (tiny sizes only)."""
+
+    def __init__(self, k, n_users, n_items, n_conds, n_ctx_dims, tuples, w0, w, V, regLw, regLf):
+        self.k, self.nu, self.ni, self.nc, self.dims = k, n_users, n_items, n_conds, n_ctx_dims
+        self.p = n_users + n_items + n_conds
+        self.tuples = tuples
+        self.size = len(tuples)
+        self.w0, self.w, self.V = w0, list(w), [list(row) for row in V]
+        self.regLw, self.regLf = regLw, regLf
+        self.X = [self.feature_vector(u, j, c) for (u, j, c, _) in tuples]   # fvalues
+        self.errors = [0.0] * self.size
+        self.Q = [[0.0] * k for _ in range(self.size)]
+
+    def feature_vector(self, u, j, c):
+        fs = [0.0] * self.p
+        iu, ij, ic = u, self.nu + j, self.nu + self.ni + c
+        for i in range(self.p):
+            if i == iu or i == ij:
+                fs[i] = 1.0
+            elif i == ic:
+                fs[i] = 1.0 / self.dims
+        return fs
+
+    def predict(self, u, j, c):
+        fs = self.feature_vector(u, j, c)
+        pred = self.w0
+        for i in range(self.p):
+            pred += self.w[i] * fs[i]
+        total = 0.0
+        for f in range(self.k):
+            s1 = s2 = 0.0
+            for i in range(self.p):
+                d = self.V[i][f] * fs[i]
+                s1 += self.V[i][f] * fs[i]
+                s2 += d * d
+            total += s1 * s1 - s2
+        return pred + 0.5 * total
+
+    def init(self):
+        for n, (u, j, c, r) in enumerate(self.tuples):
+            self.errors[n] = r - self.predict(u, j, c)
+            for f in range(self.k):
+                v = 0.0
+                for i in range(self.p):
+                    v += self.V[i][f] * self.X[n][i]
+                self.Q[n][f] = v
+
+    def sweep(self):
+        loss = 0.0
+        upd = 0.0
+        for i in range(self.size):
+            upd += self.errors[i] - self.w0
+            loss += self.errors[i] * self.errors[i]
+        upd = 0 - upd / (self.size + self.regLw)
+        for i in range(self.size):
+            self.errors[i] = self.errors[i] + upd - self.w0
+        loss += self.regLw * self.w0 * self.w0
+        self.w0 = upd
+        for l in range(self.p):
+            upd = tot = 0.0
+            for i in range(self.size):
+                fl = self.X[i][l]
+                upd += (self.errors[i] - self.w[l] * fl) * fl
+                tot += fl * fl + self.regLw
+            upd = 0 - upd / tot
+            for i in range(self.size):
+                self.errors[i] = self.errors[i] + (upd - self.w[l]) * self.X[i][l]
+            loss += self.regLw * self.w[l] * self.w[l]
+            self.w[l] = upd
+        for f in range(self.k):
+            for l in range(self.p):
+                upd = tot = 0.0
+                for i in range(self.size):
+                    fl = self.X[i][l]
+                    h = fl * self.Q[i][f] - fl * fl * self.V[l][f]
+                    upd += (self.errors[i] - self.V[l][f] * h) * h
+                    tot += h * h + self.regLf
+                    loss += self.regLf * (self.Q[i][f] * self.Q[i][f])
+                upd = 0 - upd / tot
+                for i in range(self.size):
+                    self.errors[i] = self.errors[i] + (upd - self.V[l][f]) * self.X[i][l]
+                    self.Q[i][f] = self.Q[i][f] + (upd - self.V[l][f]) * self.X[i][l]
+                self.V[l][f] = upd
+        return loss * 0.05
