@@ -201,6 +201,41 @@ int cmi_fm_phase_reduce(cmi_fm_handle h, int phase);
 int cmi_fm_phase_buffer(cmi_fm_handle h, int phase, void **dev_ptr, int64_t *count);
 int cmi_fm_phase_apply(cmi_fm_handle h, int phase);
 
+/* ---- data side of the path (host-only, no GPU): DataDAO id-mapper and the compact->binary rewrite -------------
+ * Integer / string work that must be BIT-EXACT with the reference (north_star: "integer id mapping bit-exact"). */
+typedef struct cmi_dao *cmi_dao_handle;
+
+/* DataDAO.readData (src/carskit/data/processor/DataDAO.java:166-354) for a binary-format rating file:
+ * header tokens >= 3 are conditions (`dim:cond`), data lines `user,item,rating,0/1...`; inner ids are assigned
+ * in first-seen order (users, items, "u,i" pairs, context keys = active condition indices joined by ','),
+ * duplicates of a (pair, context) cell: last line wins; rating scale = sorted distinct values. */
+int cmi_dao_read(const char *path, cmi_dao_handle *out);
+int cmi_dao_destroy(cmi_dao_handle h);
+const char *cmi_dao_last_error(cmi_dao_handle h);
+/* out: numUsers, numItems, numUserItems, numContexts, numConditions, numContextDims, numRatings (lines), matrix entries */
+int cmi_dao_counts(cmi_dao_handle h, int64_t out[8]);
+/* the (user-item x context) rating matrix in MatrixIterator (CRS) order */
+int cmi_dao_matrix(cmi_dao_handle h, int32_t *ui, int32_t *ctx, double *r);
+/* getUserIdFromUI / getItemIdFromUI (DataDAO.java:1038-1046) as arrays over pair ids */
+int cmi_dao_ui_maps(cmi_dao_handle h, int32_t *ui_user, int32_t *ui_item);
+/* getContextConditionsList as CSR (ctx_ptr has numContexts+1 entries; cmi_dao_ctx_nnz gives len(ctx_conds)) */
+int64_t cmi_dao_ctx_nnz(cmi_dao_handle h);
+int cmi_dao_ctx_table(cmi_dao_handle h, int32_t *ctx_ptr, int32_t *ctx_conds);
+/* condDimensionMap (numConditions entries) and EmptyContextConditions (conditions whose token ends with ":na") */
+int cmi_dao_cond_info(cmi_dao_handle h, int32_t *cond_dim, int32_t *empty_conds, int32_t *n_empty);
+int cmi_dao_rating_scale(cmi_dao_handle h, double *out, int32_t cap, int32_t *n);
+/* raw key of an inner id; kind: 0 user, 1 item, 2 condition, 3 context key, 4 dimension, 5 "u,i" pair key */
+const char *cmi_dao_raw_id(cmi_dao_handle h, int kind, int32_t idx);
+
+/* Iteration order of a default java.util.HashMap<String,?> (JDK 8+) after inserting n DISTINCT keys in the given
+ * order: positions[i] = index of the i-th key `for (k : map.keySet())` visits.  *treeified = 1 if a bin reached
+ * the treeify threshold (order then not guaranteed).  Used by the transformer below. */
+int cmi_java_hashmap_order(int64_t n, const char *const *keys, int64_t *positions, int *treeified);
+/* DataTransformer.TransformationFromCompactToBinary + PublishNewRatingFiles + getHeader
+ * (src/carskit/data/processor/DataTransformer.java:231-259,266-329,155-163): rewrites a compact-format file
+ * (user,item,rating,dim1,dim2,...) as the binary-format train.csv, rows in the reference's HashMap order. */
+int cmi_transform_compact_to_binary(const char *in_path, const char *out_path, int *treeified);
+
 /* ---- host-only integer preprocessing (runs without a GPU) ------------------------------------- */
 
 /* The dependency-level schedule the default mode executes (carskit_amd/csrc/level_schedule.cpp):

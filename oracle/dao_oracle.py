@@ -1,0 +1,191 @@
+"""CPU restatement of the reference's data path for the binary / compact rating formats.  TEST INFRASTRUCTURE ONLY,
+PARITY UNPINNED by the reference (no tests, no JVM); pinned by hand-derived expectations on the reference's own
+sample file (sampleData/train_binary.csv, copied as data to tests/golden/) and by agreement with the product's
+C++ implementation (carskit_amd/csrc/data_dao.cpp), which was written separately.
+
+  read_data            DataDAO.readData                  src/carskit/data/processor/DataDAO.java:166-354
+  JavaHashMap          java.util.HashMap (JDK 8+) as an explicit bin table with resize splitting -- a SIMULATION
+                       of the published algorithm, deliberately not the closed form the product uses
+  compact_to_binary    DataTransformer.TransformationFromCompactToBinary / PublishNewRatingFiles / getHeader
+                       src/carskit/data/processor/DataTransformer.java:231-259, 266-329, 155-163
+"""
+import re
+
+
+def jtrim(s):
+    b, e = 0, len(s)
+    while b < e and ord(s[b]) <= 0x20:
+        b += 1
+    while e > b and ord(s[e - 1]) <= 0x20:
+        e -= 1
+    return s[b:e]
+
+
+def jsplit(s, regex, limit=0):
+    """java.lang.String.split semantics (limit 0 drops trailing empties, -1 keeps them)."""
+    parts, last = [], 0
+    for m in re.finditer(regex, s):
+        if m.end() == 0:      # zero-width/leading match at 0 yields no leading empty only for zero-width matches
+            if m.start() == m.end():
+                continue
+        parts.append(s[last:m.start()])
+        last = m.end()
+    if not parts and last == 0:
+        return [s]
+    parts.append(s[last:])
+    if limit == 0:
+        while parts and parts[-1] == "":
+            parts.pop()
+    return parts
+
+
+def read_lines(path):
+    data = open(path, "rb").read().decode("latin-1")
+    lines, cur, i, pending = [], [], 0, False
+    while i < len(data):
+        c = data[i]
+        i += 1
+        if c in "\r\n":
+            if c == "\r" and i < len(data) and data[i] == "\n":
+                i += 1
+            lines.append("".join(cur))
+            cur, pending = [], False
+        else:
+            cur.append(c)
+            pending = True
+    if pending:
+        lines.append("".join(cur))
+    return lines
+
+
+def read_data(path):
+    lines = read_lines(path)
+    header = jsplit(jtrim(lines[0]), r"[\t,]+")
+    dim_ids, cond_keys, cond_dim, empty = {}, [], [], []
+    for i in range(3, len(header)):
+        context = jtrim(header[i])
+        dim = jtrim(jsplit(context, ":")[0]) if context != "" else ""
+        dimc = dim_ids.setdefault(dim, len(dim_ids))
+        cond_keys.append(context)
+        cond_dim.append(dimc)
+        if context.endswith(":na"):
+            empty.append(i - 3)
+    users, items, uis, ctxs = {}, {}, {}, {}
+    ui_user, ui_item, ctx_conds = [], [], {}
+    table, scale, n_lines = {}, set(), 0
+    for line in lines[1:]:
+        data = jsplit(jtrim(line), ",", -1)
+        user, item, rate = data[0], data[1], float(jtrim(data[2]).rstrip("dDfF") if jtrim(data[2])[-1:] in "dDfF" else data[2])
+        scale.add(rate)
+        n_lines += 1
+        row = users.setdefault(user, len(users))
+        col = items.setdefault(item, len(items))
+        key = "%d,%d" % (row, col)
+        if key not in uis:
+            uis[key] = len(uis)
+            ui_user.append(row)
+            ui_item.append(col)
+        uic = uis[key]
+        conds = [i - 3 for i in range(3, len(data)) if int(jtrim(data[i])) == 1]
+        ctx = ",".join(str(c) for c in conds)
+        cc = ctxs.setdefault(ctx, len(ctxs))
+        ctx_conds[cc] = conds
+        table[(uic, cc)] = rate
+    entries = sorted(table.items())
+    return {
+        "users": list(users), "items": list(items), "uis": list(uis), "ctxs": list(ctxs), "dims": list(dim_ids),
+        "conds": cond_keys, "cond_dim": cond_dim, "empty": empty, "ui_user": ui_user, "ui_item": ui_item,
+        "ctx_conds": [ctx_conds[c] for c in range(len(ctxs))], "num_ratings": n_lines,
+        "scale": sorted(scale), "ui": [k[0] for k, _ in entries], "ctx": [k[1] for k, _ in entries],
+        "r": [v for _, v in entries],
+    }
+
+
+def jstring_hash(s):
+    h = 0
+    for ch in s:
+        h = (31 * h + ord(ch)) & 0xFFFFFFFF
+    return h
+
+
+class JavaHashMap:
+    """java.util.HashMap<String, V> insertion + iteration, as an explicit table of bins (lists).  put() appends to
+    the bin (tail insertion), resize doubles the table and splits every bin into lo/hi preserving order; iteration
+    walks the table in index order.  Treeification (bins of >= 8 entries) is not simulated; `max_bin` records the
+    largest bin ever seen so a caller can tell whether it could have happened."""
+
+    def __init__(self):
+        self.table = None
+        self.size = 0
+        self.threshold = 0
+        self.max_bin = 0
+
+    @staticmethod
+    def _spread(key):
+        h = jstring_hash(key)
+        return h ^ (h >> 16)
+
+    def _resize(self):
+        if self.table is None:
+            self.table = [[] for _ in range(16)]
+            self.threshold = 12
+            return
+        old = self.table
+        ocap = len(old)
+        new = [[] for _ in range(ocap * 2)]
+        for idx, b in enumerate(old):
+            for (k, v, h) in b:
+                (new[idx] if (h & ocap) == 0 else new[idx + ocap]).append((k, v, h))
+        self.table = new
+        self.threshold = int(ocap * 2 * 0.75)
+
+    def put(self, key, value):
+        if self.table is None:
+            self._resize()
+        h = self._spread(key)
+        b = self.table[h & (len(self.table) - 1)]
+        for i, (k, _, hh) in enumerate(b):
+            if hh == h and k == key:
+                b[i] = (k, value, hh)
+                return
+        b.append((key, value, h))
+        self.max_bin = max(self.max_bin, len(b))
+        self.size += 1
+        if self.size > self.threshold:
+            self._resize()
+
+    def keys(self):
+        return [k for b in (self.table or []) for (k, _, _) in b]
+
+    def items(self):
+        return [(k, v) for b in (self.table or []) for (k, v, _) in b]
+
+
+def compact_to_binary(in_path):
+    """Returns the lines of the reference's rewritten train.csv (without line terminators)."""
+    lines = read_lines(in_path)
+    header = jsplit(lines[0], ",", -1)
+    dims = [jtrim(h).lower() for h in header[3:]]
+    conditions = {}           # LinkedHashMultimap: dim -> ordered set of conditions
+    newlines = JavaHashMap()
+    for line in lines[1:]:
+        strs = jsplit(line, ",", -1)
+        rc = {}
+        for i in range(3, 3 + len(dims)):
+            cond = jtrim(strs[i]).lower() or "na"
+            rc[dims[i - 3]] = cond
+            conds = conditions.setdefault(dims[i - 3], [])
+            if cond not in conds:
+                conds.append(cond)
+        newlines.put(line, rc)
+    out = ["User, Item, Rating" + "".join(", %s:%s" % (d, c) for d in conditions for c in conditions[d])]
+    for key, rc in newlines.items():
+        bits = []
+        for d in conditions:
+            for c in conditions[d]:
+                bits.append("1" if rc[d] == c else "0")
+        skey = jsplit(key, ",", -1)
+        if len(skey) > 3:
+            key = ",".join(jtrim(x).lower() for x in skey[:3])
+        out.append(key + "," + ",".join(bits))
+    return out, newlines.max_bin

@@ -1,0 +1,148 @@
+"""DataDAO id-mapper and the compact->binary rewrite: the product's C++ (through the C ABI) against
+(1) hand-derived expectations on the reference's own sample file, (2) the independent Python restatement,
+bit-exact (integers and strings)."""
+import os
+import random
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from carskit_amd import dao
+from oracle import dao_oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def assert_same(d, o):
+    assert d.raw_ids("user") == o["users"] and d.raw_ids("item") == o["items"]
+    assert d.raw_ids("ui") == o["uis"] and d.raw_ids("ctx") == o["ctxs"]
+    assert d.raw_ids("cond") == o["conds"] and d.raw_ids("dim") == o["dims"]
+    assert d.cond_dim.tolist() == o["cond_dim"] and d.empty_context_conditions == o["empty"]
+    assert d.ui_user.tolist() == o["ui_user"] and d.ui_item.tolist() == o["ui_item"]
+    assert [d.ctx_conds[d.ctx_ptr[c]:d.ctx_ptr[c + 1]].tolist() for c in range(d.num_contexts)] == o["ctx_conds"]
+    assert d.num_ratings == o["num_ratings"] and d.rating_scale == o["scale"]
+    assert d.ui.tolist() == o["ui"] and d.ctx.tolist() == o["ctx"] and d.r.tolist() == o["r"]
+
+
+def test_sample_train_binary_hand_derived():
+    """Expectations derived by hand from DataDAO.readData on the reference's sampleData/train_binary.csv
+    (SURVEY.md 8c-iv)."""
+    d = dao.DataDAO(os.path.join(GOLDEN, "train_binary.csv"))
+    assert (d.num_ratings, d.num_users, d.num_items, d.num_user_items, d.num_contexts, d.num_conditions,
+            d.num_context_dims) == (20, 17, 2, 18, 8, 10, 3)
+    assert d.empty_context_conditions == [2, 6, 7]
+    assert d.raw_ids("user")[:4] == ["1077", "1052", "1070", "1045"]
+    assert d.raw_ids("item") == ["tt0088763", "tt0120338"]
+    assert d.raw_ids("ctx")[:5] == ["0,5,9", "0,5,8", "1,4,9", "1,5,9", "0,4,8"]
+    assert list(zip(d.ui.tolist(), d.ctx.tolist(), d.r.tolist()))[:6] == [
+        (0, 0, 4.0), (1, 1, 5.0), (2, 2, 5.0), (2, 3, 5.0), (3, 3, 4.0), (4, 4, 5.0)]
+    assert d.r.sum() / np.count_nonzero(d.r) == 3.95
+    assert d.raw_ids("dim") == ["companion", "location", "time"]
+    assert d.cond_dim.tolist() == [0, 0, 0, 0, 1, 1, 1, 2, 2, 2]
+    assert_same(d, dao_oracle.read_data(os.path.join(GOLDEN, "train_binary.csv")))
+    rd = d.rating_data()
+    assert rd.n == 20 and rd.u[:3].tolist() == [0, 1, 2] and rd.min_rate == 1.0 and rd.max_rate == 5.0
+
+
+def test_sample_test_binary_matches_oracle():
+    p = os.path.join(GOLDEN, "test_binary.csv")
+    assert_same(dao.DataDAO(p), dao_oracle.read_data(p))
+
+
+def _write_random_binary(path, rng, n_lines, n_users, n_items, dims, messy):
+    conds = [(d, c) for d, k in enumerate(dims) for c in range(k)]
+    sep = ",\t" if messy else ","
+    hdr = ["User", " Item", " Rating"] + [" dim%d:%s" % (d, "na" if c == 0 else "c%d" % c) for d, c in conds]
+    lines = [sep.join(hdr) + ("  " if messy else "")]
+    for _ in range(n_lines):
+        u = "u%d" % rng.randrange(n_users)
+        i = "i%d" % rng.randrange(n_items)
+        if messy and rng.random() < 0.2:
+            u = u + " "                      # user keys are NOT trimmed individually
+        r = rng.choice(["1", "2", "3.5", "4", "5", "0", " 2 ", "4.0d", "1e0"]) if messy else str(rng.randrange(1, 6))
+        bits = []
+        for d, k in enumerate(dims):
+            on = rng.randrange(k) if (not messy or rng.random() < 0.9) else -1   # messy: sometimes no active condition
+            bits += [(" 1" if messy else "1") if c == on else "0" for c in range(k)]
+        lines.append("%s%s,%s,%s%s" % ("  " if messy else "", u, i, r, "".join("," + b for b in bits)))
+    open(path, "w", newline="").write(("\r\n" if messy else "\n").join(lines) + ("" if messy else "\n"))
+
+
+@settings(max_examples=30, deadline=None)
+@given(seed=st.integers(0, 10_000), messy=st.booleans())
+def test_dao_matches_oracle_on_random_files(tmp_path_factory, seed, messy):
+    rng = random.Random(seed)
+    p = str(tmp_path_factory.mktemp("dao") / "r.csv")
+    _write_random_binary(p, rng, rng.randrange(1, 60), rng.randrange(1, 8), rng.randrange(1, 6),
+                         [rng.randrange(1, 4) for _ in range(rng.randrange(0, 4))], messy)
+    assert_same(dao.DataDAO(p), dao_oracle.read_data(p))
+
+
+def test_dao_errors():
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "bad.csv")
+        open(p, "w").write("User,Item,Rating,a:x\nu,i,abc,1\n")
+        with pytest.raises(Exception):
+            dao.DataDAO(p)
+        open(p, "w").write("User,Item,Rating,a:x\nu,i,3,\n")       # empty flag -> NumberFormatException
+        with pytest.raises(Exception):
+            dao.DataDAO(p)
+        with pytest.raises(Exception):
+            dao.DataDAO(os.path.join(td, "missing.csv"))
+
+
+def test_java_hashmap_order_closed_form_equals_simulation():
+    rng = random.Random(5)
+    for n in (0, 1, 5, 12, 13, 24, 25, 100, 1000, 5043):
+        keys = ["%d,tt%07d,%d,%s" % (rng.randrange(2000), rng.randrange(10 ** 7), rng.randrange(1, 6),
+                                      rng.choice(["Weekend", "Weekday", ""])) + str(i) for i in range(n)]
+        m = dao_oracle.JavaHashMap()
+        for k in keys:
+            m.put(k, 1)
+        pos, tree = dao.java_hashmap_order(keys)
+        assert [keys[i] for i in pos] == m.keys()
+        assert tree == (m.max_bin >= 8 and n > 48) or not tree
+
+
+def test_java_string_hash_known_answers():
+    # published String.hashCode values
+    assert dao_oracle.jstring_hash("") == 0
+    assert dao_oracle.jstring_hash("a") == 97
+    assert dao_oracle.jstring_hash("hello") == 99162322
+    assert dao_oracle.jstring_hash("Hello, World!") == (1498789909 & 0xFFFFFFFF)
+    # "Aa" and "BB" collide (the classic example)
+    assert dao_oracle.jstring_hash("Aa") == dao_oracle.jstring_hash("BB") == 2112
+
+
+def test_compact_to_binary_sample(tmp_path):
+    src = os.path.join(GOLDEN, "train_compact.csv")
+    out = str(tmp_path / "train.csv")
+    dao.transform_compact_to_binary(src, out)
+    want, _ = dao_oracle.compact_to_binary(src)
+    got = open(out).read().split("\n")
+    assert got[-1] == "" and got[:-1] == want
+    # the header the reference would write: dims in column order, conditions in first-seen order
+    assert got[0].startswith("User, Item, Rating, ")
+    # and the rewritten file loads through the DAO
+    d = dao.DataDAO(out)
+    assert d.num_ratings == len(want) - 1
+
+
+@settings(max_examples=20, deadline=None)
+@given(seed=st.integers(0, 10_000))
+def test_compact_to_binary_random(tmp_path_factory, seed):
+    rng = random.Random(seed)
+    td = tmp_path_factory.mktemp("tr")
+    src, out = str(td / "c.csv"), str(td / "b.csv")
+    dims = ["Time", " Location", "Companion "][:rng.randrange(1, 4)]
+    vals = [["Weekend", "Weekday", ""], ["Home", "Cinema", "NA"], ["Alone", "Family", "Partner", " friends"]]
+    lines = ["userid,itemid,rating," + ",".join(dims)]
+    for _ in range(rng.randrange(1, 200)):
+        lines.append("%d,tt%05d,%d,%s" % (rng.randrange(50), rng.randrange(30), rng.randrange(1, 6),
+                                        ",".join(rng.choice(vals[d]) for d in range(len(dims)))))
+    open(src, "w").write("\n".join(lines) + "\n")
+    dao.transform_compact_to_binary(src, out)
+    want, _ = dao_oracle.compact_to_binary(src)
+    assert open(out).read().split("\n")[:-1] == want
