@@ -1,0 +1,73 @@
+"""BASELINE configs C1 and C2 as GPU parity cases.
+C1: BiasedMF k=10 on DePaulMovie through setting.conf and the driver, engine = libcarskit_mi355x (fp32 state),
+    against the committed golden MAE/RMSE minted by the CPU oracle (tests/golden/golden_c1_depaul_biasedmf.json).
+C2: CAMF_C k=64 fp32 on a Frappe-SHAPED synthetic set (957 users, 4 082 items, 8 dimensions / 343 conditions,
+    96 203 ratings; the real Frappe file may not be redistributed), serial schedule, against the oracle."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from carskit_amd import capi, main, recommender, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_c1_biasedmf_depaul_on_gpu_matches_golden(tmp_path):
+    shutil.copyfile(os.path.join(GOLDEN, "depaul_ratings_compact.csv"), tmp_path / "ratings.txt")
+    conf = open(os.path.join(GOLDEN, "depaul_setting.conf")).read().replace("PLACEHOLDER_SET_BY_TEST", str(tmp_path / "ratings.txt"))
+    (tmp_path / "setting.conf").write_text(conf)
+    lines = []
+    avg, algos, _ = main.run(str(tmp_path / "setting.conf"), log=lines.append, conf_overrides={"num_iters": 30})
+    want = json.load(open(os.path.join(GOLDEN, "golden_c1_depaul_biasedmf.json")))
+    for a, w in zip(algos, want["folds"]):
+        assert a.testMatrix.n == w["n_test"]
+        assert abs(a.measures["RMSE"] - w["RMSE"]) <= 1e-5 and abs(a.measures["MAE"] - w["MAE"]) <= 1e-5
+    assert abs(avg["RMSE"] - want["avg_RMSE"]) <= 1e-5
+    assert lines[-1].startswith("Final Results by BiasedMF, MAE: ")
+    # fp64 + strict: the driver's numbers are the oracle's, digit for digit
+    avg64, algos64, _ = main.run(str(tmp_path / "setting.conf"), log=lambda *a: None,
+                                 conf_overrides={"num_iters": 30, "flags": capi.FLAG_STATE_F64 | capi.FLAG_STRICT |
+                                                 capi.FLAG_SCHED_SERIAL})
+    for a, w in zip(algos64, want["folds"]):
+        assert abs(a.measures["RMSE"] - w["RMSE"]) <= 1e-12 and abs(a.measures["MAE"] - w["MAE"]) <= 1e-12
+
+
+def frappe_shaped(seed=7):
+    """957 users x 4 082 items, 8 context dimensions with Frappe's cardinalities, ~96K ratings."""
+    rng = np.random.default_rng(seed)
+    n, dims = 96203, [7, 7, 2, 3, 2, 9, 80, 233]
+    base = synth.generate(957, 4082, 0, 1, n, seed=seed, item_zipf=1.05)
+    m = base.n
+    conds = np.stack([rng.integers(0, k, m) for k in dims], axis=1)
+    offs = np.concatenate([[0], np.cumsum(dims)[:-1]])
+    rows = conds + offs
+    keys, first, inv = np.unique(rows, axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")
+    rank = np.empty(len(keys), np.int64)
+    rank[order] = np.arange(len(keys))
+    ctx = rank[inv.reshape(-1)].astype(np.int32)
+    table = keys[order]
+    ctx_ptr = (np.arange(len(table) + 1) * len(dims)).astype(np.int32)
+    r = np.clip(np.rint(np.log1p(rng.pareto(1.2, m) * 3)), 1, 9).astype(np.float64)   # heavy-tailed usage counts, log scale
+    return synth.RatingData(base.n_users, base.n_items, int(sum(dims)), len(dims), base.u, base.j, ctx, r, ctx_ptr,
+                            table.reshape(-1).astype(np.int32), 1.0, 9.0)
+
+
+def test_c2_camf_c_k64_frappe_shaped():
+    data = frappe_shaped()
+    assert data.n_conds == 343 and data.n_dims == 8
+    train, test = synth.split(data, 0.2)
+    conf = recommender.Conf(num_factors=64, num_iters=15, init_lrate=util.LR, bold_driver=True, regU=util.REG,
+                            regI=util.REG, regB=util.REG, regC=util.REGC, verbose=False)
+    gpu = recommender.CAMF_C(train, test, -1, conf)
+    cpu = recommender.CAMF_C(train, test, -1, conf, engine_factory=util.OracleEngine)
+    mg, mc = gpu.execute(), cpu.execute()
+    assert gpu.lrates == cpu.lrates                               # same bold-driver decisions
+    np.testing.assert_allclose(gpu.losses, cpu.losses, rtol=2e-5)
+    assert abs(mg["RMSE"] - mc["RMSE"]) <= 1e-5 and abs(mg["MAE"] - mc["MAE"]) <= 1e-5   # north_star fp32 bar
+    assert gpu.engine.inst.schedule_info()["kind"] == "serial"

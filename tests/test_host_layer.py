@@ -1,0 +1,140 @@
+"""Host layer above the C ABI (config parser, java.util.Random stream, fold splitter, recommender classes, driver)
+on CPU.  The compute engine is injected (the oracle) -- the product's only engine is the GPU library."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from carskit_amd import config, javarand, main, recommender, splitter, synth
+from oracle import oracle_np
+from tests import util
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_line_configer_grammar():
+    lc = config.LineConfiger("2e-2 -max -1 -bold-driver")
+    assert lc.get_main_param() == "2e-2" and lc.contains("-bold-driver")
+    assert lc.get_float("-max") == -1.0                       # "-1" is numeric: a value, not a new key
+    assert lc.get_float("-decay", -1.0) == -1.0
+    assert config.java_float(lc.get_main_param()) == 0.019999999552965164   # Java float 0.02f promoted
+    lc = config.LineConfiger("0.0001 -c 0.001")
+    assert config.java_float(lc.get_main_param()) == 9.999999747378752e-05
+    assert lc.get_float("-c") == float(np.float32(0.001)) and lc.get_float("-u", 7.0) == 7.0
+    lc = config.LineConfiger("cv -k 5 -p on --rand-seed 1 --test-view all")
+    assert lc.get_main_param() == "cv" and lc.get_int("-k") == 5 and lc.is_on("-p") and lc.get_long("--rand-seed") == 1
+    assert lc.get_string("--test-view") == "all" and lc.get_string("--early-stop") is None
+    lc = config.LineConfiger("-folder CARSKit.Workspace -verbose on, off --to-file results_all_2016.txt")
+    assert lc.get_main_param() is None and lc.get_string("-folder") == "CARSKit.Workspace"
+    assert lc.is_on("-verbose") and lc.params["-verbose"] == ["on", "off"]
+    lc = config.LineConfiger("on -topN 10")
+    assert lc.is_main_on() and lc.get_int("-topN") == 10
+    lc = config.LineConfiger("-lw 0.01 -lf 0.02")
+    assert lc.get_float("-lw") == float(np.float32(0.01))
+
+
+def test_file_configer_reads_setting_conf(tmp_path):
+    p = tmp_path / "s.conf"
+    p.write_text("# comment\ndataset.ratings.lins=/x/y/ratings.txt\nrecommender=camf_ci\nnum.factors=10\n"
+                 "learn.rate=2e-2 -max -1 -bold-driver\n! other comment\nkey\\ with\\ space = v\\\\w\n")
+    cf = config.FileConfiger(str(p))
+    assert cf.get_path("dataset.ratings") == "/x/y/ratings.txt"
+    assert cf.get_int("num.factors") == 10 and cf.get_int("num.max.iter", 100) == 100
+    assert cf.get_param_options("learn.rate").contains("-bold-driver")
+    assert cf.props["key with space"] == "v\\w"
+    c = recommender.Conf(cf)
+    assert c.bold_driver and c.init_lrate == 0.019999999552965164 and c.num_factors == 10
+
+
+def test_java_random_product_equals_oracle_stream():
+    for seed in (1, 42, 20260927):
+        a, b = javarand.JavaRandom(seed), oracle_np.JavaRandom(seed)
+        assert [a.next_double() for _ in range(50)] == [b.next_double() for _ in range(50)]
+    assert javarand.JavaRandom(42).next_double() == 0.7275636800328681
+
+
+def test_split_folds_follows_the_reference_recipe():
+    n, k, seed = 23, 5, 1
+    labels, kk = splitter.split_folds(n, k, seed)
+    assert kk == 5 and sorted(np.bincount(labels)[1:].tolist()) == [4, 4, 5, 5, 5]
+    # recipe restated in the open: draw, label by position, sort by draw, deal back in CRS order
+    g = oracle_np.JavaRandom(seed)
+    rdm = [g.next_double() for _ in range(n)]
+    fold = [int(i / (n / 5.0)) + 1 for i in range(n)]
+    want = [f for _, f in sorted(zip(rdm, fold))]
+    assert labels.tolist() == want
+    labels2, kk2 = splitter.split_folds(3, 5, seed)          # more folds than ratings
+    assert kk2 == 3 and sorted(labels2.tolist()) == [1, 2, 3]
+    data = util.small_data(n=23, seed=2)
+    tr, te = splitter.kth_fold(data.subset(np.arange(23)), labels, 2)
+    assert tr.n + te.n == 23 and te.n == int((labels == 2).sum())
+
+
+def _depaul_conf(tmp_path):
+    shutil.copyfile(os.path.join(GOLDEN, "depaul_ratings_compact.csv"), tmp_path / "ratings.txt")
+    conf = open(os.path.join(GOLDEN, "depaul_setting.conf")).read().replace("PLACEHOLDER_SET_BY_TEST", str(tmp_path / "ratings.txt"))
+    (tmp_path / "setting.conf").write_text(conf)
+    return str(tmp_path / "setting.conf")
+
+
+def test_c1_biasedmf_depaul_via_setting_conf(tmp_path):
+    """BASELINE config C1: setting.conf -> compact->binary rewrite -> DataDAO -> 5-fold CV -> BiasedMF k=10 ->
+    MAE/RMSE, with the oracle as the engine (plumbing; no GPU)."""
+    lines = []
+    avg, algos, rate_dao = main.run(_depaul_conf(tmp_path), engine_factory=util.OracleEngine, log=lines.append,
+                                    conf_overrides={"num_iters": 30})
+    assert (rate_dao.num_users, rate_dao.num_items, rate_dao.num_context_dims) == (97, 79, 3)
+    # 5 043 lines in the file, 8 of them exact repeats: the transformer keys its HashMap by the whole line, so the
+    # rewritten train.csv -- and hence the reference's own run -- has 5 035 rating lines
+    assert rate_dao.num_ratings == 5035 and rate_dao.rating_scale == [1.0, 2.0, 3.0, 4.0, 5.0]
+    assert len(algos) == 5 and all(a.algo_name == "BiasedMF" for a in algos)
+    assert sum(a.testMatrix.n for a in algos) == rate_dao.nnz
+    assert lines[-1].startswith("Final Results by BiasedMF, MAE: ") and ", RMSE: " in lines[-1] and "NAME: " in lines[-1]
+    assert 0.8 < avg["RMSE"] < 1.3 and 0.5 < avg["MAE"] < 1.1              # sane for DePaulMovie
+    # each fold is exactly a direct oracle run on the same split and init (the classes add nothing numerical)
+    a = algos[2]
+    st = synth.init_state("BiasedMF", a.trainMatrix, 10, seed=a.conf.init_seed)
+    orc = util.c_oracle("BiasedMF", a.trainMatrix, 10, st, a.globalMean)
+    losses, lrs, _ = orc.build_model(30, util.LR, bold_driver=True)
+    assert a.losses == losses.tolist() and a.lrates == lrs.tolist()
+    golden = os.path.join(GOLDEN, "golden_c1_depaul_biasedmf.json")
+    rec = {"folds": [{"MAE": x.measures["MAE"], "RMSE": x.measures["RMSE"], "n_test": x.testMatrix.n} for x in algos],
+           "avg_MAE": avg["MAE"], "avg_RMSE": avg["RMSE"], "iters": 30}
+    if os.environ.get("CARSKIT_WRITE_GOLDEN"):
+        json.dump(rec, open(golden, "w"), indent=1)
+    want = json.load(open(golden))
+    assert rec["folds"] == want["folds"] and rec["avg_RMSE"] == want["avg_RMSE"]
+
+
+def test_driver_rejects_unaccelerated_recommenders(tmp_path):
+    conf = _depaul_conf(tmp_path)
+    txt = open(conf).read().replace("recommender=biasedmf", "recommender=itemknn")
+    open(conf, "w").write(txt)
+    with pytest.raises(ValueError):
+        main.run(conf, engine_factory=util.OracleEngine, log=lambda *a: None)
+
+
+FRAPPE_ZIP = "/root/reference/context-aware_data_sets/Mobile_Frappe.zip"
+
+
+@pytest.mark.skipif(not os.path.exists(FRAPPE_ZIP), reason="the Frappe data may not be redistributed; only where the reference is mounted")
+def test_frappe_loads_through_transformer_and_dao(tmp_path):
+    """BASELINE config C2's data path on the real file (tab-separated -> comma CSV first, as CARSKit requires)."""
+    import zipfile
+    from carskit_amd import dao
+    from oracle import dao_oracle
+    raw = zipfile.ZipFile(FRAPPE_ZIP).read("Mobile_Frappe/frappe/frappe.csv").decode("utf-8")
+    src = tmp_path / "frappe_compact.csv"
+    src.write_text("\n".join(",".join(line.split("\t")) for line in raw.splitlines()) + "\n")
+    out = tmp_path / "train.csv"
+    tree = dao.transform_compact_to_binary(str(src), str(out))
+    d = dao.DataDAO(str(out))
+    assert (d.num_users, d.num_items, d.num_context_dims) == (957, 4082, 8)
+    assert d.num_ratings == 96203 and d.num_conditions == 7 + 7 + 2 + 3 + 2 + 9 + 80 + 233
+    want, max_bin = dao_oracle.compact_to_binary(str(src))
+    got = open(out).read().split("\n")[:-1]
+    assert got[0] == want[0] and sorted(got[1:]) == sorted(want[1:])
+    if max_bin < 8:              # no bin could have been treeified: the row ORDER is the reference's too
+        assert got == want and not tree

@@ -47,3 +47,32 @@ def c_oracle(model, data, k, state, gm, regU=REG, regI=REG, regB=REG, regC=REGC)
     st = {n: np.array(a, dtype=np.float64, copy=True) for n, a in state.items()}
     return oracle_c.Oracle(model, k, data.n_users, data.n_items, data.n_conds, u, j, ctx, r, data.ctx_ptr,
                            data.ctx_conds, st, gm, regU, regI, regB, regC)
+
+
+class OracleEngine:
+    """The CPU oracle behind carskit_amd.recommender's engine interface (tests only: the product engine is
+    recommender.GpuEngine)."""
+
+    def __init__(self, model, k, data, tuples, hp, flags=0, device=0):
+        from oracle import oracle_c
+        self.model, self.k, self.data, self.tuples, self.hp = model, k, data, tuples, hp
+        self.oracle_c = oracle_c
+        self.orc = None
+
+    def set_states(self, st):
+        u, j, ctx, r = self.tuples
+        st = {n: np.array(a, dtype=np.float64, copy=True) for n, a in st.items()}
+        d = self.data
+        self.orc = self.oracle_c.Oracle(self.model, self.k, d.n_users, d.n_items, d.n_conds, u, j,
+                                        ctx if ctx is not None else np.zeros(len(r), np.int32), r, d.ctx_ptr,
+                                        d.ctx_conds, st, self.hp["gm"], self.hp["regU"], self.hp["regI"],
+                                        self.hp["regB"], self.hp["regC"])
+
+    def get_states(self):
+        return {n: a for n, a in self.orc.state.items() if a is not None}
+
+    def epoch(self, lr):
+        return self.orc.epoch(lr)
+
+    def eval_ratings(self, u, j, ctx, r, lo, hi):
+        return self.orc.eval_ratings(u, j, ctx, r, lo, hi)
