@@ -340,7 +340,9 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     FlowSchedule fsch;
     h->flow = false;
     h->flow_blocks = 0;
-    if (h->want_flow && h->fast && n > 0) {
+    const bool tables_fit_raw_buffer = (int64_t)h->n_users * h->k * 4 < ((int64_t)1 << 32) &&
+                                       (int64_t)h->n_items * h->k * 4 < ((int64_t)1 << 32);
+    if (h->want_flow && h->fast && n > 0 && tables_fit_raw_buffer) {
         h->flow_blocks = flow_grid_blocks(h->device, h->k);
         if (h->flow_blocks > 0) {
             if (!build_flow_schedule(n, u, j, h->n_users, h->n_items, fsch))
@@ -501,8 +503,7 @@ static hipError_t enqueue_levels(cmi_instance *h) {
         return launch_serial<float>(make_args<float>(h), cfg, h->n, h->d_loss, h->stream);
     }
     if (h->flow) {
-        FlowArgs fa{h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->n_chunks, 0};
-        if (const char *env = getenv("CMI_FLOW_DEBUG")) fa.debug = atoi(env);
+        FlowArgs fa{h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->n_chunks};
         e = hipMemsetAsync(h->d_ver_u, 0, (size_t)h->n_users * 4, h->stream);
         if (e == hipSuccess) e = hipMemsetAsync(h->d_ver_j, 0, (size_t)h->n_items * 4, h->stream);
         if (e == hipSuccess) e = launch_flow_f32(make_args<float>(h), fa, cfg, h->flow_blocks, h->stream);

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
 // tuples of that user / item retired so far in this epoch, and the tuple at schedule position p may run
 // once they equal seq_u[p] / seq_j[p].  Because model rows now travel between workgroups (and XCDs, whose
 // L2s are not coherent with each other) INSIDE a launch, every access to model state is device-coherent:
-//   * row loads/stores are `global_load/store_dwordx4 ... sc0 sc1` (L1 bypass + write-through),
+//   * row loads/stores are `buffer_load/store_dwordx4 ... sc0 sc1` (L1 bypass + write-through),
 //   * the producer drains its stores (`s_waitcnt vmcnt(0)`) before publishing the new version with a
 //     relaxed agent-scope store; the consumer polls the version with relaxed agent-scope loads and only
 //     then issues its row loads.
@@ -240,13 +240,20 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
 // (no __syncthreads): a wave owns 4 tuples of one level per step and accumulates its loss in registers.
 // Every spin is bounded; on overflow the kernel raises *error and carries on (the host reports it).
 
-__device__ __forceinline__ f32x4 ld_row_coherent(const f32x4 *p) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
+// Device-coherent 16-byte row traffic through raw buffer instructions with cache policy sc0|sc1 (aux 17):
+// compiler-tracked (its own s_waitcnt), unlike inline-asm loads whose destination registers the allocator may
+// copy before a hand-placed wait.  A raw buffer addresses base + 32-bit byte offset: the table must be < 4 GiB
+// (checked on the host; larger models use the level schedule).
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+#define CMI_CPOL_SC0_SC1 17
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffff, 0x00020000);
 }
-__device__ __forceinline__ void st_row_coherent(f32x4 *p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+__device__ __forceinline__ f32x4 ld_row_coherent(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, CMI_CPOL_SC0_SC1));
+}
+__device__ __forceinline__ void st_row_coherent(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)byte_off, 0, CMI_CPOL_SC0_SC1);
 }
 __device__ __forceinline__ float ld_f32_coherent(const float *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -267,6 +274,7 @@ __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs f
     const int gib = tid >> 4;
     const int wave = tid >> 6;
     double wloss = 0.0; // this wave's loss over all its tuples (fixed order: static chunk assignment)
+    const __amdgpu_buffer_rsrc_t rsP = table_rsrc(a.P), rsQ = table_rsrc(a.Q);
 
     const HParams hp = *a.hp;
     const float lr = (float)hp.lr, regU = (float)hp.regU, regI = (float)hp.regI, regB = (float)hp.regB,
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs f
         }
 
         // wait until both predecessors have retired (usually true on the first poll)
-        bool ready = !live || (fa.debug & 1);
+        bool ready = !live;
         unsigned spins = 0;
         while (true) {
             if (!ready) {
@@ -306,20 +314,12 @@ __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs f
 
         double gloss = 0.0;
         if (live) {
-            f32x4 *prow = reinterpret_cast<f32x4 *>(a.P + (size_t)uu * K) + l16;
-            f32x4 *qrow = reinterpret_cast<f32x4 *>(a.Q + (size_t)jj * K) + l16;
+            const uint32_t poff = (uint32_t)uu * (K * 4) + l16 * 16, qoff = (uint32_t)jj * (K * 4) + l16 * 16;
             f32x4 p[VPL], q[VPL];
-            if (fa.debug & 4) {
 #pragma unroll
-                for (int v = 0; v < VPL; ++v) p[v] = prow[v * 16];
+            for (int v = 0; v < VPL; ++v) p[v] = ld_row_coherent(rsP, poff + v * 256);
 #pragma unroll
-                for (int v = 0; v < VPL; ++v) q[v] = qrow[v * 16];
-            } else {
-#pragma unroll
-                for (int v = 0; v < VPL; ++v) p[v] = ld_row_coherent(prow + v * 16);
-#pragma unroll
-                for (int v = 0; v < VPL; ++v) q[v] = ld_row_coherent(qrow + v * 16);
-            }
+            for (int v = 0; v < VPL; ++v) q[v] = ld_row_coherent(rsQ, qoff + v * 256);
 
             float bu = 0.f, bj = 0.f, bic = 0.f, buc = 0.f;
             if (M::has_bu) bu = ld_f32_coherent(a.userBias + uu);
@@ -335,15 +335,6 @@ __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs f
                     buc = ld_f32_coherent(puc);
                 }
             }
-            // the asm loads are invisible to the compiler's waitcnt pass: wait here, and tie the registers
-            // to the wait so no use can be scheduled above it
-            if (VPL == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(q[0])::"memory");
-            if (VPL == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(p[VPL > 1 ? 1 : 0]), "+v"(q[0]), "+v"(q[VPL > 1 ? 1 : 0])::"memory");
-            if (VPL == 4)
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(p[0]), "+v"(p[VPL > 1 ? 1 : 0]), "+v"(p[VPL > 2 ? 2 : 0]), "+v"(p[VPL > 3 ? 3 : 0]),
-                               "+v"(q[0]), "+v"(q[VPL > 1 ? 1 : 0]), "+v"(q[VPL > 2 ? 2 : 0]), "+v"(q[VPL > 3 ? 3 : 0])::"memory");
-
             float part = 0.f;
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
@@ -393,13 +384,8 @@ __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs f
     lsum += (regU * p[v].c) * p[v].c + (regI * q[v].c) * q[v].c;
                 CMI_UPD(x) CMI_UPD(y) CMI_UPD(z) CMI_UPD(w)
 #undef CMI_UPD
-                if (fa.debug & 4) {
-                    prow[v * 16] = pn;
-                    qrow[v * 16] = qn;
-                } else {
-                    st_row_coherent(prow + v * 16, pn);
-                    st_row_coherent(qrow + v * 16, qn);
-                }
+                st_row_coherent(rsP, poff + v * 256, pn);
+                st_row_coherent(rsQ, qoff + v * 256, qn);
             }
 
             const float reg_loss = row_sum16(lsum);
@@ -414,7 +400,7 @@ __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs f
         }
 
         // retire: all of this wave's state stores are written through before the versions move
-        if (!(fa.debug & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (live && l16 == 0) {
             __hip_atomic_store(fa.ver_u + uu, want_u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(fa.ver_j + jj, want_j + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -762,6 +748,7 @@ static hipError_t launch_flow_model(const SgdArgs<float> &a, const FlowArgs &fa,
     switch (a.k) {
     case 64: hipLaunchKernelGGL((sgd_flow_f32<MODEL, 1>), grid, block, 0, s, a, fa); break;
     case 128: hipLaunchKernelGGL((sgd_flow_f32<MODEL, 2>), grid, block, 0, s, a, fa); break;
+    case 256: hipLaunchKernelGGL((sgd_flow_f32<MODEL, 4>), grid, block, 0, s, a, fa); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -790,8 +777,7 @@ int flow_grid_blocks(int device, int k) {
     hipError_t e = hipErrorInvalidValue;
     if (k == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_flow_f32<CAMF_CUCI, 1>, 256, 0);
     if (k == 128) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_flow_f32<CAMF_CUCI, 2>, 256, 0);
-    // k == 256 is not offered yet: with eight 16-byte asm loads in flight the register allocator may copy a
-    // destination before the hand-placed wait (observed: NaN) -> falls back to the level schedule
+    if (k == 256) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_flow_f32<CAMF_CUCI, 4>, 256, 0);
     if (e != hipSuccess || per_cu < 2) return 0;
     int use = per_cu - 1;
     if (use > 4) use = 4;

@@ -53,7 +53,6 @@ struct FlowArgs {
     uint32_t *ver_u, *ver_j;       // per user / per item: tuples retired this epoch (zeroed before the launch)
     int32_t *error;                // set to 1 if a wait exceeded its bound (schedule stalled)
     int64_t n_chunks;              // padded positions / 16
-    int32_t debug;                 // timing experiments only (CMI_FLOW_DEBUG): 1 skip waits, 2 skip store drain, 4 plain row traffic
 };
 int flow_grid_blocks(int device, int k);       // fully co-resident grid size for the flow kernel (0 = unsupported)
 hipError_t launch_flow_f32(const SgdArgs<float> &a, const FlowArgs &fa, const LaunchCfg &cfg, int grid_blocks,

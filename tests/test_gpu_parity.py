@@ -224,7 +224,7 @@ def test_level_order_is_free():
 
 def test_dist_gpu_engine_aliases_device_state_and_exchange_is_identity_at_world1():
     """carskit_amd.dist on a real GPU: the item-side containers are aliased as torch tensors through
-    cmi_state_device_ptr (zero copy), and with one rank the RCCL exchange is the identity."""
+    cmi_state_device_ptr (zero copy), and with one rank the RCCL exchange is the identity (to fp32 rounding)."""
     import os
     import socket
     import torch
@@ -254,15 +254,16 @@ def test_dist_gpu_engine_aliases_device_state_and_exchange_is_identity_at_world1
         runner = cdist.ShardedEpochRunner(a, tdist, device_index=0, always_exchange=True)
         for _ in range(3):
             la, lb = runner.epoch(util.LR), b.train_epoch(util.LR)
-            assert la == lb
+            assert abs(la - lb) <= 1e-6 * abs(lb)
+        # start + (x - start) re-rounds x in fp32, so the exchange is the identity only to an ulp
         for name in ("P", "Q", "userBias", "icBias"):
-            assert np.array_equal(a.get_state(name, np.float32), b.get_state(name, np.float32)), name
+            np.testing.assert_allclose(a.get_state(name, np.float32), b.get_state(name, np.float32), rtol=1e-5, atol=1e-7)
     finally:
         tdist.destroy_process_group()
 
 
 @pytest.mark.parametrize("model", [m for m in util.MODELS if m != "CAMF_C"])
-@pytest.mark.parametrize("k", [64, 128])
+@pytest.mark.parametrize("k", [64, 128, 256])
 def test_flow_schedule_bit_identical_to_level_schedule(model, k):
     """The dataflow launch (levels overlapped, per-row version counters, device-coherent row traffic) must give
     the bit-identical fp32 model and loss trajectory as one launch per level: any stale cross-XCD read or a
@@ -294,7 +295,5 @@ def test_flow_schedule_hot_item_and_fallback():
         assert np.array_equal(arr, flw.get_state(name, np.float32)), name
     _, fb = make_pair("CAMF_CI", data, 10, FLOW)
     assert fb.schedule_info()["kind"] == "level"
-    _, fb256 = make_pair("CAMF_CI", data, 256, FLOW)
-    assert fb256.schedule_info()["kind"] == "level"
     _, fb64 = make_pair("CAMF_CI", data, 64, FLOW | F64)
     assert fb64.schedule_info()["kind"] == "level"
