@@ -429,8 +429,8 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (e == hipSuccess) e = upload((void **)&h->d_seq_j, fsch.seq_j, h->stream);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_ver_u, (size_t)h->n_users * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_ver_j, (size_t)h->n_items * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_flow_err, 4);
-        if (e == hipSuccess) e = hipMemsetAsync(h->d_flow_err, 0, 4, h->stream);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_flow_err, 16);
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_flow_err, 0, 16, h->stream);
     }
     if (e == hipSuccess && contextual) {
         std::vector<int32_t> cp(ctx_ptr, ctx_ptr + n_ctx + 1), cc(ctx_conds, ctx_conds + ctx_ptr[n_ctx]);
@@ -503,7 +503,7 @@ static hipError_t enqueue_levels(cmi_instance *h) {
         return launch_serial<float>(make_args<float>(h), cfg, h->n, h->d_loss, h->stream);
     }
     if (h->flow) {
-        FlowArgs fa{h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->n_chunks};
+        FlowArgs fa{h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->n_chunks, getenv("CMI_FLOW_STATS") ? 1 : 0};
         e = hipMemsetAsync(h->d_ver_u, 0, (size_t)h->n_users * 4, h->stream);
         if (e == hipSuccess) e = hipMemsetAsync(h->d_ver_j, 0, (size_t)h->n_items * 4, h->stream);
         if (e == hipSuccess) e = launch_flow_f32(make_args<float>(h), fa, cfg, h->flow_blocks, h->stream);
@@ -573,9 +573,13 @@ extern "C" int cmi_last_loss(cmi_handle h, double *loss_out) {
     if (!h || !loss_out) return CMI_E_INVALID;
     CMI_HIP(h, hipSetDevice(h->device));
     CMI_HIP(h, hipMemcpyAsync(h->h_loss, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    int32_t flow_err = 0;
-    if (h->flow) CMI_HIP(h, hipMemcpyAsync(&flow_err, h->d_flow_err, 4, hipMemcpyDeviceToHost, h->stream));
+    int32_t flow_stat[4] = {0, 0, 0, 0};
+    if (h->flow) CMI_HIP(h, hipMemcpyAsync(flow_stat, h->d_flow_err, 16, hipMemcpyDeviceToHost, h->stream));
     CMI_HIP(h, hipStreamSynchronize(h->stream));
+    const int32_t flow_err = flow_stat[0];
+    if (h->flow && getenv("CMI_FLOW_STATS"))
+        fprintf(stderr, "[cmi] flow: cumulative slow-path entries %d, polls spent waiting %d (of %lld wave-steps per epoch)\n",
+                flow_stat[1], flow_stat[2], (long long)h->n_chunks * 4);
     if (flow_err) CMI_FAIL(h, CMI_E_HIP, "dataflow epoch stalled: a tuple waited past its bound for a predecessor (model state is invalid)");
     h->last_loss = *h->h_loss;
     *loss_out = h->last_loss;

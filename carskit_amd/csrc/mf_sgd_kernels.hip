@@ -264,6 +264,51 @@ __device__ __forceinline__ void st_f32_coherent(float *p, float v) {
 
 #define CMI_FLOW_SPIN_LIMIT (1u << 22)
 
+// One 16-lane group's view of a schedule slot.
+struct FlowTuple {
+    int uu, jj, cond;
+    float rr;
+    uint32_t want_u, want_j;
+    bool live;
+};
+
+template <int MODEL>
+__device__ __forceinline__ FlowTuple flow_load_tuple(const SgdArgs<float> &a, const FlowArgs &fa, int64_t chunk,
+                                                     int gib, int l16) {
+    FlowTuple t;
+    t.uu = -1;
+    t.jj = 0;
+    t.cond = -1;
+    t.rr = 0.f;
+    t.want_u = t.want_j = 0;
+    t.live = false;
+    if (chunk < fa.n_chunks) {
+        // every field is loaded unconditionally (padding slots hold valid dummies): no load depends on another,
+        // so the whole tuple costs one round trip and can be issued two steps ahead
+        const int64_t pos = chunk * 16 + gib;
+        t.uu = a.su[pos];
+        t.jj = a.sj[pos];
+        t.rr = a.sr[pos];
+        t.want_u = fa.seq_u[pos];
+        t.want_j = fa.seq_j[pos];
+        if (MODEL != BIASEDMF && l16 < a.dmax) t.cond = a.sconds[pos * a.dmax + l16];
+        t.live = t.uu >= 0;
+    }
+    return t;
+}
+
+__device__ __forceinline__ void flow_publish(const FlowArgs &fa, const FlowTuple &t, int l16) {
+    if (t.live && l16 == 0) {
+        __hip_atomic_store(fa.ver_u + t.uu, t.want_u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fa.ver_j + t.jj, t.want_j + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Software-pipelined wave loop.  While the rows of step i are in flight the wave has already issued the version
+// poll of step i+1 and the tuple loads of step i+2, and the versions of step i-1 are published only once the
+// rows of step i have arrived: vector memory operations of a wave complete in issue order, so by then the
+// write-through stores of step i-1 (issued before those row loads) are done -- no separate store drain.
+// A step therefore costs one memory round trip (the row gather) instead of four (tuple, poll, rows, drain).
 template <int MODEL, int VPL>
 __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs fa) {
     using M = Traits<MODEL>;
@@ -279,62 +324,87 @@ __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs f
     const HParams hp = *a.hp;
     const float lr = (float)hp.lr, regU = (float)hp.regU, regI = (float)hp.regI, regB = (float)hp.regB,
                 regC = (float)hp.regC, gm = (float)hp.gm;
+    const int64_t G = gridDim.x;
 
-    for (int64_t chunk = blockIdx.x; chunk < fa.n_chunks; chunk += gridDim.x) {
-        const int64_t pos = chunk * 16 + gib;
-        const int uu = a.su[pos];
-        const int jj = a.sj[pos];
-        const bool live = uu >= 0;
-        float rr = 0.f;
-        int cond = -1;
-        uint32_t want_u = 0, want_j = 0;
-        if (live) {
-            rr = a.sr[pos];
-            want_u = fa.seq_u[pos];
-            want_j = fa.seq_j[pos];
-            if (MODEL != BIASEDMF && l16 < a.dmax) cond = a.sconds[pos * a.dmax + l16];
+    FlowTuple cur = flow_load_tuple<MODEL>(a, fa, blockIdx.x, gib, l16);
+    FlowTuple nxt = flow_load_tuple<MODEL>(a, fa, blockIdx.x + G, gib, l16);
+    FlowTuple pend; // retired but not yet published
+    pend.live = false;
+    pend.uu = pend.jj = 0;
+    pend.want_u = pend.want_j = 0;
+    // version poll of `cur`, issued one step ahead
+    uint32_t vu = 0, vj = 0;
+    if (cur.live) {
+        vu = __hip_atomic_load(fa.ver_u + cur.uu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vj = __hip_atomic_load(fa.ver_j + cur.jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    for (int64_t chunk = blockIdx.x; chunk < fa.n_chunks; chunk += G) {
+        // ---- confirm the predecessors of `cur` have retired (normally the early poll already says so)
+        bool ready = !cur.live || ((vu == cur.want_u) && (vj == cur.want_j));
+        if (!__all(ready)) {
+            // slow path: first make our own finished work visible (someone may be waiting for it), then spin
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            flow_publish(fa, pend, l16);
+            pend.live = false;
+            unsigned spins = 0;
+            if (fa.stats && (tid & 63) == 0) atomicAdd(fa.error + 1, 1); // statistics: slow-path entries
+            while (true) {
+                if (!ready) {
+                    vu = __hip_atomic_load(fa.ver_u + cur.uu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vj = __hip_atomic_load(fa.ver_j + cur.jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ready = (vu == cur.want_u) && (vj == cur.want_j);
+                }
+                if (__all(ready)) break;
+                if (++spins > CMI_FLOW_SPIN_LIMIT) {
+                    if ((tid & 63) == 0) atomicExch(fa.error, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (fa.stats && (tid & 63) == 0) atomicAdd(fa.error + 2, (int)spins); // statistics: polls spent waiting
         }
 
-        // wait until both predecessors have retired (usually true on the first poll)
-        bool ready = !live;
-        unsigned spins = 0;
-        while (true) {
-            if (!ready) {
-                const uint32_t vu = __hip_atomic_load(fa.ver_u + uu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t vj = __hip_atomic_load(fa.ver_j + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ready = (vu == want_u) && (vj == want_j);
-            }
-            if (__all(ready)) break;
-            if (++spins > CMI_FLOW_SPIN_LIMIT) {
-                if ((tid & 63) == 0) atomicExch(fa.error, 1);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-
-        double gloss = 0.0;
-        if (live) {
-            const uint32_t poff = (uint32_t)uu * (K * 4) + l16 * 16, qoff = (uint32_t)jj * (K * 4) + l16 * 16;
-            f32x4 p[VPL], q[VPL];
+        // ---- gather the rows of `cur`
+        const uint32_t poff = (uint32_t)(cur.live ? cur.uu : 0) * (K * 4) + l16 * 16;
+        const uint32_t qoff = (uint32_t)cur.jj * (K * 4) + l16 * 16;
+        f32x4 p[VPL], q[VPL];
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) p[v] = ld_row_coherent(rsP, poff + v * 256);
+        for (int v = 0; v < VPL; ++v) p[v] = ld_row_coherent(rsP, poff + v * 256);
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) q[v] = ld_row_coherent(rsQ, qoff + v * 256);
-
-            float bu = 0.f, bj = 0.f, bic = 0.f, buc = 0.f;
-            if (M::has_bu) bu = ld_f32_coherent(a.userBias + uu);
-            if (M::has_bj) bj = ld_f32_coherent(a.itemBias + jj);
-            float *pic = nullptr, *puc = nullptr;
-            if (cond >= 0) {
+        for (int v = 0; v < VPL; ++v) q[v] = ld_row_coherent(rsQ, qoff + v * 256);
+        float bu = 0.f, bj = 0.f, bic = 0.f, buc = 0.f;
+        float *pic = nullptr, *puc = nullptr;
+        if (cur.live) {
+            if (M::has_bu) bu = ld_f32_coherent(a.userBias + cur.uu);
+            if (M::has_bj) bj = ld_f32_coherent(a.itemBias + cur.jj);
+            if (cur.cond >= 0) {
                 if (M::has_ic) {
-                    pic = a.icBias + (size_t)jj * a.n_conds + cond;
+                    pic = a.icBias + (size_t)cur.jj * a.n_conds + cur.cond;
                     bic = ld_f32_coherent(pic);
                 }
                 if (M::has_uc) {
-                    puc = a.ucBias + (size_t)uu * a.n_conds + cond;
+                    puc = a.ucBias + (size_t)cur.uu * a.n_conds + cur.cond;
                     buc = ld_f32_coherent(puc);
                 }
             }
+        }
+        // ---- run ahead: poll the versions of `nxt`, fetch the tuple after it
+        uint32_t nvu = 0, nvj = 0;
+        if (nxt.live) {
+            nvu = __hip_atomic_load(fa.ver_u + nxt.uu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nvj = __hip_atomic_load(fa.ver_j + nxt.jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const FlowTuple nxt2 = flow_load_tuple<MODEL>(a, fa, chunk + 2 * G, gib, l16);
+
+        // ---- rows of `cur` have arrived => the stores of the previous step are complete: publish it.
+        // The empty asm consumes the first row register (placing the compiler's wait before it) and is a
+        // compiler barrier for the version stores that follow.
+        asm volatile("" : "+v"(p[0])::"memory");
+        flow_publish(fa, pend, l16);
+
+        double gloss = 0.0;
+        if (cur.live) {
             float part = 0.f;
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
@@ -356,14 +426,14 @@ __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs f
                 else if (M::has_uc) term = buc;
                 pred += row_sum16(term);
             }
-            const float e = rr - pred;
+            const float e = cur.rr - pred;
 
             if (l16 == 0) {
-                if (M::has_bu) st_f32_coherent(a.userBias + uu, bu + lr * (e - regB * bu));
-                if (M::has_bj) st_f32_coherent(a.itemBias + jj, bj + lr * (e - regB * bj));
+                if (M::has_bu) st_f32_coherent(a.userBias + cur.uu, bu + lr * (e - regB * bu));
+                if (M::has_bj) st_f32_coherent(a.itemBias + cur.jj, bj + lr * (e - regB * bj));
             }
             float ctx_loss = 0.f;
-            if (cond >= 0) {
+            if (cur.cond >= 0) {
                 if (M::has_ic) {
                     st_f32_coherent(pic, bic + lr * (e - regC * bic));
                     ctx_loss += bic * bic;
@@ -398,18 +468,20 @@ __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs f
                 gloss = l + (double)reg_loss;
             }
         }
-
-        // retire: all of this wave's state stores are written through before the versions move
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (live && l16 == 0) {
-            __hip_atomic_store(fa.ver_u + uu, want_u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(fa.ver_j + jj, want_j + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         // the four tuple losses of this wave, fixed order
         const double g0 = __shfl(gloss, 0, 64), g1 = __shfl(gloss, 16, 64), g2 = __shfl(gloss, 32, 64),
                      g3 = __shfl(gloss, 48, 64);
         wloss += ((g0 + g1) + g2) + g3;
+
+        pend = cur;
+        cur = nxt;
+        nxt = nxt2;
+        vu = nvu;
+        vj = nvj;
     }
+    // retire the last step
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flow_publish(fa, pend, l16);
     if ((tid & 63) == 0) a.loss_part[(int64_t)blockIdx.x * 4 + wave] = wloss;
 }
 

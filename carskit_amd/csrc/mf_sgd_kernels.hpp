@@ -53,6 +53,7 @@ struct FlowArgs {
     uint32_t *ver_u, *ver_j;       // per user / per item: tuples retired this epoch (zeroed before the launch)
     int32_t *error;                // set to 1 if a wait exceeded its bound (schedule stalled)
     int64_t n_chunks;              // padded positions / 16
+    int32_t stats;                 // CMI_FLOW_STATS: count slow-path entries / waiting polls in error[1], error[2]
 };
 int flow_grid_blocks(int device, int k);       // fully co-resident grid size for the flow kernel (0 = unsupported)
 hipError_t launch_flow_f32(const SgdArgs<float> &a, const FlowArgs &fa, const LaunchCfg &cfg, int grid_blocks,
