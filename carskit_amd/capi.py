@@ -31,6 +31,7 @@ FLAG_SCHED_SERIAL = 0x2
 FLAG_STRICT = 0x4
 FLAG_NO_GRAPH = 0x10
 FLAG_SCHED_FLOW = 0x20
+FLAG_TWO_LANE = 0x40
 
 # every symbol include/carskit_mi355x.h declares: (name, restype, argtypes)
 _vp, _i64, _i32, _dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
@@ -57,6 +58,7 @@ SYMBOLS = [
     ("cmi_schedule_info", C.c_int, [_vp, C.POINTER(_i64)]),
     ("cmi_last_epoch_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("cmi_level_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, _vp, _vp, _i64, C.POINTER(_i64)]),
+    ("cmi_split_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     ("cmi_flow_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     ("cmi_dao_read", C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     ("cmi_dao_destroy", C.c_int, [_vp]),
@@ -137,6 +139,23 @@ def level_schedule(u, j, n_users, n_items, order=0):
     if rc != OK:
         raise CmiError(rc, "cmi_level_schedule")
     return perm, off
+
+
+def split_schedule(u, j, n_users, n_items):
+    """Host-only: (perm, level_off, split) of the two-lane level schedule (see cmi_split_schedule)."""
+    u = np.ascontiguousarray(u, dtype=np.int32)
+    j = np.ascontiguousarray(j, dtype=np.int32)
+    nl = _i64()
+    rc = lib().cmi_split_schedule(len(u), _p(u), _p(j), n_users, n_items, None, None, None, 0, C.byref(nl))
+    if rc != OK:
+        raise CmiError(rc, "cmi_split_schedule")
+    perm = np.empty(len(u), dtype=np.int32)
+    off, split = np.empty(nl.value + 1, dtype=np.int64), np.empty(max(1, nl.value), dtype=np.int64)
+    rc = lib().cmi_split_schedule(len(u), _p(u), _p(j), n_users, n_items, _p(perm), _p(off), _p(split), len(off),
+                                  C.byref(nl))
+    if rc != OK:
+        raise CmiError(rc, "cmi_split_schedule")
+    return perm, off, split[:nl.value]
 
 
 def flow_schedule(u, j, n_users, n_items):
@@ -263,7 +282,7 @@ class Instance:
         self._chk(self.L.cmi_schedule_info(self.h, info))
         d = dict(zip(("levels", "max_level", "tuples", "dmax", "state_bytes", "tuple_bytes", "kind", "flow_blocks"),
                      list(info)))
-        d["kind"] = ("level", "serial", "flow")[d["kind"]]
+        d["kind"] = ("level", "serial", "flow", "two-lane")[d["kind"]]
         return d
 
     def stream(self):

@@ -21,7 +21,9 @@ using namespace cmi;
 struct cmi_instance {
     int model = 0, k = 0, n_users = 0, n_items = 0, n_conds = 0, device = 0;
     unsigned flags = 0;
-    bool f64 = false, serial = false, strict = false, use_graph = true, fast = false, want_flow = false, flow = false;
+    bool f64 = false, serial = false, strict = false, use_graph = true, fast = false, want_flow = false, flow = false,
+         want_two_lane = false, two_lane = false;
+    std::vector<int64_t> split_off; // two-lane schedule: first tail position of every level
     std::string err;
     hipStream_t stream = nullptr;
     void *state[CMI_STATE_COUNT] = {};
@@ -178,6 +180,7 @@ extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_cond
     h->strict = flags & CMI_FLAG_STRICT;
     h->use_graph = !(flags & CMI_FLAG_NO_GRAPH);
     h->want_flow = flags & CMI_FLAG_SCHED_FLOW;
+    h->want_two_lane = flags & CMI_FLAG_TWO_LANE;
     const char *step = "";
     hipError_t e = hipSuccess;
 #define TRY(x)                                                                                          \
@@ -358,9 +361,19 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         h->n_slots = (int64_t)h->flow_blocks * 4;
         h->sched_levels = fsch.n_levels;
     } else {
+        h->two_lane = false;
         if (h->serial) {
             sch.level_off = {0, n};
             sch.max_level = n;
+        } else if (h->fast && h->use_graph && h->want_two_lane && n > 0) {
+            SplitSchedule ss;
+            if (!build_split_schedule(n, u, j, h->n_users, h->n_items, ss))
+                CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: schedule construction failed");
+            sch.perm.swap(ss.perm);
+            sch.level_off = ss.level_off;
+            sch.max_level = ss.max_level;
+            h->split_off = ss.split;
+            h->two_lane = true;
         } else {
             int order = LEVEL_ORDER_CRS;
             if (const char *env = getenv("CMI_LEVEL_ORDER")) {
@@ -386,7 +399,11 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         h->slot_off.assign((size_t)n_levels + 1, 0);
         for (int64_t l = 0; l < n_levels; ++l) {
             const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
-            const int blocks = h->serial ? 0 : (h->fast ? level_blocks_f32_fast(h->k, cnt) : level_blocks_generic(cnt));
+            int blocks = h->serial ? 0 : (h->fast ? level_blocks_f32_fast(h->k, cnt) : level_blocks_generic(cnt));
+            if (h->two_lane) { // head and tail are separate launches with their own workgroup numbering
+                const int head = (int)(h->split_off[(size_t)l] - h->level_off[(size_t)l]);
+                blocks = level_blocks_f32_fast(h->k, head) + level_blocks_f32_fast(h->k, cnt - head);
+            }
             h->slot_off[(size_t)l + 1] = h->slot_off[(size_t)l] + blocks;
         }
         h->n_slots = h->slot_off[(size_t)n_levels];
@@ -462,7 +479,7 @@ extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[8]) {
     for (int w = 0; w < CMI_STATE_COUNT; ++w) sb += h->state_count[w] * (int64_t)esize(h);
     info[4] = sb;
     info[5] = h->tuple_bytes;
-    info[6] = h->flow ? 2 : (h->serial ? 1 : 0);
+    info[6] = h->flow ? 2 : (h->serial ? 1 : (h->two_lane ? 3 : 0));
     info[7] = h->flow ? h->flow_blocks : 0;
     return CMI_OK;
 }
@@ -540,6 +557,43 @@ static int enqueue_epoch(cmi_instance *h, double lrate) {
         return CMI_OK;
     }
     const bool graph = h->use_graph && !h->serial && !h->flow;
+    if (graph && !h->graph_exec && h->two_lane) {
+        // explicit DAG: head(l) <- head(l-1), tail(l-2) ; tail(l) <- tail(l-1), head(l-1)
+        hipGraph_t g = nullptr;
+        CMI_HIP(h, hipGraphCreate(&g, 0));
+        const SgdArgs<float> a = make_args<float>(h);
+        LaunchCfg cfg{h->model, h->strict};
+        const int64_t n_levels = (int64_t)h->level_off.size() - 1;
+        std::vector<hipGraphNode_t> head((size_t)n_levels), tail((size_t)n_levels);
+        hipError_t e = hipSuccess;
+        for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l) {
+            const int64_t b = h->level_off[(size_t)l], m = h->split_off[(size_t)l], en = h->level_off[(size_t)l + 1];
+            const int64_t s0 = h->slot_off[(size_t)l];
+            hipGraphNode_t deps[2];
+            size_t nd = 0;
+            if (l >= 1) deps[nd++] = head[(size_t)l - 1];
+            if (l >= 2) deps[nd++] = tail[(size_t)l - 2];
+            e = graph_add_level_fast_f32(g, &head[(size_t)l], deps, nd, a, cfg, b, (int)(m - b), s0);
+            if (e != hipSuccess) break;
+            nd = 0;
+            if (l >= 1) {
+                deps[nd++] = tail[(size_t)l - 1];
+                deps[nd++] = head[(size_t)l - 1];
+            }
+            e = graph_add_level_fast_f32(g, &tail[(size_t)l], deps, nd, a, cfg, m, (int)(en - m),
+                                         s0 + level_blocks_f32_fast(h->k, (int)(m - b)));
+        }
+        if (e == hipSuccess) {
+            hipGraphNode_t deps[2] = {head[(size_t)n_levels - 1], tail[(size_t)n_levels - 1]};
+            e = graph_add_reduce_loss(g, deps, 2, h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss);
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) {
+            h->graph_exec = nullptr;
+            CMI_FAIL(h, CMI_E_HIP, "two-lane graph construction failed: %s", hipGetErrorString(e));
+        }
+    }
     if (graph && !h->graph_exec) {
         hipGraph_t g = nullptr;
         CMI_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -795,5 +849,22 @@ extern "C" int cmi_flow_schedule(int64_t n, const int32_t *u, const int32_t *j, 
         seq_u[s] = f.seq_u[s];
         seq_j[s] = f.seq_j[s];
     }
+    return CMI_OK;
+}
+
+extern "C" int cmi_split_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
+                                  int32_t *perm, int64_t *level_off, int64_t *split, int64_t level_cap,
+                                  int64_t *n_levels) {
+    if (n < 0 || (n > 0 && (!u || !j)) || n_users <= 0 || n_items <= 0 || !n_levels) return CMI_E_INVALID;
+    for (int64_t t = 0; t < n; ++t)
+        if (u[t] < 0 || u[t] >= n_users || j[t] < 0 || j[t] >= n_items) return CMI_E_INVALID;
+    SplitSchedule ss;
+    if (!build_split_schedule(n, u, j, n_users, n_items, ss)) return CMI_E_UNSUPPORTED;
+    *n_levels = ss.n_levels();
+    if (!perm) return CMI_OK;
+    if (level_cap < ss.n_levels() + 1 || !level_off || !split) return CMI_E_INVALID;
+    for (size_t i = 0; i < ss.level_off.size(); ++i) level_off[i] = ss.level_off[i];
+    for (size_t i = 0; i < ss.split.size(); ++i) split[i] = ss.split[i];
+    for (int64_t s = 0; s < n; ++s) perm[s] = ss.perm[(size_t)s];
     return CMI_OK;
 }

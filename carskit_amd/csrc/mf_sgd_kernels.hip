@@ -23,6 +23,7 @@
 #include "mf_sgd_kernels.hpp"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace cmi {
 
@@ -799,6 +800,72 @@ static hipError_t launch_fast_model(const SgdArgs<float> &a, const LaunchCfg &, 
     case 4: return launch_fast_model_tpg<MODEL, 4>(a, begin, count, slot0, s);
     default: return launch_fast_model_tpg<MODEL, 2>(a, begin, count, slot0, s);
     }
+}
+
+template <int MODEL, int TPG>
+static void *fast_kernel_ptr(int k) {
+    switch (k) {
+    case 64: return (void *)sgd_level_fast_f32<MODEL, 1, TPG>;
+    case 128: return (void *)sgd_level_fast_f32<MODEL, 2, TPG>;
+    case 256: return (void *)sgd_level_fast_f32<MODEL, 4, TPG>;
+    }
+    return nullptr;
+}
+template <int MODEL>
+static void *fast_kernel_ptr_model(int k) {
+    switch (fast_tpg()) {
+    case 1: return fast_kernel_ptr<MODEL, 1>(k);
+    case 4: return fast_kernel_ptr<MODEL, 4>(k);
+    default: return fast_kernel_ptr<MODEL, 2>(k);
+    }
+}
+
+hipError_t graph_add_level_fast_f32(hipGraph_t g, hipGraphNode_t *node, const hipGraphNode_t *deps, size_t ndeps,
+                                    const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,
+                                    int64_t slot0) {
+    if (count <= 0) return hipGraphAddEmptyNode(node, g, deps, ndeps);
+    void *fn = nullptr;
+    switch (cfg.model) {
+    case BIASEDMF: fn = fast_kernel_ptr_model<BIASEDMF>(a.k); break;
+    case CAMF_CI: fn = fast_kernel_ptr_model<CAMF_CI>(a.k); break;
+    case CAMF_CU: fn = fast_kernel_ptr_model<CAMF_CU>(a.k); break;
+    case CAMF_CUCI: fn = fast_kernel_ptr_model<CAMF_CUCI>(a.k); break;
+    }
+    if (!fn) return hipErrorInvalidValue;
+    SgdArgs<float> args = a;
+    void *params[] = {&args, &begin, &count, &slot0};
+    hipKernelNodeParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.func = fn;
+    kp.gridDim = dim3((unsigned)level_blocks_f32_fast(a.k, count));
+    kp.blockDim = dim3(256);
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = params;
+    kp.extra = nullptr;
+    return hipGraphAddKernelNode(node, g, deps, ndeps, &kp);
+}
+
+hipError_t graph_add_reduce_loss(hipGraph_t g, const hipGraphNode_t *deps, size_t ndeps, const double *loss_part,
+                                 int64_t n_slots, double *scratch, double *loss_out) {
+    int nblk = (int)((n_slots + 4095) / 4096);
+    if (nblk < 1) nblk = 1;
+    if (nblk > 256) nblk = 256;
+    hipGraphNode_t n1, n2;
+    hipKernelNodeParams kp;
+    memset(&kp, 0, sizeof kp);
+    void *p1[] = {&loss_part, &n_slots, &scratch};
+    kp.func = (void *)reduce_loss_stage1;
+    kp.gridDim = dim3(nblk);
+    kp.blockDim = dim3(256);
+    kp.kernelParams = p1;
+    hipError_t e = hipGraphAddKernelNode(&n1, g, deps, ndeps, &kp);
+    if (e != hipSuccess) return e;
+    const double *sc = scratch;
+    void *p2[] = {&sc, &nblk, &loss_out};
+    kp.func = (void *)reduce_loss_stage2;
+    kp.gridDim = dim3(1);
+    kp.kernelParams = p2;
+    return hipGraphAddKernelNode(&n2, g, &n1, 1, &kp);
 }
 
 hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,

@@ -47,6 +47,14 @@ hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, 
 template <typename T>
 hipError_t launch_level_generic(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t begin, int count, int64_t slot0,
                                 hipStream_t s);
+// Explicit hipGraph nodes (the two-lane schedule needs a DAG, not a linear capture): one fast-path level segment,
+// and the two-stage loss reduction.  count == 0 adds an empty node so dependency chains stay uniform.
+hipError_t graph_add_level_fast_f32(hipGraph_t g, hipGraphNode_t *node, const hipGraphNode_t *deps, size_t ndeps,
+                                    const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,
+                                    int64_t slot0);
+hipError_t graph_add_reduce_loss(hipGraph_t g, const hipGraphNode_t *deps, size_t ndeps, const double *loss_part,
+                                 int64_t n_slots, double *scratch, double *loss_out);
+
 // Dataflow epoch: ONE persistent launch walks the padded schedule; tuples wait on per-row version counters.
 struct FlowArgs {
     const uint32_t *seq_u, *seq_j; // per padded position: version the tuple must observe

@@ -77,6 +77,9 @@ extern "C" {
                                       bit.  EXPERIMENTAL (round 1: correct but slower than the level launches, see
                                       DESIGN.md); fp32 state, k in {64,128}; silently falls back to the level schedule
                                       otherwise (cmi_schedule_info reports which one runs) */
+#define CMI_FLAG_TWO_LANE 0x40u /* fast path only, EXPERIMENTAL: a two-lane hipGraph in which the head of level l runs
+                                      beside the tail of level l-1 (identical result).  Measured slower than the plain
+                                      level launches in round 1 (the lanes stay in lock-step); see DESIGN.md */
 #define CMI_FLAG_NO_GRAPH 0x10u  /* launch the per-level kernels eagerly instead of replaying a hipGraph */
 
 typedef struct cmi_instance *cmi_handle;
@@ -151,8 +154,8 @@ int cmi_train_epoch_async(cmi_handle h, double lrate);
 int cmi_last_loss(cmi_handle h, double *loss_out);
 /* schedule facts: info[0]=levels (kernel launches per epoch), info[1]=largest level, info[2]=tuples,
  * info[3]=max conditions per tuple (D), info[4]=state bytes on device, info[5]=tuple-stream bytes on device,
- * info[6]=schedule kind actually running (0 level launches, 1 serial, 2 dataflow), info[7]=workgroups of the
- * dataflow launch (0 otherwise) */
+ * info[6]=schedule kind actually running (0 level launches, 1 serial, 2 dataflow, 3 two-lane level graph),
+ * info[7]=workgroups of the dataflow launch (0 otherwise) */
 int cmi_schedule_info(cmi_handle h, int64_t info[8]);
 /* GPU time of the most recent epoch's kernels measured with HIP events on cmi_stream() */
 int cmi_last_epoch_ms(cmi_handle h, float *ms);
@@ -247,6 +250,13 @@ int cmi_transform_compact_to_binary(const char *in_path, const char *out_path, i
  * 1 sort by item id, 2 sort by user id (tuples of one level commute, so this is free). */
 int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int order,
                        int32_t *perm, int64_t *level_off, int64_t level_cap, int64_t *n_levels);
+
+/* The two-lane form behind CMI_FLAG_TWO_LANE (level_schedule.cpp, build_split_schedule): same levels,
+ * tuples inside a level sorted by the position of their later predecessor, and split[l] = first position of the
+ * level's TAIL; the HEAD [level_off[l], split[l]) only depends on positions < split[l-1], so head(l) and tail(l-1)
+ * run concurrently.  level_off: *n_levels+1 entries, split: *n_levels entries (pass perm = NULL to only count). */
+int cmi_split_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int32_t *perm,
+                       int64_t *level_off, int64_t *split, int64_t level_cap, int64_t *n_levels);
 
 /* The padded dataflow form of the same schedule (CMI_FLAG_SCHED_FLOW; level_schedule.cpp): call with
  * perm = NULL to get *n_slots, then with arrays of that capacity.  perm[s] = CRS tuple index or -1 for a

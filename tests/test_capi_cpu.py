@@ -160,3 +160,44 @@ def test_flow_schedule_keeps_dependency_distance_about_one_level():
     median_level = np.median(np.diff(off))
     # the within-level sort keeps almost every dependency at least ~half a typical level away
     assert np.percentile(dist, 1) > 0.4 * median_level, (np.percentile(dist, [0.1, 1, 10, 50]), median_level)
+
+
+def _check_split(u, j, nu, ni):
+    perm, off, split = capi.split_schedule(u, j, nu, ni)
+    perm0, off0 = capi.level_schedule(u, j, nu, ni)
+    n = len(u)
+    assert off.tolist() == off0.tolist()                        # same levels as the plain schedule
+    assert sorted(perm.tolist()) == list(range(n))
+    pos = np.empty(n, dtype=np.int64)
+    pos[perm] = np.arange(n)
+    for l in range(len(off) - 1):
+        assert sorted(perm[off[l]:off[l + 1]].tolist()) == sorted(perm0[off0[l]:off0[l + 1]].tolist())
+        assert off[l] <= split[l] <= off[l + 1]
+        assert split[l] - off[l] <= (off[l + 1] - off[l] + 1) // 2   # the head is at most half of the level
+    # head(l) only depends on positions before split[l-1]; every tuple's predecessors are in earlier levels
+    last_u, last_j = {}, {}
+    level_of = np.searchsorted(off, pos, side="right") - 1
+    for t in range(n):
+        pred = max(last_u.get(int(u[t]), -1), last_j.get(int(j[t]), -1))
+        l = level_of[t]
+        if pred >= 0:
+            assert pred < off[l]
+            if pos[t] < split[l]:                                 # tuple is in the head of its level
+                assert l >= 1 and pred < split[l - 1]
+        last_u[int(u[t])] = last_j[int(j[t])] = pos[t]
+    return perm, off, split
+
+
+@settings(max_examples=30, deadline=None)
+@given(nu=st.integers(1, 9), ni=st.integers(1, 9), n=st.integers(0, 90), seed=st.integers(0, 1000))
+def test_split_schedule_property(nu, ni, n, seed):
+    rng = np.random.default_rng(seed)
+    _check_split(rng.integers(0, nu, n).astype(np.int32), rng.integers(0, ni, n).astype(np.int32), nu, ni)
+
+
+def test_split_schedule_heads_are_about_half_on_uniform_data():
+    d = synth.generate(20000, 2000, 2, 3, 400000, seed=9)
+    perm, off, split = _check_split(d.u, d.j, d.n_users, d.n_items)
+    sizes, heads = np.diff(off), split - off[:-1]
+    big = sizes > 500
+    assert np.median(heads[big] / sizes[big]) > 0.4             # the head really is ~half: two balanced lanes

@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 F64, SERIAL, STRICT, NOGRAPH = (capi.FLAG_STATE_F64, capi.FLAG_SCHED_SERIAL, capi.FLAG_STRICT, capi.FLAG_NO_GRAPH)
 FLOW = capi.FLAG_SCHED_FLOW
+TWOLANE = capi.FLAG_TWO_LANE
 
 
 def make_pair(model, data, k, flags, seed=5, regs=None):
@@ -271,15 +272,21 @@ def test_flow_schedule_bit_identical_to_level_schedule(model, k):
     data = util.small_data(n_users=20000, n_items=1500, n_dims=4, conds_per_dim=4, n=400000, seed=41)
     _, lvl = make_pair(model, data, k, 0)
     _, flw = make_pair(model, data, k, FLOW)
+    _, two = make_pair(model, data, k, TWOLANE)
     assert flw.schedule_info()["kind"] == "flow" and lvl.schedule_info()["kind"] == "level"
-    assert flw.schedule_info()["levels"] == lvl.schedule_info()["levels"]
+    assert two.schedule_info()["kind"] == "two-lane"
+    assert flw.schedule_info()["levels"] == lvl.schedule_info()["levels"] == two.schedule_info()["levels"]
+    t_losses, t_lrs = two.train(8, util.LR, bold_driver=True)
     l_losses, l_lrs = lvl.train(8, util.LR, bold_driver=True)
     f_losses, f_lrs = flw.train(8, util.LR, bold_driver=True)
     np.testing.assert_allclose(f_losses, l_losses, rtol=1e-12)   # same terms, different fixed summation tree
     assert f_lrs.tolist() == l_lrs.tolist()
-    a, b = lvl.get_states(np.float32), flw.get_states(np.float32)
+    np.testing.assert_allclose(t_losses, l_losses, rtol=1e-12)
+    assert t_lrs.tolist() == l_lrs.tolist()
+    a, b, c = lvl.get_states(np.float32), flw.get_states(np.float32), two.get_states(np.float32)
     for name in a:
         assert np.array_equal(a[name], b[name]), name
+        assert np.array_equal(a[name], c[name]), name       # two concurrent lanes: still the sequential result
 
 
 def test_flow_schedule_hot_item_and_fallback():
@@ -288,11 +295,13 @@ def test_flow_schedule_hot_item_and_fallback():
     data = util.small_data(n_users=5000, n_items=300, n_dims=2, conds_per_dim=3, n=60000, seed=42, item_zipf=1.2)
     _, lvl = make_pair("CAMF_CI", data, 64, 0)
     _, flw = make_pair("CAMF_CI", data, 64, FLOW)
+    _, two = make_pair("CAMF_CI", data, 64, TWOLANE)
     for _ in range(3):
-        a, b = lvl.train_epoch(util.LR), flw.train_epoch(util.LR)
-        assert abs(a - b) <= 1e-12 * abs(a)
+        a, b, c = lvl.train_epoch(util.LR), flw.train_epoch(util.LR), two.train_epoch(util.LR)
+        assert abs(a - b) <= 1e-12 * abs(a) and abs(a - c) <= 1e-12 * abs(a)
     for name, arr in lvl.get_states(np.float32).items():
         assert np.array_equal(arr, flw.get_state(name, np.float32)), name
+        assert np.array_equal(arr, two.get_state(name, np.float32)), name
     _, fb = make_pair("CAMF_CI", data, 10, FLOW)
     assert fb.schedule_info()["kind"] == "level"
     _, fb64 = make_pair("CAMF_CI", data, 64, FLOW | F64)
