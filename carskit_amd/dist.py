@@ -142,3 +142,67 @@ def global_mean(dist, r, device=None):
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(v)
     return float(v[0].item() / v[1].item())
+
+
+# ---- FM (ALS sweep): ratings sharded by user, per-phase exchange of (num, den) --------------------------------
+
+class GpuFMEngine:
+    """Engine over one capi.FMInstance holding this rank's ratings (users re-based to the shard)."""
+
+    def __init__(self, fm_inst, device_index):
+        import torch
+        self.inst, self.torch = fm_inst, torch
+        self.device = torch.device("cuda", device_index)
+        self._views = {}
+
+    def num_phases(self):
+        return self.inst.num_phases()
+
+    def phase_reduce(self, ph):
+        self.inst.phase_reduce(ph)
+
+    def phase_apply(self, ph):
+        self.inst.phase_apply(ph)
+
+    def phase_tensor(self, ph):
+        ptr, cnt = self.inst.phase_buffer(ph)
+        key = (ptr, cnt)
+        if key not in self._views:
+            self._views[key] = self.torch.as_tensor(_DevArray(ptr, cnt, np.float64), device=self.device)
+        return self._views[key]
+
+    def before_exchange(self):
+        self.inst.synchronize()
+
+    def after_exchange(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+def fm_phase_field(ph):
+    """-1: w0; 0 users, 1 items, 2 context features (phase numbering of cmi_fm_num_phases)."""
+    if ph == 0:
+        return -1
+    return (ph - 1) if ph < 4 else (ph - 4) % 3
+
+
+class ShardedFMRunner:
+    """One FM sweep over user-sharded ratings (reference FM.java:148-218 per phase): every rank reduces its local
+    numerator/denominator sums; phases whose coordinates are shared by all ranks (w0, items, context features) sum
+    them with an all-reduce before the update, user phases stay local (a user's ratings live on one rank).
+    Every rank then applies the same update, so the replicated item/context part of the model stays identical."""
+
+    def __init__(self, engine, dist, group=None):
+        self.engine, self.dist, self.group = engine, dist, group
+        self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+
+    def sweep(self):
+        eng, dist = self.engine, self.dist
+        for ph in range(eng.num_phases()):
+            eng.phase_reduce(ph)
+            if self.world > 1 and fm_phase_field(ph) != 0:
+                if hasattr(eng, "before_exchange"):
+                    eng.before_exchange()
+                dist.all_reduce(eng.phase_tensor(ph), op=dist.ReduceOp.SUM, group=self.group)
+                if hasattr(eng, "after_exchange"):
+                    eng.after_exchange()
+            eng.phase_apply(ph)

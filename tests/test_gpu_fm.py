@@ -77,3 +77,33 @@ def test_fm_edge_cases():
     orc.sweep()
     g2.sweep()
     np.testing.assert_allclose(g2.get_model()[2], orc.V, rtol=1e-9, atol=1e-12)
+
+
+def test_fm_sharded_runner_gpu_engine_and_phase_buffer_alias():
+    """carskit_amd.dist.GpuFMEngine: the phase buffer is aliased as a torch tensor (what RCCL all-reduces) and holds
+    the same (num, den) the NumPy engine computes; a runner sweep at world 1 equals the fused sweep."""
+    import torch
+    from carskit_amd import dist as cdist
+    from tests.fm_np_engine import NumpyFMEngine
+    data = util.small_data(n_users=50, n_items=12, n_dims=2, conds_per_dim=3, n=700, seed=54)
+    w0, w, V = fm_init_model(data.n_users, data.n_items, data.n_conds, 4, 2)
+    _, a = make_fm(data, 4, 2)
+    _, b = make_fm(data, 4, 2)
+    a.init()
+    b.init()
+    ref = NumpyFMEngine(4, data.n_users, data.n_items, data.n_conds, data.n_dims, data.u, data.j, data.ctx, data.r,
+                        w0, w, V, REGLW, REGLF, data.n)
+    eng = cdist.GpuFMEngine(a, 0)
+    for ph in (0, 2, 3, 5):
+        a.phase_reduce(ph)
+        a.synchronize()
+        ref.phase_reduce(ph)
+        got = eng.phase_tensor(ph).cpu().numpy()
+        want = ref.phase_tensor(ph).numpy()
+        np.testing.assert_allclose(got[:1] if ph == 0 else got, want[:1] if ph == 0 else want, rtol=1e-10, atol=1e-12)
+    _, c = make_fm(data, 4, 2)
+    c.init()
+    cdist.ShardedFMRunner(cdist.GpuFMEngine(c, 0), None).sweep()
+    c.synchronize()
+    b.sweep()
+    assert np.array_equal(b.get_model()[2], c.get_model()[2]) and b.get_model()[0] == c.get_model()[0]
