@@ -649,6 +649,228 @@ __global__ __launch_bounds__(64) void sgd_serial(SgdArgs<T> a, int64_t n, double
 }
 
 // ---------------------------------------------------------------------------------------------
+// fast serial path: one wave64, rows in registers, next tuple prefetched, condBias in LDS
+// ---------------------------------------------------------------------------------------------
+//
+// The reference order is one dependency chain, so the only lever is latency per tuple.  Compared with
+// sgd_serial (two passes over the rows, a chain of dependent global loads per condition) this kernel
+//   * keeps the k <= 256 factors of P[u], Q[j] in registers (lane f owns f, f+64, f+128, f+192);
+//   * issues the loads of tuple t+1 (rows, scalar biases) BEFORE computing tuple t; if t+1 shares the user or
+//     the item with t the stale prefetch is dropped and the freshly updated registers are forwarded instead;
+//   * stages 64 tuples and their condition ids per chunk (one coalesced load each) and keeps CAMF_C's whole
+//     condBias vector in LDS for the kernel's lifetime (it is what makes CAMF_C sequential);
+//   * reduces the dot with DPP (row_ror 8/4/2/1, row_bcast15, row_bcast31) instead of six bpermutes.
+// Arithmetic per element is the same expression as everywhere else; the dot and the loss are tree sums
+// (not strict).  Same-wave store -> later load of one address stays ordered in the vector memory pipeline.
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_rows_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_rows_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// v_readlane with a wave-uniform lane index: the value lands in an SGPR (a few cycles) instead of going through
+// the LDS crossbar like ds_bpermute (__shfl)
+__device__ __forceinline__ int rl(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+__device__ __forceinline__ float rl(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+__device__ __forceinline__ double rl(double x, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+
+// wave64 sum, result uniform (read from lane 63); fixed tree
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+    x += dpp_rows_f32<0x128, 0xf>(x);
+    x += dpp_rows_f32<0x124, 0xf>(x);
+    x += dpp_rows_f32<0x122, 0xf>(x);
+    x += dpp_rows_f32<0x121, 0xf>(x);       // every lane: its row's sum
+    x += dpp_rows_f32<0x142, 0xa>(x);       // row_bcast15 into rows 1,3
+    x += dpp_rows_f32<0x143, 0xc>(x);       // row_bcast31 into rows 2,3
+    return rl(x, 63);
+}
+__device__ __forceinline__ double wave_sum_dpp(double x) {
+    x += dpp_rows_f64<0x128, 0xf>(x);
+    x += dpp_rows_f64<0x124, 0xf>(x);
+    x += dpp_rows_f64<0x122, 0xf>(x);
+    x += dpp_rows_f64<0x121, 0xf>(x);
+    x += dpp_rows_f64<0x142, 0xa>(x);
+    x += dpp_rows_f64<0x143, 0xc>(x);
+    return rl(x, 63);
+}
+
+template <typename T, int MODEL, int MAXC> // k <= 64 * MAXC
+__global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, double *loss_out) {
+    using M = Traits<MODEL>;
+    extern __shared__ unsigned char smem_raw[];
+    T *s_bc = reinterpret_cast<T *>(smem_raw);                                   // [n_conds] (CAMF_C)
+    int32_t *s_conds = reinterpret_cast<int32_t *>(s_bc + (M::has_bc ? a.n_conds : 0)); // [64 x dmax] chunk
+    const int lane = threadIdx.x;
+    const int k = a.k, dmax = a.dmax;
+    const HParams hp = *a.hp;
+    const T lr = (T)hp.lr, regU = (T)hp.regU, regI = (T)hp.regI, regB = (T)hp.regB, regC = (T)hp.regC, gm = (T)hp.gm;
+    if (M::has_bc)
+        for (int c = lane; c < a.n_conds; c += 64) s_bc[c] = a.condBias[c];
+    __syncthreads();
+
+    double loss = 0.0;
+    T p[MAXC], q[MAXC], pn[MAXC], qn[MAXC]; // current rows / prefetched rows of the next tuple
+    T bu = 0, bj = 0, bu_n = 0, bj_n = 0;
+    int cu = -1, cj = -1; // user / item whose rows are in p, q
+
+    for (int64_t base = 0; base < n; base += 64) {
+        const int m = (n - base) < 64 ? (int)(n - base) : 64;
+        int mu = 0, mj = 0;
+        T mr = 0;
+        if (lane < m) {
+            mu = a.su[base + lane];
+            mj = a.sj[base + lane];
+            mr = a.sr[base + lane];
+        }
+        if (MODEL != BIASEDMF) {
+            __syncthreads();
+            for (int x = lane; x < m * dmax; x += 64) s_conds[x] = a.sconds[base * dmax + x];
+            __syncthreads();
+        }
+        for (int i = 0; i < m; ++i) {
+            const int uu = rl(mu, i), jj = rl(mj, i);
+            const T rr = rl(mr, i);
+            // ---- rows of this tuple: forwarded registers, or the prefetch, or (first tuple) a fresh load
+            if (i == 0 && base == 0) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    const int f = lane + 64 * c;
+                    pn[c] = f < k ? a.P[(size_t)uu * k + f] : (T)0;
+                    qn[c] = f < k ? a.Q[(size_t)jj * k + f] : (T)0;
+                }
+                if (M::has_bu) bu_n = a.userBias[uu];
+                if (M::has_bj) bj_n = a.itemBias[jj];
+            }
+            if (uu != cu) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) p[c] = pn[c];
+                bu = bu_n;
+            }
+            if (jj != cj) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) q[c] = qn[c];
+                bj = bj_n;
+            }
+            cu = uu;
+            cj = jj;
+            // ---- prefetch the next tuple (the last tuple of a chunk peeks into the next chunk)
+            int nu = -1, nj = -1;
+            if (i + 1 < m) {
+                nu = rl(mu, i + 1);
+                nj = rl(mj, i + 1);
+            } else if (base + 64 < n) {
+                nu = a.su[base + 64];
+                nj = a.sj[base + 64];
+            }
+            if (nu >= 0) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    const int f = lane + 64 * c;
+                    pn[c] = f < k ? a.P[(size_t)nu * k + f] : (T)0;
+                    qn[c] = f < k ? a.Q[(size_t)nj * k + f] : (T)0;
+                }
+                if (M::has_bu) bu_n = a.userBias[nu];
+                if (M::has_bj) bj_n = a.itemBias[nj];
+            }
+            // ---- condition of this lane (lane d < dmax) and its bias entries
+            int cond = -1;
+            T bc = 0, bic = 0, buc = 0;
+            T *pic = nullptr, *puc = nullptr;
+            if (MODEL != BIASEDMF && lane < dmax) cond = s_conds[i * dmax + lane];
+            if (cond >= 0) {
+                if (M::has_bc) bc = s_bc[cond];
+                if (M::has_ic) {
+                    pic = a.icBias + (size_t)jj * a.n_conds + cond;
+                    bic = *pic;
+                }
+                if (M::has_uc) {
+                    puc = a.ucBias + (size_t)uu * a.n_conds + cond;
+                    buc = *puc;
+                }
+            }
+            // ---- predict
+            T part = 0;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) part += p[c] * q[c];
+            const T dot = wave_sum_dpp(part);
+            T pred = gm;
+            if (M::has_bu) pred += bu;
+            if (M::has_bj) pred += bj;
+            pred += dot;
+            if (MODEL != BIASEDMF) {
+                T term = 0;
+                if (M::has_bc) term = bc;
+                else if (M::has_ic && M::has_uc) term = bic + buc;
+                else if (M::has_ic) term = bic;
+                else term = buc;
+                const unsigned long long present = __ballot(cond >= 0);
+                for (int d = 0; d < dmax; ++d) // the reference adds the deviations one by one, in condition order
+                    if ((present >> d) & 1ull) pred += rl(term, d);
+            }
+            const T e = rr - pred;
+            // ---- biases
+            double l = (double)(e * e);
+            if (M::has_bu) {
+                const T nb = bu + lr * (e - regB * bu);
+                if (lane == 0) a.userBias[uu] = nb;
+                l += (double)((regB * bu) * bu);
+                bu = nb;
+            }
+            if (M::has_bj) {
+                const T nb = bj + lr * (e - regB * bj);
+                if (lane == 0) a.itemBias[jj] = nb;
+                l += (double)((regB * bj) * bj);
+                bj = nb;
+            }
+            T ctx_term = 0;
+            if (cond >= 0) {
+                if (M::has_bc) {
+                    s_bc[cond] = bc + lr * (e - regC * bc);
+                    ctx_term = bc; // plain sum, weighted by regB (reference quirk, CAMF_C.java:110,115)
+                }
+                if (M::has_ic) {
+                    *pic = bic + lr * (e - regC * bic);
+                    ctx_term += bic * bic;
+                }
+                if (M::has_uc) {
+                    *puc = buc + lr * (e - regC * buc);
+                    ctx_term += buc * buc;
+                }
+            }
+            // ---- factors
+            T reg_part = 0;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int f = lane + 64 * c;
+                const T pv = p[c], qv = q[c];
+                p[c] = pv + lr * (e * qv - regU * pv);
+                q[c] = qv + lr * (e * pv - regI * qv);
+                reg_part += (regU * pv) * pv + (regI * qv) * qv;
+                if (f < k) {
+                    a.P[(size_t)uu * k + f] = p[c];
+                    a.Q[(size_t)jj * k + f] = q[c];
+                }
+            }
+            if (MODEL != BIASEDMF) l += (double)((M::has_bc ? regB : regC) * wave_sum_dpp(ctx_term));
+            l += (double)wave_sum_dpp(reg_part);
+            loss += l;
+        }
+    }
+    if (M::has_bc) {
+        __syncthreads();
+        for (int c = lane; c < a.n_conds; c += 64) a.condBias[c] = s_bc[c];
+    }
+    if (lane == 0) loss_out[0] = loss * 0.5;
+}
+
+// ---------------------------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------------------------
 
@@ -959,8 +1181,14 @@ template hipError_t launch_level_generic<double>(const SgdArgs<double> &, const 
 template <typename T, int MODEL>
 static hipError_t launch_serial_model(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t n, double *loss_out,
                                       hipStream_t s) {
+    const size_t lds = (MODEL == CAMF_C ? (size_t)a.n_conds * sizeof(T) : 0) + (size_t)64 * a.dmax * sizeof(int32_t) + 16;
     if (cfg.strict)
         hipLaunchKernelGGL((sgd_serial<T, MODEL, true>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else if (a.k <= 256 && lds <= 64 * 1024 && !getenv("CMI_SERIAL_GENERIC")) {
+        if (a.k <= 64) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 1>), dim3(1), dim3(64), lds, s, a, n, loss_out);
+        else if (a.k <= 128) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 2>), dim3(1), dim3(64), lds, s, a, n, loss_out);
+        else hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 4>), dim3(1), dim3(64), lds, s, a, n, loss_out);
+    }
     else
         hipLaunchKernelGGL((sgd_serial<T, MODEL, false>), dim3(1), dim3(64), 0, s, a, n, loss_out);
     return hipGetLastError();
