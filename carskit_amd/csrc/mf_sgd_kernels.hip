@@ -701,7 +701,11 @@ __device__ __forceinline__ double wave_sum_dpp(double x) {
     return rl(x, 63);
 }
 
-template <typename T, int MODEL, int MAXC> // k <= 64 * MAXC
+// FULL: k == 64*MAXC, so no factor lane is ever masked -- together with the unconditional prefetch and the
+// all-lane bias stores this leaves the inner loop free of memory operations under a branch, and the compiler can
+// count outstanding loads/stores exactly (s_waitcnt vmcnt(N) instead of vmcnt(0)): the wait for the prefetched
+// rows no longer drains this tuple's stores.
+template <typename T, int MODEL, int MAXC, bool FULL> // k <= 64 * MAXC
 __global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, double *loss_out) {
     using M = Traits<MODEL>;
     extern __shared__ unsigned char smem_raw[];
@@ -719,6 +723,17 @@ __global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, d
     T p[MAXC], q[MAXC], pn[MAXC], qn[MAXC]; // current rows / prefetched rows of the next tuple
     T bu = 0, bj = 0, bu_n = 0, bj_n = 0;
     int cu = -1, cj = -1; // user / item whose rows are in p, q
+    if (n > 0) { // rows of the very first tuple
+        const int u0 = a.su[0], j0 = a.sj[0];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int f = lane + 64 * c;
+            pn[c] = (FULL || f < k) ? a.P[(size_t)u0 * k + (FULL ? f : (f < k ? f : 0))] : (T)0;
+            qn[c] = (FULL || f < k) ? a.Q[(size_t)j0 * k + (FULL ? f : (f < k ? f : 0))] : (T)0;
+        }
+        if (M::has_bu) bu_n = a.userBias[u0];
+        if (M::has_bj) bj_n = a.itemBias[j0];
+    }
 
     for (int64_t base = 0; base < n; base += 64) {
         const int m = (n - base) < 64 ? (int)(n - base) : 64;
@@ -729,6 +744,11 @@ __global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, d
             mj = a.sj[base + lane];
             mr = a.sr[base + lane];
         }
+        int next_u0 = 0, next_j0 = 0; // first tuple of the next chunk (for the prefetch of this chunk's last tuple)
+        if (base + 64 < n) {
+            next_u0 = a.su[base + 64];
+            next_j0 = a.sj[base + 64];
+        }
         if (MODEL != BIASEDMF) {
             __syncthreads();
             for (int x = lane; x < m * dmax; x += 64) s_conds[x] = a.sconds[base * dmax + x];
@@ -738,16 +758,6 @@ __global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, d
             const int uu = rl(mu, i), jj = rl(mj, i);
             const T rr = rl(mr, i);
             // ---- rows of this tuple: forwarded registers, or the prefetch, or (first tuple) a fresh load
-            if (i == 0 && base == 0) {
-#pragma unroll
-                for (int c = 0; c < MAXC; ++c) {
-                    const int f = lane + 64 * c;
-                    pn[c] = f < k ? a.P[(size_t)uu * k + f] : (T)0;
-                    qn[c] = f < k ? a.Q[(size_t)jj * k + f] : (T)0;
-                }
-                if (M::has_bu) bu_n = a.userBias[uu];
-                if (M::has_bj) bj_n = a.itemBias[jj];
-            }
             if (uu != cu) {
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c) p[c] = pn[c];
@@ -761,24 +771,28 @@ __global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, d
             cu = uu;
             cj = jj;
             // ---- prefetch the next tuple (the last tuple of a chunk peeks into the next chunk)
-            int nu = -1, nj = -1;
+            // (unconditional: the last tuple of all re-reads its own rows, which are then simply not used)
+            int nu = uu, nj = jj;
             if (i + 1 < m) {
                 nu = rl(mu, i + 1);
                 nj = rl(mj, i + 1);
             } else if (base + 64 < n) {
-                nu = a.su[base + 64];
-                nj = a.sj[base + 64];
+                nu = next_u0;
+                nj = next_j0;
             }
-            if (nu >= 0) {
 #pragma unroll
-                for (int c = 0; c < MAXC; ++c) {
-                    const int f = lane + 64 * c;
+            for (int c = 0; c < MAXC; ++c) {
+                const int f = lane + 64 * c;
+                if (FULL) {
+                    pn[c] = a.P[(size_t)nu * k + f];
+                    qn[c] = a.Q[(size_t)nj * k + f];
+                } else {
                     pn[c] = f < k ? a.P[(size_t)nu * k + f] : (T)0;
                     qn[c] = f < k ? a.Q[(size_t)nj * k + f] : (T)0;
                 }
-                if (M::has_bu) bu_n = a.userBias[nu];
-                if (M::has_bj) bj_n = a.itemBias[nj];
             }
+            if (M::has_bu) bu_n = a.userBias[nu];
+            if (M::has_bj) bj_n = a.itemBias[nj];
             // ---- condition of this lane (lane d < dmax) and its bias entries
             int cond = -1;
             T bc = 0, bic = 0, buc = 0;
@@ -819,13 +833,13 @@ __global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, d
             double l = (double)(e * e);
             if (M::has_bu) {
                 const T nb = bu + lr * (e - regB * bu);
-                if (lane == 0) a.userBias[uu] = nb;
+                a.userBias[uu] = nb; // every lane stores the same value to the same word: no branch in the loop
                 l += (double)((regB * bu) * bu);
                 bu = nb;
             }
             if (M::has_bj) {
                 const T nb = bj + lr * (e - regB * bj);
-                if (lane == 0) a.itemBias[jj] = nb;
+                a.itemBias[jj] = nb;
                 l += (double)((regB * bj) * bj);
                 bj = nb;
             }
@@ -853,7 +867,7 @@ __global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, d
                 p[c] = pv + lr * (e * qv - regU * pv);
                 q[c] = qv + lr * (e * pv - regI * qv);
                 reg_part += (regU * pv) * pv + (regI * qv) * qv;
-                if (f < k) {
+                if (FULL || f < k) {
                     a.P[(size_t)uu * k + f] = p[c];
                     a.Q[(size_t)jj * k + f] = q[c];
                 }
@@ -1185,9 +1199,12 @@ static hipError_t launch_serial_model(const SgdArgs<T> &a, const LaunchCfg &cfg,
     if (cfg.strict)
         hipLaunchKernelGGL((sgd_serial<T, MODEL, true>), dim3(1), dim3(64), 0, s, a, n, loss_out);
     else if (a.k <= 256 && lds <= 64 * 1024 && !getenv("CMI_SERIAL_GENERIC")) {
-        if (a.k <= 64) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 1>), dim3(1), dim3(64), lds, s, a, n, loss_out);
-        else if (a.k <= 128) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 2>), dim3(1), dim3(64), lds, s, a, n, loss_out);
-        else hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 4>), dim3(1), dim3(64), lds, s, a, n, loss_out);
+        if (a.k == 64) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 1, true>), dim3(1), dim3(64), lds, s, a, n, loss_out);
+        else if (a.k == 128) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 2, true>), dim3(1), dim3(64), lds, s, a, n, loss_out);
+        else if (a.k == 256) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 4, true>), dim3(1), dim3(64), lds, s, a, n, loss_out);
+        else if (a.k < 64) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 1, false>), dim3(1), dim3(64), lds, s, a, n, loss_out);
+        else if (a.k < 128) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 2, false>), dim3(1), dim3(64), lds, s, a, n, loss_out);
+        else hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 4, false>), dim3(1), dim3(64), lds, s, a, n, loss_out);
     }
     else
         hipLaunchKernelGGL((sgd_serial<T, MODEL, false>), dim3(1), dim3(64), 0, s, a, n, loss_out);
