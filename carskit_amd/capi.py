@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcarskit_mi355x.so")
 
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NUMERIC, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
-MODEL_IDS = {"BiasedMF": 0, "CAMF_C": 1, "CAMF_CI": 2, "CAMF_CU": 3, "CAMF_CUCI": 4}
+MODEL_IDS = {"BiasedMF": 0, "CAMF_C": 1, "CAMF_CI": 2, "CAMF_CU": 3, "CAMF_CUCI": 4, "PMF": 5}
 STATE_IDS = {"P": 0, "Q": 1, "userBias": 2, "itemBias": 3, "condBias": 4, "ucBias": 5, "icBias": 6}
 MODEL_STATES = {
     "BiasedMF": ("P", "Q", "userBias", "itemBias"),
@@ -22,6 +22,7 @@ MODEL_STATES = {
     "CAMF_CI": ("P", "Q", "userBias", "icBias"),
     "CAMF_CU": ("P", "Q", "itemBias", "ucBias"),
     "CAMF_CUCI": ("P", "Q", "ucBias", "icBias"),
+    "PMF": ("P", "Q"),
 }
 # the state keyed by item (replicated and reconciled across GPUs when tuples are sharded by user)
 ITEM_SIDE = {"Q", "itemBias", "icBias", "condBias"}

@@ -148,7 +148,7 @@ extern "C" int cmi_destroy(cmi_handle h) {
 extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_conds, int device, unsigned flags,
                           cmi_handle *out) {
     if (out) *out = nullptr;
-    if (!out || model < 0 || model > CMI_MODEL_CAMF_CUCI || k <= 0 || n_users <= 0 || n_items <= 0 || n_conds < 0) {
+    if (!out || model < 0 || model > CMI_MODEL_PMF || k <= 0 || n_users <= 0 || n_items <= 0 || n_conds < 0) {
         g_create_err = "cmi_create: invalid argument";
         return CMI_E_INVALID;
     }
@@ -221,7 +221,7 @@ extern "C" int cmi_set_hparams(cmi_handle h, double regU, double regI, double re
     h->hp.regI = regI;
     h->hp.regB = regB;
     h->hp.regC = regC;
-    h->hp.gm = global_mean;
+    h->hp.gm = h->model == CMI_MODEL_PMF ? 0.0 : global_mean; // PMF.predict is the bare dot product
     return CMI_OK;
 }
 
@@ -304,7 +304,7 @@ static hipError_t upload(void **dst, const std::vector<V> &v, hipStream_t s) {
 extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                                const double *r, int32_t n_ctx, const int32_t *ctx_ptr, const int32_t *ctx_conds) {
     if (!h) return CMI_E_INVALID;
-    const bool contextual = h->model != CMI_MODEL_BIASEDMF;
+    const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF;
     if (n < 0 || (n > 0 && (!u || !j || !r))) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: null tuple arrays");
     if (contextual && (n_ctx < 0 || !ctx_ptr || (n > 0 && !ctx) || (n_ctx > 0 && ctx_ptr[n_ctx] > 0 && !ctx_conds)))
         CMI_FAIL(h, CMI_E_INVALID, "set_ratings: context table required for model %d", h->model);
@@ -745,7 +745,7 @@ static hipError_t run_eval(cmi_instance *h, int64_t n, const int32_t *du, const 
 static int eval_common(cmi_instance *h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                        const double *r, int bound, double lo, double hi, double min_rate, double *preds_out,
                        double sums[5]) {
-    const bool contextual = h->model != CMI_MODEL_BIASEDMF;
+    const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF;
     if (n < 0 || (n > 0 && (!u || !j))) CMI_FAIL(h, CMI_E_INVALID, "eval: null tuple arrays");
     if (contextual && n > 0 && !ctx) CMI_FAIL(h, CMI_E_INVALID, "eval: ctx required for model %d", h->model);
     if (contextual && !h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "eval: the context table comes from cmi_set_ratings; call it first");

@@ -61,6 +61,7 @@ struct Traits {
     static constexpr bool has_bc = MODEL == CAMF_C;
     static constexpr bool has_ic = MODEL == CAMF_CI || MODEL == CAMF_CUCI;
     static constexpr bool has_uc = MODEL == CAMF_CU || MODEL == CAMF_CUCI;
+    static constexpr bool has_ctx = !(MODEL == BIASEDMF || MODEL == PMF); // iterates the contextual matrix
 };
 
 // 16-byte row stores with an explicit cache policy (stores have no outputs, so inline asm is safe here)
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
             uu[i] = a.su[t];
             jj[i] = a.sj[t];
             rr[i] = a.sr[t];
-            if (MODEL != BIASEDMF && l16 < a.dmax) cond[i] = a.sconds[t * a.dmax + l16];
+            if (Traits<MODEL>::has_ctx && l16 < a.dmax) cond[i] = a.sconds[t * a.dmax + l16];
         }
     }
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
         if (M::has_bu) pred += bu[i];
         if (M::has_bj) pred += bj[i];
         pred += dot;
-        if (MODEL != BIASEDMF) {
+        if (Traits<MODEL>::has_ctx) {
             float term = 0.f; // lane d carries the deviation of the tuple's d-th condition
             if (M::has_ic && M::has_uc) term = bic[i] + buc[i];
             else if (M::has_ic) term = bic[i];
@@ -204,12 +205,12 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
         }
 
         const float reg_loss = row_sum16(lsum);
-        const float ctx_sum = (MODEL != BIASEDMF) ? row_sum16(ctx_loss) : 0.f;
+        const float ctx_sum = (Traits<MODEL>::has_ctx) ? row_sum16(ctx_loss) : 0.f;
         if (l16 == 0) {
             double l = (double)e * (double)e;
             if (M::has_bu) l += (double)regB * bu[i] * bu[i];
             if (M::has_bj) l += (double)regB * bj[i] * bj[i];
-            if (MODEL != BIASEDMF) l += (double)regC * ctx_sum;
+            if (Traits<MODEL>::has_ctx) l += (double)regC * ctx_sum;
             gloss += l + (double)reg_loss;
         }
     }
@@ -292,7 +293,7 @@ __device__ __forceinline__ FlowTuple flow_load_tuple(const SgdArgs<float> &a, co
         t.rr = a.sr[pos];
         t.want_u = fa.seq_u[pos];
         t.want_j = fa.seq_j[pos];
-        if (MODEL != BIASEDMF && l16 < a.dmax) t.cond = a.sconds[pos * a.dmax + l16];
+        if (Traits<MODEL>::has_ctx && l16 < a.dmax) t.cond = a.sconds[pos * a.dmax + l16];
         t.live = t.uu >= 0;
     }
     return t;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs f
             if (M::has_bu) pred += bu;
             if (M::has_bj) pred += bj;
             pred += dot;
-            if (MODEL != BIASEDMF) {
+            if (Traits<MODEL>::has_ctx) {
                 float term = 0.f;
                 if (M::has_ic && M::has_uc) term = bic + buc;
                 else if (M::has_ic) term = bic;
@@ -460,12 +461,12 @@ __global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs f
             }
 
             const float reg_loss = row_sum16(lsum);
-            const float ctx_sum = (MODEL != BIASEDMF) ? row_sum16(ctx_loss) : 0.f;
+            const float ctx_sum = (Traits<MODEL>::has_ctx) ? row_sum16(ctx_loss) : 0.f;
             if (l16 == 0) {
                 double l = (double)e * (double)e;
                 if (M::has_bu) l += (double)regB * bu * bu;
                 if (M::has_bj) l += (double)regB * bj * bj;
-                if (MODEL != BIASEDMF) l += (double)regC * ctx_sum;
+                if (Traits<MODEL>::has_ctx) l += (double)regC * ctx_sum;
                 gloss = l + (double)reg_loss;
             }
         }
@@ -525,7 +526,7 @@ __device__ __forceinline__ double sgd_one(const SgdArgs<T> &a, const HParams &hp
     if (M::has_bu) pred += bu;
     if (M::has_bj) pred += bj;
     pred += dot;
-    if (MODEL != BIASEDMF) {
+    if (Traits<MODEL>::has_ctx) {
         for (int d = 0; d < a.dmax; ++d) {
             const int cond = conds[d];
             if (cond < 0) break;
@@ -549,7 +550,7 @@ __device__ __forceinline__ double sgd_one(const SgdArgs<T> &a, const HParams &hp
         if (lane == 0) a.itemBias[jj] = bj + lr * (e - regB * bj);
         loss += (double)((regB * bj) * bj);
     }
-    if (MODEL != BIASEDMF) {
+    if (Traits<MODEL>::has_ctx) {
         T s_ic = 0, s_uc = 0, s_bc = 0;
         for (int d = 0; d < a.dmax; ++d) {
             const int cond = conds[d];
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, d
             next_u0 = a.su[base + 64];
             next_j0 = a.sj[base + 64];
         }
-        if (MODEL != BIASEDMF) {
+        if (Traits<MODEL>::has_ctx) {
             __syncthreads();
             for (int x = lane; x < m * dmax; x += 64) s_conds[x] = a.sconds[base * dmax + x];
             __syncthreads();
@@ -797,7 +798,7 @@ __global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, d
             int cond = -1;
             T bc = 0, bic = 0, buc = 0;
             T *pic = nullptr, *puc = nullptr;
-            if (MODEL != BIASEDMF && lane < dmax) cond = s_conds[i * dmax + lane];
+            if (Traits<MODEL>::has_ctx && lane < dmax) cond = s_conds[i * dmax + lane];
             if (cond >= 0) {
                 if (M::has_bc) bc = s_bc[cond];
                 if (M::has_ic) {
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, d
             if (M::has_bu) pred += bu;
             if (M::has_bj) pred += bj;
             pred += dot;
-            if (MODEL != BIASEDMF) {
+            if (Traits<MODEL>::has_ctx) {
                 T term = 0;
                 if (M::has_bc) term = bc;
                 else if (M::has_ic && M::has_uc) term = bic + buc;
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(64) void sgd_serial_fast(SgdArgs<T> a, int64_t n, d
                     a.Q[(size_t)jj * k + f] = q[c];
                 }
             }
-            if (MODEL != BIASEDMF) l += (double)((M::has_bc ? regB : regC) * wave_sum_dpp(ctx_term));
+            if (Traits<MODEL>::has_ctx) l += (double)((M::has_bc ? regB : regC) * wave_sum_dpp(ctx_term));
             l += (double)wave_sum_dpp(reg_part);
             loss += l;
         }
@@ -949,7 +950,7 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs<T> a, int64_t n) {
         if (has_bu) pred += (double)a.userBias[uu];
         if (has_bj) pred += (double)a.itemBias[jj];
         pred += dot;
-        if (model != BIASEDMF) {
+        if (model != BIASEDMF && model != PMF) {
             const int c = a.ctx[t];
             for (int q = a.ctx_ptr[c]; q < a.ctx_ptr[c + 1]; ++q) {
                 const int cond = a.ctx_conds[q];
@@ -1063,6 +1064,7 @@ hipError_t graph_add_level_fast_f32(hipGraph_t g, hipGraphNode_t *node, const hi
     void *fn = nullptr;
     switch (cfg.model) {
     case BIASEDMF: fn = fast_kernel_ptr_model<BIASEDMF>(a.k); break;
+    case PMF: fn = fast_kernel_ptr_model<PMF>(a.k); break;
     case CAMF_CI: fn = fast_kernel_ptr_model<CAMF_CI>(a.k); break;
     case CAMF_CU: fn = fast_kernel_ptr_model<CAMF_CU>(a.k); break;
     case CAMF_CUCI: fn = fast_kernel_ptr_model<CAMF_CUCI>(a.k); break;
@@ -1109,6 +1111,7 @@ hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, 
     if (count <= 0) return hipSuccess;
     switch (cfg.model) {
     case BIASEDMF: return launch_fast_model<BIASEDMF>(a, cfg, begin, count, slot0, s);
+    case PMF: return launch_fast_model<PMF>(a, cfg, begin, count, slot0, s);
     case CAMF_CI: return launch_fast_model<CAMF_CI>(a, cfg, begin, count, slot0, s);
     case CAMF_CU: return launch_fast_model<CAMF_CU>(a, cfg, begin, count, slot0, s);
     case CAMF_CUCI: return launch_fast_model<CAMF_CUCI>(a, cfg, begin, count, slot0, s);
@@ -1134,6 +1137,7 @@ hipError_t launch_flow_f32(const SgdArgs<float> &a, const FlowArgs &fa, const La
     if (fa.n_chunks <= 0) return hipSuccess;
     switch (cfg.model) {
     case BIASEDMF: return launch_flow_model<BIASEDMF>(a, fa, grid_blocks, s);
+    case PMF: return launch_flow_model<PMF>(a, fa, grid_blocks, s);
     case CAMF_CI: return launch_flow_model<CAMF_CI>(a, fa, grid_blocks, s);
     case CAMF_CU: return launch_flow_model<CAMF_CU>(a, fa, grid_blocks, s);
     case CAMF_CUCI: return launch_flow_model<CAMF_CUCI>(a, fa, grid_blocks, s);
@@ -1180,6 +1184,7 @@ hipError_t launch_level_generic(const SgdArgs<T> &a, const LaunchCfg &cfg, int64
     if (count <= 0) return hipSuccess;
     switch (cfg.model) {
     case BIASEDMF: return launch_generic_model<T, BIASEDMF>(a, cfg, begin, count, slot0, s);
+    case PMF: return launch_generic_model<T, PMF>(a, cfg, begin, count, slot0, s);
     case CAMF_C: return launch_generic_model<T, CAMF_C>(a, cfg, begin, count, slot0, s);
     case CAMF_CI: return launch_generic_model<T, CAMF_CI>(a, cfg, begin, count, slot0, s);
     case CAMF_CU: return launch_generic_model<T, CAMF_CU>(a, cfg, begin, count, slot0, s);
@@ -1215,6 +1220,7 @@ template <typename T>
 hipError_t launch_serial(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t n, double *loss_out, hipStream_t s) {
     switch (cfg.model) {
     case BIASEDMF: return launch_serial_model<T, BIASEDMF>(a, cfg, n, loss_out, s);
+    case PMF: return launch_serial_model<T, PMF>(a, cfg, n, loss_out, s);
     case CAMF_C: return launch_serial_model<T, CAMF_C>(a, cfg, n, loss_out, s);
     case CAMF_CI: return launch_serial_model<T, CAMF_CI>(a, cfg, n, loss_out, s);
     case CAMF_CU: return launch_serial_model<T, CAMF_CU>(a, cfg, n, loss_out, s);

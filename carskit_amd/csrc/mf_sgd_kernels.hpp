@@ -7,7 +7,7 @@
 
 namespace cmi {
 
-enum Model { BIASEDMF = 0, CAMF_C = 1, CAMF_CI = 2, CAMF_CU = 3, CAMF_CUCI = 4 };
+enum Model { BIASEDMF = 0, CAMF_C = 1, CAMF_CI = 2, CAMF_CU = 3, CAMF_CUCI = 4, PMF = 5 };
 
 // Device-resident hyper-parameters, rewritten before every epoch by set_hparams (so a captured
 // hipGraph of level launches can be replayed with a new learning rate).

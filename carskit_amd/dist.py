@@ -23,6 +23,7 @@ from . import capi
 
 ITEM_SIDE = {
     "BiasedMF": ("Q", "itemBias"),
+    "PMF": ("Q",),
     "CAMF_CI": ("Q", "icBias"),
     "CAMF_CU": ("Q", "itemBias"),
     "CAMF_CUCI": ("Q", "icBias"),

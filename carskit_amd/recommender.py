@@ -76,7 +76,7 @@ class GpuEngine:
             flags |= capi.FLAG_SCHED_SERIAL
         self.inst = capi.Instance(model, k, data.n_users, data.n_items, data.n_conds, device=device, flags=flags)
         self.inst.set_hparams(hp["regU"], hp["regI"], hp["regB"], hp["regC"], hp["gm"])
-        if model == "BiasedMF":
+        if model in ("BiasedMF", "PMF"):
             self.inst.set_ratings(u, j, None, r)
         else:
             self.inst.set_ratings(u, j, ctx, r, data.ctx_ptr, data.ctx_conds)
@@ -234,6 +234,11 @@ class BiasedMF(IterativeRecommender):   # src/carskit/alg/baseline/cf/BiasedMF.j
     is_cars = False
 
 
+class PMF(IterativeRecommender):        # src/carskit/alg/baseline/cf/PMF.java
+    algo_name = "PMF"
+    is_cars = False
+
+
 class CAMF_C(ContextRecommender):       # src/carskit/alg/cars/adaptation/dependent/dev/CAMF_C.java
     algo_name = "CAMF_C"
 
@@ -285,7 +290,7 @@ class FM(ContextRecommender):
 
 
 # the reference's factory switch (src/carskit/main/CARSKit.java:461,700-707,742), lower-cased names
-RECOMMENDERS = {"biasedmf": BiasedMF, "camf_c": CAMF_C, "camf_ci": CAMF_CI, "camf_cu": CAMF_CU,
+RECOMMENDERS = {"biasedmf": BiasedMF, "pmf": PMF, "camf_c": CAMF_C, "camf_ci": CAMF_CI, "camf_cu": CAMF_CU,
                 "camf_cuci": CAMF_CUCI, "fm": FM}
 
 

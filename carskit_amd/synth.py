@@ -261,6 +261,8 @@ def init_state(model, data, k, seed=DEFAULT_SEED + 2, dtype=np.float64):
     elif model == "CAMF_CUCI":
         st["ucBias"] = g(data.n_users, data.n_conds)
         st["icBias"] = g(data.n_items, data.n_conds)
+    elif model == "PMF":
+        pass
     else:
         raise ValueError(model)
     return st

@@ -44,6 +44,8 @@ extern "C" {
 #define CMI_MODEL_CAMF_CI 2   /* .../dev/CAMF_CI.java */
 #define CMI_MODEL_CAMF_CU 3   /* .../dev/CAMF_CU.java */
 #define CMI_MODEL_CAMF_CUCI 4 /* .../dev/CAMF_CUCI.java */
+#define CMI_MODEL_PMF 5       /* src/carskit/alg/baseline/cf/PMF.java:47-82: BiasedMF without biases and without
+                                 globalMean (predict = rowMult, IterativeRecommender.java:126-128); 2-D train matrix */
 
 /* state containers = the model fields a subclass must leave consistent
  * (IterativeRecommender.java:56-64, CAMF.java:40-42) */

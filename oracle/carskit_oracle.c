@@ -42,11 +42,13 @@ double orc_predict(const orc_problem *p, int32_t u, int32_t j, int32_t ctx) {
     const double dot = row_mult(p->P + (size_t)u * k, p->Q + (size_t)j * k, k);
     double pred;
     int32_t b = 0, e = 0;
-    if (p->model != ORC_BIASEDMF) {
+    if (p->model != ORC_BIASEDMF && p->model != ORC_PMF) {
         b = p->ctx_ptr[ctx];
         e = p->ctx_ptr[ctx + 1];
     }
     switch (p->model) {
+    case ORC_PMF: /* IterativeRecommender.java:126-128 via PMF.java:85-91: the bare dot product */
+        return dot;
     case ORC_BIASEDMF: /* BiasedMF.java:111-114 */
         return p->globalMean + p->userBias[u] + p->itemBias[j] + dot;
     case ORC_CAMF_C: /* CAMF_C.java:66-72 */
@@ -87,7 +89,7 @@ double orc_sgd_epoch(const orc_problem *p, double lRate) {
         const double euj = rujc - pred;
         double sgd;
         int32_t cb = 0, ce = 0;
-        if (p->model != ORC_BIASEDMF) {
+        if (p->model != ORC_BIASEDMF && p->model != ORC_PMF) {
             cb = p->ctx_ptr[ctx];
             ce = p->ctx_ptr[ctx + 1];
         }
@@ -95,6 +97,8 @@ double orc_sgd_epoch(const orc_problem *p, double lRate) {
         loss += euj * euj;
 
         switch (p->model) {
+        case ORC_PMF: /* PMF.java:60-71: no bias terms */
+            break;
         case ORC_BIASEDMF: { /* BiasedMF.java:70-82 */
             double bu = p->userBias[u];
             sgd = euj - regB * bu;

@@ -32,7 +32,8 @@ enum {
     ORC_CAMF_C = 1,   /* src/carskit/alg/cars/adaptation/dependent/dev/CAMF_C.java */
     ORC_CAMF_CI = 2,  /* .../dev/CAMF_CI.java */
     ORC_CAMF_CU = 3,  /* .../dev/CAMF_CU.java */
-    ORC_CAMF_CUCI = 4 /* .../dev/CAMF_CUCI.java */
+    ORC_CAMF_CUCI = 4, /* .../dev/CAMF_CUCI.java */
+    ORC_PMF = 5        /* src/carskit/alg/baseline/cf/PMF.java */
 };
 
 /* Flat view of one recommender instance's state and training tuples.

@@ -239,8 +239,19 @@ class CAMF_CUCI(Model):
         return [self.regC * si + self.regC * su]
 
 
-MODELS = {m.name: m for m in (BiasedMF, CAMF_C, CAMF_CI, CAMF_CU, CAMF_CUCI)}
-MODEL_IDS = {"BiasedMF": 0, "CAMF_C": 1, "CAMF_CI": 2, "CAMF_CU": 3, "CAMF_CUCI": 4}
+class PMF(Model):
+    """src/carskit/alg/baseline/cf/PMF.java:47-91: no biases, predict = rowMult."""
+    name = "PMF"
+
+    def predict(self, u, j, c):
+        return self.dot(u, j)
+
+    def biases(self, u, j, c, e, lr):
+        return []
+
+
+MODELS = {m.name: m for m in (BiasedMF, CAMF_C, CAMF_CI, CAMF_CU, CAMF_CUCI, PMF)}
+MODEL_IDS = {"BiasedMF": 0, "CAMF_C": 1, "CAMF_CI": 2, "CAMF_CU": 3, "CAMF_CUCI": 4, "PMF": 5}
 
 
 class Schedule:

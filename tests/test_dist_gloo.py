@@ -17,7 +17,7 @@ import torch.multiprocessing as mp
 from carskit_amd import dist as cdist, synth
 from tests import util
 
-MODELS = ["BiasedMF", "CAMF_CI", "CAMF_CU", "CAMF_CUCI"]
+MODELS = ["BiasedMF", "PMF", "CAMF_CI", "CAMF_CU", "CAMF_CUCI"]
 EPOCHS = 3
 
 

@@ -29,7 +29,7 @@ def make_pair(model, data, k, flags, seed=5, regs=None):
     u, j, ctx, r = util.tuples_for(model, data)
     inst = capi.Instance(model, k, data.n_users, data.n_items, data.n_conds, flags=flags)
     inst.set_hparams(regU, regI, regB, regC, gm)
-    if model == "BiasedMF":
+    if model in util.TWO_D:
         inst.set_ratings(u, j, None, r)
     else:
         inst.set_ratings(u, j, ctx, r, data.ctx_ptr, data.ctx_conds)
@@ -81,7 +81,7 @@ def test_level_f64_default(model):
     o_losses, _, _ = orc.build_model(10, util.LR, bold_driver=True)
     g_losses, _ = inst.train(10, util.LR, bold_driver=True)
     np.testing.assert_allclose(g_losses, o_losses, rtol=1e-11)
-    tu, tj, tctx, tr = util.tuples_for(model, test) if model != "BiasedMF" else (test.u, test.j, None, test.r)
+    tu, tj, tctx, tr = util.tuples_for(model, test) if model not in util.TWO_D else (test.u, test.j, None, test.r)
     oe = orc.eval_ratings(tu, tj, tctx, tr, 1.0, 5.0)
     ge = inst.eval_ratings(tu, tj, tctx, tr, 1.0, 5.0)
     assert oe["n"] == ge["n"]
@@ -103,14 +103,14 @@ def test_level_f32_rmse_within_1e5(model, k):
     assert g_lrs.tolist() == o_lrs.tolist()             # same bold-driver decisions
     np.testing.assert_allclose(g_losses, o_losses, rtol=2e-5)
     tu, tj, tctx, tr = (test.u, test.j, test.ctx, test.r)
-    if model == "BiasedMF":
+    if model in util.TWO_D:
         tctx = None
     oe = orc.eval_ratings(tu, tj, tctx, tr, 1.0, 5.0)
     ge = inst.eval_ratings(tu, tj, tctx, tr, 1.0, 5.0)
     assert abs(oe["RMSE"] - ge["RMSE"]) <= 1e-5          # north_star tolerance, fp32
     assert abs(oe["MAE"] - ge["MAE"]) <= 1e-5
     ot = orc.eval_ratings(*util.tuples_for(model, train), 1.0, 5.0)
-    gt = inst.eval_ratings(*util.tuples_for(model, train), 1.0, 5.0) if model != "BiasedMF" else \
+    gt = inst.eval_ratings(*util.tuples_for(model, train), 1.0, 5.0) if model not in util.TWO_D else \
         inst.eval_ratings(*util.tuples_for(model, train)[:2], None, util.tuples_for(model, train)[3], 1.0, 5.0)
     assert abs(ot["RMSE"] - gt["RMSE"]) <= 1e-5
 

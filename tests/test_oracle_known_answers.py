@@ -24,7 +24,7 @@ CONDS = [0, 2]                          # the rating's context = conditions {0, 
 
 def _expected(model):
     dot = sum(p * q for p, q in zip(P0, Q0))
-    pred = GM + dot
+    pred = (GM + dot) if model != "PMF" else dot
     if model in ("BiasedMF", "CAMF_C", "CAMF_CI"):
         pred += BU
     if model in ("BiasedMF", "CAMF_C", "CAMF_CU"):

@@ -4,7 +4,8 @@ import numpy as np
 from carskit_amd import synth
 from oracle import oracle_np
 
-MODELS = ["BiasedMF", "CAMF_C", "CAMF_CI", "CAMF_CU", "CAMF_CUCI"]
+MODELS = ["BiasedMF", "CAMF_C", "CAMF_CI", "CAMF_CU", "CAMF_CUCI", "PMF"]
+TWO_D = ("BiasedMF", "PMF")   # recommenders that iterate the 2-D (user x item) train matrix
 
 # setting.conf defaults as the doubles the reference computes with (Java float -> double)
 REG = synth.java_float(1e-4)
@@ -18,7 +19,7 @@ def small_data(n_users=23, n_items=11, n_dims=2, conds_per_dim=3, n=300, seed=7,
 
 def tuples_for(model, data):
     """(u, j, ctx, r) arrays in the order the model's buildModel iterates."""
-    if model == "BiasedMF":
+    if model in TWO_D:
         u, j, r = synth.to_2d(data)
         return u, j, np.zeros(len(r), np.int32), r
     return data.u, data.j, data.ctx, data.r
