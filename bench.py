@@ -111,9 +111,13 @@ def main():
         % (rank, data.n, data.n_users, data.n_items, data.n_ctx, time.perf_counter() - t0))
     regs = (synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-3))
     lr = synth.java_float(0.02)
-    gm = float(data.r.sum() / np.count_nonzero(data.r))
+    if world > 1:   # SparseMatrix.getGlobalAvg over ALL ranks' tuples
+        from carskit_amd import dist as cdist
+        gm = cdist.global_mean(dist, data.r, device="cuda")
+    else:
+        gm = float(data.r.sum() / np.count_nonzero(data.r))
     t0 = time.perf_counter()
-    state = synth.init_state(model, data, k, seed=synth.DEFAULT_SEED + 2 + (0 if world == 1 else 0), dtype=np.float32)
+    state = synth.init_state(model, data, k, seed=synth.DEFAULT_SEED + 2, dtype=np.float32)
     if world > 1:
         # item-side state must start identical on every rank; user-side differs per rank
         rng_u = np.random.default_rng(synth.DEFAULT_SEED + 7 + rank)
@@ -131,8 +135,7 @@ def main():
 
     trainer = None
     if world > 1:
-        from carskit_amd import dist as cdist
-        trainer = cdist.ShardedEpochRunner(inst, dist)
+        trainer = cdist.ShardedEpochRunner(inst, dist, device_index=local_rank)
     extra = []
     if args.folds > 1:
         if world > 1:

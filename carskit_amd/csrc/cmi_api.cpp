@@ -505,8 +505,6 @@ static SgdArgs<T> make_args(cmi_instance *h) {
     a.k = h->k;
     a.n_conds = h->n_conds;
     a.dmax = h->dmax;
-    a.store_mode = 0;
-    if (const char *env = getenv("CMI_LEVEL_STORE")) a.store_mode = atoi(env);
     return a;
 }
 

@@ -64,16 +64,7 @@ struct Traits {
     static constexpr bool has_ctx = !(MODEL == BIASEDMF || MODEL == PMF); // iterates the contextual matrix
 };
 
-// 16-byte row stores with an explicit cache policy (stores have no outputs, so inline asm is safe here)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_row_wt(float4 *p, float4 v) {
-    const f32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
-}
-__device__ __forceinline__ void st_row_nt(float4 *p, float4 v) {
-    const f32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(x) : "memory");
-}
 
 // ---------------------------------------------------------------------------------------------
 // fast path: fp32 state, K = 64*VPL, 16 lanes per tuple

@@ -28,7 +28,6 @@ struct SgdArgs {
     const HParams *hp;
     double *loss_part;         // one slot per workgroup of the epoch (deterministic reduction)
     int32_t k, n_conds, dmax;
-    int32_t store_mode;        // row stores of the level kernel: 0 plain (write-back L2), 1 sc0 sc1 write-through, 2 nt
 };
 
 struct LaunchCfg {
