@@ -330,7 +330,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (j[t] < 0 || j[t] >= h->n_items) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: item id %d out of range at tuple %lld", j[t], (long long)t);
         if (contextual && (ctx[t] < 0 || ctx[t] >= n_ctx)) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: context id %d out of range at tuple %lld", ctx[t], (long long)t);
     }
-    if (n >= ((int64_t)1 << 31)) CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: more than 2^31-1 tuples per instance");
+    if (n >= ((int64_t)1 << 31) - 1024) CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: more than 2^31-1025 tuples per instance");
 
     h->n = n;
     h->n_ctx = contextual ? n_ctx : 0;
