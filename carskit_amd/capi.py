@@ -62,6 +62,7 @@ SYMBOLS = [
     ("cmi_split_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     ("cmi_flow_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     ("cmi_dao_read", C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    ("cmi_dao_read_shared", C.c_int, [C.c_char_p, _vp, C.POINTER(_vp)]),
     ("cmi_dao_destroy", C.c_int, [_vp]),
     ("cmi_dao_last_error", C.c_char_p, [_vp]),
     ("cmi_dao_counts", C.c_int, [_vp, C.POINTER(_i64)]),
@@ -74,6 +75,8 @@ SYMBOLS = [
     ("cmi_dao_raw_id", C.c_char_p, [_vp, C.c_int, _i32]),
     ("cmi_java_hashmap_order", C.c_int, [_i64, _vp, _vp, C.POINTER(C.c_int)]),
     ("cmi_transform_compact_to_binary", C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]),
+    ("cmi_validate_data_format", C.c_int, [C.c_char_p]),
+    ("cmi_transform", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]),
     ("cmi_fm_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.POINTER(_vp)]),
     ("cmi_fm_destroy", C.c_int, [_vp]),
     ("cmi_fm_last_error", C.c_char_p, [_vp]),

@@ -201,7 +201,7 @@ extern "C" int cmi_dao_destroy(cmi_dao_handle h) {
     return CMI_OK;
 }
 
-extern "C" int cmi_dao_read(const char *path, cmi_dao_handle *out) {
+static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *out) {
     if (out) *out = nullptr;
     if (!path || !out) {
         g_dao_err = "cmi_dao_read: null argument";
@@ -214,6 +214,23 @@ extern "C" int cmi_dao_read(const char *path, cmi_dao_handle *out) {
         return CMI_E_INVALID;
     }
     cmi_dao *d = new cmi_dao();
+    if (base) { // `test-set`: the test DAO is constructed over the TRAIN DAO's maps (CARSKit.java:335-340) and extends them
+        d->user_ids = base->user_ids;
+        d->item_ids = base->item_ids;
+        d->ui_ids = base->ui_ids;
+        d->ctx_ids = base->ctx_ids;
+        d->dim_ids = base->dim_ids;
+        d->users = base->users;
+        d->items = base->items;
+        d->uis = base->uis;
+        d->ctxs = base->ctxs;
+        d->dims = base->dims;
+        d->conds = base->conds;
+        d->cond_dim = base->cond_dim;
+        d->ui_user = base->ui_user;
+        d->ui_item = base->ui_item;
+        d->ctx_cond_list = base->ctx_cond_list;
+    }
     // header (DataDAO.java:198-215): trim, split on runs of tab/comma, columns >= 3 are conditions
     {
         const std::vector<std::string> hd = split_runs(jtrim(lines[0]));
@@ -223,8 +240,18 @@ extern "C" int cmi_dao_read(const char *path, cmi_dao_handle *out) {
             // context.split(":")[0]: text before the first ':' (an empty first token stays empty)
             const std::string dim = jtrim(colon == std::string::npos ? context : context.substr(0, colon));
             const int32_t dimc = first_seen(d->dim_ids, d->dims, dim);
-            d->conds.push_back(context);
-            d->cond_dim.push_back(dimc);
+            if (i - 3 < d->conds.size()) {
+                // condIds.put(context, i-3) on the shared BiMap: a different token for an existing column would
+                // throw IllegalArgumentException (value already present)
+                if (d->conds[i - 3] != context) {
+                    g_dao_err = "test header column " + std::to_string(i) + " ('" + context + "') differs from the training header ('" + d->conds[i - 3] + "')";
+                    delete d;
+                    return CMI_E_INVALID;
+                }
+            } else {
+                d->conds.push_back(context);
+                d->cond_dim.push_back(dimc);
+            }
             const std::string na = ":na";
             if (context.size() >= na.size() && context.compare(context.size() - na.size(), na.size(), na) == 0)
                 d->empty_conds.push_back((int32_t)i - 3);
@@ -296,6 +323,16 @@ extern "C" int cmi_dao_read(const char *path, cmi_dao_handle *out) {
     }
     *out = d;
     return CMI_OK;
+}
+
+extern "C" int cmi_dao_read(const char *path, cmi_dao_handle *out) { return dao_read_impl(path, nullptr, out); }
+
+extern "C" int cmi_dao_read_shared(const char *path, cmi_dao_handle train, cmi_dao_handle *out) {
+    if (!train) {
+        g_dao_err = "cmi_dao_read_shared: null training DAO";
+        return CMI_E_INVALID;
+    }
+    return dao_read_impl(path, train, out);
 }
 
 extern "C" int cmi_dao_counts(cmi_dao_handle h, int64_t out[8]) {
@@ -435,8 +472,296 @@ extern "C" int cmi_java_hashmap_order(int64_t n, const char *const *keys, int64_
     return CMI_OK;
 }
 
-// DataTransformer.TransformationFromCompactToBinary + PublishNewRatingFiles (isLoose=false) + getHeader.
-// *treeified (may be NULL) is set if a HashMap bin reached the treeify threshold (row order then not guaranteed).
+// ---- DataTransformer (src/carskit/data/processor/DataTransformer.java) -------------------------------------------
+
+namespace {
+
+// Multimap<String dim, String cond>: LinkedHashMultimap (insertion order of keys and of each key's values) when
+// built while reading ONE file, TreeMultimap (both sorted by String.compareTo) when getConditions() merges the
+// training and the test file (DataTransformer.java:57-92).
+struct Conditions {
+    bool sorted = false;
+    std::vector<std::string> dims;
+    std::map<std::string, std::vector<std::string>> conds;
+    void put(const std::string &dim, const std::string &cond) {
+        auto it = conds.find(dim);
+        if (it == conds.end()) {
+            it = conds.emplace(dim, std::vector<std::string>()).first;
+            if (sorted) dims.insert(std::lower_bound(dims.begin(), dims.end(), dim), dim);
+            else dims.push_back(dim);
+        }
+        std::vector<std::string> &v = it->second;
+        if (sorted) {
+            auto p = std::lower_bound(v.begin(), v.end(), cond);
+            if (p == v.end() || *p != cond) v.insert(p, cond);
+        } else if (std::find(v.begin(), v.end(), cond) == v.end()) {
+            v.push_back(cond);
+        }
+    }
+    bool has(const std::string &dim, const std::string &cond) const {
+        auto it = conds.find(dim);
+        return it != conds.end() && std::find(it->second.begin(), it->second.end(), cond) != it->second.end();
+    }
+};
+
+// CARSKit.validateDataFormat (src/carskit/main/CARSKit.java:179-215): 1 binary, 2 loose, 3 compact
+int validate_format(const std::vector<std::string> &lines) {
+    if (lines.size() < 2) return 0;
+    const std::vector<std::string> sh = split_keep(lines[0], ','), sd = split_keep(lines[1], ',');
+    if (sh.size() >= 2 && jlower(jtrim(sh[sh.size() - 2])) == "dimension" && jlower(jtrim(sh.back())) == "condition") return 2;
+    for (size_t i = 3; i < sh.size(); ++i) {
+        int32_t v = 0;
+        bool binary_number = i < sd.size() && jparse_int(sd[i], v); // Integer.valueOf: no trim here (NumberFormatException otherwise)
+        if (binary_number) {
+            int32_t c = v < 0 ? -v : v;
+            while (c != 0) {
+                if (c % 10 > 1) binary_number = false;
+                c /= 10;
+            }
+        }
+        if (sh[i].find(':') == std::string::npos || !binary_number) return 3;
+    }
+    return 1;
+}
+
+typedef std::map<std::string, std::string> RatingContext; // HashMap<dim, cond> (only get() is used)
+
+struct NewLines { // HashMap<String key, HashMap<dim,cond>> with first-insertion order remembered
+    std::vector<std::string> keys;
+    std::unordered_map<std::string, size_t> index;
+    std::vector<RatingContext> ctx;
+    RatingContext &at(const std::string &key, bool *fresh) {
+        auto it = index.find(key);
+        if (it == index.end()) {
+            index.emplace(key, keys.size());
+            keys.push_back(key);
+            ctx.emplace_back();
+            if (fresh) *fresh = true;
+            return ctx.back();
+        }
+        if (fresh) *fresh = false;
+        return ctx[it->second];
+    }
+};
+
+// collectors used by getConditions() (DataTransformer.java:94-137)
+bool collect_conditions(const std::vector<std::string> &lines, int fmt, Conditions &c, std::string &err) {
+    const std::vector<std::string> header = split_keep(lines[0], ',');
+    if (fmt == 1) {
+        for (size_t i = 3; i < header.size(); ++i) {
+            const std::vector<std::string> strs = split_keep(header[i], ':');
+            if (strs.size() < 2) {
+                err = "binary header token without ':'";
+                return false;
+            }
+            c.put(jlower(jtrim(strs[0])), jlower(jtrim(strs[1])));
+        }
+    } else if (fmt == 2) {
+        for (size_t ln = 1; ln < lines.size(); ++ln) {
+            const std::vector<std::string> strs = split_keep(lines[ln], ',');
+            if (strs.size() < 5) {
+                err = "loose line with fewer than 5 fields";
+                return false;
+            }
+            std::string cond = jlower(jtrim(strs[4]));
+            if (cond.empty()) cond = "na";
+            c.put(jlower(jtrim(strs[3])), cond);
+        }
+    } else {
+        const size_t dimscount = header.size() - 3;
+        for (size_t ln = 1; ln < lines.size(); ++ln) {
+            const std::vector<std::string> strs = split_keep(lines[ln], ',');
+            if (strs.size() < 3 + dimscount) {
+                err = "compact line with fewer fields than the header";
+                return false;
+            }
+            for (size_t i = 3; i < 3 + dimscount; ++i) {
+                std::string cond = jlower(jtrim(strs[i]));
+                if (cond.empty()) cond = "na";
+                c.put(jlower(jtrim(header[i])), cond);
+            }
+        }
+    }
+    return true;
+}
+
+// One Transformation*ToBinary + PublishNewRatingFiles.  `given` != nullptr: the merged conditions of getConditions()
+// (then a test file does not extend them); nullptr: a fresh LinkedHashMultimap filled while reading.
+int transform_one(const std::vector<std::string> &lines, int fmt, bool is_test, const Conditions *given,
+                  const char *out_path, bool *treeified) {
+    Conditions own;
+    Conditions &cond = own;
+    if (given) own = *given;
+    NewLines nl;
+    const std::vector<std::string> header = split_keep(lines[0], ',');
+    if (fmt == 3) { // DataTransformer.java:231-259
+        if (header.size() < 3) {
+            g_dao_err = "transform: header has fewer than 3 columns";
+            return CMI_E_INVALID;
+        }
+        const size_t dimscount = header.size() - 3;
+        std::vector<std::string> dims(dimscount);
+        for (size_t i = 3; i < header.size(); ++i) dims[i - 3] = jlower(jtrim(header[i]));
+        for (size_t ln = 1; ln < lines.size(); ++ln) {
+            const std::vector<std::string> strs = split_keep(lines[ln], ',');
+            if (strs.size() < 3 + dimscount) {
+                g_dao_err = "transform: line " + std::to_string(ln + 1) + " has fewer fields than the header";
+                return CMI_E_INVALID;
+            }
+            RatingContext rc;
+            for (size_t i = 3; i < 3 + dimscount; ++i) {
+                std::string c = jlower(jtrim(strs[i]));
+                if (c.empty()) c = "na";
+                rc[dims[i - 3]] = c;
+                if (!is_test) cond.put(dims[i - 3], c);
+            }
+            nl.at(lines[ln], nullptr) = rc; // newlines.put(line, ratingcontext): the whole line is the key
+        }
+    } else if (fmt == 2) { // DataTransformer.java:196-229
+        for (size_t ln = 1; ln < lines.size(); ++ln) {
+            const std::vector<std::string> strs = split_keep(lines[ln], ',');
+            if (strs.size() < 5) {
+                g_dao_err = "transform: loose line " + std::to_string(ln + 1) + " has fewer than 5 fields";
+                return CMI_E_INVALID;
+            }
+            const std::string key = jlower(jtrim(strs[0])) + "," + jlower(jtrim(strs[1])) + "," + jlower(jtrim(strs[2]));
+            std::string c = jlower(jtrim(strs[4]));
+            if (c.empty()) c = "na";
+            const std::string dim = jlower(jtrim(strs[3]));
+            if (!is_test) cond.put(dim, c);
+            nl.at(key, nullptr)[dim] = c;
+        }
+    } else { // binary -> binary (DataTransformer.java:158-194)
+        for (size_t ln = 1; ln < lines.size(); ++ln) {
+            const std::vector<std::string> strs = split_keep(lines[ln], ',');
+            if (strs.size() < header.size()) {
+                g_dao_err = "transform: binary line " + std::to_string(ln + 1) + " has fewer fields than the header";
+                return CMI_E_INVALID;
+            }
+            RatingContext rc;
+            for (size_t i = 3; i < header.size(); ++i) {
+                int32_t v;
+                if (!jparse_int(jlower(jtrim(strs[i])), v)) {
+                    g_dao_err = "transform: line " + std::to_string(ln + 1) + ": flag '" + strs[i] + "' is not an integer";
+                    return CMI_E_INVALID;
+                }
+                if (v == 0) continue;
+                const std::vector<std::string> rs = split_keep(header[i], ':');
+                if (rs.size() < 2) {
+                    g_dao_err = "transform: binary header token without ':'";
+                    return CMI_E_INVALID;
+                }
+                rc[jlower(jtrim(rs[0]))] = jlower(jtrim(rs[1]));
+                if (!is_test) cond.put(jlower(jtrim(rs[0])), jlower(jtrim(rs[1])));
+            }
+            nl.at(lines[ln], nullptr) = rc;
+        }
+    }
+    // PublishNewRatingFiles (DataTransformer.java:266-329)
+    bool tree = false;
+    const std::vector<size_t> ord = java_hashmap_order(nl.keys, &tree);
+    if (treeified) *treeified = *treeified || tree;
+    FILE *f = fopen(out_path, "wb");
+    if (!f) {
+        g_dao_err = std::string("transform: cannot write ") + out_path;
+        return CMI_E_INVALID;
+    }
+    std::string hd = "User, Item, Rating";
+    for (const std::string &dim : cond.dims)
+        for (const std::string &c : cond.conds[dim]) hd += ", " + dim + ":" + c;
+    fprintf(f, "%s\n", hd.c_str());
+    const bool is_loose = fmt == 2;
+    for (size_t oi : ord) {
+        const RatingContext &rc = nl.ctx[oi];
+        std::string bits;
+        for (const std::string &dim : cond.dims) {
+            auto it = rc.find(dim);
+            const bool missing = it == rc.end();
+            if (missing && !is_loose) {
+                fclose(f);
+                g_dao_err = "transform: a rating has no condition for dimension '" + dim + "' (NullPointerException in the reference)";
+                return CMI_E_INVALID;
+            }
+            const std::string dimCondition = missing ? std::string() : it->second;
+            const bool isNA = missing || dimCondition == "na";
+            bool isCompleted = false;
+            for (const std::string &c : cond.conds[dim]) {
+                if (!bits.empty()) bits += ",";
+                if (is_loose) {
+                    if (isNA) {
+                        if (c == "na") {
+                            bits += "1";
+                            isCompleted = true;
+                        } else bits += "0";
+                    } else if (isCompleted) bits += "0";
+                    else if (c == dimCondition) {
+                        bits += "1";
+                        isCompleted = true;
+                    } else bits += "0";
+                } else bits += (dimCondition == c) ? "1" : "0";
+            }
+        }
+        std::string key = nl.keys[oi];
+        const std::vector<std::string> skey = split_keep(key, ',');
+        if (skey.size() > 3) key = jlower(jtrim(skey[0])) + "," + jlower(jtrim(skey[1])) + "," + jlower(jtrim(skey[2]));
+        fprintf(f, "%s,%s\n", key.c_str(), bits.c_str());
+    }
+    fclose(f);
+    return CMI_OK;
+}
+
+} // namespace
+
+extern "C" int cmi_validate_data_format(const char *path) {
+    std::vector<std::string> lines;
+    if (!path || !read_lines(path, lines, g_dao_err)) return CMI_E_INVALID;
+    return validate_format(lines);
+}
+
+// DataTransformer.run() (DataTransformer.java:331-396).  test_in == NULL: only the training file is converted
+// (binary input is copied verbatim).  Otherwise getConditions() merges both files' conditions into a SORTED
+// multimap (adding "na" to every dimension that lacks it) and both files are rewritten against it.
+extern "C" int cmi_transform(const char *train_in, const char *train_out, const char *test_in, const char *test_out,
+                             int *treeified) {
+    if (treeified) *treeified = 0;
+    if (!train_in || !train_out || (test_in && !test_out)) return CMI_E_INVALID;
+    std::vector<std::string> tr, te;
+    if (!read_lines(train_in, tr, g_dao_err)) return CMI_E_INVALID;
+    const int ftr = validate_format(tr);
+    if (ftr == 0) {
+        g_dao_err = "transform: training file has no data line";
+        return CMI_E_INVALID;
+    }
+    bool tree = false;
+    if (!test_in) {
+        if (ftr == 1) { // FileIO.copyFile
+            std::ifstream src(train_in, std::ios::binary);
+            std::ofstream dst(train_out, std::ios::binary);
+            dst << src.rdbuf();
+            return dst ? CMI_OK : CMI_E_INVALID;
+        }
+        const int rc = transform_one(tr, ftr, false, nullptr, train_out, &tree);
+        if (treeified) *treeified = tree;
+        return rc;
+    }
+    if (!read_lines(test_in, te, g_dao_err)) return CMI_E_INVALID;
+    const int fte = validate_format(te);
+    if (fte == 0) {
+        g_dao_err = "transform: test file has no data line";
+        return CMI_E_INVALID;
+    }
+    Conditions merged;
+    merged.sorted = true;
+    if (!collect_conditions(tr, ftr, merged, g_dao_err) || !collect_conditions(te, fte, merged, g_dao_err)) return CMI_E_INVALID;
+    for (const std::string &dim : std::vector<std::string>(merged.dims))
+        if (!merged.has(dim, "na")) merged.put(dim, "na");
+    int rc = transform_one(tr, ftr, false, &merged, train_out, &tree);
+    if (rc == CMI_OK) rc = transform_one(te, fte, true, &merged, test_out, &tree);
+    if (treeified) *treeified = tree;
+    return rc;
+}
+
+// kept for callers that know their input is compact
 extern "C" int cmi_transform_compact_to_binary(const char *in_path, const char *out_path, int *treeified) {
     if (!in_path || !out_path) return CMI_E_INVALID;
     std::vector<std::string> lines;
@@ -445,80 +770,8 @@ extern "C" int cmi_transform_compact_to_binary(const char *in_path, const char *
         g_dao_err = "transform: empty file";
         return CMI_E_INVALID;
     }
-    const std::vector<std::string> header = split_keep(lines[0], ','); // NOT trimmed as a whole (DataTransformer.java:234)
-    if (header.size() < 3) {
-        g_dao_err = "transform: header has fewer than 3 columns";
-        return CMI_E_INVALID;
-    }
-    const size_t dimscount = header.size() - 3;
-    std::vector<std::string> dims(dimscount);
-    for (size_t i = 3; i < header.size(); ++i) dims[i - 3] = jlower(jtrim(header[i]));
-    // conditions: LinkedHashMultimap -> dims in first-put order, conditions of a dim in first-put order, no duplicates
-    std::vector<std::string> dim_order;
-    std::unordered_map<std::string, std::vector<std::string>> dim_conds;
-    // newlines: HashMap<line, HashMap<dim, cond>>; a repeated line overwrites (same value anyway)
-    std::vector<std::string> keys;
-    std::unordered_map<std::string, size_t> key_index;
-    std::vector<std::vector<std::string>> key_conds; // per distinct line: condition of dims[d]
-    for (size_t ln = 1; ln < lines.size(); ++ln) {
-        const std::vector<std::string> strs = split_keep(lines[ln], ',');
-        if (strs.size() < 3 + dimscount) {
-            g_dao_err = "transform: line " + std::to_string(ln + 1) + " has fewer fields than the header";
-            return CMI_E_INVALID;
-        }
-        std::vector<std::string> rc(dimscount);
-        // ratingcontext.put(dims[d], cond): a later column with the same dim name overwrites an earlier one
-        std::unordered_map<std::string, std::string> by_dim;
-        for (size_t i = 3; i < 3 + dimscount; ++i) {
-            std::string cond = jlower(jtrim(strs[i]));
-            if (cond.empty()) cond = "na";
-            by_dim[dims[i - 3]] = cond;
-            auto it = dim_conds.find(dims[i - 3]);
-            if (it == dim_conds.end()) {
-                dim_order.push_back(dims[i - 3]);
-                it = dim_conds.emplace(dims[i - 3], std::vector<std::string>()).first;
-            }
-            if (std::find(it->second.begin(), it->second.end(), cond) == it->second.end()) it->second.push_back(cond);
-        }
-        for (size_t dd = 0; dd < dimscount; ++dd) rc[dd] = by_dim[dims[dd]];
-        auto ki = key_index.find(lines[ln]);
-        if (ki == key_index.end()) {
-            key_index.emplace(lines[ln], keys.size());
-            keys.push_back(lines[ln]);
-            key_conds.push_back(rc);
-        } else {
-            key_conds[ki->second] = rc;
-        }
-    }
     bool tree = false;
-    const std::vector<size_t> ord = java_hashmap_order(keys, &tree);
+    const int rc = transform_one(lines, 3, false, nullptr, out_path, &tree);
     if (treeified) *treeified = tree ? 1 : 0;
-    FILE *f = fopen(out_path, "wb");
-    if (!f) {
-        g_dao_err = std::string("transform: cannot write ") + out_path;
-        return CMI_E_INVALID;
-    }
-    std::string hd = "User, Item, Rating";
-    for (const std::string &dim : dim_order)
-        for (const std::string &cond : dim_conds[dim]) hd += ", " + dim + ":" + cond;
-    fprintf(f, "%s\n", hd.c_str());
-    for (size_t oi : ord) {
-        std::string bits;
-        for (const std::string &dim : dim_order) {
-            // ratingcontext.get(dim): the line's condition for this dimension name
-            std::string dimCondition;
-            for (size_t dd = 0; dd < dimscount; ++dd)
-                if (dims[dd] == dim) dimCondition = key_conds[oi][dd];
-            for (const std::string &cond : dim_conds[dim]) {
-                if (!bits.empty()) bits += ",";
-                bits += (dimCondition == cond) ? "1" : "0";
-            }
-        }
-        std::string key = keys[oi];
-        const std::vector<std::string> skey = split_keep(key, ',');
-        if (skey.size() > 3) key = jlower(jtrim(skey[0])) + "," + jlower(jtrim(skey[1])) + "," + jlower(jtrim(skey[2]));
-        fprintf(f, "%s,%s\n", key.c_str(), bits.c_str());
-    }
-    fclose(f);
-    return CMI_OK;
+    return rc;
 }

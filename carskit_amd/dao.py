@@ -12,10 +12,14 @@ from .synth import RatingData
 class DataDAO:
     """DataDAO.readData over a binary-format file (reference DataDAO.java:166-354)."""
 
-    def __init__(self, path):
+    def __init__(self, path, train=None):
+        """train: the training DataDAO whose id maps this (test) DAO shares and extends (`test-set` evaluation)."""
         self.L = capi.lib()
         self.h = C.c_void_p()
-        rc = self.L.cmi_dao_read(str(path).encode(), C.byref(self.h))
+        if train is None:
+            rc = self.L.cmi_dao_read(str(path).encode(), C.byref(self.h))
+        else:
+            rc = self.L.cmi_dao_read_shared(str(path).encode(), train.h, C.byref(self.h))
         if rc != capi.OK:
             self.h = None
             raise capi.CmiError(rc, self.L.cmi_dao_last_error(None).decode())
@@ -87,6 +91,23 @@ def java_hashmap_order(keys):
 def transform_compact_to_binary(in_path, out_path):
     tree = C.c_int()
     rc = capi.lib().cmi_transform_compact_to_binary(str(in_path).encode(), str(out_path).encode(), C.byref(tree))
+    if rc != capi.OK:
+        raise capi.CmiError(rc, capi.lib().cmi_dao_last_error(None).decode())
+    return bool(tree.value)
+
+
+def validate_data_format(path):
+    """1 binary, 2 loose, 3 compact (CARSKit.validateDataFormat)."""
+    return capi.lib().cmi_validate_data_format(str(path).encode())
+
+
+def transform(train_in, train_out, test_in=None, test_out=None):
+    """DataTransformer.run(): rewrite the rating file(s) in the binary format; returns True if a HashMap bin reached the
+    treeify threshold (row order then not guaranteed to be the reference's)."""
+    tree = C.c_int()
+    rc = capi.lib().cmi_transform(str(train_in).encode(), str(train_out).encode(),
+                                  None if test_in is None else str(test_in).encode(),
+                                  None if test_out is None else str(test_out).encode(), C.byref(tree))
     if rc != capi.OK:
         raise capi.CmiError(rc, capi.lib().cmi_dao_last_error(None).decode())
     return bool(tree.value)

@@ -6,7 +6,6 @@ reference's Math.random() is unseedable), run the recommender per fold, average 
 `Final Results by <algo>, MAE: ..., RMSE: ...`.  Only rating prediction (item.ranking=off semantics) is covered."""
 import argparse
 import os
-import shutil
 import sys
 
 import numpy as np
@@ -16,21 +15,9 @@ from .config import FileConfiger, LineConfiger
 from .recommender import RECOMMENDERS, Conf, get_eval_info
 
 
-def validate_data_format(path):
-    """CARSKit.validateDataFormat (:179-215): 1 binary, 2 loose, 3 compact."""
-    with open(path, encoding="latin-1") as f:
-        header = f.readline().rstrip("\r\n").split(",")
-        data = f.readline().rstrip("\r\n").split(",")
-    if len(header) >= 2 and header[-2].strip().lower() == "dimension" and header[-1].strip().lower() == "condition":
-        return 2
-    for i in range(3, len(header)):
-        tok = data[i] if i < len(data) else ""
-        if ":" not in header[i] or not (tok.strip().lstrip("-").isdigit() and set(tok.strip().lstrip("-")) <= set("01")):
-            return 3
-    return 1
-
-
 def read_data(cf, log):
+    """CARSKit.readData (:220-273): transform the rating file(s) into <workspace>/train.csv (and test.csv for
+    `test-set -f <file>`), then read them with the DataDAO.  Returns (train dao, test dao or None, workspace)."""
     rating_file = cf.get_path("dataset.ratings")
     if rating_file is None or not os.path.exists(rating_file):
         raise FileNotFoundError("Your rating file path is incorrect: File doesn't exist. Please double check your configuration.")
@@ -39,23 +26,24 @@ def read_data(cf, log):
     work = os.path.join(os.path.dirname(os.path.abspath(rating_file)), folder) + os.sep
     os.makedirs(work, exist_ok=True)
     log("WorkingPath: " + work)
-    train_csv = work + "train.csv"
-    fmt = validate_data_format(rating_file)
-    if fmt == 1:
-        shutil.copyfile(rating_file, train_csv)
-    elif fmt == 3:
-        log("You rating data is in Compact format. CARSKit is working on transformation on the data format...")
-        dao.transform_compact_to_binary(rating_file, train_csv)
-    else:
-        raise NotImplementedError("loose-format input: convert to the compact or binary format first")
-    d = dao.DataDAO(train_csv)
+    ev = LineConfiger(cf.get_string("evaluation.setup"))
+    test_file = ev.get_string("-f") if (ev.get_main_param() or "").lower().strip() == "test-set" else None
+    ro = cf.get_param_options("ratings.setup")
+    if ro is None or ro.get_int("-datatransformation", 1) > 0:
+        fmt = dao.validate_data_format(rating_file)
+        if fmt in (2, 3):
+            log("You rating data is in %s format. CARSKit is working on transformation on the data format..."
+                % ("Loose" if fmt == 2 else "Compact"))
+        dao.transform(rating_file, work + "train.csv", test_file, work + "test.csv" if test_file else None)
+    train = dao.DataDAO(work + "train.csv")
+    test = dao.DataDAO(work + "test.csv", train=train) if test_file else None
     log("Rating data set has been successfully loaded.")
-    return d, work
+    return train, test, work
 
 
 def run(config_path, engine_factory=None, log=print, conf_overrides=None):
     cf = FileConfiger(config_path)
-    rate_dao, work = read_data(cf, log)
+    rate_dao, test_dao, work = read_data(cf, log)
     data = rate_dao.rating_data()
     conf = Conf(cf, **(conf_overrides or {}))
     algo_line = LineConfiger(cf.get_string("recommender"))
@@ -78,7 +66,15 @@ def run(config_path, engine_factory=None, log=print, conf_overrides=None):
             algo.execute()
             algos.append(algo)
     elif mode == "test-set":
-        raise NotImplementedError("test-set evaluation needs the shared-id test DAO (next row N2)")
+        # the id spaces are the union's: test-only users/items exist in the model (with their initial values) exactly
+        # as in the reference, where rateDao.numUsers() is read after the test DAO extended the shared maps
+        test = test_dao.rating_data()
+        train = synth.RatingData(test.n_users, test.n_items, data.n_conds, data.n_dims, data.u, data.j, data.ctx, data.r,
+                                 test.ctx_ptr, test.ctx_conds, data.min_rate, data.max_rate, dict(data.meta))
+        test.min_rate, test.max_rate = data.min_rate, data.max_rate      # rating scale of the TRAINING dao (:198-200)
+        algo = cls(train, test, -1, conf, engine_factory, log)
+        algo.execute()
+        algos.append(algo)
     else:
         ratio = ev.get_double("-r", 0.8)
         train, test = synth.split(data, 1.0 - ratio, seed=seed)

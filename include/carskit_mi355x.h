@@ -215,6 +215,10 @@ typedef struct cmi_dao *cmi_dao_handle;
  * in first-seen order (users, items, "u,i" pairs, context keys = active condition indices joined by ','),
  * duplicates of a (pair, context) cell: last line wins; rating scale = sorted distinct values. */
 int cmi_dao_read(const char *path, cmi_dao_handle *out);
+/* `test-set` evaluation: the test DAO is built over the TRAINING DAO's id maps and extends them with unseen
+ * users/items/contexts (src/carskit/main/CARSKit.java:335-340, DataDAO.java:119-143).  The result's counts and raw-id
+ * tables are those of the union (what rateDao.numUsers() etc. return afterwards); its matrix is the test matrix. */
+int cmi_dao_read_shared(const char *path, cmi_dao_handle train, cmi_dao_handle *out);
 int cmi_dao_destroy(cmi_dao_handle h);
 const char *cmi_dao_last_error(cmi_dao_handle h);
 /* out: numUsers, numItems, numUserItems, numContexts, numConditions, numContextDims, numRatings (lines), matrix entries */
@@ -240,6 +244,12 @@ int cmi_java_hashmap_order(int64_t n, const char *const *keys, int64_t *position
  * (src/carskit/data/processor/DataTransformer.java:231-259,266-329,155-163): rewrites a compact-format file
  * (user,item,rating,dim1,dim2,...) as the binary-format train.csv, rows in the reference's HashMap order. */
 int cmi_transform_compact_to_binary(const char *in_path, const char *out_path, int *treeified);
+/* CARSKit.validateDataFormat (src/carskit/main/CARSKit.java:179-215): 1 binary, 2 loose, 3 compact, 0 no data line */
+int cmi_validate_data_format(const char *path);
+/* DataTransformer.run() (DataTransformer.java:331-396) for binary / loose / compact input.  test_in == NULL: only the
+ * training file (binary is copied).  With a test file, both are rewritten against the merged, SORTED condition set
+ * of getConditions() (DataTransformer.java:57-92). */
+int cmi_transform(const char *train_in, const char *train_out, const char *test_in, const char *test_out, int *treeified);
 
 /* ---- host-only integer preprocessing (runs without a GPU) ------------------------------------- */
 

@@ -189,3 +189,183 @@ def compact_to_binary(in_path):
             key = ",".join(jtrim(x).lower() for x in skey[:3])
         out.append(key + "," + ",".join(bits))
     return out, newlines.max_bin
+
+
+# ---- the remaining DataTransformer paths (loose, binary->binary, merged conditions) and the shared-map test DAO -------
+
+def validate_format(lines):
+    """CARSKit.validateDataFormat (src/carskit/main/CARSKit.java:179-215)."""
+    if len(lines) < 2:
+        return 0
+    sh, sd = jsplit(lines[0], ",", -1), jsplit(lines[1], ",", -1)
+    if len(sh) >= 2 and jtrim(sh[-2]).lower() == "dimension" and jtrim(sh[-1]).lower() == "condition":
+        return 2
+    for i in range(3, len(sh)):
+        tok = sd[i] if i < len(sd) else ""
+        ok = re.fullmatch(r"[+-]?\d+", tok) is not None and set(tok.lstrip("+-")) <= set("01")
+        if ":" not in sh[i] or not ok:
+            return 3
+    return 1
+
+
+class _Conds:
+    """dim -> ordered conditions; sorted=True models guava's TreeMultimap, else LinkedHashMultimap."""
+
+    def __init__(self, sorted_=False):
+        self.sorted, self.d = sorted_, {}
+
+    def put(self, dim, cond):
+        v = self.d.setdefault(dim, [])
+        if cond not in v:
+            v.append(cond)
+
+    def dims(self):
+        return sorted(self.d) if self.sorted else list(self.d)
+
+    def conds(self, dim):
+        return sorted(self.d[dim]) if self.sorted else list(self.d[dim])
+
+    def copy(self):
+        c = _Conds(self.sorted)
+        c.d = {k: list(v) for k, v in self.d.items()}
+        return c
+
+
+def _collect(lines, fmt, conds):
+    header = jsplit(lines[0], ",", -1)
+    if fmt == 1:
+        for h in header[3:]:
+            s = jsplit(h, ":", -1)
+            conds.put(jtrim(s[0]).lower(), jtrim(s[1]).lower())
+    elif fmt == 2:
+        for line in lines[1:]:
+            s = jsplit(line, ",", -1)
+            conds.put(jtrim(s[3]).lower(), jtrim(s[4]).lower() or "na")
+    else:
+        for line in lines[1:]:
+            s = jsplit(line, ",", -1)
+            for i in range(3, len(header)):
+                conds.put(jtrim(header[i]).lower(), jtrim(s[i]).lower() or "na")
+
+
+def _transform_one(lines, fmt, is_test, given):
+    conds = given.copy() if given is not None else _Conds(False)
+    header = jsplit(lines[0], ",", -1)
+    newlines = JavaHashMap()
+    store = {}
+    if fmt == 3:
+        dims = [jtrim(h).lower() for h in header[3:]]
+        for line in lines[1:]:
+            s = jsplit(line, ",", -1)
+            rc = {}
+            for i in range(3, 3 + len(dims)):
+                c = jtrim(s[i]).lower() or "na"
+                rc[dims[i - 3]] = c
+                if not is_test:
+                    conds.put(dims[i - 3], c)
+            newlines.put(line, rc)
+    elif fmt == 2:
+        for line in lines[1:]:
+            s = jsplit(line, ",", -1)
+            key = ",".join(jtrim(x).lower() for x in s[:3])
+            c = jtrim(s[4]).lower() or "na"
+            dim = jtrim(s[3]).lower()
+            if not is_test:
+                conds.put(dim, c)
+            if key not in store:
+                store[key] = {}
+                newlines.put(key, store[key])
+            store[key][dim] = c
+    else:
+        for line in lines[1:]:
+            s = jsplit(line, ",", -1)
+            rc = {}
+            for i in range(3, len(header)):
+                if int(jtrim(s[i]).lower()) == 0:
+                    continue
+                rs = jsplit(header[i], ":", -1)
+                rc[jtrim(rs[0]).lower()] = jtrim(rs[1]).lower()
+                if not is_test:
+                    conds.put(jtrim(rs[0]).lower(), jtrim(rs[1]).lower())
+            newlines.put(line, rc)
+    out = ["User, Item, Rating" + "".join(", %s:%s" % (d, c) for d in conds.dims() for c in conds.conds(d))]
+    loose = fmt == 2
+    for key, rc in newlines.items():
+        bits = []
+        for d in conds.dims():
+            dc = rc.get(d)
+            if dc is None and not loose:
+                raise TypeError("NullPointerException in the reference")
+            na = dc is None or dc == "na"
+            done = False
+            for c in conds.conds(d):
+                if loose:
+                    if na:
+                        hit = c == "na"
+                    else:
+                        hit = (not done) and c == dc
+                    done = done or hit
+                    bits.append("1" if hit else "0")
+                else:
+                    bits.append("1" if dc == c else "0")
+        skey = jsplit(key, ",", -1)
+        if len(skey) > 3:
+            key = ",".join(jtrim(x).lower() for x in skey[:3])
+        out.append(key + "," + ",".join(bits))
+    return out, newlines.max_bin
+
+
+def transform(train_path, test_path=None):
+    """DataTransformer.run(): returns (train lines, test lines or None, largest HashMap bin seen)."""
+    tr = read_lines(train_path)
+    ftr = validate_format(tr)
+    if test_path is None:
+        if ftr == 1:
+            return tr, None, 0
+        out, mb = _transform_one(tr, ftr, False, None)
+        return out, None, mb
+    te = read_lines(test_path)
+    fte = validate_format(te)
+    merged = _Conds(True)
+    _collect(tr, ftr, merged)
+    _collect(te, fte, merged)
+    for d in merged.dims():
+        if "na" not in merged.d[d]:
+            merged.put(d, "na")
+    a, m1 = _transform_one(tr, ftr, False, merged)
+    b, m2 = _transform_one(te, fte, True, merged)
+    return a, b, max(m1, m2)
+
+
+def read_data_shared(train_path, test_path):
+    """Train DAO, then the test DAO built over the same (mutated) maps (CARSKit.java:335-340).  Returns the test
+    matrix entries with the union id tables."""
+    tr = read_data(train_path)
+    users = {k: i for i, k in enumerate(tr["users"])}
+    items = {k: i for i, k in enumerate(tr["items"])}
+    uis = {k: i for i, k in enumerate(tr["uis"])}
+    ctxs = {k: i for i, k in enumerate(tr["ctxs"])}
+    ui_user, ui_item = list(tr["ui_user"]), list(tr["ui_item"])
+    ctx_conds = {i: c for i, c in enumerate(tr["ctx_conds"])}
+    lines = read_lines(test_path)
+    table, n_lines = {}, 0
+    for line in lines[1:]:
+        data = jsplit(jtrim(line), ",", -1)
+        rate = float(data[2])
+        n_lines += 1
+        row = users.setdefault(data[0], len(users))
+        col = items.setdefault(data[1], len(items))
+        key = "%d,%d" % (row, col)
+        if key not in uis:
+            uis[key] = len(uis)
+            ui_user.append(row)
+            ui_item.append(col)
+        conds = [i - 3 for i in range(3, len(data)) if int(jtrim(data[i])) == 1]
+        ctx = ",".join(str(c) for c in conds)
+        cc = ctxs.setdefault(ctx, len(ctxs))
+        ctx_conds[cc] = conds
+        table[(uis[key], cc)] = rate
+    entries = sorted(table.items())
+    return {"users": list(users), "items": list(items), "uis": list(uis), "ctxs": list(ctxs), "ui_user": ui_user,
+            "ui_item": ui_item, "ctx_conds": [ctx_conds[c] for c in range(len(ctxs))], "num_ratings": n_lines,
+            "ui": [k[0] for k, _ in entries], "ctx": [k[1] for k, _ in entries], "r": [v for _, v in entries]}

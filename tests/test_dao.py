@@ -146,3 +146,90 @@ def test_compact_to_binary_random(tmp_path_factory, seed):
     dao.transform_compact_to_binary(src, out)
     want, _ = dao_oracle.compact_to_binary(src)
     assert open(out).read().split("\n")[:-1] == want
+
+
+# ---- loose / binary input, merged (train + test) conditions, shared-map test DAO ------------------------------------
+
+def _lines(path):
+    return open(path).read().split("\n")[:-1]
+
+
+@pytest.mark.parametrize("name,fmt", [("train_binary.csv", 1), ("train_loose.csv", 2), ("train_compact.csv", 3),
+                                      ("test_binary.csv", 1), ("test_loose.csv", 2), ("test_compact.csv", 3)])
+def test_validate_data_format_on_reference_samples(name, fmt):
+    p = os.path.join(GOLDEN, name)
+    assert dao.validate_data_format(p) == fmt
+    assert dao_oracle.validate_format(dao_oracle.read_lines(p)) == fmt
+
+
+@pytest.mark.parametrize("kind", ["loose", "compact", "binary"])
+def test_transform_train_only(tmp_path, kind):
+    src = os.path.join(GOLDEN, "train_%s.csv" % kind)
+    out = str(tmp_path / "train.csv")
+    dao.transform(src, out)
+    want, _, _ = dao_oracle.transform(src)
+    assert _lines(out) == want
+    if kind == "binary":
+        assert open(out, "rb").read() == open(src, "rb").read()       # copied verbatim
+    d = dao.DataDAO(out)
+    assert d.num_context_dims == 3
+    ref = dao.DataDAO(os.path.join(GOLDEN, "train_binary.csv"))
+    assert (d.num_users, d.num_items) == (ref.num_users, ref.num_items)
+    if kind == "compact":
+        # the compact sample describes the same 20 ratings as the binary sample (row order aside); the loose
+        # format keys a rating by "user,item,rating", so same-valued ratings of a pair in different contexts merge
+        assert d.nnz == ref.nnz and sorted(d.r.tolist()) == sorted(ref.r.tolist())
+
+
+@pytest.mark.parametrize("tr,te", [("loose", "loose"), ("compact", "compact"), ("binary", "binary"),
+                                   ("compact", "loose"), ("binary", "compact")])
+def test_transform_with_test_set_and_shared_dao(tmp_path, tr, te):
+    """`test-set` evaluation: conditions merged over both files (sorted, "na" added), both rewritten, and the test
+    DAO extends the training DAO's id maps."""
+    a, b = os.path.join(GOLDEN, "train_%s.csv" % tr), os.path.join(GOLDEN, "test_%s.csv" % te)
+    oa, ob = str(tmp_path / "train.csv"), str(tmp_path / "test.csv")
+    dao.transform(a, oa, b, ob)
+    wa, wb, _ = dao_oracle.transform(a, b)
+    assert _lines(oa) == wa and _lines(ob) == wb
+    assert _lines(oa)[0] == _lines(ob)[0]                            # one header for both
+    hdr = _lines(oa)[0].split(", ")[3:]
+    assert hdr == sorted(hdr)                                        # TreeMultimap order
+    assert all(any(h == d + ":na" for h in hdr) for d in {h.split(":")[0] for h in hdr})
+    train = dao.DataDAO(oa)
+    test = dao.DataDAO(ob, train=train)
+    o = dao_oracle.read_data_shared(oa, ob)
+    assert test.raw_ids("user") == o["users"] and test.raw_ids("item") == o["items"]
+    assert test.raw_ids("ui") == o["uis"] and test.raw_ids("ctx") == o["ctxs"]
+    assert test.ui_user.tolist() == o["ui_user"] and test.ui_item.tolist() == o["ui_item"]
+    assert test.ui.tolist() == o["ui"] and test.ctx.tolist() == o["ctx"] and test.r.tolist() == o["r"]
+    assert test.num_ratings == o["num_ratings"]
+    assert test.raw_ids("user")[:train.num_users] == train.raw_ids("user")      # training ids are kept
+    assert test.num_users >= train.num_users and test.num_contexts >= train.num_contexts
+
+
+def test_shared_dao_rejects_a_different_header(tmp_path):
+    a = os.path.join(GOLDEN, "train_binary.csv")
+    train = dao.DataDAO(a)
+    bad = tmp_path / "t.csv"
+    bad.write_text("User,Item,Rating,x:a\nu,i,3,1\n")
+    with pytest.raises(Exception):
+        dao.DataDAO(str(bad), train=train)
+
+
+@settings(max_examples=20, deadline=None)
+@given(seed=st.integers(0, 10_000))
+def test_transform_loose_random(tmp_path_factory, seed):
+    rng = random.Random(seed)
+    td = tmp_path_factory.mktemp("lo")
+    src, out = str(td / "l.csv"), str(td / "b.csv")
+    dims = {"Time": ["Weekend", "Weekday", ""], "Location": ["Home", "Cinema", "NA"], "Companion": ["Alone", "Family"]}
+    lines = ["user,item,rating,dimension,condition"]
+    for _ in range(rng.randrange(1, 60)):
+        u, i, r = rng.randrange(8), rng.randrange(5), rng.randrange(1, 6)
+        for d in rng.sample(list(dims), rng.randrange(1, 4)):
+            lines.append("%d, tt%d ,%d,%s,%s" % (u, i, r, d, rng.choice(dims[d])))
+    open(src, "w").write("\n".join(lines) + "\n")
+    dao.transform(src, out)
+    want, _, _ = dao_oracle.transform(src)
+    assert _lines(out) == want
+    dao.DataDAO(out)

@@ -138,3 +138,24 @@ def test_frappe_loads_through_transformer_and_dao(tmp_path):
     assert got[0] == want[0] and sorted(got[1:]) == sorted(want[1:])
     if max_bin < 8:              # no bin could have been treeified: the row ORDER is the reference's too
         assert got == want and not tree
+
+
+def test_test_set_evaluation_via_setting_conf(tmp_path):
+    """`evaluation.setup=test-set -f <file>`: both files transformed against the merged conditions, the test DAO
+    shares and extends the training DAO's ids, the recommender is sized for the union."""
+    shutil.copyfile(os.path.join(GOLDEN, "train_compact.csv"), tmp_path / "ratings.txt")
+    shutil.copyfile(os.path.join(GOLDEN, "test_loose.csv"), tmp_path / "test.txt")
+    conf = open(os.path.join(GOLDEN, "depaul_setting.conf")).read().replace("PLACEHOLDER_SET_BY_TEST", str(tmp_path / "ratings.txt"))
+    conf = conf.replace("evaluation.setup=cv -k 5 -p off --rand-seed 1 --test-view all",
+                        "evaluation.setup=test-set -f %s --rand-seed 1" % (tmp_path / "test.txt"))
+    conf = conf.replace("recommender=biasedmf", "recommender=camf_cu")
+    (tmp_path / "setting.conf").write_text(conf)
+    lines = []
+    avg, algos, rate_dao = main.run(str(tmp_path / "setting.conf"), engine_factory=util.OracleEngine, log=lines.append,
+                                    conf_overrides={"num_iters": 5})
+    a = algos[0]
+    assert a.algo_name == "CAMF_CU" and a.testMatrix.n > 0
+    assert a.trainMatrix.n_users >= rate_dao.num_users              # union of train and test users
+    assert a.state["P"].shape == (a.trainMatrix.n_users, 10)
+    assert lines[-1].startswith("Final Results by CAMF_CU, MAE: ")
+    assert np.isfinite(avg["RMSE"])
