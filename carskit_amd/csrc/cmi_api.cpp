@@ -379,6 +379,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             if (const char *env = getenv("CMI_LEVEL_ORDER")) {
                 if (!strcmp(env, "item")) order = LEVEL_ORDER_ITEM;
                 else if (!strcmp(env, "user")) order = LEVEL_ORDER_USER;
+                else if (!strcmp(env, "xcd")) order = LEVEL_ORDER_XCD;
             }
             if (!build_level_schedule(n, u, j, h->n_users, h->n_items, order, sch))
                 CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: schedule construction failed");
@@ -816,7 +817,7 @@ extern "C" int cmi_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const
 extern "C" int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
                                   int order, int32_t *perm, int64_t *level_off, int64_t level_cap,
                                   int64_t *n_levels) {
-    if (n < 0 || (n > 0 && (!u || !j)) || n_users <= 0 || n_items <= 0 || !n_levels || order < 0 || order > 2)
+    if (n < 0 || (n > 0 && (!u || !j)) || n_users <= 0 || n_items <= 0 || !n_levels || order < 0 || order > 3)
         return CMI_E_INVALID;
     for (int64_t t = 0; t < n; ++t)
         if (u[t] < 0 || u[t] >= n_users || j[t] < 0 || j[t] >= n_items) return CMI_E_INVALID;

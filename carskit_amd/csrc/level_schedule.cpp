@@ -55,7 +55,29 @@ bool build_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t
     }
     // Tuples of a level are independent, so their order inside the level is free: sorting by item
     // (or user) id only changes which rows neighbouring lanes touch (memory locality), not the result.
-    if (within_level_order != LEVEL_ORDER_CRS) {
+    if (within_level_order == LEVEL_ORDER_XCD) {
+        // XCD affinity: workgroup b of a launch lands on XCD b % 8 (observed placement, used for speed only), so give
+        // workgroup b the tuples whose item id is b % 8 (mod 8): each XCD's L2 then only ever sees 1/8 of Q / icBias.
+        std::vector<int32_t> bucket[8];
+        for (int32_t l = 0; l < n_levels; ++l) {
+            const int64_t b = out.level_off[(size_t)l], e = out.level_off[(size_t)l + 1];
+            for (auto &v : bucket) v.clear();
+            for (int64_t q = b; q < e; ++q) bucket[j[out.perm[(size_t)q]] & 7].push_back(out.perm[(size_t)q]);
+            size_t taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int64_t w = b;
+            for (int64_t blk = 0; w < e; ++blk) {
+                int x = (int)(blk & 7), tries = 0;
+                while (taken[x] >= bucket[x].size() && tries < 8) { // bucket exhausted: borrow from the next one
+                    x = (x + 1) & 7;
+                    ++tries;
+                }
+                for (int c = 0; c < LEVEL_XCD_BLOCK && w < e; ++c) {
+                    while (taken[x] >= bucket[x].size()) x = (x + 1) & 7;
+                    out.perm[(size_t)w++] = bucket[x][taken[x]++];
+                }
+            }
+        }
+    } else if (within_level_order != LEVEL_ORDER_CRS) {
         const int32_t *key = within_level_order == LEVEL_ORDER_ITEM ? j : u;
         for (int32_t l = 0; l < n_levels; ++l) {
             auto b = out.perm.begin() + out.level_off[(size_t)l], e = out.perm.begin() + out.level_off[(size_t)l + 1];

@@ -5,7 +5,8 @@
 
 namespace cmi {
 
-enum { LEVEL_ORDER_CRS = 0, LEVEL_ORDER_ITEM = 1, LEVEL_ORDER_USER = 2 };
+enum { LEVEL_ORDER_CRS = 0, LEVEL_ORDER_ITEM = 1, LEVEL_ORDER_USER = 2, LEVEL_ORDER_XCD = 3 };
+static const int LEVEL_XCD_BLOCK = 32; // tuples per workgroup of the fast level kernel (16 groups x 2 tuples)
 
 struct LevelSchedule {
     std::vector<int32_t> perm;       // schedule position -> CRS tuple index

@@ -306,3 +306,28 @@ def test_flow_schedule_hot_item_and_fallback():
     assert fb.schedule_info()["kind"] == "level"
     _, fb64 = make_pair("CAMF_CI", data, 64, FLOW | F64)
     assert fb64.schedule_info()["kind"] == "level"
+
+
+def test_instances_are_reentrant_across_threads():
+    """The reference runs one recommender per CV fold on its own Java thread (CARSKit.java:395-412).  Handles carry
+    their own stream/graph and the library has no global state: concurrent training from several host threads gives
+    exactly the results of running the same instances one after another."""
+    import threading
+    data = util.small_data(n_users=4000, n_items=500, n_dims=3, conds_per_dim=3, n=90000, seed=71)
+    models = ["CAMF_CI", "CAMF_CU", "CAMF_CUCI", "BiasedMF", "PMF"]
+
+    def run(model, out, idx):
+        _, inst = make_pair(model, data, 64, 0, seed=idx)
+        losses, _ = inst.train(6, util.LR, bold_driver=True)
+        out[idx] = (losses.tolist(), inst.get_states(np.float32))
+
+    seq, par = {}, {}
+    for i, m in enumerate(models):
+        run(m, seq, i)
+    ths = [threading.Thread(target=run, args=(m, par, i)) for i, m in enumerate(models)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for i in range(len(models)):
+        assert par[i][0] == seq[i][0], models[i]
+        for name in seq[i][1]:
+            assert np.array_equal(par[i][1][name], seq[i][1][name]), (models[i], name)
