@@ -1,0 +1,167 @@
+// carskit_main.cpp -- `carskit-mi355x -c setting.conf`: the reference driver's flow (src/carskit/main/CARSKit.java:
+// execute :109, preset :140, readData :220, runAlgorithm :310, runCrossValidation :388, printEvalInfo :362) for the
+// recommenders libcarskit_mi355x accelerates, rating prediction only.  Links nothing but the C ABI.
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+
+#include "recommender.hpp"
+
+using namespace carskit;
+
+static std::string dirname_of(const std::string &p) {
+    const size_t s = p.find_last_of('/');
+    return s == std::string::npos ? std::string("./") : p.substr(0, s + 1);
+}
+
+struct Dao {
+    cmi_dao_handle h = nullptr;
+    int64_t counts[8] = {};
+    explicit Dao(const std::string &path, cmi_dao_handle train = nullptr) {
+        const int rc = train ? cmi_dao_read_shared(path.c_str(), train, &h) : cmi_dao_read(path.c_str(), &h);
+        if (rc != CMI_OK) throw std::runtime_error("DataDAO: " + std::string(cmi_dao_last_error(nullptr)));
+        cmi_dao_counts(h, counts);
+    }
+    ~Dao() { cmi_dao_destroy(h); }
+    RatingData ratingData() const {
+        RatingData d;
+        d.n_users = (int32_t)counts[0];
+        d.n_items = (int32_t)counts[1];
+        d.n_conds = (int32_t)counts[4];
+        d.n_dims = (int32_t)counts[5];
+        const size_t n = (size_t)counts[7], nui = (size_t)counts[2], nctx = (size_t)counts[3];
+        std::vector<int32_t> ui(n), uiu(nui), uii(nui);
+        d.ctx.resize(n);
+        d.r.resize(n);
+        cmi_dao_matrix(h, ui.data(), d.ctx.data(), d.r.data());
+        cmi_dao_ui_maps(h, uiu.data(), uii.data());
+        d.u.resize(n);
+        d.j.resize(n);
+        for (size_t t = 0; t < n; ++t) {
+            d.u[t] = uiu[(size_t)ui[t]];
+            d.j[t] = uii[(size_t)ui[t]];
+        }
+        d.ctx_ptr.resize(nctx + 1);
+        d.ctx_conds.resize((size_t)cmi_dao_ctx_nnz(h));
+        cmi_dao_ctx_table(h, d.ctx_ptr.data(), d.ctx_conds.data());
+        int32_t ns = 0;
+        cmi_dao_rating_scale(h, nullptr, 0, &ns);
+        std::vector<double> scale((size_t)ns);
+        cmi_dao_rating_scale(h, scale.data(), ns, &ns);
+        if (ns > 0) {
+            d.min_rate = scale.front();
+            d.max_rate = scale.back();
+        }
+        return d;
+    }
+};
+
+static std::string evalInfo(const Measures &m) { // Recommender.getEvalInfo, rating branch (incl. the "NAME" typo)
+    char buf[256];
+    snprintf(buf, sizeof buf, "MAE: %.6f, RMSE: %.6f, NAME: %.6f, rMAE: %.6f, rRMSE: %.6f, MPE: %.6f", m.at("MAE"), m.at("RMSE"),
+             m.at("NMAE"), m.at("rMAE"), m.at("rRMSE"), m.at("MPE"));
+    return buf;
+}
+
+static int run(const std::string &config, unsigned flags, int iters_override, bool precise) {
+    Logger log = [](const std::string &s) { std::cout << s << std::endl; };
+    FileConfiger cf(config);
+    Conf conf(cf);
+    conf.flags = flags;
+    if (iters_override > 0) conf.numIters = iters_override;
+    // preset + readData
+    const std::string ratingFile = cf.getPath("dataset.ratings");
+    if (ratingFile.empty() || !std::ifstream(ratingFile)) throw std::runtime_error("Your rating file path is incorrect: File doesn't exist. Please double check your configuration.");
+    LineConfiger out = cf.getParamOptions("output.setup");
+    const std::string work = dirname_of(ratingFile) + out.getString("-folder", "CARSKit.Workspace") + "/";
+    std::string mk = "mkdir -p '" + work + "'";
+    if (std::system(mk.c_str()) != 0) throw std::runtime_error("cannot create " + work);
+    log("WorkingPath: " + work);
+    LineConfiger ev = cf.getParamOptions("evaluation.setup");
+    const std::string mode = lower(ev.getMainParam());
+    const std::string testFile = mode == "test-set" ? ev.getString("-f") : "";
+    LineConfiger ro = cf.getParamOptions("ratings.setup");
+    if (!cf.contains("ratings.setup") || ro.getInt("-datatransformation", 1) > 0) {
+        const int fmt = cmi_validate_data_format(ratingFile.c_str());
+        if (fmt == 2 || fmt == 3)
+            log(std::string("You rating data is in ") + (fmt == 2 ? "Loose" : "Compact") + " format. CARSKit is working on transformation on the data format...");
+        int tree = 0;
+        if (cmi_transform(ratingFile.c_str(), (work + "train.csv").c_str(), testFile.empty() ? nullptr : testFile.c_str(),
+                          testFile.empty() ? nullptr : (work + "test.csv").c_str(), &tree) != CMI_OK)
+            throw std::runtime_error("DataTransformer: " + std::string(cmi_dao_last_error(nullptr)));
+    }
+    Dao rateDao(work + "train.csv");
+    log("Rating data set has been successfully loaded.");
+    RatingData data = rateDao.ratingData();
+    // runAlgorithm
+    const std::string algoName = LineConfiger(cf.getString("recommender")).getMainParam();
+    log("With Setup: " + cf.getString("evaluation.setup"));
+    std::vector<Measures> all;
+    std::string name;
+    auto runFold = [&](const RatingData &tr, const RatingData &te, int fold) {
+        auto algo = getRecommender(algoName, tr, te, fold, conf, log);
+        all.push_back(algo->execute());
+        name = algo->algoName;
+    };
+    if (mode == "cv") {
+        int k = 0;
+        const std::vector<int> labels = split_folds(data.n(), ev.getInt("-k", 5), conf.randSeed, &k);
+        for (int f = 1; f <= k; ++f) {
+            std::vector<int64_t> tr, te;
+            for (int64_t t = 0; t < data.n(); ++t) {
+                if (data.r[(size_t)t] == 0.0) continue; // reshape() drops zero entries
+                (labels[(size_t)t] == f ? te : tr).push_back(t);
+            }
+            runFold(data.subset(tr), data.subset(te), f);
+        }
+    } else if (mode == "test-set") {
+        Dao testDao(work + "test.csv", rateDao.h);
+        RatingData test = testDao.ratingData();
+        RatingData train = data; // id spaces of the union (the shared maps were extended by the test DAO)
+        train.n_users = test.n_users;
+        train.n_items = test.n_items;
+        train.ctx_ptr = test.ctx_ptr;
+        train.ctx_conds = test.ctx_conds;
+        test.min_rate = data.min_rate;
+        test.max_rate = data.max_rate;
+        runFold(train, test, -1);
+    } else { // given-ratio: the reference draws Math.random() (unseedable); a seeded stream here
+        const double ratio = ev.getDouble("-r", 0.8);
+        JavaRandom rnd(conf.randSeed);
+        std::vector<int64_t> tr, te;
+        for (int64_t t = 0; t < data.n(); ++t) (rnd.nextDouble() < ratio ? tr : te).push_back(t);
+        runFold(data.subset(tr), data.subset(te), -1);
+    }
+    Measures avg;
+    for (const Measures &m : all)
+        for (const auto &kv : m) avg[kv.first] += kv.second / (double)all.size();
+    log("Final Results by " + name + ", " + evalInfo(avg));
+    if (precise) // machine-readable, full precision (for the parity tests)
+        printf("PRECISE %s folds=%zu MAE=%.17g RMSE=%.17g\n", name.c_str(), all.size(), avg["MAE"], avg["RMSE"]);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    std::vector<std::string> configs;
+    unsigned flags = 0;
+    int iters = 0;
+    bool precise = false;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "-c") && i + 1 < argc) configs.push_back(argv[++i]);
+        else if (!strcmp(argv[i], "--flags") && i + 1 < argc) flags = (unsigned)std::strtoul(argv[++i], nullptr, 0);
+        else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = std::atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--precise")) precise = true;
+        else {
+            fprintf(stderr, "usage: carskit-mi355x -c setting.conf [-c more.conf] [--flags N] [--iters N] [--precise]\n");
+            return 2;
+        }
+    }
+    if (configs.empty()) configs.push_back("setting.conf");
+    try {
+        for (const std::string &c : configs) run(c, flags, iters, precise);
+    } catch (const std::exception &e) { // the reference logs e.getMessage() and a stack trace (CARSKit.java:96-101)
+        fprintf(stderr, "ERROR: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

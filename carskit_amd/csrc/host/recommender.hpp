@@ -1,0 +1,385 @@
+// recommender.hpp -- C++ host layer above the C ABI, mirroring the reference's plugin interface for the accelerated
+// path (same class names, hooks and lifecycle as src/carskit/generic/{Recommender,IterativeRecommender,
+// ContextRecommender}.java and the model classes).  It uses ONLY include/carskit_mi355x.h -- it is what a JVM-less
+// deployment links, and it shows the boundary is sufficient for a complete host.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/carskit_mi355x.h"
+#include "configer.hpp"
+
+namespace carskit {
+
+// StrictMath.log = fdlibm __ieee754_log (published algorithm), for finite positive normal x: glibc's log is correctly
+// rounded and differs from fdlibm in the last ulp for some arguments, which would desynchronise nextGaussian().
+inline double fdlibm_log(double x) {
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                        Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                        Lg7 = 1.479819860511658591e-01;
+    uint64_t bits;
+    static_assert(sizeof bits == sizeof x, "");
+    std::memcpy(&bits, &x, 8);
+    int32_t hx = (int32_t)(bits >> 32), k = 0;
+    if (hx < 0x00100000 || hx >= 0x7ff00000) return std::log(x);
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int32_t i0 = (hx + 0x95f64) & 0x100000;
+    bits = ((uint64_t)(uint32_t)(hx | (i0 ^ 0x3ff00000)) << 32) | (bits & 0xffffffffULL);
+    std::memcpy(&x, &bits, 8);
+    k += i0 >> 20;
+    const double f = x - 1.0, dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) {
+        if (f == 0.0) return k == 0 ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+        const double R = f * f * (0.5 - 0.33333333333333333 * f);
+        return k == 0 ? f - R : dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    const double s = f / (2.0 + f), z = s * s, w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6)), t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    if (((hx - 0x6147a) | (0x6b851 - hx)) > 0) {
+        const double hfsq = 0.5 * f * f;
+        return k == 0 ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return k == 0 ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+// java.util.Random (published algorithm): fold assignment follows the reference's stream
+// (happy.coding.math.Randoms.seed(n) -> new Random(n); uniform() -> nextDouble()).
+class JavaRandom {
+  public:
+    explicit JavaRandom(int64_t seed) : seed_(((uint64_t)seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1)) {}
+    int32_t next(int bits) {
+        seed_ = (seed_ * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
+        return (int32_t)((int64_t)seed_ >> (48 - bits));
+    }
+    double nextDouble() { return (double)(((int64_t)next(26) << 27) + next(27)) * 0x1.0p-53; }
+    double nextGaussian() { // polar method with StrictMath.log / StrictMath.sqrt
+        if (have_) {
+            have_ = false;
+            return cached_;
+        }
+        double v1, v2, s;
+        do {
+            v1 = 2 * nextDouble() - 1;
+            v2 = 2 * nextDouble() - 1;
+            s = v1 * v1 + v2 * v2;
+        } while (s >= 1 || s == 0);
+        const double m = std::sqrt(-2 * fdlibm_log(s) / s);
+        cached_ = v2 * m;
+        have_ = true;
+        return v1 * m;
+    }
+
+  private:
+    uint64_t seed_;
+    double cached_ = 0;
+    bool have_ = false;
+};
+
+// The (user-item x context) rating matrix as flat tuples in MatrixIterator (CRS) order + the id-space sizes.
+struct RatingData {
+    int32_t n_users = 0, n_items = 0, n_conds = 0, n_dims = 0;
+    std::vector<int32_t> u, j, ctx;
+    std::vector<double> r;
+    std::vector<int32_t> ctx_ptr, ctx_conds;
+    double min_rate = 1, max_rate = 5;
+    int64_t n() const { return (int64_t)r.size(); }
+    RatingData subset(const std::vector<int64_t> &idx) const {
+        RatingData d = *this;
+        d.u.clear(), d.j.clear(), d.ctx.clear(), d.r.clear();
+        for (int64_t t : idx) {
+            d.u.push_back(u[(size_t)t]);
+            d.j.push_back(j[(size_t)t]);
+            d.ctx.push_back(ctx[(size_t)t]);
+            d.r.push_back(r[(size_t)t]);
+        }
+        return d;
+    }
+};
+
+// DataSplitter.splitFolds (src/carskit/data/processor/DataSplitter.java:102-133): fold label 1..k per matrix entry
+inline std::vector<int> split_folds(int64_t n, int k_fold, int64_t seed, int *num_fold) {
+    const int nf = (int64_t)k_fold > n ? (int)n : k_fold;
+    JavaRandom rnd(seed);
+    std::vector<double> rdm((size_t)n);
+    std::vector<int> fold((size_t)n);
+    const double indv = ((double)n + 0.0) / nf;
+    for (int64_t i = 0; i < n; ++i) {
+        rdm[(size_t)i] = rnd.nextDouble();
+        fold[(size_t)i] = (int)((double)i / indv) + 1;
+    }
+    std::vector<int64_t> ord((size_t)n);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) { return rdm[(size_t)a] < rdm[(size_t)b]; });
+    std::vector<int> out((size_t)n);
+    for (int64_t i = 0; i < n; ++i) out[(size_t)i] = fold[(size_t)ord[(size_t)i]];
+    *num_fold = nf;
+    return out;
+}
+
+// static hyper-parameters (Recommender.java:194-247, IterativeRecommender.java:80-103, FM.java:53-54)
+struct Conf {
+    int numFactors = 10, numIters = 100;
+    double initLRate = java_float("0.01"), maxLRate = -1, decay = -1;
+    bool isBoldDriver = false, verbose = true;
+    double regU = java_float("0.01"), regI = regU, regB = regU, regC = regU, regLw = 0, regLf = 0;
+    std::string earlyStop; // "", "Loss", "MAE", "RMSE"
+    int64_t randSeed = 1;
+    unsigned flags = 0;
+    int device = 0;
+    Conf() {}
+    explicit Conf(const FileConfiger &cf) {
+        if (cf.contains("learn.rate")) {
+            LineConfiger lc = cf.getParamOptions("learn.rate");
+            initLRate = java_float(lc.getMainParam());
+            maxLRate = lc.getFloat("-max", -1);
+            isBoldDriver = lc.contains("-bold-driver");
+            decay = lc.getFloat("-decay", -1);
+        }
+        if (cf.contains("reg.lambda")) {
+            LineConfiger ro = cf.getParamOptions("reg.lambda");
+            const double reg = java_float(ro.getMainParam());
+            regU = ro.getFloat("-u", reg);
+            regI = ro.getFloat("-i", reg);
+            regB = ro.getFloat("-b", reg);
+            regC = ro.getFloat("-c", reg);
+        }
+        numFactors = cf.getInt("num.factors", 10);
+        numIters = cf.getInt("num.max.iter", 100);
+        if (cf.contains("evaluation.setup")) {
+            LineConfiger ev = cf.getParamOptions("evaluation.setup");
+            const std::string es = lower(ev.getString("--early-stop"));
+            earlyStop = es == "loss" ? "Loss" : es == "mae" ? "MAE" : es == "rmse" ? "RMSE" : "";
+            randSeed = ev.getLong("--rand-seed", 1);
+        }
+        if (cf.contains("output.setup")) verbose = cf.getParamOptions("output.setup").isOn("-verbose", true);
+        if (cf.contains("FM")) {
+            LineConfiger fm = cf.getParamOptions("FM");
+            regLw = fm.getFloat("-lw", 0);
+            regLf = fm.getFloat("-lf", 0);
+        }
+    }
+};
+
+typedef std::map<std::string, double> Measures;
+typedef std::function<void(const std::string &)> Logger;
+
+inline void check(int rc, cmi_handle h, const char *what) {
+    if (rc != CMI_OK) throw std::runtime_error(std::string(what) + ": " + cmi_last_error(h));
+}
+
+// carskit.generic.Recommender + IterativeRecommender (+ ContextRecommender), for the models libcarskit_mi355x runs
+class IterativeRecommender {
+  public:
+    IterativeRecommender(int model, const char *name, bool is_cars, const RatingData &train, const RatingData &test, int fold,
+                         const Conf &conf, Logger log)
+        : algoName(name), model_(model), isCARS_(is_cars), trainMatrix(train), testMatrix(test), fold_(fold), conf_(conf),
+          log_(log) {
+        lRate = conf.initLRate;
+        double s = 0;
+        int64_t cnt = 0;
+        for (double v : train.r) { // SparseMatrix.getGlobalAvg: sum / #non-zero
+            s += v;
+            if (v != 0.0) ++cnt;
+        }
+        globalMean = cnt ? s / (double)cnt : std::nan("");
+    }
+    virtual ~IterativeRecommender() {
+        if (h_) cmi_destroy(h_);
+    }
+
+    // ---- hooks, named as in the reference ---------------------------------------------------------------------
+    virtual void initModel() { // IterativeRecommender.java:232-247 + the model class: P, Q ~ N(0,0.1), then the biases
+        JavaRandom rnd(conf_.randSeed);   // the reference's init stream is unseeded: any stream is as faithful
+        auto gauss = [&](std::vector<double> &v, size_t n) {
+            v.resize(n);
+            for (double &x : v) x = 0.0 + 0.1 * rnd.nextGaussian();
+        };
+        auto unif = [&](std::vector<double> &v, size_t n) {
+            v.resize(n);
+            for (double &x : v) x = rnd.nextDouble();
+        };
+        const size_t nu = (size_t)trainMatrix.n_users, ni = (size_t)trainMatrix.n_items, nc = (size_t)trainMatrix.n_conds,
+                     k = (size_t)conf_.numFactors;
+        gauss(state[CMI_STATE_P], nu * k);
+        gauss(state[CMI_STATE_Q], ni * k);
+        switch (model_) {
+        case CMI_MODEL_BIASEDMF:
+            gauss(state[CMI_STATE_USER_BIAS], nu);
+            gauss(state[CMI_STATE_ITEM_BIAS], ni);
+            break;
+        case CMI_MODEL_CAMF_C:
+            gauss(state[CMI_STATE_USER_BIAS], nu);
+            gauss(state[CMI_STATE_ITEM_BIAS], ni);
+            gauss(state[CMI_STATE_COND_BIAS], nc);
+            break;
+        case CMI_MODEL_CAMF_CI:
+            gauss(state[CMI_STATE_USER_BIAS], nu);
+            unif(state[CMI_STATE_IC_BIAS], ni * nc); // icBias.init() = uniform(0,1), CAMF_CI.java:60
+            break;
+        case CMI_MODEL_CAMF_CU:
+            gauss(state[CMI_STATE_ITEM_BIAS], ni);
+            unif(state[CMI_STATE_UC_BIAS], nu * nc);
+            break;
+        case CMI_MODEL_CAMF_CUCI:
+            gauss(state[CMI_STATE_UC_BIAS], nu * nc);
+            gauss(state[CMI_STATE_IC_BIAS], ni * nc);
+            break;
+        default: break;
+        }
+    }
+
+    virtual void buildModel() {
+        unsigned flags = conf_.flags | (model_ == CMI_MODEL_CAMF_C ? CMI_FLAG_SCHED_SERIAL : 0u);
+        int rc = cmi_create(model_, conf_.numFactors, trainMatrix.n_users, trainMatrix.n_items, trainMatrix.n_conds,
+                            conf_.device, flags, &h_);
+        if (rc != CMI_OK) throw std::runtime_error(std::string("cmi_create: ") + cmi_last_error(nullptr));
+        check(cmi_set_hparams(h_, conf_.regU, conf_.regI, conf_.regB, conf_.regC, globalMean), h_, "cmi_set_hparams");
+        if (isCARS_) {
+            check(cmi_set_ratings(h_, trainMatrix.n(), trainMatrix.u.data(), trainMatrix.j.data(), trainMatrix.ctx.data(),
+                                  trainMatrix.r.data(), (int32_t)trainMatrix.ctx_ptr.size() - 1, trainMatrix.ctx_ptr.data(),
+                                  trainMatrix.ctx_conds.data()),
+                  h_, "cmi_set_ratings");
+        } else { // Recommender.initModel (:1076-1081): the 2-D train matrix, mean over contexts per (user,item)
+            std::vector<int32_t> u2, j2;
+            std::vector<double> r2;
+            to2d(trainMatrix, u2, j2, r2);
+            check(cmi_set_ratings(h_, (int64_t)r2.size(), u2.data(), j2.data(), nullptr, r2.data(), 0, nullptr, nullptr), h_,
+                  "cmi_set_ratings");
+        }
+        for (auto &kv : state) // copy-in
+            check(cmi_set_state(h_, kv.first, kv.second.data(), (int64_t)kv.second.size(), CMI_DTYPE_F64), h_, "cmi_set_state");
+        for (int iter = 1; iter <= conf_.numIters; ++iter) {
+            check(cmi_train_epoch(h_, lRate, &loss), h_, "cmi_train_epoch"); // the for(MatrixEntry me : trainMatrix) body
+            losses.push_back(loss);
+            if (isConverged(iter)) break;
+        }
+        for (auto &kv : state) // copy-back
+            check(cmi_get_state(h_, kv.first, kv.second.data(), (int64_t)kv.second.size(), CMI_DTYPE_F64), h_, "cmi_get_state");
+    }
+
+    virtual Measures evalRatings() { // Recommender.java:504-594 (numeric part)
+        double out[5] = {0, 0, 0, 0, 0};
+        int64_t cnt = 0;
+        check(cmi_eval_ratings(h_, testMatrix.n(), testMatrix.u.data(), testMatrix.j.data(),
+                               isCARS_ ? testMatrix.ctx.data() : nullptr, testMatrix.r.data(), trainMatrix.min_rate,
+                               trainMatrix.max_rate, out, &cnt),
+              h_, "cmi_eval_ratings");
+        return Measures{{"MAE", out[0]}, {"RMSE", out[1]}, {"NMAE", out[2]}, {"rMAE", out[3]}, {"rRMSE", out[4]}, {"MPE", 0.0}};
+    }
+
+    Measures execute() { // Recommender.java:319-366
+        auto t0 = std::chrono::steady_clock::now();
+        initModel();
+        buildModel();
+        auto t1 = std::chrono::steady_clock::now();
+        measures = evalRatings();
+        auto t2 = std::chrono::steady_clock::now();
+        measures["TrainTime"] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        measures["TestTime"] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        return measures;
+    }
+
+    bool isConverged(int iter) { // IterativeRecommender.java:145-199
+        const float delta_loss = (float)(last_loss - loss);
+        if (conf_.earlyStop == "Loss") {
+            measure = loss;
+            last_measure = last_loss;
+        } else if (conf_.earlyStop == "MAE" || conf_.earlyStop == "RMSE") {
+            measure = evalRatings()[conf_.earlyStop];
+        }
+        const float delta_measure = (float)(last_measure - measure);
+        if (conf_.verbose && log_) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "%s%s iter %d: loss = %g, delta_loss = %g, learn_rate = %g", algoName.c_str(),
+                     fold_ > 0 ? (" fold [" + std::to_string(fold_) + "]").c_str() : "", iter, (double)(float)loss,
+                     (double)delta_loss, (double)(float)lRate);
+            log_(buf);
+        }
+        if (std::isnan(loss) || std::isinf(loss))
+            throw std::runtime_error("Loss = NaN or Infinity: current settings does not fit the recommender! Change the settings and try again!");
+        const bool converged = std::fabs(loss) < 1e-5 || (delta_measure > 0 && delta_measure < 1e-5);
+        if (!converged) updateLRate(iter);
+        last_loss = loss;
+        last_measure = measure;
+        return converged;
+    }
+
+    void updateLRate(int iter) { // IterativeRecommender.java:216-229
+        if (lRate <= 0) return;
+        if (conf_.isBoldDriver && iter > 1) lRate = std::fabs(last_loss) > std::fabs(loss) ? lRate * 1.05 : lRate * 0.5;
+        else if (conf_.decay > 0 && conf_.decay < 1) lRate *= conf_.decay;
+        if (conf_.maxLRate > 0 && lRate > conf_.maxLRate) lRate = conf_.maxLRate;
+    }
+
+    static void to2d(const RatingData &d, std::vector<int32_t> &u2, std::vector<int32_t> &j2, std::vector<double> &r2) {
+        std::map<std::pair<int32_t, int32_t>, std::pair<double, double>> cell; // DataDAO.toTraditionalSparseMatrix
+        for (int64_t t = 0; t < d.n(); ++t) {
+            auto &c = cell[{d.u[(size_t)t], d.j[(size_t)t]}];
+            c.first += d.r[(size_t)t];
+            c.second += 1.0;
+        }
+        for (auto &kv : cell) {
+            u2.push_back(kv.first.first);
+            j2.push_back(kv.first.second);
+            r2.push_back(kv.second.first / kv.second.second);
+        }
+    }
+
+    std::string algoName;
+    Measures measures;
+    std::map<int, std::vector<double>> state; // CMI_STATE_* -> container (P, Q, userBias, ...)
+    std::vector<double> losses;
+    double lRate = 0, loss = 0, last_loss = 0, measure = 0, last_measure = 0, globalMean = 0;
+
+  protected:
+    int model_;
+    bool isCARS_;
+    RatingData trainMatrix, testMatrix;
+    int fold_;
+    Conf conf_;
+    Logger log_;
+    cmi_handle h_ = nullptr;
+};
+
+#define CARSKIT_MODEL(cls, id, cars)                                                                                  \
+    class cls : public IterativeRecommender {                                                                          \
+      public:                                                                                                          \
+        cls(const RatingData &tr, const RatingData &te, int fold, const Conf &c, Logger log = nullptr)                 \
+            : IterativeRecommender(id, #cls, cars, tr, te, fold, c, log) {}                                            \
+    };
+CARSKIT_MODEL(BiasedMF, CMI_MODEL_BIASEDMF, false)  // src/carskit/alg/baseline/cf/BiasedMF.java
+CARSKIT_MODEL(PMF, CMI_MODEL_PMF, false)            // src/carskit/alg/baseline/cf/PMF.java
+CARSKIT_MODEL(CAMF_C, CMI_MODEL_CAMF_C, true)       // src/carskit/alg/cars/adaptation/dependent/dev/CAMF_C.java
+CARSKIT_MODEL(CAMF_CI, CMI_MODEL_CAMF_CI, true)     // .../dev/CAMF_CI.java
+CARSKIT_MODEL(CAMF_CU, CMI_MODEL_CAMF_CU, true)     // .../dev/CAMF_CU.java
+CARSKIT_MODEL(CAMF_CUCI, CMI_MODEL_CAMF_CUCI, true) // .../dev/CAMF_CUCI.java
+#undef CARSKIT_MODEL
+
+// the factory switch of CARSKit.getRecommender (src/carskit/main/CARSKit.java:461,700-707), lower-cased names
+inline std::unique_ptr<IterativeRecommender> getRecommender(const std::string &name, const RatingData &tr, const RatingData &te,
+                                                            int fold, const Conf &c, Logger log) {
+    const std::string n = lower(name);
+    if (n == "biasedmf") return std::unique_ptr<IterativeRecommender>(new BiasedMF(tr, te, fold, c, log));
+    if (n == "pmf") return std::unique_ptr<IterativeRecommender>(new PMF(tr, te, fold, c, log));
+    if (n == "camf_c") return std::unique_ptr<IterativeRecommender>(new CAMF_C(tr, te, fold, c, log));
+    if (n == "camf_ci") return std::unique_ptr<IterativeRecommender>(new CAMF_CI(tr, te, fold, c, log));
+    if (n == "camf_cu") return std::unique_ptr<IterativeRecommender>(new CAMF_CU(tr, te, fold, c, log));
+    if (n == "camf_cuci") return std::unique_ptr<IterativeRecommender>(new CAMF_CUCI(tr, te, fold, c, log));
+    throw std::runtime_error("recommender '" + name + "' is not on the accelerated path (biasedmf, pmf, camf_c, camf_ci, camf_cu, camf_cuci)");
+}
+
+} // namespace carskit

@@ -71,3 +71,33 @@ def test_c2_camf_c_k64_frappe_shaped():
     np.testing.assert_allclose(gpu.losses, cpu.losses, rtol=2e-5)
     assert abs(mg["RMSE"] - mc["RMSE"]) <= 1e-5 and abs(mg["MAE"] - mc["MAE"]) <= 1e-5   # north_star fp32 bar
     assert gpu.engine.inst.schedule_info()["kind"] == "serial"
+
+
+def test_cpp_host_driver_c1_matches_oracle(tmp_path):
+    """The C++ host (carskit_amd/bin/carskit-mi355x: setting.conf driver + Recommender classes over the C ABI only) on
+    BASELINE config C1.  In fp64 / strict / serial mode every number it prints must be the oracle's for the same folds
+    and the same java.util.Random init stream."""
+    import re
+    import subprocess
+    from tests.test_host_layer import EXE, _depaul_conf, expected_from_oracle
+    conf = _depaul_conf(tmp_path)
+    flags = capi.FLAG_STATE_F64 | capi.FLAG_STRICT | capi.FLAG_SCHED_SERIAL
+    p = subprocess.run([EXE, "-c", conf, "--iters", "20", "--flags", str(flags), "--precise"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    m = re.search(r"PRECISE BiasedMF folds=5 MAE=(\S+) RMSE=(\S+)", p.stdout)
+    assert m, p.stdout[-500:]
+    want = expected_from_oracle(conf, "biasedmf", 20)
+    assert abs(float(m.group(1)) - want["MAE"]) <= 1e-12 and abs(float(m.group(2)) - want["RMSE"]) <= 1e-12
+    assert re.search(r"Final Results by BiasedMF, MAE: %.6f, RMSE: %.6f, NAME: " % (want["MAE"], want["RMSE"]), p.stdout)
+    # default fp32 state: the north_star tolerance
+    p32 = subprocess.run([EXE, "-c", conf, "--iters", "20", "--precise"], capture_output=True, text=True)
+    m32 = re.search(r"PRECISE BiasedMF folds=5 MAE=(\S+) RMSE=(\S+)", p32.stdout)
+    assert abs(float(m32.group(1)) - want["MAE"]) <= 1e-5 and abs(float(m32.group(2)) - want["RMSE"]) <= 1e-5
+    # a contextual model through the same driver
+    txt = open(conf).read().replace("recommender=biasedmf", "recommender=camf_cu")
+    open(conf, "w").write(txt)
+    pc = subprocess.run([EXE, "-c", conf, "--iters", "10", "--flags", str(flags), "--precise"], capture_output=True, text=True)
+    mc = re.search(r"PRECISE CAMF_CU folds=5 MAE=(\S+) RMSE=(\S+)", pc.stdout)
+    assert mc, pc.stdout[-300:] + pc.stderr
+    wc = expected_from_oracle(conf, "camf_cu", 10)
+    assert abs(float(mc.group(1)) - wc["MAE"]) <= 1e-12 and abs(float(mc.group(2)) - wc["RMSE"]) <= 1e-12

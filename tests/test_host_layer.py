@@ -159,3 +159,54 @@ def test_test_set_evaluation_via_setting_conf(tmp_path):
     assert a.state["P"].shape == (a.trainMatrix.n_users, 10)
     assert lines[-1].startswith("Final Results by CAMF_CU, MAE: ")
     assert np.isfinite(avg["RMSE"])
+
+
+EXE = os.path.join(os.path.dirname(GOLDEN), "..", "carskit_amd", "bin", "carskit-mi355x")
+
+
+def _cpp_init(model, train, k, seed):
+    """The C++ host's initModel(): java.util.Random(seed) -> P, Q ~ N(0,0.1) row-major, then the biases in source order
+    (carskit_amd/csrc/host/recommender.hpp), reproduced with the oracle's independent JRandom."""
+    from oracle import oracle_c
+    g = oracle_c.JRandom(seed)
+    st = {"P": g.gaussian((train.n_users, k)), "Q": g.gaussian((train.n_items, k))}
+    if model in ("BiasedMF", "CAMF_C"):
+        st["userBias"], st["itemBias"] = g.gaussian(train.n_users), g.gaussian(train.n_items)
+        if model == "CAMF_C":
+            st["condBias"] = g.gaussian(train.n_conds)
+    elif model == "CAMF_CI":
+        st["userBias"], st["icBias"] = g.gaussian(train.n_users), g.uniform((train.n_items, train.n_conds))
+    elif model == "CAMF_CU":
+        st["itemBias"], st["ucBias"] = g.gaussian(train.n_items), g.uniform((train.n_users, train.n_conds))
+    elif model == "CAMF_CUCI":
+        st["ucBias"], st["icBias"] = g.gaussian((train.n_users, train.n_conds)), g.gaussian((train.n_items, train.n_conds))
+    return st
+
+
+def expected_from_oracle(conf_path, model_cls_name, iters):
+    """What the C++ driver must print for a cv run: same transformer/DAO/fold assignment (shared C ABI + the Python
+    splitter, itself checked against the recipe), the C++ init stream, the oracle as the engine."""
+    class Cls(recommender.RECOMMENDERS[model_cls_name]):
+        def initModel(self):
+            self.state = _cpp_init(self.algo_name, self.trainMatrix, self.numFactors, self.conf.init_seed)
+    saved = recommender.RECOMMENDERS[model_cls_name]
+    recommender.RECOMMENDERS[model_cls_name] = Cls
+    try:
+        avg, _, _ = main.run(conf_path, engine_factory=util.OracleEngine, log=lambda *a: None,
+                             conf_overrides={"num_iters": iters})
+    finally:
+        recommender.RECOMMENDERS[model_cls_name] = saved
+    return avg
+
+
+def test_cpp_host_driver_loads_data_then_fails_loudly_without_gpu(tmp_path):
+    import subprocess
+    from carskit_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    conf = _depaul_conf(tmp_path)
+    p = subprocess.run([EXE, "-c", conf, "--iters", "3"], capture_output=True, text=True)
+    assert "Rating data set has been successfully loaded." in p.stdout and "With Setup: cv -k 5" in p.stdout
+    assert p.returncode == 1 and "no HIP device" in p.stderr and "no CPU fallback" in p.stderr
+    q = subprocess.run([EXE, "-c", str(tmp_path / "missing.conf")], capture_output=True, text=True)
+    assert q.returncode == 1 and "cannot open configuration file" in q.stderr
