@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <mutex>
+#include <thread>
 
 #include "recommender.hpp"
 
@@ -98,22 +100,41 @@ static int run(const std::string &config, unsigned flags, int iters_override, bo
     log("With Setup: " + cf.getString("evaluation.setup"));
     std::vector<Measures> all;
     std::string name;
-    auto runFold = [&](const RatingData &tr, const RatingData &te, int fold) {
-        auto algo = getRecommender(algoName, tr, te, fold, conf, log);
-        all.push_back(algo->execute());
-        name = algo->algoName;
+    std::mutex mu;
+    std::string fold_error;
+    auto runFold = [&](const RatingData &tr, const RatingData &te, int fold, size_t slot) {
+        try {
+            auto algo = getRecommender(algoName, tr, te, fold, conf, log);
+            const Measures m = algo->execute();
+            std::lock_guard<std::mutex> g(mu);
+            if (all.size() <= slot) all.resize(slot + 1);
+            all[slot] = m;
+            name = algo->algoName;
+        } catch (const std::exception &e) { // the reference logs the exception of a fold thread (Recommender.java:1162-1171)
+            std::lock_guard<std::mutex> g(mu);
+            fold_error = e.what();
+        }
     };
     if (mode == "cv") {
         int k = 0;
         const std::vector<int> labels = split_folds(data.n(), ev.getInt("-k", 5), conf.randSeed, &k);
+        const bool parallel = ev.isOn("-p", true); // one thread per fold (CARSKit.java:395-412); each fold = its own cmi_handle/stream
+        std::vector<std::thread> ts;
+        std::vector<RatingData> trs((size_t)k), tes((size_t)k);
         for (int f = 1; f <= k; ++f) {
             std::vector<int64_t> tr, te;
             for (int64_t t = 0; t < data.n(); ++t) {
                 if (data.r[(size_t)t] == 0.0) continue; // reshape() drops zero entries
                 (labels[(size_t)t] == f ? te : tr).push_back(t);
             }
-            runFold(data.subset(tr), data.subset(te), f);
+            trs[(size_t)f - 1] = data.subset(tr);
+            tes[(size_t)f - 1] = data.subset(te);
         }
+        for (int f = 1; f <= k; ++f) {
+            if (parallel) ts.emplace_back(runFold, std::cref(trs[(size_t)f - 1]), std::cref(tes[(size_t)f - 1]), f, (size_t)f - 1);
+            else runFold(trs[(size_t)f - 1], tes[(size_t)f - 1], f, (size_t)f - 1);
+        }
+        for (auto &t : ts) t.join();
     } else if (mode == "test-set") {
         Dao testDao(work + "test.csv", rateDao.h);
         RatingData test = testDao.ratingData();
@@ -124,14 +145,15 @@ static int run(const std::string &config, unsigned flags, int iters_override, bo
         train.ctx_conds = test.ctx_conds;
         test.min_rate = data.min_rate;
         test.max_rate = data.max_rate;
-        runFold(train, test, -1);
+        runFold(train, test, -1, 0);
     } else { // given-ratio: the reference draws Math.random() (unseedable); a seeded stream here
         const double ratio = ev.getDouble("-r", 0.8);
         JavaRandom rnd(conf.randSeed);
         std::vector<int64_t> tr, te;
         for (int64_t t = 0; t < data.n(); ++t) (rnd.nextDouble() < ratio ? tr : te).push_back(t);
-        runFold(data.subset(tr), data.subset(te), -1);
+        runFold(data.subset(tr), data.subset(te), -1, 0);
     }
+    if (!fold_error.empty()) throw std::runtime_error(fold_error);
     Measures avg;
     for (const Measures &m : all)
         for (const auto &kv : m) avg[kv.first] += kv.second / (double)all.size();

@@ -369,6 +369,62 @@ CARSKIT_MODEL(CAMF_CU, CMI_MODEL_CAMF_CU, true)     // .../dev/CAMF_CU.java
 CARSKIT_MODEL(CAMF_CUCI, CMI_MODEL_CAMF_CUCI, true) // .../dev/CAMF_CUCI.java
 #undef CARSKIT_MODEL
 
+// src/carskit/alg/cars/adaptation/dependent/FM.java: w0 = 0, w ~ U(0,1), V ~ N(0,0.1) (:65-70); numIters ALS sweeps, no
+// convergence check; evaluation through the generic evalRatings recipe on bounded predictions.
+class FM : public IterativeRecommender {
+  public:
+    FM(const RatingData &tr, const RatingData &te, int fold, const Conf &c, Logger log = nullptr)
+        : IterativeRecommender(-1, "FM", true, tr, te, fold, c, log) {}
+    ~FM() override {
+        if (fm_) cmi_fm_destroy(fm_);
+    }
+    void initModel() override {
+        JavaRandom rnd(conf_.randSeed);
+        const size_t p = (size_t)trainMatrix.n_users + trainMatrix.n_items + trainMatrix.n_conds;
+        w.resize(p);
+        for (double &x : w) x = rnd.nextDouble();
+        V.resize(p * (size_t)conf_.numFactors);
+        for (double &x : V) x = 0.0 + 0.1 * rnd.nextGaussian();
+        w0 = 0.0;
+    }
+    void buildModel() override {
+        if (cmi_fm_create(conf_.numFactors, trainMatrix.n_users, trainMatrix.n_items, trainMatrix.n_conds,
+                          std::max(1, trainMatrix.n_dims), conf_.device, 0, &fm_) != CMI_OK)
+            throw std::runtime_error(std::string("cmi_fm_create: ") + cmi_fm_last_error(nullptr));
+        fmcheck(cmi_fm_set_hparams(fm_, conf_.regLw, conf_.regLf, 0), "cmi_fm_set_hparams");
+        fmcheck(cmi_fm_set_ratings(fm_, trainMatrix.n(), trainMatrix.u.data(), trainMatrix.j.data(), trainMatrix.ctx.data(),
+                                   trainMatrix.r.data()), "cmi_fm_set_ratings");
+        fmcheck(cmi_fm_set_model(fm_, w0, w.data(), V.data()), "cmi_fm_set_model");
+        fmcheck(cmi_fm_train(fm_, conf_.numIters), "cmi_fm_train");
+        fmcheck(cmi_fm_get_model(fm_, &w0, w.data(), V.data()), "cmi_fm_get_model");
+    }
+    Measures evalRatings() override {
+        std::vector<double> pred((size_t)testMatrix.n());
+        fmcheck(cmi_fm_predict_batch(fm_, testMatrix.n(), testMatrix.u.data(), testMatrix.j.data(), testMatrix.ctx.data(), 1,
+                                     trainMatrix.min_rate, trainMatrix.max_rate, pred.data()), "cmi_fm_predict_batch");
+        double sa = 0, ss = 0, sra = 0, srs = 0;
+        int64_t n = 0;
+        for (size_t t = 0; t < pred.size(); ++t) {
+            if (std::isnan(pred[t])) continue;
+            const double rp = std::floor(pred[t] / trainMatrix.min_rate + 0.5) * trainMatrix.min_rate;
+            const double e = std::fabs(testMatrix.r[t] - pred[t]), re = std::fabs(testMatrix.r[t] - rp);
+            sa += e, ss += e * e, sra += re, srs += re * re;
+            ++n;
+        }
+        const double mae = sa / (double)n;
+        return Measures{{"MAE", mae}, {"RMSE", std::sqrt(ss / (double)n)}, {"NMAE", mae / (trainMatrix.max_rate - trainMatrix.min_rate)},
+                        {"rMAE", sra / (double)n}, {"rRMSE", std::sqrt(srs / (double)n)}, {"MPE", 0.0}};
+    }
+    double w0 = 0;
+    std::vector<double> w, V;
+
+  private:
+    void fmcheck(int rc, const char *what) {
+        if (rc != CMI_OK) throw std::runtime_error(std::string(what) + ": " + cmi_fm_last_error(fm_));
+    }
+    cmi_fm_handle fm_ = nullptr;
+};
+
 // the factory switch of CARSKit.getRecommender (src/carskit/main/CARSKit.java:461,700-707), lower-cased names
 inline std::unique_ptr<IterativeRecommender> getRecommender(const std::string &name, const RatingData &tr, const RatingData &te,
                                                             int fold, const Conf &c, Logger log) {
@@ -379,7 +435,8 @@ inline std::unique_ptr<IterativeRecommender> getRecommender(const std::string &n
     if (n == "camf_ci") return std::unique_ptr<IterativeRecommender>(new CAMF_CI(tr, te, fold, c, log));
     if (n == "camf_cu") return std::unique_ptr<IterativeRecommender>(new CAMF_CU(tr, te, fold, c, log));
     if (n == "camf_cuci") return std::unique_ptr<IterativeRecommender>(new CAMF_CUCI(tr, te, fold, c, log));
-    throw std::runtime_error("recommender '" + name + "' is not on the accelerated path (biasedmf, pmf, camf_c, camf_ci, camf_cu, camf_cuci)");
+    if (n == "fm") return std::unique_ptr<IterativeRecommender>(new FM(tr, te, fold, c, log));
+    throw std::runtime_error("recommender '" + name + "' is not on the accelerated path (biasedmf, pmf, camf_c, camf_ci, camf_cu, camf_cuci, fm)");
 }
 
 } // namespace carskit

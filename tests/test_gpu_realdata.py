@@ -101,3 +101,49 @@ def test_cpp_host_driver_c1_matches_oracle(tmp_path):
     assert mc, pc.stdout[-300:] + pc.stderr
     wc = expected_from_oracle(conf, "camf_cu", 10)
     assert abs(float(mc.group(1)) - wc["MAE"]) <= 1e-12 and abs(float(mc.group(2)) - wc["RMSE"]) <= 1e-12
+
+
+def test_cpp_host_driver_parallel_folds_and_fm(tmp_path):
+    """`cv -p on` (one host thread per fold, as in the reference) gives the same numbers as `-p off`; and FM through the
+    C++ driver matches the dense FM oracle on the same folds and init stream."""
+    import re
+    import subprocess
+    from carskit_amd import dao, splitter
+    from oracle import oracle_c
+    from tests.test_host_layer import EXE, _depaul_conf
+    conf = _depaul_conf(tmp_path)
+    flags = capi.FLAG_STATE_F64 | capi.FLAG_STRICT | capi.FLAG_SCHED_SERIAL
+    txt = open(conf).read().replace("recommender=biasedmf", "recommender=camf_ci")
+    open(conf, "w").write(txt)
+    off = subprocess.run([EXE, "-c", conf, "--iters", "8", "--flags", str(flags), "--precise"], capture_output=True, text=True)
+    open(conf, "w").write(txt.replace("-p off", "-p on"))
+    on = subprocess.run([EXE, "-c", conf, "--iters", "8", "--flags", str(flags), "--precise"], capture_output=True, text=True)
+    a = re.search(r"PRECISE CAMF_CI folds=5 MAE=(\S+) RMSE=(\S+)", off.stdout)
+    b = re.search(r"PRECISE CAMF_CI folds=5 MAE=(\S+) RMSE=(\S+)", on.stdout)
+    assert a and b and a.groups() == b.groups(), (off.stderr, on.stderr)
+    # FM
+    open(conf, "w").write(txt.replace("recommender=camf_ci", "recommender=fm"))
+    fm = subprocess.run([EXE, "-c", conf, "--iters", "3", "--precise"], capture_output=True, text=True)
+    m = re.search(r"PRECISE FM folds=5 MAE=(\S+) RMSE=(\S+)", fm.stdout)
+    assert m, fm.stdout[-300:] + fm.stderr
+    d = dao.DataDAO(os.path.join(os.path.dirname(conf), "CARSKit.Workspace", "train.csv"))
+    data = d.rating_data()
+    labels, k = splitter.split_folds(data.n, 5, 1)
+    reglw, reglf = synth.java_float(0.01), synth.java_float(0.02)
+    maes, rmses = [], []
+    for f in range(1, k + 1):
+        tr, te = splitter.kth_fold(data, labels, f)
+        g = oracle_c.JRandom(1)
+        p = tr.n_users + tr.n_items + tr.n_conds
+        w = g.uniform((p,))
+        V = g.gaussian((p, 10))
+        orc = oracle_c.FMOracle(10, tr.n_users, tr.n_items, tr.n_conds, max(1, tr.n_dims), tr.u, tr.j, tr.ctx, tr.r, 0.0, w, V,
+                                reglw, reglf)
+        orc.init()
+        for _ in range(3):
+            orc.sweep()
+        pred = np.clip([orc.predict(int(u), int(j), int(c)) for u, j, c in zip(te.u, te.j, te.ctx)], 1.0, 5.0)
+        err = np.abs(te.r - pred)
+        maes.append(err.mean())
+        rmses.append(np.sqrt((err * err).mean()))
+    assert abs(float(m.group(1)) - np.mean(maes)) <= 1e-9 and abs(float(m.group(2)) - np.mean(rmses)) <= 1e-9
