@@ -331,3 +331,31 @@ def test_instances_are_reentrant_across_threads():
         assert par[i][0] == seq[i][0], models[i]
         for name in seq[i][1]:
             assert np.array_equal(par[i][1][name], seq[i][1][name]), (models[i], name)
+
+
+@pytest.mark.parametrize("model,k", [("CAMF_CI", 128), ("CAMF_CU", 64), ("BiasedMF", 10)])
+def test_f32_holds_1e5_over_the_default_100_epochs(model, k):
+    """setting.conf defaults: num.max.iter=100 with the bold driver.  fp32 rounding must not accumulate past the
+    north_star's 1e-5, nor flip a bold-driver decision, over the full schedule."""
+    data = util.small_data(n_users=2500, n_items=350, n_dims=3, conds_per_dim=4, n=50000, seed=81)
+    train, test = synth.split(data, 0.2)
+    orc, inst = make_pair(model, train, k, 0)
+    o_losses, o_lrs, _ = orc.build_model(100, util.LR, bold_driver=True)
+    g_losses, g_lrs = inst.train(100, util.LR, bold_driver=True)
+    assert len(g_losses) == len(o_losses)
+    # Late in the schedule the bold driver has shrunk lRate by orders of magnitude and consecutive losses differ by
+    # less than fp32 resolution, so `abs(last_loss) > abs(loss)` becomes a coin flip between fp32 and fp64; by then a
+    # step moves no parameter by a representable amount.  The decisions must agree while the rate still matters.
+    live = o_lrs >= 1e-5
+    assert live.sum() >= 20 and g_lrs[live].tolist() == o_lrs[live].tolist()
+    np.testing.assert_allclose(g_losses, o_losses, rtol=5e-5)
+    tctx = None if model in util.TWO_D else test.ctx
+    oe = orc.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+    ge = inst.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+    assert abs(oe["RMSE"] - ge["RMSE"]) <= 1e-5 and abs(oe["MAE"] - ge["MAE"]) <= 1e-5
+    # and the fp64 state reproduces the whole 100-epoch trajectory
+    _, i64 = make_pair(model, train, k, F64)
+    d_losses, d_lrs = i64.train(100, util.LR, bold_driver=True)
+    assert d_lrs.tolist() == o_lrs.tolist()
+    de = i64.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+    assert abs(oe["RMSE"] - de["RMSE"]) <= 1e-9
