@@ -359,3 +359,22 @@ def test_f32_holds_1e5_over_the_default_100_epochs(model, k):
     assert d_lrs.tolist() == o_lrs.tolist()
     de = i64.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
     assert abs(oe["RMSE"] - de["RMSE"]) <= 1e-9
+
+
+def test_instance_can_be_reloaded_with_other_ratings():
+    """cmi_set_ratings may be called again on the same handle (next fold): the schedule, the device tuple stream and
+    the captured graph are rebuilt."""
+    d1 = util.small_data(n_users=900, n_items=120, n=15000, seed=91)
+    d2 = synth.RatingData(d1.n_users, d1.n_items, d1.n_conds, d1.n_dims, d1.u[::-1].copy(), d1.j[::-1].copy(),
+                          d1.ctx[::-1].copy(), d1.r[::-1].copy(), d1.ctx_ptr, d1.ctx_conds)
+    _, reused = make_pair("CAMF_CUCI", d1, 64, 0)
+    for _ in range(2):
+        reused.train_epoch(util.LR)
+    st = synth.init_state("CAMF_CUCI", d2, 64, seed=6)
+    reused.set_ratings(d2.u, d2.j, d2.ctx, d2.r, d2.ctx_ptr, d2.ctx_conds)
+    reused.set_states(st)
+    _, fresh = make_pair("CAMF_CUCI", d2, 64, 0, seed=6)
+    for _ in range(3):
+        assert reused.train_epoch(util.LR) == fresh.train_epoch(util.LR)
+    for name, a in fresh.get_states(np.float32).items():
+        assert np.array_equal(a, reused.get_state(name, np.float32)), name
