@@ -32,6 +32,8 @@ WORKLOADS = {
     # BASELINE.json north_star target sentence: 10M users / 1M items / 64 conditions
     "northstar": ("CAMF_CI", 128, 10_000_000, 1_000_000, 4, 16, 200_000_000),
     "small": ("CAMF_CI", 128, 100_000, 10_000, 4, 8, 5_000_000),
+    # BASELINE.json configs[4] per-GPU share: CAMF_CU k=256, 10M x 1M x 128 conditions, 500M ratings over 8 GPUs
+    "c5": ("CAMF_CU", 256, 1_250_000, 1_000_000, 4, 32, 62_500_000),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
@@ -197,7 +199,7 @@ def main():
         achieved = data.n * bytes_per_update / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(args.workload)
         out = {
-            "metric": "SGD rating-updates/sec, CAMF_CI k=128",
+            "metric": "SGD rating-updates/sec, %s k=%d" % (model, k),
             "value": total_tuples * args.steps / elapsed,
             "unit": "rating-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,7 +213,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "user-sharded x%d + RCCL all-reduce of item-side deltas" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "sgd_level_fast_f32<CAMF_CI,2>", "bytes_per_update": bytes_per_update,
+                         "kernel": "sgd_level_fast_f32<%s,%d>" % (model, k // 64), "bytes_per_update": bytes_per_update,
                          "launches_per_epoch": launches,
                          "avg_launch_us": kern_ms * 1e3 / launches,
                          "bytes_per_launch": data.n * bytes_per_update / launches},
