@@ -13,61 +13,15 @@
 #include <string>
 #include <vector>
 
+#include "cmi_instance.hpp"
 #include "level_schedule.hpp"
 #include "mf_sgd_kernels.hpp"
 
 using namespace cmi;
 
-struct cmi_instance {
-    int model = 0, k = 0, n_users = 0, n_items = 0, n_conds = 0, device = 0;
-    unsigned flags = 0;
-    bool f64 = false, serial = false, strict = false, use_graph = true, fast = false, want_flow = false, flow = false,
-         want_two_lane = false, two_lane = false;
-    std::vector<int64_t> split_off; // two-lane schedule: first tail position of every level
-    std::string err;
-    hipStream_t stream = nullptr;
-    void *state[CMI_STATE_COUNT] = {};
-    int64_t state_count[CMI_STATE_COUNT] = {};
-    // tuple stream (schedule order)
-    int64_t n = 0;
-    int dmax = 0;
-    int32_t n_ctx = 0;
-    int32_t *d_su = nullptr, *d_sj = nullptr, *d_sconds = nullptr, *d_ctx_ptr = nullptr, *d_ctx_conds = nullptr;
-    void *d_sr = nullptr;
-    uint32_t *d_seq_u = nullptr, *d_seq_j = nullptr, *d_ver_u = nullptr, *d_ver_j = nullptr;
-    int32_t *d_flow_err = nullptr;
-    int64_t n_chunks = 0;
-    int flow_blocks = 0;
-    int64_t ctx_nnz = 0;
-    std::vector<int64_t> level_off, slot_off;
-    int64_t n_slots = 0, max_level = 0, tuple_bytes = 0, sched_levels = 0;
-    double *d_loss_part = nullptr, *d_scratch = nullptr, *d_loss = nullptr;
-    HParams *d_hp = nullptr;
-    HParams hp{0, 0, 0, 0, 0, 0};
-    double *h_loss = nullptr; // pinned
-    hipGraphExec_t graph_exec = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool have_ratings = false, epoch_timed = false;
-    double last_loss = 0.0;
-};
-
 static thread_local std::string g_create_err;
 
-#define CMI_FAIL(h, code, ...)                                                                          \
-    do {                                                                                                \
-        char buf_[512];                                                                                 \
-        snprintf(buf_, sizeof buf_, __VA_ARGS__);                                                       \
-        (h)->err = buf_;                                                                                \
-        return (code);                                                                                  \
-    } while (0)
-
-#define CMI_HIP(h, expr)                                                                                \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess) CMI_FAIL(h, CMI_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
-    } while (0)
-
-static bool model_has(int model, int which) {
+bool cmi_model_has(int model, int which) {
     switch (which) {
     case CMI_STATE_P:
     case CMI_STATE_Q: return true;
@@ -193,7 +147,7 @@ extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_cond
     TRY(hipEventCreate(&h->ev0));
     TRY(hipEventCreate(&h->ev1));
     for (int w = 0; w < CMI_STATE_COUNT; ++w) {
-        if (!model_has(model, w)) continue;
+        if (!cmi_model_has(model, w)) continue;
         h->state_count[w] = state_elems(h, w);
         size_t bytes = (size_t)h->state_count[w] * esize(h);
         if (bytes == 0) continue;
@@ -230,7 +184,7 @@ extern "C" int cmi_set_hparams(cmi_handle h, double regU, double regI, double re
 static int check_state_args(cmi_instance *h, int which, const void *p, int64_t count, int dtype) {
     if (which < 0 || which >= CMI_STATE_COUNT || !p || (dtype != CMI_DTYPE_F32 && dtype != CMI_DTYPE_F64))
         CMI_FAIL(h, CMI_E_INVALID, "state: invalid argument");
-    if (!model_has(h->model, which)) CMI_FAIL(h, CMI_E_INVALID, "state %d does not exist in model %d", which, h->model);
+    if (!cmi_model_has(h->model, which)) CMI_FAIL(h, CMI_E_INVALID, "state %d does not exist in model %d", which, h->model);
     if (count != h->state_count[which])
         CMI_FAIL(h, CMI_E_INVALID, "state %d: count %lld != expected %lld", which, (long long)count,
                  (long long)h->state_count[which]);
@@ -283,7 +237,7 @@ extern "C" int cmi_get_state(cmi_handle h, int which, void *dst, int64_t count, 
 
 extern "C" int cmi_state_device_ptr(cmi_handle h, int which, void **ptr, int64_t *count, int *dtype) {
     if (!h || which < 0 || which >= CMI_STATE_COUNT) return CMI_E_INVALID;
-    if (!model_has(h->model, which)) CMI_FAIL(h, CMI_E_INVALID, "state %d does not exist in model %d", which, h->model);
+    if (!cmi_model_has(h->model, which)) CMI_FAIL(h, CMI_E_INVALID, "state %d does not exist in model %d", which, h->model);
     if (ptr) *ptr = h->state[which];
     if (count) *count = h->state_count[which];
     if (dtype) *dtype = h->f64 ? CMI_DTYPE_F64 : CMI_DTYPE_F32;

@@ -1,0 +1,60 @@
+// cmi_instance.hpp -- the object behind a cmi_handle, shared by the translation units of libcarskit_mi355x.so.
+#pragma once
+#include "../../include/carskit_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "mf_sgd_kernels.hpp"
+
+struct cmi_instance {
+    int model = 0, k = 0, n_users = 0, n_items = 0, n_conds = 0, device = 0;
+    unsigned flags = 0;
+    bool f64 = false, serial = false, strict = false, use_graph = true, fast = false, want_flow = false, flow = false,
+         want_two_lane = false, two_lane = false;
+    std::vector<int64_t> split_off; // two-lane schedule: first tail position of every level
+    std::string err;
+    hipStream_t stream = nullptr;
+    void *state[CMI_STATE_COUNT] = {};
+    int64_t state_count[CMI_STATE_COUNT] = {};
+    // tuple stream (schedule order)
+    int64_t n = 0;
+    int dmax = 0;
+    int32_t n_ctx = 0;
+    int32_t *d_su = nullptr, *d_sj = nullptr, *d_sconds = nullptr, *d_ctx_ptr = nullptr, *d_ctx_conds = nullptr;
+    void *d_sr = nullptr;
+    uint32_t *d_seq_u = nullptr, *d_seq_j = nullptr, *d_ver_u = nullptr, *d_ver_j = nullptr;
+    int32_t *d_flow_err = nullptr;
+    int64_t n_chunks = 0;
+    int flow_blocks = 0;
+    int64_t ctx_nnz = 0;
+    std::vector<int64_t> level_off, slot_off;
+    int64_t n_slots = 0, max_level = 0, tuple_bytes = 0, sched_levels = 0;
+    double *d_loss_part = nullptr, *d_scratch = nullptr, *d_loss = nullptr;
+    cmi::HParams *d_hp = nullptr;
+    cmi::HParams hp{0, 0, 0, 0, 0, 0};
+    double *h_loss = nullptr; // pinned
+    hipGraphExec_t graph_exec = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_ratings = false, epoch_timed = false;
+    double last_loss = 0.0;
+};
+
+#define CMI_FAIL(h, code, ...)                                                                          \
+    do {                                                                                                \
+        char buf_[512];                                                                                 \
+        snprintf(buf_, sizeof buf_, __VA_ARGS__);                                                       \
+        (h)->err = buf_;                                                                                \
+        return (code);                                                                                  \
+    } while (0)
+
+#define CMI_HIP(h, expr)                                                                                \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) CMI_FAIL(h, CMI_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+bool cmi_model_has(int model, int which); // which containers a model owns (cmi_api.cpp)

@@ -1,0 +1,384 @@
+// rank_api.cpp -- cmi_eval_rankings: the reference's top-N evaluation (Recommender.evalRankings,
+// src/carskit/generic/Recommender.java:668-964) with the O(queries x items x k) scoring on the GPU.
+// Host side: query / candidate / exclusion bookkeeping and the (tiny, per-query) metric formulas; device side:
+// rank_kernels.hip.  No CPU scoring path exists.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "cmi_instance.hpp"
+#include "rank_kernels.hpp"
+
+using namespace cmi;
+
+namespace {
+
+// ---- java.util.HashSet<Integer> iteration order -----------------------------------------------------------------
+// Integer.hashCode() is the value; HashMap spreads h ^ (h >>> 16), indexes with (cap-1), doubles the table when
+// size > 0.75*cap, and on a split keeps relative order inside a bucket, so iteration = (bucket, insertion order).
+std::vector<int32_t> java_int_hashset_order(const std::vector<int32_t> &first_seen) {
+    size_t cap = 16;
+    while ((double)first_seen.size() > 0.75 * (double)cap) cap <<= 1;
+    std::vector<std::pair<uint32_t, int32_t>> keyed(first_seen.size());
+    for (size_t i = 0; i < first_seen.size(); ++i) {
+        const uint32_t h = (uint32_t)first_seen[i];
+        keyed[i] = {(uint32_t)((h ^ (h >> 16)) & (cap - 1)), (int32_t)i};
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    std::vector<int32_t> out(first_seen.size());
+    for (size_t i = 0; i < keyed.size(); ++i) out[i] = first_seen[keyed[i].second];
+    return out;
+}
+
+// ---- metric formulas (happy.coding.math.Measures, read from lib/happy.coding.utils-1.2.6.jar; wrappers that cut
+// the list to the top n first: src/carskit/eval/Measures.java:13-67) -------------------------------------------------
+struct Truth {
+    const int32_t *items;
+    int n;
+    bool has(int32_t j) const { // ground-truth lists are short; sorted for the binary search
+        return std::binary_search(items, items + n, j);
+    }
+};
+
+int hits_at(const int32_t *ranked, int len, const Truth &t, int n) { // Measures.HitsAt over the FULL ranked list
+    int hits = 0;
+    for (int i = 0; i < len; ++i)
+        if (t.has(ranked[i])) {
+            if (i >= n) break;
+            ++hits;
+        }
+    return hits;
+}
+
+double auc(const int32_t *ranked, int len, const Truth &t, int num_dropped) {
+    int num_rele = 0; // Lists.overlapSize(groundTruth, rankedList)
+    for (int i = 0; i < len; ++i) num_rele += t.has(ranked[i]);
+    const long num_eval_items = (long)len + num_dropped;
+    const long num_eval_pairs = (num_eval_items - num_rele) * num_rele;
+    if (num_eval_pairs == 0) return 0.5;
+    long correct = 0, hits = 0;
+    for (int i = 0; i < len; ++i) {
+        if (!t.has(ranked[i])) correct += hits;
+        else ++hits;
+    }
+    const long num_miss = t.n - num_rele; // Lists.exceptSize(groundTruth, rankedList)
+    correct += hits * ((long)num_dropped - num_miss);
+    return (double)correct / (double)num_eval_pairs;
+}
+
+double ap(const int32_t *ranked, int len, const Truth &t) {
+    int hits = 0;
+    double s = 0.0;
+    for (int i = 0; i < len; ++i)
+        if (t.has(ranked[i])) {
+            ++hits;
+            s += hits / (i + 1.0);
+        }
+    return hits > 0 ? s / t.n : 0.0;
+}
+
+inline double log2j(double x) { return std::log(x) / std::log(2.0); } // Maths.log(x, 2)
+
+double ndcg(const int32_t *ranked, int len, const Truth &t) {
+    double dcg = 0.0, idcg = 0.0;
+    for (int i = 0; i < len; ++i)
+        if (t.has(ranked[i])) dcg += 1.0 / log2j(i + 2);
+    for (int i = 0; i < t.n; ++i) idcg += 1.0 / log2j(i + 2);
+    return dcg / idcg;
+}
+
+double rr(const int32_t *ranked, int len, const Truth &t) {
+    for (int i = 0; i < len; ++i)
+        if (t.has(ranked[i])) return 1.0 / (i + 1.0);
+    return 0.0;
+}
+
+struct NanMean { // happy.coding.math.Stats.mean(Collection): NaN entries are skipped; empty -> 0/0 = NaN
+    double s = 0.0;
+    long c = 0;
+    void add(double x) {
+        if (!std::isnan(x)) {
+            s += x;
+            ++c;
+        }
+    }
+    double value() const { return c ? s / (double)c : std::nan(""); }
+};
+
+constexpr int N_MEAS = 18; // Pre,Rec,AUC,MAP,NDCG,MRR x {5,10,N}
+
+template <typename T>
+int run_device(cmi_instance *h, const std::vector<int32_t> &cand, const std::vector<int32_t> &qu,
+               const std::vector<int32_t> &qc, const std::vector<int64_t> &excl_ptr,
+               const std::vector<int32_t> &excl_idx, double thold, int topn, std::vector<int32_t> &top_idx,
+               std::vector<double> &top_score, std::vector<int32_t> &top_count) {
+    const int nc = (int)cand.size();
+    const int64_t nq = (int64_t)qu.size();
+    const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF;
+    const bool ic_used = h->state[CMI_STATE_IC_BIAS] != nullptr;
+    const int kp = h->k + 1 + (ic_used ? h->n_conds : 0);
+    // query batch: keep the score slab around 1 GiB (it is written once and re-read topn times)
+    int64_t bq = std::max<int64_t>(64, ((int64_t)1 << 30) / ((int64_t)nc * (int64_t)sizeof(T)));
+    bq = std::min<int64_t>(bq, nq);
+    if (const char *e = getenv("CMI_RANK_BATCH")) bq = std::max<int64_t>(1, std::min<int64_t>(atoll(e), nq));
+
+    T *dA = nullptr, *dB = nullptr, *dS = nullptr, *drc = nullptr;
+    int32_t *dcand = nullptr, *dqu = nullptr, *dqc = nullptr, *dexcl = nullptr, *dtop = nullptr, *dcount = nullptr;
+    int64_t *dexptr = nullptr;
+    double *dscore = nullptr;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(p, std::max<size_t>(bytes, 8));
+    };
+    alloc((void **)&dB, (size_t)nc * kp * sizeof(T));
+    alloc((void **)&dA, (size_t)bq * kp * sizeof(T));
+    alloc((void **)&dS, (size_t)bq * nc * sizeof(T));
+    alloc((void **)&drc, (size_t)bq * sizeof(T));
+    alloc((void **)&dcand, (size_t)nc * 4);
+    alloc((void **)&dqu, (size_t)nq * 4);
+    alloc((void **)&dqc, (size_t)nq * 4);
+    alloc((void **)&dexptr, (size_t)(nq + 1) * 8);
+    alloc((void **)&dexcl, excl_idx.size() * 4);
+    alloc((void **)&dtop, (size_t)nq * topn * 4);
+    alloc((void **)&dscore, (size_t)nq * topn * 8);
+    alloc((void **)&dcount, (size_t)nq * 4);
+    auto up = [&](void *d, const void *s, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, h->stream);
+    };
+    up(dcand, cand.data(), (size_t)nc * 4);
+    up(dqu, qu.data(), (size_t)nq * 4);
+    up(dqc, qc.data(), (size_t)nq * 4);
+    up(dexptr, excl_ptr.data(), (size_t)(nq + 1) * 8);
+    up(dexcl, excl_idx.data(), excl_idx.size() * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(dtop, 0xff, (size_t)nq * topn * 4, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dscore, 0, (size_t)nq * topn * 8, h->stream);
+    if (e == hipSuccess) {
+        RankItemsArgs<T> ia{(const T *)h->state[CMI_STATE_Q], (const T *)h->state[CMI_STATE_ITEM_BIAS],
+                            (const T *)h->state[CMI_STATE_IC_BIAS], dcand, dB, nc, h->k, kp, h->n_conds};
+        e = rank_launch_build_items<T>(ia, h->stream);
+    }
+    for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += bq) {
+        const int n = (int)std::min<int64_t>(bq, nq - q0);
+        RankQueryArgs<T> qa{(const T *)h->state[CMI_STATE_P],
+                            (const T *)h->state[CMI_STATE_USER_BIAS],
+                            (const T *)h->state[CMI_STATE_UC_BIAS],
+                            (const T *)h->state[CMI_STATE_COND_BIAS],
+                            dqu + q0,
+                            dqc + q0,
+                            contextual ? h->d_ctx_ptr : nullptr,
+                            contextual ? h->d_ctx_conds : nullptr,
+                            dA,
+                            drc,
+                            h->hp.gm,
+                            h->k,
+                            kp,
+                            h->n_conds,
+                            ic_used ? 1 : 0};
+        e = rank_launch_build_queries<T>(qa, n, h->stream);
+        if (e == hipSuccess)
+            e = rank_launch_score<T>(dA, dB, drc, dS, n, nc, kp, dexptr, dexcl, (int)q0, thold, topn, dtop, dscore, dcount,
+                                     h->stream);
+    }
+    top_idx.resize((size_t)nq * topn);
+    top_score.resize((size_t)nq * topn);
+    top_count.resize((size_t)nq);
+    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_idx.data(), dtop, (size_t)nq * topn * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_score.data(), dscore, (size_t)nq * topn * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_count.data(), dcount, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    void *ptrs[] = {dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    CMI_HIP(h, e);
+    return CMI_OK;
+}
+
+} // namespace
+
+extern "C" int cmi_java_int_hashset_order(int64_t n, const int32_t *values, int32_t *out, int64_t *n_out) {
+    if (n < 0 || (n > 0 && (!values || !out)) || !n_out) return CMI_E_INVALID;
+    std::vector<int32_t> first;
+    {
+        std::vector<int32_t> sorted(values, values + n);
+        std::sort(sorted.begin(), sorted.end());
+        sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
+        std::vector<char> seen(sorted.size(), 0);
+        for (int64_t i = 0; i < n; ++i) {
+            const size_t p = std::lower_bound(sorted.begin(), sorted.end(), values[i]) - sorted.begin();
+            if (!seen[p]) {
+                seen[p] = 1;
+                first.push_back(values[i]);
+            }
+        }
+    }
+    const std::vector<int32_t> ord = java_int_hashset_order(first);
+    std::copy(ord.begin(), ord.end(), out);
+    *n_out = (int64_t)ord.size();
+    return CMI_OK;
+}
+
+extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *tu, const int32_t *tj,
+                                 const int32_t *tctx, const double *tr, int64_t n_test, const int32_t *su,
+                                 const int32_t *sj, const int32_t *sctx, const double *sr, double bin_thold,
+                                 int num_recs, int num_ignore, int strategy, double out[CMI_RANK_MEASURES],
+                                 int64_t *n_queries, int32_t *q_user, int32_t *q_ctx, int32_t *q_count,
+                                 int32_t *top_items, double *top_scores) {
+    if (!h) return CMI_E_INVALID;
+    if (!out) CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: null output");
+    if (n_train < 0 || n_test < 0 || (n_train > 0 && (!tu || !tj || !tctx)) || (n_test > 0 && (!su || !sj || !sctx || !sr)))
+        CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: null tuple arrays");
+    if (num_recs < 1)
+        CMI_FAIL(h, CMI_E_INVALID,
+                 "eval_rankings: -topN must be >= 1 (with -topN <= 0 the reference's cut-off list holds a non-positive n: "
+                 "carskit/eval/Measures.java:13-16 throws for n<0)");
+    if (strategy != CMI_RANK_UCU && strategy != CMI_RANK_UC) CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: strategy must be CMI_RANK_UCU or CMI_RANK_UC");
+    const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF;
+    if (contextual && !h->have_ratings)
+        CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: the context table comes from cmi_set_ratings; call it first");
+    auto check = [&](int64_t n, const int32_t *u, const int32_t *j, const int32_t *c, const char *what) -> int {
+        for (int64_t t = 0; t < n; ++t) {
+            if (u[t] < 0 || u[t] >= h->n_users || j[t] < 0 || j[t] >= h->n_items)
+                CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: %s user/item id out of range at tuple %lld", what, (long long)t);
+            if (c[t] < 0 || (contextual && c[t] >= h->n_ctx))
+                CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: %s context id %d out of range at tuple %lld", what, c[t], (long long)t);
+        }
+        return CMI_OK;
+    };
+    if (int rc = check(n_train, tu, tj, tctx, "train")) return rc;
+    if (int rc = check(n_test, su, sj, sctx, "test")) return rc;
+    CMI_HIP(h, hipSetDevice(h->device));
+    for (int m = 0; m < CMI_RANK_MEASURES; ++m) out[m] = std::nan("");
+    out[18] = out[19] = out[20] = 0.0; // D5/D10/DN: isDiverseUsed=false (Recommender.java:939-941)
+    if (n_queries) *n_queries = 0;
+
+    // candidate items: rateDao.getItemList(trainMatrix) -> HashSet<Integer> (DataDAO.java:1210-1218)
+    std::vector<int32_t> first_seen, degree(h->n_items, 0);
+    for (int64_t t = 0; t < n_train; ++t) {
+        if (tr && tr[t] == 0.0) continue; // a sparse matrix holds no zero entries
+        if (degree[tj[t]]++ == 0) first_seen.push_back(tj[t]);
+    }
+    std::vector<int32_t> cand = java_int_hashset_order(first_seen);
+    if (num_ignore > 0) { // drop the most popular items (Recommender.java:720-735): stable sort by degree, descending
+        std::vector<int32_t> by_deg = cand;
+        std::stable_sort(by_deg.begin(), by_deg.end(), [&](int32_t a, int32_t b) { return degree[a] > degree[b]; });
+        std::vector<char> drop(h->n_items, 0);
+        for (int i = 0; i < num_ignore && i < (int)by_deg.size(); ++i) drop[by_deg[i]] = 1;
+        cand.erase(std::remove_if(cand.begin(), cand.end(), [&](int32_t j) { return drop[j]; }), cand.end());
+    }
+    const int nc = (int)cand.size();
+    std::vector<int32_t> cand_pos(h->n_items, -1);
+    for (int i = 0; i < nc; ++i) cand_pos[cand[i]] = i;
+
+    // queries: test positives (rate > threshold) grouped by (user, context)  (DataDAO.getUserCtxList, DataDAO.java:1114-1140)
+    std::vector<int64_t> pos;
+    for (int64_t t = 0; t < n_test; ++t)
+        if (sr[t] != 0.0 && sr[t] > bin_thold) pos.push_back(t);
+    std::sort(pos.begin(), pos.end(), [&](int64_t a, int64_t b) {
+        if (su[a] != su[b]) return su[a] < su[b];
+        if (sctx[a] != sctx[b]) return sctx[a] < sctx[b];
+        return sj[a] < sj[b];
+    });
+    std::vector<int32_t> qu, qc, truth_items;
+    std::vector<int64_t> truth_ptr{0};
+    for (size_t i = 0; i < pos.size();) {
+        size_t e = i;
+        const size_t before = truth_items.size();
+        while (e < pos.size() && su[pos[e]] == su[pos[i]] && sctx[pos[e]] == sctx[pos[i]]) {
+            const int32_t j = sj[pos[e]];
+            if (cand_pos[j] >= 0 && (truth_items.size() == before || truth_items.back() != j)) truth_items.push_back(j);
+            ++e;
+        }
+        if (truth_items.size() > before) { // correctItems non-empty (Recommender.java:789-790)
+            qu.push_back(su[pos[i]]);
+            qc.push_back(sctx[pos[i]]);
+            truth_ptr.push_back((int64_t)truth_items.size());
+        }
+        i = e;
+    }
+    const int64_t nq = (int64_t)qu.size();
+
+    // exclusions: items the user rated in the same context in the training set (Recommender.java:793, 814-816)
+    std::vector<int64_t> tord;
+    for (int64_t t = 0; t < n_train; ++t)
+        if (!(tr && tr[t] == 0.0)) tord.push_back(t);
+    std::sort(tord.begin(), tord.end(), [&](int64_t a, int64_t b) {
+        if (tu[a] != tu[b]) return tu[a] < tu[b];
+        if (tctx[a] != tctx[b]) return tctx[a] < tctx[b];
+        return tj[a] < tj[b];
+    });
+    std::vector<int64_t> excl_ptr{0};
+    std::vector<int32_t> excl_idx;
+    {
+        size_t p = 0;
+        for (int64_t q = 0; q < nq; ++q) {
+            while (p < tord.size() && (tu[tord[p]] < qu[q] || (tu[tord[p]] == qu[q] && tctx[tord[p]] < qc[q]))) ++p;
+            size_t e = p;
+            while (e < tord.size() && tu[tord[e]] == qu[q] && tctx[tord[e]] == qc[q]) {
+                const int32_t cp = cand_pos[tj[tord[e]]];
+                if (cp >= 0 && (excl_idx.size() == (size_t)excl_ptr.back() || excl_idx.back() != cp)) excl_idx.push_back(cp);
+                ++e;
+            }
+            excl_ptr.push_back((int64_t)excl_idx.size());
+        }
+    }
+
+    std::vector<int32_t> top_idx, top_count;
+    std::vector<double> top_score;
+    if (nq > 0 && nc > 0) {
+        const int rc = h->f64 ? run_device<double>(h, cand, qu, qc, excl_ptr, excl_idx, bin_thold, num_recs, top_idx, top_score, top_count)
+                              : run_device<float>(h, cand, qu, qc, excl_ptr, excl_idx, bin_thold, num_recs, top_idx, top_score, top_count);
+        if (rc) return rc;
+    }
+
+    // metrics, per query then averaged per strategy (Recommender.java:850-960)
+    NanMean total[N_MEAS], per_user[N_MEAS];
+    const int cut[3] = {5, 10, num_recs};
+    std::vector<int32_t> ranked(num_recs);
+    auto flush_user = [&]() {
+        for (int m = 0; m < N_MEAS; ++m) {
+            total[m].add(per_user[m].value());
+            per_user[m] = NanMean();
+        }
+    };
+    int64_t emitted = 0;
+    for (int64_t q = 0; q < nq; ++q) {
+        const int len = top_count[q];
+        if (q_user) q_user[q] = qu[q];
+        if (q_ctx) q_ctx[q] = qc[q];
+        if (q_count) q_count[q] = len;
+        for (int i = 0; i < len; ++i) {
+            ranked[i] = cand[top_idx[(size_t)q * num_recs + i]];
+            if (top_items) top_items[(size_t)q * num_recs + i] = ranked[i];
+            if (top_scores) top_scores[(size_t)q * num_recs + i] = top_score[(size_t)q * num_recs + i];
+        }
+        for (int i = len; i < num_recs; ++i) {
+            if (top_items) top_items[(size_t)q * num_recs + i] = -1;
+            if (top_scores) top_scores[(size_t)q * num_recs + i] = std::nan("");
+        }
+        if (len > 0) { // "no recommendations available" queries are skipped (Recommender.java:818-819)
+            const Truth t{truth_items.data() + truth_ptr[q], (int)(truth_ptr[q + 1] - truth_ptr[q])};
+            const int num_cands = nc - (int)(excl_ptr[q + 1] - excl_ptr[q]);
+            const int num_dropped = num_cands - len;
+            NanMean *dst = strategy == CMI_RANK_UC ? total : per_user;
+            for (int c = 0; c < 3; ++c) {
+                const int n = cut[c], tl = std::min(n, len);
+                const int hits = hits_at(ranked.data(), len, t, n);
+                dst[0 + c].add(hits / (n + 0.0));
+                dst[3 + c].add(hits / (t.n + 0.0));
+                dst[6 + c].add(auc(ranked.data(), tl, t, num_dropped));
+                dst[9 + c].add(ap(ranked.data(), tl, t));
+                dst[12 + c].add(ndcg(ranked.data(), tl, t));
+                dst[15 + c].add(rr(ranked.data(), tl, t));
+            }
+            ++emitted;
+        }
+        // ucu: a test user contributes the NaN-skipping mean over its contexts -- NaN (skipped again) if none of
+        // its contexts produced a list (Recommender.java:903-926)
+        if (strategy == CMI_RANK_UCU && (q + 1 == nq || qu[q + 1] != qu[q])) flush_user();
+    }
+    for (int m = 0; m < N_MEAS; ++m) out[m] = total[m].value();
+    if (n_queries) *n_queries = nq;
+    (void)emitted;
+    return CMI_OK;
+}

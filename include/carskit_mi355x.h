@@ -145,6 +145,38 @@ int cmi_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j
 
 /* ---- plumbing for the host layer (multi-GPU exchange, measurement); no reference counterpart ---- */
 
+/* ---- top-N ranking evaluation: Recommender.evalRankings (src/carskit/generic/Recommender.java:668-964) ----------
+ * The reference scores every candidate item for every test (user, context) pair with one predict() call each
+ * (O(queries x items x k)); here that scoring is one dense contraction per query batch plus a fused top-N selection
+ * on the GPU, and only the per-query metric formulas (happy.coding.math.Measures via src/carskit/eval/Measures.java)
+ * run on the host.
+ *   train tuples  -> candidate items = items seen in training, in java.util.HashSet<Integer> iteration order
+ *                    (DataDAO.getItemList, DataDAO.java:1210-1218); minus the num_ignore most-rated ones
+ *                    (Recommender.java:720-735); and the per-(user, context) already-rated items that are skipped
+ *                    (Recommender.java:793-816).  tr may be NULL (all entries non-zero).
+ *   test tuples   -> queries: (user, context) pairs with at least one item rated > bin_thold that is a candidate
+ *                    (DataDAO.getUserCtxList(sm, threshold), DataDAO.java:1114-1140; Recommender.java:776-790).
+ *   score         -> ranking(u,j,c) = predict(u,j,c) unbounded (Recommender.java:1016-1018); kept if not NaN and
+ *                    > bin_thold; sorted descending, ties in candidate order (stable Collections.sort); cut at num_recs.
+ *   num_recs      -> `-topN`; must be >= 1 (the reference throws for a negative cut-off, Measures.java:13-16).
+ *   strategy      -> CMI_RANK_UCU: mean over contexts per user, then over users; CMI_RANK_UC: mean over all pairs
+ *                    (`evaluation.setup --rand-seed ... -strategy`, Recommender.java:856-926).  Stats.mean skips NaN.
+ * out[21] = Pre5 Pre10 PreN Rec5 Rec10 RecN AUC5 AUC10 AUCN MAP5 MAP10 MAPN NDCG5 NDCG10 NDCGN MRR5 MRR10 MRRN D5 D10 DN
+ * (D* = 0: diversity is off unless `-diverse`, which needs the item-similarity cache and is not built).
+ * Optional per-query outputs (NULL to skip), sized for n_test queries: q_user/q_ctx/q_count[n] and
+ * top_items/top_scores[n * num_recs] (inner item ids, -1 / NaN padded) -- the `-isResultsOut` list of the reference.
+ * Context ids index the ctx table given to cmi_set_ratings (2-D models ignore the table). */
+#define CMI_RANK_MEASURES 21
+#define CMI_RANK_UCU 0
+#define CMI_RANK_UC 1
+int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *tu, const int32_t *tj, const int32_t *tctx,
+                      const double *tr, int64_t n_test, const int32_t *su, const int32_t *sj, const int32_t *sctx,
+                      const double *sr, double bin_thold, int num_recs, int num_ignore, int strategy,
+                      double out[CMI_RANK_MEASURES], int64_t *n_queries, int32_t *q_user, int32_t *q_ctx,
+                      int32_t *q_count, int32_t *top_items, double *top_scores);
+/* iteration order of a java.util.HashSet<Integer> after add()ing values[0..n) (the candidate-item order above) */
+int cmi_java_int_hashset_order(int64_t n, const int32_t *values, int32_t *out, int64_t *n_out);
+
 /* device pointer of a state container (element type per CMI_FLAG_STATE_F64), so the host can run its
  * epoch-boundary exchange (RCCL all-reduce of item-side deltas) in place */
 int cmi_state_device_ptr(cmi_handle h, int which, void **ptr, int64_t *count, int *dtype);

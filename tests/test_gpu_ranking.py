@@ -1,0 +1,159 @@
+"""GPU parity of cmi_eval_rankings (Recommender.evalRankings, Recommender.java:668-964) against oracle/rank_oracle.py
+driven by the C oracle's scalar predict().
+
+Bars: fp64 state -> identical top-N item lists, scores within 1e-12, all 18 measures within 1e-12 (the GPU sums the
+predict() terms in a different order: dot product tree/tiled, biases folded into the contraction);
+fp32 state -> scores within 1e-4, measures within 0.02 (near-tied neighbours may swap)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from carskit_amd import capi, synth
+from oracle import oracle_c, rank_oracle
+from tests import util
+
+pytestmark = pytest.mark.gpu
+F64, SERIAL, STRICT = capi.FLAG_STATE_F64, capi.FLAG_SCHED_SERIAL, capi.FLAG_STRICT
+
+
+def _setup(model, k, flags, epochs=2, n_users=60, n_items=90, n=2500, seed=3):
+    data = synth.generate(n_users, n_items, 3, 3, n, seed=seed)
+    train, test = synth.split(data, 0.25)
+    state = synth.init_state(model, train, k, seed=9)
+    gm = 0.0 if model == "PMF" else oracle_c.global_mean(train.r)
+    orc = util.c_oracle(model, train, k, state, gm)
+    u, j, ctx, r = util.tuples_for(model, train)
+    if model == "CAMF_C":
+        flags |= SERIAL
+    inst = capi.Instance(model, k, train.n_users, train.n_items, train.n_conds, flags=flags)
+    inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, gm)
+    if model in util.TWO_D:
+        inst.set_ratings(u, j, None, r)
+    else:
+        inst.set_ratings(u, j, ctx, r, train.ctx_ptr, train.ctx_conds)
+    inst.set_states(state)
+    for _ in range(epochs):
+        orc.epoch(util.LR)
+        inst.train_epoch(util.LR)
+    return train, test, orc, inst
+
+
+def _tuples(d):
+    return list(zip(d.u.tolist(), d.j.tolist(), d.ctx.tolist(), d.r.tolist()))
+
+
+def _arrays(d):
+    return d.u, d.j, d.ctx, d.r
+
+
+def _oracle_eval(orc, train, test, **kw):
+    return rank_oracle.eval_rankings(lambda u, j, c: orc.predict(u, j, c), _tuples(train), _tuples(test), **kw)
+
+
+def _assert_same(res, lists, ref, ref_lists, tol, score_tol, same_items=True):
+    assert set(lists) == set(ref_lists)
+    for key, ref_l in ref_lists.items():
+        got = lists[key]
+        assert len(got) == len(ref_l), key
+        if same_items:
+            assert [i for i, _ in got] == [i for i, _ in ref_l], key
+        for (_, a), (_, b) in zip(got, ref_l):
+            assert abs(a - b) <= score_tol, (key, a, b)
+    for m in rank_oracle.MEASURES:
+        a, b = res[m], ref[m]
+        assert (math.isnan(a) and math.isnan(b)) or abs(a - b) <= tol, (m, a, b)
+    assert res["D5"] == res["D10"] == res["DN"] == 0.0
+
+
+@pytest.mark.parametrize("model", util.MODELS)
+@pytest.mark.parametrize("strategy", ["ucu", "uc"])
+def test_f64_rankings_match_oracle(model, strategy):
+    train, test, orc, inst = _setup(model, 10, F64 | STRICT)
+    thold = -1.0 if model == "PMF" else 2.5     # PMF scores are bare dot products, far below the rating scale
+    ref, ref_lists = _oracle_eval(orc, train, test, bin_thold=thold, num_recs=10, strategy=strategy)
+    res, lists = inst.eval_rankings(_arrays(train), _arrays(test), bin_thold=thold, num_recs=10, strategy=strategy,
+                                    with_lists=True)
+    assert len(ref_lists) > 20
+    _assert_same(res, lists, ref, ref_lists, 1e-12, 1e-12)
+
+
+@pytest.mark.parametrize("model", ["CAMF_CI", "CAMF_CUCI", "BiasedMF"])
+@pytest.mark.parametrize("k,num_recs", [(3, 3), (64, 7), (70, 25)])
+def test_f64_rankings_shapes_and_topn(model, k, num_recs):
+    train, test, orc, inst = _setup(model, k, F64 | STRICT, epochs=1)
+    ref, ref_lists = _oracle_eval(orc, train, test, bin_thold=-1.0, num_recs=num_recs)
+    res, lists = inst.eval_rankings(_arrays(train), _arrays(test), bin_thold=-1.0, num_recs=num_recs, with_lists=True)
+    _assert_same(res, lists, ref, ref_lists, 1e-12, 1e-12)
+
+
+def test_query_batching_is_invisible():
+    train, test, orc, inst = _setup("CAMF_CUCI", 10, F64 | STRICT)
+    whole = inst.eval_rankings(_arrays(train), _arrays(test), bin_thold=2.5, with_lists=True)
+    os.environ["CMI_RANK_BATCH"] = "7"
+    try:
+        split = inst.eval_rankings(_arrays(train), _arrays(test), bin_thold=2.5, with_lists=True)
+    finally:
+        del os.environ["CMI_RANK_BATCH"]
+    assert whole == split
+
+
+def test_threshold_and_ignore():
+    train, test, orc, inst = _setup("CAMF_CI", 10, F64 | STRICT)
+    for kw in (dict(bin_thold=3.5, num_recs=5), dict(bin_thold=2.5, num_recs=10, num_ignore=7),
+               dict(bin_thold=4.2, num_recs=10, strategy="uc")):
+        ref, ref_lists = _oracle_eval(orc, train, test, **kw)
+        res, lists = inst.eval_rankings(_arrays(train), _arrays(test), with_lists=True, **kw)
+        _assert_same(res, lists, ref, ref_lists, 1e-12, 1e-12)
+
+
+def test_ties_follow_the_hashset_candidate_order():
+    # all-zero model: every score equals the global mean, so the list is the first num_recs non-rated candidates
+    # in HashSet<Integer> order; item ids are sparse (0..999) so that order is NOT ascending
+    rng = np.random.default_rng(2)
+    items = rng.choice(1000, size=40, replace=False)
+    n = 400
+    d = synth.generate(30, 40, 2, 3, n, seed=4)
+    j = items[d.j].astype(np.int32)
+    tr_mask = rng.random(len(j)) < 0.75
+    train = (d.u[tr_mask], j[tr_mask], d.ctx[tr_mask], d.r[tr_mask])
+    test = (d.u[~tr_mask], j[~tr_mask], d.ctx[~tr_mask], d.r[~tr_mask])
+    inst = capi.Instance("BiasedMF", 4, 30, 1000, d.n_conds, flags=F64)
+    inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+    inst.set_states({"P": np.zeros((30, 4)), "Q": np.zeros((1000, 4)), "userBias": np.zeros(30), "itemBias": np.zeros(1000)})
+    tt = [list(zip(*(a.tolist() for a in x))) for x in (train, test)]
+    ref, ref_lists = rank_oracle.eval_rankings(lambda u, jj, c: 3.0, tt[0], tt[1], bin_thold=2.5, num_recs=10)
+    res, lists = inst.eval_rankings(train, test, bin_thold=2.5, num_recs=10, with_lists=True)
+    order = rank_oracle.java_int_hashset_order(train[1].tolist())
+    assert order != sorted(order)
+    _assert_same(res, lists, ref, ref_lists, 1e-15, 0.0)
+
+
+@pytest.mark.parametrize("model", ["CAMF_CI", "CAMF_CU", "BiasedMF"])
+def test_f32_rankings_close_to_oracle(model):
+    train, test, orc, inst = _setup(model, 32, 0, epochs=3)
+    ref, ref_lists = _oracle_eval(orc, train, test, bin_thold=2.5, num_recs=10)
+    res, lists = inst.eval_rankings(_arrays(train), _arrays(test), bin_thold=2.5, num_recs=10, with_lists=True)
+    _assert_same(res, lists, ref, ref_lists, 0.02, 1e-4, same_items=False)
+    same = sum([i for i, _ in lists[q]] == [i for i, _ in ref_lists[q]] for q in ref_lists)
+    assert same >= 0.9 * len(ref_lists)
+
+
+def test_degenerate_inputs_and_errors():
+    train, test, orc, inst = _setup("CAMF_CI", 5, F64)
+    # no positive test rating -> no query -> every measure is Stats.mean(empty) = NaN
+    res = inst.eval_rankings(_arrays(train), _arrays(test), bin_thold=99.0)
+    assert res["n_queries"] == 0 and all(math.isnan(res[m]) for m in rank_oracle.MEASURES)
+    # a threshold above every score: queries exist but nothing is recommended
+    res, lists = inst.eval_rankings(_arrays(train), (test.u, test.j, test.ctx, test.r + 50.0), bin_thold=40.0,
+                                    with_lists=True)
+    assert res["n_queries"] > 0 and not lists and math.isnan(res["Pre5"])
+    # empty training set -> no candidates
+    empty = tuple(a[:0] for a in _arrays(train))
+    res = inst.eval_rankings(empty, _arrays(test), bin_thold=2.5)
+    assert res["n_queries"] == 0
+    with pytest.raises(capi.CmiError):
+        inst.eval_rankings(_arrays(train), _arrays(test), num_recs=0)
+    with pytest.raises(capi.CmiError):
+        inst.eval_rankings((train.u + 10_000, train.j, train.ctx, train.r), _arrays(test))

@@ -1,0 +1,117 @@
+"""CPU tests of the ranking-evaluation oracle (oracle/rank_oracle.py): metric formulas against hand-computed values,
+the HashSet<Integer> candidate order, and the evalRankings control flow (Recommender.java:668-964) on a tiny case
+worked out by hand.  The product's HashSet-order entry point (pure host code) is checked against the oracle here too."""
+import math
+
+import numpy as np
+import pytest
+
+from carskit_amd import capi
+from oracle import rank_oracle as ro
+
+RANKED = [3, 1, 4, 2, 5]
+TRUTH = [1, 5, 9]
+
+
+def test_hits_prec_recall_hand_values():
+    assert ro.hits_at(RANKED, TRUTH, 5) == 2
+    assert ro.hits_at(RANKED, TRUTH, 3) == 1          # item 5 sits at index 4 >= 3 -> loop breaks
+    assert ro.hits_at(RANKED, TRUTH, 10) == 2
+    assert ro.prec_at(RANKED, TRUTH, 5) == pytest.approx(0.4, abs=0)
+    assert ro.prec_at(RANKED, TRUTH, 10) == pytest.approx(0.2, abs=0)   # denominator is n, not the list length
+    assert ro.recall_at(RANKED, TRUTH, 5) == pytest.approx(2 / 3, abs=1e-16)
+
+
+def test_ap_ndcg_rr_hand_values():
+    assert ro.ap(RANKED, TRUTH) == pytest.approx((1 / 2 + 2 / 5) / 3, abs=1e-16)
+    dcg = 1 / (math.log(3) / math.log(2)) + 1 / (math.log(6) / math.log(2))
+    idcg = 1 / 1.0 + 1 / (math.log(3) / math.log(2)) + 1 / 2.0
+    assert ro.ndcg(RANKED, TRUTH) == pytest.approx(dcg / idcg, abs=1e-15)
+    assert ro.ndcg(RANKED, TRUTH) == pytest.approx(0.47762, abs=1e-5)
+    assert ro.rr(RANKED, TRUTH) == 0.5
+    assert ro.rr([7, 8], TRUTH) == 0.0
+    assert ro.ap([7, 8], TRUTH) == 0.0
+
+
+def test_auc_hand_values():
+    # 2 relevant in the list, 13 irrelevant overall (3 listed + 10 dropped), item 9 missing: 26 pairs, 20 correct
+    assert ro.auc(RANKED, TRUTH, 10) == pytest.approx(20 / 26, abs=1e-16)
+    assert ro.auc([7, 8], TRUTH, 10) == 0.5          # no relevant item in the list -> zero pairs -> 0.5
+    assert ro.auc([1, 5], [1, 5], 0) == 0.5          # everything relevant -> zero pairs
+    assert ro.auc([1, 7], [1], 0) == 1.0
+    assert ro.auc([7, 1], [1], 0) == 0.0
+
+
+def test_mean_skips_nan():
+    assert ro.mean([1.0, float("nan"), 3.0]) == 2.0
+    assert math.isnan(ro.mean([]))
+    assert math.isnan(ro.mean([float("nan")]))
+
+
+def test_hashset_order_small_tables():
+    # 5 keys -> table of 16: bucket = key & 15, so 33 (bucket 1) precedes 2, and 18 shares bucket 2 after 2
+    assert ro.java_int_hashset_order([2, 33, 18, 7, 2]) == [33, 2, 18, 7]
+    # 13 keys -> resized to 32 (13 > 12)
+    keys = [40, 8, 72, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11]
+    assert ro.java_int_hashset_order(keys) == [1, 2, 3, 4, 5, 6, 7, 40, 8, 72, 9, 10, 11]
+    # high bits are folded in: 65536 -> h ^ h>>>16 = 65537 -> bucket 1
+    assert ro.java_int_hashset_order([65536, 0, 1]) == [0, 65536, 1]
+
+
+def test_hashset_order_library_matches_oracle():
+    rng = np.random.default_rng(5)
+    for n, hi in ((0, 10), (1, 10), (12, 100), (13, 100), (200, 1000), (5000, 200000)):
+        v = rng.integers(0, hi, size=n)
+        assert capi.java_int_hashset_order(v).tolist() == ro.java_int_hashset_order(v.tolist())
+
+
+def _tiny():
+    # items 0..5; user 0 in ctx 0 rated {0,1} in training; test positives: (0, ctx0): items 2 and 4; (0, ctx1): item 3;
+    # (1, ctx0): item 5 rated 1.0 (below threshold 2.5) -> no query for user 1
+    train = [(0, 0, 0, 4.0), (0, 1, 0, 3.0), (1, 2, 0, 5.0), (1, 3, 1, 2.0), (1, 4, 0, 4.0), (1, 5, 1, 4.0)]
+    test = [(0, 2, 0, 5.0), (0, 4, 0, 3.0), (0, 3, 1, 4.0), (1, 5, 0, 1.0)]
+    score = {0: 9.0, 1: 8.0, 2: 3.0, 3: 5.0, 4: 4.0, 5: 6.0}
+    return train, test, (lambda u, j, c: score[j] + (0.5 if c == 1 and j == 2 else 0.0))
+
+
+def test_eval_rankings_tiny_by_hand():
+    train, test, predict = _tiny()
+    m, tops = ro.eval_rankings(predict, train, test, bin_thold=2.5, num_recs=3, strategy="uc")
+    # query (0, ctx0): rated {0,1} are skipped -> 4 candidates 5,3,4,2 by score 6,5,4,3; top-3 = [5,3,4]; truth {2,4}
+    assert [j for j, _ in tops[(0, 0)]] == [5, 3, 4]
+    # query (0, ctx1): nothing rated in ctx1 -> candidates 0,1,5,3,4,2 (2 scores 3.5): top-3 = [0,1,5]; truth {3}
+    assert [j for j, _ in tops[(0, 1)]] == [0, 1, 5]
+    assert (1, 0) not in tops
+    # Pre@3: 1/3 and 0; Pre@5 uses the same 3-long list with denominator 5
+    assert m["PreN"] == pytest.approx((1 / 3 + 0) / 2, abs=1e-16)
+    assert m["Pre5"] == pytest.approx((1 / 5 + 0) / 2, abs=1e-16)
+    assert m["RecN"] == pytest.approx((1 / 2 + 0) / 2, abs=1e-16)
+    assert m["MRRN"] == pytest.approx((1 / 3 + 0) / 2, abs=1e-16)
+    assert m["MAPN"] == pytest.approx(((1 / 3) / 2 + 0) / 2, abs=1e-16)
+    # AUC (0,ctx0): 4 evaluated items, 1 relevant listed, 1 dropped (item 2, relevant & missing): pairs (4-1)*1 = 3,
+    # correct = 0 (hit comes last) + 1*(1 dropped - 1 missed) = 0 -> 0;  (0,ctx1): no relevant listed -> 0.5
+    assert m["AUCN"] == pytest.approx((0.0 + 0.5) / 2, abs=1e-16)
+    # ucu: both queries belong to user 0 -> same numbers here
+    m2, _ = ro.eval_rankings(predict, train, test, bin_thold=2.5, num_recs=3, strategy="ucu")
+    assert m2["PreN"] == m["PreN"] and m2["AUCN"] == m["AUCN"]
+
+
+def test_eval_rankings_threshold_filters_scores():
+    train, test, predict = _tiny()
+    # scores <= 4.5 are not recommended: (0,ctx0) keeps 5 and 3 only
+    _, tops = ro.eval_rankings(predict, train, test, bin_thold=4.5, num_recs=3, strategy="uc")
+    assert [j for j, _ in tops[(0, 0)]] == [5, 3]
+
+
+def test_eval_rankings_ignore_popular_items():
+    train, test, predict = _tiny()
+    train = train + [(2, 5, 0, 3.0), (2, 5, 1, 3.0)]     # item 5 becomes the most rated
+    _, tops = ro.eval_rankings(predict, train, test, bin_thold=2.5, num_recs=3, strategy="uc", num_ignore=1)
+    assert [j for j, _ in tops[(0, 0)]] == [3, 4, 2]
+    assert [j for j, _ in tops[(0, 1)]] == [0, 1, 3]
+
+
+def test_eval_rankings_rejects_nonpositive_topn():
+    train, test, predict = _tiny()
+    with pytest.raises(ValueError):
+        ro.eval_rankings(predict, train, test, num_recs=0)
