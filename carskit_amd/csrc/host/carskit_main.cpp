@@ -58,8 +58,26 @@ struct Dao {
     }
 };
 
-static std::string evalInfo(const Measures &m) { // Recommender.getEvalInfo, rating branch (incl. the "NAME" typo)
-    char buf[256];
+static std::string evalInfo(const Measures &m, const Conf &conf) { // Recommender.getEvalInfo (Recommender.java:437-499)
+    char buf[1024];
+    if (conf.isRankingPred) { // the reference's separators are irregular; kept as they are
+        const std::string n = std::to_string(conf.numRecs);
+        if (conf.numRecs != 10) {
+            const std::string fmt = "Pre5: %.6f,Pre10: %.6f, Pre" + n + ": %.6f, Rec5: %.6f, Rec10: %.6f, Rec" + n + ": %.6f, " +
+                                    "AUC5: %.6f, AUC10: %.6f, AUC" + n + ": %.6f, MAP5: %.6f, MAP10: %.6f, MAP" + n + ": %.6f, " +
+                                    "NDCG5: %.6f, NDCG10: %.6f,NDCG" + n + ": %.6f,MRR5: %.6f, MRR10: %.6f,MRR" + n + ": %.6f";
+            snprintf(buf, sizeof buf, fmt.c_str(), m.at("Pre5"), m.at("Pre10"), m.at("PreN"), m.at("Rec5"), m.at("Rec10"), m.at("RecN"),
+                     m.at("AUC5"), m.at("AUC10"), m.at("AUCN"), m.at("MAP5"), m.at("MAP10"), m.at("MAPN"), m.at("NDCG5"),
+                     m.at("NDCG10"), m.at("NDCGN"), m.at("MRR5"), m.at("MRR10"), m.at("MRRN"));
+        } else {
+            snprintf(buf, sizeof buf,
+                     "Pre5: %.6f,Pre10: %.6f, Rec5: %.6f, Rec10: %.6f, AUC5: %.6f, AUC10: %.6f, MAP5: %.6f, MAP10: %.6f,"
+                     "NDCG5: %.6f, NDCG10: %.6f,MRR5: %.6f, MRR10: %.6f",
+                     m.at("Pre5"), m.at("Pre10"), m.at("Rec5"), m.at("Rec10"), m.at("AUC5"), m.at("AUC10"), m.at("MAP5"),
+                     m.at("MAP10"), m.at("NDCG5"), m.at("NDCG10"), m.at("MRR5"), m.at("MRR10"));
+        }
+        return buf;
+    }
     snprintf(buf, sizeof buf, "MAE: %.6f, RMSE: %.6f, NAME: %.6f, rMAE: %.6f, rRMSE: %.6f, MPE: %.6f", m.at("MAE"), m.at("RMSE"),
              m.at("NMAE"), m.at("rMAE"), m.at("rRMSE"), m.at("MPE"));
     return buf;
@@ -157,8 +175,11 @@ static int run(const std::string &config, unsigned flags, int iters_override, bo
     Measures avg;
     for (const Measures &m : all)
         for (const auto &kv : m) avg[kv.first] += kv.second / (double)all.size();
-    log("Final Results by " + name + ", " + evalInfo(avg));
-    if (precise) // machine-readable, full precision (for the parity tests)
+    log("Final Results by " + name + ", " + evalInfo(avg, conf));
+    if (precise && conf.isRankingPred)
+        printf("PRECISE %s folds=%zu Pre10=%.17g Rec10=%.17g AUC10=%.17g MAP10=%.17g NDCG10=%.17g MRR10=%.17g\n", name.c_str(),
+               all.size(), avg["Pre10"], avg["Rec10"], avg["AUC10"], avg["MAP10"], avg["NDCG10"], avg["MRR10"]);
+    else if (precise) // machine-readable, full precision (for the parity tests)
         printf("PRECISE %s folds=%zu MAE=%.17g RMSE=%.17g\n", name.c_str(), all.size(), avg["MAE"], avg["RMSE"]);
     return 0;
 }

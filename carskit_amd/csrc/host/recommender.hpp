@@ -140,6 +140,11 @@ struct Conf {
     int64_t randSeed = 1;
     unsigned flags = 0;
     int device = 0;
+    // item.ranking / ratings.setup -threshold / eval.strategy (Recommender.java:211-217,242; CARSKit.java:262)
+    bool isRankingPred = false;
+    int numRecs = 10, numIgnore = -1;
+    double binThold = -1.0;
+    std::string evalStrategy = "ucu";
     Conf() {}
     explicit Conf(const FileConfiger &cf) {
         if (cf.contains("learn.rate")) {
@@ -166,6 +171,16 @@ struct Conf {
             randSeed = ev.getLong("--rand-seed", 1);
         }
         if (cf.contains("output.setup")) verbose = cf.getParamOptions("output.setup").isOn("-verbose", true);
+        if (cf.contains("item.ranking")) {
+            LineConfiger rk = cf.getParamOptions("item.ranking");
+            isRankingPred = rk.isMainOn();
+            numRecs = rk.getInt("-topN", -1);
+            if (numRecs < 0) numRecs = 10;
+            numIgnore = rk.getInt("-ignore", -1);
+            if (rk.contains("-diverse")) throw std::runtime_error("item.ranking -diverse is not on the accelerated path");
+        }
+        if (cf.contains("ratings.setup")) binThold = cf.getParamOptions("ratings.setup").getFloat("-threshold", -1);
+        evalStrategy = lower(cf.getString("eval.strategy", "ucu"));
         if (cf.contains("FM")) {
             LineConfiger fm = cf.getParamOptions("FM");
             regLw = fm.getFloat("-lw", 0);
@@ -281,12 +296,29 @@ class IterativeRecommender {
         return Measures{{"MAE", out[0]}, {"RMSE", out[1]}, {"NMAE", out[2]}, {"rMAE", out[3]}, {"rRMSE", out[4]}, {"MPE", 0.0}};
     }
 
+    virtual Measures evalRankings() { // Recommender.java:668-964
+        static const char *names[CMI_RANK_MEASURES] = {"Pre5", "Pre10", "PreN", "Rec5", "Rec10", "RecN", "AUC5", "AUC10", "AUCN",
+                                                       "MAP5", "MAP10", "MAPN", "NDCG5", "NDCG10", "NDCGN", "MRR5", "MRR10",
+                                                       "MRRN", "D5", "D10", "DN"};
+        double out[CMI_RANK_MEASURES];
+        int64_t nq = 0;
+        check(cmi_eval_rankings(h_, trainMatrix.n(), trainMatrix.u.data(), trainMatrix.j.data(), trainMatrix.ctx.data(),
+                                trainMatrix.r.data(), testMatrix.n(), testMatrix.u.data(), testMatrix.j.data(),
+                                testMatrix.ctx.data(), testMatrix.r.data(), conf_.binThold, conf_.numRecs, conf_.numIgnore,
+                                conf_.evalStrategy == "uc" ? CMI_RANK_UC : CMI_RANK_UCU, out, &nq, nullptr, nullptr, nullptr,
+                                nullptr, nullptr),
+              h_, "cmi_eval_rankings");
+        Measures m;
+        for (int i = 0; i < CMI_RANK_MEASURES; ++i) m[names[i]] = out[i];
+        return m;
+    }
+
     Measures execute() { // Recommender.java:319-366
         auto t0 = std::chrono::steady_clock::now();
         initModel();
         buildModel();
         auto t1 = std::chrono::steady_clock::now();
-        measures = evalRatings();
+        measures = conf_.isRankingPred ? evalRankings() : evalRatings(); // :346
         auto t2 = std::chrono::steady_clock::now();
         measures["TrainTime"] = std::chrono::duration<double, std::milli>(t1 - t0).count();
         measures["TestTime"] = std::chrono::duration<double, std::milli>(t2 - t1).count();
@@ -397,6 +429,9 @@ class FM : public IterativeRecommender {
         fmcheck(cmi_fm_set_model(fm_, w0, w.data(), V.data()), "cmi_fm_set_model");
         fmcheck(cmi_fm_train(fm_, conf_.numIters), "cmi_fm_train");
         fmcheck(cmi_fm_get_model(fm_, &w0, w.data(), V.data()), "cmi_fm_get_model");
+    }
+    Measures evalRankings() override {
+        throw std::runtime_error("item.ranking for FM is not on the accelerated path (rating prediction only)");
     }
     Measures evalRatings() override {
         std::vector<double> pred((size_t)testMatrix.n());

@@ -3,7 +3,7 @@
 load the config, bring the rating file to the binary format (DataTransformer), read it (DataDAO), split
 (`cv -k N` follows the reference's seeded fold assignment; `test-set`; `given-ratio` uses a seeded draw because the
 reference's Math.random() is unseedable), run the recommender per fold, average the measures, print
-`Final Results by <algo>, MAE: ..., RMSE: ...`.  Only rating prediction (item.ranking=off semantics) is covered."""
+`Final Results by <algo>, MAE: ..., RMSE: ...` (or the Pre/Rec/AUC/MAP/NDCG/MRR line when item.ranking=on)."""
 import argparse
 import os
 import sys
@@ -85,7 +85,7 @@ def run(config_path, engine_factory=None, log=print, conf_overrides=None):
     for a in algos:
         for m, v in a.measures.items():
             avg[m] = avg.get(m, 0.0) + v / len(algos)
-    info = "Final Results by %s, %s" % (algos[0].algo_name, get_eval_info(avg))
+    info = "Final Results by %s, %s" % (algos[0].algo_name, get_eval_info(avg, conf))
     log(info)
     return avg, algos, rate_dao
 

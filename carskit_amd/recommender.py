@@ -37,6 +37,8 @@ class Conf:
         self.init_mean, self.init_std = 0.0, 0.1
         self.init_seed = 1
         self.flags = 0
+        # item.ranking / ratings.setup / eval.strategy (Recommender.java:211-217,242; CARSKit.java:262)
+        self.is_ranking, self.num_recs, self.num_ignore, self.bin_thold, self.eval_strategy = False, 10, -1, -1.0, "ucu"
         if cf is not None:
             lc = cf.get_param_options("learn.rate")
             if lc is not None:
@@ -60,6 +62,19 @@ class Conf:
             out = cf.get_param_options("output.setup")
             if out is not None:
                 self.verbose = out.is_on("-verbose", True)
+            rk = cf.get_param_options("item.ranking")
+            if rk is not None:
+                self.is_ranking = rk.is_main_on()
+                self.num_recs = rk.get_int("-topN", -1)
+                if self.num_recs < 0:
+                    self.num_recs = 10
+                self.num_ignore = rk.get_int("-ignore", -1)
+                if rk.contains("-diverse"):
+                    raise ValueError("item.ranking -diverse (item-similarity diversity) is not on the accelerated path")
+            rs = cf.get_param_options("ratings.setup")
+            if rs is not None:
+                self.bin_thold = rs.get_float("-threshold", -1.0)   # a Java float, promoted where it is compared
+            self.eval_strategy = (cf.get_string("eval.strategy") or "ucu").lower()
             fm = cf.get_param_options("FM")
             if fm is not None:
                 self.reg_lw, self.reg_lf = fm.get_float("-lw", 0.0), fm.get_float("-lf", 0.0)
@@ -96,6 +111,9 @@ class GpuEngine:
     def predict(self, u, j, ctx, bound=None):
         return self.inst.predict(u, j, ctx, bound)
 
+    def eval_rankings(self, train, test, bin_thold, num_recs, num_ignore, strategy):
+        return self.inst.eval_rankings(train, test, bin_thold, num_recs, num_ignore, strategy)
+
 
 class Recommender:
     """carskit.generic.Recommender (src/carskit/generic/Recommender.java)."""
@@ -129,6 +147,15 @@ class Recommender:
         res["MPE"] = 0.0                                           # numPEs is never incremented (:569)
         return res
 
+    def evalRankings(self):                                        # Recommender.java:668-964
+        c, tr, te = self.conf, self.trainMatrix, self.testMatrix
+        if c.num_recs < 1:
+            raise ValueError("item.ranking -topN 0 (unbounded lists with a cut-off of 0) is not supported")
+        res = self.engine.eval_rankings((tr.u, tr.j, tr.ctx, tr.r), (te.u, te.j, te.ctx, te.r), c.bin_thold, c.num_recs,
+                                        c.num_ignore, "uc" if c.eval_strategy == "uc" else "ucu")
+        res.pop("n_queries", None)
+        return res
+
     def test_tuples(self):
         t = self.testMatrix
         return t.u, t.j, (t.ctx if self.is_cars else None), t.r
@@ -138,7 +165,7 @@ class Recommender:
         self.initModel()
         self.buildModel()
         t1 = time.time()
-        self.measures = self.evalRatings()
+        self.measures = self.evalRankings() if self.conf.is_ranking else self.evalRatings()   # :346
         t2 = time.time()
         self.measures["TrainTime"] = (t1 - t0) * 1e3
         self.measures["TestTime"] = (t2 - t1) * 1e3
@@ -276,6 +303,9 @@ class FM(ContextRecommender):
         w0, w, V = self.engine.get_model()
         self.state = {"w0": w0, "w": w, "V": V}
 
+    def evalRankings(self):
+        raise NotImplementedError("item.ranking for FM is not on the accelerated path (rating prediction only)")
+
     def evalRatings(self):
         t = self.testMatrix
         pred = self.engine.predict(t.u, t.j, t.ctx, bound=(self.minRate, self.maxRate))
@@ -294,7 +324,21 @@ RECOMMENDERS = {"biasedmf": BiasedMF, "pmf": PMF, "camf_c": CAMF_C, "camf_ci": C
                 "camf_cuci": CAMF_CUCI, "fm": FM}
 
 
-def get_eval_info(ms):
-    """Recommender.getEvalInfo, rating branch (Recommender.java:487-496), incl. its 'NAME' typo for NMAE."""
+def get_eval_info(ms, conf=None):
+    """Recommender.getEvalInfo (Recommender.java:437-499): ranking branch with the reference's exact (irregular)
+    separators, rating branch incl. its 'NAME' typo for NMAE."""
+    if conf is not None and conf.is_ranking:
+        n = conf.num_recs
+        if n != 10:
+            fmt = ("Pre5: %.6f,Pre10: %.6f, Pre{n}: %.6f, Rec5: %.6f, Rec10: %.6f, Rec{n}: %.6f, "
+                   "AUC5: %.6f, AUC10: %.6f, AUC{n}: %.6f, MAP5: %.6f, MAP10: %.6f, MAP{n}: %.6f, "
+                   "NDCG5: %.6f, NDCG10: %.6f,NDCG{n}: %.6f,MRR5: %.6f, MRR10: %.6f,MRR{n}: %.6f").format(n=n)
+            keys = ("Pre5", "Pre10", "PreN", "Rec5", "Rec10", "RecN", "AUC5", "AUC10", "AUCN", "MAP5", "MAP10", "MAPN",
+                    "NDCG5", "NDCG10", "NDCGN", "MRR5", "MRR10", "MRRN")
+        else:
+            fmt = ("Pre5: %.6f,Pre10: %.6f, Rec5: %.6f, Rec10: %.6f, AUC5: %.6f, AUC10: %.6f, MAP5: %.6f, MAP10: %.6f,"
+                   "NDCG5: %.6f, NDCG10: %.6f,MRR5: %.6f, MRR10: %.6f")
+            keys = ("Pre5", "Pre10", "Rec5", "Rec10", "AUC5", "AUC10", "MAP5", "MAP10", "NDCG5", "NDCG10", "MRR5", "MRR10")
+        return fmt % tuple(ms[k] for k in keys)
     return "MAE: %.6f, RMSE: %.6f, NAME: %.6f, rMAE: %.6f, rRMSE: %.6f, MPE: %.6f" % (
         ms["MAE"], ms["RMSE"], ms["NMAE"], ms["rMAE"], ms["rRMSE"], ms.get("MPE", 0.0))

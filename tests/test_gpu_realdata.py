@@ -37,6 +37,24 @@ def test_c1_biasedmf_depaul_on_gpu_matches_golden(tmp_path):
         assert abs(a.measures["RMSE"] - w["RMSE"]) <= 1e-12 and abs(a.measures["MAE"] - w["MAE"]) <= 1e-12
 
 
+def test_item_ranking_depaul_on_gpu_matches_golden(tmp_path):
+    """item.ranking=on through the driver: CAMF_CU trained and ranked on the GPU vs the oracle-minted golden.
+    fp64+strict: bit-identical model -> identical lists -> measures to 1e-12; fp32 default: within 0.02."""
+    from tests.test_host_layer import _ranking_conf
+    conf = _ranking_conf(tmp_path)
+    want = json.load(open(os.path.join(GOLDEN, "golden_depaul_camf_cu_ranking.json")))
+    lines = []
+    _, algos, _ = main.run(conf, log=lines.append, conf_overrides={"num_iters": 20, "flags": capi.FLAG_STATE_F64 | capi.FLAG_STRICT})
+    assert lines[-1].startswith("Final Results by CAMF_CU, Pre5: ")
+    for a, w in zip(algos, want["folds"]):
+        for m, v in w.items():
+            assert abs(a.measures[m] - v) <= 1e-12, (m, a.measures[m], v)
+    _, algos32, _ = main.run(conf, log=lambda *a: None, conf_overrides={"num_iters": 20})
+    for a, w in zip(algos32, want["folds"]):
+        for m, v in w.items():
+            assert abs(a.measures[m] - v) <= 0.02, (m, a.measures[m], v)
+
+
 def frappe_shaped(seed=7):
     """957 users x 4 082 items, 8 context dimensions with Frappe's cardinalities, ~96K ratings."""
     rng = np.random.default_rng(seed)
@@ -101,6 +119,24 @@ def test_cpp_host_driver_c1_matches_oracle(tmp_path):
     assert mc, pc.stdout[-300:] + pc.stderr
     wc = expected_from_oracle(conf, "camf_cu", 10)
     assert abs(float(mc.group(1)) - wc["MAE"]) <= 1e-12 and abs(float(mc.group(2)) - wc["RMSE"]) <= 1e-12
+
+
+def test_cpp_host_driver_item_ranking(tmp_path):
+    """item.ranking=on through the C++ host: fp64/strict numbers equal the oracle's (training + ranking) for the same
+    folds and init stream; the printed line has the reference's layout."""
+    import re
+    import subprocess
+    from tests.test_host_layer import EXE, _ranking_conf, expected_from_oracle
+    conf = _ranking_conf(tmp_path, "camf_ci")
+    flags = capi.FLAG_STATE_F64 | capi.FLAG_STRICT
+    p = subprocess.run([EXE, "-c", conf, "--iters", "10", "--flags", str(flags), "--precise"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    m = re.search(r"PRECISE CAMF_CI folds=5 Pre10=(\S+) Rec10=(\S+) AUC10=(\S+) MAP10=(\S+) NDCG10=(\S+) MRR10=(\S+)", p.stdout)
+    assert m, p.stdout[-500:]
+    want = expected_from_oracle(conf, "camf_ci", 10)
+    for g, name in zip(m.groups(), ("Pre10", "Rec10", "AUC10", "MAP10", "NDCG10", "MRR10")):
+        assert abs(float(g) - want[name]) <= 1e-12, (name, g, want[name])
+    assert ("Final Results by CAMF_CI, Pre5: %.6f,Pre10: %.6f, Rec5: %.6f" % (want["Pre5"], want["Pre10"], want["Rec5"])) in p.stdout
 
 
 def test_cpp_host_driver_parallel_folds_and_fm(tmp_path):

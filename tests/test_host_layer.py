@@ -108,6 +108,44 @@ def test_c1_biasedmf_depaul_via_setting_conf(tmp_path):
     assert rec["folds"] == want["folds"] and rec["avg_RMSE"] == want["avg_RMSE"]
 
 
+def _ranking_conf(tmp_path, algo="camf_cu", topn=10, extra=""):
+    conf = _depaul_conf(tmp_path)
+    txt = open(conf).read().replace("recommender=biasedmf", "recommender=" + algo)
+    txt = txt.replace("item.ranking=off -topN 10", "item.ranking=on -topN %d%s" % (topn, extra))
+    txt = txt.replace("-threshold -1", "-threshold 3")
+    open(conf, "w").write(txt)
+    return conf
+
+
+def test_item_ranking_via_setting_conf(tmp_path):
+    """item.ranking=on: execute() evaluates with evalRankings (Recommender.java:346) and the driver prints the
+    Pre/Rec/AUC/MAP/NDCG/MRR line; golden values minted by the oracle (training + ranking) on DePaulMovie."""
+    lines = []
+    avg, algos, _ = main.run(_ranking_conf(tmp_path), engine_factory=util.OracleEngine, log=lines.append,
+                             conf_overrides={"num_iters": 20})
+    assert lines[-1].startswith("Final Results by CAMF_CU, Pre5: ") and ",Pre10: " in lines[-1] and ",MRR5: " in lines[-1]
+    assert "PreN" not in lines[-1] and "RMSE" not in lines[-1]
+    assert all(a.conf.bin_thold == 3.0 and a.conf.is_ranking for a in algos)
+    assert 0.5 < avg["AUC10"] < 1.0 and 0.0 < avg["Pre10"] < 0.5 and avg["Rec10"] > avg["Rec5"] > 0.0
+    assert avg["PreN"] == avg["Pre10"] and avg["NDCGN"] == avg["NDCG10"]
+    golden = os.path.join(GOLDEN, "golden_depaul_camf_cu_ranking.json")
+    rec = {"iters": 20, "folds": [{m: a.measures[m] for m in ("Pre10", "Rec10", "AUC10", "MAP10", "NDCG10", "MRR10")} for a in algos]}
+    if os.environ.get("CARSKIT_WRITE_GOLDEN"):
+        json.dump(rec, open(golden, "w"), indent=1)
+    assert rec == json.load(open(golden))
+
+
+def test_item_ranking_topn_and_strategy_options(tmp_path):
+    conf = _ranking_conf(tmp_path, "biasedmf", topn=3, extra=" -ignore 5")
+    open(conf, "a").write("\neval.strategy=uc\n")
+    lines = []
+    avg, algos, _ = main.run(conf, engine_factory=util.OracleEngine, log=lines.append, conf_overrides={"num_iters": 5})
+    c = algos[0].conf
+    assert (c.num_recs, c.num_ignore, c.eval_strategy) == (3, 5, "uc")
+    assert ", Pre3: " in lines[-1] and ",NDCG3: " in lines[-1] and ",MRR3: " in lines[-1]
+    assert avg["Pre10"] <= 0.3 + 1e-12          # a 3-long list has at most 3 hits in the Pre@10 numerator
+
+
 def test_driver_rejects_unaccelerated_recommenders(tmp_path):
     conf = _depaul_conf(tmp_path)
     txt = open(conf).read().replace("recommender=biasedmf", "recommender=itemknn")

@@ -77,3 +77,10 @@ class OracleEngine:
 
     def eval_ratings(self, u, j, ctx, r, lo, hi):
         return self.orc.eval_ratings(u, j, ctx, r, lo, hi)
+
+    def eval_rankings(self, train, test, bin_thold, num_recs, num_ignore, strategy):
+        from oracle import rank_oracle
+        tup = lambda t: list(zip(*(np.asarray(a).tolist() for a in t)))
+        res, _ = rank_oracle.eval_rankings(lambda u, j, c: self.orc.predict(u, j, c), tup(train), tup(test), bin_thold,
+                                           num_recs, strategy, num_ignore)
+        return res
