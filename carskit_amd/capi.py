@@ -53,6 +53,7 @@ SYMBOLS = [
     ("cmi_eval_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, C.POINTER(_i64)]),
     ("cmi_eval_rankings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int, C.c_int,
                                     C.c_int, _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
+    ("cmi_last_rank_ms", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_dbl)]),
     ("cmi_java_int_hashset_order", C.c_int, [_i64, _vp, _vp, C.POINTER(_i64)]),
     ("cmi_state_device_ptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(C.c_int)]),
     ("cmi_stream", C.c_int, [_vp, C.POINTER(_vp)]),
@@ -334,6 +335,11 @@ class Instance:
         res = dict(zip(("MAE", "RMSE", "NMAE", "rMAE", "rRMSE"), out.tolist()))
         res["n"] = cnt.value
         return res
+
+    def last_rank_ms(self):
+        ms, fl = C.c_float(), _dbl()
+        self._chk(self.L.cmi_last_rank_ms(self.h, C.byref(ms), C.byref(fl)))
+        return ms.value, fl.value
 
     def eval_rankings(self, train, test, bin_thold=-1.0, num_recs=10, num_ignore=0, strategy="ucu", with_lists=False):
         """Recommender.evalRankings (Recommender.java:668-964).  train/test: (u, j, ctx, r) array tuples.

@@ -117,7 +117,10 @@ int run_device(cmi_instance *h, const std::vector<int32_t> &cand, const std::vec
     const int64_t nq = (int64_t)qu.size();
     const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF;
     const bool ic_used = h->state[CMI_STATE_IC_BIAS] != nullptr;
-    const int kp = h->k + 1 + (ic_used ? h->n_conds : 0);
+    // operand row = [factors | 1 or itemBias | one-hot conditions or icBias row], zero-padded to the GEMM's k step;
+    // row counts rounded up to the 128-row block tile (pad rows are never written back)
+    const int kp = ((h->k + 1 + (ic_used ? h->n_conds : 0)) + 31) / 32 * 32;
+    auto up128 = [](int64_t v) { return (size_t)((v + 127) / 128 * 128); };
     // query batch: keep the score slab around 1 GiB (it is written once and re-read topn times)
     int64_t bq = std::max<int64_t>(64, ((int64_t)1 << 30) / ((int64_t)nc * (int64_t)sizeof(T)));
     bq = std::min<int64_t>(bq, nq);
@@ -131,8 +134,8 @@ int run_device(cmi_instance *h, const std::vector<int32_t> &cand, const std::vec
     auto alloc = [&](void **p, size_t bytes) {
         if (e == hipSuccess) e = hipMalloc(p, std::max<size_t>(bytes, 8));
     };
-    alloc((void **)&dB, (size_t)nc * kp * sizeof(T));
-    alloc((void **)&dA, (size_t)bq * kp * sizeof(T));
+    alloc((void **)&dB, up128(nc) * kp * sizeof(T));
+    alloc((void **)&dA, up128(bq) * kp * sizeof(T));
     alloc((void **)&dS, (size_t)bq * nc * sizeof(T));
     alloc((void **)&drc, (size_t)bq * sizeof(T));
     alloc((void **)&dcand, (size_t)nc * 4);
@@ -158,6 +161,7 @@ int run_device(cmi_instance *h, const std::vector<int32_t> &cand, const std::vec
                             (const T *)h->state[CMI_STATE_IC_BIAS], dcand, dB, nc, h->k, kp, h->n_conds};
         e = rank_launch_build_items<T>(ia, h->stream);
     }
+    if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
     for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += bq) {
         const int n = (int)std::min<int64_t>(bq, nq - q0);
         RankQueryArgs<T> qa{(const T *)h->state[CMI_STATE_P],
@@ -180,6 +184,7 @@ int run_device(cmi_instance *h, const std::vector<int32_t> &cand, const std::vec
             e = rank_launch_score<T>(dA, dB, drc, dS, n, nc, kp, dexptr, dexcl, (int)q0, thold, topn, dtop, dscore, dcount,
                                      h->stream);
     }
+    if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
     top_idx.resize((size_t)nq * topn);
     top_score.resize((size_t)nq * topn);
     top_count.resize((size_t)nq);
@@ -187,6 +192,8 @@ int run_device(cmi_instance *h, const std::vector<int32_t> &cand, const std::vec
     if (e == hipSuccess && nq) e = hipMemcpyAsync(top_score.data(), dscore, (size_t)nq * topn * 8, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess && nq) e = hipMemcpyAsync(top_count.data(), dcount, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipEventElapsedTime(&h->last_rank_ms, h->ev0, h->ev1);
+    h->last_rank_flops = 2.0 * (double)nq * (double)nc * (double)kp;
     void *ptrs[] = {dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -195,6 +202,13 @@ int run_device(cmi_instance *h, const std::vector<int32_t> &cand, const std::vec
 }
 
 } // namespace
+
+extern "C" int cmi_last_rank_ms(cmi_handle h, float *ms, double *flops) {
+    if (!h) return CMI_E_INVALID;
+    if (ms) *ms = h->last_rank_ms;
+    if (flops) *flops = h->last_rank_flops;
+    return CMI_OK;
+}
 
 extern "C" int cmi_java_int_hashset_order(int64_t n, const int32_t *values, int32_t *out, int64_t *n_out) {
     if (n < 0 || (n > 0 && (!values || !out)) || !n_out) return CMI_E_INVALID;

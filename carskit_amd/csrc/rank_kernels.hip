@@ -15,6 +15,7 @@
 // reproduces the reference's stable descending sort over its candidate iteration order).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "rank_kernels.hpp"
 
@@ -26,7 +27,7 @@ template <typename T>
 __global__ void rank_build_items(RankItemsArgs<T> a) { // one block per candidate item, threads over K'
     const int c = blockIdx.x;
     const int j = a.cand[c];
-    T *dst = a.B + (size_t)c * a.kp;
+    T *dst = a.B + (size_t)c * a.kp; // kp = padded row length; columns past k + 1 + n_conds stay zero
     for (int f = threadIdx.x; f < a.kp; f += blockDim.x) {
         T v = 0;
         if (f < a.k) v = a.Q[(size_t)j * a.k + f];
@@ -109,6 +110,96 @@ __global__ __launch_bounds__(256) void rank_gemm(const T *__restrict__ A, const 
     }
 }
 
+// ---- fp32: the same contraction on the f32-input matrix cores ------------------------------------------------------
+// v_mfma_f32_32x32x2_f32: exact f32 (a k-ordered fmaf chain), 64 FLOP/clk/SIMD = the f32 vector peak, reached with one
+// VGPR per operand per lane.  Block = 128 queries x 128 candidates, BK = 32; 4 waves in a 2x2 grid, each owning a
+// 64x64 patch = 2x2 MFMA tiles (64 accumulator VGPRs).  A/B tiles go through LDS k-major ([k][row]) so that the MFMA
+// operand read (lane l: row l&31, k-slot l>>5) is one conflict-light ds_read_b32; the next tile's global loads are in
+// flight while the current one is multiplied (register double-buffer, two LDS buffers, one barrier per BK step).
+// Operands are padded by the builders: kp_pad % 32 == 0 (zero columns), row counts rounded up to 128.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RG_BM = 128, RG_BN = 128, RG_BK = 32, RG_LDS = RG_BM + 2; // +2: spreads the transposing writes over banks
+
+__global__ __launch_bounds__(256) void rank_gemm_mfma_f32(const float *__restrict__ A, const float *__restrict__ B,
+                                                          const float *__restrict__ row_const, float *__restrict__ S,
+                                                          int nq, int nc, int kp_pad, int tiles_c, int n_tiles) {
+    __shared__ float sA[2][RG_BK][RG_LDS];
+    __shared__ float sB[2][RG_BK][RG_LDS];
+    // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give XCD x the x-th contiguous
+    // eighth of the tile list (candidate tiles fastest): its L2 then sees one band of queries and sweeps the items.
+    const int per = (n_tiles + 7) / 8;
+    const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const int q0 = (tile / tiles_c) * RG_BM, c0 = (tile % tiles_c) * RG_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wq = (wave >> 1) * 64, wc = (wave & 1) * 64; // this wave's 64x64 patch inside the block tile
+    const int lrow = tid >> 3, lk = (tid & 7) * 4;         // global->LDS staging: 8 threads cover 32 k of one row
+    const float *Ag = A + (size_t)(q0 + lrow) * kp_pad + lk;
+    const float *Bg = B + (size_t)(c0 + lrow) * kp_pad + lk;
+    f32x4 ra[4], rb[4];
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const f32x4 *>(Ag + (size_t)(32 * i) * kp_pad + k0);
+            rb[i] = *reinterpret_cast<const f32x4 *>(Bg + (size_t)(32 * i) * kp_pad + k0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sA[buf][lk + e][lrow + 32 * i] = ra[i][e];
+                sB[buf][lk + e][lrow + 32 * i] = rb[i][e];
+            }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int nk = kp_pad / RG_BK;
+    const int mrow = lane & 31, mk = lane >> 5;
+    for (int it = 0; it < nk; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nk) gload((it + 1) * RG_BK);
+#pragma unroll
+        for (int kk = 0; kk < RG_BK; kk += 2) {
+            const float a0 = sA[buf][kk + mk][wq + mrow], a1 = sA[buf][kk + mk][wq + 32 + mrow];
+            const float b0 = sB[buf][kk + mk][wc + mrow], b1 = sB[buf][kk + mk][wc + 32 + mrow];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (it + 1 < nk) {
+            lstore(buf ^ 1); // the other buffer was last read one barrier ago
+            __syncthreads();
+        }
+    }
+    // D layout of the 32x32 MFMA: column (B index) = lane & 31, row (A index) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + wq + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * mk;
+            if (q >= nq) continue;
+            const float rc = row_const[q];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = c0 + wc + 32 * j + mrow;
+                if (c < nc) S[(size_t)q * nc + c] = acc[i][j][r] + rc;
+            }
+        }
+}
+
 // ---- exclusions: items the user already rated in this context (never candidates) -----------------------------------
 
 template <typename T>
@@ -162,6 +253,67 @@ __global__ __launch_bounds__(256) void rank_topn(T *S, int nq, int nc, double th
     if (lane == 0) out_count[q_base + q] = found;
 }
 
+// ---- top-N, single pass (topn <= 64): the list lives in the wave's registers, lane r = rank r ------------------------
+// The row is streamed once, 64 x RT_U scores per step.  A score enters only if it beats the current N-th best (or the
+// list is not full), so after the first few steps almost every step is a pure load + compare + ballot; expected
+// insertions per row ~ N ln(n/N).  Scores are consumed in ascending candidate order and an equal score never
+// overtakes an earlier one -> the reference's stable descending sort over its candidate order.
+constexpr int RT_U = 8;
+
+template <typename T>
+__device__ __forceinline__ T lane_bcast(T v, int l) { return __shfl(v, l, 64); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void rank_topn_stream(const T *__restrict__ S, int nq, int nc, double thold, int topn,
+                                                        int32_t *out_idx, double *out_score, int32_t *out_count,
+                                                        int q_base) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const T *row = S + (size_t)q * nc;
+    T lv = -INFINITY; // rank `lane` of the list
+    int li = -1;
+    int count = 0;
+    T t = -INFINITY;  // the N-th best once the list is full
+    for (int base = 0; base < nc; base += 64 * RT_U) {
+        T v[RT_U];
+#pragma unroll
+        for (int u = 0; u < RT_U; ++u) {
+            const int c = base + u * 64 + lane;
+            v[u] = c < nc ? row[c] : (T)-INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < RT_U; ++u) {
+            // `score > threshold`, not NaN (Recommender.java:808-812); masked items are -inf
+            unsigned long long m = __ballot((double)v[u] > thold && v[u] > -INFINITY && (count < topn || v[u] > t));
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const T cv = lane_bcast(v[u], l);
+                if (count == topn && !(cv > t)) continue;
+                const int pos = __popcll(__ballot(lane < count && lv >= cv));
+                const T uv = __shfl_up(lv, 1, 64);
+                const int ui = __shfl_up(li, 1, 64);
+                if (lane > pos) {
+                    lv = uv;
+                    li = ui;
+                }
+                if (lane == pos) {
+                    lv = cv;
+                    li = base + u * 64 + l;
+                }
+                if (count < topn) ++count;
+                if (count == topn) t = lane_bcast(lv, topn - 1);
+            }
+        }
+    }
+    if (lane < count) {
+        out_idx[(size_t)(q_base + q) * topn + lane] = li;
+        out_score[(size_t)(q_base + q) * topn + lane] = (double)lv;
+    }
+    if (lane == 0) out_count[q_base + q] = count;
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------------
 
 template <typename T>
@@ -181,10 +333,25 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
                              const int64_t *excl_ptr, const int32_t *excl_idx, int q_base, double thold, int topn,
                              int32_t *out_idx, double *out_score, int32_t *out_count, hipStream_t s) {
     if (nq <= 0 || nc <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, S, nq, nc, kp);
+    static const bool force_valu = getenv("CMI_RANK_VALU") != nullptr; // A/B experiments only
+    if constexpr (sizeof(T) == 4) {
+        if (!force_valu && kp % RG_BK == 0) {
+            const int tiles_c = (nc + RG_BN - 1) / RG_BN, n_tiles = tiles_c * ((nq + RG_BM - 1) / RG_BM);
+            hipLaunchKernelGGL(rank_gemm_mfma_f32, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, s, (const float *)A,
+                               (const float *)B, (const float *)row_const, (float *)S, nq, nc, kp, tiles_c, n_tiles);
+        } else {
+            hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, S, nq, nc, kp);
+        }
+    } else {
+        hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, S, nq, nc, kp);
+    }
     hipLaunchKernelGGL(rank_mask<T>, dim3(nq), dim3(64), 0, s, S, nc, excl_ptr, excl_idx, q_base, nq);
-    hipLaunchKernelGGL(rank_topn<T>, dim3((nq + 3) / 4), dim3(256), 0, s, S, nq, nc, thold, topn, out_idx, out_score,
-                       out_count, q_base);
+    if (topn <= 64)
+        hipLaunchKernelGGL(rank_topn_stream<T>, dim3((nq + 3) / 4), dim3(256), 0, s, (const T *)S, nq, nc, thold, topn, out_idx,
+                           out_score, out_count, q_base);
+    else // long lists: one extraction pass per rank
+        hipLaunchKernelGGL(rank_topn<T>, dim3((nq + 3) / 4), dim3(256), 0, s, S, nq, nc, thold, topn, out_idx, out_score,
+                           out_count, q_base);
     return hipGetLastError();
 }
 

@@ -174,6 +174,10 @@ int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *tu, const in
                       const double *sr, double bin_thold, int num_recs, int num_ignore, int strategy,
                       double out[CMI_RANK_MEASURES], int64_t *n_queries, int32_t *q_user, int32_t *q_ctx,
                       int32_t *q_count, int32_t *top_items, double *top_scores);
+/* measurement: GPU time (HIP events on cmi_stream()) of the most recent cmi_eval_rankings scoring loop (operand
+ * gather + contraction + mask + top-N over all query batches) and the flops of its contraction
+ * (2 x queries x candidates x padded operand length) */
+int cmi_last_rank_ms(cmi_handle h, float *ms, double *flops);
 /* iteration order of a java.util.HashSet<Integer> after add()ing values[0..n) (the candidate-item order above) */
 int cmi_java_int_hashset_order(int64_t n, const int32_t *values, int32_t *out, int64_t *n_out);
 

@@ -75,6 +75,10 @@ double orc_predict(const orc_problem *p, int32_t u, int32_t j, int32_t ctx) {
     }
 }
 
+void orc_predict_items(const orc_problem *p, int32_t u, int32_t ctx, int32_t n, const int32_t *items, double *out) {
+    for (int32_t i = 0; i < n; ++i) out[i] = orc_predict(p, u, items[i], ctx);
+}
+
 /* ---- one epoch of buildModel() ------------------------------------------------------------ */
 
 double orc_sgd_epoch(const orc_problem *p, double lRate) {

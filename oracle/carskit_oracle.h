@@ -89,6 +89,8 @@ int orc_build_model(const orc_problem *p, orc_schedule *s, int numIters, double 
 
 /* predict(u,j,c) of the model (unbounded) */
 double orc_predict(const orc_problem *p, int32_t u, int32_t j, int32_t ctx);
+/* ranking(u, j, c) for a list of items (Recommender.java:806: one predict() per candidate) */
+void orc_predict_items(const orc_problem *p, int32_t u, int32_t ctx, int32_t n, const int32_t *items, double *out);
 
 /* Recommender.evalRatings numeric part (src/carskit/generic/Recommender.java:504-594).
  * out[0]=MAE out[1]=RMSE out[2]=NMAE out[3]=rMAE out[4]=rRMSE ; returns numCount */

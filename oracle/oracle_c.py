@@ -67,6 +67,8 @@ def lib():
         L.orc_is_converged.argtypes = [C.POINTER(OrcSchedule), C.c_int, C.c_int]
         L.orc_build_model.restype = C.c_int
         L.orc_build_model.argtypes = [C.POINTER(OrcProblem), C.POINTER(OrcSchedule), C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_predict_items.restype = None
+        L.orc_predict_items.argtypes = [C.POINTER(OrcProblem), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.orc_predict.restype = C.c_double
         L.orc_predict.argtypes = [C.POINTER(OrcProblem), C.c_int32, C.c_int32, C.c_int32]
         L.orc_eval_ratings.restype = C.c_int64
@@ -136,6 +138,12 @@ class Oracle:
 
     def predict(self, u, j, ctx):
         return self.L.orc_predict(C.byref(self.p), u, j, ctx)
+
+    def predict_items(self, u, ctx, items):
+        items = np.ascontiguousarray(items, dtype=np.int32)
+        out = np.empty(len(items))
+        self.L.orc_predict_items(C.byref(self.p), u, ctx, len(items), _p(items), _p(out))
+        return out
 
     def eval_ratings(self, tu, tj, tctx, tr, min_rate, max_rate, want_preds=False):
         tu = np.ascontiguousarray(tu, dtype=np.int32)

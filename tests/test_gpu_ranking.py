@@ -80,7 +80,7 @@ def test_f64_rankings_match_oracle(model, strategy):
 
 
 @pytest.mark.parametrize("model", ["CAMF_CI", "CAMF_CUCI", "BiasedMF"])
-@pytest.mark.parametrize("k,num_recs", [(3, 3), (64, 7), (70, 25)])
+@pytest.mark.parametrize("k,num_recs", [(3, 3), (64, 7), (70, 25), (10, 64), (10, 70)])
 def test_f64_rankings_shapes_and_topn(model, k, num_recs):
     train, test, orc, inst = _setup(model, k, F64 | STRICT, epochs=1)
     ref, ref_lists = _oracle_eval(orc, train, test, bin_thold=-1.0, num_recs=num_recs)

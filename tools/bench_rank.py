@@ -1,0 +1,70 @@
+"""Measure cmi_eval_rankings (Recommender.evalRankings, Recommender.java:668-964) on synthetic data: every test
+(user, context) query scores ALL candidate items.  Prints one JSON line: queries/s, the contraction's TFLOP/s against
+the f32 matrix peak (157.3 TF, MI355X_MICROARCH.md), and a bounded CPU-oracle sample for scale."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from carskit_amd import capi, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=50000)
+    ap.add_argument("--items", type=int, default=20000)
+    ap.add_argument("--ratings", type=int, default=2000000)
+    ap.add_argument("--k", type=int, default=128)
+    ap.add_argument("--model", default="CAMF_CI")
+    ap.add_argument("--topn", type=int, default=10)
+    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--cpu-queries", type=int, default=200)
+    a = ap.parse_args()
+    data = synth.generate_fast(a.users, a.items, 4, 6, a.ratings, seed=11)
+    train, test = synth.split(data, 0.2, seed=3)
+    state = synth.init_state(a.model, train, a.k, seed=5)
+    inst = capi.Instance(a.model, a.k, train.n_users, train.n_items, train.n_conds,
+                         flags=a.flags | (capi.FLAG_SCHED_SERIAL if a.model == "CAMF_C" else 0))
+    inst.set_hparams(1e-4, 1e-4, 1e-4, 1e-3, float(train.r.mean()))
+    inst.set_ratings(train.u, train.j, train.ctx, train.r, train.ctx_ptr, train.ctx_conds)
+    inst.set_states(state)
+    tr, te = (train.u, train.j, train.ctx, train.r), (test.u, test.j, test.ctx, test.r)
+    best = None
+    for _ in range(a.reps):
+        t0 = time.time()
+        res = inst.eval_rankings(tr, te, bin_thold=2.5, num_recs=a.topn)
+        wall = time.time() - t0
+        ms, flops = inst.last_rank_ms()
+        if best is None or ms < best[0]:
+            best = (ms, flops, wall)
+    ms, flops, wall = best
+    nq = res["n_queries"]
+    out = {"metric": "evalRankings queries/s", "value": nq / (ms * 1e-3), "unit": "queries/s", "queries": nq,
+           "candidates": int(len(np.unique(train.j))), "k": a.k, "model": a.model, "device_ms": ms, "wall_s": wall,
+           "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": flops / (ms * 1e-3) / 1e12 / 157.3},
+           "dtype": "f64" if a.flags & capi.FLAG_STATE_F64 else "f32", "AUC10": res["AUC10"]}
+    if a.cpu_queries > 0:
+        from oracle import oracle_c, rank_oracle
+        orc = oracle_c.Oracle(a.model, a.k, train.n_users, train.n_items, train.n_conds, train.u, train.j, train.ctx, train.r,
+                              train.ctx_ptr, train.ctx_conds, {n: v.astype(np.float64) for n, v in state.items()},
+                              float(train.r.mean()), 1e-4, 1e-4, 1e-4, 1e-3)
+        cand = np.unique(train.j).astype(np.int32)
+        qs = list(zip(test.u[:a.cpu_queries].tolist(), test.ctx[:a.cpu_queries].tolist()))
+        t0 = time.time()
+        for (u, c) in qs:
+            sc = orc.predict_items(u, c, cand)
+            np.argsort(-sc, kind="stable")[:a.topn]
+        dt = time.time() - t0
+        out["cpu_baseline"] = {"value": len(qs) / dt, "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": "%d queries x %d candidates, C oracle predict() per pair + a stable sort" % (len(qs), len(cand))}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
