@@ -170,19 +170,38 @@ __global__ __launch_bounds__(256) void rank_gemm_mfma_f32(const float *__restric
     for (int it = 0; it < nk; ++it) {
         const int buf = it & 1;
         if (it + 1 < nk) gload((it + 1) * RG_BK);
+        // operand registers are double-buffered by hand: the ds_reads of k-step s+1 are issued before the four
+        // MFMAs of step s (256 cycles of matrix-pipe work), so their latency never stalls the pipe
+        float a0[2], a1[2], b0[2], b1[2];
+        a0[0] = sA[buf][mk][wq + mrow];
+        a1[0] = sA[buf][mk][wq + 32 + mrow];
+        b0[0] = sB[buf][mk][wc + mrow];
+        b1[0] = sB[buf][mk][wc + 32 + mrow];
 #pragma unroll
-        for (int kk = 0; kk < RG_BK; kk += 2) {
-            const float a0 = sA[buf][kk + mk][wq + mrow], a1 = sA[buf][kk + mk][wq + 32 + mrow];
-            const float b0 = sB[buf][kk + mk][wc + mrow], b1 = sB[buf][kk + mk][wc + 32 + mrow];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int st = 0; st < RG_BK / 2; ++st) {
+            const int cur = st & 1, nxt = cur ^ 1;
+            if (st + 1 < RG_BK / 2) {
+                const int kk = 2 * (st + 1) + mk;
+                a0[nxt] = sA[buf][kk][wq + mrow];
+                a1[nxt] = sA[buf][kk][wq + 32 + mrow];
+                b0[nxt] = sB[buf][kk][wc + mrow];
+                b1[nxt] = sB[buf][kk][wc + 32 + mrow];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], b0[cur], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], b1[cur], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], b0[cur], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], b1[cur], acc[1][1], 0, 0, 0);
+            // pin the interleave (the machine scheduler otherwise sinks the reads behind the MFMAs to save 4 VGPRs):
+            // [DS reads of the next step] then [4 MFMA]
+            if (st == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            else if (st + 1 < RG_BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (st == RG_BK / 4 && it + 1 < nk) { // mid-tile: the prefetched next tile goes to the idle LDS buffer
+                lstore(buf ^ 1);
+                __builtin_amdgcn_sched_group_barrier(0x200, 16, 0);
+            }
         }
-        if (it + 1 < nk) {
-            lstore(buf ^ 1); // the other buffer was last read one barrier ago
-            __syncthreads();
-        }
+        if (it + 1 < nk) __syncthreads(); // the other buffer was last read one barrier ago
     }
     // D layout of the 32x32 MFMA: column (B index) = lane & 31, row (A index) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
