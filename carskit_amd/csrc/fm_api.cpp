@@ -19,8 +19,12 @@ struct cmi_fm_instance {
     std::string err;
     hipStream_t stream = nullptr;
     double *d_w0 = nullptr, *d_w = nullptr, *d_V = nullptr;
-    double *d_err = nullptr, *d_Qt = nullptr, *d_r = nullptr, *d_part = nullptr, *d_scratch = nullptr;
-    int32_t *d_u = nullptr, *d_j = nullptr, *d_ctx = nullptr, *d_sup[3] = {};
+    double *d_r = nullptr, *d_part = nullptr, *d_scratch = nullptr;
+    double2 *d_R = nullptr, *d_tab = nullptr;
+    int32_t *d_u = nullptr, *d_j = nullptr, *d_ctx = nullptr, *d_sup[3] = {}, *d_sup_a[3] = {}, *d_sup_b[3] = {};
+    bool pend_j_set = false, pend_c_set = false; // item / context deltas not yet folded into errors[]
+    int col_f = -1;                               // factor whose column is loaded in d_tab[].x
+    int uval_f = -1;                              // factor whose user entries are in d_R[].y
     int64_t *d_off[3] = {};
     int64_t part_count = 0;
     double regLw = 0, regLf = 0;
@@ -46,16 +50,18 @@ static thread_local std::string g_fm_create_err;
 extern "C" const char *cmi_fm_last_error(cmi_fm_handle h) { return h ? h->err.c_str() : g_fm_create_err.c_str(); }
 
 static void fm_free_ratings(cmi_fm_instance *h) {
-    void *ptrs[] = {h->d_err, h->d_Qt, h->d_r, h->d_u, h->d_j, h->d_ctx, h->d_sup[0], h->d_sup[1], h->d_sup[2],
-                    h->d_off[0], h->d_off[1], h->d_off[2]};
+    void *ptrs[] = {h->d_R, h->d_r, h->d_u, h->d_j, h->d_ctx, h->d_sup[1], h->d_sup[2], h->d_sup_a[1], h->d_sup_a[2],
+                    h->d_sup_b[1], h->d_sup_b[2], h->d_off[0], h->d_off[1], h->d_off[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    h->d_err = h->d_Qt = h->d_r = nullptr;
+    h->d_R = nullptr;
+    h->d_r = nullptr;
     h->d_u = h->d_j = h->d_ctx = nullptr;
     for (int f = 0; f < 3; ++f) {
-        h->d_sup[f] = nullptr;
+        h->d_sup[f] = h->d_sup_a[f] = h->d_sup_b[f] = nullptr;
         h->d_off[f] = nullptr;
     }
+    h->pend_j_set = h->pend_c_set = false;
     h->have_ratings = h->initialised = false;
     h->n = 0;
 }
@@ -65,7 +71,7 @@ extern "C" int cmi_fm_destroy(cmi_fm_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     fm_free_ratings(h);
-    void *ptrs[] = {h->d_w0, h->d_w, h->d_V, h->d_part, h->d_scratch};
+    void *ptrs[] = {h->d_w0, h->d_w, h->d_V, h->d_part, h->d_scratch, h->d_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -106,6 +112,8 @@ extern "C" int cmi_fm_create(int k, int n_users, int n_items, int n_conds, int n
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_V, (size_t)h->p * k * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_part, (size_t)h->part_count * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_scratch, 256 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_tab, (size_t)h->p * sizeof(double2));
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_tab, 0, (size_t)h->p * sizeof(double2), h->stream);
     if (e != hipSuccess) {
         g_fm_create_err = std::string("cmi_fm_create: ") + hipGetErrorString(e);
         cmi_fm_destroy(h);
@@ -132,6 +140,7 @@ extern "C" int cmi_fm_set_model(cmi_fm_handle h, double w0, const double *w, con
     FM_HIP(h, hipStreamSynchronize(h->stream));
     h->have_model = true;
     h->initialised = false;
+    h->col_f = -1;
     return CMI_OK;
 }
 
@@ -188,12 +197,22 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
     }
     for (int l = 0; l < h->n_items; ++l) joff[(size_t)l + 1] += joff[(size_t)l];
     for (int l = 0; l < h->n_conds; ++l) coff[(size_t)l + 1] += coff[(size_t)l];
-    std::vector<int32_t> jsup((size_t)n), csup((size_t)coff[(size_t)h->n_conds]);
+    // each entry carries the rating's other two feature ids, so a reduce pass gathers nothing but errors[]
+    const size_t ncs = (size_t)coff[(size_t)h->n_conds];
+    std::vector<int32_t> jsup((size_t)n), jsup_u((size_t)n), jsup_c((size_t)n), csup(ncs), csup_u(ncs), csup_j(ncs);
     {
         std::vector<int64_t> cj(joff.begin(), joff.end() - 1), cc(coff.begin(), coff.end() - 1);
         for (int64_t s = 0; s < n; ++s) {
-            jsup[(size_t)cj[(size_t)sj[(size_t)s]]++] = (int32_t)s;
-            if (sc[(size_t)s] < h->n_conds) csup[(size_t)cc[(size_t)sc[(size_t)s]]++] = (int32_t)s;
+            const size_t pj = (size_t)cj[(size_t)sj[(size_t)s]]++;
+            jsup[pj] = (int32_t)s;
+            jsup_u[pj] = su[(size_t)s];
+            jsup_c[pj] = sc[(size_t)s];
+            if (sc[(size_t)s] < h->n_conds) {
+                const size_t pc = (size_t)cc[(size_t)sc[(size_t)s]]++;
+                csup[pc] = (int32_t)s;
+                csup_u[pc] = su[(size_t)s];
+                csup_j[pc] = sj[(size_t)s];
+            }
         }
     }
     hipError_t e = up(&h->d_u, su, h->stream);
@@ -202,11 +221,14 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
     if (e == hipSuccess) e = up(&h->d_r, sr, h->stream);
     if (e == hipSuccess) e = up(&h->d_sup[1], jsup, h->stream);
     if (e == hipSuccess) e = up(&h->d_sup[2], csup, h->stream);
+    if (e == hipSuccess) e = up(&h->d_sup_a[1], jsup_u, h->stream);
+    if (e == hipSuccess) e = up(&h->d_sup_b[1], jsup_c, h->stream);
+    if (e == hipSuccess) e = up(&h->d_sup_a[2], csup_u, h->stream);
+    if (e == hipSuccess) e = up(&h->d_sup_b[2], csup_j, h->stream);
     if (e == hipSuccess) e = up(&h->d_off[0], uoff, h->stream);
     if (e == hipSuccess) e = up(&h->d_off[1], joff, h->stream);
     if (e == hipSuccess) e = up(&h->d_off[2], coff, h->stream);
-    if (e == hipSuccess && n > 0) e = hipMalloc((void **)&h->d_err, (size_t)n * sizeof(double));
-    if (e == hipSuccess && n > 0) e = hipMalloc((void **)&h->d_Qt, (size_t)n * h->k * sizeof(double));
+    if (e == hipSuccess && n > 0) e = hipMalloc((void **)&h->d_R, (size_t)n * sizeof(double2));
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         fm_free_ratings(h);
@@ -222,15 +244,18 @@ static FmArgs fm_args(cmi_fm_instance *h) {
     a.w0 = h->d_w0;
     a.w = h->d_w;
     a.V = h->d_V;
-    a.err = h->d_err;
-    a.Qt = h->d_Qt;
+    a.R = h->d_R;
+    a.tab = h->d_tab;
+    a.pending = (h->pend_j_set ? 1 : 0) | (h->pend_c_set ? 2 : 0);
     a.u = h->d_u;
     a.j = h->d_j;
     a.ctx = h->d_ctx;
     a.r = h->d_r;
-    a.sup[0] = nullptr;
-    a.sup[1] = h->d_sup[1];
-    a.sup[2] = h->d_sup[2];
+    for (int f = 0; f < 3; ++f) {
+        a.sup[f] = h->d_sup[f];
+        a.sup_a[f] = h->d_sup_a[f];
+        a.sup_b[f] = h->d_sup_b[f];
+    }
     for (int f = 0; f < 3; ++f) a.sup_off[f] = h->d_off[f];
     a.field_count[0] = h->n_users;
     a.field_count[1] = h->n_items;
@@ -259,6 +284,8 @@ static int fm_ready(cmi_fm_instance *h, bool need_init) {
 extern "C" int cmi_fm_init(cmi_fm_handle h) {
     if (!h) return CMI_E_INVALID;
     if (int rc = fm_ready(h, false)) return rc;
+    h->pend_j_set = h->pend_c_set = false;
+    h->col_f = h->uval_f = -1;
     FM_HIP(h, fm_launch_init(fm_args(h), h->stream));
     FM_HIP(h, hipStreamSynchronize(h->stream));
     h->initialised = true;
@@ -283,11 +310,40 @@ static bool phase_decode(cmi_fm_instance *h, int phase, int *field, int *f) {
     return true;
 }
 
+// ---- phase driver: keeps the lazy-error bookkeeping consistent for any call order ---------------------------------
+// Usual order (w0, then per factor: users, items, contexts): the user phase and the w0 phase fold the pending item /
+// context deltas into errors[] on their own sequential pass, so no extra pass is ever launched.
+static int fm_before_phase(cmi_fm_instance *h, int field, int f) {
+    if (f >= 0 && h->col_f != f) {
+        FM_HIP(h, fm_launch_col_load(fm_args(h), f, h->stream));
+        h->col_f = f;
+    }
+    if (f >= 0 && field != 0 && h->uval_f != f) { // only when driven out of order: the user phase of f leaves them there
+        FM_HIP(h, fm_launch_uval(fm_args(h), h->stream));
+        h->uval_f = f;
+    }
+    // an item phase overwrites pend_j and a context phase pend_c: fold first if they still hold deltas
+    if ((field == 1 && (h->pend_j_set || h->pend_c_set)) || (field == 2 && h->pend_c_set)) {
+        FM_HIP(h, fm_launch_flush(fm_args(h), h->stream));
+        h->pend_j_set = h->pend_c_set = false;
+    }
+    return CMI_OK;
+}
+
+static int fm_after_apply(cmi_fm_instance *h, int field, int f = -1) {
+    if (field == 0 && f >= 0) h->uval_f = f;
+    if (field <= 0) h->pend_j_set = h->pend_c_set = false; // w0 (-1) and user (0) passes rewrote errors[] with the deltas folded in
+    else if (field == 1) h->pend_j_set = true;
+    else h->pend_c_set = true;
+    return CMI_OK;
+}
+
 extern "C" int cmi_fm_phase_reduce(cmi_fm_handle h, int phase) {
     if (!h) return CMI_E_INVALID;
     if (int rc = fm_ready(h, true)) return rc;
     int field, f;
     if (!phase_decode(h, phase, &field, &f)) FM_FAIL(h, CMI_E_INVALID, "fm: bad phase %d", phase);
+    if (int rc = fm_before_phase(h, field, f)) return rc;
     const FmArgs a = fm_args(h);
     if (phase == 0) FM_HIP(h, fm_launch_w0_reduce(a, h->d_scratch, h->stream));
     else FM_HIP(h, fm_launch_field(a, field, f, 0, h->stream));
@@ -309,21 +365,25 @@ extern "C" int cmi_fm_phase_apply(cmi_fm_handle h, int phase) {
     if (int rc = fm_ready(h, true)) return rc;
     int field, f;
     if (!phase_decode(h, phase, &field, &f)) FM_FAIL(h, CMI_E_INVALID, "fm: bad phase %d", phase);
+    if (h->last_phase != phase) FM_FAIL(h, CMI_E_INVALID, "fm: phase_apply(%d) without the matching phase_reduce", phase);
     const FmArgs a = fm_args(h);
     if (phase == 0) FM_HIP(h, fm_launch_w0_apply(a, h->stream));
     else FM_HIP(h, fm_launch_field(a, field, f, 1, h->stream));
-    return CMI_OK;
+    return fm_after_apply(h, field, f);
 }
 
 extern "C" int cmi_fm_sweep(cmi_fm_handle h) {
     if (!h) return CMI_E_INVALID;
     if (int rc = fm_ready(h, true)) return rc;
-    const FmArgs a = fm_args(h);
-    FM_HIP(h, fm_launch_w0_reduce(a, h->d_scratch, h->stream));
-    FM_HIP(h, fm_launch_w0_apply(a, h->stream));
-    for (int field = 0; field < 3; ++field) FM_HIP(h, fm_launch_field(a, field, -1, 2, h->stream));
-    for (int f = 0; f < h->k; ++f)
-        for (int field = 0; field < 3; ++field) FM_HIP(h, fm_launch_field(a, field, f, 2, h->stream));
+    FM_HIP(h, fm_launch_w0_reduce(fm_args(h), h->d_scratch, h->stream));
+    FM_HIP(h, fm_launch_w0_apply(fm_args(h), h->stream));
+    fm_after_apply(h, -1);
+    for (int f = -1; f < h->k; ++f)
+        for (int field = 0; field < 3; ++field) {
+            if (int rc = fm_before_phase(h, field, f)) return rc;
+            FM_HIP(h, fm_launch_field(fm_args(h), field, f, 2, h->stream));
+            fm_after_apply(h, field, f);
+        }
     return CMI_OK;
 }
 

@@ -11,13 +11,21 @@
 //   * the coordinates of one FIELD (all users / all items / all context features) have pairwise disjoint
 //     supports, so their sequential updates commute exactly and run in parallel;
 //   * the denominator is sum_{support} h^2 + size*reg.
-// One sweep = 1 (w0) + 3 (w: users, items, contexts) + 3k (V, per factor) phases.  Each phase is a segmented
-// reduction (num, den per coordinate) followed by the coordinate update and the error / Q update on the support.
-// fp64 throughout (the reference's precision); sums are tree-reduced, so results match the sequential Java
-// sums to rounding (tests hold 1e-9).  HBM-bound gather/scatter over errors[] and one Q column: no MFMA.
+// One sweep = 1 (w0) + 3 (w: users, items, contexts) + 3k (V, per factor) phases.
 //
-// Split reduce/apply kernels exist so a multi-GPU host can all-reduce (num, den) between them; the fused
-// kernel is used on a single GPU.
+// HBM traffic is what bounds a sweep, so the per-rating state is kept to ONE fp64 array:
+//   * the reference's cache Q[i][f] = sum_l V[l][f] x_il (FM.java:134-146, 209-210) is not stored (k*size*8 bytes,
+//     re-read and re-written by every factor phase): with three features per rating it is V[u][f] + V[item][f] +
+//     xc*V[ctx][f], gathered from a dense copy of column f (`col`, p doubles: L2/MALL resident).  Same value up to
+//     rounding (the reference accumulates deltas into Q; RMSE holds 1e-9 against the order-exact oracle).
+//   * storage order = sorted by user, so the user field streams errors[] sequentially (wave per user, fused
+//     reduce + apply);
+//   * the item / context fields only GATHER errors[] (their CSR carries the other two feature ids) and leave their
+//     coordinate deltas next to the column entries (tab[].y); the next user phase (or the w0 phase of the next sweep) folds them into
+//     errors[] on its sequential pass.  No random write ever happens.
+// fp64 throughout (the reference's precision); sums are tree-reduced.  Gather/stream work: no MFMA.
+//
+// Split reduce/apply modes exist so a multi-GPU host can all-reduce (num, den) between them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -40,28 +48,66 @@ __device__ __forceinline__ double block_sum(double x, double *lds) {
     return s;
 }
 
-// feature value of field: users/items 1, context 1/numContextDims
-__device__ __forceinline__ double field_x(const FmArgs &a, int field) { return field == 2 ? a.xc : 1.0; }
+// true error of storage position i (pending item / context deltas folded in)
+__device__ __forceinline__ double fm_err(const FmArgs &a, int64_t i, int jj, int c) {
+    double e = a.R[i].x;
+    if (a.pending & 1) e += a.tab[a.n_users + jj].y;
+    if ((a.pending & 2) && c < a.n_conds) e += a.xc * a.tab[(int64_t)a.n_users + a.n_items + c].y;
+    return e;
+}
+
+// supporting rating s of coordinate l of FIELD -> true error et and h = x_il * (sum of the OTHER features' column
+// entries times their values) = x*Q[i][f] - x*x*theta of FM.java:178,198.  One 16-byte gather per table touched:
+// tab[] pairs a coordinate's column entry with its pending delta, R[] pairs a rating's error with its user's entry.
+template <int FIELD>
+__device__ __forceinline__ void fm_row(const FmArgs &a, int f, int64_t l, int64_t s, double x, double &et, double &h) {
+    const int64_t jbase = a.n_users, cbase = (int64_t)a.n_users + a.n_items;
+    double other = 0.0;
+    if (FIELD == 0) {
+        const int jj = a.j[s], c = a.ctx[s];
+        const double2 t = a.tab[jbase + jj];
+        et = a.R[s].x;
+        if (a.pending & 1) et += t.y;
+        other = t.x;
+        if (c < a.n_conds) {
+            const double2 tc = a.tab[cbase + c];
+            if (a.pending & 2) et += a.xc * tc.y;
+            other += a.xc * tc.x;
+        }
+    } else if (FIELD == 1) { // pending deltas are always folded before an item phase
+        const double2 r = a.R[a.sup[1][s]];
+        const int c = a.sup_b[1][s];
+        et = r.x;
+        other = r.y;
+        if (c < a.n_conds) other += a.xc * a.tab[cbase + c].x;
+    } else {
+        const double2 r = a.R[a.sup[2][s]];
+        const double2 t = a.tab[jbase + a.sup_b[2][s]];
+        et = r.x;
+        if (a.pending & 1) et += t.y;
+        other = r.y + t.x;
+    }
+    h = f < 0 ? x : x * other;
+}
 
 // MODE 0: reduce only (writes part[l], part[count+l]); MODE 1: apply only (reads part); MODE 2: fused.
-// f < 0: linear weights w; f >= 0: factor column f of V.
-template <int BLOCK, int MODE>
-__global__ __launch_bounds__(BLOCK) void fm_field_kernel(FmArgs a, int field, int f) {
+// f < 0: linear weights w; f >= 0: factor column f of V (working copy in a.tab[].x).
+// h_i = x_il * (sum of the OTHER features' column entries times their values) = x*Q[i][f] - x*x*theta of FM.java:178,198.
+template <int BLOCK, int MODE, int FIELD>
+__global__ __launch_bounds__(BLOCK) void fm_field_kernel(FmArgs a, int f) {
     __shared__ double lds[BLOCK / 64 + 2];
     const int l = blockIdx.x; // coordinate within the field
-    const int64_t b = a.sup_off[field][l], e = a.sup_off[field][l + 1];
-    const int32_t *sup = a.sup[field];
-    const int64_t base = field == 0 ? 0 : (field == 1 ? a.n_users : (int64_t)a.n_users + a.n_items);
-    double *theta_p = f < 0 ? a.w + base + l : a.V + (size_t)(base + l) * a.k + f;
-    const double theta = *theta_p;
-    const double x = field_x(a, field);
-    double *q = f < 0 ? nullptr : a.Qt + (size_t)f * a.n;
+    const int64_t b = a.sup_off[FIELD][l], e = a.sup_off[FIELD][l + 1];
+    const int64_t ubase = 0, jbase = a.n_users, cbase = (int64_t)a.n_users + a.n_items;
+    const int64_t base = FIELD == 0 ? ubase : (FIELD == 1 ? jbase : cbase);
+    const double theta = f < 0 ? a.w[base + l] : a.tab[base + l].x;
+    const double x = FIELD == 2 ? a.xc : 1.0;
     double num = 0.0, den = 0.0;
     if (MODE != 1) {
         for (int64_t s = b + threadIdx.x; s < e; s += BLOCK) {
-            const int32_t i = sup ? sup[s] : (int32_t)s; // users: the storage order IS sorted by user
-            const double h = f < 0 ? x : x * q[i] - x * x * theta;
-            num += (a.err[i] - theta * h) * h;
+            double et, h;
+            fm_row<FIELD>(a, f, l, s, x, et, h);
+            num += (et - theta * h) * h;
             den += h * h;
         }
         num = block_sum<BLOCK>(num, lds);
@@ -69,24 +115,132 @@ __global__ __launch_bounds__(BLOCK) void fm_field_kernel(FmArgs a, int field, in
         if (MODE == 0) {
             if (threadIdx.x == 0) {
                 a.part[l] = num;
-                a.part[a.field_count[field] + l] = den;
+                a.part[a.field_count[FIELD] + l] = den;
             }
             return;
         }
     } else {
         num = a.part[l];
-        den = a.part[a.field_count[field] + l];
+        den = a.part[a.field_count[FIELD] + l];
     }
     const double reg = f < 0 ? a.regLw : a.regLf;
     const double upd = 0.0 - num / (den + (double)a.global_size * reg);
     const double delta = upd - theta;
-    for (int64_t s = b + threadIdx.x; s < e; s += BLOCK) {
-        const int32_t i = sup ? sup[s] : (int32_t)s;
-        a.err[i] = a.err[i] + delta * x;
-        if (q) q[i] = q[i] + delta * x;
+    if (FIELD == 0) { // the sequential field: errors[] are rewritten here, pending deltas folded in
+        for (int64_t s = b + threadIdx.x; s < e; s += BLOCK)
+            a.R[s] = make_double2(fm_err(a, s, a.j[s], a.ctx[s]) + delta * x, f < 0 ? 0.0 : upd);
+        if (BLOCK > 64) __syncthreads();
     }
-    if (BLOCK > 64) __syncthreads();
-    if (threadIdx.x == 0) *theta_p = upd;
+    if (threadIdx.x == 0) {
+        // errors[i] += delta * x of an item / context coordinate is applied lazily by the next sequential pass
+        if (f < 0) {
+            a.w[base + l] = upd;
+            if (FIELD != 0) a.tab[base + l].y = delta;
+        } else {
+            a.tab[base + l] = make_double2(upd, FIELD == 0 ? 0.0 : delta);
+            a.V[(size_t)(base + l) * a.k + f] = upd;
+        }
+    }
+}
+
+// Short supports (the usual case: a user's or an item's ratings): LANES-wide lane groups, 64/LANES coordinates per
+// wave, up to 4*LANES supporting ratings held in registers -- one pass over the support instead of two, and a quarter
+// of the waves.  A phase over short supports is bound by the per-wave chain of dependent loads (offsets -> ids /
+// errors -> column gathers), not by bytes, so fewer, fuller waves and a shorter chain are what count.  Coordinates
+// with more than 4*LANES ratings take the two-loop path inside the same kernel.
+template <int LANES, int MODE, int FIELD>
+__global__ __launch_bounds__(256) void fm_field_sub(FmArgs a, int f) {
+    constexpr int CH = 4;
+    const int sub = threadIdx.x % LANES;
+    const int64_t l = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LANES; // coordinate within the field
+    const bool live = l < a.field_count[FIELD];
+    const int64_t b = live ? a.sup_off[FIELD][l] : 0, e = live ? a.sup_off[FIELD][l + 1] : 0;
+    const int64_t ubase = 0, jbase = a.n_users, cbase = (int64_t)a.n_users + a.n_items;
+    const int64_t base = FIELD == 0 ? ubase : (FIELD == 1 ? jbase : cbase);
+    const double theta = !live ? 0.0 : (f < 0 ? a.w[base + l] : a.tab[base + l].x);
+    const double x = FIELD == 2 ? a.xc : 1.0;
+    const bool small = (e - b) <= CH * LANES;
+    double et[CH], num = 0.0, den = 0.0;
+    if (MODE != 1) {
+        if (small) {
+#pragma unroll
+            for (int c4 = 0; c4 < CH; ++c4) {
+                const int64_t s = b + c4 * LANES + sub;
+                et[c4] = 0.0;
+                if (s < e) {
+                    double h;
+                    fm_row<FIELD>(a, f, l, s, x, et[c4], h);
+                    num += (et[c4] - theta * h) * h;
+                    den += h * h;
+                }
+            }
+        } else {
+            for (int64_t s = b + sub; s < e; s += LANES) {
+                double e1, h;
+                fm_row<FIELD>(a, f, l, s, x, e1, h);
+                num += (e1 - theta * h) * h;
+                den += h * h;
+            }
+        }
+#pragma unroll
+        for (int m = LANES / 2; m >= 1; m >>= 1) {
+            num += __shfl_xor(num, m, 64);
+            den += __shfl_xor(den, m, 64);
+        }
+        if (MODE == 0) {
+            if (live && sub == 0) {
+                a.part[l] = num;
+                a.part[a.field_count[FIELD] + l] = den;
+            }
+            return;
+        }
+    } else if (live) {
+        num = a.part[l];
+        den = a.part[a.field_count[FIELD] + l];
+    }
+    if (!live) return;
+    const double reg = f < 0 ? a.regLw : a.regLf;
+    const double upd = 0.0 - num / (den + (double)a.global_size * reg);
+    const double delta = upd - theta;
+    if (FIELD == 0) { // the sequential field rewrites errors[] with the pending deltas folded in
+        if (MODE == 2 && small) {
+#pragma unroll
+            for (int c4 = 0; c4 < CH; ++c4) {
+                const int64_t s = b + c4 * LANES + sub;
+                if (s < e) a.R[s] = make_double2(et[c4] + delta * x, f < 0 ? 0.0 : upd);
+            }
+        } else {
+            for (int64_t s = b + sub; s < e; s += LANES)
+                a.R[s] = make_double2(fm_err(a, s, a.j[s], a.ctx[s]) + delta * x, f < 0 ? 0.0 : upd);
+        }
+    }
+    if (sub == 0) {
+        // errors[i] += delta * x of an item / context coordinate is applied lazily by the next sequential pass
+        if (f < 0) {
+            a.w[base + l] = upd;
+            if (FIELD != 0) a.tab[base + l].y = delta;
+        } else {
+            a.tab[base + l] = make_double2(upd, FIELD == 0 ? 0.0 : delta);
+            a.V[(size_t)(base + l) * a.k + f] = upd;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fm_col_load(FmArgs a, int f, int64_t p) {
+    for (int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x; l < p; l += (int64_t)gridDim.x * 256)
+        a.tab[l].x = a.V[(size_t)l * a.k + f]; // .y (a pending delta of the previous factor's phase) is kept
+}
+
+// R[i].y = column entry of the rating's user (only needed when an item / context phase of factor f is driven without
+// the user phase of f right before it)
+__global__ __launch_bounds__(256) void fm_uval_kernel(FmArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) a.R[i].y = a.tab[a.u[i]].x;
+}
+
+// errors[i] += pending deltas (only needed when phases are driven out of the usual order)
+__global__ __launch_bounds__(256) void fm_flush_kernel(FmArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256)
+        a.R[i].x = fm_err(a, i, a.j[i], a.ctx[i]);
 }
 
 // w0 phase, reduce: part[0] = sum(err_i - w0) over the local ratings (fixed two-stage tree)
@@ -96,7 +250,7 @@ __global__ __launch_bounds__(256) void fm_w0_reduce1(FmArgs a, double *scratch) 
     const int64_t b = (int64_t)blockIdx.x * chunk, e = (b + chunk) < a.n ? (b + chunk) : a.n;
     const double w0 = *a.w0;
     double s = 0.0;
-    for (int64_t i = b + threadIdx.x; i < e; i += 256) s += a.err[i] - w0;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) s += fm_err(a, i, a.j[i], a.ctx[i]) - w0;
     s = block_sum<256>(s, lds);
     if (threadIdx.x == 0) scratch[blockIdx.x] = s;
 }
@@ -114,12 +268,12 @@ __global__ __launch_bounds__(256) void fm_w0_apply(FmArgs a) {
     const double w0 = *a.w0;
     const double upd = 0.0 - a.part[0] / ((double)a.global_size + a.regLw);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256)
-        a.err[i] = a.err[i] + upd - w0;
+        a.R[i].x = fm_err(a, i, a.j[i], a.ctx[i]) + upd - w0;
     if (blockIdx.x == 0 && threadIdx.x == 0) a.part[2] = upd; // committed to *w0 by fm_w0_commit after all blocks read w0
 }
 __global__ void fm_w0_commit(FmArgs a) { *a.w0 = a.part[2]; }
 
-// pre-pass (FM.java:117-146): errors[i] = r_i - predict(i), Q[i][f] = sum_l V[l][f] x_il.  One wave per rating.
+// pre-pass (FM.java:117-146): errors[i] = r_i - predict(i) (Q is not materialised, see the header).  One wave per rating.
 __global__ __launch_bounds__(256) void fm_init_kernel(FmArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * 4;
@@ -138,7 +292,6 @@ __global__ __launch_bounds__(256) void fm_init_kernel(FmArgs a) {
                 s1 += d2;
                 s2 += d2 * d2;
             }
-            a.Qt[(size_t)f * a.n + i] = s1;
             pair += s1 * s1 - s2;
         }
 #pragma unroll
@@ -147,7 +300,7 @@ __global__ __launch_bounds__(256) void fm_init_kernel(FmArgs a) {
             double pred = *a.w0 + a.w[u];
             pred += a.w[a.n_users + j];
             if (has_c) pred += a.w[a.n_users + a.n_items + c] * a.xc;
-            a.err[i] = a.r[i] - (pred + 0.5 * pair);
+            a.R[i] = make_double2(a.r[i] - (pred + 0.5 * pair), 0.0);
         }
     }
 }
@@ -187,23 +340,61 @@ __global__ __launch_bounds__(256) void fm_predict_kernel(FmArgs a, int64_t n, co
 
 // ---- launchers ------------------------------------------------------------------------------------------
 
-template <int MODE>
-static hipError_t launch_field_mode(const FmArgs &a, int field, int f, hipStream_t s) {
-    const int count = a.field_count[field];
+template <int MODE, int FIELD>
+static hipError_t launch_field_mode(const FmArgs &a, int f, int64_t avg_support, hipStream_t s) {
+    const int count = a.field_count[FIELD];
     if (count <= 0) return hipSuccess;
-    if (field == 2) // few coordinates with very long supports: a whole 1024-thread workgroup each
-        hipLaunchKernelGGL((fm_field_kernel<1024, MODE>), dim3(count), dim3(1024), 0, s, a, field, f);
+    if (avg_support > 2048) // few coordinates with very long supports: a whole 1024-thread workgroup each
+        hipLaunchKernelGGL((fm_field_kernel<1024, MODE, FIELD>), dim3(count), dim3(1024), 0, s, a, f);
+    else if (avg_support > 192)
+        hipLaunchKernelGGL((fm_field_kernel<256, MODE, FIELD>), dim3(count), dim3(256), 0, s, a, f);
+    else if (avg_support > 48) // 64/LANES coordinates per wave
+        hipLaunchKernelGGL((fm_field_sub<32, MODE, FIELD>), dim3((count + 7) / 8), dim3(256), 0, s, a, f);
     else
-        hipLaunchKernelGGL((fm_field_kernel<64, MODE>), dim3(count), dim3(64), 0, s, a, field, f);
+        hipLaunchKernelGGL((fm_field_sub<16, MODE, FIELD>), dim3((count + 15) / 16), dim3(256), 0, s, a, f);
     return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_field(const FmArgs &a, int field, int f, hipStream_t s) {
+    const int64_t avg = a.field_count[field] > 0 ? a.n / a.field_count[field] : 0; // context supports are a subset: fine
+    switch (field) {
+    case 0: return launch_field_mode<MODE, 0>(a, f, avg, s);
+    case 1: return launch_field_mode<MODE, 1>(a, f, avg, s);
+    default: return launch_field_mode<MODE, 2>(a, f, avg, s);
+    }
 }
 
 hipError_t fm_launch_field(const FmArgs &a, int field, int f, int mode, hipStream_t s) {
     switch (mode) {
-    case 0: return launch_field_mode<0>(a, field, f, s);
-    case 1: return launch_field_mode<1>(a, field, f, s);
-    default: return launch_field_mode<2>(a, field, f, s);
+    case 0: return launch_field<0>(a, field, f, s);
+    case 1: return launch_field<1>(a, field, f, s);
+    default: return launch_field<2>(a, field, f, s);
     }
+}
+
+hipError_t fm_launch_col_load(const FmArgs &a, int f, hipStream_t s) {
+    const int64_t p = (int64_t)a.n_users + a.n_items + a.n_conds;
+    int64_t blocks = (p + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fm_col_load, dim3((unsigned)blocks), dim3(256), 0, s, a, f, p);
+    return hipGetLastError();
+}
+
+hipError_t fm_launch_uval(const FmArgs &a, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    int64_t blocks = (a.n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(fm_uval_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t fm_launch_flush(const FmArgs &a, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    int64_t blocks = (a.n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(fm_flush_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t fm_launch_w0_reduce(const FmArgs &a, double *scratch, hipStream_t s) {

@@ -120,7 +120,11 @@ __global__ __launch_bounds__(256) void rank_gemm(const T *__restrict__ A, const 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RG_BM = 128, RG_BN = 128, RG_BK = 32, RG_LDS = RG_BM + 2; // +2: spreads the transposing writes over banks
+#ifndef CMI_RG_BK
+#define CMI_RG_BK 32
+#endif
+constexpr int RG_BM = 128, RG_BN = 128, RG_BK = CMI_RG_BK, RG_LDS = RG_BM + 2;
+constexpr int RG_TPR = RG_BK / 4, RG_RPP = 256 / RG_TPR, RG_NP = RG_BM / RG_RPP; // staging: threads per row, rows per pass, passes // +2: spreads the transposing writes over banks
 
 __global__ __launch_bounds__(256) void rank_gemm_mfma_f32(const float *__restrict__ A, const float *__restrict__ B,
                                                           const float *__restrict__ row_const, float *__restrict__ S,
@@ -135,10 +139,10 @@ __global__ __launch_bounds__(256) void rank_gemm_mfma_f32(const float *__restric
     const int q0 = (tile / tiles_c) * RG_BM, c0 = (tile % tiles_c) * RG_BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wq = (wave >> 1) * 64, wc = (wave & 1) * 64; // this wave's 64x64 patch inside the block tile
-    const int lrow = tid >> 3, lk = (tid & 7) * 4;         // global->LDS staging: 8 threads cover 32 k of one row
+    const int lrow = tid / RG_TPR, lk = (tid % RG_TPR) * 4; // global->LDS staging: RG_TPR threads cover the BK k of one row
     const float *Ag = A + (size_t)(q0 + lrow) * kp_pad + lk;
     const float *Bg = B + (size_t)(c0 + lrow) * kp_pad + lk;
-    f32x4 ra[4], rb[4];
+    f32x4 ra[RG_NP], rb[RG_NP];
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -148,18 +152,18 @@ __global__ __launch_bounds__(256) void rank_gemm_mfma_f32(const float *__restric
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const f32x4 *>(Ag + (size_t)(32 * i) * kp_pad + k0);
-            rb[i] = *reinterpret_cast<const f32x4 *>(Bg + (size_t)(32 * i) * kp_pad + k0);
+        for (int i = 0; i < RG_NP; ++i) {
+            ra[i] = *reinterpret_cast<const f32x4 *>(Ag + (size_t)(RG_RPP * i) * kp_pad + k0);
+            rb[i] = *reinterpret_cast<const f32x4 *>(Bg + (size_t)(RG_RPP * i) * kp_pad + k0);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RG_NP; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sA[buf][lk + e][lrow + 32 * i] = ra[i][e];
-                sB[buf][lk + e][lrow + 32 * i] = rb[i][e];
+                sA[buf][lk + e][lrow + RG_RPP * i] = ra[i][e];
+                sB[buf][lk + e][lrow + RG_RPP * i] = rb[i][e];
             }
     };
     gload(0);
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void rank_gemm_mfma_f32(const float *__restric
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             if (st == RG_BK / 4 && it + 1 < nk) { // mid-tile: the prefetched next tile goes to the idle LDS buffer
                 lstore(buf ^ 1);
-                __builtin_amdgcn_sched_group_barrier(0x200, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 4 * RG_NP, 0);
             }
         }
         if (it + 1 < nk) __syncthreads(); // the other buffer was last read one barrier ago

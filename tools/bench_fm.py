@@ -34,7 +34,7 @@ def main():
     phases = 4 + 3 * k
     # algorithmic bytes per rating per sweep (SURVEY 8d, fp64 here): (3+3k) passes over errors (8 B r + 8 B w) and, for the
     # 3k factor passes, one Q column entry (8 B r + 8 B w)
-    bytes_per_rating = 16 * (3 + 3 * k) + 16 * 3 * k
+    bytes_per_rating = 16 * (3 + 3 * k) + 16 * 3 * k   # the REFERENCE algorithm's compulsory traffic (errors[] + one Q column entry per phase)
     print("sweep %.1f ms (%d phases, %.1f us/phase): %.1f M rating-sweeps/s, %.0f GB/s algorithmic (fp64) = %.1f%% of 8 TB/s"
           % (dt * 1e3, phases, dt * 1e6 / phases, data.n / dt / 1e6, data.n * bytes_per_rating / dt / 1e9,
              100 * data.n * bytes_per_rating / dt / 8e12))
