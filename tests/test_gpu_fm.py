@@ -107,3 +107,53 @@ def test_fm_sharded_runner_gpu_engine_and_phase_buffer_alias():
     c.synchronize()
     b.sweep()
     assert np.array_equal(b.get_model()[2], c.get_model()[2]) and b.get_model()[0] == c.get_model()[0]
+
+
+def test_fm_phases_in_any_order_match_the_numpy_engine():
+    """The lazy error bookkeeping (item / context deltas folded by the next sequential pass, per-rating user entries
+    left by the user phase) must be invisible: drive reduce+apply phases in an order the sweep never uses and compare
+    with the dense NumPy phase engine after every step."""
+    from tests.fm_np_engine import NumpyFMEngine
+    data = util.small_data(n_users=45, n_items=14, n_dims=2, conds_per_dim=3, n=650, seed=55)
+    k = 3
+    w0, w, V = fm_init_model(data.n_users, data.n_items, data.n_conds, k, 2)
+    _, g = make_fm(data, k, 2)
+    g.init()
+    ref = NumpyFMEngine(k, data.n_users, data.n_items, data.n_conds, data.n_dims, data.u, data.j, data.ctx, data.r,
+                        w0, w, V, REGLW, REGLF, data.n)
+    order = [2, 3, 2, 5, 6, 5, 9, 3, 0, 8, 4, 12, 11, 10, 6, 6, 1, 0]
+    assert max(order) < g.num_phases()
+    for ph in order:
+        g.phase_reduce(ph)
+        ref.phase_reduce(ph)
+        g.phase_apply(ph)
+        ref.phase_apply(ph)
+        gw0, gw, gV = g.get_model()
+        np.testing.assert_allclose(gw0, ref.w0, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gw, ref.w, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gV, ref.V, rtol=1e-9, atol=1e-12)
+    g.sweep()
+    for ph in range(ref.num_phases()):
+        ref.phase_reduce(ph)
+        ref.phase_apply(ph)
+    np.testing.assert_allclose(g.get_model()[2], ref.V, rtol=1e-8, atol=1e-11)
+    p = g.predict(data.u, data.j, data.ctx)
+    assert np.all(np.isfinite(p))
+
+
+@pytest.mark.parametrize("n_users,n_items,n,zipf", [(3, 40, 1500, None), (1, 30, 900, None), (400, 2, 1200, None),
+                                                     (300, 25, 3000, 1.3), (2, 2, 60, None)])
+def test_fm_support_length_paths(n_users, n_items, n, zipf):
+    """Every kernel path by support length: 16/32-lane groups with the in-register and the two-loop variant (hot
+    coordinates), 256- and 1024-thread workgroups per coordinate (few users or items with very long supports)."""
+    data = util.small_data(n_users=n_users, n_items=n_items, n_dims=3, conds_per_dim=4, n=n, seed=56, item_zipf=zipf)
+    orc, g = make_fm(data, 5, 6)
+    orc.init()
+    g.init()
+    for _ in range(2):
+        orc.sweep()
+        g.sweep()
+    w0, w, V = g.get_model()
+    np.testing.assert_allclose(w0, orc.w0, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(w, orc.w, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(V, orc.V.reshape(V.shape), rtol=1e-8, atol=1e-11)
