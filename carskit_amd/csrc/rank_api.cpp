@@ -106,6 +106,26 @@ struct NanMean { // happy.coding.math.Stats.mean(Collection): NaN entries are sk
     double value() const { return c ? s / (double)c : std::nan(""); }
 };
 
+// tuple indices `sel` ordered by (user, context, item): counting sort by user, then each user's short run is sorted
+// (O(n) instead of one comparison sort over millions of tuples)
+std::vector<int64_t> order_by_user_ctx_item(int n_users, const std::vector<int64_t> &sel, const int32_t *u, const int32_t *c,
+                                            const int32_t *j) {
+    std::vector<int64_t> off((size_t)n_users + 1, 0), out(sel.size());
+    for (int64_t t : sel) off[(size_t)u[t] + 1]++;
+    for (int l = 0; l < n_users; ++l) off[(size_t)l + 1] += off[(size_t)l];
+    {
+        std::vector<int64_t> cur(off.begin(), off.end() - 1);
+        for (int64_t t : sel) out[(size_t)cur[(size_t)u[t]]++] = t;
+    }
+    for (int l = 0; l < n_users; ++l)
+        if (off[(size_t)l + 1] - off[(size_t)l] > 1)
+            std::sort(out.begin() + off[(size_t)l], out.begin() + off[(size_t)l + 1], [&](int64_t a, int64_t b) {
+                if (c[a] != c[b]) return c[a] < c[b];
+                return j[a] < j[b];
+            });
+    return out;
+}
+
 constexpr int N_MEAS = 18; // Pre,Rec,AUC,MAP,NDCG,MRR x {5,10,N}
 
 template <typename T>
@@ -288,11 +308,7 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
     std::vector<int64_t> pos;
     for (int64_t t = 0; t < n_test; ++t)
         if (sr[t] != 0.0 && sr[t] > bin_thold) pos.push_back(t);
-    std::sort(pos.begin(), pos.end(), [&](int64_t a, int64_t b) {
-        if (su[a] != su[b]) return su[a] < su[b];
-        if (sctx[a] != sctx[b]) return sctx[a] < sctx[b];
-        return sj[a] < sj[b];
-    });
+    pos = order_by_user_ctx_item(h->n_users, pos, su, sctx, sj);
     std::vector<int32_t> qu, qc, truth_items;
     std::vector<int64_t> truth_ptr{0};
     for (size_t i = 0; i < pos.size();) {
@@ -316,11 +332,7 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
     std::vector<int64_t> tord;
     for (int64_t t = 0; t < n_train; ++t)
         if (!(tr && tr[t] == 0.0)) tord.push_back(t);
-    std::sort(tord.begin(), tord.end(), [&](int64_t a, int64_t b) {
-        if (tu[a] != tu[b]) return tu[a] < tu[b];
-        if (tctx[a] != tctx[b]) return tctx[a] < tctx[b];
-        return tj[a] < tj[b];
-    });
+    tord = order_by_user_ctx_item(h->n_users, tord, tu, tctx, tj);
     std::vector<int64_t> excl_ptr{0};
     std::vector<int32_t> excl_idx;
     {
