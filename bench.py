@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tuples", type=int, default=20_000_000)
     ap.add_argument("--flags", type=int, default=0, help="extra cmi_create flags (e.g. 16 = no hipGraph)")
+    ap.add_argument("--k", type=int, default=0, help="experiment knob: override the workload's num.factors")
+    ap.add_argument("--model", default="", help="experiment knob: override the workload's recommender")
     ap.add_argument("--folds", type=int, default=1,
                     help="independent recommender instances per GPU trained concurrently (the reference's `cv -p on`: "
                          "one thread per fold), each on its own stream; value then aggregates all of them")
@@ -106,6 +108,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     model, k, n_users, n_items, n_dims, cpd, n_ratings = WORKLOADS[args.workload]
+    if args.k > 0:
+        k = args.k
+    if args.model:
+        model = args.model
     t0 = time.perf_counter()
     # every rank owns its own users (seeded by rank); items and contexts are the shared, replicated side
     data = synth.generate_fast(n_users, n_items, n_dims, cpd, n_ratings, seed=synth.DEFAULT_SEED + 1000 * rank)

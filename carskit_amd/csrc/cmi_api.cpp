@@ -291,6 +291,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     h->dmax = dmax;
     LaunchCfg cfg{h->model, h->strict};
     h->fast = !h->serial && has_fast_path(h->k, dmax, h->f64, cfg);
+    h->small = !h->serial && !h->fast && has_small_path(h->k, dmax, h->f64, cfg);
 
     // schedule
     LevelSchedule sch;
@@ -354,7 +355,10 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         h->slot_off.assign((size_t)n_levels + 1, 0);
         for (int64_t l = 0; l < n_levels; ++l) {
             const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
-            int blocks = h->serial ? 0 : (h->fast ? level_blocks_f32_fast(h->k, cnt) : level_blocks_generic(cnt));
+            int blocks = h->serial ? 0
+                         : h->fast ? level_blocks_f32_fast(h->k, cnt)
+                         : h->small ? level_blocks_small(h->k, dmax, cnt)
+                                    : level_blocks_generic(cnt);
             if (h->two_lane) { // head and tail are separate launches with their own workgroup numbering
                 const int head = (int)(h->split_off[(size_t)l] - h->level_off[(size_t)l]);
                 blocks = level_blocks_f32_fast(h->k, head) + level_blocks_f32_fast(h->k, cnt - head);
@@ -491,8 +495,9 @@ static hipError_t enqueue_levels(cmi_instance *h) {
         for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l) {
             const int64_t b = h->level_off[(size_t)l];
             const int cnt = (int)(h->level_off[(size_t)l + 1] - b);
-            e = h->fast ? launch_level_fast_f32(a, cfg, b, cnt, h->slot_off[(size_t)l], h->stream)
-                        : launch_level_generic<float>(a, cfg, b, cnt, h->slot_off[(size_t)l], h->stream);
+            e = h->fast    ? launch_level_fast_f32(a, cfg, b, cnt, h->slot_off[(size_t)l], h->stream)
+                : h->small ? launch_level_small_f32(a, cfg, b, cnt, h->slot_off[(size_t)l], h->stream)
+                           : launch_level_generic<float>(a, cfg, b, cnt, h->slot_off[(size_t)l], h->stream);
         }
     }
     if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);

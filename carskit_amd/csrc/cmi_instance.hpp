@@ -13,7 +13,7 @@
 struct cmi_instance {
     int model = 0, k = 0, n_users = 0, n_items = 0, n_conds = 0, device = 0;
     unsigned flags = 0;
-    bool f64 = false, serial = false, strict = false, use_graph = true, fast = false, want_flow = false, flow = false,
+    bool f64 = false, serial = false, strict = false, use_graph = true, fast = false, small = false, want_flow = false, flow = false,
          want_two_lane = false, two_lane = false;
     std::vector<int64_t> split_off; // two-lane schedule: first tail position of every level
     std::string err;

@@ -219,6 +219,155 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
 // ---------------------------------------------------------------------------------------------
 // dataflow path: one persistent launch per epoch, levels overlap (fp32 state, K = 64*VPL)
 // ---------------------------------------------------------------------------------------------
+// small-k fast path (fp32 state, any k <= 64 that is not 64: the reference's default num.factors is 10)
+// ---------------------------------------------------------------------------------------------
+// LPT lanes per tuple (4, 8 or 16 -> 16, 8 or 4 tuples per wave64), lane l owns factors l, l+LPT, l+2*LPT, l+3*LPT
+// (scalar loads: rows of k floats are not 16-byte aligned for general k) and the tuple's l-th condition, so
+// LPT >= dmax and 4*LPT >= k.  Same arithmetic as sgd_level_fast_f32; the group sums run on DPP quad permutes and
+// row (half-)mirrors.  With the generic kernel a k=10 epoch of the C3 shape cost 1.8x the k=128 one (a whole wave per
+// tuple, 10 of 64 lanes busy); this one moves the same few bytes with 16 tuples per wave.
+template <int LPT>
+__device__ __forceinline__ float group_sum(float x) {
+    x += dpp_f32<0xB1>(x); // quad_perm [1,0,3,2]
+    x += dpp_f32<0x4E>(x); // quad_perm [2,3,0,1]
+    if (LPT >= 8) x += dpp_f32<0x141>(x);  // row_half_mirror: lane i <- lane 7-i of its half row (the other quad's total)
+    if (LPT >= 16) x += dpp_f32<0x140>(x); // row_mirror: lane i <- lane 15-i (the other half's total)
+    return x;
+}
+
+template <int MODEL, int LPT, int TPG>
+__global__ __launch_bounds__(256) void sgd_level_small_f32(SgdArgs<float> a, int64_t begin, int count, int64_t slot0) {
+    using M = Traits<MODEL>;
+    static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
+    constexpr int GPB = 256 / LPT; // groups per workgroup
+    constexpr int VPL = 4;
+    __shared__ double s_loss[GPB];
+    const int tid = threadIdx.x;
+    const int lt = tid % LPT;
+    const int gib = tid / LPT;
+    const int g0 = blockIdx.x * (GPB * TPG) + gib; // tuple i of this group: g0 + GPB*i
+    const int k = a.k;
+    double gloss = 0.0;
+    const HParams hp = *a.hp;
+    const float lr = (float)hp.lr, regU = (float)hp.regU, regI = (float)hp.regI, regB = (float)hp.regB,
+                regC = (float)hp.regC, gm = (float)hp.gm;
+
+    bool live[TPG];
+    int uu[TPG], jj[TPG], cond[TPG];
+    float rr[TPG];
+#pragma unroll
+    for (int i = 0; i < TPG; ++i) {
+        const int g = g0 + GPB * i;
+        live[i] = g < count;
+        uu[i] = jj[i] = 0;
+        rr[i] = 0.f;
+        cond[i] = -1;
+        if (live[i]) {
+            const int64_t t = begin + g;
+            uu[i] = a.su[t];
+            jj[i] = a.sj[t];
+            rr[i] = a.sr[t];
+            if (Traits<MODEL>::has_ctx && lt < a.dmax) cond[i] = a.sconds[t * a.dmax + lt];
+        }
+    }
+    float *prow[TPG], *qrow[TPG];
+    float p[TPG][VPL], q[TPG][VPL];
+    float bu[TPG], bj[TPG], bic[TPG], buc[TPG];
+    float *pic[TPG], *puc[TPG];
+#pragma unroll
+    for (int i = 0; i < TPG; ++i) {
+        prow[i] = a.P + (size_t)uu[i] * k + lt;
+        qrow[i] = a.Q + (size_t)jj[i] * k + lt;
+        bu[i] = bj[i] = bic[i] = buc[i] = 0.f;
+        pic[i] = puc[i] = nullptr;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) p[i][v] = q[i][v] = 0.f;
+        if (live[i]) {
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+                if (lt + v * LPT < k) {
+                    p[i][v] = prow[i][v * LPT];
+                    q[i][v] = qrow[i][v * LPT];
+                }
+            if (M::has_bu) bu[i] = a.userBias[uu[i]];
+            if (M::has_bj) bj[i] = a.itemBias[jj[i]];
+            if (cond[i] >= 0) {
+                if (M::has_ic) {
+                    pic[i] = a.icBias + (size_t)jj[i] * a.n_conds + cond[i];
+                    bic[i] = *pic[i];
+                }
+                if (M::has_uc) {
+                    puc[i] = a.ucBias + (size_t)uu[i] * a.n_conds + cond[i];
+                    buc[i] = *puc[i];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TPG; ++i) {
+        if (!live[i]) continue; // group-uniform
+        float part = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) part += p[i][v] * q[i][v];
+        const float dot = group_sum<LPT>(part);
+        float pred = gm;
+        if (M::has_bu) pred += bu[i];
+        if (M::has_bj) pred += bj[i];
+        pred += dot;
+        if (Traits<MODEL>::has_ctx) {
+            float term = 0.f; // lane d carries the deviation of the tuple's d-th condition
+            if (M::has_ic && M::has_uc) term = bic[i] + buc[i];
+            else if (M::has_ic) term = bic[i];
+            else if (M::has_uc) term = buc[i];
+            pred += group_sum<LPT>(term);
+        }
+        const float e = rr[i] - pred;
+        if (lt == 0) {
+            if (M::has_bu) a.userBias[uu[i]] = bu[i] + lr * (e - regB * bu[i]);
+            if (M::has_bj) a.itemBias[jj[i]] = bj[i] + lr * (e - regB * bj[i]);
+        }
+        float ctx_loss = 0.f;
+        if (cond[i] >= 0) {
+            if (M::has_ic) {
+                *pic[i] = bic[i] + lr * (e - regC * bic[i]);
+                ctx_loss += bic[i] * bic[i];
+            }
+            if (M::has_uc) {
+                *puc[i] = buc[i] + lr * (e - regC * buc[i]);
+                ctx_loss += buc[i] * buc[i];
+            }
+        }
+        float lsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+            if (lt + v * LPT < k) {
+                const float pv = p[i][v], qv = q[i][v];
+                prow[i][v * LPT] = pv + lr * (e * qv - regU * pv);
+                qrow[i][v * LPT] = qv + lr * (e * pv - regI * qv);
+                lsum += (regU * pv) * pv + (regI * qv) * qv;
+            }
+        const float reg_loss = group_sum<LPT>(lsum);
+        const float ctx_sum = (Traits<MODEL>::has_ctx) ? group_sum<LPT>(ctx_loss) : 0.f;
+        if (lt == 0) {
+            double l = (double)e * (double)e;
+            if (M::has_bu) l += (double)regB * bu[i] * bu[i];
+            if (M::has_bj) l += (double)regB * bj[i] * bj[i];
+            if (Traits<MODEL>::has_ctx) l += (double)regC * ctx_sum;
+            gloss += l + (double)reg_loss;
+        }
+    }
+    if (lt == 0) s_loss[gib] = gloss;
+    __syncthreads();
+    if (tid < 64) { // fixed-shape tree over the GPB group sums
+        double s = 0.0;
+        for (int g = tid; g < GPB; g += 64) s += s_loss[g];
+        s = wave_sum64(s);
+        if (tid == 0) a.loss_part[slot0 + blockIdx.x] = s;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 //
 // Same arithmetic and lane layout as sgd_level_fast_f32, but instead of a kernel boundary after every
 // dependency level each tuple waits for exactly its own two predecessors: ver_u[u] / ver_j[j] count the
@@ -1005,6 +1154,45 @@ bool has_fast_path(int k, int dmax, bool f64, const LaunchCfg &cfg) {
     if (!(k == 64 || k == 128 || k == 256)) return false;
     if (dmax > 16) return false;
     return true;
+}
+
+// small-k path: lanes per tuple
+int small_lpt(int k, int dmax) {
+    if (k <= 16 && dmax <= 4) return 4;
+    if (k <= 32 && dmax <= 8) return 8;
+    return 16;
+}
+bool has_small_path(int k, int dmax, bool f64, const LaunchCfg &cfg) {
+    if (f64 || cfg.strict || cfg.model == CAMF_C) return false;
+    if (getenv("CMI_NO_SMALL_K")) return false; // A/B experiments
+    return k < 64 && dmax <= 16;
+}
+constexpr int SMALL_TPG = 2;
+int level_blocks_small(int k, int dmax, int count) {
+    const int per = (256 / small_lpt(k, dmax)) * SMALL_TPG;
+    return (count + per - 1) / per;
+}
+template <int MODEL>
+static hipError_t launch_small_model(const SgdArgs<float> &a, int64_t begin, int count, int64_t slot0, hipStream_t s) {
+    const dim3 grid(level_blocks_small(a.k, a.dmax, count)), block(256);
+    switch (small_lpt(a.k, a.dmax)) {
+    case 4: hipLaunchKernelGGL((sgd_level_small_f32<MODEL, 4, SMALL_TPG>), grid, block, 0, s, a, begin, count, slot0); break;
+    case 8: hipLaunchKernelGGL((sgd_level_small_f32<MODEL, 8, SMALL_TPG>), grid, block, 0, s, a, begin, count, slot0); break;
+    default: hipLaunchKernelGGL((sgd_level_small_f32<MODEL, 16, SMALL_TPG>), grid, block, 0, s, a, begin, count, slot0); break;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_level_small_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count, int64_t slot0,
+                                  hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    switch (cfg.model) {
+    case BIASEDMF: return launch_small_model<BIASEDMF>(a, begin, count, slot0, s);
+    case PMF: return launch_small_model<PMF>(a, begin, count, slot0, s);
+    case CAMF_CI: return launch_small_model<CAMF_CI>(a, begin, count, slot0, s);
+    case CAMF_CU: return launch_small_model<CAMF_CU>(a, begin, count, slot0, s);
+    case CAMF_CUCI: return launch_small_model<CAMF_CUCI>(a, begin, count, slot0, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int MODEL, int TPG>

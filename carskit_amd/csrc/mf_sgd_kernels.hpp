@@ -39,6 +39,11 @@ struct LaunchCfg {
 int level_blocks_f32_fast(int k, int count);
 int level_blocks_generic(int count);
 bool has_fast_path(int k, int dmax, bool f64, const LaunchCfg &cfg);
+// small-k fast path (fp32 state, k < 64): 4 / 8 / 16 lanes per tuple
+bool has_small_path(int k, int dmax, bool f64, const LaunchCfg &cfg);
+int level_blocks_small(int k, int dmax, int count);
+hipError_t launch_level_small_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count, int64_t slot0,
+                                  hipStream_t s);
 
 // one dependency level: tuples [begin, begin+count) of the schedule run concurrently
 hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,

@@ -115,6 +115,28 @@ def test_level_f32_rmse_within_1e5(model, k):
     assert abs(ot["RMSE"] - gt["RMSE"]) <= 1e-5
 
 
+@pytest.mark.parametrize("model", ["CAMF_CI", "CAMF_CUCI", "BiasedMF"])
+@pytest.mark.parametrize("k,n_dims", [(1, 1), (3, 2), (10, 4), (16, 4), (17, 3), (20, 6), (32, 8), (33, 2), (50, 5), (63, 12), (10, 16)])
+def test_small_k_path_f32(model, k, n_dims):
+    """k < 64 (the reference's default is 10): the 4 / 8 / 16-lanes-per-tuple kernels, every lane-count variant and
+    ragged k.  Same bars as the k = 64/128/256 path: bold-driver decisions identical, loss 2e-5, RMSE/MAE 1e-5."""
+    data = util.small_data(n_users=1500, n_items=300, n_dims=n_dims, conds_per_dim=3, n=30000, seed=27)
+    train, test = synth.split(data, 0.2)
+    orc, inst = make_pair(model, train, k, 0)
+    assert inst.schedule_info()["levels"] > 1
+    o_losses, o_lrs, _ = orc.build_model(12, util.LR, bold_driver=True)
+    g_losses, g_lrs = inst.train(12, util.LR, bold_driver=True)
+    assert g_lrs.tolist() == o_lrs.tolist()
+    np.testing.assert_allclose(g_losses, o_losses, rtol=2e-5)
+    tctx = None if model in util.TWO_D else test.ctx
+    oe = orc.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+    ge = inst.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+    assert abs(oe["RMSE"] - ge["RMSE"]) <= 1e-5 and abs(oe["MAE"] - ge["MAE"]) <= 1e-5
+    for name, a in inst.get_states().items():
+        ref = orc.state[name].reshape(a.shape)
+        assert np.max(np.abs(ref - a)) <= 2e-4, name
+
+
 def test_camf_c_serial_f32():
     """CAMF_C (config C2 shape: k=64, fp32): condBias is shared by every tuple, so only the serial
     schedule is order-exact."""
