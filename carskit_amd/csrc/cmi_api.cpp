@@ -300,7 +300,8 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     h->flow_blocks = 0;
     const bool tables_fit_raw_buffer = (int64_t)h->n_users * h->k * 4 < ((int64_t)1 << 32) &&
                                        (int64_t)h->n_items * h->k * 4 < ((int64_t)1 << 32);
-    if (h->want_flow && h->fast && n > 0 && tables_fit_raw_buffer) {
+    const bool exact_k = h->k == 64 || h->k == 128 || h->k == 256; // the experimental schedules only exist for these
+    if (h->want_flow && h->fast && exact_k && n > 0 && tables_fit_raw_buffer) {
         h->flow_blocks = flow_grid_blocks(h->device, h->k);
         if (h->flow_blocks > 0) {
             if (!build_flow_schedule(n, u, j, h->n_users, h->n_items, fsch))
@@ -320,7 +321,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (h->serial) {
             sch.level_off = {0, n};
             sch.max_level = n;
-        } else if (h->fast && h->use_graph && h->want_two_lane && n > 0) {
+        } else if (h->fast && exact_k && h->use_graph && h->want_two_lane && n > 0) {
             SplitSchedule ss;
             if (!build_split_schedule(n, u, j, h->n_users, h->n_items, ss))
                 CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: schedule construction failed");

@@ -72,12 +72,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // TPG = tuples each 16-lane group processes CONCURRENTLY (all their loads are issued before the first use):
 // more bytes in flight per wave and 1/TPG as many workgroups to dispatch per level.
-template <int MODEL, int VPL, int TPG>
+template <int MODEL, int VPL, int TPG, bool RAGGED = false>
 __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int64_t begin, int count,
                                                           int64_t slot0) {
     using M = Traits<MODEL>;
     static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
-    constexpr int K = 64 * VPL;
+    // RAGGED: any k with k % 4 == 0 and 64*(VPL-1) < k <= 64*VPL (rows stay 16-byte aligned); float4 slots past k are masked
+    const int K = RAGGED ? a.k : 64 * VPL;
     __shared__ double s_loss[16];
     const int tid = threadIdx.x;
     const int l16 = tid & 15;
@@ -116,9 +117,15 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
         pic[i] = puc[i] = nullptr;
         if (live[i]) {
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) p[i][v] = prow[i][v * 16];
+            for (int v = 0; v < VPL; ++v) {
+                p[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!RAGGED || 4 * l16 + 64 * v < K) p[i][v] = prow[i][v * 16];
+            }
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) q[i][v] = qrow[i][v * 16];
+            for (int v = 0; v < VPL; ++v) {
+                q[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!RAGGED || 4 * l16 + 64 * v < K) q[i][v] = qrow[i][v * 16];
+            }
             if (M::has_bu) bu[i] = a.userBias[uu[i]];
             if (M::has_bj) bj[i] = a.itemBias[jj[i]];
             if (cond[i] >= 0) {
@@ -191,8 +198,10 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
     lsum += (regU * p[i][v].c) * p[i][v].c + (regI * q[i][v].c) * q[i][v].c;
             CMI_UPD(x) CMI_UPD(y) CMI_UPD(z) CMI_UPD(w)
 #undef CMI_UPD
-            prow[i][v * 16] = pn;
-            qrow[i][v * 16] = qn;
+            if (!RAGGED || 4 * l16 + 64 * v < K) {
+                prow[i][v * 16] = pn;
+                qrow[i][v * 16] = qn;
+            }
         }
 
         const float reg_loss = row_sum16(lsum);
@@ -1151,7 +1160,7 @@ int level_blocks_generic(int count) { return (count + 3) / 4; }
 
 bool has_fast_path(int k, int dmax, bool f64, const LaunchCfg &cfg) {
     if (f64 || cfg.strict) return false;
-    if (!(k == 64 || k == 128 || k == 256)) return false;
+    if (k < 64 || k > 256 || k % 4 != 0) return false; // k = 64/128/256: exact kernels; other multiples of 4: masked float4 slots
     if (dmax > 16) return false;
     return true;
 }
@@ -1203,7 +1212,11 @@ static hipError_t launch_fast_model_tpg(const SgdArgs<float> &a, int64_t begin, 
     case 64: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 1, TPG>), grid, block, 0, s, a, begin, count, slot0); break;
     case 128: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 2, TPG>), grid, block, 0, s, a, begin, count, slot0); break;
     case 256: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 4, TPG>), grid, block, 0, s, a, begin, count, slot0); break;
-    default: return hipErrorInvalidValue;
+    default: // ragged k (multiple of 4)
+        if (a.k < 128) hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 2, TPG, true>), grid, block, 0, s, a, begin, count, slot0);
+        else if (a.k < 192) hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 3, TPG, true>), grid, block, 0, s, a, begin, count, slot0);
+        else hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 4, TPG, true>), grid, block, 0, s, a, begin, count, slot0);
+        break;
     }
     return hipGetLastError();
 }
@@ -1224,6 +1237,11 @@ static void *fast_kernel_ptr(int k) {
     case 64: return (void *)sgd_level_fast_f32<MODEL, 1, TPG>;
     case 128: return (void *)sgd_level_fast_f32<MODEL, 2, TPG>;
     case 256: return (void *)sgd_level_fast_f32<MODEL, 4, TPG>;
+    }
+    if (k > 64 && k < 256 && k % 4 == 0) {
+        if (k < 128) return (void *)sgd_level_fast_f32<MODEL, 2, TPG, true>;
+        if (k < 192) return (void *)sgd_level_fast_f32<MODEL, 3, TPG, true>;
+        return (void *)sgd_level_fast_f32<MODEL, 4, TPG, true>;
     }
     return nullptr;
 }

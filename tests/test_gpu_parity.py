@@ -116,10 +116,11 @@ def test_level_f32_rmse_within_1e5(model, k):
 
 
 @pytest.mark.parametrize("model", ["CAMF_CI", "CAMF_CUCI", "BiasedMF"])
-@pytest.mark.parametrize("k,n_dims", [(1, 1), (3, 2), (10, 4), (16, 4), (17, 3), (20, 6), (32, 8), (33, 2), (50, 5), (63, 12), (10, 16)])
+@pytest.mark.parametrize("k,n_dims", [(1, 1), (3, 2), (10, 4), (16, 4), (17, 3), (20, 6), (32, 8), (33, 2), (50, 5), (63, 12), (10, 16),
+                                      (68, 3), (100, 4), (124, 2), (132, 4), (188, 3), (192, 2), (200, 4), (252, 5)])
 def test_small_k_path_f32(model, k, n_dims):
     """k < 64 (the reference's default is 10): the 4 / 8 / 16-lanes-per-tuple kernels, every lane-count variant and
-    ragged k.  Same bars as the k = 64/128/256 path: bold-driver decisions identical, loss 2e-5, RMSE/MAE 1e-5."""
+    ragged k; 64 < k < 256 with k % 4 == 0: the float4 kernel with masked slots.  Same bars as the k = 64/128/256 path: bold-driver decisions identical, loss 2e-5, RMSE/MAE 1e-5."""
     data = util.small_data(n_users=1500, n_items=300, n_dims=n_dims, conds_per_dim=3, n=30000, seed=27)
     train, test = synth.split(data, 0.2)
     orc, inst = make_pair(model, train, k, 0)
