@@ -66,13 +66,36 @@ struct Traits {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Device-coherent 16-byte row traffic through raw buffer instructions with cache policy sc0|sc1 (aux 17):
+// compiler-tracked (its own s_waitcnt), unlike inline-asm loads whose destination registers the allocator may
+// copy before a hand-placed wait.  A raw buffer addresses base + 32-bit byte offset: the table must be < 4 GiB
+// (checked on the host; larger models use the level schedule).
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+#define CMI_CPOL_SC0_SC1 17
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ld_row_coherent(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, CMI_CPOL_SC0_SC1));
+}
+__device__ __forceinline__ void st_row_coherent(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)byte_off, 0, CMI_CPOL_SC0_SC1);
+}
+__device__ __forceinline__ float ld_f32_coherent(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_f32_coherent(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // fast path: fp32 state, K = 64*VPL, 16 lanes per tuple
 // ---------------------------------------------------------------------------------------------
 
 // TPG = tuples each 16-lane group processes CONCURRENTLY (all their loads are issued before the first use):
 // more bytes in flight per wave and 1/TPG as many workgroups to dispatch per level.
-template <int MODEL, int VPL, int TPG, bool RAGGED = false>
+template <int MODEL, int VPL, int TPG, bool RAGGED = false, bool COH = false>
 __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int64_t begin, int count,
                                                           int64_t slot0) {
     using M = Traits<MODEL>;
@@ -105,6 +128,9 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
         }
     }
 
+    // COH (experiment CMI_LEVEL_COHERENT=1): all model traffic device-coherent (sc0 sc1: write-through stores, L2-bypassing
+    // loads), so a launch leaves no dirty lines in the XCD L2s for the end-of-kernel write-back
+    const __amdgpu_buffer_rsrc_t rsP = table_rsrc(a.P), rsQ = table_rsrc(a.Q);
     float4 *prow[TPG], *qrow[TPG];
     float4 p[TPG][VPL], q[TPG][VPL];
     float bu[TPG], bj[TPG], bic[TPG], buc[TPG];
@@ -119,23 +145,37 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
                 p[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!RAGGED || 4 * l16 + 64 * v < K) p[i][v] = prow[i][v * 16];
+                if (!RAGGED || 4 * l16 + 64 * v < K) {
+                    if (COH) {
+                        const f32x4 t = ld_row_coherent(rsP, (uint32_t)(((size_t)uu[i] * K + 4 * l16 + 64 * v) * 4));
+                        p[i][v] = make_float4(t.x, t.y, t.z, t.w);
+                    } else {
+                        p[i][v] = prow[i][v * 16];
+                    }
+                }
             }
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
                 q[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!RAGGED || 4 * l16 + 64 * v < K) q[i][v] = qrow[i][v * 16];
+                if (!RAGGED || 4 * l16 + 64 * v < K) {
+                    if (COH) {
+                        const f32x4 t = ld_row_coherent(rsQ, (uint32_t)(((size_t)jj[i] * K + 4 * l16 + 64 * v) * 4));
+                        q[i][v] = make_float4(t.x, t.y, t.z, t.w);
+                    } else {
+                        q[i][v] = qrow[i][v * 16];
+                    }
+                }
             }
-            if (M::has_bu) bu[i] = a.userBias[uu[i]];
-            if (M::has_bj) bj[i] = a.itemBias[jj[i]];
+            if (M::has_bu) bu[i] = COH ? ld_f32_coherent(a.userBias + uu[i]) : a.userBias[uu[i]];
+            if (M::has_bj) bj[i] = COH ? ld_f32_coherent(a.itemBias + jj[i]) : a.itemBias[jj[i]];
             if (cond[i] >= 0) {
                 if (M::has_ic) {
                     pic[i] = a.icBias + (size_t)jj[i] * a.n_conds + cond[i];
-                    bic[i] = *pic[i];
+                    bic[i] = COH ? ld_f32_coherent(pic[i]) : *pic[i];
                 }
                 if (M::has_uc) {
                     puc[i] = a.ucBias + (size_t)uu[i] * a.n_conds + cond[i];
-                    buc[i] = *puc[i];
+                    buc[i] = COH ? ld_f32_coherent(puc[i]) : *puc[i];
                 }
             }
         }
@@ -173,17 +213,24 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
 
         // scalar biases: lane 0 of the group owns the store
         if (l16 == 0) {
-            if (M::has_bu) a.userBias[uu[i]] = bu[i] + lr * (e - regB * bu[i]);
-            if (M::has_bj) a.itemBias[jj[i]] = bj[i] + lr * (e - regB * bj[i]);
+            if (COH) {
+                if (M::has_bu) st_f32_coherent(a.userBias + uu[i], bu[i] + lr * (e - regB * bu[i]));
+                if (M::has_bj) st_f32_coherent(a.itemBias + jj[i], bj[i] + lr * (e - regB * bj[i]));
+            } else {
+                if (M::has_bu) a.userBias[uu[i]] = bu[i] + lr * (e - regB * bu[i]);
+                if (M::has_bj) a.itemBias[jj[i]] = bj[i] + lr * (e - regB * bj[i]);
+            }
         }
         float ctx_loss = 0.f;
         if (cond[i] >= 0) {
             if (M::has_ic) {
-                *pic[i] = bic[i] + lr * (e - regC * bic[i]);
+                if (COH) st_f32_coherent(pic[i], bic[i] + lr * (e - regC * bic[i]));
+                else *pic[i] = bic[i] + lr * (e - regC * bic[i]);
                 ctx_loss += bic[i] * bic[i];
             }
             if (M::has_uc) {
-                *puc[i] = buc[i] + lr * (e - regC * buc[i]);
+                if (COH) st_f32_coherent(puc[i], buc[i] + lr * (e - regC * buc[i]));
+                else *puc[i] = buc[i] + lr * (e - regC * buc[i]);
                 ctx_loss += buc[i] * buc[i];
             }
         }
@@ -199,8 +246,16 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
             CMI_UPD(x) CMI_UPD(y) CMI_UPD(z) CMI_UPD(w)
 #undef CMI_UPD
             if (!RAGGED || 4 * l16 + 64 * v < K) {
-                prow[i][v * 16] = pn;
-                qrow[i][v * 16] = qn;
+                if (COH) {
+                    f32x4 tp, tq;
+                    tp.x = pn.x, tp.y = pn.y, tp.z = pn.z, tp.w = pn.w;
+                    tq.x = qn.x, tq.y = qn.y, tq.z = qn.z, tq.w = qn.w;
+                    st_row_coherent(rsP, (uint32_t)(((size_t)uu[i] * K + 4 * l16 + 64 * v) * 4), tp);
+                    st_row_coherent(rsQ, (uint32_t)(((size_t)jj[i] * K + 4 * l16 + 64 * v) * 4), tq);
+                } else {
+                    prow[i][v * 16] = pn;
+                    qrow[i][v * 16] = qn;
+                }
             }
         }
 
@@ -390,28 +445,6 @@ __global__ __launch_bounds__(256) void sgd_level_small_f32(SgdArgs<float> a, int
 // The tuple stream itself is read-only and uses plain loads.  Waves never synchronise with each other
 // (no __syncthreads): a wave owns 4 tuples of one level per step and accumulates its loss in registers.
 // Every spin is bounded; on overflow the kernel raises *error and carries on (the host reports it).
-
-// Device-coherent 16-byte row traffic through raw buffer instructions with cache policy sc0|sc1 (aux 17):
-// compiler-tracked (its own s_waitcnt), unlike inline-asm loads whose destination registers the allocator may
-// copy before a hand-placed wait.  A raw buffer addresses base + 32-bit byte offset: the table must be < 4 GiB
-// (checked on the host; larger models use the level schedule).
-typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
-#define CMI_CPOL_SC0_SC1 17
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void *base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffff, 0x00020000);
-}
-__device__ __forceinline__ f32x4 ld_row_coherent(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, CMI_CPOL_SC0_SC1));
-}
-__device__ __forceinline__ void st_row_coherent(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)byte_off, 0, CMI_CPOL_SC0_SC1);
-}
-__device__ __forceinline__ float ld_f32_coherent(const float *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_f32_coherent(float *p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 #define CMI_FLOW_SPIN_LIMIT (1u << 22)
 
@@ -1145,6 +1178,10 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs<T> a, int64_t n) {
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 
+static bool level_coherent() { // experiment: device-coherent model traffic in the level kernel (k = 128, tables < 4 GiB)
+    static const bool on = getenv("CMI_LEVEL_COHERENT") != nullptr;
+    return on;
+}
 static int g_fast_tpg = -1;
 static int fast_tpg() { // tuples per 16-lane group (CMI_LEVEL_TPG overrides for experiments)
     if (g_fast_tpg < 0) {
@@ -1210,7 +1247,10 @@ static hipError_t launch_fast_model_tpg(const SgdArgs<float> &a, int64_t begin, 
     const dim3 grid((count + 16 * TPG - 1) / (16 * TPG)), block(256);
     switch (a.k) {
     case 64: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 1, TPG>), grid, block, 0, s, a, begin, count, slot0); break;
-    case 128: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 2, TPG>), grid, block, 0, s, a, begin, count, slot0); break;
+    case 128:
+        if (level_coherent()) hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 2, TPG, false, true>), grid, block, 0, s, a, begin, count, slot0);
+        else hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 2, TPG>), grid, block, 0, s, a, begin, count, slot0);
+        break;
     case 256: hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 4, TPG>), grid, block, 0, s, a, begin, count, slot0); break;
     default: // ragged k (multiple of 4)
         if (a.k < 128) hipLaunchKernelGGL((sgd_level_fast_f32<MODEL, 2, TPG, true>), grid, block, 0, s, a, begin, count, slot0);
@@ -1235,7 +1275,7 @@ template <int MODEL, int TPG>
 static void *fast_kernel_ptr(int k) {
     switch (k) {
     case 64: return (void *)sgd_level_fast_f32<MODEL, 1, TPG>;
-    case 128: return (void *)sgd_level_fast_f32<MODEL, 2, TPG>;
+    case 128: return level_coherent() ? (void *)sgd_level_fast_f32<MODEL, 2, TPG, false, true> : (void *)sgd_level_fast_f32<MODEL, 2, TPG>;
     case 256: return (void *)sgd_level_fast_f32<MODEL, 4, TPG>;
     }
     if (k > 64 && k < 256 && k % 4 == 0) {
