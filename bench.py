@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="extra cmi_create flags (e.g. 16 = no hipGraph)")
     ap.add_argument("--k", type=int, default=0, help="experiment knob: override the workload's num.factors")
     ap.add_argument("--model", default="", help="experiment knob: override the workload's recommender")
+    ap.add_argument("--item-zipf", type=float, default=0.0,
+                    help="stress knob (SURVEY 8d): draw items from Zipf(a) instead of uniformly (slow generator; use with --workload small)")
     ap.add_argument("--folds", type=int, default=1,
                     help="independent recommender instances per GPU trained concurrently (the reference's `cv -p on`: "
                          "one thread per fold), each on its own stream; value then aggregates all of them")
@@ -114,7 +116,11 @@ def main():
         model = args.model
     t0 = time.perf_counter()
     # every rank owns its own users (seeded by rank); items and contexts are the shared, replicated side
-    data = synth.generate_fast(n_users, n_items, n_dims, cpd, n_ratings, seed=synth.DEFAULT_SEED + 1000 * rank)
+    if args.item_zipf > 0:
+        data = synth.generate(n_users, n_items, n_dims, cpd, n_ratings, seed=synth.DEFAULT_SEED + 1000 * rank,
+                              item_zipf=args.item_zipf)
+    else:
+        data = synth.generate_fast(n_users, n_items, n_dims, cpd, n_ratings, seed=synth.DEFAULT_SEED + 1000 * rank)
     log("rank %d: generated %d tuples (%d users, %d items, %d contexts) in %.1fs"
         % (rank, data.n, data.n_users, data.n_items, data.n_ctx, time.perf_counter() - t0))
     regs = (synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-3))

@@ -65,12 +65,15 @@ static void free_ratings(cmi_instance *h) {
         h->graph_exec = nullptr;
     }
     void *ptrs[] = {h->d_su, h->d_sj, h->d_sconds, h->d_ctx_ptr, h->d_ctx_conds, h->d_sr, h->d_loss_part,
-                    h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err};
+                    h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->d_tail_off};
     for (void *p : ptrs)
         if (p) hipFree(p);
     h->d_su = h->d_sj = h->d_sconds = h->d_ctx_ptr = h->d_ctx_conds = nullptr;
     h->d_seq_u = h->d_seq_j = h->d_ver_u = h->d_ver_j = nullptr;
     h->d_flow_err = nullptr;
+    h->d_tail_off = nullptr;
+    h->n_launches = h->n_tail = 0;
+    h->tail_len.clear();
     h->flow = false;
     h->d_sr = nullptr;
     h->d_loss_part = nullptr;
@@ -353,6 +356,26 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         h->max_level = sch.max_level;
         const int64_t n_levels = (int64_t)h->level_off.size() - 1;
         h->sched_levels = n_levels;
+        // narrow runs (heavy-tailed degrees): every maximal run of >= TAIL_MIN_LEVELS consecutive levels with <= TAIL_MAX
+        // tuples each is walked by ONE single-workgroup launch instead of one launch per level
+        h->tail_len.assign((size_t)n_levels, 0);
+        h->n_launches = 0;
+        if (!h->serial && !h->two_lane && !getenv("CMI_NO_TAIL")) {
+            constexpr int64_t TAIL_MAX = 256, TAIL_MIN_LEVELS = 16;
+            for (int64_t l = 0; l < n_levels;) {
+                int64_t e2 = l;
+                while (e2 < n_levels && e2 - l < ((int64_t)1 << 30) &&
+                       h->level_off[(size_t)e2 + 1] - h->level_off[(size_t)e2] <= TAIL_MAX)
+                    ++e2;
+                if (e2 - l >= TAIL_MIN_LEVELS) {
+                    h->tail_len[(size_t)l] = (int32_t)(e2 - l);
+                    for (int64_t q = l + 1; q < e2; ++q) h->tail_len[(size_t)q] = -1;
+                    l = e2;
+                } else {
+                    l = e2 > l ? e2 : l + 1;
+                }
+            }
+        }
         h->slot_off.assign((size_t)n_levels + 1, 0);
         for (int64_t l = 0; l < n_levels; ++l) {
             const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
@@ -364,9 +387,15 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
                 const int head = (int)(h->split_off[(size_t)l] - h->level_off[(size_t)l]);
                 blocks = level_blocks_f32_fast(h->k, head) + level_blocks_f32_fast(h->k, cnt - head);
             }
+            if (h->tail_len[(size_t)l] > 0) blocks = 1;       // a narrow run owns one loss slot ...
+            else if (h->tail_len[(size_t)l] < 0) blocks = 0;  // ... at its first level
+            if (h->tail_len[(size_t)l] >= 0) ++h->n_launches;
             h->slot_off[(size_t)l + 1] = h->slot_off[(size_t)l] + blocks;
         }
         h->n_slots = h->slot_off[(size_t)n_levels];
+        h->n_tail = 0;
+        for (int32_t t : h->tail_len)
+            if (t > 0) h->n_tail += t;
     }
 
     // tuple stream in schedule order, conditions pre-expanded to [n x dmax] (-1 padded) so the kernels
@@ -417,6 +446,12 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // cp/cc are locals
     }
     if (e == hipSuccess && h->n_slots > 0) e = hipMalloc((void **)&h->d_loss_part, (size_t)h->n_slots * sizeof(double));
+    if (e == hipSuccess && h->n_tail > 0) { // the tail launches read their level offsets from the device
+        e = hipMalloc((void **)&h->d_tail_off, h->level_off.size() * sizeof(int64_t));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(h->d_tail_off, h->level_off.data(), h->level_off.size() * sizeof(int64_t), hipMemcpyHostToDevice,
+                               h->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         free_ratings(h);
@@ -431,7 +466,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
 extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[8]) {
     if (!h || !info) return CMI_E_INVALID;
     if (!h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "schedule_info: call cmi_set_ratings first");
-    info[0] = h->sched_levels;
+    info[0] = h->n_tail > 0 ? h->n_launches : h->sched_levels; // launches: a narrow run of levels shares one
     info[1] = h->max_level;
     info[2] = h->n;
     info[3] = h->dmax;
@@ -487,13 +522,26 @@ static hipError_t enqueue_levels(cmi_instance *h) {
     }
     if (h->f64) {
         const SgdArgs<double> a = make_args<double>(h);
-        for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l)
+        for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l) {
+            const int32_t run = h->tail_len.empty() ? 0 : h->tail_len[(size_t)l];
+            if (run > 0) {
+                e = launch_tail<double>(a, cfg, h->d_tail_off + l, run, h->slot_off[(size_t)l], h->stream);
+                l += run - 1;
+                continue;
+            }
             e = launch_level_generic<double>(a, cfg, h->level_off[(size_t)l],
                                              (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]),
                                              h->slot_off[(size_t)l], h->stream);
+        }
     } else {
         const SgdArgs<float> a = make_args<float>(h);
         for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l) {
+            const int32_t run = h->tail_len.empty() ? 0 : h->tail_len[(size_t)l];
+            if (run > 0) {
+                e = launch_tail_f32(a, cfg, h->fast ? 1 : (h->small ? 2 : 0), h->d_tail_off + l, run, h->slot_off[(size_t)l], h->stream);
+                l += run - 1;
+                continue;
+            }
             const int64_t b = h->level_off[(size_t)l];
             const int cnt = (int)(h->level_off[(size_t)l + 1] - b);
             e = h->fast    ? launch_level_fast_f32(a, cfg, b, cnt, h->slot_off[(size_t)l], h->stream)
@@ -515,7 +563,8 @@ static int enqueue_epoch(cmi_instance *h, double lrate) {
         h->epoch_timed = false;
         return CMI_OK;
     }
-    const bool graph = h->use_graph && !h->serial && !h->flow;
+    // a graph of several hundred thousand kernel nodes is neither instantiable in reasonable time nor useful
+    const bool graph = h->use_graph && !h->serial && !h->flow && (h->n_tail > 0 ? h->n_launches : (int64_t)h->level_off.size() - 1) <= 65536;
     if (graph && !h->graph_exec && h->two_lane) {
         // explicit DAG: head(l) <- head(l-1), tail(l-2) ; tail(l) <- tail(l-1), head(l-1)
         hipGraph_t g = nullptr;

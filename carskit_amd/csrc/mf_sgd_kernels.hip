@@ -95,18 +95,16 @@ __device__ __forceinline__ void st_f32_coherent(float *p, float v) {
 
 // TPG = tuples each 16-lane group processes CONCURRENTLY (all their loads are issued before the first use):
 // more bytes in flight per wave and 1/TPG as many workgroups to dispatch per level.
-template <int MODEL, int VPL, int TPG, bool RAGGED = false, bool COH = false>
-__global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int64_t begin, int count,
-                                                          int64_t slot0) {
+// The update of TPG tuples by one 16-lane group: tuples g0, g0 + GS, ... of the level [begin, begin + count).
+// Returns the group's loss contribution (valid in lane 0 of the group).  GS = groups that work side by side (16 per
+// 256-thread workgroup of a level launch; 64 in the single 1024-thread workgroup of a narrow-run launch), so that
+// neighbouring groups read neighbouring tuples of the stream.
+template <int MODEL, int VPL, int TPG, bool RAGGED, bool COH, int GS>
+__device__ __forceinline__ double fast_tuples_f32(const SgdArgs<float> &a, int64_t begin, int count, int g0, int l16) {
     using M = Traits<MODEL>;
     static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
     // RAGGED: any k with k % 4 == 0 and 64*(VPL-1) < k <= 64*VPL (rows stay 16-byte aligned); float4 slots past k are masked
     const int K = RAGGED ? a.k : 64 * VPL;
-    __shared__ double s_loss[16];
-    const int tid = threadIdx.x;
-    const int l16 = tid & 15;
-    const int gib = tid >> 4;
-    const int g0 = blockIdx.x * (16 * TPG) + gib; // tuple i of this group: g0 + 16*i (keeps the stream loads coalesced)
     double gloss = 0.0;
 
     bool live[TPG];
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
     float rr[TPG];
 #pragma unroll
     for (int i = 0; i < TPG; ++i) {
-        const int g = g0 + 16 * i;
+        const int g = g0 + GS * i;
         live[i] = g < count;
         uu[i] = jj[i] = 0;
         rr[i] = 0.f;
@@ -270,6 +268,18 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
         }
     }
 
+    return gloss;
+}
+
+template <int MODEL, int VPL, int TPG, bool RAGGED = false, bool COH = false>
+__global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int64_t begin, int count,
+                                                          int64_t slot0) {
+    __shared__ double s_loss[16];
+    const int tid = threadIdx.x;
+    const int l16 = tid & 15;
+    const int gib = tid >> 4;
+    // tuple i of this group: g0 + 16*i (keeps the stream loads coalesced)
+    const double gloss = fast_tuples_f32<MODEL, VPL, TPG, RAGGED, COH, 16>(a, begin, count, blockIdx.x * (16 * TPG) + gib, l16);
     if (l16 == 0) s_loss[gib] = gloss;
     __syncthreads();
     if (tid == 0) {
@@ -299,17 +309,11 @@ __device__ __forceinline__ float group_sum(float x) {
     return x;
 }
 
-template <int MODEL, int LPT, int TPG>
-__global__ __launch_bounds__(256) void sgd_level_small_f32(SgdArgs<float> a, int64_t begin, int count, int64_t slot0) {
+template <int MODEL, int LPT, int TPG, int GS>
+__device__ __forceinline__ double small_tuples_f32(const SgdArgs<float> &a, int64_t begin, int count, int g0, int lt) {
     using M = Traits<MODEL>;
     static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
-    constexpr int GPB = 256 / LPT; // groups per workgroup
     constexpr int VPL = 4;
-    __shared__ double s_loss[GPB];
-    const int tid = threadIdx.x;
-    const int lt = tid % LPT;
-    const int gib = tid / LPT;
-    const int g0 = blockIdx.x * (GPB * TPG) + gib; // tuple i of this group: g0 + GPB*i
     const int k = a.k;
     double gloss = 0.0;
     const HParams hp = *a.hp;
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void sgd_level_small_f32(SgdArgs<float> a, int
     float rr[TPG];
 #pragma unroll
     for (int i = 0; i < TPG; ++i) {
-        const int g = g0 + GPB * i;
+        const int g = g0 + GS * i;
         live[i] = g < count;
         uu[i] = jj[i] = 0;
         rr[i] = 0.f;
@@ -420,6 +424,18 @@ __global__ __launch_bounds__(256) void sgd_level_small_f32(SgdArgs<float> a, int
             gloss += l + (double)reg_loss;
         }
     }
+    return gloss;
+}
+
+template <int MODEL, int LPT, int TPG>
+__global__ __launch_bounds__(256) void sgd_level_small_f32(SgdArgs<float> a, int64_t begin, int count, int64_t slot0) {
+    constexpr int GPB = 256 / LPT; // groups per workgroup
+    __shared__ double s_loss[GPB];
+    const int tid = threadIdx.x;
+    const int lt = tid % LPT;
+    const int gib = tid / LPT;
+    // tuple i of this group: g0 + GPB*i
+    const double gloss = small_tuples_f32<MODEL, LPT, TPG, GPB>(a, begin, count, blockIdx.x * (GPB * TPG) + gib, lt);
     if (lt == 0) s_loss[gib] = gloss;
     __syncthreads();
     if (tid < 64) { // fixed-shape tree over the GPB group sums
@@ -803,6 +819,85 @@ __global__ __launch_bounds__(256) void sgd_level_generic(SgdArgs<T> a, int64_t b
     if (lane == 0) s_loss[wave] = gl;
     __syncthreads();
     if (threadIdx.x == 0) a.loss_part[slot0 + blockIdx.x] = ((s_loss[0] + s_loss[1]) + s_loss[2]) + s_loss[3];
+}
+
+// The narrow tail of a schedule: with heavy-tailed item (or user) degrees the longest chains belong to a few hot rows
+// and the last levels hold a handful of tuples each -- hundreds of thousands of them for a Zipf item distribution.
+// One launch per such level would cost ~7 us apiece; here ONE workgroup walks all tail levels inside one launch:
+// wave w takes tuples w, w+16, ... of the level, a workgroup barrier separates levels.  All 16 waves share the CU's
+// vector L1 and its XCD's L2, so the barrier's workgroup-scope ordering is all the coherence that is needed, and the
+// hot rows stay cache-resident from one level to the next.
+template <typename T, int MODEL, bool STRICT>
+__global__ __launch_bounds__(1024) void sgd_tail_kernel(SgdArgs<T> a, const int64_t *__restrict__ tail_off, int n_tail,
+                                                        int64_t slot) {
+    __shared__ double s_loss[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const HParams hp = *a.hp;
+    double gl = 0.0;
+    int64_t b = tail_off[0];
+    for (int l = 0; l < n_tail; ++l) {
+        const int64_t e = tail_off[l + 1];
+        for (int64_t t = b + wave; t < e; t += 16)
+            gl += sgd_one<T, MODEL, STRICT>(a, hp, a.su[t], a.sj[t], a.sr[t], a.sconds + t * a.dmax, lane, 0.0);
+        b = e;
+        __syncthreads(); // release/acquire at workgroup scope: the next level sees this level's rows
+    }
+    if (lane == 0) s_loss[wave] = gl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sum += s_loss[w];
+        a.loss_part[slot] = sum;
+    }
+}
+
+// the same walk with the arithmetic (and hence the bits) of the level kernels it stands in for: 64 sixteen-lane groups
+template <int MODEL, int VPL, bool RAGGED>
+__global__ __launch_bounds__(1024) void sgd_tail_fast_f32(SgdArgs<float> a, const int64_t *__restrict__ tail_off, int n_tail,
+                                                          int64_t slot) {
+    __shared__ double s_loss[64];
+    const int l16 = threadIdx.x & 15, gib = threadIdx.x >> 4;
+    double gl = 0.0;
+    int64_t b = tail_off[0];
+    for (int l = 0; l < n_tail; ++l) {
+        const int64_t e = tail_off[l + 1];
+        const int cnt = (int)(e - b);
+        for (int base = 0; base < cnt; base += 64) gl += fast_tuples_f32<MODEL, VPL, 1, RAGGED, false, 64>(a, b, cnt, base + gib, l16);
+        b = e;
+        __syncthreads();
+    }
+    if (l16 == 0) s_loss[gib] = gl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+        for (int g = 0; g < 64; ++g) sum += s_loss[g];
+        a.loss_part[slot] = sum;
+    }
+}
+
+template <int MODEL, int LPT>
+__global__ __launch_bounds__(1024) void sgd_tail_small_f32(SgdArgs<float> a, const int64_t *__restrict__ tail_off, int n_tail,
+                                                           int64_t slot) {
+    constexpr int G = 1024 / LPT;
+    __shared__ double s_loss[G];
+    const int lt = threadIdx.x % LPT, gib = threadIdx.x / LPT;
+    double gl = 0.0;
+    int64_t b = tail_off[0];
+    for (int l = 0; l < n_tail; ++l) {
+        const int64_t e = tail_off[l + 1];
+        const int cnt = (int)(e - b);
+        for (int base = 0; base < cnt; base += G) gl += small_tuples_f32<MODEL, LPT, 1, G>(a, b, cnt, base + gib, lt);
+        b = e;
+        __syncthreads();
+    }
+    if (lt == 0) s_loss[gib] = gl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+        for (int g = 0; g < G; ++g) sum += s_loss[g];
+        a.loss_part[slot] = sum;
+    }
 }
 
 // One wavefront, tuples strictly in stream order: the reference's single-threaded semantics.
@@ -1414,6 +1509,72 @@ static hipError_t launch_generic_model(const SgdArgs<T> &a, const LaunchCfg &cfg
         hipLaunchKernelGGL((sgd_level_generic<T, MODEL, false>), grid, block, 0, s, a, begin, count, slot0);
     return hipGetLastError();
 }
+
+template <typename T>
+hipError_t launch_tail(const SgdArgs<T> &a, const LaunchCfg &cfg, const int64_t *tail_off, int n_tail, int64_t slot,
+                       hipStream_t s);
+template <int MODEL>
+static hipError_t launch_tail_fast_model(const SgdArgs<float> &a, const int64_t *tail_off, int n_tail, int64_t slot, hipStream_t s) {
+    const dim3 g(1), b(1024);
+    switch (a.k) {
+    case 64: hipLaunchKernelGGL((sgd_tail_fast_f32<MODEL, 1, false>), g, b, 0, s, a, tail_off, n_tail, slot); break;
+    case 128: hipLaunchKernelGGL((sgd_tail_fast_f32<MODEL, 2, false>), g, b, 0, s, a, tail_off, n_tail, slot); break;
+    case 256: hipLaunchKernelGGL((sgd_tail_fast_f32<MODEL, 4, false>), g, b, 0, s, a, tail_off, n_tail, slot); break;
+    default:
+        if (a.k < 128) hipLaunchKernelGGL((sgd_tail_fast_f32<MODEL, 2, true>), g, b, 0, s, a, tail_off, n_tail, slot);
+        else if (a.k < 192) hipLaunchKernelGGL((sgd_tail_fast_f32<MODEL, 3, true>), g, b, 0, s, a, tail_off, n_tail, slot);
+        else hipLaunchKernelGGL((sgd_tail_fast_f32<MODEL, 4, true>), g, b, 0, s, a, tail_off, n_tail, slot);
+    }
+    return hipGetLastError();
+}
+template <int MODEL>
+static hipError_t launch_tail_small_model(const SgdArgs<float> &a, const int64_t *tail_off, int n_tail, int64_t slot, hipStream_t s) {
+    const dim3 g(1), b(1024);
+    switch (small_lpt(a.k, a.dmax)) {
+    case 4: hipLaunchKernelGGL((sgd_tail_small_f32<MODEL, 4>), g, b, 0, s, a, tail_off, n_tail, slot); break;
+    case 8: hipLaunchKernelGGL((sgd_tail_small_f32<MODEL, 8>), g, b, 0, s, a, tail_off, n_tail, slot); break;
+    default: hipLaunchKernelGGL((sgd_tail_small_f32<MODEL, 16>), g, b, 0, s, a, tail_off, n_tail, slot); break;
+    }
+    return hipGetLastError();
+}
+// kind: 0 generic (any k / fp64 / strict), 1 the float4 kernels' arithmetic, 2 the small-k kernels' arithmetic
+hipError_t launch_tail_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, int kind, const int64_t *tail_off, int n_tail,
+                           int64_t slot, hipStream_t s) {
+    if (n_tail <= 0) return hipSuccess;
+    if (kind == 0) return launch_tail<float>(a, cfg, tail_off, n_tail, slot, s);
+    switch (cfg.model) {
+    case BIASEDMF: return kind == 1 ? launch_tail_fast_model<BIASEDMF>(a, tail_off, n_tail, slot, s) : launch_tail_small_model<BIASEDMF>(a, tail_off, n_tail, slot, s);
+    case PMF: return kind == 1 ? launch_tail_fast_model<PMF>(a, tail_off, n_tail, slot, s) : launch_tail_small_model<PMF>(a, tail_off, n_tail, slot, s);
+    case CAMF_CI: return kind == 1 ? launch_tail_fast_model<CAMF_CI>(a, tail_off, n_tail, slot, s) : launch_tail_small_model<CAMF_CI>(a, tail_off, n_tail, slot, s);
+    case CAMF_CU: return kind == 1 ? launch_tail_fast_model<CAMF_CU>(a, tail_off, n_tail, slot, s) : launch_tail_small_model<CAMF_CU>(a, tail_off, n_tail, slot, s);
+    case CAMF_CUCI: return kind == 1 ? launch_tail_fast_model<CAMF_CUCI>(a, tail_off, n_tail, slot, s) : launch_tail_small_model<CAMF_CUCI>(a, tail_off, n_tail, slot, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <typename T, int MODEL>
+static hipError_t launch_tail_model(const SgdArgs<T> &a, const LaunchCfg &cfg, const int64_t *tail_off, int n_tail,
+                                    int64_t slot, hipStream_t s) {
+    if (cfg.strict) hipLaunchKernelGGL((sgd_tail_kernel<T, MODEL, true>), dim3(1), dim3(1024), 0, s, a, tail_off, n_tail, slot);
+    else hipLaunchKernelGGL((sgd_tail_kernel<T, MODEL, false>), dim3(1), dim3(1024), 0, s, a, tail_off, n_tail, slot);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_tail(const SgdArgs<T> &a, const LaunchCfg &cfg, const int64_t *tail_off, int n_tail, int64_t slot,
+                       hipStream_t s) {
+    if (n_tail <= 0) return hipSuccess;
+    switch (cfg.model) {
+    case BIASEDMF: return launch_tail_model<T, BIASEDMF>(a, cfg, tail_off, n_tail, slot, s);
+    case PMF: return launch_tail_model<T, PMF>(a, cfg, tail_off, n_tail, slot, s);
+    case CAMF_CI: return launch_tail_model<T, CAMF_CI>(a, cfg, tail_off, n_tail, slot, s);
+    case CAMF_CU: return launch_tail_model<T, CAMF_CU>(a, cfg, tail_off, n_tail, slot, s);
+    case CAMF_CUCI: return launch_tail_model<T, CAMF_CUCI>(a, cfg, tail_off, n_tail, slot, s);
+    }
+    return hipErrorInvalidValue;
+}
+template hipError_t launch_tail<float>(const SgdArgs<float> &, const LaunchCfg &, const int64_t *, int, int64_t, hipStream_t);
+template hipError_t launch_tail<double>(const SgdArgs<double> &, const LaunchCfg &, const int64_t *, int, int64_t, hipStream_t);
 
 template <typename T>
 hipError_t launch_level_generic(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t begin, int count, int64_t slot0,

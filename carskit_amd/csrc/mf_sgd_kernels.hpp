@@ -39,6 +39,14 @@ struct LaunchCfg {
 int level_blocks_f32_fast(int k, int count);
 int level_blocks_generic(int count);
 bool has_fast_path(int k, int dmax, bool f64, const LaunchCfg &cfg);
+// all narrow tail levels of a schedule in one launch (one workgroup, a barrier per level); tail_off = n_tail+1 device offsets
+template <typename T>
+hipError_t launch_tail(const SgdArgs<T> &a, const LaunchCfg &cfg, const int64_t *tail_off, int n_tail, int64_t slot,
+                       hipStream_t s);
+// fp32 state: kind 0 = generic arithmetic, 1 = the float4 level kernels', 2 = the small-k level kernels' (same bits as the
+// level launches the run replaces)
+hipError_t launch_tail_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, int kind, const int64_t *tail_off, int n_tail,
+                           int64_t slot, hipStream_t s);
 // small-k fast path (fp32 state, k < 64): 4 / 8 / 16 lanes per tuple
 bool has_small_path(int k, int dmax, bool f64, const LaunchCfg &cfg);
 int level_blocks_small(int k, int dmax, int count);

@@ -190,7 +190,8 @@ int cmi_synchronize(cmi_handle h);
 /* enqueue one epoch without reading the loss back (pair with cmi_synchronize / cmi_last_loss) */
 int cmi_train_epoch_async(cmi_handle h, double lrate);
 int cmi_last_loss(cmi_handle h, double *loss_out);
-/* schedule facts: info[0]=levels (kernel launches per epoch), info[1]=largest level, info[2]=tuples,
+/* schedule facts: info[0]=level launches per epoch (a long run of narrow final levels counts as ONE launch: a single
+ * workgroup walks them),  info[1]=largest level, info[2]=tuples,
  * info[3]=max conditions per tuple (D), info[4]=state bytes on device, info[5]=tuple-stream bytes on device,
  * info[6]=schedule kind actually running (0 level launches, 1 serial, 2 dataflow, 3 two-lane level graph),
  * info[7]=workgroups of the dataflow launch (0 otherwise) */
