@@ -95,12 +95,32 @@ __device__ __forceinline__ void st_f32_coherent(float *p, float v) {
 
 // TPG = tuples each 16-lane group processes CONCURRENTLY (all their loads are issued before the first use):
 // more bytes in flight per wave and 1/TPG as many workgroups to dispatch per level.
+// ids of one tuple as a lane group sees them (lane l additionally holds the tuple's l-th condition)
+struct TupleIds {
+    int uu, jj, cond;
+    float rr;
+    bool live;
+};
+template <bool HAS_CTX>
+__device__ __forceinline__ TupleIds load_tuple_ids(const SgdArgs<float> &a, int64_t begin, int count, int g, int lane_in_group) {
+    TupleIds t{0, 0, -1, 0.f, g < count};
+    if (t.live) {
+        const int64_t s = begin + g;
+        t.uu = a.su[s];
+        t.jj = a.sj[s];
+        t.rr = a.sr[s];
+        if (HAS_CTX && lane_in_group < a.dmax) t.cond = a.sconds[s * a.dmax + lane_in_group];
+    }
+    return t;
+}
+
 // The update of TPG tuples by one 16-lane group: tuples g0, g0 + GS, ... of the level [begin, begin + count).
 // Returns the group's loss contribution (valid in lane 0 of the group).  GS = groups that work side by side (16 per
 // 256-thread workgroup of a level launch; 64 in the single 1024-thread workgroup of a narrow-run launch), so that
 // neighbouring groups read neighbouring tuples of the stream.
-template <int MODEL, int VPL, int TPG, bool RAGGED, bool COH, int GS>
-__device__ __forceinline__ double fast_tuples_f32(const SgdArgs<float> &a, int64_t begin, int count, int g0, int l16) {
+template <int MODEL, int VPL, int TPG, bool RAGGED, bool COH, int GS, bool PRE = false>
+__device__ __forceinline__ double fast_tuples_f32(const SgdArgs<float> &a, int64_t begin, int count, int g0, int l16,
+                                                  const TupleIds *pre = nullptr) {
     using M = Traits<MODEL>;
     static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
     // RAGGED: any k with k % 4 == 0 and 64*(VPL-1) < k <= 64*VPL (rows stay 16-byte aligned); float4 slots past k are masked
@@ -112,18 +132,13 @@ __device__ __forceinline__ double fast_tuples_f32(const SgdArgs<float> &a, int64
     float rr[TPG];
 #pragma unroll
     for (int i = 0; i < TPG; ++i) {
-        const int g = g0 + GS * i;
-        live[i] = g < count;
-        uu[i] = jj[i] = 0;
-        rr[i] = 0.f;
-        cond[i] = -1;
-        if (live[i]) {
-            const int64_t t = begin + g;
-            uu[i] = a.su[t];
-            jj[i] = a.sj[t];
-            rr[i] = a.sr[t];
-            if (Traits<MODEL>::has_ctx && l16 < a.dmax) cond[i] = a.sconds[t * a.dmax + l16];
-        }
+        // PRE (narrow-run launches, TPG = 1): the ids were loaded while the previous level was still being computed
+        const TupleIds t = PRE ? *pre : load_tuple_ids<Traits<MODEL>::has_ctx>(a, begin, count, g0 + GS * i, l16);
+        live[i] = t.live;
+        uu[i] = t.uu;
+        jj[i] = t.jj;
+        rr[i] = t.rr;
+        cond[i] = t.cond;
     }
 
     // COH (experiment CMI_LEVEL_COHERENT=1): all model traffic device-coherent (sc0 sc1: write-through stores, L2-bypassing
@@ -309,8 +324,9 @@ __device__ __forceinline__ float group_sum(float x) {
     return x;
 }
 
-template <int MODEL, int LPT, int TPG, int GS>
-__device__ __forceinline__ double small_tuples_f32(const SgdArgs<float> &a, int64_t begin, int count, int g0, int lt) {
+template <int MODEL, int LPT, int TPG, int GS, bool PRE = false>
+__device__ __forceinline__ double small_tuples_f32(const SgdArgs<float> &a, int64_t begin, int count, int g0, int lt,
+                                                   const TupleIds *pre = nullptr) {
     using M = Traits<MODEL>;
     static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
     constexpr int VPL = 4;
@@ -325,18 +341,12 @@ __device__ __forceinline__ double small_tuples_f32(const SgdArgs<float> &a, int6
     float rr[TPG];
 #pragma unroll
     for (int i = 0; i < TPG; ++i) {
-        const int g = g0 + GS * i;
-        live[i] = g < count;
-        uu[i] = jj[i] = 0;
-        rr[i] = 0.f;
-        cond[i] = -1;
-        if (live[i]) {
-            const int64_t t = begin + g;
-            uu[i] = a.su[t];
-            jj[i] = a.sj[t];
-            rr[i] = a.sr[t];
-            if (Traits<MODEL>::has_ctx && lt < a.dmax) cond[i] = a.sconds[t * a.dmax + lt];
-        }
+        const TupleIds t = PRE ? *pre : load_tuple_ids<Traits<MODEL>::has_ctx>(a, begin, count, g0 + GS * i, lt);
+        live[i] = t.live;
+        uu[i] = t.uu;
+        jj[i] = t.jj;
+        rr[i] = t.rr;
+        cond[i] = t.cond;
     }
     float *prow[TPG], *qrow[TPG];
     float p[TPG][VPL], q[TPG][VPL];
@@ -860,11 +870,19 @@ __global__ __launch_bounds__(1024) void sgd_tail_fast_f32(SgdArgs<float> a, cons
     const int l16 = threadIdx.x & 15, gib = threadIdx.x >> 4;
     double gl = 0.0;
     int64_t b = tail_off[0];
+    // the tuple ids of a level do not depend on the previous level's updates: they are fetched one level ahead, which
+    // takes one of the two dependent memory round trips (ids -> rows) off every level's critical path
+    int64_t e = tail_off[1];
+    TupleIds next = load_tuple_ids<Traits<MODEL>::has_ctx>(a, b, (int)(e - b), gib, l16);
     for (int l = 0; l < n_tail; ++l) {
-        const int64_t e = tail_off[l + 1];
         const int cnt = (int)(e - b);
-        for (int base = 0; base < cnt; base += 64) gl += fast_tuples_f32<MODEL, VPL, 1, RAGGED, false, 64>(a, b, cnt, base + gib, l16);
+        const TupleIds cur = next;
+        const int64_t e2 = l + 1 < n_tail ? tail_off[l + 2] : e;
+        if (l + 1 < n_tail) next = load_tuple_ids<Traits<MODEL>::has_ctx>(a, e, (int)(e2 - e), gib, l16);
+        gl += fast_tuples_f32<MODEL, VPL, 1, RAGGED, false, 64, true>(a, b, cnt, gib, l16, &cur);
+        for (int base = 64; base < cnt; base += 64) gl += fast_tuples_f32<MODEL, VPL, 1, RAGGED, false, 64>(a, b, cnt, base + gib, l16);
         b = e;
+        e = e2;
         __syncthreads();
     }
     if (l16 == 0) s_loss[gib] = gl;
@@ -884,11 +902,17 @@ __global__ __launch_bounds__(1024) void sgd_tail_small_f32(SgdArgs<float> a, con
     const int lt = threadIdx.x % LPT, gib = threadIdx.x / LPT;
     double gl = 0.0;
     int64_t b = tail_off[0];
-    for (int l = 0; l < n_tail; ++l) {
-        const int64_t e = tail_off[l + 1];
+    int64_t e = tail_off[1];
+    TupleIds next = load_tuple_ids<Traits<MODEL>::has_ctx>(a, b, (int)(e - b), gib, lt);
+    for (int l = 0; l < n_tail; ++l) { // ids one level ahead, as in sgd_tail_fast_f32
         const int cnt = (int)(e - b);
-        for (int base = 0; base < cnt; base += G) gl += small_tuples_f32<MODEL, LPT, 1, G>(a, b, cnt, base + gib, lt);
+        const TupleIds cur = next;
+        const int64_t e2 = l + 1 < n_tail ? tail_off[l + 2] : e;
+        if (l + 1 < n_tail) next = load_tuple_ids<Traits<MODEL>::has_ctx>(a, e, (int)(e2 - e), gib, lt);
+        gl += small_tuples_f32<MODEL, LPT, 1, G, true>(a, b, cnt, gib, lt, &cur);
+        for (int base = G; base < cnt; base += G) gl += small_tuples_f32<MODEL, LPT, 1, G>(a, b, cnt, base + gib, lt);
         b = e;
+        e = e2;
         __syncthreads();
     }
     if (lt == 0) s_loss[gib] = gl;
