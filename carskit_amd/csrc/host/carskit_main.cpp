@@ -122,7 +122,10 @@ static int run(const std::string &config, unsigned flags, int iters_override, bo
     std::string fold_error;
     auto runFold = [&](const RatingData &tr, const RatingData &te, int fold, size_t slot) {
         try {
-            auto algo = getRecommender(algoName, tr, te, fold, conf, log);
+            Conf fc = conf; // fold -> GPU round robin (the reference runs one thread per fold, CARSKit.java:395-412)
+            const int ngpu = cmi_device_count();
+            if (ngpu > 1 && fold > 0) fc.device = (fold - 1) % ngpu;
+            auto algo = getRecommender(algoName, tr, te, fold, fc, log);
             const Measures m = algo->execute();
             std::lock_guard<std::mutex> g(mu);
             if (all.size() <= slot) all.resize(slot + 1);

@@ -60,11 +60,23 @@ def run(config_path, engine_factory=None, log=print, conf_overrides=None):
     if mode == "cv":
         k = ev.get_int("-k", 5)
         labels, k = splitter.split_folds(data.n, k, seed)
+        from . import capi
+        ngpu = capi.device_count() if engine_factory is None else 0
         for f in range(1, k + 1):
             train, test = splitter.kth_fold(data, labels, f)
             algo = cls(train, test, f, conf, engine_factory, log)
-            algo.execute()
+            if ngpu > 1:
+                algo.device = (f - 1) % ngpu                          # fold -> GPU round robin
             algos.append(algo)
+        if ev.is_on("-p", True) and engine_factory is None and len(algos) > 1:
+            # `cv -p on`: one thread per fold (CARSKit.java:395-412); every fold owns its handle and stream, and the
+            # library calls release the GIL, so the folds' epochs overlap on the GPU(s)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=len(algos)) as pool:
+                list(pool.map(lambda a: a.execute(), algos))
+        else:
+            for algo in algos:
+                algo.execute()
     elif mode == "test-set":
         # the id spaces are the union's: test-only users/items exist in the model (with their initial values) exactly
         # as in the reference, where rateDao.numUsers() is read after the test DAO extended the shared maps

@@ -129,6 +129,7 @@ class Recommender:
         self.minRate, self.maxRate = train.min_rate, train.max_rate      # full data's rating scale (:198-200)
         self.globalMean = float(np.sum(train.r) / np.count_nonzero(train.r)) if train.n else float("nan")  # :265
         self.engine_factory = engine_factory or GpuEngine
+        self.device = 0                                               # set by the driver: fold -> GPU round robin
         self.measures = {}
         self.log = log or (lambda *a: None)
         self.engine = None
@@ -206,7 +207,7 @@ class IterativeRecommender(Recommender):
         hp = {"regU": self.conf.regU, "regI": self.conf.regI, "regB": self.conf.regB, "regC": self.conf.regC,
               "gm": self.globalMean}
         self.engine = self.engine_factory(self.algo_name, self.numFactors, self.trainMatrix, self.train_tuples(), hp,
-                                          flags=self.conf.flags)
+                                          flags=self.conf.flags, device=self.device)
         self.engine.set_states(self.state)                          # copy-in
         for it in range(1, self.numIters + 1):
             self.lrates.append(self.lRate)
@@ -295,7 +296,7 @@ class FM(ContextRecommender):
 
     def buildModel(self):
         d = self.trainMatrix
-        self.engine = capi.FMInstance(self.numFactors, d.n_users, d.n_items, d.n_conds, max(1, d.n_dims))
+        self.engine = capi.FMInstance(self.numFactors, d.n_users, d.n_items, d.n_conds, max(1, d.n_dims), device=self.device)
         self.engine.set_hparams(self.conf.reg_lw, self.conf.reg_lf)
         self.engine.set_ratings(d.u, d.j, d.ctx, d.r)
         self.engine.set_model(self.state["w0"], self.state["w"], self.state["V"])
