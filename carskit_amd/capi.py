@@ -53,6 +53,8 @@ SYMBOLS = [
     ("cmi_eval_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, C.POINTER(_i64)]),
     ("cmi_eval_rankings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int, C.c_int,
                                     C.c_int, _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
+    ("cmi_fm_eval_rankings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int, C.c_int,
+                                       C.c_int, _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
     ("cmi_last_rank_ms", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_dbl)]),
     ("cmi_java_int_hashset_order", C.c_int, [_i64, _vp, _vp, C.POINTER(_i64)]),
     ("cmi_state_device_ptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(C.c_int)]),
@@ -194,6 +196,36 @@ def flow_schedule(u, j, n_users, n_items):
     if rc != OK:
         raise CmiError(rc, "cmi_flow_schedule")
     return perm, su, sj
+
+
+def _eval_rankings(fn, chk, h, train, test, bin_thold=-1.0, num_recs=10, num_ignore=0, strategy="ucu", with_lists=False):
+    """Recommender.evalRankings (Recommender.java:668-964).  train/test: (u, j, ctx, r) array tuples.
+    Returns {measure: value}; with_lists also returns {(u, ctx): [(item, score), ...]}."""
+    c32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    tu, tj, tc, tr = c32(train[0]), c32(train[1]), c32(train[2]), f64(train[3])
+    su, sj, sc, sr = c32(test[0]), c32(test[1]), c32(test[2]), f64(test[3])
+    out, nq = np.zeros(len(RANK_MEASURES)), _i64()
+    n = max(len(su), 1)
+    if with_lists:
+        qu, qc, qn = (np.zeros(n, np.int32) for _ in range(3))
+        items, scores = np.zeros(n * num_recs, np.int32), np.zeros(n * num_recs)
+    else:
+        qu = qc = qn = items = scores = None
+    chk(fn(h, len(tu), _p(tu), _p(tj), _p(tc), _p(tr), len(su), _p(su), _p(sj), _p(sc),
+                                       _p(sr), float(bin_thold), int(num_recs), int(num_ignore),
+                                       {"ucu": 0, "uc": 1}[strategy], _p(out), C.byref(nq), _p(qu), _p(qc), _p(qn),
+                                       _p(items), _p(scores)))
+    res = dict(zip(RANK_MEASURES, out.tolist()))
+    res["n_queries"] = nq.value
+    if not with_lists:
+        return res
+    lists = {}
+    for q in range(nq.value):
+        if qn[q] > 0:
+            lists[(int(qu[q]), int(qc[q]))] = [(int(items[q * num_recs + i]), float(scores[q * num_recs + i]))
+                                               for i in range(qn[q])]
+    return res, lists
 
 
 class Instance:
@@ -344,31 +376,8 @@ class Instance:
     def eval_rankings(self, train, test, bin_thold=-1.0, num_recs=10, num_ignore=0, strategy="ucu", with_lists=False):
         """Recommender.evalRankings (Recommender.java:668-964).  train/test: (u, j, ctx, r) array tuples.
         Returns {measure: value}; with_lists also returns {(u, ctx): [(item, score), ...]}."""
-        c32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
-        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
-        tu, tj, tc, tr = c32(train[0]), c32(train[1]), c32(train[2]), f64(train[3])
-        su, sj, sc, sr = c32(test[0]), c32(test[1]), c32(test[2]), f64(test[3])
-        out, nq = np.zeros(len(RANK_MEASURES)), _i64()
-        n = max(len(su), 1)
-        if with_lists:
-            qu, qc, qn = (np.zeros(n, np.int32) for _ in range(3))
-            items, scores = np.zeros(n * num_recs, np.int32), np.zeros(n * num_recs)
-        else:
-            qu = qc = qn = items = scores = None
-        self._chk(self.L.cmi_eval_rankings(self.h, len(tu), _p(tu), _p(tj), _p(tc), _p(tr), len(su), _p(su), _p(sj), _p(sc),
-                                           _p(sr), float(bin_thold), int(num_recs), int(num_ignore),
-                                           {"ucu": 0, "uc": 1}[strategy], _p(out), C.byref(nq), _p(qu), _p(qc), _p(qn),
-                                           _p(items), _p(scores)))
-        res = dict(zip(RANK_MEASURES, out.tolist()))
-        res["n_queries"] = nq.value
-        if not with_lists:
-            return res
-        lists = {}
-        for q in range(nq.value):
-            if qn[q] > 0:
-                lists[(int(qu[q]), int(qc[q]))] = [(int(items[q * num_recs + i]), float(scores[q * num_recs + i]))
-                                                   for i in range(qn[q])]
-        return res, lists
+        return _eval_rankings(self.L.cmi_eval_rankings, self._chk, self.h, train, test, bin_thold, num_recs, num_ignore,
+                              strategy, with_lists)
 
 
 class FMInstance:
@@ -427,6 +436,11 @@ class FMInstance:
 
     def train(self, num_iters):
         self._chk(self.L.cmi_fm_train(self.h, num_iters))
+
+    def eval_rankings(self, train, test, bin_thold=-1.0, num_recs=10, num_ignore=0, strategy="ucu", with_lists=False):
+        """Recommender.evalRankings with FM.predict as the scorer (see Instance.eval_rankings)."""
+        return _eval_rankings(self.L.cmi_fm_eval_rankings, self._chk, self.h, train, test, bin_thold, num_recs, num_ignore,
+                              strategy, with_lists)
 
     def num_phases(self):
         return self.L.cmi_fm_num_phases(self.h)

@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "fm_kernels.hpp"
+#include "rank_host.hpp"
+#include "rank_kernels.hpp"
 
 using namespace cmi;
 
@@ -430,5 +432,63 @@ extern "C" int cmi_fm_predict_batch(cmi_fm_handle h, int64_t n, const int32_t *u
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     FM_HIP(h, e);
+    return CMI_OK;
+}
+
+// Recommender.evalRankings for the FM recommender (Recommender.java:668-964 with FM.predict, FM.java:93-113): same
+// bookkeeping, contraction and top-N selection as cmi_eval_rankings; fp64 like the rest of the FM path.
+extern "C" int cmi_fm_eval_rankings(cmi_fm_handle h, int64_t n_train, const int32_t *tu, const int32_t *tj, const int32_t *tctx,
+                                    const double *tr, int64_t n_test, const int32_t *su, const int32_t *sj, const int32_t *sctx,
+                                    const double *sr, double bin_thold, int num_recs, int num_ignore, int strategy,
+                                    double out[CMI_RANK_MEASURES], int64_t *n_queries, int32_t *q_user, int32_t *q_ctx,
+                                    int32_t *q_count, int32_t *top_items, double *top_scores) {
+    if (!h) return CMI_E_INVALID;
+    if (!out) FM_FAIL(h, CMI_E_INVALID, "fm_eval_rankings: null output");
+    if (!h->have_model) FM_FAIL(h, CMI_E_INVALID, "fm: call cmi_fm_set_model first");
+    if (n_train < 0 || n_test < 0 || (n_train > 0 && (!tu || !tj || !tctx)) || (n_test > 0 && (!su || !sj || !sctx || !sr)))
+        FM_FAIL(h, CMI_E_INVALID, "fm_eval_rankings: null tuple arrays");
+    if (num_recs < 1) FM_FAIL(h, CMI_E_INVALID, "fm_eval_rankings: -topN must be >= 1");
+    if (strategy != CMI_RANK_UCU && strategy != CMI_RANK_UC) FM_FAIL(h, CMI_E_INVALID, "fm_eval_rankings: bad strategy");
+    for (int pass = 0; pass < 2; ++pass) {
+        const int64_t n = pass ? n_test : n_train;
+        const int32_t *u = pass ? su : tu, *j = pass ? sj : tj, *c = pass ? sctx : tctx;
+        for (int64_t t = 0; t < n; ++t)
+            if (u[t] < 0 || u[t] >= h->n_users || j[t] < 0 || j[t] >= h->n_items || c[t] < 0)
+                FM_FAIL(h, CMI_E_INVALID, "fm_eval_rankings: id out of range at %s tuple %lld", pass ? "test" : "train", (long long)t);
+    }
+    FM_HIP(h, hipSetDevice(h->device));
+    if (n_queries) *n_queries = 0;
+    RankPlan plan;
+    rank_build_plan(h->n_users, h->n_items, RankTuples{n_train, tu, tj, tctx, tr}, RankTuples{n_test, su, sj, sctx, sr}, bin_thold,
+                    num_ignore, plan);
+    std::vector<int32_t> top_idx, top_count;
+    std::vector<double> top_score;
+    if (!plan.qu.empty() && !plan.cand.empty()) {
+        RankOperands<double> ops;
+        ops.k_logical = h->k + 1;
+        const RankFmArgs base{h->d_w0, h->d_w, h->d_V, h->k, 0, h->n_users, h->n_items, h->n_conds, 1.0 / (double)h->n_ctx_dims};
+        ops.build_items = [base](double *dB, const int32_t *dcand, int nc, int kp, hipStream_t s) {
+            RankFmArgs a = base;
+            a.kp = kp;
+            return rank_launch_fm_items(a, dcand, nc, dB, s);
+        };
+        ops.build_queries = [base](double *dA, double *drc, const int32_t *dqu, const int32_t *dqc, int n, int kp, hipStream_t s) {
+            RankFmArgs a = base;
+            a.kp = kp;
+            return rank_launch_fm_queries(a, dqu, dqc, n, dA, drc, s);
+        };
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        hipError_t e = hipEventCreate(&ev0);
+        if (e == hipSuccess) e = hipEventCreate(&ev1);
+        if (e == hipSuccess)
+            e = rank_run_device<double>(h->stream, ev0, ev1, plan, ops, bin_thold, num_recs, top_idx, top_score, top_count, nullptr, nullptr);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        FM_HIP(h, e);
+    } else {
+        top_count.assign(plan.qu.size(), 0);
+    }
+    rank_metrics(plan, strategy, num_recs, top_idx, top_score, top_count, out, q_user, q_ctx, q_count, top_items, top_scores);
+    if (n_queries) *n_queries = (int64_t)plan.qu.size();
     return CMI_OK;
 }

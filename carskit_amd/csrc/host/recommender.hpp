@@ -430,8 +430,21 @@ class FM : public IterativeRecommender {
         fmcheck(cmi_fm_train(fm_, conf_.numIters), "cmi_fm_train");
         fmcheck(cmi_fm_get_model(fm_, &w0, w.data(), V.data()), "cmi_fm_get_model");
     }
-    Measures evalRankings() override {
-        throw std::runtime_error("item.ranking for FM is not on the accelerated path (rating prediction only)");
+    Measures evalRankings() override { // Recommender.java:668-964 with FM.predict
+        static const char *names[CMI_RANK_MEASURES] = {"Pre5", "Pre10", "PreN", "Rec5", "Rec10", "RecN", "AUC5", "AUC10", "AUCN",
+                                                       "MAP5", "MAP10", "MAPN", "NDCG5", "NDCG10", "NDCGN", "MRR5", "MRR10",
+                                                       "MRRN", "D5", "D10", "DN"};
+        double out[CMI_RANK_MEASURES];
+        int64_t nq = 0;
+        if (cmi_fm_eval_rankings(fm_, trainMatrix.n(), trainMatrix.u.data(), trainMatrix.j.data(), trainMatrix.ctx.data(),
+                                 trainMatrix.r.data(), testMatrix.n(), testMatrix.u.data(), testMatrix.j.data(),
+                                 testMatrix.ctx.data(), testMatrix.r.data(), conf_.binThold, conf_.numRecs, conf_.numIgnore,
+                                 conf_.evalStrategy == "uc" ? CMI_RANK_UC : CMI_RANK_UCU, out, &nq, nullptr, nullptr, nullptr,
+                                 nullptr, nullptr) != CMI_OK)
+            throw std::runtime_error(std::string("cmi_fm_eval_rankings: ") + cmi_fm_last_error(fm_));
+        Measures m;
+        for (int i = 0; i < CMI_RANK_MEASURES; ++i) m[names[i]] = out[i];
+        return m;
     }
     Measures evalRatings() override {
         std::vector<double> pred((size_t)testMatrix.n());

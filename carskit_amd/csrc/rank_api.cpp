@@ -8,6 +8,7 @@
 #include <numeric>
 
 #include "cmi_instance.hpp"
+#include "rank_host.hpp"
 #include "rank_kernels.hpp"
 
 using namespace cmi;
@@ -128,18 +129,152 @@ std::vector<int64_t> order_by_user_ctx_item(int n_users, const std::vector<int64
 
 constexpr int N_MEAS = 18; // Pre,Rec,AUC,MAP,NDCG,MRR x {5,10,N}
 
+} // namespace
+
+namespace cmi {
+
+void rank_build_plan(int n_users, int n_items, const RankTuples &train, const RankTuples &test, double bin_thold,
+                     int num_ignore, RankPlan &plan) {
+    // candidate items: rateDao.getItemList(trainMatrix) -> HashSet<Integer> (DataDAO.java:1210-1218)
+    std::vector<int32_t> first_seen, degree(n_items, 0);
+    for (int64_t t = 0; t < train.n; ++t) {
+        if (train.r && train.r[t] == 0.0) continue; // a sparse matrix holds no zero entries
+        if (degree[train.j[t]]++ == 0) first_seen.push_back(train.j[t]);
+    }
+    std::vector<int32_t> &cand = plan.cand;
+    cand = java_int_hashset_order(first_seen);
+    if (num_ignore > 0) { // drop the most popular items (Recommender.java:720-735): stable sort by degree, descending
+        std::vector<int32_t> by_deg = cand;
+        std::stable_sort(by_deg.begin(), by_deg.end(), [&](int32_t a, int32_t b) { return degree[a] > degree[b]; });
+        std::vector<char> drop(n_items, 0);
+        for (int i = 0; i < num_ignore && i < (int)by_deg.size(); ++i) drop[by_deg[i]] = 1;
+        cand.erase(std::remove_if(cand.begin(), cand.end(), [&](int32_t j) { return drop[j]; }), cand.end());
+    }
+    const int nc = (int)cand.size();
+    std::vector<int32_t> cand_pos(n_items, -1);
+    for (int i = 0; i < nc; ++i) cand_pos[cand[i]] = i;
+
+    // queries: test positives (rate > threshold) grouped by (user, context)  (DataDAO.getUserCtxList, DataDAO.java:1114-1140)
+    std::vector<int64_t> pos;
+    for (int64_t t = 0; t < test.n; ++t)
+        if (test.r[t] != 0.0 && test.r[t] > bin_thold) pos.push_back(t);
+    pos = order_by_user_ctx_item(n_users, pos, test.u, test.ctx, test.j);
+    std::vector<int32_t> &qu = plan.qu, &qc = plan.qc, &truth_items = plan.truth_items;
+    std::vector<int64_t> &truth_ptr = plan.truth_ptr;
+    qu.clear();
+    qc.clear();
+    truth_items.clear();
+    truth_ptr.assign(1, 0);
+    for (size_t i = 0; i < pos.size();) {
+        size_t e = i;
+        const size_t before = truth_items.size();
+        while (e < pos.size() && test.u[pos[e]] == test.u[pos[i]] && test.ctx[pos[e]] == test.ctx[pos[i]]) {
+            const int32_t j = test.j[pos[e]];
+            if (cand_pos[j] >= 0 && (truth_items.size() == before || truth_items.back() != j)) truth_items.push_back(j);
+            ++e;
+        }
+        if (truth_items.size() > before) { // correctItems non-empty (Recommender.java:789-790)
+            qu.push_back(test.u[pos[i]]);
+            qc.push_back(test.ctx[pos[i]]);
+            truth_ptr.push_back((int64_t)truth_items.size());
+        }
+        i = e;
+    }
+    const int64_t nq = (int64_t)qu.size();
+
+    // exclusions: items the user rated in the same context in the training set (Recommender.java:793, 814-816)
+    std::vector<int64_t> tord;
+    for (int64_t t = 0; t < train.n; ++t)
+        if (!(train.r && train.r[t] == 0.0)) tord.push_back(t);
+    tord = order_by_user_ctx_item(n_users, tord, train.u, train.ctx, train.j);
+    std::vector<int64_t> &excl_ptr = plan.excl_ptr;
+    std::vector<int32_t> &excl_idx = plan.excl_idx;
+    excl_ptr.assign(1, 0);
+    excl_idx.clear();
+    {
+        size_t p = 0;
+        for (int64_t q = 0; q < nq; ++q) {
+            while (p < tord.size() && (train.u[tord[p]] < qu[q] || (train.u[tord[p]] == qu[q] && train.ctx[tord[p]] < qc[q]))) ++p;
+            size_t e = p;
+            while (e < tord.size() && train.u[tord[e]] == qu[q] && train.ctx[tord[e]] == qc[q]) {
+                const int32_t cp = cand_pos[train.j[tord[e]]];
+                if (cp >= 0 && (excl_idx.size() == (size_t)excl_ptr.back() || excl_idx.back() != cp)) excl_idx.push_back(cp);
+                ++e;
+            }
+            excl_ptr.push_back((int64_t)excl_idx.size());
+        }
+    }
+
+}
+
+void rank_metrics(const RankPlan &plan, int strategy, int num_recs, const std::vector<int32_t> &top_idx,
+                  const std::vector<double> &top_score, const std::vector<int32_t> &top_count, double *out,
+                  int32_t *q_user, int32_t *q_ctx, int32_t *q_count, int32_t *top_items, double *top_scores) {
+    const int64_t nq = (int64_t)plan.qu.size();
+    const int nc = (int)plan.cand.size();
+    for (int m = 0; m < CMI_RANK_MEASURES; ++m) out[m] = std::nan("");
+    out[18] = out[19] = out[20] = 0.0; // D5/D10/DN: isDiverseUsed=false (Recommender.java:939-941)
+    // metrics, per query then averaged per strategy (Recommender.java:850-960)
+    NanMean total[N_MEAS], per_user[N_MEAS];
+    const int cut[3] = {5, 10, num_recs};
+    std::vector<int32_t> ranked(num_recs);
+    auto flush_user = [&]() {
+        for (int m = 0; m < N_MEAS; ++m) {
+            total[m].add(per_user[m].value());
+            per_user[m] = NanMean();
+        }
+    };
+    int64_t emitted = 0;
+    for (int64_t q = 0; q < nq; ++q) {
+        const int len = top_count[q];
+        if (q_user) q_user[q] = plan.qu[q];
+        if (q_ctx) q_ctx[q] = plan.qc[q];
+        if (q_count) q_count[q] = len;
+        for (int i = 0; i < len; ++i) {
+            ranked[i] = plan.cand[top_idx[(size_t)q * num_recs + i]];
+            if (top_items) top_items[(size_t)q * num_recs + i] = ranked[i];
+            if (top_scores) top_scores[(size_t)q * num_recs + i] = top_score[(size_t)q * num_recs + i];
+        }
+        for (int i = len; i < num_recs; ++i) {
+            if (top_items) top_items[(size_t)q * num_recs + i] = -1;
+            if (top_scores) top_scores[(size_t)q * num_recs + i] = std::nan("");
+        }
+        if (len > 0) { // "no recommendations available" queries are skipped (Recommender.java:818-819)
+            const Truth t{plan.truth_items.data() + plan.truth_ptr[q], (int)(plan.truth_ptr[q + 1] - plan.truth_ptr[q])};
+            const int num_cands = nc - (int)(plan.excl_ptr[q + 1] - plan.excl_ptr[q]);
+            const int num_dropped = num_cands - len;
+            NanMean *dst = strategy == CMI_RANK_UC ? total : per_user;
+            for (int c = 0; c < 3; ++c) {
+                const int n = cut[c], tl = std::min(n, len);
+                const int hits = hits_at(ranked.data(), len, t, n);
+                dst[0 + c].add(hits / (n + 0.0));
+                dst[3 + c].add(hits / (t.n + 0.0));
+                dst[6 + c].add(auc(ranked.data(), tl, t, num_dropped));
+                dst[9 + c].add(ap(ranked.data(), tl, t));
+                dst[12 + c].add(ndcg(ranked.data(), tl, t));
+                dst[15 + c].add(rr(ranked.data(), tl, t));
+            }
+            ++emitted;
+        }
+        // ucu: a test user contributes the NaN-skipping mean over its contexts -- NaN (skipped again) if none of
+        // its contexts produced a list (Recommender.java:903-926)
+        if (strategy == CMI_RANK_UCU && (q + 1 == nq || plan.qu[q + 1] != plan.qu[q])) flush_user();
+    }
+    for (int m = 0; m < N_MEAS; ++m) out[m] = total[m].value();
+    (void)emitted;
+}
+
 template <typename T>
-int run_device(cmi_instance *h, const std::vector<int32_t> &cand, const std::vector<int32_t> &qu,
-               const std::vector<int32_t> &qc, const std::vector<int64_t> &excl_ptr,
-               const std::vector<int32_t> &excl_idx, double thold, int topn, std::vector<int32_t> &top_idx,
-               std::vector<double> &top_score, std::vector<int32_t> &top_count) {
+hipError_t rank_run_device(hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, const RankPlan &plan, const RankOperands<T> &ops,
+                           double thold, int topn, std::vector<int32_t> &top_idx, std::vector<double> &top_score,
+                           std::vector<int32_t> &top_count, float *ms, double *flops) {
+    const std::vector<int32_t> &cand = plan.cand, &qu = plan.qu, &qc = plan.qc, &excl_idx = plan.excl_idx;
+    const std::vector<int64_t> &excl_ptr = plan.excl_ptr;
     const int nc = (int)cand.size();
     const int64_t nq = (int64_t)qu.size();
-    const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF;
-    const bool ic_used = h->state[CMI_STATE_IC_BIAS] != nullptr;
-    // operand row = [factors | 1 or itemBias | one-hot conditions or icBias row], zero-padded to the GEMM's k step;
-    // row counts rounded up to the 128-row block tile (pad rows are never written back)
-    const int kp = ((h->k + 1 + (ic_used ? h->n_conds : 0)) + 31) / 32 * 32;
+    // operand rows are zero-padded to the GEMM's k step; row counts rounded up to the 128-row block tile (pad rows are
+    // never written back)
+    const int kp = (ops.k_logical + 31) / 32 * 32;
     auto up128 = [](int64_t v) { return (size_t)((v + 127) / 128 * 128); };
     // query batch: keep the score slab around 1 GiB (it is written once and re-read topn times)
     int64_t bq = std::max<int64_t>(64, ((int64_t)1 << 30) / ((int64_t)nc * (int64_t)sizeof(T)));
@@ -167,29 +302,64 @@ int run_device(cmi_instance *h, const std::vector<int32_t> &cand, const std::vec
     alloc((void **)&dscore, (size_t)nq * topn * 8);
     alloc((void **)&dcount, (size_t)nq * 4);
     auto up = [&](void *d, const void *s, size_t bytes) {
-        if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream);
     };
     up(dcand, cand.data(), (size_t)nc * 4);
     up(dqu, qu.data(), (size_t)nq * 4);
     up(dqc, qc.data(), (size_t)nq * 4);
     up(dexptr, excl_ptr.data(), (size_t)(nq + 1) * 8);
     up(dexcl, excl_idx.data(), excl_idx.size() * 4);
-    if (e == hipSuccess) e = hipMemsetAsync(dtop, 0xff, (size_t)nq * topn * 4, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dscore, 0, (size_t)nq * topn * 8, h->stream);
-    if (e == hipSuccess) {
-        RankItemsArgs<T> ia{(const T *)h->state[CMI_STATE_Q], (const T *)h->state[CMI_STATE_ITEM_BIAS],
-                            (const T *)h->state[CMI_STATE_IC_BIAS], dcand, dB, nc, h->k, kp, h->n_conds};
-        e = rank_launch_build_items<T>(ia, h->stream);
-    }
-    if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dtop, 0xff, (size_t)nq * topn * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dscore, 0, (size_t)nq * topn * 8, stream);
+    if (e == hipSuccess) e = ops.build_items(dB, dcand, nc, kp, stream);
+    if (e == hipSuccess) e = hipEventRecord(ev0, stream);
     for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += bq) {
         const int n = (int)std::min<int64_t>(bq, nq - q0);
+        e = ops.build_queries(dA, drc, dqu + q0, dqc + q0, n, kp, stream);
+        if (e == hipSuccess)
+            e = rank_launch_score<T>(dA, dB, drc, dS, n, nc, kp, dexptr, dexcl, (int)q0, thold, topn, dtop, dscore, dcount,
+                                     stream);
+    }
+    if (e == hipSuccess) e = hipEventRecord(ev1, stream);
+    top_idx.resize((size_t)nq * topn);
+    top_score.resize((size_t)nq * topn);
+    top_count.resize((size_t)nq);
+    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_idx.data(), dtop, (size_t)nq * topn * 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_score.data(), dscore, (size_t)nq * topn * 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_count.data(), dcount, (size_t)nq * 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess && ms) e = hipEventElapsedTime(ms, ev0, ev1);
+    if (flops) *flops = 2.0 * (double)nq * (double)nc * (double)kp;
+    void *ptrs[] = {dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    return e;
+}
+template hipError_t rank_run_device<float>(hipStream_t, hipEvent_t, hipEvent_t, const RankPlan &, const RankOperands<float> &, double, int,
+                                           std::vector<int32_t> &, std::vector<double> &, std::vector<int32_t> &, float *, double *);
+template hipError_t rank_run_device<double>(hipStream_t, hipEvent_t, hipEvent_t, const RankPlan &, const RankOperands<double> &, double, int,
+                                            std::vector<int32_t> &, std::vector<double> &, std::vector<int32_t> &, float *, double *);
+
+
+} // namespace cmi
+
+// operand builders of the MF family (BiasedMF, PMF, CAMF_*): see rank_kernels.hip
+template <typename T>
+static RankOperands<T> mf_operands(cmi_instance *h, int k_logical, bool contextual, bool ic_used) {
+    RankOperands<T> ops;
+    ops.k_logical = k_logical;
+    ops.build_items = [h](T *dB, const int32_t *dcand, int nc, int kp, hipStream_t s) {
+        RankItemsArgs<T> ia{(const T *)h->state[CMI_STATE_Q], (const T *)h->state[CMI_STATE_ITEM_BIAS],
+                            (const T *)h->state[CMI_STATE_IC_BIAS], dcand, dB, nc, h->k, kp, h->n_conds};
+        return rank_launch_build_items<T>(ia, s);
+    };
+    ops.build_queries = [h, contextual, ic_used](T *dA, T *drc, const int32_t *dqu, const int32_t *dqc, int n, int kp, hipStream_t s) {
         RankQueryArgs<T> qa{(const T *)h->state[CMI_STATE_P],
                             (const T *)h->state[CMI_STATE_USER_BIAS],
                             (const T *)h->state[CMI_STATE_UC_BIAS],
                             (const T *)h->state[CMI_STATE_COND_BIAS],
-                            dqu + q0,
-                            dqc + q0,
+                            dqu,
+                            dqc,
                             contextual ? h->d_ctx_ptr : nullptr,
                             contextual ? h->d_ctx_conds : nullptr,
                             dA,
@@ -199,29 +369,10 @@ int run_device(cmi_instance *h, const std::vector<int32_t> &cand, const std::vec
                             kp,
                             h->n_conds,
                             ic_used ? 1 : 0};
-        e = rank_launch_build_queries<T>(qa, n, h->stream);
-        if (e == hipSuccess)
-            e = rank_launch_score<T>(dA, dB, drc, dS, n, nc, kp, dexptr, dexcl, (int)q0, thold, topn, dtop, dscore, dcount,
-                                     h->stream);
-    }
-    if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
-    top_idx.resize((size_t)nq * topn);
-    top_score.resize((size_t)nq * topn);
-    top_count.resize((size_t)nq);
-    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_idx.data(), dtop, (size_t)nq * topn * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_score.data(), dscore, (size_t)nq * topn * 8, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_count.data(), dcount, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e == hipSuccess) e = hipEventElapsedTime(&h->last_rank_ms, h->ev0, h->ev1);
-    h->last_rank_flops = 2.0 * (double)nq * (double)nc * (double)kp;
-    void *ptrs[] = {dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount};
-    for (void *p : ptrs)
-        if (p) hipFree(p);
-    CMI_HIP(h, e);
-    return CMI_OK;
+        return rank_launch_build_queries<T>(qa, n, s);
+    };
+    return ops;
 }
-
-} // namespace
 
 extern "C" int cmi_last_rank_ms(cmi_handle h, float *ms, double *flops) {
     if (!h) return CMI_E_INVALID;
@@ -282,129 +433,26 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
     if (int rc = check(n_train, tu, tj, tctx, "train")) return rc;
     if (int rc = check(n_test, su, sj, sctx, "test")) return rc;
     CMI_HIP(h, hipSetDevice(h->device));
-    for (int m = 0; m < CMI_RANK_MEASURES; ++m) out[m] = std::nan("");
-    out[18] = out[19] = out[20] = 0.0; // D5/D10/DN: isDiverseUsed=false (Recommender.java:939-941)
     if (n_queries) *n_queries = 0;
 
-    // candidate items: rateDao.getItemList(trainMatrix) -> HashSet<Integer> (DataDAO.java:1210-1218)
-    std::vector<int32_t> first_seen, degree(h->n_items, 0);
-    for (int64_t t = 0; t < n_train; ++t) {
-        if (tr && tr[t] == 0.0) continue; // a sparse matrix holds no zero entries
-        if (degree[tj[t]]++ == 0) first_seen.push_back(tj[t]);
-    }
-    std::vector<int32_t> cand = java_int_hashset_order(first_seen);
-    if (num_ignore > 0) { // drop the most popular items (Recommender.java:720-735): stable sort by degree, descending
-        std::vector<int32_t> by_deg = cand;
-        std::stable_sort(by_deg.begin(), by_deg.end(), [&](int32_t a, int32_t b) { return degree[a] > degree[b]; });
-        std::vector<char> drop(h->n_items, 0);
-        for (int i = 0; i < num_ignore && i < (int)by_deg.size(); ++i) drop[by_deg[i]] = 1;
-        cand.erase(std::remove_if(cand.begin(), cand.end(), [&](int32_t j) { return drop[j]; }), cand.end());
-    }
-    const int nc = (int)cand.size();
-    std::vector<int32_t> cand_pos(h->n_items, -1);
-    for (int i = 0; i < nc; ++i) cand_pos[cand[i]] = i;
-
-    // queries: test positives (rate > threshold) grouped by (user, context)  (DataDAO.getUserCtxList, DataDAO.java:1114-1140)
-    std::vector<int64_t> pos;
-    for (int64_t t = 0; t < n_test; ++t)
-        if (sr[t] != 0.0 && sr[t] > bin_thold) pos.push_back(t);
-    pos = order_by_user_ctx_item(h->n_users, pos, su, sctx, sj);
-    std::vector<int32_t> qu, qc, truth_items;
-    std::vector<int64_t> truth_ptr{0};
-    for (size_t i = 0; i < pos.size();) {
-        size_t e = i;
-        const size_t before = truth_items.size();
-        while (e < pos.size() && su[pos[e]] == su[pos[i]] && sctx[pos[e]] == sctx[pos[i]]) {
-            const int32_t j = sj[pos[e]];
-            if (cand_pos[j] >= 0 && (truth_items.size() == before || truth_items.back() != j)) truth_items.push_back(j);
-            ++e;
-        }
-        if (truth_items.size() > before) { // correctItems non-empty (Recommender.java:789-790)
-            qu.push_back(su[pos[i]]);
-            qc.push_back(sctx[pos[i]]);
-            truth_ptr.push_back((int64_t)truth_items.size());
-        }
-        i = e;
-    }
-    const int64_t nq = (int64_t)qu.size();
-
-    // exclusions: items the user rated in the same context in the training set (Recommender.java:793, 814-816)
-    std::vector<int64_t> tord;
-    for (int64_t t = 0; t < n_train; ++t)
-        if (!(tr && tr[t] == 0.0)) tord.push_back(t);
-    tord = order_by_user_ctx_item(h->n_users, tord, tu, tctx, tj);
-    std::vector<int64_t> excl_ptr{0};
-    std::vector<int32_t> excl_idx;
-    {
-        size_t p = 0;
-        for (int64_t q = 0; q < nq; ++q) {
-            while (p < tord.size() && (tu[tord[p]] < qu[q] || (tu[tord[p]] == qu[q] && tctx[tord[p]] < qc[q]))) ++p;
-            size_t e = p;
-            while (e < tord.size() && tu[tord[e]] == qu[q] && tctx[tord[e]] == qc[q]) {
-                const int32_t cp = cand_pos[tj[tord[e]]];
-                if (cp >= 0 && (excl_idx.size() == (size_t)excl_ptr.back() || excl_idx.back() != cp)) excl_idx.push_back(cp);
-                ++e;
-            }
-            excl_ptr.push_back((int64_t)excl_idx.size());
-        }
-    }
-
+    RankPlan plan;
+    rank_build_plan(h->n_users, h->n_items, RankTuples{n_train, tu, tj, tctx, tr}, RankTuples{n_test, su, sj, sctx, sr}, bin_thold,
+                    num_ignore, plan);
     std::vector<int32_t> top_idx, top_count;
     std::vector<double> top_score;
-    if (nq > 0 && nc > 0) {
-        const int rc = h->f64 ? run_device<double>(h, cand, qu, qc, excl_ptr, excl_idx, bin_thold, num_recs, top_idx, top_score, top_count)
-                              : run_device<float>(h, cand, qu, qc, excl_ptr, excl_idx, bin_thold, num_recs, top_idx, top_score, top_count);
-        if (rc) return rc;
+    if (!plan.qu.empty() && !plan.cand.empty()) {
+        const bool ic_used = h->state[CMI_STATE_IC_BIAS] != nullptr;
+        const int k_logical = h->k + 1 + (ic_used ? h->n_conds : 0); // [factors | 1 or itemBias | one-hot conditions or icBias row]
+        hipError_t e;
+        if (h->f64) e = rank_run_device<double>(h->stream, h->ev0, h->ev1, plan, mf_operands<double>(h, k_logical, contextual, ic_used), bin_thold,
+                                                num_recs, top_idx, top_score, top_count, &h->last_rank_ms, &h->last_rank_flops);
+        else e = rank_run_device<float>(h->stream, h->ev0, h->ev1, plan, mf_operands<float>(h, k_logical, contextual, ic_used), bin_thold,
+                                        num_recs, top_idx, top_score, top_count, &h->last_rank_ms, &h->last_rank_flops);
+        CMI_HIP(h, e);
+    } else {
+        top_count.assign(plan.qu.size(), 0);
     }
-
-    // metrics, per query then averaged per strategy (Recommender.java:850-960)
-    NanMean total[N_MEAS], per_user[N_MEAS];
-    const int cut[3] = {5, 10, num_recs};
-    std::vector<int32_t> ranked(num_recs);
-    auto flush_user = [&]() {
-        for (int m = 0; m < N_MEAS; ++m) {
-            total[m].add(per_user[m].value());
-            per_user[m] = NanMean();
-        }
-    };
-    int64_t emitted = 0;
-    for (int64_t q = 0; q < nq; ++q) {
-        const int len = top_count[q];
-        if (q_user) q_user[q] = qu[q];
-        if (q_ctx) q_ctx[q] = qc[q];
-        if (q_count) q_count[q] = len;
-        for (int i = 0; i < len; ++i) {
-            ranked[i] = cand[top_idx[(size_t)q * num_recs + i]];
-            if (top_items) top_items[(size_t)q * num_recs + i] = ranked[i];
-            if (top_scores) top_scores[(size_t)q * num_recs + i] = top_score[(size_t)q * num_recs + i];
-        }
-        for (int i = len; i < num_recs; ++i) {
-            if (top_items) top_items[(size_t)q * num_recs + i] = -1;
-            if (top_scores) top_scores[(size_t)q * num_recs + i] = std::nan("");
-        }
-        if (len > 0) { // "no recommendations available" queries are skipped (Recommender.java:818-819)
-            const Truth t{truth_items.data() + truth_ptr[q], (int)(truth_ptr[q + 1] - truth_ptr[q])};
-            const int num_cands = nc - (int)(excl_ptr[q + 1] - excl_ptr[q]);
-            const int num_dropped = num_cands - len;
-            NanMean *dst = strategy == CMI_RANK_UC ? total : per_user;
-            for (int c = 0; c < 3; ++c) {
-                const int n = cut[c], tl = std::min(n, len);
-                const int hits = hits_at(ranked.data(), len, t, n);
-                dst[0 + c].add(hits / (n + 0.0));
-                dst[3 + c].add(hits / (t.n + 0.0));
-                dst[6 + c].add(auc(ranked.data(), tl, t, num_dropped));
-                dst[9 + c].add(ap(ranked.data(), tl, t));
-                dst[12 + c].add(ndcg(ranked.data(), tl, t));
-                dst[15 + c].add(rr(ranked.data(), tl, t));
-            }
-            ++emitted;
-        }
-        // ucu: a test user contributes the NaN-skipping mean over its contexts -- NaN (skipped again) if none of
-        // its contexts produced a list (Recommender.java:903-926)
-        if (strategy == CMI_RANK_UCU && (q + 1 == nq || qu[q + 1] != qu[q])) flush_user();
-    }
-    for (int m = 0; m < N_MEAS; ++m) out[m] = total[m].value();
-    if (n_queries) *n_queries = nq;
-    (void)emitted;
+    rank_metrics(plan, strategy, num_recs, top_idx, top_score, top_count, out, q_user, q_ctx, q_count, top_items, top_scores);
+    if (n_queries) *n_queries = (int64_t)plan.qu.size();
     return CMI_OK;
 }

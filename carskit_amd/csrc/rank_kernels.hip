@@ -65,6 +65,58 @@ __global__ void rank_build_queries(RankQueryArgs<T> a) { // one block per query
     }
 }
 
+// ---- FM operands ------------------------------------------------------------------------------------------------------
+
+__global__ void rank_fm_items(RankFmArgs a, const int32_t *cand, double *B) { // one block per candidate
+    const int64_t l = (int64_t)a.n_users + cand[blockIdx.x];
+    double *dst = B + (size_t)blockIdx.x * a.kp;
+    for (int f = threadIdx.x; f < a.kp; f += blockDim.x) dst[f] = f < a.k ? a.V[(size_t)l * a.k + f] : (f == a.k ? a.w[l] : 0.0);
+}
+
+__global__ void rank_fm_queries(RankFmArgs a, const int32_t *qu, const int32_t *qc, double *A, double *row_const) {
+    __shared__ double part[64];
+    const int u = qu[blockIdx.x], c = qc[blockIdx.x];
+    const bool has_c = c < a.n_conds; // the reference's index quirk (FM.java:81-86)
+    const double *vu = a.V + (size_t)u * a.k;
+    const double *vc = a.V + (size_t)((int64_t)a.n_users + a.n_items + (has_c ? c : 0)) * a.k;
+    double *dst = A + (size_t)blockIdx.x * a.kp;
+    double dot = 0.0;
+    for (int f = threadIdx.x; f < a.kp; f += blockDim.x) {
+        double v = 0.0;
+        if (f < a.k) {
+            v = vu[f];
+            if (has_c) {
+                v += a.xc * vc[f];
+                dot += vu[f] * vc[f];
+            }
+        } else if (f == a.k) {
+            v = 1.0;
+        }
+        dst[f] = v;
+    }
+    part[threadIdx.x] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int t = 0; t < (int)blockDim.x; ++t) s += part[t];
+        double rc = *a.w0 + a.w[u];
+        if (has_c) rc += a.xc * a.w[(int64_t)a.n_users + a.n_items + c] + a.xc * s;
+        row_const[blockIdx.x] = rc;
+    }
+}
+
+hipError_t rank_launch_fm_items(const RankFmArgs &a, const int32_t *cand, int nc, double *B, hipStream_t s) {
+    if (nc <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rank_fm_items, dim3(nc), dim3(64), 0, s, a, cand, B);
+    return hipGetLastError();
+}
+hipError_t rank_launch_fm_queries(const RankFmArgs &a, const int32_t *qu, const int32_t *qc, int nq, double *A, double *row_const,
+                                  hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rank_fm_queries, dim3(nq), dim3(64), 0, s, a, qu, qc, A, row_const);
+    return hipGetLastError();
+}
+
 // ---- S[q][c] = <A[q,:], B[c,:]> + row_const[q]  (LDS-tiled, 64x64 tile, 4x4 per thread) -------------------------
 
 template <typename T>

@@ -24,6 +24,17 @@ struct RankQueryArgs {
     int k, kp, n_conds, icBias_used;
 };
 
+// FM (FM.java:93-113): score = w0 + w_u + w_j + xc*w_c + <Vu,Vj> + xc*<Vu,Vc> + xc*<Vj,Vc>  (context feature only if c < n_conds)
+//   b_j = [V[item j] | w[item j]],  a_q = [V[u] + xc*V[c] | 1],  row constant = w0 + w_u + xc*w_c + xc*<Vu,Vc>
+struct RankFmArgs {
+    const double *w0, *w, *V; // V: p x k row-major, p = n_users + n_items + n_conds
+    int k, kp, n_users, n_items, n_conds;
+    double xc;
+};
+hipError_t rank_launch_fm_items(const RankFmArgs &a, const int32_t *cand, int nc, double *B, hipStream_t s);
+hipError_t rank_launch_fm_queries(const RankFmArgs &a, const int32_t *qu, const int32_t *qc, int nq, double *A, double *row_const,
+                                  hipStream_t s);
+
 template <typename T>
 hipError_t rank_launch_build_items(const RankItemsArgs<T> &a, hipStream_t s);
 template <typename T>

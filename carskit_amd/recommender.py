@@ -304,8 +304,14 @@ class FM(ContextRecommender):
         w0, w, V = self.engine.get_model()
         self.state = {"w0": w0, "w": w, "V": V}
 
-    def evalRankings(self):
-        raise NotImplementedError("item.ranking for FM is not on the accelerated path (rating prediction only)")
+    def evalRankings(self):                                        # Recommender.java:668-964 with FM.predict
+        c, tr, te = self.conf, self.trainMatrix, self.testMatrix
+        if c.num_recs < 1:
+            raise ValueError("item.ranking -topN 0 (unbounded lists with a cut-off of 0) is not supported")
+        res = self.engine.eval_rankings((tr.u, tr.j, tr.ctx, tr.r), (te.u, te.j, te.ctx, te.r), c.bin_thold, c.num_recs,
+                                        c.num_ignore, "uc" if c.eval_strategy == "uc" else "ucu")
+        res.pop("n_queries", None)
+        return res
 
     def evalRatings(self):
         t = self.testMatrix

@@ -234,6 +234,13 @@ int cmi_fm_train(cmi_fm_handle h, int num_iters);
 int cmi_fm_predict_batch(cmi_fm_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                          int bound, double lo, double hi, double *out);
 int cmi_fm_synchronize(cmi_fm_handle h);
+/* Recommender.evalRankings (Recommender.java:668-964) with FM.predict (FM.java:93-113) as the scorer: arguments, outputs
+ * and semantics exactly as cmi_eval_rankings above */
+int cmi_fm_eval_rankings(cmi_fm_handle h, int64_t n_train, const int32_t *tu, const int32_t *tj, const int32_t *tctx,
+                         const double *tr, int64_t n_test, const int32_t *su, const int32_t *sj, const int32_t *sctx,
+                         const double *sr, double bin_thold, int num_recs, int num_ignore, int strategy, double out[21],
+                         int64_t *n_queries, int32_t *q_user, int32_t *q_ctx, int32_t *q_count, int32_t *top_items,
+                         double *top_scores);
 /* multi-GPU plumbing (no reference counterpart): a sweep is cmi_fm_num_phases() phases (0: w0; 1-3: w of the
  * user / item / context-feature field; 4+3f+field: column f of V).  phase_reduce leaves the local partial sums
  * [num(count/2) | den(count/2)] in a device buffer the host may all-reduce (ratings sharded across ranks),

@@ -157,3 +157,30 @@ def test_degenerate_inputs_and_errors():
         inst.eval_rankings(_arrays(train), _arrays(test), num_recs=0)
     with pytest.raises(capi.CmiError):
         inst.eval_rankings((train.u + 10_000, train.j, train.ctx, train.r), _arrays(test))
+
+
+@pytest.mark.parametrize("k,strategy", [(4, "ucu"), (33, "uc")])
+def test_fm_rankings_match_oracle(k, strategy):
+    """cmi_fm_eval_rankings: FM.predict (FM.java:93-113) as the scorer; the oracle ranks with the dense C restatement of
+    FM.predict after the same sweeps.  fp64 on both sides: identical lists, scores and measures to 1e-9 (the FM model
+    itself is held to 1e-8, tests/test_gpu_fm.py)."""
+    from tests.test_oracle_fm import REGLF, REGLW, fm_init_model
+    data = synth.generate(60, 90, 3, 3, 2500, seed=3)
+    train, test = synth.split(data, 0.25)
+    w0, w, V = fm_init_model(train.n_users, train.n_items, train.n_conds, k, 2)
+    orc = oracle_c.FMOracle(k, train.n_users, train.n_items, train.n_conds, train.n_dims, train.u, train.j, train.ctx, train.r,
+                            w0, w, V, REGLW, REGLF)
+    g = capi.FMInstance(k, train.n_users, train.n_items, train.n_conds, train.n_dims)
+    g.set_hparams(REGLW, REGLF)
+    g.set_ratings(train.u, train.j, train.ctx, train.r)
+    g.set_model(w0, w, V)
+    orc.init()
+    g.init()
+    for _ in range(2):
+        orc.sweep()
+        g.sweep()
+    ref, ref_lists = rank_oracle.eval_rankings(lambda u, j, c: orc.predict(u, j, c), _tuples(train), _tuples(test),
+                                               bin_thold=-5.0, num_recs=10, strategy=strategy)
+    res, lists = g.eval_rankings(_arrays(train), _arrays(test), bin_thold=-5.0, num_recs=10, strategy=strategy, with_lists=True)
+    assert len(ref_lists) > 20    # (the reference's FM regularises with size*reg: its scores sit far below the rating scale)
+    _assert_same(res, lists, ref, ref_lists, 1e-9, 1e-8)
