@@ -65,13 +65,15 @@ static void free_ratings(cmi_instance *h) {
         h->graph_exec = nullptr;
     }
     void *ptrs[] = {h->d_su, h->d_sj, h->d_sconds, h->d_ctx_ptr, h->d_ctx_conds, h->d_sr, h->d_loss_part,
-                    h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->d_tail_off};
+                    h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->d_tail_off, h->d_blk_off};
     for (void *p : ptrs)
         if (p) hipFree(p);
     h->d_su = h->d_sj = h->d_sconds = h->d_ctx_ptr = h->d_ctx_conds = nullptr;
     h->d_seq_u = h->d_seq_j = h->d_ver_u = h->d_ver_j = nullptr;
     h->d_flow_err = nullptr;
     h->d_tail_off = nullptr;
+    h->d_blk_off = nullptr;
+    h->blk_off.clear();
     h->n_launches = h->n_tail = 0;
     h->tail_len.clear();
     h->flow = false;
@@ -324,6 +326,26 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (h->serial) {
             sch.level_off = {0, n};
             sch.max_level = n;
+            // CAMF_C: conflict-free CRS blocks (consecutive tuples sharing no user and no item, <= 64) -- see sgd_camfc_blocks
+            h->blk_off.clear();
+            if (h->model == CMI_MODEL_CAMF_C && !h->strict && h->k <= 256 && dmax <= 16 && n > 0 && n < ((int64_t)1 << 31) &&
+                camfc_blocks_lds(h->n_conds, dmax, esize(h)) <= 64 * 1024 && !getenv("CMI_NO_CAMFC_BLOCKS")) {
+                std::vector<int32_t> seen_u((size_t)h->n_users, -1), seen_j((size_t)h->n_items, -1);
+                std::vector<int32_t> off{0};
+                int32_t cur = 0, len = 0;
+                for (int64_t t = 0; t < n; ++t) {
+                    if (len == 64 || seen_u[(size_t)u[t]] == cur || seen_j[(size_t)j[t]] == cur) {
+                        off.push_back((int32_t)t);
+                        ++cur;
+                        len = 0;
+                    }
+                    seen_u[(size_t)u[t]] = cur;
+                    seen_j[(size_t)j[t]] = cur;
+                    ++len;
+                }
+                off.push_back((int32_t)n);
+                if ((double)n / (double)(off.size() - 1) >= 3.0) h->blk_off.swap(off); // shorter runs: the serial wave is faster
+            }
         } else if (h->fast && exact_k && h->use_graph && h->want_two_lane && n > 0) {
             SplitSchedule ss;
             if (!build_split_schedule(n, u, j, h->n_users, h->n_items, ss))
@@ -446,6 +468,11 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // cp/cc are locals
     }
     if (e == hipSuccess && h->n_slots > 0) e = hipMalloc((void **)&h->d_loss_part, (size_t)h->n_slots * sizeof(double));
+    if (e == hipSuccess && !h->blk_off.empty()) {
+        e = hipMalloc((void **)&h->d_blk_off, h->blk_off.size() * sizeof(int32_t));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(h->d_blk_off, h->blk_off.data(), h->blk_off.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+    }
     if (e == hipSuccess && h->n_tail > 0) { // the tail launches read their level offsets from the device
         e = hipMalloc((void **)&h->d_tail_off, h->level_off.size() * sizeof(int64_t));
         if (e == hipSuccess)
@@ -475,7 +502,7 @@ extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[8]) {
     info[4] = sb;
     info[5] = h->tuple_bytes;
     info[6] = h->flow ? 2 : (h->serial ? 1 : (h->two_lane ? 3 : 0));
-    info[7] = h->flow ? h->flow_blocks : 0;
+    info[7] = h->flow ? h->flow_blocks : (h->d_blk_off ? (int64_t)h->blk_off.size() - 1 : 0);
     return CMI_OK;
 }
 
@@ -509,6 +536,11 @@ static hipError_t enqueue_levels(cmi_instance *h) {
     hipError_t e = hipSuccess;
     const int64_t n_levels = (int64_t)h->level_off.size() - 1;
     if (h->serial) {
+        if (h->d_blk_off) { // CAMF_C over conflict-free blocks
+            const int nb = (int)h->blk_off.size() - 1;
+            if (h->f64) return launch_camfc_blocks<double>(make_args<double>(h), h->d_blk_off, nb, h->d_loss, h->stream);
+            return launch_camfc_blocks<float>(make_args<float>(h), h->d_blk_off, nb, h->d_loss, h->stream);
+        }
         if (h->f64) return launch_serial<double>(make_args<double>(h), cfg, h->n, h->d_loss, h->stream);
         return launch_serial<float>(make_args<float>(h), cfg, h->n, h->d_loss, h->stream);
     }

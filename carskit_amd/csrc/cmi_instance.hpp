@@ -35,6 +35,8 @@ struct cmi_instance {
     int64_t n_launches = 0, n_tail = 0; // launches per epoch; levels that live inside narrow runs
     std::vector<int32_t> tail_len;      // per level: >0 = a narrow run of that many levels starts here (one launch), -1 = inside one
     int64_t *d_tail_off = nullptr;
+    std::vector<int32_t> blk_off; // CAMF_C: conflict-free CRS blocks (empty: the serial wave is used)
+    int32_t *d_blk_off = nullptr;
     int64_t n_slots = 0, max_level = 0, tuple_bytes = 0, sched_levels = 0;
     double *d_loss_part = nullptr, *d_scratch = nullptr, *d_loss = nullptr;
     cmi::HParams *d_hp = nullptr;

@@ -1619,6 +1619,153 @@ template hipError_t launch_level_generic<float>(const SgdArgs<float> &, const La
 template hipError_t launch_level_generic<double>(const SgdArgs<double> &, const LaunchCfg &, int64_t, int, int64_t,
                                                  hipStream_t);
 
+// ---------------------------------------------------------------------------------------------
+// CAMF_C, exact and (partly) parallel: conflict-free CRS blocks
+// ---------------------------------------------------------------------------------------------
+// condBias is read and written by EVERY rating, so CAMF_C's tuples form one dependent chain in CRS order.  But the
+// chain only runs through a scalar: with  base_t = ((gm + bu) + bj) + <P[u],Q[j]>  the tuple needs
+//     e_t = r_t - (base_t + b[c_1] + ... + b[c_D]),      b[c_d] += lr * (e_t - regC * b[c_d]),
+// and everything else (bu, bj, P[u], Q[j]) is an update scaled by e_t.  Inside a run of consecutive CRS tuples that share
+// no user and no item ("block", <= 64 tuples, found on the host) every base_t depends only on state from before the
+// block, so:   A  all base_t in parallel (gather + dot, rows stay in registers),
+//              B  one wave walks the block in CRS order doing only the scalar condBias recurrence (condBias lives in LDS),
+//              C  all row / bias updates in parallel from the registers.
+// Same values as the sequential loop (no algebraic re-association across tuples); only the dot's summation tree differs,
+// as in every non-strict kernel.  One 1024-thread workgroup = 64 sixteen-lane groups walks all blocks of the epoch.
+// Pays off when the CRS order is not sorted by user/item (the reference's DataTransformer emits HashMap order); short
+// blocks fall back to sgd_serial_fast.
+template <int W>
+__device__ __forceinline__ double group_sum_t(double x) {
+#pragma unroll
+    for (int m = W / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+template <int W>
+__device__ __forceinline__ float group_sum_t(float x) { return group_sum<W>(x); }
+
+template <typename T, int NV>
+__global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int32_t *__restrict__ blk_off, int n_blocks,
+                                                         double *loss_out) {
+    extern __shared__ unsigned char smem_raw[];
+    double *s_loss = reinterpret_cast<double *>(smem_raw);       // [64] per-group partials at the end
+    T *s_base = reinterpret_cast<T *>(s_loss + 64);               // [64] base_t, then e_t
+    T *s_r = s_base + 64;                                         // [64]
+    int32_t *s_conds = reinterpret_cast<int32_t *>(s_r + 64);     // [64 x dmax]
+    T *s_bc = reinterpret_cast<T *>(s_conds + 64 * (a.dmax > 0 ? a.dmax : 1)); // [n_conds] condBias, resident for the whole epoch
+    const int tid = threadIdx.x, l16 = tid & 15, g = tid >> 4;
+    const int k = a.k, dmax = a.dmax;
+    const HParams hp = *a.hp;
+    const T lr = (T)hp.lr, regU = (T)hp.regU, regI = (T)hp.regI, regB = (T)hp.regB, regC = (T)hp.regC, gm = (T)hp.gm;
+    for (int c = tid; c < a.n_conds; c += 1024) s_bc[c] = a.condBias[c];
+    double gloss = 0.0;  // groups: e^2-free parts (biases, factors); wave 0 lane 0: e^2 and the condBias term
+    int b0 = blk_off[0];
+    __syncthreads();
+    for (int blk = 0; blk < n_blocks; ++blk) {
+        const int b1 = blk_off[blk + 1];
+        const int cnt = b1 - b0; // <= 64: tuple g of the block belongs to group g
+        // ---- A: base_t, rows into registers
+        const bool live = g < cnt;
+        int uu = 0, jj = 0;
+        T p[NV], q[NV], bu = 0, bj = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) p[i] = q[i] = 0;
+        if (live) {
+            const int64_t t = (int64_t)b0 + g;
+            uu = a.su[t];
+            jj = a.sj[t];
+            if (l16 < dmax) s_conds[g * dmax + l16] = a.sconds[t * dmax + l16];
+            if (l16 == 0) s_r[g] = a.sr[t];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int f = l16 + 16 * i;
+                if (f < k) {
+                    p[i] = a.P[(size_t)uu * k + f];
+                    q[i] = a.Q[(size_t)jj * k + f];
+                }
+            }
+            bu = a.userBias[uu];
+            bj = a.itemBias[jj];
+        }
+        T part = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) part += p[i] * q[i];
+        const T dot = group_sum_t<16>(part);
+        if (live && l16 == 0) s_base[g] = ((gm + bu) + bj) + dot;
+        __syncthreads();
+        // ---- B: the scalar chain, wave 0, CRS order; lane d owns the tuple's d-th condition
+        if (tid < 64) {
+            double l = 0.0;
+            for (int t = 0; t < cnt; ++t) {
+                int cond = -1;
+                T bc = 0;
+                if (tid < dmax) cond = s_conds[t * dmax + tid];
+                if (cond >= 0) bc = s_bc[cond];
+                T pred = s_base[t];
+                T bc_sum = 0;
+                const unsigned long long present = __ballot(cond >= 0);
+                for (int d = 0; d < dmax; ++d) // the reference adds the deviations one by one, in condition order
+                    if ((present >> d) & 1ull) {
+                        const T v = rl(bc, d);
+                        pred += v;
+                        bc_sum += v; // plain sum, weighted by regB: reference quirk (CAMF_C.java:110,115)
+                    }
+                const T e = s_r[t] - pred;
+                if (cond >= 0) s_bc[cond] = bc + lr * (e - regC * bc);
+                if (tid == 0) s_base[t] = e; // base_t is consumed: the slot now carries e_t for phase C
+                l += (double)(e * e) + (double)(regB * bc_sum);
+            }
+            if (tid == 0) gloss += l;
+        }
+        __syncthreads();
+        // ---- C: everything scaled by e_t, from the registers
+        if (live) {
+            const T e = s_base[g];
+            T reg_part = 0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int f = l16 + 16 * i;
+                if (f < k) {
+                    const T pv = p[i], qv = q[i];
+                    a.P[(size_t)uu * k + f] = pv + lr * (e * qv - regU * pv);
+                    a.Q[(size_t)jj * k + f] = qv + lr * (e * pv - regI * qv);
+                    reg_part += (regU * pv) * pv + (regI * qv) * qv;
+                }
+            }
+            const T reg_sum = group_sum_t<16>(reg_part);
+            if (l16 == 0) {
+                a.userBias[uu] = bu + lr * (e - regB * bu);
+                a.itemBias[jj] = bj + lr * (e - regB * bj);
+                gloss += (double)((regB * bu) * bu) + (double)((regB * bj) * bj) + (double)reg_sum;
+            }
+        }
+        b0 = b1;
+        __syncthreads(); // this block's rows are visible (workgroup scope) before the next block gathers
+    }
+    if (l16 == 0) s_loss[g] = gloss;
+    __syncthreads();
+    for (int c = tid; c < a.n_conds; c += 1024) a.condBias[c] = s_bc[c];
+    if (tid == 0) {
+        double sum = 0.0;
+        for (int i = 0; i < 64; ++i) sum += s_loss[i];
+        loss_out[0] = sum * 0.5;
+    }
+}
+
+size_t camfc_blocks_lds(int n_conds, int dmax, size_t esize) {
+    return (size_t)n_conds * esize + 128 * esize + 64 * sizeof(double) + (size_t)64 * (dmax > 0 ? dmax : 1) * sizeof(int32_t) + 64;
+}
+
+template <typename T>
+hipError_t launch_camfc_blocks(const SgdArgs<T> &a, const int32_t *blk_off, int n_blocks, double *loss_out, hipStream_t s) {
+    const size_t lds = camfc_blocks_lds(a.n_conds, a.dmax, sizeof(T));
+    if (a.k <= 64) hipLaunchKernelGGL((sgd_camfc_blocks<T, 4>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
+    else if (a.k <= 128) hipLaunchKernelGGL((sgd_camfc_blocks<T, 8>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
+    else hipLaunchKernelGGL((sgd_camfc_blocks<T, 16>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
+    return hipGetLastError();
+}
+template hipError_t launch_camfc_blocks<float>(const SgdArgs<float> &, const int32_t *, int, double *, hipStream_t);
+template hipError_t launch_camfc_blocks<double>(const SgdArgs<double> &, const int32_t *, int, double *, hipStream_t);
+
 template <typename T, int MODEL>
 static hipError_t launch_serial_model(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t n, double *loss_out,
                                       hipStream_t s) {

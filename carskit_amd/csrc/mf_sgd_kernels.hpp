@@ -47,6 +47,11 @@ hipError_t launch_tail(const SgdArgs<T> &a, const LaunchCfg &cfg, const int64_t 
 // level launches the run replaces)
 hipError_t launch_tail_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, int kind, const int64_t *tail_off, int n_tail,
                            int64_t slot, hipStream_t s);
+// CAMF_C over conflict-free CRS blocks (<= 64 tuples sharing no user and no item; blk_off = n_blocks+1 device offsets):
+// exact, with the per-tuple gather/dot/update parallel inside a block and only the scalar condBias chain sequential
+size_t camfc_blocks_lds(int n_conds, int dmax, size_t esize);
+template <typename T>
+hipError_t launch_camfc_blocks(const SgdArgs<T> &a, const int32_t *blk_off, int n_blocks, double *loss_out, hipStream_t s);
 // small-k fast path (fp32 state, k < 64): 4 / 8 / 16 lanes per tuple
 bool has_small_path(int k, int dmax, bool f64, const LaunchCfg &cfg);
 int level_blocks_small(int k, int dmax, int count);

@@ -194,7 +194,8 @@ int cmi_last_loss(cmi_handle h, double *loss_out);
  * workgroup walks them),  info[1]=largest level, info[2]=tuples,
  * info[3]=max conditions per tuple (D), info[4]=state bytes on device, info[5]=tuple-stream bytes on device,
  * info[6]=schedule kind actually running (0 level launches, 1 serial, 2 dataflow, 3 two-lane level graph),
- * info[7]=workgroups of the dataflow launch (0 otherwise) */
+ * info[7]=workgroups of the dataflow launch; for CAMF_C the number of conflict-free CRS blocks its epoch is cut into
+ * (0: the serial wave) */
 int cmi_schedule_info(cmi_handle h, int64_t info[8]);
 /* GPU time of the most recent epoch's kernels measured with HIP events on cmi_stream() */
 int cmi_last_epoch_ms(cmi_handle h, float *ms);

@@ -25,11 +25,12 @@ def main():
         inst.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
         inst.set_states(state)
         inst.train_epoch(util.LR)
+        name += " (%d blocks)" % inst.schedule_info()["flow_blocks"] if inst.schedule_info()["flow_blocks"] else ""
         t0 = time.perf_counter()
         for _ in range(3):
             inst.train_epoch(util.LR)
         dt = (time.perf_counter() - t0) / 3
-        print("%-20s %.1f ms/epoch  %.2f M updates/s" % (name, dt * 1e3, data.n / dt / 1e6), flush=True)
+        print("%-34s %.1f ms/epoch  %.2f M updates/s" % (name, dt * 1e3, data.n / dt / 1e6), flush=True)
     orc = util.c_oracle("CAMF_C", data, k, state, gm)
     t0 = time.perf_counter()
     for _ in range(3):
