@@ -179,6 +179,40 @@ def test_camf_c_serial_f32():
     assert abs(oe["RMSE"] - ge["RMSE"]) <= 1e-5 and abs(oe["MAE"] - ge["MAE"]) <= 1e-5
 
 
+@pytest.mark.parametrize("k,n_dims,flags", [(3, 1, 0), (64, 4, 0), (130, 8, 0), (256, 16, 0), (10, 3, F64), (100, 5, F64)])
+def test_camf_c_conflict_free_blocks(k, n_dims, flags):
+    """CAMF_C through sgd_camfc_blocks (parallel gather/dot/update inside runs of CRS tuples sharing no user and no item,
+    sequential scalar condBias chain): bold-driver decisions and loss trajectory of the sequential oracle, RMSE/MAE
+    within 1e-5 (fp32 state) / 1e-9 (fp64 state); CMI_NO_CAMFC_BLOCKS (the serial wave) must agree too."""
+    data = util.small_data(n_users=900, n_items=700, n_dims=n_dims, conds_per_dim=3, n=9000, seed=33)
+    train, test = synth.split(data, 0.2)
+    orc, inst = make_pair("CAMF_C", train, k, SERIAL | flags)
+    info = inst.schedule_info()
+    assert info["kind"] == "serial" and info["flow_blocks"] > 0 and train.n / info["flow_blocks"] >= 3
+    o_losses, o_lrs, _ = orc.build_model(10, util.LR, bold_driver=True)
+    g_losses, g_lrs = inst.train(10, util.LR, bold_driver=True)
+    assert g_lrs.tolist() == o_lrs.tolist()
+    np.testing.assert_allclose(g_losses, o_losses, rtol=1e-10 if flags else 2e-5)
+    tol = 1e-9 if flags else 1e-5
+    oe = orc.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
+    ge = inst.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
+    assert abs(oe["RMSE"] - ge["RMSE"]) <= tol and abs(oe["MAE"] - ge["MAE"]) <= tol
+    assert_state_equal(orc, inst, exact=False, atol=1e-9 if flags else 2e-4)
+
+
+def test_camf_c_user_sorted_input_keeps_the_serial_wave():
+    # consecutive CRS tuples of one user: every conflict-free run has length 1 -> no blocks
+    data = util.small_data(n_users=40, n_items=300, n_dims=2, conds_per_dim=3, n=3000, seed=34)
+    order = np.lexsort((data.j, data.u))
+    import dataclasses
+    srt = dataclasses.replace(data, u=data.u[order], j=data.j[order], ctx=data.ctx[order], r=data.r[order])
+    orc, inst = make_pair("CAMF_C", srt, 16, SERIAL)
+    assert inst.schedule_info()["flow_blocks"] == 0
+    for _ in range(2):
+        lo, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
+        assert abs(lo - lg) <= 2e-5 * abs(lo)
+
+
 def test_predict_batch_and_bounds():
     data = util.small_data(n_users=50, n_items=20, n=500, seed=26)
     orc, inst = make_pair("CAMF_CUCI", data, 16, F64)
