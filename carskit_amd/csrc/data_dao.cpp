@@ -110,6 +110,37 @@ bool read_lines(const char *path, std::vector<std::string> &lines, std::string &
     return true;
 }
 
+// the same line structure without one std::string per line: (offset, length) spans into the file image
+bool read_spans(const char *path, std::string &all, std::vector<std::pair<size_t, size_t>> &spans, std::string &err) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) {
+        err = std::string("cannot open ") + path;
+        return false;
+    }
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    all.resize(sz > 0 ? (size_t)sz : 0);
+    const size_t got = all.empty() ? 0 : std::fread(&all[0], 1, all.size(), f);
+    std::fclose(f);
+    all.resize(got);
+    size_t i = 0, b = 0;
+    const size_t n = all.size();
+    while (i < n) {
+        const char c = all[i];
+        if (c == '\n' || c == '\r') {
+            spans.emplace_back(b, i - b);
+            ++i;
+            if (c == '\r' && i < n && all[i] == '\n') ++i;
+            b = i;
+        } else {
+            ++i;
+        }
+    }
+    if (b < n) spans.emplace_back(b, n - b);
+    return true;
+}
+
 // Double.valueOf(String): optional surrounding whitespace, optional trailing f/F/d/D, decimal or hex float,
 // "NaN", "Infinity" with optional sign
 bool jparse_double(const std::string &raw, double &out) {
@@ -167,6 +198,101 @@ bool jparse_int(const std::string &s, int32_t &out) {
     return true;
 }
 
+// first-seen id assignment keyed by raw byte strings (HashMap<String,Integer>.containsKey / put(key, size()) of the
+// reference, DataDAO.java:237-241,266-268,332-333): open addressing over the names vector, no per-lookup allocation
+class StrIndex {
+  public:
+    int32_t find_or_add(const char *p, size_t n, std::vector<std::string> &names) {
+        if ((names.size() + 1) * 2 > slots_.size()) grow(names);
+        const uint64_t h = hash(p, n);
+        size_t i = (size_t)h & (slots_.size() - 1);
+        while (slots_[i].id >= 0) {
+            if (slots_[i].h == h) {
+                const std::string &s = names[(size_t)slots_[i].id];
+                if (s.size() == n && std::memcmp(s.data(), p, n) == 0) return slots_[i].id;
+            }
+            i = (i + 1) & (slots_.size() - 1);
+        }
+        const int32_t id = (int32_t)names.size();
+        names.emplace_back(p, n);
+        slots_[i] = Slot{h, id};
+        return id;
+    }
+    void rebuild(const std::vector<std::string> &names) { // after the names were copied from another DAO
+        slots_.clear();
+        grow(names);
+    }
+
+  private:
+    static uint64_t hash(const char *p, size_t n) { // FNV-1a, 64 bit
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+        return h ^ (h >> 29);
+    }
+    void grow(const std::vector<std::string> &names) {
+        size_t cap = slots_.empty() ? 1024 : slots_.size() * 2;
+        while (cap < (names.size() + 1) * 2) cap *= 2;
+        slots_.assign(cap, Slot{0, -1});
+        for (size_t id = 0; id < names.size(); ++id) {
+            const uint64_t h = hash(names[id].data(), names[id].size());
+            size_t i = (size_t)h & (cap - 1);
+            while (slots_[i].id >= 0) i = (i + 1) & (cap - 1);
+            slots_[i] = Slot{h, (int32_t)id};
+        }
+    }
+    struct Slot {
+        uint64_t h;
+        int32_t id;
+    };
+    std::vector<Slot> slots_;
+};
+
+// (user, item) pair -> ui id, first seen (the reference keys a HashMap by the string "<u>,<i>" of inner ids)
+class PairIndex {
+  public:
+    // returns the id; *fresh tells whether the pair was new (then id == previous size)
+    int32_t find_or_add(uint64_t key, int32_t next_id, bool *fresh) {
+        if ((size_ + 1) * 2 > slots_.size()) grow();
+        size_t i = (size_t)mix(key) & (slots_.size() - 1);
+        while (slots_[i].id >= 0) {
+            if (slots_[i].key == key) {
+                *fresh = false;
+                return slots_[i].id;
+            }
+            i = (i + 1) & (slots_.size() - 1);
+        }
+        slots_[i] = Slot{key, next_id};
+        ++size_;
+        *fresh = true;
+        return next_id;
+    }
+
+  private:
+    static uint64_t mix(uint64_t x) {
+        x ^= x >> 33;
+        x *= 0xff51afd7ed558ccdull;
+        x ^= x >> 33;
+        return x;
+    }
+    struct Slot {
+        uint64_t key;
+        int32_t id;
+    };
+    void grow() {
+        std::vector<Slot> old;
+        old.swap(slots_);
+        slots_.assign(old.empty() ? 1024 : old.size() * 2, Slot{0, -1});
+        for (const Slot &s : old)
+            if (s.id >= 0) {
+                size_t i = (size_t)mix(s.key) & (slots_.size() - 1);
+                while (slots_[i].id >= 0) i = (i + 1) & (slots_.size() - 1);
+                slots_[i] = s;
+            }
+    }
+    std::vector<Slot> slots_;
+    size_t size_ = 0;
+};
+
 template <typename M>
 int32_t first_seen(M &m, std::vector<std::string> &names, const std::string &key) {
     auto it = m.find(key);
@@ -181,8 +307,11 @@ int32_t first_seen(M &m, std::vector<std::string> &names, const std::string &key
 
 struct cmi_dao {
     std::string err;
-    std::unordered_map<std::string, int32_t> user_ids, item_ids, ui_ids, ctx_ids, dim_ids;
-    std::vector<std::string> users, items, uis, ctxs, dims, conds; // inner id -> raw key
+    std::unordered_map<std::string, int32_t> dim_ids;
+    StrIndex user_ids, item_ids, ctx_ids;           // first-seen ids over users / items / ctxs
+    PairIndex ui_ids;                               // (user << 32 | item) -> ui id; the reference keys the string "u,i"
+    std::vector<std::string> users, items, ctxs, dims, conds; // inner id -> raw key
+    mutable std::string scratch;                    // cmi_dao_raw_id(kind 5) formats "u,i" on demand
     std::vector<int32_t> ui_user, ui_item, cond_dim, empty_conds;
     std::vector<std::vector<int32_t>> ctx_cond_list;
     std::vector<double> rating_scale;
@@ -207,23 +336,23 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
         g_dao_err = "cmi_dao_read: null argument";
         return CMI_E_INVALID;
     }
-    std::vector<std::string> lines;
-    if (!read_lines(path, lines, g_dao_err)) return CMI_E_INVALID;
+    std::string image;
+    std::vector<std::pair<size_t, size_t>> lines; // spans into `image`
+    if (!read_spans(path, image, lines, g_dao_err)) return CMI_E_INVALID;
     if (lines.empty()) {
         g_dao_err = "cmi_dao_read: empty file (the reference dereferences a null header line)";
         return CMI_E_INVALID;
     }
     cmi_dao *d = new cmi_dao();
     if (base) { // `test-set`: the test DAO is constructed over the TRAIN DAO's maps (CARSKit.java:335-340) and extends them
-        d->user_ids = base->user_ids;
-        d->item_ids = base->item_ids;
         d->ui_ids = base->ui_ids;
-        d->ctx_ids = base->ctx_ids;
         d->dim_ids = base->dim_ids;
         d->users = base->users;
         d->items = base->items;
-        d->uis = base->uis;
         d->ctxs = base->ctxs;
+        d->user_ids.rebuild(d->users);
+        d->item_ids.rebuild(d->items);
+        d->ctx_ids.rebuild(d->ctxs);
         d->dims = base->dims;
         d->conds = base->conds;
         d->cond_dim = base->cond_dim;
@@ -233,7 +362,7 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
     }
     // header (DataDAO.java:198-215): trim, split on runs of tab/comma, columns >= 3 are conditions
     {
-        const std::vector<std::string> hd = split_runs(jtrim(lines[0]));
+        const std::vector<std::string> hd = split_runs(jtrim(image.substr(lines[0].first, lines[0].second)));
         for (size_t i = 3; i < hd.size(); ++i) {
             const std::string context = jtrim(hd[i]);
             const size_t colon = context.find(':');
@@ -258,49 +387,95 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
         }
     }
     const int32_t n_conds = (int32_t)d->conds.size();
-    // data lines (DataDAO.java:222-345); dataTable.put(uic, cc, rate): the LAST line of a (ui, ctx) cell wins
-    std::map<std::pair<int32_t, int32_t>, double> table; // ordered by (ui, ctx) = CRS order
+    // data lines (DataDAO.java:222-345); dataTable.put(uic, cc, rate): the LAST line of a (ui, ctx) cell wins.
+    // Fields are scanned in place (no per-line allocations); the general Double.valueOf / Integer.valueOf restatements
+    // are only called for tokens that are not plain digits.
+    struct Cell {
+        uint64_t key; // ui << 32 | ctx  (CRS order = ascending key)
+        double rate;
+    };
+    std::vector<Cell> cells;
+    cells.reserve(lines.size());
     std::vector<double> scale;
+    std::vector<int32_t> cond_list;
+    std::string ctx;
     for (size_t ln = 1; ln < lines.size(); ++ln) {
-        const std::vector<std::string> data = split_keep(jtrim(lines[ln]), ',');
-        if (data.size() < 3) {
+        const char *const raw = image.data() + lines[ln].first;
+        // line.trim(): strip chars <= ' ' at both ends
+        size_t lb = 0, le = lines[ln].second;
+        while (lb < le && (unsigned char)raw[lb] <= ' ') ++lb;
+        while (le > lb && (unsigned char)raw[le - 1] <= ' ') --le;
+        const char *p = raw + lb, *const end = raw + le;
+        // split(",", -1): every comma separates, empties kept
+        auto next_field = [&](const char *&fb, const char *&fe) -> bool {
+            if (p > end) return false;
+            fb = p;
+            const char *c = (const char *)std::memchr(p, ',', (size_t)(end - p));
+            fe = c ? c : end;
+            p = fe + 1; // one past the comma; > end after the last field
+            return true;
+        };
+        const char *ub, *ue, *ib, *ie, *rb, *re;
+        if (!next_field(ub, ue) || !next_field(ib, ie) || !next_field(rb, re)) {
             d->err = "line " + std::to_string(ln + 1) + ": fewer than 3 fields (ArrayIndexOutOfBounds in the reference)";
             g_dao_err = d->err;
             delete d;
             return CMI_E_INVALID;
         }
-        double rate;
-        if (!jparse_double(data[2], rate)) {
-            g_dao_err = "line " + std::to_string(ln + 1) + ": rating '" + data[2] + "' is not a number (NumberFormatException)";
-            delete d;
-            return CMI_E_INVALID;
+        double rate = 0.0;
+        {
+            bool simple = re > rb && re - rb <= 15; // [0-9]+ ( . [0-9]+ )? : exact in double for <= 15 digits
+            int64_t ip = 0, fp = 0, fdig = 0;
+            const char *c = rb;
+            for (; simple && c < re && *c >= '0' && *c <= '9'; ++c) ip = ip * 10 + (*c - '0');
+            if (simple && c == rb) simple = false;
+            if (simple && c < re && *c == '.') {
+                ++c;
+                const char *f0 = c;
+                for (; c < re && *c >= '0' && *c <= '9'; ++c, ++fdig) fp = fp * 10 + (*c - '0');
+                if (c == f0) simple = false;
+            }
+            if (simple && c == re && fdig == 0) rate = (double)ip;
+            else if (!jparse_double(std::string(rb, re), rate)) { // everything else: the Double.valueOf restatement
+                g_dao_err = "line " + std::to_string(ln + 1) + ": rating '" + std::string(rb, re) + "' is not a number (NumberFormatException)";
+                delete d;
+                return CMI_E_INVALID;
+            }
         }
         scale.push_back(rate);
         d->num_ratings++;
-        const int32_t row = first_seen(d->user_ids, d->users, data[0]); // NOT trimmed (DataDAO.java:226-227)
-        const int32_t col = first_seen(d->item_ids, d->items, data[1]);
-        const std::string useritem = std::to_string(row) + "," + std::to_string(col);
-        const int32_t uic = first_seen(d->ui_ids, d->uis, useritem);
-        if ((size_t)uic == d->ui_user.size()) {
+        const int32_t row = d->user_ids.find_or_add(ub, (size_t)(ue - ub), d->users); // NOT trimmed (DataDAO.java:226-227)
+        const int32_t col = d->item_ids.find_or_add(ib, (size_t)(ie - ib), d->items);
+        const uint64_t uikey = ((uint64_t)(uint32_t)row << 32) | (uint32_t)col;
+        bool fresh = false;
+        const int32_t uic = d->ui_ids.find_or_add(uikey, (int32_t)d->ui_user.size(), &fresh);
+        if (fresh) {
             d->ui_user.push_back(row);
             d->ui_item.push_back(col);
         }
-        std::string ctx;
-        std::vector<int32_t> cond_list;
-        for (size_t i = 3; i < data.size(); ++i) {
+        ctx.clear();
+        cond_list.clear();
+        const char *fb, *fe;
+        for (int32_t ci = 0; next_field(fb, fe); ++ci) {
             int32_t value;
-            if (!jparse_int(jtrim(data[i]), value)) {
-                g_dao_err = "line " + std::to_string(ln + 1) + ": condition flag '" + data[i] + "' is not an integer (NumberFormatException)";
+            while (fb < fe && (unsigned char)*fb <= ' ') ++fb; // data[i].trim()
+            while (fe > fb && (unsigned char)fe[-1] <= ' ') --fe;
+            if (fe - fb == 1 && (*fb == '0' || *fb == '1')) value = *fb - '0';
+            else if (!jparse_int(std::string(fb, fe), value)) {
+                g_dao_err = "line " + std::to_string(ln + 1) + ": condition flag '" + std::string(fb, fe) + "' is not an integer (NumberFormatException)";
                 delete d;
                 return CMI_E_INVALID;
             }
             if (value == 1) {
-                if (!ctx.empty()) ctx += ",";
-                ctx += std::to_string(i - 3);
-                cond_list.push_back((int32_t)i - 3);
+                if (!ctx.empty()) ctx += ',';
+                char num[12];
+                int nd = 0, v = ci;
+                do num[nd++] = (char)('0' + v % 10); while ((v /= 10) > 0);
+                while (nd > 0) ctx += num[--nd];
+                cond_list.push_back(ci);
             }
         }
-        const int32_t cc = first_seen(d->ctx_ids, d->ctxs, ctx);
+        const int32_t cc = d->ctx_ids.find_or_add(ctx.data(), ctx.size(), d->ctxs);
         if ((size_t)cc == d->ctx_cond_list.size()) d->ctx_cond_list.push_back(cond_list);
         else d->ctx_cond_list[(size_t)cc] = cond_list; // contextConditionsList.put(cc, condList): same list by construction
         for (int32_t c : cond_list)
@@ -309,17 +484,20 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
                 delete d;
                 return CMI_E_INVALID;
             }
-        table[{uic, cc}] = rate;
+        cells.push_back(Cell{((uint64_t)(uint32_t)uic << 32) | (uint32_t)cc, rate});
     }
     // ratingScale: sorted distinct values (DataDAO.java:348-350)
     std::sort(scale.begin(), scale.end());
     scale.erase(std::unique(scale.begin(), scale.end()), scale.end());
     d->rating_scale = scale;
-    d->m_ui.reserve(table.size());
-    for (auto &kv : table) {
-        d->m_ui.push_back(kv.first.first);
-        d->m_ctx.push_back(kv.first.second);
-        d->m_r.push_back(kv.second);
+    // CRS order; a stable sort keeps the file order inside a cell, whose LAST entry wins
+    std::stable_sort(cells.begin(), cells.end(), [](const Cell &x, const Cell &y) { return x.key < y.key; });
+    d->m_ui.reserve(cells.size());
+    for (size_t i = 0; i < cells.size(); ++i) {
+        if (i + 1 < cells.size() && cells[i + 1].key == cells[i].key) continue;
+        d->m_ui.push_back((int32_t)(cells[i].key >> 32));
+        d->m_ctx.push_back((int32_t)(cells[i].key & 0xffffffffu));
+        d->m_r.push_back(cells[i].rate);
     }
     *out = d;
     return CMI_OK;
@@ -339,7 +517,7 @@ extern "C" int cmi_dao_counts(cmi_dao_handle h, int64_t out[8]) {
     if (!h || !out) return CMI_E_INVALID;
     out[0] = (int64_t)h->users.size();
     out[1] = (int64_t)h->items.size();
-    out[2] = (int64_t)h->uis.size();
+    out[2] = (int64_t)h->ui_user.size();
     out[3] = (int64_t)h->ctxs.size();
     out[4] = (int64_t)h->conds.size();
     out[5] = (int64_t)h->dims.size();
@@ -415,7 +593,10 @@ extern "C" const char *cmi_dao_raw_id(cmi_dao_handle h, int kind, int32_t idx) {
     case 2: v = &h->conds; break;
     case 3: v = &h->ctxs; break;
     case 4: v = &h->dims; break;
-    case 5: v = &h->uis; break;
+    case 5: // the reference's key string of a (user, item) pair: inner ids joined by ',' (DataDAO.java:266)
+        if ((size_t)idx >= h->ui_user.size()) return nullptr;
+        h->scratch = std::to_string(h->ui_user[(size_t)idx]) + "," + std::to_string(h->ui_item[(size_t)idx]);
+        return h->scratch.c_str();
     default: return nullptr;
     }
     return (size_t)idx < v->size() ? (*v)[(size_t)idx].c_str() : nullptr;
