@@ -51,6 +51,8 @@ SYMBOLS = [
                             C.POINTER(_dbl)]),
     ("cmi_predict_batch", C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, _dbl, _dbl, _vp]),
     ("cmi_eval_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, C.POINTER(_i64)]),
+    ("cmi_set_eval_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    ("cmi_eval_resident", C.c_int, [_vp, _dbl, _dbl, _vp, C.POINTER(_i64)]),
     ("cmi_eval_rankings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int, C.c_int,
                                     C.c_int, _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
     ("cmi_fm_eval_rankings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int, C.c_int,
@@ -364,6 +366,20 @@ class Instance:
         out, cnt = np.zeros(5), _i64()
         self._chk(self.L.cmi_eval_ratings(self.h, len(r), _p(u), _p(j), _p(ctx), _p(r), min_rate, max_rate, _p(out),
                                           C.byref(cnt)))
+        res = dict(zip(("MAE", "RMSE", "NMAE", "rMAE", "rRMSE"), out.tolist()))
+        res["n"] = cnt.value
+        return res
+
+    def set_eval_ratings(self, u, j, ctx, r):
+        """Keep the test tuples on the device for per-epoch evaluation (`--early-stop MAE|RMSE`)."""
+        c32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        u, j, ctx = c32(u), c32(j), c32(ctx)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        self._chk(self.L.cmi_set_eval_ratings(self.h, len(r), _p(u), _p(j), _p(ctx), _p(r)))
+
+    def eval_resident(self, min_rate, max_rate):
+        out, cnt = np.zeros(5), _i64()
+        self._chk(self.L.cmi_eval_resident(self.h, min_rate, max_rate, _p(out), C.byref(cnt)))
         res = dict(zip(("MAE", "RMSE", "NMAE", "rMAE", "rRMSE"), out.tolist()))
         res["n"] = cnt.value
         return res

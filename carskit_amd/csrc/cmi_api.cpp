@@ -88,6 +88,11 @@ extern "C" int cmi_destroy(cmi_handle h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     free_ratings(h);
+    {
+        void *ev[] = {h->d_eu, h->d_ej, h->d_ectx, h->d_er, h->d_epart};
+        for (void *p : ev)
+            if (p) hipFree(p);
+    }
     for (void *&p : h->state)
         if (p) {
             hipFree(p);
@@ -854,6 +859,77 @@ extern "C" int cmi_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const
 }
 
 // ---- host-only schedule export ------------------------------------------------------------------------
+
+// ---- resident test tuples: `--early-stop MAE|RMSE` evaluates the test set after EVERY epoch (IterativeRecommender.java:
+// 156-161); uploading it once instead of per call keeps that loop on the device
+static void free_eval_set(cmi_instance *h) {
+    void *ptrs[] = {h->d_eu, h->d_ej, h->d_ectx, h->d_er, h->d_epart};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    h->d_eu = h->d_ej = h->d_ectx = nullptr;
+    h->d_er = h->d_epart = nullptr;
+    h->n_eval = 0;
+}
+
+extern "C" int cmi_set_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
+                                    const double *r) {
+    if (!h) return CMI_E_INVALID;
+    const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF;
+    if (n < 0 || (n > 0 && (!u || !j || !r || (contextual && !ctx)))) CMI_FAIL(h, CMI_E_INVALID, "set_eval_ratings: null arrays");
+    if (contextual && !h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "set_eval_ratings: the context table comes from cmi_set_ratings; call it first");
+    for (int64_t t = 0; t < n; ++t) {
+        if (u[t] < 0 || u[t] >= h->n_users || j[t] < 0 || j[t] >= h->n_items)
+            CMI_FAIL(h, CMI_E_INVALID, "set_eval_ratings: user/item id out of range at tuple %lld", (long long)t);
+        if (contextual && (ctx[t] < 0 || ctx[t] >= h->n_ctx))
+            CMI_FAIL(h, CMI_E_INVALID, "set_eval_ratings: context id %d out of range at tuple %lld", ctx[t], (long long)t);
+    }
+    CMI_HIP(h, hipSetDevice(h->device));
+    CMI_HIP(h, hipStreamSynchronize(h->stream));
+    free_eval_set(h);
+    if (n == 0) return CMI_OK;
+    hipError_t e = hipMalloc((void **)&h->d_eu, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_ej, (size_t)n * 4);
+    if (e == hipSuccess && contextual) e = hipMalloc((void **)&h->d_ectx, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_er, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_epart, (size_t)eval_blocks(n) * 5 * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->d_eu, u, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->d_ej, j, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && contextual) e = hipMemcpyAsync(h->d_ectx, ctx, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->d_er, r, (size_t)n * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        free_eval_set(h);
+        CMI_FAIL(h, CMI_E_HIP, "set_eval_ratings: %s", hipGetErrorString(e));
+    }
+    h->n_eval = n;
+    return CMI_OK;
+}
+
+extern "C" int cmi_eval_resident(cmi_handle h, double min_rate, double max_rate, double out[5], int64_t *count) {
+    if (!h || !out) return CMI_E_INVALID;
+    if (h->n_eval <= 0) CMI_FAIL(h, CMI_E_INVALID, "eval_resident: call cmi_set_eval_ratings first");
+    CMI_HIP(h, hipSetDevice(h->device));
+    const int64_t n = h->n_eval;
+    const int blocks = eval_blocks(n);
+    std::vector<double> part((size_t)blocks * 5);
+    hipError_t e = h->f64 ? run_eval<double>(h, n, h->d_eu, h->d_ej, h->d_ectx, h->d_er, nullptr, h->d_epart, 1, min_rate, max_rate, min_rate)
+                          : run_eval<float>(h, n, h->d_eu, h->d_ej, h->d_ectx, h->d_er, nullptr, h->d_epart, 1, min_rate, max_rate, min_rate);
+    if (e == hipSuccess) e = hipMemcpyAsync(part.data(), h->d_epart, part.size() * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    CMI_HIP(h, e);
+    double sums[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < blocks; ++b)
+        for (int c = 0; c < 5; ++c) sums[c] += part[(size_t)b * 5 + c];
+    const double cnt = sums[4];
+    const double mae = sums[0] / cnt;
+    out[0] = mae;
+    out[1] = std::sqrt(sums[1] / cnt);
+    out[2] = mae / (max_rate - min_rate);
+    out[3] = sums[2] / cnt;
+    out[4] = std::sqrt(sums[3] / cnt);
+    if (count) *count = (int64_t)cnt;
+    return CMI_OK;
+}
 
 extern "C" int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
                                   int order, int32_t *perm, int64_t *level_off, int64_t level_cap,

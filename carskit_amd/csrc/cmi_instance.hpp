@@ -46,6 +46,10 @@ struct cmi_instance {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_ratings = false, epoch_timed = false;
     double last_loss = 0.0;
+    // resident test tuples (cmi_set_eval_ratings)
+    int32_t *d_eu = nullptr, *d_ej = nullptr, *d_ectx = nullptr;
+    double *d_er = nullptr, *d_epart = nullptr;
+    int64_t n_eval = 0;
     float last_rank_ms = 0.f;    // device time of the most recent cmi_eval_rankings scoring loop (HIP events)
     double last_rank_flops = 0.0; // 2 * queries * candidates * padded operand length of that loop
 };

@@ -277,6 +277,12 @@ class IterativeRecommender {
         }
         for (auto &kv : state) // copy-in
             check(cmi_set_state(h_, kv.first, kv.second.data(), (int64_t)kv.second.size(), CMI_DTYPE_F64), h_, "cmi_set_state");
+        if (conf_.earlyStop == "MAE" || conf_.earlyStop == "RMSE") { // evaluated after every epoch: keep the test tuples on the device
+            check(cmi_set_eval_ratings(h_, testMatrix.n(), testMatrix.u.data(), testMatrix.j.data(),
+                                       isCARS_ ? testMatrix.ctx.data() : nullptr, testMatrix.r.data()),
+                  h_, "cmi_set_eval_ratings");
+            evalResident_ = testMatrix.n() > 0;
+        }
         for (int iter = 1; iter <= conf_.numIters; ++iter) {
             check(cmi_train_epoch(h_, lRate, &loss), h_, "cmi_train_epoch"); // the for(MatrixEntry me : trainMatrix) body
             losses.push_back(loss);
@@ -289,6 +295,9 @@ class IterativeRecommender {
     virtual Measures evalRatings() { // Recommender.java:504-594 (numeric part)
         double out[5] = {0, 0, 0, 0, 0};
         int64_t cnt = 0;
+        if (evalResident_)
+            check(cmi_eval_resident(h_, trainMatrix.min_rate, trainMatrix.max_rate, out, &cnt), h_, "cmi_eval_resident");
+        else
         check(cmi_eval_ratings(h_, testMatrix.n(), testMatrix.u.data(), testMatrix.j.data(),
                                isCARS_ ? testMatrix.ctx.data() : nullptr, testMatrix.r.data(), trainMatrix.min_rate,
                                trainMatrix.max_rate, out, &cnt),
@@ -373,6 +382,7 @@ class IterativeRecommender {
 
     std::string algoName;
     Measures measures;
+    bool evalResident_ = false;
     std::map<int, std::vector<double>> state; // CMI_STATE_* -> container (P, Q, userBias, ...)
     std::vector<double> losses;
     double lRate = 0, loss = 0, last_loss = 0, measure = 0, last_measure = 0, globalMean = 0;

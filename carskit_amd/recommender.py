@@ -114,6 +114,13 @@ class GpuEngine:
     def eval_rankings(self, train, test, bin_thold, num_recs, num_ignore, strategy):
         return self.inst.eval_rankings(train, test, bin_thold, num_recs, num_ignore, strategy)
 
+    def set_eval_ratings(self, u, j, ctx, r):      # test tuples resident on the device (per-epoch early-stop evaluation)
+        self.inst.set_eval_ratings(u, j, ctx, r)
+        self.eval_resident_ready = True
+
+    def eval_resident(self, lo, hi):
+        return self.inst.eval_resident(lo, hi)
+
 
 class Recommender:
     """carskit.generic.Recommender (src/carskit/generic/Recommender.java)."""
@@ -143,8 +150,11 @@ class Recommender:
 
     def evalRatings(self):
         t = self.testMatrix
-        tu, tj, tc, tr = self.test_tuples()
-        res = self.engine.eval_ratings(tu, tj, tc, tr, self.minRate, self.maxRate)
+        if getattr(self.engine, "eval_resident_ready", False):
+            res = self.engine.eval_resident(self.minRate, self.maxRate)
+        else:
+            tu, tj, tc, tr = self.test_tuples()
+            res = self.engine.eval_ratings(tu, tj, tc, tr, self.minRate, self.maxRate)
         res["MPE"] = 0.0                                           # numPEs is never incremented (:569)
         return res
 
@@ -209,6 +219,8 @@ class IterativeRecommender(Recommender):
         self.engine = self.engine_factory(self.algo_name, self.numFactors, self.trainMatrix, self.train_tuples(), hp,
                                           flags=self.conf.flags, device=self.device)
         self.engine.set_states(self.state)                          # copy-in
+        if self.conf.early_stop in ("MAE", "RMSE") and hasattr(self.engine, "set_eval_ratings"):
+            self.engine.set_eval_ratings(*self.test_tuples())       # evaluated after every epoch: keep it on the device
         for it in range(1, self.numIters + 1):
             self.lrates.append(self.lRate)
             self.loss = self.engine.epoch(self.lRate)               # the for(MatrixEntry me : trainMatrix) body

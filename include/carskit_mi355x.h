@@ -145,6 +145,11 @@ int cmi_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j
 
 /* ---- plumbing for the host layer (multi-GPU exchange, measurement); no reference counterpart ---- */
 
+/* `--early-stop MAE|RMSE` evaluates the test set after every epoch (IterativeRecommender.java:156-161): upload the test tuples
+ * once, then evaluate from device memory.  Same numbers as cmi_eval_ratings on the same tuples. */
+int cmi_set_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r);
+int cmi_eval_resident(cmi_handle h, double min_rate, double max_rate, double out[5], int64_t *count);
+
 /* ---- top-N ranking evaluation: Recommender.evalRankings (src/carskit/generic/Recommender.java:668-964) ----------
  * The reference scores every candidate item for every test (user, context) pair with one predict() call each
  * (O(queries x items x k)); here that scoring is one dense contraction per query batch plus a fused top-N selection

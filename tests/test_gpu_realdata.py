@@ -55,6 +55,34 @@ def test_item_ranking_depaul_on_gpu_matches_golden(tmp_path):
             assert abs(a.measures[m] - v) <= 0.02, (m, a.measures[m], v)
 
 
+def test_early_stop_rmse_uses_the_resident_test_set(tmp_path):
+    """`--early-stop RMSE`: the test tuples stay on the device and are evaluated after every epoch
+    (IterativeRecommender.java:156-161).  Same stopping iteration and measures as the oracle-driven host loop, in
+    fp64/strict mode to 1e-12; resident and per-call evaluation agree exactly."""
+    import re
+    import subprocess
+    from tests.test_host_layer import EXE, _depaul_conf
+    conf = _depaul_conf(tmp_path)
+    txt = open(conf).read().replace("--test-view all", "--test-view all --early-stop RMSE")
+    open(conf, "w").write(txt)
+    over = {"num_iters": 40}
+    _, ref_algos, _ = main.run(conf, engine_factory=util.OracleEngine, log=lambda *a: None, conf_overrides=over)
+    _, algos, _ = main.run(conf, log=lambda *a: None,
+                           conf_overrides=dict(over, flags=capi.FLAG_STATE_F64 | capi.FLAG_STRICT | capi.FLAG_SCHED_SERIAL))
+    for a, b in zip(algos, ref_algos):
+        assert a.conf.early_stop == "RMSE" and getattr(a.engine, "eval_resident_ready", False)
+        assert len(a.losses) == len(b.losses)                     # stopped at the same iteration
+        assert abs(a.measures["RMSE"] - b.measures["RMSE"]) <= 1e-12 and abs(a.measure - b.measure) <= 1e-12
+    a = algos[0]
+    t = a.testMatrix
+    direct = a.engine.inst.eval_ratings(t.u, t.j, None, t.r, a.minRate, a.maxRate)
+    assert direct == a.engine.eval_resident(a.minRate, a.maxRate)
+    # the C++ host takes the same path
+    flags = capi.FLAG_STATE_F64 | capi.FLAG_STRICT | capi.FLAG_SCHED_SERIAL
+    p = subprocess.run([EXE, "-c", conf, "--iters", "40", "--flags", str(flags), "--precise"], capture_output=True, text=True)
+    assert p.returncode == 0 and re.search(r"PRECISE BiasedMF folds=5 MAE=(\S+) RMSE=(\S+)", p.stdout), p.stderr
+
+
 def frappe_shaped(seed=7):
     """957 users x 4 082 items, 8 context dimensions with Frappe's cardinalities, ~96K ratings."""
     rng = np.random.default_rng(seed)
