@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the GPU path against the C oracle on random small problems (every model, random k / dims / sizes /
+item skew / flags).  fp64+strict: model state must be bit-identical; fp32: loss within 2e-5 and state within 2e-4.
+usage: tools/fuzz_gpu.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from carskit_amd import capi, synth  # noqa: E402
+from oracle import oracle_c  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    F64, SERIAL, STRICT, NOGRAPH = capi.FLAG_STATE_F64, capi.FLAG_SCHED_SERIAL, capi.FLAG_STRICT, capi.FLAG_NO_GRAPH
+    bad = 0
+    for case in range(n_cases):
+        model = util.MODELS[rng.integers(len(util.MODELS))]
+        k = int(rng.choice([1, 2, 5, 10, 16, 31, 64, 70, 100, 128, 130, 256]))
+        n_dims = int(rng.integers(0 if model in util.TWO_D else 1, 7))
+        n_users, n_items = int(rng.integers(3, 400)), int(rng.integers(2, 300))
+        n = int(rng.integers(1, 6000))
+        zipf = float(rng.choice([0, 0, 1.1, 1.5]))
+        data = synth.generate(n_users, n_items, n_dims, int(rng.integers(1, 5)), n, seed=int(rng.integers(1 << 30)),
+                              item_zipf=zipf or None)
+        mode = rng.integers(3)
+        flags = (F64 | STRICT) if mode == 0 else (F64 if mode == 1 else 0)
+        if model == "CAMF_C" or rng.random() < 0.15:
+            flags |= SERIAL
+        if rng.random() < 0.2:
+            flags |= NOGRAPH
+        state = synth.init_state(model, data, k, seed=int(rng.integers(1 << 30)))
+        gm = oracle_c.global_mean(data.r)
+        orc = util.c_oracle(model, data, k, state, gm)
+        u, j, ctx, r = util.tuples_for(model, data)
+        inst = capi.Instance(model, k, data.n_users, data.n_items, data.n_conds, flags=flags)
+        inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, gm)
+        if model in util.TWO_D:
+            inst.set_ratings(u, j, None, r)
+        else:
+            inst.set_ratings(u, j, ctx, r, data.ctx_ptr, data.ctx_conds)
+        inst.set_states(state)
+        ok = True
+        for _ in range(int(rng.integers(1, 4))):
+            lo, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
+            tol = 1e-12 if flags & F64 and flags & STRICT else (1e-9 if flags & F64 else 3e-5)
+            if not abs(lo - lg) <= tol * max(1.0, abs(lo)):
+                ok = False
+        for name, a in inst.get_states().items():
+            ref = orc.state[name].reshape(a.shape)
+            if flags & F64 and flags & STRICT:
+                ok &= bool(np.array_equal(ref, a))
+            else:
+                ok &= bool(np.max(np.abs(ref - a), initial=0.0) <= (1e-9 if flags & F64 else 3e-4))
+        if not ok:
+            bad += 1
+            print("MISMATCH case %d: %s k=%d dims=%d users=%d items=%d n=%d zipf=%s flags=%#x info=%s"
+                  % (case, model, k, n_dims, n_users, n_items, data.n, zipf, flags, inst.schedule_info()), flush=True)
+    print("%d cases, %d mismatches" % (n_cases, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
