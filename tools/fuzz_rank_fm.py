@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Differential fuzz of cmi_eval_rankings (fp64 state) and of the FM sweep against their oracles on random small problems.
+usage: tools/fuzz_rank_fm.py [n_cases] [seed]"""
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from carskit_amd import capi, synth  # noqa: E402
+from oracle import oracle_c, rank_oracle  # noqa: E402
+from tests import util  # noqa: E402
+from tests.test_oracle_fm import REGLF, REGLW, fm_init_model  # noqa: E402
+
+
+def tuples(d):
+    return list(zip(d.u.tolist(), d.j.tolist(), d.ctx.tolist(), d.r.tolist()))
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0
+    for case in range(n_cases):
+        n_users, n_items = int(rng.integers(3, 120)), int(rng.integers(3, 400))
+        n_dims = int(rng.integers(1, 5))
+        data = synth.generate(n_users, n_items, n_dims, int(rng.integers(1, 4)), int(rng.integers(20, 3000)),
+                              seed=int(rng.integers(1 << 30)), item_zipf=float(rng.choice([0, 1.2])) or None)
+        train, test = synth.split(data, 0.3, seed=int(rng.integers(1 << 30)))
+        if train.n == 0 or test.n == 0:
+            continue
+        k = int(rng.choice([1, 4, 10, 33, 64]))
+        kw = dict(bin_thold=float(rng.choice([-1.0, 2.5, 3.5])), num_recs=int(rng.choice([1, 3, 10, 40, 70])),
+                  num_ignore=int(rng.choice([0, 0, 2])), strategy=str(rng.choice(["ucu", "uc"])))
+        if rng.random() < 0.3:   # FM
+            w0, w, V = fm_init_model(train.n_users, train.n_items, train.n_conds, k, int(rng.integers(100)))
+            orc = oracle_c.FMOracle(k, train.n_users, train.n_items, train.n_conds, train.n_dims, train.u, train.j, train.ctx,
+                                    train.r, w0, w, V, REGLW, REGLF)
+            g = capi.FMInstance(k, train.n_users, train.n_items, train.n_conds, train.n_dims)
+            g.set_hparams(REGLW, REGLF)
+            g.set_ratings(train.u, train.j, train.ctx, train.r)
+            g.set_model(w0, w, V)
+            orc.init()
+            g.init()
+            for _ in range(int(rng.integers(1, 3))):
+                orc.sweep()
+                g.sweep()
+            gw0, gw, gV = g.get_model()
+            # the dense order-exact oracle and the sparse formulation (GPU, tests/fm_np_engine.py) agree to ~1e-10 on
+            # well-conditioned problems; tiny data sets with k=64 can amplify the rounding differences (an independent
+            # NumPy run of the sparse formulation shows the same gap), so the bar here is loose and the ranking comparison
+            # is skipped when the two models already differ
+            scale = max(1.0, float(np.max(np.abs(gV))))
+            dv = max(float(np.max(np.abs(gV - orc.V.reshape(gV.shape)))), float(np.max(np.abs(gw - orc.w))))
+            ok = dv <= 1e-3 * scale
+            if dv > 1e-9 * scale:
+                if not ok:
+                    bad += 1
+                    print("MISMATCH case %d: FM model differs by %.3e (scale %.3e)" % (case, dv, scale), flush=True)
+                continue
+            if not ok:
+                print("  FM model differs: max |dV| %.3e (max |V| %.3e), max |dw| %.3e" % (
+                    np.max(np.abs(gV - orc.V.reshape(gV.shape))), np.max(np.abs(gV)), np.max(np.abs(gw - orc.w))), flush=True)
+            kw["bin_thold"] = -50.0
+            predict, inst, name, tol = (lambda u, j, c: orc.predict(u, j, c)), g, "FM", 1e-7
+        else:
+            model = util.MODELS[rng.integers(len(util.MODELS))]
+            state = synth.init_state(model, train, k, seed=int(rng.integers(1 << 30)))
+            gm = 0.0 if model == "PMF" else oracle_c.global_mean(train.r)
+            if model == "PMF":
+                kw["bin_thold"] = -1.0
+            orc = util.c_oracle(model, train, k, state, gm)
+            u, j, ctx, r = util.tuples_for(model, train)
+            flags = capi.FLAG_STATE_F64 | capi.FLAG_STRICT | (capi.FLAG_SCHED_SERIAL if model == "CAMF_C" else 0)
+            inst = capi.Instance(model, k, train.n_users, train.n_items, train.n_conds, flags=flags)
+            inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, gm)
+            if model in util.TWO_D:
+                inst.set_ratings(u, j, None, r)
+            else:
+                inst.set_ratings(u, j, ctx, r, train.ctx_ptr, train.ctx_conds)
+            inst.set_states(state)
+            orc.epoch(util.LR)
+            inst.train_epoch(util.LR)
+            ok = True
+            predict, name, tol = (lambda u, j, c: orc.predict(u, j, c)), model, 1e-11
+        ref, ref_lists = rank_oracle.eval_rankings(predict, tuples(train), tuples(test), kw["bin_thold"], kw["num_recs"],
+                                                   kw["strategy"], kw["num_ignore"])
+        res, lists = inst.eval_rankings((train.u, train.j, train.ctx, train.r), (test.u, test.j, test.ctx, test.r),
+                                        with_lists=True, **kw)
+        if set(lists) != set(ref_lists):
+            print("  query sets differ", len(lists), len(ref_lists), flush=True)
+            ok = False
+        if ok:
+            for key, rl in ref_lists.items():
+                gl = lists[key]
+                same = len(gl) == len(rl) and all(abs(a[1] - b[1]) <= tol * max(1.0, abs(b[1])) for a, b in zip(gl, rl))
+                # items must agree except inside groups of (near-)equal scores
+                if same and [i for i, _ in gl] != [i for i, _ in rl]:
+                    same = all(a[0] == b[0] or abs(a[1] - b[1]) <= tol for a, b in zip(gl, rl))
+                if not same:
+                    print("  list differs at", key, gl[:4], rl[:4], flush=True)
+                ok &= same
+            for m in rank_oracle.MEASURES:
+                a, b = res[m], ref[m]
+                ok &= (math.isnan(a) and math.isnan(b)) or abs(a - b) <= (1e-9 if name != "FM" else 1e-6)
+        if not ok:
+            bad += 1
+            print("MISMATCH case %d: %s k=%d users=%d items=%d train=%d test=%d %s" % (case, name, k, n_users, n_items, train.n, test.n, kw),
+                  flush=True)
+    print("%d cases, %d mismatches" % (n_cases, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
