@@ -106,8 +106,15 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("CMI_BENCH_SHARE_GPU"):
+            # test hook (tests/test_gpu_bench_ranks.py): two ranks on ONE GPU over gloo, to exercise this N>1 code path on
+            # a single-GPU box; never a measurement configuration
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     model, k, n_users, n_items, n_dims, cpd, n_ratings = WORKLOADS[args.workload]
     if args.k > 0:
