@@ -101,6 +101,7 @@ SYMBOLS = [
     ("cmi_fm_phase_reduce", C.c_int, [_vp, C.c_int]),
     ("cmi_fm_phase_buffer", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64)]),
     ("cmi_fm_phase_apply", C.c_int, [_vp, C.c_int]),
+    ("cmi_fm_phase_run", C.c_int, [_vp, C.c_int]),
 ]
 
 _LIB = None
@@ -468,6 +469,9 @@ class FMInstance:
         ptr, cnt = _vp(), _i64()
         self._chk(self.L.cmi_fm_phase_buffer(self.h, phase, C.byref(ptr), C.byref(cnt)))
         return ptr.value, cnt.value
+
+    def phase_run(self, phase):
+        self._chk(self.L.cmi_fm_phase_run(self.h, phase))
 
     def phase_apply(self, phase):
         self._chk(self.L.cmi_fm_phase_apply(self.h, phase))

@@ -374,6 +374,24 @@ extern "C" int cmi_fm_phase_apply(cmi_fm_handle h, int phase) {
     return fm_after_apply(h, field, f);
 }
 
+// one phase, reduce + update fused (no exchange point): what cmi_fm_sweep runs per phase; a multi-GPU host uses it for the
+// phases whose coordinates live on one rank only (the user field of user-sharded ratings)
+extern "C" int cmi_fm_phase_run(cmi_fm_handle h, int phase) {
+    if (!h) return CMI_E_INVALID;
+    if (int rc = fm_ready(h, true)) return rc;
+    int field, f;
+    if (!phase_decode(h, phase, &field, &f)) FM_FAIL(h, CMI_E_INVALID, "fm: bad phase %d", phase);
+    if (int rc = fm_before_phase(h, field, f)) return rc;
+    if (phase == 0) {
+        FM_HIP(h, fm_launch_w0_reduce(fm_args(h), h->d_scratch, h->stream));
+        FM_HIP(h, fm_launch_w0_apply(fm_args(h), h->stream));
+    } else {
+        FM_HIP(h, fm_launch_field(fm_args(h), field, f, 2, h->stream));
+    }
+    h->last_phase = -1;
+    return fm_after_apply(h, field, f);
+}
+
 extern "C" int cmi_fm_sweep(cmi_fm_handle h) {
     if (!h) return CMI_E_INVALID;
     if (int rc = fm_ready(h, true)) return rc;

@@ -165,6 +165,9 @@ class GpuFMEngine:
     def phase_apply(self, ph):
         self.inst.phase_apply(ph)
 
+    def phase_run(self, ph):
+        self.inst.phase_run(ph)
+
     def phase_tensor(self, ph):
         ptr, cnt = self.inst.phase_buffer(ph)
         key = (ptr, cnt)
@@ -199,6 +202,9 @@ class ShardedFMRunner:
     def sweep(self):
         eng, dist = self.engine, self.dist
         for ph in range(eng.num_phases()):
+            if (self.world == 1 or fm_phase_field(ph) == 0) and hasattr(eng, "phase_run"):
+                eng.phase_run(ph)       # nothing to exchange: reduce + update in one pass
+                continue
             eng.phase_reduce(ph)
             if self.world > 1 and fm_phase_field(ph) != 0:
                 if hasattr(eng, "before_exchange"):

@@ -255,6 +255,8 @@ int cmi_fm_num_phases(cmi_fm_handle h);
 int cmi_fm_phase_reduce(cmi_fm_handle h, int phase);
 int cmi_fm_phase_buffer(cmi_fm_handle h, int phase, void **dev_ptr, int64_t *count);
 int cmi_fm_phase_apply(cmi_fm_handle h, int phase);
+/* reduce + apply of one phase fused (no exchange point), for phases whose coordinates are local to the rank */
+int cmi_fm_phase_run(cmi_fm_handle h, int phase);
 
 /* ---- data side of the path (host-only, no GPU): DataDAO id-mapper and the compact->binary rewrite -------------
  * Integer / string work that must be BIT-EXACT with the reference (north_star: "integer id mapping bit-exact"). */
