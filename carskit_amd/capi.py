@@ -97,6 +97,7 @@ SYMBOLS = [
     ("cmi_fm_train", C.c_int, [_vp, C.c_int]),
     ("cmi_fm_predict_batch", C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, _dbl, _dbl, _vp]),
     ("cmi_fm_synchronize", C.c_int, [_vp]),
+    ("cmi_fm_stream", C.c_int, [_vp, C.POINTER(_vp)]),
     ("cmi_fm_num_phases", C.c_int, [_vp]),
     ("cmi_fm_phase_reduce", C.c_int, [_vp, C.c_int]),
     ("cmi_fm_phase_buffer", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64)]),
@@ -478,6 +479,11 @@ class FMInstance:
 
     def synchronize(self):
         self._chk(self.L.cmi_fm_synchronize(self.h))
+
+    def stream_ptr(self):
+        p = _vp()
+        self._chk(self.L.cmi_fm_stream(self.h, C.byref(p)))
+        return p.value
 
     def predict(self, u, j, ctx, bound=None):
         c32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)

@@ -416,6 +416,12 @@ extern "C" int cmi_fm_train(cmi_fm_handle h, int num_iters) {
     return CMI_OK;
 }
 
+extern "C" int cmi_fm_stream(cmi_fm_handle h, void **stream) {
+    if (!h || !stream) return CMI_E_INVALID;
+    *stream = (void *)h->stream;
+    return CMI_OK;
+}
+
 extern "C" int cmi_fm_synchronize(cmi_fm_handle h) {
     if (!h) return CMI_E_INVALID;
     FM_HIP(h, hipSetDevice(h->device));

@@ -151,10 +151,16 @@ class GpuFMEngine:
     """Engine over one capi.FMInstance holding this rank's ratings (users re-based to the shard)."""
 
     def __init__(self, fm_inst, device_index):
+        import os
         import torch
         self.inst, self.torch = fm_inst, torch
         self.device = torch.device("cuda", device_index)
         self._views = {}
+        # The ~130 exchanged phases of a sweep are each a few hundred microseconds long: a host round trip before and after
+        # every collective would cost as much as the phases.  The instance's own HIP stream is therefore made torch's current
+        # stream for the collective, which orders  reduce kernel -> all-reduce -> apply kernel  on the device with no host
+        # synchronisation at all.  CMI_DIST_SYNC=1 restores the blocking form.
+        self.ext = None if os.environ.get("CMI_DIST_SYNC") else torch.cuda.ExternalStream(fm_inst.stream_ptr(), device=self.device)
 
     def num_phases(self):
         return self.inst.num_phases()
@@ -176,10 +182,17 @@ class GpuFMEngine:
         return self._views[key]
 
     def before_exchange(self):
-        self.inst.synchronize()
+        if self.ext is None:
+            self.inst.synchronize()
 
     def after_exchange(self):
-        self.torch.cuda.synchronize(self.device)
+        if self.ext is None:
+            self.torch.cuda.synchronize(self.device)
+
+    def exchange_stream(self):
+        """Context manager under which the runner issues the collective."""
+        import contextlib
+        return self.torch.cuda.stream(self.ext) if self.ext is not None else contextlib.nullcontext()
 
 
 def fm_phase_field(ph):
@@ -195,21 +208,28 @@ class ShardedFMRunner:
     them with an all-reduce before the update, user phases stay local (a user's ratings live on one rank).
     Every rank then applies the same update, so the replicated item/context part of the model stays identical."""
 
-    def __init__(self, engine, dist, group=None):
+    def __init__(self, engine, dist, group=None, always_exchange=False):
         self.engine, self.dist, self.group = engine, dist, group
         self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+        # tests: run the exchange path (collective included) even at world size 1
+        self.always_exchange = always_exchange and dist is not None and dist.is_initialized()
 
     def sweep(self):
         eng, dist = self.engine, self.dist
         for ph in range(eng.num_phases()):
-            if (self.world == 1 or fm_phase_field(ph) == 0) and hasattr(eng, "phase_run"):
+            exchange = (self.world > 1 or self.always_exchange) and fm_phase_field(ph) != 0
+            if not exchange and hasattr(eng, "phase_run"):
                 eng.phase_run(ph)       # nothing to exchange: reduce + update in one pass
                 continue
             eng.phase_reduce(ph)
-            if self.world > 1 and fm_phase_field(ph) != 0:
+            if exchange:
                 if hasattr(eng, "before_exchange"):
                     eng.before_exchange()
-                dist.all_reduce(eng.phase_tensor(ph), op=dist.ReduceOp.SUM, group=self.group)
+                if hasattr(eng, "exchange_stream"):
+                    with eng.exchange_stream():
+                        dist.all_reduce(eng.phase_tensor(ph), op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    dist.all_reduce(eng.phase_tensor(ph), op=dist.ReduceOp.SUM, group=self.group)
                 if hasattr(eng, "after_exchange"):
                     eng.after_exchange()
             eng.phase_apply(ph)

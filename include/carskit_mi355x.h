@@ -240,6 +240,8 @@ int cmi_fm_train(cmi_fm_handle h, int num_iters);
 int cmi_fm_predict_batch(cmi_fm_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                          int bound, double lo, double hi, double *out);
 int cmi_fm_synchronize(cmi_fm_handle h);
+/* the HIP stream (hipStream_t) all of this handle's work is enqueued on (a multi-GPU host orders its collectives on it) */
+int cmi_fm_stream(cmi_fm_handle h, void **stream);
 /* Recommender.evalRankings (Recommender.java:668-964) with FM.predict (FM.java:93-113) as the scorer: arguments, outputs
  * and semantics exactly as cmi_eval_rankings above */
 int cmi_fm_eval_rankings(cmi_fm_handle h, int64_t n_train, const int32_t *tu, const int32_t *tj, const int32_t *tctx,

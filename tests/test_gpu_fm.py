@@ -157,3 +157,38 @@ def test_fm_support_length_paths(n_users, n_items, n, zipf):
     np.testing.assert_allclose(w0, orc.w0, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(w, orc.w, rtol=1e-8, atol=1e-11)
     np.testing.assert_allclose(V, orc.V.reshape(V.shape), rtol=1e-8, atol=1e-11)
+
+
+def test_fm_runner_exchange_path_on_the_instance_stream_with_rccl():
+    """The multi-GPU FM sweep orders  reduce kernel -> all-reduce -> apply kernel  on the instance's own HIP stream (torch's
+    ExternalStream), with no host synchronisation.  With one rank the all-reduce is the identity, so the exchanged sweep
+    must equal the fused sweep bit for bit -- any missing ordering between the library's kernels and RCCL would show."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as tdist
+    from carskit_amd import dist as cdist
+    data = util.small_data(n_users=300, n_items=120, n_dims=2, conds_per_dim=3, n=20000, seed=57)
+    _, a = make_fm(data, 8, 3)
+    _, b = make_fm(data, 8, 3)
+    a.init()
+    b.init()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        eng = cdist.GpuFMEngine(a, 0)
+        assert eng.ext is not None
+        run = cdist.ShardedFMRunner(eng, tdist, always_exchange=True)
+        for _ in range(3):
+            run.sweep()
+            b.sweep()
+        a.synchronize()
+        torch.cuda.synchronize()
+        for x, y in zip(a.get_model(), b.get_model()):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+    finally:
+        tdist.destroy_process_group()
