@@ -329,6 +329,11 @@ class Instance:
     def synchronize(self):
         self._chk(self.L.cmi_synchronize(self.h))
 
+    def stream_ptr(self):
+        p = _vp()
+        self._chk(self.L.cmi_stream(self.h, C.byref(p)))
+        return p.value
+
     def last_epoch_ms(self):
         ms = C.c_float()
         self._chk(self.L.cmi_last_epoch_ms(self.h, C.byref(ms)))

@@ -51,6 +51,11 @@ class GpuEngine:
         for name in ITEM_SIDE[inst.model]:
             ptr, cnt, dt = inst.state_device_ptr(name)
             self.item[name] = torch.as_tensor(_DevArray(ptr, cnt, dt), device=self.device)
+        # One exchange per epoch: two host synchronisations around it cost nothing next to a 25 ms epoch, so the blocking
+        # form is the default here.  CMI_DIST_STREAM=1 issues the exchange with the instance's HIP stream as torch's current
+        # stream instead (device-side ordering, as the FM runner does for its ~130 exchanges per sweep).
+        import os
+        self.ext = torch.cuda.ExternalStream(inst.stream_ptr(), device=self.device) if os.environ.get("CMI_DIST_STREAM") else None
 
     def epoch_local(self, lr):
         self.inst.train_epoch_async(lr)
@@ -61,10 +66,16 @@ class GpuEngine:
         return self.item
 
     def before_exchange(self):
-        self.inst.synchronize()               # kernels of the epoch are done before torch touches the state
+        if self.ext is None:
+            self.inst.synchronize()               # kernels of the epoch are done before torch touches the state
 
     def after_exchange(self):
-        self.torch.cuda.synchronize(self.device)  # exchange finished before the next epoch's kernels start
+        if self.ext is None:
+            self.torch.cuda.synchronize(self.device)  # exchange finished before the next epoch's kernels start
+
+    def exchange_stream(self):
+        import contextlib
+        return self.torch.cuda.stream(self.ext) if self.ext is not None else contextlib.nullcontext()
 
 
 class ShardedEpochRunner:
@@ -95,24 +106,28 @@ class ShardedEpochRunner:
             return loss
         if hasattr(self.engine, "before_exchange"):
             self.engine.before_exchange()
-        item = self.engine.item_state()
-        off = 0
-        for n in self.names:
-            x = item[n].view(-1)
-            torch.sub(x, self.start[n].view(-1), out=self.bucket[off:off + x.numel()])
-            off += x.numel()
-        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
-        off = 0
-        for n in self.names:
-            x = item[n].view(-1)
-            torch.add(self.start[n].view(-1), self.bucket[off:off + x.numel()], out=x)
-            self.start[n].view(-1).copy_(x)
-            off += x.numel()
-        lt = torch.tensor([loss], dtype=torch.float64, device=self.bucket.device)
-        dist.all_reduce(lt, op=dist.ReduceOp.SUM, group=self.group)
+        import contextlib
+        ctx = self.engine.exchange_stream() if hasattr(self.engine, "exchange_stream") else contextlib.nullcontext()
+        with ctx:
+            item = self.engine.item_state()
+            off = 0
+            for n in self.names:
+                x = item[n].view(-1)
+                torch.sub(x, self.start[n].view(-1), out=self.bucket[off:off + x.numel()])
+                off += x.numel()
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+            off = 0
+            for n in self.names:
+                x = item[n].view(-1)
+                torch.add(self.start[n].view(-1), self.bucket[off:off + x.numel()], out=x)
+                self.start[n].view(-1).copy_(x)
+                off += x.numel()
+            lt = torch.tensor([loss], dtype=torch.float64, device=self.bucket.device)
+            dist.all_reduce(lt, op=dist.ReduceOp.SUM, group=self.group)
+            total = float(lt.item())    # read back on the same stream the all-reduce was ordered on
         if hasattr(self.engine, "after_exchange"):
             self.engine.after_exchange()
-        return float(lt.item())
+        return total
 
 
 def shard_by_user(data, rank, world):
