@@ -37,8 +37,7 @@ int main() {
     hipEventCreate(&e1);
     const int rounds = 1000;
     for (int work : {0, 4}) {
-        for (int bpc : {1, 2, 4, 8}) {
-            const int blocks = 256 * bpc;
+        for (int blocks : {4, 8, 16, 32, 64, 256, 512, 1024, 2048}) {
             hipMemset(counter, 0, 4);
             void *args[] = {&counter, (void *)&rounds, &sink, &src, (void *)&work};
             hipEventRecord(e0);
