@@ -58,6 +58,8 @@ SYMBOLS = [
     ("cmi_fm_eval_rankings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int, C.c_int,
                                        C.c_int, _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
     ("cmi_last_rank_ms", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_dbl)]),
+    ("cmi_rank_plan", C.c_int, [C.c_int32, C.c_int32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int,
+                                C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("cmi_java_int_hashset_order", C.c_int, [_i64, _vp, _vp, C.POINTER(_i64)]),
     ("cmi_state_device_ptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(C.c_int)]),
     ("cmi_stream", C.c_int, [_vp, C.POINTER(_vp)]),
@@ -117,8 +119,31 @@ def java_int_hashset_order(values):
     out, n = np.zeros(max(len(v), 1), np.int32), _i64()
     rc = lib().cmi_java_int_hashset_order(len(v), _p(v), _p(out), C.byref(n))
     if rc:
-        raise CmiError("cmi_java_int_hashset_order failed: %d" % rc)
+        raise CmiError(rc, "cmi_java_int_hashset_order")
     return out[:n.value].copy()
+
+
+def rank_plan(n_users, n_items, train, test, bin_thold=-1.0, num_ignore=0):
+    """Host-only: (candidates, [(user, ctx, correct items, excluded candidate positions), ...]) as cmi_eval_rankings sees them."""
+    c32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    tu, tj, tc, tr = c32(train[0]), c32(train[1]), c32(train[2]), f64(train[3])
+    su, sj, sc, sr = c32(test[0]), c32(test[1]), c32(test[2]), f64(test[3])
+    sizes = (_i64 * 4)()
+    args = (n_users, n_items, len(tu), _p(tu), _p(tj), _p(tc), _p(tr), len(su), _p(su), _p(sj), _p(sc), _p(sr), float(bin_thold),
+            int(num_ignore), sizes)
+    rc = lib().cmi_rank_plan(*args, None, None, None, None, None, None, None)
+    if rc:
+        raise CmiError(rc, "cmi_rank_plan")
+    nc, nq, nt, ne = list(sizes)
+    cand, qu, qc = np.zeros(max(nc, 1), np.int32), np.zeros(max(nq, 1), np.int32), np.zeros(max(nq, 1), np.int32)
+    tp, ti = np.zeros(nq + 1, np.int64), np.zeros(max(nt, 1), np.int32)
+    ep, ei = np.zeros(nq + 1, np.int64), np.zeros(max(ne, 1), np.int32)
+    rc = lib().cmi_rank_plan(*args, _p(cand), _p(qu), _p(qc), _p(tp), _p(ti), _p(ep), _p(ei))
+    if rc:
+        raise CmiError(rc, "cmi_rank_plan")
+    queries = [(int(qu[q]), int(qc[q]), ti[tp[q]:tp[q + 1]].tolist(), ei[ep[q]:ep[q + 1]].tolist()) for q in range(nq)]
+    return cand[:nc].tolist(), queries
 
 
 class CmiError(RuntimeError):

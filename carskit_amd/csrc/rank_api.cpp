@@ -381,6 +381,38 @@ extern "C" int cmi_last_rank_ms(cmi_handle h, float *ms, double *flops) {
     return CMI_OK;
 }
 
+// host-only: the bookkeeping of cmi_eval_rankings without a device -- candidates (in HashSet<Integer> order, minus the ignored),
+// queries, their correct items and the candidate positions excluded per query.  Two-call protocol: sizes first (null
+// outputs), then the arrays.  sizes = {n_cand, n_queries, n_truth, n_excl}.
+extern "C" int cmi_rank_plan(int32_t n_users, int32_t n_items, int64_t n_train, const int32_t *tu, const int32_t *tj,
+                             const int32_t *tctx, const double *tr, int64_t n_test, const int32_t *su, const int32_t *sj,
+                             const int32_t *sctx, const double *sr, double bin_thold, int num_ignore, int64_t sizes[4],
+                             int32_t *cand, int32_t *q_user, int32_t *q_ctx, int64_t *truth_ptr, int32_t *truth_items,
+                             int64_t *excl_ptr, int32_t *excl_idx) {
+    if (!sizes || n_users <= 0 || n_items <= 0 || n_train < 0 || n_test < 0 || (n_train > 0 && (!tu || !tj || !tctx)) ||
+        (n_test > 0 && (!su || !sj || !sctx || !sr)))
+        return CMI_E_INVALID;
+    for (int64_t t = 0; t < n_train; ++t)
+        if (tu[t] < 0 || tu[t] >= n_users || tj[t] < 0 || tj[t] >= n_items || tctx[t] < 0) return CMI_E_INVALID;
+    for (int64_t t = 0; t < n_test; ++t)
+        if (su[t] < 0 || su[t] >= n_users || sj[t] < 0 || sj[t] >= n_items || sctx[t] < 0) return CMI_E_INVALID;
+    RankPlan plan;
+    rank_build_plan(n_users, n_items, RankTuples{n_train, tu, tj, tctx, tr}, RankTuples{n_test, su, sj, sctx, sr}, bin_thold,
+                    num_ignore, plan);
+    sizes[0] = (int64_t)plan.cand.size();
+    sizes[1] = (int64_t)plan.qu.size();
+    sizes[2] = (int64_t)plan.truth_items.size();
+    sizes[3] = (int64_t)plan.excl_idx.size();
+    if (cand) std::copy(plan.cand.begin(), plan.cand.end(), cand);
+    if (q_user) std::copy(plan.qu.begin(), plan.qu.end(), q_user);
+    if (q_ctx) std::copy(plan.qc.begin(), plan.qc.end(), q_ctx);
+    if (truth_ptr) std::copy(plan.truth_ptr.begin(), plan.truth_ptr.end(), truth_ptr);
+    if (truth_items) std::copy(plan.truth_items.begin(), plan.truth_items.end(), truth_items);
+    if (excl_ptr) std::copy(plan.excl_ptr.begin(), plan.excl_ptr.end(), excl_ptr);
+    if (excl_idx) std::copy(plan.excl_idx.begin(), plan.excl_idx.end(), excl_idx);
+    return CMI_OK;
+}
+
 extern "C" int cmi_java_int_hashset_order(int64_t n, const int32_t *values, int32_t *out, int64_t *n_out) {
     if (n < 0 || (n > 0 && (!values || !out)) || !n_out) return CMI_E_INVALID;
     std::vector<int32_t> first;

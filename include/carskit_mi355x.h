@@ -183,6 +183,14 @@ int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *tu, const in
  * gather + contraction + mask + top-N over all query batches) and the flops of its contraction
  * (2 x queries x candidates x padded operand length) */
 int cmi_last_rank_ms(cmi_handle h, float *ms, double *flops);
+/* host-only (no GPU): the bookkeeping cmi_eval_rankings does before scoring -- candidate items in HashSet<Integer> order minus the
+ * `num_ignore` most rated (Recommender.java:704-735), the (user, context) queries with their correct items (:776-790), and per
+ * query the candidate POSITIONS of the items already rated in that context (:793-816).  Call once with null arrays for
+ * sizes = {n_cand, n_queries, n_truth, n_excl}, then with arrays (truth_ptr / excl_ptr hold n_queries + 1 offsets). */
+int cmi_rank_plan(int32_t n_users, int32_t n_items, int64_t n_train, const int32_t *tu, const int32_t *tj, const int32_t *tctx,
+                  const double *tr, int64_t n_test, const int32_t *su, const int32_t *sj, const int32_t *sctx, const double *sr,
+                  double bin_thold, int num_ignore, int64_t sizes[4], int32_t *cand, int32_t *q_user, int32_t *q_ctx,
+                  int64_t *truth_ptr, int32_t *truth_items, int64_t *excl_ptr, int32_t *excl_idx);
 /* iteration order of a java.util.HashSet<Integer> after add()ing values[0..n) (the candidate-item order above) */
 int cmi_java_int_hashset_order(int64_t n, const int32_t *values, int32_t *out, int64_t *n_out);
 

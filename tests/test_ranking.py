@@ -115,3 +115,46 @@ def test_eval_rankings_rejects_nonpositive_topn():
     train, test, predict = _tiny()
     with pytest.raises(ValueError):
         ro.eval_rankings(predict, train, test, num_recs=0)
+
+
+@pytest.mark.parametrize("seed,num_ignore,thold", [(1, 0, 2.5), (2, 3, 3.5), (3, 0, -1.0), (4, 1, 4.5)])
+def test_rank_plan_bookkeeping_matches_a_python_derivation(seed, num_ignore, thold):
+    """cmi_rank_plan (host-only part of cmi_eval_rankings): candidates, queries, correct items and per-query exclusions
+    against a direct Python derivation from the rules of Recommender.evalRankings (Recommender.java:704-816)."""
+    rng = np.random.default_rng(seed)
+    n_users, n_items, n = 40, 500, 900
+    items = rng.choice(n_items, size=60, replace=False)          # sparse ids: HashSet order != ascending
+    u = rng.integers(0, n_users, n).astype(np.int32)
+    j = items[rng.integers(0, len(items), n)].astype(np.int32)
+    c = rng.integers(0, 6, n).astype(np.int32)
+    r = rng.integers(1, 6, n).astype(np.float64)
+    keep = np.unique(np.stack([u, j, c], 1), axis=0, return_index=True)[1]
+    keep.sort()
+    u, j, c, r = u[keep], j[keep], c[keep], r[keep]
+    tr = rng.random(len(u)) < 0.7
+    train, test = (u[tr], j[tr], c[tr], r[tr]), (u[~tr], j[~tr], c[~tr], r[~tr])
+    cand, queries = capi.rank_plan(n_users, n_items, train, test, thold, num_ignore)
+    # expected candidates
+    exp_cand = ro.java_int_hashset_order(train[1].tolist())
+    if num_ignore:
+        deg = {}
+        for jj in train[1].tolist():
+            deg[jj] = deg.get(jj, 0) + 1
+        drop = set(sorted(exp_cand, key=lambda x: -deg[x])[:num_ignore])
+        exp_cand = [x for x in exp_cand if x not in drop]
+    assert cand == exp_cand and cand != sorted(cand)
+    pos = {x: i for i, x in enumerate(cand)}
+    # expected queries
+    truth, rated = {}, {}
+    for uu, jj, cc, rr in zip(*(a.tolist() for a in test)):
+        if rr > thold and jj in pos:
+            truth.setdefault((uu, cc), set()).add(jj)
+    for uu, jj, cc, rr in zip(*(a.tolist() for a in train)):
+        if jj in pos:
+            rated.setdefault((uu, cc), set()).add(pos[jj])
+    got = {(qu, qc): (t, e) for qu, qc, t, e in queries}
+    assert set(got) == set(truth) and len(queries) == len(truth)
+    assert [(q[0], q[1]) for q in queries] == sorted(truth)       # (user, context) order
+    for key, items_ in truth.items():
+        t, e = got[key]
+        assert t == sorted(items_) and sorted(e) == sorted(rated.get(key, set())) and len(set(e)) == len(e)
