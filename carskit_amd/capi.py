@@ -60,6 +60,7 @@ SYMBOLS = [
     ("cmi_last_rank_ms", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_dbl)]),
     ("cmi_rank_plan", C.c_int, [C.c_int32, C.c_int32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int,
                                 C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("cmi_rank_list_measures", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     ("cmi_java_int_hashset_order", C.c_int, [_i64, _vp, _vp, C.POINTER(_i64)]),
     ("cmi_state_device_ptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(C.c_int)]),
     ("cmi_stream", C.c_int, [_vp, C.POINTER(_vp)]),
@@ -121,6 +122,17 @@ def java_int_hashset_order(values):
     if rc:
         raise CmiError(rc, "cmi_java_int_hashset_order")
     return out[:n.value].copy()
+
+
+def rank_list_measures(ranked, truth, num_dropped, num_recs):
+    """Host-only: {measure: value} of one ranked list (already cut at num_recs), as cmi_eval_rankings computes per query."""
+    rk = np.ascontiguousarray(ranked, dtype=np.int32)
+    tr = np.ascontiguousarray(sorted(set(truth)), dtype=np.int32)
+    out = np.zeros(18)
+    rc = lib().cmi_rank_list_measures(_p(rk), len(rk), _p(tr), len(tr), int(num_dropped), int(num_recs), _p(out))
+    if rc:
+        raise CmiError(rc, "cmi_rank_list_measures")
+    return dict(zip(RANK_MEASURES[:18], out.tolist()))
 
 
 def rank_plan(n_users, n_items, train, test, bin_thold=-1.0, num_ignore=0):

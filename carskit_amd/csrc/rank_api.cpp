@@ -129,6 +129,22 @@ std::vector<int64_t> order_by_user_ctx_item(int n_users, const std::vector<int64
 
 constexpr int N_MEAS = 18; // Pre,Rec,AUC,MAP,NDCG,MRR x {5,10,N}
 
+// the 18 measures of ONE ranked list (already cut at num_recs): index = measure * 3 + cut-off, cut-offs {5, 10, num_recs}
+// (Recommender.java:852-858 through carskit.eval.Measures.*At)
+void list_measures(const int32_t *ranked, int len, const Truth &t, int num_dropped, int num_recs, double vals[N_MEAS]) {
+    const int cut[3] = {5, 10, num_recs};
+    for (int c = 0; c < 3; ++c) {
+        const int n = cut[c], tl = std::min(n, len);
+        const int hits = hits_at(ranked, len, t, n);
+        vals[0 + c] = hits / (n + 0.0);
+        vals[3 + c] = hits / (t.n + 0.0);
+        vals[6 + c] = auc(ranked, tl, t, num_dropped);
+        vals[9 + c] = ap(ranked, tl, t);
+        vals[12 + c] = ndcg(ranked, tl, t);
+        vals[15 + c] = rr(ranked, tl, t);
+    }
+}
+
 } // namespace
 
 namespace cmi {
@@ -216,7 +232,6 @@ void rank_metrics(const RankPlan &plan, int strategy, int num_recs, const std::v
     out[18] = out[19] = out[20] = 0.0; // D5/D10/DN: isDiverseUsed=false (Recommender.java:939-941)
     // metrics, per query then averaged per strategy (Recommender.java:850-960)
     NanMean total[N_MEAS], per_user[N_MEAS];
-    const int cut[3] = {5, 10, num_recs};
     std::vector<int32_t> ranked(num_recs);
     auto flush_user = [&]() {
         for (int m = 0; m < N_MEAS; ++m) {
@@ -244,16 +259,9 @@ void rank_metrics(const RankPlan &plan, int strategy, int num_recs, const std::v
             const int num_cands = nc - (int)(plan.excl_ptr[q + 1] - plan.excl_ptr[q]);
             const int num_dropped = num_cands - len;
             NanMean *dst = strategy == CMI_RANK_UC ? total : per_user;
-            for (int c = 0; c < 3; ++c) {
-                const int n = cut[c], tl = std::min(n, len);
-                const int hits = hits_at(ranked.data(), len, t, n);
-                dst[0 + c].add(hits / (n + 0.0));
-                dst[3 + c].add(hits / (t.n + 0.0));
-                dst[6 + c].add(auc(ranked.data(), tl, t, num_dropped));
-                dst[9 + c].add(ap(ranked.data(), tl, t));
-                dst[12 + c].add(ndcg(ranked.data(), tl, t));
-                dst[15 + c].add(rr(ranked.data(), tl, t));
-            }
+            double vals[N_MEAS];
+            list_measures(ranked.data(), len, t, num_dropped, num_recs, vals);
+            for (int m = 0; m < N_MEAS; ++m) dst[m].add(vals[m]);
             ++emitted;
         }
         // ucu: a test user contributes the NaN-skipping mean over its contexts -- NaN (skipped again) if none of
@@ -410,6 +418,17 @@ extern "C" int cmi_rank_plan(int32_t n_users, int32_t n_items, int64_t n_train, 
     if (truth_items) std::copy(plan.truth_items.begin(), plan.truth_items.end(), truth_items);
     if (excl_ptr) std::copy(plan.excl_ptr.begin(), plan.excl_ptr.end(), excl_ptr);
     if (excl_idx) std::copy(plan.excl_idx.begin(), plan.excl_idx.end(), excl_idx);
+    return CMI_OK;
+}
+
+// host-only: the 18 measures of one ranked list, as cmi_eval_rankings computes them per query
+extern "C" int cmi_rank_list_measures(const int32_t *ranked, int len, const int32_t *truth_sorted, int n_truth, int num_dropped,
+                                      int num_recs, double out[18]) {
+    if (len < 0 || n_truth <= 0 || num_recs < 1 || !truth_sorted || !out || (len > 0 && !ranked)) return CMI_E_INVALID;
+    for (int i = 1; i < n_truth; ++i)
+        if (truth_sorted[i - 1] >= truth_sorted[i]) return CMI_E_INVALID; // strictly ascending (binary search)
+    const Truth t{truth_sorted, n_truth};
+    list_measures(ranked, len, t, num_dropped, num_recs, out);
     return CMI_OK;
 }
 

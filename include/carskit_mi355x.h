@@ -191,6 +191,11 @@ int cmi_rank_plan(int32_t n_users, int32_t n_items, int64_t n_train, const int32
                   const double *tr, int64_t n_test, const int32_t *su, const int32_t *sj, const int32_t *sctx, const double *sr,
                   double bin_thold, int num_ignore, int64_t sizes[4], int32_t *cand, int32_t *q_user, int32_t *q_ctx,
                   int64_t *truth_ptr, int32_t *truth_items, int64_t *excl_ptr, int32_t *excl_idx);
+/* host-only: the 18 measures of ONE ranked list exactly as cmi_eval_rankings computes them per query (out[measure*3 + cut-off],
+ * measures Pre Rec AUC MAP NDCG MRR, cut-offs {5, 10, num_recs}); ranked = the list already cut at num_recs, truth = the query's
+ * correct items in ascending order, num_dropped = candidates not listed (Recommender.java:850-858) */
+int cmi_rank_list_measures(const int32_t *ranked, int len, const int32_t *truth_sorted, int n_truth, int num_dropped,
+                           int num_recs, double out[18]);
 /* iteration order of a java.util.HashSet<Integer> after add()ing values[0..n) (the candidate-item order above) */
 int cmi_java_int_hashset_order(int64_t n, const int32_t *values, int32_t *out, int64_t *n_out);
 

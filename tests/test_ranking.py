@@ -158,3 +158,25 @@ def test_rank_plan_bookkeeping_matches_a_python_derivation(seed, num_ignore, tho
     for key, items_ in truth.items():
         t, e = got[key]
         assert t == sorted(items_) and sorted(e) == sorted(rated.get(key, set())) and len(set(e)) == len(e)
+
+
+def test_list_measures_library_matches_oracle_formulas():
+    """The product's per-list metric code (host C++) against the oracle's formulas on random lists."""
+    rng = np.random.default_rng(9)
+    for _ in range(300):
+        num_recs = int(rng.choice([1, 3, 5, 7, 10, 25]))
+        universe = rng.permutation(60)
+        ranked = universe[:int(rng.integers(0, num_recs + 1))].tolist()
+        truth = rng.choice(60, size=int(rng.integers(1, 8)), replace=False).tolist()
+        dropped = int(rng.integers(0, 50))
+        got = capi.rank_list_measures(ranked, truth, dropped, num_recs)
+        for tag, n in (("5", 5), ("10", 10), ("N", num_recs)):
+            top = ro.top_n(ranked, n)
+            want = {"Pre": ro.prec_at(ranked, truth, n), "Rec": ro.recall_at(ranked, truth, n), "AUC": ro.auc(top, truth, dropped),
+                    "MAP": ro.ap(top, truth), "NDCG": ro.ndcg(top, truth), "MRR": ro.rr(top, truth)}
+            for m, v in want.items():
+                assert got[m + tag] == pytest.approx(v, abs=1e-15), (m + tag, ranked, truth, dropped)
+    # the hand-computed list of the oracle tests, through the library
+    g = capi.rank_list_measures([3, 1, 4, 2, 5], [1, 5, 9], 10, 5)
+    assert g["Pre5"] == 0.4 and g["MRR5"] == 0.5 and g["AUC5"] == pytest.approx(20 / 26, abs=1e-16)
+    assert g["MAP5"] == pytest.approx((1 / 2 + 2 / 5) / 3, abs=1e-16)
