@@ -61,6 +61,8 @@ SYMBOLS = [
     ("cmi_rank_plan", C.c_int, [C.c_int32, C.c_int32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int,
                                 C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("cmi_rank_list_measures", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    ("cmi_narrow_runs", C.c_int, [_i64, _vp, _i64, _i64, _vp, C.POINTER(_i64)]),
+    ("cmi_conflict_free_blocks", C.c_int, [_i64, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _i64, C.POINTER(_i64)]),
     ("cmi_java_int_hashset_order", C.c_int, [_i64, _vp, _vp, C.POINTER(_i64)]),
     ("cmi_state_device_ptr", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(C.c_int)]),
     ("cmi_stream", C.c_int, [_vp, C.POINTER(_vp)]),
@@ -122,6 +124,30 @@ def java_int_hashset_order(values):
     if rc:
         raise CmiError(rc, "cmi_java_int_hashset_order")
     return out[:n.value].copy()
+
+
+def narrow_runs(level_off, max_tuples=256, min_levels=16):
+    off = np.ascontiguousarray(level_off, dtype=np.int64)
+    run = np.zeros(max(len(off) - 1, 1), np.int32)
+    nl = _i64()
+    rc = lib().cmi_narrow_runs(len(off) - 1, _p(off), max_tuples, min_levels, _p(run), C.byref(nl))
+    if rc:
+        raise CmiError(rc, "cmi_narrow_runs")
+    return run[:len(off) - 1].copy(), nl.value
+
+
+def conflict_free_blocks(u, j, n_users, n_items, max_block=64):
+    u = np.ascontiguousarray(u, dtype=np.int32)
+    j = np.ascontiguousarray(j, dtype=np.int32)
+    nb = _i64()
+    rc = lib().cmi_conflict_free_blocks(len(u), _p(u), _p(j), n_users, n_items, max_block, None, 0, C.byref(nb))
+    if rc:
+        raise CmiError(rc, "cmi_conflict_free_blocks")
+    off = np.zeros(nb.value + 1, np.int32)
+    rc = lib().cmi_conflict_free_blocks(len(u), _p(u), _p(j), n_users, n_items, max_block, _p(off), len(off), C.byref(nb))
+    if rc:
+        raise CmiError(rc, "cmi_conflict_free_blocks")
+    return off
 
 
 def rank_list_measures(ranked, truth, num_dropped, num_recs):

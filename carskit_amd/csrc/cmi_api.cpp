@@ -335,20 +335,8 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             h->blk_off.clear();
             if (h->model == CMI_MODEL_CAMF_C && !h->strict && h->k <= 256 && dmax <= 16 && n > 0 && n < ((int64_t)1 << 31) &&
                 camfc_blocks_lds(h->n_conds, dmax, esize(h)) <= 64 * 1024 && !getenv("CMI_NO_CAMFC_BLOCKS")) {
-                std::vector<int32_t> seen_u((size_t)h->n_users, -1), seen_j((size_t)h->n_items, -1);
-                std::vector<int32_t> off{0};
-                int32_t cur = 0, len = 0;
-                for (int64_t t = 0; t < n; ++t) {
-                    if (len == 64 || seen_u[(size_t)u[t]] == cur || seen_j[(size_t)j[t]] == cur) {
-                        off.push_back((int32_t)t);
-                        ++cur;
-                        len = 0;
-                    }
-                    seen_u[(size_t)u[t]] = cur;
-                    seen_j[(size_t)j[t]] = cur;
-                    ++len;
-                }
-                off.push_back((int32_t)n);
+                std::vector<int32_t> off;
+                build_conflict_free_blocks(n, u, j, h->n_users, h->n_items, 64, off);
                 if ((double)n / (double)(off.size() - 1) >= 3.0) h->blk_off.swap(off); // shorter runs: the serial wave is faster
             }
         } else if (h->fast && exact_k && h->use_graph && h->want_two_lane && n > 0) {
@@ -387,22 +375,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         // tuples each is walked by ONE single-workgroup launch instead of one launch per level
         h->tail_len.assign((size_t)n_levels, 0);
         h->n_launches = 0;
-        if (!h->serial && !h->two_lane && !getenv("CMI_NO_TAIL")) {
-            constexpr int64_t TAIL_MAX = 256, TAIL_MIN_LEVELS = 16;
-            for (int64_t l = 0; l < n_levels;) {
-                int64_t e2 = l;
-                while (e2 < n_levels && e2 - l < ((int64_t)1 << 30) &&
-                       h->level_off[(size_t)e2 + 1] - h->level_off[(size_t)e2] <= TAIL_MAX)
-                    ++e2;
-                if (e2 - l >= TAIL_MIN_LEVELS) {
-                    h->tail_len[(size_t)l] = (int32_t)(e2 - l);
-                    for (int64_t q = l + 1; q < e2; ++q) h->tail_len[(size_t)q] = -1;
-                    l = e2;
-                } else {
-                    l = e2 > l ? e2 : l + 1;
-                }
-            }
-        }
+        if (!h->serial && !h->two_lane && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 256, 16, h->tail_len);
         h->slot_off.assign((size_t)n_levels + 1, 0);
         for (int64_t l = 0; l < n_levels; ++l) {
             const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
@@ -965,6 +938,32 @@ extern "C" int cmi_flow_schedule(int64_t n, const int32_t *u, const int32_t *j, 
         seq_u[s] = f.seq_u[s];
         seq_j[s] = f.seq_j[s];
     }
+    return CMI_OK;
+}
+
+// host-only views of the two schedule post-passes (tests): narrow runs of a level schedule, conflict-free CRS blocks
+extern "C" int cmi_narrow_runs(int64_t n_levels, const int64_t *level_off, int64_t max_tuples, int64_t min_levels,
+                               int32_t *run_len, int64_t *n_launches) {
+    if (n_levels < 0 || !level_off || !n_launches || (n_levels > 0 && !run_len)) return CMI_E_INVALID;
+    std::vector<int64_t> off(level_off, level_off + n_levels + 1);
+    std::vector<int32_t> rl;
+    *n_launches = build_narrow_runs(off, max_tuples, min_levels, rl);
+    for (int64_t l = 0; l < n_levels; ++l) run_len[l] = rl[(size_t)l];
+    return CMI_OK;
+}
+
+extern "C" int cmi_conflict_free_blocks(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
+                                        int32_t max_block, int32_t *off, int64_t off_cap, int64_t *n_blocks) {
+    if (n < 0 || (n > 0 && (!u || !j)) || n_users <= 0 || n_items <= 0 || max_block <= 0 || !n_blocks || n >= ((int64_t)1 << 31))
+        return CMI_E_INVALID;
+    for (int64_t t = 0; t < n; ++t)
+        if (u[t] < 0 || u[t] >= n_users || j[t] < 0 || j[t] >= n_items) return CMI_E_INVALID;
+    std::vector<int32_t> o;
+    build_conflict_free_blocks(n, u, j, n_users, n_items, max_block, o);
+    *n_blocks = (int64_t)o.size() - 1;
+    if (!off) return CMI_OK;
+    if (off_cap < (int64_t)o.size()) return CMI_E_INVALID;
+    std::copy(o.begin(), o.end(), off);
     return CMI_OK;
 }
 

@@ -232,4 +232,44 @@ bool build_split_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t
     return true;
 }
 
+
+int64_t build_narrow_runs(const std::vector<int64_t> &level_off, int64_t max_tuples, int64_t min_levels, std::vector<int32_t> &run_len) {
+    const int64_t n_levels = (int64_t)level_off.size() - 1;
+    run_len.assign((size_t)(n_levels > 0 ? n_levels : 0), 0);
+    int64_t launches = 0;
+    for (int64_t l = 0; l < n_levels;) {
+        int64_t e = l;
+        while (e < n_levels && e - l < ((int64_t)1 << 30) && level_off[(size_t)e + 1] - level_off[(size_t)e] <= max_tuples) ++e;
+        if (e - l >= min_levels) {
+            run_len[(size_t)l] = (int32_t)(e - l);
+            for (int64_t q = l + 1; q < e; ++q) run_len[(size_t)q] = -1;
+            ++launches;
+            l = e;
+        } else {
+            const int64_t stop = e > l ? e : l + 1; // these levels keep their own launches
+            launches += stop - l;
+            l = stop;
+        }
+    }
+    return launches;
+}
+
+void build_conflict_free_blocks(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int max_block,
+                                std::vector<int32_t> &off) {
+    std::vector<int32_t> seen_u((size_t)n_users, -1), seen_j((size_t)n_items, -1);
+    off.assign(1, 0);
+    int32_t cur = 0, len = 0;
+    for (int64_t t = 0; t < n; ++t) {
+        if (len == max_block || seen_u[(size_t)u[t]] == cur || seen_j[(size_t)j[t]] == cur) {
+            off.push_back((int32_t)t);
+            ++cur;
+            len = 0;
+        }
+        seen_u[(size_t)u[t]] = cur;
+        seen_j[(size_t)j[t]] = cur;
+        ++len;
+    }
+    if (n > 0) off.push_back((int32_t)n);
+}
+
 } // namespace cmi

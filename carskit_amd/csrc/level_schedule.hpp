@@ -43,4 +43,15 @@ bool build_split_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t
 bool build_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
                           int within_level_order, LevelSchedule &out);
 
+
+// Narrow runs of a level schedule: run_len[l] > 0 = a run of that many consecutive levels, each with <= max_tuples tuples,
+// starts at level l (one launch walks it); -1 = inside such a run; 0 = the level is launched on its own.  Runs shorter than
+// min_levels are not formed.  Returns the number of launches per epoch.
+int64_t build_narrow_runs(const std::vector<int64_t> &level_off, int64_t max_tuples, int64_t min_levels, std::vector<int32_t> &run_len);
+
+// Conflict-free CRS blocks (CAMF_C): maximal runs of consecutive tuples that share no user and no item, cut at max_block
+// tuples.  off = block offsets (n_blocks + 1 entries).
+void build_conflict_free_blocks(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int max_block,
+                                std::vector<int32_t> &off);
+
 } // namespace cmi

@@ -330,6 +330,15 @@ int cmi_transform(const char *train_in, const char *train_out, const char *test_
 int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int order,
                        int32_t *perm, int64_t *level_off, int64_t level_cap, int64_t *n_levels);
 
+/* host-only views of two schedule post-passes (tests).  cmi_narrow_runs: run_len[l] > 0 = a run of that many consecutive
+ * levels with <= max_tuples tuples each starts at level l and is walked by ONE launch (the library uses 256 / 16), -1 = inside
+ * a run, 0 = own launch; *n_launches = launches per epoch.  cmi_conflict_free_blocks: CAMF_C's CRS blocks -- maximal runs of
+ * consecutive tuples sharing no user and no item, cut at max_block (the library uses 64); off may be NULL to query *n_blocks. */
+int cmi_narrow_runs(int64_t n_levels, const int64_t *level_off, int64_t max_tuples, int64_t min_levels, int32_t *run_len,
+                    int64_t *n_launches);
+int cmi_conflict_free_blocks(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int32_t max_block,
+                             int32_t *off, int64_t off_cap, int64_t *n_blocks);
+
 /* The two-lane form behind CMI_FLAG_TWO_LANE (level_schedule.cpp, build_split_schedule): same levels,
  * tuples inside a level sorted by the position of their later predecessor, and split[l] = first position of the
  * level's TAIL; the HEAD [level_off[l], split[l]) only depends on positions < split[l-1], so head(l) and tail(l-1)

@@ -201,3 +201,54 @@ def test_split_schedule_heads_are_about_half_on_uniform_data():
     sizes, heads = np.diff(off), split - off[:-1]
     big = sizes > 500
     assert np.median(heads[big] / sizes[big]) > 0.4             # the head really is ~half: two balanced lanes
+
+
+def test_narrow_runs_properties():
+    """Runs partition the levels: every run has >= min_levels levels, all <= max_tuples; levels outside runs are either
+    wide or sit in a too-short narrow stretch; launches = runs + lone levels."""
+    rng = np.random.default_rng(12)
+    for _ in range(50):
+        n_levels = int(rng.integers(0, 300))
+        sizes = np.where(rng.random(n_levels) < 0.7, rng.integers(1, 257, n_levels), rng.integers(257, 5000, n_levels))
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        run, launches = capi.narrow_runs(off, 256, 16)
+        l, expect_launches = 0, 0
+        while l < n_levels:
+            if run[l] > 0:
+                e = l + run[l]
+                assert run[l] >= 16 and np.all(sizes[l:e] <= 256) and np.all(run[l + 1:e] == -1)
+                assert e == n_levels or sizes[e] > 256                      # maximal to the right
+                assert l == 0 or sizes[l - 1] > 256                           # and to the left
+                l = e
+            else:
+                assert run[l] == 0
+                l += 1
+            expect_launches += 1
+        assert launches == expect_launches
+        # a narrow stretch that is NOT a run is shorter than min_levels
+        l = 0
+        while l < n_levels:
+            if run[l] == 0 and sizes[l] <= 256:
+                e = l
+                while e < n_levels and run[e] == 0 and sizes[e] <= 256:
+                    e += 1
+                assert e - l < 16
+                l = e
+            else:
+                l += 1
+
+
+def test_conflict_free_blocks_properties():
+    rng = np.random.default_rng(13)
+    for n_users, n_items, n in ((5, 4, 200), (50, 40, 1000), (1000, 800, 3000), (3, 3, 0)):
+        u = rng.integers(0, n_users, n).astype(np.int32)
+        j = rng.integers(0, n_items, n).astype(np.int32)
+        off = capi.conflict_free_blocks(u, j, n_users, n_items, 64)
+        if n == 0:
+            assert off.tolist() == [0]
+            continue
+        assert off[0] == 0 and off[-1] == n and np.all(np.diff(off) > 0) and np.all(np.diff(off) <= 64)
+        for b, e in zip(off[:-1], off[1:]):
+            assert len(set(u[b:e].tolist())) == e - b and len(set(j[b:e].tolist())) == e - b      # conflict-free
+            if e < n and e - b < 64:                                                              # maximal: the next tuple conflicts
+                assert u[e] in set(u[b:e].tolist()) or j[e] in set(j[b:e].tolist())
