@@ -1,6 +1,6 @@
 // carskit_main.cpp -- `carskit-mi355x -c setting.conf`: the reference driver's flow (src/carskit/main/CARSKit.java:
 // execute :109, preset :140, readData :220, runAlgorithm :310, runCrossValidation :388, printEvalInfo :362) for the
-// recommenders libcarskit_mi355x accelerates, rating prediction only.  Links nothing but the C ABI.
+// recommenders libcarskit_mi355x accelerates (rating prediction, or top-N evaluation with item.ranking=on).  Links nothing but the C ABI.
 #include <cstdio>
 #include <cstring>
 #include <iostream>
