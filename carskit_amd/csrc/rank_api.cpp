@@ -282,7 +282,7 @@ hipError_t rank_run_device(hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, c
     const int64_t nq = (int64_t)qu.size();
     // operand rows are zero-padded to the GEMM's k step; row counts rounded up to the 128-row block tile (pad rows are
     // never written back)
-    const int kp = (ops.k_logical + 31) / 32 * 32;
+    const int kp = (ops.k_logical + 15) / 16 * 16; // multiple of both kernels' k step
     auto up128 = [](int64_t v) { return (size_t)((v + 127) / 128 * 128); };
     // query batch: keep the score slab around 1 GiB (it is written once and re-read topn times)
     int64_t bq = std::max<int64_t>(64, ((int64_t)1 << 30) / ((int64_t)nc * (int64_t)sizeof(T)));
