@@ -142,8 +142,12 @@ def main():
     if world > 1:
         # item-side state must start identical on every rank; user-side differs per rank
         rng_u = np.random.default_rng(synth.DEFAULT_SEED + 7 + rank)
+        # (only the user-side containers this model owns: CAMF_CU / CAMF_CUCI / PMF have no userBias)
         state["P"] = (0.1 * rng_u.standard_normal(state["P"].shape)).astype(np.float32)
-        state["userBias"] = (0.1 * rng_u.standard_normal(state["userBias"].shape)).astype(np.float32)
+        if "userBias" in state:
+            state["userBias"] = (0.1 * rng_u.standard_normal(state["userBias"].shape)).astype(np.float32)
+        if "ucBias" in state:
+            state["ucBias"] = rng_u.random(state["ucBias"].shape).astype(np.float32)
     log("rank %d: init state in %.1fs" % (rank, time.perf_counter() - t0))
 
     t0 = time.perf_counter()
@@ -232,7 +236,9 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "user-sharded x%d + RCCL all-reduce of item-side deltas" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "sgd_level_fast_f32<%s,%d>" % (model, k // 64), "bytes_per_update": bytes_per_update,
+                         "kernel": ("sgd_chain_level<float,%s,%d,hub=%s>" % (model, k // 64, info["kind"][6:])
+                                    if info["kind"].startswith("chain") else "sgd_level_fast_f32<%s,%d>" % (model, k // 64)),
+                         "schedule": info["kind"], "bytes_per_update": bytes_per_update,
                          "launches_per_epoch": launches,
                          "avg_launch_us": kern_ms * 1e3 / launches,
                          "bytes_per_launch": data.n * bytes_per_update / launches},

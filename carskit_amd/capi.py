@@ -33,6 +33,8 @@ FLAG_STRICT = 0x4
 FLAG_NO_GRAPH = 0x10
 FLAG_SCHED_FLOW = 0x20
 FLAG_TWO_LANE = 0x40
+FLAG_SCHED_CHAIN = 0x80
+FLAG_NO_CHAIN = 0x100
 
 # every symbol include/carskit_mi355x.h declares: (name, restype, argtypes)
 _vp, _i64, _i32, _dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
@@ -72,6 +74,8 @@ SYMBOLS = [
     ("cmi_schedule_info", C.c_int, [_vp, C.POINTER(_i64)]),
     ("cmi_last_epoch_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("cmi_level_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, _vp, _vp, _i64, C.POINTER(_i64)]),
+    ("cmi_chain_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _i64, C.POINTER(_i64),
+                                     C.POINTER(_i64), C.POINTER(C.c_int)]),
     ("cmi_split_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     ("cmi_flow_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     ("cmi_dao_read", C.c_int, [C.c_char_p, C.POINTER(_vp)]),
@@ -229,6 +233,26 @@ def level_schedule(u, j, n_users, n_items, order=0):
     if rc != OK:
         raise CmiError(rc, "cmi_level_schedule")
     return perm, off
+
+
+def chain_schedule(u, j, n_users, n_items, hub=-1, max_chain=16):
+    """Host-only: (perm, unit_off, level_off, hub_is_item) of the hub-chain level schedule (see cmi_chain_schedule)."""
+    u = np.ascontiguousarray(u, dtype=np.int32)
+    j = np.ascontiguousarray(j, dtype=np.int32)
+    n = len(u)
+    nu, nl, hub_used = _i64(), _i64(), C.c_int()
+    rc = lib().cmi_chain_schedule(n, _p(u), _p(j), n_users, n_items, hub, max_chain, None, None, 0, None, 0, C.byref(nu),
+                                  C.byref(nl), C.byref(hub_used))
+    if rc != OK:
+        raise CmiError(rc, "cmi_chain_schedule")
+    perm = np.empty(n, dtype=np.int32)
+    unit_off = np.empty(nu.value + 1, dtype=np.int32)
+    level_off = np.empty(nl.value + 1, dtype=np.int64)
+    rc = lib().cmi_chain_schedule(n, _p(u), _p(j), n_users, n_items, hub, max_chain, _p(perm), _p(unit_off), len(unit_off),
+                                  _p(level_off), len(level_off), C.byref(nu), C.byref(nl), C.byref(hub_used))
+    if rc != OK:
+        raise CmiError(rc, "cmi_chain_schedule")
+    return perm, unit_off, level_off, bool(hub_used.value)
 
 
 def split_schedule(u, j, n_users, n_items):
@@ -407,7 +431,7 @@ class Instance:
         self._chk(self.L.cmi_schedule_info(self.h, info))
         d = dict(zip(("levels", "max_level", "tuples", "dmax", "state_bytes", "tuple_bytes", "kind", "flow_blocks"),
                      list(info)))
-        d["kind"] = ("level", "serial", "flow", "two-lane")[d["kind"]]
+        d["kind"] = ("level", "serial", "flow", "two-lane", "chain-item", "chain-user")[d["kind"]]
         return d
 
     def stream(self):

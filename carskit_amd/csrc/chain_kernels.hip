@@ -1,0 +1,391 @@
+// chain_kernels.hip -- the hub-chain level kernel (gfx950): the default SGD path for BiasedMF / PMF / CAMF_CI / CAMF_CU /
+// CAMF_CUCI whenever the schedule's levels are wide (reference loop: e.g. CAMF_CI.java:79-123).
+//
+// The plain level kernel (mf_sgd_kernels.hip) reads and writes BOTH rows of every tuple from HBM and needs one launch per
+// tuple of the busiest row.  Here a 16-lane group walks a UNIT of the chain schedule (level_schedule.cpp,
+// build_chain_schedule): up to max_chain tuples that are consecutive in the CRS order of one HUB row.  The hub row
+// (Q[j] when chaining along items, P[u] along users), its scalar bias and its context-bias row stay ON CHIP for the whole
+// unit -- factors in registers, the icBias / ucBias row in LDS -- and only the SPOKE rows stream through: the hub side's
+// HBM traffic drops by the mean unit length and the epoch has as many launches as the longest chain of UNITS.
+// Per tuple the arithmetic is the same expression, in the same order, as fast_tuples_f32 -- so for fp32 state the model is
+// bit-identical to the plain level schedule's (tests/test_gpu_chain.py) -- and T = double gives the fp64-state fast path.
+//
+// Lane layout as in sgd_level_fast_f32: lane l of the group owns the 16-byte vectors {l, l+16, ...} of both rows (whole
+// 256-B segments per load/store instruction), lane d < D owns the tuple's d-th condition, lane 0 the scalar biases; dot and
+// loss partials are reduced with DPP row rotations.  Spoke rows are prefetched one tuple ahead, tuple ids two ahead.
+// HBM-bound gather/scatter: no MFMA.
+#include "mf_sgd_kernels.hpp"
+#include "sgd_device.hpp"
+
+#include <cstdlib>
+
+namespace cmi {
+
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+    typedef float4 type;
+    static constexpr int E = 4;
+};
+template <>
+struct Vec16<double> {
+    typedef double2 type;
+    static constexpr int E = 2;
+};
+__device__ __forceinline__ void unpack(const float4 &v, float *x) { x[0] = v.x, x[1] = v.y, x[2] = v.z, x[3] = v.w; }
+__device__ __forceinline__ void unpack(const double2 &v, double *x) { x[0] = v.x, x[1] = v.y; }
+__device__ __forceinline__ float4 pack(const float *x) { return make_float4(x[0], x[1], x[2], x[3]); }
+__device__ __forceinline__ double2 pack(const double *x) { return make_double2(x[0], x[1]); }
+
+// The hub's context-bias row lives in LDS and is read / written by DIFFERENT lanes of the same wave from one tuple to the next.
+// LDS operations of a wave execute in program order, so all that is needed is that the compiler keeps that order: a
+// compiler-only barrier (a fence would also drain the spoke-row prefetch).
+__device__ __forceinline__ void chain_lds_order() { asm volatile("" ::: "memory"); }
+
+// the spoke side of one tuple: factor vectors, scalar bias (lane-uniform), the lane's context-bias cell
+template <typename T, int NV>
+struct SpokeRow {
+    typename Vec16<T>::type v[NV];
+    T sb, sc;
+    T *psc;
+    int spoke, cond;
+};
+
+template <typename T, int MODEL, int NV, bool RAGGED, bool HUB_ITEM>
+__device__ __forceinline__ void chain_load_spoke(const SgdArgs<T> &a, int spoke, int cond, int l16, int K, SpokeRow<T, NV> &r) {
+    using M = Traits<MODEL>;
+    using V = typename Vec16<T>::type;
+    constexpr int E = Vec16<T>::E;
+    constexpr bool SB = HUB_ITEM ? M::has_bu : M::has_bj;  // scalar bias on the spoke side
+    constexpr bool SC = HUB_ITEM ? M::has_uc : M::has_ic;  // context-bias table on the spoke side
+    T *tab = HUB_ITEM ? a.P : a.Q;
+    const V *row = reinterpret_cast<const V *>(tab + (size_t)spoke * K) + l16;
+    r.spoke = spoke;
+    r.cond = cond;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        T z[E];
+#pragma unroll
+        for (int c = 0; c < E; ++c) z[c] = (T)0;
+        r.v[v] = pack(z);
+        if (!RAGGED || E * l16 + 16 * E * v < K) r.v[v] = row[v * 16];
+    }
+    r.sb = (T)0;
+    r.sc = (T)0;
+    r.psc = nullptr;
+    if (SB) r.sb = (HUB_ITEM ? a.userBias : a.itemBias)[spoke];
+    if (SC && cond >= 0) {
+        r.psc = (HUB_ITEM ? a.ucBias : a.icBias) + (size_t)spoke * a.n_conds + cond;
+        r.sc = *r.psc;
+    }
+}
+
+template <typename T>
+struct ChainHp {
+    T lr, regU, regI, regB, regC, gm;
+};
+
+// One update: hub registers (h, hb, the LDS copy of the hub's context-bias row) x spoke row `cur`.  p = user side, q = item side;
+// every expression is the one of fast_tuples_f32 (mf_sgd_kernels.hip), in the same order.
+template <typename T, int MODEL, int NV, bool RAGGED, bool HUB_ITEM>
+__device__ __forceinline__ void chain_step(const SgdArgs<T> &a, const ChainHp<T> &hp, T (&h)[NV][Vec16<T>::E], T &hb, T *s_hc,
+                                           const SpokeRow<T, NV> &cur, T rr, int l16, int K, double &gloss) {
+    using M = Traits<MODEL>;
+    using V = typename Vec16<T>::type;
+    constexpr int E = Vec16<T>::E;
+    constexpr bool HB = HUB_ITEM ? M::has_bj : M::has_bu;  // scalar bias on the hub side
+    constexpr bool SB = HUB_ITEM ? M::has_bu : M::has_bj;
+    constexpr bool HC = HUB_ITEM ? M::has_ic : M::has_uc;  // context-bias table on the hub side (row kept in LDS)
+    constexpr bool SC = HUB_ITEM ? M::has_uc : M::has_ic;
+    const T lr = hp.lr, regU = hp.regU, regI = hp.regI, regB = hp.regB, regC = hp.regC;
+
+    T sp[NV][E];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) unpack(cur.v[v], sp[v]);
+    T part = (T)0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int c = 0; c < E; ++c) part += HUB_ITEM ? sp[v][c] * h[v][c] : h[v][c] * sp[v][c];
+    const T dot = row_sum16(part);
+
+    T hcv = (T)0; // the lane's hub-side context-bias cell (from the LDS copy of the hub's row)
+    if (HC) {
+        chain_lds_order();
+        if (cur.cond >= 0) hcv = s_hc[cur.cond];
+    }
+    const T bu = HUB_ITEM ? cur.sb : hb, bj = HUB_ITEM ? hb : cur.sb;
+    const T bic = HUB_ITEM ? hcv : cur.sc, buc = HUB_ITEM ? cur.sc : hcv;
+    T pred = hp.gm;
+    if (M::has_bu) pred += bu;
+    if (M::has_bj) pred += bj;
+    pred += dot;
+    if (M::has_ctx) {
+        T term = (T)0; // lane d carries the deviation of the tuple's d-th condition
+        if (M::has_ic && M::has_uc) term = bic + buc;
+        else if (M::has_ic) term = bic;
+        else if (M::has_uc) term = buc;
+        pred += row_sum16(term);
+    }
+    const T e = rr - pred;
+
+    // scalar biases: the hub's stays in registers, lane 0 stores the spoke's
+    if (HB) hb = hb + lr * (e - regB * hb);
+    if (SB && l16 == 0) (HUB_ITEM ? a.userBias : a.itemBias)[cur.spoke] = cur.sb + lr * (e - regB * cur.sb);
+    T ctx_loss = (T)0;
+    if (cur.cond >= 0) {
+        if (M::has_ic) ctx_loss += bic * bic;
+        if (M::has_uc) ctx_loss += buc * buc;
+        if (HC) s_hc[cur.cond] = hcv + lr * (e - regC * hcv);
+        if (SC) *cur.psc = cur.sc + lr * (e - regC * cur.sc);
+    }
+    if (HC) chain_lds_order();
+
+    T lsum = (T)0;
+    T *stab = HUB_ITEM ? a.P : a.Q;
+    V *srow = reinterpret_cast<V *>(stab + (size_t)cur.spoke * K) + l16;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        T sn[E];
+#pragma unroll
+        for (int c = 0; c < E; ++c) {
+            const T p = HUB_ITEM ? sp[v][c] : h[v][c], q = HUB_ITEM ? h[v][c] : sp[v][c];
+            const T pn = p + lr * (e * q - regU * p);
+            const T qn = q + lr * (e * p - regI * q);
+            lsum += (regU * p) * p + (regI * q) * q;
+            h[v][c] = HUB_ITEM ? qn : pn;
+            sn[c] = HUB_ITEM ? pn : qn;
+        }
+        if (!RAGGED || E * l16 + 16 * E * v < K) srow[v * 16] = pack(sn);
+    }
+    const T reg_loss = row_sum16(lsum);
+    const T ctx_sum = M::has_ctx ? row_sum16(ctx_loss) : (T)0;
+    if (l16 == 0) {
+        double l = (double)e * (double)e;
+        if (M::has_bu) l += (double)regB * bu * bu;
+        if (M::has_bj) l += (double)regB * bj * bj;
+        if (M::has_ctx) l += (double)regC * ctx_sum;
+        gloss += l + (double)reg_loss;
+    }
+}
+
+// LDS per 16-lane group: [hub context-bias row: n_conds x T (if the hub side has one)] [ratings: 16 x T] [spoke ids: 16 x i32]
+// [condition ids: 16 x dmax x i32] -- the unit's ids are staged once (one coalesced round trip) so that the chain loop has no
+// dependent global id -> row load pairs.
+__host__ __device__ inline size_t chain_group_lds(int n_conds_hub, int dmax, size_t esize) {
+    size_t b = (size_t)n_conds_hub * esize + 16 * esize + 16 * 4 + (size_t)16 * (dmax > 0 ? dmax : 0) * 4;
+    return (b + 15) & ~(size_t)15;
+}
+
+template <typename T, int MODEL, int NV, bool RAGGED, bool HUB_ITEM>
+__global__ __launch_bounds__(256) void sgd_chain_level(SgdArgs<T> a, const int32_t *__restrict__ unit_off, int64_t ubegin, int count,
+                                                       int64_t slot0) {
+    using M = Traits<MODEL>;
+    using V = typename Vec16<T>::type;
+    constexpr int E = Vec16<T>::E;
+    static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
+    constexpr bool HB = HUB_ITEM ? M::has_bj : M::has_bu;
+    constexpr bool HC = HUB_ITEM ? M::has_ic : M::has_uc;
+    extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+    __shared__ double s_loss[16];
+    const int tid = threadIdx.x, l16 = tid & 15, gib = tid >> 4;
+    const int g = blockIdx.x * 16 + gib;
+    const int K = RAGGED ? a.k : NV * 16 * E;
+    const int dmax = M::has_ctx ? a.dmax : 0;
+    double gloss = 0.0;
+    const HParams hpd = *a.hp;
+    const ChainHp<T> hp{(T)hpd.lr, (T)hpd.regU, (T)hpd.regI, (T)hpd.regB, (T)hpd.regC, (T)hpd.gm};
+
+    if (g < count) { // group-uniform
+        const int32_t tb = unit_off[ubegin + g], te = unit_off[ubegin + g + 1];
+        const int len = te - tb; // 1 .. 16
+        unsigned char *gbase = chain_smem + (size_t)gib * chain_group_lds(HC ? a.n_conds : 0, dmax, sizeof(T));
+        T *s_hc = reinterpret_cast<T *>(gbase);
+        T *s_rr = s_hc + (HC ? a.n_conds : 0);
+        int *s_sp = reinterpret_cast<int *>(s_rr + 16);
+        int *s_cd = s_sp + 16;
+
+        // ---- round trip 2: every id load of the unit is issued before the first one is used
+        const int hub = HUB_ITEM ? a.sj[tb] : a.su[tb];
+        const int sp0 = HUB_ITEM ? a.su[tb] : a.sj[tb];
+        const int cd0 = l16 < dmax ? a.sconds[(int64_t)tb * dmax + l16] : -1;
+        int my_sp = 0;
+        T my_rr = (T)0;
+        if (l16 < len) {
+            my_sp = HUB_ITEM ? a.su[tb + l16] : a.sj[tb + l16];
+            my_rr = a.sr[tb + l16];
+        }
+        const int n_cd = len * dmax; // <= 256 condition ids, staged 16 per pass
+        int cdv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cdv[r] = -1;
+            if (l16 + 16 * r < n_cd) cdv[r] = a.sconds[(int64_t)tb * dmax + l16 + 16 * r];
+        }
+
+        // ---- round trip 3: the hub row comes on chip once, together with the first spoke row
+        T *htab = HUB_ITEM ? a.Q : a.P;
+        V *hrow = reinterpret_cast<V *>(htab + (size_t)hub * K) + l16;
+        T h[NV][E];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+#pragma unroll
+            for (int c = 0; c < E; ++c) h[v][c] = (T)0;
+            if (!RAGGED || E * l16 + 16 * E * v < K) {
+                const V t = hrow[v * 16];
+                unpack(t, h[v]);
+            }
+        }
+        T hb = (T)0;
+        T *phb = nullptr;
+        if (HB) {
+            phb = (HUB_ITEM ? a.itemBias : a.userBias) + hub;
+            hb = *phb;
+        }
+        T *hc_row = nullptr;
+        T hcv4[4];
+        if (HC) {
+            hc_row = (HUB_ITEM ? a.icBias : a.ucBias) + (size_t)hub * a.n_conds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                hcv4[r] = (T)0;
+                if (l16 + 16 * r < a.n_conds) hcv4[r] = hc_row[l16 + 16 * r];
+            }
+        }
+        SpokeRow<T, NV> A, B;
+        chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, sp0, cd0, l16, K, A);
+
+        // ---- ids and the hub's context-bias row into LDS
+        if (l16 < len) {
+            s_sp[l16] = my_sp;
+            s_rr[l16] = my_rr;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (l16 + 16 * r < n_cd) s_cd[l16 + 16 * r] = cdv[r];
+        for (int c = l16 + 64; c < n_cd; c += 16) s_cd[c] = a.sconds[(int64_t)tb * dmax + c]; // dmax > 4 with long units
+        if (HC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (l16 + 16 * r < a.n_conds) s_hc[l16 + 16 * r] = hcv4[r];
+            for (int c = l16 + 64; c < a.n_conds; c += 16) s_hc[c] = hc_row[c]; // more than 64 conditions
+        }
+        chain_lds_order();
+
+        // ---- the chain: spoke rows ping-pong between two register sets, the next one in flight while this one is used
+        int i = 0;
+        while (true) {
+            if (i + 1 < len)
+                chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, B);
+            chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, A, s_rr[i], l16, K, gloss);
+            if (++i >= len) break;
+            if (i + 1 < len)
+                chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, A);
+            chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, B, s_rr[i], l16, K, gloss);
+            if (++i >= len) break;
+        }
+
+        // ---- the hub row leaves the chip once
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (!RAGGED || E * l16 + 16 * E * v < K) hrow[v * 16] = pack(h[v]);
+        if (HB && l16 == 0) *phb = hb;
+        if (HC) {
+            chain_lds_order();
+            for (int c = l16; c < a.n_conds; c += 16) hc_row[c] = s_hc[c];
+        }
+    }
+
+    if (l16 == 0) s_loss[gib] = gloss;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += s_loss[i];
+        a.loss_part[slot0 + blockIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+
+bool has_chain_path(int model, int k, int dmax, int n_conds, bool f64, bool strict) {
+    if (strict || model == CAMF_C) return false;
+    if (dmax > 16) return false;
+    if (f64) {
+        if (k < 32 || k > 256 || k % 2 != 0) return false;
+    } else {
+        if (k < 64 || k > 256 || k % 4 != 0) return false;
+    }
+    if (chain_lds_bytes(model, n_conds, dmax, f64, true) > 64 * 1024 || chain_lds_bytes(model, n_conds, dmax, f64, false) > 64 * 1024) return false;
+    return true;
+}
+
+size_t chain_lds_bytes(int model, int n_conds, int dmax, bool f64, bool hub_is_item) {
+    const bool has_ic = model == CAMF_CI || model == CAMF_CUCI, has_uc = model == CAMF_CU || model == CAMF_CUCI;
+    const bool hc = hub_is_item ? has_ic : has_uc;
+    const bool has_ctx = model != BIASEDMF && model != PMF;
+    return 16 * chain_group_lds(hc ? n_conds : 0, has_ctx ? dmax : 0, f64 ? 8 : 4);
+}
+
+int chain_level_blocks(int count) { return (count + 15) / 16; }
+
+template <typename T, int MODEL, int NV, bool RAGGED>
+static void *chain_kernel_hub(bool hub_is_item) {
+    return hub_is_item ? (void *)sgd_chain_level<T, MODEL, NV, RAGGED, true> : (void *)sgd_chain_level<T, MODEL, NV, RAGGED, false>;
+}
+
+template <typename T, int MODEL>
+static void *chain_kernel_k(int k, bool hub_is_item) {
+    constexpr int E = Vec16<T>::E;
+    const int per = 16 * E; // factors one vector slot covers across the group
+    if (k % per == 0) {
+        switch (k / per) {
+        case 1: return chain_kernel_hub<T, MODEL, 1, false>(hub_is_item);
+        case 2: return chain_kernel_hub<T, MODEL, 2, false>(hub_is_item);
+        case 4: return chain_kernel_hub<T, MODEL, 4, false>(hub_is_item);
+        case 8: if (E == 2) return chain_kernel_hub<T, MODEL, 8, false>(hub_is_item); break;
+        }
+    }
+    const int nv = (k + per - 1) / per; // masked vector slots past k
+    if (nv <= 2) return chain_kernel_hub<T, MODEL, 2, true>(hub_is_item);
+    if (nv <= 3) return chain_kernel_hub<T, MODEL, 3, true>(hub_is_item);
+    if (nv <= 4) return chain_kernel_hub<T, MODEL, 4, true>(hub_is_item);
+    if (E == 2) {
+        if (nv <= 6) return chain_kernel_hub<T, MODEL, 6, true>(hub_is_item);
+        if (nv <= 8) return chain_kernel_hub<T, MODEL, 8, true>(hub_is_item);
+    }
+    return nullptr;
+}
+
+template <typename T>
+static void *chain_kernel_ptr(int model, int k, bool hub_is_item) {
+    switch (model) {
+    case BIASEDMF: return chain_kernel_k<T, BIASEDMF>(k, hub_is_item);
+    case PMF: return chain_kernel_k<T, PMF>(k, hub_is_item);
+    case CAMF_CI: return chain_kernel_k<T, CAMF_CI>(k, hub_is_item);
+    case CAMF_CU: return chain_kernel_k<T, CAMF_CU>(k, hub_is_item);
+    case CAMF_CUCI: return chain_kernel_k<T, CAMF_CUCI>(k, hub_is_item);
+    }
+    return nullptr;
+}
+
+template <typename T>
+hipError_t launch_chain_level(const SgdArgs<T> &a, const LaunchCfg &cfg, bool hub_is_item, const int32_t *unit_off, int64_t ubegin,
+                              int count, int64_t slot0, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    void *fn = chain_kernel_ptr<T>(cfg.model, a.k, hub_is_item);
+    if (!fn) return hipErrorInvalidValue;
+    SgdArgs<T> args = a;
+    void *params[] = {&args, &unit_off, &ubegin, &count, &slot0};
+    const size_t lds = chain_lds_bytes(cfg.model, a.n_conds, a.dmax, sizeof(T) == 8, hub_is_item);
+    return hipLaunchKernel(fn, dim3((unsigned)chain_level_blocks(count)), dim3(256), params, lds, s);
+}
+template hipError_t launch_chain_level<float>(const SgdArgs<float> &, const LaunchCfg &, bool, const int32_t *, int64_t, int, int64_t,
+                                              hipStream_t);
+template hipError_t launch_chain_level<double>(const SgdArgs<double> &, const LaunchCfg &, bool, const int32_t *, int64_t, int, int64_t,
+                                               hipStream_t);
+
+} // namespace cmi

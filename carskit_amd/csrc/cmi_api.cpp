@@ -59,13 +59,24 @@ extern "C" int cmi_device_count(void) {
 
 extern "C" const char *cmi_last_error(cmi_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+static void free_eval_set(cmi_instance *h) {
+    void *ptrs[] = {h->d_eu, h->d_ej, h->d_ectx, h->d_er, h->d_epart};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    h->d_eu = h->d_ej = h->d_ectx = nullptr;
+    h->d_er = h->d_epart = nullptr;
+    h->n_eval = 0;
+}
+
+// the resident test tuples index the context table of the ratings they were uploaded against: they go with it
 static void free_ratings(cmi_instance *h) {
+    free_eval_set(h);
     if (h->graph_exec) {
         hipGraphExecDestroy(h->graph_exec);
         h->graph_exec = nullptr;
     }
     void *ptrs[] = {h->d_su, h->d_sj, h->d_sconds, h->d_ctx_ptr, h->d_ctx_conds, h->d_sr, h->d_loss_part,
-                    h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->d_tail_off, h->d_blk_off};
+                    h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->d_tail_off, h->d_blk_off, h->d_unit_off};
     for (void *p : ptrs)
         if (p) hipFree(p);
     h->d_su = h->d_sj = h->d_sconds = h->d_ctx_ptr = h->d_ctx_conds = nullptr;
@@ -73,6 +84,9 @@ static void free_ratings(cmi_instance *h) {
     h->d_flow_err = nullptr;
     h->d_tail_off = nullptr;
     h->d_blk_off = nullptr;
+    h->d_unit_off = nullptr;
+    h->chain = false;
+    h->n_units = 0;
     h->blk_off.clear();
     h->n_launches = h->n_tail = 0;
     h->tail_len.clear();
@@ -88,11 +102,6 @@ extern "C" int cmi_destroy(cmi_handle h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     free_ratings(h);
-    {
-        void *ev[] = {h->d_eu, h->d_ej, h->d_ectx, h->d_er, h->d_epart};
-        for (void *p : ev)
-            if (p) hipFree(p);
-    }
     for (void *&p : h->state)
         if (p) {
             hipFree(p);
@@ -265,6 +274,27 @@ static hipError_t upload(void **dst, const std::vector<V> &v, hipStream_t s) {
     return hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice, s);
 }
 
+// Hub-chain level schedule (level_schedule.cpp): used when forced, or when its levels are wide enough to fill the chip
+// (narrow levels -- heavy-tailed degrees, tiny data -- stay with the plain levels and their narrow-run launches).
+static int chain_max_len() {
+    int v = 16; // the kernel stages a unit's ids in 16 LDS slots per group
+    if (const char *env = getenv("CMI_CHAIN_MAX")) v = atoi(env);
+    return v < 1 ? 1 : (v > 16 ? 16 : v);
+}
+static bool try_chain(cmi_instance *h, int64_t n, const int32_t *u, const int32_t *j, ChainSchedule &csch) {
+    int hub = -1;
+    if (const char *env = getenv("CMI_CHAIN_HUB")) hub = !strcmp(env, "item") ? 1 : (!strcmp(env, "user") ? 0 : -1);
+    if (!build_chain_schedule(n, u, j, h->n_users, h->n_items, hub, chain_max_len(), csch)) return false;
+    int64_t min_width = 2048; // mean units per level
+    if (const char *env = getenv("CMI_CHAIN_MIN_WIDTH")) min_width = atoll(env);
+    const bool forced = h->flags & CMI_FLAG_SCHED_CHAIN;
+    if (!forced && csch.n_units() < min_width * csch.n_levels()) return false;
+    h->chain = true;
+    h->chain_hub_item = csch.hub_is_item != 0;
+    h->n_units = csch.n_units();
+    return true;
+}
+
 extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                                const double *r, int32_t n_ctx, const int32_t *ctx_ptr, const int32_t *ctx_conds) {
     if (!h) return CMI_E_INVALID;
@@ -306,6 +336,12 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     // schedule
     LevelSchedule sch;
     FlowSchedule fsch;
+    ChainSchedule csch;
+    const bool chain_ok = !h->serial && !h->want_flow && !h->want_two_lane && !(h->flags & CMI_FLAG_NO_CHAIN) &&
+                          has_chain_path(h->model, h->k, dmax, h->n_conds, h->f64, h->strict) && !getenv("CMI_NO_CHAIN");
+    if ((h->flags & CMI_FLAG_SCHED_CHAIN) && !chain_ok)
+        CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: CMI_FLAG_SCHED_CHAIN: no hub-chain kernel for model %d, k=%d, %s state%s (or another "
+                 "schedule flag is set)", h->model, h->k, h->f64 ? "fp64" : "fp32", h->strict ? ", strict" : "");
     h->flow = false;
     h->flow_blocks = 0;
     const bool tables_fit_raw_buffer = (int64_t)h->n_users * h->k * 4 < ((int64_t)1 << 32) &&
@@ -339,6 +375,11 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
                 build_conflict_free_blocks(n, u, j, h->n_users, h->n_items, 64, off);
                 if ((double)n / (double)(off.size() - 1) >= 3.0) h->blk_off.swap(off); // shorter runs: the serial wave is faster
             }
+        } else if (chain_ok && n > 0 && try_chain(h, n, u, j, csch)) {
+            // hub-chain levels: level_off indexes UNITS; sch.perm carries the stream order
+            sch.perm.swap(csch.perm);
+            sch.level_off = csch.level_off;
+            sch.max_level = csch.max_level_units;
         } else if (h->fast && exact_k && h->use_graph && h->want_two_lane && n > 0) {
             SplitSchedule ss;
             if (!build_split_schedule(n, u, j, h->n_users, h->n_items, ss))
@@ -358,15 +399,18 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             if (!build_level_schedule(n, u, j, h->n_users, h->n_items, order, sch))
                 CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: schedule construction failed");
         }
-        if (const char *env = getenv("CMI_DEBUG_MERGE_LEVELS")) { // TIMING EXPERIMENT ONLY: wrong results
+#ifdef CMI_TIMING_EXPERIMENTS // never in a release build: merging dependent levels gives WRONG results (boundary-cost timing only)
+        if (const char *env = getenv("CMI_DEBUG_MERGE_LEVELS")) {
             const int m = atoi(env);
             if (m > 1) {
+                fprintf(stderr, "[cmi] CMI_DEBUG_MERGE_LEVELS=%d: dependent levels merged, results are WRONG (timing experiment)\n", m);
                 std::vector<int64_t> lo;
                 for (size_t i = 0; i + 1 < sch.level_off.size(); i += (size_t)m) lo.push_back(sch.level_off[i]);
                 lo.push_back(sch.level_off.back());
                 sch.level_off = lo;
             }
         }
+#endif
         h->level_off = sch.level_off;
         h->max_level = sch.max_level;
         const int64_t n_levels = (int64_t)h->level_off.size() - 1;
@@ -375,11 +419,12 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         // tuples each is walked by ONE single-workgroup launch instead of one launch per level
         h->tail_len.assign((size_t)n_levels, 0);
         h->n_launches = 0;
-        if (!h->serial && !h->two_lane && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 256, 16, h->tail_len);
+        if (!h->serial && !h->two_lane && !h->chain && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 256, 16, h->tail_len);
         h->slot_off.assign((size_t)n_levels + 1, 0);
         for (int64_t l = 0; l < n_levels; ++l) {
             const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
             int blocks = h->serial ? 0
+                         : h->chain ? chain_level_blocks(cnt)
                          : h->fast ? level_blocks_f32_fast(h->k, cnt)
                          : h->small ? level_blocks_small(h->k, dmax, cnt)
                                     : level_blocks_generic(cnt);
@@ -445,7 +490,12 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (e == hipSuccess) e = upload((void **)&h->d_ctx_conds, cc, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // cp/cc are locals
     }
-    if (e == hipSuccess && h->n_slots > 0) e = hipMalloc((void **)&h->d_loss_part, (size_t)h->n_slots * sizeof(double));
+    if (e == hipSuccess && h->chain) e = upload((void **)&h->d_unit_off, csch.unit_off, h->stream);
+    if (e == hipSuccess && h->n_slots > 0) {
+        // zeroed: a launch shape that writes fewer slots than were reserved must not feed garbage into the loss
+        e = hipMalloc((void **)&h->d_loss_part, (size_t)h->n_slots * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_loss_part, 0, (size_t)h->n_slots * sizeof(double), h->stream);
+    }
     if (e == hipSuccess && !h->blk_off.empty()) {
         e = hipMalloc((void **)&h->d_blk_off, h->blk_off.size() * sizeof(int32_t));
         if (e == hipSuccess)
@@ -463,7 +513,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         CMI_FAIL(h, CMI_E_HIP, "set_ratings: upload failed: %s", hipGetErrorString(e));
     }
     h->n = n;
-    h->tuple_bytes = ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + (h->flow ? 8 : 0));
+    h->tuple_bytes = ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + (h->flow ? 8 : 0)) + (h->chain ? 4 * (h->n_units + 1) : 0);
     h->have_ratings = true;
     return CMI_OK;
 }
@@ -479,8 +529,8 @@ extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[8]) {
     for (int w = 0; w < CMI_STATE_COUNT; ++w) sb += h->state_count[w] * (int64_t)esize(h);
     info[4] = sb;
     info[5] = h->tuple_bytes;
-    info[6] = h->flow ? 2 : (h->serial ? 1 : (h->two_lane ? 3 : 0));
-    info[7] = h->flow ? h->flow_blocks : (h->d_blk_off ? (int64_t)h->blk_off.size() - 1 : 0);
+    info[6] = h->flow ? 2 : (h->serial ? 1 : (h->two_lane ? 3 : (h->chain ? (h->chain_hub_item ? 4 : 5) : 0)));
+    info[7] = h->flow ? h->flow_blocks : (h->chain ? h->n_units : (h->d_blk_off ? (int64_t)h->blk_off.size() - 1 : 0));
     return CMI_OK;
 }
 
@@ -530,7 +580,14 @@ static hipError_t enqueue_levels(cmi_instance *h) {
         if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);
         return e;
     }
-    if (h->f64) {
+    if (h->chain) {
+        for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l) {
+            const int64_t b = h->level_off[(size_t)l];
+            const int cnt = (int)(h->level_off[(size_t)l + 1] - b);
+            e = h->f64 ? launch_chain_level<double>(make_args<double>(h), cfg, h->chain_hub_item, h->d_unit_off, b, cnt, h->slot_off[(size_t)l], h->stream)
+                       : launch_chain_level<float>(make_args<float>(h), cfg, h->chain_hub_item, h->d_unit_off, b, cnt, h->slot_off[(size_t)l], h->stream);
+        }
+    } else if (h->f64) {
         const SgdArgs<double> a = make_args<double>(h);
         for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l) {
             const int32_t run = h->tail_len.empty() ? 0 : h->tail_len[(size_t)l];
@@ -835,14 +892,6 @@ extern "C" int cmi_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const
 
 // ---- resident test tuples: `--early-stop MAE|RMSE` evaluates the test set after EVERY epoch (IterativeRecommender.java:
 // 156-161); uploading it once instead of per call keeps that loop on the device
-static void free_eval_set(cmi_instance *h) {
-    void *ptrs[] = {h->d_eu, h->d_ej, h->d_ectx, h->d_er, h->d_epart};
-    for (void *p : ptrs)
-        if (p) hipFree(p);
-    h->d_eu = h->d_ej = h->d_ectx = nullptr;
-    h->d_er = h->d_epart = nullptr;
-    h->n_eval = 0;
-}
 
 extern "C" int cmi_set_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                                     const double *r) {
@@ -920,6 +969,25 @@ extern "C" int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j,
     }
     if (perm)
         for (int64_t s = 0; s < n; ++s) perm[s] = sch.perm[(size_t)s];
+    return CMI_OK;
+}
+
+extern "C" int cmi_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub,
+                                  int max_chain, int32_t *perm, int32_t *unit_off, int64_t unit_cap, int64_t *level_off,
+                                  int64_t level_cap, int64_t *n_units, int64_t *n_levels, int *hub_used) {
+    if (n < 0 || (n > 0 && (!u || !j)) || n_users <= 0 || n_items <= 0 || !n_units || !n_levels || max_chain < 1) return CMI_E_INVALID;
+    for (int64_t t = 0; t < n; ++t)
+        if (u[t] < 0 || u[t] >= n_users || j[t] < 0 || j[t] >= n_items) return CMI_E_INVALID;
+    ChainSchedule cs;
+    if (!build_chain_schedule(n, u, j, n_users, n_items, hub, max_chain, cs)) return CMI_E_UNSUPPORTED;
+    *n_units = cs.n_units();
+    *n_levels = cs.n_levels();
+    if (hub_used) *hub_used = cs.hub_is_item;
+    if (!perm) return CMI_OK;
+    if (!unit_off || !level_off || unit_cap < cs.n_units() + 1 || level_cap < cs.n_levels() + 1) return CMI_E_INVALID;
+    std::copy(cs.perm.begin(), cs.perm.end(), perm);
+    std::copy(cs.unit_off.begin(), cs.unit_off.end(), unit_off);
+    std::copy(cs.level_off.begin(), cs.level_off.end(), level_off);
     return CMI_OK;
 }
 

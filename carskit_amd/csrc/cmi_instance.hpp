@@ -15,6 +15,9 @@ struct cmi_instance {
     unsigned flags = 0;
     bool f64 = false, serial = false, strict = false, use_graph = true, fast = false, small = false, want_flow = false, flow = false,
          want_two_lane = false, two_lane = false;
+    bool chain = false, chain_hub_item = true; // hub-chain level schedule: level_off holds UNIT indices, d_unit_off the units
+    int32_t *d_unit_off = nullptr;
+    int64_t n_units = 0;
     std::vector<int64_t> split_off; // two-lane schedule: first tail position of every level
     std::string err;
     hipStream_t stream = nullptr;

@@ -272,4 +272,103 @@ void build_conflict_free_blocks(int64_t n, const int32_t *u, const int32_t *j, i
     if (n > 0) off.push_back((int32_t)n);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Hub-chain level schedule.
+//
+// The plain level schedule puts two tuples of the same item (or user) into different levels, so a row that is updated m
+// times per epoch is read and written m times from HBM and the epoch has at least m dependent launches.  But the reference's
+// order only says that the tuples of one row run in CRS order -- it does not say that somebody else has to run in between.
+// So let consecutive tuples of one HUB row (say item j: tuples t1 < t2 < ... in CRS order) be executed back to back by the
+// same 16-lane group, with Q[j], itemBias[j] and icBias[j,:] kept on chip between them, whenever the OTHER row of the later
+// tuple (its user) is already final, i.e. the user's previous tuple sits in a strictly earlier level:
+//     A = level of the hub row's previous tuple, B = level of the spoke row's previous tuple
+//     A > B and the hub's current unit has room  ->  the tuple joins that unit (same level A)
+//     otherwise                                  ->  it opens a new unit in level max(A, B) + 1.
+// Invariants (property-tested in tests/test_level_schedule.py): two tuples of one level that share a user or an item are in
+// the same unit; a unit's tuples share the hub, are consecutive in the hub's CRS chain and have pairwise distinct spokes
+// (equal spokes would give A == B); for every user and every item the (level, position in unit) order of its tuples is the
+// CRS order.  Hence executing levels in sequence, units of a level in parallel, and a unit's tuples in order applies to
+// every state element the same updates with the same operands as the sequential walk -- the same result as the plain
+// level schedule, bit for bit at equal arithmetic.
+// Inside a level the units are sorted by length, longest first (free: they are independent): the 4 groups of a wave then
+// walk chains of similar length and the longest chains are dispatched first.
+static void chain_pass(int64_t n, const int32_t *hub, const int32_t *spoke, int32_t n_hub, int32_t n_spoke, int max_chain,
+                       std::vector<int32_t> *level_out, std::vector<int32_t> *unit_out, std::vector<int32_t> *unit_level,
+                       std::vector<uint8_t> *unit_len, int32_t &n_levels, int64_t &n_units) {
+    std::vector<int32_t> lh((size_t)n_hub, 0), ls((size_t)n_spoke, 0), cur((size_t)n_hub, -1);
+    std::vector<uint8_t> cl((size_t)n_hub, 0);
+    n_levels = 0;
+    n_units = 0;
+    for (int64_t t = 0; t < n; ++t) {
+        const size_t hh = (size_t)hub[t], ss = (size_t)spoke[t];
+        const int32_t A = lh[hh], B = ls[ss];
+        int32_t l;
+        if (A > B && cl[hh] < max_chain) {
+            l = A;
+            cl[hh]++;
+            if (unit_len) (*unit_len)[(size_t)cur[hh]]++;
+        } else {
+            l = (A > B ? A : B) + 1;
+            cl[hh] = 1;
+            cur[hh] = (int32_t)n_units++;
+            if (unit_level) {
+                unit_level->push_back(l);
+                unit_len->push_back(1);
+            }
+        }
+        lh[hh] = ls[ss] = l;
+        if (level_out) (*level_out)[(size_t)t] = l;
+        if (unit_out) (*unit_out)[(size_t)t] = cur[hh];
+        if (l > n_levels) n_levels = l;
+    }
+}
+
+bool build_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int max_chain,
+                          ChainSchedule &out) {
+    out = ChainSchedule();
+    out.unit_off.push_back(0);
+    out.level_off.push_back(0);
+    if (max_chain < 1) max_chain = 1;
+    if (max_chain > 255) max_chain = 255;
+    out.hub_is_item = hub == 0 ? 0 : 1;
+    if (n <= 0) return true;
+    if (n >= (int64_t)1 << 31) return false;
+    int32_t nl = 0;
+    int64_t nu = 0;
+    if (hub < 0) { // fewer units = fewer hub-row round trips through HBM
+        int64_t units_item = 0, units_user = 0;
+        chain_pass(n, j, u, n_items, n_users, max_chain, nullptr, nullptr, nullptr, nullptr, nl, units_item);
+        chain_pass(n, u, j, n_users, n_items, max_chain, nullptr, nullptr, nullptr, nullptr, nl, units_user);
+        hub = units_item <= units_user ? 1 : 0;
+    }
+    out.hub_is_item = hub ? 1 : 0;
+    std::vector<int32_t> unit_of((size_t)n), unit_level;
+    std::vector<uint8_t> unit_len;
+    if (hub) chain_pass(n, j, u, n_items, n_users, max_chain, nullptr, &unit_of, &unit_level, &unit_len, nl, nu);
+    else chain_pass(n, u, j, n_users, n_items, max_chain, nullptr, &unit_of, &unit_level, &unit_len, nl, nu);
+    // counting sort of the units by (level ascending, length descending), stable in unit id (= CRS order of the first tuple)
+    const size_t nkeys = (size_t)nl * (size_t)max_chain;
+    std::vector<int64_t> key_off(nkeys + 1, 0);
+    auto key = [&](int64_t q) { return (size_t)(unit_level[(size_t)q] - 1) * (size_t)max_chain + (size_t)(max_chain - unit_len[(size_t)q]); };
+    for (int64_t q = 0; q < nu; ++q) key_off[key(q) + 1]++;
+    for (size_t x = 0; x < nkeys; ++x) key_off[x + 1] += key_off[x];
+    out.level_off.assign((size_t)nl + 1, 0);
+    for (int32_t l = 0; l <= nl; ++l) out.level_off[(size_t)l] = key_off[(size_t)l * (size_t)max_chain];
+    for (int32_t l = 0; l < nl; ++l) out.max_level_units = std::max(out.max_level_units, out.level_off[(size_t)l + 1] - out.level_off[(size_t)l]);
+    std::vector<int32_t> rank((size_t)nu); // unit id -> position in the schedule
+    {
+        std::vector<int64_t> cur(key_off.begin(), key_off.end() - 1);
+        for (int64_t q = 0; q < nu; ++q) rank[(size_t)q] = (int32_t)cur[key(q)]++;
+    }
+    out.unit_off.assign((size_t)nu + 1, 0);
+    for (int64_t q = 0; q < nu; ++q) out.unit_off[(size_t)rank[(size_t)q] + 1] = unit_len[(size_t)q];
+    for (int64_t q = 0; q < nu; ++q) out.unit_off[(size_t)q + 1] += out.unit_off[(size_t)q];
+    out.perm.resize((size_t)n);
+    {
+        std::vector<int32_t> fill(out.unit_off.begin(), out.unit_off.end() - 1);
+        for (int64_t t = 0; t < n; ++t) out.perm[(size_t)fill[(size_t)rank[(size_t)unit_of[(size_t)t]]]++] = (int32_t)t;
+    }
+    return true;
+}
+
 } // namespace cmi

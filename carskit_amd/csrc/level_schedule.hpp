@@ -44,6 +44,22 @@ bool build_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t
                           int within_level_order, LevelSchedule &out);
 
 
+// Hub-chain level schedule (see build_chain_schedule in level_schedule.cpp): a UNIT is a run of <= max_chain tuples that are
+// consecutive in the CRS order of one hub row (an item, or a user) and whose other-side rows (spokes) are pairwise distinct;
+// one 16-lane group walks a unit in order with the hub row resident in registers.  Units of a level are pairwise independent.
+struct ChainSchedule {
+    std::vector<int32_t> perm;      // stream position -> CRS tuple index; a unit's tuples are contiguous, in CRS order
+    std::vector<int32_t> unit_off;  // n_units+1 offsets into perm
+    std::vector<int64_t> level_off; // n_levels+1 offsets into unit_off (unit indices)
+    int hub_is_item = 1;
+    int64_t max_level_units = 0;    // most units in one level
+    int64_t n_units() const { return (int64_t)unit_off.size() - 1; }
+    int64_t n_levels() const { return (int64_t)level_off.size() - 1; }
+};
+// hub: 0 = chain along users (P[u] resident), 1 = along items (Q[j] resident), -1 = whichever gives fewer units
+bool build_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int max_chain,
+                          ChainSchedule &out);
+
 // Narrow runs of a level schedule: run_len[l] > 0 = a run of that many consecutive levels, each with <= max_tuples tuples,
 // starts at level l (one launch walks it); -1 = inside such a run; 0 = the level is launched on its own.  Runs shorter than
 // min_levels are not formed.  Returns the number of launches per epoch.

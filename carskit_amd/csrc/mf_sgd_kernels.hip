@@ -21,48 +21,12 @@
 // Built with -ffp-contract=off: the JVM never fuses a*b+c, and the strict fp64 path is bit-compared
 // with the CPU oracle.
 #include "mf_sgd_kernels.hpp"
+#include "sgd_device.hpp"
 
 #include <cstdlib>
 #include <cstring>
 
 namespace cmi {
-
-// ---------------------------------------------------------------------------------------------
-// cross-lane helpers
-// ---------------------------------------------------------------------------------------------
-
-// DPP row_ror:n -- lane l of each 16-lane row reads lane (l - n) mod 16 of the same row.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
-}
-
-// Sum over the 16 lanes of a DPP row; every lane ends with the bit-identical total (the rotation
-// tree pairs the same operands in every lane, and fp add is commutative).
-__device__ __forceinline__ float row_sum16(float x) {
-    x += dpp_f32<0x128>(x); // row_ror:8
-    x += dpp_f32<0x124>(x); // row_ror:4
-    x += dpp_f32<0x122>(x); // row_ror:2
-    x += dpp_f32<0x121>(x); // row_ror:1
-    return x;
-}
-
-template <typename T>
-__device__ __forceinline__ T wave_sum64(T x) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-    return x;
-}
-
-template <int MODEL>
-struct Traits {
-    static constexpr bool has_bu = MODEL == BIASEDMF || MODEL == CAMF_C || MODEL == CAMF_CI;
-    static constexpr bool has_bj = MODEL == BIASEDMF || MODEL == CAMF_C || MODEL == CAMF_CU;
-    static constexpr bool has_bc = MODEL == CAMF_C;
-    static constexpr bool has_ic = MODEL == CAMF_CI || MODEL == CAMF_CUCI;
-    static constexpr bool has_uc = MODEL == CAMF_CU || MODEL == CAMF_CUCI;
-    static constexpr bool has_ctx = !(MODEL == BIASEDMF || MODEL == PMF); // iterates the contextual matrix
-};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

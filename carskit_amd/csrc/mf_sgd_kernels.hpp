@@ -72,6 +72,15 @@ hipError_t graph_add_level_fast_f32(hipGraph_t g, hipGraphNode_t *node, const hi
 hipError_t graph_add_reduce_loss(hipGraph_t g, const hipGraphNode_t *deps, size_t ndeps, const double *loss_part,
                                  int64_t n_slots, double *scratch, double *loss_out);
 
+// Hub-chain level kernel (chain_kernels.hip): one 16-lane group walks a unit of the chain schedule with the hub row on chip.
+// units [ubegin, ubegin+count) of unit_off (n_units+1 device offsets into the tuple stream) form one level.
+bool has_chain_path(int model, int k, int dmax, int n_conds, bool f64, bool strict);
+size_t chain_lds_bytes(int model, int n_conds, int dmax, bool f64, bool hub_is_item);
+int chain_level_blocks(int count);
+template <typename T>
+hipError_t launch_chain_level(const SgdArgs<T> &a, const LaunchCfg &cfg, bool hub_is_item, const int32_t *unit_off, int64_t ubegin,
+                              int count, int64_t slot0, hipStream_t s);
+
 // Dataflow epoch: ONE persistent launch walks the padded schedule; tuples wait on per-row version counters.
 struct FlowArgs {
     const uint32_t *seq_u, *seq_j; // per padded position: version the tuple must observe

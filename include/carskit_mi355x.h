@@ -82,6 +82,12 @@ extern "C" {
 #define CMI_FLAG_TWO_LANE 0x40u /* fast path only, EXPERIMENTAL: a two-lane hipGraph in which the head of level l runs
                                       beside the tail of level l-1 (identical result).  Measured slower than the plain
                                       level launches in round 1 (the lanes stay in lock-step); see DESIGN.md */
+#define CMI_FLAG_SCHED_CHAIN 0x80u /* force the hub-chain level schedule (the default whenever its levels are wide enough):
+                                      consecutive tuples of one item (or user) whose other row is already final run back to
+                                      back in one 16-lane group with the shared row, its bias and its context-bias row kept on
+                                      chip; same result as the plain level schedule, bit for bit in fp32.
+                                      CMI_E_UNSUPPORTED at cmi_set_ratings if the model/k has no chain kernel */
+#define CMI_FLAG_NO_CHAIN 0x100u /* never use the hub-chain schedule (A/B runs against the plain level launches) */
 #define CMI_FLAG_NO_GRAPH 0x10u  /* launch the per-level kernels eagerly instead of replaying a hipGraph */
 
 typedef struct cmi_instance *cmi_handle;
@@ -211,7 +217,8 @@ int cmi_last_loss(cmi_handle h, double *loss_out);
 /* schedule facts: info[0]=level launches per epoch (a long run of narrow final levels counts as ONE launch: a single
  * workgroup walks them),  info[1]=largest level, info[2]=tuples,
  * info[3]=max conditions per tuple (D), info[4]=state bytes on device, info[5]=tuple-stream bytes on device,
- * info[6]=schedule kind actually running (0 level launches, 1 serial, 2 dataflow, 3 two-lane level graph),
+ * info[6]=schedule kind actually running (0 level launches, 1 serial, 2 dataflow, 3 two-lane level graph,
+ * 4 hub-chain levels along items, 5 hub-chain levels along users; then info[1]=most units in a level, info[7]=units),
  * info[7]=workgroups of the dataflow launch; for CAMF_C the number of conflict-free CRS blocks its epoch is cut into
  * (0: the serial wave) */
 int cmi_schedule_info(cmi_handle h, int64_t info[8]);
@@ -329,6 +336,14 @@ int cmi_transform(const char *train_in, const char *train_out, const char *test_
  * 1 sort by item id, 2 sort by user id (tuples of one level commute, so this is free). */
 int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int order,
                        int32_t *perm, int64_t *level_off, int64_t level_cap, int64_t *n_levels);
+
+/* The hub-chain form of the level schedule (level_schedule.cpp, build_chain_schedule; the default execution order).  hub: 1 chain
+ * along items, 0 along users, -1 pick the one with fewer units (*hub_used reports it).  perm[n]: stream position -> CRS tuple;
+ * unit_off[*n_units+1]: offsets of the units in perm; level_off[*n_levels+1]: offsets of the levels in unit_off (unit indices).
+ * Pass perm = NULL to only count (*n_units, *n_levels). */
+int cmi_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int max_chain,
+                       int32_t *perm, int32_t *unit_off, int64_t unit_cap, int64_t *level_off, int64_t level_cap,
+                       int64_t *n_units, int64_t *n_levels, int *hub_used);
 
 /* host-only views of two schedule post-passes (tests).  cmi_narrow_runs: run_len[l] > 0 = a run of that many consecutive
  * levels with <= max_tuples tuples each starts at level l and is walked by ONE launch (the library uses 256 / 16), -1 = inside

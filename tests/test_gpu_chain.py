@@ -1,0 +1,133 @@
+"""The hub-chain level kernel (carskit_amd/csrc/chain_kernels.hip; the default path on wide data) on the GPU.
+
+Bars:
+  * fp32 state: model state BIT-IDENTICAL to the plain level schedule's (same per-tuple expressions, and the chain schedule
+    commutes exactly -- tests/test_chain_schedule.py), loss to 1e-12 relative (same terms, other summation tree); and the
+    north_star bar against the oracle (RMSE/MAE within 1e-5);
+  * fp64 state (the fp64 fast path): RMSE/MAE within 1e-9 of the oracle, state within 1e-12.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from carskit_amd import capi, synth
+from oracle import oracle_c
+from tests import util
+from tests.test_gpu_parity import assert_state_equal, make_pair
+
+pytestmark = pytest.mark.gpu
+
+CHAIN, NOCHAIN, F64 = capi.FLAG_SCHED_CHAIN, capi.FLAG_NO_CHAIN, capi.FLAG_STATE_F64
+LEVEL_MODELS = [m for m in util.MODELS if m != "CAMF_C"]
+
+
+def _with_hub(hub, fn):
+    old = os.environ.get("CMI_CHAIN_HUB")
+    os.environ["CMI_CHAIN_HUB"] = hub
+    try:
+        return fn()
+    finally:
+        if old is None:
+            del os.environ["CMI_CHAIN_HUB"]
+        else:
+            os.environ["CMI_CHAIN_HUB"] = old
+
+
+@pytest.mark.parametrize("model", LEVEL_MODELS)
+@pytest.mark.parametrize("k", [64, 100, 128, 256])
+@pytest.mark.parametrize("hub", ["item", "user"])
+def test_chain_f32_state_bitwise_equals_plain_levels(model, k, hub):
+    data = util.small_data(n_users=3000, n_items=300, n_dims=4, conds_per_dim=4, n=50000, seed=31)
+    _, plain = make_pair(model, data, k, NOCHAIN)
+    _, chain = _with_hub(hub, lambda: make_pair(model, data, k, CHAIN))
+    info = chain.schedule_info()
+    assert info["kind"] == "chain-" + hub
+    u, j, _, _ = util.tuples_for(model, data)
+    assert info["levels"] < len(capi.level_schedule(u, j, data.n_users, data.n_items)[1]) - 1
+    lr = util.LR
+    for _ in range(3):
+        lp, lc = plain.train_epoch(lr), chain.train_epoch(lr)
+        assert abs(lp - lc) <= 1e-12 * abs(lp)
+    sp, sc = plain.get_states(), chain.get_states()
+    for name in sp:
+        assert np.array_equal(sp[name], sc[name]), name
+
+
+@pytest.mark.parametrize("model", LEVEL_MODELS)
+@pytest.mark.parametrize("hub", ["item", "user"])
+def test_chain_f32_vs_oracle_north_star_bar(model, hub):
+    data = util.small_data(n_users=3000, n_items=400, n_dims=4, conds_per_dim=4, n=60000, seed=24)
+    train, test = synth.split(data, 0.2)
+    orc, inst = _with_hub(hub, lambda: make_pair(model, train, 128, CHAIN))
+    o_losses, o_lrs, _ = orc.build_model(20, util.LR, bold_driver=True)
+    g_losses, g_lrs = inst.train(20, util.LR, bold_driver=True)
+    assert g_lrs.tolist() == o_lrs.tolist()
+    np.testing.assert_allclose(g_losses, o_losses, rtol=2e-5)
+    tctx = None if model in util.TWO_D else test.ctx
+    oe = orc.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+    ge = inst.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+    assert abs(oe["RMSE"] - ge["RMSE"]) <= 1e-5 and abs(oe["MAE"] - ge["MAE"]) <= 1e-5
+
+
+@pytest.mark.parametrize("model", LEVEL_MODELS)
+@pytest.mark.parametrize("k", [32, 64, 70, 128, 256])
+@pytest.mark.parametrize("hub", ["item", "user"])
+def test_chain_f64_fast_path_vs_oracle(model, k, hub):
+    data = util.small_data(n_users=400, n_items=60, n_dims=3, conds_per_dim=4, n=8000, seed=23)
+    train, test = synth.split(data, 0.2)
+    orc, inst = _with_hub(hub, lambda: make_pair(model, train, k, F64 | CHAIN))
+    assert inst.schedule_info()["kind"] == "chain-" + hub
+    o_losses, _, _ = orc.build_model(10, util.LR, bold_driver=True)
+    g_losses, _ = inst.train(10, util.LR, bold_driver=True)
+    np.testing.assert_allclose(g_losses, o_losses, rtol=1e-11)
+    tctx = None if model in util.TWO_D else test.ctx
+    oe = orc.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+    ge = inst.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+    for key in ("MAE", "RMSE", "NMAE", "rMAE", "rRMSE"):
+        assert abs(oe[key] - ge[key]) <= 1e-9, key
+    assert_state_equal(orc, inst, exact=False, atol=1e-12)
+
+
+@pytest.mark.parametrize("model", ["CAMF_CI", "CAMF_CU", "CAMF_CUCI"])
+def test_chain_many_conditions_and_dimensions(model):
+    """> 64 conditions (the LDS row is filled / written back by the remainder loops) and 6 dimensions with long units
+    (more than 64 condition ids staged per unit)."""
+    data = synth.generate(1500, 40, 6, 14, 40000, seed=41)   # 84 conditions, D = 6, ~1000 ratings per item
+    for hub in ("item", "user"):
+        _, plain = make_pair(model, data, 64, NOCHAIN)
+        _, chain = _with_hub(hub, lambda: make_pair(model, data, 64, CHAIN))
+        for _ in range(2):
+            lp, lc = plain.train_epoch(util.LR), chain.train_epoch(util.LR)
+            assert abs(lp - lc) <= 1e-12 * abs(lp)
+        sp, sc = plain.get_states(), chain.get_states()
+        for name in sp:
+            assert np.array_equal(sp[name], sc[name]), (hub, name)
+
+
+def test_chain_repeated_pairs_in_many_contexts():
+    """DePaulMovie-like data: the same (user, item) pair rated in several contexts = consecutive CRS tuples sharing BOTH rows;
+    they must never share a unit."""
+    data = synth.generate(40, 30, 2, 3, 6000, seed=43)      # 1200 pairs x up to 9 contexts
+    for model in ("CAMF_CI", "CAMF_CUCI"):
+        orc, inst = make_pair(model, data, 64, F64 | CHAIN)
+        for _ in range(3):
+            lo, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
+            assert abs(lo - lg) <= 1e-11 * abs(lo)
+        assert_state_equal(orc, inst, exact=False, atol=1e-12)
+
+
+def test_chain_is_the_default_on_wide_data_and_not_on_narrow():
+    wide = synth.generate_fast(200_000, 20_000, 4, 8, 4_000_000, seed=3)
+    state = synth.init_state("CAMF_CI", wide, 64, dtype=np.float32)
+    inst = capi.Instance("CAMF_CI", 64, wide.n_users, wide.n_items, wide.n_conds)
+    inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+    inst.set_ratings(wide.u, wide.j, wide.ctx, wide.r, wide.ctx_ptr, wide.ctx_conds)
+    inst.set_states(state)
+    assert inst.schedule_info()["kind"] == "chain-item"
+    assert np.isfinite(inst.train_epoch(util.LR))
+    narrow = util.small_data(n_users=300, n_items=40, n=4000, seed=22)
+    _, inst2 = make_pair("CAMF_CI", narrow, 64, 0)
+    assert inst2.schedule_info()["kind"] == "level"
+    with pytest.raises(capi.CmiError):       # forcing it where no chain kernel exists is an error, not a silent fallback
+        make_pair("CAMF_CI", narrow, 10, CHAIN)
