@@ -4,17 +4,20 @@
 A "step" is one epoch of buildModel(): one pass of the fused gather-dot-AXPY update over every training
 tuple, through the C ABI (libcarskit_mi355x.so), with tuples and model already resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|northstar|small]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|northstar|c5|small]
 
 N>1 is launched by the driver through torch.distributed.run (one rank per GPU): tuples are sharded by
 user (each rank owns its own users and their ratings: weak scaling, per-GPU work fixed), the item-side
-state (Q, icBias) is replicated and its per-epoch deltas are summed with an RCCL all-reduce
-(carskit_amd/dist.py).  Prints ONE JSON line on rank 0.
+state (Q, icBias) is replicated and the mean of the ranks' per-epoch moves is applied after a reduce-scatter +
+all-gather of one flat bucket over RCCL (carskit_amd/dist.py).  Prints ONE JSON line on rank 0:
+the BASELINE metric at fp32 state (`value`, `roofline`, `cpu_baseline`), plus -- at N=1 -- a secondary `f64` object (the same
+workload with the model kept in fp64, the reference's own precision) and the part's measured ceilings (`roofline.peak_measured`).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -38,21 +41,24 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
-def algorithmic_bytes(model, k, d):
-    """B = 16 + 4D + 16k + 8S + 8DT (fp32 state, int32 ids, compulsory traffic, no reuse)."""
-    s, t = {"BiasedMF": (2, 0), "CAMF_C": (2, 1), "CAMF_CI": (1, 1), "CAMF_CU": (1, 1), "CAMF_CUCI": (0, 2)}[model]
-    return 16 + 4 * d + 16 * k + 8 * s + 8 * d * t
+def algorithmic_bytes(model, k, d, esize=4):
+    """B = 16 + 4D + 16k + 8S + 8DT for fp32 state (int32 ids, compulsory traffic, no reuse).  With fp64
+    state every model element and the rating double: B = 20 + 4D + 32k + 16S + 16DT."""
+    s, t = {"BiasedMF": (2, 0), "PMF": (0, 0), "CAMF_C": (2, 1), "CAMF_CI": (1, 1), "CAMF_CU": (1, 1), "CAMF_CUCI": (0, 2)}[model]
+    return 12 + esize + 4 * d + 4 * esize * k + 2 * esize * s + 2 * esize * d * t
 
 
-def measured_traffic(workload):
+def measured_traffic(workload, schedule):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/<round>_<workload>_pmc.json, written
-    by tools/pmc_summary.py from FETCH_SIZE/WRITE_SIZE runs of this same command); None if not collected."""
+    by tools/pmc_summary.py from FETCH_SIZE/WRITE_SIZE runs of this same command); None if not collected for the schedule
+    that is running."""
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % workload)))
-    if not cands:
-        return None, None
-    d = json.load(open(cands[-1]))
-    return d.get("hbm_bytes_per_launch"), os.path.relpath(cands[-1], ROOT)
+    for path in reversed(cands):
+        d = json.load(open(path))
+        if d.get("schedule", "level") == schedule:
+            return d.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def log(*a):
@@ -60,19 +66,56 @@ def log(*a):
 
 
 def cpu_baseline(model, k, data, state, gm, regs, lr, budget_tuples):
-    """The oracle (order-exact fp64 restatement of the Java loop, 1 thread) on a prefix of the same tuples."""
+    """The oracle (order-exact fp64 restatement of the Java loop, 1 thread) on a prefix of the same tuples; then five of them
+    side by side = what the reference's `cv -k 5 -p on` (one Java thread per fold, CARSKit.java:395-412) gets out of the host."""
     from oracle import oracle_c
     m = min(data.n, budget_tuples)
-    st = {n: np.asarray(a, dtype=np.float64) for n, a in state.items()}
-    orc = oracle_c.Oracle(model, k, data.n_users, data.n_items, data.n_conds, data.u[:m], data.j[:m], data.ctx[:m],
-                          data.r[:m], data.ctx_ptr, data.ctx_conds, st, gm, *regs)
+
+    def make():
+        st = {n: np.asarray(a, dtype=np.float64) for n, a in state.items()}
+        return oracle_c.Oracle(model, k, data.n_users, data.n_items, data.n_conds, data.u[:m], data.j[:m], data.ctx[:m],
+                               data.r[:m], data.ctx_ptr, data.ctx_conds, st, gm, *regs)
+    orc = make()
     t0 = time.perf_counter()
     orc.epoch(lr)
     dt = time.perf_counter() - t0
-    return {"value": m / dt, "unit": "rating-updates/s", "cores": 1, "kind": "port",
-            "sample": "1 epoch over the first %d tuples of the same workload, fp64 order-exact C restatement of the "
-                      "Java loop, single thread (host has %d cores; the reference loop is single-threaded per fold)"
-                      % (m, os.cpu_count() or 0), "seconds": dt}
+    out = {"value": m / dt, "unit": "rating-updates/s", "cores": 1, "kind": "port",
+           "sample": "1 epoch over the first %d tuples of the same workload, fp64 order-exact C restatement of the "
+                     "Java loop, single thread (host has %d cores; the reference loop is single-threaded per fold)"
+                     % (m, os.cpu_count() or 0), "seconds": dt}
+    folds = [orc] + [make() for _ in range(4)]
+    ths = [threading.Thread(target=o.epoch, args=(lr,)) for o in folds]   # the C call releases the GIL
+    t0 = time.perf_counter()
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    dt5 = time.perf_counter() - t0
+    out["five_fold"] = {"value": 5 * m / dt5, "cores": 5, "seconds": dt5,
+                        "sample": "5 independent folds (5 threads) over the same prefix, aggregate updates/s"}
+    return out
+
+
+def make_instance(model, k, data, n_items, state, regs, gm, device, flags):
+    inst = capi.Instance(model, k, data.n_users, n_items, data.n_conds, device=device, flags=flags)
+    inst.set_hparams(*regs, gm)
+    inst.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
+    inst.set_states(state)
+    return inst
+
+
+def roofline(model, k, n_dims, data_n, info, kern_ms, esize, workload):
+    bpu = algorithmic_bytes(model, k, n_dims, esize)
+    launches = info["levels"]
+    achieved = data_n * bpu / (kern_ms * 1e-3) / 1e9
+    chain = info["kind"].startswith("chain")
+    tname = "float" if esize == 4 else "double"
+    traffic, src = measured_traffic(workload, info["kind"]) if esize == 4 else (None, None)
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src,
+            "kernel": ("sgd_chain_level<%s,%s,hub=%s>" % (tname, model, info["kind"][6:]) if chain
+                       else "sgd_level_fast_f32<%s,%d>" % (model, k // 64) if esize == 4 else "sgd_level_generic<double,%s>" % model),
+            "schedule": info["kind"], "bytes_per_update": bpu, "launches_per_epoch": launches,
+            "units_per_epoch": info["flow_blocks"] if chain else None,
+            "avg_launch_us": kern_ms * 1e3 / launches, "bytes_per_launch": data_n * bpu / launches}
 
 
 def main():
@@ -83,7 +126,11 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tuples", type=int, default=20_000_000)
-    ap.add_argument("--flags", type=int, default=0, help="extra cmi_create flags (e.g. 16 = no hipGraph)")
+    ap.add_argument("--no-f64", action="store_true", help="skip the secondary fp64-state measurement")
+    ap.add_argument("--f64-steps", type=int, default=3)
+    ap.add_argument("--no-calibration", action="store_true", help="skip the in-run HBM calibration kernels")
+    ap.add_argument("--merge", default="mean", choices=("mean", "sum"), help="multi-GPU merge rule of the item-side moves")
+    ap.add_argument("--flags", type=int, default=0, help="extra cmi_create flags (e.g. 16 = no hipGraph, 256 = no hub-chain)")
     ap.add_argument("--k", type=int, default=0, help="experiment knob: override the workload's num.factors")
     ap.add_argument("--model", default="", help="experiment knob: override the workload's recommender")
     ap.add_argument("--item-zipf", type=float, default=0.0,
@@ -141,8 +188,8 @@ def main():
     state = synth.init_state(model, data, k, seed=synth.DEFAULT_SEED + 2, dtype=np.float32)
     if world > 1:
         # item-side state must start identical on every rank; user-side differs per rank
-        rng_u = np.random.default_rng(synth.DEFAULT_SEED + 7 + rank)
         # (only the user-side containers this model owns: CAMF_CU / CAMF_CUCI / PMF have no userBias)
+        rng_u = np.random.default_rng(synth.DEFAULT_SEED + 7 + rank)
         state["P"] = (0.1 * rng_u.standard_normal(state["P"].shape)).astype(np.float32)
         if "userBias" in state:
             state["userBias"] = (0.1 * rng_u.standard_normal(state["userBias"].shape)).astype(np.float32)
@@ -151,32 +198,24 @@ def main():
     log("rank %d: init state in %.1fs" % (rank, time.perf_counter() - t0))
 
     t0 = time.perf_counter()
-    inst = capi.Instance(model, k, data.n_users, n_items, data.n_conds, device=local_rank, flags=args.flags)
-    inst.set_hparams(*regs, gm)
-    inst.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
-    inst.set_states(state)
+    inst = make_instance(model, k, data, n_items, state, regs, gm, local_rank, args.flags)
     info = inst.schedule_info()
     log("rank %d: schedule + upload in %.1fs: %s" % (rank, time.perf_counter() - t0, info))
 
     trainer = None
     if world > 1:
-        trainer = cdist.ShardedEpochRunner(inst, dist, device_index=local_rank)
+        trainer = cdist.ShardedEpochRunner(inst, dist, device_index=local_rank, merge=args.merge)
     extra = []
     if args.folds > 1:
         if world > 1:
             raise SystemExit("--folds is a single-GPU mode")
         for _ in range(args.folds - 1):        # further folds: same tuples, independent models and streams
-            other = capi.Instance(model, k, data.n_users, n_items, data.n_conds, device=local_rank, flags=args.flags)
-            other.set_hparams(*regs, gm)
-            other.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
-            other.set_states(state)
-            extra.append(other)
+            extra.append(make_instance(model, k, data, n_items, state, regs, gm, local_rank, args.flags))
 
     def step():
         if trainer is not None:
             return trainer.epoch(lr)
         if extra:
-            import threading
             ths = [threading.Thread(target=o.train_epoch, args=(lr,)) for o in extra]
             [t.start() for t in ths]
             loss = inst.train_epoch(lr)
@@ -190,17 +229,20 @@ def main():
         torch.cuda.synchronize()
         inst.synchronize()
 
+    losses = []
     for _ in range(args.warmup):
-        step()
+        losses.append(step())
     barrier()
     t0 = time.perf_counter()
     gpu_ms = []
-    loss = None
     for _ in range(args.steps):
-        loss = step()
+        losses.append(step())
         gpu_ms.append(inst.last_epoch_ms())
     barrier()
     elapsed = time.perf_counter() - t0
+    # a diverging run is not a measurement: the loss must be finite and must not have grown over the run (one rate, no bold driver)
+    if not np.all(np.isfinite(losses)) or (len(losses) > 1 and losses[-1] > losses[0]):
+        raise SystemExit("bench: training diverged (epoch losses %s) -- throughput of a diverging run is not reported" % losses)
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -212,15 +254,11 @@ def main():
         total_tuples = float(data.n) * args.folds
 
     if rank == 0:
-        bytes_per_update = algorithmic_bytes(model, k, n_dims)
         kern_ms = float(np.mean(gpu_ms))          # HIP events on the instance stream around one epoch's launches
-        launches = info["levels"]
         # with concurrent folds the streams overlap, so the per-stream event time no longer isolates one kernel:
         # use the wall time of the step for the aggregate
         if args.folds > 1:
             kern_ms = elapsed / args.steps * 1e3 / args.folds
-        achieved = data.n * bytes_per_update / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(args.workload)
         out = {
             "metric": "SGD rating-updates/sec, %s k=%d" % (model, k),
             "value": total_tuples * args.steps / elapsed,
@@ -230,19 +268,47 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s k=%d, %d users x %d items x %d conditions (%d dims), %d ratings per GPU, "
-                                   "lr 0.02f reg 1e-4f regC 1e-3f, order-exact dependency-level schedule"
-                                   % (args.workload, model, k, data.n_users, n_items, data.n_conds, n_dims, data.n),
-                       "levels_per_epoch": launches, "final_loss": loss, "concurrent_folds": args.folds,
-                       "parallelism": "1 GPU" if world == 1 else "user-sharded x%d + RCCL all-reduce of item-side deltas" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("sgd_chain_level<float,%s,%d,hub=%s>" % (model, k // 64, info["kind"][6:])
-                                    if info["kind"].startswith("chain") else "sgd_level_fast_f32<%s,%d>" % (model, k // 64)),
-                         "schedule": info["kind"], "bytes_per_update": bytes_per_update,
-                         "launches_per_epoch": launches,
-                         "avg_launch_us": kern_ms * 1e3 / launches,
-                         "bytes_per_launch": data.n * bytes_per_update / launches},
+                                   "lr 0.02f reg 1e-4f regC 1e-3f, order-exact %s schedule"
+                                   % (args.workload, model, k, data.n_users, n_items, data.n_conds, n_dims, data.n,
+                                      "hub-chain level" if info["kind"].startswith("chain") else "dependency-level"),
+                       "levels_per_epoch": info["levels"], "first_loss": losses[0], "final_loss": losses[-1],
+                       "concurrent_folds": args.folds,
+                       "parallelism": "1 GPU" if world == 1 else
+                       "user-sharded x%d + RCCL reduce-scatter/all-gather of item-side moves (%s merge)" % (world, args.merge)},
+            "roofline": roofline(model, k, n_dims, data.n, info, kern_ms, 4, args.workload),
         }
+        for o in extra:
+            o.close()
+        if world == 1 and not args.no_calibration:
+            try:
+                inst.synchronize()
+                cp, rw = capi.measure_hbm(local_rank, 4 << 30)
+                out["roofline"]["peak_measured"] = {"copy_GBps": cp, "random_512B_row_rw_GBps": rw,
+                                                    "method": "cmi_measure_hbm over a 4 GiB scratch buffer, best of 3 after warm-up"}
+            except Exception as e:
+                out["roofline"]["peak_measured"] = {"error": repr(e)}
+        if world == 1 and not args.no_f64 and args.folds == 1:
+            # secondary line: the same workload with the model kept in fp64 on the GPU (the reference's precision)
+            try:
+                inst.close()
+                st64 = {n: a.astype(np.float64) for n, a in state.items()}
+                i64 = make_instance(model, k, data, n_items, st64, regs, gm, local_rank, args.flags | capi.FLAG_STATE_F64)
+                info64 = i64.schedule_info()
+                l64 = [i64.train_epoch(lr)]
+                i64.synchronize()
+                t0 = time.perf_counter()
+                ms64 = []
+                for _ in range(args.f64_steps):
+                    l64.append(i64.train_epoch(lr))
+                    ms64.append(i64.last_epoch_ms())
+                i64.synchronize()
+                el64 = time.perf_counter() - t0
+                out["f64"] = {"dtype": "f64", "value": data.n * args.f64_steps / el64, "unit": "rating-updates/s",
+                              "steps": args.f64_steps, "ms_per_step": el64 / args.f64_steps * 1e3, "final_loss": l64[-1],
+                              "roofline": roofline(model, k, n_dims, data.n, info64, float(np.mean(ms64)), 8, args.workload)}
+                i64.close()
+            except Exception as e:
+                out["f64"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(model, k, data, state, gm, regs, lr, args.cpu_tuples)

@@ -51,6 +51,8 @@ SYMBOLS = [
     ("cmi_train_epoch", C.c_int, [_vp, _dbl, C.POINTER(_dbl)]),
     ("cmi_train", C.c_int, [_vp, C.c_int, _dbl, _dbl, C.c_int, _dbl, C.c_int, _vp, _vp, C.POINTER(C.c_int),
                             C.POINTER(_dbl)]),
+    ("cmi_train_from", C.c_int, [_vp, C.c_int, _dbl, C.c_int, _dbl, _dbl, C.c_int, _dbl, C.c_int, _vp, _vp, C.POINTER(C.c_int),
+                                 C.POINTER(_dbl)]),
     ("cmi_predict_batch", C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, _dbl, _dbl, _vp]),
     ("cmi_eval_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, C.POINTER(_i64)]),
     ("cmi_set_eval_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
@@ -71,7 +73,14 @@ SYMBOLS = [
     ("cmi_synchronize", C.c_int, [_vp]),
     ("cmi_train_epoch_async", C.c_int, [_vp, _dbl]),
     ("cmi_last_loss", C.c_int, [_vp, C.POINTER(_dbl)]),
+    ("cmi_save_model", C.c_int, [_vp, C.c_char_p, C.c_double, C.c_double, C.c_int]),
+    ("cmi_load_model", C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    ("cmi_measure_hbm", C.c_int, [C.c_int, _i64, C.POINTER(C.c_double)]),
     ("cmi_schedule_info", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("cmi_exchange_setup", C.c_int, [_vp, _i64, C.POINTER(_vp), C.POINTER(_i64)]),
+    ("cmi_exchange_pack", C.c_int, [_vp]),
+    ("cmi_exchange_apply", C.c_int, [_vp, C.c_double]),
+    ("cmi_loss_device_ptr", C.c_int, [_vp, C.POINTER(_vp)]),
     ("cmi_last_epoch_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("cmi_level_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, _vp, _vp, _i64, C.POINTER(_i64)]),
     ("cmi_chain_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _i64, C.POINTER(_i64),
@@ -216,6 +225,15 @@ def device_count():
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def measure_hbm(device=0, nbytes=4 << 30):
+    """(copy GB/s, random-512-B-row read-modify-write GB/s) measured on the device right now (cmi_measure_hbm)."""
+    out = (C.c_double * 2)()
+    rc = lib().cmi_measure_hbm(device, nbytes, out)
+    if rc != OK:
+        raise CmiError(rc, "cmi_measure_hbm")
+    return float(out[0]), float(out[1])
 
 
 def level_schedule(u, j, n_users, n_items, order=0):
@@ -404,11 +422,13 @@ class Instance:
         self._chk(self.L.cmi_last_loss(self.h, C.byref(loss)))
         return loss.value
 
-    def train(self, num_iters, init_lrate, max_lrate=-1.0, bold_driver=False, decay=-1.0, early_stop=0):
+    def train(self, num_iters, init_lrate, max_lrate=-1.0, bold_driver=False, decay=-1.0, early_stop=0, first_iter=1,
+              prev_loss=0.0):
+        """cmi_train (first_iter == 1) / cmi_train_from: returns (losses, lrates) of the epochs run"""
         losses, lrs = np.zeros(num_iters), np.zeros(num_iters)
         n, final = C.c_int(0), _dbl(0)
-        rc = self.L.cmi_train(self.h, num_iters, init_lrate, max_lrate, int(bold_driver), decay, early_stop,
-                              _p(losses), _p(lrs), C.byref(n), C.byref(final))
+        rc = self.L.cmi_train_from(self.h, first_iter, prev_loss, num_iters, init_lrate, max_lrate, int(bold_driver), decay,
+                                   early_stop, _p(losses), _p(lrs), C.byref(n), C.byref(final))
         self.iters_run, self.final_lrate = n.value, final.value
         self._chk(rc)
         return losses[:n.value], lrs[:n.value]
@@ -438,6 +458,32 @@ class Instance:
         s = _vp()
         self._chk(self.L.cmi_stream(self.h, C.byref(s)))
         return s.value
+
+    def save_model(self, path, lrate=0.0, last_loss=0.0, epochs_done=0):
+        self._chk(self.L.cmi_save_model(self.h, str(path).encode(), lrate, last_loss, epochs_done))
+
+    def load_model(self, path):
+        """-> (lrate, last_loss, epochs_done) stored with the model"""
+        lr, ll, ep = C.c_double(), C.c_double(), C.c_int()
+        self._chk(self.L.cmi_load_model(self.h, str(path).encode(), C.byref(lr), C.byref(ll), C.byref(ep)))
+        return lr.value, ll.value, ep.value
+
+    def exchange_setup(self, pad_to=1):
+        """(device pointer, element count, numpy dtype) of the item-side exchange bucket; snapshots the current state."""
+        ptr, cnt = _vp(), _i64()
+        self._chk(self.L.cmi_exchange_setup(self.h, pad_to, C.byref(ptr), C.byref(cnt)))
+        return ptr.value, cnt.value, (np.float64 if self.flags & FLAG_STATE_F64 else np.float32)
+
+    def exchange_pack(self):
+        self._chk(self.L.cmi_exchange_pack(self.h))
+
+    def exchange_apply(self, scale):
+        self._chk(self.L.cmi_exchange_apply(self.h, float(scale)))
+
+    def loss_device_ptr(self):
+        p = _vp()
+        self._chk(self.L.cmi_loss_device_ptr(self.h, C.byref(p)))
+        return p.value
 
     def state_device_ptr(self, name):
         ptr, cnt, dt = _vp(), _i64(), C.c_int()

@@ -107,6 +107,8 @@ extern "C" int cmi_destroy(cmi_handle h) {
             hipFree(p);
             p = nullptr;
         }
+    if (h->d_xbucket) hipFree(h->d_xbucket);
+    if (h->d_xsnap) hipFree(h->d_xsnap);
     if (h->d_scratch) hipFree(h->d_scratch);
     if (h->d_loss) hipFree(h->d_loss);
     if (h->d_hp) hipFree(h->d_hp);
@@ -724,21 +726,25 @@ extern "C" int cmi_train_epoch(cmi_handle h, double lrate, double *loss_out) {
     return CMI_OK;
 }
 
-// IterativeRecommender.isConverged + updateLRate (IterativeRecommender.java:145-229), host side.
-extern "C" int cmi_train(cmi_handle h, int num_iters, double init_lrate, double max_lrate, int bold_driver,
-                         double decay, int early_stop, double *losses, double *lrates, int *iters_run,
-                         double *final_lrate) {
+// IterativeRecommender.isConverged + updateLRate (IterativeRecommender.java:145-229), host side.  first_iter / last_loss let a
+// reloaded model (cmi_load_model) continue the loop exactly where it stopped: the bold driver compares with the previous epoch's
+// loss and is off in iteration 1 only.
+extern "C" int cmi_train_from(cmi_handle h, int first_iter, double prev_loss, int num_iters, double init_lrate, double max_lrate,
+                              int bold_driver, double decay, int early_stop, double *losses, double *lrates, int *iters_run,
+                              double *final_lrate) {
     if (!h) return CMI_E_INVALID;
+    if (first_iter < 1) CMI_FAIL(h, CMI_E_INVALID, "train: first_iter must be >= 1");
     if (early_stop != 0 && early_stop != 1) CMI_FAIL(h, CMI_E_UNSUPPORTED, "train: early_stop must be 0 (none) or 1 (loss)");
-    double lr = init_lrate, last_loss = 0.0, measure = 0.0, last_measure = 0.0;
-    int it = 0;
+    double lr = init_lrate, last_loss = prev_loss, measure = 0.0, last_measure = 0.0;
+    if (early_stop == 1) last_measure = measure = prev_loss;
     if (iters_run) *iters_run = 0;
-    for (it = 1; it <= num_iters; ++it) {
+    for (int n = 0; n < num_iters; ++n) {
+        const int it = first_iter + n;
         double loss = 0.0;
-        if (lrates) lrates[it - 1] = lr;
+        if (lrates) lrates[n] = lr;
         if (int rc = cmi_train_epoch(h, lr, &loss)) return rc;
-        if (losses) losses[it - 1] = loss;
-        if (iters_run) *iters_run = it;
+        if (losses) losses[n] = loss;
+        if (iters_run) *iters_run = n + 1;
         if (early_stop == 1) {
             measure = loss;
             last_measure = last_loss;
@@ -762,9 +768,90 @@ extern "C" int cmi_train(cmi_handle h, int num_iters, double init_lrate, double 
     return CMI_OK;
 }
 
+extern "C" int cmi_train(cmi_handle h, int num_iters, double init_lrate, double max_lrate, int bold_driver,
+                         double decay, int early_stop, double *losses, double *lrates, int *iters_run,
+                         double *final_lrate) {
+    return cmi_train_from(h, 1, 0.0, num_iters, init_lrate, max_lrate, bold_driver, decay, early_stop, losses, lrates, iters_run, final_lrate);
+}
+
 extern "C" int cmi_stream(cmi_handle h, void **stream) {
     if (!h || !stream) return CMI_E_INVALID;
     *stream = (void *)h->stream;
+    return CMI_OK;
+}
+
+// ---- multi-GPU exchange plumbing ----------------------------------------------------------------------
+extern "C" int cmi_exchange_setup(cmi_handle h, int64_t pad_to, void **bucket, int64_t *count) {
+    if (!h || !bucket || !count || pad_to < 1) return CMI_E_INVALID;
+    if (h->model == CMI_MODEL_CAMF_C) CMI_FAIL(h, CMI_E_UNSUPPORTED, "exchange: CAMF_C shares condBias between all tuples and is not sharded");
+    CMI_HIP(h, hipSetDevice(h->device));
+    CMI_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->d_xbucket) hipFree(h->d_xbucket);
+    if (h->d_xsnap) hipFree(h->d_xsnap);
+    h->d_xbucket = h->d_xsnap = nullptr;
+    h->x_which.clear();
+    h->x_off.clear();
+    int64_t off = 0;
+    for (int w : {CMI_STATE_Q, CMI_STATE_ITEM_BIAS, CMI_STATE_IC_BIAS}) {
+        if (!cmi_model_has(h->model, w)) continue;
+        h->x_which.push_back(w);
+        h->x_off.push_back(off);
+        off += (h->state_count[w] + 3) / 4 * 4;
+    }
+    {   // total: a multiple of pad_to (even split over the ranks of a reduce-scatter) and of 4 elements (16-byte vectors)
+        int64_t g = pad_to, r4 = 4;
+        while (r4) {
+            const int64_t t = g % r4;
+            g = r4;
+            r4 = t;
+        }
+        const int64_t step = pad_to / g * 4;
+        off = (off + step - 1) / step * step;
+    }
+    h->x_count = off;
+    const size_t bytes = (size_t)off * esize(h);
+    CMI_HIP(h, hipMalloc(&h->d_xbucket, bytes));
+    CMI_HIP(h, hipMalloc(&h->d_xsnap, bytes));
+    CMI_HIP(h, hipMemsetAsync(h->d_xbucket, 0, bytes, h->stream));
+    CMI_HIP(h, hipMemsetAsync(h->d_xsnap, 0, bytes, h->stream));
+    for (size_t i = 0; i < h->x_which.size(); ++i) {
+        const int w = h->x_which[i];
+        CMI_HIP(h, hipMemcpyAsync((char *)h->d_xsnap + (size_t)h->x_off[i] * esize(h), h->state[w], (size_t)h->state_count[w] * esize(h),
+                                  hipMemcpyDeviceToDevice, h->stream));
+    }
+    CMI_HIP(h, hipStreamSynchronize(h->stream));
+    *bucket = h->d_xbucket;
+    *count = h->x_count;
+    return CMI_OK;
+}
+
+extern "C" int cmi_exchange_pack(cmi_handle h) {
+    if (!h) return CMI_E_INVALID;
+    if (!h->d_xbucket) CMI_FAIL(h, CMI_E_INVALID, "exchange_pack: call cmi_exchange_setup first");
+    CMI_HIP(h, hipSetDevice(h->device));
+    for (size_t i = 0; i < h->x_which.size(); ++i) {
+        const int w = h->x_which[i];
+        const size_t ob = (size_t)h->x_off[i] * esize(h);
+        CMI_HIP(h, launch_delta_pack(h->state[w], (char *)h->d_xsnap + ob, (char *)h->d_xbucket + ob, h->state_count[w], h->f64, h->stream));
+    }
+    return CMI_OK;
+}
+
+extern "C" int cmi_exchange_apply(cmi_handle h, double scale) {
+    if (!h) return CMI_E_INVALID;
+    if (!h->d_xbucket) CMI_FAIL(h, CMI_E_INVALID, "exchange_apply: call cmi_exchange_setup first");
+    CMI_HIP(h, hipSetDevice(h->device));
+    for (size_t i = 0; i < h->x_which.size(); ++i) {
+        const int w = h->x_which[i];
+        const size_t ob = (size_t)h->x_off[i] * esize(h);
+        CMI_HIP(h, launch_delta_apply(h->state[w], (char *)h->d_xsnap + ob, (char *)h->d_xbucket + ob, scale, h->state_count[w], h->f64, h->stream));
+    }
+    return CMI_OK;
+}
+
+extern "C" int cmi_loss_device_ptr(cmi_handle h, void **ptr) {
+    if (!h || !ptr) return CMI_E_INVALID;
+    *ptr = h->d_loss;
     return CMI_OK;
 }
 

@@ -53,6 +53,11 @@ struct cmi_instance {
     int32_t *d_eu = nullptr, *d_ej = nullptr, *d_ectx = nullptr;
     double *d_er = nullptr, *d_epart = nullptr;
     int64_t n_eval = 0;
+    // multi-GPU exchange of the item-side containers (cmi_exchange_*): bucket and snapshot share one layout
+    void *d_xbucket = nullptr, *d_xsnap = nullptr;
+    int64_t x_count = 0;
+    std::vector<int> x_which;       // containers in the bucket, in order
+    std::vector<int64_t> x_off;     // their element offsets (16-byte aligned segments)
     float last_rank_ms = 0.f;    // device time of the most recent cmi_eval_rankings scoring loop (HIP events)
     double last_rank_flops = 0.0; // 2 * queries * candidates * padded operand length of that loop
 };

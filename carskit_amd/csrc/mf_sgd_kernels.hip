@@ -1191,6 +1191,44 @@ __global__ void convert_kernel(const S *src, D *dst, int64_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// multi-GPU exchange of the replicated item-side state (carskit_amd/dist.py): two elementwise passes around the collective
+// ---------------------------------------------------------------------------------------------
+// pack:  bucket = state - snapshot                       (this rank's movement during the epoch)
+// apply: state = snapshot + scale * bucket; snapshot = state   (bucket now holds the sum over ranks)
+template <typename T>
+__global__ __launch_bounds__(256) void delta_pack_kernel(const T *__restrict__ state, const T *__restrict__ snap, T *__restrict__ bucket,
+                                                         int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        bucket[i] = state[i] - snap[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void delta_apply_kernel(T *__restrict__ state, T *__restrict__ snap, const T *__restrict__ bucket, T scale,
+                                                          int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T v = snap[i] + scale * bucket[i];
+        state[i] = v;
+        snap[i] = v;
+    }
+}
+// the float4 forms move 16 B per lane (segments are 16-byte aligned and padded to 4 elements on the host side)
+__global__ __launch_bounds__(256) void delta_pack_f32x4(const float4 *__restrict__ state, const float4 *__restrict__ snap,
+                                                        float4 *__restrict__ bucket, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = state[i], b = snap[i];
+        bucket[i] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    }
+}
+__global__ __launch_bounds__(256) void delta_apply_f32x4(float4 *__restrict__ state, float4 *__restrict__ snap, const float4 *__restrict__ bucket,
+                                                         float scale, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 b = snap[i], d = bucket[i];
+        const float4 v = make_float4(b.x + scale * d.x, b.y + scale * d.y, b.z + scale * d.z, b.w + scale * d.w);
+        state[i] = v;
+        snap[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // predict / evalRatings (Recommender.java:306-317, 504-594): fp64 arithmetic over the stored state
 // ---------------------------------------------------------------------------------------------
 
@@ -1793,6 +1831,27 @@ hipError_t launch_eval(const EvalArgs<T> &a, int64_t n, hipStream_t s) {
 }
 template hipError_t launch_eval<float>(const EvalArgs<float> &, int64_t, hipStream_t);
 template hipError_t launch_eval<double>(const EvalArgs<double> &, int64_t, hipStream_t);
+
+static unsigned elementwise_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+hipError_t launch_delta_pack(const void *state, const void *snap, void *bucket, int64_t n, bool f64, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (f64) hipLaunchKernelGGL(delta_pack_kernel<double>, dim3(elementwise_blocks(n)), dim3(256), 0, s, (const double *)state, (const double *)snap, (double *)bucket, n);
+    else if (n % 4 == 0 && ((uintptr_t)state | (uintptr_t)snap | (uintptr_t)bucket) % 16 == 0)
+        hipLaunchKernelGGL(delta_pack_f32x4, dim3(elementwise_blocks(n / 4)), dim3(256), 0, s, (const float4 *)state, (const float4 *)snap, (float4 *)bucket, n / 4);
+    else hipLaunchKernelGGL(delta_pack_kernel<float>, dim3(elementwise_blocks(n)), dim3(256), 0, s, (const float *)state, (const float *)snap, (float *)bucket, n);
+    return hipGetLastError();
+}
+hipError_t launch_delta_apply(void *state, void *snap, const void *bucket, double scale, int64_t n, bool f64, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (f64) hipLaunchKernelGGL(delta_apply_kernel<double>, dim3(elementwise_blocks(n)), dim3(256), 0, s, (double *)state, (double *)snap, (const double *)bucket, scale, n);
+    else if (n % 4 == 0 && ((uintptr_t)state | (uintptr_t)snap | (uintptr_t)bucket) % 16 == 0)
+        hipLaunchKernelGGL(delta_apply_f32x4, dim3(elementwise_blocks(n / 4)), dim3(256), 0, s, (float4 *)state, (float4 *)snap, (const float4 *)bucket, (float)scale, n / 4);
+    else hipLaunchKernelGGL(delta_apply_kernel<float>, dim3(elementwise_blocks(n)), dim3(256), 0, s, (float *)state, (float *)snap, (const float *)bucket, (float)scale, n);
+    return hipGetLastError();
+}
 
 hipError_t launch_convert(const void *src, int src_f64, void *dst, int dst_f64, int64_t n, hipStream_t s) {
     if (n <= 0) return hipSuccess;

@@ -118,6 +118,10 @@ int eval_blocks(int64_t n);
 template <typename T>
 hipError_t launch_eval(const EvalArgs<T> &a, int64_t n, hipStream_t s);
 
+// multi-GPU exchange passes (element type per f64): bucket = state - snap ; state = snap = snap + scale * bucket
+hipError_t launch_delta_pack(const void *state, const void *snap, void *bucket, int64_t n, bool f64, hipStream_t s);
+hipError_t launch_delta_apply(void *state, void *snap, const void *bucket, double scale, int64_t n, bool f64, hipStream_t s);
+
 // dtype conversion for cmi_set_state / cmi_get_state staging
 hipError_t launch_convert(const void *src, int src_f64, void *dst, int dst_f64, int64_t n, hipStream_t s);
 

@@ -5,8 +5,8 @@ naturally BY USER: P[u], userBias[u], ucBias[u,*] are then touched by exactly on
 item-side containers (Q, itemBias, icBias) are replicated.  One epoch =
 
     every rank:  local SGD epoch over its own tuples (order-exact level schedule, cmi_train_epoch_async)
-    exchange:    delta_r = itemside_r - itemside_at_epoch_start ;  all-reduce(sum) ;
-                 itemside = itemside_at_epoch_start + sum_r delta_r          (one flat bucket, RCCL over xGMI)
+    exchange:    delta_r = itemside_r - itemside_at_epoch_start ;  reduce-scatter + all-gather (sum) of one flat bucket ;
+                 itemside = itemside_at_epoch_start + (sum_r delta_r) / W    (RCCL over xGMI; "mean" merge, see ShardedEpochRunner)
     loss:        all-reduce(sum) of the per-rank epoch losses (feeds the host's bold-driver / isConverged)
 
 With world_size == 1 this is exactly the single-GPU path.  With more ranks it is NOT the reference's
@@ -40,93 +40,148 @@ class _DevArray:
 
 
 class GpuEngine:
-    """Engine over one capi.Instance: the item-side containers are aliased as torch tensors in place."""
+    """Engine over one capi.Instance.  The exchange runs entirely on the instance's HIP stream: two hand-written elementwise
+    kernels (cmi_exchange_pack / cmi_exchange_apply) around the collective, which torch issues with that stream as its current
+    stream (torch.cuda.ExternalStream) -- local epoch -> pack -> reduce-scatter + all-gather -> apply -> loss all-reduce are
+    ordered on the device, and the host synchronises once per epoch, when it reads the loss it needs for isConverged()."""
 
-    def __init__(self, inst, device_index):
+    def __init__(self, inst, device_index, world=1):
         import torch
         self.inst = inst
         self.torch = torch
         self.device = torch.device("cuda", device_index)
-        self.item = {}
-        for name in ITEM_SIDE[inst.model]:
-            ptr, cnt, dt = inst.state_device_ptr(name)
-            self.item[name] = torch.as_tensor(_DevArray(ptr, cnt, dt), device=self.device)
-        # One exchange per epoch: two host synchronisations around it cost nothing next to a 25 ms epoch, so the blocking
-        # form is the default here.  CMI_DIST_STREAM=1 issues the exchange with the instance's HIP stream as torch's current
-        # stream instead (device-side ordering, as the FM runner does for its ~130 exchanges per sweep).
-        import os
-        self.ext = torch.cuda.ExternalStream(inst.stream_ptr(), device=self.device) if os.environ.get("CMI_DIST_STREAM") else None
+        ptr, cnt, dt = inst.exchange_setup(pad_to=max(1, world))   # also snapshots the item-side state
+        self.bucket = torch.as_tensor(_DevArray(ptr, cnt, dt), device=self.device)
+        self.loss = torch.as_tensor(_DevArray(inst.loss_device_ptr(), 1, np.float64), device=self.device)
+        self.ext = torch.cuda.ExternalStream(inst.stream_ptr(), device=self.device)
 
-    def epoch_local(self, lr):
+    def start_epoch(self, lr):
         self.inst.train_epoch_async(lr)
-        loss = self.inst.last_loss()          # synchronises the instance stream
-        return loss
 
-    def item_state(self):
-        return self.item
+    def local_loss(self):
+        return self.inst.last_loss()          # synchronises the instance stream
 
-    def before_exchange(self):
-        if self.ext is None:
-            self.inst.synchronize()               # kernels of the epoch are done before torch touches the state
+    def exchange_stream(self):
+        return self.torch.cuda.stream(self.ext)
 
-    def after_exchange(self):
-        if self.ext is None:
-            self.torch.cuda.synchronize(self.device)  # exchange finished before the next epoch's kernels start
+    def pack(self):
+        self.inst.exchange_pack()
+        return self.bucket
+
+    def apply(self, scale):
+        self.inst.exchange_apply(scale)
+
+    def loss_tensor(self):
+        return self.loss
+
+    def finish(self):
+        self.inst.synchronize()
+
+
+class TorchEngineMixin:
+    """pack / apply for engines whose item-side state is a dict of torch tensors (the CPU test engines): the same algebra as the
+    HIP kernels, in torch ops."""
+
+    def _setup_exchange(self, world):
+        import torch
+        item = self.item_state()
+        self._names = list(item)
+        total = sum(t.numel() for t in item.values())
+        total = (total + world - 1) // world * world
+        any_t = next(iter(item.values()))
+        self._bucket = torch.zeros(total, dtype=any_t.dtype, device=any_t.device)
+        self._snap = {n: t.clone() for n, t in item.items()}
+        self._loss = torch.zeros(1, dtype=torch.float64, device=any_t.device)
+
+    def start_epoch(self, lr):
+        self._loss[0] = self.epoch_local(lr)
+
+    def local_loss(self):
+        return float(self._loss.item())
 
     def exchange_stream(self):
         import contextlib
-        return self.torch.cuda.stream(self.ext) if self.ext is not None else contextlib.nullcontext()
+        return contextlib.nullcontext()
+
+    def pack(self):
+        import torch
+        off = 0
+        for n in self._names:
+            x = self.item_state()[n].view(-1)
+            torch.sub(x, self._snap[n].view(-1), out=self._bucket[off:off + x.numel()])
+            off += x.numel()
+        return self._bucket
+
+    def apply(self, scale):
+        off = 0
+        for n in self._names:
+            x = self.item_state()[n].view(-1)
+            x.copy_(self._snap[n].view(-1) + scale * self._bucket[off:off + x.numel()])
+            self._snap[n].view(-1).copy_(x)
+            off += x.numel()
+
+    def loss_tensor(self):
+        return self._loss
+
+    def finish(self):
+        pass
+
+
+MERGE_RULES = ("mean", "sum")
 
 
 class ShardedEpochRunner:
-    def __init__(self, engine_or_inst, dist, device_index=None, group=None, always_exchange=False):
+    """One global epoch = every rank's local order-exact epoch over its users' ratings, then
+        item_side = start + scale * sum_r (item_side_r - start),   scale = 1/W ("mean", default) or 1 ("sum").
+    Which rule: tests/exp_merge_rule.py (table in DESIGN.md section 7) -- with W stale local passes the SUM of the moves
+    overshoots as soon as a rank's pass moves an item row a good part of the way to its optimum (the bench's weak-scaling shape:
+    500 ratings per item per rank at lr 0.02), the loss starts to oscillate and the bold driver collapses the rate; the MEAN never
+    increased the loss in any configuration tried and stays closest to the sequential (W = 1) result for W >= 4."""
+
+    def __init__(self, engine_or_inst, dist, device_index=None, group=None, always_exchange=False, merge="mean"):
         import torch
+        if merge not in MERGE_RULES:
+            raise ValueError("merge must be one of %s" % (MERGE_RULES,))
         self.torch = torch
         self.dist = dist
         self.group = group
+        self.merge = merge
+        self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
         if isinstance(engine_or_inst, capi.Instance):
             if device_index is None:
                 device_index = torch.cuda.current_device()
-            engine_or_inst = GpuEngine(engine_or_inst, device_index)
+            engine_or_inst = GpuEngine(engine_or_inst, device_index, self.world)
         self.engine = engine_or_inst
-        item = self.engine.item_state()
-        self.names = list(item)
-        total = sum(t.numel() for t in item.values())
-        any_t = next(iter(item.values()))
-        self.bucket = torch.empty(total, dtype=any_t.dtype, device=any_t.device)
-        self.start = {n: t.clone() for n, t in item.items()}   # item-side state at epoch start
-        self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+        if hasattr(self.engine, "_setup_exchange"):
+            self.engine._setup_exchange(self.world)
         self.always_exchange = always_exchange and dist is not None and dist.is_initialized()
+        import os
+        backend = dist.get_backend(group) if dist is not None and dist.is_initialized() else ""
+        # reduce-scatter + all-gather of the bucket (each rank's slice of a 1 GB Q goes straight to its owner and back: 2 x S/W per
+        # link pair on the fully connected xGMI mesh) where the backend has them (RCCL); gloo (CPU tests) only has all-reduce
+        # (in-place forms: this rank's slice of the bucket is both the reduce-scatter output and the all-gather input)
+        self.rs_ag = backend == "nccl" and (self.world > 1 or self.always_exchange) and not os.environ.get("CMI_DIST_ALLREDUCE")
 
     def epoch(self, lr):
         """One global epoch; returns the global loss (sum over ranks)."""
-        torch, dist = self.torch, self.dist
-        loss = self.engine.epoch_local(lr)
+        dist, eng = self.dist, self.engine
+        eng.start_epoch(lr)
         if self.world == 1 and not self.always_exchange:
-            return loss
-        if hasattr(self.engine, "before_exchange"):
-            self.engine.before_exchange()
-        import contextlib
-        ctx = self.engine.exchange_stream() if hasattr(self.engine, "exchange_stream") else contextlib.nullcontext()
-        with ctx:
-            item = self.engine.item_state()
-            off = 0
-            for n in self.names:
-                x = item[n].view(-1)
-                torch.sub(x, self.start[n].view(-1), out=self.bucket[off:off + x.numel()])
-                off += x.numel()
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
-            off = 0
-            for n in self.names:
-                x = item[n].view(-1)
-                torch.add(self.start[n].view(-1), self.bucket[off:off + x.numel()], out=x)
-                self.start[n].view(-1).copy_(x)
-                off += x.numel()
-            lt = torch.tensor([loss], dtype=torch.float64, device=self.bucket.device)
+            return eng.local_loss()
+        scale = 1.0 / self.world if self.merge == "mean" else 1.0
+        with eng.exchange_stream():
+            bucket = eng.pack()
+            if self.rs_ag:
+                shard = bucket.view(self.world, -1)[dist.get_rank(self.group)]
+                dist.reduce_scatter_tensor(shard, bucket, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_gather_into_tensor(bucket, shard, group=self.group)
+            else:
+                dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            eng.apply(scale)
+            lt = eng.loss_tensor()
             dist.all_reduce(lt, op=dist.ReduceOp.SUM, group=self.group)
-            total = float(lt.item())    # read back on the same stream the all-reduce was ordered on
-        if hasattr(self.engine, "after_exchange"):
-            self.engine.after_exchange()
+            total = float(lt.item())    # read back on the stream the collectives were ordered on: the one host sync of the epoch
+        eng.finish()
         return total
 
 

@@ -95,6 +95,10 @@ typedef struct cmi_instance *cmi_handle;
 /* library / device probes (no reference counterpart) */
 int cmi_abi_version(void);
 int cmi_device_count(void); /* 0 when no HIP device is visible; never fails */
+/* measurement: what this GPU sustains right now, GB/s (read + write bytes) over a scratch buffer of `bytes` (>= 1 MiB; use >= 2 GiB
+ * to be past the 256 MB Infinity Cache): out[0] = streaming float4 copy, out[1] = random 512-byte-row read-modify-write (the SGD
+ * kernels' row traffic pattern).  bench.py reports both beside the spec peak. */
+int cmi_measure_hbm(int device, int64_t bytes, double out[2]);
 
 /* new Recommender(trainMatrix, testMatrix, fold) + initModel() container allocation
  * (Recommender.java:180-275, IterativeRecommender.java:232-247, CAMF_CI.java:51-63 ...).
@@ -137,6 +141,23 @@ int cmi_train_epoch(cmi_handle h, double lrate, double *loss_out);
  * NaN/Inf loss -> CMI_E_NUMERIC (the reference calls System.exit(-1)). */
 int cmi_train(cmi_handle h, int num_iters, double init_lrate, double max_lrate, int bold_driver, double decay,
               int early_stop, double *losses, double *lrates, int *iters_run, double *final_lrate);
+
+/* saveModel() / loadModel() (IterativeRecommender.java:249-292), as ONE documented, versioned, checksummed file holding every
+ * container of the model (the reference serialises P, Q, userBias, itemBias with Java object streams and forgets condBias /
+ * ucBias / icBias), the hyper-parameters of cmi_set_hparams, and the resume state of the epoch loop (the learning rate the next
+ * epoch would use, the last epoch's loss, epochs done): training N epochs, saving, loading into a fresh handle and training M more
+ * equals training N + M epochs.  Layout: carskit_amd/csrc/model_io.cpp.  cmi_load_model checks that the file matches the handle
+ * (model, k, sizes) and its checksum before it changes anything; lrate / last_loss / epochs_done may be NULL.  Host I/O only (the
+ * state moves through cmi_get_state / cmi_set_state).  NOT the reference's Java serialization format (no JVM to verify one). */
+int cmi_save_model(cmi_handle h, const char *path, double lrate, double last_loss, int epochs_done);
+int cmi_load_model(cmi_handle h, const char *path, double *lrate, double *last_loss, int *epochs_done);
+
+/* cmi_train continued: epochs first_iter .. first_iter + num_iters - 1 of the same loop, prev_loss = the loss of epoch
+ * first_iter - 1 (what isConverged()/updateLRate() compare with).  cmi_train == cmi_train_from(first_iter = 1, prev_loss = 0).
+ * With cmi_save_model / cmi_load_model: N epochs, save, load, cmi_train_from(N + 1, ...) equals N + M epochs in one go. */
+int cmi_train_from(cmi_handle h, int first_iter, double prev_loss, int num_iters, double init_lrate, double max_lrate,
+                   int bold_driver, double decay, int early_stop, double *losses, double *lrates, int *iters_run,
+                   double *final_lrate);
 
 /* predict(u, j, c, bound) for n tuples (Recommender.java:306-317 + the model's predict());
  * bound != 0 clamps to [lo, hi].  ctx may be NULL for BiasedMF. */
@@ -210,6 +231,20 @@ int cmi_java_int_hashset_order(int64_t n, const int32_t *values, int32_t *out, i
 int cmi_state_device_ptr(cmi_handle h, int which, void **ptr, int64_t *count, int *dtype);
 /* the HIP stream (hipStream_t) all of this handle's work is enqueued on */
 int cmi_stream(cmi_handle h, void **stream);
+/* Epoch-boundary exchange of the REPLICATED item-side containers when ratings are sharded by user over several GPUs
+ * (carskit_amd/dist.py; the reference loop is sequential, CAMF_CI.java:79-123, so this has no counterpart there).  One flat
+ * device buffer, the "bucket" (element type = state dtype), holds container after container (Q, then itemBias / icBias as the
+ * model owns them; every segment padded to 4 elements, the total to a multiple of pad_to so that it splits evenly over the
+ * ranks of a reduce-scatter) this rank's movement of the item-side state since the last snapshot:
+ *   cmi_exchange_setup  allocates bucket + snapshot, snapshot = current state; returns the bucket's device address / length
+ *   cmi_exchange_pack   bucket = state - snapshot                       -> the host sums the bucket over ranks (RCCL)
+ *   cmi_exchange_apply  state = snapshot + scale * bucket; snapshot = state        (scale = 1/W: mean of the ranks' moves)
+ * All enqueued on cmi_stream().  CAMF_C (shared condBias, serial-only) is not sharded: CMI_E_UNSUPPORTED. */
+int cmi_exchange_setup(cmi_handle h, int64_t pad_to, void **bucket, int64_t *count);
+int cmi_exchange_pack(cmi_handle h);
+int cmi_exchange_apply(cmi_handle h, double scale);
+/* device address of the double the most recent epoch's loss is left in (so the host can sum it over ranks on the device) */
+int cmi_loss_device_ptr(cmi_handle h, void **ptr);
 int cmi_synchronize(cmi_handle h);
 /* enqueue one epoch without reading the loss back (pair with cmi_synchronize / cmi_last_loss) */
 int cmi_train_epoch_async(cmi_handle h, double lrate);

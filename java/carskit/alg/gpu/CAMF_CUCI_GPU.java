@@ -1,26 +1,26 @@
-// CAMF_CI_GPU.java -- drop-in for carskit.alg.cars.adaptation.dependent.dev.CAMF_CI: identical constructor, initModel() and predict()
+// CAMF_CUCI_GPU.java -- drop-in for carskit.alg.cars.adaptation.dependent.dev.CAMF_CUCI: identical constructor, initModel() and predict()
 // (inherited); buildModel() runs on the GPU through GpuSupport.buildModel, evalRatings() reads the device model while training
 // is in progress (so `--early-stop MAE|RMSE` sees the live model, IterativeRecommender.java:156-161).  Registered in the reference's
-// factory switch next to "camf_ci" (src/carskit/main/CARSKit.java:702) as "camf_ci_gpu".
+// factory switch next to "camf_cuci" (src/carskit/main/CARSKit.java:706) as "camf_cuci_gpu".
 // Source only (no JDK in this image): NOT compiled or run here; tests/test_java_binding_text.py checks the NativeMF calls as text.
 package carskit.alg.gpu;
 
-import carskit.alg.cars.adaptation.dependent.dev.CAMF_CI;
+import carskit.alg.cars.adaptation.dependent.dev.CAMF_CUCI;
 import carskit.data.structure.SparseMatrix;
 import java.util.List;
 import java.util.Map;
 
-public class CAMF_CI_GPU extends CAMF_CI implements GpuHost {
+public class CAMF_CUCI_GPU extends CAMF_CUCI implements GpuHost {
     private long gpuHandle = 0L;
 
-    public CAMF_CI_GPU(SparseMatrix trainMatrix, SparseMatrix testMatrix, int fold) {
+    public CAMF_CUCI_GPU(SparseMatrix trainMatrix, SparseMatrix testMatrix, int fold) {
         super(trainMatrix, testMatrix, fold);
-        this.algoName = "CAMF_CI_GPU";
+        this.algoName = "CAMF_CUCI_GPU";
     }
 
     @Override
     protected void buildModel() throws Exception {
-        GpuSupport.buildModel(this);   // replaces CAMF_CI.java:79-123
+        GpuSupport.buildModel(this);   // replaces CAMF_CUCI.java:83-126
     }
 
     @Override
@@ -30,7 +30,7 @@ public class CAMF_CI_GPU extends CAMF_CI implements GpuHost {
     }
 
     // ---- GpuHost: the protected members of the reference classes GpuSupport needs ----
-    public int modelId() { return NativeMF.CAMF_CI; }
+    public int modelId() { return NativeMF.CAMF_CUCI; }
     public int createFlags() { return 0; }
     public int factors() { return numFactors; }
     public int users() { return numUsers; }
@@ -56,13 +56,13 @@ public class CAMF_CI_GPU extends CAMF_CI implements GpuHost {
     public void copyIn(long h) {
         NativeMF.setMatrix(h, NativeMF.P, Rows.of(P));
         NativeMF.setMatrix(h, NativeMF.Q, Rows.of(Q));
-        NativeMF.setVector(h, NativeMF.USER_BIAS, userBias.getData());
-        NativeMF.setMatrix(h, NativeMF.IC_BIAS, Rows.of(icBias));
+        NativeMF.setMatrix(h, NativeMF.UC_BIAS, Rows.ofTable(ucBias, numUsers, numConditions));
+        NativeMF.setMatrix(h, NativeMF.IC_BIAS, Rows.ofTable(icBias, numItems, numConditions));
     }
     public void copyOut(long h) {
         NativeMF.getMatrix(h, NativeMF.P, Rows.of(P));
         NativeMF.getMatrix(h, NativeMF.Q, Rows.of(Q));
-        NativeMF.getVector(h, NativeMF.USER_BIAS, userBias.getData());
-        NativeMF.getMatrix(h, NativeMF.IC_BIAS, Rows.of(icBias));
+        Rows.intoTable(ucBias, Rows.fetch(h, NativeMF.UC_BIAS, numUsers, numConditions));
+        Rows.intoTable(icBias, Rows.fetch(h, NativeMF.IC_BIAS, numItems, numConditions));
     }
 }

@@ -1,26 +1,26 @@
-// CAMF_CI_GPU.java -- drop-in for carskit.alg.cars.adaptation.dependent.dev.CAMF_CI: identical constructor, initModel() and predict()
+// CAMF_C_GPU.java -- drop-in for carskit.alg.cars.adaptation.dependent.dev.CAMF_C: identical constructor, initModel() and predict()
 // (inherited); buildModel() runs on the GPU through GpuSupport.buildModel, evalRatings() reads the device model while training
 // is in progress (so `--early-stop MAE|RMSE` sees the live model, IterativeRecommender.java:156-161).  Registered in the reference's
-// factory switch next to "camf_ci" (src/carskit/main/CARSKit.java:702) as "camf_ci_gpu".
+// factory switch next to "camf_c" (src/carskit/main/CARSKit.java:700) as "camf_c_gpu".
 // Source only (no JDK in this image): NOT compiled or run here; tests/test_java_binding_text.py checks the NativeMF calls as text.
 package carskit.alg.gpu;
 
-import carskit.alg.cars.adaptation.dependent.dev.CAMF_CI;
+import carskit.alg.cars.adaptation.dependent.dev.CAMF_C;
 import carskit.data.structure.SparseMatrix;
 import java.util.List;
 import java.util.Map;
 
-public class CAMF_CI_GPU extends CAMF_CI implements GpuHost {
+public class CAMF_C_GPU extends CAMF_C implements GpuHost {
     private long gpuHandle = 0L;
 
-    public CAMF_CI_GPU(SparseMatrix trainMatrix, SparseMatrix testMatrix, int fold) {
+    public CAMF_C_GPU(SparseMatrix trainMatrix, SparseMatrix testMatrix, int fold) {
         super(trainMatrix, testMatrix, fold);
-        this.algoName = "CAMF_CI_GPU";
+        this.algoName = "CAMF_C_GPU";
     }
 
     @Override
     protected void buildModel() throws Exception {
-        GpuSupport.buildModel(this);   // replaces CAMF_CI.java:79-123
+        GpuSupport.buildModel(this);   // replaces CAMF_C.java:79-130
     }
 
     @Override
@@ -30,8 +30,8 @@ public class CAMF_CI_GPU extends CAMF_CI implements GpuHost {
     }
 
     // ---- GpuHost: the protected members of the reference classes GpuSupport needs ----
-    public int modelId() { return NativeMF.CAMF_CI; }
-    public int createFlags() { return 0; }
+    public int modelId() { return NativeMF.CAMF_C; }
+    public int createFlags() { return NativeMF.FLAG_SCHED_SERIAL; }
     public int factors() { return numFactors; }
     public int users() { return numUsers; }
     public int items() { return numItems; }
@@ -57,12 +57,14 @@ public class CAMF_CI_GPU extends CAMF_CI implements GpuHost {
         NativeMF.setMatrix(h, NativeMF.P, Rows.of(P));
         NativeMF.setMatrix(h, NativeMF.Q, Rows.of(Q));
         NativeMF.setVector(h, NativeMF.USER_BIAS, userBias.getData());
-        NativeMF.setMatrix(h, NativeMF.IC_BIAS, Rows.of(icBias));
+        NativeMF.setVector(h, NativeMF.ITEM_BIAS, itemBias.getData());
+        NativeMF.setVector(h, NativeMF.COND_BIAS, condBias.getData());
     }
     public void copyOut(long h) {
         NativeMF.getMatrix(h, NativeMF.P, Rows.of(P));
         NativeMF.getMatrix(h, NativeMF.Q, Rows.of(Q));
         NativeMF.getVector(h, NativeMF.USER_BIAS, userBias.getData());
-        NativeMF.getMatrix(h, NativeMF.IC_BIAS, Rows.of(icBias));
+        NativeMF.getVector(h, NativeMF.ITEM_BIAS, itemBias.getData());
+        NativeMF.getVector(h, NativeMF.COND_BIAS, condBias.getData());
     }
 }

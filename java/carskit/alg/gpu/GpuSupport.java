@@ -1,0 +1,125 @@
+// GpuSupport.java -- the part of buildModel()/evalRatings() every *_GPU recommender shares.  Only marshalling and the
+// reference's own control flow (the epoch loop with isConverged()); all arithmetic is behind NativeMF.
+// Source only: NOT compiled or run here (no JDK in the build image).
+package carskit.alg.gpu;
+
+import carskit.data.processor.DataDAO;
+import carskit.data.structure.SparseMatrix;
+import carskit.generic.Recommender;
+import carskit.generic.Recommender.Measure;
+import java.util.ArrayList;
+import java.util.HashMap;
+import java.util.List;
+import java.util.Map;
+
+final class GpuSupport {
+    private GpuSupport() {}
+
+    /** fold -> GPU round robin (the reference runs one thread per fold, CARSKit.java:395-412); -Dcarskit.gpus=N */
+    static int deviceFor(int fold) {
+        return Math.max(0, fold - 1) % Math.max(1, Integer.getInteger("carskit.gpus", 1));
+    }
+
+    /** {uiUser, uiItem}: DataDAO.getUserIdFromUI / getItemIdFromUI (DataDAO.java:1038-1046) for every pair id */
+    static int[][] pairMaps(DataDAO dao, int numPairs) {
+        int[] uiUser = new int[numPairs], uiItem = new int[numPairs];
+        for (int ui = 0; ui < numPairs; ui++) {
+            uiUser[ui] = dao.getUserIdFromUI(ui);
+            uiItem[ui] = dao.getItemIdFromUI(ui);
+        }
+        return new int[][] {uiUser, uiItem};
+    }
+
+    /** {ctxPtr, ctxConds}: getConditions(ctx) for every context id, flattened once (ContextRecommender.java:53-61) */
+    static int[][] contextTable(GpuHost r, int numCtx) {
+        int[] ctxPtr = new int[numCtx + 1];
+        ArrayList<Integer> conds = new ArrayList<Integer>();
+        for (int c = 0; c < numCtx; c++) {
+            conds.addAll(r.conditionsOf(c));
+            ctxPtr[c + 1] = conds.size();
+        }
+        int[] ctxConds = new int[conds.size()];
+        for (int i = 0; i < ctxConds.length; i++) ctxConds[i] = conds.get(i);
+        return new int[][] {ctxPtr, ctxConds};
+    }
+
+    /** the tuples `for (MatrixEntry me : m)` yields, as {u, j, ctx} + rates (test side: setEvalRatings / evalRankings) */
+    static Object[] tuples(SparseMatrix m, DataDAO dao) {
+        int[] rowPtr = m.getRowPointers(), colInd = m.getColumnIndices();
+        double[] data = m.getData();
+        int n = colInd.length;
+        int[] u = new int[n], j = new int[n], ctx = new int[n];
+        double[] r = new double[n];
+        for (int row = 0; row + 1 < rowPtr.length; row++)
+            for (int q = rowPtr[row]; q < rowPtr[row + 1]; q++) {
+                u[q] = dao.getUserIdFromUI(row);
+                j[q] = dao.getItemIdFromUI(row);
+                ctx[q] = colInd[q];
+                r[q] = data[q];
+            }
+        return new Object[] {u, j, ctx, r};
+    }
+
+    /** The replacement of the reference's buildModel(): upload once, run the epoch loop with the UNCHANGED Java isConverged()
+     *  (bold driver, decay, early stop, NaN exit: IterativeRecommender.java:145-229), copy the model back. */
+    static void buildModel(GpuHost r) throws Exception {
+        boolean twoD = r.modelId() == NativeMF.BIASEDMF || r.modelId() == NativeMF.PMF;
+        long h = NativeMF.create(r.modelId(), r.factors(), r.users(), r.items(), r.conditions(), deviceFor(r.foldId()), r.createFlags());
+        try {
+            DataDAO dao = Recommender.rateDao;
+            SparseMatrix tm = r.contextualTrain();
+            if (twoD) {
+                librec.data.SparseMatrix t2 = r.train2D();
+                NativeMF.setRatings2D(h, t2.getRowPointers(), t2.getColumnIndices(), t2.getData());
+            } else {
+                int[][] ui = pairMaps(dao, tm.numRows());
+                int[][] ct = contextTable(r, tm.numColumns());
+                NativeMF.setRatingsCsr(h, tm.getRowPointers(), tm.getColumnIndices(), tm.getData(), ui[0], ui[1], ct[0], ct[1]);
+            }
+            double[] reg = r.regularizers();
+            NativeMF.setHparams(h, reg[0], reg[1], reg[2], reg[3], r.mean());
+            r.copyIn(h);
+            if (r.evaluatesDuringTraining() && r.contextualTest() != null) {
+                // `--early-stop MAE|RMSE`: isConverged() scores the test set after EVERY epoch; the Java-side containers are
+                // stale until copyOut, so evalRatings() of the drop-in reads the device model instead (evalResident below)
+                Object[] t = tuples(r.contextualTest(), dao);
+                NativeMF.setEvalRatings(h, (int[]) t[0], (int[]) t[1], twoD ? null : (int[]) t[2], (double[]) t[3]);
+            }
+            r.handle(h);
+            for (int iter = 1; iter <= r.iterations(); iter++) {
+                double loss = NativeMF.trainEpoch(h, r.learnRate());   // replaces e.g. CAMF_CI.java:79-123
+                if (r.epochDone(iter, loss)) break;                    // unchanged Java: loss = ...; isConverged(iter)
+            }
+            r.copyOut(h);   // predict() / evalRatings() / evalRankings() / saveModel() keep working unchanged afterwards
+        } finally {
+            r.handle(0L);
+            NativeMF.destroy(h);
+        }
+    }
+
+    /** evalRatings() while the native handle is live: the same measures the reference computes (Recommender.java:504-594),
+     *  from the model on the device. */
+    static Map<Measure, Double> evalResident(long h, double minRate, double maxRate) {
+        double[] m = NativeMF.evalResident(h, minRate, maxRate);
+        Map<Measure, Double> out = new HashMap<Measure, Double>();
+        out.put(Measure.MAE, m[0]);
+        out.put(Measure.RMSE, m[1]);
+        out.put(Measure.NMAE, m[2]);
+        out.put(Measure.rMAE, m[3]);
+        out.put(Measure.rRMSE, m[4]);
+        out.put(Measure.MPE, 0.0);
+        return out;
+    }
+
+    /** cmi_eval_rankings out[21] -> the reference's measure map (Recommender.java:930-960) */
+    static Map<Measure, Double> rankingMeasures(double[] out) {
+        Measure[] order = {Measure.Pre5, Measure.Pre10, Measure.PreN, Measure.Rec5, Measure.Rec10, Measure.RecN, Measure.AUC5,
+                           Measure.AUC10, Measure.AUCN, Measure.MAP5, Measure.MAP10, Measure.MAPN, Measure.NDCG5, Measure.NDCG10,
+                           Measure.NDCGN, Measure.MRR5, Measure.MRR10, Measure.MRRN, Measure.D5, Measure.D10, Measure.DN};
+        Map<Measure, Double> m = new HashMap<Measure, Double>();
+        for (int i = 0; i < order.length; i++) m.put(order[i], out[i]);
+        return m;
+    }
+
+    static List<Integer> none() { return new ArrayList<Integer>(); }
+}

@@ -1,13 +1,39 @@
-// Rows.java -- live row arrays of a librec DenseMatrix (row(i,false) is a shallow view, SURVEY 8b).
-// Source only: NOT compiled or tested here.
+// Rows.java -- live row arrays of a librec DenseMatrix (row(i,false) is a shallow view, SURVEY 8b), and the dense image of the
+// guava Table<Integer,Integer,Double> CAMF_CUCI keeps its context-bias tables in (CAMF_CUCI.java:43-66: every (row, condition)
+// cell is present).  Source only: NOT compiled or run here.
 package carskit.alg.gpu;
 
+import com.google.common.collect.Table;
 import librec.data.DenseMatrix;
 
 final class Rows {
+    private Rows() {}
+
     static double[][] of(DenseMatrix m) {
         double[][] rows = new double[m.numRows()][];
         for (int i = 0; i < rows.length; i++) rows[i] = m.row(i, false).getData();
         return rows;
+    }
+
+    static double[][] ofTable(Table<Integer, Integer, Double> t, int numRows, int numCols) {
+        double[][] rows = new double[numRows][numCols];
+        for (int i = 0; i < numRows; i++)
+            for (int c = 0; c < numCols; c++) {
+                Double v = t.get(i, c);
+                rows[i][c] = v == null ? 0.0 : v;
+            }
+        return rows;
+    }
+
+    /** cmi_get_state into a fresh dense image (for containers that are not double[][] on the Java side) */
+    static double[][] fetch(long h, int which, int numRows, int numCols) {
+        double[][] rows = new double[numRows][numCols];
+        NativeMF.getMatrix(h, which, rows);
+        return rows;
+    }
+
+    static void intoTable(Table<Integer, Integer, Double> t, double[][] rows) {
+        for (int i = 0; i < rows.length; i++)
+            for (int c = 0; c < rows[i].length; c++) t.put(i, c, rows[i][c]);
     }
 }

@@ -1,126 +1,346 @@
-// carskit_jni.cpp -- JNI shim: carskit.alg.gpu.NativeMF -> include/carskit_mi355x.h.  No logic lives here.
-// Build (only where a JDK exists; NOT built or tested in this image, which has no jni.h):
-//   g++ -O2 -fPIC -shared -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude jni/carskit_jni.cpp \
-//       -Lcarskit_amd/lib -lcarskit_mi355x -o libcarskit_mi355x_jni.so
+// carskit_jni.cpp -- JNI shim: carskit.alg.gpu.NativeMF -> include/carskit_mi355x.h.  No logic lives here: every function
+// copies its Java arrays into native buffers, makes ONE C-ABI call (or the get/set pair of one container) and turns a non-zero
+// status into a RuntimeException carrying cmi_last_error().
+// Build (only where a JDK exists; NOT built or run in this image, which has no jni.h):
+//   g++ -O2 -fPIC -shared -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude jni/carskit_jni.cpp
+//       -Lcarskit_amd/lib -lcarskit_mi355x -o libcarskit_mi355x_jni.so          (one command line)
+// tests/test_java_binding_text.py keeps this file and java/carskit/alg/gpu/NativeMF.java in step (names and JNI signatures).
+//
+// Arrays are COPIED out with Get<Type>ArrayRegion before any library call: cmi_set_ratings builds its schedule for seconds and
+// blocks on HIP, which must not happen inside a Get/ReleasePrimitiveArrayCritical region (the JVM may stall every other thread's
+// GC for that long, and no other JNI call is legal inside one).
 #include <jni.h>
 
+#include <cstddef>
+#include <cstdint>
 #include <vector>
 
 #include "carskit_mi355x.h"
 
-static void throw_cmi(JNIEnv *env, cmi_handle h, int rc) {
-    if (rc == CMI_OK) return;
-    env->ThrowNew(env->FindClass("java/lang/RuntimeException"), cmi_last_error(h));
+namespace {
+
+void throw_msg(JNIEnv *env, const char *msg) { env->ThrowNew(env->FindClass("java/lang/RuntimeException"), msg); }
+void throw_cmi(JNIEnv *env, cmi_handle h, int rc) {
+    if (rc != CMI_OK) throw_msg(env, cmi_last_error(h));
 }
+void throw_fm(JNIEnv *env, cmi_fm_handle h, int rc) {
+    if (rc != CMI_OK) throw_msg(env, cmi_fm_last_error(h));
+}
+
+std::vector<int32_t> ints(JNIEnv *env, jintArray a) {
+    std::vector<int32_t> v;
+    if (!a) return v;
+    v.resize((std::size_t)env->GetArrayLength(a));
+    if (!v.empty()) env->GetIntArrayRegion(a, 0, (jsize)v.size(), reinterpret_cast<jint *>(v.data()));
+    return v;
+}
+std::vector<double> doubles(JNIEnv *env, jdoubleArray a) {
+    std::vector<double> v;
+    if (!a) return v;
+    v.resize((std::size_t)env->GetArrayLength(a));
+    if (!v.empty()) env->GetDoubleArrayRegion(a, 0, (jsize)v.size(), v.data());
+    return v;
+}
+jdoubleArray to_java(JNIEnv *env, const double *p, std::size_t n) {
+    jdoubleArray res = env->NewDoubleArray((jsize)n);
+    if (res && n) env->SetDoubleArrayRegion(res, 0, (jsize)n, p);
+    return res;
+}
+// rows of a double[][] <-> one row-major buffer
+std::vector<double> flatten(JNIEnv *env, jobjectArray rows, jsize *nr_out, jsize *nc_out) {
+    const jsize nr = rows ? env->GetArrayLength(rows) : 0;
+    jsize nc = 0;
+    if (nr > 0) {
+        jdoubleArray r0 = (jdoubleArray)env->GetObjectArrayElement(rows, 0);
+        nc = env->GetArrayLength(r0);
+        env->DeleteLocalRef(r0);
+    }
+    std::vector<double> flat((std::size_t)nr * (std::size_t)nc);
+    for (jsize i = 0; i < nr; ++i) {
+        jdoubleArray row = (jdoubleArray)env->GetObjectArrayElement(rows, i);
+        env->GetDoubleArrayRegion(row, 0, nc, flat.data() + (std::size_t)i * nc);
+        env->DeleteLocalRef(row);
+    }
+    *nr_out = nr;
+    *nc_out = nc;
+    return flat;
+}
+void scatter(JNIEnv *env, jobjectArray rows, const std::vector<double> &flat, jsize nr, jsize nc) {
+    for (jsize i = 0; i < nr; ++i) {
+        jdoubleArray row = (jdoubleArray)env->GetObjectArrayElement(rows, i);
+        env->SetDoubleArrayRegion(row, 0, nc, flat.data() + (std::size_t)i * nc);
+        env->DeleteLocalRef(row);
+    }
+}
+// CSR rows (user-item pair ids) -> per-tuple (user, item): what `for (MatrixEntry me : trainMatrix)` yields
+void expand_pairs(const std::vector<int32_t> &row_ptr, const std::vector<int32_t> &ui_user, const std::vector<int32_t> &ui_item,
+                  std::size_t n, std::vector<int32_t> &u, std::vector<int32_t> &j) {
+    u.assign(n, 0);
+    j.assign(n, 0);
+    for (std::size_t r = 0; r + 1 < row_ptr.size(); ++r)
+        for (int32_t q = row_ptr[r]; q < row_ptr[r + 1]; ++q) {
+            u[(std::size_t)q] = ui_user[r];
+            j[(std::size_t)q] = ui_item[r];
+        }
+}
+
+} // namespace
 
 extern "C" {
 
-JNIEXPORT jlong JNICALL Java_carskit_alg_gpu_NativeMF_create(JNIEnv *env, jclass, jint model, jint k, jint nu,
-                                                            jint ni, jint nc, jint device, jint flags) {
+JNIEXPORT jlong JNICALL Java_carskit_alg_gpu_NativeMF_create(JNIEnv *env, jclass, jint model, jint k, jint nUsers, jint nItems,
+                                                            jint nConds, jint device, jint flags) {
     cmi_handle h = nullptr;
-    int rc = cmi_create(model, k, nu, ni, nc, device, (unsigned)flags, &h);
+    const int rc = cmi_create(model, k, nUsers, nItems, nConds, device, (unsigned)flags, &h);
     if (rc != CMI_OK) throw_cmi(env, nullptr, rc);
     return (jlong)h;
 }
 
 JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_destroy(JNIEnv *, jclass, jlong h) { cmi_destroy((cmi_handle)h); }
 
-JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setRatingsCsr(JNIEnv *env, jclass, jlong h, jintArray rowPtr,
-                                                                   jintArray colInd, jdoubleArray data,
-                                                                   jintArray uiUser, jintArray uiItem,
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setRatingsCsr(JNIEnv *env, jclass, jlong h, jintArray rowPtr, jintArray colInd,
+                                                                   jdoubleArray data, jintArray uiUser, jintArray uiItem,
                                                                    jintArray ctxPtr, jintArray ctxConds) {
-    const jsize nRows = env->GetArrayLength(rowPtr) - 1, n = env->GetArrayLength(colInd);
-    jint *rp = (jint *)env->GetPrimitiveArrayCritical(rowPtr, nullptr);
-    jint *uu = (jint *)env->GetPrimitiveArrayCritical(uiUser, nullptr);
-    jint *ui = (jint *)env->GetPrimitiveArrayCritical(uiItem, nullptr);
-    std::vector<int32_t> u((size_t)n), j((size_t)n); // expand CSR rows to per-tuple (user, item)
-    for (jsize r = 0; r < nRows; ++r)
-        for (jint q = rp[r]; q < rp[r + 1]; ++q) {
-            u[(size_t)q] = uu[r];
-            j[(size_t)q] = ui[r];
-        }
-    env->ReleasePrimitiveArrayCritical(uiItem, ui, JNI_ABORT);
-    env->ReleasePrimitiveArrayCritical(uiUser, uu, JNI_ABORT);
-    env->ReleasePrimitiveArrayCritical(rowPtr, rp, JNI_ABORT);
-    jint *ci = (jint *)env->GetPrimitiveArrayCritical(colInd, nullptr);
-    jdouble *d = (jdouble *)env->GetPrimitiveArrayCritical(data, nullptr);
-    jint *cp = (jint *)env->GetPrimitiveArrayCritical(ctxPtr, nullptr);
-    jint *cc = (jint *)env->GetPrimitiveArrayCritical(ctxConds, nullptr);
-    int rc = cmi_set_ratings((cmi_handle)h, n, u.data(), j.data(), (const int32_t *)ci, d,
-                             env->GetArrayLength(ctxPtr) - 1, (const int32_t *)cp, (const int32_t *)cc);
-    env->ReleasePrimitiveArrayCritical(ctxConds, cc, JNI_ABORT);
-    env->ReleasePrimitiveArrayCritical(ctxPtr, cp, JNI_ABORT);
-    env->ReleasePrimitiveArrayCritical(data, d, JNI_ABORT);
-    env->ReleasePrimitiveArrayCritical(colInd, ci, JNI_ABORT);
-    throw_cmi(env, (cmi_handle)h, rc);
+    const std::vector<int32_t> rp = ints(env, rowPtr), ci = ints(env, colInd), uu = ints(env, uiUser), ui = ints(env, uiItem),
+                               cp = ints(env, ctxPtr), cc = ints(env, ctxConds);
+    const std::vector<double> d = doubles(env, data);
+    std::vector<int32_t> u, j;
+    expand_pairs(rp, uu, ui, ci.size(), u, j);
+    throw_cmi(env, (cmi_handle)h,
+              cmi_set_ratings((cmi_handle)h, (int64_t)ci.size(), u.data(), j.data(), ci.data(), d.data(), (int32_t)cp.size() - 1, cp.data(),
+                              cc.data()));
 }
 
-static void matrix_io(JNIEnv *env, jlong h, jint which, jobjectArray rows, bool set) {
-    const jsize nr = env->GetArrayLength(rows);
-    if (nr == 0) return;
-    jdoubleArray r0 = (jdoubleArray)env->GetObjectArrayElement(rows, 0);
-    const jsize nc = env->GetArrayLength(r0);
-    std::vector<double> flat((size_t)nr * nc);
-    if (!set) {
-        int rc = cmi_get_state((cmi_handle)h, which, flat.data(), (int64_t)flat.size(), CMI_DTYPE_F64);
-        if (rc != CMI_OK) return throw_cmi(env, (cmi_handle)h, rc);
-    }
-    for (jsize i = 0; i < nr; ++i) {
-        jdoubleArray row = (jdoubleArray)env->GetObjectArrayElement(rows, i);
-        if (set) env->GetDoubleArrayRegion(row, 0, nc, flat.data() + (size_t)i * nc);
-        else env->SetDoubleArrayRegion(row, 0, nc, flat.data() + (size_t)i * nc);
-        env->DeleteLocalRef(row);
-    }
-    if (set) throw_cmi(env, (cmi_handle)h, cmi_set_state((cmi_handle)h, which, flat.data(), (int64_t)flat.size(), CMI_DTYPE_F64));
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setRatings2D(JNIEnv *env, jclass, jlong h, jintArray rowPtr, jintArray colInd,
+                                                                  jdoubleArray data) {
+    const std::vector<int32_t> rp = ints(env, rowPtr), ci = ints(env, colInd);
+    const std::vector<double> d = doubles(env, data);
+    std::vector<int32_t> u(ci.size());
+    for (std::size_t r = 0; r + 1 < rp.size(); ++r)
+        for (int32_t q = rp[r]; q < rp[r + 1]; ++q) u[(std::size_t)q] = (int32_t)r; // the 2-D train matrix: row = user, column = item
+    throw_cmi(env, (cmi_handle)h, cmi_set_ratings((cmi_handle)h, (int64_t)ci.size(), u.data(), ci.data(), nullptr, d.data(), 0, nullptr, nullptr));
 }
 
-JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setMatrix(JNIEnv *env, jclass, jlong h, jint w, jobjectArray rows) { matrix_io(env, h, w, rows, true); }
-JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_getMatrix(JNIEnv *env, jclass, jlong h, jint w, jobjectArray rows) { matrix_io(env, h, w, rows, false); }
-
-JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setVector(JNIEnv *env, jclass, jlong h, jint w, jdoubleArray v) {
-    jdouble *p = env->GetDoubleArrayElements(v, nullptr);
-    int rc = cmi_set_state((cmi_handle)h, w, p, env->GetArrayLength(v), CMI_DTYPE_F64);
-    env->ReleaseDoubleArrayElements(v, p, JNI_ABORT);
-    throw_cmi(env, (cmi_handle)h, rc);
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setMatrix(JNIEnv *env, jclass, jlong h, jint which, jobjectArray rows) {
+    jsize nr = 0, nc = 0;
+    const std::vector<double> flat = flatten(env, rows, &nr, &nc);
+    throw_cmi(env, (cmi_handle)h, cmi_set_state((cmi_handle)h, which, flat.data(), (int64_t)flat.size(), CMI_DTYPE_F64));
 }
 
-JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_getVector(JNIEnv *env, jclass, jlong h, jint w, jdoubleArray v) {
-    jdouble *p = env->GetDoubleArrayElements(v, nullptr);
-    int rc = cmi_get_state((cmi_handle)h, w, p, env->GetArrayLength(v), CMI_DTYPE_F64);
-    env->ReleaseDoubleArrayElements(v, p, 0);
-    throw_cmi(env, (cmi_handle)h, rc);
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_getMatrix(JNIEnv *env, jclass, jlong h, jint which, jobjectArray rows) {
+    jsize nr = 0, nc = 0;
+    std::vector<double> flat = flatten(env, rows, &nr, &nc); // for the shape
+    const int rc = cmi_get_state((cmi_handle)h, which, flat.data(), (int64_t)flat.size(), CMI_DTYPE_F64);
+    if (rc != CMI_OK) return throw_cmi(env, (cmi_handle)h, rc);
+    scatter(env, rows, flat, nr, nc);
 }
 
-JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setHparams(JNIEnv *env, jclass, jlong h, jdouble ru, jdouble ri,
-                                                                jdouble rb, jdouble rc_, jdouble gm) {
-    throw_cmi(env, (cmi_handle)h, cmi_set_hparams((cmi_handle)h, ru, ri, rb, rc_, gm));
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setVector(JNIEnv *env, jclass, jlong h, jint which, jdoubleArray v) {
+    const std::vector<double> p = doubles(env, v);
+    throw_cmi(env, (cmi_handle)h, cmi_set_state((cmi_handle)h, which, p.data(), (int64_t)p.size(), CMI_DTYPE_F64));
 }
 
-JNIEXPORT jdouble JNICALL Java_carskit_alg_gpu_NativeMF_trainEpoch(JNIEnv *env, jclass, jlong h, jdouble lr) {
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_getVector(JNIEnv *env, jclass, jlong h, jint which, jdoubleArray v) {
+    std::vector<double> p((std::size_t)env->GetArrayLength(v));
+    const int rc = cmi_get_state((cmi_handle)h, which, p.data(), (int64_t)p.size(), CMI_DTYPE_F64);
+    if (rc != CMI_OK) return throw_cmi(env, (cmi_handle)h, rc);
+    env->SetDoubleArrayRegion(v, 0, (jsize)p.size(), p.data());
+}
+
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setHparams(JNIEnv *env, jclass, jlong h, jdouble regU, jdouble regI, jdouble regB,
+                                                                jdouble regC, jdouble globalMean) {
+    throw_cmi(env, (cmi_handle)h, cmi_set_hparams((cmi_handle)h, regU, regI, regB, regC, globalMean));
+}
+
+JNIEXPORT jdouble JNICALL Java_carskit_alg_gpu_NativeMF_trainEpoch(JNIEnv *env, jclass, jlong h, jdouble lRate) {
     double loss = 0;
-    throw_cmi(env, (cmi_handle)h, cmi_train_epoch((cmi_handle)h, lr, &loss));
+    throw_cmi(env, (cmi_handle)h, cmi_train_epoch((cmi_handle)h, lRate, &loss));
     return loss;
 }
 
-JNIEXPORT jdoubleArray JNICALL Java_carskit_alg_gpu_NativeMF_evalRatings(JNIEnv *env, jclass, jlong h, jintArray u,
-                                                                         jintArray j, jintArray ctx, jdoubleArray r,
-                                                                         jdouble lo, jdouble hi) {
-    const jsize n = env->GetArrayLength(u);
-    jint *pu = env->GetIntArrayElements(u, nullptr), *pj = env->GetIntArrayElements(j, nullptr);
-    jint *pc = ctx ? env->GetIntArrayElements(ctx, nullptr) : nullptr;
-    jdouble *pr = env->GetDoubleArrayElements(r, nullptr);
-    double out[6];
-    int64_t cnt = 0;
-    int rc = cmi_eval_ratings((cmi_handle)h, n, (const int32_t *)pu, (const int32_t *)pj, (const int32_t *)pc, pr, lo, hi, out, &cnt);
-    out[5] = (double)cnt;
-    env->ReleaseDoubleArrayElements(r, pr, JNI_ABORT);
-    if (pc) env->ReleaseIntArrayElements(ctx, pc, JNI_ABORT);
-    env->ReleaseIntArrayElements(j, pj, JNI_ABORT);
-    env->ReleaseIntArrayElements(u, pu, JNI_ABORT);
+JNIEXPORT jint JNICALL Java_carskit_alg_gpu_NativeMF_train(JNIEnv *env, jclass, jlong h, jint numIters, jdouble initLRate,
+                                                           jdouble maxLRate, jint boldDriver, jdouble decay, jint earlyStop,
+                                                           jdoubleArray losses, jdoubleArray lrates) {
+    std::vector<double> ls((std::size_t)(numIters > 0 ? numIters : 0)), rs(ls.size());
+    int run = 0;
+    const int rc = cmi_train((cmi_handle)h, numIters, initLRate, maxLRate, boldDriver, decay, earlyStop, ls.data(), rs.data(), &run, nullptr);
+    if (losses && run > 0) env->SetDoubleArrayRegion(losses, 0, run, ls.data());
+    if (lrates && run > 0) env->SetDoubleArrayRegion(lrates, 0, run, rs.data());
     throw_cmi(env, (cmi_handle)h, rc);
-    jdoubleArray res = env->NewDoubleArray(6);
-    env->SetDoubleArrayRegion(res, 0, 6, out);
-    return res;
+    return run;
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_carskit_alg_gpu_NativeMF_evalRatings(JNIEnv *env, jclass, jlong h, jintArray u, jintArray j,
+                                                                         jintArray ctx, jdoubleArray r, jdouble minRate,
+                                                                         jdouble maxRate) {
+    const std::vector<int32_t> pu = ints(env, u), pj = ints(env, j), pc = ints(env, ctx);
+    const std::vector<double> pr = doubles(env, r);
+    double out[6] = {0, 0, 0, 0, 0, 0};
+    int64_t cnt = 0;
+    const int rc = cmi_eval_ratings((cmi_handle)h, (int64_t)pu.size(), pu.data(), pj.data(), ctx ? pc.data() : nullptr, pr.data(), minRate,
+                                    maxRate, out, &cnt);
+    out[5] = (double)cnt;
+    if (rc != CMI_OK) {
+        throw_cmi(env, (cmi_handle)h, rc);
+        return nullptr;
+    }
+    return to_java(env, out, 6);
+}
+
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setEvalRatings(JNIEnv *env, jclass, jlong h, jintArray u, jintArray j,
+                                                                    jintArray ctx, jdoubleArray r) {
+    const std::vector<int32_t> pu = ints(env, u), pj = ints(env, j), pc = ints(env, ctx);
+    const std::vector<double> pr = doubles(env, r);
+    throw_cmi(env, (cmi_handle)h,
+              cmi_set_eval_ratings((cmi_handle)h, (int64_t)pu.size(), pu.data(), pj.data(), ctx ? pc.data() : nullptr, pr.data()));
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_carskit_alg_gpu_NativeMF_evalResident(JNIEnv *env, jclass, jlong h, jdouble minRate,
+                                                                          jdouble maxRate) {
+    double out[6] = {0, 0, 0, 0, 0, 0};
+    int64_t cnt = 0;
+    const int rc = cmi_eval_resident((cmi_handle)h, minRate, maxRate, out, &cnt);
+    out[5] = (double)cnt;
+    if (rc != CMI_OK) {
+        throw_cmi(env, (cmi_handle)h, rc);
+        return nullptr;
+    }
+    return to_java(env, out, 6);
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_carskit_alg_gpu_NativeMF_predictBatch(JNIEnv *env, jclass, jlong h, jintArray u, jintArray j,
+                                                                          jintArray ctx, jint bound, jdouble lo, jdouble hi) {
+    const std::vector<int32_t> pu = ints(env, u), pj = ints(env, j), pc = ints(env, ctx);
+    std::vector<double> out(pu.size());
+    const int rc = cmi_predict_batch((cmi_handle)h, (int64_t)pu.size(), pu.data(), pj.data(), ctx ? pc.data() : nullptr, bound, lo, hi, out.data());
+    if (rc != CMI_OK) {
+        throw_cmi(env, (cmi_handle)h, rc);
+        return nullptr;
+    }
+    return to_java(env, out.data(), out.size());
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_carskit_alg_gpu_NativeMF_evalRankings(JNIEnv *env, jclass, jlong h, jintArray tu, jintArray tj,
+                                                                          jintArray tctx, jdoubleArray tr, jintArray su, jintArray sj,
+                                                                          jintArray sctx, jdoubleArray sr, jdouble binThold,
+                                                                          jint numRecs, jint numIgnore, jint strategy) {
+    const std::vector<int32_t> a = ints(env, tu), b = ints(env, tj), c = ints(env, tctx), d = ints(env, su), e = ints(env, sj), f = ints(env, sctx);
+    const std::vector<double> ra = doubles(env, tr), rb = doubles(env, sr);
+    double out[CMI_RANK_MEASURES];
+    int64_t nq = 0;
+    const int rc = cmi_eval_rankings((cmi_handle)h, (int64_t)a.size(), a.data(), b.data(), tctx ? c.data() : nullptr, ra.data(), (int64_t)d.size(),
+                                     d.data(), e.data(), sctx ? f.data() : nullptr, rb.data(), binThold, numRecs, numIgnore, strategy, out, &nq,
+                                     nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc != CMI_OK) {
+        throw_cmi(env, (cmi_handle)h, rc);
+        return nullptr;
+    }
+    return to_java(env, out, CMI_RANK_MEASURES);
+}
+
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_saveModel(JNIEnv *env, jclass, jlong h, jstring path, jdouble lRate, jdouble lastLoss,
+                                                               jint epochsDone) {
+    const char *p = env->GetStringUTFChars(path, nullptr);
+    const int rc = cmi_save_model((cmi_handle)h, p, lRate, lastLoss, epochsDone);
+    env->ReleaseStringUTFChars(path, p);
+    throw_cmi(env, (cmi_handle)h, rc);
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_carskit_alg_gpu_NativeMF_loadModel(JNIEnv *env, jclass, jlong h, jstring path) {
+    const char *p = env->GetStringUTFChars(path, nullptr);
+    double out[3] = {0, 0, 0};
+    int done = 0;
+    const int rc = cmi_load_model((cmi_handle)h, p, &out[0], &out[1], &done);
+    env->ReleaseStringUTFChars(path, p);
+    out[2] = (double)done;
+    if (rc != CMI_OK) {
+        throw_cmi(env, (cmi_handle)h, rc);
+        return nullptr;
+    }
+    return to_java(env, out, 3);
+}
+
+// ---- FM -----------------------------------------------------------------------------------------------------------
+
+JNIEXPORT jlong JNICALL Java_carskit_alg_gpu_NativeMF_fmCreate(JNIEnv *env, jclass, jint k, jint nUsers, jint nItems, jint nConds,
+                                                              jint nCtxDims, jint device, jint flags) {
+    cmi_fm_handle h = nullptr;
+    const int rc = cmi_fm_create(k, nUsers, nItems, nConds, nCtxDims, device, (unsigned)flags, &h);
+    if (rc != CMI_OK) throw_fm(env, nullptr, rc);
+    return (jlong)h;
+}
+
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_fmDestroy(JNIEnv *, jclass, jlong h) { cmi_fm_destroy((cmi_fm_handle)h); }
+
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_fmSetHparams(JNIEnv *env, jclass, jlong h, jdouble regLw, jdouble regLf,
+                                                                  jlong globalSize) {
+    throw_fm(env, (cmi_fm_handle)h, cmi_fm_set_hparams((cmi_fm_handle)h, regLw, regLf, (int64_t)globalSize));
+}
+
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_fmSetRatingsCsr(JNIEnv *env, jclass, jlong h, jintArray rowPtr, jintArray colInd,
+                                                                     jdoubleArray data, jintArray uiUser, jintArray uiItem) {
+    const std::vector<int32_t> rp = ints(env, rowPtr), ci = ints(env, colInd), uu = ints(env, uiUser), ui = ints(env, uiItem);
+    const std::vector<double> d = doubles(env, data);
+    std::vector<int32_t> u, j;
+    expand_pairs(rp, uu, ui, ci.size(), u, j);
+    throw_fm(env, (cmi_fm_handle)h, cmi_fm_set_ratings((cmi_fm_handle)h, (int64_t)ci.size(), u.data(), j.data(), ci.data(), d.data()));
+}
+
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_fmSetModel(JNIEnv *env, jclass, jlong h, jdouble w0, jdoubleArray w,
+                                                                jobjectArray vRows) {
+    const std::vector<double> pw = doubles(env, w);
+    jsize nr = 0, nc = 0;
+    const std::vector<double> flat = flatten(env, vRows, &nr, &nc);
+    throw_fm(env, (cmi_fm_handle)h, cmi_fm_set_model((cmi_fm_handle)h, w0, pw.data(), flat.data()));
+}
+
+JNIEXPORT jdouble JNICALL Java_carskit_alg_gpu_NativeMF_fmGetModel(JNIEnv *env, jclass, jlong h, jdoubleArray w, jobjectArray vRows) {
+    std::vector<double> pw((std::size_t)env->GetArrayLength(w));
+    jsize nr = 0, nc = 0;
+    std::vector<double> flat = flatten(env, vRows, &nr, &nc); // for the shape
+    double w0 = 0;
+    const int rc = cmi_fm_get_model((cmi_fm_handle)h, &w0, pw.data(), flat.data());
+    if (rc != CMI_OK) {
+        throw_fm(env, (cmi_fm_handle)h, rc);
+        return 0;
+    }
+    env->SetDoubleArrayRegion(w, 0, (jsize)pw.size(), pw.data());
+    scatter(env, vRows, flat, nr, nc);
+    return w0;
+}
+
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_fmTrain(JNIEnv *env, jclass, jlong h, jint numIters) {
+    throw_fm(env, (cmi_fm_handle)h, cmi_fm_train((cmi_fm_handle)h, numIters));
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_carskit_alg_gpu_NativeMF_fmPredictBatch(JNIEnv *env, jclass, jlong h, jintArray u, jintArray j,
+                                                                            jintArray ctx, jint bound, jdouble lo, jdouble hi) {
+    const std::vector<int32_t> pu = ints(env, u), pj = ints(env, j), pc = ints(env, ctx);
+    std::vector<double> out(pu.size());
+    const int rc = cmi_fm_predict_batch((cmi_fm_handle)h, (int64_t)pu.size(), pu.data(), pj.data(), pc.data(), bound, lo, hi, out.data());
+    if (rc != CMI_OK) {
+        throw_fm(env, (cmi_fm_handle)h, rc);
+        return nullptr;
+    }
+    return to_java(env, out.data(), out.size());
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_carskit_alg_gpu_NativeMF_fmEvalRankings(JNIEnv *env, jclass, jlong h, jintArray tu, jintArray tj,
+                                                                            jintArray tctx, jdoubleArray tr, jintArray su, jintArray sj,
+                                                                            jintArray sctx, jdoubleArray sr, jdouble binThold,
+                                                                            jint numRecs, jint numIgnore, jint strategy) {
+    const std::vector<int32_t> a = ints(env, tu), b = ints(env, tj), c = ints(env, tctx), d = ints(env, su), e = ints(env, sj), f = ints(env, sctx);
+    const std::vector<double> ra = doubles(env, tr), rb = doubles(env, sr);
+    double out[CMI_RANK_MEASURES];
+    int64_t nq = 0;
+    const int rc = cmi_fm_eval_rankings((cmi_fm_handle)h, (int64_t)a.size(), a.data(), b.data(), c.data(), ra.data(), (int64_t)d.size(), d.data(),
+                                        e.data(), f.data(), rb.data(), binThold, numRecs, numIgnore, strategy, out, &nq, nullptr, nullptr,
+                                        nullptr, nullptr, nullptr);
+    if (rc != CMI_OK) {
+        throw_fm(env, (cmi_fm_handle)h, rc);
+        return nullptr;
+    }
+    return to_java(env, out, CMI_RANK_MEASURES);
 }
 
 } // extern "C"

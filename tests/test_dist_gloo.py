@@ -21,7 +21,7 @@ MODELS = ["BiasedMF", "PMF", "CAMF_CI", "CAMF_CU", "CAMF_CUCI"]
 EPOCHS = 3
 
 
-class OracleEngine:
+class OracleEngine(cdist.TorchEngineMixin):
     """Engine protocol over the CPU oracle (tests only)."""
 
     def __init__(self, model, shard, k, state, gm):
@@ -48,8 +48,9 @@ def _shard_for(model, data, rank, world):
     return shard, lo, hi
 
 
-def _simulate(model, data, k, gm, world, lr):
+def _simulate(model, data, k, gm, world, lr, merge="mean"):
     """Single-process restatement of the sharded algorithm (all ranks in turn, deltas summed in rank order)."""
+    scale = 1.0 / world if merge == "mean" else 1.0
     engines = []
     for r in range(world):
         shard, lo, hi = _shard_for(model, data, r, world)
@@ -61,14 +62,14 @@ def _simulate(model, data, k, gm, world, lr):
         for n in start:
             assert world == 2
             delta = (engines[0].item[n] - start[n]) + (engines[1].item[n] - start[n])
-            merged = start[n] + delta
+            merged = start[n] + scale * delta
             for e in engines:
                 e.item[n].copy_(merged)
         losses.append(ls[0] + ls[1])
     return engines, losses
 
 
-def _worker(rank, world, port, model, k, tmpdir):
+def _worker(rank, world, port, model, k, tmpdir, merge="mean"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     tdist.init_process_group("gloo", rank=rank, world_size=world)
@@ -79,9 +80,9 @@ def _worker(rank, world, port, model, k, tmpdir):
         gm = float(data.r.sum() / np.count_nonzero(data.r))
         shard, lo, hi = _shard_for(model, data, rank, world)
         eng = OracleEngine(model, shard, k, _shard_state(model, data, k, lo, hi), gm)
-        runner = cdist.ShardedEpochRunner(eng, tdist)
+        runner = cdist.ShardedEpochRunner(eng, tdist, merge=merge)
         got_losses = [runner.epoch(util.LR) for _ in range(EPOCHS)]
-        sim, want_losses = _simulate(model, data, k, gm, world, util.LR)
+        sim, want_losses = _simulate(model, data, k, gm, world, util.LR, merge)
         assert got_losses == want_losses, (got_losses, want_losses)
         for n, a in eng.orc.state.items():
             if a is not None:
@@ -107,6 +108,11 @@ def _free_port():
 @pytest.mark.parametrize("model", MODELS)
 def test_sharded_epoch_world2_gloo(model, tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), model, 6, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_sharded_epoch_world2_gloo_sum_rule(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), "CAMF_CI", 6, str(tmp_path), "sum"), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 

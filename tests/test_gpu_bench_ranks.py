@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_share_one_gpu():
+@pytest.mark.parametrize("model", ["", "CAMF_CU", "CAMF_CUCI"])   # models without userBias crashed the N>1 branch in round 1
+def test_bench_two_ranks_share_one_gpu(model):
     import socket
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
@@ -21,7 +22,7 @@ def test_bench_two_ranks_share_one_gpu():
     env = dict(os.environ, CMI_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--workload", "small"]
+           "--workload", "small"] + (["--model", model] if model else [])
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -29,5 +30,6 @@ def test_bench_two_ranks_share_one_gpu():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["roofline"]["bound"] == "hbm" and "cpu_baseline" not in rec     # the CPU leg is rank 0 at N=1 only
-    assert rec["config"]["parallelism"].startswith("user-sharded x2")
+    assert rec["config"]["parallelism"].startswith("user-sharded x2") and "mean merge" in rec["config"]["parallelism"]
+    assert rec["config"]["final_loss"] < rec["config"]["first_loss"]            # the merged run converges
     assert "5000000 ratings per GPU" in rec["config"]["workload"]                # weak scaling: per-GPU work is fixed

@@ -75,14 +75,14 @@ def _sgd_worker(rank, world, port, tmpdir):
             return inst
         mine = make(rank)
         run = cdist.ShardedEpochRunner(mine, tdist, device_index=0)
-        # in-process simulation: both shards trained locally from the same item-side start, deltas summed
+        # in-process simulation: both shards trained locally from the same item-side start, the MEAN of their moves applied
         sims = [make(r) for r in range(world)]
         losses = []
         for _ in range(3):
             losses.append(run.epoch(util.LR))
             start = {n: sims[0].get_states()[n].copy() for n in ("Q", "icBias")}
             local_losses = [s.train_epoch(util.LR) for s in sims]
-            merged = {n: start[n] + sum((s.get_states()[n] - start[n]) for s in sims) for n in start}
+            merged = {n: start[n] + sum((s.get_states()[n] - start[n]) for s in sims) / world for n in start}
             for s in sims:
                 s.set_states({n: merged[n] for n in merged})
             # (the simulation merges in fp64 on the host, the runner in fp32 on the device: states agree to an fp32 ulp)

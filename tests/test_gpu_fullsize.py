@@ -1,7 +1,14 @@
-"""BASELINE.json's full C3 size (CAMF_CI k=128, 1 M users x 100 K items x 32 conditions, 50 M ratings) on the GPU:
-a direct one-epoch comparison with the CPU oracle (about 30 s of single-thread CPU), plus size-independent
-properties -- idempotence at lr = 0, loss consistency with evalRatings, and schedule independence (the level
-schedule, eager launches and the two-lane graph give the bit-identical model)."""
+"""BASELINE.json's configurations at their full (per-GPU) sizes on the GPU.
+
+C3 (CAMF_CI k=128, 1 M users x 100 K items x 32 conditions, 50 M ratings): a direct one-epoch comparison with the CPU oracle
+(about 30 s of single-thread CPU), plus size-independent properties -- idempotence at lr = 0, loss consistency with
+evalRatings, and schedule independence (hub-chain levels, plain levels, eager launches and the two-lane graph give the
+bit-identical model).
+C5 (CAMF_CU k=256, one GPU's share of 10 M x 1 M x 128 conditions / 500 M ratings = 1.25 M users, 62.5 M ratings) and the
+north_star shape (CAMF_CI k=128, 10 M x 1 M x 64 conditions, 200 M ratings): the same properties at full size, and a one-epoch
+oracle comparison on a 5 M-tuple prefix (same id spaces, same tables).
+C4 (FM k=64, one GPU's share of 5 M x 500 K x 64 / 200 M ratings = 625 K users, 25 M ratings): whole-train == init + sweeps,
+phase-split == fused sweep, the incremental error cache stays consistent with the model, predictions == the FM formula."""
 import numpy as np
 import pytest
 
@@ -33,7 +40,8 @@ def _inst(c3, flags=0):
 def test_c3_one_epoch_matches_oracle(c3):
     data, state, gm = c3
     inst = _inst(c3)
-    assert inst.schedule_info()["tuples"] == data.n and inst.schedule_info()["levels"] > 500
+    info = inst.schedule_info()
+    assert info["tuples"] == data.n and info["kind"] == "chain-item" and 200 < info["levels"] < 400
     lg = inst.train_epoch(util.LR)
     orc = util.c_oracle("CAMF_CI", data, K, {n: a.astype(np.float64) for n, a in state.items()}, gm)
     lo = orc.epoch(util.LR)
@@ -69,7 +77,7 @@ def test_c3_lr_zero_is_idempotent_and_loss_is_consistent(c3):
 
 def test_c3_schedules_agree_bit_for_bit(c3):
     outs = []
-    for flags in (0, capi.FLAG_NO_GRAPH, capi.FLAG_TWO_LANE):
+    for flags in (0, capi.FLAG_NO_CHAIN, capi.FLAG_NO_CHAIN | capi.FLAG_NO_GRAPH, capi.FLAG_TWO_LANE):
         inst = _inst(c3, flags)
         losses = [inst.train_epoch(util.LR) for _ in range(2)]
         outs.append((losses, inst.get_state("P", np.float32), inst.get_state("Q", np.float32),
@@ -79,3 +87,165 @@ def test_c3_schedules_agree_bit_for_bit(c3):
         np.testing.assert_allclose(other[0], outs[0][0], rtol=1e-12)
         for a, b in zip(outs[0][1:], other[1:]):
             assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C5 share and the north_star shape
+# ---------------------------------------------------------------------------------------------------------------------
+
+BIG = {
+    # name: (model, k, users, items, dims, conds/dim, ratings)
+    "c5": ("CAMF_CU", 256, 1_250_000, 1_000_000, 4, 32, 62_500_000),
+    "northstar": ("CAMF_CI", 128, 10_000_000, 1_000_000, 4, 16, 200_000_000),
+}
+
+
+def _big_inst(model, k, data, state, gm, flags=0, n=None):
+    n = data.n if n is None else n
+    inst = capi.Instance(model, k, data.n_users, data.n_items, data.n_conds, flags=flags)
+    inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, gm)
+    inst.set_ratings(data.u[:n], data.j[:n], data.ctx[:n], data.r[:n], data.ctx_ptr, data.ctx_conds)
+    inst.set_states(state)
+    return inst
+
+
+def _reg_terms(model, data, state):
+    """Regulariser part of the epoch loss at the given model: sum over tuples of regU|P[u]|^2 + regI|Q[j]|^2 + the bias terms."""
+    P, Q = state["P"].astype(np.float64), state["Q"].astype(np.float64)
+    np2, nq2 = (P * P).sum(axis=1), (Q * Q).sum(axis=1)
+    conds = data.ctx_conds.reshape(-1, data.n_dims)[data.ctx]
+    reg = util.REG * np.bincount(data.u, minlength=data.n_users).dot(np2) + util.REG * np.bincount(data.j, minlength=data.n_items).dot(nq2)
+    if model == "CAMF_CI":
+        bu, ic = state["userBias"].astype(np.float64), state["icBias"].astype(np.float64)
+        reg += util.REG * np.bincount(data.u, minlength=data.n_users).dot(bu ** 2)
+        for d in range(data.n_dims):
+            reg += util.REGC * (ic[data.j, conds[:, d]] ** 2).sum()
+    else:  # CAMF_CU
+        bj, uc = state["itemBias"].astype(np.float64), state["ucBias"].astype(np.float64)
+        reg += util.REG * np.bincount(data.j, minlength=data.n_items).dot(bj ** 2)
+        for d in range(data.n_dims):
+            reg += util.REGC * (uc[data.u, conds[:, d]] ** 2).sum()
+    return reg
+
+
+@pytest.mark.parametrize("name", ["c5", "northstar"])
+def test_big_shapes_full_size_properties_and_prefix_oracle(name):
+    model, k, nu, ni, nd, cpd, nr = BIG[name]
+    data = synth.generate_fast(nu, ni, nd, cpd, nr)
+    state = synth.init_state(model, data, k, dtype=np.float32)
+    gm = float(data.r.sum() / np.count_nonzero(data.r))
+
+    # (1) lr = 0: nothing moves, and the epoch loss equals 0.5 * (sum e^2 + regularisers) at the initial model
+    inst = _big_inst(model, k, data, state, gm)
+    info = inst.schedule_info()
+    assert info["tuples"] == data.n and info["kind"].startswith("chain")
+    loss0 = inst.train_epoch(0.0)
+    for n_, a in state.items():
+        assert np.array_equal(inst.get_state(n_, np.float32), a), n_
+    step = 1 << 24
+    e2 = 0.0
+    for b in range(0, data.n, step):
+        sl = slice(b, min(data.n, b + step))
+        e2 += float(np.sum((data.r[sl] - inst.predict(data.u[sl], data.j[sl], data.ctx[sl])) ** 2))
+    assert abs(loss0 - 0.5 * (e2 + _reg_terms(model, data, state))) <= 2e-6 * loss0
+
+    # (2) schedule independence at full size: hub-chain levels == plain level launches, bit for bit
+    l1 = inst.train_epoch(util.LR)
+    got = {n_: inst.get_state(n_, np.float32) for n_ in state}
+    del inst
+    plain = _big_inst(model, k, data, state, gm, flags=capi.FLAG_NO_CHAIN)
+    assert plain.schedule_info()["kind"] == "level"
+    plain.train_epoch(0.0)
+    l2 = plain.train_epoch(util.LR)
+    assert abs(l1 - l2) <= 1e-12 * abs(l2)
+    for n_ in state:
+        assert np.array_equal(plain.get_state(n_, np.float32), got[n_]), n_
+    del plain, got
+
+    # (3) one epoch over the first 5 M tuples (full-size tables on the GPU) against the CPU oracle.  The oracle's arithmetic does
+    # not depend on the id values, so it runs on the users / items the prefix touches (compacted ids) -- same tuples, same rows.
+    m = 5_000_000
+    pre = _big_inst(model, k, data, state, gm, n=m)
+    lg = pre.train_epoch(util.LR)
+    uu, ui = np.unique(data.u[:m], return_inverse=True)
+    jj, ji = np.unique(data.j[:m], return_inverse=True)
+    sub = synth.RatingData(len(uu), len(jj), data.n_conds, data.n_dims, ui.astype(np.int32), ji.astype(np.int32), data.ctx[:m],
+                           data.r[:m], data.ctx_ptr, data.ctx_conds)
+    rows = {"P": uu, "userBias": uu, "ucBias": uu, "Q": jj, "itemBias": jj, "icBias": jj}
+    orc = util.c_oracle(model, sub, k, {n_: a[rows[n_]].astype(np.float64) for n_, a in state.items()}, gm)
+    lo = orc.epoch(util.LR)
+    assert abs(lg - lo) <= 1e-6 * abs(lo)
+    for n_ in state:
+        got_rows = pre.get_state(n_, np.float32)[rows[n_]].astype(np.float64)
+        d = np.abs(got_rows - orc.state[n_].reshape(got_rows.shape))
+        assert d.max() <= 2e-5, (n_, d.max())
+    idx = np.arange(0, m, 5)
+    ge = pre.eval_ratings(data.u[idx], data.j[idx], data.ctx[idx], data.r[idx], 1.0, 5.0)
+    oe = orc.eval_ratings(sub.u[idx], sub.j[idx], sub.ctx[idx], sub.r[idx], 1.0, 5.0)
+    assert abs(ge["RMSE"] - oe["RMSE"]) <= 1e-5 and abs(ge["MAE"] - oe["MAE"]) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C4 share: FM k=64, 625 K users x 500 K items x 64 conditions, 25 M ratings (FM.java:115-220)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _fm_predict_np(w0, w, V, nu, ni, nc, n_dims, u, j, c):
+    """FM.predict (FM.java:93-113) in its pairwise form for the <= 3 non-zero features of a rating."""
+    xc = 1.0 / n_dims
+    has = c < nc
+    cc = np.where(has, c, 0)
+    vu, vj, vc = V[u], V[nu + j], V[nu + ni + cc] * (xc * has)[:, None]
+    lin = w0 + w[u] + w[nu + j] + w[nu + ni + cc] * xc * has
+    s = vu + vj + vc
+    return lin + 0.5 * ((s * s).sum(axis=1) - (vu * vu).sum(axis=1) - (vj * vj).sum(axis=1) - (vc * vc).sum(axis=1))
+
+
+def test_c4_fm_share_full_size():
+    k = 64
+    data = synth.generate_fast(625_000, 500_000, 4, 16, 25_000_000)
+    p = data.n_users + data.n_items + data.n_conds
+    rng = np.random.default_rng(1)
+    w_init, V_init = rng.random(p), 0.1 * rng.standard_normal((p, k))
+    regw, regf = synth.java_float(0.01), synth.java_float(0.02)
+
+    def make():
+        g = capi.FMInstance(k, data.n_users, data.n_items, data.n_conds, data.n_dims)
+        g.set_hparams(regw, regf)
+        g.set_ratings(data.u, data.j, data.ctx, data.r)
+        g.set_model(0.0, w_init, V_init)
+        return g
+
+    a, b = make(), make()
+    a.train(2)                                   # whole buildModel(): init + 2 sweeps
+    b.init()
+    b.sweep()                                    # fused sweep ...
+    for ph in range(b.num_phases()):             # ... then one sweep as split reduce / apply phases (the multi-GPU form)
+        b.phase_reduce(ph)
+        b.phase_apply(ph)
+    b.synchronize()
+    ma, mb = a.get_model(), b.get_model()
+    assert ma[0] == mb[0] and np.array_equal(ma[1], mb[1]) and np.array_equal(ma[2], mb[2])
+    del b
+
+    # predictions on a sample == the FM formula over the returned model
+    idx = np.arange(0, data.n, 100)
+    got = a.predict(data.u[idx], data.j[idx], data.ctx[idx])
+    want = _fm_predict_np(ma[0], ma[1], ma[2], data.n_users, data.n_items, data.n_conds, data.n_dims,
+                          data.u[idx].astype(np.int64), data.j[idx].astype(np.int64), data.ctx[idx].astype(np.int64))
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+    rmse2 = float(np.sqrt(np.mean((data.r[idx] - got) ** 2)))
+
+    # the incremental errors[] / Q cache of buildModel() (FM.java:133-146, updated in place by every coordinate step) is still
+    # what a fresh pre-pass computes from the model: continuing == re-initialising from the same model
+    c = make()
+    c.set_model(*ma)
+    c.init()
+    c.sweep()
+    a.sweep()
+    mc, ma3 = c.get_model(), a.get_model()
+    assert abs(mc[0] - ma3[0]) <= 1e-9 * max(1.0, abs(ma3[0]))
+    np.testing.assert_allclose(mc[1], ma3[1], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(mc[2], ma3[2], rtol=1e-6, atol=1e-9)
+    # every coordinate step minimises the regularised squared error in its coordinate: the training error keeps falling
+    rmse3 = float(np.sqrt(np.mean((data.r[idx] - a.predict(data.u[idx], data.j[idx], data.ctx[idx])) ** 2)))
+    assert rmse3 < rmse2

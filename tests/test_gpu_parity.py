@@ -308,8 +308,9 @@ def test_level_order_is_free():
 
 
 def test_dist_gpu_engine_aliases_device_state_and_exchange_is_identity_at_world1():
-    """carskit_amd.dist on a real GPU: the item-side containers are aliased as torch tensors through
-    cmi_state_device_ptr (zero copy), and with one rank the RCCL exchange is the identity (to fp32 rounding)."""
+    """carskit_amd.dist on a real GPU: the exchange bucket of cmi_exchange_setup is aliased as a torch tensor (zero copy), the
+    HIP pack kernel leaves this rank's item-side movement in it, and with one rank the RCCL reduce-scatter + all-gather exchange
+    is the identity (to fp32 rounding)."""
     import os
     import socket
     import torch
@@ -319,16 +320,21 @@ def test_dist_gpu_engine_aliases_device_state_and_exchange_is_identity_at_world1
     _, a = make_pair("CAMF_CI", data, 128, 0)
     _, b = make_pair("CAMF_CI", data, 128, 0)
     eng = cdist.GpuEngine(a, 0)
-    q = eng.item["Q"]
-    assert q.is_cuda and q.numel() == data.n_items * 128
-    assert np.array_equal(q.cpu().numpy().reshape(data.n_items, 128), a.get_state("Q", np.float32))
-    saved = q[:128].clone()
-    q[:128] = 7.0                                           # torch writes land in the library's buffer
-    torch.cuda.synchronize()
-    assert np.all(a.get_state("Q", np.float32)[0] == 7.0)
-    q[:128] = saved
-    torch.cuda.synchronize()
-    assert np.array_equal(a.get_state("Q", np.float32), b.get_state("Q", np.float32))
+    nq, nic = data.n_items * 128, data.n_items * data.n_conds
+    assert eng.bucket.is_cuda and eng.bucket.numel() >= nq + nic and eng.bucket.numel() % 4 == 0
+    q0, ic0 = a.get_state("Q", np.float32), a.get_state("icBias", np.float32)
+    a.train_epoch(util.LR)
+    b.train_epoch(util.LR)
+    got = eng.pack()
+    a.synchronize()
+    got = got.cpu().numpy()
+    assert np.array_equal(got[:nq].reshape(q0.shape), a.get_state("Q", np.float32) - q0)            # bucket = state - snapshot
+    assert np.array_equal(got[nq:nq + nic].reshape(ic0.shape), a.get_state("icBias", np.float32) - ic0)
+    eng.apply(1.0)                                         # snapshot + 1 * (state - snapshot): the same model to an fp32 ulp
+    a.synchronize()
+    np.testing.assert_allclose(a.get_state("Q", np.float32), b.get_state("Q", np.float32), rtol=1e-6, atol=1e-8)
+    loss_t = eng.loss_tensor()
+    assert loss_t.dtype == torch.float64 and abs(float(loss_t.item()) - a.last_loss()) == 0.0
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -337,6 +343,7 @@ def test_dist_gpu_engine_aliases_device_state_and_exchange_is_identity_at_world1
     tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         runner = cdist.ShardedEpochRunner(a, tdist, device_index=0, always_exchange=True)
+        assert runner.rs_ag                                # RCCL: in-place reduce-scatter + all-gather of the bucket
         for _ in range(3):
             la, lb = runner.epoch(util.LR), b.train_epoch(util.LR)
             assert abs(la - lb) <= 1e-6 * abs(lb)
