@@ -14,8 +14,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcarskit_mi355x.so")
 
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NUMERIC, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
-MODEL_IDS = {"BiasedMF": 0, "CAMF_C": 1, "CAMF_CI": 2, "CAMF_CU": 3, "CAMF_CUCI": 4, "PMF": 5}
-STATE_IDS = {"P": 0, "Q": 1, "userBias": 2, "itemBias": 3, "condBias": 4, "ucBias": 5, "icBias": 6}
+MODEL_IDS = {"BiasedMF": 0, "CAMF_C": 1, "CAMF_CI": 2, "CAMF_CU": 3, "CAMF_CUCI": 4, "PMF": 5,
+             "SVD++": 6, "CAMF_ICS": 7, "CAMF_LCS": 8, "CAMF_MCS": 9}
+STATE_IDS = {"P": 0, "Q": 1, "userBias": 2, "itemBias": 3, "condBias": 4, "ucBias": 5, "icBias": 6,
+             "Y": 7, "ccMatrix": 8, "cfMatrix": 9, "cVector": 10}
 MODEL_STATES = {
     "BiasedMF": ("P", "Q", "userBias", "itemBias"),
     "CAMF_C": ("P", "Q", "userBias", "itemBias", "condBias"),
@@ -23,6 +25,10 @@ MODEL_STATES = {
     "CAMF_CU": ("P", "Q", "itemBias", "ucBias"),
     "CAMF_CUCI": ("P", "Q", "ucBias", "icBias"),
     "PMF": ("P", "Q"),
+    "SVD++": ("P", "Q", "userBias", "itemBias", "Y"),
+    "CAMF_ICS": ("P", "Q", "ccMatrix"),
+    "CAMF_LCS": ("P", "Q", "cfMatrix"),
+    "CAMF_MCS": ("P", "Q", "cVector"),
 }
 # the state keyed by item (replicated and reconciled across GPUs when tuples are sharded by user)
 ITEM_SIDE = {"Q", "itemBias", "icBias", "condBias"}
@@ -47,6 +53,7 @@ SYMBOLS = [
     ("cmi_set_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     ("cmi_set_state", C.c_int, [_vp, C.c_int, _vp, _i64, C.c_int]),
     ("cmi_get_state", C.c_int, [_vp, C.c_int, _vp, _i64, C.c_int]),
+    ("cmi_set_sim_params", C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int]),
     ("cmi_set_hparams", C.c_int, [_vp, _dbl, _dbl, _dbl, _dbl, _dbl]),
     ("cmi_train_epoch", C.c_int, [_vp, _dbl, C.POINTER(_dbl)]),
     ("cmi_train", C.c_int, [_vp, C.c_int, _dbl, _dbl, C.c_int, _dbl, C.c_int, _vp, _vp, C.POINTER(C.c_int),
@@ -345,6 +352,7 @@ class Instance:
         self.model = model if isinstance(model, str) else {v: n for n, v in MODEL_IDS.items()}[model]
         self.k, self.n_users, self.n_items, self.n_conds = k, n_users, n_items, n_conds
         self.flags = flags
+        self.num_f = 0
         self.h = _vp()
         rc = self.L.cmi_create(MODEL_IDS[self.model], k, n_users, n_items, n_conds, device, flags, C.byref(self.h))
         if rc != OK:
@@ -373,6 +381,12 @@ class Instance:
         self.close()
 
     # -- data ---------------------------------------------------------------------------------------
+    def set_sim_params(self, num_f, n_ctx_dims, empty_conds):
+        """CAMF_ICS / LCS / MCS: EmptyContextConditions, `-f` of CAMF_LCS, rateDao.numContextDims() (cmi_set_sim_params)"""
+        e = np.ascontiguousarray(empty_conds, dtype=np.int32)
+        self._chk(self.L.cmi_set_sim_params(self.h, int(num_f), int(n_ctx_dims), _p(e), len(e)))
+        self.num_f = int(num_f)
+
     def set_ratings(self, u, j, ctx, r, ctx_ptr=None, ctx_conds=None):
         c32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
         u, j, ctx, ctx_ptr, ctx_conds = c32(u), c32(j), c32(ctx), c32(ctx_ptr), c32(ctx_conds)
@@ -395,7 +409,8 @@ class Instance:
     def state_shape(self, name):
         return {"P": (self.n_users, self.k), "Q": (self.n_items, self.k), "userBias": (self.n_users,),
                 "itemBias": (self.n_items,), "condBias": (self.n_conds,), "ucBias": (self.n_users, self.n_conds),
-                "icBias": (self.n_items, self.n_conds)}[name]
+                "icBias": (self.n_items, self.n_conds), "Y": (self.n_items, self.k), "ccMatrix": (self.n_conds, self.n_conds),
+                "cfMatrix": (self.n_conds, self.num_f), "cVector": (self.n_conds,)}[name]
 
     def get_state(self, name, dtype=np.float64):
         out = np.empty(self.state_shape(name), dtype=dtype)

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,8 +26,12 @@ bool cmi_model_has(int model, int which) {
     switch (which) {
     case CMI_STATE_P:
     case CMI_STATE_Q: return true;
-    case CMI_STATE_USER_BIAS: return model == CMI_MODEL_BIASEDMF || model == CMI_MODEL_CAMF_C || model == CMI_MODEL_CAMF_CI;
-    case CMI_STATE_ITEM_BIAS: return model == CMI_MODEL_BIASEDMF || model == CMI_MODEL_CAMF_C || model == CMI_MODEL_CAMF_CU;
+    case CMI_STATE_USER_BIAS: return model == CMI_MODEL_BIASEDMF || model == CMI_MODEL_CAMF_C || model == CMI_MODEL_CAMF_CI || model == CMI_MODEL_SVDPP;
+    case CMI_STATE_ITEM_BIAS: return model == CMI_MODEL_BIASEDMF || model == CMI_MODEL_CAMF_C || model == CMI_MODEL_CAMF_CU || model == CMI_MODEL_SVDPP;
+    case CMI_STATE_Y: return model == CMI_MODEL_SVDPP;
+    case CMI_STATE_CC_MATRIX: return model == CMI_MODEL_CAMF_ICS;
+    case CMI_STATE_CF_MATRIX: return model == CMI_MODEL_CAMF_LCS;
+    case CMI_STATE_C_VECTOR: return model == CMI_MODEL_CAMF_MCS;
     case CMI_STATE_COND_BIAS: return model == CMI_MODEL_CAMF_C;
     case CMI_STATE_UC_BIAS: return model == CMI_MODEL_CAMF_CU || model == CMI_MODEL_CAMF_CUCI;
     case CMI_STATE_IC_BIAS: return model == CMI_MODEL_CAMF_CI || model == CMI_MODEL_CAMF_CUCI;
@@ -43,11 +48,17 @@ static int64_t state_elems(const cmi_instance *h, int which) {
     case CMI_STATE_COND_BIAS: return h->n_conds;
     case CMI_STATE_UC_BIAS: return (int64_t)h->n_users * h->n_conds;
     case CMI_STATE_IC_BIAS: return (int64_t)h->n_items * h->n_conds;
+    case CMI_STATE_Y: return (int64_t)h->n_items * h->k;
+    case CMI_STATE_CC_MATRIX: return (int64_t)h->n_conds * h->n_conds;
+    case CMI_STATE_CF_MATRIX: return (int64_t)h->n_conds * h->num_f; // 0 until cmi_set_sim_params
+    case CMI_STATE_C_VECTOR: return h->n_conds;
     }
     return 0;
 }
 
 static size_t esize(const cmi_instance *h) { return h->f64 ? 8 : 4; }
+static bool is_ext_model(int model) { return model >= CMI_MODEL_SVDPP && model <= CMI_MODEL_CAMF_MCS; }
+static bool is_2d_model(int model) { return model == CMI_MODEL_BIASEDMF || model == CMI_MODEL_PMF || model == CMI_MODEL_SVDPP; }
 
 extern "C" int cmi_abi_version(void) { return CMI_ABI_VERSION; }
 
@@ -76,7 +87,9 @@ static void free_ratings(cmi_instance *h) {
         h->graph_exec = nullptr;
     }
     void *ptrs[] = {h->d_su, h->d_sj, h->d_sconds, h->d_ctx_ptr, h->d_ctx_conds, h->d_sr, h->d_loss_part,
-                    h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->d_tail_off, h->d_blk_off, h->d_unit_off};
+                    h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->d_tail_off, h->d_blk_off, h->d_unit_off,
+                    h->d_ui_ptr, h->d_ui_items};
+    h->d_ui_ptr = h->d_ui_items = nullptr;
     for (void *p : ptrs)
         if (p) hipFree(p);
     h->d_su = h->d_sj = h->d_sconds = h->d_ctx_ptr = h->d_ctx_conds = nullptr;
@@ -107,6 +120,7 @@ extern "C" int cmi_destroy(cmi_handle h) {
             hipFree(p);
             p = nullptr;
         }
+    if (h->d_empty) hipFree(h->d_empty);
     if (h->d_xbucket) hipFree(h->d_xbucket);
     if (h->d_xsnap) hipFree(h->d_xsnap);
     if (h->d_scratch) hipFree(h->d_scratch);
@@ -123,7 +137,7 @@ extern "C" int cmi_destroy(cmi_handle h) {
 extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_conds, int device, unsigned flags,
                           cmi_handle *out) {
     if (out) *out = nullptr;
-    if (!out || model < 0 || model > CMI_MODEL_PMF || k <= 0 || n_users <= 0 || n_items <= 0 || n_conds < 0) {
+    if (!out || model < 0 || model > CMI_MODEL_CAMF_MCS || k <= 0 || n_users <= 0 || n_items <= 0 || n_conds < 0) {
         g_create_err = "cmi_create: invalid argument";
         return CMI_E_INVALID;
     }
@@ -140,6 +154,12 @@ extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_cond
         g_create_err =
             "cmi_create: CAMF_C updates the shared condBias vector on every tuple, so its tuples do not commute and "
             "no order-exact level schedule exists; pass CMI_FLAG_SCHED_SERIAL";
+        return CMI_E_UNSUPPORTED;
+    }
+    if (is_ext_model(model) && !(flags & CMI_FLAG_SCHED_SERIAL)) {
+        g_create_err =
+            "cmi_create: SVD++ / CAMF_ICS / CAMF_LCS / CAMF_MCS update parameters shared by (nearly) every tuple, so no order-exact "
+            "parallel schedule exists; pass CMI_FLAG_SCHED_SERIAL";
         return CMI_E_UNSUPPORTED;
     }
     cmi_instance *h = new cmi_instance();
@@ -197,6 +217,37 @@ extern "C" int cmi_set_hparams(cmi_handle h, double regU, double regI, double re
     h->hp.regB = regB;
     h->hp.regC = regC;
     h->hp.gm = h->model == CMI_MODEL_PMF ? 0.0 : global_mean; // PMF.predict is the bare dot product
+    return CMI_OK;
+}
+
+extern "C" int cmi_set_sim_params(cmi_handle h, int num_f, int n_ctx_dims, const int32_t *empty_conds, int n_empty) {
+    if (!h) return CMI_E_INVALID;
+    if (!is_ext_model(h->model) || h->model == CMI_MODEL_SVDPP) return CMI_OK; // nothing to configure
+    if (n_empty < 0 || (n_empty > 0 && !empty_conds) || n_ctx_dims < 1 || (h->model == CMI_MODEL_CAMF_LCS && num_f < 1))
+        CMI_FAIL(h, CMI_E_INVALID, "set_sim_params: invalid argument");
+    for (int i = 0; i < n_empty; ++i)
+        if (empty_conds[i] < 0 || empty_conds[i] >= h->n_conds) CMI_FAIL(h, CMI_E_INVALID, "set_sim_params: empty condition id %d out of range", empty_conds[i]);
+    CMI_HIP(h, hipSetDevice(h->device));
+    CMI_HIP(h, hipStreamSynchronize(h->stream));
+    h->n_ctx_dims = n_ctx_dims;
+    h->empty_conds.assign(empty_conds, empty_conds + n_empty);
+    if (h->d_empty) hipFree(h->d_empty);
+    h->d_empty = nullptr;
+    if (n_empty > 0) {
+        CMI_HIP(h, hipMalloc((void **)&h->d_empty, (size_t)n_empty * 4));
+        CMI_HIP(h, hipMemcpy(h->d_empty, empty_conds, (size_t)n_empty * 4, hipMemcpyHostToDevice));
+    }
+    if (h->model == CMI_MODEL_CAMF_LCS && num_f != h->num_f) {
+        if (h->state[CMI_STATE_CF_MATRIX]) hipFree(h->state[CMI_STATE_CF_MATRIX]);
+        h->state[CMI_STATE_CF_MATRIX] = nullptr;
+        h->num_f = num_f;
+        h->state_count[CMI_STATE_CF_MATRIX] = (int64_t)h->n_conds * num_f;
+        const size_t bytes = (size_t)h->state_count[CMI_STATE_CF_MATRIX] * esize(h);
+        if (bytes) {
+            CMI_HIP(h, hipMalloc(&h->state[CMI_STATE_CF_MATRIX], bytes));
+            CMI_HIP(h, hipMemset(h->state[CMI_STATE_CF_MATRIX], 0, bytes));
+        }
+    }
     return CMI_OK;
 }
 
@@ -300,8 +351,14 @@ static bool try_chain(cmi_instance *h, int64_t n, const int32_t *u, const int32_
 extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                                const double *r, int32_t n_ctx, const int32_t *ctx_ptr, const int32_t *ctx_conds) {
     if (!h) return CMI_E_INVALID;
-    const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF;
+    const bool contextual = !is_2d_model(h->model);
     if (n < 0 || (n > 0 && (!u || !j || !r))) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: null tuple arrays");
+    if (is_ext_model(h->model) && h->model != CMI_MODEL_SVDPP && (h->empty_conds.empty() || (h->model == CMI_MODEL_CAMF_LCS && h->num_f < 1)))
+        CMI_FAIL(h, CMI_E_INVALID, "set_ratings: call cmi_set_sim_params first (EmptyContextConditions%s)", h->model == CMI_MODEL_CAMF_LCS ? ", numF" : "");
+    if (contextual && is_ext_model(h->model) && n_ctx > 0 && ctx_ptr) {
+        for (int32_t c = 0; c < n_ctx; ++c)
+            if (ctx_ptr[c + 1] - ctx_ptr[c] > 16) CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: more than 16 conditions per context");
+    }
     if (contextual && (n_ctx < 0 || !ctx_ptr || (n > 0 && !ctx) || (n_ctx > 0 && ctx_ptr[n_ctx] > 0 && !ctx_conds)))
         CMI_FAIL(h, CMI_E_INVALID, "set_ratings: context table required for model %d", h->model);
     CMI_HIP(h, hipSetDevice(h->device));
@@ -493,6 +550,20 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // cp/cc are locals
     }
     if (e == hipSuccess && h->chain) e = upload((void **)&h->d_unit_off, csch.unit_off, h->stream);
+    if (e == hipSuccess && h->model == CMI_MODEL_SVDPP) {
+        // userItemsCache = train.rowColumnsCache (SVDPlusPlus.java:52): the items of every user in the 2-D train matrix, ascending
+        std::vector<int32_t> ptr((size_t)h->n_users + 1, 0), items((size_t)n);
+        for (int64_t t = 0; t < n; ++t) ptr[(size_t)u[t] + 1]++;
+        for (int32_t x = 0; x < h->n_users; ++x) ptr[(size_t)x + 1] += ptr[(size_t)x];
+        {
+            std::vector<int32_t> cur(ptr.begin(), ptr.end() - 1);
+            for (int64_t t = 0; t < n; ++t) items[(size_t)cur[(size_t)u[t]]++] = j[t];
+        }
+        for (int32_t x = 0; x < h->n_users; ++x) std::sort(items.begin() + ptr[(size_t)x], items.begin() + ptr[(size_t)x + 1]);
+        e = upload((void **)&h->d_ui_ptr, ptr, h->stream);
+        if (e == hipSuccess) e = upload((void **)&h->d_ui_items, items, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // ptr/items are locals
+    }
     if (e == hipSuccess && h->n_slots > 0) {
         // zeroed: a launch shape that writes fewer slots than were reserved must not feed garbage into the loss
         e = hipMalloc((void **)&h->d_loss_part, (size_t)h->n_slots * sizeof(double));
@@ -560,11 +631,44 @@ static SgdArgs<T> make_args(cmi_instance *h) {
     return a;
 }
 
+template <typename T>
+static ExtArgs<T> make_ext_args(cmi_instance *h) {
+    ExtArgs<T> a;
+    a.P = (T *)h->state[CMI_STATE_P];
+    a.Q = (T *)h->state[CMI_STATE_Q];
+    a.userBias = (T *)h->state[CMI_STATE_USER_BIAS];
+    a.itemBias = (T *)h->state[CMI_STATE_ITEM_BIAS];
+    a.Y = (T *)h->state[CMI_STATE_Y];
+    a.cc = (T *)h->state[CMI_STATE_CC_MATRIX];
+    a.cf = (T *)h->state[CMI_STATE_CF_MATRIX];
+    a.cv = (T *)h->state[CMI_STATE_C_VECTOR];
+    a.su = h->d_su;
+    a.sj = h->d_sj;
+    a.sr = (const T *)h->d_sr;
+    a.sconds = h->d_sconds;
+    a.empty_conds = h->d_empty;
+    a.ui_ptr = h->d_ui_ptr;
+    a.ui_items = h->d_ui_items;
+    a.hp = h->d_hp;
+    a.upbound = 1.0 / std::sqrt((double)h->n_ctx_dims); // CAMF_MCS.java:47
+    a.lowbound = 1.0 / std::pow(10.0, 100.0);             // CAMF_MCS.java:48
+    a.k = h->k;
+    a.n_conds = h->n_conds;
+    a.dmax = h->dmax;
+    a.num_f = h->num_f;
+    a.n_empty = (int32_t)h->empty_conds.size();
+    return a;
+}
+
 // enqueue every level of one epoch + the loss reduction on h->stream
 static hipError_t enqueue_levels(cmi_instance *h) {
     LaunchCfg cfg{h->model, h->strict};
     hipError_t e = hipSuccess;
     const int64_t n_levels = (int64_t)h->level_off.size() - 1;
+    if (is_ext_model(h->model)) {
+        if (h->f64) return launch_ext_serial<double>(make_ext_args<double>(h), h->model, h->strict, h->n, h->d_loss, h->stream);
+        return launch_ext_serial<float>(make_ext_args<float>(h), h->model, h->strict, h->n, h->d_loss, h->stream);
+    }
     if (h->serial) {
         if (h->d_blk_off) { // CAMF_C over conflict-free blocks
             const int nb = (int)h->blk_off.size() - 1;
@@ -786,6 +890,7 @@ extern "C" int cmi_exchange_setup(cmi_handle h, int64_t pad_to, void **bucket, i
     if (h->model == CMI_MODEL_CAMF_C) CMI_FAIL(h, CMI_E_UNSUPPORTED, "exchange: CAMF_C shares condBias between all tuples and is not sharded");
     CMI_HIP(h, hipSetDevice(h->device));
     CMI_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->d_empty) hipFree(h->d_empty);
     if (h->d_xbucket) hipFree(h->d_xbucket);
     if (h->d_xsnap) hipFree(h->d_xsnap);
     h->d_xbucket = h->d_xsnap = nullptr;
@@ -874,9 +979,49 @@ extern "C" int cmi_last_epoch_ms(cmi_handle h, float *ms) {
 // ---- predict / evalRatings -------------------------------------------------------------------------
 
 template <typename T>
+cmi::ExtEvalArgs<T> cmi_ext_eval_args(cmi_instance *h, const int32_t *du, const int32_t *dj, const int32_t *dctx, const double *dr,
+                                      double *dpreds, double *dpart, int bound, double lo, double hi, double min_rate) {
+    ExtEvalArgs<T> x;
+    x.P = (const T *)h->state[CMI_STATE_P];
+    x.Q = (const T *)h->state[CMI_STATE_Q];
+    x.userBias = (const T *)h->state[CMI_STATE_USER_BIAS];
+    x.itemBias = (const T *)h->state[CMI_STATE_ITEM_BIAS];
+    x.Y = (const T *)h->state[CMI_STATE_Y];
+    x.cc = (const T *)h->state[CMI_STATE_CC_MATRIX];
+    x.cf = (const T *)h->state[CMI_STATE_CF_MATRIX];
+    x.cv = (const T *)h->state[CMI_STATE_C_VECTOR];
+    x.u = du;
+    x.j = dj;
+    x.ctx = dctx;
+    x.r = dr;
+    x.ctx_ptr = h->d_ctx_ptr;
+    x.ctx_conds = h->d_ctx_conds;
+    x.empty_conds = h->d_empty;
+    x.ui_ptr = h->d_ui_ptr;
+    x.ui_items = h->d_ui_items;
+    x.preds = dpreds;
+    x.part = dpart;
+    x.gm = h->hp.gm;
+    x.lo = lo;
+    x.hi = hi;
+    x.min_rate = min_rate;
+    x.k = h->k;
+    x.n_conds = h->n_conds;
+    x.num_f = h->num_f;
+    x.n_empty = (int32_t)h->empty_conds.size();
+    x.bound = bound;
+    x.model = h->model;
+    return x;
+}
+template cmi::ExtEvalArgs<float> cmi_ext_eval_args<float>(cmi_instance *, const int32_t *, const int32_t *, const int32_t *, const double *, double *, double *, int, double, double, double);
+template cmi::ExtEvalArgs<double> cmi_ext_eval_args<double>(cmi_instance *, const int32_t *, const int32_t *, const int32_t *, const double *, double *, double *, int, double, double, double);
+
+template <typename T>
 static hipError_t run_eval(cmi_instance *h, int64_t n, const int32_t *du, const int32_t *dj, const int32_t *dctx,
                            const double *dr, double *dpreds, double *dpart, int bound, double lo, double hi,
                            double min_rate) {
+    if (is_ext_model(h->model))
+        return launch_ext_eval<T>(cmi_ext_eval_args<T>(h, du, dj, dctx, dr, dpreds, dpart, bound, lo, hi, min_rate), n, h->stream);
     EvalArgs<T> a;
     a.P = (const T *)h->state[CMI_STATE_P];
     a.Q = (const T *)h->state[CMI_STATE_Q];
@@ -907,7 +1052,8 @@ static hipError_t run_eval(cmi_instance *h, int64_t n, const int32_t *du, const 
 static int eval_common(cmi_instance *h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                        const double *r, int bound, double lo, double hi, double min_rate, double *preds_out,
                        double sums[5]) {
-    const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF;
+    const bool contextual = !is_2d_model(h->model);
+    if (h->model == CMI_MODEL_SVDPP && !h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "eval: SVD++ predicts with the users' training items; call cmi_set_ratings first");
     if (n < 0 || (n > 0 && (!u || !j))) CMI_FAIL(h, CMI_E_INVALID, "eval: null tuple arrays");
     if (contextual && n > 0 && !ctx) CMI_FAIL(h, CMI_E_INVALID, "eval: ctx required for model %d", h->model);
     if (contextual && !h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "eval: the context table comes from cmi_set_ratings; call it first");
@@ -983,7 +1129,7 @@ extern "C" int cmi_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const
 extern "C" int cmi_set_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                                     const double *r) {
     if (!h) return CMI_E_INVALID;
-    const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF;
+    const bool contextual = !is_2d_model(h->model);
     if (n < 0 || (n > 0 && (!u || !j || !r || (contextual && !ctx)))) CMI_FAIL(h, CMI_E_INVALID, "set_eval_ratings: null arrays");
     if (contextual && !h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "set_eval_ratings: the context table comes from cmi_set_ratings; call it first");
     for (int64_t t = 0; t < n; ++t) {

@@ -58,6 +58,10 @@ struct cmi_instance {
     int64_t x_count = 0;
     std::vector<int> x_which;       // containers in the bucket, in order
     std::vector<int64_t> x_off;     // their element offsets (16-byte aligned segments)
+    // SVD++ / CAMF_*CS (ext_kernels.hip)
+    int num_f = 0, n_ctx_dims = 1;
+    std::vector<int32_t> empty_conds;
+    int32_t *d_empty = nullptr, *d_ui_ptr = nullptr, *d_ui_items = nullptr;
     float last_rank_ms = 0.f;    // device time of the most recent cmi_eval_rankings scoring loop (HIP events)
     double last_rank_flops = 0.0; // 2 * queries * candidates * padded operand length of that loop
 };
@@ -77,3 +81,7 @@ struct cmi_instance {
     } while (0)
 
 bool cmi_model_has(int model, int which); // which containers a model owns (cmi_api.cpp)
+// evaluation-side view of an SVD++ / CAMF_*CS instance (cmi_api.cpp); the tuple / output pointers may be null for the ranking operands
+template <typename T>
+cmi::ExtEvalArgs<T> cmi_ext_eval_args(cmi_instance *h, const int32_t *du, const int32_t *dj, const int32_t *dctx, const double *dr,
+                                      double *dpreds, double *dpart, int bound, double lo, double hi, double min_rate);

@@ -46,6 +46,12 @@ struct Dao {
         d.ctx_ptr.resize(nctx + 1);
         d.ctx_conds.resize((size_t)cmi_dao_ctx_nnz(h));
         cmi_dao_ctx_table(h, d.ctx_ptr.data(), d.ctx_conds.data());
+        {
+            std::vector<int32_t> cond_dim((size_t)std::max<int64_t>(1, counts[4])), empty((size_t)std::max<int64_t>(1, counts[4]));
+            int32_t n_empty = 0;
+            cmi_dao_cond_info(h, cond_dim.data(), empty.data(), &n_empty);
+            d.empty_conds.assign(empty.begin(), empty.begin() + n_empty);
+        }
         int32_t ns = 0;
         cmi_dao_rating_scale(h, nullptr, 0, &ns);
         std::vector<double> scale((size_t)ns);
@@ -115,6 +121,10 @@ static int run(const std::string &config, unsigned flags, int iters_override, bo
     RatingData data = rateDao.ratingData();
     // runAlgorithm
     const std::string algoName = LineConfiger(cf.getString("recommender")).getMainParam();
+    {   // the similarity-based CAMF recommenders are top-N models: their constructors switch the (static) isRankingPred on
+        const std::string a = lower(algoName);
+        if (a == "camf_ics" || a == "camf_lcs" || a == "camf_mcs") conf.isRankingPred = true;
+    }
     log("With Setup: " + cf.getString("evaluation.setup"));
     std::vector<Measures> all;
     std::string name;

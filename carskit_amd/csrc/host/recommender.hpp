@@ -95,6 +95,7 @@ struct RatingData {
     std::vector<int32_t> u, j, ctx;
     std::vector<double> r;
     std::vector<int32_t> ctx_ptr, ctx_conds;
+    std::vector<int32_t> empty_conds; // EmptyContextConditions (DataDAO.java:213-214): the ":na" conditions in header order
     double min_rate = 1, max_rate = 5;
     int64_t n() const { return (int64_t)r.size(); }
     RatingData subset(const std::vector<int64_t> &idx) const {
@@ -145,6 +146,7 @@ struct Conf {
     int numRecs = 10, numIgnore = -1;
     double binThold = -1.0;
     std::string evalStrategy = "ucu";
+    int numF = 10; // `-f` of the recommender line (CAMF_LCS.java:37: algoOptions.getInt("-f", 10))
     Conf() {}
     explicit Conf(const FileConfiger &cf) {
         if (cf.contains("learn.rate")) {
@@ -181,6 +183,7 @@ struct Conf {
         }
         if (cf.contains("ratings.setup")) binThold = cf.getParamOptions("ratings.setup").getFloat("-threshold", -1);
         evalStrategy = lower(cf.getString("eval.strategy", "ucu"));
+        if (cf.contains("recommender")) numF = cf.getParamOptions("recommender").getInt("-f", 10);
         if (cf.contains("FM")) {
             LineConfiger fm = cf.getParamOptions("FM");
             regLw = fm.getFloat("-lw", 0);
@@ -253,16 +256,40 @@ class IterativeRecommender {
             gauss(state[CMI_STATE_UC_BIAS], nu * nc);
             gauss(state[CMI_STATE_IC_BIAS], ni * nc);
             break;
+        case CMI_MODEL_SVDPP: // SVDPlusPlus.java:46-53: BiasedMF.initModel, then Y.init(initMean, initStd)
+            gauss(state[CMI_STATE_USER_BIAS], nu);
+            gauss(state[CMI_STATE_ITEM_BIAS], ni);
+            gauss(state[CMI_STATE_Y], ni * k);
+            break;
+        case CMI_MODEL_CAMF_ICS: // CAMF_ICS.java:36-51: isRankingPred -> P.init(), Q.init() (uniform) on top of the gaussian draws
+            unif(state[CMI_STATE_P], nu * k);
+            unif(state[CMI_STATE_Q], ni * k);
+            state[CMI_STATE_CC_MATRIX].assign(nc * nc, 1.0);
+            break;
+        case CMI_MODEL_CAMF_LCS: // CAMF_LCS.java:34-41: cfMatrix_LCS.init() = uniform(0,1)
+            unif(state[CMI_STATE_CF_MATRIX], nc * (size_t)conf_.numF);
+            break;
+        case CMI_MODEL_CAMF_MCS: { // CAMF_MCS.java:41-52: cVector_MCS.init(upbound) = uniform(0, 1/sqrt(numContextDims))
+            const double up = 1.0 / std::sqrt((double)std::max(1, trainMatrix.n_dims));
+            unif(state[CMI_STATE_C_VECTOR], nc);
+            for (double &x : state[CMI_STATE_C_VECTOR]) x *= up;
+            break;
+        }
         default: break;
         }
     }
 
     virtual void buildModel() {
-        unsigned flags = conf_.flags | (model_ == CMI_MODEL_CAMF_C ? CMI_FLAG_SCHED_SERIAL : 0u);
+        const bool chained = model_ == CMI_MODEL_CAMF_C || (model_ >= CMI_MODEL_SVDPP && model_ <= CMI_MODEL_CAMF_MCS);
+        unsigned flags = conf_.flags | (chained ? CMI_FLAG_SCHED_SERIAL : 0u); // one dependent chain in CRS order
         int rc = cmi_create(model_, conf_.numFactors, trainMatrix.n_users, trainMatrix.n_items, trainMatrix.n_conds,
                             conf_.device, flags, &h_);
         if (rc != CMI_OK) throw std::runtime_error(std::string("cmi_create: ") + cmi_last_error(nullptr));
         check(cmi_set_hparams(h_, conf_.regU, conf_.regI, conf_.regB, conf_.regC, globalMean), h_, "cmi_set_hparams");
+        if (model_ >= CMI_MODEL_CAMF_ICS && model_ <= CMI_MODEL_CAMF_MCS)
+            check(cmi_set_sim_params(h_, conf_.numF, std::max(1, trainMatrix.n_dims), trainMatrix.empty_conds.data(),
+                                     (int)trainMatrix.empty_conds.size()),
+                  h_, "cmi_set_sim_params");
         if (isCARS_) {
             check(cmi_set_ratings(h_, trainMatrix.n(), trainMatrix.u.data(), trainMatrix.j.data(), trainMatrix.ctx.data(),
                                   trainMatrix.r.data(), (int32_t)trainMatrix.ctx_ptr.size() - 1, trainMatrix.ctx_ptr.data(),
@@ -409,7 +436,23 @@ CARSKIT_MODEL(CAMF_C, CMI_MODEL_CAMF_C, true)       // src/carskit/alg/cars/adap
 CARSKIT_MODEL(CAMF_CI, CMI_MODEL_CAMF_CI, true)     // .../dev/CAMF_CI.java
 CARSKIT_MODEL(CAMF_CU, CMI_MODEL_CAMF_CU, true)     // .../dev/CAMF_CU.java
 CARSKIT_MODEL(CAMF_CUCI, CMI_MODEL_CAMF_CUCI, true) // .../dev/CAMF_CUCI.java
+CARSKIT_MODEL(SVDPlusPlus, CMI_MODEL_SVDPP, false)  // src/carskit/alg/baseline/cf/SVDPlusPlus.java (2-D train matrix)
 #undef CARSKIT_MODEL
+
+// The similarity-based CAMF models are top-N recommenders: their constructors set the static isRankingPred = true
+// (CAMF_ICS.java:31, CAMF_LCS.java:31, CAMF_MCS.java:37), so execute() evaluates with evalRankings() whatever item.ranking says.
+#define CARSKIT_SIM_MODEL(cls, id)                                                                                     \
+    class cls : public IterativeRecommender {                                                                          \
+      public:                                                                                                          \
+        cls(const RatingData &tr, const RatingData &te, int fold, const Conf &c, Logger log = nullptr)                 \
+            : IterativeRecommender(id, #cls, true, tr, te, fold, c, log) {                                             \
+            conf_.isRankingPred = true;                                                                                \
+        }                                                                                                              \
+    };
+CARSKIT_SIM_MODEL(CAMF_ICS, CMI_MODEL_CAMF_ICS) // src/carskit/alg/cars/adaptation/dependent/sim/CAMF_ICS.java
+CARSKIT_SIM_MODEL(CAMF_LCS, CMI_MODEL_CAMF_LCS) // .../sim/CAMF_LCS.java
+CARSKIT_SIM_MODEL(CAMF_MCS, CMI_MODEL_CAMF_MCS) // .../sim/CAMF_MCS.java
+#undef CARSKIT_SIM_MODEL
 
 // src/carskit/alg/cars/adaptation/dependent/FM.java: w0 = 0, w ~ U(0,1), V ~ N(0,0.1) (:65-70); numIters ALS sweeps, no
 // convergence check; evaluation through the generic evalRatings recipe on bounded predictions.
@@ -483,7 +526,7 @@ class FM : public IterativeRecommender {
     cmi_fm_handle fm_ = nullptr;
 };
 
-// the factory switch of CARSKit.getRecommender (src/carskit/main/CARSKit.java:461,700-707), lower-cased names
+// the factory switch of CARSKit.getRecommender (src/carskit/main/CARSKit.java:461-469,700-712,742), lower-cased names
 inline std::unique_ptr<IterativeRecommender> getRecommender(const std::string &name, const RatingData &tr, const RatingData &te,
                                                             int fold, const Conf &c, Logger log) {
     const std::string n = lower(name);
@@ -494,7 +537,11 @@ inline std::unique_ptr<IterativeRecommender> getRecommender(const std::string &n
     if (n == "camf_cu") return std::unique_ptr<IterativeRecommender>(new CAMF_CU(tr, te, fold, c, log));
     if (n == "camf_cuci") return std::unique_ptr<IterativeRecommender>(new CAMF_CUCI(tr, te, fold, c, log));
     if (n == "fm") return std::unique_ptr<IterativeRecommender>(new FM(tr, te, fold, c, log));
-    throw std::runtime_error("recommender '" + name + "' is not on the accelerated path (biasedmf, pmf, camf_c, camf_ci, camf_cu, camf_cuci, fm)");
+    if (n == "svd++") return std::unique_ptr<IterativeRecommender>(new SVDPlusPlus(tr, te, fold, c, log));   // CARSKit.java:469
+    if (n == "camf_ics") return std::unique_ptr<IterativeRecommender>(new CAMF_ICS(tr, te, fold, c, log));   // CARSKit.java:708
+    if (n == "camf_lcs") return std::unique_ptr<IterativeRecommender>(new CAMF_LCS(tr, te, fold, c, log));   // CARSKit.java:710
+    if (n == "camf_mcs") return std::unique_ptr<IterativeRecommender>(new CAMF_MCS(tr, te, fold, c, log));   // CARSKit.java:712
+    throw std::runtime_error("recommender '" + name + "' is not on the accelerated path (biasedmf, pmf, svd++, camf_c, camf_ci, camf_cu, camf_cuci, camf_ics, camf_lcs, camf_mcs, fm)");
 }
 
 } // namespace carskit

@@ -7,7 +7,8 @@
 
 namespace cmi {
 
-enum Model { BIASEDMF = 0, CAMF_C = 1, CAMF_CI = 2, CAMF_CU = 3, CAMF_CUCI = 4, PMF = 5 };
+enum Model { BIASEDMF = 0, CAMF_C = 1, CAMF_CI = 2, CAMF_CU = 3, CAMF_CUCI = 4, PMF = 5,
+             SVDPP = 6, CAMF_ICS = 7, CAMF_LCS = 8, CAMF_MCS = 9 }; // 6..9: ext_kernels.hip (serial only)
 
 // Device-resident hyper-parameters, rewritten before every epoch by set_hparams (so a captured
 // hipGraph of level launches can be replayed with a new learning rate).
@@ -121,6 +122,45 @@ hipError_t launch_eval(const EvalArgs<T> &a, int64_t n, hipStream_t s);
 // multi-GPU exchange passes (element type per f64): bucket = state - snap ; state = snap = snap + scale * bucket
 hipError_t launch_delta_pack(const void *state, const void *snap, void *bucket, int64_t n, bool f64, hipStream_t s);
 hipError_t launch_delta_apply(void *state, void *snap, const void *bucket, double scale, int64_t n, bool f64, hipStream_t s);
+
+// ---- SVD++ / CAMF_ICS / CAMF_LCS / CAMF_MCS (ext_kernels.hip): serial only ----
+template <typename T>
+struct ExtArgs {
+    T *P, *Q, *userBias, *itemBias;  // userBias / itemBias / Y: SVD++
+    T *Y;                            // [n_items x k]
+    T *cc;                           // CAMF_ICS: [n_conds x n_conds], kept symmetric
+    T *cf;                           // CAMF_LCS: [n_conds x num_f]
+    T *cv;                           // CAMF_MCS: [n_conds]
+    const int32_t *su, *sj;          // tuples in the reference's (CRS) order
+    const T *sr;
+    const int32_t *sconds;           // [n x dmax], -1 padded
+    const int32_t *empty_conds;      // EmptyContextConditions: the i-th condition of a context pairs with empty_conds[i]
+    const int32_t *ui_ptr, *ui_items; // SVD++: items of every user in the 2-D train matrix (userItemsCache), ascending
+    const HParams *hp;
+    double upbound, lowbound;        // CAMF_MCS.java:47-48
+    int32_t k, n_conds, dmax, num_f, n_empty;
+};
+template <typename T>
+hipError_t launch_ext_serial(const ExtArgs<T> &a, int model, bool strict, int64_t n, double *loss_out, hipStream_t s);
+
+template <typename T>
+struct ExtEvalArgs {
+    const T *P, *Q, *userBias, *itemBias, *Y, *cc, *cf, *cv;
+    const int32_t *u, *j, *ctx;
+    const double *r;
+    const int32_t *ctx_ptr, *ctx_conds, *empty_conds, *ui_ptr, *ui_items;
+    double *preds, *part;
+    double gm, lo, hi, min_rate;
+    int32_t k, n_conds, num_f, n_empty, bound, model;
+};
+template <typename T>
+hipError_t launch_ext_eval(const ExtEvalArgs<T> &a, int64_t n, hipStream_t s);
+// operands of the ranking evaluation for these models (see ext_kernels.hip)
+template <typename T>
+hipError_t launch_ext_rank_items(const ExtEvalArgs<T> &a, const int32_t *cand, int nc, T *B, int kp, hipStream_t s);
+template <typename T>
+hipError_t launch_ext_rank_queries(const ExtEvalArgs<T> &a, const int32_t *qu, const int32_t *qc, int nq, T *A, T *row_const, int kp,
+                                   hipStream_t s);
 
 // dtype conversion for cmi_set_state / cmi_get_state staging
 hipError_t launch_convert(const void *src, int src_f64, void *dst, int dst_f64, int64_t n, hipStream_t s);

@@ -382,6 +382,20 @@ static RankOperands<T> mf_operands(cmi_instance *h, int k_logical, bool contextu
     return ops;
 }
 
+// operand builders of SVD++ / CAMF_ICS / CAMF_LCS / CAMF_MCS: see ext_kernels.hip
+template <typename T>
+static RankOperands<T> ext_operands(cmi_instance *h, int k_logical) {
+    RankOperands<T> ops;
+    ops.k_logical = k_logical;
+    ops.build_items = [h](T *dB, const int32_t *dcand, int nc, int kp, hipStream_t s) {
+        return launch_ext_rank_items<T>(cmi_ext_eval_args<T>(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 1), dcand, nc, dB, kp, s);
+    };
+    ops.build_queries = [h](T *dA, T *drc, const int32_t *dqu, const int32_t *dqc, int n, int kp, hipStream_t s) {
+        return launch_ext_rank_queries<T>(cmi_ext_eval_args<T>(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 1), dqu, dqc, n, dA, drc, kp, s);
+    };
+    return ops;
+}
+
 extern "C" int cmi_last_rank_ms(cmi_handle h, float *ms, double *flops) {
     if (!h) return CMI_E_INVALID;
     if (ms) *ms = h->last_rank_ms;
@@ -469,8 +483,9 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
                  "eval_rankings: -topN must be >= 1 (with -topN <= 0 the reference's cut-off list holds a non-positive n: "
                  "carskit/eval/Measures.java:13-16 throws for n<0)");
     if (strategy != CMI_RANK_UCU && strategy != CMI_RANK_UC) CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: strategy must be CMI_RANK_UCU or CMI_RANK_UC");
-    const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF;
-    if (contextual && !h->have_ratings)
+    const bool ext = h->model >= CMI_MODEL_SVDPP && h->model <= CMI_MODEL_CAMF_MCS;
+    const bool contextual = h->model != CMI_MODEL_BIASEDMF && h->model != CMI_MODEL_PMF && h->model != CMI_MODEL_SVDPP;
+    if ((contextual || ext) && !h->have_ratings)
         CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: the context table comes from cmi_set_ratings; call it first");
     auto check = [&](int64_t n, const int32_t *u, const int32_t *j, const int32_t *c, const char *what) -> int {
         for (int64_t t = 0; t < n; ++t) {
@@ -493,9 +508,14 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
     std::vector<double> top_score;
     if (!plan.qu.empty() && !plan.cand.empty()) {
         const bool ic_used = h->state[CMI_STATE_IC_BIAS] != nullptr;
-        const int k_logical = h->k + 1 + (ic_used ? h->n_conds : 0); // [factors | 1 or itemBias | one-hot conditions or icBias row]
+        const int k_logical = ext ? h->k + (h->model == CMI_MODEL_SVDPP ? 1 : 0)
+                                  : h->k + 1 + (ic_used ? h->n_conds : 0); // [factors | 1 or itemBias | one-hot conditions or icBias row]
         hipError_t e;
-        if (h->f64) e = rank_run_device<double>(h->stream, h->ev0, h->ev1, plan, mf_operands<double>(h, k_logical, contextual, ic_used), bin_thold,
+        if (ext && h->f64) e = rank_run_device<double>(h->stream, h->ev0, h->ev1, plan, ext_operands<double>(h, k_logical), bin_thold, num_recs,
+                                                       top_idx, top_score, top_count, &h->last_rank_ms, &h->last_rank_flops);
+        else if (ext) e = rank_run_device<float>(h->stream, h->ev0, h->ev1, plan, ext_operands<float>(h, k_logical), bin_thold, num_recs, top_idx,
+                                                 top_score, top_count, &h->last_rank_ms, &h->last_rank_flops);
+        else if (h->f64) e = rank_run_device<double>(h->stream, h->ev0, h->ev1, plan, mf_operands<double>(h, k_logical, contextual, ic_used), bin_thold,
                                                 num_recs, top_idx, top_score, top_count, &h->last_rank_ms, &h->last_rank_flops);
         else e = rank_run_device<float>(h->stream, h->ev0, h->ev1, plan, mf_operands<float>(h, k_logical, contextual, ic_used), bin_thold,
                                         num_recs, top_idx, top_score, top_count, &h->last_rank_ms, &h->last_rank_flops);

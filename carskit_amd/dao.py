@@ -63,7 +63,8 @@ class DataDAO:
         """The matrix as the tuple arrays the recommenders take (u, j per entry through the ui maps)."""
         return RatingData(self.num_users, self.num_items, self.num_conditions, self.num_context_dims,
                           self.ui_user[self.ui], self.ui_item[self.ui], self.ctx.copy(), self.r.copy(), self.ctx_ptr,
-                          self.ctx_conds, self.rating_scale[0], self.rating_scale[-1], {"source": "DataDAO"})
+                          self.ctx_conds, self.rating_scale[0], self.rating_scale[-1], {"source": "DataDAO"},
+                          np.asarray(self.empty_context_conditions, dtype=np.int32))
 
     def close(self):
         if getattr(self, "h", None):

@@ -82,7 +82,7 @@ def run(config_path, engine_factory=None, log=print, conf_overrides=None):
         # as in the reference, where rateDao.numUsers() is read after the test DAO extended the shared maps
         test = test_dao.rating_data()
         train = synth.RatingData(test.n_users, test.n_items, data.n_conds, data.n_dims, data.u, data.j, data.ctx, data.r,
-                                 test.ctx_ptr, test.ctx_conds, data.min_rate, data.max_rate, dict(data.meta))
+                                 test.ctx_ptr, test.ctx_conds, data.min_rate, data.max_rate, dict(data.meta), data.empty_conds)
         test.min_rate, test.max_rate = data.min_rate, data.max_rate      # rating scale of the TRAINING dao (:198-200)
         algo = cls(train, test, -1, conf, engine_factory, log)
         algo.execute()
@@ -97,7 +97,7 @@ def run(config_path, engine_factory=None, log=print, conf_overrides=None):
     for a in algos:
         for m, v in a.measures.items():
             avg[m] = avg.get(m, 0.0) + v / len(algos)
-    info = "Final Results by %s, %s" % (algos[0].algo_name, get_eval_info(avg, conf))
+    info = "Final Results by %s, %s" % (algos[0].algo_name, get_eval_info(avg, algos[0].conf))   # (top-N models force ranking)
     log(info)
     return avg, algos, rate_dao
 

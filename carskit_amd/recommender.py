@@ -34,6 +34,7 @@ class Conf:
         self.reg = self.regU = self.regI = self.regB = self.regC = java_float("0.01")
         self.early_stop, self.verbose = None, True
         self.reg_lw = self.reg_lf = 0.0
+        self.num_f = 10     # `-f` of the recommender line (CAMF_LCS.java:37)
         self.init_mean, self.init_std = 0.0, 0.1
         self.init_seed = 1
         self.flags = 0
@@ -75,6 +76,9 @@ class Conf:
             if rs is not None:
                 self.bin_thold = rs.get_float("-threshold", -1.0)   # a Java float, promoted where it is compared
             self.eval_strategy = (cf.get_string("eval.strategy") or "ucu").lower()
+            rec = cf.get_param_options("recommender")
+            if rec is not None:
+                self.num_f = rec.get_int("-f", 10)
             fm = cf.get_param_options("FM")
             if fm is not None:
                 self.reg_lw, self.reg_lf = fm.get_float("-lw", 0.0), fm.get_float("-lf", 0.0)
@@ -87,11 +91,15 @@ class GpuEngine:
 
     def __init__(self, model, k, data, tuples, hp, flags=0, device=0):
         u, j, ctx, r = tuples
-        if model == "CAMF_C":
+        if model in ("CAMF_C", "SVD++", "CAMF_ICS", "CAMF_LCS", "CAMF_MCS"):   # one dependent chain in CRS order
             flags |= capi.FLAG_SCHED_SERIAL
         self.inst = capi.Instance(model, k, data.n_users, data.n_items, data.n_conds, device=device, flags=flags)
         self.inst.set_hparams(hp["regU"], hp["regI"], hp["regB"], hp["regC"], hp["gm"])
-        if model in ("BiasedMF", "PMF"):
+        if model in ("CAMF_ICS", "CAMF_LCS", "CAMF_MCS"):
+            if data.empty_conds is None:
+                raise ValueError("%s needs EmptyContextConditions (the ':na' condition of every dimension)" % model)
+            self.inst.set_sim_params(hp.get("numF", 10), max(1, data.n_dims), data.empty_conds)
+        if model in ("BiasedMF", "PMF", "SVD++"):
             self.inst.set_ratings(u, j, None, r)
         else:
             self.inst.set_ratings(u, j, ctx, r, data.ctx_ptr, data.ctx_conds)
@@ -211,11 +219,12 @@ class IterativeRecommender(Recommender):
         no two reference runs agree, so any seeded stream is as faithful as any other; callers that need parity
         assign self.state themselves before buildModel()."""
         if not self.state:
+            self.trainMatrix.meta["num_f"] = self.conf.num_f
             self.state = synth.init_state(self.algo_name, self.trainMatrix, self.numFactors, seed=self.conf.init_seed)
 
     def buildModel(self):
         hp = {"regU": self.conf.regU, "regI": self.conf.regI, "regB": self.conf.regB, "regC": self.conf.regC,
-              "gm": self.globalMean}
+              "gm": self.globalMean, "numF": self.conf.num_f}
         self.engine = self.engine_factory(self.algo_name, self.numFactors, self.trainMatrix, self.train_tuples(), hp,
                                           flags=self.conf.flags, device=self.device)
         self.engine.set_states(self.state)                          # copy-in
@@ -295,6 +304,34 @@ class CAMF_CUCI(ContextRecommender):    # .../dev/CAMF_CUCI.java
     algo_name = "CAMF_CUCI"
 
 
+class SVDPlusPlus(IterativeRecommender):   # src/carskit/alg/baseline/cf/SVDPlusPlus.java (2-D train matrix)
+    algo_name = "SVD++"
+    is_cars = False
+
+
+class _SimCAMF(ContextRecommender):
+    """The similarity-based CAMF recommenders are top-N models: their constructors set isRankingPred = true
+    (CAMF_ICS.java:31, CAMF_LCS.java:31, CAMF_MCS.java:37), so execute() evaluates with evalRankings()."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        import copy
+        self.conf = copy.copy(self.conf)
+        self.conf.is_ranking = True
+
+
+class CAMF_ICS(_SimCAMF):               # src/carskit/alg/cars/adaptation/dependent/sim/CAMF_ICS.java
+    algo_name = "CAMF_ICS"
+
+
+class CAMF_LCS(_SimCAMF):               # .../sim/CAMF_LCS.java
+    algo_name = "CAMF_LCS"
+
+
+class CAMF_MCS(_SimCAMF):               # .../sim/CAMF_MCS.java
+    algo_name = "CAMF_MCS"
+
+
 class FM(ContextRecommender):
     """src/carskit/alg/cars/adaptation/dependent/FM.java: w0 = 0, w ~ U(0,1), V ~ N(0, 0.1); numIters ALS sweeps,
     no convergence check."""
@@ -338,9 +375,9 @@ class FM(ContextRecommender):
                 "rMAE": float(rerr.sum() / n), "rRMSE": float(np.sqrt((rerr * rerr).sum() / n)), "MPE": 0.0, "n": n}
 
 
-# the reference's factory switch (src/carskit/main/CARSKit.java:461,700-707,742), lower-cased names
-RECOMMENDERS = {"biasedmf": BiasedMF, "pmf": PMF, "camf_c": CAMF_C, "camf_ci": CAMF_CI, "camf_cu": CAMF_CU,
-                "camf_cuci": CAMF_CUCI, "fm": FM}
+# the reference's factory switch (src/carskit/main/CARSKit.java:461-469,700-712,742), lower-cased names
+RECOMMENDERS = {"biasedmf": BiasedMF, "pmf": PMF, "svd++": SVDPlusPlus, "camf_c": CAMF_C, "camf_ci": CAMF_CI, "camf_cu": CAMF_CU,
+                "camf_cuci": CAMF_CUCI, "camf_ics": CAMF_ICS, "camf_lcs": CAMF_LCS, "camf_mcs": CAMF_MCS, "fm": FM}
 
 
 def get_eval_info(ms, conf=None):

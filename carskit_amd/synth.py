@@ -26,6 +26,7 @@ class RatingData:
     min_rate: float = 1.0
     max_rate: float = 5.0
     meta: dict = field(default_factory=dict)
+    empty_conds: object = None   # EmptyContextConditions (DataDAO.java:213-214): the ":na" condition of every dimension, header order
 
     @property
     def n(self):
@@ -40,7 +41,7 @@ class RatingData:
         idx = np.asarray(idx)
         return RatingData(self.n_users, self.n_items, self.n_conds, self.n_dims, self.u[idx], self.j[idx],
                           self.ctx[idx], self.r[idx], self.ctx_ptr, self.ctx_conds, self.min_rate, self.max_rate,
-                          dict(self.meta))
+                          dict(self.meta), self.empty_conds)
 
 
 def _first_seen_ids(keys):
@@ -263,6 +264,16 @@ def init_state(model, data, k, seed=DEFAULT_SEED + 2, dtype=np.float64):
         st["icBias"] = g(data.n_items, data.n_conds)
     elif model == "PMF":
         pass
+    elif model == "SVD++":                       # SVDPlusPlus.java:46-53: BiasedMF.initModel, then Y ~ N(0, 0.1)
+        st["userBias"], st["itemBias"] = g(data.n_users), g(data.n_items)
+        st["Y"] = g(data.n_items, k)
+    elif model == "CAMF_ICS":                    # CAMF_ICS.java:36-51: P, Q re-drawn uniform(0,1); all similarities start at 1
+        st["P"], st["Q"] = rng.random((data.n_users, k)).astype(dtype), rng.random((data.n_items, k)).astype(dtype)
+        st["ccMatrix"] = np.ones((data.n_conds, data.n_conds), dtype=dtype)
+    elif model == "CAMF_LCS":                    # CAMF_LCS.java:34-41: cfMatrix_LCS ~ uniform(0,1), numF columns
+        st["cfMatrix"] = rng.random((data.n_conds, int(data.meta.get("num_f", 10)))).astype(dtype)
+    elif model == "CAMF_MCS":                    # CAMF_MCS.java:41-52: positions ~ uniform(0, 1/sqrt(numContextDims))
+        st["cVector"] = (rng.random(data.n_conds) / np.sqrt(max(1, data.n_dims))).astype(dtype)
     else:
         raise ValueError(model)
     return st

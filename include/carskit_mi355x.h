@@ -46,6 +46,14 @@ extern "C" {
 #define CMI_MODEL_CAMF_CUCI 4 /* .../dev/CAMF_CUCI.java */
 #define CMI_MODEL_PMF 5       /* src/carskit/alg/baseline/cf/PMF.java:47-82: BiasedMF without biases and without
                                  globalMean (predict = rowMult, IterativeRecommender.java:126-128); 2-D train matrix */
+/* the remaining SGD recommenders of the same family (CARSKit.java:469,708-712).  Every rating updates parameters every other
+ * rating reads (Y rows of all the user's items; the condition-similarity scalars / vectors / positions), so their exact semantics
+ * are one dependent chain: CMI_FLAG_SCHED_SERIAL is required, as for CAMF_C.  cmi_set_sim_params must be called before
+ * cmi_set_ratings for the three CAMF_*CS models. */
+#define CMI_MODEL_SVDPP 6     /* src/carskit/alg/baseline/cf/SVDPlusPlus.java:46-146 (2-D train matrix, like BiasedMF) */
+#define CMI_MODEL_CAMF_ICS 7  /* src/carskit/alg/cars/adaptation/dependent/sim/CAMF_ICS.java:33-133 */
+#define CMI_MODEL_CAMF_LCS 8  /* .../sim/CAMF_LCS.java:34-147 */
+#define CMI_MODEL_CAMF_MCS 9  /* .../sim/CAMF_MCS.java:38-166 */
 
 /* state containers = the model fields a subclass must leave consistent
  * (IterativeRecommender.java:56-64, CAMF.java:40-42) */
@@ -56,7 +64,11 @@ extern "C" {
 #define CMI_STATE_COND_BIAS 4 /* DenseVector condBias numConditions         (CAMF_C) */
 #define CMI_STATE_UC_BIAS 5   /* DenseMatrix ucBias   numUsers x numConditions (CAMF_CU, CAMF_CUCI) */
 #define CMI_STATE_IC_BIAS 6   /* DenseMatrix icBias   numItems x numConditions (CAMF_CI, CAMF_CUCI) */
-#define CMI_STATE_COUNT 7
+#define CMI_STATE_Y 7         /* DenseMatrix Y            numItems x k                (SVD++, SVDPlusPlus.java:36) */
+#define CMI_STATE_CC_MATRIX 8 /* SymmMatrix ccMatrix_ICS  numConditions x numConditions, exchanged as the full symmetric matrix (CAMF.java:45) */
+#define CMI_STATE_CF_MATRIX 9 /* DenseMatrix cfMatrix_LCS numConditions x numF       (CAMF.java:46; numF from cmi_set_sim_params) */
+#define CMI_STATE_C_VECTOR 10 /* DenseVector cVector_MCS  numConditions               (CAMF.java:47) */
+#define CMI_STATE_COUNT 11
 
 /* host buffer element types for cmi_set_state / cmi_get_state */
 #define CMI_DTYPE_F32 0
@@ -124,6 +136,12 @@ int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j,
  * elements = rows*cols).  Converts between the host dtype and the device state dtype. */
 int cmi_set_state(cmi_handle h, int which, const void *src, int64_t count, int dtype);
 int cmi_get_state(cmi_handle h, int which, void *dst, int64_t count, int dtype);
+
+/* CAMF_ICS / CAMF_LCS / CAMF_MCS: EmptyContextConditions (ContextRecommender.java:43 = the ":na" conditions in header order,
+ * DataDAO.java:213-214; the i-th condition of a context is compared with empty_conds[i]), numF = `-f` of the CAMF_LCS option line
+ * (CAMF_LCS.java:37; allocates cfMatrix_LCS), and rateDao.numContextDims() (CAMF_MCS.java:47: upbound = 1/sqrt(dims)).  Ignored
+ * by the other models. */
+int cmi_set_sim_params(cmi_handle h, int num_f, int n_ctx_dims, const int32_t *empty_conds, int n_empty);
 
 /* regU/regI/regB/regC (IterativeRecommender.java:40,94-98: Java floats promoted to double) and
  * globalMean (Recommender.java:265) */

@@ -33,7 +33,12 @@ enum {
     ORC_CAMF_CI = 2,  /* .../dev/CAMF_CI.java */
     ORC_CAMF_CU = 3,  /* .../dev/CAMF_CU.java */
     ORC_CAMF_CUCI = 4, /* .../dev/CAMF_CUCI.java */
-    ORC_PMF = 5        /* src/carskit/alg/baseline/cf/PMF.java */
+    ORC_PMF = 5,       /* src/carskit/alg/baseline/cf/PMF.java */
+    /* carskit_oracle_sim.c */
+    ORC_SVDPP = 6,     /* src/carskit/alg/baseline/cf/SVDPlusPlus.java */
+    ORC_CAMF_ICS = 7,  /* src/carskit/alg/cars/adaptation/dependent/sim/CAMF_ICS.java */
+    ORC_CAMF_LCS = 8,  /* .../sim/CAMF_LCS.java */
+    ORC_CAMF_MCS = 9   /* .../sim/CAMF_MCS.java */
 };
 
 /* Flat view of one recommender instance's state and training tuples.
@@ -115,6 +120,28 @@ double orc_jrandom_next_gaussian(orc_jrandom *g);
 /* librec DenseMatrix.init(mean,sigma) / init() restated over a flat array */
 void orc_init_gaussian(orc_jrandom *g, double *a, int64_t n, double mean, double sigma);
 void orc_init_uniform(orc_jrandom *g, double *a, int64_t n, double range);
+
+/* ---- SVD++ and the similarity-based CAMF family, see carskit_oracle_sim.c ------------------------
+ * SVD++ iterates the 2-D train matrix (u, j, r; ctx unused) and needs userItemsCache = the items of every user in that matrix
+ * as CSR (ui_ptr / ui_items, items ascending = librec rowColumnsCache).  The CAMF_*CS models iterate the contextual matrix and
+ * pair the i-th condition of a context with empty_conds[i] (EmptyContextConditions, the ":na" conditions in header order). */
+typedef struct {
+    int32_t model, k, n_users, n_items, n_conds, numF;
+    int64_t n;
+    const int32_t *u, *j, *ctx;
+    const double *r;
+    const int32_t *ctx_ptr, *ctx_conds, *empty_conds;
+    const int32_t *ui_ptr, *ui_items;  /* SVD++ */
+    double *P, *Q;                     /* n_users x k, n_items x k */
+    double *userBias, *itemBias, *Y;   /* SVD++: Y is n_items x k */
+    double *ccMatrix;                  /* CAMF_ICS: n_conds x n_conds, kept symmetric (librec SymmMatrix) */
+    double *cfMatrix;                  /* CAMF_LCS: n_conds x numF */
+    double *cVector;                   /* CAMF_MCS: n_conds */
+    double globalMean, regU, regI, regB, regC;
+    double upbound, lowbound;          /* CAMF_MCS.java:47-48: 1/sqrt(numContextDims), 1e-100 */
+} orc_sim_problem;
+double orc_sim_predict(const orc_sim_problem *p, int32_t u, int32_t j, int32_t ctx);
+double orc_sim_epoch(const orc_sim_problem *p, double lRate); /* one pass of buildModel()'s loop, loss already scaled */
 
 /* ---- FM (src/carskit/alg/cars/adaptation/dependent/FM.java), see carskit_oracle_fm.c ---------------- */
 typedef struct {

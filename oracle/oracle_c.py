@@ -45,13 +45,27 @@ class OrcFM(C.Structure):
     ]
 
 
+class OrcSim(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("k", C.c_int32), ("n_users", C.c_int32), ("n_items", C.c_int32), ("n_conds", C.c_int32),
+        ("numF", C.c_int32), ("n", C.c_int64),
+        ("u", C.c_void_p), ("j", C.c_void_p), ("ctx", C.c_void_p), ("r", C.c_void_p),
+        ("ctx_ptr", C.c_void_p), ("ctx_conds", C.c_void_p), ("empty_conds", C.c_void_p),
+        ("ui_ptr", C.c_void_p), ("ui_items", C.c_void_p),
+        ("P", C.c_void_p), ("Q", C.c_void_p), ("userBias", C.c_void_p), ("itemBias", C.c_void_p), ("Y", C.c_void_p),
+        ("ccMatrix", C.c_void_p), ("cfMatrix", C.c_void_p), ("cVector", C.c_void_p),
+        ("globalMean", C.c_double), ("regU", C.c_double), ("regI", C.c_double), ("regB", C.c_double), ("regC", C.c_double),
+        ("upbound", C.c_double), ("lowbound", C.c_double),
+    ]
+
+
 class OrcJRandom(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("nextNextGaussian", C.c_double), ("haveNextNextGaussian", C.c_int32)]
 
 
 def build(force=False):
     so = os.path.join(_HERE, "libcarskit_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("carskit_oracle.c", "carskit_oracle_fm.c", "carskit_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("carskit_oracle.c", "carskit_oracle_fm.c", "carskit_oracle_sim.c", "carskit_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
@@ -85,6 +99,10 @@ def lib():
         L.orc_jrandom_next_gaussian.argtypes = [C.POINTER(OrcJRandom)]
         L.orc_init_gaussian.argtypes = [C.POINTER(OrcJRandom), C.c_void_p, C.c_int64, C.c_double, C.c_double]
         L.orc_init_uniform.argtypes = [C.POINTER(OrcJRandom), C.c_void_p, C.c_int64, C.c_double]
+        L.orc_sim_predict.restype = C.c_double
+        L.orc_sim_predict.argtypes = [C.POINTER(OrcSim), C.c_int32, C.c_int32, C.c_int32]
+        L.orc_sim_epoch.restype = C.c_double
+        L.orc_sim_epoch.argtypes = [C.POINTER(OrcSim), C.c_double]
         L.orc_fm_predict.restype = C.c_double
         L.orc_fm_predict.argtypes = [C.POINTER(OrcFM), C.c_int32, C.c_int32, C.c_int32]
         L.orc_fm_init.argtypes = [C.POINTER(OrcFM)]
@@ -220,3 +238,43 @@ class FMOracle:
 
     def predict(self, u, j, c):
         return self.L.orc_fm_predict(C.byref(self.m), u, j, c)
+
+
+SIM_MODEL_IDS = {"SVD++": 6, "CAMF_ICS": 7, "CAMF_LCS": 8, "CAMF_MCS": 9}
+SIM_STATE_NAMES = ("P", "Q", "userBias", "itemBias", "Y", "ccMatrix", "cfMatrix", "cVector")
+
+
+def user_items_csr(u, j, n_users):
+    """librec SparseMatrix.rowColumnsCache of the 2-D train matrix: the items of every user, ascending (SVDPlusPlus.java:52)."""
+    u = np.asarray(u, dtype=np.int64)
+    order = np.lexsort((np.asarray(j), u))
+    ptr = np.zeros(n_users + 1, dtype=np.int32)
+    np.add.at(ptr, u + 1, 1)
+    return np.cumsum(ptr).astype(np.int32), np.asarray(j, dtype=np.int32)[order]
+
+
+class SimOracle:
+    """SVD++ / CAMF_ICS / CAMF_LCS / CAMF_MCS over flat numpy arrays (state updated in place)."""
+
+    def __init__(self, model, k, n_users, n_items, n_conds, u, j, ctx, r, ctx_ptr, ctx_conds, empty_conds, state, global_mean,
+                 regU, regI, regB, regC, n_ctx_dims=1):
+        self.L = lib()
+        c32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        self.u, self.j, self.ctx = c32(u), c32(j), c32(ctx)
+        self.r = np.ascontiguousarray(r, dtype=np.float64)
+        self.ctx_ptr, self.ctx_conds, self.empty = c32(ctx_ptr), c32(ctx_conds), c32(empty_conds)
+        self.state = {nm: (None if state.get(nm) is None else np.ascontiguousarray(state[nm], dtype=np.float64)) for nm in SIM_STATE_NAMES}
+        self.ui_ptr = self.ui_items = None
+        if model == "SVD++":
+            self.ui_ptr, self.ui_items = user_items_csr(self.u, self.j, n_users)
+        numF = self.state["cfMatrix"].shape[1] if self.state["cfMatrix"] is not None else 0
+        self.p = OrcSim(SIM_MODEL_IDS[model], k, n_users, n_items, n_conds, numF, len(self.r), _p(self.u), _p(self.j), _p(self.ctx),
+                        _p(self.r), _p(self.ctx_ptr), _p(self.ctx_conds), _p(self.empty), _p(self.ui_ptr), _p(self.ui_items),
+                        *[_p(self.state[nm]) for nm in SIM_STATE_NAMES], global_mean, regU, regI, regB, regC,
+                        1.0 / np.sqrt(n_ctx_dims), 1.0 / (10.0 ** 100))
+
+    def epoch(self, lrate):
+        return self.L.orc_sim_epoch(C.byref(self.p), lrate)
+
+    def predict(self, u, j, ctx=-1):
+        return self.L.orc_sim_predict(C.byref(self.p), u, j, ctx)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# usage (on the GPU box, via gpurun): tools/gpu_profile_round.sh <round tag, e.g. r02> <workload> [kernel substring]
+# One bench line, a rocprofv3 kernel-trace summary and two separate PMC passes (FETCH_SIZE, WRITE_SIZE) of the SAME bench.py
+# command; results land in gpurun_out/prof_<tag>_<workload>/ and the summaries the judge reads are copied to profiles/ by hand.
+tag=$1; wl=$2; kern=${3:-sgd_chain_level}
+export TMPDIR=/tmp
+out=$PWD/gpurun_out/prof_${tag}_${wl}
+mkdir -p $out
+args=(--workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-f64 --no-calibration)
+python bench.py "${args[@]}" > $out/bench.json 2> $out/bench.err
+timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python bench.py "${args[@]}" > $out/stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 1200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o pmc -- python bench.py "${args[@]}" > $out/$c.log 2>&1
+done
+timeout 1200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $out/SQ -o pmc -- python bench.py "${args[@]}" > $out/SQ.log 2>&1
+python tools/pmc_summary.py $out/FETCH_SIZE/pmc_counter_collection.csv $out/WRITE_SIZE/pmc_counter_collection.csv $kern $out/bench.json $out/pmc.json > $out/pmc_summary.log 2>&1
+# keep only the per-kernel stats csv (the traces are large)
+find $out -name "*kernel_trace.csv" -size +20M -delete
+ls -la $out $out/stats | head -40
