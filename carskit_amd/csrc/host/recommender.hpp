@@ -424,11 +424,12 @@ class IterativeRecommender {
     cmi_handle h_ = nullptr;
 };
 
-#define CARSKIT_MODEL(cls, id, cars)                                                                                  \
+#define CARSKIT_MODEL(cls, id, cars) CARSKIT_NAMED_MODEL(cls, #cls, id, cars)
+#define CARSKIT_NAMED_MODEL(cls, name, id, cars)                                                                      \
     class cls : public IterativeRecommender {                                                                          \
       public:                                                                                                          \
         cls(const RatingData &tr, const RatingData &te, int fold, const Conf &c, Logger log = nullptr)                 \
-            : IterativeRecommender(id, #cls, cars, tr, te, fold, c, log) {}                                            \
+            : IterativeRecommender(id, name, cars, tr, te, fold, c, log) {}                                            \
     };
 CARSKIT_MODEL(BiasedMF, CMI_MODEL_BIASEDMF, false)  // src/carskit/alg/baseline/cf/BiasedMF.java
 CARSKIT_MODEL(PMF, CMI_MODEL_PMF, false)            // src/carskit/alg/baseline/cf/PMF.java
@@ -436,8 +437,9 @@ CARSKIT_MODEL(CAMF_C, CMI_MODEL_CAMF_C, true)       // src/carskit/alg/cars/adap
 CARSKIT_MODEL(CAMF_CI, CMI_MODEL_CAMF_CI, true)     // .../dev/CAMF_CI.java
 CARSKIT_MODEL(CAMF_CU, CMI_MODEL_CAMF_CU, true)     // .../dev/CAMF_CU.java
 CARSKIT_MODEL(CAMF_CUCI, CMI_MODEL_CAMF_CUCI, true) // .../dev/CAMF_CUCI.java
-CARSKIT_MODEL(SVDPlusPlus, CMI_MODEL_SVDPP, false)  // src/carskit/alg/baseline/cf/SVDPlusPlus.java (2-D train matrix)
+CARSKIT_NAMED_MODEL(SVDPlusPlus, "SVD++", CMI_MODEL_SVDPP, false) // src/carskit/alg/baseline/cf/SVDPlusPlus.java:42 (algoName = "SVD++"; 2-D train matrix)
 #undef CARSKIT_MODEL
+#undef CARSKIT_NAMED_MODEL
 
 // The similarity-based CAMF models are top-N recommenders: their constructors set the static isRankingPred = true
 // (CAMF_ICS.java:31, CAMF_LCS.java:31, CAMF_MCS.java:37), so execute() evaluates with evalRankings() whatever item.ranking says.

@@ -211,3 +211,42 @@ def test_cpp_host_driver_parallel_folds_and_fm(tmp_path):
         maes.append(err.mean())
         rmses.append(np.sqrt((err * err).mean()))
     assert abs(float(m.group(1)) - np.mean(maes)) <= 1e-9 and abs(float(m.group(2)) - np.mean(rmses)) <= 1e-9
+
+
+@pytest.mark.parametrize("algo,name", [("svd++", "SVD++"), ("camf_ics", "CAMF_ICS"), ("camf_lcs -f 6", "CAMF_LCS"), ("camf_mcs", "CAMF_MCS")])
+def test_n1_recommenders_through_both_hosts_strict_bit_exact(tmp_path, algo, name):
+    """SURVEY 8(f) N1 done-criterion: `recommender=svd++|camf_ics|camf_lcs|camf_mcs` through the Python host and the C++ host,
+    fp64 + strict: per-fold losses bit-identical to the oracle-driven run and the evaluation measures equal to 1e-12 (DePaulMovie,
+    5-fold CV, ':na' conditions from the compact->binary transformer as EmptyContextConditions)."""
+    import re
+    import subprocess
+    from tests.test_host_layer import EXE, _depaul_conf
+    conf = _depaul_conf(tmp_path)
+    txt = open(conf).read().replace("recommender=biasedmf", "recommender=" + algo).replace("learn.rate=2e-2", "learn.rate=2e-3")
+    open(conf, "w").write(txt)
+    flags = capi.FLAG_STATE_F64 | capi.FLAG_STRICT | capi.FLAG_SCHED_SERIAL
+    _, ref, _ = main.run(conf, engine_factory=util.OracleEngine, log=lambda *a: None, conf_overrides={"num_iters": 6})
+    _, gpu, _ = main.run(conf, log=lambda *a: None, conf_overrides={"num_iters": 6, "flags": flags})
+    keys = ("MAE", "RMSE") if name == "SVD++" else ("Pre10", "Rec10", "AUC10", "MAP10", "NDCG10", "MRR10")
+    for a, b in zip(gpu, ref):
+        assert a.losses == b.losses and a.lrates == b.lrates                    # bit-identical epochs
+        for n_, arr in a.state.items():
+            assert np.array_equal(arr, b.state[n_].reshape(arr.shape)), n_
+        for m in keys:
+            assert abs(a.measures[m] - b.measures[m]) <= 1e-12, m
+    # the C++ host (its own java.util.Random init stream, reproduced by expected_from_oracle): the oracle's numbers, to 1e-12
+    from tests.test_host_layer import expected_from_oracle
+    p64 = subprocess.run([EXE, "-c", conf, "--iters", "6", "--flags", str(flags), "--precise"], capture_output=True, text=True)
+    assert p64.returncode == 0, p64.stderr
+    want = expected_from_oracle(conf, algo.split()[0], 6)
+    if name == "SVD++":
+        m64 = re.search(r"PRECISE SVD\+\+ folds=5 MAE=(\S+) RMSE=(\S+)", p64.stdout)
+        assert m64, p64.stdout[-400:] + p64.stderr
+        assert abs(float(m64.group(1)) - want["MAE"]) <= 1e-12 and abs(float(m64.group(2)) - want["RMSE"]) <= 1e-12
+        assert "Final Results by SVD++, MAE: " in p64.stdout
+    else:
+        m64 = re.search(r"PRECISE %s folds=5 Pre10=(\S+) Rec10=(\S+) AUC10=(\S+) MAP10=(\S+) NDCG10=(\S+) MRR10=(\S+)" % name, p64.stdout)
+        assert m64, p64.stdout[-400:] + p64.stderr
+        for g_, key in zip(m64.groups(), ("Pre10", "Rec10", "AUC10", "MAP10", "NDCG10", "MRR10")):
+            assert abs(float(g_) - want[key]) <= 1e-12, (key, g_, want[key])
+        assert ("Final Results by %s, Pre5: " % name) in p64.stdout

@@ -38,7 +38,8 @@ def _state(model, d, k, seed=7):
         st["P"] *= 0.3
         st["cfMatrix"] = rng.random((d.n_conds, NUM_F))
     else:
-        st["cVector"] = rng.random(d.n_conds) / np.sqrt(d.n_dims)
+        st["P"] *= 0.02      # keeps e * dot small, so the positions stay inside (0, upbound) instead of being parked on a bound
+        st["cVector"] = (0.2 + 0.6 * rng.random(d.n_conds)) / np.sqrt(d.n_dims)
     return st
 
 
@@ -84,6 +85,9 @@ def test_wave_f64_and_f32(model):
     train, test = synth.split(d, 0.2)
     for flags, tol_state, tol_pred in ((F64, 1e-11, 1e-10), (0, 2e-4, 2e-4)):
         orc, inst = make(model, train, empty, 64, flags)
+        # (CAMF_MCS's update has a sign discontinuity -- diff / dist with positions that the clipping rule parks on the same
+        #  bound -- so once positions saturate, a different ROUNDING of the dot product is a different trajectory and only the
+        #  strict kernel can follow the oracle; _state() keeps this problem in the smooth regime)
         for _ in range(5):
             lo, lg = orc.epoch(LR), inst.train_epoch(LR)
             assert abs(lo - lg) <= (1e-12 if flags else 2e-5) * abs(lo)

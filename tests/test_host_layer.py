@@ -218,6 +218,16 @@ def _cpp_init(model, train, k, seed):
         st["itemBias"], st["ucBias"] = g.gaussian(train.n_items), g.uniform((train.n_users, train.n_conds))
     elif model == "CAMF_CUCI":
         st["ucBias"], st["icBias"] = g.gaussian((train.n_users, train.n_conds)), g.gaussian((train.n_items, train.n_conds))
+    elif model == "SVD++":
+        st["userBias"], st["itemBias"] = g.gaussian(train.n_users), g.gaussian(train.n_items)
+        st["Y"] = g.gaussian((train.n_items, k))
+    elif model == "CAMF_ICS":     # P, Q re-drawn uniform on top of the gaussian draws (CAMF_ICS.java:36-51)
+        st["P"], st["Q"] = g.uniform((train.n_users, k)), g.uniform((train.n_items, k))
+        st["ccMatrix"] = np.ones((train.n_conds, train.n_conds))
+    elif model == "CAMF_LCS":
+        st["cfMatrix"] = g.uniform((train.n_conds, int(train.meta.get("num_f", 10))))
+    elif model == "CAMF_MCS":
+        st["cVector"] = g.uniform(train.n_conds) * (1.0 / np.sqrt(max(1, train.n_dims)))
     return st
 
 
@@ -226,6 +236,7 @@ def expected_from_oracle(conf_path, model_cls_name, iters):
     splitter, itself checked against the recipe), the C++ init stream, the oracle as the engine."""
     class Cls(recommender.RECOMMENDERS[model_cls_name]):
         def initModel(self):
+            self.trainMatrix.meta["num_f"] = self.conf.num_f
             self.state = _cpp_init(self.algo_name, self.trainMatrix, self.numFactors, self.conf.init_seed)
     saved = recommender.RECOMMENDERS[model_cls_name]
     recommender.RECOMMENDERS[model_cls_name] = Cls
@@ -248,3 +259,41 @@ def test_cpp_host_driver_loads_data_then_fails_loudly_without_gpu(tmp_path):
     assert p.returncode == 1 and "no HIP device" in p.stderr and "no CPU fallback" in p.stderr
     q = subprocess.run([EXE, "-c", str(tmp_path / "missing.conf")], capture_output=True, text=True)
     assert q.returncode == 1 and "cannot open configuration file" in q.stderr
+
+
+@pytest.mark.parametrize("algo,name", [("svd++", "SVD++"), ("camf_ics", "CAMF_ICS"), ("camf_lcs -f 6", "CAMF_LCS"), ("camf_mcs", "CAMF_MCS")])
+def test_n1_recommenders_via_setting_conf(tmp_path, algo, name):
+    """`recommender=svd++|camf_ics|camf_lcs|camf_mcs` resolve (CARSKit.java:469,708-712), the transformer's ':na'
+    conditions reach the models as EmptyContextConditions, the three similarity models evaluate as top-N recommenders whatever
+    item.ranking says, and every fold equals a direct oracle run (plumbing; the oracle is the engine here, no GPU)."""
+    conf = _depaul_conf(tmp_path)
+    txt = open(conf).read().replace("recommender=biasedmf", "recommender=" + algo).replace("learn.rate=2e-2", "learn.rate=2e-3")
+    open(conf, "w").write(txt)
+    lines = []
+    avg, algos, rate_dao = main.run(conf, engine_factory=util.OracleEngine, log=lines.append, conf_overrides={"num_iters": 6})
+    assert len(algos) == 5 and all(a.algo_name == name for a in algos)
+    assert rate_dao.empty_context_conditions and len(rate_dao.empty_context_conditions) == rate_dao.num_context_dims
+    a = algos[1]
+    assert all(np.isfinite(a.losses)) and a.losses[-1] < a.losses[0]
+    if name == "SVD++":
+        assert lines[-1].startswith("Final Results by SVD++, MAE: ") and 0.5 < avg["RMSE"] < 2.0
+    else:
+        assert a.conf.is_ranking and lines[-1].startswith("Final Results by %s, Pre5: " % name) and 0.4 < avg["AUC10"] <= 1.0
+        assert a.conf.num_f == (6 if name == "CAMF_LCS" else 10)
+        if name == "CAMF_LCS":
+            assert a.state["cfMatrix"].shape == (rate_dao.num_conditions, 6)
+    # the fold is exactly a direct oracle run on the same split and init
+    from oracle import oracle_c
+    a.trainMatrix.meta["num_f"] = a.conf.num_f
+    st = synth.init_state(name, a.trainMatrix, 10, seed=a.conf.init_seed)
+    u, j, ctx, r = a.train_tuples()
+    orc = oracle_c.SimOracle(name, 10, a.numUsers, a.numItems, a.numConditions, u, j, ctx, r, a.trainMatrix.ctx_ptr, a.trainMatrix.ctx_conds,
+                             a.trainMatrix.empty_conds, st, a.globalMean, a.conf.regU, a.conf.regI, a.conf.regB, a.conf.regC,
+                             n_ctx_dims=a.trainMatrix.n_dims)
+    lr, last, losses = a.conf.init_lrate, 0.0, []
+    for it in range(1, 7):
+        losses.append(orc.epoch(lr))
+        if it > 1:
+            lr = lr * 1.05 if abs(last) > abs(losses[-1]) else lr * 0.5
+        last = losses[-1]
+    assert a.losses == losses

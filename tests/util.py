@@ -64,6 +64,11 @@ class OracleEngine:
         u, j, ctx, r = self.tuples
         st = {n: np.array(a, dtype=np.float64, copy=True) for n, a in st.items()}
         d = self.data
+        if self.model in self.oracle_c.SIM_MODEL_IDS:   # SVD++ / CAMF_ICS / CAMF_LCS / CAMF_MCS: carskit_oracle_sim.c
+            self.orc = self.oracle_c.SimOracle(self.model, self.k, d.n_users, d.n_items, d.n_conds, u, j, ctx, r, d.ctx_ptr, d.ctx_conds,
+                                               d.empty_conds, st, self.hp["gm"], self.hp["regU"], self.hp["regI"], self.hp["regB"],
+                                               self.hp["regC"], n_ctx_dims=max(1, d.n_dims))
+            return
         self.orc = self.oracle_c.Oracle(self.model, self.k, d.n_users, d.n_items, d.n_conds, u, j,
                                         ctx if ctx is not None else np.zeros(len(r), np.int32), r, d.ctx_ptr,
                                         d.ctx_conds, st, self.hp["gm"], self.hp["regU"], self.hp["regI"],
@@ -76,6 +81,15 @@ class OracleEngine:
         return self.orc.epoch(lr)
 
     def eval_ratings(self, u, j, ctx, r, lo, hi):
+        if self.model in self.oracle_c.SIM_MODEL_IDS:    # Recommender.evalRatings (Recommender.java:504-594) over predict()
+            pred = np.array([min(max(self.orc.predict(int(a), int(b), -1 if ctx is None else int(c)), lo), hi)
+                             for a, b, c in zip(u, j, ctx if ctx is not None else u)])
+            err = np.abs(np.asarray(r) - pred)
+            rerr = np.abs(np.asarray(r) - np.floor(pred / lo + 0.5) * lo)
+            n = len(err)
+            mae = float(err.sum() / n)
+            return {"MAE": mae, "RMSE": float(np.sqrt((err * err).sum() / n)), "NMAE": mae / (hi - lo), "rMAE": float(rerr.sum() / n),
+                    "rRMSE": float(np.sqrt((rerr * rerr).sum() / n)), "n": n}
         return self.orc.eval_ratings(u, j, ctx, r, lo, hi)
 
     def eval_rankings(self, train, test, bin_thold, num_recs, num_ignore, strategy):
