@@ -178,14 +178,136 @@ __host__ __device__ inline size_t chain_group_lds(int n_conds_hub, int dmax, siz
     return (b + 15) & ~(size_t)15;
 }
 
+// Everything a group needs to know about its unit before it touches the model: bounds and ids (none of it depends on the
+// updates of earlier levels, so a multi-level walk loads it one level ahead).
+template <typename T>
+struct ChainPre {
+    int32_t tb, len;
+    int hub, sp0, cd0, my_sp;
+    T my_rr;
+    int cdv[4];
+};
+
+// round trip 2 of a unit: every id load is issued before the first one is used
+template <typename T, bool HAS_CTX, bool HUB_ITEM>
+__device__ __forceinline__ ChainPre<T> chain_prefetch_ids(const SgdArgs<T> &a, int32_t tb, int32_t te, int l16, int dmax) {
+    ChainPre<T> p;
+    p.tb = tb;
+    p.len = te - tb; // 1 .. 16
+    p.hub = HUB_ITEM ? a.sj[tb] : a.su[tb];
+    p.sp0 = HUB_ITEM ? a.su[tb] : a.sj[tb];
+    p.cd0 = (HAS_CTX && l16 < dmax) ? a.sconds[(int64_t)tb * dmax + l16] : -1;
+    p.my_sp = 0;
+    p.my_rr = (T)0;
+    if (l16 < p.len) {
+        p.my_sp = HUB_ITEM ? a.su[tb + l16] : a.sj[tb + l16];
+        p.my_rr = a.sr[tb + l16];
+    }
+    const int n_cd = p.len * dmax; // <= 256 condition ids, staged 16 per pass
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        p.cdv[r] = -1;
+        if (l16 + 16 * r < n_cd) p.cdv[r] = a.sconds[(int64_t)tb * dmax + l16 + 16 * r];
+    }
+    return p;
+}
+
+// One unit: round trip 3 (hub row + first spoke row), the chain, the write-back of the hub side.  gbase = this group's LDS.
+template <typename T, int MODEL, int NV, bool RAGGED, bool HUB_ITEM>
+__device__ __forceinline__ void chain_unit(const SgdArgs<T> &a, const ChainHp<T> &hp, const ChainPre<T> &pre, unsigned char *gbase, int l16,
+                                           int K, int dmax, double &gloss) {
+    using M = Traits<MODEL>;
+    using V = typename Vec16<T>::type;
+    constexpr int E = Vec16<T>::E;
+    constexpr bool HB = HUB_ITEM ? M::has_bj : M::has_bu;
+    constexpr bool HC = HUB_ITEM ? M::has_ic : M::has_uc;
+    const int len = pre.len;
+    const int32_t tb = pre.tb;
+    T *s_hc = reinterpret_cast<T *>(gbase);
+    T *s_rr = s_hc + (HC ? a.n_conds : 0);
+    int *s_sp = reinterpret_cast<int *>(s_rr + 16);
+    int *s_cd = s_sp + 16;
+    const int n_cd = len * dmax;
+
+    // ---- round trip 3: the hub row comes on chip once, together with the first spoke row
+    T *htab = HUB_ITEM ? a.Q : a.P;
+    V *hrow = reinterpret_cast<V *>(htab + (size_t)pre.hub * K) + l16;
+    T h[NV][E];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+        for (int c = 0; c < E; ++c) h[v][c] = (T)0;
+        if (!RAGGED || E * l16 + 16 * E * v < K) {
+            const V t = hrow[v * 16];
+            unpack(t, h[v]);
+        }
+    }
+    T hb = (T)0;
+    T *phb = nullptr;
+    if (HB) {
+        phb = (HUB_ITEM ? a.itemBias : a.userBias) + pre.hub;
+        hb = *phb;
+    }
+    T *hc_row = nullptr;
+    T hcv4[4];
+    if (HC) {
+        hc_row = (HUB_ITEM ? a.icBias : a.ucBias) + (size_t)pre.hub * a.n_conds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            hcv4[r] = (T)0;
+            if (l16 + 16 * r < a.n_conds) hcv4[r] = hc_row[l16 + 16 * r];
+        }
+    }
+    SpokeRow<T, NV> A, B;
+    chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, pre.sp0, pre.cd0, l16, K, A);
+
+    // ---- ids and the hub's context-bias row into LDS
+    if (l16 < len) {
+        s_sp[l16] = pre.my_sp;
+        s_rr[l16] = pre.my_rr;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (l16 + 16 * r < n_cd) s_cd[l16 + 16 * r] = pre.cdv[r];
+    for (int c = l16 + 64; c < n_cd; c += 16) s_cd[c] = a.sconds[(int64_t)tb * dmax + c]; // dmax > 4 with long units
+    if (HC) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (l16 + 16 * r < a.n_conds) s_hc[l16 + 16 * r] = hcv4[r];
+        for (int c = l16 + 64; c < a.n_conds; c += 16) s_hc[c] = hc_row[c]; // more than 64 conditions
+    }
+    chain_lds_order();
+
+    // ---- the chain: spoke rows ping-pong between two register sets, the next one in flight while this one is used
+    int i = 0;
+    while (true) {
+        if (i + 1 < len)
+            chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, B);
+        chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, A, s_rr[i], l16, K, gloss);
+        if (++i >= len) break;
+        if (i + 1 < len)
+            chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, A);
+        chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, B, s_rr[i], l16, K, gloss);
+        if (++i >= len) break;
+    }
+
+    // ---- the hub row leaves the chip once
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        if (!RAGGED || E * l16 + 16 * E * v < K) hrow[v * 16] = pack(h[v]);
+    if (HB && l16 == 0) *phb = hb;
+    if (HC) {
+        chain_lds_order();
+        for (int c = l16; c < a.n_conds; c += 16) hc_row[c] = s_hc[c];
+    }
+}
+
 template <typename T, int MODEL, int NV, bool RAGGED, bool HUB_ITEM>
 __global__ __launch_bounds__(256) void sgd_chain_level(SgdArgs<T> a, const int32_t *__restrict__ unit_off, int64_t ubegin, int count,
                                                        int64_t slot0) {
     using M = Traits<MODEL>;
-    using V = typename Vec16<T>::type;
     constexpr int E = Vec16<T>::E;
     static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
-    constexpr bool HB = HUB_ITEM ? M::has_bj : M::has_bu;
     constexpr bool HC = HUB_ITEM ? M::has_ic : M::has_uc;
     extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
     __shared__ double s_loss[16];
@@ -198,103 +320,10 @@ __global__ __launch_bounds__(256) void sgd_chain_level(SgdArgs<T> a, const int32
     const ChainHp<T> hp{(T)hpd.lr, (T)hpd.regU, (T)hpd.regI, (T)hpd.regB, (T)hpd.regC, (T)hpd.gm};
 
     if (g < count) { // group-uniform
-        const int32_t tb = unit_off[ubegin + g], te = unit_off[ubegin + g + 1];
-        const int len = te - tb; // 1 .. 16
-        unsigned char *gbase = chain_smem + (size_t)gib * chain_group_lds(HC ? a.n_conds : 0, dmax, sizeof(T));
-        T *s_hc = reinterpret_cast<T *>(gbase);
-        T *s_rr = s_hc + (HC ? a.n_conds : 0);
-        int *s_sp = reinterpret_cast<int *>(s_rr + 16);
-        int *s_cd = s_sp + 16;
-
-        // ---- round trip 2: every id load of the unit is issued before the first one is used
-        const int hub = HUB_ITEM ? a.sj[tb] : a.su[tb];
-        const int sp0 = HUB_ITEM ? a.su[tb] : a.sj[tb];
-        const int cd0 = l16 < dmax ? a.sconds[(int64_t)tb * dmax + l16] : -1;
-        int my_sp = 0;
-        T my_rr = (T)0;
-        if (l16 < len) {
-            my_sp = HUB_ITEM ? a.su[tb + l16] : a.sj[tb + l16];
-            my_rr = a.sr[tb + l16];
-        }
-        const int n_cd = len * dmax; // <= 256 condition ids, staged 16 per pass
-        int cdv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            cdv[r] = -1;
-            if (l16 + 16 * r < n_cd) cdv[r] = a.sconds[(int64_t)tb * dmax + l16 + 16 * r];
-        }
-
-        // ---- round trip 3: the hub row comes on chip once, together with the first spoke row
-        T *htab = HUB_ITEM ? a.Q : a.P;
-        V *hrow = reinterpret_cast<V *>(htab + (size_t)hub * K) + l16;
-        T h[NV][E];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-#pragma unroll
-            for (int c = 0; c < E; ++c) h[v][c] = (T)0;
-            if (!RAGGED || E * l16 + 16 * E * v < K) {
-                const V t = hrow[v * 16];
-                unpack(t, h[v]);
-            }
-        }
-        T hb = (T)0;
-        T *phb = nullptr;
-        if (HB) {
-            phb = (HUB_ITEM ? a.itemBias : a.userBias) + hub;
-            hb = *phb;
-        }
-        T *hc_row = nullptr;
-        T hcv4[4];
-        if (HC) {
-            hc_row = (HUB_ITEM ? a.icBias : a.ucBias) + (size_t)hub * a.n_conds;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                hcv4[r] = (T)0;
-                if (l16 + 16 * r < a.n_conds) hcv4[r] = hc_row[l16 + 16 * r];
-            }
-        }
-        SpokeRow<T, NV> A, B;
-        chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, sp0, cd0, l16, K, A);
-
-        // ---- ids and the hub's context-bias row into LDS
-        if (l16 < len) {
-            s_sp[l16] = my_sp;
-            s_rr[l16] = my_rr;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (l16 + 16 * r < n_cd) s_cd[l16 + 16 * r] = cdv[r];
-        for (int c = l16 + 64; c < n_cd; c += 16) s_cd[c] = a.sconds[(int64_t)tb * dmax + c]; // dmax > 4 with long units
-        if (HC) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (l16 + 16 * r < a.n_conds) s_hc[l16 + 16 * r] = hcv4[r];
-            for (int c = l16 + 64; c < a.n_conds; c += 16) s_hc[c] = hc_row[c]; // more than 64 conditions
-        }
-        chain_lds_order();
-
-        // ---- the chain: spoke rows ping-pong between two register sets, the next one in flight while this one is used
-        int i = 0;
-        while (true) {
-            if (i + 1 < len)
-                chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, B);
-            chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, A, s_rr[i], l16, K, gloss);
-            if (++i >= len) break;
-            if (i + 1 < len)
-                chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, A);
-            chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, B, s_rr[i], l16, K, gloss);
-            if (++i >= len) break;
-        }
-
-        // ---- the hub row leaves the chip once
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-            if (!RAGGED || E * l16 + 16 * E * v < K) hrow[v * 16] = pack(h[v]);
-        if (HB && l16 == 0) *phb = hb;
-        if (HC) {
-            chain_lds_order();
-            for (int c = l16; c < a.n_conds; c += 16) hc_row[c] = s_hc[c];
-        }
+        const int32_t tb = unit_off[ubegin + g], te = unit_off[ubegin + g + 1];  // round trip 1
+        const ChainPre<T> pre = chain_prefetch_ids<T, M::has_ctx, HUB_ITEM>(a, tb, te, l16, dmax);
+        chain_unit<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, pre, chain_smem + (size_t)gib * chain_group_lds(HC ? a.n_conds : 0, dmax, sizeof(T)),
+                                                   l16, K, dmax, gloss);
     }
 
     if (l16 == 0) s_loss[gib] = gloss;
@@ -304,6 +333,67 @@ __global__ __launch_bounds__(256) void sgd_chain_level(SgdArgs<T> a, const int32
 #pragma unroll
         for (int i = 0; i < 16; ++i) s += s_loss[i];
         a.loss_part[slot0 + blockIdx.x] = s;
+    }
+}
+
+// Narrow runs of chain levels (heavy-tailed degrees: the hot rows' chains force hundreds of thousands of levels holding a few dozen
+// units each).  ONE 1024-thread workgroup = 64 groups walks a whole run of levels with <= 64 units each: group g takes unit g of
+// every level, a workgroup barrier separates levels (all waves share the CU's L1 and its XCD's L2: workgroup-scope ordering is all
+// the coherence needed, as in sgd_tail_fast_f32).  Bounds and ids do not depend on the updates: the bounds of level l+2 and the ids
+// of level l+1 are loaded while level l computes, so a level's critical path is ONE dependent round trip (its rows) + its chain.
+// Same per-tuple code as sgd_chain_level, hence the same bits.
+template <typename T, int MODEL, int NV, bool RAGGED, bool HUB_ITEM>
+__global__ __launch_bounds__(1024) void sgd_chain_tail(SgdArgs<T> a, const int32_t *__restrict__ unit_off, const int64_t *__restrict__ lvl_off,
+                                                       int n_levels, int64_t slot) {
+    using M = Traits<MODEL>;
+    constexpr int E = Vec16<T>::E;
+    constexpr bool HC = HUB_ITEM ? M::has_ic : M::has_uc;
+    extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+    __shared__ double s_loss[64];
+    const int tid = threadIdx.x, l16 = tid & 15, gib = tid >> 4;
+    const int K = RAGGED ? a.k : NV * 16 * E;
+    const int dmax = M::has_ctx ? a.dmax : 0;
+    unsigned char *gbase = chain_smem + (size_t)gib * chain_group_lds(HC ? a.n_conds : 0, dmax, sizeof(T));
+    double gloss = 0.0;
+    const HParams hpd = *a.hp;
+    const ChainHp<T> hp{(T)hpd.lr, (T)hpd.regU, (T)hpd.regI, (T)hpd.regB, (T)hpd.regC, (T)hpd.gm};
+
+    // software pipeline over levels: `nb` = unit bounds of the next level, `pre` = ids of the current level
+    int64_t lo = lvl_off[0], hi = lvl_off[1];
+    bool have = lo + gib < hi;
+    ChainPre<T> pre;
+    pre.len = 0;
+    if (have) pre = chain_prefetch_ids<T, M::has_ctx, HUB_ITEM>(a, unit_off[lo + gib], unit_off[lo + gib + 1], l16, dmax);
+    int64_t nlo = hi, nhi = n_levels > 1 ? lvl_off[2] : hi;
+    bool nhave = n_levels > 1 && nlo + gib < nhi;
+    int32_t nb0 = 0, nb1 = 0;
+    if (nhave) {
+        nb0 = unit_off[nlo + gib];
+        nb1 = unit_off[nlo + gib + 1];
+    }
+    for (int l = 0; l < n_levels; ++l) {
+        const ChainPre<T> cur = pre;
+        const bool cur_have = have;
+        // ids of level l+1 (its bounds arrived during level l-1), bounds of level l+2
+        have = nhave;
+        if (nhave) pre = chain_prefetch_ids<T, M::has_ctx, HUB_ITEM>(a, nb0, nb1, l16, dmax);
+        const int64_t n2lo = nhi, n2hi = l + 3 <= n_levels ? lvl_off[l + 3] : nhi;
+        nhave = l + 2 < n_levels && n2lo + gib < n2hi;
+        if (nhave) {
+            nb0 = unit_off[n2lo + gib];
+            nb1 = unit_off[n2lo + gib + 1];
+        }
+        nlo = n2lo;
+        nhi = n2hi;
+        if (cur_have) chain_unit<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, cur, gbase, l16, K, dmax, gloss);
+        __syncthreads(); // release/acquire at workgroup scope: the next level sees this level's rows
+    }
+    if (l16 == 0) s_loss[gib] = gloss;
+    __syncthreads();
+    if (tid == 0) {
+        double sum = 0.0;
+        for (int g = 0; g < 64; ++g) sum += s_loss[g];
+        a.loss_part[slot] = sum;
     }
 }
 
@@ -332,42 +422,48 @@ size_t chain_lds_bytes(int model, int n_conds, int dmax, bool f64, bool hub_is_i
 
 int chain_level_blocks(int count) { return (count + 15) / 16; }
 
+// a narrow-run launch keeps 64 groups' LDS in one workgroup
+bool has_chain_tail(int model, int n_conds, int dmax, bool f64) {
+    return 4 * chain_lds_bytes(model, n_conds, dmax, f64, true) <= 64 * 1024 && 4 * chain_lds_bytes(model, n_conds, dmax, f64, false) <= 64 * 1024;
+}
+
 template <typename T, int MODEL, int NV, bool RAGGED>
-static void *chain_kernel_hub(bool hub_is_item) {
+static void *chain_kernel_hub(bool hub_is_item, bool tail) {
+    if (tail) return hub_is_item ? (void *)sgd_chain_tail<T, MODEL, NV, RAGGED, true> : (void *)sgd_chain_tail<T, MODEL, NV, RAGGED, false>;
     return hub_is_item ? (void *)sgd_chain_level<T, MODEL, NV, RAGGED, true> : (void *)sgd_chain_level<T, MODEL, NV, RAGGED, false>;
 }
 
 template <typename T, int MODEL>
-static void *chain_kernel_k(int k, bool hub_is_item) {
+static void *chain_kernel_k(int k, bool hub_is_item, bool tail) {
     constexpr int E = Vec16<T>::E;
     const int per = 16 * E; // factors one vector slot covers across the group
     if (k % per == 0) {
         switch (k / per) {
-        case 1: return chain_kernel_hub<T, MODEL, 1, false>(hub_is_item);
-        case 2: return chain_kernel_hub<T, MODEL, 2, false>(hub_is_item);
-        case 4: return chain_kernel_hub<T, MODEL, 4, false>(hub_is_item);
-        case 8: if (E == 2) return chain_kernel_hub<T, MODEL, 8, false>(hub_is_item); break;
+        case 1: return chain_kernel_hub<T, MODEL, 1, false>(hub_is_item, tail);
+        case 2: return chain_kernel_hub<T, MODEL, 2, false>(hub_is_item, tail);
+        case 4: return chain_kernel_hub<T, MODEL, 4, false>(hub_is_item, tail);
+        case 8: if (E == 2) return chain_kernel_hub<T, MODEL, 8, false>(hub_is_item, tail); break;
         }
     }
     const int nv = (k + per - 1) / per; // masked vector slots past k
-    if (nv <= 2) return chain_kernel_hub<T, MODEL, 2, true>(hub_is_item);
-    if (nv <= 3) return chain_kernel_hub<T, MODEL, 3, true>(hub_is_item);
-    if (nv <= 4) return chain_kernel_hub<T, MODEL, 4, true>(hub_is_item);
+    if (nv <= 2) return chain_kernel_hub<T, MODEL, 2, true>(hub_is_item, tail);
+    if (nv <= 3) return chain_kernel_hub<T, MODEL, 3, true>(hub_is_item, tail);
+    if (nv <= 4) return chain_kernel_hub<T, MODEL, 4, true>(hub_is_item, tail);
     if (E == 2) {
-        if (nv <= 6) return chain_kernel_hub<T, MODEL, 6, true>(hub_is_item);
-        if (nv <= 8) return chain_kernel_hub<T, MODEL, 8, true>(hub_is_item);
+        if (nv <= 6) return chain_kernel_hub<T, MODEL, 6, true>(hub_is_item, tail);
+        if (nv <= 8) return chain_kernel_hub<T, MODEL, 8, true>(hub_is_item, tail);
     }
     return nullptr;
 }
 
 template <typename T>
-static void *chain_kernel_ptr(int model, int k, bool hub_is_item) {
+static void *chain_kernel_ptr(int model, int k, bool hub_is_item, bool tail) {
     switch (model) {
-    case BIASEDMF: return chain_kernel_k<T, BIASEDMF>(k, hub_is_item);
-    case PMF: return chain_kernel_k<T, PMF>(k, hub_is_item);
-    case CAMF_CI: return chain_kernel_k<T, CAMF_CI>(k, hub_is_item);
-    case CAMF_CU: return chain_kernel_k<T, CAMF_CU>(k, hub_is_item);
-    case CAMF_CUCI: return chain_kernel_k<T, CAMF_CUCI>(k, hub_is_item);
+    case BIASEDMF: return chain_kernel_k<T, BIASEDMF>(k, hub_is_item, tail);
+    case PMF: return chain_kernel_k<T, PMF>(k, hub_is_item, tail);
+    case CAMF_CI: return chain_kernel_k<T, CAMF_CI>(k, hub_is_item, tail);
+    case CAMF_CU: return chain_kernel_k<T, CAMF_CU>(k, hub_is_item, tail);
+    case CAMF_CUCI: return chain_kernel_k<T, CAMF_CUCI>(k, hub_is_item, tail);
     }
     return nullptr;
 }
@@ -376,13 +472,29 @@ template <typename T>
 hipError_t launch_chain_level(const SgdArgs<T> &a, const LaunchCfg &cfg, bool hub_is_item, const int32_t *unit_off, int64_t ubegin,
                               int count, int64_t slot0, hipStream_t s) {
     if (count <= 0) return hipSuccess;
-    void *fn = chain_kernel_ptr<T>(cfg.model, a.k, hub_is_item);
+    void *fn = chain_kernel_ptr<T>(cfg.model, a.k, hub_is_item, false);
     if (!fn) return hipErrorInvalidValue;
     SgdArgs<T> args = a;
     void *params[] = {&args, &unit_off, &ubegin, &count, &slot0};
     const size_t lds = chain_lds_bytes(cfg.model, a.n_conds, a.dmax, sizeof(T) == 8, hub_is_item);
     return hipLaunchKernel(fn, dim3((unsigned)chain_level_blocks(count)), dim3(256), params, lds, s);
 }
+template <typename T>
+hipError_t launch_chain_tail(const SgdArgs<T> &a, const LaunchCfg &cfg, bool hub_is_item, const int32_t *unit_off, const int64_t *lvl_off,
+                             int n_levels, int64_t slot, hipStream_t s) {
+    if (n_levels <= 0) return hipSuccess;
+    void *fn = chain_kernel_ptr<T>(cfg.model, a.k, hub_is_item, true);
+    if (!fn) return hipErrorInvalidValue;
+    SgdArgs<T> args = a;
+    void *params[] = {&args, &unit_off, &lvl_off, &n_levels, &slot};
+    const size_t lds = 4 * chain_lds_bytes(cfg.model, a.n_conds, a.dmax, sizeof(T) == 8, hub_is_item);
+    return hipLaunchKernel(fn, dim3(1), dim3(1024), params, lds, s);
+}
+template hipError_t launch_chain_tail<float>(const SgdArgs<float> &, const LaunchCfg &, bool, const int32_t *, const int64_t *, int, int64_t,
+                                             hipStream_t);
+template hipError_t launch_chain_tail<double>(const SgdArgs<double> &, const LaunchCfg &, bool, const int32_t *, const int64_t *, int, int64_t,
+                                              hipStream_t);
+
 template hipError_t launch_chain_level<float>(const SgdArgs<float> &, const LaunchCfg &, bool, const int32_t *, int64_t, int, int64_t,
                                               hipStream_t);
 template hipError_t launch_chain_level<double>(const SgdArgs<double> &, const LaunchCfg &, bool, const int32_t *, int64_t, int, int64_t,

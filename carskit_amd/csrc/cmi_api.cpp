@@ -341,6 +341,10 @@ static bool try_chain(cmi_instance *h, int64_t n, const int32_t *u, const int32_
     int64_t min_width = 2048; // mean units per level
     if (const char *env = getenv("CMI_CHAIN_MIN_WIDTH")) min_width = atoll(env);
     const bool forced = h->flags & CMI_FLAG_SCHED_CHAIN;
+    // Narrow levels (heavy-tailed degrees, tiny data) keep the plain levels and their narrow-run launches: measured on C3-size
+    // Zipf(0.8) items, the chain schedule has 2.5x fewer levels (434 K vs 1.10 M) but a narrow chain level is latency-bound on
+    // the HBM round trip of EVERY spoke row of its longest unit (one row in flight per group), 3.77 s per epoch against 2.61 s for
+    // the plain narrow-run walk.  Forced (CMI_FLAG_SCHED_CHAIN) it still runs, runs of narrow levels sharing a launch (sgd_chain_tail).
     if (!forced && csch.n_units() < min_width * csch.n_levels()) return false;
     h->chain = true;
     h->chain_hub_item = csch.hub_is_item != 0;
@@ -479,6 +483,8 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         h->tail_len.assign((size_t)n_levels, 0);
         h->n_launches = 0;
         if (!h->serial && !h->two_lane && !h->chain && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 256, 16, h->tail_len);
+        // chain levels: a run of >= 16 consecutive levels with <= 64 UNITS each is walked by one 64-group workgroup (sgd_chain_tail)
+        if (h->chain && has_chain_tail(h->model, h->n_conds, dmax, h->f64) && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 64, 16, h->tail_len);
         h->slot_off.assign((size_t)n_levels + 1, 0);
         for (int64_t l = 0; l < n_levels; ++l) {
             const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
@@ -688,6 +694,13 @@ static hipError_t enqueue_levels(cmi_instance *h) {
     }
     if (h->chain) {
         for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l) {
+            const int32_t run = h->tail_len.empty() ? 0 : h->tail_len[(size_t)l];
+            if (run > 0) {
+                e = h->f64 ? launch_chain_tail<double>(make_args<double>(h), cfg, h->chain_hub_item, h->d_unit_off, h->d_tail_off + l, run, h->slot_off[(size_t)l], h->stream)
+                           : launch_chain_tail<float>(make_args<float>(h), cfg, h->chain_hub_item, h->d_unit_off, h->d_tail_off + l, run, h->slot_off[(size_t)l], h->stream);
+                l += run - 1;
+                continue;
+            }
             const int64_t b = h->level_off[(size_t)l];
             const int cnt = (int)(h->level_off[(size_t)l + 1] - b);
             e = h->f64 ? launch_chain_level<double>(make_args<double>(h), cfg, h->chain_hub_item, h->d_unit_off, b, cnt, h->slot_off[(size_t)l], h->stream)

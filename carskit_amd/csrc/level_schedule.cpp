@@ -323,6 +323,14 @@ static void chain_pass(int64_t n, const int32_t *hub, const int32_t *spoke, int3
     }
 }
 
+int64_t count_plain_levels(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items) {
+    if (n <= 0) return 0;
+    int32_t nl = 0;
+    int64_t nu = 0;
+    chain_pass(n, j, u, n_items, n_users, 1, nullptr, nullptr, nullptr, nullptr, nl, nu); // max_chain 1 = the plain level recurrence
+    return nl;
+}
+
 bool build_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int max_chain,
                           ChainSchedule &out) {
     out = ChainSchedule();

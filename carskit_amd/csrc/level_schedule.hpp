@@ -60,6 +60,9 @@ struct ChainSchedule {
 bool build_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int max_chain,
                           ChainSchedule &out);
 
+// number of levels of the plain schedule (longest dependency chain), without building it
+int64_t count_plain_levels(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items);
+
 // Narrow runs of a level schedule: run_len[l] > 0 = a run of that many consecutive levels, each with <= max_tuples tuples,
 // starts at level l (one launch walks it); -1 = inside such a run; 0 = the level is launched on its own.  Runs shorter than
 // min_levels are not formed.  Returns the number of launches per epoch.
