@@ -124,7 +124,7 @@ class GpuEngine:
 
     def set_eval_ratings(self, u, j, ctx, r):      # test tuples resident on the device (per-epoch early-stop evaluation)
         self.inst.set_eval_ratings(u, j, ctx, r)
-        self.eval_resident_ready = True
+        self.eval_resident_ready = len(r) > 0      # an empty test set has nothing resident: fall back to the per-call path
 
     def eval_resident(self, lo, hi):
         return self.inst.eval_resident(lo, hi)

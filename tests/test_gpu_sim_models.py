@@ -119,3 +119,34 @@ def test_save_load_roundtrip_of_the_extra_containers(tmp_path):
         b.load_model(tmp_path / "m.cmi")
         for name, arr in a.get_states().items():
             assert np.array_equal(arr, b.get_states()[name]), (model, name)
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_rankings_match_oracle_in_fp64(model):
+    """cmi_eval_rankings for these models (score = <a_q, b_j> + const_q with a_q = s(c) * P[u], or for SVD++
+    a_q = [P[u] + sum Y / sqrt|N(u)| | 1]; ext_kernels.hip) against oracle/rank_oracle.py driven by the oracle's scalar predict():
+    identical top-N lists, scores within 1e-10, all measures within 1e-12."""
+    from oracle import rank_oracle
+    d, empty = _data(seed=83, n=2500)
+    train, test = synth.split(d, 0.25)
+    orc, inst = make(model, train, empty, 16, F64 | STRICT)
+    for _ in range(2):
+        orc.epoch(LR)
+        inst.train_epoch(LR)
+    tup = lambda t: list(zip(t.u.tolist(), t.j.tolist(), t.ctx.tolist(), t.r.tolist()))
+    ref, ref_lists = rank_oracle.eval_rankings(lambda u, j, c: orc.predict(u, j, -1 if model == "SVD++" else c), tup(train), tup(test),
+                                               bin_thold=-1.0, num_recs=10, strategy="ucu", num_ignore=-1)
+    res, lists = inst.eval_rankings((train.u, train.j, train.ctx, train.r), (test.u, test.j, test.ctx, test.r), bin_thold=-1.0,
+                                    num_recs=10, num_ignore=-1, strategy="ucu", with_lists=True)
+    assert res.pop("n_queries") == len(ref_lists) > 20
+    for key, want in ref_lists.items():
+        got = lists[key]
+        assert [i for i, _ in got] == [i for i, _ in want], key
+        assert max(abs(a - b) for (_, a), (_, b) in zip(got, want)) <= 1e-10
+    for m, v in ref.items():
+        assert abs(res[m] - v) <= 1e-12, m
+
+
+def test_measure_hbm_reports_plausible_rates():
+    copy, rows = capi.measure_hbm(0, 2 << 30)
+    assert 1500 < copy < 8000 and 1500 < rows < 8000          # GB/s: a working MI355X sits at 4-6.5 TB/s on both
