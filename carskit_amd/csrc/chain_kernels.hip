@@ -398,6 +398,218 @@ __global__ __launch_bounds__(1024) void sgd_chain_tail(SgdArgs<T> a, const int32
 }
 
 // ---------------------------------------------------------------------------------------------
+// small k (fp32 state, k < 64: the reference's default num.factors is 10): LPT = 4, 8 or 16 lanes per unit
+// ---------------------------------------------------------------------------------------------
+// Same walk as sgd_chain_level with the lane layout of sgd_level_small_f32 (mf_sgd_kernels.hip): lane l of the group owns
+// factors l, l+LPT, l+2*LPT, l+3*LPT (scalar loads: rows of k floats are not 16-byte aligned for general k) and the tuple's l-th
+// condition, so LPT >= dmax and 4*LPT >= k; 256/LPT units per workgroup.  Per tuple the expressions are small_tuples_f32's, in
+// the same order (bit-identical fp32 model).  At this k a level is a few megabytes, i.e. the epoch is bound by the number of
+// dependent launches -- which is what the chain schedule cuts (939 -> 285 for the C3 shape).
+struct SmallSpoke {
+    float v[4];
+    float sb, sc;
+    float *psc;
+    int spoke, cond;
+};
+
+template <int MODEL, int LPT, bool HUB_ITEM>
+__device__ __forceinline__ void small_load_spoke(const SgdArgs<float> &a, int spoke, int cond, int lt, int k, SmallSpoke &r) {
+    using M = Traits<MODEL>;
+    constexpr bool SB = HUB_ITEM ? M::has_bu : M::has_bj;
+    constexpr bool SC = HUB_ITEM ? M::has_uc : M::has_ic;
+    const float *row = (HUB_ITEM ? a.P : a.Q) + (size_t)spoke * k + lt;
+    r.spoke = spoke;
+    r.cond = cond;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        r.v[v] = 0.f;
+        if (lt + v * LPT < k) r.v[v] = row[v * LPT];
+    }
+    r.sb = r.sc = 0.f;
+    r.psc = nullptr;
+    if (SB) r.sb = (HUB_ITEM ? a.userBias : a.itemBias)[spoke];
+    if (SC && cond >= 0) {
+        r.psc = (HUB_ITEM ? a.ucBias : a.icBias) + (size_t)spoke * a.n_conds + cond;
+        r.sc = *r.psc;
+    }
+}
+
+template <int MODEL, int LPT, bool HUB_ITEM>
+__device__ __forceinline__ void small_step(const SgdArgs<float> &a, const ChainHp<float> &hp, float (&h)[4], float &hb, float *s_hc,
+                                           const SmallSpoke &cur, float rr, int lt, int k, double &gloss) {
+    using M = Traits<MODEL>;
+    constexpr bool HB = HUB_ITEM ? M::has_bj : M::has_bu;
+    constexpr bool SB = HUB_ITEM ? M::has_bu : M::has_bj;
+    constexpr bool HC = HUB_ITEM ? M::has_ic : M::has_uc;
+    constexpr bool SC = HUB_ITEM ? M::has_uc : M::has_ic;
+    const float lr = hp.lr, regU = hp.regU, regI = hp.regI, regB = hp.regB, regC = hp.regC;
+    float part = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part += HUB_ITEM ? cur.v[v] * h[v] : h[v] * cur.v[v];
+    const float dot = group_sum<LPT>(part);
+    float hcv = 0.f;
+    if (HC) {
+        chain_lds_order();
+        if (cur.cond >= 0) hcv = s_hc[cur.cond];
+    }
+    const float bu = HUB_ITEM ? cur.sb : hb, bj = HUB_ITEM ? hb : cur.sb;
+    const float bic = HUB_ITEM ? hcv : cur.sc, buc = HUB_ITEM ? cur.sc : hcv;
+    float pred = hp.gm;
+    if (M::has_bu) pred += bu;
+    if (M::has_bj) pred += bj;
+    pred += dot;
+    if (M::has_ctx) {
+        float term = 0.f;
+        if (M::has_ic && M::has_uc) term = bic + buc;
+        else if (M::has_ic) term = bic;
+        else if (M::has_uc) term = buc;
+        pred += group_sum<LPT>(term);
+    }
+    const float e = rr - pred;
+    if (HB) hb = hb + lr * (e - regB * hb);
+    if (SB && lt == 0) (HUB_ITEM ? a.userBias : a.itemBias)[cur.spoke] = cur.sb + lr * (e - regB * cur.sb);
+    float ctx_loss = 0.f;
+    if (cur.cond >= 0) {
+        if (M::has_ic) ctx_loss += bic * bic;
+        if (M::has_uc) ctx_loss += buc * buc;
+        if (HC) s_hc[cur.cond] = hcv + lr * (e - regC * hcv);
+        if (SC) *cur.psc = cur.sc + lr * (e - regC * cur.sc);
+    }
+    if (HC) chain_lds_order();
+    float lsum = 0.f;
+    float *srow = (HUB_ITEM ? a.P : a.Q) + (size_t)cur.spoke * k + lt;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+        if (lt + v * LPT < k) {
+            const float pv = HUB_ITEM ? cur.v[v] : h[v], qv = HUB_ITEM ? h[v] : cur.v[v];
+            const float pn = pv + lr * (e * qv - regU * pv);
+            const float qn = qv + lr * (e * pv - regI * qv);
+            lsum += (regU * pv) * pv + (regI * qv) * qv;
+            h[v] = HUB_ITEM ? qn : pn;
+            srow[v * LPT] = HUB_ITEM ? pn : qn;
+        }
+    const float reg_loss = group_sum<LPT>(lsum);
+    const float ctx_sum = M::has_ctx ? group_sum<LPT>(ctx_loss) : 0.f;
+    if (lt == 0) {
+        double l = (double)e * (double)e;
+        if (M::has_bu) l += (double)regB * bu * bu;
+        if (M::has_bj) l += (double)regB * bj * bj;
+        if (M::has_ctx) l += (double)regC * ctx_sum;
+        gloss += l + (double)reg_loss;
+    }
+}
+
+template <int MODEL, int LPT, bool HUB_ITEM>
+__global__ __launch_bounds__(256) void sgd_chain_small(SgdArgs<float> a, const int32_t *__restrict__ unit_off, int64_t ubegin, int count,
+                                                       int64_t slot0) {
+    using M = Traits<MODEL>;
+    static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
+    constexpr bool HB = HUB_ITEM ? M::has_bj : M::has_bu;
+    constexpr bool HC = HUB_ITEM ? M::has_ic : M::has_uc;
+    constexpr int GPB = 256 / LPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+    __shared__ double s_loss[GPB];
+    const int tid = threadIdx.x, lt = tid % LPT, gib = tid / LPT;
+    const int g = blockIdx.x * GPB + gib;
+    const int k = a.k;
+    const int dmax = M::has_ctx ? a.dmax : 0;
+    double gloss = 0.0;
+    const HParams hpd = *a.hp;
+    const ChainHp<float> hp{(float)hpd.lr, (float)hpd.regU, (float)hpd.regI, (float)hpd.regB, (float)hpd.regC, (float)hpd.gm};
+
+    if (g < count) { // group-uniform
+        const int32_t tb = unit_off[ubegin + g], te = unit_off[ubegin + g + 1];
+        const int len = te - tb; // 1 .. 16
+        unsigned char *gbase = chain_smem + (size_t)gib * chain_group_lds(HC ? a.n_conds : 0, dmax, sizeof(float));
+        float *s_hc = reinterpret_cast<float *>(gbase);
+        float *s_rr = s_hc + (HC ? a.n_conds : 0);
+        int *s_sp = reinterpret_cast<int *>(s_rr + 16);
+        int *s_cd = s_sp + 16;
+        const int n_cd = len * dmax;
+
+        // ---- ids: every load issued before the first is used (16 / LPT passes over the unit's tuples, <= 16 over its conditions)
+        const int hub = HUB_ITEM ? a.sj[tb] : a.su[tb];
+        const int sp0 = HUB_ITEM ? a.su[tb] : a.sj[tb];
+        const int cd0 = lt < dmax ? a.sconds[(int64_t)tb * dmax + lt] : -1;
+        int my_sp[16 / LPT];
+        float my_rr[16 / LPT];
+#pragma unroll
+        for (int r = 0; r < 16 / LPT; ++r) {
+            my_sp[r] = 0;
+            my_rr[r] = 0.f;
+            if (lt + r * LPT < len) {
+                my_sp[r] = HUB_ITEM ? a.su[tb + lt + r * LPT] : a.sj[tb + lt + r * LPT];
+                my_rr[r] = a.sr[tb + lt + r * LPT];
+            }
+        }
+        int cdv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cdv[r] = -1;
+            if (lt + r * LPT < n_cd) cdv[r] = a.sconds[(int64_t)tb * dmax + lt + r * LPT];
+        }
+        // ---- the hub row comes on chip once, together with the first spoke row
+        float *hrow = (HUB_ITEM ? a.Q : a.P) + (size_t)hub * k + lt;
+        float h[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            h[v] = 0.f;
+            if (lt + v * LPT < k) h[v] = hrow[v * LPT];
+        }
+        float hb = 0.f;
+        float *phb = nullptr;
+        if (HB) {
+            phb = (HUB_ITEM ? a.itemBias : a.userBias) + hub;
+            hb = *phb;
+        }
+        float *hc_row = HC ? (HUB_ITEM ? a.icBias : a.ucBias) + (size_t)hub * a.n_conds : nullptr;
+        SmallSpoke A, B;
+        small_load_spoke<MODEL, LPT, HUB_ITEM>(a, sp0, cd0, lt, k, A);
+        // ---- ids and the hub's context-bias row into LDS
+#pragma unroll
+        for (int r = 0; r < 16 / LPT; ++r)
+            if (lt + r * LPT < len) {
+                s_sp[lt + r * LPT] = my_sp[r];
+                s_rr[lt + r * LPT] = my_rr[r];
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (lt + r * LPT < n_cd) s_cd[lt + r * LPT] = cdv[r];
+        for (int c = lt + 4 * LPT; c < n_cd; c += LPT) s_cd[c] = a.sconds[(int64_t)tb * dmax + c];
+        if (HC)
+            for (int c = lt; c < a.n_conds; c += LPT) s_hc[c] = hc_row[c];
+        chain_lds_order();
+
+        int i = 0;
+        while (true) {
+            if (i + 1 < len) small_load_spoke<MODEL, LPT, HUB_ITEM>(a, s_sp[i + 1], lt < dmax ? s_cd[(i + 1) * dmax + lt] : -1, lt, k, B);
+            small_step<MODEL, LPT, HUB_ITEM>(a, hp, h, hb, s_hc, A, s_rr[i], lt, k, gloss);
+            if (++i >= len) break;
+            if (i + 1 < len) small_load_spoke<MODEL, LPT, HUB_ITEM>(a, s_sp[i + 1], lt < dmax ? s_cd[(i + 1) * dmax + lt] : -1, lt, k, A);
+            small_step<MODEL, LPT, HUB_ITEM>(a, hp, h, hb, s_hc, B, s_rr[i], lt, k, gloss);
+            if (++i >= len) break;
+        }
+        // ---- the hub row leaves the chip once
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (lt + v * LPT < k) hrow[v * LPT] = h[v];
+        if (HB && lt == 0) *phb = hb;
+        if (HC) {
+            chain_lds_order();
+            for (int c = lt; c < a.n_conds; c += LPT) hc_row[c] = s_hc[c];
+        }
+    }
+    if (lt == 0) s_loss[gib] = gloss;
+    __syncthreads();
+    if (tid < 64) { // fixed-shape tree over the GPB group sums
+        double sum = 0.0;
+        for (int q = tid; q < GPB; q += 64) sum += s_loss[q];
+        sum = wave_sum64(sum);
+        if (tid == 0) a.loss_part[slot0 + blockIdx.x] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 
@@ -407,9 +619,11 @@ bool has_chain_path(int model, int k, int dmax, int n_conds, bool f64, bool stri
     if (f64) {
         if (k < 32 || k > 256 || k % 2 != 0) return false;
     } else {
-        if (k < 64 || k > 256 || k % 4 != 0) return false;
+        if (k > 256 || (k >= 64 && k % 4 != 0)) return false; // k < 64: sgd_chain_small (any k)
     }
-    if (chain_lds_bytes(model, n_conds, dmax, f64, true) > 64 * 1024 || chain_lds_bytes(model, n_conds, dmax, f64, false) > 64 * 1024) return false;
+    const int groups = chain_groups_per_block(k, dmax, f64);
+    if (groups * chain_lds_bytes(model, n_conds, dmax, f64, true) / 16 > 64 * 1024 || groups * chain_lds_bytes(model, n_conds, dmax, f64, false) / 16 > 64 * 1024)
+        return false;
     return true;
 }
 
@@ -420,10 +634,21 @@ size_t chain_lds_bytes(int model, int n_conds, int dmax, bool f64, bool hub_is_i
     return 16 * chain_group_lds(hc ? n_conds : 0, has_ctx ? dmax : 0, f64 ? 8 : 4);
 }
 
-int chain_level_blocks(int count) { return (count + 15) / 16; }
+// lanes per unit of the small-k kernel (as small_lpt in mf_sgd_kernels.hip): LPT >= dmax and 4 * LPT >= k
+static int chain_small_lpt(int k, int dmax) {
+    if (k <= 16 && dmax <= 4) return 4;
+    if (k <= 32 && dmax <= 8) return 8;
+    return 16;
+}
+int chain_groups_per_block(int k, int dmax, bool f64) { return (!f64 && k < 64) ? 256 / chain_small_lpt(k, dmax) : 16; }
+int chain_level_blocks(int k, int dmax, bool f64, int count) {
+    const int g = chain_groups_per_block(k, dmax, f64);
+    return (count + g - 1) / g;
+}
 
 // a narrow-run launch keeps 64 groups' LDS in one workgroup
-bool has_chain_tail(int model, int n_conds, int dmax, bool f64) {
+bool has_chain_tail(int model, int k, int n_conds, int dmax, bool f64) {
+    if (!f64 && k < 64) return false; // the small-k kernel has no multi-level form
     return 4 * chain_lds_bytes(model, n_conds, dmax, f64, true) <= 64 * 1024 && 4 * chain_lds_bytes(model, n_conds, dmax, f64, false) <= 64 * 1024;
 }
 
@@ -468,16 +693,41 @@ static void *chain_kernel_ptr(int model, int k, bool hub_is_item, bool tail) {
     return nullptr;
 }
 
+template <int MODEL, int LPT>
+static void *chain_small_hub(bool hub_is_item) {
+    return hub_is_item ? (void *)sgd_chain_small<MODEL, LPT, true> : (void *)sgd_chain_small<MODEL, LPT, false>;
+}
+template <int MODEL>
+static void *chain_small_lpt_ptr(int lpt, bool hub_is_item) {
+    switch (lpt) {
+    case 4: return chain_small_hub<MODEL, 4>(hub_is_item);
+    case 8: return chain_small_hub<MODEL, 8>(hub_is_item);
+    default: return chain_small_hub<MODEL, 16>(hub_is_item);
+    }
+}
+static void *chain_small_ptr(int model, int lpt, bool hub_is_item) {
+    switch (model) {
+    case BIASEDMF: return chain_small_lpt_ptr<BIASEDMF>(lpt, hub_is_item);
+    case PMF: return chain_small_lpt_ptr<PMF>(lpt, hub_is_item);
+    case CAMF_CI: return chain_small_lpt_ptr<CAMF_CI>(lpt, hub_is_item);
+    case CAMF_CU: return chain_small_lpt_ptr<CAMF_CU>(lpt, hub_is_item);
+    case CAMF_CUCI: return chain_small_lpt_ptr<CAMF_CUCI>(lpt, hub_is_item);
+    }
+    return nullptr;
+}
+
 template <typename T>
 hipError_t launch_chain_level(const SgdArgs<T> &a, const LaunchCfg &cfg, bool hub_is_item, const int32_t *unit_off, int64_t ubegin,
                               int count, int64_t slot0, hipStream_t s) {
     if (count <= 0) return hipSuccess;
-    void *fn = chain_kernel_ptr<T>(cfg.model, a.k, hub_is_item, false);
+    const bool f64 = sizeof(T) == 8;
+    const int groups = chain_groups_per_block(a.k, a.dmax, f64);
+    void *fn = (!f64 && a.k < 64) ? chain_small_ptr(cfg.model, 256 / groups, hub_is_item) : chain_kernel_ptr<T>(cfg.model, a.k, hub_is_item, false);
     if (!fn) return hipErrorInvalidValue;
     SgdArgs<T> args = a;
     void *params[] = {&args, &unit_off, &ubegin, &count, &slot0};
-    const size_t lds = chain_lds_bytes(cfg.model, a.n_conds, a.dmax, sizeof(T) == 8, hub_is_item);
-    return hipLaunchKernel(fn, dim3((unsigned)chain_level_blocks(count)), dim3(256), params, lds, s);
+    const size_t lds = (size_t)groups * (chain_lds_bytes(cfg.model, a.n_conds, a.dmax, f64, hub_is_item) / 16);
+    return hipLaunchKernel(fn, dim3((unsigned)chain_level_blocks(a.k, a.dmax, f64, count)), dim3(256), params, lds, s);
 }
 template <typename T>
 hipError_t launch_chain_tail(const SgdArgs<T> &a, const LaunchCfg &cfg, bool hub_is_item, const int32_t *unit_off, const int64_t *lvl_off,

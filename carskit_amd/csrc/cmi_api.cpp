@@ -484,12 +484,12 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         h->n_launches = 0;
         if (!h->serial && !h->two_lane && !h->chain && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 256, 16, h->tail_len);
         // chain levels: a run of >= 16 consecutive levels with <= 64 UNITS each is walked by one 64-group workgroup (sgd_chain_tail)
-        if (h->chain && has_chain_tail(h->model, h->n_conds, dmax, h->f64) && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 64, 16, h->tail_len);
+        if (h->chain && has_chain_tail(h->model, h->k, h->n_conds, dmax, h->f64) && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 64, 16, h->tail_len);
         h->slot_off.assign((size_t)n_levels + 1, 0);
         for (int64_t l = 0; l < n_levels; ++l) {
             const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
             int blocks = h->serial ? 0
-                         : h->chain ? chain_level_blocks(cnt)
+                         : h->chain ? chain_level_blocks(h->k, dmax, h->f64, cnt)
                          : h->fast ? level_blocks_f32_fast(h->k, cnt)
                          : h->small ? level_blocks_small(h->k, dmax, cnt)
                                     : level_blocks_generic(cnt);

@@ -279,14 +279,6 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
 // LPT >= dmax and 4*LPT >= k.  Same arithmetic as sgd_level_fast_f32; the group sums run on DPP quad permutes and
 // row (half-)mirrors.  With the generic kernel a k=10 epoch of the C3 shape cost 1.8x the k=128 one (a whole wave per
 // tuple, 10 of 64 lanes busy); this one moves the same few bytes with 16 tuples per wave.
-template <int LPT>
-__device__ __forceinline__ float group_sum(float x) {
-    x += dpp_f32<0xB1>(x); // quad_perm [1,0,3,2]
-    x += dpp_f32<0x4E>(x); // quad_perm [2,3,0,1]
-    if (LPT >= 8) x += dpp_f32<0x141>(x);  // row_half_mirror: lane i <- lane 7-i of its half row (the other quad's total)
-    if (LPT >= 16) x += dpp_f32<0x140>(x); // row_mirror: lane i <- lane 15-i (the other half's total)
-    return x;
-}
 
 template <int MODEL, int LPT, int TPG, int GS, bool PRE = false>
 __device__ __forceinline__ double small_tuples_f32(const SgdArgs<float> &a, int64_t begin, int count, int g0, int lt,

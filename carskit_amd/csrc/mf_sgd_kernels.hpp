@@ -77,10 +77,11 @@ hipError_t graph_add_reduce_loss(hipGraph_t g, const hipGraphNode_t *deps, size_
 // units [ubegin, ubegin+count) of unit_off (n_units+1 device offsets into the tuple stream) form one level.
 bool has_chain_path(int model, int k, int dmax, int n_conds, bool f64, bool strict);
 size_t chain_lds_bytes(int model, int n_conds, int dmax, bool f64, bool hub_is_item);
-int chain_level_blocks(int count);
+int chain_groups_per_block(int k, int dmax, bool f64);   // units per 256-thread workgroup (16; 16 / 32 / 64 for fp32 k < 64)
+int chain_level_blocks(int k, int dmax, bool f64, int count);
 // a run of n_levels narrow chain levels (<= 64 units each) walked by ONE workgroup; lvl_off = device offsets (unit indices) of the
 // run's levels, n_levels + 1 entries
-bool has_chain_tail(int model, int n_conds, int dmax, bool f64);
+bool has_chain_tail(int model, int k, int n_conds, int dmax, bool f64);
 template <typename T>
 hipError_t launch_chain_tail(const SgdArgs<T> &a, const LaunchCfg &cfg, bool hub_is_item, const int32_t *unit_off, const int64_t *lvl_off,
                              int n_levels, int64_t slot, hipStream_t s);

@@ -45,6 +45,17 @@ struct Traits {
 };
 
 
+// Sum over the LPT (4, 8 or 16) lanes of a group that shares one tuple in the small-k kernels: quad permutes, then row
+// (half-)mirrors; every lane of the group ends with the same total.
+template <int LPT>
+__device__ __forceinline__ float group_sum(float x) {
+    x += dpp_f32<0xB1>(x); // quad_perm [1,0,3,2]
+    x += dpp_f32<0x4E>(x); // quad_perm [2,3,0,1]
+    if (LPT >= 8) x += dpp_f32<0x141>(x);  // row_half_mirror: lane i <- lane 7-i of its half row (the other quad's total)
+    if (LPT >= 16) x += dpp_f32<0x140>(x); // row_mirror: lane i <- lane 15-i (the other half's total)
+    return x;
+}
+
 // fp64 flavour of the 16-lane DPP row sum (both dwords rotated with the same control)
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x) {

@@ -35,7 +35,7 @@ def _with_hub(hub, fn):
 
 
 @pytest.mark.parametrize("model", LEVEL_MODELS)
-@pytest.mark.parametrize("k", [64, 100, 128, 256])
+@pytest.mark.parametrize("k", [10, 31, 48, 64, 100, 128, 256])
 @pytest.mark.parametrize("hub", ["item", "user"])
 def test_chain_f32_state_bitwise_equals_plain_levels(model, k, hub):
     data = util.small_data(n_users=3000, n_items=300, n_dims=4, conds_per_dim=4, n=50000, seed=31)
@@ -89,6 +89,26 @@ def test_chain_f64_fast_path_vs_oracle(model, k, hub):
     assert_state_equal(orc, inst, exact=False, atol=1e-12)
 
 
+@pytest.mark.parametrize("model", LEVEL_MODELS)
+@pytest.mark.parametrize("k,n_dims", [(1, 1), (5, 3), (10, 2), (16, 4), (17, 4), (20, 7), (32, 8), (33, 2), (63, 12)])
+def test_chain_small_k_lane_layouts_bitwise_equal_plain(model, k, n_dims):
+    """sgd_chain_small (fp32, k < 64; the reference's default num.factors is 10): 4, 8 or 16 lanes per unit by (k, D), ragged rows,
+    more condition ids per unit than 4 per lane; vs the plain level schedule's small-k kernel, and vs the oracle at the north_star bar."""
+    data = synth.generate(2000, 150, n_dims, 3, 30000, seed=100 + k)
+    for hub in ("item", "user"):
+        _, plain = make_pair(model, data, k, NOCHAIN)
+        orc, chain = _with_hub(hub, lambda: make_pair(model, data, k, CHAIN))
+        assert chain.schedule_info()["kind"] == "chain-" + hub
+        for _ in range(3):
+            lp, lc, lo = plain.train_epoch(util.LR), chain.train_epoch(util.LR), orc.epoch(util.LR)
+            assert abs(lp - lc) <= 1e-12 * abs(lp)
+            assert abs(lo - lc) <= 3e-5 * abs(lo)
+        sp, sc = plain.get_states(), chain.get_states()
+        for name in sp:
+            assert np.array_equal(sp[name], sc[name]), (hub, name)
+        assert_state_equal(orc, chain, exact=False, atol=3e-4)
+
+
 @pytest.mark.parametrize("model", ["CAMF_CI", "CAMF_CU", "CAMF_CUCI"])
 def test_chain_many_conditions_and_dimensions(model):
     """> 64 conditions (the LDS row is filled / written back by the remainder loops) and 6 dimensions with long units
@@ -130,7 +150,7 @@ def test_chain_is_the_default_on_wide_data_and_not_on_narrow():
     _, inst2 = make_pair("CAMF_CI", narrow, 64, 0)
     assert inst2.schedule_info()["kind"] == "level"
     with pytest.raises(capi.CmiError):       # forcing it where no chain kernel exists is an error, not a silent fallback
-        make_pair("CAMF_CI", narrow, 10, CHAIN)
+        make_pair("CAMF_CI", narrow, 300, CHAIN)
 
 
 def test_chain_tail_on_heavy_tailed_items_bitwise_equals_plain():

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz of the GPU path against the C oracle on random small problems (every model, random k / dims / sizes /
-item skew / flags).  fp64+strict: model state must be bit-identical; fp32: loss within 2e-5 and state within 2e-4.
+item skew / flags, incl. the hub-chain kernels forced on both hub sides -- narrow data sends them through sgd_chain_tail).
+fp64+strict: model state must be bit-identical; fp32: loss within 2e-5 and state within 2e-4.
 usage: tools/fuzz_gpu.py [n_cases] [seed]"""
 import os
 import sys
@@ -18,7 +19,8 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     F64, SERIAL, STRICT, NOGRAPH = capi.FLAG_STATE_F64, capi.FLAG_SCHED_SERIAL, capi.FLAG_STRICT, capi.FLAG_NO_GRAPH
-    bad = 0
+    CHAIN = capi.FLAG_SCHED_CHAIN
+    bad = chained = 0
     for case in range(n_cases):
         model = util.MODELS[rng.integers(len(util.MODELS))]
         k = int(rng.choice([1, 2, 5, 10, 16, 31, 64, 70, 100, 128, 130, 256]))
@@ -34,6 +36,14 @@ def main():
             flags |= SERIAL
         if rng.random() < 0.2:
             flags |= NOGRAPH
+        # the hub-chain kernels wherever one exists for this (model, k, precision): fp32 k < 64 (any) and 64..256 (k % 4 == 0), fp64 k = 32..256 (even)
+        chain_ok = (model != "CAMF_C" and not flags & (SERIAL | STRICT) and n_dims <= 16 and
+                    ((flags & F64 and 32 <= k <= 256 and k % 2 == 0) or (not flags & F64 and (k < 64 or (k <= 256 and k % 4 == 0)))))
+        if chain_ok and rng.random() < 0.7:
+            flags |= CHAIN
+            os.environ["CMI_CHAIN_HUB"] = str(rng.choice(["item", "user", "auto"]))
+            os.environ["CMI_CHAIN_MAX"] = str(int(rng.choice([1, 2, 5, 16])))
+            chained += 1
         state = synth.init_state(model, data, k, seed=int(rng.integers(1 << 30)))
         gm = oracle_c.global_mean(data.r)
         orc = util.c_oracle(model, data, k, state, gm)
@@ -61,7 +71,7 @@ def main():
             bad += 1
             print("MISMATCH case %d: %s k=%d dims=%d users=%d items=%d n=%d zipf=%s flags=%#x info=%s"
                   % (case, model, k, n_dims, n_users, n_items, data.n, zipf, flags, inst.schedule_info()), flush=True)
-    print("%d cases, %d mismatches" % (n_cases, bad))
+    print("%d cases (%d through the hub-chain kernels), %d mismatches" % (n_cases, chained, bad))
     return 1 if bad else 0
 
 
