@@ -118,7 +118,8 @@ def roofline(model, k, n_dims, data_n, info, kern_ms, esize, workload):
             "traffic_GBps": (traffic / avg_us / 1e3) if traffic else None,
             "traffic_over_algorithmic": (traffic / (data_n * bpu / launches)) if traffic else None,
             "kernel": ("sgd_chain_level<%s,%s,hub=%s>" % (tname, model, info["kind"][6:]) if chain
-                       else "sgd_level_fast_f32<%s,%d>" % (model, k // 64) if esize == 4 else "sgd_level_generic<double,%s>" % model),
+                       else "sgd_owner<%s,%s,hub=%s> (latency-bound by the hottest row's chain, not by HBM)" % (tname, model, info["kind"][6:])
+                       if info["kind"].startswith("owner") else "sgd_level_fast_f32<%s,%d>" % (model, k // 64) if esize == 4 else "sgd_level_generic<double,%s>" % model),
             "schedule": info["kind"], "bytes_per_update": bpu, "launches_per_epoch": launches,
             "units_per_epoch": info["flow_blocks"] if chain else None,
             "avg_launch_us": avg_us, "bytes_per_launch": data_n * bpu / launches}

@@ -41,6 +41,8 @@ FLAG_SCHED_FLOW = 0x20
 FLAG_TWO_LANE = 0x40
 FLAG_SCHED_CHAIN = 0x80
 FLAG_NO_CHAIN = 0x100
+FLAG_SCHED_OWNER = 0x200
+OWN_HUB_FWD, OWN_HUB_LATE, OWN_HUB_STORE, OWN_SPK_FWD, OWN_SPK_STORE = 1, 2, 4, 8, 16
 
 # every symbol include/carskit_mi355x.h declares: (name, restype, argtypes)
 _vp, _i64, _i32, _dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
@@ -90,6 +92,7 @@ SYMBOLS = [
     ("cmi_loss_device_ptr", C.c_int, [_vp, C.POINTER(_vp)]),
     ("cmi_last_epoch_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("cmi_level_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, _vp, _vp, _i64, C.POINTER(_i64)]),
+    ("cmi_owner_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(C.c_int)]),
     ("cmi_chain_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _i64, C.POINTER(_i64),
                                      C.POINTER(_i64), C.POINTER(C.c_int)]),
     ("cmi_split_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
@@ -280,6 +283,23 @@ def chain_schedule(u, j, n_users, n_items, hub=-1, max_chain=16):
     return perm, unit_off, level_off, bool(hub_used.value)
 
 
+def owner_schedule(u, j, n_users, n_items, n_owners, hub=-1, depth=8):
+    """Host-only: (perm, own_off, want, flags, hub_is_item) of the owner (dataflow) schedule (see cmi_owner_schedule)."""
+    u = np.ascontiguousarray(u, dtype=np.int32)
+    j = np.ascontiguousarray(j, dtype=np.int32)
+    n = len(u)
+    perm = np.empty(n, dtype=np.int32)
+    own_off = np.empty(n_owners + 1, dtype=np.int64)
+    want = np.empty(n, dtype=np.uint32)
+    flags = np.empty(n, dtype=np.uint32)
+    hub_used = C.c_int()
+    rc = lib().cmi_owner_schedule(n, _p(u), _p(j), n_users, n_items, hub, n_owners, depth, _p(perm), _p(own_off), _p(want), _p(flags),
+                                  C.byref(hub_used))
+    if rc != OK:
+        raise CmiError(rc, "cmi_owner_schedule")
+    return perm, own_off, want, flags, bool(hub_used.value)
+
+
 def split_schedule(u, j, n_users, n_items):
     """Host-only: (perm, level_off, split) of the two-lane level schedule (see cmi_split_schedule)."""
     u = np.ascontiguousarray(u, dtype=np.int32)
@@ -466,7 +486,7 @@ class Instance:
         self._chk(self.L.cmi_schedule_info(self.h, info))
         d = dict(zip(("levels", "max_level", "tuples", "dmax", "state_bytes", "tuple_bytes", "kind", "flow_blocks"),
                      list(info)))
-        d["kind"] = ("level", "serial", "flow", "two-lane", "chain-item", "chain-user")[d["kind"]]
+        d["kind"] = ("level", "serial", "flow", "two-lane", "chain-item", "chain-user", "owner-item", "owner-user")[d["kind"]]
         return d
 
     def stream(self):

@@ -88,7 +88,11 @@ static void free_ratings(cmi_instance *h) {
     }
     void *ptrs[] = {h->d_su, h->d_sj, h->d_sconds, h->d_ctx_ptr, h->d_ctx_conds, h->d_sr, h->d_loss_part,
                     h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->d_tail_off, h->d_blk_off, h->d_unit_off,
-                    h->d_ui_ptr, h->d_ui_items};
+                    h->d_ui_ptr, h->d_ui_items, h->d_own_recs, h->d_own_off, h->d_tagged};
+    h->d_own_recs = nullptr;
+    h->d_own_off = nullptr;
+    h->d_tagged = nullptr;
+    h->owner = false;
     h->d_ui_ptr = h->d_ui_items = nullptr;
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -176,6 +180,7 @@ extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_cond
     h->use_graph = !(flags & CMI_FLAG_NO_GRAPH);
     h->want_flow = flags & CMI_FLAG_SCHED_FLOW;
     h->want_two_lane = flags & CMI_FLAG_TWO_LANE;
+    h->want_owner = flags & CMI_FLAG_SCHED_OWNER;
     const char *step = "";
     hipError_t e = hipSuccess;
 #define TRY(x)                                                                                          \
@@ -400,7 +405,8 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     LevelSchedule sch;
     FlowSchedule fsch;
     ChainSchedule csch;
-    const bool chain_ok = !h->serial && !h->want_flow && !h->want_two_lane && !(h->flags & CMI_FLAG_NO_CHAIN) &&
+    OwnerSchedule osch;
+    const bool chain_ok = !h->serial && !h->want_flow && !h->want_two_lane && !h->want_owner && !(h->flags & CMI_FLAG_NO_CHAIN) &&
                           has_chain_path(h->model, h->k, dmax, h->n_conds, h->f64, h->strict) && !getenv("CMI_NO_CHAIN");
     if ((h->flags & CMI_FLAG_SCHED_CHAIN) && !chain_ok)
         CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: CMI_FLAG_SCHED_CHAIN: no hub-chain kernel for model %d, k=%d, %s state%s (or another "
@@ -418,7 +424,37 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             h->flow = true;
         }
     }
-    if (h->flow) {
+    h->owner = false;
+    if (h->want_owner) {
+        if (h->serial || h->want_flow || h->want_two_lane || !has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict))
+            CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: CMI_FLAG_SCHED_OWNER: no owner kernel for model %d, k=%d, %d conditions, %s state%s (or "
+                     "another schedule flag is set)", h->model, h->k, h->n_conds, h->f64 ? "fp64" : "fp32", h->strict ? ", strict" : "");
+        int hub = -1;
+        if (const char *env = getenv("CMI_OWNER_HUB")) hub = !strcmp(env, "item") ? 1 : (!strcmp(env, "user") ? 0 : -1);
+        if (n > 0) {
+            // the owners must all be resident: as many as the device holds wavefronts of the kernel (either hub side: same registers)
+            int waves = owner_grid_waves(h->device, h->model, h->k, h->f64, true);
+            if (const char *env = getenv("CMI_OWNER_WAVES")) {
+                const int v = atoi(env);
+                if (v >= 1 && v < waves) waves = v;
+            }
+            if (waves < 1) CMI_FAIL(h, CMI_E_HIP, "set_ratings: owner kernel occupancy query failed");
+            if (!build_owner_schedule(n, u, j, h->n_users, h->n_items, hub, waves, owner_depth(), osch))
+                CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: owner schedule construction failed");
+            h->owner = true;
+            h->owner_hub_item = osch.hub_is_item != 0;
+            h->n_owners = waves;
+        }
+    }
+    if (h->owner) {
+        h->level_off = {0, n};
+        h->max_level = osch.max_load;
+        h->slot_off = {0, (int64_t)h->n_owners};
+        h->n_slots = h->n_owners;
+        h->sched_levels = 1;
+        h->two_lane = false;
+        sch.perm.swap(osch.perm);
+    } else if (h->flow) {
         h->level_off = {0, (int64_t)fsch.perm.size()};
         h->max_level = fsch.max_level;
         h->n_chunks = fsch.n_chunks();
@@ -556,6 +592,36 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // cp/cc are locals
     }
     if (e == hipSuccess && h->chain) e = upload((void **)&h->d_unit_off, csch.unit_off, h->stream);
+    if (e == hipSuccess && h->owner) {
+        const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
+        h->own_stride = owner_record_stride(h->model, h->k, h->n_conds, h->f64, h->owner_hub_item);
+        const int64_t stride128 = h->own_stride / 16; // granules of 8 bytes -> 128-byte units
+        if ((int64_t)n_spokes * stride128 >= ((int64_t)1 << 32)) {
+            free_ratings(h);
+            CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: owner schedule: the record table exceeds 2^32 x 128 bytes");
+        }
+        std::vector<OwnerRec> recs((size_t)n);
+        for (int64_t s = 0; s < n; ++s) {
+            const int64_t t = sch.perm[(size_t)s];
+            OwnerRec &q = recs[(size_t)s];
+            q.off128 = (uint32_t)((int64_t)(h->owner_hub_item ? u[t] : j[t]) * stride128);
+            q.hub = h->owner_hub_item ? j[t] : u[t];
+            q.want = osch.want[(size_t)s];
+            q.flags = osch.flags[(size_t)s];
+            q.mask = 0;
+            if (contextual)
+                for (int32_t c = ctx_ptr[ctx[t]]; c < ctx_ptr[ctx[t] + 1]; ++c) q.mask |= (uint64_t)1 << ctx_conds[c];
+            q.rating.d = 0.0;
+            if (h->f64) q.rating.d = r[t];
+            else q.rating.f = (float)r[t];
+        }
+        e = upload((void **)&h->d_own_recs, recs, h->stream);
+        if (e == hipSuccess) e = upload((void **)&h->d_own_off, osch.own_off, h->stream);
+        if (e == hipSuccess) e = hipMalloc(&h->d_tagged, (size_t)n_spokes * (size_t)h->own_stride * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_flow_err, 16);
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_flow_err, 0, 16, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // recs is a local
+    }
     if (e == hipSuccess && h->model == CMI_MODEL_SVDPP) {
         // userItemsCache = train.rowColumnsCache (SVDPlusPlus.java:52): the items of every user in the 2-D train matrix, ascending
         std::vector<int32_t> ptr((size_t)h->n_users + 1, 0), items((size_t)n);
@@ -592,7 +658,8 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         CMI_FAIL(h, CMI_E_HIP, "set_ratings: upload failed: %s", hipGetErrorString(e));
     }
     h->n = n;
-    h->tuple_bytes = ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + (h->flow ? 8 : 0)) + (h->chain ? 4 * (h->n_units + 1) : 0);
+    h->tuple_bytes = h->owner ? ns * (int64_t)sizeof(OwnerRec)
+                              : ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + (h->flow ? 8 : 0)) + (h->chain ? 4 * (h->n_units + 1) : 0);
     h->have_ratings = true;
     return CMI_OK;
 }
@@ -608,8 +675,8 @@ extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[8]) {
     for (int w = 0; w < CMI_STATE_COUNT; ++w) sb += h->state_count[w] * (int64_t)esize(h);
     info[4] = sb;
     info[5] = h->tuple_bytes;
-    info[6] = h->flow ? 2 : (h->serial ? 1 : (h->two_lane ? 3 : (h->chain ? (h->chain_hub_item ? 4 : 5) : 0)));
-    info[7] = h->flow ? h->flow_blocks : (h->chain ? h->n_units : (h->d_blk_off ? (int64_t)h->blk_off.size() - 1 : 0));
+    info[6] = h->owner ? (h->owner_hub_item ? 6 : 7) : h->flow ? 2 : (h->serial ? 1 : (h->two_lane ? 3 : (h->chain ? (h->chain_hub_item ? 4 : 5) : 0)));
+    info[7] = h->owner ? h->n_owners : h->flow ? h->flow_blocks : (h->chain ? h->n_units : (h->d_blk_off ? (int64_t)h->blk_off.size() - 1 : 0));
     return CMI_OK;
 }
 
@@ -684,6 +751,15 @@ static hipError_t enqueue_levels(cmi_instance *h) {
         if (h->f64) return launch_serial<double>(make_args<double>(h), cfg, h->n, h->d_loss, h->stream);
         return launch_serial<float>(make_args<float>(h), cfg, h->n, h->d_loss, h->stream);
     }
+    if (h->owner) {
+        const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
+        e = h->f64 ? launch_owner_epoch<double>(make_args<double>(h), h->model, h->owner_hub_item, h->d_own_recs, h->d_own_off, h->n_owners, h->d_tagged,
+                                                h->own_stride, n_spokes, h->d_flow_err, h->stream)
+                   : launch_owner_epoch<float>(make_args<float>(h), h->model, h->owner_hub_item, h->d_own_recs, h->d_own_off, h->n_owners, h->d_tagged,
+                                               h->own_stride, n_spokes, h->d_flow_err, h->stream);
+        if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);
+        return e;
+    }
     if (h->flow) {
         FlowArgs fa{h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->n_chunks, getenv("CMI_FLOW_STATS") ? 1 : 0};
         e = hipMemsetAsync(h->d_ver_u, 0, (size_t)h->n_users * 4, h->stream);
@@ -750,7 +826,7 @@ static int enqueue_epoch(cmi_instance *h, double lrate) {
         return CMI_OK;
     }
     // a graph of several hundred thousand kernel nodes is neither instantiable in reasonable time nor useful
-    const bool graph = h->use_graph && !h->serial && !h->flow && (h->n_tail > 0 ? h->n_launches : (int64_t)h->level_off.size() - 1) <= 65536;
+    const bool graph = h->use_graph && !h->serial && !h->flow && !h->owner && (h->n_tail > 0 ? h->n_launches : (int64_t)h->level_off.size() - 1) <= 65536;
     if (graph && !h->graph_exec && h->two_lane) {
         // explicit DAG: head(l) <- head(l-1), tail(l-2) ; tail(l) <- tail(l-1), head(l-1)
         hipGraph_t g = nullptr;
@@ -822,7 +898,7 @@ extern "C" int cmi_last_loss(cmi_handle h, double *loss_out) {
     CMI_HIP(h, hipSetDevice(h->device));
     CMI_HIP(h, hipMemcpyAsync(h->h_loss, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     int32_t flow_stat[4] = {0, 0, 0, 0};
-    if (h->flow) CMI_HIP(h, hipMemcpyAsync(flow_stat, h->d_flow_err, 16, hipMemcpyDeviceToHost, h->stream));
+    if (h->flow || h->owner) CMI_HIP(h, hipMemcpyAsync(flow_stat, h->d_flow_err, 16, hipMemcpyDeviceToHost, h->stream));
     CMI_HIP(h, hipStreamSynchronize(h->stream));
     const int32_t flow_err = flow_stat[0];
     if (h->flow && getenv("CMI_FLOW_STATS"))
@@ -1234,6 +1310,22 @@ extern "C" int cmi_chain_schedule(int64_t n, const int32_t *u, const int32_t *j,
     std::copy(cs.perm.begin(), cs.perm.end(), perm);
     std::copy(cs.unit_off.begin(), cs.unit_off.end(), unit_off);
     std::copy(cs.level_off.begin(), cs.level_off.end(), level_off);
+    return CMI_OK;
+}
+
+extern "C" int cmi_owner_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int n_owners,
+                                  int depth, int32_t *perm, int64_t *own_off, uint32_t *want, uint32_t *flags, int *hub_used) {
+    if (n < 0 || (n > 0 && (!u || !j)) || n_users <= 0 || n_items <= 0 || n_owners < 1 || depth < 1 || !perm || !own_off || !want || !flags)
+        return CMI_E_INVALID;
+    for (int64_t t = 0; t < n; ++t)
+        if (u[t] < 0 || u[t] >= n_users || j[t] < 0 || j[t] >= n_items) return CMI_E_INVALID;
+    OwnerSchedule os;
+    if (!build_owner_schedule(n, u, j, n_users, n_items, hub, n_owners, depth, os)) return CMI_E_UNSUPPORTED;
+    if (hub_used) *hub_used = os.hub_is_item;
+    std::copy(os.perm.begin(), os.perm.end(), perm);
+    std::copy(os.own_off.begin(), os.own_off.end(), own_off);
+    std::copy(os.want.begin(), os.want.end(), want);
+    std::copy(os.flags.begin(), os.flags.end(), flags);
     return CMI_OK;
 }
 

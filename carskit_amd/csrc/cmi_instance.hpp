@@ -18,6 +18,13 @@ struct cmi_instance {
     bool chain = false, chain_hub_item = true; // hub-chain level schedule: level_off holds UNIT indices, d_unit_off the units
     int32_t *d_unit_off = nullptr;
     int64_t n_units = 0;
+    // owner (dataflow) schedule: one persistent launch, d_own_recs = the owners' lists, d_tagged = the spoke side's tagged records
+    bool want_owner = false, owner = false, owner_hub_item = true;
+    int n_owners = 0;
+    cmi::OwnerRec *d_own_recs = nullptr;
+    int64_t *d_own_off = nullptr;
+    void *d_tagged = nullptr;
+    int64_t own_stride = 0;
     std::vector<int64_t> split_off; // two-lane schedule: first tail position of every level
     std::string err;
     hipStream_t stream = nullptr;

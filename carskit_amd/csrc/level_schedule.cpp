@@ -16,6 +16,9 @@
 // CMI_FLAG_SCHED_SERIAL.)
 #include "level_schedule.hpp"
 
+#include <queue>
+#include <functional>
+#include <utility>
 #include <algorithm>
 #include <numeric>
 
@@ -322,6 +325,103 @@ static void chain_pass(int64_t n, const int32_t *hub, const int32_t *spoke, int3
         if (l > n_levels) n_levels = l;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// owner (dataflow) schedule
+// ---------------------------------------------------------------------------------------------
+// Heavy-tailed degrees make the dependency levels narrow: the hottest row's tuples form one chain as long as its degree, and a
+// level-synchronous epoch pays a launch (or a workgroup barrier) per link.  Here every hub row has ONE owner for the whole epoch.  An
+// owner walks the tuples of all its rows in CRS order, so
+//   * the chain along a hub row never leaves the owner's registers (OWN_HUB_FWD: same hub row as the owner's previous tuple);
+//   * the only state that crosses owners is the spoke row, whose record in HBM carries, in every 8-byte granule, the number of
+//     updates applied to it so far this epoch; a tuple may use the record once every granule carries want[pos];
+//   * the tuple with the smallest CRS index that has not run yet is always at the head of its owner's list and all its predecessors
+//     have run, so with every owner resident the epoch cannot deadlock.
+// Rows are dealt to owners longest-processing-time-first (a heap over the owners' loads), so the hottest rows sit alone.
+bool build_owner_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int n_owners,
+                          int depth, OwnerSchedule &out) {
+    if (n < 0 || n >= ((int64_t)1 << 31) - 1024 || n_owners < 1 || depth < 1) return false;
+    std::vector<int64_t> deg_u((size_t)n_users, 0), deg_j((size_t)n_items, 0);
+    for (int64_t t = 0; t < n; ++t) {
+        deg_u[(size_t)u[t]]++;
+        deg_j[(size_t)j[t]]++;
+    }
+    if (hub < 0) {
+        int64_t mu = 0, mj = 0;
+        for (int64_t d : deg_u) mu = std::max(mu, d);
+        for (int64_t d : deg_j) mj = std::max(mj, d);
+        hub = mj >= mu ? 1 : 0;
+    }
+    out.hub_is_item = hub ? 1 : 0;
+    const int32_t *hv = hub ? j : u, *sv = hub ? u : j;
+    const int32_t n_hubs = hub ? n_items : n_users, n_spokes = hub ? n_users : n_items;
+    const std::vector<int64_t> &deg = hub ? deg_j : deg_u;
+
+    // longest-processing-time-first: rows by degree (descending, ties by id), each to the least loaded owner (ties by owner id)
+    std::vector<int32_t> order;
+    order.reserve((size_t)n_hubs);
+    for (int32_t x = 0; x < n_hubs; ++x)
+        if (deg[(size_t)x] > 0) order.push_back(x);
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] != deg[(size_t)b] ? deg[(size_t)a] > deg[(size_t)b] : a < b; });
+    typedef std::pair<int64_t, int32_t> Load; // (tuples, owner)
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (int32_t w = 0; w < n_owners; ++w) heap.push(Load(0, w));
+    std::vector<int32_t> owner((size_t)n_hubs, -1);
+    std::vector<int64_t> load((size_t)n_owners, 0);
+    for (int32_t x : order) {
+        Load l = heap.top();
+        heap.pop();
+        owner[(size_t)x] = l.second;
+        l.first += deg[(size_t)x];
+        load[(size_t)l.second] = l.first;
+        heap.push(l);
+    }
+    out.own_off.assign((size_t)n_owners + 1, 0);
+    out.max_load = 0;
+    for (int32_t w = 0; w < n_owners; ++w) {
+        out.own_off[(size_t)w + 1] = out.own_off[(size_t)w] + load[(size_t)w];
+        out.max_load = std::max(out.max_load, load[(size_t)w]);
+    }
+    // the owners' lists, each in CRS order; want = the spoke row's update count before the tuple
+    out.perm.assign((size_t)n, 0);
+    out.want.assign((size_t)n, 0);
+    out.flags.assign((size_t)n, 0);
+    {
+        std::vector<int64_t> cur(out.own_off.begin(), out.own_off.end() - 1);
+        std::vector<uint32_t> seen((size_t)n_spokes, 0);
+        for (int64_t t = 0; t < n; ++t) {
+            const int64_t pos = cur[(size_t)owner[(size_t)hv[t]]]++;
+            out.perm[(size_t)pos] = (int32_t)t;
+            out.want[(size_t)pos] = seen[(size_t)sv[t]]++;
+        }
+    }
+    std::vector<int64_t> last_pos((size_t)n_hubs, -1); // list position of the hub row's previous tuple
+    for (int32_t w = 0; w < n_owners; ++w) {
+        const int64_t b = out.own_off[(size_t)w], e = out.own_off[(size_t)w + 1];
+        for (int64_t pos = b; pos < e; ++pos) {
+            const int64_t t = out.perm[(size_t)pos];
+            uint32_t f = 0;
+            const int64_t lp = last_pos[(size_t)hv[t]];
+            if (lp >= 0) {
+                if (pos - lp == 1) f |= OWN_HUB_FWD;
+                else if (pos - lp <= depth) f |= OWN_HUB_LATE;
+            }
+            last_pos[(size_t)hv[t]] = pos;
+            if (pos > b) {
+                const int64_t tp = out.perm[(size_t)pos - 1];
+                if (sv[tp] == sv[t] && out.want[(size_t)pos] == out.want[(size_t)pos - 1] + 1) f |= OWN_SPK_FWD;
+            }
+            out.flags[(size_t)pos] = f;
+        }
+        for (int64_t pos = b; pos < e; ++pos) { // a row goes back to HBM when the next tuple does not take it over in registers
+            const uint32_t nf = pos + 1 < e ? out.flags[(size_t)pos + 1] : 0u;
+            if (!(nf & OWN_HUB_FWD)) out.flags[(size_t)pos] |= OWN_HUB_STORE;
+            if (!(nf & OWN_SPK_FWD)) out.flags[(size_t)pos] |= OWN_SPK_STORE;
+        }
+    }
+    return true;
+}
+
 
 int64_t count_plain_levels(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items) {
     if (n <= 0) return 0;

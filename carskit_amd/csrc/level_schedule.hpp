@@ -60,6 +60,24 @@ struct ChainSchedule {
 bool build_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int max_chain,
                           ChainSchedule &out);
 
+// Owner (dataflow) schedule for heavy-tailed degrees (see build_owner_schedule in level_schedule.cpp): every hub row (an item, or a
+// user) belongs to ONE owner -- a wavefront of the persistent sgd_owner kernel -- which walks all tuples of its rows in CRS order with
+// the current hub row in registers; the other side's rows (spokes) travel between owners through tagged records in HBM.
+enum { OWN_HUB_FWD = 1, OWN_HUB_LATE = 2, OWN_HUB_STORE = 4, OWN_SPK_FWD = 8, OWN_SPK_STORE = 16 };
+struct OwnerSchedule {
+    std::vector<int32_t> perm;     // list position -> CRS tuple index; an owner's tuples are contiguous, in CRS order
+    std::vector<int64_t> own_off;  // n_owners+1 offsets into perm
+    std::vector<uint32_t> want;    // per position: how many earlier tuples of the epoch share its spoke row (= the tag it must carry)
+    std::vector<uint32_t> flags;   // per position: OWN_* bits
+    int hub_is_item = 1;
+    int64_t max_load = 0;          // tuples of the busiest owner
+    int64_t n_owners() const { return (int64_t)own_off.size() - 1; }
+};
+// hub: 0 = users are owned, 1 = items are owned, -1 = the side with the larger maximum degree.  depth = prefetch distance of the
+// kernel (a hub row written fewer than depth+1 places back in the owner's list must be re-read late, OWN_HUB_LATE).
+bool build_owner_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int n_owners,
+                          int depth, OwnerSchedule &out);
+
 // number of levels of the plain schedule (longest dependency chain), without building it
 int64_t count_plain_levels(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items);
 

@@ -172,4 +172,26 @@ hipError_t launch_ext_rank_queries(const ExtEvalArgs<T> &a, const int32_t *qu, c
 // dtype conversion for cmi_set_state / cmi_get_state staging
 hipError_t launch_convert(const void *src, int src_f64, void *dst, int dst_f64, int64_t n, hipStream_t s);
 
+
+// ---- owner (dataflow) epoch for heavy-tailed degrees (owner_kernels.hip; schedule: build_owner_schedule) ----
+struct OwnerRec {       // one tuple of an owner's list, read through scalar loads (32 bytes)
+    uint32_t off128;    // the spoke row's tagged record, in 128-byte units from the start of the record table
+    int32_t hub;        // the row the owner keeps
+    uint32_t want;      // tag the spoke record must carry (= its update count before this tuple)
+    uint32_t flags;     // OWN_* (level_schedule.hpp)
+    uint64_t mask;      // bit c = condition c is in the tuple's context (used as a lane mask)
+    union {
+        double d;       // fp64 state
+        float f;        // fp32 state
+    } rating;
+};
+bool has_owner_path(int model, int k, int n_conds, bool f64, bool strict);
+int owner_depth();                                                                        // read-ahead distance of the kernel
+int64_t owner_record_stride(int model, int k, int n_conds, bool f64, bool hub_is_item);   // granules (8 bytes) per spoke record
+int owner_grid_waves(int device, int model, int k, bool f64, bool hub_is_item);           // owners that are resident together
+// tag pass + the persistent epoch + untag pass; loss partials in a.loss_part[0 .. n_owners)
+template <typename T>
+hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, const OwnerRec *recs, const int64_t *own_off, int n_owners,
+                              void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s);
+
 } // namespace cmi

@@ -1,0 +1,493 @@
+// owner_kernels.hip -- the owner (dataflow) epoch for heavy-tailed degrees: ONE persistent launch, no levels.
+//
+// Schedule: level_schedule.cpp, build_owner_schedule.  Every hub row (an item, or a user) has one owner for the whole epoch: a
+// wavefront of sgd_owner.  The owner walks the tuples of all its rows in CRS order (SGD order of the reference, IterativeRecommender /
+// CAMF_CI.java:66-121 and siblings), which makes the epoch order-exact by construction:
+//   * hub side (Q row, itemBias, icBias row when items are owned): private to the owner, plain loads/stores; while consecutive tuples
+//     of the list share the hub row it stays in registers -- the chain along the hottest row, which a level schedule pays a launch
+//     or a barrier per link for, costs one dot product + one axpy of latency per link here;
+//   * spoke side (P row, userBias, ucBias row): the row's RECORD in a tagged copy of the table.  A record is a run of 8-byte granules
+//     {tag, 32 data bits}, written by single 8-byte device-coherent (sc1, write-through) stores and read by 8-byte sc1 loads; the tag
+//     is the number of updates applied to the row so far this epoch.  The tuple that needs update count `want` may use the record
+//     once EVERY granule carries tag == want: the data is the flag, so there is no separate version word, no store drain and no
+//     fence (CDNA4 hand-off recipe R2: data-tagged granules).  A granule is never torn (one aligned 8-byte store) and a record in
+//     mid-update simply fails the test.  The updated record is written back with tag want + 1.
+//   * records are read D tuples AHEAD of their use (speculatively: a record that was not ready yet fails its tag test at use, and
+//     only then does the owner poll) -- the owner of a hot row is bound by the arithmetic chain, not by HBM latency.
+// A tag pass before the launch builds the records (tag 0) from the model tables and an untag pass after it writes them back, both
+// at copy speed.  Everything in sgd_owner is wave-uniform: one tuple per wavefront step, the tuple's fields arrive through scalar
+// loads, and lane l holds elements l, l+64, ... of each row, condition l of the context-bias rows.
+#include "sgd_device.hpp"
+#include "level_schedule.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace cmi {
+
+typedef unsigned long long gran_t;
+
+__device__ __forceinline__ gran_t ld_gran(const gran_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_gran(gran_t *p, gran_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One model element (T) as tagged granules: fp32 = one granule, fp64 = two (low word, high word).
+template <typename T>
+struct Tagged;
+template <>
+struct Tagged<float> {
+    static constexpr int NW = 1;
+    struct Raw {
+        gran_t g0;
+    };
+    static __device__ __forceinline__ Raw zero() { return Raw{0ull}; }
+    static __device__ __forceinline__ Raw load(const gran_t *rec, int e) { return Raw{ld_gran(rec + e)}; }
+    static __device__ __forceinline__ bool ok(const Raw &r, uint32_t want) { return (uint32_t)(r.g0 >> 32) == want; }
+    static __device__ __forceinline__ float value(const Raw &r) { return __uint_as_float((uint32_t)r.g0); }
+    static __device__ __forceinline__ void store(gran_t *rec, int e, float v, uint32_t tag) {
+        st_gran(rec + e, ((gran_t)tag << 32) | (gran_t)__float_as_uint(v));
+    }
+    static __device__ __forceinline__ void store_plain(gran_t *rec, int e, float v, uint32_t tag) {
+        rec[e] = ((gran_t)tag << 32) | (gran_t)__float_as_uint(v);
+    }
+};
+template <>
+struct Tagged<double> {
+    static constexpr int NW = 2;
+    struct Raw {
+        gran_t g0, g1;
+    };
+    static __device__ __forceinline__ Raw zero() { return Raw{0ull, 0ull}; }
+    static __device__ __forceinline__ Raw load(const gran_t *rec, int e) { return Raw{ld_gran(rec + 2 * e), ld_gran(rec + 2 * e + 1)}; }
+    static __device__ __forceinline__ bool ok(const Raw &r, uint32_t want) {
+        return (uint32_t)(r.g0 >> 32) == want && (uint32_t)(r.g1 >> 32) == want;
+    }
+    static __device__ __forceinline__ double value(const Raw &r) {
+        return __longlong_as_double((long long)(((gran_t)(uint32_t)r.g1 << 32) | (gran_t)(uint32_t)r.g0));
+    }
+    static __device__ __forceinline__ void store(gran_t *rec, int e, double v, uint32_t tag) {
+        const gran_t b = (gran_t)__double_as_longlong(v);
+        st_gran(rec + 2 * e, ((gran_t)tag << 32) | (b & 0xffffffffull));
+        st_gran(rec + 2 * e + 1, ((gran_t)tag << 32) | (b >> 32));
+    }
+    static __device__ __forceinline__ void store_plain(gran_t *rec, int e, double v, uint32_t tag) {
+        const gran_t b = (gran_t)__double_as_longlong(v);
+        rec[2 * e] = ((gran_t)tag << 32) | (b & 0xffffffffull);
+        rec[2 * e + 1] = ((gran_t)tag << 32) | (b >> 32);
+    }
+};
+
+// Which containers sit on which side (spoke = the side that travels in records).
+template <int MODEL, bool HUB_ITEM>
+struct Sides {
+    using M = Traits<MODEL>;
+    static constexpr bool HB = HUB_ITEM ? M::has_bj : M::has_bu; // hub scalar bias
+    static constexpr bool SB = HUB_ITEM ? M::has_bu : M::has_bj; // spoke scalar bias
+    static constexpr bool HC = HUB_ITEM ? M::has_ic : M::has_uc; // hub context-bias row
+    static constexpr bool SC = HUB_ITEM ? M::has_uc : M::has_ic; // spoke context-bias row
+};
+
+// Record layout, in elements: [0, 64 VPL) the factor row PADDED to whole wavefronts (lane l owns elements l VPL .. l VPL + VPL - 1),
+// then 64 elements of the context-bias row (lane c = condition c) when the spoke side has one, then the scalar bias.  The padding is
+// what lets the steady state run without a single masked access: every lane loads and stores all its granules, the elements past k
+// (past n_conds) are zeros that stay zero under the update.
+__host__ __device__ inline int64_t owner_record_granules(int vpl, bool sc, bool sb, int nw) {
+    const int64_t g = (int64_t)(64 * vpl + (sc ? 64 : 0) + (sb ? 1 : 0)) * nw;
+    return (g + 15) & ~(int64_t)15; // 128-byte multiples (OwnerRec::off128)
+}
+__host__ __device__ inline int owner_vpl(int k) { return k <= 64 ? 1 : (k <= 128 ? 2 : 4); }
+
+// Sum over the wavefront as a uniform value: DPP row rotations (every lane of a 16-lane row gets the row total), then row 0 into
+// row 1 and row 2 into row 3 (row_bcast:15), rows 0+1 into row 3 (row_bcast:31); lane 63 holds ((r2 + r3) + (r0 + r1)).
+__device__ __forceinline__ float wave_total(float x) {
+    x = row_sum16(x);
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xc, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ double wave_total(double x) {
+    x = row_sum16(x);
+    x += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x142, 0xa, 0xf, false),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x142, 0xa, 0xf, false));
+    x += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x143, 0xc, 0xf, false),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x143, 0xc, 0xf, false));
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+
+// ---------------------------------------------------------------------------------------------
+// tag / untag passes: model tables <-> tagged records (one wavefront per record, grid-stride)
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool TO_RECORDS>
+__global__ __launch_bounds__(256) void owner_records(T *__restrict__ rows, T *__restrict__ ctx, T *__restrict__ bias, gran_t *__restrict__ tagged,
+                                                     int64_t stride, int n_spokes, int k, int ncs, int vpl) {
+    const int lane = threadIdx.x & 63;
+    const int row_cap = 64 * vpl;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    for (int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < n_spokes; s += waves) {
+        gran_t *rec = tagged + s * stride;
+        for (int e = lane; e < row_cap; e += 64) {
+            if (TO_RECORDS) Tagged<T>::store_plain(rec, e, e < k ? rows[s * k + e] : (T)0, 0u);
+            else if (e < k) rows[s * k + e] = Tagged<T>::value(Tagged<T>::load(rec, e));
+        }
+        if (ctx) {
+            if (TO_RECORDS) Tagged<T>::store_plain(rec, row_cap + lane, lane < ncs ? ctx[s * ncs + lane] : (T)0, 0u);
+            else if (lane < ncs) ctx[s * ncs + lane] = Tagged<T>::value(Tagged<T>::load(rec, row_cap + lane));
+        }
+        if (bias && lane == 0) {
+            const int e = row_cap + (ctx ? 64 : 0);
+            if (TO_RECORDS) Tagged<T>::store_plain(rec, e, bias[s], 0u);
+            else bias[s] = Tagged<T>::value(Tagged<T>::load(rec, e));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the epoch
+// ---------------------------------------------------------------------------------------------
+#define CMI_OWNER_SPIN_LIMIT (1u << 24)
+
+// what a list position prefetches, D positions ahead of its use
+template <typename T, int VPL>
+struct OwnerSlot {
+    typename Tagged<T>::Raw x[VPL], sc, sb; // spoke record: this lane's row elements, context bias of condition `lane`, scalar bias
+    T hq[VPL], hc, hb;                      // hub side, plain
+};
+
+template <typename T, int MODEL, int VPL, bool HUB_ITEM>
+__device__ __forceinline__ void owner_load_spoke(const gran_t *rec, int lane, OwnerSlot<T, VPL> &s) {
+    using S = Sides<MODEL, HUB_ITEM>;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) s.x[v] = Tagged<T>::load(rec, lane * VPL + v);
+    if (S::SC) s.sc = Tagged<T>::load(rec, 64 * VPL + lane);
+    if (S::SB) s.sb = Tagged<T>::load(rec, 64 * VPL + (S::SC ? 64 : 0)); // the same granule(s) in every lane
+}
+
+template <typename T, int MODEL, int VPL, bool HUB_ITEM>
+__device__ __forceinline__ bool owner_spoke_ok(const OwnerSlot<T, VPL> &s, uint32_t want) {
+    using S = Sides<MODEL, HUB_ITEM>;
+    bool ok = true;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) ok &= Tagged<T>::ok(s.x[v], want);
+    if (S::SC) ok &= Tagged<T>::ok(s.sc, want);
+    if (S::SB) ok &= Tagged<T>::ok(s.sb, want);
+    return ok;
+}
+
+// hub side: the model tables themselves.  Loads are unmasked (a lane past the end of the row reads the row's last element instead and
+// the value is zeroed where it is taken into the working registers): a masked load would need a zeroed default, and the copy that
+// merges the two makes the compiler wait for the load on the spot.
+template <typename T, int MODEL, int VPL, bool HUB_ITEM>
+__device__ __forceinline__ void owner_load_hub(const SgdArgs<T> &a, int hub, int lane, int k, T (&hq)[VPL], T &hc, T &hb) {
+    using S = Sides<MODEL, HUB_ITEM>;
+    const T *row = (HUB_ITEM ? a.Q : a.P) + (size_t)hub * k;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) hq[v] = row[min(lane * VPL + v, k - 1)];
+    if (S::HC) hc = (HUB_ITEM ? a.icBias : a.ucBias)[(size_t)hub * a.n_conds + min(lane, a.n_conds - 1)];
+    if (S::HB) hb = (HUB_ITEM ? a.itemBias : a.userBias)[hub];
+}
+
+__device__ __forceinline__ float owner_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double owner_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// make the compiler finish the loads of `v` here (a wait it places before an instruction that reads the register)
+__device__ __forceinline__ void owner_settle(float &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void owner_settle(double &v) { asm volatile("" : "+v"(v)); }
+
+template <typename T>
+__device__ __forceinline__ T owner_rating(const OwnerRec &r);
+template <>
+__device__ __forceinline__ float owner_rating<float>(const OwnerRec &r) { return r.rating.f; }
+template <>
+__device__ __forceinline__ double owner_rating<double>(const OwnerRec &r) { return r.rating.d; }
+
+// A lone wavefront issues one instruction every four cycles whatever its kind, so the hottest owner's pace is the INSTRUCTION COUNT
+// of a step: the step is written for few instructions -- condition masks go straight into v_cndmask as lane masks (inverse ballot),
+// the wave sum leaves through one readlane, the fp32 update is two fused operations per element (new = (1 - lrate reg) old + (lrate
+// e) other: the same value as old + lrate (e other - reg old) up to rounding; the fp64 kernel keeps the reference's expression and
+// operation order), the loss is accumulated per lane and reduced once per owner.
+template <typename T, int MODEL, int VPL, int D, bool HUB_ITEM>
+__global__ __launch_bounds__(256, 2) void sgd_owner(SgdArgs<T> a, const OwnerRec *__restrict__ recs, const int64_t *__restrict__ own_off,
+                                                    gran_t *tagged, int *error, int n_owners) {
+    using M = Traits<MODEL>;
+    using S = Sides<MODEL, HUB_ITEM>;
+    static_assert(MODEL != CAMF_C, "CAMF_C has no owner schedule (shared condBias)");
+    constexpr bool F32 = sizeof(T) == 4;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (w >= n_owners) return;
+    const int k = a.k;
+    const HParams hpd = *a.hp;
+    const T lr = (T)hpd.lr, regU = (T)hpd.regU, regI = (T)hpd.regI, regB = (T)hpd.regB, regC = (T)hpd.regC, gm = (T)hpd.gm;
+    const T keepU = (T)1 - lr * regU, keepI = (T)1 - lr * regI, keepB = (T)1 - lr * regB, keepC = (T)1 - lr * regC; // fp32 form
+    const int64_t c0 = own_off[w];
+    const int len = (int)(own_off[w + 1] - c0);
+    if (len == 0) {
+        if (lane == 0) a.loss_part[w] = 0.0;
+        return;
+    }
+    recs += c0;
+
+    OwnerSlot<T, VPL> slot[D];
+    // current rows (registers): hub row / context-bias row / bias, and the spoke's after its latest update
+    T h[VPL], hc = (T)0, hb = (T)0, x[VPL], sc = (T)0, sb = (T)0;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) h[v] = x[v] = (T)0;
+    // loss: per lane sums of squares, scaled and reduced once at the end (flushed to double every round of D steps)
+    T sq_p = (T)0, sq_q = (T)0, sq_c = (T)0, sq_e = (T)0, sq_b = (T)0;
+    double acc = 0.0;
+
+    // The spoke record is ALWAYS read ahead (a fixed number of memory operations per step keeps the compiler's counted waits deep);
+    // the hub side only when the step will not take it over in registers.
+    auto prefetch = [&](const OwnerRec &r, OwnerSlot<T, VPL> &s) {
+        owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(tagged + ((size_t)r.off128 << 4), lane, s);
+        if (!(r.flags & (OWN_HUB_FWD | OWN_HUB_LATE))) owner_load_hub<T, MODEL, VPL, HUB_ITEM>(a, r.hub, lane, k, s.hq, s.hc, s.hb);
+    };
+
+#pragma unroll
+    for (int d = 0; d < D; ++d) prefetch(recs[d < len ? d : len - 1], slot[d]);
+    // list entries arrive one step ahead of their use (scalar loads): the step's own, and the one it reads ahead for
+    OwnerRec r_run = recs[0], r_ahead = recs[D < len ? D : len - 1];
+
+    // one step of the list: tuple c, whose read-ahead sits in s; ends by reading ahead for tuple c + D into the same registers
+    auto step = [&](int c, OwnerSlot<T, VPL> &s) {
+        const OwnerRec r = r_run, p = r_ahead;
+        r_run = recs[c + 1 < len ? c + 1 : len - 1];
+        r_ahead = recs[c + 1 + D < len ? c + 1 + D : len - 1];
+        gran_t *rec = tagged + ((size_t)r.off128 << 4);
+
+        // ---- hub side: registers (same row as the previous step) | read ahead | re-read now (written < D steps ago)
+        if (!(r.flags & OWN_HUB_FWD)) {
+            if (r.flags & OWN_HUB_LATE) {
+                owner_load_hub<T, MODEL, VPL, HUB_ITEM>(a, r.hub, lane, k, s.hq, s.hc, s.hb);
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) owner_settle(s.hq[v]);
+                owner_settle(s.hc);
+                owner_settle(s.hb);
+            }
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) h[v] = lane * VPL + v < k ? s.hq[v] : (T)0;
+            if (S::HC) hc = lane < a.n_conds ? s.hc : (T)0;
+            if (S::HB) hb = s.hb;
+        }
+        // ---- spoke side: registers | the record read ahead, if every granule carries the tag | poll
+        if (!(r.flags & OWN_SPK_FWD)) {
+            if (!__all(owner_spoke_ok<T, MODEL, VPL, HUB_ITEM>(s, r.want))) {
+                unsigned spins = 0;
+                while (true) { // the predecessor has not written the record yet (or was in the middle of it)
+                    __builtin_amdgcn_s_sleep(4);
+                    owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rec, lane, s);
+                    if (__all(owner_spoke_ok<T, MODEL, VPL, HUB_ITEM>(s, r.want))) break;
+                    if (++spins > CMI_OWNER_SPIN_LIMIT) {
+                        if (lane == 0) atomicExch(error, 1);
+                        break;
+                    }
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) x[v] = Tagged<T>::value(s.x[v]);
+            if (S::SC) sc = Tagged<T>::value(s.sc);
+            if (S::SB) sb = Tagged<T>::value(s.sb);
+        }
+
+        // ---- prediction: gm + bu + bj + (p.q + the context deviations); lane c adds the deviations of condition c
+        const bool sel = M::has_ctx && __builtin_amdgcn_inverse_ballot_w64(r.mask);
+        T part = (T)0;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) part = owner_fma(x[v], h[v], part);
+        if (M::has_ctx) {
+            T term = (T)0;
+            if (S::HC && S::SC) term = HUB_ITEM ? hc + sc : sc + hc; // bic + buc
+            else if (S::HC) term = hc;
+            else if (S::SC) term = sc;
+            part += sel ? term : (T)0;
+        }
+        const T tot = wave_total(part);
+        const T bu = HUB_ITEM ? sb : hb, bj = HUB_ITEM ? hb : sb;
+        T pred = gm;
+        if (M::has_bu) pred += bu;
+        if (M::has_bj) pred += bj;
+        pred += tot;
+        const T e = owner_rating<T>(r) - pred;
+
+        // ---- loss pieces (old values)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const T pv = HUB_ITEM ? x[v] : h[v], qv = HUB_ITEM ? h[v] : x[v];
+            sq_p = owner_fma(pv, pv, sq_p);
+            sq_q = owner_fma(qv, qv, sq_q);
+        }
+        if (M::has_ctx) {
+            T cc = sq_c;
+            if (S::HC) cc = owner_fma(hc, hc, cc);
+            if (S::SC) cc = owner_fma(sc, sc, cc);
+            sq_c = sel ? cc : sq_c;
+        }
+        sq_e = owner_fma(e, e, sq_e);
+        if (M::has_bu) sq_b = owner_fma(bu, bu, sq_b);
+        if (M::has_bj) sq_b = owner_fma(bj, bj, sq_b);
+
+        // ---- updates (all from the old values)
+        if constexpr (F32) {
+            const T le = lr * e;
+            if (S::HB) hb = owner_fma(keepB, hb, le);
+            if (S::SB) sb = owner_fma(keepB, sb, le);
+            if (S::HC) hc = sel ? owner_fma(keepC, hc, le) : hc;
+            if (S::SC) sc = sel ? owner_fma(keepC, sc, le) : sc;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                const T pv = HUB_ITEM ? x[v] : h[v], qv = HUB_ITEM ? h[v] : x[v];
+                const T pn = owner_fma(le, qv, keepU * pv);
+                const T qn = owner_fma(le, pv, keepI * qv);
+                x[v] = HUB_ITEM ? pn : qn;
+                h[v] = HUB_ITEM ? qn : pn;
+            }
+        } else {
+            if (S::HB) hb = hb + lr * (e - regB * hb);
+            if (S::SB) sb = sb + lr * (e - regB * sb);
+            if (S::HC) hc = sel ? hc + lr * (e - regC * hc) : hc;
+            if (S::SC) sc = sel ? sc + lr * (e - regC * sc) : sc;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                const T pv = HUB_ITEM ? x[v] : h[v], qv = HUB_ITEM ? h[v] : x[v];
+                const T pn = pv + lr * (e * qv - regU * pv);
+                const T qn = qv + lr * (e * pv - regI * qv);
+                x[v] = HUB_ITEM ? pn : qn;
+                h[v] = HUB_ITEM ? qn : pn;
+            }
+        }
+
+        // ---- the spoke record goes back with the next tag (always: one store sequence per step); the hub side when the next
+        //      step of the list does not take it over in registers
+        {
+            const uint32_t tag = r.want + 1u;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) Tagged<T>::store(rec, lane * VPL + v, x[v], tag);
+            if (S::SC) Tagged<T>::store(rec, 64 * VPL + lane, sc, tag);
+            if (S::SB) Tagged<T>::store(rec, 64 * VPL + (S::SC ? 64 : 0), sb, tag);
+        }
+        if (r.flags & OWN_HUB_STORE) {
+            T *row = (HUB_ITEM ? a.Q : a.P) + (size_t)r.hub * k;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+                if (lane * VPL + v < k) row[lane * VPL + v] = h[v];
+            if (S::HC && lane < a.n_conds) (HUB_ITEM ? a.icBias : a.ucBias)[(size_t)r.hub * a.n_conds + lane] = hc;
+            if (S::HB && lane == 0) (HUB_ITEM ? a.itemBias : a.userBias)[r.hub] = hb;
+        }
+
+        // ---- read ahead for the step D places down the list (after this step's stores: program order covers a row of this
+        //      owner that comes round again); past the end of the list the last entry is read again, to no effect
+        prefetch(p, s);
+    };
+    auto flush_loss = [&]() {
+        acc += (double)regU * (double)sq_p + (double)regI * (double)sq_q + (double)regC * (double)sq_c;
+        if (lane == 0) acc += (double)sq_e + (double)regB * (double)sq_b; // the uniform terms, once
+        sq_p = sq_q = sq_c = sq_e = sq_b = (T)0;
+    };
+
+    // Full rounds of D steps carry no exit inside the round: an exit edge from the middle of a round to the loop latch would make
+    // the shortest path to the next round's first wait a few operations long, and the compiler would size every wait for it.
+    int base = 0;
+    for (; base + D <= len; base += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) step(base + d, slot[d]);
+        flush_loss();
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+        if (base + d >= len) break;
+        step(base + d, slot[d]);
+    }
+    flush_loss();
+    acc = wave_sum64(acc);
+    if (lane == 0) a.loss_part[w] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static const int OWNER_DEPTH = 8;
+
+bool has_owner_path(int model, int k, int n_conds, bool f64, bool strict) {
+    if (strict) return false;
+    if (model != BIASEDMF && model != PMF && model != CAMF_CI && model != CAMF_CU && model != CAMF_CUCI) return false;
+    if (k < 1 || k > (f64 ? 128 : 256)) return false;
+    const bool has_ctx = model != BIASEDMF && model != PMF;
+    if (has_ctx && n_conds > 64) return false; // lane c carries condition c
+    return true;
+}
+int owner_depth() { return OWNER_DEPTH; }
+
+int64_t owner_record_stride(int model, int k, int n_conds, bool f64, bool hub_is_item) {
+    const bool has_ic = model == CAMF_CI || model == CAMF_CUCI, has_uc = model == CAMF_CU || model == CAMF_CUCI;
+    const bool has_bu = model == BIASEDMF || model == CAMF_CI, has_bj = model == BIASEDMF || model == CAMF_CU;
+    const bool sc = hub_is_item ? has_uc : has_ic, sb = hub_is_item ? has_bu : has_bj;
+    return owner_record_granules(owner_vpl(k), sc, sb, f64 ? 2 : 1);
+}
+
+template <typename T, int MODEL, int VPL>
+static void *owner_kernel_hub(bool hub_is_item) {
+    return hub_is_item ? (void *)sgd_owner<T, MODEL, VPL, OWNER_DEPTH, true> : (void *)sgd_owner<T, MODEL, VPL, OWNER_DEPTH, false>;
+}
+template <typename T, int MODEL>
+static void *owner_kernel_k(int k, bool hub_is_item) {
+    if (k <= 64) return owner_kernel_hub<T, MODEL, 1>(hub_is_item);
+    if (k <= 128) return owner_kernel_hub<T, MODEL, 2>(hub_is_item);
+    if (sizeof(T) == 4) return owner_kernel_hub<float, MODEL, 4>(hub_is_item);
+    return nullptr;
+}
+template <typename T>
+static void *owner_kernel_ptr(int model, int k, bool hub_is_item) {
+    switch (model) {
+    case BIASEDMF: return owner_kernel_k<T, BIASEDMF>(k, hub_is_item);
+    case PMF: return owner_kernel_k<T, PMF>(k, hub_is_item);
+    case CAMF_CI: return owner_kernel_k<T, CAMF_CI>(k, hub_is_item);
+    case CAMF_CU: return owner_kernel_k<T, CAMF_CU>(k, hub_is_item);
+    case CAMF_CUCI: return owner_kernel_k<T, CAMF_CUCI>(k, hub_is_item);
+    }
+    return nullptr;
+}
+
+// Owners = wavefronts that are resident together (a waiting owner must never keep a runnable one off the chip).
+int owner_grid_waves(int device, int model, int k, bool f64, bool hub_is_item) {
+    void *fn = f64 ? owner_kernel_ptr<double>(model, k, hub_is_item) : owner_kernel_ptr<float>(model, k, hub_is_item);
+    if (!fn) return 0;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) return 0;
+    if (per_cu > 2) per_cu = 2; // __launch_bounds__(256, 2); the occupancy query can over-report by one block at high SGPR counts
+    if (const char *env = getenv("CMI_OWNER_BLOCKS_PER_CU")) {
+        const int v = atoi(env);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
+    return cus * per_cu * 4;
+}
+
+template <typename T>
+hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, const OwnerRec *recs, const int64_t *own_off, int n_owners,
+                              void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s) {
+    void *fn = owner_kernel_ptr<T>(model, a.k, hub_is_item);
+    if (!fn) return hipErrorInvalidValue;
+    const bool has_ic = model == CAMF_CI || model == CAMF_CUCI, has_uc = model == CAMF_CU || model == CAMF_CUCI;
+    const bool has_bu = model == BIASEDMF || model == CAMF_CI, has_bj = model == BIASEDMF || model == CAMF_CU;
+    const bool sc = hub_is_item ? has_uc : has_ic, sb = hub_is_item ? has_bu : has_bj;
+    T *rows = hub_is_item ? a.P : a.Q;
+    T *ctx = sc ? (hub_is_item ? a.ucBias : a.icBias) : nullptr;
+    T *bias = sb ? (hub_is_item ? a.userBias : a.itemBias) : nullptr;
+    const int ncs = sc ? a.n_conds : 0, vpl = owner_vpl(a.k);
+    const int pass_blocks = (int)std::min<int64_t>(((int64_t)n_spokes + 3) / 4, 256 * 16);
+    hipLaunchKernelGGL((owner_records<T, true>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl);
+    SgdArgs<T> args = a;
+    gran_t *tg = (gran_t *)tagged;
+    void *params[] = {&args, &recs, &own_off, &tg, &error, &n_owners};
+    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)((n_owners + 3) / 4)), dim3(256), params, 0, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((owner_records<T, false>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl);
+    return hipGetLastError();
+}
+template hipError_t launch_owner_epoch<float>(const SgdArgs<float> &, int, bool, const OwnerRec *, const int64_t *, int, void *, int64_t, int, int *,
+                                              hipStream_t);
+template hipError_t launch_owner_epoch<double>(const SgdArgs<double> &, int, bool, const OwnerRec *, const int64_t *, int, void *, int64_t, int, int *,
+                                               hipStream_t);
+
+} // namespace cmi

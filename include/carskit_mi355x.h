@@ -100,6 +100,10 @@ extern "C" {
                                       chip; same result as the plain level schedule, bit for bit in fp32.
                                       CMI_E_UNSUPPORTED at cmi_set_ratings if the model/k has no chain kernel */
 #define CMI_FLAG_NO_CHAIN 0x100u /* never use the hub-chain schedule (A/B runs against the plain level launches) */
+#define CMI_FLAG_SCHED_OWNER 0x200u /* heavy-tailed degrees: ONE persistent launch per epoch in which every row of the heavy side
+                                     * (items, or users) is owned by one wavefront that walks the row's tuples in CRS order with the
+                                     * row in registers; the other side's rows travel between owners as tagged records
+                                     * (owner_kernels.hip).  Order-exact like the level schedules; k <= 256 (fp64: 128), <= 64 conditions */
 #define CMI_FLAG_NO_GRAPH 0x10u  /* launch the per-level kernels eagerly instead of replaying a hipGraph */
 
 typedef struct cmi_instance *cmi_handle;
@@ -406,6 +410,14 @@ int cmi_narrow_runs(int64_t n_levels, const int64_t *level_off, int64_t max_tupl
                     int64_t *n_launches);
 int cmi_conflict_free_blocks(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int32_t max_block,
                              int32_t *off, int64_t off_cap, int64_t *n_blocks);
+
+/* The owner form behind CMI_FLAG_SCHED_OWNER (level_schedule.cpp, build_owner_schedule).  hub: 1 items are owned, 0 users, -1 the side
+ * with the larger maximum degree (*hub_used reports it).  perm[n]: list position -> CRS tuple (an owner's tuples contiguous, in CRS
+ * order); own_off[n_owners+1]; want[n]: updates of the tuple's spoke row that precede it; flags[n]: bit 0 hub row taken over in
+ * registers from the previous list entry, bit 1 hub row re-read late (written < depth+1 entries back), bit 2 hub row stored, bit 3
+ * spoke row taken over in registers, bit 4 spoke record stored. */
+int cmi_owner_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int n_owners, int depth,
+                       int32_t *perm, int64_t *own_off, uint32_t *want, uint32_t *flags, int *hub_used);
 
 /* The two-lane form behind CMI_FLAG_TWO_LANE (level_schedule.cpp, build_split_schedule): same levels,
  * tuples inside a level sorted by the position of their later predecessor, and split[l] = first position of the

@@ -1,0 +1,128 @@
+"""The owner (dataflow) epoch (carskit_amd/csrc/owner_kernels.hip, CMI_FLAG_SCHED_OWNER) on the GPU.
+
+One persistent launch; rows of the heavy side owned by wavefronts, the other side's rows handed between owners as tagged records.
+Bars: fp64 state -- the order-exact epoch, so state within 1e-11 of the oracle and loss to 1e-10 relative (a stale or torn record
+would be off by ~lrate * error, eight orders above); fp32 state -- the north_star bar (loss 3e-5 relative, state 3e-4).
+Every case runs with few owners (long lists, many rows per owner) and with as many owners as the chip holds (most lists short, the
+hand-offs cross XCDs), on uniform and on heavy-tailed items, for both hub sides.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from carskit_amd import capi, synth
+from tests import util
+from tests.test_gpu_parity import assert_state_equal, make_pair
+
+pytestmark = pytest.mark.gpu
+
+OWNER, F64 = capi.FLAG_SCHED_OWNER, capi.FLAG_STATE_F64
+LEVEL_MODELS = [m for m in util.MODELS if m != "CAMF_C"]
+
+
+def _env(fn, **kv):
+    old = {k: os.environ.get(k) for k in kv}
+    for k, v in kv.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _run(model, data, k, flags, hub, waves, epochs=3, loss_tol=1e-10, exact=False, atol=1e-11):
+    orc, inst = _env(lambda: make_pair(model, data, k, flags | OWNER), CMI_OWNER_HUB=hub, CMI_OWNER_WAVES=waves)
+    info = inst.schedule_info()
+    assert info["kind"] == "owner-" + hub
+    for _ in range(epochs):
+        lo, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
+        assert abs(lo - lg) <= loss_tol * abs(lo), (lo, lg)
+    assert_state_equal(orc, inst, exact=exact, atol=atol)
+    return inst
+
+
+@pytest.mark.parametrize("model", LEVEL_MODELS)
+@pytest.mark.parametrize("hub", ["item", "user"])
+@pytest.mark.parametrize("k", [10, 64, 100, 128])
+def test_owner_f64_vs_oracle(model, hub, k):
+    data = synth.generate(500, 60, 3, 4, 12000, seed=70 + k, item_zipf=1.1)
+    for waves in (5, None):
+        _run(model, data, k, F64, hub, waves)
+
+
+@pytest.mark.parametrize("model", LEVEL_MODELS)
+@pytest.mark.parametrize("hub", ["item", "user"])
+@pytest.mark.parametrize("k", [10, 64, 128, 200, 256])
+def test_owner_f32_vs_oracle_north_star_bar(model, hub, k):
+    data = synth.generate(800, 90, 4, 4, 20000, seed=170 + k, item_zipf=0.8)
+    for waves in (16, None):
+        _run(model, data, k, 0, hub, waves, loss_tol=3e-5, atol=3e-4)
+
+
+@pytest.mark.parametrize("zipf", [None, 1.5])
+def test_owner_uniform_and_very_hot_items(zipf):
+    data = synth.generate(3000, 200, 4, 4, 80000, seed=81, item_zipf=zipf)
+    for model in ("CAMF_CI", "CAMF_CUCI", "BiasedMF"):
+        _run(model, data, 64, F64, "item", None, epochs=2)
+
+
+def test_owner_repeated_pairs_in_many_contexts():
+    """DePaulMovie-like: the same (user, item) pair in several contexts = consecutive list entries sharing BOTH rows (the spoke row
+    is taken over in registers, its record still goes out with every tag)."""
+    data = synth.generate(40, 30, 2, 3, 6000, seed=43)
+    for model in ("CAMF_CI", "CAMF_CU", "CAMF_CUCI"):
+        for hub in ("item", "user"):
+            _run(model, data, 64, F64, hub, 7)
+            _run(model, data, 64, F64, hub, None)
+
+
+def test_owner_64_conditions_and_the_unsupported_shapes():
+    data = synth.generate(300, 50, 4, 16, 9000, seed=44)          # 64 conditions: lane c carries condition c, none to spare
+    assert data.n_conds == 64
+    _run("CAMF_CUCI", data, 32, F64, "item", None)
+    _run("CAMF_CUCI", data, 32, F64, "user", 9)
+    big = synth.generate(300, 50, 5, 16, 9000, seed=45)           # 80 conditions
+    with pytest.raises(capi.CmiError):
+        make_pair("CAMF_CI", big, 32, OWNER)
+    with pytest.raises(capi.CmiError):
+        make_pair("CAMF_CI", data, 300, OWNER)
+    with pytest.raises(capi.CmiError):
+        make_pair("CAMF_CI", data, 200, OWNER | F64)              # fp64 records: k <= 128
+    with pytest.raises(capi.CmiError):
+        make_pair("CAMF_C", data, 32, OWNER | capi.FLAG_SCHED_SERIAL)
+
+
+def test_owner_many_epochs_under_uneven_load_stays_exact():
+    """Heavy-tailed items at a size where the hottest owner walks tens of thousands of tuples while most owners wait on it:
+    the hand-offs happen under load, consumer caches warm.  Ten epochs, checked against the serial fp64 walk on the GPU."""
+    data = synth.generate(20000, 2000, 4, 8, 600000, seed=91, item_zipf=1.1)
+    _, own = _env(lambda: make_pair("CAMF_CI", data, 128, F64 | OWNER), CMI_OWNER_HUB=None, CMI_OWNER_WAVES=None)
+    _, ser = make_pair("CAMF_CI", data, 128, F64 | capi.FLAG_SCHED_SERIAL)
+    assert own.schedule_info()["kind"] == "owner-item"
+    for _ in range(10):
+        lo, ls = own.train_epoch(util.LR), ser.train_epoch(util.LR)
+        assert abs(lo - ls) <= 1e-10 * abs(ls)
+    so, ss = own.get_states(), ser.get_states()
+    for name in ss:
+        assert np.max(np.abs(so[name] - ss[name])) <= 1e-11, name
+
+
+def test_owner_epoch_leaves_the_tables_usable_by_the_other_paths():
+    """The untag pass writes the records back: evaluation (plain table reads) after an owner epoch sees the trained model."""
+    data = util.small_data(n_users=600, n_items=80, n_dims=3, conds_per_dim=4, n=15000, seed=33)
+    train, test = synth.split(data, 0.2)
+    orc, inst = make_pair("CAMF_CI", train, 64, F64 | OWNER)
+    for _ in range(3):
+        orc.epoch(util.LR)
+        inst.train_epoch(util.LR)
+    oe = orc.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
+    ge = inst.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
+    assert abs(oe["RMSE"] - ge["RMSE"]) <= 1e-9 and abs(oe["MAE"] - ge["MAE"]) <= 1e-9
