@@ -595,16 +595,27 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     if (e == hipSuccess && h->owner) {
         const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
         h->own_stride = owner_record_stride(h->model, h->k, h->n_conds, h->f64, h->owner_hub_item);
-        const int64_t stride128 = h->own_stride / 16; // granules of 8 bytes -> 128-byte units
-        if ((int64_t)n_spokes * stride128 >= ((int64_t)1 << 32)) {
+        const int64_t rec_bytes = h->own_stride * 8;
+        if (((int64_t)n_spokes + h->n_owners) * rec_bytes >= ((int64_t)1 << 32) - 65536) {
             free_ratings(h);
-            CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: owner schedule: the record table exceeds 2^32 x 128 bytes");
+            CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: owner schedule: the record table (%d records of %lld bytes) must stay below 4 GB",
+                     n_spokes, (long long)rec_bytes);
         }
-        std::vector<OwnerRec> recs((size_t)n);
+        // every owner's list is followed by 2 x depth inert entries (OWN_NOP) on the owner's dummy record behind the table: the kernel
+        // runs whole rounds of up to `depth` steps and reads entries depth + 1 places ahead, unchecked
+        const int pad = 2 * owner_depth();
+        std::vector<OwnerRec> recs((size_t)n + (size_t)h->n_owners * (size_t)pad);
+        int64_t out = 0;
+        int32_t w = 0;
+        auto nop = [&](int32_t owner) {
+            return OwnerRec{(uint32_t)(((int64_t)n_spokes + owner) * rec_bytes), 0, 0, OWN_HUB_FWD | OWN_SPK_FWD | OWN_NOP, 0, {0.0}};
+        };
+        for (; w < h->n_owners && osch.own_off[(size_t)w + 1] == 0; ++w) // owners without tuples ahead of the first list
+            for (int i = 0; i < pad; ++i) recs[(size_t)out++] = nop(w);
         for (int64_t s = 0; s < n; ++s) {
             const int64_t t = sch.perm[(size_t)s];
-            OwnerRec &q = recs[(size_t)s];
-            q.off128 = (uint32_t)((int64_t)(h->owner_hub_item ? u[t] : j[t]) * stride128);
+            OwnerRec &q = recs[(size_t)out++];
+            q.off = (uint32_t)((int64_t)(h->owner_hub_item ? u[t] : j[t]) * rec_bytes);
             q.hub = h->owner_hub_item ? j[t] : u[t];
             q.want = osch.want[(size_t)s];
             q.flags = osch.flags[(size_t)s];
@@ -614,10 +625,16 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             q.rating.d = 0.0;
             if (h->f64) q.rating.d = r[t];
             else q.rating.f = (float)r[t];
+            while (w < h->n_owners && s + 1 == osch.own_off[(size_t)w + 1]) { // the end of owner w's list (and of empty owners after it)
+                for (int i = 0; i < pad; ++i) recs[(size_t)out++] = nop(w);
+                ++w;
+            }
         }
+        for (; w < h->n_owners; ++w) // owners without tuples (n == 0 never gets here)
+            for (int i = 0; i < pad; ++i) recs[(size_t)out++] = nop(w);
         e = upload((void **)&h->d_own_recs, recs, h->stream);
         if (e == hipSuccess) e = upload((void **)&h->d_own_off, osch.own_off, h->stream);
-        if (e == hipSuccess) e = hipMalloc(&h->d_tagged, (size_t)n_spokes * (size_t)h->own_stride * 8);
+        if (e == hipSuccess) e = hipMalloc(&h->d_tagged, ((size_t)n_spokes + (size_t)h->n_owners) * (size_t)h->own_stride * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_flow_err, 16);
         if (e == hipSuccess) e = hipMemsetAsync(h->d_flow_err, 0, 16, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // recs is a local
@@ -658,7 +675,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         CMI_FAIL(h, CMI_E_HIP, "set_ratings: upload failed: %s", hipGetErrorString(e));
     }
     h->n = n;
-    h->tuple_bytes = h->owner ? ns * (int64_t)sizeof(OwnerRec)
+    h->tuple_bytes = h->owner ? (ns + (int64_t)h->n_owners * 2 * owner_depth()) * (int64_t)sizeof(OwnerRec)
                               : ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + (h->flow ? 8 : 0)) + (h->chain ? 4 * (h->n_units + 1) : 0);
     h->have_ratings = true;
     return CMI_OK;
@@ -904,6 +921,9 @@ extern "C" int cmi_last_loss(cmi_handle h, double *loss_out) {
     if (h->flow && getenv("CMI_FLOW_STATS"))
         fprintf(stderr, "[cmi] flow: cumulative slow-path entries %d, polls spent waiting %d (of %lld wave-steps per epoch)\n",
                 flow_stat[1], flow_stat[2], (long long)h->n_chunks * 4);
+    if (h->owner && getenv("CMI_OWNER_STATS"))
+        fprintf(stderr, "[cmi] owner: cumulative -- busiest owner (%lld tuples per epoch) found %d records not ready and polled %d times; all owners: %d "
+                "records not ready (of %lld tuples per epoch)\n", (long long)h->max_level, flow_stat[1], flow_stat[2], flow_stat[3], (long long)h->n);
     if (flow_err) CMI_FAIL(h, CMI_E_HIP, "dataflow epoch stalled: a tuple waited past its bound for a predecessor (model state is invalid)");
     h->last_loss = *h->h_loss;
     *loss_out = h->last_loss;

@@ -63,7 +63,8 @@ bool build_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t
 // Owner (dataflow) schedule for heavy-tailed degrees (see build_owner_schedule in level_schedule.cpp): every hub row (an item, or a
 // user) belongs to ONE owner -- a wavefront of the persistent sgd_owner kernel -- which walks all tuples of its rows in CRS order with
 // the current hub row in registers; the other side's rows (spokes) travel between owners through tagged records in HBM.
-enum { OWN_HUB_FWD = 1, OWN_HUB_LATE = 2, OWN_HUB_STORE = 4, OWN_SPK_FWD = 8, OWN_SPK_STORE = 16 };
+enum { OWN_HUB_FWD = 1, OWN_HUB_LATE = 2, OWN_HUB_STORE = 4, OWN_SPK_FWD = 8, OWN_SPK_STORE = 16,
+       OWN_NOP = 32 /* list padding, added by cmi_set_ratings */ };
 struct OwnerSchedule {
     std::vector<int32_t> perm;     // list position -> CRS tuple index; an owner's tuples are contiguous, in CRS order
     std::vector<int64_t> own_off;  // n_owners+1 offsets into perm

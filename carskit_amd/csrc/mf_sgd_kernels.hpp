@@ -175,7 +175,7 @@ hipError_t launch_convert(const void *src, int src_f64, void *dst, int dst_f64, 
 
 // ---- owner (dataflow) epoch for heavy-tailed degrees (owner_kernels.hip; schedule: build_owner_schedule) ----
 struct OwnerRec {       // one tuple of an owner's list, read through scalar loads (32 bytes)
-    uint32_t off128;    // the spoke row's tagged record, in 128-byte units from the start of the record table
+    uint32_t off;       // byte offset of the spoke row's tagged record in the record table (< 4 GB: one buffer resource)
     int32_t hub;        // the row the owner keeps
     uint32_t want;      // tag the spoke record must carry (= its update count before this tuple)
     uint32_t flags;     // OWN_* (level_schedule.hpp)

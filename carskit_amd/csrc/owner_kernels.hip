@@ -146,31 +146,84 @@ __global__ __launch_bounds__(256) void owner_records(T *__restrict__ rows, T *__
 // the epoch
 // ---------------------------------------------------------------------------------------------
 #define CMI_OWNER_SPIN_LIMIT (1u << 24)
+static const int OWNER_DEPTH_MAX = 16; // every list is followed by OWNER_DEPTH_MAX + 1 inert entries (cmi_api.cpp), whatever D a kernel uses
+
+// Spoke records go through buffer instructions: one resource over the record table, the record's byte offset in the scalar offset
+// (no address arithmetic per step), 16 bytes = two granules per lane and instruction, device-coherent (sc0 sc1: write-through
+// stores, L1-bypassing loads).  A 16-byte access is two aligned granules; each granule stays whole.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define CMI_OWNER_CPOL 17 /* sc0 sc1 */
+
+// W words (W = 2: one granule, 4: two, 8: four) of this lane at byte `voff` of the record at byte `soff` of the table
+template <int W>
+__device__ __forceinline__ void owner_ld_words(__amdgpu_buffer_rsrc_t rs, int voff, int soff, uint32_t (&w)[W]) {
+    static_assert(W == 2 || W == 4 || W == 8, "one, two or four granules");
+    if constexpr (W == 2) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, CMI_OWNER_CPOL);
+        w[0] = t.x, w[1] = t.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < W / 4; ++i) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * i, soff, CMI_OWNER_CPOL);
+            w[4 * i] = t.x, w[4 * i + 1] = t.y, w[4 * i + 2] = t.z, w[4 * i + 3] = t.w;
+        }
+    }
+}
+template <int W>
+__device__ __forceinline__ void owner_st_words(__amdgpu_buffer_rsrc_t rs, int voff, int soff, const uint32_t (&w)[W]) {
+    if constexpr (W == 2) {
+        u32x2 t;
+        t.x = w[0], t.y = w[1];
+        __builtin_amdgcn_raw_buffer_store_b64(t, rs, voff, soff, CMI_OWNER_CPOL);
+    } else {
+#pragma unroll
+        for (int i = 0; i < W / 4; ++i) {
+            u32x4 t;
+            t.x = w[4 * i], t.y = w[4 * i + 1], t.z = w[4 * i + 2], t.w = w[4 * i + 3];
+            __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff + 16 * i, soff, CMI_OWNER_CPOL);
+        }
+    }
+}
+// element i of a word array {data, tag, data, tag, ...} (fp64: {low, tag, high, tag})
+__device__ __forceinline__ float owner_elem(const uint32_t *w, int i, float) { return __uint_as_float(w[2 * i]); }
+__device__ __forceinline__ double owner_elem(const uint32_t *w, int i, double) {
+    return __hiloint2double((int)w[4 * i + 2], (int)w[4 * i]);
+}
+__device__ __forceinline__ void owner_pack(uint32_t *w, int i, float v, uint32_t tag) { w[2 * i] = __float_as_uint(v), w[2 * i + 1] = tag; }
+__device__ __forceinline__ void owner_pack(uint32_t *w, int i, double v, uint32_t tag) {
+    w[4 * i] = (uint32_t)__double2loint(v), w[4 * i + 1] = tag, w[4 * i + 2] = (uint32_t)__double2hiint(v), w[4 * i + 3] = tag;
+}
 
 // what a list position prefetches, D positions ahead of its use
 template <typename T, int VPL>
 struct OwnerSlot {
-    typename Tagged<T>::Raw x[VPL], sc, sb; // spoke record: this lane's row elements, context bias of condition `lane`, scalar bias
-    T hq[VPL], hc, hb;                      // hub side, plain
+    static constexpr int NW = Tagged<T>::NW;
+    uint32_t xw[VPL * NW * 2], cw[NW * 2], bw[NW * 2]; // spoke record: this lane's row elements, context bias of condition `lane`, bias
+    T hq[VPL], hc, hb;                                 // hub side, plain
 };
 
 template <typename T, int MODEL, int VPL, bool HUB_ITEM>
-__device__ __forceinline__ void owner_load_spoke(const gran_t *rec, int lane, OwnerSlot<T, VPL> &s) {
+__device__ __forceinline__ void owner_load_spoke(__amdgpu_buffer_rsrc_t rs, int soff, int lane, OwnerSlot<T, VPL> &s) {
     using S = Sides<MODEL, HUB_ITEM>;
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) s.x[v] = Tagged<T>::load(rec, lane * VPL + v);
-    if (S::SC) s.sc = Tagged<T>::load(rec, 64 * VPL + lane);
-    if (S::SB) s.sb = Tagged<T>::load(rec, 64 * VPL + (S::SC ? 64 : 0)); // the same granule(s) in every lane
+    constexpr int NW = Tagged<T>::NW;
+    owner_ld_words(rs, lane * (VPL * NW * 8), soff, s.xw);
+    if (S::SC) owner_ld_words(rs, 64 * VPL * NW * 8 + lane * (NW * 8), soff, s.cw);
+    if (S::SB) owner_ld_words(rs, (64 * VPL + (S::SC ? 64 : 0)) * NW * 8, soff, s.bw); // the same granule(s) in every lane
 }
 
 template <typename T, int MODEL, int VPL, bool HUB_ITEM>
 __device__ __forceinline__ bool owner_spoke_ok(const OwnerSlot<T, VPL> &s, uint32_t want) {
     using S = Sides<MODEL, HUB_ITEM>;
+    constexpr int NW = Tagged<T>::NW;
     bool ok = true;
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) ok &= Tagged<T>::ok(s.x[v], want);
-    if (S::SC) ok &= Tagged<T>::ok(s.sc, want);
-    if (S::SB) ok &= Tagged<T>::ok(s.sb, want);
+    for (int i = 0; i < VPL * NW; ++i) ok &= s.xw[2 * i + 1] == want;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        if (S::SC) ok &= s.cw[2 * i + 1] == want;
+        if (S::SB) ok &= s.bw[2 * i + 1] == want;
+    }
     return ok;
 }
 
@@ -207,8 +260,9 @@ __device__ __forceinline__ double owner_rating<double>(const OwnerRec &r) { retu
 // e) other: the same value as old + lrate (e other - reg old) up to rounding; the fp64 kernel keeps the reference's expression and
 // operation order), the loss is accumulated per lane and reduced once per owner.
 template <typename T, int MODEL, int VPL, int D, bool HUB_ITEM>
-__global__ __launch_bounds__(256, 2) void sgd_owner(SgdArgs<T> a, const OwnerRec *__restrict__ recs, const int64_t *__restrict__ own_off,
+__global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec *__restrict__ recs, const int64_t *__restrict__ own_off,
                                                     gran_t *tagged, int *error, int n_owners) {
+    constexpr int NW = Tagged<T>::NW;
     using M = Traits<MODEL>;
     using S = Sides<MODEL, HUB_ITEM>;
     static_assert(MODEL != CAMF_C, "CAMF_C has no owner schedule (shared condBias)");
@@ -220,8 +274,12 @@ __global__ __launch_bounds__(256, 2) void sgd_owner(SgdArgs<T> a, const OwnerRec
     const HParams hpd = *a.hp;
     const T lr = (T)hpd.lr, regU = (T)hpd.regU, regI = (T)hpd.regI, regB = (T)hpd.regB, regC = (T)hpd.regC, gm = (T)hpd.gm;
     const T keepU = (T)1 - lr * regU, keepI = (T)1 - lr * regI, keepB = (T)1 - lr * regB, keepC = (T)1 - lr * regC; // fp32 form
-    const int64_t c0 = own_off[w];
-    const int len = (int)(own_off[w + 1] - c0);
+    // the owner's list, followed by 2 OWNER_DEPTH_MAX inert entries (OWN_NOP: the step computes nothing and stores to / reads ahead from
+    // the owner's dummy record behind the table): enough to complete the last round and to read D + 1 entries past it
+    static_assert(D <= OWNER_DEPTH_MAX, "list padding");
+    const int64_t c0 = own_off[w] + (int64_t)w * (2 * OWNER_DEPTH_MAX);
+    const int len = (int)(own_off[w + 1] - own_off[w]);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tagged, 0, 0xffffffff, 0x00020000);
     if (len == 0) {
         if (lane == 0) a.loss_part[w] = 0.0;
         return;
@@ -236,25 +294,26 @@ __global__ __launch_bounds__(256, 2) void sgd_owner(SgdArgs<T> a, const OwnerRec
     // loss: per lane sums of squares, scaled and reduced once at the end (flushed to double every round of D steps)
     T sq_p = (T)0, sq_q = (T)0, sq_c = (T)0, sq_e = (T)0, sq_b = (T)0;
     double acc = 0.0;
+    int n_late = 0, n_polls = 0;
 
     // The spoke record is ALWAYS read ahead (a fixed number of memory operations per step keeps the compiler's counted waits deep);
     // the hub side only when the step will not take it over in registers.
     auto prefetch = [&](const OwnerRec &r, OwnerSlot<T, VPL> &s) {
-        owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(tagged + ((size_t)r.off128 << 4), lane, s);
+        owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rs, (int)r.off, lane, s);
         if (!(r.flags & (OWN_HUB_FWD | OWN_HUB_LATE))) owner_load_hub<T, MODEL, VPL, HUB_ITEM>(a, r.hub, lane, k, s.hq, s.hc, s.hb);
     };
 
 #pragma unroll
-    for (int d = 0; d < D; ++d) prefetch(recs[d < len ? d : len - 1], slot[d]);
+    for (int d = 0; d < D; ++d) prefetch(recs[d], slot[d]);
     // list entries arrive one step ahead of their use (scalar loads): the step's own, and the one it reads ahead for
-    OwnerRec r_run = recs[0], r_ahead = recs[D < len ? D : len - 1];
+    OwnerRec r_run = recs[0], r_ahead = recs[D];
 
     // one step of the list: tuple c, whose read-ahead sits in s; ends by reading ahead for tuple c + D into the same registers
     auto step = [&](int c, OwnerSlot<T, VPL> &s) {
         const OwnerRec r = r_run, p = r_ahead;
-        r_run = recs[c + 1 < len ? c + 1 : len - 1];
-        r_ahead = recs[c + 1 + D < len ? c + 1 + D : len - 1];
-        gran_t *rec = tagged + ((size_t)r.off128 << 4);
+        r_run = recs[c + 1];
+        r_ahead = recs[c + 1 + D];
+        if (!(r.flags & OWN_NOP)) { // OWN_NOP: past the end of the list; only the fixed store / read-ahead sequence runs, on a dummy record
 
         // ---- hub side: registers (same row as the previous step) | read ahead | re-read now (written < D steps ago)
         if (!(r.flags & OWN_HUB_FWD)) {
@@ -276,18 +335,20 @@ __global__ __launch_bounds__(256, 2) void sgd_owner(SgdArgs<T> a, const OwnerRec
                 unsigned spins = 0;
                 while (true) { // the predecessor has not written the record yet (or was in the middle of it)
                     __builtin_amdgcn_s_sleep(4);
-                    owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rec, lane, s);
+                    owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rs, (int)r.off, lane, s);
                     if (__all(owner_spoke_ok<T, MODEL, VPL, HUB_ITEM>(s, r.want))) break;
                     if (++spins > CMI_OWNER_SPIN_LIMIT) {
                         if (lane == 0) atomicExch(error, 1);
                         break;
                     }
                 }
+                n_late += 1; // statistics: records that were not ready when their step came, and the polls spent on them
+                n_polls += (int)spins + 1;
             }
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) x[v] = Tagged<T>::value(s.x[v]);
-            if (S::SC) sc = Tagged<T>::value(s.sc);
-            if (S::SB) sb = Tagged<T>::value(s.sb);
+            for (int v = 0; v < VPL; ++v) x[v] = owner_elem(s.xw, v, (T)0);
+            if (S::SC) sc = owner_elem(s.cw, 0, (T)0);
+            if (S::SB) sb = owner_elem(s.bw, 0, (T)0);
         }
 
         // ---- prediction: gm + bu + bj + (p.q + the context deviations); lane c adds the deviations of condition c
@@ -326,6 +387,12 @@ __global__ __launch_bounds__(256, 2) void sgd_owner(SgdArgs<T> a, const OwnerRec
         sq_e = owner_fma(e, e, sq_e);
         if (M::has_bu) sq_b = owner_fma(bu, bu, sq_b);
         if (M::has_bj) sq_b = owner_fma(bj, bj, sq_b);
+        // computed HERE: left alone, the compiler sinks these to the end of the round and keeps every step's old rows alive until then
+        owner_settle(sq_p);
+        owner_settle(sq_q);
+        if (M::has_ctx) owner_settle(sq_c);
+        owner_settle(sq_e);
+        if (M::has_bu || M::has_bj) owner_settle(sq_b);
 
         // ---- updates (all from the old values)
         if constexpr (F32) {
@@ -357,14 +424,24 @@ __global__ __launch_bounds__(256, 2) void sgd_owner(SgdArgs<T> a, const OwnerRec
             }
         }
 
+        } // !OWN_NOP
+
         // ---- the spoke record goes back with the next tag (always: one store sequence per step); the hub side when the next
         //      step of the list does not take it over in registers
         {
             const uint32_t tag = r.want + 1u;
+            uint32_t ow[VPL * NW * 2], oc[NW * 2], ob[NW * 2];
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) Tagged<T>::store(rec, lane * VPL + v, x[v], tag);
-            if (S::SC) Tagged<T>::store(rec, 64 * VPL + lane, sc, tag);
-            if (S::SB) Tagged<T>::store(rec, 64 * VPL + (S::SC ? 64 : 0), sb, tag);
+            for (int v = 0; v < VPL; ++v) owner_pack(ow, v, x[v], tag);
+            owner_st_words(rs, lane * (VPL * NW * 8), (int)r.off, ow);
+            if (S::SC) {
+                owner_pack(oc, 0, sc, tag);
+                owner_st_words(rs, 64 * VPL * NW * 8 + lane * (NW * 8), (int)r.off, oc);
+            }
+            if (S::SB) {
+                owner_pack(ob, 0, sb, tag);
+                owner_st_words(rs, (64 * VPL + (S::SC ? 64 : 0)) * NW * 8, (int)r.off, ob);
+            }
         }
         if (r.flags & OWN_HUB_STORE) {
             T *row = (HUB_ITEM ? a.Q : a.P) + (size_t)r.hub * k;
@@ -385,28 +462,38 @@ __global__ __launch_bounds__(256, 2) void sgd_owner(SgdArgs<T> a, const OwnerRec
         sq_p = sq_q = sq_c = sq_e = sq_b = (T)0;
     };
 
-    // Full rounds of D steps carry no exit inside the round: an exit edge from the middle of a round to the loop latch would make
-    // the shortest path to the next round's first wait a few operations long, and the compiler would size every wait for it.
-    int base = 0;
-    for (; base + D <= len; base += D) {
+    // Rounds of D steps with no exit inside the round (an exit edge from the middle of a round to the loop latch would make the
+    // shortest path to the next round's first wait a few operations long, and the compiler would size every wait for it): the list
+    // is followed by inert entries (OWN_NOP) up to a whole number of rounds.
+    for (int base = 0; base < len; base += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) step(base + d, slot[d]);
         flush_loss();
     }
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d) {
-        if (base + d >= len) break;
-        step(base + d, slot[d]);
-    }
-    flush_loss();
     acc = wave_sum64(acc);
-    if (lane == 0) a.loss_part[w] = acc;
+    if (lane == 0) {
+        a.loss_part[w] = acc;
+        if (n_late) { // statistics (CMI_OWNER_STATS): the busiest owner is owner 0
+            if (w == 0) {
+                atomicAdd(error + 1, n_late);
+                atomicAdd(error + 2, n_polls);
+            }
+            atomicAdd(error + 3, n_late);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static const int OWNER_DEPTH = 8;
+// Read-ahead distance.  Loads and write-through stores retire through ONE in-order counter (vmcnt, at most 63 outstanding), so the wait
+// for a record read D steps ago also waits for the stores issued before it, and a write-through store takes microseconds to be
+// acknowledged: the step time cannot go below (store latency) / D.  D = 16 where a step issues 4 memory operations, 8 where it
+// issues more (wider rows) -- 15 x 4 = 60 operations in flight.
+template <typename T, int VPL>
+struct OwnerDepth {
+    static constexpr int D = (sizeof(T) == 4 && VPL <= 2) ? 16 : 8;
+};
 
 bool has_owner_path(int model, int k, int n_conds, bool f64, bool strict) {
     if (strict) return false;
@@ -416,7 +503,7 @@ bool has_owner_path(int model, int k, int n_conds, bool f64, bool strict) {
     if (has_ctx && n_conds > 64) return false; // lane c carries condition c
     return true;
 }
-int owner_depth() { return OWNER_DEPTH; }
+int owner_depth() { return OWNER_DEPTH_MAX; }
 
 int64_t owner_record_stride(int model, int k, int n_conds, bool f64, bool hub_is_item) {
     const bool has_ic = model == CAMF_CI || model == CAMF_CUCI, has_uc = model == CAMF_CU || model == CAMF_CUCI;
@@ -427,7 +514,8 @@ int64_t owner_record_stride(int model, int k, int n_conds, bool f64, bool hub_is
 
 template <typename T, int MODEL, int VPL>
 static void *owner_kernel_hub(bool hub_is_item) {
-    return hub_is_item ? (void *)sgd_owner<T, MODEL, VPL, OWNER_DEPTH, true> : (void *)sgd_owner<T, MODEL, VPL, OWNER_DEPTH, false>;
+    constexpr int D = OwnerDepth<T, VPL>::D;
+    return hub_is_item ? (void *)sgd_owner<T, MODEL, VPL, D, true> : (void *)sgd_owner<T, MODEL, VPL, D, false>;
 }
 template <typename T, int MODEL>
 static void *owner_kernel_k(int k, bool hub_is_item) {
@@ -455,7 +543,7 @@ int owner_grid_waves(int device, int model, int k, bool f64, bool hub_is_item) {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) return 0;
-    if (per_cu > 2) per_cu = 2; // __launch_bounds__(256, 2); the occupancy query can over-report by one block at high SGPR counts
+    if (per_cu > 1) per_cu = 1; // __launch_bounds__(256, 1): one owner per SIMD, the whole register file for its read-ahead
     if (const char *env = getenv("CMI_OWNER_BLOCKS_PER_CU")) {
         const int v = atoi(env);
         if (v >= 1 && v < per_cu) per_cu = v;
