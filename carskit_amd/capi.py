@@ -42,6 +42,7 @@ FLAG_TWO_LANE = 0x40
 FLAG_SCHED_CHAIN = 0x80
 FLAG_NO_CHAIN = 0x100
 FLAG_SCHED_OWNER = 0x200
+FLAG_NO_OWNER = 0x400
 OWN_HUB_FWD, OWN_HUB_LATE, OWN_HUB_STORE, OWN_SPK_FWD, OWN_SPK_STORE = 1, 2, 4, 8, 16
 
 # every symbol include/carskit_mi355x.h declares: (name, restype, argtypes)

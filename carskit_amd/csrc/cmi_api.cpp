@@ -425,10 +425,32 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         }
     }
     h->owner = false;
-    if (h->want_owner) {
-        if (h->serial || h->want_flow || h->want_two_lane || !has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict))
-            CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: CMI_FLAG_SCHED_OWNER: no owner kernel for model %d, k=%d, %d conditions, %s state%s (or "
-                     "another schedule flag is set)", h->model, h->k, h->n_conds, h->f64 ? "fp64" : "fp32", h->strict ? ", strict" : "");
+    if (h->want_owner && (h->serial || h->want_flow || h->want_two_lane || !has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict)))
+        CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: CMI_FLAG_SCHED_OWNER: no owner kernel for model %d, k=%d, %d conditions, %s state%s (or "
+                 "another schedule flag is set)", h->model, h->k, h->n_conds, h->f64 ? "fp64" : "fp32", h->strict ? ", strict" : "");
+    // the hub-chain levels first: wide data is theirs
+    const bool use_chain = !h->flow && !h->serial && chain_ok && n > 0 && try_chain(h, n, u, j, csch);
+    bool use_owner = h->want_owner;
+    if (!use_owner && !use_chain && !h->flow && !h->serial && !h->want_two_lane && !(h->flags & (CMI_FLAG_SCHED_CHAIN | CMI_FLAG_NO_OWNER)) &&
+        !getenv("CMI_NO_OWNER") && has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict)) {
+        // Narrow levels on a large data set = heavy-tailed degrees: every level costs a kernel boundary or a workgroup barrier (>= 2 us),
+        // and there are at least as many levels as the hottest row has tuples.  The owner epoch pays ~0.35 us per tuple of the hottest
+        // row it owns and a hand-off (~4 us) per tuple of the hottest row on the other side.  Taken when that is at least twice faster.
+        int64_t min_tuples = (int64_t)1 << 20;
+        if (const char *env = getenv("CMI_OWNER_MIN_TUPLES")) min_tuples = atoll(env);
+        if (n >= min_tuples) {
+            std::vector<int32_t> du((size_t)h->n_users, 0), dj((size_t)h->n_items, 0);
+            for (int64_t t = 0; t < n; ++t) {
+                du[(size_t)u[t]]++;
+                dj[(size_t)j[t]]++;
+            }
+            const double mu = *std::max_element(du.begin(), du.end()), mj = *std::max_element(dj.begin(), dj.end());
+            const double est_owner = std::max(std::max(mu, mj) * 0.35e-6, std::min(mu, mj) * 4e-6) + 3e-3;
+            const double est_levels = (double)count_plain_levels(n, u, j, h->n_users, h->n_items) * 2e-6;
+            use_owner = est_levels >= 2.0 * est_owner;
+        }
+    }
+    if (use_owner) {
         int hub = -1;
         if (const char *env = getenv("CMI_OWNER_HUB")) hub = !strcmp(env, "item") ? 1 : (!strcmp(env, "user") ? 0 : -1);
         if (n > 0) {
@@ -474,7 +496,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
                 build_conflict_free_blocks(n, u, j, h->n_users, h->n_items, 64, off);
                 if ((double)n / (double)(off.size() - 1) >= 3.0) h->blk_off.swap(off); // shorter runs: the serial wave is faster
             }
-        } else if (chain_ok && n > 0 && try_chain(h, n, u, j, csch)) {
+        } else if (use_chain) {
             // hub-chain levels: level_off indexes UNITS; sch.perm carries the stream order
             sch.perm.swap(csch.perm);
             sch.level_off = csch.level_off;

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
     // the hub side only when the step will not take it over in registers.
     auto prefetch = [&](const OwnerRec &r, OwnerSlot<T, VPL> &s) {
         owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rs, (int)r.off, lane, s);
-        if (!(r.flags & (OWN_HUB_FWD | OWN_HUB_LATE))) owner_load_hub<T, MODEL, VPL, HUB_ITEM>(a, r.hub, lane, k, s.hq, s.hc, s.hb);
+        if (__builtin_expect(!(r.flags & (OWN_HUB_FWD | OWN_HUB_LATE)), 0)) owner_load_hub<T, MODEL, VPL, HUB_ITEM>(a, r.hub, lane, k, s.hq, s.hc, s.hb);
     };
 
 #pragma unroll
@@ -313,10 +313,10 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
         const OwnerRec r = r_run, p = r_ahead;
         r_run = recs[c + 1];
         r_ahead = recs[c + 1 + D];
-        if (!(r.flags & OWN_NOP)) { // OWN_NOP: past the end of the list; only the fixed store / read-ahead sequence runs, on a dummy record
+        if (__builtin_expect(!(r.flags & OWN_NOP), 1)) { // OWN_NOP: past the end of the list; only the fixed store / read-ahead sequence runs, on a dummy record
 
         // ---- hub side: registers (same row as the previous step) | read ahead | re-read now (written < D steps ago)
-        if (!(r.flags & OWN_HUB_FWD)) {
+        if (__builtin_expect(!(r.flags & OWN_HUB_FWD), 0)) { // (unlikely: the layout that matters is the hottest owner's)
             if (r.flags & OWN_HUB_LATE) {
                 owner_load_hub<T, MODEL, VPL, HUB_ITEM>(a, r.hub, lane, k, s.hq, s.hc, s.hb);
 #pragma unroll
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
         }
         // ---- spoke side: registers | the record read ahead, if every granule carries the tag | poll
         if (!(r.flags & OWN_SPK_FWD)) {
-            if (!__all(owner_spoke_ok<T, MODEL, VPL, HUB_ITEM>(s, r.want))) {
+            if (__builtin_expect(!__all(owner_spoke_ok<T, MODEL, VPL, HUB_ITEM>(s, r.want)), 0)) {
                 unsigned spins = 0;
                 while (true) { // the predecessor has not written the record yet (or was in the middle of it)
                     __builtin_amdgcn_s_sleep(4);
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
                 owner_st_words(rs, (64 * VPL + (S::SC ? 64 : 0)) * NW * 8, (int)r.off, ob);
             }
         }
-        if (r.flags & OWN_HUB_STORE) {
+        if (__builtin_expect(r.flags & OWN_HUB_STORE, 0)) {
             T *row = (HUB_ITEM ? a.Q : a.P) + (size_t)r.hub * k;
 #pragma unroll
             for (int v = 0; v < VPL; ++v)

@@ -126,3 +126,32 @@ def test_owner_epoch_leaves_the_tables_usable_by_the_other_paths():
     oe = orc.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
     ge = inst.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0)
     assert abs(oe["RMSE"] - ge["RMSE"]) <= 1e-9 and abs(oe["MAE"] - ge["MAE"]) <= 1e-9
+
+
+def test_owner_is_picked_for_large_heavy_tailed_data_and_not_for_uniform():
+    """>= 2^20 tuples whose levels are narrow: the owner epoch is the default; CMI_FLAG_NO_OWNER keeps the plain levels (same model to
+    fp32 rounding: the owner kernel's fp32 update is the fused two-operation form).  Uniform data of the same size stays on the hub-chain
+    levels."""
+    data = synth.generate(50_000, 5_000, 4, 8, 2_000_000, seed=17, item_zipf=1.0)
+    state = synth.init_state("CAMF_CI", data, 64, dtype=np.float32)
+    insts = []
+    for flags in (0, capi.FLAG_NO_OWNER):
+        inst = capi.Instance("CAMF_CI", 64, data.n_users, data.n_items, data.n_conds, flags=flags)
+        inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+        inst.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
+        inst.set_states(state)
+        insts.append(inst)
+    assert insts[0].schedule_info()["kind"] == "owner-item"
+    assert insts[1].schedule_info()["kind"] == "level"
+    for _ in range(2):
+        lo, lp = insts[0].train_epoch(util.LR), insts[1].train_epoch(util.LR)
+        assert abs(lo - lp) <= 2e-5 * abs(lp)
+    so, sp = insts[0].get_states(), insts[1].get_states()
+    for name in sp:
+        # two different fp32 roundings of a ~400 000-step recurrence along the hottest item's row (values ~1): 2.5e-4 apart
+        assert np.max(np.abs(so[name] - sp[name])) <= 1e-3, name
+    wide = synth.generate_fast(100_000, 10_000, 4, 8, 2_000_000, seed=3)
+    inst = capi.Instance("CAMF_CI", 64, wide.n_users, wide.n_items, wide.n_conds)
+    inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+    inst.set_ratings(wide.u, wide.j, wide.ctx, wide.r, wide.ctx_ptr, wide.ctx_conds)
+    assert inst.schedule_info()["kind"].startswith("chain-")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz of the GPU path against the C oracle on random small problems (every model, random k / dims / sizes /
-item skew / flags, incl. the hub-chain kernels forced on both hub sides -- narrow data sends them through sgd_chain_tail).
+item skew / flags, incl. the hub-chain kernels forced on both hub sides -- narrow data sends them through sgd_chain_tail -- and the
+owner (dataflow) kernel with few / many owners).
 fp64+strict: model state must be bit-identical; fp32: loss within 2e-5 and state within 2e-4.
 usage: tools/fuzz_gpu.py [n_cases] [seed]"""
 import os
@@ -19,8 +20,8 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     F64, SERIAL, STRICT, NOGRAPH = capi.FLAG_STATE_F64, capi.FLAG_SCHED_SERIAL, capi.FLAG_STRICT, capi.FLAG_NO_GRAPH
-    CHAIN = capi.FLAG_SCHED_CHAIN
-    bad = chained = 0
+    CHAIN, OWNER = capi.FLAG_SCHED_CHAIN, capi.FLAG_SCHED_OWNER
+    bad = chained = owned = 0
     for case in range(n_cases):
         model = util.MODELS[rng.integers(len(util.MODELS))]
         k = int(rng.choice([1, 2, 5, 10, 16, 31, 64, 70, 100, 128, 130, 256]))
@@ -44,6 +45,16 @@ def main():
             os.environ["CMI_CHAIN_HUB"] = str(rng.choice(["item", "user", "auto"]))
             os.environ["CMI_CHAIN_MAX"] = str(int(rng.choice([1, 2, 5, 16])))
             chained += 1
+        # the owner (dataflow) epoch: every level model, k <= 256 (fp64: 128), <= 64 conditions; few or many owners, either hub side
+        owner_ok = (model != "CAMF_C" and not flags & (SERIAL | STRICT | CHAIN) and k <= (128 if flags & F64 else 256) and
+                    (model in util.TWO_D or data.n_conds <= 64))
+        os.environ.pop("CMI_OWNER_WAVES", None)
+        if owner_ok and rng.random() < 0.4:
+            flags |= OWNER
+            os.environ["CMI_OWNER_HUB"] = str(rng.choice(["item", "user", "auto"]))
+            if rng.random() < 0.5:
+                os.environ["CMI_OWNER_WAVES"] = str(int(rng.choice([1, 3, 17, 200])))
+            owned += 1
         state = synth.init_state(model, data, k, seed=int(rng.integers(1 << 30)))
         gm = oracle_c.global_mean(data.r)
         orc = util.c_oracle(model, data, k, state, gm)
@@ -71,7 +82,7 @@ def main():
             bad += 1
             print("MISMATCH case %d: %s k=%d dims=%d users=%d items=%d n=%d zipf=%s flags=%#x info=%s"
                   % (case, model, k, n_dims, n_users, n_items, data.n, zipf, flags, inst.schedule_info()), flush=True)
-    print("%d cases (%d through the hub-chain kernels), %d mismatches" % (n_cases, chained, bad))
+    print("%d cases (%d through the hub-chain kernels, %d through the owner kernel), %d mismatches" % (n_cases, chained, owned, bad))
     return 1 if bad else 0
 
 
