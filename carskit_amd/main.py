@@ -1,4 +1,10 @@
-"""`python -m carskit_amd.main -c setting.conf` -- the reference driver's flow for the accelerated recommenders
+"""Host-flow MIRROR used by the tests; the product host is the C++ one (carskit_amd/csrc/host, built to carskit_amd/bin/carskit-mi355x),
+and `python -m carskit_amd.main -c setting.conf` simply runs that binary.  run() below restates the same flow in Python for one
+reason: it takes an `engine_factory`, so the tests can put the CPU ORACLE behind the identical host logic (config parsing, splits,
+bold driver, early stop, measures) and compare the two hosts and the two engines line by line (tests/test_host_layer.py,
+tests/test_gpu_realdata.py).  It is test plumbing, not a second product.
+
+The reference driver's flow for the accelerated recommenders
 (src/carskit/main/CARSKit.java: execute :109, preset :140, readData :220, runAlgorithm :310, runCrossValidation :388):
 load the config, bring the rating file to the binary format (DataTransformer), read it (DataDAO), split
 (`cv -k N` follows the reference's seeded fold assignment; `test-set`; `given-ratio` uses a seeded draw because the
@@ -103,12 +109,24 @@ def run(config_path, engine_factory=None, log=print, conf_overrides=None):
 
 
 def main(argv=None):
+    """The command line runs the PRODUCT host: the C++ driver over the C ABI (`--python-host` keeps the mirror reachable for debugging)."""
     ap = argparse.ArgumentParser(prog="carskit_amd")
     ap.add_argument("-c", dest="configs", action="append", default=None)
+    ap.add_argument("--python-host", action="store_true", help="run the Python mirror of the host flow instead of the C++ driver")
     args = ap.parse_args(argv)
+    if args.python_host:
+        for c in args.configs or ["setting.conf"]:
+            run(c)
+        return 0
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "carskit-mi355x")
+    if not os.path.exists(exe):
+        raise FileNotFoundError("%s is not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % exe)
+    cmd = [exe]
     for c in args.configs or ["setting.conf"]:
-        run(c)
+        cmd += ["-c", c]
+    return subprocess.call(cmd)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    sys.exit(main(sys.argv[1:]))
