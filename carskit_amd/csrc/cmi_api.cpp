@@ -792,9 +792,9 @@ static hipError_t enqueue_levels(cmi_instance *h) {
     }
     if (h->owner) {
         const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
-        e = h->f64 ? launch_owner_epoch<double>(make_args<double>(h), h->model, h->owner_hub_item, h->d_own_recs, h->d_own_off, h->n_owners, h->d_tagged,
+        e = h->f64 ? launch_owner_epoch<double>(make_args<double>(h), h->model, h->owner_hub_item, h->strict, h->d_own_recs, h->d_own_off, h->n_owners, h->d_tagged,
                                                 h->own_stride, n_spokes, h->d_flow_err, h->stream)
-                   : launch_owner_epoch<float>(make_args<float>(h), h->model, h->owner_hub_item, h->d_own_recs, h->d_own_off, h->n_owners, h->d_tagged,
+                   : launch_owner_epoch<float>(make_args<float>(h), h->model, h->owner_hub_item, false, h->d_own_recs, h->d_own_off, h->n_owners, h->d_tagged,
                                                h->own_stride, n_spokes, h->d_flow_err, h->stream);
         if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);
         return e;

@@ -259,7 +259,7 @@ __device__ __forceinline__ double owner_rating<double>(const OwnerRec &r) { retu
 // the wave sum leaves through one readlane, the fp32 update is two fused operations per element (new = (1 - lrate reg) old + (lrate
 // e) other: the same value as old + lrate (e other - reg old) up to rounding; the fp64 kernel keeps the reference's expression and
 // operation order), the loss is accumulated per lane and reduced once per owner.
-template <typename T, int MODEL, int VPL, int D, bool HUB_ITEM>
+template <typename T, int MODEL, int VPL, int D, bool HUB_ITEM, bool STRICT>
 __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec *__restrict__ recs, const int64_t *__restrict__ own_off,
                                                     gran_t *tagged, int *error, int n_owners) {
     constexpr int NW = Tagged<T>::NW;
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
     using S = Sides<MODEL, HUB_ITEM>;
     static_assert(MODEL != CAMF_C, "CAMF_C has no owner schedule (shared condBias)");
     constexpr bool F32 = sizeof(T) == 4;
+    static_assert(!STRICT || !F32, "the strict form is the fp64 reference arithmetic");
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (w >= n_owners) return;
@@ -353,22 +354,44 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
 
         // ---- prediction: gm + bu + bj + (p.q + the context deviations); lane c adds the deviations of condition c
         const bool sel = M::has_ctx && __builtin_amdgcn_inverse_ballot_w64(r.mask);
-        T part = (T)0;
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) part = owner_fma(x[v], h[v], part);
-        if (M::has_ctx) {
-            T term = (T)0;
-            if (S::HC && S::SC) term = HUB_ITEM ? hc + sc : sc + hc; // bic + buc
-            else if (S::HC) term = hc;
-            else if (S::SC) term = sc;
-            part += sel ? term : (T)0;
-        }
-        const T tot = wave_total(part);
         const T bu = HUB_ITEM ? sb : hb, bj = HUB_ITEM ? hb : sb;
         T pred = gm;
         if (M::has_bu) pred += bu;
         if (M::has_bj) pred += bj;
-        pred += tot;
+        if constexpr (STRICT) {
+            // the reference's operation order (fp64 state): DenseMatrix.rowMult sums m[f] * n[f] with f ascending (lane l holds
+            // elements l VPL ...), then predict() adds the deviations condition by condition in ascending column order
+            T prod[VPL];
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) prod[v] = HUB_ITEM ? x[v] * h[v] : h[v] * x[v];
+            T dot = (T)0;
+            const int lanes = (k + VPL - 1) / VPL;
+            for (int l = 0; l < lanes; ++l) {
+#pragma unroll
+                for (int v = 0; v < VPL; ++v)
+                    if (l * VPL + v < k) dot += __shfl(prod[v], l, 64);
+            }
+            pred += dot;
+            if (M::has_ctx) {
+                T term = (T)0;
+                if (S::HC && S::SC) term = HUB_ITEM ? hc + sc : sc + hc; // bic + buc
+                else if (S::HC) term = hc;
+                else if (S::SC) term = sc;
+                for (uint64_t m = r.mask; m; m &= m - 1) pred += __shfl(term, __builtin_ctzll(m), 64);
+            }
+        } else {
+            T part = (T)0;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) part = owner_fma(x[v], h[v], part);
+            if (M::has_ctx) {
+                T term = (T)0;
+                if (S::HC && S::SC) term = HUB_ITEM ? hc + sc : sc + hc; // bic + buc
+                else if (S::HC) term = hc;
+                else if (S::SC) term = sc;
+                part += sel ? term : (T)0;
+            }
+            pred += wave_total(part);
+        }
         const T e = owner_rating<T>(r) - pred;
 
         // ---- loss pieces (old values)
@@ -496,7 +519,7 @@ struct OwnerDepth {
 };
 
 bool has_owner_path(int model, int k, int n_conds, bool f64, bool strict) {
-    if (strict) return false;
+    if (strict && !f64) return false; // the strict form is the fp64 reference arithmetic
     if (model != BIASEDMF && model != PMF && model != CAMF_CI && model != CAMF_CU && model != CAMF_CUCI) return false;
     if (k < 1 || k > (f64 ? 128 : 256)) return false;
     const bool has_ctx = model != BIASEDMF && model != PMF;
@@ -513,32 +536,35 @@ int64_t owner_record_stride(int model, int k, int n_conds, bool f64, bool hub_is
 }
 
 template <typename T, int MODEL, int VPL>
-static void *owner_kernel_hub(bool hub_is_item) {
+static void *owner_kernel_hub(bool hub_is_item, bool strict) {
     constexpr int D = OwnerDepth<T, VPL>::D;
-    return hub_is_item ? (void *)sgd_owner<T, MODEL, VPL, D, true> : (void *)sgd_owner<T, MODEL, VPL, D, false>;
+    if constexpr (sizeof(T) == 8) {
+        if (strict) return hub_is_item ? (void *)sgd_owner<T, MODEL, VPL, D, true, true> : (void *)sgd_owner<T, MODEL, VPL, D, false, true>;
+    }
+    return hub_is_item ? (void *)sgd_owner<T, MODEL, VPL, D, true, false> : (void *)sgd_owner<T, MODEL, VPL, D, false, false>;
 }
 template <typename T, int MODEL>
-static void *owner_kernel_k(int k, bool hub_is_item) {
-    if (k <= 64) return owner_kernel_hub<T, MODEL, 1>(hub_is_item);
-    if (k <= 128) return owner_kernel_hub<T, MODEL, 2>(hub_is_item);
-    if (sizeof(T) == 4) return owner_kernel_hub<float, MODEL, 4>(hub_is_item);
+static void *owner_kernel_k(int k, bool hub_is_item, bool strict) {
+    if (k <= 64) return owner_kernel_hub<T, MODEL, 1>(hub_is_item, strict);
+    if (k <= 128) return owner_kernel_hub<T, MODEL, 2>(hub_is_item, strict);
+    if (sizeof(T) == 4) return owner_kernel_hub<float, MODEL, 4>(hub_is_item, strict);
     return nullptr;
 }
 template <typename T>
-static void *owner_kernel_ptr(int model, int k, bool hub_is_item) {
+static void *owner_kernel_ptr(int model, int k, bool hub_is_item, bool strict) {
     switch (model) {
-    case BIASEDMF: return owner_kernel_k<T, BIASEDMF>(k, hub_is_item);
-    case PMF: return owner_kernel_k<T, PMF>(k, hub_is_item);
-    case CAMF_CI: return owner_kernel_k<T, CAMF_CI>(k, hub_is_item);
-    case CAMF_CU: return owner_kernel_k<T, CAMF_CU>(k, hub_is_item);
-    case CAMF_CUCI: return owner_kernel_k<T, CAMF_CUCI>(k, hub_is_item);
+    case BIASEDMF: return owner_kernel_k<T, BIASEDMF>(k, hub_is_item, strict);
+    case PMF: return owner_kernel_k<T, PMF>(k, hub_is_item, strict);
+    case CAMF_CI: return owner_kernel_k<T, CAMF_CI>(k, hub_is_item, strict);
+    case CAMF_CU: return owner_kernel_k<T, CAMF_CU>(k, hub_is_item, strict);
+    case CAMF_CUCI: return owner_kernel_k<T, CAMF_CUCI>(k, hub_is_item, strict);
     }
     return nullptr;
 }
 
 // Owners = wavefronts that are resident together (a waiting owner must never keep a runnable one off the chip).
 int owner_grid_waves(int device, int model, int k, bool f64, bool hub_is_item) {
-    void *fn = f64 ? owner_kernel_ptr<double>(model, k, hub_is_item) : owner_kernel_ptr<float>(model, k, hub_is_item);
+    void *fn = f64 ? owner_kernel_ptr<double>(model, k, hub_is_item, false) : owner_kernel_ptr<float>(model, k, hub_is_item, false);
     if (!fn) return 0;
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) return 0;
@@ -552,9 +578,9 @@ int owner_grid_waves(int device, int model, int k, bool f64, bool hub_is_item) {
 }
 
 template <typename T>
-hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, const OwnerRec *recs, const int64_t *own_off, int n_owners,
-                              void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s) {
-    void *fn = owner_kernel_ptr<T>(model, a.k, hub_is_item);
+hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, bool strict, const OwnerRec *recs, const int64_t *own_off,
+                              int n_owners, void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s) {
+    void *fn = owner_kernel_ptr<T>(model, a.k, hub_is_item, strict);
     if (!fn) return hipErrorInvalidValue;
     const bool has_ic = model == CAMF_CI || model == CAMF_CUCI, has_uc = model == CAMF_CU || model == CAMF_CUCI;
     const bool has_bu = model == BIASEDMF || model == CAMF_CI, has_bj = model == BIASEDMF || model == CAMF_CU;
@@ -573,9 +599,9 @@ hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, 
     hipLaunchKernelGGL((owner_records<T, false>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl);
     return hipGetLastError();
 }
-template hipError_t launch_owner_epoch<float>(const SgdArgs<float> &, int, bool, const OwnerRec *, const int64_t *, int, void *, int64_t, int, int *,
-                                              hipStream_t);
-template hipError_t launch_owner_epoch<double>(const SgdArgs<double> &, int, bool, const OwnerRec *, const int64_t *, int, void *, int64_t, int, int *,
-                                               hipStream_t);
+template hipError_t launch_owner_epoch<float>(const SgdArgs<float> &, int, bool, bool, const OwnerRec *, const int64_t *, int, void *, int64_t, int,
+                                              int *, hipStream_t);
+template hipError_t launch_owner_epoch<double>(const SgdArgs<double> &, int, bool, bool, const OwnerRec *, const int64_t *, int, void *, int64_t, int,
+                                               int *, hipStream_t);
 
 } // namespace cmi

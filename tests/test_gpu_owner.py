@@ -60,6 +60,18 @@ def test_owner_f64_vs_oracle(model, hub, k):
 
 @pytest.mark.parametrize("model", LEVEL_MODELS)
 @pytest.mark.parametrize("hub", ["item", "user"])
+@pytest.mark.parametrize("k", [3, 10, 64, 70, 128])
+def test_owner_strict_f64_state_bit_identical_to_oracle(model, hub, k):
+    """CMI_FLAG_STRICT with the owner epoch: the reference's operation order inside every update (left-to-right dot product, deviations
+    added condition by condition) -- the model state after three epochs over heavy-tailed items is BIT-IDENTICAL to the sequential
+    oracle's, whatever the number of owners; the loss (same terms, per-owner partial sums) to 1e-12."""
+    data = synth.generate(500, 60, 3, 4, 12000, seed=270 + k, item_zipf=1.3)
+    for waves in (3, None):
+        _run(model, data, k, F64 | capi.FLAG_STRICT, hub, waves, loss_tol=1e-12, exact=True)
+
+
+@pytest.mark.parametrize("model", LEVEL_MODELS)
+@pytest.mark.parametrize("hub", ["item", "user"])
 @pytest.mark.parametrize("k", [10, 64, 128, 200, 256])
 def test_owner_f32_vs_oracle_north_star_bar(model, hub, k):
     data = synth.generate(800, 90, 4, 4, 20000, seed=170 + k, item_zipf=0.8)
