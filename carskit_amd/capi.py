@@ -488,6 +488,9 @@ class Instance:
         d = dict(zip(("levels", "max_level", "tuples", "dmax", "state_bytes", "tuple_bytes", "kind", "flow_blocks"),
                      list(info)))
         d["kind"] = ("level", "serial", "flow", "two-lane", "chain-item", "chain-user", "owner-item", "owner-user")[d["kind"]]
+        if d["kind"].startswith("owner"):      # owners in the low word, of which teams (three wavefronts each) in the high word
+            d["teams"] = d["flow_blocks"] >> 32
+            d["flow_blocks"] &= 0xffffffff
         return d
 
     def stream(self):

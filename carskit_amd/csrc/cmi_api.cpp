@@ -463,6 +463,49 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             if (waves < 1) CMI_FAIL(h, CMI_E_HIP, "set_ratings: owner kernel occupancy query failed");
             if (!build_owner_schedule(n, u, j, h->n_users, h->n_items, hub, waves, owner_depth(), osch))
                 CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: owner schedule construction failed");
+            // Teams: the leading owners (the hottest rows, alone in their lists) whose list is long enough to bound the epoch run as three
+            // wavefronts in a workgroup of their own instead of one wavefront among four.  A team takes a whole workgroup, so the owner
+            // count shrinks by three per team and the rows are dealt again.
+            h->n_team = 0;
+            int64_t team_min = 8192;
+            const char *team_env = getenv("CMI_OWNER_TEAM");
+            if (const char *env = getenv("CMI_OWNER_TEAM_MIN")) team_min = atoll(env);
+            auto leading_single_hub = [&](const OwnerSchedule &os, int limit) {
+                int t = 0;
+                for (; t < limit && t < (int)os.n_owners(); ++t) {
+                    const int64_t b = os.own_off[(size_t)t], e = os.own_off[(size_t)t + 1];
+                    if (e - b < team_min) break;
+                    bool single = true;
+                    for (int64_t pos = b + 1; pos < e && single; ++pos) single = os.flags[(size_t)pos] & OWN_HUB_FWD;
+                    if (!single) break;
+                }
+                return t;
+            };
+            const int wgs = (waves + 3) / 4; // resident workgroups
+            if (h->strict || (team_env && !strcmp(team_env, "0"))) {
+                // one wavefront per owner throughout
+            } else if (team_env && !strcmp(team_env, "all")) { // testing: every owner a team, whatever its list
+                if (waves > wgs) {
+                    waves = wgs;
+                    if (!build_owner_schedule(n, u, j, h->n_users, h->n_items, hub, waves, owner_depth(), osch))
+                        CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: owner schedule construction failed");
+                }
+                h->n_team = waves;
+            } else {
+                int t = leading_single_hub(osch, wgs / 2);
+                if (t > 0) {
+                    const int fewer = waves - 3 * t;
+                    if (fewer >= t + 1 && build_owner_schedule(n, u, j, h->n_users, h->n_items, hub, fewer, owner_depth(), osch)) {
+                        waves = fewer;
+                        t = std::min(t, leading_single_hub(osch, t));
+                    } else {
+                        t = 0;
+                        if (!build_owner_schedule(n, u, j, h->n_users, h->n_items, hub, waves, owner_depth(), osch))
+                            CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: owner schedule construction failed");
+                    }
+                }
+                h->n_team = t;
+            }
             h->owner = true;
             h->owner_hub_item = osch.hub_is_item != 0;
             h->n_owners = waves;
@@ -715,7 +758,7 @@ extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[8]) {
     info[4] = sb;
     info[5] = h->tuple_bytes;
     info[6] = h->owner ? (h->owner_hub_item ? 6 : 7) : h->flow ? 2 : (h->serial ? 1 : (h->two_lane ? 3 : (h->chain ? (h->chain_hub_item ? 4 : 5) : 0)));
-    info[7] = h->owner ? h->n_owners : h->flow ? h->flow_blocks : (h->chain ? h->n_units : (h->d_blk_off ? (int64_t)h->blk_off.size() - 1 : 0));
+    info[7] = h->owner ? ((int64_t)h->n_owners | ((int64_t)h->n_team << 32)) : h->flow ? h->flow_blocks : (h->chain ? h->n_units : (h->d_blk_off ? (int64_t)h->blk_off.size() - 1 : 0));
     return CMI_OK;
 }
 
@@ -792,9 +835,9 @@ static hipError_t enqueue_levels(cmi_instance *h) {
     }
     if (h->owner) {
         const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
-        e = h->f64 ? launch_owner_epoch<double>(make_args<double>(h), h->model, h->owner_hub_item, h->strict, h->d_own_recs, h->d_own_off, h->n_owners, h->d_tagged,
+        e = h->f64 ? launch_owner_epoch<double>(make_args<double>(h), h->model, h->owner_hub_item, h->strict, h->d_own_recs, h->d_own_off, h->n_owners, h->n_team, h->d_tagged,
                                                 h->own_stride, n_spokes, h->d_flow_err, h->stream)
-                   : launch_owner_epoch<float>(make_args<float>(h), h->model, h->owner_hub_item, false, h->d_own_recs, h->d_own_off, h->n_owners, h->d_tagged,
+                   : launch_owner_epoch<float>(make_args<float>(h), h->model, h->owner_hub_item, false, h->d_own_recs, h->d_own_off, h->n_owners, h->n_team, h->d_tagged,
                                                h->own_stride, n_spokes, h->d_flow_err, h->stream);
         if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);
         return e;
@@ -943,7 +986,10 @@ extern "C" int cmi_last_loss(cmi_handle h, double *loss_out) {
     if (h->flow && getenv("CMI_FLOW_STATS"))
         fprintf(stderr, "[cmi] flow: cumulative slow-path entries %d, polls spent waiting %d (of %lld wave-steps per epoch)\n",
                 flow_stat[1], flow_stat[2], (long long)h->n_chunks * 4);
-    if (h->owner && getenv("CMI_OWNER_STATS"))
+    if (h->owner && h->n_team > 0 && getenv("CMI_OWNER_STATS"))
+        fprintf(stderr, "[cmi] owner teams: %d; cumulative, busiest owner: compute wave found the ring empty %d times, loader found it full %d times\n",
+                h->n_team, flow_stat[1], flow_stat[2]);
+    else if (h->owner && getenv("CMI_OWNER_STATS"))
         fprintf(stderr, "[cmi] owner: cumulative -- busiest owner (%lld tuples per epoch) found %d records not ready and polled %d times; all owners: %d "
                 "records not ready (of %lld tuples per epoch)\n", (long long)h->max_level, flow_stat[1], flow_stat[2], flow_stat[3], (long long)h->n);
     if (flow_err) CMI_FAIL(h, CMI_E_HIP, "dataflow epoch stalled: a tuple waited past its bound for a predecessor (model state is invalid)");

@@ -20,7 +20,7 @@ struct cmi_instance {
     int64_t n_units = 0;
     // owner (dataflow) schedule: one persistent launch, d_own_recs = the owners' lists, d_tagged = the spoke side's tagged records
     bool want_owner = false, owner = false, owner_hub_item = true;
-    int n_owners = 0;
+    int n_owners = 0, n_team = 0; // owners [0, n_team) run as teams of three wavefronts
     cmi::OwnerRec *d_own_recs = nullptr;
     int64_t *d_own_off = nullptr;
     void *d_tagged = nullptr;

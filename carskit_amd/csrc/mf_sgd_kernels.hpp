@@ -191,7 +191,8 @@ int64_t owner_record_stride(int model, int k, int n_conds, bool f64, bool hub_is
 int owner_grid_waves(int device, int model, int k, bool f64, bool hub_is_item);           // owners that are resident together
 // tag pass + the persistent epoch + untag pass; loss partials in a.loss_part[0 .. n_owners)
 template <typename T>
+// owners [0, n_team) run as teams of three wavefronts (one workgroup each), the rest four to a workgroup
 hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, bool strict, const OwnerRec *recs, const int64_t *own_off,
-                              int n_owners, void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s);
+                              int n_owners, int n_team, void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s);
 
 } // namespace cmi

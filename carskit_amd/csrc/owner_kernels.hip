@@ -254,6 +254,376 @@ __device__ __forceinline__ float owner_rating<float>(const OwnerRec &r) { return
 template <>
 __device__ __forceinline__ double owner_rating<double>(const OwnerRec &r) { return r.rating.d; }
 
+template <typename T>
+struct OwnerHp {
+    T lr, regU, regI, regB, regC, gm, keepU, keepI, keepB, keepC; // keepX = 1 - lrate regX (the fp32 form of the update)
+};
+
+// One SGD update on the rows in registers: prediction, loss pieces, new values (h: hub row, x: spoke row; hc / sc their context-bias
+// rows with lane c = condition c; hb / sb the scalar biases).  Shared by the wave-per-owner step and the team kernel's compute wave.
+template <typename T, int MODEL, int VPL, bool HUB_ITEM, bool STRICT>
+__device__ __forceinline__ void owner_update(const OwnerRec &r, const OwnerHp<T> &hp, int k, T (&h)[VPL], T &hc, T &hb, T (&x)[VPL], T &sc, T &sb,
+                                             T &sq_p, T &sq_q, T &sq_c, T &sq_e, T &sq_b) {
+    using M = Traits<MODEL>;
+    using S = Sides<MODEL, HUB_ITEM>;
+    constexpr bool F32 = sizeof(T) == 4;
+    // ---- prediction: hp.gm + bu + bj + (p.q + the context deviations); lane c adds the deviations of condition c
+    const bool sel = M::has_ctx && __builtin_amdgcn_inverse_ballot_w64(r.mask);
+    const T bu = HUB_ITEM ? sb : hb, bj = HUB_ITEM ? hb : sb;
+    T pred = hp.gm;
+    if (M::has_bu) pred += bu;
+    if (M::has_bj) pred += bj;
+    if constexpr (STRICT) {
+        // the reference's operation order (fp64 state): DenseMatrix.rowMult sums m[f] * n[f] with f ascending (lane l holds
+        // elements l VPL ...), then predict() adds the deviations condition by condition in ascending column order
+        T prod[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) prod[v] = HUB_ITEM ? x[v] * h[v] : h[v] * x[v];
+        T dot = (T)0;
+        const int lanes = (k + VPL - 1) / VPL;
+        for (int l = 0; l < lanes; ++l) {
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+                if (l * VPL + v < k) dot += __shfl(prod[v], l, 64);
+        }
+        pred += dot;
+        if (M::has_ctx) {
+            T term = (T)0;
+            if (S::HC && S::SC) term = HUB_ITEM ? hc + sc : sc + hc; // bic + buc
+            else if (S::HC) term = hc;
+            else if (S::SC) term = sc;
+            for (uint64_t m = r.mask; m; m &= m - 1) pred += __shfl(term, __builtin_ctzll(m), 64);
+        }
+    } else {
+        T part = (T)0;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) part = owner_fma(x[v], h[v], part);
+        if (M::has_ctx) {
+            T term = (T)0;
+            if (S::HC && S::SC) term = HUB_ITEM ? hc + sc : sc + hc; // bic + buc
+            else if (S::HC) term = hc;
+            else if (S::SC) term = sc;
+            part += sel ? term : (T)0;
+        }
+        pred += wave_total(part);
+    }
+    const T e = owner_rating<T>(r) - pred;
+
+    // ---- loss pieces (old values)
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const T pv = HUB_ITEM ? x[v] : h[v], qv = HUB_ITEM ? h[v] : x[v];
+        sq_p = owner_fma(pv, pv, sq_p);
+        sq_q = owner_fma(qv, qv, sq_q);
+    }
+    if (M::has_ctx) {
+        T cc = sq_c;
+        if (S::HC) cc = owner_fma(hc, hc, cc);
+        if (S::SC) cc = owner_fma(sc, sc, cc);
+        sq_c = sel ? cc : sq_c;
+    }
+    sq_e = owner_fma(e, e, sq_e);
+    if (M::has_bu) sq_b = owner_fma(bu, bu, sq_b);
+    if (M::has_bj) sq_b = owner_fma(bj, bj, sq_b);
+    // computed HERE: left alone, the compiler sinks these to the end of the round and keeps every step's old rows alive until then
+    owner_settle(sq_p);
+    owner_settle(sq_q);
+    if (M::has_ctx) owner_settle(sq_c);
+    owner_settle(sq_e);
+    if (M::has_bu || M::has_bj) owner_settle(sq_b);
+
+    // ---- updates (all from the old values)
+    if constexpr (F32) {
+        const T le = hp.lr * e;
+        if (S::HB) hb = owner_fma(hp.keepB, hb, le);
+        if (S::SB) sb = owner_fma(hp.keepB, sb, le);
+        if (S::HC) hc = sel ? owner_fma(hp.keepC, hc, le) : hc;
+        if (S::SC) sc = sel ? owner_fma(hp.keepC, sc, le) : sc;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const T pv = HUB_ITEM ? x[v] : h[v], qv = HUB_ITEM ? h[v] : x[v];
+            const T pn = owner_fma(le, qv, hp.keepU * pv);
+            const T qn = owner_fma(le, pv, hp.keepI * qv);
+            x[v] = HUB_ITEM ? pn : qn;
+            h[v] = HUB_ITEM ? qn : pn;
+        }
+    } else {
+        if (S::HB) hb = hb + hp.lr * (e - hp.regB * hb);
+        if (S::SB) sb = sb + hp.lr * (e - hp.regB * sb);
+        if (S::HC) hc = sel ? hc + hp.lr * (e - hp.regC * hc) : hc;
+        if (S::SC) sc = sel ? sc + hp.lr * (e - hp.regC * sc) : sc;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const T pv = HUB_ITEM ? x[v] : h[v], qv = HUB_ITEM ? h[v] : x[v];
+            const T pn = pv + hp.lr * (e * qv - hp.regU * pv);
+            const T qn = qv + hp.lr * (e * pv - hp.regI * qv);
+            x[v] = HUB_ITEM ? pn : qn;
+            h[v] = HUB_ITEM ? qn : pn;
+        }
+    }
+
+}
+
+// ---------------------------------------------------------------------------------------------
+// team form: the hottest owners as THREE wavefronts each (one workgroup = one owner)
+// ---------------------------------------------------------------------------------------------
+// A lone wavefront issues a dependent instruction every ~10 cycles and an independent one every ~5.4 (tools/micro/issue_rate.hip), so the
+// pace of the owner of a hot row is the instruction count of its step.  For the owners whose list is long enough to bound the epoch,
+// the step is split over three wavefronts of one workgroup, on three SIMDs, that pass the spoke rows through a ring in LDS:
+//   loader  (wave 1): reads the records ahead (D deep, as the one-wave form does), validates the tags -- polling when a predecessor is
+//                     late -- and puts the row, context biases and bias of entry c into ring slot c mod R;  n_ready = c + 1
+//   compute (wave 0): hub row in registers; takes slot c, runs owner_update, puts the new values back into the slot;  n_done = c + 1
+//   storer  (wave 2): takes the new values, tags them want + 1 and writes the record through;  n_stored = c + 1 (the slot is free again)
+// The three counters live in LDS, each written by one wave: LDS operations of a wave execute in order, so "data, then counter" needs no
+// fence, and the readers poll.  What is left on the compute wave is the arithmetic chain itself.  Any list is handled correctly (a hub
+// switch loads the hub row synchronously), but the form only pays for single-hub lists: cmi_set_ratings gives it to the longest ones.
+static const int OWNER_TEAM_RING = 32;
+
+template <typename T, int VPL>
+struct TeamVec {
+    typedef T type __attribute__((ext_vector_type(VPL)));
+};
+template <typename T>
+struct TeamVec<T, 1> {
+    typedef T type;
+};
+// LDS pointers keep their address space explicitly: through a generic pointer these accesses would become flat_load / flat_store, which
+// travel the vector-memory path and count on both vmcnt and lgkmcnt
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+template <typename T, int VPL>
+__device__ __forceinline__ void team_get(const lds_u8 *p, T (&v)[VPL]) {
+    typedef typename TeamVec<T, VPL>::type V;
+    const V t = *(const volatile __attribute__((address_space(3))) V *)p;
+    if constexpr (VPL == 1) v[0] = t;
+    else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[i] = t[i];
+    }
+}
+template <typename T, int VPL>
+__device__ __forceinline__ void team_put(lds_u8 *p, const T (&v)[VPL]) {
+    typedef typename TeamVec<T, VPL>::type V;
+    V t;
+    if constexpr (VPL == 1) t = v[0];
+    else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) t[i] = v[i];
+    }
+    *(volatile __attribute__((address_space(3))) V *)p = t;
+}
+
+// A zero the compiler cannot see through, derived from a value read from LDS: an index that adds it cannot be formed -- and the scalar
+// load that uses it cannot be issued -- before that LDS read has returned.  Scalar loads and LDS operations share one counter, which can
+// only be waited down to zero while a scalar load is outstanding; issued after the step's LDS reads, the load of the next list entry has
+// the whole arithmetic of the step to complete in instead of being waited for together with them.
+__device__ __forceinline__ int team_after(float v) { return __builtin_amdgcn_readfirstlane(__float_as_int(v)) & 0; }
+__device__ __forceinline__ int team_after(double v) { return __builtin_amdgcn_readfirstlane(__double2loint(v)) & 0; }
+
+template <typename T, int MODEL, int VPL, bool HUB_ITEM>
+__host__ __device__ constexpr int team_slot_bytes() { // row | context biases | bias (16)
+    return 64 * VPL * (int)sizeof(T) + ((HUB_ITEM ? Traits<MODEL>::has_uc : Traits<MODEL>::has_ic) ? 64 * (int)sizeof(T) : 0) + 16;
+}
+
+template <typename T, int MODEL, int VPL, int D, bool HUB_ITEM>
+__device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *__restrict__ recs, int len, int w, __amdgpu_buffer_rsrc_t rs,
+                                           const OwnerHp<T> &hp, int *error) {
+    using S = Sides<MODEL, HUB_ITEM>;
+    constexpr int NW = Tagged<T>::NW, R = OWNER_TEAM_RING;
+    constexpr int XB = 64 * VPL * (int)sizeof(T), CB = S::SC ? 64 * (int)sizeof(T) : 0, SLOT = team_slot_bytes<T, MODEL, VPL, HUB_ITEM>();
+    constexpr int OFF_SB = XB + CB;
+    static_assert(D <= R, "the loader never waits for ring space on the inert entries that complete its last round");
+    extern __shared__ __attribute__((aligned(16))) unsigned char team_lds[];
+    volatile __attribute__((address_space(3))) uint32_t *ctr =
+        (volatile __attribute__((address_space(3))) uint32_t *)team_lds; // [0] n_ready, [1] n_done, [2] n_stored
+    lds_u8 *ring = (lds_u8 *)team_lds + 64;
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const int k = a.k;
+    if (threadIdx.x < 3) ctr[threadIdx.x] = 0u;
+    __syncthreads();
+    if (role == 3) return;
+
+    if (role == 1) { // ---------------- loader
+        OwnerSlot<T, VPL> slot[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rs, (int)recs[d].off, lane, slot[d]);
+        OwnerRec r_run = recs[0], r_ahead = recs[D];
+        uint32_t freed = 0; // entries the storer is known to have taken out of the ring
+        auto step = [&](int c, OwnerSlot<T, VPL> &s) {
+            const OwnerRec r = r_run, p = r_ahead;
+            r_run = recs[c + 1];
+            r_ahead = recs[c + 1 + D];
+            if (__builtin_expect(!(r.flags & OWN_NOP), 1)) {
+                if (__builtin_expect((uint32_t)c - freed >= (uint32_t)R, 0)) {
+                    unsigned spins = 0;
+                    while ((uint32_t)c - (freed = ctr[2]) >= (uint32_t)R) {
+                        if (w == 0 && lane == 0 && spins == 0) atomicAdd(error + 2, 1); // statistics: the ring was full
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > CMI_OWNER_SPIN_LIMIT) {
+                            if (lane == 0) atomicExch(error, 1);
+                            break;
+                        }
+                    }
+                }
+                lds_u8 *sl = ring + (c % R) * SLOT;
+                T sbv[1];
+                sbv[0] = (T)0;
+                if (!(r.flags & OWN_SPK_FWD)) {
+                    if (__builtin_expect(!__all(owner_spoke_ok<T, MODEL, VPL, HUB_ITEM>(s, r.want)), 0)) {
+                        unsigned spins = 0;
+                        while (true) {
+                            __builtin_amdgcn_s_sleep(4);
+                            owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rs, (int)r.off, lane, s);
+                            if (__all(owner_spoke_ok<T, MODEL, VPL, HUB_ITEM>(s, r.want))) break;
+                            if (++spins > CMI_OWNER_SPIN_LIMIT) {
+                                if (lane == 0) atomicExch(error, 1);
+                                break;
+                            }
+                        }
+                    }
+                    T xv[VPL], one[1];
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v) xv[v] = owner_elem(s.xw, v, (T)0);
+                    team_put<T, VPL>(sl + lane * (VPL * (int)sizeof(T)), xv);
+                    if (S::SC) {
+                        one[0] = owner_elem(s.cw, 0, (T)0);
+                        team_put<T, 1>(sl + XB + lane * (int)sizeof(T), one);
+                    }
+                    if (S::SB) sbv[0] = owner_elem(s.bw, 0, (T)0);
+                }
+                if (lane == 0) { // the counter after the slot's data: LDS operations of a wave execute in order
+                    if (S::SB && !(r.flags & OWN_SPK_FWD)) team_put<T, 1>(sl + OFF_SB, sbv);
+                    ctr[0] = (uint32_t)c + 1u;
+                }
+            }
+            owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rs, (int)p.off, lane, s);
+        };
+        for (int base = 0; base < len; base += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) step(base + d, slot[d]);
+        }
+        return;
+    }
+
+    if (role == 2) { // ---------------- storer
+        uint32_t done = 0;
+        OwnerRec r_next = recs[0];
+        for (int c = 0; c < len; ++c) {
+            const OwnerRec r = r_next;
+            if (__builtin_expect((uint32_t)c >= done, 0)) {
+                unsigned spins = 0;
+                while ((uint32_t)c >= (done = ctr[1])) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > CMI_OWNER_SPIN_LIMIT) {
+                        if (lane == 0) atomicExch(error, 1);
+                        break;
+                    }
+                }
+            }
+            const lds_u8 *sl = ring + (c % R) * SLOT;
+            T xv[VPL], cv[1], bv[1];
+            team_get<T, VPL>(sl + lane * (VPL * (int)sizeof(T)), xv);
+            if (S::SC) team_get<T, 1>(sl + XB + lane * (int)sizeof(T), cv);
+            if (S::SB) team_get<T, 1>(sl + OFF_SB, bv);
+            r_next = recs[c + 1 + team_after(xv[0])];
+            const uint32_t tag = r.want + 1u;
+            uint32_t ow[VPL * NW * 2], oc[NW * 2], ob[NW * 2];
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) owner_pack(ow, v, xv[v], tag);
+            owner_st_words(rs, lane * (VPL * NW * 8), (int)r.off, ow);
+            if (S::SC) {
+                owner_pack(oc, 0, cv[0], tag);
+                owner_st_words(rs, 64 * VPL * NW * 8 + lane * (NW * 8), (int)r.off, oc);
+            }
+            if (S::SB) {
+                owner_pack(ob, 0, bv[0], tag);
+                owner_st_words(rs, (64 * VPL + (S::SC ? 64 : 0)) * NW * 8, (int)r.off, ob);
+            }
+            if (lane == 0) ctr[2] = (uint32_t)c + 1u; // after the reads of the slot (in order): the loader may refill it
+        }
+        return;
+    }
+
+    // ---------------- compute
+    T h[VPL], hc = (T)0, hb = (T)0, x[VPL], sc = (T)0, sb = (T)0;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) h[v] = x[v] = (T)0;
+    T sq_p = (T)0, sq_q = (T)0, sq_c = (T)0, sq_e = (T)0, sq_b = (T)0;
+    double acc = 0.0;
+    uint32_t ready = 0;
+    OwnerRec r_next = recs[0];
+    for (int c = 0; c < len; ++c) {
+        const OwnerRec r = r_next;
+        // EVERY entry waits for the loader (also those whose row is taken over in registers): the loader's ring arithmetic counts on
+        // the compute wave never being ahead of it.  Only the owner's head entry is ever waited for.
+        if (__builtin_expect((uint32_t)c >= ready, 0)) {
+            unsigned spins = 0;
+            while ((uint32_t)c >= (ready = ctr[0])) {
+                if (w == 0 && lane == 0 && spins == 0) atomicAdd(error + 1, 1); // statistics: the compute wave waited for the loader
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > CMI_OWNER_SPIN_LIMIT) {
+                    if (lane == 0) atomicExch(error, 1);
+                    break;
+                }
+            }
+        }
+        lds_u8 *sl = ring + (c % R) * SLOT;
+        if (__builtin_expect(!(r.flags & OWN_HUB_FWD), 0)) { // a single-hub list: once
+            T hq[VPL], hcq = (T)0, hbq = (T)0;
+            owner_load_hub<T, MODEL, VPL, HUB_ITEM>(a, r.hub, lane, k, hq, hcq, hbq);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) h[v] = lane * VPL + v < k ? hq[v] : (T)0;
+            if (S::HC) hc = lane < a.n_conds ? hcq : (T)0;
+            if (S::HB) hb = hbq;
+        }
+        if (!(r.flags & OWN_SPK_FWD)) {
+            T one[1];
+            team_get<T, VPL>(sl + lane * (VPL * (int)sizeof(T)), x);
+            if (S::SC) {
+                team_get<T, 1>(sl + XB + lane * (int)sizeof(T), one);
+                sc = one[0];
+            }
+            if (S::SB) {
+                team_get<T, 1>(sl + OFF_SB, one);
+                sb = one[0];
+            }
+        }
+        r_next = recs[c + 1 + team_after(x[0])];
+        owner_update<T, MODEL, VPL, HUB_ITEM, false>(r, hp, k, h, hc, hb, x, sc, sb, sq_p, sq_q, sq_c, sq_e, sq_b);
+        {
+            T one[1];
+            team_put<T, VPL>(sl + lane * (VPL * (int)sizeof(T)), x);
+            if (S::SC) {
+                one[0] = sc;
+                team_put<T, 1>(sl + XB + lane * (int)sizeof(T), one);
+            }
+            if (lane == 0) {
+                if (S::SB) {
+                    one[0] = sb;
+                    team_put<T, 1>(sl + OFF_SB, one);
+                }
+                ctr[1] = (uint32_t)c + 1u;
+            }
+        }
+        if (__builtin_expect(r.flags & OWN_HUB_STORE, 0)) {
+            T *row = (HUB_ITEM ? a.Q : a.P) + (size_t)r.hub * k;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+                if (lane * VPL + v < k) row[lane * VPL + v] = h[v];
+            if (S::HC && lane < a.n_conds) (HUB_ITEM ? a.icBias : a.ucBias)[(size_t)r.hub * a.n_conds + lane] = hc;
+            if (S::HB && lane == 0) (HUB_ITEM ? a.itemBias : a.userBias)[r.hub] = hb;
+        }
+        if ((c & 15) == 15) { // flush the float partial sums of squares into the double accumulator
+            acc += (double)hp.regU * (double)sq_p + (double)hp.regI * (double)sq_q + (double)hp.regC * (double)sq_c;
+            if (lane == 0) acc += (double)sq_e + (double)hp.regB * (double)sq_b;
+            sq_p = sq_q = sq_c = sq_e = sq_b = (T)0;
+        }
+    }
+    acc += (double)hp.regU * (double)sq_p + (double)hp.regI * (double)sq_q + (double)hp.regC * (double)sq_c;
+    if (lane == 0) acc += (double)sq_e + (double)hp.regB * (double)sq_b;
+    acc = wave_sum64(acc);
+    if (lane == 0) a.loss_part[w] = acc;
+}
+
 // A lone wavefront issues one instruction every four cycles whatever its kind, so the hottest owner's pace is the INSTRUCTION COUNT
 // of a step: the step is written for few instructions -- condition masks go straight into v_cndmask as lane masks (inverse ballot),
 // the wave sum leaves through one readlane, the fp32 update is two fused operations per element (new = (1 - lrate reg) old + (lrate
@@ -261,7 +631,7 @@ __device__ __forceinline__ double owner_rating<double>(const OwnerRec &r) { retu
 // operation order), the loss is accumulated per lane and reduced once per owner.
 template <typename T, int MODEL, int VPL, int D, bool HUB_ITEM, bool STRICT>
 __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec *__restrict__ recs, const int64_t *__restrict__ own_off,
-                                                    gran_t *tagged, int *error, int n_owners) {
+                                                    gran_t *tagged, int *error, int n_owners, int n_team) {
     constexpr int NW = Tagged<T>::NW;
     using M = Traits<MODEL>;
     using S = Sides<MODEL, HUB_ITEM>;
@@ -269,12 +639,14 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
     constexpr bool F32 = sizeof(T) == 4;
     static_assert(!STRICT || !F32, "the strict form is the fp64 reference arithmetic");
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    // workgroups [0, n_team): one owner each, as a team of three wavefronts; the rest: four owners each, one per wavefront
+    const bool team = !STRICT && (int)blockIdx.x < n_team;
+    const int w = team ? (int)blockIdx.x : __builtin_amdgcn_readfirstlane(n_team + ((int)blockIdx.x - n_team) * 4 + (int)(threadIdx.x >> 6));
     if (w >= n_owners) return;
     const int k = a.k;
     const HParams hpd = *a.hp;
     const T lr = (T)hpd.lr, regU = (T)hpd.regU, regI = (T)hpd.regI, regB = (T)hpd.regB, regC = (T)hpd.regC, gm = (T)hpd.gm;
-    const T keepU = (T)1 - lr * regU, keepI = (T)1 - lr * regI, keepB = (T)1 - lr * regB, keepC = (T)1 - lr * regC; // fp32 form
+    const OwnerHp<T> hp{lr, regU, regI, regB, regC, gm, (T)1 - lr * regU, (T)1 - lr * regI, (T)1 - lr * regB, (T)1 - lr * regC};
     // the owner's list, followed by 2 OWNER_DEPTH_MAX inert entries (OWN_NOP: the step computes nothing and stores to / reads ahead from
     // the owner's dummy record behind the table): enough to complete the last round and to read D + 1 entries past it
     static_assert(D <= OWNER_DEPTH_MAX, "list padding");
@@ -282,10 +654,16 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
     const int len = (int)(own_off[w + 1] - own_off[w]);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tagged, 0, 0xffffffff, 0x00020000);
     if (len == 0) {
-        if (lane == 0) a.loss_part[w] = 0.0;
+        if (lane == 0 && (!team || threadIdx.x < 64)) a.loss_part[w] = 0.0;
         return;
     }
     recs += c0;
+    if constexpr (!STRICT) {
+        if (team) {
+            owner_team<T, MODEL, VPL, D, HUB_ITEM>(a, recs, len, w, rs, hp, error);
+            return;
+        }
+    }
 
     OwnerSlot<T, VPL> slot[D];
     // current rows (registers): hub row / context-bias row / bias, and the spoke's after its latest update
@@ -352,101 +730,7 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
             if (S::SB) sb = owner_elem(s.bw, 0, (T)0);
         }
 
-        // ---- prediction: gm + bu + bj + (p.q + the context deviations); lane c adds the deviations of condition c
-        const bool sel = M::has_ctx && __builtin_amdgcn_inverse_ballot_w64(r.mask);
-        const T bu = HUB_ITEM ? sb : hb, bj = HUB_ITEM ? hb : sb;
-        T pred = gm;
-        if (M::has_bu) pred += bu;
-        if (M::has_bj) pred += bj;
-        if constexpr (STRICT) {
-            // the reference's operation order (fp64 state): DenseMatrix.rowMult sums m[f] * n[f] with f ascending (lane l holds
-            // elements l VPL ...), then predict() adds the deviations condition by condition in ascending column order
-            T prod[VPL];
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) prod[v] = HUB_ITEM ? x[v] * h[v] : h[v] * x[v];
-            T dot = (T)0;
-            const int lanes = (k + VPL - 1) / VPL;
-            for (int l = 0; l < lanes; ++l) {
-#pragma unroll
-                for (int v = 0; v < VPL; ++v)
-                    if (l * VPL + v < k) dot += __shfl(prod[v], l, 64);
-            }
-            pred += dot;
-            if (M::has_ctx) {
-                T term = (T)0;
-                if (S::HC && S::SC) term = HUB_ITEM ? hc + sc : sc + hc; // bic + buc
-                else if (S::HC) term = hc;
-                else if (S::SC) term = sc;
-                for (uint64_t m = r.mask; m; m &= m - 1) pred += __shfl(term, __builtin_ctzll(m), 64);
-            }
-        } else {
-            T part = (T)0;
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) part = owner_fma(x[v], h[v], part);
-            if (M::has_ctx) {
-                T term = (T)0;
-                if (S::HC && S::SC) term = HUB_ITEM ? hc + sc : sc + hc; // bic + buc
-                else if (S::HC) term = hc;
-                else if (S::SC) term = sc;
-                part += sel ? term : (T)0;
-            }
-            pred += wave_total(part);
-        }
-        const T e = owner_rating<T>(r) - pred;
-
-        // ---- loss pieces (old values)
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-            const T pv = HUB_ITEM ? x[v] : h[v], qv = HUB_ITEM ? h[v] : x[v];
-            sq_p = owner_fma(pv, pv, sq_p);
-            sq_q = owner_fma(qv, qv, sq_q);
-        }
-        if (M::has_ctx) {
-            T cc = sq_c;
-            if (S::HC) cc = owner_fma(hc, hc, cc);
-            if (S::SC) cc = owner_fma(sc, sc, cc);
-            sq_c = sel ? cc : sq_c;
-        }
-        sq_e = owner_fma(e, e, sq_e);
-        if (M::has_bu) sq_b = owner_fma(bu, bu, sq_b);
-        if (M::has_bj) sq_b = owner_fma(bj, bj, sq_b);
-        // computed HERE: left alone, the compiler sinks these to the end of the round and keeps every step's old rows alive until then
-        owner_settle(sq_p);
-        owner_settle(sq_q);
-        if (M::has_ctx) owner_settle(sq_c);
-        owner_settle(sq_e);
-        if (M::has_bu || M::has_bj) owner_settle(sq_b);
-
-        // ---- updates (all from the old values)
-        if constexpr (F32) {
-            const T le = lr * e;
-            if (S::HB) hb = owner_fma(keepB, hb, le);
-            if (S::SB) sb = owner_fma(keepB, sb, le);
-            if (S::HC) hc = sel ? owner_fma(keepC, hc, le) : hc;
-            if (S::SC) sc = sel ? owner_fma(keepC, sc, le) : sc;
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) {
-                const T pv = HUB_ITEM ? x[v] : h[v], qv = HUB_ITEM ? h[v] : x[v];
-                const T pn = owner_fma(le, qv, keepU * pv);
-                const T qn = owner_fma(le, pv, keepI * qv);
-                x[v] = HUB_ITEM ? pn : qn;
-                h[v] = HUB_ITEM ? qn : pn;
-            }
-        } else {
-            if (S::HB) hb = hb + lr * (e - regB * hb);
-            if (S::SB) sb = sb + lr * (e - regB * sb);
-            if (S::HC) hc = sel ? hc + lr * (e - regC * hc) : hc;
-            if (S::SC) sc = sel ? sc + lr * (e - regC * sc) : sc;
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) {
-                const T pv = HUB_ITEM ? x[v] : h[v], qv = HUB_ITEM ? h[v] : x[v];
-                const T pn = pv + lr * (e * qv - regU * pv);
-                const T qn = qv + lr * (e * pv - regI * qv);
-                x[v] = HUB_ITEM ? pn : qn;
-                h[v] = HUB_ITEM ? qn : pn;
-            }
-        }
-
+        owner_update<T, MODEL, VPL, HUB_ITEM, STRICT>(r, hp, k, h, hc, hb, x, sc, sb, sq_p, sq_q, sq_c, sq_e, sq_b);
         } // !OWN_NOP
 
         // ---- the spoke record goes back with the next tag (always: one store sequence per step); the hub side when the next
@@ -577,9 +861,31 @@ int owner_grid_waves(int device, int model, int k, bool f64, bool hub_is_item) {
     return cus * per_cu * 4;
 }
 
+template <typename T, int MODEL, int VPL>
+static size_t owner_team_lds_hub(bool hub_is_item) {
+    return 64 + (size_t)OWNER_TEAM_RING * (size_t)(hub_is_item ? team_slot_bytes<T, MODEL, VPL, true>() : team_slot_bytes<T, MODEL, VPL, false>());
+}
+template <typename T, int MODEL>
+static size_t owner_team_lds_k(int k, bool hub_is_item) {
+    if (k <= 64) return owner_team_lds_hub<T, MODEL, 1>(hub_is_item);
+    if (k <= 128) return owner_team_lds_hub<T, MODEL, 2>(hub_is_item);
+    return owner_team_lds_hub<T, MODEL, 4>(hub_is_item);
+}
+template <typename T>
+static size_t owner_team_lds(int model, int k, bool hub_is_item) {
+    switch (model) {
+    case BIASEDMF: return owner_team_lds_k<T, BIASEDMF>(k, hub_is_item);
+    case PMF: return owner_team_lds_k<T, PMF>(k, hub_is_item);
+    case CAMF_CI: return owner_team_lds_k<T, CAMF_CI>(k, hub_is_item);
+    case CAMF_CU: return owner_team_lds_k<T, CAMF_CU>(k, hub_is_item);
+    case CAMF_CUCI: return owner_team_lds_k<T, CAMF_CUCI>(k, hub_is_item);
+    }
+    return 0;
+}
+
 template <typename T>
 hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, bool strict, const OwnerRec *recs, const int64_t *own_off,
-                              int n_owners, void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s) {
+                              int n_owners, int n_team, void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s) {
     void *fn = owner_kernel_ptr<T>(model, a.k, hub_is_item, strict);
     if (!fn) return hipErrorInvalidValue;
     const bool has_ic = model == CAMF_CI || model == CAMF_CUCI, has_uc = model == CAMF_CU || model == CAMF_CUCI;
@@ -593,15 +899,17 @@ hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, 
     hipLaunchKernelGGL((owner_records<T, true>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl);
     SgdArgs<T> args = a;
     gran_t *tg = (gran_t *)tagged;
-    void *params[] = {&args, &recs, &own_off, &tg, &error, &n_owners};
-    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)((n_owners + 3) / 4)), dim3(256), params, 0, s);
+    if (strict) n_team = 0;
+    void *params[] = {&args, &recs, &own_off, &tg, &error, &n_owners, &n_team};
+    const size_t lds = n_team > 0 ? owner_team_lds<T>(model, a.k, hub_is_item) : 0;
+    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(n_team + (n_owners - n_team + 3) / 4)), dim3(256), params, lds, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((owner_records<T, false>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl);
     return hipGetLastError();
 }
-template hipError_t launch_owner_epoch<float>(const SgdArgs<float> &, int, bool, bool, const OwnerRec *, const int64_t *, int, void *, int64_t, int,
-                                              int *, hipStream_t);
-template hipError_t launch_owner_epoch<double>(const SgdArgs<double> &, int, bool, bool, const OwnerRec *, const int64_t *, int, void *, int64_t, int,
-                                               int *, hipStream_t);
+template hipError_t launch_owner_epoch<float>(const SgdArgs<float> &, int, bool, bool, const OwnerRec *, const int64_t *, int, int, void *, int64_t,
+                                              int, int *, hipStream_t);
+template hipError_t launch_owner_epoch<double>(const SgdArgs<double> &, int, bool, bool, const OwnerRec *, const int64_t *, int, int, void *, int64_t,
+                                               int, int *, hipStream_t);
 
 } // namespace cmi

@@ -277,7 +277,9 @@ int cmi_last_loss(cmi_handle h, double *loss_out);
  * workgroup walks them),  info[1]=largest level, info[2]=tuples,
  * info[3]=max conditions per tuple (D), info[4]=state bytes on device, info[5]=tuple-stream bytes on device,
  * info[6]=schedule kind actually running (0 level launches, 1 serial, 2 dataflow, 3 two-lane level graph,
- * 4 hub-chain levels along items, 5 hub-chain levels along users; then info[1]=most units in a level, info[7]=units),
+ * 4 hub-chain levels along items, 5 hub-chain levels along users; then info[1]=most units in a level, info[7]=units;
+ * 6 owner epoch with items owned, 7 with users owned; then info[0]=1, info[1]=tuples of the busiest owner, info[7]=owners in the
+ * low 32 bits and, in the high 32 bits, how many of them run as teams of three wavefronts),
  * info[7]=workgroups of the dataflow launch; for CAMF_C the number of conflict-free CRS blocks its epoch is cut into
  * (0: the serial wave) */
 int cmi_schedule_info(cmi_handle h, int64_t info[8]);

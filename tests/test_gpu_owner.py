@@ -38,8 +38,8 @@ def _env(fn, **kv):
                 os.environ[k] = v
 
 
-def _run(model, data, k, flags, hub, waves, epochs=3, loss_tol=1e-10, exact=False, atol=1e-11):
-    orc, inst = _env(lambda: make_pair(model, data, k, flags | OWNER), CMI_OWNER_HUB=hub, CMI_OWNER_WAVES=waves)
+def _run(model, data, k, flags, hub, waves, epochs=3, loss_tol=1e-10, exact=False, atol=1e-11, team=None):
+    orc, inst = _env(lambda: make_pair(model, data, k, flags | OWNER), CMI_OWNER_HUB=hub, CMI_OWNER_WAVES=waves, CMI_OWNER_TEAM=team)
     info = inst.schedule_info()
     assert info["kind"] == "owner-" + hub
     for _ in range(epochs):
@@ -77,6 +77,33 @@ def test_owner_f32_vs_oracle_north_star_bar(model, hub, k):
     data = synth.generate(800, 90, 4, 4, 20000, seed=170 + k, item_zipf=0.8)
     for waves in (16, None):
         _run(model, data, k, 0, hub, waves, loss_tol=3e-5, atol=3e-4)
+
+
+@pytest.mark.parametrize("model", LEVEL_MODELS)
+@pytest.mark.parametrize("hub", ["item", "user"])
+@pytest.mark.parametrize("k,flags", [(10, F64), (128, F64), (64, 0), (200, 0)])
+def test_owner_team_form(model, hub, k, flags):
+    """The team form (a workgroup of three wavefronts per owner: loader -> LDS ring -> compute -> LDS ring -> storer), which
+    cmi_set_ratings gives to the hottest single-row owners, forced on EVERY owner here (CMI_OWNER_TEAM=all), lists with many rows
+    included: same bars as the one-wavefront form."""
+    data = synth.generate(600, 70, 3, 4, 15000, seed=370 + k, item_zipf=1.1)
+    for waves in (8, None):
+        if flags:
+            _run(model, data, k, flags, hub, waves, team="all")
+        else:
+            _run(model, data, k, flags, hub, waves, loss_tol=3e-5, atol=3e-4, team="all")
+
+
+def test_owner_team_form_is_picked_for_the_hottest_rows():
+    data = synth.generate(20000, 2000, 4, 8, 600000, seed=91, item_zipf=1.1)
+    for team, expect in ((None, True), ("0", False)):
+        orc, inst = _env(lambda: make_pair("CAMF_CI", data, 64, F64 | OWNER), CMI_OWNER_TEAM=team, CMI_OWNER_TEAM_MIN=4096)
+        info = inst.schedule_info()
+        assert info["kind"] == "owner-item" and (info["teams"] > 0) == expect, info
+        for _ in range(2):
+            lo, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
+            assert abs(lo - lg) <= 1e-10 * abs(lo)
+        assert_state_equal(orc, inst, exact=False, atol=1e-11)
 
 
 @pytest.mark.parametrize("zipf", [None, 1.5])

@@ -54,6 +54,7 @@ def main():
             os.environ["CMI_OWNER_HUB"] = str(rng.choice(["item", "user", "auto"]))
             if rng.random() < 0.5:
                 os.environ["CMI_OWNER_WAVES"] = str(int(rng.choice([1, 3, 17, 200])))
+            os.environ["CMI_OWNER_TEAM"] = str(rng.choice(["all", "0"]))      # every owner a team of three wavefronts / none
             owned += 1
         state = synth.init_state(model, data, k, seed=int(rng.integers(1 << 30)))
         gm = oracle_c.global_mean(data.r)
