@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "cmi_instance.hpp"
@@ -834,12 +835,20 @@ static hipError_t enqueue_levels(cmi_instance *h) {
         return launch_serial<float>(make_args<float>(h), cfg, h->n, h->d_loss, h->stream);
     }
     if (h->owner) {
+        // The owner epoch is a persistent launch whose workgroups wait for each other: every one of them has to be resident, i.e. it
+        // needs the device to itself.  Two of them in flight at once (two folds of `cv -p on` on one GPU, each on its own stream) could
+        // each hold part of the compute units and wait forever for the rest, so owner epochs of one process run one at a time: the lock
+        // is held from the launch until the stream has drained (cmi_train_epoch_async is synchronous for this schedule).  Across
+        // PROCESSES nothing protects it: one owner-schedule instance per GPU at a time.
+        static std::mutex owner_epoch_lock;
+        std::lock_guard<std::mutex> guard(owner_epoch_lock);
         const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
         e = h->f64 ? launch_owner_epoch<double>(make_args<double>(h), h->model, h->owner_hub_item, h->strict, h->d_own_recs, h->d_own_off, h->n_owners, h->n_team, h->d_tagged,
                                                 h->own_stride, n_spokes, h->d_flow_err, h->stream)
                    : launch_owner_epoch<float>(make_args<float>(h), h->model, h->owner_hub_item, false, h->d_own_recs, h->d_own_off, h->n_owners, h->n_team, h->d_tagged,
                                                h->own_stride, n_spokes, h->d_flow_err, h->stream);
         if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         return e;
     }
     if (h->flow) {

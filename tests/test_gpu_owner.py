@@ -194,3 +194,26 @@ def test_owner_is_picked_for_large_heavy_tailed_data_and_not_for_uniform():
     inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
     inst.set_ratings(wide.u, wide.j, wide.ctx, wide.r, wide.ctx_ptr, wide.ctx_conds)
     assert inst.schedule_info()["kind"].startswith("chain-")
+
+
+def test_owner_epochs_of_concurrent_folds_do_not_starve_each_other():
+    """`cv -p on`: several folds train from their own threads on one GPU.  An owner epoch needs every one of its workgroups resident,
+    so two of them in flight at once could wait for each other forever; the library runs them one at a time.  Three instances, three
+    threads, three epochs each: all finish and each matches its own oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    pairs = []
+    for seed in (1, 2, 3):
+        data = synth.generate(3000, 300, 3, 4, 120000, seed=400 + seed, item_zipf=1.2)
+        pairs.append(make_pair("CAMF_CI", data, 64, F64 | OWNER))
+
+    def work(pair):
+        orc, inst = pair
+        return [inst.train_epoch(util.LR) for _ in range(3)]
+
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        losses = list(pool.map(work, pairs))
+    for (orc, inst), ls in zip(pairs, losses):
+        for lg in ls:
+            lo = orc.epoch(util.LR)
+            assert abs(lo - lg) <= 1e-10 * abs(lo)
+        assert_state_equal(orc, inst, exact=False, atol=1e-11)
