@@ -435,8 +435,9 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     if (!use_owner && !use_chain && !h->flow && !h->serial && !h->want_two_lane && !(h->flags & (CMI_FLAG_SCHED_CHAIN | CMI_FLAG_NO_OWNER)) &&
         !getenv("CMI_NO_OWNER") && has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict)) {
         // Narrow levels on a large data set = heavy-tailed degrees: every level costs a kernel boundary or a workgroup barrier (>= 2 us),
-        // and there are at least as many levels as the hottest row has tuples.  The owner epoch pays ~0.35 us per tuple of the hottest
-        // row it owns and a hand-off (~4 us) per tuple of the hottest row on the other side.  Taken when that is at least twice faster.
+        // and there are at least as many levels as the hottest row has tuples.  The owner epoch pays ~0.3 us per tuple of the hottest
+        // row it owns and a hand-off (0.86 us measured, tools/exp_owner_handoff.py) per tuple of the hottest row on the other side.
+        // Taken when that is at least twice faster.
         int64_t min_tuples = (int64_t)1 << 20;
         if (const char *env = getenv("CMI_OWNER_MIN_TUPLES")) min_tuples = atoll(env);
         if (n >= min_tuples) {
@@ -446,7 +447,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
                 dj[(size_t)j[t]]++;
             }
             const double mu = *std::max_element(du.begin(), du.end()), mj = *std::max_element(dj.begin(), dj.end());
-            const double est_owner = std::max(std::max(mu, mj) * 0.35e-6, std::min(mu, mj) * 4e-6) + 3e-3;
+            const double est_owner = std::max(std::max(mu, mj) * 0.3e-6, std::min(mu, mj) * 1e-6) + 3e-3;
             const double est_levels = (double)count_plain_levels(n, u, j, h->n_users, h->n_items) * 2e-6;
             use_owner = est_levels >= 2.0 * est_owner;
         }
