@@ -624,8 +624,8 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
     if (lane == 0) a.loss_part[w] = acc;
 }
 
-// A lone wavefront issues one instruction every four cycles whatever its kind, so the hottest owner's pace is the INSTRUCTION COUNT
-// of a step: the step is written for few instructions -- condition masks go straight into v_cndmask as lane masks (inverse ballot),
+// A lone wavefront issues a dependent instruction every ~10 cycles and an independent one every ~5.4 (tools/micro/issue_rate.hip), so
+// the hottest owner's pace is the INSTRUCTION COUNT of a step: the step is written for few instructions -- condition masks go straight into v_cndmask as lane masks (inverse ballot),
 // the wave sum leaves through one readlane, the fp32 update is two fused operations per element (new = (1 - lrate reg) old + (lrate
 // e) other: the same value as old + lrate (e other - reg old) up to rounding; the fp64 kernel keeps the reference's expression and
 // operation order), the loss is accumulated per lane and reduced once per owner.
@@ -633,7 +633,6 @@ template <typename T, int MODEL, int VPL, int D, bool HUB_ITEM, bool STRICT>
 __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec *__restrict__ recs, const int64_t *__restrict__ own_off,
                                                     gran_t *tagged, int *error, int n_owners, int n_team) {
     constexpr int NW = Tagged<T>::NW;
-    using M = Traits<MODEL>;
     using S = Sides<MODEL, HUB_ITEM>;
     static_assert(MODEL != CAMF_C, "CAMF_C has no owner schedule (shared condBias)");
     constexpr bool F32 = sizeof(T) == 4;
