@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """SURVEY 8(d)'s heavy-tail stress run: CAMF_CI k=128, 100 K users x 10 K items, 5 M ratings, Zipf(1.1) items (the hottest item holds
 about 15 % of the ratings).  GPU epoch (default schedule and, for comparison, the level walk) against the CPU oracle on the same tuples.
-usage: tools/bench_zipf_small.py [zipf]"""
+usage: tests/tools/bench_zipf_small.py [zipf]"""
 import json
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from carskit_amd import capi, synth  # noqa: E402
 from oracle import oracle_c  # noqa: E402

@@ -3,13 +3,13 @@
 item skew / flags, incl. the hub-chain kernels forced on both hub sides -- narrow data sends them through sgd_chain_tail -- and the
 owner (dataflow) kernel with few / many owners).
 fp64+strict: model state must be bit-identical; fp32: loss within 2e-5 and state within 2e-4.
-usage: tools/fuzz_gpu.py [n_cases] [seed]"""
+usage: tests/tools/fuzz_gpu.py [n_cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from carskit_amd import capi, synth  # noqa: E402
 from oracle import oracle_c  # noqa: E402

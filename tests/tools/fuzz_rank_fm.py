@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Differential fuzz of cmi_eval_rankings (fp64 state) and of the FM sweep against their oracles on random small problems.
-usage: tools/fuzz_rank_fm.py [n_cases] [seed]"""
+usage: tests/tools/fuzz_rank_fm.py [n_cases] [seed]"""
 import math
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from carskit_amd import capi, synth  # noqa: E402
 from oracle import oracle_c, rank_oracle  # noqa: E402
