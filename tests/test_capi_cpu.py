@@ -34,14 +34,18 @@ def test_no_cpu_fallback():
 
 
 def test_product_package_never_imports_oracle():
-    """No file of the product package imports, loads or links anything under oracle/ (comments may mention it)."""
+    """No file of the product package -- nor of tools/, include/, java/, jni/ -- imports, loads or links anything under oracle/
+    (comments may mention it).  Only tests/ (incl. tests/tools/), __graft_entry__.smoke() and bench.py's cpu_baseline leg do."""
     pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b|from\s+\.\.?oracle\b)|libcarskit_oracle|oracle_c\b|oracle_np\b|"
                      r"carskit_oracle\.h|[\"'/]oracle/", re.M)
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "carskit_amd")):
-        for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
-                src = open(os.path.join(dirpath, f)).read()
-                assert not pat.search(src), os.path.join(dirpath, f)
+    for top in ("carskit_amd", "tools", "include", "java", "jni"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".c", ".sh", ".java")) or f == "Makefile":
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert not pat.search(src), os.path.join(dirpath, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert len(re.findall(r"^\s*from oracle import", bench, re.M)) == 1 and "def cpu_baseline" in bench.split("from oracle import")[0][-2500:]
 
 
 def _check_schedule(u, j, nu, ni, order):
