@@ -16,7 +16,7 @@ import time
 
 import numpy as np
 
-from . import capi, synth
+from carskit_amd import capi, synth
 from .config import java_float
 
 

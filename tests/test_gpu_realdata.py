@@ -10,7 +10,8 @@ import shutil
 import numpy as np
 import pytest
 
-from carskit_amd import capi, main, recommender, synth
+from carskit_amd import capi, synth
+from tests.hostmirror import main, recommender
 from tests import util
 
 pytestmark = pytest.mark.gpu
@@ -172,7 +173,8 @@ def test_cpp_host_driver_parallel_folds_and_fm(tmp_path):
     C++ driver matches the dense FM oracle on the same folds and init stream."""
     import re
     import subprocess
-    from carskit_amd import dao, splitter
+    from carskit_amd import dao
+    from tests.hostmirror import splitter
     from oracle import oracle_c
     from tests.test_host_layer import EXE, _depaul_conf
     conf = _depaul_conf(tmp_path)

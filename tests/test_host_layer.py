@@ -7,7 +7,8 @@ import shutil
 import numpy as np
 import pytest
 
-from carskit_amd import config, javarand, main, recommender, splitter, synth
+from carskit_amd import synth
+from tests.hostmirror import config, javarand, main, recommender, splitter
 from oracle import oracle_np
 from tests import util
 

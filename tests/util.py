@@ -51,7 +51,7 @@ def c_oracle(model, data, k, state, gm, regU=REG, regI=REG, regB=REG, regC=REGC)
 
 
 class OracleEngine:
-    """The CPU oracle behind carskit_amd.recommender's engine interface (tests only: the product engine is
+    """The CPU oracle behind tests.hostmirror.recommender's engine interface (tests only: the product engine is
     recommender.GpuEngine)."""
 
     def __init__(self, model, k, data, tuples, hp, flags=0, device=0):
