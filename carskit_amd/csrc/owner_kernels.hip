@@ -7,8 +7,8 @@
 //     of the list share the hub row it stays in registers -- the chain along the hottest row, which a level schedule pays a launch
 //     or a barrier per link for, costs one dot product + one axpy of latency per link here;
 //   * spoke side (P row, userBias, ucBias row): the row's RECORD in a tagged copy of the table.  A record is a run of 8-byte granules
-//     {tag, 32 data bits}, written by single 8-byte device-coherent (sc1, write-through) stores and read by 8-byte sc1 loads; the tag
-//     is the number of updates applied to the row so far this epoch.  The tuple that needs update count `want` may use the record
+//     {32 data bits, tag}, written by device-coherent (sc0 sc1, write-through) stores and read by L1-bypassing loads, one or two
+//     whole aligned granules per lane and instruction; the tag is the number of updates applied to the row so far this epoch.  The tuple that needs update count `want` may use the record
 //     once EVERY granule carries tag == want: the data is the flag, so there is no separate version word, no store drain and no
 //     fence (CDNA4 hand-off recipe R2: data-tagged granules).  A granule is never torn (one aligned 8-byte store) and a record in
 //     mid-update simply fails the test.  The updated record is written back with tag want + 1.
@@ -16,7 +16,10 @@
 //     only then does the owner poll) -- the owner of a hot row is bound by the arithmetic chain, not by HBM latency.
 // A tag pass before the launch builds the records (tag 0) from the model tables and an untag pass after it writes them back, both
 // at copy speed.  Everything in sgd_owner is wave-uniform: one tuple per wavefront step, the tuple's fields arrive through scalar
-// loads, and lane l holds elements l, l+64, ... of each row, condition l of the context-bias rows.
+// loads, and lane l holds elements l VPL ... l VPL + VPL - 1 of each row, condition l of the context-bias rows.
+// Two forms share the launch: four one-wavefront owners per workgroup (sgd_owner's body), and, for the owners of the hottest rows, a
+// workgroup per owner whose three wavefronts split the step (owner_team: loader -> LDS ring -> compute -> LDS ring -> storer).
+// With CMI_FLAG_STRICT (fp64) the step uses the reference's operation order throughout and the model is bit-identical to the oracle's.
 #include "sgd_device.hpp"
 #include "level_schedule.hpp"
 
