@@ -436,9 +436,10 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         !getenv("CMI_NO_OWNER") && has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict)) {
         // Narrow levels on a large data set = heavy-tailed degrees: every level costs a kernel boundary or a workgroup barrier (>= 2 us),
         // and there are at least as many levels as the hottest row has tuples.  The owner epoch pays ~0.3 us per tuple of the hottest
-        // row it owns and a hand-off (0.86 us measured, tools/exp_owner_handoff.py) per tuple of the hottest row on the other side.
-        // Taken when that is at least twice faster.
-        int64_t min_tuples = (int64_t)1 << 20;
+        // row it owns and a hand-off (0.86 us measured, tools/exp_owner_handoff.py) per tuple of the hottest row on the other side,
+        // plus ~0.3 ms for the tag / untag passes and the launch.  Taken for heavy-tailed data when that is at least twice faster
+        // (measured: 3.3-3.7x at 100 K - 800 K ratings with Zipf(1.1) items, tests/tools/bench_zipf_small.py).
+        int64_t min_tuples = (int64_t)1 << 16;
         if (const char *env = getenv("CMI_OWNER_MIN_TUPLES")) min_tuples = atoll(env);
         if (n >= min_tuples) {
             std::vector<int32_t> du((size_t)h->n_users, 0), dj((size_t)h->n_items, 0);
@@ -447,9 +448,21 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
                 dj[(size_t)j[t]]++;
             }
             const double mu = *std::max_element(du.begin(), du.end()), mj = *std::max_element(dj.begin(), dj.end());
-            const double est_owner = std::max(std::max(mu, mj) * 0.3e-6, std::min(mu, mj) * 1e-6) + 3e-3;
-            const double est_levels = (double)count_plain_levels(n, u, j, h->n_users, h->n_items) * 2e-6;
-            use_owner = est_levels >= 2.0 * est_owner;
+            const bool hub_item = mj >= mu; // what build_owner_schedule will pick
+            int64_t rows_used = 0;          // rows of the hub side that have tuples at all
+            for (int32_t d : (hub_item ? dj : du)) rows_used += d > 0;
+            // heavy-tailed = the hottest hub row holds at least 8 average rows' worth of tuples (uniform data: 1.5 - 2)
+            const bool skewed = std::max(mu, mj) * (double)rows_used >= 8.0 * (double)n;
+            // the tagged record table is addressed through one buffer resource: below 4 GB
+            const int64_t rec_bytes = owner_record_stride(h->model, h->k, h->n_conds, h->f64, hub_item) * 8;
+            const bool table_fits = ((int64_t)(hub_item ? h->n_users : h->n_items) + 4096) * rec_bytes < ((int64_t)1 << 32) - 65536;
+            if (skewed && table_fits) {
+                // owner: the hottest chains, or the bulk spread over ~1 000 owners at ~0.5 us per tuple of a list that switches rows
+                const double est_owner = std::max(std::max(std::max(mu, mj) * 0.3e-6, std::min(mu, mj) * 1e-6), (double)n * 0.5e-6 / 1024.0) + 0.3e-3;
+                // levels: a boundary or barrier per level plus the traffic (2 KB per tuple at ~5 TB/s)
+                const double est_levels = (double)count_plain_levels(n, u, j, h->n_users, h->n_items) * 2e-6 + (double)n * 0.4e-9;
+                use_owner = est_levels >= 2.0 * est_owner;
+            }
         }
     }
     if (use_owner) {

@@ -104,7 +104,7 @@ extern "C" {
                                      * (items, or users) is owned by one wavefront that walks the row's tuples in CRS order with the
                                      * row in registers; the other side's rows travel between owners as tagged records
                                      * (owner_kernels.hip).  Order-exact like the level schedules; k <= 256 (fp64: 128), <= 64 conditions */
-#define CMI_FLAG_NO_OWNER 0x400u /* never pick the owner schedule automatically (it is picked for >= 2^20 tuples whose dependency levels
+#define CMI_FLAG_NO_OWNER 0x400u /* never pick the owner schedule automatically (it is picked for >= 2^16 tuples whose dependency levels
                                   * are narrow -- heavy-tailed degrees -- when its estimated epoch is at least twice shorter) */
 #define CMI_FLAG_NO_GRAPH 0x10u  /* launch the per-level kernels eagerly instead of replaying a hipGraph */
 

@@ -157,14 +157,15 @@ def test_chain_tail_on_heavy_tailed_items_bitwise_equals_plain():
     """Heavy-tailed item degrees: the hot items' chains force tens of thousands of narrow levels.  Forced, the hub-chain schedule
     walks runs of narrow chain levels in one launch (sgd_chain_tail: one workgroup, a barrier per level; ids one level ahead) and is
     still bit-identical to the plain level schedule.  It is NOT chosen automatically there: a narrow chain level is bound by the
-    latency of every spoke row of its longest unit, and measured slower than the plain narrow-run walk."""
+    latency of every spoke row of its longest unit, and measured slower than the plain narrow-run walk; the
+    automatic choice for such data is the owner epoch."""
     data = synth.generate(20000, 2000, 4, 4, 400_000, seed=51, item_zipf=0.9)
     for model, k in (("CAMF_CI", 128), ("CAMF_CU", 64), ("BiasedMF", 64)):
-        _, plain = make_pair(model, data, k, NOCHAIN)
+        _, plain = make_pair(model, data, k, NOCHAIN | capi.FLAG_NO_OWNER)
         _, auto = make_pair(model, data, k, 0)
         _, chain = make_pair(model, data, k, CHAIN)
         kind = chain.schedule_info()["kind"]
-        assert auto.schedule_info()["kind"] == "level" and kind.startswith("chain-")
+        assert auto.schedule_info()["kind"] == "owner-item" and kind.startswith("chain-")   # narrow levels: the owner epoch by default
         u, j, _, _ = util.tuples_for(model, data)
         _, _, lo, _ = capi.chain_schedule(u, j, data.n_users, data.n_items, 1 if kind == "chain-item" else 0, 16)
         assert chain.schedule_info()["levels"] < 0.2 * (len(lo) - 1)       # launches: runs of narrow levels share one

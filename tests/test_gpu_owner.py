@@ -168,7 +168,7 @@ def test_owner_epoch_leaves_the_tables_usable_by_the_other_paths():
 
 
 def test_owner_is_picked_for_large_heavy_tailed_data_and_not_for_uniform():
-    """>= 2^20 tuples whose levels are narrow: the owner epoch is the default; CMI_FLAG_NO_OWNER keeps the plain levels (same model to
+    """>= 2^16 tuples whose levels are narrow: the owner epoch is the default; CMI_FLAG_NO_OWNER keeps the plain levels (same model to
     fp32 rounding: the owner kernel's fp32 update is the fused two-operation form).  Uniform data of the same size stays on the hub-chain
     levels."""
     data = synth.generate(50_000, 5_000, 4, 8, 2_000_000, seed=17, item_zipf=1.0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """SURVEY 8(d)'s heavy-tail stress run: CAMF_CI k=128, 100 K users x 10 K items, 5 M ratings, Zipf(1.1) items (the hottest item holds
 about 15 % of the ratings).  GPU epoch (default schedule and, for comparison, the level walk) against the CPU oracle on the same tuples.
-usage: tests/tools/bench_zipf_small.py [zipf]"""
+usage: tests/tools/bench_zipf_small.py [zipf [users items ratings]]"""
 import json
 import os
 import sys
@@ -18,13 +18,14 @@ from tests import util  # noqa: E402
 
 def main():
     z = float(sys.argv[1]) if len(sys.argv) > 1 else 1.1
-    data = synth.generate(100_000, 10_000, 4, 8, 5_000_000, seed=7, item_zipf=z)
+    nu, ni, n = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (100_000, 10_000, 5_000_000)
+    data = synth.generate(nu, ni, 4, 8, n, seed=7, item_zipf=z)
     k = 128
     state = synth.init_state("CAMF_CI", data, k, dtype=np.float32)
     gm = oracle_c.global_mean(data.r)
     out = {"workload": "CAMF_CI k=128, %d users x %d items, %d ratings, Zipf(%g) items, hottest item %d ratings"
            % (data.n_users, data.n_items, data.n, z, int(np.bincount(data.j).max()))}
-    for name, flags in (("default", 0), ("level_walk", capi.FLAG_NO_OWNER)):
+    for name, flags in (("default", 0), ("level_walk", capi.FLAG_NO_OWNER), ("owner_forced", capi.FLAG_SCHED_OWNER)):
         inst = capi.Instance("CAMF_CI", k, data.n_users, data.n_items, data.n_conds, flags=flags)
         inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, gm)
         inst.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
