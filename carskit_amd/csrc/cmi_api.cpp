@@ -470,7 +470,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (const char *env = getenv("CMI_OWNER_HUB")) hub = !strcmp(env, "item") ? 1 : (!strcmp(env, "user") ? 0 : -1);
         if (n > 0) {
             // the owners must all be resident: as many as the device holds wavefronts of the kernel (either hub side: same registers)
-            int waves = owner_grid_waves(h->device, h->model, h->k, h->f64, true);
+            int waves = owner_grid_waves(h->device, h->model, h->n_conds, h->k, h->f64, true);
             if (const char *env = getenv("CMI_OWNER_WAVES")) {
                 const int v = atoi(env);
                 if (v >= 1 && v < waves) waves = v;
@@ -684,34 +684,43 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         // every owner's list is followed by 2 x depth inert entries (OWN_NOP) on the owner's dummy record behind the table: the kernel
         // runs whole rounds of up to `depth` steps and reads entries depth + 1 places ahead, unchecked
         const int pad = 2 * owner_depth();
-        std::vector<OwnerRec> recs((size_t)n + (size_t)h->n_owners * (size_t)pad);
+        const int ncw = owner_mask_words(h->model, h->n_conds);
+        const size_t rb = owner_rec_bytes(ncw);   // OwnerRecT<ncw>: {off, hub, want, flags, rating, mask[ncw]}
+        std::vector<uint64_t> recs(((size_t)n + (size_t)h->n_owners * (size_t)pad) * (rb / 8), 0);
+        auto put = [&](int64_t pos, uint32_t off, int32_t hub, uint32_t want, uint32_t flags, double rating, const uint64_t *mask) {
+            unsigned char *q = reinterpret_cast<unsigned char *>(recs.data()) + (size_t)pos * rb;
+            memcpy(q, &off, 4);
+            memcpy(q + 4, &hub, 4);
+            memcpy(q + 8, &want, 4);
+            memcpy(q + 12, &flags, 4);
+            if (h->f64) memcpy(q + 16, &rating, 8);
+            else {
+                const float rf = (float)rating;
+                memcpy(q + 16, &rf, 4);
+            }
+            if (mask) memcpy(q + 24, mask, 8 * (size_t)ncw);
+        };
         int64_t out = 0;
         int32_t w = 0;
         auto nop = [&](int32_t owner) {
-            return OwnerRec{(uint32_t)(((int64_t)n_spokes + owner) * rec_bytes), 0, 0, OWN_HUB_FWD | OWN_SPK_FWD | OWN_NOP, 0, {0.0}};
+            put(out++, (uint32_t)(((int64_t)n_spokes + owner) * rec_bytes), 0, 0, OWN_HUB_FWD | OWN_SPK_FWD | OWN_NOP, 0.0, nullptr);
         };
         for (; w < h->n_owners && osch.own_off[(size_t)w + 1] == 0; ++w) // owners without tuples ahead of the first list
-            for (int i = 0; i < pad; ++i) recs[(size_t)out++] = nop(w);
+            for (int i = 0; i < pad; ++i) nop(w);
         for (int64_t s = 0; s < n; ++s) {
             const int64_t t = sch.perm[(size_t)s];
-            OwnerRec &q = recs[(size_t)out++];
-            q.off = (uint32_t)((int64_t)(h->owner_hub_item ? u[t] : j[t]) * rec_bytes);
-            q.hub = h->owner_hub_item ? j[t] : u[t];
-            q.want = osch.want[(size_t)s];
-            q.flags = osch.flags[(size_t)s];
-            q.mask = 0;
+            uint64_t mask[6] = {0, 0, 0, 0, 0, 0};
             if (contextual)
-                for (int32_t c = ctx_ptr[ctx[t]]; c < ctx_ptr[ctx[t] + 1]; ++c) q.mask |= (uint64_t)1 << ctx_conds[c];
-            q.rating.d = 0.0;
-            if (h->f64) q.rating.d = r[t];
-            else q.rating.f = (float)r[t];
+                for (int32_t c = ctx_ptr[ctx[t]]; c < ctx_ptr[ctx[t] + 1]; ++c) mask[ctx_conds[c] >> 6] |= (uint64_t)1 << (ctx_conds[c] & 63);
+            put(out++, (uint32_t)((int64_t)(h->owner_hub_item ? u[t] : j[t]) * rec_bytes), h->owner_hub_item ? j[t] : u[t], osch.want[(size_t)s],
+                osch.flags[(size_t)s], r[t], mask);
             while (w < h->n_owners && s + 1 == osch.own_off[(size_t)w + 1]) { // the end of owner w's list (and of empty owners after it)
-                for (int i = 0; i < pad; ++i) recs[(size_t)out++] = nop(w);
+                for (int i = 0; i < pad; ++i) nop(w);
                 ++w;
             }
         }
         for (; w < h->n_owners; ++w) // owners without tuples (n == 0 never gets here)
-            for (int i = 0; i < pad; ++i) recs[(size_t)out++] = nop(w);
+            for (int i = 0; i < pad; ++i) nop(w);
         e = upload((void **)&h->d_own_recs, recs, h->stream);
         if (e == hipSuccess) e = upload((void **)&h->d_own_off, osch.own_off, h->stream);
         if (e == hipSuccess) e = hipMalloc(&h->d_tagged, ((size_t)n_spokes + (size_t)h->n_owners) * (size_t)h->own_stride * 8);
@@ -755,7 +764,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         CMI_FAIL(h, CMI_E_HIP, "set_ratings: upload failed: %s", hipGetErrorString(e));
     }
     h->n = n;
-    h->tuple_bytes = h->owner ? (ns + (int64_t)h->n_owners * 2 * owner_depth()) * (int64_t)sizeof(OwnerRec)
+    h->tuple_bytes = h->owner ? (ns + (int64_t)h->n_owners * 2 * owner_depth()) * (int64_t)owner_rec_bytes(owner_mask_words(h->model, h->n_conds))
                               : ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + (h->flow ? 8 : 0)) + (h->chain ? 4 * (h->n_units + 1) : 0);
     h->have_ratings = true;
     return CMI_OK;

@@ -174,25 +174,28 @@ hipError_t launch_convert(const void *src, int src_f64, void *dst, int dst_f64, 
 
 
 // ---- owner (dataflow) epoch for heavy-tailed degrees (owner_kernels.hip; schedule: build_owner_schedule) ----
-struct OwnerRec {       // one tuple of an owner's list, read through scalar loads (32 bytes)
+template <int NCW>
+struct OwnerRecT {      // one tuple of an owner's list, read through scalar loads (24 + 8 NCW bytes)
     uint32_t off;       // byte offset of the spoke row's tagged record in the record table (< 4 GB: one buffer resource)
     int32_t hub;        // the row the owner keeps
     uint32_t want;      // tag the spoke record must carry (= its update count before this tuple)
     uint32_t flags;     // OWN_* (level_schedule.hpp)
-    uint64_t mask;      // bit c = condition c is in the tuple's context (used as a lane mask)
     union {
         double d;       // fp64 state
         float f;        // fp32 state
     } rating;
+    uint64_t mask[NCW]; // bit c of word w = condition 64 w + c is in the tuple's context (each word is used as a lane mask)
 };
+inline size_t owner_rec_bytes(int ncw) { return 24 + 8 * (size_t)ncw; }
+int owner_mask_words(int model, int n_conds);                                             // NCW for a model: 1, 2 or 6
 bool has_owner_path(int model, int k, int n_conds, bool f64, bool strict);
 int owner_depth();                                                                        // read-ahead distance of the kernel
 int64_t owner_record_stride(int model, int k, int n_conds, bool f64, bool hub_is_item);   // granules (8 bytes) per spoke record
-int owner_grid_waves(int device, int model, int k, bool f64, bool hub_is_item);           // owners that are resident together
+int owner_grid_waves(int device, int model, int n_conds, int k, bool f64, bool hub_is_item);           // owners that are resident together
 // tag pass + the persistent epoch + untag pass; loss partials in a.loss_part[0 .. n_owners)
 template <typename T>
 // owners [0, n_team) run as teams of three wavefronts (one workgroup each), the rest four to a workgroup
-hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, bool strict, const OwnerRec *recs, const int64_t *own_off,
+hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, bool strict, const void *recs, const int64_t *own_off,
                               int n_owners, int n_team, void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s);
 
 } // namespace cmi

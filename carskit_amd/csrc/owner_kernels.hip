@@ -16,7 +16,7 @@
 //     only then does the owner poll) -- the owner of a hot row is bound by the arithmetic chain, not by HBM latency.
 // A tag pass before the launch builds the records (tag 0) from the model tables and an untag pass after it writes them back, both
 // at copy speed.  Everything in sgd_owner is wave-uniform: one tuple per wavefront step, the tuple's fields arrive through scalar
-// loads, and lane l holds elements l VPL ... l VPL + VPL - 1 of each row, condition l of the context-bias rows.
+// loads, and lane l holds elements l VPL ... l VPL + VPL - 1 of each row, conditions l, l + 64, ... of the context-bias rows (NCW words).
 // Two forms share the launch: four one-wavefront owners per workgroup (sgd_owner's body), and, for the owners of the hottest rows, a
 // workgroup per owner whose three wavefronts split the step (owner_team: loader -> LDS ring -> compute -> LDS ring -> storer).
 // With CMI_FLAG_STRICT (fp64) the step uses the reference's operation order throughout and the model is bit-identical to the oracle's.
@@ -92,12 +92,12 @@ struct Sides {
 };
 
 // Record layout, in elements: [0, 64 VPL) the factor row PADDED to whole wavefronts (lane l owns elements l VPL .. l VPL + VPL - 1),
-// then 64 elements of the context-bias row (lane c = condition c) when the spoke side has one, then the scalar bias.  The padding is
+// then 64 NCW elements of the context-bias row (lane l holds conditions l, l + 64, ...) when the spoke side has one, then the scalar bias.  The padding is
 // what lets the steady state run without a single masked access: every lane loads and stores all its granules, the elements past k
 // (past n_conds) are zeros that stay zero under the update.
-__host__ __device__ inline int64_t owner_record_granules(int vpl, bool sc, bool sb, int nw) {
-    const int64_t g = (int64_t)(64 * vpl + (sc ? 64 : 0) + (sb ? 1 : 0)) * nw;
-    return (g + 15) & ~(int64_t)15; // 128-byte multiples (OwnerRec::off128)
+__host__ __device__ inline int64_t owner_record_granules(int vpl, int ncw, bool sb, int nw) { // ncw: 64-condition words of the context row (0: none)
+    const int64_t g = (int64_t)(64 * vpl + 64 * ncw + (sb ? 1 : 0)) * nw;
+    return (g + 15) & ~(int64_t)15; // 128-byte multiples
 }
 __host__ __device__ inline int owner_vpl(int k) { return k <= 64 ? 1 : (k <= 128 ? 2 : 4); }
 
@@ -123,7 +123,7 @@ __device__ __forceinline__ double wave_total(double x) {
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool TO_RECORDS>
 __global__ __launch_bounds__(256) void owner_records(T *__restrict__ rows, T *__restrict__ ctx, T *__restrict__ bias, gran_t *__restrict__ tagged,
-                                                     int64_t stride, int n_spokes, int k, int ncs, int vpl) {
+                                                     int64_t stride, int n_spokes, int k, int ncs, int vpl, int ncw) {
     const int lane = threadIdx.x & 63;
     const int row_cap = 64 * vpl;
     const int64_t waves = (int64_t)gridDim.x * 4;
@@ -133,12 +133,13 @@ __global__ __launch_bounds__(256) void owner_records(T *__restrict__ rows, T *__
             if (TO_RECORDS) Tagged<T>::store_plain(rec, e, e < k ? rows[s * k + e] : (T)0, 0u);
             else if (e < k) rows[s * k + e] = Tagged<T>::value(Tagged<T>::load(rec, e));
         }
-        if (ctx) {
-            if (TO_RECORDS) Tagged<T>::store_plain(rec, row_cap + lane, lane < ncs ? ctx[s * ncs + lane] : (T)0, 0u);
-            else if (lane < ncs) ctx[s * ncs + lane] = Tagged<T>::value(Tagged<T>::load(rec, row_cap + lane));
-        }
+        if (ctx)
+            for (int c = lane; c < 64 * ncw; c += 64) {
+                if (TO_RECORDS) Tagged<T>::store_plain(rec, row_cap + c, c < ncs ? ctx[s * ncs + c] : (T)0, 0u);
+                else if (c < ncs) ctx[s * ncs + c] = Tagged<T>::value(Tagged<T>::load(rec, row_cap + c));
+            }
         if (bias && lane == 0) {
-            const int e = row_cap + (ctx ? 64 : 0);
+            const int e = row_cap + (ctx ? 64 * ncw : 0);
             if (TO_RECORDS) Tagged<T>::store_plain(rec, e, bias[s], 0u);
             else bias[s] = Tagged<T>::value(Tagged<T>::load(rec, e));
         }
@@ -199,24 +200,27 @@ __device__ __forceinline__ void owner_pack(uint32_t *w, int i, double v, uint32_
 }
 
 // what a list position prefetches, D positions ahead of its use
-template <typename T, int VPL>
+template <typename T, int VPL, int NCW>
 struct OwnerSlot {
     static constexpr int NW = Tagged<T>::NW;
-    uint32_t xw[VPL * NW * 2], cw[NW * 2], bw[NW * 2]; // spoke record: this lane's row elements, context bias of condition `lane`, bias
-    T hq[VPL], hc, hb;                                 // hub side, plain
+    uint32_t xw[VPL * NW * 2], cw[NCW][NW * 2], bw[NW * 2]; // spoke record: this lane's row elements, context biases of conditions lane + 64 w, bias
+    T hq[VPL], hc[NCW], hb;                                 // hub side, plain
 };
 
-template <typename T, int MODEL, int VPL, bool HUB_ITEM>
-__device__ __forceinline__ void owner_load_spoke(__amdgpu_buffer_rsrc_t rs, int soff, int lane, OwnerSlot<T, VPL> &s) {
+template <typename T, int MODEL, int VPL, int NCW, bool HUB_ITEM>
+__device__ __forceinline__ void owner_load_spoke(__amdgpu_buffer_rsrc_t rs, int soff, int lane, OwnerSlot<T, VPL, NCW> &s) {
     using S = Sides<MODEL, HUB_ITEM>;
     constexpr int NW = Tagged<T>::NW;
     owner_ld_words(rs, lane * (VPL * NW * 8), soff, s.xw);
-    if (S::SC) owner_ld_words(rs, 64 * VPL * NW * 8 + lane * (NW * 8), soff, s.cw);
-    if (S::SB) owner_ld_words(rs, (64 * VPL + (S::SC ? 64 : 0)) * NW * 8, soff, s.bw); // the same granule(s) in every lane
+    if (S::SC) {
+#pragma unroll
+        for (int w = 0; w < NCW; ++w) owner_ld_words(rs, (64 * VPL + 64 * w) * NW * 8 + lane * (NW * 8), soff, s.cw[w]);
+    }
+    if (S::SB) owner_ld_words(rs, (64 * VPL + (S::SC ? 64 * NCW : 0)) * NW * 8, soff, s.bw); // the same granule(s) in every lane
 }
 
-template <typename T, int MODEL, int VPL, bool HUB_ITEM>
-__device__ __forceinline__ bool owner_spoke_ok(const OwnerSlot<T, VPL> &s, uint32_t want) {
+template <typename T, int MODEL, int VPL, int NCW, bool HUB_ITEM>
+__device__ __forceinline__ bool owner_spoke_ok(const OwnerSlot<T, VPL, NCW> &s, uint32_t want) {
     using S = Sides<MODEL, HUB_ITEM>;
     constexpr int NW = Tagged<T>::NW;
     bool ok = true;
@@ -224,7 +228,10 @@ __device__ __forceinline__ bool owner_spoke_ok(const OwnerSlot<T, VPL> &s, uint3
     for (int i = 0; i < VPL * NW; ++i) ok &= s.xw[2 * i + 1] == want;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-        if (S::SC) ok &= s.cw[2 * i + 1] == want;
+        if (S::SC) {
+#pragma unroll
+            for (int w = 0; w < NCW; ++w) ok &= s.cw[w][2 * i + 1] == want;
+        }
         if (S::SB) ok &= s.bw[2 * i + 1] == want;
     }
     return ok;
@@ -233,13 +240,16 @@ __device__ __forceinline__ bool owner_spoke_ok(const OwnerSlot<T, VPL> &s, uint3
 // hub side: the model tables themselves.  Loads are unmasked (a lane past the end of the row reads the row's last element instead and
 // the value is zeroed where it is taken into the working registers): a masked load would need a zeroed default, and the copy that
 // merges the two makes the compiler wait for the load on the spot.
-template <typename T, int MODEL, int VPL, bool HUB_ITEM>
-__device__ __forceinline__ void owner_load_hub(const SgdArgs<T> &a, int hub, int lane, int k, T (&hq)[VPL], T &hc, T &hb) {
+template <typename T, int MODEL, int VPL, int NCW, bool HUB_ITEM>
+__device__ __forceinline__ void owner_load_hub(const SgdArgs<T> &a, int hub, int lane, int k, T (&hq)[VPL], T (&hc)[NCW], T &hb) {
     using S = Sides<MODEL, HUB_ITEM>;
     const T *row = (HUB_ITEM ? a.Q : a.P) + (size_t)hub * k;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) hq[v] = row[min(lane * VPL + v, k - 1)];
-    if (S::HC) hc = (HUB_ITEM ? a.icBias : a.ucBias)[(size_t)hub * a.n_conds + min(lane, a.n_conds - 1)];
+    if (S::HC) {
+#pragma unroll
+        for (int w = 0; w < NCW; ++w) hc[w] = (HUB_ITEM ? a.icBias : a.ucBias)[(size_t)hub * a.n_conds + min(lane + 64 * w, a.n_conds - 1)];
+    }
     if (S::HB) hb = (HUB_ITEM ? a.itemBias : a.userBias)[hub];
 }
 
@@ -251,11 +261,17 @@ __device__ __forceinline__ void owner_settle(float &v) { asm volatile("" : "+v"(
 __device__ __forceinline__ void owner_settle(double &v) { asm volatile("" : "+v"(v)); }
 
 template <typename T>
-__device__ __forceinline__ T owner_rating(const OwnerRec &r);
+struct OwnerRating;
 template <>
-__device__ __forceinline__ float owner_rating<float>(const OwnerRec &r) { return r.rating.f; }
+struct OwnerRating<float> {
+    template <int NCW>
+    static __device__ __forceinline__ float get(const OwnerRecT<NCW> &r) { return r.rating.f; }
+};
 template <>
-__device__ __forceinline__ double owner_rating<double>(const OwnerRec &r) { return r.rating.d; }
+struct OwnerRating<double> {
+    template <int NCW>
+    static __device__ __forceinline__ double get(const OwnerRecT<NCW> &r) { return r.rating.d; }
+};
 
 template <typename T>
 struct OwnerHp {
@@ -264,14 +280,23 @@ struct OwnerHp {
 
 // One SGD update on the rows in registers: prediction, loss pieces, new values (h: hub row, x: spoke row; hc / sc their context-bias
 // rows with lane c = condition c; hb / sb the scalar biases).  Shared by the wave-per-owner step and the team kernel's compute wave.
-template <typename T, int MODEL, int VPL, bool HUB_ITEM, bool STRICT>
-__device__ __forceinline__ void owner_update(const OwnerRec &r, const OwnerHp<T> &hp, int k, T (&h)[VPL], T &hc, T &hb, T (&x)[VPL], T &sc, T &sb,
-                                             T &sq_p, T &sq_q, T &sq_c, T &sq_e, T &sq_b) {
+template <typename T, int MODEL, int VPL, int NCW, bool HUB_ITEM, bool STRICT>
+__device__ __forceinline__ void owner_update(const OwnerRecT<NCW> &r, const OwnerHp<T> &hp, int k, T (&h)[VPL], T (&hc)[NCW], T &hb, T (&x)[VPL],
+                                             T (&sc)[NCW], T &sb, T &sq_p, T &sq_q, T &sq_c, T &sq_e, T &sq_b) {
     using M = Traits<MODEL>;
     using S = Sides<MODEL, HUB_ITEM>;
     constexpr bool F32 = sizeof(T) == 4;
-    // ---- prediction: hp.gm + bu + bj + (p.q + the context deviations); lane c adds the deviations of condition c
-    const bool sel = M::has_ctx && __builtin_amdgcn_inverse_ballot_w64(r.mask);
+    // ---- prediction: hp.gm + bu + bj + (p.q + the context deviations); lane l adds the deviations of conditions l + 64 w
+    bool sel[NCW];
+    T term[NCW];
+#pragma unroll
+    for (int w = 0; w < NCW; ++w) {
+        sel[w] = M::has_ctx && __builtin_amdgcn_inverse_ballot_w64(r.mask[w]);
+        term[w] = (T)0;
+        if (S::HC && S::SC) term[w] = HUB_ITEM ? hc[w] + sc[w] : sc[w] + hc[w]; // bic + buc
+        else if (S::HC) term[w] = hc[w];
+        else if (S::SC) term[w] = sc[w];
+    }
     const T bu = HUB_ITEM ? sb : hb, bj = HUB_ITEM ? hb : sb;
     T pred = hp.gm;
     if (M::has_bu) pred += bu;
@@ -291,26 +316,21 @@ __device__ __forceinline__ void owner_update(const OwnerRec &r, const OwnerHp<T>
         }
         pred += dot;
         if (M::has_ctx) {
-            T term = (T)0;
-            if (S::HC && S::SC) term = HUB_ITEM ? hc + sc : sc + hc; // bic + buc
-            else if (S::HC) term = hc;
-            else if (S::SC) term = sc;
-            for (uint64_t m = r.mask; m; m &= m - 1) pred += __shfl(term, __builtin_ctzll(m), 64);
+#pragma unroll
+            for (int w = 0; w < NCW; ++w)
+                for (uint64_t m = r.mask[w]; m; m &= m - 1) pred += __shfl(term[w], __builtin_ctzll(m), 64);
         }
     } else {
         T part = (T)0;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) part = owner_fma(x[v], h[v], part);
         if (M::has_ctx) {
-            T term = (T)0;
-            if (S::HC && S::SC) term = HUB_ITEM ? hc + sc : sc + hc; // bic + buc
-            else if (S::HC) term = hc;
-            else if (S::SC) term = sc;
-            part += sel ? term : (T)0;
+#pragma unroll
+            for (int w = 0; w < NCW; ++w) part += sel[w] ? term[w] : (T)0;
         }
         pred += wave_total(part);
     }
-    const T e = owner_rating<T>(r) - pred;
+    const T e = OwnerRating<T>::get(r) - pred;
 
     // ---- loss pieces (old values)
 #pragma unroll
@@ -320,10 +340,13 @@ __device__ __forceinline__ void owner_update(const OwnerRec &r, const OwnerHp<T>
         sq_q = owner_fma(qv, qv, sq_q);
     }
     if (M::has_ctx) {
-        T cc = sq_c;
-        if (S::HC) cc = owner_fma(hc, hc, cc);
-        if (S::SC) cc = owner_fma(sc, sc, cc);
-        sq_c = sel ? cc : sq_c;
+#pragma unroll
+        for (int w = 0; w < NCW; ++w) {
+            T cc = sq_c;
+            if (S::HC) cc = owner_fma(hc[w], hc[w], cc);
+            if (S::SC) cc = owner_fma(sc[w], sc[w], cc);
+            sq_c = sel[w] ? cc : sq_c;
+        }
     }
     sq_e = owner_fma(e, e, sq_e);
     if (M::has_bu) sq_b = owner_fma(bu, bu, sq_b);
@@ -340,8 +363,11 @@ __device__ __forceinline__ void owner_update(const OwnerRec &r, const OwnerHp<T>
         const T le = hp.lr * e;
         if (S::HB) hb = owner_fma(hp.keepB, hb, le);
         if (S::SB) sb = owner_fma(hp.keepB, sb, le);
-        if (S::HC) hc = sel ? owner_fma(hp.keepC, hc, le) : hc;
-        if (S::SC) sc = sel ? owner_fma(hp.keepC, sc, le) : sc;
+#pragma unroll
+        for (int w = 0; w < NCW; ++w) {
+            if (S::HC) hc[w] = sel[w] ? owner_fma(hp.keepC, hc[w], le) : hc[w];
+            if (S::SC) sc[w] = sel[w] ? owner_fma(hp.keepC, sc[w], le) : sc[w];
+        }
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
             const T pv = HUB_ITEM ? x[v] : h[v], qv = HUB_ITEM ? h[v] : x[v];
@@ -353,8 +379,11 @@ __device__ __forceinline__ void owner_update(const OwnerRec &r, const OwnerHp<T>
     } else {
         if (S::HB) hb = hb + hp.lr * (e - hp.regB * hb);
         if (S::SB) sb = sb + hp.lr * (e - hp.regB * sb);
-        if (S::HC) hc = sel ? hc + hp.lr * (e - hp.regC * hc) : hc;
-        if (S::SC) sc = sel ? sc + hp.lr * (e - hp.regC * sc) : sc;
+#pragma unroll
+        for (int w = 0; w < NCW; ++w) {
+            if (S::HC) hc[w] = sel[w] ? hc[w] + hp.lr * (e - hp.regC * hc[w]) : hc[w];
+            if (S::SC) sc[w] = sel[w] ? sc[w] + hp.lr * (e - hp.regC * sc[w]) : sc[w];
+        }
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
             const T pv = HUB_ITEM ? x[v] : h[v], qv = HUB_ITEM ? h[v] : x[v];
@@ -364,7 +393,6 @@ __device__ __forceinline__ void owner_update(const OwnerRec &r, const OwnerHp<T>
             h[v] = HUB_ITEM ? qn : pn;
         }
     }
-
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -422,17 +450,18 @@ __device__ __forceinline__ void team_put(lds_u8 *p, const T (&v)[VPL]) {
 __device__ __forceinline__ int team_after(float v) { return __builtin_amdgcn_readfirstlane(__float_as_int(v)) & 0; }
 __device__ __forceinline__ int team_after(double v) { return __builtin_amdgcn_readfirstlane(__double2loint(v)) & 0; }
 
-template <typename T, int MODEL, int VPL, bool HUB_ITEM>
+template <typename T, int MODEL, int VPL, int NCW, bool HUB_ITEM>
 __host__ __device__ constexpr int team_slot_bytes() { // row | context biases | bias (16)
-    return 64 * VPL * (int)sizeof(T) + ((HUB_ITEM ? Traits<MODEL>::has_uc : Traits<MODEL>::has_ic) ? 64 * (int)sizeof(T) : 0) + 16;
+    return 64 * VPL * (int)sizeof(T) + ((HUB_ITEM ? Traits<MODEL>::has_uc : Traits<MODEL>::has_ic) ? 64 * NCW * (int)sizeof(T) : 0) + 16;
 }
 
-template <typename T, int MODEL, int VPL, int D, bool HUB_ITEM>
-__device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *__restrict__ recs, int len, int w, __amdgpu_buffer_rsrc_t rs,
+template <typename T, int MODEL, int VPL, int NCW, int D, bool HUB_ITEM>
+__device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<NCW> *__restrict__ recs, int len, int w, __amdgpu_buffer_rsrc_t rs,
                                            const OwnerHp<T> &hp, int *error) {
+    typedef OwnerRecT<NCW> OwnerRec;
     using S = Sides<MODEL, HUB_ITEM>;
     constexpr int NW = Tagged<T>::NW, R = OWNER_TEAM_RING;
-    constexpr int XB = 64 * VPL * (int)sizeof(T), CB = S::SC ? 64 * (int)sizeof(T) : 0, SLOT = team_slot_bytes<T, MODEL, VPL, HUB_ITEM>();
+    constexpr int XB = 64 * VPL * (int)sizeof(T), CB = S::SC ? 64 * NCW * (int)sizeof(T) : 0, SLOT = team_slot_bytes<T, MODEL, VPL, NCW, HUB_ITEM>();
     constexpr int OFF_SB = XB + CB;
     static_assert(D <= R, "the loader never waits for ring space on the inert entries that complete its last round");
     extern __shared__ __attribute__((aligned(16))) unsigned char team_lds[];
@@ -446,12 +475,12 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
     if (role == 3) return;
 
     if (role == 1) { // ---------------- loader
-        OwnerSlot<T, VPL> slot[D];
+        OwnerSlot<T, VPL, NCW> slot[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rs, (int)recs[d].off, lane, slot[d]);
+        for (int d = 0; d < D; ++d) owner_load_spoke<T, MODEL, VPL, NCW, HUB_ITEM>(rs, (int)recs[d].off, lane, slot[d]);
         OwnerRec r_run = recs[0], r_ahead = recs[D];
         uint32_t freed = 0; // entries the storer is known to have taken out of the ring
-        auto step = [&](int c, OwnerSlot<T, VPL> &s) {
+        auto step = [&](int c, OwnerSlot<T, VPL, NCW> &s) {
             const OwnerRec r = r_run, p = r_ahead;
             r_run = recs[c + 1];
             r_ahead = recs[c + 1 + D];
@@ -471,12 +500,12 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
                 T sbv[1];
                 sbv[0] = (T)0;
                 if (!(r.flags & OWN_SPK_FWD)) {
-                    if (__builtin_expect(!__all(owner_spoke_ok<T, MODEL, VPL, HUB_ITEM>(s, r.want)), 0)) {
+                    if (__builtin_expect(!__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want)), 0)) {
                         unsigned spins = 0;
                         while (true) {
                             __builtin_amdgcn_s_sleep(4);
-                            owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rs, (int)r.off, lane, s);
-                            if (__all(owner_spoke_ok<T, MODEL, VPL, HUB_ITEM>(s, r.want))) break;
+                            owner_load_spoke<T, MODEL, VPL, NCW, HUB_ITEM>(rs, (int)r.off, lane, s);
+                            if (__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want))) break;
                             if (++spins > CMI_OWNER_SPIN_LIMIT) {
                                 if (lane == 0) atomicExch(error, 1);
                                 break;
@@ -488,8 +517,11 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
                     for (int v = 0; v < VPL; ++v) xv[v] = owner_elem(s.xw, v, (T)0);
                     team_put<T, VPL>(sl + lane * (VPL * (int)sizeof(T)), xv);
                     if (S::SC) {
-                        one[0] = owner_elem(s.cw, 0, (T)0);
-                        team_put<T, 1>(sl + XB + lane * (int)sizeof(T), one);
+#pragma unroll
+                        for (int cw = 0; cw < NCW; ++cw) {
+                            one[0] = owner_elem(s.cw[cw], 0, (T)0);
+                            team_put<T, 1>(sl + XB + (64 * cw + lane) * (int)sizeof(T), one);
+                        }
                     }
                     if (S::SB) sbv[0] = owner_elem(s.bw, 0, (T)0);
                 }
@@ -498,7 +530,7 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
                     ctr[0] = (uint32_t)c + 1u;
                 }
             }
-            owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rs, (int)p.off, lane, s);
+            owner_load_spoke<T, MODEL, VPL, NCW, HUB_ITEM>(rs, (int)p.off, lane, s);
         };
         for (int base = 0; base < len; base += D) {
 #pragma unroll
@@ -523,9 +555,12 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
                 }
             }
             const lds_u8 *sl = ring + (c % R) * SLOT;
-            T xv[VPL], cv[1], bv[1];
+            T xv[VPL], cv[NCW][1], bv[1];
             team_get<T, VPL>(sl + lane * (VPL * (int)sizeof(T)), xv);
-            if (S::SC) team_get<T, 1>(sl + XB + lane * (int)sizeof(T), cv);
+            if (S::SC) {
+#pragma unroll
+                for (int cw = 0; cw < NCW; ++cw) team_get<T, 1>(sl + XB + (64 * cw + lane) * (int)sizeof(T), cv[cw]);
+            }
             if (S::SB) team_get<T, 1>(sl + OFF_SB, bv);
             r_next = recs[c + 1 + team_after(xv[0])];
             const uint32_t tag = r.want + 1u;
@@ -534,12 +569,15 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
             for (int v = 0; v < VPL; ++v) owner_pack(ow, v, xv[v], tag);
             owner_st_words(rs, lane * (VPL * NW * 8), (int)r.off, ow);
             if (S::SC) {
-                owner_pack(oc, 0, cv[0], tag);
-                owner_st_words(rs, 64 * VPL * NW * 8 + lane * (NW * 8), (int)r.off, oc);
+#pragma unroll
+                for (int cw = 0; cw < NCW; ++cw) {
+                    owner_pack(oc, 0, cv[cw][0], tag);
+                    owner_st_words(rs, (64 * VPL + 64 * cw) * NW * 8 + lane * (NW * 8), (int)r.off, oc);
+                }
             }
             if (S::SB) {
                 owner_pack(ob, 0, bv[0], tag);
-                owner_st_words(rs, (64 * VPL + (S::SC ? 64 : 0)) * NW * 8, (int)r.off, ob);
+                owner_st_words(rs, (64 * VPL + (S::SC ? 64 * NCW : 0)) * NW * 8, (int)r.off, ob);
             }
             if (lane == 0) ctr[2] = (uint32_t)c + 1u; // after the reads of the slot (in order): the loader may refill it
         }
@@ -547,9 +585,11 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
     }
 
     // ---------------- compute
-    T h[VPL], hc = (T)0, hb = (T)0, x[VPL], sc = (T)0, sb = (T)0;
+    T h[VPL], hc[NCW], hb = (T)0, x[VPL], sc[NCW], sb = (T)0;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) h[v] = x[v] = (T)0;
+#pragma unroll
+    for (int cw = 0; cw < NCW; ++cw) hc[cw] = sc[cw] = (T)0;
     T sq_p = (T)0, sq_q = (T)0, sq_c = (T)0, sq_e = (T)0, sq_b = (T)0;
     double acc = 0.0;
     uint32_t ready = 0;
@@ -571,19 +611,27 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
         }
         lds_u8 *sl = ring + (c % R) * SLOT;
         if (__builtin_expect(!(r.flags & OWN_HUB_FWD), 0)) { // a single-hub list: once
-            T hq[VPL], hcq = (T)0, hbq = (T)0;
-            owner_load_hub<T, MODEL, VPL, HUB_ITEM>(a, r.hub, lane, k, hq, hcq, hbq);
+            T hq[VPL], hcq[NCW], hbq = (T)0;
+#pragma unroll
+            for (int cw = 0; cw < NCW; ++cw) hcq[cw] = (T)0;
+            owner_load_hub<T, MODEL, VPL, NCW, HUB_ITEM>(a, r.hub, lane, k, hq, hcq, hbq);
 #pragma unroll
             for (int v = 0; v < VPL; ++v) h[v] = lane * VPL + v < k ? hq[v] : (T)0;
-            if (S::HC) hc = lane < a.n_conds ? hcq : (T)0;
+            if (S::HC) {
+#pragma unroll
+                for (int cw = 0; cw < NCW; ++cw) hc[cw] = lane + 64 * cw < a.n_conds ? hcq[cw] : (T)0;
+            }
             if (S::HB) hb = hbq;
         }
         if (!(r.flags & OWN_SPK_FWD)) {
             T one[1];
             team_get<T, VPL>(sl + lane * (VPL * (int)sizeof(T)), x);
             if (S::SC) {
-                team_get<T, 1>(sl + XB + lane * (int)sizeof(T), one);
-                sc = one[0];
+#pragma unroll
+                for (int cw = 0; cw < NCW; ++cw) {
+                    team_get<T, 1>(sl + XB + (64 * cw + lane) * (int)sizeof(T), one);
+                    sc[cw] = one[0];
+                }
             }
             if (S::SB) {
                 team_get<T, 1>(sl + OFF_SB, one);
@@ -591,13 +639,16 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
             }
         }
         r_next = recs[c + 1 + team_after(x[0])];
-        owner_update<T, MODEL, VPL, HUB_ITEM, false>(r, hp, k, h, hc, hb, x, sc, sb, sq_p, sq_q, sq_c, sq_e, sq_b);
+        owner_update<T, MODEL, VPL, NCW, HUB_ITEM, false>(r, hp, k, h, hc, hb, x, sc, sb, sq_p, sq_q, sq_c, sq_e, sq_b);
         {
             T one[1];
             team_put<T, VPL>(sl + lane * (VPL * (int)sizeof(T)), x);
             if (S::SC) {
-                one[0] = sc;
-                team_put<T, 1>(sl + XB + lane * (int)sizeof(T), one);
+#pragma unroll
+                for (int cw = 0; cw < NCW; ++cw) {
+                    one[0] = sc[cw];
+                    team_put<T, 1>(sl + XB + (64 * cw + lane) * (int)sizeof(T), one);
+                }
             }
             if (lane == 0) {
                 if (S::SB) {
@@ -612,7 +663,11 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
                 if (lane * VPL + v < k) row[lane * VPL + v] = h[v];
-            if (S::HC && lane < a.n_conds) (HUB_ITEM ? a.icBias : a.ucBias)[(size_t)r.hub * a.n_conds + lane] = hc;
+            if (S::HC) {
+#pragma unroll
+                for (int cw = 0; cw < NCW; ++cw)
+                    if (lane + 64 * cw < a.n_conds) (HUB_ITEM ? a.icBias : a.ucBias)[(size_t)r.hub * a.n_conds + lane + 64 * cw] = hc[cw];
+            }
             if (S::HB && lane == 0) (HUB_ITEM ? a.itemBias : a.userBias)[r.hub] = hb;
         }
         if ((c & 15) == 15) { // flush the float partial sums of squares into the double accumulator
@@ -632,9 +687,10 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRec *
 // the wave sum leaves through one readlane, the fp32 update is two fused operations per element (new = (1 - lrate reg) old + (lrate
 // e) other: the same value as old + lrate (e other - reg old) up to rounding; the fp64 kernel keeps the reference's expression and
 // operation order), the loss is accumulated per lane and reduced once per owner.
-template <typename T, int MODEL, int VPL, int D, bool HUB_ITEM, bool STRICT>
-__global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec *__restrict__ recs, const int64_t *__restrict__ own_off,
+template <typename T, int MODEL, int VPL, int NCW, int D, bool HUB_ITEM, bool STRICT>
+__global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRecT<NCW> *__restrict__ recs, const int64_t *__restrict__ own_off,
                                                     gran_t *tagged, int *error, int n_owners, int n_team) {
+    typedef OwnerRecT<NCW> OwnerRec;
     constexpr int NW = Tagged<T>::NW;
     using S = Sides<MODEL, HUB_ITEM>;
     static_assert(MODEL != CAMF_C, "CAMF_C has no owner schedule (shared condBias)");
@@ -662,16 +718,18 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
     recs += c0;
     if constexpr (!STRICT) {
         if (team) {
-            owner_team<T, MODEL, VPL, D, HUB_ITEM>(a, recs, len, w, rs, hp, error);
+            owner_team<T, MODEL, VPL, NCW, D, HUB_ITEM>(a, recs, len, w, rs, hp, error);
             return;
         }
     }
 
-    OwnerSlot<T, VPL> slot[D];
+    OwnerSlot<T, VPL, NCW> slot[D];
     // current rows (registers): hub row / context-bias row / bias, and the spoke's after its latest update
-    T h[VPL], hc = (T)0, hb = (T)0, x[VPL], sc = (T)0, sb = (T)0;
+    T h[VPL], hc[NCW], hb = (T)0, x[VPL], sc[NCW], sb = (T)0;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) h[v] = x[v] = (T)0;
+#pragma unroll
+    for (int cw = 0; cw < NCW; ++cw) hc[cw] = sc[cw] = (T)0;
     // loss: per lane sums of squares, scaled and reduced once at the end (flushed to double every round of D steps)
     T sq_p = (T)0, sq_q = (T)0, sq_c = (T)0, sq_e = (T)0, sq_b = (T)0;
     double acc = 0.0;
@@ -679,9 +737,9 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
 
     // The spoke record is ALWAYS read ahead (a fixed number of memory operations per step keeps the compiler's counted waits deep);
     // the hub side only when the step will not take it over in registers.
-    auto prefetch = [&](const OwnerRec &r, OwnerSlot<T, VPL> &s) {
-        owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rs, (int)r.off, lane, s);
-        if (__builtin_expect(!(r.flags & (OWN_HUB_FWD | OWN_HUB_LATE)), 0)) owner_load_hub<T, MODEL, VPL, HUB_ITEM>(a, r.hub, lane, k, s.hq, s.hc, s.hb);
+    auto prefetch = [&](const OwnerRec &r, OwnerSlot<T, VPL, NCW> &s) {
+        owner_load_spoke<T, MODEL, VPL, NCW, HUB_ITEM>(rs, (int)r.off, lane, s);
+        if (__builtin_expect(!(r.flags & (OWN_HUB_FWD | OWN_HUB_LATE)), 0)) owner_load_hub<T, MODEL, VPL, NCW, HUB_ITEM>(a, r.hub, lane, k, s.hq, s.hc, s.hb);
     };
 
 #pragma unroll
@@ -690,7 +748,7 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
     OwnerRec r_run = recs[0], r_ahead = recs[D];
 
     // one step of the list: tuple c, whose read-ahead sits in s; ends by reading ahead for tuple c + D into the same registers
-    auto step = [&](int c, OwnerSlot<T, VPL> &s) {
+    auto step = [&](int c, OwnerSlot<T, VPL, NCW> &s) {
         const OwnerRec r = r_run, p = r_ahead;
         r_run = recs[c + 1];
         r_ahead = recs[c + 1 + D];
@@ -699,25 +757,31 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
         // ---- hub side: registers (same row as the previous step) | read ahead | re-read now (written < D steps ago)
         if (__builtin_expect(!(r.flags & OWN_HUB_FWD), 0)) { // (unlikely: the layout that matters is the hottest owner's)
             if (r.flags & OWN_HUB_LATE) {
-                owner_load_hub<T, MODEL, VPL, HUB_ITEM>(a, r.hub, lane, k, s.hq, s.hc, s.hb);
+                owner_load_hub<T, MODEL, VPL, NCW, HUB_ITEM>(a, r.hub, lane, k, s.hq, s.hc, s.hb);
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) owner_settle(s.hq[v]);
-                owner_settle(s.hc);
+                if (S::HC) {
+#pragma unroll
+                    for (int cw = 0; cw < NCW; ++cw) owner_settle(s.hc[cw]);
+                }
                 owner_settle(s.hb);
             }
 #pragma unroll
             for (int v = 0; v < VPL; ++v) h[v] = lane * VPL + v < k ? s.hq[v] : (T)0;
-            if (S::HC) hc = lane < a.n_conds ? s.hc : (T)0;
+            if (S::HC) {
+#pragma unroll
+                for (int cw = 0; cw < NCW; ++cw) hc[cw] = lane + 64 * cw < a.n_conds ? s.hc[cw] : (T)0;
+            }
             if (S::HB) hb = s.hb;
         }
         // ---- spoke side: registers | the record read ahead, if every granule carries the tag | poll
         if (!(r.flags & OWN_SPK_FWD)) {
-            if (__builtin_expect(!__all(owner_spoke_ok<T, MODEL, VPL, HUB_ITEM>(s, r.want)), 0)) {
+            if (__builtin_expect(!__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want)), 0)) {
                 unsigned spins = 0;
                 while (true) { // the predecessor has not written the record yet (or was in the middle of it)
                     __builtin_amdgcn_s_sleep(4);
-                    owner_load_spoke<T, MODEL, VPL, HUB_ITEM>(rs, (int)r.off, lane, s);
-                    if (__all(owner_spoke_ok<T, MODEL, VPL, HUB_ITEM>(s, r.want))) break;
+                    owner_load_spoke<T, MODEL, VPL, NCW, HUB_ITEM>(rs, (int)r.off, lane, s);
+                    if (__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want))) break;
                     if (++spins > CMI_OWNER_SPIN_LIMIT) {
                         if (lane == 0) atomicExch(error, 1);
                         break;
@@ -728,11 +792,14 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
             }
 #pragma unroll
             for (int v = 0; v < VPL; ++v) x[v] = owner_elem(s.xw, v, (T)0);
-            if (S::SC) sc = owner_elem(s.cw, 0, (T)0);
+            if (S::SC) {
+#pragma unroll
+                for (int cw = 0; cw < NCW; ++cw) sc[cw] = owner_elem(s.cw[cw], 0, (T)0);
+            }
             if (S::SB) sb = owner_elem(s.bw, 0, (T)0);
         }
 
-        owner_update<T, MODEL, VPL, HUB_ITEM, STRICT>(r, hp, k, h, hc, hb, x, sc, sb, sq_p, sq_q, sq_c, sq_e, sq_b);
+        owner_update<T, MODEL, VPL, NCW, HUB_ITEM, STRICT>(r, hp, k, h, hc, hb, x, sc, sb, sq_p, sq_q, sq_c, sq_e, sq_b);
         } // !OWN_NOP
 
         // ---- the spoke record goes back with the next tag (always: one store sequence per step); the hub side when the next
@@ -744,12 +811,15 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
             for (int v = 0; v < VPL; ++v) owner_pack(ow, v, x[v], tag);
             owner_st_words(rs, lane * (VPL * NW * 8), (int)r.off, ow);
             if (S::SC) {
-                owner_pack(oc, 0, sc, tag);
-                owner_st_words(rs, 64 * VPL * NW * 8 + lane * (NW * 8), (int)r.off, oc);
+#pragma unroll
+                for (int cw = 0; cw < NCW; ++cw) {
+                    owner_pack(oc, 0, sc[cw], tag);
+                    owner_st_words(rs, (64 * VPL + 64 * cw) * NW * 8 + lane * (NW * 8), (int)r.off, oc);
+                }
             }
             if (S::SB) {
                 owner_pack(ob, 0, sb, tag);
-                owner_st_words(rs, (64 * VPL + (S::SC ? 64 : 0)) * NW * 8, (int)r.off, ob);
+                owner_st_words(rs, (64 * VPL + (S::SC ? 64 * NCW : 0)) * NW * 8, (int)r.off, ob);
             }
         }
         if (__builtin_expect(r.flags & OWN_HUB_STORE, 0)) {
@@ -757,7 +827,11 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
                 if (lane * VPL + v < k) row[lane * VPL + v] = h[v];
-            if (S::HC && lane < a.n_conds) (HUB_ITEM ? a.icBias : a.ucBias)[(size_t)r.hub * a.n_conds + lane] = hc;
+            if (S::HC) {
+#pragma unroll
+                for (int cw = 0; cw < NCW; ++cw)
+                    if (lane + 64 * cw < a.n_conds) (HUB_ITEM ? a.icBias : a.ucBias)[(size_t)r.hub * a.n_conds + lane + 64 * cw] = hc[cw];
+            }
             if (S::HB && lane == 0) (HUB_ITEM ? a.itemBias : a.userBias)[r.hub] = hb;
         }
 
@@ -797,19 +871,26 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
 // ---------------------------------------------------------------------------------------------
 // Read-ahead distance.  Loads and write-through stores retire through ONE in-order counter (vmcnt, at most 63 outstanding), so the wait
 // for a record read D steps ago also waits for the stores issued before it, and a write-through store takes microseconds to be
-// acknowledged: the step time cannot go below (store latency) / D.  D = 16 where a step issues 4 memory operations, 8 where it
-// issues more (wider rows) -- 15 x 4 = 60 operations in flight.
-template <typename T, int VPL>
+// acknowledged: the step time cannot go below (store latency) / D.  D = 16 where a step issues 4 memory operations (fp32, k <= 128, at
+// most 64 conditions: 15 x 4 = 60 in flight), 8 where it issues up to 8, 4 for the widest context rows (6 x 64 conditions).
+template <typename T, int VPL, int NCW>
 struct OwnerDepth {
-    static constexpr int D = (sizeof(T) == 4 && VPL <= 2) ? 16 : 8;
+    static constexpr int D = (sizeof(T) == 4 && VPL <= 2 && NCW == 1) ? 16 : (NCW <= 2 ? 8 : 4);
 };
+
+// 64-condition words of a context-bias row: 1, 2 or 6 (<= 64, <= 128, <= 384 conditions); models without context: 1
+int owner_mask_words(int model, int n_conds) {
+    const bool has_ctx = model != BIASEDMF && model != PMF;
+    if (!has_ctx || n_conds <= 64) return 1;
+    return n_conds <= 128 ? 2 : 6;
+}
 
 bool has_owner_path(int model, int k, int n_conds, bool f64, bool strict) {
     if (strict && !f64) return false; // the strict form is the fp64 reference arithmetic
     if (model != BIASEDMF && model != PMF && model != CAMF_CI && model != CAMF_CU && model != CAMF_CUCI) return false;
     if (k < 1 || k > (f64 ? 128 : 256)) return false;
     const bool has_ctx = model != BIASEDMF && model != PMF;
-    if (has_ctx && n_conds > 64) return false; // lane c carries condition c
+    if (has_ctx && n_conds > 384) return false; // lane l carries conditions l, l + 64, ..., l + 320
     return true;
 }
 int owner_depth() { return OWNER_DEPTH_MAX; }
@@ -818,39 +899,54 @@ int64_t owner_record_stride(int model, int k, int n_conds, bool f64, bool hub_is
     const bool has_ic = model == CAMF_CI || model == CAMF_CUCI, has_uc = model == CAMF_CU || model == CAMF_CUCI;
     const bool has_bu = model == BIASEDMF || model == CAMF_CI, has_bj = model == BIASEDMF || model == CAMF_CU;
     const bool sc = hub_is_item ? has_uc : has_ic, sb = hub_is_item ? has_bu : has_bj;
-    return owner_record_granules(owner_vpl(k), sc, sb, f64 ? 2 : 1);
+    return owner_record_granules(owner_vpl(k), sc ? owner_mask_words(model, n_conds) : 0, sb, f64 ? 2 : 1);
 }
 
-template <typename T, int MODEL, int VPL>
-static void *owner_kernel_hub(bool hub_is_item, bool strict) {
-    constexpr int D = OwnerDepth<T, VPL>::D;
+// what the launch needs to know about one instantiation
+struct OwnerKernel {
+    void *fn;
+    size_t team_lds;
+};
+template <typename T, int MODEL, int VPL, int NCW>
+static OwnerKernel owner_kernel_hub(bool hub_is_item, bool strict) {
+    constexpr int D = OwnerDepth<T, VPL, NCW>::D;
+    const size_t lds = 64 + (size_t)OWNER_TEAM_RING *
+                                (size_t)(hub_is_item ? team_slot_bytes<T, MODEL, VPL, NCW, true>() : team_slot_bytes<T, MODEL, VPL, NCW, false>());
     if constexpr (sizeof(T) == 8) {
-        if (strict) return hub_is_item ? (void *)sgd_owner<T, MODEL, VPL, D, true, true> : (void *)sgd_owner<T, MODEL, VPL, D, false, true>;
+        if (strict)
+            return {hub_is_item ? (void *)sgd_owner<T, MODEL, VPL, NCW, D, true, true> : (void *)sgd_owner<T, MODEL, VPL, NCW, D, false, true>, 0};
     }
-    return hub_is_item ? (void *)sgd_owner<T, MODEL, VPL, D, true, false> : (void *)sgd_owner<T, MODEL, VPL, D, false, false>;
+    return {hub_is_item ? (void *)sgd_owner<T, MODEL, VPL, NCW, D, true, false> : (void *)sgd_owner<T, MODEL, VPL, NCW, D, false, false>, lds};
+}
+template <typename T, int MODEL, int NCW>
+static OwnerKernel owner_kernel_k(int k, bool hub_is_item, bool strict) {
+    if (k <= 64) return owner_kernel_hub<T, MODEL, 1, NCW>(hub_is_item, strict);
+    if (k <= 128) return owner_kernel_hub<T, MODEL, 2, NCW>(hub_is_item, strict);
+    if constexpr (sizeof(T) == 4) return owner_kernel_hub<float, MODEL, 4, NCW>(hub_is_item, strict);
+    return {nullptr, 0};
 }
 template <typename T, int MODEL>
-static void *owner_kernel_k(int k, bool hub_is_item, bool strict) {
-    if (k <= 64) return owner_kernel_hub<T, MODEL, 1>(hub_is_item, strict);
-    if (k <= 128) return owner_kernel_hub<T, MODEL, 2>(hub_is_item, strict);
-    if (sizeof(T) == 4) return owner_kernel_hub<float, MODEL, 4>(hub_is_item, strict);
-    return nullptr;
+static OwnerKernel owner_kernel_ctx(int ncw, int k, bool hub_is_item, bool strict) {
+    if (ncw == 1) return owner_kernel_k<T, MODEL, 1>(k, hub_is_item, strict);
+    if (ncw == 2) return owner_kernel_k<T, MODEL, 2>(k, hub_is_item, strict);
+    return owner_kernel_k<T, MODEL, 6>(k, hub_is_item, strict);
 }
 template <typename T>
-static void *owner_kernel_ptr(int model, int k, bool hub_is_item, bool strict) {
+static OwnerKernel owner_kernel(int model, int n_conds, int k, bool hub_is_item, bool strict) {
+    const int ncw = owner_mask_words(model, n_conds);
     switch (model) {
-    case BIASEDMF: return owner_kernel_k<T, BIASEDMF>(k, hub_is_item, strict);
-    case PMF: return owner_kernel_k<T, PMF>(k, hub_is_item, strict);
-    case CAMF_CI: return owner_kernel_k<T, CAMF_CI>(k, hub_is_item, strict);
-    case CAMF_CU: return owner_kernel_k<T, CAMF_CU>(k, hub_is_item, strict);
-    case CAMF_CUCI: return owner_kernel_k<T, CAMF_CUCI>(k, hub_is_item, strict);
+    case BIASEDMF: return owner_kernel_k<T, BIASEDMF, 1>(k, hub_is_item, strict);
+    case PMF: return owner_kernel_k<T, PMF, 1>(k, hub_is_item, strict);
+    case CAMF_CI: return owner_kernel_ctx<T, CAMF_CI>(ncw, k, hub_is_item, strict);
+    case CAMF_CU: return owner_kernel_ctx<T, CAMF_CU>(ncw, k, hub_is_item, strict);
+    case CAMF_CUCI: return owner_kernel_ctx<T, CAMF_CUCI>(ncw, k, hub_is_item, strict);
     }
-    return nullptr;
+    return {nullptr, 0};
 }
 
 // Owners = wavefronts that are resident together (a waiting owner must never keep a runnable one off the chip).
-int owner_grid_waves(int device, int model, int k, bool f64, bool hub_is_item) {
-    void *fn = f64 ? owner_kernel_ptr<double>(model, k, hub_is_item, false) : owner_kernel_ptr<float>(model, k, hub_is_item, false);
+int owner_grid_waves(int device, int model, int n_conds, int k, bool f64, bool hub_is_item) {
+    void *fn = f64 ? owner_kernel<double>(model, n_conds, k, hub_is_item, false).fn : owner_kernel<float>(model, n_conds, k, hub_is_item, false).fn;
     if (!fn) return 0;
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) return 0;
@@ -863,55 +959,35 @@ int owner_grid_waves(int device, int model, int k, bool f64, bool hub_is_item) {
     return cus * per_cu * 4;
 }
 
-template <typename T, int MODEL, int VPL>
-static size_t owner_team_lds_hub(bool hub_is_item) {
-    return 64 + (size_t)OWNER_TEAM_RING * (size_t)(hub_is_item ? team_slot_bytes<T, MODEL, VPL, true>() : team_slot_bytes<T, MODEL, VPL, false>());
-}
-template <typename T, int MODEL>
-static size_t owner_team_lds_k(int k, bool hub_is_item) {
-    if (k <= 64) return owner_team_lds_hub<T, MODEL, 1>(hub_is_item);
-    if (k <= 128) return owner_team_lds_hub<T, MODEL, 2>(hub_is_item);
-    return owner_team_lds_hub<T, MODEL, 4>(hub_is_item);
-}
 template <typename T>
-static size_t owner_team_lds(int model, int k, bool hub_is_item) {
-    switch (model) {
-    case BIASEDMF: return owner_team_lds_k<T, BIASEDMF>(k, hub_is_item);
-    case PMF: return owner_team_lds_k<T, PMF>(k, hub_is_item);
-    case CAMF_CI: return owner_team_lds_k<T, CAMF_CI>(k, hub_is_item);
-    case CAMF_CU: return owner_team_lds_k<T, CAMF_CU>(k, hub_is_item);
-    case CAMF_CUCI: return owner_team_lds_k<T, CAMF_CUCI>(k, hub_is_item);
-    }
-    return 0;
-}
-
-template <typename T>
-hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, bool strict, const OwnerRec *recs, const int64_t *own_off,
+hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, bool strict, const void *recs, const int64_t *own_off,
                               int n_owners, int n_team, void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s) {
-    void *fn = owner_kernel_ptr<T>(model, a.k, hub_is_item, strict);
-    if (!fn) return hipErrorInvalidValue;
+    const OwnerKernel kn = owner_kernel<T>(model, a.n_conds, a.k, hub_is_item, strict);
+    if (!kn.fn) return hipErrorInvalidValue;
     const bool has_ic = model == CAMF_CI || model == CAMF_CUCI, has_uc = model == CAMF_CU || model == CAMF_CUCI;
     const bool has_bu = model == BIASEDMF || model == CAMF_CI, has_bj = model == BIASEDMF || model == CAMF_CU;
     const bool sc = hub_is_item ? has_uc : has_ic, sb = hub_is_item ? has_bu : has_bj;
     T *rows = hub_is_item ? a.P : a.Q;
     T *ctx = sc ? (hub_is_item ? a.ucBias : a.icBias) : nullptr;
     T *bias = sb ? (hub_is_item ? a.userBias : a.itemBias) : nullptr;
-    const int ncs = sc ? a.n_conds : 0, vpl = owner_vpl(a.k);
+    const int ncs = sc ? a.n_conds : 0, vpl = owner_vpl(a.k), ncw = owner_mask_words(model, a.n_conds);
     const int pass_blocks = (int)std::min<int64_t>(((int64_t)n_spokes + 3) / 4, 256 * 16);
-    hipLaunchKernelGGL((owner_records<T, true>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl);
+    hipLaunchKernelGGL((owner_records<T, true>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl,
+                       ncw);
     SgdArgs<T> args = a;
     gran_t *tg = (gran_t *)tagged;
     if (strict) n_team = 0;
     void *params[] = {&args, &recs, &own_off, &tg, &error, &n_owners, &n_team};
-    const size_t lds = n_team > 0 ? owner_team_lds<T>(model, a.k, hub_is_item) : 0;
-    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(n_team + (n_owners - n_team + 3) / 4)), dim3(256), params, lds, s);
+    const size_t lds = n_team > 0 ? kn.team_lds : 0;
+    hipError_t e = hipLaunchKernel(kn.fn, dim3((unsigned)(n_team + (n_owners - n_team + 3) / 4)), dim3(256), params, lds, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((owner_records<T, false>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl);
+    hipLaunchKernelGGL((owner_records<T, false>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl,
+                       ncw);
     return hipGetLastError();
 }
-template hipError_t launch_owner_epoch<float>(const SgdArgs<float> &, int, bool, bool, const OwnerRec *, const int64_t *, int, int, void *, int64_t,
-                                              int, int *, hipStream_t);
-template hipError_t launch_owner_epoch<double>(const SgdArgs<double> &, int, bool, bool, const OwnerRec *, const int64_t *, int, int, void *, int64_t,
-                                               int, int *, hipStream_t);
+template hipError_t launch_owner_epoch<float>(const SgdArgs<float> &, int, bool, bool, const void *, const int64_t *, int, int, void *, int64_t, int,
+                                              int *, hipStream_t);
+template hipError_t launch_owner_epoch<double>(const SgdArgs<double> &, int, bool, bool, const void *, const int64_t *, int, int, void *, int64_t, int,
+                                               int *, hipStream_t);
 
 } // namespace cmi

@@ -103,7 +103,7 @@ extern "C" {
 #define CMI_FLAG_SCHED_OWNER 0x200u /* heavy-tailed degrees: ONE persistent launch per epoch in which every row of the heavy side
                                      * (items, or users) is owned by one wavefront that walks the row's tuples in CRS order with the
                                      * row in registers; the other side's rows travel between owners as tagged records
-                                     * (owner_kernels.hip).  Order-exact like the level schedules; k <= 256 (fp64: 128), <= 64 conditions */
+                                     * (owner_kernels.hip).  Order-exact like the level schedules; k <= 256 (fp64: 128), <= 384 conditions */
 #define CMI_FLAG_NO_OWNER 0x400u /* never pick the owner schedule automatically (it is picked for >= 2^16 tuples whose dependency levels
                                   * are narrow -- heavy-tailed degrees -- when its estimated epoch is at least twice shorter) */
 #define CMI_FLAG_NO_GRAPH 0x10u  /* launch the per-level kernels eagerly instead of replaying a hipGraph */

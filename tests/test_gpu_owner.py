@@ -128,15 +128,32 @@ def test_owner_64_conditions_and_the_unsupported_shapes():
     assert data.n_conds == 64
     _run("CAMF_CUCI", data, 32, F64, "item", None)
     _run("CAMF_CUCI", data, 32, F64, "user", 9)
-    big = synth.generate(300, 50, 5, 16, 9000, seed=45)           # 80 conditions
+    huge = synth.generate(300, 50, 5, 80, 9000, seed=45)          # 400 conditions: more than 6 words of 64
     with pytest.raises(capi.CmiError):
-        make_pair("CAMF_CI", big, 32, OWNER)
+        make_pair("CAMF_CI", huge, 32, OWNER)
+    _run("BiasedMF", huge, 32, F64, "item", None)                 # ... which a model without context does not care about
     with pytest.raises(capi.CmiError):
         make_pair("CAMF_CI", data, 300, OWNER)
     with pytest.raises(capi.CmiError):
         make_pair("CAMF_CI", data, 200, OWNER | F64)              # fp64 records: k <= 128
     with pytest.raises(capi.CmiError):
         make_pair("CAMF_C", data, 32, OWNER | capi.FLAG_SCHED_SERIAL)
+
+
+@pytest.mark.parametrize("model", ["CAMF_CI", "CAMF_CU", "CAMF_CUCI"])
+@pytest.mark.parametrize("dims,cpd", [(4, 25), (7, 49)])
+def test_owner_more_than_64_conditions(model, dims, cpd):
+    """100 conditions (two 64-condition words per context-bias row and per tuple mask; BASELINE C5 has 128) and 343 (six words;
+    Frappe's count): lane l carries conditions l, l + 64, ...  fp64 vs the oracle for both hub sides, few / all owners, the team form
+    forced on every owner, strict fp64 bit-identical, and fp32 at the north_star bar."""
+    data = synth.generate(500, 60, dims, cpd, 12000, seed=500 + dims, item_zipf=1.1)
+    assert data.n_conds == dims * cpd
+    for hub in ("item", "user"):
+        _run(model, data, 64, F64, hub, 6)
+        _run(model, data, 100, F64, hub, None, team="all")
+        _run(model, data, 10, F64 | capi.FLAG_STRICT, hub, None, loss_tol=1e-12, exact=True)
+        _run(model, data, 128, 0, hub, None, loss_tol=3e-5, atol=3e-4)
+        _run(model, data, 200, 0, hub, 11, loss_tol=3e-5, atol=3e-4, team="all")
 
 
 def test_owner_many_epochs_under_uneven_load_stays_exact():

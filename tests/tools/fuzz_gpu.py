@@ -45,9 +45,9 @@ def main():
             os.environ["CMI_CHAIN_HUB"] = str(rng.choice(["item", "user", "auto"]))
             os.environ["CMI_CHAIN_MAX"] = str(int(rng.choice([1, 2, 5, 16])))
             chained += 1
-        # the owner (dataflow) epoch: every level model, k <= 256 (fp64: 128), <= 64 conditions; few or many owners, either hub side
+        # the owner (dataflow) epoch: every level model, k <= 256 (fp64: 128), <= 384 conditions; few or many owners, either hub side
         owner_ok = (model != "CAMF_C" and not flags & (SERIAL | CHAIN) and k <= (128 if flags & F64 else 256) and
-                    (model in util.TWO_D or data.n_conds <= 64))
+                    (model in util.TWO_D or data.n_conds <= 384))
         os.environ.pop("CMI_OWNER_WAVES", None)
         if owner_ok and rng.random() < 0.4:
             flags |= OWNER
