@@ -106,6 +106,25 @@ def test_owner_team_form_is_picked_for_the_hottest_rows():
         assert_state_equal(orc, inst, exact=False, atol=1e-11)
 
 
+@pytest.mark.parametrize("model", LEVEL_MODELS)
+@pytest.mark.parametrize("team", ["0", "all"])
+def test_owner_f32_twenty_epochs_bold_driver_north_star_bar(model, team):
+    """The north_star bar for the fp32 owner epoch on heavy-tailed items: 20 epochs under the bold driver take the same learning-rate
+    decisions as the fp64 oracle, the loss trajectory agrees to 3e-5 and RMSE / MAE on held-out ratings to 1e-5."""
+    data = synth.generate(3000, 400, 4, 4, 60000, seed=24, item_zipf=1.1)
+    train, test = synth.split(data, 0.2)
+    orc, inst = _env(lambda: make_pair(model, train, 128, OWNER), CMI_OWNER_TEAM=team)
+    assert inst.schedule_info()["kind"].startswith("owner")
+    o_losses, o_lrs, _ = orc.build_model(20, util.LR, bold_driver=True)
+    g_losses, g_lrs = inst.train(20, util.LR, bold_driver=True)
+    assert g_lrs.tolist() == o_lrs.tolist()
+    np.testing.assert_allclose(g_losses, o_losses, rtol=3e-5)
+    tctx = None if model in util.TWO_D else test.ctx
+    oe = orc.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+    ge = inst.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+    assert abs(oe["RMSE"] - ge["RMSE"]) <= 1e-5 and abs(oe["MAE"] - ge["MAE"]) <= 1e-5
+
+
 @pytest.mark.parametrize("zipf", [None, 1.5])
 def test_owner_uniform_and_very_hot_items(zipf):
     data = synth.generate(3000, 200, 4, 4, 80000, seed=81, item_zipf=zipf)
