@@ -13,6 +13,8 @@ public final class NativeMF {
     public static final int BIASEDMF = 0, CAMF_C = 1, CAMF_CI = 2, CAMF_CU = 3, CAMF_CUCI = 4, PMF = 5;
     public static final int P = 0, Q = 1, USER_BIAS = 2, ITEM_BIAS = 3, COND_BIAS = 4, UC_BIAS = 5, IC_BIAS = 6;
     public static final int FLAG_STATE_F64 = 1, FLAG_SCHED_SERIAL = 2, FLAG_STRICT = 4, FLAG_NO_GRAPH = 16;
+    /** schedule overrides (include/carskit_mi355x.h); the library picks hub-chain levels / the owner epoch / plain levels by itself */
+    public static final int FLAG_SCHED_CHAIN = 0x80, FLAG_NO_CHAIN = 0x100, FLAG_SCHED_OWNER = 0x200, FLAG_NO_OWNER = 0x400;
     public static final int RANK_UCU = 0, RANK_UC = 1;
 
     /** cmi_create; returns the handle, throws RuntimeException(cmi_last_error) on failure. */

@@ -74,7 +74,7 @@ def test_java_sources_use_only_existing_native_members_and_header_constants():
     for decl in re.findall(r"public\s+static\s+final\s+int\s+([^;]+);", nm):
         for part in decl.split(","):
             k, v = part.split("=")
-            consts[k.strip()] = int(v.strip())
+            consts[k.strip()] = int(v.strip(), 0)
     hdr = _read("include", "carskit_mi355x.h")
     hconst = {k: int(v, 0) for k, v in re.findall(r"#define\s+(CMI_[A-Z_0-9]+)\s+\(?(-?(?:0x)?[0-9a-fA-F]+)u?\)?", hdr)}
     for jname, hname in [("BIASEDMF", "CMI_MODEL_BIASEDMF"), ("CAMF_C", "CMI_MODEL_CAMF_C"), ("CAMF_CI", "CMI_MODEL_CAMF_CI"),
@@ -83,7 +83,9 @@ def test_java_sources_use_only_existing_native_members_and_header_constants():
                          ("ITEM_BIAS", "CMI_STATE_ITEM_BIAS"), ("COND_BIAS", "CMI_STATE_COND_BIAS"), ("UC_BIAS", "CMI_STATE_UC_BIAS"),
                          ("IC_BIAS", "CMI_STATE_IC_BIAS"), ("FLAG_STATE_F64", "CMI_FLAG_STATE_F64"),
                          ("FLAG_SCHED_SERIAL", "CMI_FLAG_SCHED_SERIAL"), ("FLAG_STRICT", "CMI_FLAG_STRICT"),
-                         ("FLAG_NO_GRAPH", "CMI_FLAG_NO_GRAPH"), ("RANK_UCU", "CMI_RANK_UCU"), ("RANK_UC", "CMI_RANK_UC")]:
+                         ("FLAG_NO_GRAPH", "CMI_FLAG_NO_GRAPH"), ("FLAG_SCHED_CHAIN", "CMI_FLAG_SCHED_CHAIN"),
+                         ("FLAG_NO_CHAIN", "CMI_FLAG_NO_CHAIN"), ("FLAG_SCHED_OWNER", "CMI_FLAG_SCHED_OWNER"),
+                         ("FLAG_NO_OWNER", "CMI_FLAG_NO_OWNER"), ("RANK_UCU", "CMI_RANK_UCU"), ("RANK_UC", "CMI_RANK_UC")]:
         assert consts[jname] == hconst[hname], (jname, hname)
     used = set()
     for f in os.listdir(JAVA_DIR):
