@@ -415,7 +415,10 @@ int cmi_narrow_runs(int64_t n_levels, const int64_t *level_off, int64_t max_tupl
 int cmi_conflict_free_blocks(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int32_t max_block,
                              int32_t *off, int64_t off_cap, int64_t *n_blocks);
 
-/* The owner form behind CMI_FLAG_SCHED_OWNER (level_schedule.cpp, build_owner_schedule).  hub: 1 items are owned, 0 users, -1 the side
+/* The owner form behind CMI_FLAG_SCHED_OWNER (level_schedule.cpp, build_owner_schedule): like the level schedules it replaces the
+ * reference's implicit "one tuple after another" order (librec MatrixIterator in `for (MatrixEntry me : trainMatrix)`,
+ * CAMF_CI.java:80) by an explicit order-exact one -- every row of the heavy side is walked by one owner in CRS order, the other side's
+ * rows wait for their update count.  hub: 1 items are owned, 0 users, -1 the side
  * with the larger maximum degree (*hub_used reports it).  perm[n]: list position -> CRS tuple (an owner's tuples contiguous, in CRS
  * order); own_off[n_owners+1]; want[n]: updates of the tuple's spoke row that precede it; flags[n]: bit 0 hub row taken over in
  * registers from the previous list entry, bit 1 hub row re-read late (written < depth+1 entries back), bit 2 hub row stored, bit 3
