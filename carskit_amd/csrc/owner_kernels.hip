@@ -447,8 +447,13 @@ __device__ __forceinline__ void team_put(lds_u8 *p, const T (&v)[VPL]) {
 // load that uses it cannot be issued -- before that LDS read has returned.  Scalar loads and LDS operations share one counter, which can
 // only be waited down to zero while a scalar load is outstanding; issued after the step's LDS reads, the load of the next list entry has
 // the whole arithmetic of the step to complete in instead of being waited for together with them.
-__device__ __forceinline__ int team_after(float v) { return __builtin_amdgcn_readfirstlane(__float_as_int(v)) & 0; }
-__device__ __forceinline__ int team_after(double v) { return __builtin_amdgcn_readfirstlane(__double2loint(v)) & 0; }
+__device__ __forceinline__ int team_zero_after(int bits) {
+    int z;
+    asm volatile("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__builtin_amdgcn_readfirstlane(bits)) : "scc"); // opaque: `bits & 0` would be folded away
+    return z;
+}
+__device__ __forceinline__ int team_after(float v) { return team_zero_after(__float_as_int(v)); }
+__device__ __forceinline__ int team_after(double v) { return team_zero_after(__double2loint(v)); }
 
 template <typename T, int MODEL, int VPL, int NCW, bool HUB_ITEM>
 __host__ __device__ constexpr int team_slot_bytes() { // row | context biases | bias (16)
@@ -562,7 +567,12 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
                 for (int cw = 0; cw < NCW; ++cw) team_get<T, 1>(sl + XB + (64 * cw + lane) * (int)sizeof(T), cv[cw]);
             }
             if (S::SB) team_get<T, 1>(sl + OFF_SB, bv);
-            r_next = recs[c + 1 + team_after(xv[0])];
+            {
+                T last = xv[0];
+                if (S::SC) last = cv[NCW - 1][0];
+                if (S::SB) last = bv[0];
+                r_next = recs[c + 1 + team_after(last)];
+            }
             const uint32_t tag = r.want + 1u;
             uint32_t ow[VPL * NW * 2], oc[NW * 2], ob[NW * 2];
 #pragma unroll
@@ -638,7 +648,12 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
                 sb = one[0];
             }
         }
-        r_next = recs[c + 1 + team_after(x[0])];
+        {
+            T last = x[0]; // the value of the step's LAST LDS read: every read has returned before the next entry is requested
+            if (S::SC) last = sc[NCW - 1];
+            if (S::SB) last = sb;
+            r_next = recs[c + 1 + team_after(last)];
+        }
         owner_update<T, MODEL, VPL, NCW, HUB_ITEM, false>(r, hp, k, h, hc, hb, x, sc, sb, sq_p, sq_q, sq_c, sq_e, sq_b);
         {
             T one[1];
