@@ -273,6 +273,12 @@ struct OwnerRating<double> {
     static __device__ __forceinline__ double get(const OwnerRecT<NCW> &r) { return r.rating.d; }
 };
 
+// value of lane l (wave-uniform l): v_readlane, not the LDS permute __shfl would use
+__device__ __forceinline__ float owner_lane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double owner_lane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 template <typename T>
 struct OwnerHp {
     T lr, regU, regI, regB, regC, gm, keepU, keepI, keepB, keepC; // keepX = 1 - lrate regX (the fp32 form of the update)
@@ -312,13 +318,13 @@ __device__ __forceinline__ void owner_update(const OwnerRecT<NCW> &r, const Owne
         for (int l = 0; l < lanes; ++l) {
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
-                if (l * VPL + v < k) dot += __shfl(prod[v], l, 64);
+                if (l * VPL + v < k) dot += owner_lane(prod[v], l);
         }
         pred += dot;
         if (M::has_ctx) {
 #pragma unroll
             for (int w = 0; w < NCW; ++w)
-                for (uint64_t m = r.mask[w]; m; m &= m - 1) pred += __shfl(term[w], __builtin_ctzll(m), 64);
+                for (uint64_t m = r.mask[w]; m; m &= m - 1) pred += owner_lane(term[w], __builtin_ctzll(m));
         }
     } else {
         T part = (T)0;
