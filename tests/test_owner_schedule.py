@@ -7,6 +7,7 @@
 """
 import numpy as np
 import pytest
+from hypothesis import given, settings, strategies as st
 
 from carskit_amd import capi, synth
 
@@ -102,3 +103,76 @@ def test_any_tag_respecting_interleaving_is_the_sequential_epoch(seed):
             head[w] += 1
             done += 1
         assert np.array_equal(P, P2) and np.array_equal(Q, Q2)
+
+
+def _random_tag_respecting_order(u, j, nu, ni, n_owners, hub, rng):
+    """A global execution order that the owner epoch could produce: repeatedly pick, at random, an owner whose head entry's spoke
+    row carries the wanted update count, and run that entry.  Returns the CRS indices in execution order."""
+    perm, off, want, flags, hub_item = capi.owner_schedule(u, j, nu, ni, n_owners, hub=hub)
+    spoke = u if hub_item else j
+    tag = np.zeros(max(nu, ni), dtype=np.int64)
+    head = off[:-1].copy()
+    order = []
+    while len(order) < len(u):
+        ready = [w for w in range(n_owners) if head[w] < off[w + 1] and tag[spoke[perm[head[w]]]] == want[head[w]]]
+        assert ready, "stuck"
+        w = int(rng.choice(ready))
+        t = int(perm[head[w]])
+        order.append(t)
+        tag[spoke[t]] += 1
+        head[w] += 1
+    return np.asarray(order, dtype=np.int64)
+
+
+@settings(max_examples=60, deadline=None)
+@given(nu=st.integers(1, 9), ni=st.integers(1, 9), n=st.integers(0, 90), seed=st.integers(0, 1000), hub=st.integers(-1, 1),
+       n_owners=st.integers(1, 12), depth=st.integers(1, 16))
+def test_owner_schedule_property(nu, ni, n, seed, hub, n_owners, depth):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, nu, n).astype(np.int32)
+    j = rng.integers(0, ni, n).astype(np.int32)
+    perm, off, want, flags, hub_item = capi.owner_schedule(u, j, nu, ni, n_owners, hub=hub, depth=depth)
+    assert sorted(perm.tolist()) == list(range(n)) and off[0] == 0 and off[-1] == n
+    hv, sv = (j, u) if hub_item else (u, j)
+    owner_of = {}
+    for w in range(n_owners):
+        lst = perm[off[w]:off[w + 1]]
+        assert np.all(np.diff(lst) > 0)
+        for t in lst:
+            assert owner_of.setdefault(int(hv[t]), w) == w
+    seen = {}
+    for t in range(n):                                   # want = rank of the tuple in its spoke row's CRS chain
+        pos = int(np.nonzero(perm == t)[0][0])
+        assert want[pos] == seen.get(int(sv[t]), 0)
+        seen[int(sv[t])] = seen.get(int(sv[t]), 0) + 1
+    if n:                                                # and any tag-respecting interleaving runs to the end
+        order = _random_tag_respecting_order(u, j, nu, ni, n_owners, hub, rng)
+        for key in (u, j):                               # ... keeping every row's tuples in CRS order
+            for x in np.unique(key):
+                ts = order[key[order] == x]
+                assert np.all(np.diff(ts) > 0)
+
+
+def test_oracle_replay_in_owner_execution_order_equals_sequential_epoch_bitwise():
+    """Oracle replay: the oracle's single-tuple update applied in an execution order of the owner epoch (random tag-respecting
+    interleaving of the owners' lists) gives the sequential epoch's model bit for bit (fp64), for models with state on both sides."""
+    from oracle import oracle_c
+    from tests.util import LR, REG, REGC
+    d = synth.generate(60, 25, 2, 3, 1500, seed=11, item_zipf=1.2)
+    k = 6
+    gm = oracle_c.global_mean(d.r)
+    rng = np.random.default_rng(5)
+    for model in ("CAMF_CUCI", "CAMF_CI", "CAMF_CU", "BiasedMF"):
+        state = synth.init_state(model, d, k, seed=3)
+        mk = lambda u, j, c, r: oracle_c.Oracle(model, k, d.n_users, d.n_items, d.n_conds, u, j, c, r, d.ctx_ptr, d.ctx_conds,
+                                                {n: a.copy() for n, a in state.items()}, gm, REG, REG, REG, REGC)
+        seq = mk(d.u, d.j, d.ctx, d.r)
+        seq.epoch(LR)
+        for hub in (0, 1):
+            for n_owners in (3, 40):
+                order = _random_tag_respecting_order(d.u, d.j, d.n_users, d.n_items, n_owners, hub, rng)
+                rep = mk(d.u[order], d.j[order], d.ctx[order], d.r[order])
+                rep.epoch(LR)
+                for name, a in seq.state.items():
+                    if a is not None:
+                        assert np.array_equal(a, rep.state[name]), (model, hub, n_owners, name)
