@@ -443,11 +443,13 @@ bool build_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t
     if (n >= (int64_t)1 << 31) return false;
     int32_t nl = 0;
     int64_t nu = 0;
-    if (hub < 0) { // fewer units = fewer hub-row round trips through HBM
+    if (hub < 0) { // fewer units = fewer hub-row round trips through HBM; -2 / -3: a preferred side wins up to 1.3x the other's units
         int64_t units_item = 0, units_user = 0;
         chain_pass(n, j, u, n_items, n_users, max_chain, nullptr, nullptr, nullptr, nullptr, nl, units_item);
         chain_pass(n, u, j, n_users, n_items, max_chain, nullptr, nullptr, nullptr, nullptr, nl, units_user);
-        hub = units_item <= units_user ? 1 : 0;
+        if (hub == -2) hub = (double)units_user <= 1.3 * (double)units_item ? 0 : 1;
+        else if (hub == -3) hub = (double)units_item <= 1.3 * (double)units_user ? 1 : 0;
+        else hub = units_item <= units_user ? 1 : 0;
     }
     out.hub_is_item = hub ? 1 : 0;
     std::vector<int32_t> unit_of((size_t)n), unit_level;

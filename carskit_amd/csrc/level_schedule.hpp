@@ -56,7 +56,9 @@ struct ChainSchedule {
     int64_t n_units() const { return (int64_t)unit_off.size() - 1; }
     int64_t n_levels() const { return (int64_t)level_off.size() - 1; }
 };
-// hub: 0 = chain along users (P[u] resident), 1 = along items (Q[j] resident), -1 = whichever gives fewer units
+// hub: 0 = chain along users (P[u] resident), 1 = along items (Q[j] resident), -1 = whichever gives fewer units, -2 / -3 = users / items
+// unless that costs more than 1.3x the units of the other side (the side that carries the model's context-bias rows: kept on chip along a
+// unit they cost one coalesced row per unit instead of scattered 4-byte read-modify-writes per tuple)
 bool build_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int max_chain,
                           ChainSchedule &out);
 
