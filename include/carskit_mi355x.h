@@ -399,7 +399,8 @@ int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_
                        int32_t *perm, int64_t *level_off, int64_t level_cap, int64_t *n_levels);
 
 /* The hub-chain form of the level schedule (level_schedule.cpp, build_chain_schedule; the default execution order).  hub: 1 chain
- * along items, 0 along users, -1 pick the one with fewer units (*hub_used reports it).  perm[n]: stream position -> CRS tuple;
+ * along items, 0 along users, -1 pick the one with fewer units, -2 / -3 users / items unless that costs more than 1.3x the units of the
+ * other side (what cmi_set_ratings uses for CAMF_CU / CAMF_CI: the side with the context-bias rows) (*hub_used reports the choice).  perm[n]: stream position -> CRS tuple;
  * unit_off[*n_units+1]: offsets of the units in perm; level_off[*n_levels+1]: offsets of the levels in unit_off (unit indices).
  * Pass perm = NULL to only count (*n_units, *n_levels). */
 int cmi_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int max_chain,
