@@ -47,7 +47,7 @@ __device__ __forceinline__ void chain_lds_order() { asm volatile("" ::: "memory"
 template <typename T, int NV>
 struct SpokeRow {
     typename Vec16<T>::type v[NV];
-    T sb, sc;
+    T sc;
     T *psc;
     int spoke, cond;
 };
@@ -57,8 +57,7 @@ __device__ __forceinline__ void chain_load_spoke(const SgdArgs<T> &a, int spoke,
     using M = Traits<MODEL>;
     using V = typename Vec16<T>::type;
     constexpr int E = Vec16<T>::E;
-    constexpr bool SB = HUB_ITEM ? M::has_bu : M::has_bj;  // scalar bias on the spoke side
-    constexpr bool SC = HUB_ITEM ? M::has_uc : M::has_ic;  // context-bias table on the spoke side
+    constexpr bool SC = HUB_ITEM ? M::has_uc : M::has_ic;  // context-bias table on the spoke side (the scalar bias: chain_unit)
     T *tab = HUB_ITEM ? a.P : a.Q;
     const V *row = reinterpret_cast<const V *>(tab + (size_t)spoke * K) + l16;
     r.spoke = spoke;
@@ -71,10 +70,8 @@ __device__ __forceinline__ void chain_load_spoke(const SgdArgs<T> &a, int spoke,
         r.v[v] = pack(z);
         if (!RAGGED || E * l16 + 16 * E * v < K) r.v[v] = row[v * 16];
     }
-    r.sb = (T)0;
     r.sc = (T)0;
     r.psc = nullptr;
-    if (SB) r.sb = (HUB_ITEM ? a.userBias : a.itemBias)[spoke];
     if (SC && cond >= 0) {
         r.psc = (HUB_ITEM ? a.ucBias : a.icBias) + (size_t)spoke * a.n_conds + cond;
         r.sc = *r.psc;
@@ -89,7 +86,7 @@ struct ChainHp {
 // One update: hub registers (h, hb, the LDS copy of the hub's context-bias row) x spoke row `cur`.  p = user side, q = item side;
 // every expression is the one of fast_tuples_f32 (mf_sgd_kernels.hip), in the same order.
 template <typename T, int MODEL, int NV, bool RAGGED, bool HUB_ITEM>
-__device__ __forceinline__ void chain_step(const SgdArgs<T> &a, const ChainHp<T> &hp, T (&h)[NV][Vec16<T>::E], T &hb, T *s_hc,
+__device__ __forceinline__ void chain_step(const SgdArgs<T> &a, const ChainHp<T> &hp, T (&h)[NV][Vec16<T>::E], T &hb, T *s_hc, T *s_sb,
                                            const SpokeRow<T, NV> &cur, T rr, int l16, int K, double &gloss) {
     using M = Traits<MODEL>;
     using V = typename Vec16<T>::type;
@@ -115,7 +112,8 @@ __device__ __forceinline__ void chain_step(const SgdArgs<T> &a, const ChainHp<T>
         chain_lds_order();
         if (cur.cond >= 0) hcv = s_hc[cur.cond];
     }
-    const T bu = HUB_ITEM ? cur.sb : hb, bj = HUB_ITEM ? hb : cur.sb;
+    const T sbv = SB ? *s_sb : (T)0; // the spoke's scalar bias: this tuple's slot of the unit's bias batch (LDS)
+    const T bu = HUB_ITEM ? sbv : hb, bj = HUB_ITEM ? hb : sbv;
     const T bic = HUB_ITEM ? hcv : cur.sc, buc = HUB_ITEM ? cur.sc : hcv;
     T pred = hp.gm;
     if (M::has_bu) pred += bu;
@@ -130,9 +128,9 @@ __device__ __forceinline__ void chain_step(const SgdArgs<T> &a, const ChainHp<T>
     }
     const T e = rr - pred;
 
-    // scalar biases: the hub's stays in registers, lane 0 stores the spoke's
+    // scalar biases: the hub's stays in registers, the spoke's goes back to its LDS slot (the unit's biases leave in one store)
     if (HB) hb = hb + lr * (e - regB * hb);
-    if (SB && l16 == 0) (HUB_ITEM ? a.userBias : a.itemBias)[cur.spoke] = cur.sb + lr * (e - regB * cur.sb);
+    if (SB && l16 == 0) *s_sb = sbv + lr * (e - regB * sbv);
     T ctx_loss = (T)0;
     if (cur.cond >= 0) {
         if (M::has_ic) ctx_loss += bic * bic;
@@ -170,11 +168,12 @@ __device__ __forceinline__ void chain_step(const SgdArgs<T> &a, const ChainHp<T>
     }
 }
 
-// LDS per 16-lane group: [hub context-bias row: n_conds x T (if the hub side has one)] [ratings: 16 x T] [spoke ids: 16 x i32]
+// LDS per 16-lane group: [hub context-bias row: n_conds x T (if the hub side has one)] [ratings: 16 x T] [spoke scalar biases: 16 x T]
+// [spoke ids: 16 x i32]
 // [condition ids: 16 x dmax x i32] -- the unit's ids are staged once (one coalesced round trip) so that the chain loop has no
 // dependent global id -> row load pairs.
 __host__ __device__ inline size_t chain_group_lds(int n_conds_hub, int dmax, size_t esize) {
-    size_t b = (size_t)n_conds_hub * esize + 16 * esize + 16 * 4 + (size_t)16 * (dmax > 0 ? dmax : 0) * 4;
+    size_t b = (size_t)n_conds_hub * esize + 32 * esize + 16 * 4 + (size_t)16 * (dmax > 0 ? dmax : 0) * 4;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -221,11 +220,13 @@ __device__ __forceinline__ void chain_unit(const SgdArgs<T> &a, const ChainHp<T>
     constexpr int E = Vec16<T>::E;
     constexpr bool HB = HUB_ITEM ? M::has_bj : M::has_bu;
     constexpr bool HC = HUB_ITEM ? M::has_ic : M::has_uc;
+    constexpr bool SB = HUB_ITEM ? M::has_bu : M::has_bj;
     const int len = pre.len;
     const int32_t tb = pre.tb;
     T *s_hc = reinterpret_cast<T *>(gbase);
     T *s_rr = s_hc + (HC ? a.n_conds : 0);
-    int *s_sp = reinterpret_cast<int *>(s_rr + 16);
+    T *s_sb = s_rr + 16;
+    int *s_sp = reinterpret_cast<int *>(s_sb + 16);
     int *s_cd = s_sp + 16;
     const int n_cd = len * dmax;
 
@@ -258,13 +259,19 @@ __device__ __forceinline__ void chain_unit(const SgdArgs<T> &a, const ChainHp<T>
             if (l16 + 16 * r < a.n_conds) hcv4[r] = hc_row[l16 + 16 * r];
         }
     }
+    // the scalar biases of ALL the unit's spoke rows in one load (lane i: tuple i's; a unit's spoke rows are pairwise distinct) instead
+    // of one 4-byte gather and one 4-byte scatter per tuple, each a memory instruction with one useful lane in sixteen
+    T *sb_tab = HUB_ITEM ? a.userBias : a.itemBias;
+    T my_sb = (T)0;
+    if (SB && l16 < len) my_sb = sb_tab[pre.my_sp];
     SpokeRow<T, NV> A, B;
     chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, pre.sp0, pre.cd0, l16, K, A);
 
-    // ---- ids and the hub's context-bias row into LDS
+    // ---- ids, the spoke biases and the hub's context-bias row into LDS
     if (l16 < len) {
         s_sp[l16] = pre.my_sp;
         s_rr[l16] = pre.my_rr;
+        if (SB) s_sb[l16] = my_sb;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -283,11 +290,11 @@ __device__ __forceinline__ void chain_unit(const SgdArgs<T> &a, const ChainHp<T>
     while (true) {
         if (i + 1 < len)
             chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, B);
-        chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, A, s_rr[i], l16, K, gloss);
+        chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, s_sb + i, A, s_rr[i], l16, K, gloss);
         if (++i >= len) break;
         if (i + 1 < len)
             chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, A);
-        chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, B, s_rr[i], l16, K, gloss);
+        chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, s_sb + i, B, s_rr[i], l16, K, gloss);
         if (++i >= len) break;
     }
 
@@ -296,6 +303,10 @@ __device__ __forceinline__ void chain_unit(const SgdArgs<T> &a, const ChainHp<T>
     for (int v = 0; v < NV; ++v)
         if (!RAGGED || E * l16 + 16 * E * v < K) hrow[v * 16] = pack(h[v]);
     if (HB && l16 == 0) *phb = hb;
+    if (SB) { // the unit's spoke biases leave in one store
+        chain_lds_order();
+        if (l16 < len) sb_tab[s_sp[l16]] = s_sb[l16];
+    }
     if (HC) {
         chain_lds_order();
         for (int c = l16; c < a.n_conds; c += 16) hc_row[c] = s_hc[c];
