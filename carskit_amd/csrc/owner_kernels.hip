@@ -1000,6 +1000,7 @@ hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, 
     if (strict) n_team = 0;
     void *params[] = {&args, &recs, &own_off, &tg, &error, &n_owners, &n_team};
     const size_t lds = n_team > 0 ? kn.team_lds : 0;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(kn.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); // up to 131 KB (fp64, 6 mask words)
     hipError_t e = hipLaunchKernel(kn.fn, dim3((unsigned)(n_team + (n_owners - n_team + 3) / 4)), dim3(256), params, lds, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((owner_records<T, false>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl,
