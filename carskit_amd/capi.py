@@ -87,6 +87,7 @@ SYMBOLS = [
     ("cmi_load_model", C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("cmi_measure_hbm", C.c_int, [C.c_int, _i64, C.POINTER(C.c_double)]),
     ("cmi_schedule_info", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("cmi_schedule_traffic", C.c_int, [_vp, C.POINTER(_i64)]),
     ("cmi_exchange_setup", C.c_int, [_vp, _i64, C.POINTER(_vp), C.POINTER(_i64)]),
     ("cmi_exchange_pack", C.c_int, [_vp]),
     ("cmi_exchange_apply", C.c_int, [_vp, C.c_double]),
@@ -492,6 +493,12 @@ class Instance:
             d["teams"] = d["flow_blocks"] >> 32
             d["flow_blocks"] &= 0xffffffff
         return d
+
+    def schedule_traffic(self):
+        """HBM bytes per epoch derived from the loaded schedule: {"sector", "own", "algorithmic", "models_reuse"} (cmi_schedule_traffic)"""
+        out = (_i64 * 4)()
+        self._chk(self.L.cmi_schedule_traffic(self.h, out))
+        return {"sector": out[0], "own": out[1], "algorithmic": out[2], "models_reuse": bool(out[3])}
 
     def stream(self):
         s = _vp()

@@ -23,6 +23,43 @@ using namespace cmi;
 
 static thread_local std::string g_create_err;
 
+// The owner epoch (one persistent launch whose workgroups wait for each other) needs its device to itself while it runs.  One
+// mutex per device orders the owner epochs of this process (folds on DIFFERENT devices no longer wait for each other: ADVICE r2);
+// an advisory flock() on a per-device file orders them across processes (two ranks sharing a GPU).  Best effort: if the lock file
+// cannot be opened the epoch still runs, and its waits stay bounded.
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+struct OwnerDeviceLock {
+    static constexpr int MAX_DEV = 64;
+    static std::mutex &mtx(int dev) {
+        static std::mutex m[MAX_DEV];
+        return m[dev >= 0 && dev < MAX_DEV ? dev : 0];
+    }
+    std::unique_lock<std::mutex> lk;
+    int fd = -1;
+    explicit OwnerDeviceLock(int dev) : lk(mtx(dev)) {
+        char bus[64] = "";
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", dev);
+        for (char *c = bus; *c; ++c)
+            if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+        const char *dir = getenv("TMPDIR");
+        char path[256];
+        snprintf(path, sizeof path, "%s/cmi_owner_epoch_%s.lock", dir && *dir ? dir : "/tmp", bus);
+        fd = open(path, O_CREAT | O_RDWR, 0666);
+        if (fd >= 0 && flock(fd, LOCK_EX) != 0) {
+            close(fd);
+            fd = -1;
+        }
+    }
+    ~OwnerDeviceLock() {
+        if (fd >= 0) {
+            flock(fd, LOCK_UN);
+            close(fd);
+        }
+    }
+};
+
 bool cmi_model_has(int model, int which) {
     switch (which) {
     case CMI_STATE_P:
@@ -94,6 +131,7 @@ static void free_ratings(cmi_instance *h) {
     h->d_own_off = nullptr;
     h->d_tagged = nullptr;
     h->owner = false;
+    h->owner_stalled = false;
     h->d_ui_ptr = h->d_ui_items = nullptr;
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -269,6 +307,18 @@ static int check_state_args(cmi_instance *h, int which, const void *p, int64_t c
     return CMI_OK;
 }
 
+// The multi-GPU exchange keeps a snapshot of the item-side containers as of the last merge (cmi_exchange_setup / _apply) and ships
+// `container - snapshot`.  A container rewritten from the host (cmi_set_state, cmi_load_model) restarts from that value on every
+// rank, so its snapshot segment follows it -- otherwise the next pack would ship the jump as if it were this rank's SGD move.
+static hipError_t refresh_exchange_snapshot(cmi_instance *h, int which) {
+    if (!h->d_xsnap) return hipSuccess;
+    for (size_t i = 0; i < h->x_which.size(); ++i)
+        if (h->x_which[i] == which)
+            return hipMemcpyAsync((char *)h->d_xsnap + (size_t)h->x_off[i] * esize(h), h->state[which], (size_t)h->state_count[which] * esize(h),
+                                  hipMemcpyDeviceToDevice, h->stream);
+    return hipSuccess;
+}
+
 extern "C" int cmi_set_state(cmi_handle h, int which, const void *src, int64_t count, int dtype) {
     if (!h) return CMI_E_INVALID;
     if (int rc = check_state_args(h, which, src, count, dtype)) return rc;
@@ -277,6 +327,7 @@ extern "C" int cmi_set_state(cmi_handle h, int which, const void *src, int64_t c
     const bool src_f64 = dtype == CMI_DTYPE_F64;
     if (src_f64 == h->f64) {
         CMI_HIP(h, hipMemcpyAsync(h->state[which], src, (size_t)count * esize(h), hipMemcpyHostToDevice, h->stream));
+        CMI_HIP(h, refresh_exchange_snapshot(h, which));
         CMI_HIP(h, hipStreamSynchronize(h->stream));
         return CMI_OK;
     }
@@ -285,6 +336,7 @@ extern "C" int cmi_set_state(cmi_handle h, int which, const void *src, int64_t c
     CMI_HIP(h, hipMalloc(&stage, sb));
     hipError_t e = hipMemcpyAsync(stage, src, sb, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = launch_convert(stage, src_f64, h->state[which], h->f64, count, h->stream);
+    if (e == hipSuccess) e = refresh_exchange_snapshot(h, which);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     hipFree(stage);
     CMI_HIP(h, e);
@@ -428,6 +480,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         }
     }
     h->owner = false;
+    h->owner_stalled = false;
     if (h->want_owner && (h->serial || h->want_flow || h->want_two_lane || !has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict)))
         CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: CMI_FLAG_SCHED_OWNER: no owner kernel for model %d, k=%d, %d conditions, %s state%s (or "
                  "another schedule flag is set)", h->model, h->k, h->n_conds, h->f64 ? "fp64" : "fp32", h->strict ? ", strict" : "");
@@ -788,6 +841,45 @@ extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[8]) {
     return CMI_OK;
 }
 
+// HBM bytes one epoch of the schedule that is actually loaded has to move, from the schedule itself (bench.py's roofline numerator since
+// round 3: SURVEY 8(d)'s per-update figure assumes both rows of every tuple come from HBM, which the hub-chain kernel undercuts by
+// keeping the hub row on chip along a unit).  Per UNIT of a chain schedule: the hub row, the hub's scalar bias and the hub's
+// context-bias row, read and written once, plus its unit_off entry; per TUPLE: the spoke row read and written, the tuple stream
+// (su, sj, sr, sconds), the spoke's scalar bias and the spoke side's context-bias cells.  Plain level schedules: both sides per tuple.
+// out[0] bills every scattered scalar at the 64-byte sector it occupies on the way in and on the way out (what the memory system
+// moves), out[1] at its own size (what the algorithm needs), out[2] = SURVEY 8(d)'s no-reuse figure, out[3] = 1 if hub reuse is modelled.
+extern "C" int cmi_schedule_traffic(cmi_handle h, int64_t out[4]) {
+    if (!h || !out) return CMI_E_INVALID;
+    if (!h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "schedule_traffic: call cmi_set_ratings first");
+    const int64_t e = (int64_t)esize(h), K = h->k, D = h->dmax, NC = h->n_conds, n = h->n;
+    const bool bu = cmi_model_has(h->model, CMI_STATE_USER_BIAS), bj = cmi_model_has(h->model, CMI_STATE_ITEM_BIAS);
+    const bool uc = cmi_model_has(h->model, CMI_STATE_UC_BIAS), ic = cmi_model_has(h->model, CMI_STATE_IC_BIAS);
+    const bool cb = cmi_model_has(h->model, CMI_STATE_COND_BIAS);
+    const int64_t SECT = 64;
+    const int64_t row = 2 * K * e, stream = 8 + e + 4 * D;
+    const int64_t row_sectors = (NC * e + SECT - 1) / SECT;              // a context-bias row, in sectors
+    const int64_t cells_sect = 2 * SECT * std::min<int64_t>(D, row_sectors), cells_own = 2 * e * D; // D scattered cells of one row
+    const int64_t ctx_row_sect = 2 * row_sectors * SECT, ctx_row_own = 2 * NC * e;                 // the whole row, coalesced
+    const int64_t S = (bu ? 1 : 0) + (bj ? 1 : 0), T = (uc ? 1 : 0) + (ic ? 1 : 0) + (cb ? 1 : 0);
+    out[2] = n * (12 + e + 4 * D + 2 * row + 2 * e * S + 2 * e * D * T);
+    if (h->chain) {
+        const bool hi = h->chain_hub_item;
+        const bool hub_b = hi ? bj : bu, spk_b = hi ? bu : bj, hub_c = hi ? ic : uc, spk_c = hi ? uc : ic;
+        const int64_t unit_sect = row + (hub_b ? 2 * SECT : 0) + (hub_c ? ctx_row_sect : 0) + 4;
+        const int64_t unit_own = row + (hub_b ? 2 * e : 0) + (hub_c ? ctx_row_own : 0) + 4;
+        const int64_t tup_sect = stream + row + (spk_b ? 2 * SECT : 0) + (spk_c ? cells_sect : 0);
+        const int64_t tup_own = stream + row + (spk_b ? 2 * e : 0) + (spk_c ? cells_own : 0);
+        out[0] = h->n_units * unit_sect + n * tup_sect;
+        out[1] = h->n_units * unit_own + n * tup_own;
+        out[3] = 1;
+    } else {
+        out[0] = n * (stream + 2 * row + S * 2 * SECT + T * cells_sect);
+        out[1] = n * (stream + 2 * row + S * 2 * e + T * cells_own);
+        out[3] = 0;
+    }
+    return CMI_OK;
+}
+
 // ---- training -------------------------------------------------------------------------------------
 
 template <typename T>
@@ -864,9 +956,10 @@ static hipError_t enqueue_levels(cmi_instance *h) {
         // needs the device to itself.  Two of them in flight at once (two folds of `cv -p on` on one GPU, each on its own stream) could
         // each hold part of the compute units and wait forever for the rest, so owner epochs of one process run one at a time: the lock
         // is held from the launch until the stream has drained (cmi_train_epoch_async is synchronous for this schedule).  Across
-        // PROCESSES nothing protects it: one owner-schedule instance per GPU at a time.
-        static std::mutex owner_epoch_lock;
-        std::lock_guard<std::mutex> guard(owner_epoch_lock);
+        // PROCESSES an advisory lock on a per-device file does the same (OwnerDeviceLock); should a foreign persistent kernel hold
+        // compute units anyway, the waits are bounded, the first one to expire ends every other wait early (owner_spin_expired) and the
+        // epoch is reported as failed right here -- also on the cmi_train_epoch_async path, which never calls cmi_last_loss.
+        OwnerDeviceLock guard(h->device);
         const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
         e = h->f64 ? launch_owner_epoch<double>(make_args<double>(h), h->model, h->owner_hub_item, h->strict, h->d_own_recs, h->d_own_off, h->n_owners, h->n_team, h->d_tagged,
                                                 h->own_stride, n_spokes, h->d_flow_err, h->stream)
@@ -874,6 +967,14 @@ static hipError_t enqueue_levels(cmi_instance *h) {
                                                h->own_stride, n_spokes, h->d_flow_err, h->stream);
         if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) {
+            int32_t stalled = 0;
+            e = hipMemcpy(&stalled, h->d_flow_err, 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && stalled) {
+                h->owner_stalled = true;
+                e = hipErrorLaunchFailure;
+            }
+        }
         return e;
     }
     if (h->flow) {
@@ -998,7 +1099,13 @@ static int enqueue_epoch(cmi_instance *h, double lrate) {
     }
     CMI_HIP(h, hipEventRecord(h->ev0, h->stream));
     if (graph) CMI_HIP(h, hipGraphLaunch(h->graph_exec, h->stream));
-    else CMI_HIP(h, enqueue_levels(h));
+    else {
+        const hipError_t e = enqueue_levels(h);
+        if (h->owner_stalled)
+            CMI_FAIL(h, CMI_E_HIP, "owner epoch stalled: a tuple waited past its bound for a predecessor's record (is another persistent kernel "
+                     "holding compute units of device %d?) -- the model state is invalid; reload it and use CMI_FLAG_NO_OWNER", h->device);
+        CMI_HIP(h, e);
+    }
     CMI_HIP(h, hipEventRecord(h->ev1, h->stream));
     h->epoch_timed = true;
     return CMI_OK;
@@ -1099,9 +1206,11 @@ extern "C" int cmi_stream(cmi_handle h, void **stream) {
 extern "C" int cmi_exchange_setup(cmi_handle h, int64_t pad_to, void **bucket, int64_t *count) {
     if (!h || !bucket || !count || pad_to < 1) return CMI_E_INVALID;
     if (h->model == CMI_MODEL_CAMF_C) CMI_FAIL(h, CMI_E_UNSUPPORTED, "exchange: CAMF_C shares condBias between all tuples and is not sharded");
+    // SVD++ (Y) and CAMF_ICS / LCS / MCS (ccMatrix, cfMatrix, cVector) update containers every tuple reads: they are not in the bucket,
+    // so a merge would silently leave them diverged between the ranks
+    if (is_ext_model(h->model)) CMI_FAIL(h, CMI_E_UNSUPPORTED, "exchange: model %d is a single serial chain and is not sharded", h->model);
     CMI_HIP(h, hipSetDevice(h->device));
     CMI_HIP(h, hipStreamSynchronize(h->stream));
-    if (h->d_empty) hipFree(h->d_empty);
     if (h->d_xbucket) hipFree(h->d_xbucket);
     if (h->d_xsnap) hipFree(h->d_xsnap);
     h->d_xbucket = h->d_xsnap = nullptr;

@@ -21,6 +21,7 @@ struct cmi_instance {
     // owner (dataflow) schedule: one persistent launch, d_own_recs = the owners' lists, d_tagged = the spoke side's tagged records
     bool want_owner = false, owner = false, owner_hub_item = true;
     int n_owners = 0, n_team = 0; // owners [0, n_team) run as teams of three wavefronts
+    bool owner_stalled = false;   // an owner epoch hit its wait bound: the model state is invalid (sticky until cmi_set_ratings)
     void *d_own_recs = nullptr; // cmi::OwnerRecT<NCW>[]
     int64_t *d_own_off = nullptr;
     void *d_tagged = nullptr;

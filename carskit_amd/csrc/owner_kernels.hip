@@ -150,6 +150,17 @@ __global__ __launch_bounds__(256) void owner_records(T *__restrict__ rows, T *__
 // the epoch
 // ---------------------------------------------------------------------------------------------
 #define CMI_OWNER_SPIN_LIMIT (1u << 24)
+// One more poll of a wait loop.  True = leave the loop: either this wait has exhausted its bound (the epoch is flagged as stalled:
+// error[0] = 1) or ANOTHER owner has already flagged it -- then the model state is lost anyway and every later wait gives up after
+// its first poll instead of spinning to the bound again.  The flag is read once per 4096 polls: the cold path of a cold path.
+__device__ __forceinline__ bool owner_spin_expired(unsigned &spins, int *error, int lane) {
+    if ((spins++ & 4095u) == 0 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+    if (spins > CMI_OWNER_SPIN_LIMIT) {
+        if (lane == 0) atomicExch(error, 1);
+        return true;
+    }
+    return false;
+}
 static const int OWNER_DEPTH_MAX = 16; // every list is followed by OWNER_DEPTH_MAX + 1 inert entries (cmi_api.cpp), whatever D a kernel uses
 
 // Spoke records go through buffer instructions: one resource over the record table, the record's byte offset in the scalar offset
@@ -501,10 +512,7 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
                     while ((uint32_t)c - (freed = ctr[2]) >= (uint32_t)R) {
                         if (w == 0 && lane == 0 && spins == 0) atomicAdd(error + 2, 1); // statistics: the ring was full
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > CMI_OWNER_SPIN_LIMIT) {
-                            if (lane == 0) atomicExch(error, 1);
-                            break;
-                        }
+                        if (owner_spin_expired(spins, error, lane)) break;
                     }
                 }
                 lds_u8 *sl = ring + (c % R) * SLOT;
@@ -517,10 +525,7 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
                             __builtin_amdgcn_s_sleep(4);
                             owner_load_spoke<T, MODEL, VPL, NCW, HUB_ITEM>(rs, (int)r.off, lane, s);
                             if (__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want))) break;
-                            if (++spins > CMI_OWNER_SPIN_LIMIT) {
-                                if (lane == 0) atomicExch(error, 1);
-                                break;
-                            }
+                            if (owner_spin_expired(spins, error, lane)) break;
                         }
                     }
                     T xv[VPL], one[1];
@@ -559,10 +564,7 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
                 unsigned spins = 0;
                 while ((uint32_t)c >= (done = ctr[1])) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > CMI_OWNER_SPIN_LIMIT) {
-                        if (lane == 0) atomicExch(error, 1);
-                        break;
-                    }
+                    if (owner_spin_expired(spins, error, lane)) break;
                 }
             }
             const lds_u8 *sl = ring + (c % R) * SLOT;
@@ -619,10 +621,7 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
             while ((uint32_t)c >= (ready = ctr[0])) {
                 if (w == 0 && lane == 0 && spins == 0) atomicAdd(error + 1, 1); // statistics: the compute wave waited for the loader
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > CMI_OWNER_SPIN_LIMIT) {
-                    if (lane == 0) atomicExch(error, 1);
-                    break;
-                }
+                if (owner_spin_expired(spins, error, lane)) break;
             }
         }
         lds_u8 *sl = ring + (c % R) * SLOT;
@@ -803,10 +802,7 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
                     __builtin_amdgcn_s_sleep(4);
                     owner_load_spoke<T, MODEL, VPL, NCW, HUB_ITEM>(rs, (int)r.off, lane, s);
                     if (__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want))) break;
-                    if (++spins > CMI_OWNER_SPIN_LIMIT) {
-                        if (lane == 0) atomicExch(error, 1);
-                        break;
-                    }
+                    if (owner_spin_expired(spins, error, lane)) break;
                 }
                 n_late += 1; // statistics: records that were not ready when their step came, and the polls spent on them
                 n_polls += (int)spins + 1;

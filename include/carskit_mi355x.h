@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CMI_ABI_VERSION 1
+#define CMI_ABI_VERSION 2 /* 2: round-2/3 additions (models 6-9, states 7-10, owner/chain flags, mean merge, cmi_group_*) */
 
 /* status codes */
 #define CMI_OK 0
@@ -283,6 +283,11 @@ int cmi_last_loss(cmi_handle h, double *loss_out);
  * info[7]=workgroups of the dataflow launch; for CAMF_C the number of conflict-free CRS blocks its epoch is cut into
  * (0: the serial wave) */
 int cmi_schedule_info(cmi_handle h, int64_t info[8]);
+/* HBM bytes one epoch of the loaded schedule has to move, derived from the schedule (no reference counterpart: measurement).
+ * out[0]: every scattered scalar billed at its 64-byte sector, read and written (hub-chain schedules: hub row, hub bias and hub
+ * context-bias row once per UNIT; spoke row, tuple stream, spoke bias and spoke context-bias cells per tuple); out[1]: the same with
+ * scalars at their own size; out[2]: SURVEY 8(d)'s no-reuse algorithmic bytes; out[3]: 1 if on-chip hub reuse is modelled */
+int cmi_schedule_traffic(cmi_handle h, int64_t out[4]);
 /* GPU time of the most recent epoch's kernels measured with HIP events on cmi_stream() */
 int cmi_last_epoch_ms(cmi_handle h, float *ms);
 
