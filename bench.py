@@ -11,7 +11,14 @@ user (each rank owns its own users and their ratings: weak scaling, per-GPU work
 state (Q, icBias) is replicated and the mean of the ranks' per-epoch moves is applied after a reduce-scatter +
 all-gather of one flat bucket over RCCL (carskit_amd/dist.py).  Prints ONE JSON line on rank 0:
 the BASELINE metric at fp32 state (`value`, `roofline`, `cpu_baseline`), plus -- at N=1 -- a secondary `f64` object (the same
-workload with the model kept in fp64, the reference's own precision) and the part's measured ceilings (`roofline.peak_measured`).
+workload with the model kept in fp64, the reference's own precision), the part's measured ceilings (`roofline.peak_measured`) and a
+`northstar` object: the shape BASELINE.json's north_star target sentence names (10 M users x 1 M items x 64 conditions, 200 M
+ratings) timed the same way in the same run.
+
+roofline.frac = HBM bytes the loaded SCHEDULE has to move (cmi_schedule_traffic: hub row / bias / context-bias row once per unit of
+the hub-chain schedule, spoke row + tuple stream + scalar-bias sectors per tuple) / kernel time / 8 TB/s.  SURVEY 8(d)'s no-reuse
+figure is kept beside it as `frac_algorithmic` (it can exceed 1 because the kernel keeps the hub row on chip); the committed
+rocprofv3 PMC pass of the same command is the cross-check (`traffic`), and the run aborts if model and counters differ by > 5 %.
 """
 import argparse
 import json
@@ -102,27 +109,81 @@ def make_instance(model, k, data, n_items, state, regs, gm, device, flags):
     return inst
 
 
-def roofline(model, k, n_dims, data_n, info, kern_ms, esize, workload):
+def roofline(model, k, n_dims, data_n, info, sched, kern_ms, esize, workload):
+    """HBM roofline of the epoch's dominant kernel.  Numerator = bytes the schedule that ran has to move (`sched`, from
+    cmi_schedule_traffic, scattered scalars billed at their 64-byte sectors); SURVEY 8(d)'s no-reuse bytes ride along as
+    `*_algorithmic`; the PMC pass committed under profiles/ for this workload + schedule + dtype is the cross-check."""
     bpu = algorithmic_bytes(model, k, n_dims, esize)
     launches = info["levels"]
-    achieved = data_n * bpu / (kern_ms * 1e-3) / 1e9
+    sec = kern_ms * 1e-3
+    achieved = sched["sector"] / sec / 1e9
     chain = info["kind"].startswith("chain")
     tname = "float" if esize == 4 else "double"
-    traffic, src = measured_traffic(workload, info["kind"]) if esize == 4 else (None, None)
+    traffic, src = measured_traffic(workload + ("" if esize == 4 else "_f64"), info["kind"])
     avg_us = kern_ms * 1e3 / launches
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            # `achieved` prices the run at SURVEY 8(d)'s ALGORITHMIC bytes (both rows of every tuple from HBM, no reuse).  The
-            # hub-chain kernel keeps the shared row on chip across a unit, so the bytes it really moves (`traffic`, PMC) are
-            # fewer than that and `frac` may exceed what a no-reuse kernel could reach; `traffic_GBps` is the real HBM rate.
-            "traffic": traffic, "traffic_source": src,
-            "traffic_GBps": (traffic / avg_us / 1e3) if traffic else None,
-            "traffic_over_algorithmic": (traffic / (data_n * bpu / launches)) if traffic else None,
-            "kernel": ("sgd_chain_level<%s,%s,hub=%s>" % (tname, model, info["kind"][6:]) if chain
-                       else "sgd_owner<%s,%s,hub=%s> (latency-bound by the hottest row's chain, not by HBM)" % (tname, model, info["kind"][6:])
-                       if info["kind"].startswith("owner") else "sgd_level_fast_f32<%s,%d>" % (model, k // 64) if esize == 4 else "sgd_level_generic<double,%s>" % model),
-            "schedule": info["kind"], "bytes_per_update": bpu, "launches_per_epoch": launches,
-            "units_per_epoch": info["flow_blocks"] if chain else None,
-            "avg_launch_us": avg_us, "bytes_per_launch": data_n * bpu / launches}
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "bytes_model": "schedule: per unit hub row + hub bias sector + hub context-bias row (r+w once), per tuple spoke row r+w + "
+                          "tuple stream + 64-B sectors of the scattered scalars (cmi_schedule_traffic)" if sched["models_reuse"] else
+                          "schedule: both rows r+w + tuple stream + 64-B sectors of the scattered scalars per tuple (cmi_schedule_traffic)",
+           "bytes_per_epoch": sched["sector"], "bytes_per_launch": sched["sector"] / launches,
+           "bytes_per_update": sched["sector"] / data_n, "bytes_per_update_own_size_scalars": sched["own"] / data_n,
+           # SURVEY 8(d): both rows of every tuple from HBM, no reuse -- what round 1/2 priced the run at; NOT a bound for the chain kernel
+           "bytes_per_update_algorithmic": bpu, "achieved_algorithmic": data_n * bpu / sec / 1e9,
+           "frac_algorithmic": data_n * bpu / sec / 1e9 / HBM_PEAK_GBS,
+           # rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE per launch, tools/pmc_summary.py) of the same command, committed under profiles/
+           "traffic": traffic, "traffic_source": src,
+           "traffic_GBps": (traffic / avg_us / 1e3) if traffic else None,
+           "traffic_over_model": (traffic * launches / sched["sector"]) if traffic else None,
+           "kernel": ("sgd_chain_level<%s,%s,hub=%s>" % (tname, model, info["kind"][6:]) if chain
+                      else "sgd_owner<%s,%s,hub=%s> (latency-bound by the hottest row's chain, not by HBM)" % (tname, model, info["kind"][6:])
+                      if info["kind"].startswith("owner") else "sgd_level_fast_f32<%s,%d>" % (model, k // 64) if esize == 4 else "sgd_level_generic<double,%s>" % model),
+           "schedule": info["kind"], "launches_per_epoch": launches,
+           "units_per_epoch": info["flow_blocks"] if chain else None,
+           "avg_launch_us": avg_us}
+    if traffic and abs(out["traffic_over_model"] - 1.0) > 0.05:
+        raise SystemExit("bench: the schedule-derived HBM bytes (%.1f MB per launch) and the PMC pass %s (%.1f MB per launch) differ by "
+                         "more than 5 %% -- the roofline numerator is not trustworthy, fix the model or re-profile"
+                         % (sched["sector"] / launches / 1e6, src, traffic / 1e6))
+    return out
+
+
+def timed_epochs(inst, lr, steps, warmup):
+    """W untimed + K timed epochs of one instance: (losses, wall seconds, mean HIP-event ms per epoch on the instance's stream)."""
+    losses = [inst.train_epoch(lr) for _ in range(warmup)]
+    inst.synchronize()
+    t0 = time.perf_counter()
+    ms = []
+    for _ in range(steps):
+        losses.append(inst.train_epoch(lr))
+        ms.append(inst.last_epoch_ms())
+    inst.synchronize()
+    return losses, time.perf_counter() - t0, float(np.mean(ms))
+
+
+def secondary_workload(name, steps, warmup, device, flags, regs, lr):
+    """Another workload of WORKLOADS in the same run (the `northstar` object of the N=1 line): generated, scheduled, uploaded and
+    timed exactly like the primary one, with its own roofline."""
+    model, k, n_users, n_items, n_dims, cpd, n_ratings = WORKLOADS[name]
+    t0 = time.perf_counter()
+    data = synth.generate_fast(n_users, n_items, n_dims, cpd, n_ratings, seed=synth.DEFAULT_SEED)
+    gm = float(data.r.sum() / np.count_nonzero(data.r))
+    state = synth.init_state(model, data, k, seed=synth.DEFAULT_SEED + 2, dtype=np.float32)
+    inst = make_instance(model, k, data, n_items, state, regs, gm, device, flags)
+    info, sched = inst.schedule_info(), inst.schedule_traffic()
+    log("%s: %d tuples generated, scheduled and uploaded in %.1fs: %s" % (name, data.n, time.perf_counter() - t0, info))
+    del state
+    losses, el, kern_ms = timed_epochs(inst, lr, steps, warmup)
+    if not np.all(np.isfinite(losses)) or losses[-1] > losses[0]:
+        raise SystemExit("bench: %s diverged (epoch losses %s)" % (name, losses))
+    out = {"workload": "%s: %s k=%d, %d users x %d items x %d conditions (%d dims), %d ratings, order-exact %s schedule"
+                       % (name, model, k, data.n_users, n_items, data.n_conds, n_dims, data.n,
+                          "hub-chain level" if info["kind"].startswith("chain") else "owner (dataflow)" if info["kind"].startswith("owner")
+                          else "dependency-level"),
+           "dtype": "f32", "value": data.n * steps / el, "unit": "rating-updates/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": el / steps * 1e3, "levels_per_epoch": info["levels"], "first_loss": losses[0], "final_loss": losses[-1],
+           "roofline": roofline(model, k, n_dims, data.n, info, sched, kern_ms, 4, name)}
+    inst.close()
+    return out
 
 
 def main():
@@ -136,6 +197,10 @@ def main():
     ap.add_argument("--no-f64", action="store_true", help="skip the secondary fp64-state measurement")
     ap.add_argument("--f64-steps", type=int, default=3)
     ap.add_argument("--no-calibration", action="store_true", help="skip the in-run HBM calibration kernels")
+    ap.add_argument("--no-northstar", action="store_true",
+                    help="skip the `northstar` object (the north_star target shape, 200 M ratings: ~1.5 min of generation + upload)")
+    ap.add_argument("--northstar-steps", type=int, default=5)
+    ap.add_argument("--f64-primary", action="store_true", help="profiling knob: the PRIMARY measurement keeps the model in fp64 (PMC passes of the fp64 kernel)")
     ap.add_argument("--merge", default="mean", choices=("mean", "sum"), help="multi-GPU merge rule of the item-side moves")
     ap.add_argument("--flags", type=int, default=0, help="extra cmi_create flags (e.g. 16 = no hipGraph, 256 = no hub-chain)")
     ap.add_argument("--k", type=int, default=0, help="experiment knob: override the workload's num.factors")
@@ -192,7 +257,11 @@ def main():
     else:
         gm = float(data.r.sum() / np.count_nonzero(data.r))
     t0 = time.perf_counter()
-    state = synth.init_state(model, data, k, seed=synth.DEFAULT_SEED + 2, dtype=np.float32)
+    es = 8 if args.f64_primary else 4
+    if args.f64_primary:
+        args.flags |= capi.FLAG_STATE_F64
+        args.no_f64 = True
+    state = synth.init_state(model, data, k, seed=synth.DEFAULT_SEED + 2, dtype=np.float64 if es == 8 else np.float32)
     if world > 1:
         # item-side state must start identical on every rank; user-side differs per rank
         # (only the user-side containers this model owns: CAMF_CU / CAMF_CUCI / PMF have no userBias)
@@ -206,7 +275,7 @@ def main():
 
     t0 = time.perf_counter()
     inst = make_instance(model, k, data, n_items, state, regs, gm, local_rank, args.flags)
-    info = inst.schedule_info()
+    info, sched = inst.schedule_info(), inst.schedule_traffic()
     log("rank %d: schedule + upload in %.1fs: %s" % (rank, time.perf_counter() - t0, info))
 
     trainer = None
@@ -273,16 +342,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f64" if es == 8 else "f32", "data": "synthetic",
             "config": {"workload": "%s: %s k=%d, %d users x %d items x %d conditions (%d dims), %d ratings per GPU, "
                                    "lr 0.02f reg 1e-4f regC 1e-3f, order-exact %s schedule"
                                    % (args.workload, model, k, data.n_users, n_items, data.n_conds, n_dims, data.n,
-                                      "hub-chain level" if info["kind"].startswith("chain") else "dependency-level"),
+                                      "hub-chain level" if info["kind"].startswith("chain") else
+                                      "owner (dataflow)" if info["kind"].startswith("owner") else "dependency-level"),
                        "levels_per_epoch": info["levels"], "first_loss": losses[0], "final_loss": losses[-1],
                        "concurrent_folds": args.folds,
                        "parallelism": "1 GPU" if world == 1 else
                        "user-sharded x%d + RCCL reduce-scatter/all-gather of item-side moves (%s merge)" % (world, args.merge)},
-            "roofline": roofline(model, k, n_dims, data.n, info, kern_ms, 4, args.workload),
+            "roofline": roofline(model, k, n_dims, data.n, info, sched, kern_ms, es, args.workload),
         }
         for o in extra:
             o.close()
@@ -300,19 +370,12 @@ def main():
                 inst.close()
                 st64 = {n: a.astype(np.float64) for n, a in state.items()}
                 i64 = make_instance(model, k, data, n_items, st64, regs, gm, local_rank, args.flags | capi.FLAG_STATE_F64)
-                info64 = i64.schedule_info()
-                l64 = [i64.train_epoch(lr)]
-                i64.synchronize()
-                t0 = time.perf_counter()
-                ms64 = []
-                for _ in range(args.f64_steps):
-                    l64.append(i64.train_epoch(lr))
-                    ms64.append(i64.last_epoch_ms())
-                i64.synchronize()
-                el64 = time.perf_counter() - t0
+                info64, sched64 = i64.schedule_info(), i64.schedule_traffic()
+                del st64
+                l64, el64, ms64 = timed_epochs(i64, lr, args.f64_steps, 1)
                 out["f64"] = {"dtype": "f64", "value": data.n * args.f64_steps / el64, "unit": "rating-updates/s",
                               "steps": args.f64_steps, "ms_per_step": el64 / args.f64_steps * 1e3, "final_loss": l64[-1],
-                              "roofline": roofline(model, k, n_dims, data.n, info64, float(np.mean(ms64)), 8, args.workload)}
+                              "roofline": roofline(model, k, n_dims, data.n, info64, sched64, ms64, 8, args.workload)}
                 i64.close()
             except Exception as e:
                 out["f64"] = {"value": None, "error": repr(e)}
@@ -321,6 +384,16 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(model, k, data, state, gm, regs, lr, args.cpu_tuples)
             except Exception as e:  # the oracle is only the reported baseline, never the product path
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        if world == 1 and args.folds == 1 and args.workload == "c3" and not args.no_northstar and not args.item_zipf:
+            # the shape the north_star target sentence is quoted on, driver-timed in the same run
+            try:
+                inst.close()
+                del data, state
+                out["northstar"] = secondary_workload("northstar", args.northstar_steps, args.warmup, local_rank, args.flags, regs, lr)
+            except SystemExit:
+                raise
+            except Exception as e:
+                out["northstar"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -89,6 +89,23 @@ SYMBOLS = [
     ("cmi_schedule_info", C.c_int, [_vp, C.POINTER(_i64)]),
     ("cmi_schedule_traffic", C.c_int, [_vp, C.POINTER(_i64)]),
     ("cmi_exchange_setup", C.c_int, [_vp, _i64, C.POINTER(_vp), C.POINTER(_i64)]),
+    ("cmi_group_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_uint, C.POINTER(_vp)]),
+    ("cmi_group_destroy", C.c_int, [_vp]),
+    ("cmi_group_last_error", C.c_char_p, [_vp]),
+    ("cmi_group_size", C.c_int, [_vp]),
+    ("cmi_group_set_hparams", C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    ("cmi_group_set_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    ("cmi_group_set_state", C.c_int, [_vp, C.c_int, _vp, _i64, C.c_int]),
+    ("cmi_group_get_state", C.c_int, [_vp, C.c_int, _vp, _i64, C.c_int]),
+    ("cmi_group_train_epoch", C.c_int, [_vp, C.c_double, C.POINTER(C.c_double)]),
+    ("cmi_group_train", C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, _vp, _vp, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_double)]),
+    ("cmi_group_train_from", C.c_int, [_vp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, _vp, _vp,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    ("cmi_group_eval_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, C.c_double, C.c_double, _vp, C.POINTER(_i64)]),
+    ("cmi_group_predict_batch", C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, C.c_double, C.c_double, _vp]),
+    ("cmi_group_shard_info", C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
+    ("cmi_group_member", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("cmi_exchange_pack", C.c_int, [_vp]),
     ("cmi_exchange_apply", C.c_int, [_vp, C.c_double]),
     ("cmi_loss_device_ptr", C.c_int, [_vp, C.POINTER(_vp)]),
@@ -364,6 +381,117 @@ def _eval_rankings(fn, chk, h, train, test, bin_thold=-1.0, num_recs=10, num_ign
             lists[(int(qu[q]), int(qc[q]))] = [(int(items[q * num_recs + i]), float(scores[q * num_recs + i]))
                                                for i in range(qn[q])]
     return res, lists
+
+
+class Group:
+    """One recommender trained over several GPUs from this one process (a `cmi_group_handle`): ratings sharded by user, item-side
+    containers merged (mean of the shards' moves) after every epoch through RCCL, or in-process when shards share a device."""
+
+    def __init__(self, model, k, n_users, n_items, n_conds, n_shards, devices=None, flags=0):
+        self.L = lib()
+        self.model = model if isinstance(model, str) else {v: n for n, v in MODEL_IDS.items()}[model]
+        self.k, self.n_users, self.n_items, self.n_conds, self.num_f = k, n_users, n_items, n_conds, 0
+        self.h = _vp()
+        dev = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        rc = self.L.cmi_group_create(MODEL_IDS[self.model], k, n_users, n_items, n_conds, n_shards, _p(dev), flags, C.byref(self.h))
+        if rc != OK:
+            self.h = None
+            raise CmiError(rc, self.L.cmi_group_last_error(None).decode())
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise CmiError(rc, self.L.cmi_group_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cmi_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return self.L.cmi_group_size(self.h)
+
+    def set_hparams(self, regU, regI, regB, regC, global_mean):
+        self._chk(self.L.cmi_group_set_hparams(self.h, regU, regI, regB, regC, global_mean))
+
+    def set_ratings(self, u, j, ctx, r, ctx_ptr=None, ctx_conds=None):
+        c32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        u, j, ctx, ctx_ptr, ctx_conds = c32(u), c32(j), c32(ctx), c32(ctx_ptr), c32(ctx_conds)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        n_ctx = 0 if ctx_ptr is None else len(ctx_ptr) - 1
+        self._chk(self.L.cmi_group_set_ratings(self.h, len(r), _p(u), _p(j), _p(ctx), _p(r), n_ctx, _p(ctx_ptr), _p(ctx_conds)))
+
+    def set_state(self, name, arr):
+        a = np.ascontiguousarray(arr)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float64)
+        self._chk(self.L.cmi_group_set_state(self.h, STATE_IDS[name], _p(a), a.size, 1 if a.dtype == np.float64 else 0))
+
+    def set_states(self, state):
+        for name, arr in state.items():
+            if arr is not None:
+                self.set_state(name, arr)
+
+    def get_state(self, name, dtype=np.float64):
+        out = np.empty(Instance.state_shape(self, name), dtype=dtype)
+        self._chk(self.L.cmi_group_get_state(self.h, STATE_IDS[name], _p(out), out.size, 1 if dtype == np.float64 else 0))
+        return out
+
+    def get_states(self, dtype=np.float64):
+        return {name: self.get_state(name, dtype) for name in MODEL_STATES[self.model]}
+
+    def train_epoch(self, lrate):
+        loss = _dbl()
+        self._chk(self.L.cmi_group_train_epoch(self.h, lrate, C.byref(loss)))
+        return loss.value
+
+    def train(self, num_iters, init_lrate, max_lrate=-1.0, bold_driver=False, decay=-1.0, early_stop=0, first_iter=1, prev_loss=0.0):
+        losses, lrs = np.zeros(num_iters), np.zeros(num_iters)
+        n, final = C.c_int(0), _dbl(0)
+        rc = self.L.cmi_group_train_from(self.h, first_iter, prev_loss, num_iters, init_lrate, max_lrate, int(bold_driver), decay,
+                                         early_stop, _p(losses), _p(lrs), C.byref(n), C.byref(final))
+        self.iters_run, self.final_lrate = n.value, final.value
+        self._chk(rc)
+        return losses[:n.value], lrs[:n.value]
+
+    def eval_ratings(self, u, j, ctx, r, min_rate, max_rate):
+        c32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        u, j, ctx = c32(u), c32(j), c32(ctx)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        out, cnt = np.zeros(5), _i64()
+        self._chk(self.L.cmi_group_eval_ratings(self.h, len(r), _p(u), _p(j), _p(ctx), _p(r), min_rate, max_rate, _p(out), C.byref(cnt)))
+        res = dict(zip(("MAE", "RMSE", "NMAE", "rMAE", "rRMSE"), out.tolist()))
+        res["n"] = cnt.value
+        return res
+
+    def predict_batch(self, u, j, ctx, bound=False, lo=0.0, hi=0.0):
+        c32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        u, j, ctx = c32(u), c32(j), c32(ctx)
+        out = np.empty(len(u))
+        self._chk(self.L.cmi_group_predict_batch(self.h, len(u), _p(u), _p(j), _p(ctx), int(bound), lo, hi, _p(out)))
+        return out
+
+    def shard_info(self, shard):
+        info = (_i64 * 6)()
+        self._chk(self.L.cmi_group_shard_info(self.h, shard, info))
+        return {"user_lo": info[0], "user_hi": info[1], "tuples": info[2], "device": info[3],
+                "exchange": ("none", "rccl", "in-process")[info[4]], "bucket_elems": info[5]}
+
+    def member(self, shard):
+        """The shard's instance as a borrowed capi.Instance (the group owns it: do not close)."""
+        h = _vp()
+        self._chk(self.L.cmi_group_member(self.h, shard, C.byref(h)))
+        inst = Instance.__new__(Instance)
+        inst.L, inst.h, inst.model, inst.k = self.L, h, self.model, self.k
+        si = self.shard_info(shard)
+        inst.n_users, inst.n_items, inst.n_conds, inst.num_f, inst.flags = si["user_hi"] - si["user_lo"], self.n_items, self.n_conds, 0, 0
+        inst.close = lambda: None
+        return inst
 
 
 class Instance:

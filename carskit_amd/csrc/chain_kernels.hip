@@ -286,17 +286,33 @@ __device__ __forceinline__ void chain_unit(const SgdArgs<T> &a, const ChainHp<T>
     chain_lds_order();
 
     // ---- the chain: spoke rows ping-pong between two register sets, the next one in flight while this one is used
-    int i = 0;
-    while (true) {
-        if (i + 1 < len)
-            chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, B);
+    // The chain.  Spoke rows ping-pong between two register sets: the row of tuple i + 1 is requested before tuple i is computed.
+    // What it takes for the waits to stay PARTIAL (round 2's loop compiled to s_waitcnt vmcnt(0) right after the read-ahead's issue,
+    // i.e. load -> wait -> compute; `hipcc -S` excerpt in DESIGN.md section 5):
+    //  * the read-ahead is issued unconditionally -- behind `if (i + 1 < len)` the compiler cannot count the loads in flight at the
+    //    join.  Past the end of the unit the slot re-reads the unit's last row (an L1 / L2 hit, discarded);
+    //  * the loop has ONE exit, at the bottom, after a whole pair of tuples: an exit between the two halves leaves a static path
+    //    "second half skipped -> loop header" on which the read-ahead's destination registers are still pending, and the header's
+    //    address arithmetic reuses them -> a wait at the top of every iteration, ahead of the read-ahead's issue.  An odd tuple runs
+    //    after the loop;
+    //  * nothing is in flight on entry (the prologue's pending loads would be merged into the header's bookkeeping the same way).
+    // Per pair the wave then issues [load B][store A][load A'][store B] and waits with vmcnt(4) / vmcnt(5): the two loads of the row
+    // read ahead and the two stores of the previous row stay in flight while a row is computed.
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    const int pairs = len >> 1;
+    for (int t = 0; t < pairs; ++t) {
+        const int i = 2 * t;
+        chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, B);
+        chain_lds_order();
         chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, s_sb + i, A, s_rr[i], l16, K, gloss);
-        if (++i >= len) break;
-        if (i + 1 < len)
-            chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, A);
-        chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, s_sb + i, B, s_rr[i], l16, K, gloss);
-        if (++i >= len) break;
+        {
+            const int nx = i + 2 < len ? i + 2 : len - 1;
+            chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[nx], l16 < dmax ? s_cd[nx * dmax + l16] : -1, l16, K, A);
+        }
+        chain_lds_order();
+        chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, s_sb + i + 1, B, s_rr[i + 1], l16, K, gloss);
     }
+    if (len & 1) chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, s_sb + len - 1, A, s_rr[len - 1], l16, K, gloss);
 
     // ---- the hub row leaves the chip once
 #pragma unroll

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <mutex>
 #include <vector>
@@ -1151,12 +1152,16 @@ extern "C" int cmi_train_epoch(cmi_handle h, double lrate, double *loss_out) {
 // IterativeRecommender.isConverged + updateLRate (IterativeRecommender.java:145-229), host side.  first_iter / last_loss let a
 // reloaded model (cmi_load_model) continue the loop exactly where it stopped: the bold driver compares with the previous epoch's
 // loss and is off in iteration 1 only.
-extern "C" int cmi_train_from(cmi_handle h, int first_iter, double prev_loss, int num_iters, double init_lrate, double max_lrate,
-                              int bold_driver, double decay, int early_stop, double *losses, double *lrates, int *iters_run,
-                              double *final_lrate) {
-    if (!h) return CMI_E_INVALID;
-    if (first_iter < 1) CMI_FAIL(h, CMI_E_INVALID, "train: first_iter must be >= 1");
-    if (early_stop != 0 && early_stop != 1) CMI_FAIL(h, CMI_E_UNSUPPORTED, "train: early_stop must be 0 (none) or 1 (loss)");
+// (shared with cmi_group_train_from: `epoch` runs one epoch at the given rate and returns the loss the host steers by)
+int cmi_train_loop(const std::function<int(double, double *)> &epoch, std::string &err, int first_iter, double prev_loss, int num_iters,
+                   double init_lrate, double max_lrate, int bold_driver, double decay, int early_stop, double *losses, double *lrates,
+                   int *iters_run, double *final_lrate) {
+    auto fail = [&](int code, const char *msg) {
+        err = msg;
+        return code;
+    };
+    if (first_iter < 1) return fail(CMI_E_INVALID, "train: first_iter must be >= 1");
+    if (early_stop != 0 && early_stop != 1) return fail(CMI_E_UNSUPPORTED, "train: early_stop must be 0 (none) or 1 (loss)");
     double lr = init_lrate, last_loss = prev_loss, measure = 0.0, last_measure = 0.0;
     if (early_stop == 1) last_measure = measure = prev_loss;
     if (iters_run) *iters_run = 0;
@@ -1164,7 +1169,7 @@ extern "C" int cmi_train_from(cmi_handle h, int first_iter, double prev_loss, in
         const int it = first_iter + n;
         double loss = 0.0;
         if (lrates) lrates[n] = lr;
-        if (int rc = cmi_train_epoch(h, lr, &loss)) return rc;
+        if (int rc = epoch(lr, &loss)) return rc;
         if (losses) losses[n] = loss;
         if (iters_run) *iters_run = n + 1;
         if (early_stop == 1) {
@@ -1174,7 +1179,9 @@ extern "C" int cmi_train_from(cmi_handle h, int first_iter, double prev_loss, in
         const float delta_measure = (float)(last_measure - measure);
         if (std::isnan(loss) || std::isinf(loss)) {
             if (final_lrate) *final_lrate = lr;
-            CMI_FAIL(h, CMI_E_NUMERIC, "Loss = NaN or Infinity at iteration %d: current settings do not fit the recommender", it);
+            char buf[160];
+            snprintf(buf, sizeof buf, "Loss = NaN or Infinity at iteration %d: current settings do not fit the recommender", it);
+            return fail(CMI_E_NUMERIC, buf);
         }
         const bool converged = std::fabs(loss) < 1e-5 || (delta_measure > 0 && delta_measure < 1e-5);
         if (!converged && lr > 0) {
@@ -1188,6 +1195,17 @@ extern "C" int cmi_train_from(cmi_handle h, int first_iter, double prev_loss, in
     }
     if (final_lrate) *final_lrate = lr;
     return CMI_OK;
+}
+
+extern "C" int cmi_train_from(cmi_handle h, int first_iter, double prev_loss, int num_iters, double init_lrate, double max_lrate,
+                              int bold_driver, double decay, int early_stop, double *losses, double *lrates, int *iters_run,
+                              double *final_lrate) {
+    if (!h) return CMI_E_INVALID;
+    std::string err;
+    const int rc = cmi_train_loop([h](double lr, double *loss) { return cmi_train_epoch(h, lr, loss); }, err, first_iter, prev_loss,
+                                  num_iters, init_lrate, max_lrate, bold_driver, decay, early_stop, losses, lrates, iters_run, final_lrate);
+    if (rc != CMI_OK && !err.empty()) h->err = err;
+    return rc;
 }
 
 extern "C" int cmi_train(cmi_handle h, int num_iters, double init_lrate, double max_lrate, int bold_driver,
@@ -1439,6 +1457,12 @@ extern "C" int cmi_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, const
     out[4] = std::sqrt(sums[3] / cnt);
     if (count) *count = (int64_t)cnt;
     return CMI_OK;
+}
+
+// the five sums behind cmi_eval_ratings (sum|e|, sum e^2, rounded forms, count), so that cmi_group_eval_ratings can merge shards exactly
+int cmi_eval_sums(cmi_instance *h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r, double min_rate,
+                  double max_rate, double sums[5]) {
+    return eval_common(h, n, u, j, ctx, r, 1, min_rate, max_rate, min_rate, nullptr, sums);
 }
 
 // ---- host-only schedule export ------------------------------------------------------------------------

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -93,3 +94,10 @@ bool cmi_model_has(int model, int which); // which containers a model owns (cmi_
 template <typename T>
 cmi::ExtEvalArgs<T> cmi_ext_eval_args(cmi_instance *h, const int32_t *du, const int32_t *dj, const int32_t *dctx, const double *dr,
                                       double *dpreds, double *dpart, int bound, double lo, double hi, double min_rate);
+
+// IterativeRecommender.isConverged + updateLRate around an epoch function (cmi_api.cpp; shared by cmi_train_from and cmi_group_train_from)
+int cmi_train_loop(const std::function<int(double, double *)> &epoch, std::string &err, int first_iter, double prev_loss, int num_iters,
+                   double init_lrate, double max_lrate, int bold_driver, double decay, int early_stop, double *losses, double *lrates,
+                   int *iters_run, double *final_lrate);
+int cmi_eval_sums(cmi_instance *h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r, double min_rate,
+                  double max_rate, double sums[5]);

@@ -1,0 +1,508 @@
+// group_api.cpp -- cmi_group_*: ONE handle that trains one recommender over several GPUs of a node from a single host process
+// (the Java / C++ hosts have one process; carskit_amd/dist.py is the one-process-per-GPU form of the same algorithm).
+//
+// The reference path is a single sequential loop (e.g. CAMF_CI.java:79-123) and shards nowhere; its only parallelism is one
+// thread per fold (CARSKit.java:395-412).  The algorithm shards BY USER: P[u], userBias[u], ucBias[u,:] are touched
+// by exactly one shard; the item-side containers (Q, itemBias, icBias) are replicated and merged once per epoch:
+//
+//     every shard:  local order-exact epoch over its users' ratings             (cmi_train_epoch_async, concurrently)
+//     exchange:     bucket_s = item_side_s - snapshot   (cmi_exchange_pack)
+//                   reduce-scatter + all-gather of the buckets (RCCL over xGMI: ncclReduceScatter / ncclAllGather, one grouped
+//                   call over all communicators of this process, on the instances' own streams)
+//                   item_side = snapshot + bucket / W   (cmi_exchange_apply: the MEAN of the shards' moves)
+//     loss:         all-reduce (sum) of the fp64 epoch losses -> what isConverged()/updateLRate() steer by
+//
+// Shards that share a device (a group of N on ONE GPU: the form the tests run on a single-GPU box) or CMI_GROUP_NO_RCCL=1 use
+// the in-process exchange instead: the buckets are summed in shard order on shard 0's stream and copied back (peer copies) --
+// the same arithmetic, no communicator.
+#include "../../include/carskit_mi355x.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cmi_instance.hpp"
+
+struct cmi_group {
+    int model = 0, k = 0, n_users = 0, n_items = 0, n_conds = 0;
+    unsigned flags = 0;
+    bool f64 = false;
+    std::vector<int> dev;            // device of every shard
+    std::vector<cmi_handle> inst;    // created by cmi_group_set_ratings (their user counts depend on the cut)
+    std::vector<int32_t> cut;        // W + 1 user-id boundaries
+    std::vector<int64_t> shard_n;    // tuples per shard
+    std::vector<void *> bucket;
+    std::vector<hipEvent_t> ev;      // per shard; ev[W] = shard 0's "sum ready"
+    int64_t x_count = 0;
+    bool rccl = false;
+    std::vector<ncclComm_t> comm;
+    void *d_stage = nullptr;         // in-process exchange: staging buffer on shard 0's device
+    double hp[5] = {0, 0, 0, 0, 0};  // regU regI regB regC globalMean
+    bool have_hp = false;
+    std::string err;
+    float last_ms = 0.f;
+};
+
+static thread_local std::string g_group_create_err;
+
+#define GRP_FAIL(g, code, ...)                    \
+    do {                                          \
+        char buf_[512];                           \
+        snprintf(buf_, sizeof buf_, __VA_ARGS__); \
+        (g)->err = buf_;                          \
+        return (code);                            \
+    } while (0)
+#define GRP_HIP(g, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) GRP_FAIL(g, CMI_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define GRP_NCCL(g, expr)                                                                                 \
+    do {                                                                                                  \
+        ncclResult_t r_ = (expr);                                                                         \
+        if (r_ != ncclSuccess) GRP_FAIL(g, CMI_E_HIP, "%s failed: %s", #expr, ncclGetErrorString(r_));   \
+    } while (0)
+// a member call failed: carry its message
+#define GRP_MEMBER(g, i, expr)                                                                                   \
+    do {                                                                                                         \
+        int rc_ = (expr);                                                                                        \
+        if (rc_ != CMI_OK) GRP_FAIL(g, rc_, "shard %d (device %d): %s", (int)(i), (g)->dev[(size_t)(i)], cmi_last_error((g)->inst[(size_t)(i)])); \
+    } while (0)
+
+static bool user_side(int which) { return which == CMI_STATE_P || which == CMI_STATE_USER_BIAS || which == CMI_STATE_UC_BIAS; }
+
+template <typename T>
+__global__ void group_add_kernel(T *__restrict__ acc, const T *__restrict__ x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] += x[i];
+}
+static hipError_t group_add(void *acc, const void *x, int64_t n, bool f64, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (f64) hipLaunchKernelGGL(group_add_kernel<double>, dim3(blocks), dim3(256), 0, s, (double *)acc, (const double *)x, n);
+    else hipLaunchKernelGGL(group_add_kernel<float>, dim3(blocks), dim3(256), 0, s, (float *)acc, (const float *)x, n);
+    return hipGetLastError();
+}
+
+extern "C" const char *cmi_group_last_error(cmi_group_handle g) { return g ? g->err.c_str() : g_group_create_err.c_str(); }
+
+static void group_free_instances(cmi_group *g) {
+    for (ncclComm_t c : g->comm)
+        if (c) ncclCommDestroy(c);
+    g->comm.clear();
+    if (g->d_stage) {
+        hipSetDevice(g->dev[0]);
+        hipFree(g->d_stage);
+        g->d_stage = nullptr;
+    }
+    for (size_t i = 0; i < g->ev.size(); ++i)
+        if (g->ev[i]) {
+            hipSetDevice(g->dev[i + 1 == g->ev.size() ? 0 : i]);
+            hipEventDestroy(g->ev[i]);
+        }
+    g->ev.clear();
+    for (cmi_handle h : g->inst)
+        if (h) cmi_destroy(h);
+    g->inst.clear();
+    g->bucket.clear();
+    g->cut.clear();
+    g->shard_n.clear();
+}
+
+extern "C" int cmi_group_destroy(cmi_group_handle g) {
+    if (!g) return CMI_OK;
+    group_free_instances(g);
+    delete g;
+    return CMI_OK;
+}
+
+extern "C" int cmi_group_create(int model, int k, int n_users, int n_items, int n_conds, int n_shards, const int *devices, unsigned flags,
+                                cmi_group_handle *out) {
+    if (out) *out = nullptr;
+    if (!out || n_shards < 1 || n_shards > 64 || k <= 0 || n_users < n_shards || n_items <= 0 || n_conds < 0) {
+        g_group_create_err = "cmi_group_create: invalid argument (1..64 shards, at least one user per shard)";
+        return CMI_E_INVALID;
+    }
+    if (model == CMI_MODEL_CAMF_C || (model >= CMI_MODEL_SVDPP && model <= CMI_MODEL_CAMF_MCS)) {
+        if (n_shards > 1) {
+            g_group_create_err = "cmi_group_create: CAMF_C, SVD++ and CAMF_ICS/LCS/MCS are single serial chains (every tuple updates "
+                                 "parameters every other tuple reads) and are not sharded; use one shard";
+            return CMI_E_UNSUPPORTED;
+        }
+    }
+    const int ndev = cmi_device_count();
+    if (ndev <= 0) {
+        g_group_create_err = "cmi_group_create: no HIP device visible (libcarskit_mi355x has no CPU fallback)";
+        return CMI_E_NO_DEVICE;
+    }
+    cmi_group *g = new cmi_group();
+    g->model = model, g->k = k, g->n_users = n_users, g->n_items = n_items, g->n_conds = n_conds, g->flags = flags;
+    g->f64 = flags & CMI_FLAG_STATE_F64;
+    for (int s = 0; s < n_shards; ++s) {
+        const int d = devices ? devices[s] : s % ndev; // default: round robin over the visible devices
+        if (d < 0 || d >= ndev) {
+            g_group_create_err = "cmi_group_create: device index out of range";
+            delete g;
+            return CMI_E_INVALID;
+        }
+        g->dev.push_back(d);
+    }
+    *out = g;
+    return CMI_OK;
+}
+
+extern "C" int cmi_group_size(cmi_group_handle g) { return g ? (int)g->dev.size() : 0; }
+
+extern "C" int cmi_group_set_hparams(cmi_group_handle g, double regU, double regI, double regB, double regC, double global_mean) {
+    if (!g) return CMI_E_INVALID;
+    g->hp[0] = regU, g->hp[1] = regI, g->hp[2] = regB, g->hp[3] = regC, g->hp[4] = global_mean;
+    g->have_hp = true;
+    for (size_t i = 0; i < g->inst.size(); ++i) GRP_MEMBER(g, i, cmi_set_hparams(g->inst[i], regU, regI, regB, regC, global_mean));
+    return CMI_OK;
+}
+
+// Contiguous user-id ranges cut so that every shard holds about n / W tuples (the rule of carskit_amd/dist.py shard_by_user:
+// boundary r = first user at which the running tuple count reaches n * r / W, at least one user per shard).
+static void cut_users(int64_t n, const int32_t *u, int32_t n_users, int W, std::vector<int32_t> &cut) {
+    std::vector<int64_t> cum((size_t)n_users + 1, 0);
+    for (int64_t t = 0; t < n; ++t) cum[(size_t)u[t] + 1]++;
+    for (int32_t x = 0; x < n_users; ++x) cum[(size_t)x + 1] += cum[(size_t)x];
+    cut.assign((size_t)W + 1, 0);
+    for (int r = 1; r < W; ++r) {
+        const double target = (double)n * r / W;
+        // first index c with cum[c] >= target   (numpy.searchsorted(cum, target, side="left"))
+        int32_t c = (int32_t)(std::lower_bound(cum.begin(), cum.end(), target, [](int64_t a, double b) { return (double)a < b; }) - cum.begin());
+        c = std::max(c, cut[(size_t)r - 1] + 1);
+        c = std::min(c, n_users - (W - r));
+        cut[(size_t)r] = c;
+    }
+    cut[(size_t)W] = n_users;
+}
+
+static int shard_of(const std::vector<int32_t> &cut, int32_t user) {
+    return (int)(std::upper_bound(cut.begin() + 1, cut.end(), user) - cut.begin() - 1);
+}
+
+extern "C" int cmi_group_set_ratings(cmi_group_handle g, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r,
+                                     int32_t n_ctx, const int32_t *ctx_ptr, const int32_t *ctx_conds) {
+    if (!g) return CMI_E_INVALID;
+    if (n < 0 || (n > 0 && (!u || !j || !r))) GRP_FAIL(g, CMI_E_INVALID, "group_set_ratings: null tuple arrays");
+    const int W = (int)g->dev.size();
+    for (int64_t t = 0; t < n; ++t)
+        if (u[t] < 0 || u[t] >= g->n_users) GRP_FAIL(g, CMI_E_INVALID, "group_set_ratings: user id %d out of range at tuple %lld", u[t], (long long)t);
+    group_free_instances(g);
+    cut_users(n, u, g->n_users, W, g->cut);
+    // tuples of every shard, CRS order kept, user ids re-based to the shard
+    std::vector<std::vector<int32_t>> su((size_t)W), sj((size_t)W), sc((size_t)W);
+    std::vector<std::vector<double>> sr((size_t)W);
+    g->shard_n.assign((size_t)W, 0);
+    for (int64_t t = 0; t < n; ++t) g->shard_n[(size_t)shard_of(g->cut, u[t])]++;
+    for (int s = 0; s < W; ++s) {
+        su[(size_t)s].reserve((size_t)g->shard_n[(size_t)s]);
+        sj[(size_t)s].reserve((size_t)g->shard_n[(size_t)s]);
+        if (ctx) sc[(size_t)s].reserve((size_t)g->shard_n[(size_t)s]);
+        sr[(size_t)s].reserve((size_t)g->shard_n[(size_t)s]);
+    }
+    for (int64_t t = 0; t < n; ++t) {
+        const int s = shard_of(g->cut, u[t]);
+        su[(size_t)s].push_back(u[t] - g->cut[(size_t)s]);
+        sj[(size_t)s].push_back(j[t]);
+        if (ctx) sc[(size_t)s].push_back(ctx[t]);
+        sr[(size_t)s].push_back(r[t]);
+    }
+    g->inst.assign((size_t)W, nullptr);
+    for (int s = 0; s < W; ++s) {
+        const int rc = cmi_create(g->model, g->k, g->cut[(size_t)s + 1] - g->cut[(size_t)s], g->n_items, g->n_conds, g->dev[(size_t)s], g->flags,
+                                  &g->inst[(size_t)s]);
+        if (rc != CMI_OK) GRP_FAIL(g, rc, "shard %d (device %d): %s", s, g->dev[(size_t)s], cmi_last_error(nullptr));
+        if (g->have_hp) GRP_MEMBER(g, s, cmi_set_hparams(g->inst[(size_t)s], g->hp[0], g->hp[1], g->hp[2], g->hp[3], g->hp[4]));
+    }
+    // schedule construction is host integer work (seconds for tens of millions of tuples): one thread per shard
+    std::vector<int> rcs((size_t)W, CMI_OK);
+    {
+        std::vector<std::thread> th;
+        for (int s = 0; s < W; ++s)
+            th.emplace_back([&, s] {
+                rcs[(size_t)s] = cmi_set_ratings(g->inst[(size_t)s], g->shard_n[(size_t)s], su[(size_t)s].data(), sj[(size_t)s].data(),
+                                                 ctx ? sc[(size_t)s].data() : nullptr, sr[(size_t)s].data(), n_ctx, ctx_ptr, ctx_conds);
+            });
+        for (std::thread &t : th) t.join();
+    }
+    for (int s = 0; s < W; ++s)
+        if (rcs[(size_t)s] != CMI_OK) GRP_FAIL(g, rcs[(size_t)s], "shard %d (device %d): %s", s, g->dev[(size_t)s], cmi_last_error(g->inst[(size_t)s]));
+    if (W == 1) return CMI_OK;
+
+    // exchange plumbing
+    g->bucket.assign((size_t)W, nullptr);
+    for (int s = 0; s < W; ++s) {
+        int64_t cnt = 0;
+        GRP_MEMBER(g, s, cmi_exchange_setup(g->inst[(size_t)s], W, &g->bucket[(size_t)s], &cnt));
+        if (s == 0) g->x_count = cnt;
+        else if (cnt != g->x_count) GRP_FAIL(g, CMI_E_INVALID, "group_set_ratings: bucket sizes differ between shards");
+    }
+    bool distinct = true;
+    for (int a = 0; a < W; ++a)
+        for (int b = a + 1; b < W; ++b) distinct = distinct && g->dev[(size_t)a] != g->dev[(size_t)b];
+    g->rccl = distinct && !getenv("CMI_GROUP_NO_RCCL");
+    g->ev.assign((size_t)W + 1, nullptr);
+    for (int s = 0; s <= W; ++s) { // ev[W] belongs to shard 0's device
+        GRP_HIP(g, hipSetDevice(g->dev[s == W ? 0 : (size_t)s]));
+        GRP_HIP(g, hipEventCreateWithFlags(&g->ev[(size_t)s], hipEventDisableTiming));
+    }
+    if (g->rccl) {
+        g->comm.assign((size_t)W, nullptr);
+        GRP_NCCL(g, ncclCommInitAll(g->comm.data(), W, g->dev.data()));
+    } else {
+        GRP_HIP(g, hipSetDevice(g->dev[0]));
+        GRP_HIP(g, hipMalloc(&g->d_stage, (size_t)g->x_count * (g->f64 ? 8 : 4) + 8));
+        for (int s = 1; s < W; ++s)
+            if (g->dev[(size_t)s] != g->dev[0]) {
+                int can = 0;
+                hipDeviceCanAccessPeer(&can, g->dev[0], g->dev[(size_t)s]);
+                if (can) {
+                    hipSetDevice(g->dev[0]);
+                    hipDeviceEnablePeerAccess(g->dev[(size_t)s], 0); // already enabled is fine
+                    hipSetDevice(g->dev[(size_t)s]);
+                    hipDeviceEnablePeerAccess(g->dev[0], 0);
+                    (void)hipGetLastError();
+                }
+            }
+    }
+    return CMI_OK;
+}
+
+static int need_ratings(cmi_group *g, const char *what) {
+    if (g->inst.empty()) GRP_FAIL(g, CMI_E_INVALID, "%s: call cmi_group_set_ratings first (the user cut depends on the ratings)", what);
+    return CMI_OK;
+}
+
+extern "C" int cmi_group_set_state(cmi_group_handle g, int which, const void *src, int64_t count, int dtype) {
+    if (!g || !src) return CMI_E_INVALID;
+    if (int rc = need_ratings(g, "group_set_state")) return rc;
+    const int W = (int)g->inst.size();
+    const size_t es = dtype == CMI_DTYPE_F64 ? 8 : 4;
+    if (!user_side(which)) {
+        for (int s = 0; s < W; ++s) GRP_MEMBER(g, s, cmi_set_state(g->inst[(size_t)s], which, src, count, dtype));
+        return CMI_OK;
+    }
+    if (count % g->n_users != 0) GRP_FAIL(g, CMI_E_INVALID, "group_set_state: container %d: %lld elements is not a multiple of %d users", which, (long long)count, g->n_users);
+    const int64_t cols = count / g->n_users;
+    for (int s = 0; s < W; ++s) {
+        const int64_t lo = g->cut[(size_t)s], hi = g->cut[(size_t)s + 1];
+        GRP_MEMBER(g, s, cmi_set_state(g->inst[(size_t)s], which, (const char *)src + (size_t)(lo * cols) * es, (hi - lo) * cols, dtype));
+    }
+    return CMI_OK;
+}
+
+extern "C" int cmi_group_get_state(cmi_group_handle g, int which, void *dst, int64_t count, int dtype) {
+    if (!g || !dst) return CMI_E_INVALID;
+    if (int rc = need_ratings(g, "group_get_state")) return rc;
+    const int W = (int)g->inst.size();
+    const size_t es = dtype == CMI_DTYPE_F64 ? 8 : 4;
+    if (!user_side(which)) { // replicated: every shard holds the merged value
+        GRP_MEMBER(g, 0, cmi_get_state(g->inst[0], which, dst, count, dtype));
+        return CMI_OK;
+    }
+    if (count % g->n_users != 0) GRP_FAIL(g, CMI_E_INVALID, "group_get_state: container %d: %lld elements is not a multiple of %d users", which, (long long)count, g->n_users);
+    const int64_t cols = count / g->n_users;
+    for (int s = 0; s < W; ++s) {
+        const int64_t lo = g->cut[(size_t)s], hi = g->cut[(size_t)s + 1];
+        GRP_MEMBER(g, s, cmi_get_state(g->inst[(size_t)s], which, (char *)dst + (size_t)(lo * cols) * es, (hi - lo) * cols, dtype));
+    }
+    return CMI_OK;
+}
+
+// the epoch-boundary merge of the item-side containers + the global loss; everything enqueued on the shards' streams
+static int group_exchange(cmi_group *g) {
+    const int W = (int)g->inst.size();
+    const size_t es = g->f64 ? 8 : 4;
+    std::vector<hipStream_t> st((size_t)W);
+    std::vector<double *> dl((size_t)W);
+    for (int s = 0; s < W; ++s) {
+        GRP_MEMBER(g, s, cmi_exchange_pack(g->inst[(size_t)s]));
+        GRP_MEMBER(g, s, cmi_stream(g->inst[(size_t)s], (void **)&st[(size_t)s]));
+        GRP_MEMBER(g, s, cmi_loss_device_ptr(g->inst[(size_t)s], (void **)&dl[(size_t)s]));
+    }
+    if (g->rccl) {
+        // xGMI is point to point: reduce-scatter + all-gather moves 2 x S/W per link pair on the fully connected mesh where a ring
+        // all-reduce is bound by one link; in place: shard s's slice of its own bucket is the reduce-scatter output and the
+        // all-gather input
+        const size_t chunk = (size_t)(g->x_count / W);
+        const ncclDataType_t dt = g->f64 ? ncclDouble : ncclFloat;
+        const bool allreduce = getenv("CMI_DIST_ALLREDUCE") != nullptr;
+        if (allreduce) {
+            GRP_NCCL(g, ncclGroupStart());
+            for (int s = 0; s < W; ++s) GRP_NCCL(g, ncclAllReduce(g->bucket[(size_t)s], g->bucket[(size_t)s], (size_t)g->x_count, dt, ncclSum, g->comm[(size_t)s], st[(size_t)s]));
+            GRP_NCCL(g, ncclGroupEnd());
+        } else {
+            GRP_NCCL(g, ncclGroupStart());
+            for (int s = 0; s < W; ++s)
+                GRP_NCCL(g, ncclReduceScatter(g->bucket[(size_t)s], (char *)g->bucket[(size_t)s] + (size_t)s * chunk * es, chunk, dt, ncclSum, g->comm[(size_t)s], st[(size_t)s]));
+            GRP_NCCL(g, ncclGroupEnd());
+            GRP_NCCL(g, ncclGroupStart());
+            for (int s = 0; s < W; ++s)
+                GRP_NCCL(g, ncclAllGather((char *)g->bucket[(size_t)s] + (size_t)s * chunk * es, g->bucket[(size_t)s], chunk, dt, g->comm[(size_t)s], st[(size_t)s]));
+            GRP_NCCL(g, ncclGroupEnd());
+        }
+        GRP_NCCL(g, ncclGroupStart());
+        for (int s = 0; s < W; ++s) GRP_NCCL(g, ncclAllReduce(dl[(size_t)s], dl[(size_t)s], 1, ncclDouble, ncclSum, g->comm[(size_t)s], st[(size_t)s]));
+        GRP_NCCL(g, ncclGroupEnd());
+    } else {
+        // in-process: shard 0's stream waits for every shard's pack, sums the buckets (and the losses) in shard order, the others copy
+        // the sums back on their own streams
+        for (int s = 1; s < W; ++s) {
+            GRP_HIP(g, hipSetDevice(g->dev[(size_t)s]));
+            GRP_HIP(g, hipEventRecord(g->ev[(size_t)s], st[(size_t)s]));
+        }
+        GRP_HIP(g, hipSetDevice(g->dev[0]));
+        double *stage_loss = (double *)((char *)g->d_stage + (size_t)g->x_count * es);
+        for (int s = 1; s < W; ++s) {
+            GRP_HIP(g, hipStreamWaitEvent(st[0], g->ev[(size_t)s], 0));
+            const void *src = g->bucket[(size_t)s];
+            if (g->dev[(size_t)s] != g->dev[0]) {
+                GRP_HIP(g, hipMemcpyPeerAsync(g->d_stage, g->dev[0], g->bucket[(size_t)s], g->dev[(size_t)s], (size_t)g->x_count * es, st[0]));
+                GRP_HIP(g, hipMemcpyPeerAsync(stage_loss, g->dev[0], dl[(size_t)s], g->dev[(size_t)s], 8, st[0]));
+                src = g->d_stage;
+                GRP_HIP(g, group_add(dl[0], stage_loss, 1, true, st[0]));
+            } else {
+                GRP_HIP(g, group_add(dl[0], dl[(size_t)s], 1, true, st[0]));
+            }
+            GRP_HIP(g, group_add(g->bucket[0], src, g->x_count, g->f64, st[0]));
+        }
+        GRP_HIP(g, hipEventRecord(g->ev[(size_t)W], st[0]));
+        for (int s = 1; s < W; ++s) {
+            GRP_HIP(g, hipSetDevice(g->dev[(size_t)s]));
+            GRP_HIP(g, hipStreamWaitEvent(st[(size_t)s], g->ev[(size_t)W], 0));
+            GRP_HIP(g, hipMemcpyPeerAsync(g->bucket[(size_t)s], g->dev[(size_t)s], g->bucket[0], g->dev[0], (size_t)g->x_count * es, st[(size_t)s]));
+            GRP_HIP(g, hipMemcpyPeerAsync(dl[(size_t)s], g->dev[(size_t)s], dl[0], g->dev[0], 8, st[(size_t)s]));
+            GRP_HIP(g, hipEventRecord(g->ev[(size_t)s], st[(size_t)s])); // shard 0 must not start its next pack before the copies have read bucket 0
+        }
+        GRP_HIP(g, hipSetDevice(g->dev[0]));
+        for (int s = 1; s < W; ++s) GRP_HIP(g, hipStreamWaitEvent(st[0], g->ev[(size_t)s], 0));
+    }
+    for (int s = 0; s < W; ++s) GRP_MEMBER(g, s, cmi_exchange_apply(g->inst[(size_t)s], 1.0 / W));
+    return CMI_OK;
+}
+
+extern "C" int cmi_group_train_epoch(cmi_group_handle g, double lrate, double *loss_out) {
+    if (!g) return CMI_E_INVALID;
+    if (int rc = need_ratings(g, "group_train_epoch")) return rc;
+    const int W = (int)g->inst.size();
+    for (int s = 0; s < W; ++s) GRP_MEMBER(g, s, cmi_train_epoch_async(g->inst[(size_t)s], lrate));
+    if (W > 1)
+        if (int rc = group_exchange(g)) return rc;
+    // the one host synchronisation of the epoch: the (already global) loss of shard 0, then the other shards' streams
+    double loss = 0.0, other = 0.0;
+    GRP_MEMBER(g, 0, cmi_last_loss(g->inst[0], &loss));
+    for (int s = 1; s < W; ++s) GRP_MEMBER(g, s, cmi_last_loss(g->inst[(size_t)s], &other)); // also surfaces a stalled owner epoch of that shard
+    if (loss_out) *loss_out = loss;
+    return CMI_OK;
+}
+
+extern "C" int cmi_group_train_from(cmi_group_handle g, int first_iter, double prev_loss, int num_iters, double init_lrate, double max_lrate,
+                                    int bold_driver, double decay, int early_stop, double *losses, double *lrates, int *iters_run,
+                                    double *final_lrate) {
+    if (!g) return CMI_E_INVALID;
+    std::string err;
+    const int rc = cmi_train_loop([g](double lr, double *loss) { return cmi_group_train_epoch(g, lr, loss); }, err, first_iter, prev_loss, num_iters,
+                                  init_lrate, max_lrate, bold_driver, decay, early_stop, losses, lrates, iters_run, final_lrate);
+    if (rc != CMI_OK && !err.empty()) g->err = err;
+    return rc;
+}
+
+extern "C" int cmi_group_train(cmi_group_handle g, int num_iters, double init_lrate, double max_lrate, int bold_driver, double decay,
+                               int early_stop, double *losses, double *lrates, int *iters_run, double *final_lrate) {
+    return cmi_group_train_from(g, 1, 0.0, num_iters, init_lrate, max_lrate, bold_driver, decay, early_stop, losses, lrates, iters_run, final_lrate);
+}
+
+// test tuples go to the shard that owns their user
+struct Routed {
+    std::vector<std::vector<int32_t>> u, j, c;
+    std::vector<std::vector<double>> r;
+    std::vector<std::vector<int64_t>> pos;
+};
+static int route(cmi_group *g, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r, Routed &o) {
+    const size_t W = g->inst.size();
+    o.u.assign(W, {}), o.j.assign(W, {}), o.c.assign(W, {}), o.r.assign(W, {}), o.pos.assign(W, {});
+    for (int64_t t = 0; t < n; ++t) {
+        if (u[t] < 0 || u[t] >= g->n_users) GRP_FAIL(g, CMI_E_INVALID, "eval: user id %d out of range at tuple %lld", u[t], (long long)t);
+        const size_t s = (size_t)shard_of(g->cut, u[t]);
+        o.u[s].push_back(u[t] - g->cut[s]);
+        o.j[s].push_back(j[t]);
+        if (ctx) o.c[s].push_back(ctx[t]);
+        if (r) o.r[s].push_back(r[t]);
+        o.pos[s].push_back(t);
+    }
+    return CMI_OK;
+}
+
+extern "C" int cmi_group_eval_ratings(cmi_group_handle g, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r,
+                                      double min_rate, double max_rate, double *out, int64_t *count) {
+    if (!g || !out) return CMI_E_INVALID;
+    if (int rc = need_ratings(g, "group_eval_ratings")) return rc;
+    if (n < 0 || (n > 0 && (!u || !j || !r))) GRP_FAIL(g, CMI_E_INVALID, "group_eval_ratings: null argument");
+    Routed ro;
+    if (int rc = route(g, n, u, j, ctx, r, ro)) return rc;
+    double tot[5] = {0, 0, 0, 0, 0};
+    for (size_t s = 0; s < g->inst.size(); ++s) {
+        double sums[5];
+        const int64_t m = (int64_t)ro.u[s].size();
+        GRP_MEMBER(g, s, cmi_eval_sums(g->inst[s], m, ro.u[s].data(), ro.j[s].data(), ctx ? ro.c[s].data() : nullptr, ro.r[s].data(), min_rate, max_rate, sums));
+        for (int c = 0; c < 5; ++c) tot[c] += sums[c];
+    }
+    const double cnt = tot[4], mae = tot[0] / cnt;
+    out[0] = mae;
+    out[1] = std::sqrt(tot[1] / cnt);
+    out[2] = mae / (max_rate - min_rate);
+    out[3] = tot[2] / cnt;
+    out[4] = std::sqrt(tot[3] / cnt);
+    if (count) *count = (int64_t)cnt;
+    return CMI_OK;
+}
+
+extern "C" int cmi_group_predict_batch(cmi_group_handle g, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, int bound, double lo,
+                                       double hi, double *out) {
+    if (!g || !out) return CMI_E_INVALID;
+    if (int rc = need_ratings(g, "group_predict_batch")) return rc;
+    if (n < 0 || (n > 0 && (!u || !j))) GRP_FAIL(g, CMI_E_INVALID, "group_predict_batch: null argument");
+    Routed ro;
+    if (int rc = route(g, n, u, j, ctx, nullptr, ro)) return rc;
+    std::vector<double> tmp;
+    for (size_t s = 0; s < g->inst.size(); ++s) {
+        const int64_t m = (int64_t)ro.u[s].size();
+        if (m == 0) continue;
+        tmp.resize((size_t)m);
+        GRP_MEMBER(g, s, cmi_predict_batch(g->inst[s], m, ro.u[s].data(), ro.j[s].data(), ctx ? ro.c[s].data() : nullptr, bound, lo, hi, tmp.data()));
+        for (int64_t q = 0; q < m; ++q) out[ro.pos[s][(size_t)q]] = tmp[(size_t)q];
+    }
+    return CMI_OK;
+}
+
+extern "C" int cmi_group_shard_info(cmi_group_handle g, int shard, int64_t info[6]) {
+    if (!g || !info) return CMI_E_INVALID;
+    if (int rc = need_ratings(g, "group_shard_info")) return rc;
+    if (shard < 0 || shard >= (int)g->inst.size()) GRP_FAIL(g, CMI_E_INVALID, "group_shard_info: shard %d out of range", shard);
+    info[0] = g->cut[(size_t)shard];
+    info[1] = g->cut[(size_t)shard + 1];
+    info[2] = g->shard_n[(size_t)shard];
+    info[3] = g->dev[(size_t)shard];
+    info[4] = g->inst.size() > 1 ? (g->rccl ? 1 : 2) : 0; // exchange: 0 none (one shard), 1 RCCL, 2 in-process
+    info[5] = g->x_count;
+    return CMI_OK;
+}
+
+extern "C" int cmi_group_member(cmi_group_handle g, int shard, cmi_handle *out) {
+    if (!g || !out) return CMI_E_INVALID;
+    if (int rc = need_ratings(g, "group_member")) return rc;
+    if (shard < 0 || shard >= (int)g->inst.size()) GRP_FAIL(g, CMI_E_INVALID, "group_member: shard %d out of range", shard);
+    *out = g->inst[(size_t)shard];
+    return CMI_OK;
+}

@@ -291,6 +291,50 @@ int cmi_schedule_traffic(cmi_handle h, int64_t out[4]);
 /* GPU time of the most recent epoch's kernels measured with HIP events on cmi_stream() */
 int cmi_last_epoch_ms(cmi_handle h, float *ms);
 
+/* ---- one recommender over several GPUs from ONE host process (carskit_amd/csrc/group_api.cpp) -------------------------------
+ * The reference trains one fold on one thread (CARSKit.java:395-412 is its only parallelism: a thread per fold) -- there is no
+ * counterpart to translate.  SURVEY 8b's `device_mask` entry, as a handle of its own: ratings are sharded BY USER over n_shards
+ * instances (contiguous user ranges holding about n / n_shards tuples each; user-side containers P, userBias, ucBias live on
+ * exactly one shard), the item-side containers (Q, itemBias, icBias) are replicated and merged after every epoch:
+ *     item_side = snapshot + (sum over shards of (item_side_shard - snapshot)) / n_shards        (the MEAN of the shards' moves)
+ * through ncclReduceScatter + ncclAllGather over xGMI on the shards' own streams (librccl, one communicator per shard, grouped
+ * calls), and the fp64 epoch losses are all-reduced, so cmi_group_train_epoch returns the GLOBAL loss and the unchanged host-side
+ * isConverged()/updateLRate() keeps steering.  Shards that share a device (or CMI_GROUP_NO_RCCL=1) use an in-process exchange
+ * (sum in shard order on shard 0's stream) instead -- same arithmetic.  n_shards = 1 is exactly the single-instance path.
+ * With n_shards > 1 this is NOT the reference's sequential semantics (n_shards local SGD streams merged per epoch): accuracy is
+ * reported as a band against the 1-GPU result.  CAMF_C / SVD++ / CAMF_*CS are serial chains: 1 shard only.
+ * Call order: create, set_hparams, set_ratings (creates the instances: their user counts depend on the cut), set_state, train.
+ * devices: n_shards device indices (may repeat), or NULL = round robin over the visible devices. */
+typedef struct cmi_group *cmi_group_handle;
+int cmi_group_create(int model, int k, int n_users, int n_items, int n_conds, int n_shards, const int *devices, unsigned flags,
+                     cmi_group_handle *out);
+int cmi_group_destroy(cmi_group_handle g);
+const char *cmi_group_last_error(cmi_group_handle g);
+int cmi_group_size(cmi_group_handle g);
+int cmi_group_set_hparams(cmi_group_handle g, double regU, double regI, double regB, double regC, double global_mean);
+/* the WHOLE training matrix, as for cmi_set_ratings; the library cuts it by user */
+int cmi_group_set_ratings(cmi_group_handle g, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r,
+                          int32_t n_ctx, const int32_t *ctx_ptr, const int32_t *ctx_conds);
+/* whole containers in the reference's shapes (count = rows * cols over ALL users / items): user-side ones are scattered to /
+ * gathered from the owning shards, item-side ones are replicated / read from shard 0 */
+int cmi_group_set_state(cmi_group_handle g, int which, const void *src, int64_t count, int dtype);
+int cmi_group_get_state(cmi_group_handle g, int which, void *dst, int64_t count, int dtype);
+int cmi_group_train_epoch(cmi_group_handle g, double lrate, double *loss_out);
+int cmi_group_train(cmi_group_handle g, int num_iters, double init_lrate, double max_lrate, int bold_driver, double decay, int early_stop,
+                    double *losses, double *lrates, int *iters_run, double *final_lrate);
+int cmi_group_train_from(cmi_group_handle g, int first_iter, double prev_loss, int num_iters, double init_lrate, double max_lrate,
+                         int bold_driver, double decay, int early_stop, double *losses, double *lrates, int *iters_run, double *final_lrate);
+/* test tuples are routed to the shard that owns their user; the error sums are merged exactly */
+int cmi_group_eval_ratings(cmi_group_handle g, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r,
+                           double min_rate, double max_rate, double *out, int64_t *count);
+int cmi_group_predict_batch(cmi_group_handle g, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, int bound, double lo,
+                            double hi, double *out);
+/* info[0..1] = [first, last) user of the shard, info[2] = its tuples, info[3] = its device, info[4] = exchange in use (0 none: one
+ * shard, 1 RCCL, 2 in-process), info[5] = elements of the exchanged bucket */
+int cmi_group_shard_info(cmi_group_handle g, int shard, int64_t info[6]);
+/* the shard's instance (owned by the group), e.g. for cmi_schedule_info / cmi_last_epoch_ms */
+int cmi_group_member(cmi_group_handle g, int shard, cmi_handle *out);
+
 /* ---- FM: src/carskit/alg/cars/adaptation/dependent/FM.java (ALS / coordinate-descent sweep, not SGD) ---------
  * Separate handle type: the state is (w0, w[p], V[p x k]) with p = numUsers+numItems+numConditions
  * (FM.java:57-74) plus the per-rating errors[] and Q[][] of buildModel() (FM.java:117-146).  fp64 on the

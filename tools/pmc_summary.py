@@ -21,12 +21,18 @@ def main():
                          us=float((k.End_Timestamp - k.Start_Timestamp).mean() / 1e3))
     fetch_b = res["fetch"]["kb"] * 1024 * 2      # gfx950: FETCH_SIZE tallies 16 B/lane coalesced reads at half (MI355X_MICROARCH.md, HBM)
     write_b = res["write"]["kb"] * 1024          # WRITE_SIZE taken as is (uncalibrated)
-    alg = float(roof["bytes_per_launch"])
+    if "bytes_per_update_algorithmic" in roof:   # round 3 lines: bytes_per_launch is the schedule-derived figure
+        tuples = roof["bytes_per_epoch"] / roof["bytes_per_update"]
+        alg = float(roof["bytes_per_update_algorithmic"]) * tuples / roof["launches_per_epoch"]
+        model_b = float(roof["bytes_per_launch"])
+    else:
+        alg, model_b = float(roof["bytes_per_launch"]), None
     rec = {"kernel": kern, "schedule": roof.get("schedule", "level"), "workload": bench["config"]["workload"],
            "launches_profiled": res["fetch"]["launches"], "launches_per_epoch": roof["launches_per_epoch"],
            "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
            "hbm_bytes_per_launch": fetch_b + write_b, "algorithmic_bytes_per_launch": alg,
            "traffic_over_algorithmic": (fetch_b + write_b) / alg,
+           "schedule_model_bytes_per_launch": model_b, "traffic_over_schedule_model": ((fetch_b + write_b) / model_b) if model_b else None,
            "profiled_launch_us": 0.5 * (res["fetch"]["us"] + res["write"]["us"]),
            "real_traffic_GBps_profiled": (fetch_b + write_b) / (0.5 * (res["fetch"]["us"] + res["write"]["us"])) / 1e3,
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace; "
