@@ -53,16 +53,17 @@ public class BiasedMF_GPU extends BiasedMF implements GpuHost {
         loss = epochLoss;
         return isConverged(iter);      // unchanged reference code: IterativeRecommender.java:145-199
     }
+    public void prepare(long h) {}
     public void copyIn(long h) {
-        NativeMF.setMatrix(h, NativeMF.P, Rows.of(P));
-        NativeMF.setMatrix(h, NativeMF.Q, Rows.of(Q));
-        NativeMF.setVector(h, NativeMF.USER_BIAS, userBias.getData());
-        NativeMF.setVector(h, NativeMF.ITEM_BIAS, itemBias.getData());
+        Dev.setMatrix(h, NativeMF.P, Rows.of(P));
+        Dev.setMatrix(h, NativeMF.Q, Rows.of(Q));
+        Dev.setVector(h, NativeMF.USER_BIAS, userBias.getData());
+        Dev.setVector(h, NativeMF.ITEM_BIAS, itemBias.getData());
     }
     public void copyOut(long h) {
-        NativeMF.getMatrix(h, NativeMF.P, Rows.of(P));
-        NativeMF.getMatrix(h, NativeMF.Q, Rows.of(Q));
-        NativeMF.getVector(h, NativeMF.USER_BIAS, userBias.getData());
-        NativeMF.getVector(h, NativeMF.ITEM_BIAS, itemBias.getData());
+        Dev.getMatrix(h, NativeMF.P, Rows.of(P));
+        Dev.getMatrix(h, NativeMF.Q, Rows.of(Q));
+        Dev.getVector(h, NativeMF.USER_BIAS, userBias.getData());
+        Dev.getVector(h, NativeMF.ITEM_BIAS, itemBias.getData());
     }
 }

@@ -53,15 +53,16 @@ public class CAMF_CUCI_GPU extends CAMF_CUCI implements GpuHost {
         loss = epochLoss;
         return isConverged(iter);      // unchanged reference code: IterativeRecommender.java:145-199
     }
+    public void prepare(long h) {}
     public void copyIn(long h) {
-        NativeMF.setMatrix(h, NativeMF.P, Rows.of(P));
-        NativeMF.setMatrix(h, NativeMF.Q, Rows.of(Q));
-        NativeMF.setMatrix(h, NativeMF.UC_BIAS, Rows.ofTable(ucBias, numUsers, numConditions));
-        NativeMF.setMatrix(h, NativeMF.IC_BIAS, Rows.ofTable(icBias, numItems, numConditions));
+        Dev.setMatrix(h, NativeMF.P, Rows.of(P));
+        Dev.setMatrix(h, NativeMF.Q, Rows.of(Q));
+        Dev.setMatrix(h, NativeMF.UC_BIAS, Rows.ofTable(ucBias, numUsers, numConditions));
+        Dev.setMatrix(h, NativeMF.IC_BIAS, Rows.ofTable(icBias, numItems, numConditions));
     }
     public void copyOut(long h) {
-        NativeMF.getMatrix(h, NativeMF.P, Rows.of(P));
-        NativeMF.getMatrix(h, NativeMF.Q, Rows.of(Q));
+        Dev.getMatrix(h, NativeMF.P, Rows.of(P));
+        Dev.getMatrix(h, NativeMF.Q, Rows.of(Q));
         Rows.intoTable(ucBias, Rows.fetch(h, NativeMF.UC_BIAS, numUsers, numConditions));
         Rows.intoTable(icBias, Rows.fetch(h, NativeMF.IC_BIAS, numItems, numConditions));
     }

@@ -26,7 +26,8 @@ interface GpuHost {
     int iterations();                    // numIters
     double learnRate();                  // lRate, re-read every epoch: isConverged() -> updateLRate() changes it
     boolean evaluatesDuringTraining();   // earlyStopMeasure is MAE / RMSE / ...: isConverged() calls evalRatings() per epoch
-    void copyIn(long h);                 // NativeMF.setMatrix / setVector of the containers this model owns
+    void prepare(long h);                // calls that must precede the ratings (CAMF_ICS/LCS/MCS: NativeMF.setSimParams); usually empty
+    void copyIn(long h);                 // Dev.setMatrix / setVector of the containers this model owns
     void copyOut(long h);                // ... and back
     void handle(long h);                 // the live native handle (0 outside buildModel); evalRatings() consults it
     boolean epochDone(int iter, double epochLoss) throws Exception; // { loss = epochLoss; return isConverged(iter); }

@@ -60,14 +60,25 @@ final class GpuSupport {
         return new Object[] {u, j, ctx, r};
     }
 
+    /** -Dcarskit.shards=N: ONE recommender trained over N GPUs (ratings cut by user inside the library, item-side containers merged
+     *  over RCCL after every epoch: cmi_group_*).  Default 1 = the single-GPU order-exact path.  Not the same thing as
+     *  -Dcarskit.gpus (folds -> GPUs, the reference's own parallelism, CARSKit.java:395-412). */
+    static int shards() { return Math.max(1, Integer.getInteger("carskit.shards", 1)); }
+
     /** The replacement of the reference's buildModel(): upload once, run the epoch loop with the UNCHANGED Java isConverged()
      *  (bold driver, decay, early stop, NaN exit: IterativeRecommender.java:145-229), copy the model back. */
     static void buildModel(GpuHost r) throws Exception {
-        boolean twoD = r.modelId() == NativeMF.BIASEDMF || r.modelId() == NativeMF.PMF;
+        boolean serialChain = (r.createFlags() & NativeMF.FLAG_SCHED_SERIAL) != 0;   // CAMF_C, SVD++, CAMF_ICS/LCS/MCS: not sharded
+        if (shards() > 1 && !serialChain) {
+            buildModelSharded(r, shards());
+            return;
+        }
+        boolean twoD = r.modelId() == NativeMF.BIASEDMF || r.modelId() == NativeMF.PMF || r.modelId() == NativeMF.SVDPP;
         long h = NativeMF.create(r.modelId(), r.factors(), r.users(), r.items(), r.conditions(), deviceFor(r.foldId()), r.createFlags());
         try {
             DataDAO dao = Recommender.rateDao;
             SparseMatrix tm = r.contextualTrain();
+            r.prepare(h);
             if (twoD) {
                 librec.data.SparseMatrix t2 = r.train2D();
                 NativeMF.setRatings2D(h, t2.getRowPointers(), t2.getColumnIndices(), t2.getData());
@@ -94,6 +105,38 @@ final class GpuSupport {
         } finally {
             r.handle(0L);
             NativeMF.destroy(h);
+        }
+    }
+
+    /** The same flow over a cmi_group: the library shards the CSR arrays by user, every epoch returns the GLOBAL loss, so the
+     *  unchanged isConverged() steers all shards.  `--early-stop MAE|RMSE` would need the live model per epoch on the host side:
+     *  not wired for groups (use --early-stop loss, or one GPU). */
+    static void buildModelSharded(GpuHost r, int nShards) throws Exception {
+        if (r.evaluatesDuringTraining())
+            throw new UnsupportedOperationException("-Dcarskit.shards > 1 supports --early-stop loss only");
+        boolean twoD = r.modelId() == NativeMF.BIASEDMF || r.modelId() == NativeMF.PMF;
+        long g = NativeMF.groupCreate(r.modelId(), r.factors(), r.users(), r.items(), r.conditions(), nShards, null, r.createFlags());
+        try {
+            DataDAO dao = Recommender.rateDao;
+            SparseMatrix tm = r.contextualTrain();
+            double[] reg = r.regularizers();
+            NativeMF.groupSetHparams(g, reg[0], reg[1], reg[2], reg[3], r.mean());
+            if (twoD) {
+                librec.data.SparseMatrix t2 = r.train2D();
+                NativeMF.groupSetRatings2D(g, t2.getRowPointers(), t2.getColumnIndices(), t2.getData());
+            } else {
+                int[][] ui = pairMaps(dao, tm.numRows());
+                int[][] ct = contextTable(r, tm.numColumns());
+                NativeMF.groupSetRatingsCsr(g, tm.getRowPointers(), tm.getColumnIndices(), tm.getData(), ui[0], ui[1], ct[0], ct[1]);
+            }
+            r.copyIn(Dev.ofGroup(g));
+            for (int iter = 1; iter <= r.iterations(); iter++) {
+                double loss = NativeMF.groupTrainEpoch(g, r.learnRate());
+                if (r.epochDone(iter, loss)) break;
+            }
+            r.copyOut(Dev.ofGroup(g));
+        } finally {
+            NativeMF.groupDestroy(g);
         }
     }
 

@@ -11,7 +11,11 @@ public final class NativeMF {
     private NativeMF() {}
 
     public static final int BIASEDMF = 0, CAMF_C = 1, CAMF_CI = 2, CAMF_CU = 3, CAMF_CUCI = 4, PMF = 5;
+    /** the remaining SGD recommenders of the family (CARSKit.java:469,708-712): serial chains, FLAG_SCHED_SERIAL required */
+    public static final int SVDPP = 6, CAMF_ICS = 7, CAMF_LCS = 8, CAMF_MCS = 9;
     public static final int P = 0, Q = 1, USER_BIAS = 2, ITEM_BIAS = 3, COND_BIAS = 4, UC_BIAS = 5, IC_BIAS = 6;
+    /** SVD++ Y (numItems x k); ccMatrix_ICS as the full symmetric matrix; cfMatrix_LCS (numConditions x numF); cVector_MCS */
+    public static final int Y = 7, CC_MATRIX = 8, CF_MATRIX = 9, C_VECTOR = 10;
     public static final int FLAG_STATE_F64 = 1, FLAG_SCHED_SERIAL = 2, FLAG_STRICT = 4, FLAG_NO_GRAPH = 16;
     /** schedule overrides (include/carskit_mi355x.h); the library picks hub-chain levels / the owner epoch / plain levels by itself */
     public static final int FLAG_SCHED_CHAIN = 0x80, FLAG_NO_CHAIN = 0x100, FLAG_SCHED_OWNER = 0x200, FLAG_NO_OWNER = 0x400;
@@ -55,6 +59,29 @@ public final class NativeMF {
     public static native void saveModel(long h, String path, double lRate, double lastLoss, int epochsDone);
     /** returns {lRate, lastLoss, epochsDone} as stored with the model */
     public static native double[] loadModel(long h, String path);
+
+    /** cmi_set_sim_params: EmptyContextConditions (ContextRecommender.java:43), `-f` of CAMF_LCS (CAMF_LCS.java:37) and
+     *  rateDao.numContextDims() (CAMF_MCS.java:44); call before setRatingsCsr for CAMF_ICS / LCS / MCS. */
+    public static native void setSimParams(long h, int numF, int nCtxDims, int[] emptyConds);
+
+    // ---- one recommender sharded by user over several GPUs (cmi_group_*; -Dcarskit.shards=N) ---------------------------
+    /** cmi_group_create: devices = one index per shard, or null for round robin over the visible GPUs. */
+    public static native long groupCreate(int model, int k, int nUsers, int nItems, int nConds, int nShards, int[] devices, int flags);
+    public static native void groupDestroy(long g);
+    public static native void groupSetHparams(long g, double regU, double regI, double regB, double regC, double globalMean);
+    /** the WHOLE training matrix, as setRatingsCsr / setRatings2D; the library cuts it by user */
+    public static native void groupSetRatingsCsr(long g, int[] rowPtr, int[] colInd, double[] data, int[] uiUser, int[] uiItem,
+                                                 int[] ctxPtr, int[] ctxConds);
+    public static native void groupSetRatings2D(long g, int[] rowPtr, int[] colInd, double[] data);
+    /** whole containers: user-side ones are scattered to / gathered from the owning shards, item-side ones replicated */
+    public static native void groupSetMatrix(long g, int which, double[][] rows);
+    public static native void groupGetMatrix(long g, int which, double[][] rows);
+    public static native void groupSetVector(long g, int which, double[] v);
+    public static native void groupGetVector(long g, int which, double[] v);
+    /** cmi_group_train_epoch: every shard's local pass + the merge of the item-side moves; returns the GLOBAL loss */
+    public static native double groupTrainEpoch(long g, double lRate);
+    /** cmi_group_eval_ratings: {MAE, RMSE, NMAE, rMAE, rRMSE, count}, test tuples routed to the shard that owns their user */
+    public static native double[] groupEvalRatings(long g, int[] u, int[] j, int[] ctx, double[] r, double minRate, double maxRate);
 
     // ---- FM (src/carskit/alg/cars/adaptation/dependent/FM.java) --------------------------------------------------
     public static native long fmCreate(int k, int nUsers, int nItems, int nConds, int nCtxDims, int device, int flags);

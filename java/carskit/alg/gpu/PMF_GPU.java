@@ -53,12 +53,13 @@ public class PMF_GPU extends PMF implements GpuHost {
         loss = epochLoss;
         return isConverged(iter);      // unchanged reference code: IterativeRecommender.java:145-199
     }
+    public void prepare(long h) {}
     public void copyIn(long h) {
-        NativeMF.setMatrix(h, NativeMF.P, Rows.of(P));
-        NativeMF.setMatrix(h, NativeMF.Q, Rows.of(Q));
+        Dev.setMatrix(h, NativeMF.P, Rows.of(P));
+        Dev.setMatrix(h, NativeMF.Q, Rows.of(Q));
     }
     public void copyOut(long h) {
-        NativeMF.getMatrix(h, NativeMF.P, Rows.of(P));
-        NativeMF.getMatrix(h, NativeMF.Q, Rows.of(Q));
+        Dev.getMatrix(h, NativeMF.P, Rows.of(P));
+        Dev.getMatrix(h, NativeMF.Q, Rows.of(Q));
     }
 }

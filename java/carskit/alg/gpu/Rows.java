@@ -5,6 +5,7 @@ package carskit.alg.gpu;
 
 import com.google.common.collect.Table;
 import librec.data.DenseMatrix;
+import librec.data.SymmMatrix;
 
 final class Rows {
     private Rows() {}
@@ -25,10 +26,23 @@ final class Rows {
         return rows;
     }
 
+    /** ccMatrix_ICS (librec SymmMatrix, CAMF.java:45) as the full symmetric dense image the C ABI exchanges */
+    static double[][] ofSymm(SymmMatrix m, int dim) {
+        double[][] rows = new double[dim][dim];
+        for (int i = 0; i < dim; i++)
+            for (int j = 0; j < dim; j++) rows[i][j] = m.get(i, j);
+        return rows;
+    }
+
+    static void intoSymm(SymmMatrix m, double[][] rows) {
+        for (int i = 0; i < rows.length; i++)
+            for (int j = i; j < rows.length; j++) m.set(i, j, rows[i][j]);
+    }
+
     /** cmi_get_state into a fresh dense image (for containers that are not double[][] on the Java side) */
     static double[][] fetch(long h, int which, int numRows, int numCols) {
         double[][] rows = new double[numRows][numCols];
-        NativeMF.getMatrix(h, which, rows);
+        Dev.getMatrix(h, which, rows);
         return rows;
     }
 

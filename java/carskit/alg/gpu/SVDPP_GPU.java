@@ -1,26 +1,28 @@
-// CAMF_CI_GPU.java -- drop-in for carskit.alg.cars.adaptation.dependent.dev.CAMF_CI: identical constructor, initModel() and predict()
-// (inherited); buildModel() runs on the GPU through GpuSupport.buildModel, evalRatings() reads the device model while training
-// is in progress (so `--early-stop MAE|RMSE` sees the live model, IterativeRecommender.java:156-161).  Registered in the reference's
-// factory switch next to "camf_ci" (src/carskit/main/CARSKit.java:702) as "camf_ci_gpu".
+// SVDPP_GPU.java -- drop-in for carskit.alg.baseline.cf.SVDPlusPlus: identical constructor, initModel() and predict() (inherited);
+// buildModel() runs on the GPU through GpuSupport.buildModel.  Every rating of this model updates parameters that every
+// other rating reads, so its exact semantics are ONE dependent chain in CRS order: the library requires FLAG_SCHED_SERIAL and replays
+// the reference's operation sequence (bit-identical to the Java arithmetic with FLAG_STATE_F64 | FLAG_STRICT); a GPU is the wrong
+// machine for such a chain -- the class exists so that the name resolves to the same library with the same parity guarantees.
+// Registered in the reference's factory switch next to "svd++" (src/carskit/main/CARSKit.java:469) as "svd++_gpu".
 // Source only (no JDK in this image): NOT compiled or run here; tests/test_java_binding_text.py checks the NativeMF calls as text.
 package carskit.alg.gpu;
 
-import carskit.alg.cars.adaptation.dependent.dev.CAMF_CI;
+import carskit.alg.baseline.cf.SVDPlusPlus;
 import carskit.data.structure.SparseMatrix;
 import java.util.List;
 import java.util.Map;
 
-public class CAMF_CI_GPU extends CAMF_CI implements GpuHost {
+public class SVDPP_GPU extends SVDPlusPlus implements GpuHost {
     private long gpuHandle = 0L;
 
-    public CAMF_CI_GPU(SparseMatrix trainMatrix, SparseMatrix testMatrix, int fold) {
+    public SVDPP_GPU(SparseMatrix trainMatrix, SparseMatrix testMatrix, int fold) {
         super(trainMatrix, testMatrix, fold);
-        this.algoName = "CAMF_CI_GPU";
+        this.algoName = "SVDPP_GPU";
     }
 
     @Override
     protected void buildModel() throws Exception {
-        GpuSupport.buildModel(this);   // replaces CAMF_CI.java:79-123
+        GpuSupport.buildModel(this);
     }
 
     @Override
@@ -30,17 +32,17 @@ public class CAMF_CI_GPU extends CAMF_CI implements GpuHost {
     }
 
     // ---- GpuHost: the protected members of the reference classes GpuSupport needs ----
-    public int modelId() { return NativeMF.CAMF_CI; }
-    public int createFlags() { return 0; }
+    public int modelId() { return NativeMF.SVDPP; }
+    public int createFlags() { return NativeMF.FLAG_SCHED_SERIAL | NativeMF.FLAG_STATE_F64 | NativeMF.FLAG_STRICT; }
     public int factors() { return numFactors; }
     public int users() { return numUsers; }
     public int items() { return numItems; }
-    public int conditions() { return numConditions; }
+    public int conditions() { return 0; }
     public int foldId() { return fold; }
     public SparseMatrix contextualTrain() { return trainMatrix; }
     public SparseMatrix contextualTest() { return testMatrix; }
     public librec.data.SparseMatrix train2D() { return train; }
-    public List<Integer> conditionsOf(int ctx) { return getConditions(ctx); }
+    public List<Integer> conditionsOf(int ctx) { return GpuSupport.none(); }
     public double[] regularizers() { return new double[] {regU, regI, regB, regC}; }
     public double mean() { return globalMean; }
     public double minRating() { return minRate; }
@@ -58,12 +60,14 @@ public class CAMF_CI_GPU extends CAMF_CI implements GpuHost {
         Dev.setMatrix(h, NativeMF.P, Rows.of(P));
         Dev.setMatrix(h, NativeMF.Q, Rows.of(Q));
         Dev.setVector(h, NativeMF.USER_BIAS, userBias.getData());
-        Dev.setMatrix(h, NativeMF.IC_BIAS, Rows.of(icBias));
+        Dev.setVector(h, NativeMF.ITEM_BIAS, itemBias.getData());
+        Dev.setMatrix(h, NativeMF.Y, Rows.of(Y));
     }
     public void copyOut(long h) {
         Dev.getMatrix(h, NativeMF.P, Rows.of(P));
         Dev.getMatrix(h, NativeMF.Q, Rows.of(Q));
         Dev.getVector(h, NativeMF.USER_BIAS, userBias.getData());
-        Dev.getMatrix(h, NativeMF.IC_BIAS, Rows.of(icBias));
+        Dev.getVector(h, NativeMF.ITEM_BIAS, itemBias.getData());
+        Dev.getMatrix(h, NativeMF.Y, Rows.of(Y));
     }
 }

@@ -3,9 +3,9 @@
 A single-GPU box runs a group of N shards on device 0 through the in-process exchange; it must equal, bit for bit, the same
 algorithm driven by hand over N separate capi.Instances with the library's own pack / apply kernels and a float32 sum of the buckets
 in shard order -- which is exactly what carskit_amd.dist.ShardedEpochRunner does with gloo's all-reduce at world size 2
-(tests/test_gpu_dist_two_ranks.py ties that runner to the host-side simulation).  RCCL itself is exercised at one shard per device,
-which on this box means a group of one with the exchange forced (CMI_GROUP_FORCE_RCCL has no meaning for one shard: the RCCL path
-with W > 1 needs W devices and is covered by the driver's multi-GPU run only).  Against the oracle: a group of ONE is the plain
+(tests/test_gpu_dist_two_ranks.py ties that runner to the host-side simulation).  The RCCL path (one shard per DEVICE,
+ncclCommInitAll refuses two ranks on one device) cannot run on a single-GPU box: it is the same pack / apply kernels around
+ncclReduceScatter + ncclAllGather and is exercised by multi-GPU runs only -- said plainly in DESIGN.md section 7.  Against the oracle: a group of ONE is the plain
 instance, i.e. the order-exact path; a group of N is N local order-exact passes merged, checked against N oracles merged the same
 way on the host."""
 import ctypes as C

@@ -85,7 +85,10 @@ def test_java_sources_use_only_existing_native_members_and_header_constants():
                          ("FLAG_SCHED_SERIAL", "CMI_FLAG_SCHED_SERIAL"), ("FLAG_STRICT", "CMI_FLAG_STRICT"),
                          ("FLAG_NO_GRAPH", "CMI_FLAG_NO_GRAPH"), ("FLAG_SCHED_CHAIN", "CMI_FLAG_SCHED_CHAIN"),
                          ("FLAG_NO_CHAIN", "CMI_FLAG_NO_CHAIN"), ("FLAG_SCHED_OWNER", "CMI_FLAG_SCHED_OWNER"),
-                         ("FLAG_NO_OWNER", "CMI_FLAG_NO_OWNER"), ("RANK_UCU", "CMI_RANK_UCU"), ("RANK_UC", "CMI_RANK_UC")]:
+                         ("FLAG_NO_OWNER", "CMI_FLAG_NO_OWNER"), ("RANK_UCU", "CMI_RANK_UCU"), ("RANK_UC", "CMI_RANK_UC"),
+                         ("SVDPP", "CMI_MODEL_SVDPP"), ("CAMF_ICS", "CMI_MODEL_CAMF_ICS"), ("CAMF_LCS", "CMI_MODEL_CAMF_LCS"),
+                         ("CAMF_MCS", "CMI_MODEL_CAMF_MCS"), ("Y", "CMI_STATE_Y"), ("CC_MATRIX", "CMI_STATE_CC_MATRIX"),
+                         ("CF_MATRIX", "CMI_STATE_CF_MATRIX"), ("C_VECTOR", "CMI_STATE_C_VECTOR")]:
         assert consts[jname] == hconst[hname], (jname, hname)
     used = set()
     for f in os.listdir(JAVA_DIR):
@@ -101,7 +104,39 @@ def test_java_sources_use_only_existing_native_members_and_header_constants():
 
 
 FACTORY = {"biasedmf": "BiasedMF_GPU", "pmf": "PMF_GPU", "camf_c": "CAMF_C_GPU", "camf_ci": "CAMF_CI_GPU",
-           "camf_cu": "CAMF_CU_GPU", "camf_cuci": "CAMF_CUCI_GPU", "fm": "FM_GPU"}
+           "camf_cu": "CAMF_CU_GPU", "camf_cuci": "CAMF_CUCI_GPU", "fm": "FM_GPU",
+           # SURVEY 8(f) N1 names (CARSKit.java:469,708-712)
+           "svd++": "SVDPP_GPU", "camf_ics": "CAMF_ICS_GPU", "camf_lcs": "CAMF_LCS_GPU", "camf_mcs": "CAMF_MCS_GPU"}
+
+
+def test_jni_shim_compiles_against_a_stub_jni_header():
+    """`g++ -fsyntax-only` of the shim against tests/jni_stub/jni.h (the JNI types and the JNIEnv members the shim uses, signatures
+    from the JNI specification) and the real include/carskit_mi355x.h: every statement type-checks against the C ABI.  A compile check,
+    not parity evidence -- no JVM exists here."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    assert gxx, "g++ is part of the build image"
+    res = subprocess.run([gxx, "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "jni_stub"),
+                          "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "jni", "carskit_jni.cpp")],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+
+
+def test_jni_shim_validates_array_lengths_before_every_tuple_or_csr_call():
+    """mismatched Java arrays must throw IllegalArgumentException, not index native memory out of bounds."""
+    shim = _strip_comments(_read("jni", "carskit_jni.cpp"))
+    bodies = re.split(r"JNIEXPORT", shim)[1:]
+    checked = 0
+    for b in bodies:
+        if re.search(r"\bexpand_pairs\s*\(", b) or "rp[r + 1]" in b:
+            assert "bad_csr(" in b, b[:120]
+            checked += 1
+        if re.search(r"cmi_(group_|fm_)?(eval_ratings|set_eval_ratings|predict_batch|eval_rankings)\s*\(", b):
+            assert "bad_tuples(" in b, b[:120]
+            checked += 1
+    assert checked >= 12
+    assert "java/lang/IllegalArgumentException" in shim
 
 
 def test_every_hot_path_recommender_name_has_a_class_and_integration_md_shows_only_what_exists():
@@ -114,11 +149,11 @@ def test_every_hot_path_recommender_name_has_a_class_and_integration_md_shows_on
         assert re.search(r"public\s+class\s+%s\s+extends\s+\w+" % cls, src)
         assert re.search(r"public\s+%s\s*\(\s*SparseMatrix\s+\w+\s*,\s*SparseMatrix\s+\w+\s*,\s*int\s+\w+\s*\)" % cls, src)  # the factory's constructor
         assert "buildModel()" in src
-        assert re.search(r'case\s+"%s_gpu"\s*:\s*return\s+new\s+carskit\.alg\.gpu\.%s\(' % (name, cls), integ), name
+        assert re.search(r'case\s+"%s_gpu"\s*:\s*return\s+new\s+carskit\.alg\.gpu\.%s\(' % (re.escape(name), cls), integ), name
     for cls in re.findall(r"carskit\.alg\.gpu\.(\w+)\(", integ):
         assert os.path.exists(os.path.join(JAVA_DIR, cls + ".java")), cls
     for member in re.findall(r"NativeMF\.(\w+)\(", integ):
         assert member in natives, "INTEGRATION.md shows NativeMF.%s, which does not exist" % member
     hdr = _read("include", "carskit_mi355x.h")
-    for fn in set(re.findall(r"`(cmi_[a-z_0-9]+)`", integ)) - {"cmi_handle", "cmi_fm_handle", "cmi_dao_handle"}:
+    for fn in set(re.findall(r"`(cmi_[a-z_0-9]+)`", integ)) - {"cmi_handle", "cmi_fm_handle", "cmi_dao_handle", "cmi_group_handle"}:
         assert re.search(r"\b%s\s*\(" % fn, hdr), fn
