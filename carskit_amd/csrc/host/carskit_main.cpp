@@ -89,7 +89,7 @@ static std::string evalInfo(const Measures &m, const Conf &conf) { // Recommende
     return buf;
 }
 
-static int run(const std::string &config, unsigned flags, int iters_override, bool precise) {
+static int run(const std::string &config, unsigned flags, int iters_override, bool precise, bool load_model) {
     Logger log = [](const std::string &s) { std::cout << s << std::endl; };
     FileConfiger cf(config);
     Conf conf(cf);
@@ -103,6 +103,8 @@ static int run(const std::string &config, unsigned flags, int iters_override, bo
     std::string mk = "mkdir -p '" + work + "'";
     if (std::system(mk.c_str()) != 0) throw std::runtime_error("cannot create " + work);
     log("WorkingPath: " + work);
+    conf.workingPath = work;
+    conf.loadModel = load_model;
     LineConfiger ev = cf.getParamOptions("evaluation.setup");
     const std::string mode = lower(ev.getMainParam());
     const std::string testFile = mode == "test-set" ? ev.getString("-f") : "";
@@ -201,20 +203,21 @@ int main(int argc, char **argv) {
     std::vector<std::string> configs;
     unsigned flags = 0;
     int iters = 0;
-    bool precise = false;
+    bool precise = false, load_model = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-c") && i + 1 < argc) configs.push_back(argv[++i]);
         else if (!strcmp(argv[i], "--flags") && i + 1 < argc) flags = (unsigned)std::strtoul(argv[++i], nullptr, 0);
         else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = std::atoi(argv[++i]);
         else if (!strcmp(argv[i], "--precise")) precise = true;
+        else if (!strcmp(argv[i], "--load-model")) load_model = true; // evaluate the models `--save-model` left in the workspace instead of training
         else {
-            fprintf(stderr, "usage: carskit-mi355x -c setting.conf [-c more.conf] [--flags N] [--iters N] [--precise]\n");
+            fprintf(stderr, "usage: carskit-mi355x -c setting.conf [-c more.conf] [--flags N] [--iters N] [--precise] [--load-model]\n");
             return 2;
         }
     }
     if (configs.empty()) configs.push_back("setting.conf");
     try {
-        for (const std::string &c : configs) run(c, flags, iters, precise);
+        for (const std::string &c : configs) run(c, flags, iters, precise, load_model);
     } catch (const std::exception &e) { // the reference logs e.getMessage() and a stack trace (CARSKit.java:96-101)
         fprintf(stderr, "ERROR: %s\n", e.what());
         return 1;

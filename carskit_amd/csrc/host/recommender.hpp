@@ -147,6 +147,10 @@ struct Conf {
     double binThold = -1.0;
     std::string evalStrategy = "ucu";
     int numF = 10; // `-f` of the recommender line (CAMF_LCS.java:37: algoOptions.getInt("-f", 10))
+    // `output.setup ... --save-model` (Recommender.java:240,364-365) and the reference's loadModel() branch of execute()
+    // (Recommender.java:332-338: reachable only with Debug.OFF there; here the driver's --load-model flag)
+    bool isSaveModel = false, loadModel = false;
+    std::string workingPath;
     Conf() {}
     explicit Conf(const FileConfiger &cf) {
         if (cf.contains("learn.rate")) {
@@ -172,7 +176,10 @@ struct Conf {
             earlyStop = es == "loss" ? "Loss" : es == "mae" ? "MAE" : es == "rmse" ? "RMSE" : "";
             randSeed = ev.getLong("--rand-seed", 1);
         }
-        if (cf.contains("output.setup")) verbose = cf.getParamOptions("output.setup").isOn("-verbose", true);
+        if (cf.contains("output.setup")) {
+            verbose = cf.getParamOptions("output.setup").isOn("-verbose", true);
+            isSaveModel = cf.getParamOptions("output.setup").contains("--save-model");
+        }
         if (cf.contains("item.ranking")) {
             LineConfiger rk = cf.getParamOptions("item.ranking");
             isRankingPred = rk.isMainOn();
@@ -310,10 +317,18 @@ class IterativeRecommender {
                   h_, "cmi_set_eval_ratings");
             evalResident_ = testMatrix.n() > 0;
         }
-        for (int iter = 1; iter <= conf_.numIters; ++iter) {
-            check(cmi_train_epoch(h_, lRate, &loss), h_, "cmi_train_epoch"); // the for(MatrixEntry me : trainMatrix) body
-            losses.push_back(loss);
-            if (isConverged(iter)) break;
+        if (conf_.loadModel) { // Recommender.execute's loadModel() branch (:332-338): the stored model instead of initModel + the epochs
+            int done = 0;
+            check(cmi_load_model(h_, modelPath().c_str(), &lRate, &last_loss, &done), h_, "cmi_load_model");
+            itersDone = done;
+            if (log_) log_("A recommender model is loaded from " + modelPath());
+        } else {
+            for (int iter = 1; iter <= conf_.numIters; ++iter) {
+                check(cmi_train_epoch(h_, lRate, &loss), h_, "cmi_train_epoch"); // the for(MatrixEntry me : trainMatrix) body
+                losses.push_back(loss);
+                itersDone = iter;
+                if (isConverged(iter)) break;
+            }
         }
         for (auto &kv : state) // copy-back
             check(cmi_get_state(h_, kv.first, kv.second.data(), (int64_t)kv.second.size(), CMI_DTYPE_F64), h_, "cmi_get_state");
@@ -358,8 +373,27 @@ class IterativeRecommender {
         auto t2 = std::chrono::steady_clock::now();
         measures["TrainTime"] = std::chrono::duration<double, std::milli>(t1 - t0).count();
         measures["TestTime"] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        if (conf_.isSaveModel) saveModel(); // :364-365
         return measures;
     }
+
+    // <workingPath>/<algoName>/model<foldInfo>.cmi -- the reference writes <workingPath>/<algoName>/{userFactors,itemFactors,userBiases,
+    // itemBiases}<foldInfo>.bin as Java object streams and forgets the context tables (IterativeRecommender.java:249-270); here ONE
+    // cmi_save_model file holds every container plus the loop's resume state (lRate, last loss, epochs done)
+    std::string modelPath() const {
+        return conf_.workingPath + algoName + "/model" + (fold_ > 0 ? " fold [" + std::to_string(fold_) + "]" : "") + ".cmi";
+    }
+    void saveModel() {
+        if (!h_) { // FM keeps its model behind a cmi_fm_handle, which has no persistence entry point
+            if (log_) log_("--save-model: not available for " + algoName);
+            return;
+        }
+        const std::string mk = "mkdir -p '" + conf_.workingPath + algoName + "'";
+        if (std::system(mk.c_str()) != 0) throw std::runtime_error("cannot create " + conf_.workingPath + algoName);
+        check(cmi_save_model(h_, modelPath().c_str(), lRate, last_loss, itersDone), h_, "cmi_save_model");
+        if (log_) log_("Learned models are saved to folder \"" + conf_.workingPath + algoName + "/\"");
+    }
+    int itersDone = 0;
 
     bool isConverged(int iter) { // IterativeRecommender.java:145-199
         const float delta_loss = (float)(last_loss - loss);

@@ -8,13 +8,18 @@
 //
 // File layout (little endian):
 //   0   char[8]  magic "CMIMODL1"
-//   8   u32      format version (1)
+//   8   u32      format version (2; version-1 files, which lack the block at 96, are still read)
 //   12  u32      model id (CMI_MODEL_*)
 //   16  u32 k, u32 n_users, u32 n_items, u32 n_conds
 //   32  f64      globalMean, regU, regI, regB, regC            (what predict()/a resumed buildModel() need besides the tables)
 //   72  f64      lRate, last_loss ; u32 epochs_done, u32 n_containers      (resume state of the epoch loop)
-//   96  per container: u32 which (CMI_STATE_*), u32 reserved, u64 count, then count f64 values (row-major, as cmi_get_state)
+//   96  (version 2) u32 numF, u32 n_ctx_dims, u32 n_empty, i32 empty_conds[n_empty]: what predict() of CAMF_ICS / LCS / MCS needs
+//       besides the tables (cmi_set_sim_params).  On load they are RESTORED into a handle that has none yet and VERIFIED against a
+//       handle that has (a model trained with other EmptyContextConditions must not pass unnoticed: ADVICE r2)
+//   ..  per container: u32 which (CMI_STATE_*), u32 reserved, u64 count, then count f64 values (row-major, as cmi_get_state)
 //   end u64      FNV-1a 64 of every preceding byte
+// cmi_load_model also OVERWRITES the handle's regularisers and globalMean with the stored ones (a resumed buildModel() must use the
+// hyper-parameters the model was trained with).
 // Values are always stored as fp64: lossless for both state dtypes (fp32 state widens exactly and narrows back exactly).
 #include <cstdint>
 #include <cstdio>
@@ -84,7 +89,7 @@ extern "C" int cmi_save_model(cmi_handle h, const char *path, double lrate, doub
     if (!f) CMI_FAIL(h, CMI_E_INVALID, "save_model: cannot open %s for writing", path);
     Writer w{f};
     w.put(kMagic, 8);
-    w.u32(1);
+    w.u32(2);
     w.u32((uint32_t)h->model);
     w.u32((uint32_t)h->k);
     w.u32((uint32_t)h->n_users);
@@ -102,6 +107,10 @@ extern "C" int cmi_save_model(cmi_handle h, const char *path, double lrate, doub
     for (int c = 0; c < CMI_STATE_COUNT; ++c)
         if (cmi_model_has(h->model, c)) ++nc;
     w.u32(nc);
+    w.u32((uint32_t)h->num_f);
+    w.u32((uint32_t)h->n_ctx_dims);
+    w.u32((uint32_t)h->empty_conds.size());
+    if (!h->empty_conds.empty()) w.put(h->empty_conds.data(), h->empty_conds.size() * 4);
     std::vector<double> buf;
     int rc = CMI_OK;
     for (int c = 0; c < CMI_STATE_COUNT && rc == CMI_OK; ++c) {
@@ -135,7 +144,7 @@ extern "C" int cmi_load_model(cmi_handle h, const char *path, double *lrate, dou
         CMI_FAIL(h, CMI_E_INVALID, __VA_ARGS__); \
     } while (0)
     if (!r.ok || memcmp(magic, kMagic, 8) != 0) LOAD_FAIL("load_model: %s is not a CMIMODL1 file", path);
-    if (version != 1) LOAD_FAIL("load_model: format version %u not supported (this library reads version 1)", version);
+    if (version != 1 && version != 2) LOAD_FAIL("load_model: format version %u not supported (this library reads versions 1 and 2)", version);
     if ((int)model != h->model || (int)k != h->k || (int)nu != h->n_users || (int)ni != h->n_items || (int)ncd != h->n_conds)
         LOAD_FAIL("load_model: file holds model %u k=%u %ux%u users/items %u conditions, the handle is model %d k=%d %dx%d %d", model, k,
                   nu, ni, ncd, h->model, h->k, h->n_users, h->n_items, h->n_conds);
@@ -143,13 +152,29 @@ extern "C" int cmi_load_model(cmi_handle h, const char *path, double *lrate, dou
     for (double &v : hp) v = r.f64();
     const double lr = r.f64(), ll = r.f64();
     const uint32_t ep = r.u32(), nc = r.u32();
+    uint32_t f_numf = 0, f_dims = 1;
+    std::vector<int32_t> f_empty;
+    if (version >= 2) {
+        f_numf = r.u32();
+        f_dims = r.u32();
+        const uint32_t ne = r.u32();
+        if (!r.ok || ne > (uint32_t)h->n_conds + 1024u) LOAD_FAIL("load_model: %s is truncated or corrupt (sim-parameter block)", path);
+        f_empty.resize(ne);
+        if (ne) r.get(f_empty.data(), (size_t)ne * 4);
+        if (!h->empty_conds.empty() && (f_empty != h->empty_conds || (int)f_numf != h->num_f || (int)f_dims != h->n_ctx_dims))
+            LOAD_FAIL("load_model: %s was trained with other EmptyContextConditions / numF / context dimensions than this handle has "
+                      "(cmi_set_sim_params)", path);
+    }
     std::vector<std::vector<double>> tabs(CMI_STATE_COUNT);
     std::vector<bool> seen(CMI_STATE_COUNT, false);
     for (uint32_t i = 0; i < nc && r.ok; ++i) {
         const uint32_t which = r.u32();
         (void)r.u32();
         const uint64_t count = r.u64();
-        if (!r.ok || which >= CMI_STATE_COUNT || !cmi_model_has(h->model, (int)which) || (int64_t)count != h->state_count[which] || seen[which])
+        // a handle without sim params yet gets them from the file (below): its cfMatrix then has n_conds x numF elements
+        int64_t expect = which < CMI_STATE_COUNT ? h->state_count[which] : -1;
+        if (which == CMI_STATE_CF_MATRIX && version >= 2 && h->empty_conds.empty()) expect = (int64_t)h->n_conds * (int64_t)f_numf;
+        if (!r.ok || which >= CMI_STATE_COUNT || !cmi_model_has(h->model, (int)which) || (int64_t)count != expect || seen[which])
             LOAD_FAIL("load_model: unexpected container %u (count %llu) in %s", which, (unsigned long long)count, path);
         seen[which] = true;
         tabs[which].resize((size_t)count);
@@ -164,6 +189,8 @@ extern "C" int cmi_load_model(cmi_handle h, const char *path, double *lrate, dou
 #undef LOAD_FAIL
     fclose(f);
     // only now touch the handle: a bad file leaves the model as it was
+    if (version >= 2 && h->empty_conds.empty() && !f_empty.empty())
+        if (int rc = cmi_set_sim_params(h, (int)f_numf, (int)f_dims, f_empty.data(), (int)f_empty.size())) return rc;
     for (int c = 0; c < CMI_STATE_COUNT; ++c)
         if (seen[c] && !tabs[c].empty())
             if (int rc = cmi_set_state(h, c, tabs[c].data(), (int64_t)tabs[c].size(), CMI_DTYPE_F64)) return rc;

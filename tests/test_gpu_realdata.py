@@ -150,6 +150,33 @@ def test_cpp_host_driver_c1_matches_oracle(tmp_path):
     assert abs(float(mc.group(1)) - wc["MAE"]) <= 1e-12 and abs(float(mc.group(2)) - wc["RMSE"]) <= 1e-12
 
 
+def test_cpp_host_save_model_then_load_model(tmp_path):
+    """`output.setup ... --save-model` through the C++ host (Recommender.java:240,364-365; IterativeRecommender.java:249-270): one
+    model file per fold appears under <workspace>/<algo>/; a second run with --load-model evaluates those files instead of
+    training (the reference's loadModel() branch, Recommender.java:332-338) and prints the identical measures -- context tables
+    included, which the reference's own saveModel() forgets."""
+    import glob
+    import re
+    import subprocess
+    from tests.test_host_layer import EXE, _depaul_conf
+    conf = _depaul_conf(tmp_path)
+    txt = open(conf).read().replace("recommender=biasedmf", "recommender=camf_ci").replace("-verbose off", "-verbose off --save-model")
+    open(conf, "w").write(txt)
+    flags = capi.FLAG_STATE_F64 | capi.FLAG_STRICT
+    p = subprocess.run([EXE, "-c", conf, "--iters", "8", "--flags", str(flags), "--precise"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    m = re.search(r"PRECISE CAMF_CI folds=5 MAE=(\S+) RMSE=(\S+)", p.stdout)
+    assert m, p.stdout[-500:]
+    files = sorted(glob.glob(str(tmp_path / "CARSKit.Workspace" / "CAMF_CI" / "model fold [[]*[]].cmi")))
+    assert len(files) == 5, files
+    assert "Learned models are saved to folder" in p.stdout
+    q = subprocess.run([EXE, "-c", conf, "--iters", "8", "--flags", str(flags), "--precise", "--load-model"], capture_output=True, text=True)
+    assert q.returncode == 0, q.stderr
+    assert "A recommender model is loaded from" in q.stdout and " iter 1:" not in q.stdout
+    m2 = re.search(r"PRECISE CAMF_CI folds=5 MAE=(\S+) RMSE=(\S+)", q.stdout)
+    assert m2 and m2.groups() == m.groups(), (m.groups(), m2 and m2.groups())
+
+
 def test_cpp_host_driver_item_ranking(tmp_path):
     """item.ranking=on through the C++ host: fp64/strict numbers equal the oracle's (training + ranking) for the same
     folds and init stream; the printed line has the reference's layout."""
