@@ -1,0 +1,798 @@
+"""A small JVM bytecode interpreter -- TEST INFRASTRUCTURE, build container only (see classfile.py).
+
+Executes the methods of librec.data.{DenseMatrix, DenseVector, SparseMatrix(+MatrixIterator, SparseMatrixEntry)} and
+librec.util.{Randoms, Stats} straight from the reference's vendored jar.  What is interpreted is the jar's own bytecode; what is
+NOT in the jar -- the JDK and guava classes those methods call (java.util.Random, Integer/Double boxes, Iterator/Set/Map views,
+guava Table / Multimap, Arrays.sort, StringBuilder) -- is provided by the host classes at the bottom of this file, written from
+their public specifications.  java.util.Random in particular is oracle/oracle_np.JavaRandom (LCG + polar nextGaussian with
+fdlibm's log, pinned by known answers in tests/test_java_random.py): the vectors minted here therefore pin librec's ORDER of draws
+and its arithmetic on them, not the JDK's generator a second time.
+
+Value model: int/short/byte/char/boolean -> Python int (32-bit wrapped), long -> JLong, float -> JFloat, double -> Python float,
+references -> JObject / JArray / host objects / None.  Category-2 values take one stack entry here (dup2 / pop2 look at the type).
+"""
+import math
+import struct
+
+from .classfile import Jar, parse_descriptor
+
+
+class JLong(int):
+    pass
+
+
+class JFloat(float):
+    pass
+
+
+class JavaThrow(Exception):
+    def __init__(self, obj):
+        super().__init__(repr(obj))
+        self.obj = obj
+
+
+class JObject:
+    def __init__(self, cls_name):
+        self.cls_name = cls_name
+        self.fields = {}
+
+    def __repr__(self):
+        return "<%s %s>" % (self.cls_name, {k: v for k, v in self.fields.items() if not isinstance(v, (JObject, JArray))})
+
+
+class JArray:
+    def __init__(self, elem, data):
+        self.elem, self.data = elem, data
+
+    def __repr__(self):
+        return "<%s[%d]>" % (self.elem, len(self.data))
+
+
+def i32(v):
+    v &= 0xFFFFFFFF
+    return v - (1 << 32) if v & 0x80000000 else v
+
+
+def i64(v):
+    v &= 0xFFFFFFFFFFFFFFFF
+    return JLong(v - (1 << 64) if v & (1 << 63) else v)
+
+
+def f32(v):
+    return JFloat(struct.unpack("f", struct.pack("f", v))[0])
+
+
+def is_cat2(v):
+    return isinstance(v, JLong) or (isinstance(v, float) and not isinstance(v, JFloat))
+
+
+DEFAULTS = {"I": 0, "S": 0, "B": 0, "C": 0, "Z": 0, "J": JLong(0), "F": JFloat(0.0), "D": 0.0}
+ATYPE = {4: "Z", 5: "C", 6: "F", 7: "D", 8: "B", 9: "S", 10: "I", 11: "J"}
+
+
+class VM:
+    def __init__(self, jar_path, host=None):
+        self.jar = Jar(jar_path)
+        self.statics = {}
+        self.initialized = set()
+        self.host = host or {}
+        self.steps = 0
+
+    # -- class / member resolution ------------------------------------------------------------------------------------------
+    def ensure_init(self, cls_name):
+        if cls_name in self.initialized or not self.jar.has(cls_name):
+            return
+        self.initialized.add(cls_name)
+        cf = self.jar.load(cls_name)
+        if cf.super_name:
+            self.ensure_init(cf.super_name)
+        for acc, nm, ds, const in cf.fields:
+            if acc & 0x0008:
+                self.statics[(cls_name, nm)] = const[1] if const else DEFAULTS.get(ds[0])
+        m = cf.methods.get(("<clinit>", "()V"))
+        if m:
+            self.run(m, [])
+
+    def find_method(self, cls_name, name, desc):
+        c = cls_name
+        while c and self.jar.has(c):
+            cf = self.jar.load(c)
+            m = cf.methods.get((name, desc))
+            if m and m.code is not None:
+                return m
+            c = cf.super_name
+        return None
+
+    def new_object(self, cls_name):
+        o = JObject(cls_name)
+        c = cls_name
+        while c and self.jar.has(c):
+            cf = self.jar.load(c)
+            for acc, nm, ds, _ in cf.fields:
+                if not acc & 0x0008:
+                    o.fields.setdefault(nm, DEFAULTS.get(ds[0]))
+            c = cf.super_name
+        return o
+
+    # -- calls --------------------------------------------------------------------------------------------------------------
+    def call(self, cls_name, name, desc, args):
+        """invoke a static or instance method by name (args include `this` for instance methods)"""
+        self.ensure_init(cls_name)
+        m = self.find_method(cls_name, name, desc)
+        if m is None:
+            raise KeyError("%s.%s%s" % (cls_name, name, desc))
+        return self.run(m, list(args))
+
+    def invoke(self, kind, owner, name, desc, args):
+        if kind == "static":
+            if self.jar.has(owner):
+                return self.call(owner, name, desc, args)
+            return self.host_static(owner, name, desc, args)
+        this = args[0]
+        if this is None:
+            raise JavaThrow("java/lang/NullPointerException calling %s.%s" % (owner, name))
+        if isinstance(this, JObject):
+            start = owner if kind == "special" else this.cls_name
+            m = self.find_method(start, name, desc)
+            if m is not None:
+                self.ensure_init(m.cls.name)
+                return self.run(m, list(args))
+            if name == "<init>" and not self.jar.has(owner):   # java/lang/Object.<init>
+                return None
+            if name == "getClass":
+                return ("class", this.cls_name)
+            raise KeyError("%s.%s%s on %r" % (owner, name, desc, this))
+        return this.jcall(self, name, desc, args[1:])          # host object
+
+    def host_static(self, owner, name, desc, args):
+        fn = HOST_STATICS.get((owner, name, desc)) or HOST_STATICS.get((owner, name))
+        if fn is None:
+            raise KeyError("no host implementation of static %s.%s%s" % (owner, name, desc))
+        return fn(self, *args)
+
+    # -- the interpreter loop ---------------------------------------------------------------------------------------------------
+    def run(self, m, args):
+        cf, code = m.cls, m.code
+        loc = [None] * (m.max_locals + 2)
+        arg_types, _ = parse_descriptor(m.desc)
+        i = 0
+        if not m.static:
+            loc[0] = args[0]
+            args = args[1:]
+            i = 1
+        for t, v in zip(arg_types, args):
+            loc[i] = v
+            i += 2 if t in ("J", "D") else 1
+        st = []
+        pc = 0
+        push, pop = st.append, st.pop
+
+        def s2(at):
+            return struct.unpack(">h", code[at:at + 2])[0]
+
+        def u2(at):
+            return (code[at] << 8) | code[at + 1]
+
+        while True:
+            self.steps += 1
+            op = code[pc]
+            # ---- constants
+            if op == 0:
+                pc += 1
+            elif op == 1:
+                push(None); pc += 1
+            elif 2 <= op <= 8:
+                push(op - 3); pc += 1
+            elif op in (9, 10):
+                push(JLong(op - 9)); pc += 1
+            elif 11 <= op <= 13:
+                push(JFloat(op - 11)); pc += 1
+            elif op in (14, 15):
+                push(float(op - 14)); pc += 1
+            elif op == 16:
+                push(struct.unpack("b", code[pc + 1:pc + 2])[0]); pc += 2
+            elif op == 17:
+                push(s2(pc + 1)); pc += 3
+            elif op in (18, 19, 20):
+                idx = code[pc + 1] if op == 18 else u2(pc + 1)
+                c = cf.cp[idx]
+                if c[0] == 3:
+                    push(c[1])
+                elif c[0] == 4:
+                    push(JFloat(c[1]))
+                elif c[0] == 5:
+                    push(JLong(c[1]))
+                elif c[0] == 6:
+                    push(c[1])
+                elif c[0] == 8:
+                    push(JString(cf.utf8(c[1])))
+                elif c[0] == 7:
+                    push(("class", cf.utf8(c[1])))
+                else:
+                    raise NotImplementedError("ldc of tag %d" % c[0])
+                pc += 2 if op == 18 else 3
+            # ---- loads / stores
+            elif 21 <= op <= 25:
+                push(loc[code[pc + 1]]); pc += 2
+            elif 26 <= op <= 45:
+                push(loc[(op - 26) % 4]); pc += 1
+            elif 46 <= op <= 53:                      # xaload
+                idx = pop(); arr = pop()
+                if arr is None:
+                    raise JavaThrow("java/lang/NullPointerException (array load)")
+                if not 0 <= idx < len(arr.data):
+                    raise JavaThrow("java/lang/ArrayIndexOutOfBoundsException: %d" % idx)
+                push(arr.data[idx]); pc += 1
+            elif 54 <= op <= 58:
+                loc[code[pc + 1]] = pop(); pc += 2
+            elif 59 <= op <= 78:
+                loc[(op - 59) % 4] = pop(); pc += 1
+            elif 79 <= op <= 86:                      # xastore
+                v = pop(); idx = pop(); arr = pop()
+                if arr is None:
+                    raise JavaThrow("java/lang/NullPointerException (array store)")
+                if not 0 <= idx < len(arr.data):
+                    raise JavaThrow("java/lang/ArrayIndexOutOfBoundsException: %d" % idx)
+                if op in (84, 85, 86):                # bastore / castore / sastore narrow
+                    v = {84: lambda x: struct.unpack("b", struct.pack("B", x & 0xFF))[0], 85: lambda x: x & 0xFFFF,
+                         86: lambda x: struct.unpack("h", struct.pack("H", x & 0xFFFF))[0]}[op](v)
+                arr.data[idx] = v; pc += 1
+            # ---- stack
+            elif op == 87:
+                pop(); pc += 1
+            elif op == 88:
+                if not is_cat2(pop()):
+                    pop()
+                pc += 1
+            elif op == 89:
+                push(st[-1]); pc += 1
+            elif op == 90:
+                a = pop(); b = pop(); st.extend((a, b, a)); pc += 1
+            elif op == 91:                            # dup_x2
+                a = pop(); b = pop()
+                if is_cat2(b):
+                    st.extend((a, b, a))
+                else:
+                    c = pop(); st.extend((a, c, b, a))
+                pc += 1
+            elif op == 92:                            # dup2
+                if is_cat2(st[-1]):
+                    push(st[-1])
+                else:
+                    st.extend(st[-2:])
+                pc += 1
+            elif op == 93:                            # dup2_x1
+                a = pop()
+                if is_cat2(a):
+                    b = pop(); st.extend((a, b, a))
+                else:
+                    b = pop(); c = pop(); st.extend((b, a, c, b, a))
+                pc += 1
+            elif op == 95:
+                a = pop(); b = pop(); st.extend((a, b)); pc += 1
+            # ---- arithmetic
+            elif 96 <= op <= 119:
+                kind = (op - 96) % 4                  # 0 int, 1 long, 2 float, 3 double
+                group = (op - 96) // 4                # add sub mul div rem neg
+                if group == 5:
+                    a = pop()
+                    push(i32(-a) if kind == 0 else i64(-a) if kind == 1 else f32(-a) if kind == 2 else -a)
+                else:
+                    b = pop(); a = pop()
+                    if kind in (0, 1):
+                        wrap = i32 if kind == 0 else i64
+                        if group == 0:
+                            r = a + b
+                        elif group == 1:
+                            r = a - b
+                        elif group == 2:
+                            r = a * b
+                        else:
+                            if b == 0:
+                                raise JavaThrow("java/lang/ArithmeticException: / by zero")
+                            q = abs(a) // abs(b) * (1 if (a < 0) == (b < 0) else -1)      # truncation toward zero
+                            r = q if group == 3 else a - q * b
+                        push(wrap(r))
+                    else:
+                        a, b = float(a), float(b)
+                        if group == 0:
+                            r = a + b
+                        elif group == 1:
+                            r = a - b
+                        elif group == 2:
+                            r = a * b
+                        elif group == 3:
+                            if b == 0.0:
+                                r = math.nan if (a == 0.0 or a != a) else math.copysign(math.inf, a) * math.copysign(1.0, b)
+                            else:
+                                r = a / b
+                        else:
+                            r = math.nan if (b == 0.0 or math.isinf(a) or a != a or b != b) else math.fmod(a, b)
+                        push(f32(r) if kind == 2 else r)
+                pc += 1
+            elif 120 <= op <= 131:                    # shifts and bitwise
+                b = pop(); a = pop()
+                long_ = op % 2 == 1
+                wrap, bits = (i64, 64) if long_ else (i32, 32)
+                if op in (120, 121):
+                    r = a << (b & (bits - 1))
+                elif op in (122, 123):
+                    r = a >> (b & (bits - 1))
+                elif op in (124, 125):
+                    r = (a & ((1 << bits) - 1)) >> (b & (bits - 1))
+                elif op in (126, 127):
+                    r = a & b
+                elif op in (128, 129):
+                    r = a | b
+                else:
+                    r = a ^ b
+                push(wrap(r)); pc += 1
+            elif op == 132:
+                idx = code[pc + 1]
+                loc[idx] = i32(loc[idx] + struct.unpack("b", code[pc + 2:pc + 3])[0]); pc += 3
+            # ---- conversions
+            elif 133 <= op <= 147:
+                a = pop()
+                if op == 133:
+                    r = JLong(a)
+                elif op == 134:
+                    r = f32(float(a))
+                elif op == 135:
+                    r = float(a)
+                elif op == 136:
+                    r = i32(a)
+                elif op == 137:
+                    r = f32(float(a))
+                elif op == 138:
+                    r = float(int(a))
+                elif op in (139, 142):                # f2i / d2i
+                    r = 0 if a != a else max(-2 ** 31, min(2 ** 31 - 1, int(a))) if not math.isinf(a) else (2 ** 31 - 1 if a > 0 else -2 ** 31)
+                elif op in (140, 143):                # f2l / d2l
+                    r = JLong(0) if a != a else JLong(max(-2 ** 63, min(2 ** 63 - 1, int(a)))) if not math.isinf(a) else JLong(2 ** 63 - 1 if a > 0 else -2 ** 63)
+                elif op == 141:
+                    r = float(a)
+                elif op == 144:
+                    r = f32(a)
+                elif op == 145:
+                    r = struct.unpack("b", struct.pack("B", a & 0xFF))[0]
+                elif op == 146:
+                    r = a & 0xFFFF
+                else:
+                    r = struct.unpack("h", struct.pack("H", a & 0xFFFF))[0]
+                push(r); pc += 1
+            # ---- comparisons
+            elif op == 148:
+                b = pop(); a = pop(); push((a > b) - (a < b)); pc += 1
+            elif 149 <= op <= 152:
+                b = pop(); a = pop()
+                if a != a or b != b:
+                    push(-1 if op in (149, 151) else 1)
+                else:
+                    push((a > b) - (a < b))
+                pc += 1
+            elif 153 <= op <= 158:
+                a = pop()
+                t = (a == 0, a != 0, a < 0, a >= 0, a > 0, a <= 0)[op - 153]
+                pc = pc + s2(pc + 1) if t else pc + 3
+            elif 159 <= op <= 164:
+                b = pop(); a = pop()
+                t = (a == b, a != b, a < b, a >= b, a > b, a <= b)[op - 159]
+                pc = pc + s2(pc + 1) if t else pc + 3
+            elif op in (165, 166):
+                b = pop(); a = pop()
+                t = (a is b) if op == 165 else (a is not b)
+                pc = pc + s2(pc + 1) if t else pc + 3
+            elif op == 167:
+                pc += s2(pc + 1)
+            elif op == 170:                           # tableswitch
+                base = pc
+                q = (pc + 4) & ~3
+                dflt, lo, hi = struct.unpack(">iii", code[q:q + 12])
+                v = pop()
+                pc = base + (struct.unpack(">i", code[q + 12 + 4 * (v - lo):q + 16 + 4 * (v - lo)])[0] if lo <= v <= hi else dflt)
+            elif op == 171:                           # lookupswitch
+                base = pc
+                q = (pc + 4) & ~3
+                dflt, n = struct.unpack(">ii", code[q:q + 8])
+                v = pop()
+                pc = base + dflt
+                for t in range(n):
+                    key, off = struct.unpack(">ii", code[q + 8 + 8 * t:q + 16 + 8 * t])
+                    if key == v:
+                        pc = base + off
+                        break
+            elif 172 <= op <= 176:
+                return pop()
+            elif op == 177:
+                return None
+            # ---- fields
+            elif op == 178:
+                owner, nm, ds = cf.member_ref(u2(pc + 1))
+                self.ensure_init(owner)
+                if (owner, nm) in self.statics:
+                    push(self.statics[(owner, nm)])
+                else:
+                    push(HOST_STATIC_FIELDS[(owner, nm)])
+                pc += 3
+            elif op == 179:
+                owner, nm, ds = cf.member_ref(u2(pc + 1))
+                self.ensure_init(owner)
+                self.statics[(owner, nm)] = pop(); pc += 3
+            elif op == 180:
+                _, nm, _ = cf.member_ref(u2(pc + 1))
+                o = pop()
+                if o is None:
+                    raise JavaThrow("java/lang/NullPointerException (getfield %s)" % nm)
+                push(o.fields[nm]); pc += 3
+            elif op == 181:
+                _, nm, _ = cf.member_ref(u2(pc + 1))
+                v = pop(); o = pop()
+                o.fields[nm] = v; pc += 3
+            # ---- invocations
+            elif 182 <= op <= 185:
+                owner, nm, ds = cf.member_ref(u2(pc + 1))
+                arg_t, ret_t = parse_descriptor(ds)
+                n = len(arg_t) + (0 if op == 184 else 1)
+                args2 = st[len(st) - n:] if n else []
+                del st[len(st) - n:]
+                r = self.invoke({182: "virtual", 183: "special", 184: "static", 185: "interface"}[op], owner, nm, ds, args2)
+                if ret_t != "V":
+                    if ret_t == "Z" and isinstance(r, bool):
+                        r = int(r)
+                    push(r)
+                pc += 5 if op == 185 else 3
+            # ---- objects and arrays
+            elif op == 187:
+                name = cf.class_name(u2(pc + 1))
+                if self.jar.has(name):
+                    self.ensure_init(name)
+                    push(self.new_object(name))
+                else:
+                    push(HOST_CLASSES[name]())
+                pc += 3
+            elif op == 188:
+                n = pop()
+                t = ATYPE[code[pc + 1]]
+                push(JArray(t, [DEFAULTS[t]] * n)); pc += 2
+            elif op == 189:
+                n = pop()
+                push(JArray("L" + cf.class_name(u2(pc + 1)), [None] * n)); pc += 3
+            elif op == 190:
+                a = pop()
+                if a is None:
+                    raise JavaThrow("java/lang/NullPointerException (arraylength)")
+                push(len(a.data)); pc += 1
+            elif op == 191:
+                raise JavaThrow(pop())
+            elif op == 192:
+                pc += 3                               # checkcast: trusted
+            elif op == 193:
+                name = cf.class_name(u2(pc + 1))
+                o = pop()
+                push(int(o is not None and (getattr(o, "cls_name", None) == name or name in getattr(o, "JAVA_TYPES", ()))))
+                pc += 3
+            elif op == 197:                           # multianewarray
+                desc = cf.class_name(u2(pc + 1))
+                dims = code[pc + 3]
+                counts = st[len(st) - dims:]
+                del st[len(st) - dims:]
+
+                def build(level, d):
+                    elem = d[1:]
+                    if level == len(counts) - 1:
+                        dv = DEFAULTS.get(elem[0]) if elem[0] != "[" else None
+                        return JArray(elem, [dv] * counts[level])
+                    return JArray(elem, [build(level + 1, elem) for _ in range(counts[level])])
+                push(build(0, desc)); pc += 4
+            elif op == 198:
+                pc = pc + s2(pc + 1) if pop() is None else pc + 3
+            elif op == 199:
+                pc = pc + s2(pc + 1) if pop() is not None else pc + 3
+            elif op in (194, 195):
+                pop(); pc += 1                        # monitorenter / monitorexit
+            else:
+                raise NotImplementedError("opcode %d at %s pc=%d" % (op, m, pc))
+
+
+# ---- host side: the JDK / guava surface the interpreted methods call, from the public specifications ------------------------
+
+class JString:
+    JAVA_TYPES = ("java/lang/String",)
+
+    def __init__(self, s):
+        self.s = s
+
+    def jcall(self, vm, name, desc, args):
+        if name == "toString":
+            return self
+        if name == "length":
+            return len(self.s)
+        if name == "equals":
+            return int(isinstance(args[0], JString) and args[0].s == self.s)
+        raise KeyError("String." + name)
+
+    def __repr__(self):
+        return repr(self.s)
+
+
+class Box:
+    """java.lang.Integer / Double (Number)"""
+
+    def __init__(self, v, kind):
+        self.v, self.kind = v, kind
+        self.JAVA_TYPES = ("java/lang/Number", "java/lang/" + kind)
+
+    def jcall(self, vm, name, desc, args):
+        if name == "intValue":
+            return i32(int(self.v))
+        if name == "doubleValue":
+            return float(self.v)
+        if name == "equals":
+            return int(isinstance(args[0], Box) and args[0].v == self.v)
+        if name == "hashCode":
+            return i32(int(self.v))
+        raise KeyError("%s.%s" % (self.kind, name))
+
+    def __hash__(self):
+        return hash(self.v)
+
+    def __eq__(self, o):
+        return isinstance(o, Box) and o.v == self.v
+
+    def __repr__(self):
+        return "%s(%r)" % (self.kind, self.v)
+
+
+class JIterator:
+    def __init__(self, items):
+        self.items, self.i = list(items), 0
+
+    def jcall(self, vm, name, desc, args):
+        if name == "hasNext":
+            return int(self.i < len(self.items))
+        if name == "next":
+            self.i += 1
+            return self.items[self.i - 1]
+        raise KeyError("Iterator." + name)
+
+
+class JCollection:
+    """read-only Collection / Set / List view over a Python list (iteration order = list order)"""
+    JAVA_TYPES = ("java/util/Collection", "java/util/Set", "java/util/List")
+
+    def __init__(self, items=None):
+        self.items = list(items or [])
+
+    def jcall(self, vm, name, desc, args):
+        if name == "iterator":
+            return JIterator(self.items)
+        if name == "size":
+            return len(self.items)
+        if name == "add":
+            self.items.append(args[0])
+            return 1
+        if name == "get":
+            return self.items[args[0]]
+        if name == "isEmpty":
+            return int(not self.items)
+        if name == "contains":
+            return int(args[0] in self.items)
+        if name == "<init>":
+            return None
+        raise KeyError("Collection." + name)
+
+
+class JMapView:
+    JAVA_TYPES = ("java/util/Map",)
+
+    def __init__(self, d):
+        self.d = d
+
+    def jcall(self, vm, name, desc, args):
+        if name == "keySet":
+            return JCollection(self.d.keys())
+        if name == "size":
+            return len(self.d)
+        if name == "get":
+            return self.d.get(args[0])
+        if name == "values":
+            return JCollection(self.d.values())
+        raise KeyError("Map." + name)
+
+
+class Cell:
+    def __init__(self, r, c, v):
+        self.r, self.c, self.v = r, c, v
+
+    def jcall(self, vm, name, desc, args):
+        return {"getRowKey": self.r, "getColumnKey": self.c, "getValue": self.v}[name]
+
+
+class GuavaTable:
+    """com.google.common.collect.Table<Integer,Integer,Double> (HashBasedTable): put overwrites; cellSet / row / column views.
+    Iteration order here = insertion order of the rows, then of the columns inside a row.  librec's SparseMatrix.construct sorts the
+    column indices of every row itself (Arrays.sort), so its result does not depend on the table's iteration order."""
+    JAVA_TYPES = ("com/google/common/collect/Table",)
+
+    def __init__(self):
+        self.rows = {}
+
+    def put(self, r, c, v):
+        self.rows.setdefault(Box(r, "Integer"), {})[Box(c, "Integer")] = Box(float(v), "Double")
+
+    def jcall(self, vm, name, desc, args):
+        if name == "put":
+            old = self.rows.setdefault(args[0], {}).get(args[1])
+            self.rows[args[0]][args[1]] = args[2]
+            return old
+        if name == "size":
+            return sum(len(r) for r in self.rows.values())
+        if name == "cellSet":
+            return JCollection([Cell(r, c, v) for r, cols in self.rows.items() for c, v in cols.items()])
+        if name == "row":
+            return JMapView(self.rows.get(args[0], {}))
+        if name == "column":
+            return JMapView({r: cols[args[0]] for r, cols in self.rows.items() if args[0] in cols})
+        if name == "rowKeySet":
+            return JCollection(self.rows.keys())
+        raise KeyError("Table." + name)
+
+
+class GuavaMultimap:
+    JAVA_TYPES = ("com/google/common/collect/Multimap",)
+
+    def __init__(self):
+        self.d = {}
+
+    def put(self, k, v):
+        self.jcall(None, "put", "", [Box(k, "Integer"), Box(v, "Integer")])
+
+    def jcall(self, vm, name, desc, args):
+        if name == "put":
+            s = self.d.setdefault(args[0], [])
+            if args[1] in s:
+                return 0
+            s.append(args[1])
+            return 1
+        if name == "get":
+            return JCollection(self.d.get(args[0], []))
+        if name == "size":
+            return sum(len(v) for v in self.d.values())
+        raise KeyError("Multimap." + name)
+
+
+class HostRandom:
+    """java.util.Random via oracle/oracle_np.JavaRandom (the Python restatement of the published algorithm: 48-bit LCG, polar
+    nextGaussian over fdlibm's log; known answers in tests/test_java_random.py)"""
+    JAVA_TYPES = ("java/util/Random",)
+
+    def __init__(self):
+        self.r = None
+
+    def jcall(self, vm, name, desc, args):
+        from oracle.oracle_np import JavaRandom
+        if name == "<init>":
+            self.r = JavaRandom(int(args[0]) if args else 0)
+            return None
+        if name == "nextDouble":
+            return self.r.next_double()
+        if name == "nextGaussian":
+            return self.r.next_gaussian()
+        if name == "nextInt":
+            if args:
+                raise KeyError("Random.nextInt(bound) is not needed by the interpreted methods")
+            return self.r.next_int()
+        raise KeyError("Random." + name)
+
+
+class HostStringBuilder:
+    def __init__(self):
+        self.s = ""
+
+    def jcall(self, vm, name, desc, args):
+        if name == "<init>":
+            self.s = args[0].s if args else ""
+            return None
+        if name == "append":
+            a = args[0]
+            self.s += a.s if isinstance(a, JString) else repr(a) if isinstance(a, float) else str(a)
+            return self
+        if name == "toString":
+            return JString(self.s)
+        raise KeyError("StringBuilder." + name)
+
+
+class HostThrowable:
+    def __init__(self, kind="java/lang/Throwable"):
+        self.kind, self.msg = kind, None
+
+    def jcall(self, vm, name, desc, args):
+        if name == "<init>":
+            self.msg = args[0] if args else None
+            return None
+        raise KeyError("Throwable." + name)
+
+    def __repr__(self):
+        return "%s(%r)" % (self.kind, self.msg)
+
+
+HOST_CLASSES = {
+    "java/util/Random": HostRandom,
+    "java/util/ArrayList": JCollection,
+    "java/lang/StringBuilder": HostStringBuilder,
+    "java/lang/AssertionError": lambda: HostThrowable("java/lang/AssertionError"),
+    "java/lang/IllegalArgumentException": lambda: HostThrowable("java/lang/IllegalArgumentException"),
+    "java/lang/UnsupportedOperationException": lambda: HostThrowable("java/lang/UnsupportedOperationException"),
+    "java/util/NoSuchElementException": lambda: HostThrowable("java/util/NoSuchElementException"),
+}
+HOST_STATIC_FIELDS = {}
+
+
+def _arrays_sort_range(vm, arr, lo, hi):
+    arr.data[lo:hi] = sorted(arr.data[lo:hi])
+
+
+def _binary_search(vm, arr, lo, hi, key):
+    """java.util.Arrays.binarySearch(int[], from, to, key): index, or -(insertion point) - 1"""
+    a, b = lo, hi - 1
+    while a <= b:
+        mid = (a + b) >> 1
+        if arr.data[mid] < key:
+            a = mid + 1
+        elif arr.data[mid] > key:
+            b = mid - 1
+        else:
+            return mid
+    return -(a + 1)
+
+
+HOST_STATICS = {
+    ("java/lang/System", "currentTimeMillis"): lambda vm: JLong(0),
+    ("java/lang/Integer", "valueOf", "(I)Ljava/lang/Integer;"): lambda vm, v: Box(v, "Integer"),
+    ("java/lang/Double", "valueOf", "(D)Ljava/lang/Double;"): lambda vm, v: Box(v, "Double"),
+    ("java/lang/Double", "isNaN", "(D)Z"): lambda vm, v: int(v != v),
+    ("java/lang/Math", "sqrt"): lambda vm, v: math.sqrt(v) if v >= 0 else math.nan,
+    ("java/lang/Math", "abs", "(D)D"): lambda vm, v: abs(v),
+    ("java/lang/Math", "abs", "(I)I"): lambda vm, v: i32(abs(v)),
+    ("java/util/Arrays", "sort", "([III)V"): _arrays_sort_range,
+    ("java/util/Arrays", "binarySearch", "([IIII)I"): _binary_search,
+    ("com/google/common/collect/HashBasedTable", "create"): lambda vm: GuavaTable(),
+    ("com/google/common/collect/HashMultimap", "create"): lambda vm: GuavaMultimap(),
+}
+
+
+# java/lang/Class.desiredAssertionStatus() -> false (assertions off, the JVM default): handled as a "virtual" call on the
+# ("class", name) tuples ldc pushes
+class _ClassShim:
+    pass
+
+
+def _patch_class_calls():
+    orig = VM.invoke
+
+    def invoke(self, kind, owner, name, desc, args):
+        if owner == "java/lang/Class" and name == "desiredAssertionStatus":
+            return 0
+        if owner == "java/lang/Object" and name == "<init>":
+            return None
+        return orig(self, kind, owner, name, desc, args)
+    VM.invoke = invoke
+
+
+_patch_class_calls()
+
+
+# ---- conveniences for the minting script ---------------------------------------------------------------------------------------
+
+def darray(values):
+    return JArray("D", [float(v) for v in values])
+
+
+def dmatrix(rows):
+    return JArray("[D", [darray(r) for r in rows])
+
+
+def to_list(a):
+    if isinstance(a, JArray):
+        return [to_list(x) for x in a.data]
+    return a
