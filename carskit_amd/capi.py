@@ -98,6 +98,7 @@ SYMBOLS = [
     ("cmi_group_set_state", C.c_int, [_vp, C.c_int, _vp, _i64, C.c_int]),
     ("cmi_group_get_state", C.c_int, [_vp, C.c_int, _vp, _i64, C.c_int]),
     ("cmi_group_train_epoch", C.c_int, [_vp, C.c_double, C.POINTER(C.c_double)]),
+    ("cmi_group_set_lr_scale", C.c_int, [_vp, C.c_double]),
     ("cmi_group_train", C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, _vp, _vp, C.POINTER(C.c_int),
                                   C.POINTER(C.c_double)]),
     ("cmi_group_train_from", C.c_int, [_vp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, _vp, _vp,
@@ -444,6 +445,9 @@ class Group:
 
     def get_states(self, dtype=np.float64):
         return {name: self.get_state(name, dtype) for name in MODEL_STATES[self.model]}
+
+    def set_lr_scale(self, scale):
+        self._chk(self.L.cmi_group_set_lr_scale(self.h, float(scale)))
 
     def train_epoch(self, lrate):
         loss = _dbl()

@@ -45,6 +45,7 @@ struct cmi_group {
     bool rccl = false;
     std::vector<ncclComm_t> comm;
     void *d_stage = nullptr;         // in-process exchange: staging buffer on shard 0's device
+    double lr_scale = 1.0;           // local learning rate = lrate x lr_scale (cmi_group_set_lr_scale)
     double hp[5] = {0, 0, 0, 0, 0};  // regU regI regB regC globalMean
     bool have_hp = false;
     std::string err;
@@ -396,7 +397,8 @@ extern "C" int cmi_group_train_epoch(cmi_group_handle g, double lrate, double *l
     if (!g) return CMI_E_INVALID;
     if (int rc = need_ratings(g, "group_train_epoch")) return rc;
     const int W = (int)g->inst.size();
-    for (int s = 0; s < W; ++s) GRP_MEMBER(g, s, cmi_train_epoch_async(g->inst[(size_t)s], lrate));
+    const double local_lr = W > 1 ? lrate * g->lr_scale : lrate;
+    for (int s = 0; s < W; ++s) GRP_MEMBER(g, s, cmi_train_epoch_async(g->inst[(size_t)s], local_lr));
     if (W > 1)
         if (int rc = group_exchange(g)) return rc;
     // the one host synchronisation of the epoch: the (already global) loss of shard 0, then the other shards' streams
@@ -404,6 +406,16 @@ extern "C" int cmi_group_train_epoch(cmi_group_handle g, double lrate, double *l
     GRP_MEMBER(g, 0, cmi_last_loss(g->inst[0], &loss));
     for (int s = 1; s < W; ++s) GRP_MEMBER(g, s, cmi_last_loss(g->inst[(size_t)s], &other)); // also surfaces a stalled owner epoch of that shard
     if (loss_out) *loss_out = loss;
+    return CMI_OK;
+}
+
+// The mean merge divides every item row's move by W: at equal rate a W-shard run needs 1.2x / 1.4x / 1.6x the epochs of the sequential
+// run for the same training RMSE (W = 2 / 4 / 8).  Scaling the LOCAL rate by sqrt(W) brings that to <= 1.2x, lr x W diverges at W = 8
+// (tests/exp_merge_rule.py --time-to-rmse).  The host keeps steering the base rate (bold driver); default 1.
+extern "C" int cmi_group_set_lr_scale(cmi_group_handle g, double scale) {
+    if (!g) return CMI_E_INVALID;
+    if (!(scale > 0.0)) GRP_FAIL(g, CMI_E_INVALID, "group_set_lr_scale: scale must be positive");
+    g->lr_scale = scale;
     return CMI_OK;
 }
 

@@ -320,6 +320,10 @@ int cmi_group_set_ratings(cmi_group_handle g, int64_t n, const int32_t *u, const
 int cmi_group_set_state(cmi_group_handle g, int which, const void *src, int64_t count, int dtype);
 int cmi_group_get_state(cmi_group_handle g, int which, void *dst, int64_t count, int dtype);
 int cmi_group_train_epoch(cmi_group_handle g, double lrate, double *loss_out);
+/* local learning rate of every shard = lrate x scale when the group has more than one shard (default 1).  The mean merge divides an
+ * item row's move by the shard count, so at equal rate a sharded run needs more epochs for the same training RMSE (1.2x / 1.4x / 1.6x
+ * at 2 / 4 / 8 shards); scale = sqrt(n_shards) recovers it to <= 1.2x -- what the Java / C++ hosts set */
+int cmi_group_set_lr_scale(cmi_group_handle g, double scale);
 int cmi_group_train(cmi_group_handle g, int num_iters, double init_lrate, double max_lrate, int bold_driver, double decay, int early_stop,
                     double *losses, double *lrates, int *iters_run, double *final_lrate);
 int cmi_group_train_from(cmi_group_handle g, int first_iter, double prev_loss, int num_iters, double init_lrate, double max_lrate,

@@ -130,6 +130,9 @@ final class GpuSupport {
                 NativeMF.groupSetRatingsCsr(g, tm.getRowPointers(), tm.getColumnIndices(), tm.getData(), ui[0], ui[1], ct[0], ct[1]);
             }
             r.copyIn(Dev.ofGroup(g));
+            // the mean merge slows convergence per epoch (1.2x / 1.4x / 1.6x at 2 / 4 / 8 shards); sqrt(N) on the LOCAL rate recovers
+            // it to <= 1.2x while isConverged()'s bold driver keeps steering the base rate (DESIGN.md section 7); -Dcarskit.shards.lrscale=1 opts out
+            NativeMF.groupSetLrScale(g, Double.parseDouble(System.getProperty("carskit.shards.lrscale", Double.toString(Math.sqrt(nShards)))));
             for (int iter = 1; iter <= r.iterations(); iter++) {
                 double loss = NativeMF.groupTrainEpoch(g, r.learnRate());
                 if (r.epochDone(iter, loss)) break;

@@ -78,6 +78,8 @@ public final class NativeMF {
     public static native void groupGetMatrix(long g, int which, double[][] rows);
     public static native void groupSetVector(long g, int which, double[] v);
     public static native void groupGetVector(long g, int which, double[] v);
+    /** cmi_group_set_lr_scale: local learning rate = lRate x scale (GpuSupport sets sqrt(nShards): near-sequential epochs-to-RMSE) */
+    public static native void groupSetLrScale(long g, double scale);
     /** cmi_group_train_epoch: every shard's local pass + the merge of the item-side moves; returns the GLOBAL loss */
     public static native double groupTrainEpoch(long g, double lRate);
     /** cmi_group_eval_ratings: {MAE, RMSE, NMAE, rMAE, rRMSE, count}, test tuples routed to the shard that owns their user */

@@ -459,6 +459,10 @@ JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_groupGetVector(JNIEnv *env,
     env->SetDoubleArrayRegion(v, 0, (jsize)p.size(), p.data());
 }
 
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_groupSetLrScale(JNIEnv *env, jclass, jlong g, jdouble scale) {
+    throw_group(env, (cmi_group_handle)g, cmi_group_set_lr_scale((cmi_group_handle)g, scale));
+}
+
 JNIEXPORT jdouble JNICALL Java_carskit_alg_gpu_NativeMF_groupTrainEpoch(JNIEnv *env, jclass, jlong g, jdouble lRate) {
     double loss = 0;
     throw_group(env, (cmi_group_handle)g, cmi_group_train_epoch((cmi_group_handle)g, lRate, &loss));

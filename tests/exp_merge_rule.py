@@ -25,8 +25,11 @@ from tests import util  # noqa: E402
 USER_SIDE = ("P", "userBias", "ucBias")
 
 
-def run_sharded(model, train, test, k, world, rule, epochs, lr0=util.LR, seed=77):
-    """Train `epochs` bold-driver epochs with `world` in-process ranks; returns (test RMSE, losses)."""
+def run_sharded(model, train, test, k, world, rule, epochs, lr0=util.LR, seed=77, track=None, stop_at=None):
+    """Train `epochs` bold-driver epochs with `world` in-process ranks; returns (test RMSE, losses, train RMSE).
+    rule: "sum" | "mean" | "adaptive" | "adaptive_tr" | "weighted" (per item / per cell, every rank's move weighted by its share of
+    that item's ratings: equals "mean" on uniform data, differs under skew) ; lr0 may be scaled by the caller (lr x sqrt(W), lr x W).
+    track: a list that receives the TRAINING RMSE of the assembled model after every epoch; stop_at: stop as soon as it is <= this."""
     gm = float(train.r.sum() / np.count_nonzero(train.r))
     st = synth.init_state(model, train, k, seed=seed)
     ranks = []
@@ -42,6 +45,30 @@ def run_sharded(model, train, test, k, world, rule, epochs, lr0=util.LR, seed=77
     if model not in util.TWO_D:
         for t in range(train.n):
             n_jc[train.j[t], conds[train.ctx[t]]] += 1
+    # "weighted": rank r's share of the ratings of item j (of cell (j, cond))
+    if rule == "weighted" and world > 1:
+        w_j, w_jc = [], []
+        for o, lo, hi in ranks:
+            m = (train.u >= lo) & (train.u < hi)
+            nj = np.bincount(train.j[m], minlength=train.n_items).astype(np.float64)
+            w_j.append(nj / np.maximum(n_j, 1.0))
+            njc = np.zeros((train.n_items, train.n_conds))
+            if model not in util.TWO_D:
+                for t in np.flatnonzero(m):
+                    njc[train.j[t], conds[train.ctx[t]]] += 1
+            w_jc.append(njc / np.maximum(n_jc, 1.0))
+
+    def assembled():
+        full = {n: ranks[0][0].state[n] for n in names}
+        for n in st:
+            if n in USER_SIDE:
+                full[n] = np.concatenate([o.state[n].reshape(hi - lo, -1) for o, lo, hi in ranks]).reshape(st[n].shape)
+        return full
+
+    def train_rmse_now():
+        trctx = None if model in util.TWO_D else train.ctx
+        return util.c_oracle(model, train, k, assembled(), gm).eval_ratings(train.u, train.j, trctx, train.r, 1.0, 5.0)["RMSE"]
+
     lr, last = lr0, 0.0
     losses = []
     for it in range(1, epochs + 1):
@@ -66,6 +93,11 @@ def run_sharded(model, train, test, k, world, rule, epochs, lr0=util.LR, seed=77
                     a = np.maximum(a, 1e-12)
                     cc = world * (-np.expm1(-a / world)) / (-np.expm1(-a))
                     merged = start[n] + delta / cc
+                elif rule == "weighted":
+                    merged = start[n].copy()
+                    for (o, _, _), wj, wjc in zip(ranks, w_j, w_jc):
+                        d = o.state[n] - start[n]
+                        merged += d * (wj[:, None] if n == "Q" else wj if n == "itemBias" else wjc)
                 else:
                     merged = start[n] + delta / c
                 for o, _, _ in ranks:
@@ -76,16 +108,45 @@ def run_sharded(model, train, test, k, world, rule, epochs, lr0=util.LR, seed=77
         if it > 1:   # IterativeRecommender.updateLRate, bold driver (IterativeRecommender.java:216-229)
             lr = lr * 1.05 if abs(last) > abs(loss) else lr * 0.5
         last = loss
+        if track is not None or stop_at is not None:
+            tr_now = train_rmse_now()
+            if track is not None:
+                track.append(tr_now)
+            if stop_at is not None and tr_now <= stop_at:
+                break
     # evaluate with the assembled global model
-    full = {n: ranks[0][0].state[n] for n in names}
-    for n in st:
-        if n in USER_SIDE:
-            full[n] = np.concatenate([o.state[n].reshape(hi - lo, -1) for o, lo, hi in ranks]).reshape(st[n].shape)
+    full = assembled()
     ev = util.c_oracle(model, test, k, full, gm)
     tctx = None if model in util.TWO_D else test.ctx
     trctx = None if model in util.TWO_D else train.ctx
     tr = util.c_oracle(model, train, k, full, gm).eval_ratings(train.u, train.j, trctx, train.r, 1.0, 5.0)["RMSE"]
     return ev.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)["RMSE"], losses, tr
+
+
+def time_to_rmse(args):
+    """how many epochs does a W-rank run need to reach the TRAINING RMSE the sequential (W = 1) run has after
+    `--epochs` epochs -- for the mean rule, the per-item weighted mean, and the mean with the local learning rate scaled by sqrt(W) / W
+    (the bold driver keeps steering from there).  'near-linear in updates/s' is not near-linear in time-to-RMSE: this is the factor."""
+    data = synth.generate(args.users, args.items, 4, 4, args.users * args.per_user, seed=5, item_zipf=args.item_zipf or None)
+    train, test = synth.split(data, 0.2)
+    base_track = []
+    base_rmse, _, _ = run_sharded(args.model, train, test, args.k, 1, "sum", args.epochs, track=base_track)
+    target = base_track[-1]
+    print(json.dumps({"world": 1, "rule": "sequential", "epochs": args.epochs, "train_rmse": target, "test_rmse": base_rmse}), flush=True)
+    out = []
+    cap = 6 * args.epochs
+    for world in (2, 4, 8):
+        for name, rule, scale in (("mean", "mean", 1.0), ("weighted", "weighted", 1.0), ("mean, lr x sqrt(W)", "mean", world ** 0.5),
+                                  ("mean, lr x W", "mean", float(world)), ("sum", "sum", 1.0)):
+            tr = []
+            rmse, losses, _ = run_sharded(args.model, train, test, args.k, world, rule, cap, lr0=util.LR * scale, track=tr, stop_at=target)
+            reached = bool(tr and tr[-1] <= target)
+            rec = {"world": world, "rule": name, "epochs_to_target": len(tr) if reached else None, "slowdown_vs_sequential":
+                   (len(tr) / args.epochs) if reached else None, "train_rmse_at_stop": tr[-1] if tr else None, "test_rmse": rmse,
+                   "loss_increases": int(np.sum(np.diff(losses) > 0)), "diverged": bool(not np.all(np.isfinite(losses)))}
+            print(json.dumps(rec), flush=True)
+            out.append(rec)
+    return out
 
 
 def main():
@@ -98,7 +159,11 @@ def main():
     ap.add_argument("--per-user", type=int, default=25)
     ap.add_argument("--rules", default="sum,mean,adaptive,adaptive_tr")
     ap.add_argument("--shapes", default="strong,weak")
+    ap.add_argument("--time-to-rmse", action="store_true", help="epochs to reach the sequential run's training RMSE (table in DESIGN.md section 7)")
+    ap.add_argument("--item-zipf", type=float, default=0.0)
     args = ap.parse_args()
+    if args.time_to_rmse:
+        return time_to_rmse(args)
     out = []
     for shape in args.shapes.split(","):
         for world in (1, 2, 4, 8):

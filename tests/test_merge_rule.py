@@ -37,3 +37,23 @@ def test_sum_rule_overshoots_at_eight_ranks(data):
     _, sum_losses, _ = run_sharded("CAMF_CI", train, test, 16, 8, "sum", 20)
     assert np.sum(np.diff(sum_losses) > 0) >= 1
     assert sum_losses[-1] >= 1.5 * mean_losses[-1]
+
+
+def test_sqrt_lr_scaling_recovers_time_to_rmse(data):
+    """updates/s scale with W, epochs-to-equal-RMSE do not -- the mean merge needs 1.2x / 1.4x / 1.6x the epochs
+    of the sequential run at W = 2 / 4 / 8 (table in DESIGN.md section 7, tests/exp_merge_rule.py --time-to-rmse).  Scaling the LOCAL
+    learning rate by sqrt(W) (the host's bold driver keeps steering the base rate) brings that to <= 1.2x without the overshoot of
+    the sum rule or of lr x W (which diverges at W = 8); it is what the hosts set for a sharded group (cmi_group_set_lr_scale)."""
+    from tests import util
+    train, test = data
+    track = []
+    run_sharded("CAMF_CI", train, test, 16, 1, "sum", 20, track=track)
+    target = track[-1]
+    for world in (4, 8):
+        plain, scaled = [], []
+        run_sharded("CAMF_CI", train, test, 16, world, "mean", 80, track=plain, stop_at=target)
+        _, losses, _ = run_sharded("CAMF_CI", train, test, 16, world, "mean", 80, lr0=util.LR * world ** 0.5, track=scaled, stop_at=target)
+        assert np.all(np.isfinite(losses))
+        assert scaled[-1] <= target and plain[-1] <= target, (world, scaled[-1], plain[-1], target)
+        assert len(scaled) <= 1.3 * 20, (world, len(scaled))              # near the sequential run's epoch count
+        assert len(scaled) < len(plain), (world, len(scaled), len(plain))   # and ahead of the unscaled mean
