@@ -186,12 +186,107 @@ def secondary_workload(name, steps, warmup, device, flags, regs, lr):
     return out
 
 
+def bench_fm(args):
+    """--workload c4: one GPU's share of BASELINE configs[3] (FM k=64, 5 M users x 500 K items x 64 conditions, 200 M ratings over
+    8 GPUs -> 625 K users / 25 M ratings per GPU).  A step = one ALS sweep (FM.java:148-218: 1 + 3 + 3k coordinate phases)."""
+    k, n_users, n_items, n = 64, 625_000, 500_000, 25_000_000
+    data = synth.generate_fast(n_users, n_items, 4, 16, n)
+    p = data.n_users + data.n_items + data.n_conds
+    rng = np.random.default_rng(1)
+    g = capi.FMInstance(k, data.n_users, data.n_items, data.n_conds, data.n_dims)
+    g.set_hparams(synth.java_float(0.01), synth.java_float(0.02))
+    g.set_ratings(data.u, data.j, data.ctx, data.r)
+    g.set_model(0.0, rng.random(p), 0.1 * rng.standard_normal((p, k)))
+    g.init()
+    for _ in range(args.warmup):
+        g.sweep()
+    g.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.sweep()
+    g.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    phases = 4 + 3 * k
+    # the REFERENCE algorithm's compulsory traffic per rating and sweep (SURVEY 8d, fp64): every phase reads and writes errors[],
+    # every factor phase also one Q column entry.  This implementation does not store Q at all and moves far fewer bytes; what
+    # bounds it is the rate of random 16-byte gathers of the item / context phases (one per rating and factor), not HBM bandwidth.
+    ref_bytes = 16 * (3 + 3 * k) + 16 * 3 * k
+    gathers = data.n * (1 + 2 * k)        # item + context phases gather {error, V[user][f]} per rating (the user phase streams)
+    out = {"metric": "FM ALS rating-sweeps/sec, k=%d" % k, "value": data.n / dt, "unit": "rating-sweeps/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic",
+           "config": {"workload": "c4 share: FM k=%d, %d users x %d items x %d conditions, %d ratings (one GPU of BASELINE configs[3])"
+                                  % (k, data.n_users, data.n_items, data.n_conds, data.n), "phases_per_sweep": phases},
+           "roofline": {"bound": "hbm", "achieved": data.n * ref_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": data.n * ref_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                        "bytes_model": "the reference ALGORITHM's compulsory traffic (errors[] r+w per phase, one Q entry r+w per factor phase): "
+                                       "%d B per rating-sweep; this implementation never stores Q, so its real traffic is far lower" % ref_bytes,
+                        "limiter": "random 16-byte gather rate of the item / context phases",
+                        "gathers_per_s": gathers / dt, "gather_rate_ceiling_per_s": 54e9,
+                        "gather_frac": gathers / dt / 54e9,
+                        "gather_ceiling_source": "tools/micro/atomic_f64.hip, tools/micro/gather_window.hip (53-56 G random 16-B gathers/s on this part)",
+                        "kernel": "fm_field_phase (item / context field), fm_user_phase", "avg_phase_us": dt * 1e6 / phases}}
+    print(json.dumps(out), flush=True)
+
+
+def bench_rank(args):
+    """--workload rank: Recommender.evalRankings (Recommender.java:668-964) for CAMF_CI k=128: every test (user, context) query scores
+    ALL candidate items -- the one GEMM-shaped operation of this code base (f32 matrix cores).  A step = one whole evaluation."""
+    model, k = "CAMF_CI", 128
+    data = synth.generate_fast(50_000, 20_000, 4, 6, 2_000_000, seed=11)
+    train, test = synth.split(data, 0.2, seed=3)
+    state = synth.init_state(model, train, k, seed=5)
+    inst = capi.Instance(model, k, train.n_users, train.n_items, train.n_conds, flags=args.flags)
+    inst.set_hparams(1e-4, 1e-4, 1e-4, 1e-3, float(train.r.mean()))
+    inst.set_ratings(train.u, train.j, train.ctx, train.r, train.ctx_ptr, train.ctx_conds)
+    inst.set_states(state)
+    tr, te = (train.u, train.j, train.ctx, train.r), (test.u, test.j, test.ctx, test.r)
+    for _ in range(args.warmup):
+        inst.eval_rankings(tr, te, bin_thold=2.5, num_recs=10)
+    ms, walls = [], []
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        res = inst.eval_rankings(tr, te, bin_thold=2.5, num_recs=10)
+        walls.append(time.perf_counter() - t0)
+        dev_ms, flops = inst.last_rank_ms()
+        ms.append(dev_ms)
+    dev = float(np.mean(ms)) * 1e-3
+    nq = res["n_queries"]
+    out = {"metric": "evalRankings queries/sec, %s k=%d" % (model, k), "value": nq / dev, "unit": "queries/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dev * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "rank: %s k=%d, %d users x %d items, %d queries x %d candidates, top-10" %
+                                  (model, k, train.n_users, train.n_items, nq, int(len(np.unique(train.j)))),
+                      "host_wall_ms_per_step": float(np.mean(walls)) * 1e3,
+                      "note": "value = queries / device time of the scoring loop (HIP events); the host wall adds the plan (candidates, "
+                              "queries, exclusions) and the per-query measures"},
+           "roofline": {"bound": "mfma", "achieved": flops / dev / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / dev / 1e12 / 157.3,
+                        "flops_model": "2 x queries x candidates x padded operand length of the contraction, over the WHOLE scoring loop "
+                                       "(operand gather + contraction + selection)", "kernel": "rank_gemm_mfma_f32 (v_mfma_f32_32x32x2_f32)"},
+           "AUC10": res["AUC10"]}
+    if not args.no_cpu_baseline:
+        from oracle import oracle_c
+        orc = oracle_c.Oracle(model, k, train.n_users, train.n_items, train.n_conds, train.u, train.j, train.ctx, train.r, train.ctx_ptr,
+                              train.ctx_conds, {n_: v.astype(np.float64) for n_, v in state.items()}, float(train.r.mean()), 1e-4, 1e-4, 1e-4, 1e-3)
+        cand = np.unique(train.j).astype(np.int32)
+        qs = list(zip(test.u[:200].tolist(), test.ctx[:200].tolist()))
+        t0 = time.perf_counter()
+        for (u, c) in qs:
+            np.argsort(-orc.predict_items(u, c, cand), kind="stable")[:10]
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": len(qs) / dt, "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": "%d queries x %d candidates: the C oracle's predict() per pair + a stable sort" % (len(qs), len(cand))}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + ["c4", "rank"],
+                    help="c3 (default) / northstar / c5 / small: the SGD hot path; c4: one GPU's share of the FM configuration (ALS sweep); "
+                         "rank: evalRankings (top-N scoring on the f32 matrix cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tuples", type=int, default=20_000_000)
     ap.add_argument("--no-f64", action="store_true", help="skip the secondary fp64-state measurement")
@@ -212,6 +307,10 @@ def main():
                          "one thread per fold), each on its own stream; value then aggregates all of them")
     args = ap.parse_args()
 
+    if args.workload in ("c4", "rank"):
+        if args.gpus != 1:
+            raise SystemExit("--workload %s is a single-GPU measurement (FM over ranks: carskit_amd.dist.ShardedFMRunner, tests/test_dist_fm_gloo.py)" % args.workload)
+        return bench_fm(args) if args.workload == "c4" else bench_rank(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -284,8 +284,16 @@ hipError_t rank_run_device(hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, c
     // never written back)
     const int kp = (ops.k_logical + 15) / 16 * 16; // multiple of both kernels' k step
     auto up128 = [](int64_t v) { return (size_t)((v + 127) / 128 * 128); };
-    // query batch: keep the score slab around 1 GiB (it is written once and re-read topn times)
-    int64_t bq = std::max<int64_t>(64, ((int64_t)1 << 30) / ((int64_t)nc * (int64_t)sizeof(T)));
+    // fp32 state with many candidates: the slab-free form (rank_kernels.hip, RankFilter) -- a sample of the candidates gives every query a
+    // lower bound of its N-th best score, the full contraction then appends only the scores that can still make the list; the
+    // [queries x candidates] score slab (21.5 GB for 270 K queries x 20 K items) is never written or re-read
+    bool filtered = false;
+    if constexpr (sizeof(T) == 4) filtered = rank_filter_usable(nc, kp, topn);
+    const int ns = filtered ? rank_filter_sample(nc) : nc;
+    const int cap = 1024;
+    // query batch: keep the score slab (or the sample slab + the survivor lists) around 1 GiB
+    const int64_t per_query = filtered ? (int64_t)ns * 4 + (int64_t)cap * 8 : (int64_t)nc * (int64_t)sizeof(T);
+    int64_t bq = std::max<int64_t>(64, ((int64_t)1 << 30) / per_query);
     bq = std::min<int64_t>(bq, nq);
     if (const char *e = getenv("CMI_RANK_BATCH")) bq = std::max<int64_t>(1, std::min<int64_t>(atoll(e), nq));
 
@@ -293,13 +301,23 @@ hipError_t rank_run_device(hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, c
     int32_t *dcand = nullptr, *dqu = nullptr, *dqc = nullptr, *dexcl = nullptr, *dtop = nullptr, *dcount = nullptr;
     int64_t *dexptr = nullptr;
     double *dscore = nullptr;
+    float *dtau = nullptr;
+    int *dcnt = nullptr, *dover = nullptr;
+    int2 *dlist = nullptr;
+    T *dS_full = nullptr; // slab form, allocated only if a filtered batch overflows
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {
         if (e == hipSuccess) e = hipMalloc(p, std::max<size_t>(bytes, 8));
     };
     alloc((void **)&dB, up128(nc) * kp * sizeof(T));
     alloc((void **)&dA, up128(bq) * kp * sizeof(T));
-    alloc((void **)&dS, (size_t)bq * nc * sizeof(T));
+    alloc((void **)&dS, (size_t)bq * (size_t)ns * sizeof(T));
+    if (filtered) {
+        alloc((void **)&dtau, (size_t)bq * 4);
+        alloc((void **)&dcnt, (size_t)bq * 4);
+        alloc((void **)&dover, 4);
+        alloc((void **)&dlist, (size_t)bq * cap * sizeof(int2));
+    }
     alloc((void **)&drc, (size_t)bq * sizeof(T));
     alloc((void **)&dcand, (size_t)nc * 4);
     alloc((void **)&dqu, (size_t)nq * 4);
@@ -324,9 +342,31 @@ hipError_t rank_run_device(hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, c
     for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += bq) {
         const int n = (int)std::min<int64_t>(bq, nq - q0);
         e = ops.build_queries(dA, drc, dqu + q0, dqc + q0, n, kp, stream);
-        if (e == hipSuccess)
-            e = rank_launch_score<T>(dA, dB, drc, dS, n, nc, kp, dexptr, dexcl, (int)q0, thold, topn, dtop, dscore, dcount,
-                                     stream);
+        if (e != hipSuccess) break;
+        if (filtered) {
+            if constexpr (sizeof(T) == 4) {
+                e = hipMemsetAsync(dover, 0, 4, stream);
+                if (e == hipSuccess)
+                    e = rank_launch_score_filtered((const float *)dA, (const float *)dB, (const float *)drc, (float *)dS, n, nc, kp, dexptr, dexcl,
+                                                   (int)q0, thold, topn, dtau, dcnt, dlist, cap, dover, dtop, dscore, dcount, stream);
+                int over = 0;
+                if (e == hipSuccess) e = hipMemcpyAsync(&over, dover, 4, hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream); // one host round trip per ~100 K queries
+                if (e == hipSuccess && over > 0) {
+                    // some query keeps more than `cap` candidates at or above its bound (heavy ties, or too few qualifying scores in the
+                    // sample): this batch goes through the slab form, in sub-batches of the slab's size
+                    const int64_t sub = std::max<int64_t>(64, ((int64_t)1 << 30) / ((int64_t)nc * 4));
+                    if (!dS_full) e = hipMalloc((void **)&dS_full, (size_t)std::min<int64_t>(sub, bq) * (size_t)nc * 4);
+                    for (int64_t s0 = 0; s0 < n && e == hipSuccess; s0 += sub) {
+                        const int m = (int)std::min<int64_t>(sub, n - s0);
+                        e = rank_launch_score<T>(dA + (size_t)s0 * kp, dB, drc + s0, dS_full, m, nc, kp, dexptr, dexcl, (int)(q0 + s0), thold, topn,
+                                                 dtop, dscore, dcount, stream);
+                    }
+                }
+            }
+        } else {
+            e = rank_launch_score<T>(dA, dB, drc, dS, n, nc, kp, dexptr, dexcl, (int)q0, thold, topn, dtop, dscore, dcount, stream);
+        }
     }
     if (e == hipSuccess) e = hipEventRecord(ev1, stream);
     top_idx.resize((size_t)nq * topn);
@@ -338,7 +378,7 @@ hipError_t rank_run_device(hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, c
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e == hipSuccess && ms) e = hipEventElapsedTime(ms, ev0, ev1);
     if (flops) *flops = 2.0 * (double)nq * (double)nc * (double)kp;
-    void *ptrs[] = {dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount};
+    void *ptrs[] = {dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount, dtau, dcnt, dover, dlist, dS_full};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     return e;

@@ -184,3 +184,58 @@ def test_fm_rankings_match_oracle(k, strategy):
     res, lists = g.eval_rankings(_arrays(train), _arrays(test), bin_thold=-5.0, num_recs=10, strategy=strategy, with_lists=True)
     assert len(ref_lists) > 20    # (the reference's FM regularises with size*reg: its scores sit far below the rating scale)
     _assert_same(res, lists, ref, ref_lists, 1e-9, 1e-8)
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: v for k, v in env.items() if v is not None})
+    for k, v in env.items():
+        if v is None:
+            os.environ.pop(k, None)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("model,num_recs,thold", [("CAMF_CI", 10, 2.5), ("BiasedMF", 5, -1.0), ("CAMF_CU", 64, 3.9)])
+def test_slab_free_scoring_is_identical_to_the_slab_form(model, num_recs, thold):
+    """fp32 state with many candidates takes the slab-free path (round 3: a sample of the candidates bounds every query's N-th best
+    score, the full contraction keeps only the scores that can still make the list -- the [queries x candidates] slab is never
+    written).  Same contraction, exact filter: lists, scores and measures must be IDENTICAL to the slab form's, item for item."""
+    train, test, orc, inst = _setup(model, 32, 0, epochs=2, n_users=120, n_items=1600, n=9000, seed=8)
+    kw = dict(bin_thold=thold, num_recs=num_recs, with_lists=True)
+    slab = _with_env({"CMI_RANK_NO_FILTER": "1"}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
+    free = _with_env({"CMI_RANK_NO_FILTER": None, "CMI_RANK_SAMPLE": "128"}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
+    assert free[0]["n_queries"] == slab[0]["n_queries"] > 0
+    assert set(free[1]) == set(slab[1])
+    for key in slab[1]:
+        assert free[1][key] == slab[1][key], key                         # (item, score) pairs, bit for bit, same order
+    for m, v in slab[0].items():
+        assert free[0][m] == v or (math.isnan(v) and math.isnan(free[0][m])), m
+    # and the slab form itself is the one the oracle tests above pin (fp32 bar)
+    ref, ref_lists = _oracle_eval(orc, train, test, bin_thold=thold, num_recs=num_recs)
+    _assert_same(slab[0], slab[1], ref, ref_lists, 0.03, 1e-4, same_items=False)
+
+
+def test_slab_free_scoring_falls_back_when_a_list_overflows():
+    """An all-tied model keeps EVERY candidate at its bound: the survivor lists overflow (> 1024 per query) and the batch is repeated
+    through the slab form -- ties still resolve in HashSet candidate order."""
+    rng = np.random.default_rng(5)
+    n_items = 1500
+    d = synth.generate(25, n_items, 2, 3, 6000, seed=6)
+    tr_mask = rng.random(d.n) < 0.8
+    train = (d.u[tr_mask], d.j[tr_mask], d.ctx[tr_mask], d.r[tr_mask])
+    test = (d.u[~tr_mask], d.j[~tr_mask], d.ctx[~tr_mask], d.r[~tr_mask])
+    inst = capi.Instance("BiasedMF", 4, 25, n_items, d.n_conds)
+    inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+    inst.set_states({"P": np.zeros((25, 4)), "Q": np.zeros((n_items, 4)), "userBias": np.zeros(25), "itemBias": np.zeros(n_items)})
+    tt = [list(zip(*(a.tolist() for a in x))) for x in (train, test)]
+    ref, ref_lists = rank_oracle.eval_rankings(lambda u, jj, c: 3.0, tt[0], tt[1], bin_thold=2.5, num_recs=10)
+    res, lists = _with_env({"CMI_RANK_NO_FILTER": None, "CMI_RANK_SAMPLE": "128"},
+                           lambda: inst.eval_rankings(train, test, bin_thold=2.5, num_recs=10, with_lists=True))
+    _assert_same(res, lists, ref, ref_lists, 1e-15, 0.0)
