@@ -72,10 +72,23 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(model, k, data, state, gm, regs, lr, budget_tuples):
+def cpu_baseline(model, k, data, state, gm, regs, lr, budget_tuples, rank_queries=None):
     """The oracle (order-exact fp64 restatement of the Java loop, 1 thread) on a prefix of the same tuples; then five of them
-    side by side = what the reference's `cv -k 5 -p on` (one Java thread per fold, CARSKit.java:395-412) gets out of the host."""
+    side by side = what the reference's `cv -k 5 -p on` (one Java thread per fold, CARSKit.java:395-412) gets out of the host.
+    rank_queries = (test data, n): the evalRankings baseline instead -- the oracle's predict() per (query, candidate) pair + a stable sort."""
     from oracle import oracle_c
+    if rank_queries is not None:
+        test, nq = rank_queries
+        orc = oracle_c.Oracle(model, k, data.n_users, data.n_items, data.n_conds, data.u, data.j, data.ctx, data.r, data.ctx_ptr,
+                              data.ctx_conds, {n_: np.asarray(v, dtype=np.float64) for n_, v in state.items()}, gm, *regs)
+        cand = np.unique(data.j).astype(np.int32)
+        qs = list(zip(test.u[:nq].tolist(), test.ctx[:nq].tolist()))
+        t0 = time.perf_counter()
+        for (u, c) in qs:
+            np.argsort(-orc.predict_items(u, c, cand), kind="stable")[:10]
+        dt = time.perf_counter() - t0
+        return {"value": len(qs) / dt, "unit": "queries/s", "cores": 1, "kind": "port",
+                "sample": "%d queries x %d candidates: the C oracle's predict() per pair + a stable sort" % (len(qs), len(cand))}
     m = min(data.n, budget_tuples)
 
     def make():
@@ -265,17 +278,7 @@ def bench_rank(args):
                                        "(operand gather + contraction + selection)", "kernel": "rank_gemm_mfma_f32 (v_mfma_f32_32x32x2_f32)"},
            "AUC10": res["AUC10"]}
     if not args.no_cpu_baseline:
-        from oracle import oracle_c
-        orc = oracle_c.Oracle(model, k, train.n_users, train.n_items, train.n_conds, train.u, train.j, train.ctx, train.r, train.ctx_ptr,
-                              train.ctx_conds, {n_: v.astype(np.float64) for n_, v in state.items()}, float(train.r.mean()), 1e-4, 1e-4, 1e-4, 1e-3)
-        cand = np.unique(train.j).astype(np.int32)
-        qs = list(zip(test.u[:200].tolist(), test.ctx[:200].tolist()))
-        t0 = time.perf_counter()
-        for (u, c) in qs:
-            np.argsort(-orc.predict_items(u, c, cand), kind="stable")[:10]
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": len(qs) / dt, "unit": "queries/s", "cores": 1, "kind": "port",
-                               "sample": "%d queries x %d candidates: the C oracle's predict() per pair + a stable sort" % (len(qs), len(cand))}
+        out["cpu_baseline"] = cpu_baseline(model, k, train, state, float(train.r.mean()), (1e-4, 1e-4, 1e-4, 1e-3), 0.0, 0, rank_queries=(test, 200))
     print(json.dumps(out), flush=True)
 
 

@@ -88,6 +88,7 @@ SYMBOLS = [
     ("cmi_measure_hbm", C.c_int, [C.c_int, _i64, C.POINTER(C.c_double)]),
     ("cmi_schedule_info", C.c_int, [_vp, C.POINTER(_i64)]),
     ("cmi_schedule_traffic", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("cmi_schedule_note", C.c_char_p, [_vp]),
     ("cmi_exchange_setup", C.c_int, [_vp, _i64, C.POINTER(_vp), C.POINTER(_i64)]),
     ("cmi_group_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_uint, C.POINTER(_vp)]),
     ("cmi_group_destroy", C.c_int, [_vp]),
@@ -625,6 +626,9 @@ class Instance:
             d["teams"] = d["flow_blocks"] >> 32
             d["flow_blocks"] &= 0xffffffff
         return d
+
+    def schedule_note(self):
+        return self.L.cmi_schedule_note(self.h).decode()
 
     def schedule_traffic(self):
         """HBM bytes per epoch derived from the loaded schedule: {"sector", "own", "algorithmic", "models_reuse"} (cmi_schedule_traffic)"""

@@ -488,6 +488,11 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     // the hub-chain levels first: wide data is theirs
     const bool use_chain = !h->flow && !h->serial && chain_ok && n > 0 && try_chain(h, n, u, j, csch);
     bool use_owner = h->want_owner;
+    h->sched_note.clear();
+    if (!use_owner && !use_chain && !h->flow && !h->serial && !h->want_two_lane && n >= ((int64_t)1 << 16) &&
+        !has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict) && !(h->flags & CMI_FLAG_NO_OWNER))
+        h->sched_note = "narrow dependency levels on a large data set (heavy-tailed degrees?) and no owner kernel for this configuration "
+                        "(limits: <= 384 conditions, k <= 256 (fp64: 128)): the level walk runs -- order-exact, roughly 10x slower on such data";
     if (!use_owner && !use_chain && !h->flow && !h->serial && !h->want_two_lane && !(h->flags & (CMI_FLAG_SCHED_CHAIN | CMI_FLAG_NO_OWNER)) &&
         !getenv("CMI_NO_OWNER") && has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict)) {
         // Narrow levels on a large data set = heavy-tailed degrees: every level costs a kernel boundary or a workgroup barrier (>= 2 us),
@@ -512,6 +517,10 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             // the tagged record table is addressed through one buffer resource: below 4 GB
             const int64_t rec_bytes = owner_record_stride(h->model, h->k, h->n_conds, h->f64, hub_item) * 8;
             const bool table_fits = ((int64_t)(hub_item ? h->n_users : h->n_items) + 4096) * rec_bytes < ((int64_t)1 << 32) - 65536;
+            h->sched_note.clear();
+            if (skewed && !table_fits)
+                h->sched_note = "heavy-tailed degrees, but the owner epoch's tagged record table would exceed 4 GB (too many spoke rows at this k): "
+                                "the level walk runs instead -- order-exact, roughly 10x slower on such data";
             if (skewed && table_fits) {
                 // owner: the hottest chains, or the bulk spread over ~1 000 owners at ~0.5 us per tuple of a list that switches rows
                 const double est_owner = std::max(std::max(std::max(mu, mj) * 0.3e-6, std::min(mu, mj) * 1e-6), (double)n * 0.5e-6 / 1024.0) + 0.3e-3;
@@ -880,6 +889,8 @@ extern "C" int cmi_schedule_traffic(cmi_handle h, int64_t out[4]) {
     }
     return CMI_OK;
 }
+
+extern "C" const char *cmi_schedule_note(cmi_handle h) { return h ? h->sched_note.c_str() : ""; }
 
 // ---- training -------------------------------------------------------------------------------------
 

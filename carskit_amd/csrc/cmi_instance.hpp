@@ -29,6 +29,7 @@ struct cmi_instance {
     int64_t own_stride = 0;
     std::vector<int64_t> split_off; // two-lane schedule: first tail position of every level
     std::string err;
+    std::string sched_note; // why a slower schedule than the data calls for is running (cmi_schedule_note); empty = nothing to say
     hipStream_t stream = nullptr;
     void *state[CMI_STATE_COUNT] = {};
     int64_t state_count[CMI_STATE_COUNT] = {};

@@ -309,6 +309,7 @@ class IterativeRecommender {
             check(cmi_set_ratings(h_, (int64_t)r2.size(), u2.data(), j2.data(), nullptr, r2.data(), 0, nullptr, nullptr), h_,
                   "cmi_set_ratings");
         }
+        if (*cmi_schedule_note(h_) && log_) log_(std::string("note: ") + cmi_schedule_note(h_));
         for (auto &kv : state) // copy-in
             check(cmi_set_state(h_, kv.first, kv.second.data(), (int64_t)kv.second.size(), CMI_DTYPE_F64), h_, "cmi_set_state");
         if (conf_.earlyStop == "MAE" || conf_.earlyStop == "RMSE") { // evaluated after every epoch: keep the test tuples on the device

@@ -283,6 +283,9 @@ int cmi_last_loss(cmi_handle h, double *loss_out);
  * info[7]=workgroups of the dataflow launch; for CAMF_C the number of conflict-free CRS blocks its epoch is cut into
  * (0: the serial wave) */
 int cmi_schedule_info(cmi_handle h, int64_t info[8]);
+/* "" or one sentence saying why cmi_set_ratings could not pick the schedule the data calls for (heavy-tailed degrees outside the owner
+ * epoch's limits: the order-exact level walk runs, correct but roughly 10x slower) -- visible to the host instead of silent */
+const char *cmi_schedule_note(cmi_handle h);
 /* HBM bytes one epoch of the loaded schedule has to move, derived from the schedule (no reference counterpart: measurement).
  * out[0]: every scattered scalar billed at its 64-byte sector, read and written (hub-chain schedules: hub row, hub bias and hub
  * context-bias row once per UNIT; spoke row, tuple stream, spoke bias and spoke context-bias cells per tuple); out[1]: the same with

@@ -253,3 +253,21 @@ def test_owner_epochs_of_concurrent_folds_do_not_starve_each_other():
             lo = orc.epoch(util.LR)
             assert abs(lo - lg) <= 1e-10 * abs(lo)
         assert_state_equal(orc, inst, exact=False, atol=1e-11)
+
+
+def test_schedule_note_when_owner_limits_force_the_level_walk():
+    """outside the owner epoch's limits (here: more than 384 conditions) heavy-tailed data silently got the 10x slower level
+    walk; cmi_schedule_note now says so (and is empty when nothing is lost)."""
+    data = synth.generate(3000, 400, 4, 100, 70_000, seed=21, item_zipf=1.1)      # 400 conditions > 384
+    st = synth.init_state("CAMF_CI", data, 64, seed=3, dtype=np.float32)
+    inst = capi.Instance("CAMF_CI", 64, data.n_users, data.n_items, data.n_conds)
+    inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+    inst.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
+    inst.set_states(st)
+    assert inst.schedule_info()["kind"] == "level" and "level walk" in inst.schedule_note()
+    l0 = inst.train_epoch(util.LR)
+    assert np.isfinite(l0)
+    small = util.small_data(n_users=50, n_items=20, n=800, seed=2)                # tiny uniform data: nothing to report
+    i2 = capi.Instance("CAMF_CI", 8, small.n_users, small.n_items, small.n_conds)
+    i2.set_ratings(small.u, small.j, small.ctx, small.r, small.ctx_ptr, small.ctx_conds)
+    assert i2.schedule_note() == ""

@@ -53,6 +53,52 @@ __global__ __launch_bounds__(256) void rows(char *tab, float *bias, uint64_t n_r
     }
 }
 
+// (3) "rows live where they are used next": every tuple owns an arena slot; a group READS its rows sequentially (stream order) and
+// WRITES each updated row to a random slot (the slot of the row's next tuple).  bias = 1: the scalar rides in a padded 576-B slot? no --
+// here it is still a separate gather/scatter table; bias = 0: rows only.
+template <int BIAS>
+__global__ __launch_bounds__(256) void rows_next_use(char *arena, float *bias, uint64_t n_slots, uint64_t n_bias, uint64_t n_groups, int per,
+                                                     uint64_t salt) {
+    const uint64_t g = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    if (g >= n_groups) return;
+    const uint64_t first = (g * (uint64_t)per) % (n_slots - (uint64_t)per);
+    float4 a0 = *reinterpret_cast<float4 *>(arena + first * 512 + 16 * l16), a1 = *reinterpret_cast<float4 *>(arena + first * 512 + 256 + 16 * l16);
+    for (int i = 0; i < per; ++i) {
+        float4 n0 = a0, n1 = a1;
+        if (i + 1 < per) {
+            n0 = *reinterpret_cast<float4 *>(arena + (first + i + 1) * 512 + 16 * l16);
+            n1 = *reinterpret_cast<float4 *>(arena + (first + i + 1) * 512 + 256 + 16 * l16);
+        }
+        const uint64_t dst = mix((g * (uint64_t)per + (uint64_t)i) ^ salt) % n_slots;
+        a0.x += 1.f; a1.w += 1.f;
+        *reinterpret_cast<float4 *>(arena + dst * 512 + 16 * l16) = a0;
+        *reinterpret_cast<float4 *>(arena + dst * 512 + 256 + 16 * l16) = a1;
+        if (BIAS == 1 && l16 == 0) {
+            const uint64_t b = mix(dst ^ 0x55) % n_bias;
+            bias[b] += 1.f;
+        }
+        a0 = n0; a1 = n1;
+    }
+}
+
+static float time_next_use(int bias, char *arena, float *btab, uint64_t n_slots, uint64_t n_bias) {
+    const uint64_t n_groups = 1u << 20;
+    const int per = 4;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        const dim3 grid((unsigned)((n_groups + 15) / 16));
+        hipEventRecord(e0);
+        if (bias == 0) hipLaunchKernelGGL((rows_next_use<0>), grid, dim3(256), 0, 0, arena, btab, n_slots, n_bias, n_groups, per, (uint64_t)rep * 7919);
+        else hipLaunchKernelGGL((rows_next_use<1>), grid, dim3(256), 0, 0, arena, btab, n_slots, n_bias, n_groups, per, (uint64_t)rep * 7919);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    return best;
+}
+
 static float time_variant(int bias, char *tab, float *btab, uint64_t n_rows, uint64_t stride, uint64_t window_rows) {
     const uint64_t n_groups = 1u << 20; // 4 M row visits per launch
     const int per = 4;
@@ -97,6 +143,20 @@ int main() {
             printf("{\"exp\": \"window\", \"n_rows\": 10000000, \"window_MB\": %llu, \"bias\": %d, \"ms\": %.4f, \"row_GBps\": %.0f}\n",
                    (unsigned long long)wmb, bias, ms, visits * 1024.0 / ms / 1e6);
         }
+    }
+    // (3) sequential reads + random writes over arenas of 25.6 GB (C3: one slot per tuple) -- allocated separately
+    hipFree(tab);
+    for (uint64_t gb : {(uint64_t)2, (uint64_t)25}) {
+        const size_t bytes = (size_t)gb << 30;
+        char *arena;
+        if (hipMalloc(&arena, bytes) != hipSuccess) { printf("{\"exp\": \"next_use\", \"error\": \"alloc %llu GB failed\"}\n", (unsigned long long)gb); continue; }
+        hipMemset(arena, 0, bytes);
+        for (int bias : {0, 1}) {
+            const float ms = time_next_use(bias, arena, btab, bytes / 512, 1000000);
+            printf("{\"exp\": \"next_use\", \"arena_GB\": %llu, \"bias\": %d, \"ms\": %.4f, \"row_GBps\": %.0f}\n", (unsigned long long)gb, bias, ms,
+                   visits * 1024.0 / ms / 1e6);
+        }
+        hipFree(arena);
     }
     return 0;
 }
