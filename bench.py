@@ -150,7 +150,7 @@ def roofline(model, k, n_dims, data_n, info, sched, kern_ms, esize, workload):
            "kernel": ("sgd_chain_level<%s,%s,hub=%s>" % (tname, model, info["kind"][6:]) if chain
                       else "sgd_owner<%s,%s,hub=%s> (latency-bound by the hottest row's chain, not by HBM)" % (tname, model, info["kind"][6:])
                       if info["kind"].startswith("owner") else "sgd_level_fast_f32<%s,%d>" % (model, k // 64) if esize == 4 else "sgd_level_generic<double,%s>" % model),
-           "schedule": info["kind"], "launches_per_epoch": launches,
+           "schedule": info["kind"], "spoke_arena": sched.get("spoke_arena", False), "launches_per_epoch": launches,
            "units_per_epoch": info["flow_blocks"] if chain else None,
            "avg_launch_us": avg_us}
     if traffic and abs(out["traffic_over_model"] - 1.0) > 0.05:

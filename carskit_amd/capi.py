@@ -43,6 +43,8 @@ FLAG_SCHED_CHAIN = 0x80
 FLAG_NO_CHAIN = 0x100
 FLAG_SCHED_OWNER = 0x200
 FLAG_NO_OWNER = 0x400
+FLAG_SPOKE_ARENA = 0x800
+FLAG_NO_ARENA = 0x1000
 OWN_HUB_FWD, OWN_HUB_LATE, OWN_HUB_STORE, OWN_SPK_FWD, OWN_SPK_STORE = 1, 2, 4, 8, 16
 
 # every symbol include/carskit_mi355x.h declares: (name, restype, argtypes)
@@ -634,7 +636,7 @@ class Instance:
         """HBM bytes per epoch derived from the loaded schedule: {"sector", "own", "algorithmic", "models_reuse"} (cmi_schedule_traffic)"""
         out = (_i64 * 4)()
         self._chk(self.L.cmi_schedule_traffic(self.h, out))
-        return {"sector": out[0], "own": out[1], "algorithmic": out[2], "models_reuse": bool(out[3])}
+        return {"sector": out[0], "own": out[1], "algorithmic": out[2], "models_reuse": bool(out[3] & 1), "spoke_arena": bool(out[3] & 2)}
 
     def stream(self):
         s = _vp()

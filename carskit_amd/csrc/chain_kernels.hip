@@ -50,16 +50,25 @@ struct SpokeRow {
     T sc;
     T *psc;
     int spoke, cond;
+    T *dst; // where the updated row goes: the model table's row, or (spoke arena) the slot of the row's next tuple
 };
 
+// pos / nx: stream position of the tuple and of the same spoke row's next tuple (only read when the spoke arena is on)
 template <typename T, int MODEL, int NV, bool RAGGED, bool HUB_ITEM>
-__device__ __forceinline__ void chain_load_spoke(const SgdArgs<T> &a, int spoke, int cond, int l16, int K, SpokeRow<T, NV> &r) {
+__device__ __forceinline__ void chain_load_spoke(const SgdArgs<T> &a, int spoke, int cond, int l16, int K, SpokeRow<T, NV> &r, int64_t pos = 0,
+                                                 int nx = 0) {
     using M = Traits<MODEL>;
     using V = typename Vec16<T>::type;
     constexpr int E = Vec16<T>::E;
     constexpr bool SC = HUB_ITEM ? M::has_uc : M::has_ic;  // context-bias table on the spoke side (the scalar bias: chain_unit)
     T *tab = HUB_ITEM ? a.P : a.Q;
-    const V *row = reinterpret_cast<const V *>(tab + (size_t)spoke * K) + l16;
+    // Spoke arena (a.arena != null, wave-uniform): the row of the tuple at stream position `pos` sits in arena[pos] -- a unit's rows are
+    // CONTIGUOUS there and units follow each other in launch order, so the spoke reads of a level are one sequential stream instead of
+    // random 512-B rows over a multi-GB table (north_star: 2.4 address-translation misses per tuple).  The updated
+    // row is written to the slot of the same row's NEXT tuple: random full-line writes.
+    const T *src = a.arena ? a.arena + (size_t)pos * K : tab + (size_t)spoke * K;
+    r.dst = a.arena ? a.arena + (size_t)nx * K : tab + (size_t)spoke * K;
+    const V *row = reinterpret_cast<const V *>(src) + l16;
     r.spoke = spoke;
     r.cond = cond;
 #pragma unroll
@@ -141,8 +150,7 @@ __device__ __forceinline__ void chain_step(const SgdArgs<T> &a, const ChainHp<T>
     if (HC) chain_lds_order();
 
     T lsum = (T)0;
-    T *stab = HUB_ITEM ? a.P : a.Q;
-    V *srow = reinterpret_cast<V *>(stab + (size_t)cur.spoke * K) + l16;
+    V *srow = reinterpret_cast<V *>(cur.dst) + l16;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         T sn[E];
@@ -170,10 +178,11 @@ __device__ __forceinline__ void chain_step(const SgdArgs<T> &a, const ChainHp<T>
 
 // LDS per 16-lane group: [hub context-bias row: n_conds x T (if the hub side has one)] [ratings: 16 x T] [spoke scalar biases: 16 x T]
 // [spoke ids: 16 x i32]
+// [next positions: 16 x i32 (spoke arena)]
 // [condition ids: 16 x dmax x i32] -- the unit's ids are staged once (one coalesced round trip) so that the chain loop has no
 // dependent global id -> row load pairs.
 __host__ __device__ inline size_t chain_group_lds(int n_conds_hub, int dmax, size_t esize) {
-    size_t b = (size_t)n_conds_hub * esize + 32 * esize + 16 * 4 + (size_t)16 * (dmax > 0 ? dmax : 0) * 4;
+    size_t b = (size_t)n_conds_hub * esize + 32 * esize + 32 * 4 + (size_t)16 * (dmax > 0 ? dmax : 0) * 4;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -182,7 +191,7 @@ __host__ __device__ inline size_t chain_group_lds(int n_conds_hub, int dmax, siz
 template <typename T>
 struct ChainPre {
     int32_t tb, len;
-    int hub, sp0, cd0, my_sp;
+    int hub, sp0, cd0, my_sp, my_nx, nx0;
     T my_rr;
     int cdv[4];
 };
@@ -197,10 +206,13 @@ __device__ __forceinline__ ChainPre<T> chain_prefetch_ids(const SgdArgs<T> &a, i
     p.sp0 = HUB_ITEM ? a.su[tb] : a.sj[tb];
     p.cd0 = (HAS_CTX && l16 < dmax) ? a.sconds[(int64_t)tb * dmax + l16] : -1;
     p.my_sp = 0;
+    p.my_nx = 0;
     p.my_rr = (T)0;
+    p.nx0 = a.next_pos ? a.next_pos[tb] : 0;
     if (l16 < p.len) {
         p.my_sp = HUB_ITEM ? a.su[tb + l16] : a.sj[tb + l16];
         p.my_rr = a.sr[tb + l16];
+        if (a.next_pos) p.my_nx = a.next_pos[tb + l16];
     }
     const int n_cd = p.len * dmax; // <= 256 condition ids, staged 16 per pass
 #pragma unroll
@@ -227,7 +239,8 @@ __device__ __forceinline__ void chain_unit(const SgdArgs<T> &a, const ChainHp<T>
     T *s_rr = s_hc + (HC ? a.n_conds : 0);
     T *s_sb = s_rr + 16;
     int *s_sp = reinterpret_cast<int *>(s_sb + 16);
-    int *s_cd = s_sp + 16;
+    int *s_nx = s_sp + 16;
+    int *s_cd = s_nx + 16;
     const int n_cd = len * dmax;
 
     // ---- round trip 3: the hub row comes on chip once, together with the first spoke row
@@ -265,11 +278,12 @@ __device__ __forceinline__ void chain_unit(const SgdArgs<T> &a, const ChainHp<T>
     T my_sb = (T)0;
     if (SB && l16 < len) my_sb = sb_tab[pre.my_sp];
     SpokeRow<T, NV> A, B;
-    chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, pre.sp0, pre.cd0, l16, K, A);
+    chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, pre.sp0, pre.cd0, l16, K, A, tb, pre.nx0);
 
     // ---- ids, the spoke biases and the hub's context-bias row into LDS
     if (l16 < len) {
         s_sp[l16] = pre.my_sp;
+        s_nx[l16] = pre.my_nx;
         s_rr[l16] = pre.my_rr;
         if (SB) s_sb[l16] = my_sb;
     }
@@ -302,12 +316,12 @@ __device__ __forceinline__ void chain_unit(const SgdArgs<T> &a, const ChainHp<T>
     const int pairs = len >> 1;
     for (int t = 0; t < pairs; ++t) {
         const int i = 2 * t;
-        chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, B);
+        chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[i + 1], l16 < dmax ? s_cd[(i + 1) * dmax + l16] : -1, l16, K, B, tb + i + 1, s_nx[i + 1]);
         chain_lds_order();
         chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, s_sb + i, A, s_rr[i], l16, K, gloss);
         {
             const int nx = i + 2 < len ? i + 2 : len - 1;
-            chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[nx], l16 < dmax ? s_cd[nx * dmax + l16] : -1, l16, K, A);
+            chain_load_spoke<T, MODEL, NV, RAGGED, HUB_ITEM>(a, s_sp[nx], l16 < dmax ? s_cd[nx * dmax + l16] : -1, l16, K, A, tb + nx, s_nx[nx]);
         }
         chain_lds_order();
         chain_step<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, h, hb, s_hc, s_sb + i + 1, B, s_rr[i + 1], l16, K, gloss);
@@ -635,6 +649,44 @@ __global__ __launch_bounds__(256) void sgd_chain_small(SgdArgs<float> a, const i
         if (tid == 0) a.loss_part[slot0 + blockIdx.x] = sum;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// spoke arena <-> model table: one 16-byte vector per thread, a row's first tuple slot holds its live value between epochs
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool TO_ARENA>
+__global__ __launch_bounds__(256) void arena_rows_kernel(T *table, T *arena, const int32_t *__restrict__ first_pos, int64_t n_rows, int k) {
+    using V = typename Vec16<T>::type;
+    constexpr int E = Vec16<T>::E;
+    const int vec_per_row = k / E;                       // k % E == 0 (the chain kernels' own requirement for vector rows)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = i / vec_per_row;
+    const int v = (int)(i % vec_per_row);
+    if (row >= n_rows) return;
+    const int32_t p = first_pos[row];
+    if (p < 0) return;                                   // a row without tuples never enters the arena
+    V *t = reinterpret_cast<V *>(table + (size_t)row * k) + v;
+    V *a = reinterpret_cast<V *>(arena + (size_t)p * k) + v;
+    if (TO_ARENA) *a = *t;
+    else *t = *a;
+}
+template <typename T>
+hipError_t launch_arena_scatter(const T *table, T *arena, const int32_t *first_pos, int64_t n_rows, int k, hipStream_t s) {
+    const int64_t n = n_rows * (k / Vec16<T>::E);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL((arena_rows_kernel<T, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, const_cast<T *>(table), arena, first_pos, n_rows, k);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_arena_gather(T *table, const T *arena, const int32_t *first_pos, int64_t n_rows, int k, hipStream_t s) {
+    const int64_t n = n_rows * (k / Vec16<T>::E);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL((arena_rows_kernel<T, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, table, const_cast<T *>(arena), first_pos, n_rows, k);
+    return hipGetLastError();
+}
+template hipError_t launch_arena_scatter<float>(const float *, float *, const int32_t *, int64_t, int, hipStream_t);
+template hipError_t launch_arena_scatter<double>(const double *, double *, const int32_t *, int64_t, int, hipStream_t);
+template hipError_t launch_arena_gather<float>(float *, const float *, const int32_t *, int64_t, int, hipStream_t);
+template hipError_t launch_arena_gather<double>(double *, const double *, const int32_t *, int64_t, int, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
 // host-side launchers

@@ -120,6 +120,14 @@ static void free_eval_set(cmi_instance *h) {
 
 // the resident test tuples index the context table of the ratings they were uploaded against: they go with it
 static void free_ratings(cmi_instance *h) {
+    if (h->arena_on && h->arena_valid && !h->table_valid) cmi_sync_table_from_arena(h); // the live rows are in the arena: bring them home first
+    for (void **p : {(void **)&h->d_arena, (void **)&h->d_next, (void **)&h->d_first})
+        if (*p) {
+            hipFree(*p);
+            *p = nullptr;
+        }
+    h->arena_on = h->arena_valid = false;
+    h->table_valid = true;
     free_eval_set(h);
     if (h->graph_exec) {
         hipGraphExecDestroy(h->graph_exec);
@@ -324,6 +332,10 @@ extern "C" int cmi_set_state(cmi_handle h, int which, const void *src, int64_t c
     if (!h) return CMI_E_INVALID;
     if (int rc = check_state_args(h, which, src, count, dtype)) return rc;
     if (count == 0) return CMI_OK;
+    if (h->arena_on && which == h->arena_which) { // the whole table is rewritten: the arena's copy of these rows is stale from here on
+        h->table_valid = true;
+        h->arena_valid = false;
+    }
     CMI_HIP(h, hipSetDevice(h->device));
     const bool src_f64 = dtype == CMI_DTYPE_F64;
     if (src_f64 == h->f64) {
@@ -348,6 +360,7 @@ extern "C" int cmi_get_state(cmi_handle h, int which, void *dst, int64_t count, 
     if (!h) return CMI_E_INVALID;
     if (int rc = check_state_args(h, which, dst, count, dtype)) return rc;
     if (count == 0) return CMI_OK;
+    if (int rc = cmi_sync_table_from_arena(h)) return rc;
     CMI_HIP(h, hipSetDevice(h->device));
     const bool dst_f64 = dtype == CMI_DTYPE_F64;
     if (dst_f64 == h->f64) {
@@ -369,6 +382,7 @@ extern "C" int cmi_get_state(cmi_handle h, int which, void *dst, int64_t count, 
 extern "C" int cmi_state_device_ptr(cmi_handle h, int which, void **ptr, int64_t *count, int *dtype) {
     if (!h || which < 0 || which >= CMI_STATE_COUNT) return CMI_E_INVALID;
     if (!cmi_model_has(h->model, which)) CMI_FAIL(h, CMI_E_INVALID, "state %d does not exist in model %d", which, h->model);
+    if (int rc = cmi_sync_table_from_arena(h)) return rc; // (spoke arena: the table is current as of this call only)
     if (ptr) *ptr = h->state[which];
     if (count) *count = h->state_count[which];
     if (dtype) *dtype = h->f64 ? CMI_DTYPE_F64 : CMI_DTYPE_F32;
@@ -737,6 +751,47 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // cp/cc are locals
     }
     if (e == hipSuccess && h->chain) e = upload((void **)&h->d_unit_off, csch.unit_off, h->stream);
+    if (e == hipSuccess && h->chain && !(h->flags & CMI_FLAG_NO_ARENA) && !getenv("CMI_NO_ARENA") && h->k >= 64 && h->k % (h->f64 ? 2 : 4) == 0) {
+        // Spoke arena (SgdArgs::arena): worth its memory when the spoke table is large -- random 512-B rows over >= 2 GiB run at ~0.5 of
+        // the HBM peak (address-translation misses, DRAM page misses), sequential reads + random full-line writes at ~0.7
+        // (tools/micro/row_bias.hip: 4.10 vs 5.73 TB/s) -- and smaller tables gain nothing (5.58 vs 5.61).
+        const int64_t spokes = h->chain_hub_item ? h->n_users : h->n_items;
+        const size_t table_bytes = (size_t)spokes * (size_t)h->k * esize(h), arena_bytes = (size_t)n * (size_t)h->k * esize(h);
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const bool forced = (h->flags & CMI_FLAG_SPOKE_ARENA) || getenv("CMI_ARENA");
+        if (forced || (table_bytes >= ((size_t)2 << 30) && (double)arena_bytes <= 0.6 * (double)free_b)) {
+            // next_pos[p] = stream position of the next tuple of the same spoke row (its tuples sit in ascending levels, hence ascending
+            // positions); the last one wraps to the first: that is where the row waits for the next epoch
+            std::vector<int32_t> nxt((size_t)n), first((size_t)spokes, -1);
+            const std::vector<int32_t> &sp = h->chain_hub_item ? su : sj;
+            for (int64_t p = n - 1; p >= 0; --p) {
+                const int32_t r = sp[(size_t)p];
+                nxt[(size_t)p] = first[(size_t)r]; // -1 for the row's last tuple: patched below
+                first[(size_t)r] = (int32_t)p;
+            }
+            for (int64_t p = 0; p < n; ++p)
+                if (nxt[(size_t)p] < 0) nxt[(size_t)p] = first[(size_t)sp[(size_t)p]];
+            e = upload((void **)&h->d_next, nxt, h->stream);
+            if (e == hipSuccess) e = upload((void **)&h->d_first, first, h->stream);
+            if (e == hipSuccess) e = hipMalloc(&h->d_arena, arena_bytes);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // nxt / first are locals
+            if (e == hipSuccess) {
+                h->arena_on = true;
+                h->arena_valid = false;
+                h->table_valid = true;
+                h->arena_which = h->chain_hub_item ? CMI_STATE_P : CMI_STATE_Q;
+            } else if (!forced) { // not enough memory after all: run without
+                (void)hipGetLastError();
+                for (void **q : {(void **)&h->d_arena, (void **)&h->d_next, (void **)&h->d_first})
+                    if (*q) {
+                        hipFree(*q);
+                        *q = nullptr;
+                    }
+                e = hipSuccess;
+            }
+        }
+    }
     if (e == hipSuccess && h->owner) {
         const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
         h->own_stride = owner_record_stride(h->model, h->k, h->n_conds, h->f64, h->owner_hub_item);
@@ -830,7 +885,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     }
     h->n = n;
     h->tuple_bytes = h->owner ? (ns + (int64_t)h->n_owners * 2 * owner_depth()) * (int64_t)owner_rec_bytes(owner_mask_words(h->model, h->n_conds))
-                              : ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + (h->flow ? 8 : 0)) + (h->chain ? 4 * (h->n_units + 1) : 0);
+                              : ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + (h->flow ? 8 : 0)) + (h->chain ? 4 * (h->n_units + 1) : 0) + (h->arena_on ? 4 * ns : 0);
     h->have_ratings = true;
     return CMI_OK;
 }
@@ -877,11 +932,12 @@ extern "C" int cmi_schedule_traffic(cmi_handle h, int64_t out[4]) {
         const bool hub_b = hi ? bj : bu, spk_b = hi ? bu : bj, hub_c = hi ? ic : uc, spk_c = hi ? uc : ic;
         const int64_t unit_sect = row + (hub_b ? 2 * SECT : 0) + (hub_c ? ctx_row_sect : 0) + 4;
         const int64_t unit_own = row + (hub_b ? 2 * e : 0) + (hub_c ? ctx_row_own : 0) + 4;
-        const int64_t tup_sect = stream + row + (spk_b ? 2 * SECT : 0) + (spk_c ? cells_sect : 0);
-        const int64_t tup_own = stream + row + (spk_b ? 2 * e : 0) + (spk_c ? cells_own : 0);
+        const int64_t arena_idx = h->arena_on ? 4 : 0; // next_pos of the spoke arena
+        const int64_t tup_sect = stream + arena_idx + row + (spk_b ? 2 * SECT : 0) + (spk_c ? cells_sect : 0);
+        const int64_t tup_own = stream + arena_idx + row + (spk_b ? 2 * e : 0) + (spk_c ? cells_own : 0);
         out[0] = h->n_units * unit_sect + n * tup_sect;
         out[1] = h->n_units * unit_own + n * tup_own;
-        out[3] = 1;
+        out[3] = 1 | (h->arena_on ? 2 : 0);
     } else {
         out[0] = n * (stream + 2 * row + S * 2 * SECT + T * cells_sect);
         out[1] = n * (stream + 2 * row + S * 2 * e + T * cells_own);
@@ -913,7 +969,30 @@ static SgdArgs<T> make_args(cmi_instance *h) {
     a.k = h->k;
     a.n_conds = h->n_conds;
     a.dmax = h->dmax;
+    if (h->arena_on) {
+        a.arena = (T *)h->d_arena;
+        a.next_pos = h->d_next;
+    }
     return a;
+}
+
+// ---- spoke arena <-> model table ------------------------------------------------------------------------------------------
+int cmi_sync_table_from_arena(cmi_instance *h) {
+    if (!h->arena_on || h->table_valid) return CMI_OK;
+    CMI_HIP(h, hipSetDevice(h->device));
+    const int64_t rows = h->arena_which == CMI_STATE_P ? h->n_users : h->n_items;
+    CMI_HIP(h, h->f64 ? launch_arena_gather<double>((double *)h->state[h->arena_which], (const double *)h->d_arena, h->d_first, rows, h->k, h->stream)
+                      : launch_arena_gather<float>((float *)h->state[h->arena_which], (const float *)h->d_arena, h->d_first, rows, h->k, h->stream));
+    h->table_valid = true;
+    return CMI_OK;
+}
+static int sync_arena_from_table(cmi_instance *h) {
+    if (!h->arena_on || h->arena_valid) return CMI_OK;
+    const int64_t rows = h->arena_which == CMI_STATE_P ? h->n_users : h->n_items;
+    CMI_HIP(h, h->f64 ? launch_arena_scatter<double>((const double *)h->state[h->arena_which], (double *)h->d_arena, h->d_first, rows, h->k, h->stream)
+                      : launch_arena_scatter<float>((const float *)h->state[h->arena_which], (float *)h->d_arena, h->d_first, rows, h->k, h->stream));
+    h->arena_valid = true;
+    return CMI_OK;
 }
 
 template <typename T>
@@ -1109,6 +1188,10 @@ static int enqueue_epoch(cmi_instance *h, double lrate) {
             CMI_FAIL(h, CMI_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
         }
     }
+    if (h->arena_on) {
+        if (int rc = sync_arena_from_table(h)) return rc; // (outside the captured graph: only after the table was rewritten)
+        h->table_valid = false;                          // this epoch moves the spoke rows inside the arena only
+    }
     CMI_HIP(h, hipEventRecord(h->ev0, h->stream));
     if (graph) CMI_HIP(h, hipGraphLaunch(h->graph_exec, h->stream));
     else {
@@ -1239,6 +1322,7 @@ extern "C" int cmi_exchange_setup(cmi_handle h, int64_t pad_to, void **bucket, i
     // so a merge would silently leave them diverged between the ranks
     if (is_ext_model(h->model)) CMI_FAIL(h, CMI_E_UNSUPPORTED, "exchange: model %d is a single serial chain and is not sharded", h->model);
     CMI_HIP(h, hipSetDevice(h->device));
+    if (int rc = cmi_sync_table_from_arena(h)) return rc;
     CMI_HIP(h, hipStreamSynchronize(h->stream));
     if (h->d_xbucket) hipFree(h->d_xbucket);
     if (h->d_xsnap) hipFree(h->d_xsnap);
@@ -1283,6 +1367,8 @@ extern "C" int cmi_exchange_pack(cmi_handle h) {
     if (!h) return CMI_E_INVALID;
     if (!h->d_xbucket) CMI_FAIL(h, CMI_E_INVALID, "exchange_pack: call cmi_exchange_setup first");
     CMI_HIP(h, hipSetDevice(h->device));
+    if (h->arena_on && h->arena_which == CMI_STATE_Q) // the item side is the spoke side (hub = user): Q's live rows are in the arena
+        if (int rc = cmi_sync_table_from_arena(h)) return rc;
     for (size_t i = 0; i < h->x_which.size(); ++i) {
         const int w = h->x_which[i];
         const size_t ob = (size_t)h->x_off[i] * esize(h);
@@ -1295,6 +1381,10 @@ extern "C" int cmi_exchange_apply(cmi_handle h, double scale) {
     if (!h) return CMI_E_INVALID;
     if (!h->d_xbucket) CMI_FAIL(h, CMI_E_INVALID, "exchange_apply: call cmi_exchange_setup first");
     CMI_HIP(h, hipSetDevice(h->device));
+    if (h->arena_on && h->arena_which == CMI_STATE_Q) { // Q is rewritten below: the arena's copy is stale until the next epoch re-scatters
+        if (int rc = cmi_sync_table_from_arena(h)) return rc;
+        h->arena_valid = false;
+    }
     for (size_t i = 0; i < h->x_which.size(); ++i) {
         const int w = h->x_which[i];
         const size_t ob = (size_t)h->x_off[i] * esize(h);
@@ -1415,6 +1505,7 @@ static int eval_common(cmi_instance *h, int64_t n, const int32_t *u, const int32
     for (int c = 0; c < 5; ++c) sums[c] = 0.0;
     if (n == 0) return CMI_OK;
     CMI_HIP(h, hipSetDevice(h->device));
+    if (int rc = cmi_sync_table_from_arena(h)) return rc;
     int32_t *du = nullptr, *dj = nullptr, *dctx = nullptr;
     double *dr = nullptr, *dpreds = nullptr, *dpart = nullptr;
     const int blocks = eval_blocks(n);
@@ -1519,6 +1610,7 @@ extern "C" int cmi_eval_resident(cmi_handle h, double min_rate, double max_rate,
     if (!h || !out) return CMI_E_INVALID;
     if (h->n_eval <= 0) CMI_FAIL(h, CMI_E_INVALID, "eval_resident: call cmi_set_eval_ratings first");
     CMI_HIP(h, hipSetDevice(h->device));
+    if (int rc = cmi_sync_table_from_arena(h)) return rc;
     const int64_t n = h->n_eval;
     const int blocks = eval_blocks(n);
     std::vector<double> part((size_t)blocks * 5);

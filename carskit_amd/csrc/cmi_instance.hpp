@@ -19,6 +19,13 @@ struct cmi_instance {
     bool chain = false, chain_hub_item = true; // hub-chain level schedule: level_off holds UNIT indices, d_unit_off the units
     int32_t *d_unit_off = nullptr;
     int64_t n_units = 0;
+    // spoke arena of the hub-chain schedule (SgdArgs::arena): one slot per tuple, in schedule order.  While arena_valid the live value of
+    // every spoke row with tuples sits in the slot of its FIRST tuple; the model table (state[arena_which]) is only current while
+    // table_valid -- every reader of the table goes through cmi_sync_table_from_arena first
+    bool arena_on = false, arena_valid = false, table_valid = true;
+    int arena_which = 0;             // CMI_STATE_P (hub = item) or CMI_STATE_Q (hub = user)
+    void *d_arena = nullptr;
+    int32_t *d_next = nullptr, *d_first = nullptr;
     // owner (dataflow) schedule: one persistent launch, d_own_recs = the owners' lists, d_tagged = the spoke side's tagged records
     bool want_owner = false, owner = false, owner_hub_item = true;
     int n_owners = 0, n_team = 0; // owners [0, n_team) run as teams of three wavefronts
@@ -102,3 +109,6 @@ int cmi_train_loop(const std::function<int(double, double *)> &epoch, std::strin
                    int *iters_run, double *final_lrate);
 int cmi_eval_sums(cmi_instance *h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r, double min_rate,
                   double max_rate, double sums[5]);
+
+// spoke arena (cmi_api.cpp): make the model table current (gather from the arena) / say that the table was rewritten (arena stale)
+int cmi_sync_table_from_arena(cmi_instance *h);

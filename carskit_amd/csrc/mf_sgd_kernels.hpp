@@ -29,7 +29,18 @@ struct SgdArgs {
     const HParams *hp;
     double *loss_part;         // one slot per workgroup of the epoch (deterministic reduction)
     int32_t k, n_conds, dmax;
+    // hub-chain levels, large spoke table (round 3): the spoke row of the tuple at stream position p lives in arena[p] -- read
+    // sequentially in schedule order -- and goes back to arena[next_pos[p]], the slot of the same row's next tuple (chain_kernels.hip).
+    // null: rows are read from / written to the model table itself
+    T *arena = nullptr;
+    const int32_t *next_pos = nullptr;
 };
+
+// spoke arena <-> model table (n_rows rows of k elements; first_pos[row] = stream position of the row's first tuple, -1: none)
+template <typename T>
+hipError_t launch_arena_scatter(const T *table, T *arena, const int32_t *first_pos, int64_t n_rows, int k, hipStream_t s);
+template <typename T>
+hipError_t launch_arena_gather(T *table, const T *arena, const int32_t *first_pos, int64_t n_rows, int k, hipStream_t s);
 
 struct LaunchCfg {
     int model;

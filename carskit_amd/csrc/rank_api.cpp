@@ -516,6 +516,7 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
                                  int32_t *top_items, double *top_scores) {
     if (!h) return CMI_E_INVALID;
     if (!out) CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: null output");
+    if (int rc = cmi_sync_table_from_arena(h)) return rc;
     if (n_train < 0 || n_test < 0 || (n_train > 0 && (!tu || !tj || !tctx)) || (n_test > 0 && (!su || !sj || !sctx || !sr)))
         CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: null tuple arrays");
     if (num_recs < 1)

@@ -528,8 +528,11 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
 // (2) the same contraction over ALL candidates with the filtering epilogue; (3) selection from the survivor lists.  *overflow (device)
 // counts rows whose list did not fit `cap`: the caller then repeats the batch through rank_launch_score.  Same scores, same lists.
 bool rank_filter_usable(int nc, int kp, int topn) {
-    const bool off = getenv("CMI_RANK_NO_FILTER") != nullptr; // (read per call: the tests switch it within one process)
-    return !off && getenv("CMI_RANK_VALU") == nullptr && topn <= 64 && kp % RG_BK == 0 && nc >= 4 * rank_filter_sample(nc);
+    // OPT-IN (CMI_RANK_FILTER=1): measured on the 270 K x 20 K case it is SLOWER than the slab form (35.1 vs 23.5 ms: the ~54 M atomic
+    // appends of the filtering epilogue cost more than the 21.5 GB slab write they replace, and the list selection adds 8 ms) -- kept,
+    // with its tests, as the record of that experiment.  Read per call: the tests switch it within one process.
+    const bool on = getenv("CMI_RANK_FILTER") != nullptr && getenv("CMI_RANK_NO_FILTER") == nullptr;
+    return on && getenv("CMI_RANK_VALU") == nullptr && topn <= 64 && kp % RG_BK == 0 && nc >= 4 * rank_filter_sample(nc);
 }
 int rank_filter_sample(int nc) {
     (void)nc;

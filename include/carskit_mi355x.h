@@ -106,6 +106,13 @@ extern "C" {
                                      * (owner_kernels.hip).  Order-exact like the level schedules; k <= 256 (fp64: 128), <= 384 conditions */
 #define CMI_FLAG_NO_OWNER 0x400u /* never pick the owner schedule automatically (it is picked for >= 2^16 tuples whose dependency levels
                                   * are narrow -- heavy-tailed degrees -- when its estimated epoch is at least twice shorter) */
+#define CMI_FLAG_SPOKE_ARENA 0x800u /* hub-chain schedule: keep the spoke rows in an arena of one slot per tuple, in schedule order -- the row
+                                      of the tuple at stream position p is READ from slot p (a level's spoke reads become one sequential
+                                      stream) and WRITTEN to the slot of the same row's next tuple.  Same arithmetic, same bits; costs
+                                      tuples x k x 4 (8) bytes of HBM.  Picked automatically when the spoke table is >= 2 GiB (random 512-B
+                                      rows over such a table run at 0.5 of the HBM peak, the arena form at 0.7) and the arena fits in 60 % of
+                                      the free device memory; CMI_FLAG_NO_ARENA opts out */
+#define CMI_FLAG_NO_ARENA 0x1000u
 #define CMI_FLAG_NO_GRAPH 0x10u  /* launch the per-level kernels eagerly instead of replaying a hipGraph */
 
 typedef struct cmi_instance *cmi_handle;
@@ -289,7 +296,7 @@ const char *cmi_schedule_note(cmi_handle h);
 /* HBM bytes one epoch of the loaded schedule has to move, derived from the schedule (no reference counterpart: measurement).
  * out[0]: every scattered scalar billed at its 64-byte sector, read and written (hub-chain schedules: hub row, hub bias and hub
  * context-bias row once per UNIT; spoke row, tuple stream, spoke bias and spoke context-bias cells per tuple); out[1]: the same with
- * scalars at their own size; out[2]: SURVEY 8(d)'s no-reuse algorithmic bytes; out[3]: 1 if on-chip hub reuse is modelled */
+ * scalars at their own size; out[2]: SURVEY 8(d)'s no-reuse algorithmic bytes; out[3]: bit 0 = on-chip hub reuse is modelled, bit 1 = the spoke arena is in use */
 int cmi_schedule_traffic(cmi_handle h, int64_t out[4]);
 /* GPU time of the most recent epoch's kernels measured with HIP events on cmi_stream() */
 int cmi_last_epoch_ms(cmi_handle h, float *ms);

@@ -19,6 +19,8 @@ public final class NativeMF {
     public static final int FLAG_STATE_F64 = 1, FLAG_SCHED_SERIAL = 2, FLAG_STRICT = 4, FLAG_NO_GRAPH = 16;
     /** schedule overrides (include/carskit_mi355x.h); the library picks hub-chain levels / the owner epoch / plain levels by itself */
     public static final int FLAG_SCHED_CHAIN = 0x80, FLAG_NO_CHAIN = 0x100, FLAG_SCHED_OWNER = 0x200, FLAG_NO_OWNER = 0x400;
+    /** spoke arena of the hub-chain schedule (picked automatically for spoke tables of 2 GiB and more) */
+    public static final int FLAG_SPOKE_ARENA = 0x800, FLAG_NO_ARENA = 0x1000;
     public static final int RANK_UCU = 0, RANK_UC = 1;
 
     /** cmi_create; returns the handle, throws RuntimeException(cmi_last_error) on failure. */

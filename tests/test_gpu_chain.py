@@ -181,3 +181,87 @@ def test_chain_tail_on_heavy_tailed_items_bitwise_equals_plain():
         lo_, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
         assert abs(lo_ - lg) <= 1e-11 * abs(lo_)
     assert_state_equal(orc, inst, exact=False, atol=1e-12)
+
+
+ARENA = capi.FLAG_SPOKE_ARENA
+
+
+@pytest.mark.parametrize("model", LEVEL_MODELS)
+@pytest.mark.parametrize("k,flags", [(64, 0), (100, 0), (128, 0), (256, 0), (64, F64), (128, F64)])
+@pytest.mark.parametrize("hub", ["item", "user"])
+def test_spoke_arena_is_bit_identical_and_every_reader_sees_the_live_rows(model, k, flags, hub):
+    """Round 3: the spoke arena (SgdArgs::arena; the default for spoke tables of 2 GiB and more, forced here) moves WHERE a spoke row
+    lives between its tuples -- read from the slot of its own tuple, written to the slot of the row's next tuple -- not what is computed:
+    the model must equal the table-resident form bit for bit, and everything that reads the model between epochs (get_state, evaluation,
+    prediction, a rewritten container, save / load) must see the rows that currently live in the arena."""
+    data = util.small_data(n_users=1200, n_items=260, n_dims=3, conds_per_dim=4, n=24000, seed=41)
+    train, test = synth.split(data, 0.2)
+    _, ref = _with_hub(hub, lambda: make_pair(model, train, k, CHAIN | flags | capi.FLAG_NO_ARENA))
+    orc, arena = _with_hub(hub, lambda: make_pair(model, train, k, CHAIN | flags | ARENA))
+    assert arena.schedule_traffic()["spoke_arena"] and not ref.schedule_traffic()["spoke_arena"]
+    tctx = None if model in util.TWO_D else test.ctx
+    for ep in range(4):
+        lr_, la_ = ref.train_epoch(util.LR), arena.train_epoch(util.LR)
+        assert lr_ == la_, (ep, lr_, la_)
+        if ep == 1:      # readers in the middle of training
+            for name, a in ref.get_states().items():
+                assert np.array_equal(a, arena.get_state(name)), name
+            er = ref.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+            ea = arena.eval_ratings(test.u, test.j, tctx, test.r, 1.0, 5.0)
+            assert er == ea
+            assert np.array_equal(ref.predict(test.u[:64], test.j[:64], None if tctx is None else tctx[:64]),
+                                  arena.predict(test.u[:64], test.j[:64], None if tctx is None else tctx[:64]))
+        if ep == 2:      # a container rewritten from the host between epochs (both the arena-backed one and the other side)
+            st = ref.get_states()
+            for name in ("P", "Q"):
+                new = (st[name] * 0.5).astype(st[name].dtype)
+                ref.set_state(name, new)
+                arena.set_state(name, new)
+    for name, a in ref.get_states().items():
+        assert np.array_equal(a, arena.get_state(name)), name
+
+
+def test_spoke_arena_survives_save_load_and_a_new_rating_set(tmp_path):
+    data = util.small_data(n_users=900, n_items=200, n_dims=3, conds_per_dim=3, n=15000, seed=43)
+    _, ref = make_pair("CAMF_CI", data, 128, CHAIN | capi.FLAG_NO_ARENA)
+    _, a = make_pair("CAMF_CI", data, 128, CHAIN | ARENA)
+    for _ in range(2):
+        ref.train_epoch(util.LR)
+        a.train_epoch(util.LR)
+    p = tmp_path / "arena.cmi"
+    a.save_model(p)                                              # goes through get_state: the live rows
+    _, b = make_pair("CAMF_CI", data, 128, CHAIN | ARENA, seed=9)
+    b.load_model(p)                                              # goes through set_state: the arena is refilled before the next epoch
+    ref.train_epoch(util.LR)
+    b.train_epoch(util.LR)
+    for name, x in ref.get_states().items():
+        assert np.array_equal(x, b.get_state(name)), name
+    # a second cmi_set_ratings on the same handle: the live rows come home before the arena is rebuilt
+    half = data.subset(np.arange(data.n // 2))
+    for inst in (ref, b):
+        inst.set_ratings(half.u, half.j, half.ctx, half.r, half.ctx_ptr, half.ctx_conds)
+        inst.train_epoch(util.LR)
+    for name, x in ref.get_states().items():
+        assert np.array_equal(x, b.get_state(name)), name
+
+
+def test_spoke_arena_with_the_item_side_in_the_arena_through_the_exchange():
+    """hub = user puts Q -- a container the multi-GPU exchange packs and rewrites -- into the arena: a group of two shards on one
+    device must still equal the table-resident group bit for bit."""
+    model, k = "CAMF_CU", 64
+    data = util.small_data(n_users=700, n_items=160, n_dims=3, conds_per_dim=3, n=14000, seed=47)
+    gm = oracle_c.global_mean(data.r)
+    state = synth.init_state(model, data, k, seed=5, dtype=np.float32)
+
+    def group(flags):
+        g = capi.Group(model, k, data.n_users, data.n_items, data.n_conds, 2, devices=[0, 0], flags=CHAIN | flags)
+        g.set_hparams(util.REG, util.REG, util.REG, util.REGC, gm)
+        g.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
+        g.set_states(state)
+        return g
+    ga, gr = _with_hub("user", lambda: group(ARENA)), _with_hub("user", lambda: group(capi.FLAG_NO_ARENA))
+    assert ga.member(0).schedule_info()["kind"] == "chain-user" and ga.member(0).schedule_traffic()["spoke_arena"]
+    for _ in range(3):
+        assert ga.train_epoch(util.LR) == gr.train_epoch(util.LR)
+    for name, x in gr.get_states(np.float32).items():
+        assert np.array_equal(x, ga.get_state(name, np.float32)), name

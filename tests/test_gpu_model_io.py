@@ -112,8 +112,8 @@ def test_sim_params_travel_with_the_file_and_are_verified(tmp_path):
     b = make(None)                                   # no sim params yet: the file restores them, then the ratings can be set
     b.load_model(p)
     b.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
-    pa = a.predict_batch(data.u[:20], data.j[:20], data.ctx[:20])
-    pb = b.predict_batch(data.u[:20], data.j[:20], data.ctx[:20])
+    pa = a.predict(data.u[:20], data.j[:20], data.ctx[:20])
+    pb = b.predict(data.u[:20], data.j[:20], data.ctx[:20])
     assert np.array_equal(pa, pb)
     c = make([1, 3])                                 # other EmptyContextConditions: refused
     with pytest.raises(capi.CmiError, match="EmptyContextConditions"):

@@ -204,13 +204,13 @@ def _with_env(env, fn):
 
 @pytest.mark.parametrize("model,num_recs,thold", [("CAMF_CI", 10, 2.5), ("BiasedMF", 5, -1.0), ("CAMF_CU", 64, 3.9)])
 def test_slab_free_scoring_is_identical_to_the_slab_form(model, num_recs, thold):
-    """fp32 state with many candidates takes the slab-free path (round 3: a sample of the candidates bounds every query's N-th best
+    """The slab-free scoring path (opt-in, CMI_RANK_FILTER=1; round 3: a sample of the candidates bounds every query's N-th best
     score, the full contraction keeps only the scores that can still make the list -- the [queries x candidates] slab is never
     written).  Same contraction, exact filter: lists, scores and measures must be IDENTICAL to the slab form's, item for item."""
     train, test, orc, inst = _setup(model, 32, 0, epochs=2, n_users=120, n_items=1600, n=9000, seed=8)
     kw = dict(bin_thold=thold, num_recs=num_recs, with_lists=True)
-    slab = _with_env({"CMI_RANK_NO_FILTER": "1"}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
-    free = _with_env({"CMI_RANK_NO_FILTER": None, "CMI_RANK_SAMPLE": "128"}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
+    slab = _with_env({"CMI_RANK_NO_FILTER": "1", "CMI_RANK_FILTER": None}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
+    free = _with_env({"CMI_RANK_NO_FILTER": None, "CMI_RANK_FILTER": "1", "CMI_RANK_SAMPLE": "128"}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
     assert free[0]["n_queries"] == slab[0]["n_queries"] > 0
     assert set(free[1]) == set(slab[1])
     for key in slab[1]:
@@ -236,6 +236,6 @@ def test_slab_free_scoring_falls_back_when_a_list_overflows():
     inst.set_states({"P": np.zeros((25, 4)), "Q": np.zeros((n_items, 4)), "userBias": np.zeros(25), "itemBias": np.zeros(n_items)})
     tt = [list(zip(*(a.tolist() for a in x))) for x in (train, test)]
     ref, ref_lists = rank_oracle.eval_rankings(lambda u, jj, c: 3.0, tt[0], tt[1], bin_thold=2.5, num_recs=10)
-    res, lists = _with_env({"CMI_RANK_NO_FILTER": None, "CMI_RANK_SAMPLE": "128"},
+    res, lists = _with_env({"CMI_RANK_NO_FILTER": None, "CMI_RANK_FILTER": "1", "CMI_RANK_SAMPLE": "128"},
                            lambda: inst.eval_rankings(train, test, bin_thold=2.5, num_recs=10, with_lists=True))
     _assert_same(res, lists, ref, ref_lists, 1e-15, 0.0)

@@ -85,7 +85,8 @@ def test_java_sources_use_only_existing_native_members_and_header_constants():
                          ("FLAG_SCHED_SERIAL", "CMI_FLAG_SCHED_SERIAL"), ("FLAG_STRICT", "CMI_FLAG_STRICT"),
                          ("FLAG_NO_GRAPH", "CMI_FLAG_NO_GRAPH"), ("FLAG_SCHED_CHAIN", "CMI_FLAG_SCHED_CHAIN"),
                          ("FLAG_NO_CHAIN", "CMI_FLAG_NO_CHAIN"), ("FLAG_SCHED_OWNER", "CMI_FLAG_SCHED_OWNER"),
-                         ("FLAG_NO_OWNER", "CMI_FLAG_NO_OWNER"), ("RANK_UCU", "CMI_RANK_UCU"), ("RANK_UC", "CMI_RANK_UC"),
+                         ("FLAG_NO_OWNER", "CMI_FLAG_NO_OWNER"), ("FLAG_SPOKE_ARENA", "CMI_FLAG_SPOKE_ARENA"),
+                         ("FLAG_NO_ARENA", "CMI_FLAG_NO_ARENA"), ("RANK_UCU", "CMI_RANK_UCU"), ("RANK_UC", "CMI_RANK_UC"),
                          ("SVDPP", "CMI_MODEL_SVDPP"), ("CAMF_ICS", "CMI_MODEL_CAMF_ICS"), ("CAMF_LCS", "CMI_MODEL_CAMF_LCS"),
                          ("CAMF_MCS", "CMI_MODEL_CAMF_MCS"), ("Y", "CMI_STATE_Y"), ("CC_MATRIX", "CMI_STATE_CC_MATRIX"),
                          ("CF_MATRIX", "CMI_STATE_CF_MATRIX"), ("C_VECTOR", "CMI_STATE_C_VECTOR")]:

@@ -140,5 +140,5 @@ def test_gpu_predict_reproduces_the_jars_row_mult(case):
     inst = capi.Instance("PMF", k, 2, 2, 0, flags=capi.FLAG_STATE_F64)
     inst.set_hparams(0.0, 0.0, 0.0, 0.0, 0.0)
     inst.set_states({"P": np.stack([np.full(k, 0.5), a]), "Q": np.stack([b, np.full(k, -0.25)])})
-    got = inst.predict_batch(np.array([1], np.int32), np.array([0], np.int32), None)[0]
+    got = inst.predict(np.array([1], np.int32), np.array([0], np.int32), None)[0]
     assert abs(got - fx(case["result"])) <= 4e-16 * k * float(np.sum(np.abs(a * b)))

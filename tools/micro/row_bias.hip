@@ -146,7 +146,7 @@ int main() {
     }
     // (3) sequential reads + random writes over arenas of 25.6 GB (C3: one slot per tuple) -- allocated separately
     hipFree(tab);
-    for (uint64_t gb : {(uint64_t)2, (uint64_t)25}) {
+    for (uint64_t gb : {(uint64_t)2, (uint64_t)25, (uint64_t)100}) {
         const size_t bytes = (size_t)gb << 30;
         char *arena;
         if (hipMalloc(&arena, bytes) != hipSuccess) { printf("{\"exp\": \"next_use\", \"error\": \"alloc %llu GB failed\"}\n", (unsigned long long)gb); continue; }
