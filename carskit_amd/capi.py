@@ -91,6 +91,7 @@ SYMBOLS = [
     ("cmi_schedule_info", C.c_int, [_vp, C.POINTER(_i64)]),
     ("cmi_schedule_traffic", C.c_int, [_vp, C.POINTER(_i64)]),
     ("cmi_schedule_note", C.c_char_p, [_vp]),
+    ("cmi_arena_positions", C.c_int, [_i64, _vp, _i32, _vp, _vp]),
     ("cmi_exchange_setup", C.c_int, [_vp, _i64, C.POINTER(_vp), C.POINTER(_i64)]),
     ("cmi_group_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_uint, C.POINTER(_vp)]),
     ("cmi_group_destroy", C.c_int, [_vp]),
@@ -321,6 +322,16 @@ def owner_schedule(u, j, n_users, n_items, n_owners, hub=-1, depth=8):
     if rc != OK:
         raise CmiError(rc, "cmi_owner_schedule")
     return perm, own_off, want, flags, bool(hub_used.value)
+
+
+def arena_positions(spoke, n_spokes):
+    """Host-only: (next, first) of the spoke arena for a stream of spoke row ids (see cmi_arena_positions)."""
+    spoke = np.ascontiguousarray(spoke, dtype=np.int32)
+    nxt, first = np.empty(len(spoke), dtype=np.int32), np.empty(n_spokes, dtype=np.int32)
+    rc = lib().cmi_arena_positions(len(spoke), _p(spoke), n_spokes, _p(nxt), _p(first))
+    if rc != OK:
+        raise CmiError(rc, "cmi_arena_positions")
+    return nxt, first
 
 
 def split_schedule(u, j, n_users, n_items):

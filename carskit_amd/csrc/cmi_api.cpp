@@ -400,6 +400,28 @@ static hipError_t upload(void **dst, const std::vector<V> &v, hipStream_t s) {
     return hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice, s);
 }
 
+// Spoke arena bookkeeping: next[p] = stream position of the next tuple of the same spoke row (a row's tuples sit in ascending levels,
+// hence ascending positions); the row's last tuple wraps to its first -- that is where the row waits for the next epoch.
+// first[row] = position of the row's first tuple, -1 for a row without tuples.
+static void arena_positions(int64_t n, const int32_t *spoke, int64_t n_spokes, int32_t *next, int32_t *first) {
+    for (int64_t r = 0; r < n_spokes; ++r) first[r] = -1;
+    for (int64_t p = n - 1; p >= 0; --p) {
+        const int32_t r = spoke[p];
+        next[p] = first[r]; // -1 for the row's last tuple: patched below
+        first[r] = (int32_t)p;
+    }
+    for (int64_t p = 0; p < n; ++p)
+        if (next[p] < 0) next[p] = first[spoke[p]];
+}
+// host-only export of the same (tests/test_chain_schedule.py)
+extern "C" int cmi_arena_positions(int64_t n, const int32_t *spoke, int32_t n_spokes, int32_t *next, int32_t *first) {
+    if (n < 0 || n_spokes < 0 || (n > 0 && (!spoke || !next)) || (n_spokes > 0 && !first)) return CMI_E_INVALID;
+    for (int64_t p = 0; p < n; ++p)
+        if (spoke[p] < 0 || spoke[p] >= n_spokes) return CMI_E_INVALID;
+    arena_positions(n, spoke, n_spokes, next, first);
+    return CMI_OK;
+}
+
 // Hub-chain level schedule (level_schedule.cpp): used when forced, or when its levels are wide enough to fill the chip
 // (narrow levels -- heavy-tailed degrees, tiny data -- stay with the plain levels and their narrow-run launches).
 static int chain_max_len() {
@@ -765,13 +787,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             // positions); the last one wraps to the first: that is where the row waits for the next epoch
             std::vector<int32_t> nxt((size_t)n), first((size_t)spokes, -1);
             const std::vector<int32_t> &sp = h->chain_hub_item ? su : sj;
-            for (int64_t p = n - 1; p >= 0; --p) {
-                const int32_t r = sp[(size_t)p];
-                nxt[(size_t)p] = first[(size_t)r]; // -1 for the row's last tuple: patched below
-                first[(size_t)r] = (int32_t)p;
-            }
-            for (int64_t p = 0; p < n; ++p)
-                if (nxt[(size_t)p] < 0) nxt[(size_t)p] = first[(size_t)sp[(size_t)p]];
+            arena_positions(n, sp.data(), spokes, nxt.data(), first.data());
             e = upload((void **)&h->d_next, nxt, h->stream);
             if (e == hipSuccess) e = upload((void **)&h->d_first, first, h->stream);
             if (e == hipSuccess) e = hipMalloc(&h->d_arena, arena_bytes);

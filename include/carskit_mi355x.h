@@ -290,6 +290,10 @@ int cmi_last_loss(cmi_handle h, double *loss_out);
  * info[7]=workgroups of the dataflow launch; for CAMF_C the number of conflict-free CRS blocks its epoch is cut into
  * (0: the serial wave) */
 int cmi_schedule_info(cmi_handle h, int64_t info[8]);
+/* host-only: the bookkeeping of the spoke arena (CMI_FLAG_SPOKE_ARENA).  spoke[p] = spoke row id of the tuple at stream position p;
+ * next[p] = position of the next tuple of the same row, the last one wrapping to the first; first[row] = position of the row's first
+ * tuple or -1 */
+int cmi_arena_positions(int64_t n, const int32_t *spoke, int32_t n_spokes, int32_t *next, int32_t *first);
 /* "" or one sentence saying why cmi_set_ratings could not pick the schedule the data calls for (heavy-tailed degrees outside the owner
  * epoch's limits: the order-exact level walk runs, correct but roughly 10x slower) -- visible to the host instead of silent */
 const char *cmi_schedule_note(cmi_handle h);

@@ -107,3 +107,35 @@ def test_schedule_order_replay_equals_sequential_epoch_bitwise():
             for name, a in seq.state.items():
                 if a is not None:
                     assert np.array_equal(a, rep.state[name]), (model, hub, name)
+
+
+def test_arena_positions_thread_every_row_through_its_tuples_in_order():
+    """The spoke arena's bookkeeping (cmi_arena_positions): following next[] from first[row] visits exactly the row's stream positions in
+    ascending order and returns to first[row]; rows without tuples have first = -1.  Simulating an epoch on it -- every position READS its
+    own slot and WRITES slot next[p] -- each row's value must pass through all of its tuples in order and end in first[row]."""
+    rng = np.random.default_rng(3)
+    for n, n_spokes in ((0, 3), (1, 1), (200, 7), (5000, 900), (3000, 5000)):
+        spoke = rng.integers(0, n_spokes, n).astype(np.int32)
+        nxt, first = capi.arena_positions(spoke, n_spokes)
+        for r in range(n_spokes):
+            pos = np.flatnonzero(spoke == r)
+            if len(pos) == 0:
+                assert first[r] == -1
+                continue
+            assert first[r] == pos[0]
+            walk, p = [], int(first[r])
+            for _ in range(len(pos)):
+                walk.append(p)
+                p = int(nxt[p])
+            assert walk == pos.tolist() and p == first[r]
+        # one simulated epoch: slot values are (row, number of updates applied so far)
+        slot = {int(first[r]): (r, 0) for r in range(n_spokes) if first[r] >= 0}
+        for p in range(n):
+            row, cnt = slot.pop(p)                     # the tuple at p finds its row's live value in its own slot
+            assert row == spoke[p]
+            slot[int(nxt[p])] = (row, cnt + 1)
+        for r in range(n_spokes):
+            if first[r] >= 0:
+                assert slot[int(first[r])] == (r, int(np.sum(spoke == r)))
+    with pytest.raises(capi.CmiError):
+        capi.arena_positions(np.array([0, 5], np.int32), 3)
