@@ -7,7 +7,7 @@ tag=$1; wl=$2; kern=${3:-sgd_chain_level}; extra=${4:-}; sfx=${5:-}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_${tag}_${wl}${sfx}
 mkdir -p $out
-args=(--workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-f64 --no-calibration --no-northstar $extra)
+args=(--workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-f64 --no-calibration --no-northstar --no-extras $extra)
 python bench.py "${args[@]}" > $out/bench.json 2> $out/bench.err
 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python bench.py "${args[@]}" > $out/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
