@@ -1,0 +1,1102 @@
+"""A small interpreter for the subset of Java SOURCE the reference's hot path is written in -- TEST INFRASTRUCTURE, build container only.
+
+The reference's recommenders exist as Java source only (src/carskit/**); there is no compiler and no JVM in this image, and no compiled
+CARSKit classes ship with it.  oracle/jvm/interp.py executes the third-party jar the loops call into; this module
+executes the loops themselves: it tokenises a .java file, finds method bodies, parses them (statements: blocks, local declarations,
+if / for / for-each / while / switch / break / continue / return; expressions with Java's precedence: assignment and compound assignment,
+?:, || &&, comparisons, + - * / %, unary, casts, ++ --, calls, field access, new) and evaluates them over
+  * librec objects living in the bytecode VM (DenseMatrix, DenseVector, SparseMatrix, MatrixEntry, SymmMatrix: their methods run from
+    the jar's bytecode),
+  * host stand-ins for the JDK / guava classes (interp.py) and for the parts of CARSKit outside the loop (rateDao: id maps),
+  * the fields of a `this` object the minting script fills in (hyper-parameters, model containers).
+`this` has a CHAIN of source files (e.g. CAMF_CI.java -> CAMF.java -> ContextRecommender.java -> IterativeRecommender.java ->
+Recommender.java): an unqualified call resolves to the first class in the chain that declares a method of that name and arity, `super.m()`
+to the next one after the caller's -- Java's virtual dispatch for the methods on this path.
+
+Numeric model: int -> Python int (32-bit wrap on + - *, truncating / and %), double -> Python float, float -> interp.JFloat (every
+float-typed result rounded to binary32), boolean -> bool.  Math.pow(x, 2) is x * x (what fdlibm's and HotSpot's pow return for y == 2).
+What is executed is the reference's text, read where it lies under /root/reference at minting time; nothing of it is copied into this
+repository -- the fixtures hold numbers only (oracle/mint_reference_src.py).
+"""
+import math
+import re
+
+from .interp import Box, JArray, JCollection, JFloat, JLong, JObject, JString, f32, i32
+from .classfile import parse_descriptor
+
+PRIMS = {"int", "double", "float", "boolean", "long", "char", "byte", "short"}
+KEYWORDS = PRIMS | {"for", "if", "else", "while", "do", "switch", "case", "default", "break", "continue", "return", "new", "null", "true",
+                    "false", "this", "super", "throw", "final", "instanceof", "try", "catch", "finally", "void"}
+
+TOKEN_RE = re.compile(r"""
+    (?P<ws>\s+) |
+    (?P<lc>//[^\n]*) |
+    (?P<bc>/\*.*?\*/) |
+    (?P<num>(?:\d+\.\d*|\.\d+|\d+)(?:[eE][+-]?\d+)?[fFdDlL]?) |
+    (?P<str>"(?:\\.|[^"\\])*") |
+    (?P<chr>'(?:\\.|[^'\\])') |
+    (?P<id>[A-Za-z_$][A-Za-z_$0-9]*) |
+    (?P<op>>>>=|<<=|>>=|>>>|\+\+|--|\+=|-=|\*=|/=|%=|&=|\|=|\^=|==|!=|<=|>=|&&|\|\||<<|->|[-+*/%=<>!?:;,.()\[\]{}@&|^~])
+""", re.S | re.X)
+
+
+def tokenize(src):
+    out, pos = [], 0
+    while pos < len(src):
+        m = TOKEN_RE.match(src, pos)
+        if not m:
+            raise SyntaxError("cannot tokenize at %r" % src[pos:pos + 30])
+        pos = m.end()
+        kind = m.lastgroup
+        if kind in ("ws", "lc", "bc"):
+            continue
+        out.append((kind, m.group(kind)))
+    return out
+
+
+class Parser:
+    def __init__(self, toks):
+        self.t, self.p = toks, 0
+
+    # -- token helpers
+    def peek(self, k=0):
+        return self.t[self.p + k] if self.p + k < len(self.t) else ("eof", "")
+
+    def at(self, val, k=0):
+        return self.peek(k)[1] == val and self.peek(k)[0] in ("op", "id")
+
+    def eat(self, val=None):
+        tok = self.peek()
+        if val is not None and tok[1] != val:
+            raise SyntaxError("expected %r, found %r (token %d)" % (val, tok[1], self.p))
+        self.p += 1
+        return tok
+
+    # -- types: Name(.Name)* [<...>] ([])*
+    def try_type(self):
+        save = self.p
+        tok = self.peek()
+        if tok[0] != "id" or (tok[1] in KEYWORDS and tok[1] not in PRIMS):
+            return None
+        name = self.eat()[1]
+        while self.at(".") and self.peek(1)[0] == "id":
+            self.eat()
+            name += "." + self.eat()[1]
+        if self.at("<"):
+            depth = 0
+            while True:
+                v = self.eat()[1]
+                if v == "<":
+                    depth += 1
+                elif v == ">":
+                    depth -= 1
+                elif v == ">>":
+                    depth -= 2
+                elif v in (";", "(", ")", "{", "=") or self.peek()[0] == "eof":
+                    self.p = save
+                    return None
+                if depth <= 0:
+                    break
+        dims = 0
+        while self.at("[") and self.at("]", 1):
+            self.eat(), self.eat()
+            dims += 1
+        return (name, dims)
+
+    # -- statements
+    def block(self):
+        self.eat("{")
+        body = []
+        while not self.at("}"):
+            body.append(self.statement())
+        self.eat("}")
+        return ("block", body)
+
+    def statement(self):
+        tok = self.peek()
+        v = tok[1]
+        if v == "{" and tok[0] == "op":
+            return self.block()
+        if v == ";" and tok[0] == "op":
+            self.eat()
+            return ("empty",)
+        if tok[0] == "id":
+            if v == "if":
+                self.eat()
+                self.eat("(")
+                c = self.expr()
+                self.eat(")")
+                a = self.statement()
+                b = None
+                if self.at("else"):
+                    self.eat()
+                    b = self.statement()
+                return ("if", c, a, b)
+            if v == "for":
+                return self.for_stmt()
+            if v == "while":
+                self.eat()
+                self.eat("(")
+                c = self.expr()
+                self.eat(")")
+                return ("while", c, self.statement())
+            if v == "switch":
+                return self.switch_stmt()
+            if v == "break":
+                self.eat(), self.eat(";")
+                return ("break",)
+            if v == "continue":
+                self.eat(), self.eat(";")
+                return ("continue",)
+            if v == "return":
+                self.eat()
+                e = None if self.at(";") else self.expr()
+                self.eat(";")
+                return ("return", e)
+            if v == "throw":
+                self.eat()
+                e = self.expr()
+                self.eat(";")
+                return ("throw", e)
+            if v == "final":
+                self.eat()
+                return self.statement()
+            if v == "try":
+                self.eat()
+                body = self.block()
+                while self.at("catch"):
+                    self.eat(), self.eat("(")
+                    while not self.at(")"):
+                        self.eat()
+                    self.eat(")")
+                    self.block()
+                if self.at("finally"):
+                    self.eat()
+                    self.block()
+                return body
+        decl = self.try_local_decl()
+        if decl is not None:
+            self.eat(";")
+            return decl
+        e = self.expr()
+        self.eat(";")
+        return ("expr", e)
+
+    def try_local_decl(self):
+        save = self.p
+        ty = self.try_type()
+        if ty is None or self.peek()[0] != "id" or self.peek()[1] in KEYWORDS or self.peek(1)[1] not in ("=", ";", ",", ":"):
+            self.p = save
+            return None
+        decls = []
+        while True:
+            name = self.eat()[1]
+            init = None
+            if self.at("="):
+                self.eat()
+                init = self.expr_no_comma()
+            decls.append((name, init))
+            if self.at(","):
+                self.eat()
+                continue
+            break
+        return ("decl", ty, decls)
+
+    def for_stmt(self):
+        self.eat("for")
+        self.eat("(")
+        save = self.p
+        ty = self.try_type()
+        if ty is not None and self.peek()[0] == "id" and self.at(":", 1):
+            name = self.eat()[1]
+            self.eat(":")
+            it = self.expr()
+            self.eat(")")
+            return ("foreach", ty, name, it, self.statement())
+        self.p = save
+        init = []
+        if not self.at(";"):
+            d = self.try_local_decl()
+            if d is not None:
+                init.append(d)
+            else:
+                init.append(("expr", self.expr_no_comma()))
+                while self.at(","):
+                    self.eat()
+                    init.append(("expr", self.expr_no_comma()))
+        self.eat(";")
+        cond = None if self.at(";") else self.expr()
+        self.eat(";")
+        upd = []
+        if not self.at(")"):
+            upd.append(self.expr_no_comma())
+            while self.at(","):
+                self.eat()
+                upd.append(self.expr_no_comma())
+        self.eat(")")
+        return ("for", init, cond, upd, self.statement())
+
+    def switch_stmt(self):
+        self.eat("switch")
+        self.eat("(")
+        e = self.expr()
+        self.eat(")")
+        self.eat("{")
+        cases = []  # (label expr or None for default, [statements])
+        while not self.at("}"):
+            if self.at("case"):
+                self.eat()
+                lab = self.expr()
+                self.eat(":")
+                cases.append((lab, []))
+            elif self.at("default"):
+                self.eat(), self.eat(":")
+                cases.append((None, []))
+            else:
+                cases[-1][1].append(self.statement())
+        self.eat("}")
+        return ("switch", e, cases)
+
+    # -- expressions
+    def expr(self):
+        return self.expr_no_comma()
+
+    def expr_no_comma(self):
+        lhs = self.ternary()
+        if self.peek()[0] == "op" and self.peek()[1] in ("=", "+=", "-=", "*=", "/=", "%="):
+            op = self.eat()[1]
+            rhs = self.expr_no_comma()
+            return ("assign", op, lhs, rhs)
+        return lhs
+
+    def ternary(self):
+        c = self.binary(0)
+        if self.at("?"):
+            self.eat()
+            a = self.expr_no_comma()
+            self.eat(":")
+            b = self.expr_no_comma()
+            return ("cond", c, a, b)
+        return c
+
+    LEVELS = [("||",), ("&&",), ("|",), ("^",), ("&",), ("==", "!="), ("<", ">", "<=", ">=", "instanceof"), ("<<", ">>", ">>>"), ("+", "-"),
+              ("*", "/", "%")]
+
+    def binary(self, lvl):
+        if lvl == len(self.LEVELS):
+            return self.unary()
+        lhs = self.binary(lvl + 1)
+        while self.peek()[1] in self.LEVELS[lvl] and self.peek()[0] in ("op", "id"):
+            op = self.eat()[1]
+            if op == "instanceof":
+                self.try_type()
+                lhs = ("lit", True)
+                continue
+            rhs = self.binary(lvl + 1)
+            lhs = ("bin", op, lhs, rhs)
+        return lhs
+
+    def unary(self):
+        tok = self.peek()
+        if tok[0] == "op" and tok[1] in ("-", "+", "!", "~"):
+            self.eat()
+            return ("un", tok[1], self.unary())
+        if tok[0] == "op" and tok[1] in ("++", "--"):
+            self.eat()
+            return ("preinc", tok[1], self.unary())
+        if tok[0] == "op" and tok[1] == "(":  # a cast?
+            save = self.p
+            self.eat()
+            ty = self.try_type()
+            if ty is not None and self.at(")"):
+                self.eat()
+                nxt = self.peek()
+                prim = ty[0] in PRIMS and ty[1] == 0
+                starts_operand = nxt[0] in ("id", "num", "str", "chr") or (nxt[0] == "op" and nxt[1] in ("(", "!", "~"))
+                if prim and nxt[0] == "op" and nxt[1] in ("-", "+"):
+                    starts_operand = True
+                if (prim or nxt[0] != "op" or nxt[1] in ("(", "!", "~")) and starts_operand and not (nxt[0] == "id" and nxt[1] == "instanceof"):
+                    return ("cast", ty, self.unary())
+            self.p = save
+        return self.postfix()
+
+    def postfix(self):
+        e = self.primary()
+        while True:
+            if self.at("."):
+                self.eat()
+                name = self.eat()[1]
+                if self.at("("):
+                    e = ("call", e, name, self.args())
+                else:
+                    e = ("field", e, name)
+            elif self.at("["):
+                self.eat()
+                i = self.expr()
+                self.eat("]")
+                e = ("index", e, i)
+            elif self.peek()[0] == "op" and self.peek()[1] in ("++", "--"):
+                e = ("postinc", self.eat()[1], e)
+            else:
+                return e
+
+    def args(self):
+        self.eat("(")
+        out = []
+        while not self.at(")"):
+            out.append(self.expr_no_comma())
+            if self.at(","):
+                self.eat()
+        self.eat(")")
+        return out
+
+    def primary(self):
+        kind, v = self.peek()
+        if kind == "num":
+            self.eat()
+            s = v.rstrip("fFdDlL")
+            if v[-1] in "fF":
+                return ("lit", f32(float(s)))
+            if v[-1] in "lL":
+                return ("lit", JLong(int(s)))
+            if v[-1] in "dD" or any(c in s for c in ".eE"):
+                return ("lit", float(s))
+            return ("lit", int(s))
+        if kind == "str":
+            self.eat()
+            return ("lit", bytes(v[1:-1], "utf-8").decode("unicode_escape"))
+        if kind == "chr":
+            self.eat()
+            return ("lit", ord(bytes(v[1:-1], "utf-8").decode("unicode_escape")))
+        if kind == "op" and v == "(":
+            self.eat()
+            e = self.expr()
+            self.eat(")")
+            return ("paren", e)
+        if kind == "id":
+            if v in ("true", "false"):
+                self.eat()
+                return ("lit", v == "true")
+            if v == "null":
+                self.eat()
+                return ("lit", None)
+            if v == "new":
+                self.eat()
+                ty = self.try_type_for_new()
+                if self.at("["):
+                    self.eat()
+                    n = self.expr()
+                    self.eat("]")
+                    return ("newarray", ty, n)
+                a = self.args()
+                if self.at("{"):  # anonymous class body: not on this path
+                    raise SyntaxError("anonymous classes are not supported")
+                return ("new", ty, a)
+            self.eat()
+            if self.at("("):
+                return ("call", None, v, self.args())
+            return ("name", v)
+        raise SyntaxError("unexpected token %r" % (v,))
+
+    def try_type_for_new(self):
+        name = self.eat()[1]
+        while self.at(".") and self.peek(1)[0] == "id":
+            self.eat()
+            name += "." + self.eat()[1]
+        if self.at("<"):
+            depth = 0
+            while True:
+                v = self.eat()[1]
+                depth += {"<": 1, ">": -1, ">>": -2}.get(v, 0)
+                if depth <= 0:
+                    break
+        return name
+
+
+def find_methods(src):
+    """{name: [(param names, body AST, class simple name)]} of the top-level class of a .java file"""
+    toks = tokenize(src)
+    methods, depth, i, cls = {}, 0, 0, None
+    while i < len(toks):
+        kind, v = toks[i]
+        if kind == "op" and v == "@":          # annotation: skip its name (and arguments)
+            i += 2
+            if i < len(toks) and toks[i][1] == "(":
+                d = 0
+                while True:
+                    d += {"(": 1, ")": -1}.get(toks[i][1], 0)
+                    i += 1
+                    if d == 0:
+                        break
+            continue
+        if kind == "id" and v in ("class", "interface", "enum") and depth == 0 and cls is None:
+            cls = toks[i + 1][1]
+        if kind == "op" and v == "{":
+            depth += 1
+        elif kind == "op" and v == "}":
+            depth -= 1
+        elif depth == 1 and kind == "id" and v not in KEYWORDS and i + 1 < len(toks) and toks[i + 1][1] == "(" and toks[i - 1][0] in ("id", "op") \
+                and (toks[i - 1][0] == "id" or toks[i - 1][1] in ("]", ">")) and toks[i - 1][1] not in ("new", "return", "=", ".") and v != cls:
+            # a method declaration: Type name ( params ) [throws ...] { body }
+            j = i + 2
+            params, cur = [], []
+            d = 1
+            while d > 0:
+                t = toks[j]
+                if t[1] == "(":
+                    d += 1
+                elif t[1] == ")":
+                    d -= 1
+                    if d == 0:
+                        break
+                if t[1] == "," and d == 1:
+                    params.append(cur)
+                    cur = []
+                else:
+                    cur.append(t)
+                j += 1
+            if cur:
+                params.append(cur)
+            j += 1
+            while toks[j][1] not in ("{", ";"):
+                j += 1
+            if toks[j][1] == "{":
+                # the body is only PARSED when the method is first called (a class has many methods this subset cannot parse and never
+                # needs to); here it is skipped by matching braces
+                d2, e = 0, j
+                while True:
+                    d2 += {"{": 1, "}": -1}.get(toks[e][1], 0) if toks[e][0] == "op" else 0
+                    e += 1
+                    if d2 == 0:
+                        break
+                names = [pp[-1][1] for pp in params]
+                types = [" ".join(t[1] for t in pp[:-1] if t[1] != "final") for pp in params]
+                methods.setdefault(v, []).append([names, types, ("lazy", toks, j), cls])
+                i = e
+                continue
+        i += 1
+    return methods, cls
+
+
+class Break(Exception):
+    pass
+
+
+class Continue(Exception):
+    pass
+
+
+class Return(Exception):
+    def __init__(self, v):
+        self.v = v
+
+
+class JavaExit(Exception):
+    pass
+
+
+class EnumConst:
+    def __init__(self, cls, name):
+        self.cls, self.name = cls, name
+
+    def __repr__(self):
+        return "%s.%s" % (self.cls, self.name)
+
+    def __eq__(self, o):
+        return isinstance(o, EnumConst) and o.name == self.name
+
+    def __hash__(self):
+        return hash(self.name)
+
+
+def unbox(v):
+    if isinstance(v, Box):
+        return v.v if v.kind == "Double" else int(v.v)
+    return v
+
+
+class This:
+    """An instance of a reference class: a chain of parsed source files (most derived first), fields, and host-provided members."""
+
+    def __init__(self, vm, sources, class_map):
+        self.vm = vm
+        self.chain = []
+        for path in sources:
+            methods, cls = find_methods(open(path).read())
+            self.chain.append((cls, methods))
+        self.fields = {}
+        self.host = {}          # name -> python callable(*args): methods of `this` outside the interpreted sources
+        self.hooks = {}         # name -> python callable(this, args): runs before the source method of that name
+        self.class_map = class_map   # simple class name -> jar class (for static calls / new)
+        self.statements = 0
+
+    def find(self, name, nargs, after=None):
+        start = 0
+        if after is not None:
+            start = [c for c, _ in self.chain].index(after) + 1
+        for cls, methods in self.chain[start:]:
+            for rec in methods.get(name, []):
+                if len(rec[0]) == nargs:
+                    if rec[2][0] == "lazy":
+                        p = Parser(rec[2][1])
+                        p.p = rec[2][2]
+                        rec[2] = p.block()
+                    return cls, rec[0], rec[1], rec[2]
+        return None
+
+    def call(self, name, args, after=None):
+        m = self.find(name, len(args), after)
+        if m is None:
+            if name in self.host:
+                return self.host[name](*args)
+            raise KeyError("no source or host method %s/%d on %s" % (name, len(args), self.chain[0][0]))
+        if name in self.hooks and after is None:
+            self.hooks[name](self, args)
+        cls, names, types, body = m
+        env = Env(self, cls)
+        for n, t, a in zip(names, types, args):
+            env.declare(n, coerce(t.split()[-1] if t else "", a))
+        try:
+            env.exec(body)
+        except Return as r:
+            return r.v
+        return None
+
+
+def coerce(ty, v):
+    """Java assignment conversion of v to declared type `ty` (simple name)"""
+    v = unbox(v)
+    if ty == "double" and isinstance(v, (int, float)) and not isinstance(v, bool):
+        return float(v)
+    if ty == "float" and isinstance(v, (int, float)) and not isinstance(v, bool):
+        return f32(float(v))
+    if ty == "int" and isinstance(v, float):
+        raise TypeError("possible lossy conversion from double to int")
+    return v
+
+
+class Env:
+    def __init__(self, this, cls):
+        self.this, self.cls = this, cls
+        self.scopes = [{}]
+        self.types = [{}]
+
+    def declare(self, name, v, ty=""):
+        self.scopes[-1][name] = v
+        self.types[-1][name] = ty
+
+    def lookup_scope(self, name):
+        for s, t in zip(reversed(self.scopes), reversed(self.types)):
+            if name in s:
+                return s, t
+        return None, None
+
+    # ---- statements
+    def exec(self, node):
+        self.this.statements += 1
+        k = node[0]
+        if k == "block":
+            self.scopes.append({})
+            self.types.append({})
+            try:
+                for s in node[1]:
+                    self.exec(s)
+            finally:
+                self.scopes.pop()
+                self.types.pop()
+        elif k == "decl":
+            ty = node[1][0] if node[1][1] == 0 else node[1][0] + "[]"
+            for name, init in node[2]:
+                v = coerce(ty, self.eval(init)) if init is not None else {"int": 0, "double": 0.0, "float": f32(0.0), "boolean": False}.get(ty)
+                self.declare(name, v, ty)
+        elif k == "expr":
+            self.eval(node[1])
+        elif k == "if":
+            if self.truth(self.eval(node[1])):
+                self.exec(node[2])
+            elif node[3] is not None:
+                self.exec(node[3])
+        elif k == "for":
+            self.scopes.append({})
+            self.types.append({})
+            try:
+                for s in node[1]:
+                    self.exec(s)
+                while node[2] is None or self.truth(self.eval(node[2])):
+                    try:
+                        self.exec(node[4])
+                    except Continue:
+                        pass
+                    except Break:
+                        break
+                    for u in node[3]:
+                        self.eval(u)
+            finally:
+                self.scopes.pop()
+                self.types.pop()
+        elif k == "foreach":
+            ty = node[1][0]
+            for v in self.iterate(self.eval(node[3])):
+                self.scopes.append({})
+                self.types.append({})
+                try:
+                    self.declare(node[2], coerce(ty, v) if ty in PRIMS else v, ty)
+                    self.exec(node[4])
+                except Continue:
+                    pass
+                except Break:
+                    break
+                finally:
+                    self.scopes.pop()
+                    self.types.pop()
+        elif k == "while":
+            while self.truth(self.eval(node[1])):
+                try:
+                    self.exec(node[2])
+                except Continue:
+                    continue
+                except Break:
+                    break
+        elif k == "switch":
+            v = self.eval(node[1])
+            matched = False
+            try:
+                for lab, body in node[2]:
+                    if not matched:
+                        if lab is None:
+                            matched = True
+                        else:
+                            lv = EnumConst("?", lab[1]) if lab[0] == "name" and isinstance(v, EnumConst) else self.eval(lab)
+                            matched = lv == v
+                    if matched:
+                        for s in body:
+                            self.exec(s)
+            except Break:
+                pass
+        elif k == "break":
+            raise Break()
+        elif k == "continue":
+            raise Continue()
+        elif k == "return":
+            raise Return(None if node[1] is None else self.eval(node[1]))
+        elif k == "throw":
+            raise RuntimeError("Java throw: %r" % (self.eval(node[1]),))
+        elif k == "empty":
+            pass
+        else:
+            raise NotImplementedError(k)
+
+    def truth(self, v):
+        v = unbox(v)
+        if isinstance(v, bool):
+            return v
+        if isinstance(v, int):
+            return v != 0
+        raise TypeError("not a boolean: %r" % (v,))
+
+    def iterate(self, coll):
+        if isinstance(coll, list):
+            return list(coll)
+        if isinstance(coll, JArray):
+            return list(coll.data)
+        vm = self.this.vm
+        it = vm.invoke("interface", "java/lang/Iterable", "iterator", "()Ljava/util/Iterator;", [coll]) if isinstance(coll, JObject) else coll.jcall(vm, "iterator", "", [])
+
+        def gen():
+            while vm.invoke("interface", "java/util/Iterator", "hasNext", "()Z", [it]):
+                yield vm.invoke("interface", "java/util/Iterator", "next", "()Ljava/lang/Object;", [it])
+        return gen()
+
+    # ---- expressions
+    def eval(self, n):
+        k = n[0]
+        if k == "lit":
+            return n[1]
+        if k == "paren":
+            return self.eval(n[1])
+        if k == "name":
+            return self.get_name(n[1])
+        if k == "bin":
+            return self.binop(n[1], n[2], n[3])
+        if k == "un":
+            v = unbox(self.eval(n[2]))
+            if n[1] == "-":
+                return f32(-v) if isinstance(v, JFloat) else (-v if isinstance(v, float) else i32(-v))
+            if n[1] == "+":
+                return v
+            if n[1] == "!":
+                return not self.truth(v)
+            return i32(~v)
+        if k == "cast":
+            v = unbox(self.eval(n[2]))
+            ty = n[1][0]
+            if ty == "float":
+                return f32(float(v))
+            if ty == "double":
+                return float(v)
+            if ty == "int":
+                if isinstance(v, float):
+                    return 0 if v != v else max(-2 ** 31, min(2 ** 31 - 1, int(v)))
+                return i32(int(v))
+            if ty == "long":
+                return JLong(int(v))
+            return v
+        if k == "cond":
+            return self.eval(n[2]) if self.truth(self.eval(n[1])) else self.eval(n[3])
+        if k == "assign":
+            return self.assign(n[1], n[2], n[3])
+        if k in ("postinc", "preinc"):
+            old = unbox(self.eval(n[2]))
+            new = old + (1 if n[1] == "++" else -1)
+            new = i32(new) if isinstance(old, int) else new
+            self.store(n[2], new)
+            return old if k == "postinc" else new
+        if k == "field":
+            return self.get_field(n[1], n[2])
+        if k == "index":
+            a, i = self.eval(n[1]), unbox(self.eval(n[2]))
+            return a[i] if isinstance(a, list) else a.data[i]
+        if k == "call":
+            return self.call(n[1], n[2], [self.eval(a) for a in n[3]])
+        if k == "new":
+            return self.new(n[1], [self.eval(a) for a in n[2]])
+        if k == "newarray":
+            return [None] * unbox(self.eval(n[2]))
+        raise NotImplementedError(k)
+
+    def get_name(self, name):
+        s, _ = self.lookup_scope(name)
+        if s is not None:
+            return s[name]
+        if name in self.this.fields:
+            return self.this.fields[name]
+        if name == "this":
+            return self.this
+        return ("class", name)            # a class name used as a qualifier (Math, DenseMatrix, Measure, ...)
+
+    def get_field(self, obj_node, name):
+        obj = self.eval(obj_node)
+        if isinstance(obj, tuple) and obj[0] == "class":
+            if obj[1] in self.this.fields.get("__enums__", ()):
+                return EnumConst(obj[1], name)
+            if (obj[1], name) in STATIC_FIELDS:
+                return STATIC_FIELDS[(obj[1], name)]
+            return EnumConst(obj[1], name)
+        if obj is self.this:
+            return self.this.fields[name]
+        if isinstance(obj, list) and name == "length":
+            return len(obj)
+        if isinstance(obj, JArray) and name == "length":
+            return len(obj.data)
+        if isinstance(obj, JObject):
+            return obj.fields[name]
+        raise KeyError("field %s of %r" % (name, obj))
+
+    def store(self, target, v):
+        if target[0] == "paren":
+            return self.store(target[1], v)
+        if target[0] == "name":
+            s, t = self.lookup_scope(target[1])
+            if s is not None:
+                s[target[1]] = coerce(t.get(target[1], ""), v)
+                return
+            if target[1] in self.this.fields:
+                old = self.this.fields[target[1]]
+                self.this.fields[target[1]] = float(v) if isinstance(old, float) and not isinstance(old, JFloat) and isinstance(v, int) \
+                    and not isinstance(v, bool) else (f32(float(v)) if isinstance(old, JFloat) else v)
+                return
+            raise KeyError("assignment to unknown name %s" % target[1])
+        if target[0] == "field":
+            obj = self.eval(target[1])
+            if obj is self.this:
+                self.this.fields[target[2]] = v
+            else:
+                obj.fields[target[2]] = v
+            return
+        if target[0] == "index":
+            a, i = self.eval(target[1]), unbox(self.eval(target[2]))
+            if isinstance(a, list):
+                a[i] = v
+            else:
+                a.data[i] = v
+            return
+        raise NotImplementedError("assignment target %s" % target[0])
+
+    def assign(self, op, lhs, rhs):
+        r = self.eval(rhs)
+        if op != "=":
+            cur = self.eval(lhs)
+            r2 = self.arith(op[:-1], cur, r)
+            # compound assignment casts back to the type of the left-hand side
+            cu = unbox(cur)
+            if isinstance(cu, JFloat):
+                r2 = f32(float(r2))
+            elif isinstance(cu, int) and not isinstance(cu, bool) and isinstance(r2, float):
+                r2 = max(-2 ** 31, min(2 ** 31 - 1, int(r2)))
+            r = r2
+        self.store(lhs, unbox(r) if op != "=" else r)
+        return r
+
+    def binop(self, op, a, b):
+        if op == "&&":
+            return self.truth(self.eval(a)) and self.truth(self.eval(b))
+        if op == "||":
+            return self.truth(self.eval(a)) or self.truth(self.eval(b))
+        x, y = self.eval(a), self.eval(b)
+        if op in ("==", "!="):
+            xu, yu = unbox(x), unbox(y)
+            if isinstance(xu, (int, float, bool)) and isinstance(yu, (int, float, bool)):
+                eq = xu == yu
+            elif isinstance(xu, EnumConst) or isinstance(yu, EnumConst):
+                eq = xu == yu
+            else:
+                eq = xu is yu
+            return eq if op == "==" else not eq
+        if op in ("<", ">", "<=", ">="):
+            x, y = unbox(x), unbox(y)
+            return {"<": x < y, ">": x > y, "<=": x <= y, ">=": x >= y}[op]
+        return self.arith(op, x, y)
+
+    def arith(self, op, x, y):
+        x, y = unbox(x), unbox(y)
+        if op == "+" and (isinstance(x, str) or isinstance(y, str)):
+            return java_str(x) + java_str(y)
+        if isinstance(x, bool) or isinstance(y, bool):
+            if op in ("&", "|", "^"):
+                return {"&": x and y, "|": x or y, "^": x != y}[op]
+            raise TypeError("arithmetic on boolean")
+        fl = isinstance(x, float) or isinstance(y, float)
+        both_f32 = fl and all(isinstance(v, (JFloat, int)) for v in (x, y)) and any(isinstance(v, JFloat) for v in (x, y))
+        if fl:
+            x, y = float(x), float(y)
+            if op == "+":
+                r = x + y
+            elif op == "-":
+                r = x - y
+            elif op == "*":
+                r = x * y
+            elif op == "/":
+                r = (math.nan if (x == 0.0 or x != x) else math.copysign(math.inf, x) * math.copysign(1.0, y)) if y == 0.0 else x / y
+            elif op == "%":
+                r = math.fmod(x, y) if y != 0.0 else math.nan
+            else:
+                raise TypeError("operator %s on floating point" % op)
+            return f32(r) if both_f32 else r
+        wrap = (lambda v: JLong(((v + 2 ** 63) % 2 ** 64) - 2 ** 63)) if isinstance(x, JLong) or isinstance(y, JLong) else i32
+        if op == "+":
+            return wrap(x + y)
+        if op == "-":
+            return wrap(x - y)
+        if op == "*":
+            return wrap(x * y)
+        if op in ("/", "%"):
+            if y == 0:
+                raise ZeroDivisionError("/ by zero")
+            q = abs(x) // abs(y) * (1 if (x < 0) == (y < 0) else -1)
+            return wrap(q if op == "/" else x - q * y)
+        if op == "<<":
+            return wrap(x << (y & 31))
+        if op == ">>":
+            return wrap(x >> (y & 31))
+        if op == "&":
+            return wrap(x & y)
+        if op == "|":
+            return wrap(x | y)
+        if op == "^":
+            return wrap(x ^ y)
+        raise NotImplementedError(op)
+
+    # ---- calls
+    def call(self, target, name, args):
+        this, vm = self.this, self.this.vm
+        if target is None:
+            return this.call(name, args)
+        if target[0] == "name" and target[1] == "super":
+            return this.call(name, args, after=self.cls)
+        obj = self.eval(target)
+        if obj is this:
+            return this.call(name, args)
+        if isinstance(obj, tuple) and obj[0] == "class":
+            return self.static_call(obj[1], name, args)
+        if obj is None:
+            raise RuntimeError("NullPointerException: .%s() on null" % name)
+        if isinstance(obj, JObject):
+            return vm_call(vm, obj, obj.cls_name, name, args, static=False)
+        if isinstance(obj, str):
+            return string_method(obj, name, args)
+        if isinstance(obj, list):
+            raise KeyError("method %s on array" % name)
+        if isinstance(obj, Box):
+            return obj.jcall(vm, name, "", [unbox(a) for a in args])
+        if isinstance(obj, EnumConst):
+            if name in ("toString", "name"):
+                return obj.name
+            raise KeyError("enum method " + name)
+        if hasattr(obj, "jcall"):
+            r = obj.jcall(vm, name, "", [to_host(a) for a in args])
+            return from_host(r)
+        if hasattr(obj, name):
+            return getattr(obj, name)(*[unbox(a) for a in args])
+        raise KeyError("cannot call %s on %r" % (name, obj))
+
+    def static_call(self, cls, name, args):
+        a = [unbox(x) for x in args]
+        key = (cls, name)
+        if key in STATIC_CALLS:
+            return STATIC_CALLS[key](*a)
+        jar_cls = self.this.class_map.get(cls)
+        if jar_cls is not None:
+            return vm_call(self.this.vm, None, jar_cls, name, args, static=True)
+        if cls in ("Logs",):
+            return None
+        raise KeyError("static %s.%s" % (cls, name))
+
+    def new(self, ty, args):
+        simple = ty.split(".")[-1]
+        if simple in ("ArrayList", "LinkedList"):
+            return JCollection()
+        jar_cls = self.this.class_map.get(simple)
+        if jar_cls is None:
+            raise KeyError("new %s" % ty)
+        o = self.this.vm.new_object(jar_cls)
+        vm_call(self.this.vm, o, jar_cls, "<init>", args, static=False)
+        return o
+
+
+def to_host(v):
+    """a Java value on its way into a host collection: primitives are boxed"""
+    if isinstance(v, bool) or v is None or isinstance(v, (Box, JObject)):
+        return v
+    if isinstance(v, float):
+        return Box(float(v), "Double")
+    if isinstance(v, int):
+        return Box(int(v), "Integer")
+    if isinstance(v, str):
+        return JString(v)
+    return v
+
+
+def from_host(v):
+    if isinstance(v, JString):
+        return v.s
+    return v
+
+
+def java_str(v):
+    if isinstance(v, str):
+        return v
+    if v is None:
+        return "null"
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, float):
+        return repr(float(v))
+    return str(v)
+
+
+def string_method(s, name, args):
+    a = [unbox(x) for x in args]
+    if name == "split":
+        sep = a[0]
+        parts = s.split(sep) if sep not in (".", "|") else re.split(re.escape(sep), s)
+        while parts and parts[-1] == "":        # String.split(regex) drops trailing empty strings
+            parts.pop()
+        return parts
+    if name == "trim":
+        return s.strip(" \t\n\r\f\v")
+    if name == "equals":
+        return s == a[0]
+    if name == "length":
+        return len(s)
+    if name == "toLowerCase":
+        return s.lower()
+    if name == "isEmpty":
+        return s == ""
+    raise KeyError("String." + name)
+
+
+def _math_pow(x, y):
+    if y == 2:
+        return float(x) * float(x)      # fdlibm e_pow.c: "y is 2" -> x*x; HotSpot's intrinsic does the same
+    return math.pow(x, y)
+
+
+STATIC_CALLS = {
+    ("Math", "pow"): _math_pow,
+    ("Math", "abs"): lambda x: abs(x),
+    ("Math", "sqrt"): lambda x: math.sqrt(x) if x >= 0 else math.nan,
+    ("Math", "max"): lambda a, b: max(a, b),
+    ("Math", "min"): lambda a, b: min(a, b),
+    ("Math", "exp"): math.exp,
+    ("Math", "log"): math.log,
+    ("Double", "isNaN"): lambda x: x != x,
+    ("Double", "isInfinite"): lambda x: math.isinf(x),
+    ("Integer", "valueOf"): lambda x: Box(int(x), "Integer"),
+    ("Integer", "parseInt"): lambda x: int(x),
+    ("Double", "valueOf"): lambda x: Box(float(x), "Double"),
+    ("String", "format"): lambda *a: "<formatted>",
+    ("Logs", "debug"): lambda *a: None,
+    ("Logs", "info"): lambda *a: None,
+    ("Logs", "error"): lambda *a: None,
+    ("Logs", "warn"): lambda *a: None,
+}
+
+
+def _exit(code):
+    raise JavaExit("System.exit(%r)" % (code,))
+
+
+STATIC_CALLS[("System", "exit")] = _exit
+STATIC_FIELDS = {("Double", "MAX_VALUE"): 1.7976931348623157e308, ("Integer", "MAX_VALUE"): 2 ** 31 - 1}
+
+
+def vm_call(vm, obj, cls, name, args, static):
+    """call a jar method by NAME: pick the overload whose descriptor fits the argument values"""
+    best = None
+    c = cls
+    while c and vm.jar.has(c):
+        cf = vm.jar.load(c)
+        for (nm, ds), m in cf.methods.items():
+            if nm != name or m.code is None or m.static != static:
+                continue
+            ptypes, ret = parse_descriptor(ds)
+            if len(ptypes) != len(args):
+                continue
+            conv, score, ok = [], 0, True
+            for t, a in zip(ptypes, args):
+                a = unbox(a) if t[0] not in "L[" else a
+                if t == "I" and isinstance(a, int) and not isinstance(a, (bool, JLong)):
+                    conv.append(a)
+                    score += 2
+                elif t == "D" and isinstance(a, float):
+                    conv.append(float(a))
+                    score += 2
+                elif t == "D" and isinstance(a, int) and not isinstance(a, bool):
+                    conv.append(float(a))
+                    score += 1
+                elif t == "Z" and isinstance(a, bool):
+                    conv.append(int(a))
+                    score += 2
+                elif t == "J" and isinstance(a, int) and not isinstance(a, bool):
+                    conv.append(JLong(a))
+                    score += 1
+                elif t[0] in "L[" and (a is None or isinstance(a, (JObject, JArray)) or hasattr(a, "jcall")):
+                    conv.append(a)
+                    score += 2 if isinstance(a, JObject) and ("L" + a.cls_name + ";") == t else 1
+                elif t[0] == "L" and t in ("Ljava/lang/Object;", "Ljava/lang/Integer;", "Ljava/lang/Double;") and isinstance(a, (int, float)):
+                    conv.append(to_host(a))
+                    score += 1
+                else:
+                    ok = False
+                    break
+            if ok and (best is None or score > best[0]):
+                best = (score, c, nm, ds, conv, ret)
+        c = cf.super_name
+    if best is None:
+        raise KeyError("no overload of %s.%s for %r" % (cls, name, args))
+    _, c, nm, ds, conv, ret = best
+    vm.ensure_init(c)
+    r = vm.invoke("static" if static else ("special" if name == "<init>" else "virtual"), c, nm, ds, ([] if static else [obj]) + conv)
+    if ret == "Z":
+        return bool(r)
+    return from_host(r)

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Mint tests/golden/reference_src_*.json by EXECUTING the reference's own Java source for the hot path (build container only).
+
+    python oracle/mint_reference_src.py [/root/reference]
+
+For every level-schedulable recommender of the path -- BiasedMF, PMF, CAMF_C, CAMF_CI, CAMF_CU, CAMF_CUCI -- the reference's
+`buildModel()` is run, statement by statement, from the text of its .java files (src/carskit/alg/**, src/carskit/generic/**) by
+oracle/jvm/javasrc.py: `predict(u, j, c, bound)`, the model's own `predict`, `getConditions`, `isConverged` and `updateLRate` are the
+reference's methods too (resolved through the class chain like Java's virtual dispatch), and every `P.get / P.add / rowMult / userBias.add
+/ for (MatrixEntry me : trainMatrix)` goes into the vendored librec jar's BYTECODE through oracle/jvm/interp.py.  Only what lies outside the
+loop is provided by this script: the initial containers, the hyper-parameters as the Java fields would hold them (float fields as
+floats), `rateDao`'s id maps, and guava's Table for CAMF_CUCI's bias tables.
+
+Inputs and outputs (model state after the epochs, the loss and learning rate of every epoch) are written as data, doubles as hex --
+tests/test_reference_src_golden.py then requires the C oracle, the Python restatement and (on a GPU) the strict fp64 kernels to
+reproduce them BIT FOR BIT.  This is the closest thing to running the reference that a JVM-less image allows: its own statements, its own
+operator order, its own reads-before-writes -- interpreted, not restated.  The reference's text is read where it lies; none of it enters
+this repository.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.jvm import javasrc  # noqa: E402
+from oracle.jvm.interp import VM, Box, GuavaMultimap, GuavaTable, JString, darray, dmatrix, f32, to_list  # noqa: E402
+
+DM, DV, SM = "librec/data/DenseMatrix", "librec/data/DenseVector", "librec/data/SparseMatrix"
+CLASS_MAP = {"DenseMatrix": DM, "DenseVector": DV, "SparseMatrix": SM, "SymmMatrix": "librec/data/SymmMatrix",
+             "Randoms": "librec/util/Randoms", "Stats": "librec/util/Stats"}
+
+
+def hx(v):
+    return float(v).hex()
+
+
+class RateDao:
+    """carskit.data.processor.DataDAO, the three getters the loop uses (DataDAO.java:945-951, 1038-1046): id maps built by the caller"""
+
+    def __init__(self, ui_user, ui_item, ctx_keys):
+        self.ui_user, self.ui_item, self.ctx_keys = ui_user, ui_item, ctx_keys
+
+    def jcall(self, vm, name, desc, args):
+        a = [x.v if isinstance(x, Box) else x for x in args]
+        if name == "getUserIdFromUI":
+            return int(self.ui_user[a[0]])
+        if name == "getItemIdFromUI":
+            return int(self.ui_item[a[0]])
+        if name == "getContextId":
+            return JString(self.ctx_keys[a[0]])
+        raise KeyError("rateDao." + name)
+
+
+class BoxTable(GuavaTable):
+    """guava Table<Integer,Integer,Double> as CAMF_CUCI uses it (get / put with auto-boxing)"""
+
+    def jcall(self, vm, name, desc, args):
+        if name == "get":
+            return self.rows[args[0]][args[1]]
+        return super().jcall(vm, name, desc, args)
+
+
+def dense(vm, arr):
+    m = vm.new_object(DM)
+    vm.call(DM, "<init>", "([[D)V", [m, dmatrix(np.asarray(arr, dtype=np.float64))])
+    return m
+
+
+def vector(vm, arr):
+    v = vm.new_object(DV)
+    vm.call(DV, "<init>", "([D)V", [v, darray(np.asarray(arr, dtype=np.float64))])
+    return v
+
+
+def sparse(vm, n_rows, n_cols, cells):
+    t, cm = GuavaTable(), GuavaMultimap()
+    for r, c, v in cells:
+        t.put(int(r), int(c), float(v))
+        cm.put(int(c), int(r))
+    s = vm.new_object(SM)
+    vm.call(SM, "<init>", "(IILcom/google/common/collect/Table;Lcom/google/common/collect/Multimap;)V", [s, n_rows, n_cols, t, cm])
+    return s
+
+
+def problem(rng, n_users, n_items, n_dims, conds_per_dim, n_ratings):
+    """a small contextual rating set in the reference's shapes: (ui pair, context) cells of a sparse matrix, CRS order"""
+    n_conds = n_dims * conds_per_dim
+    pairs, ctxs, cells = {}, {}, {}
+    ui_user, ui_item, ctx_keys = [], [], []
+    while len(cells) < n_ratings:
+        u, j = int(rng.integers(n_users)), int(rng.integers(n_items))
+        conds = tuple(d * conds_per_dim + int(rng.integers(conds_per_dim)) for d in range(n_dims))
+        if (u, j) not in pairs:
+            pairs[(u, j)] = len(pairs)
+            ui_user.append(u)
+            ui_item.append(j)
+        key = ",".join(str(c) for c in conds)
+        if key not in ctxs:
+            ctxs[key] = len(ctxs)
+            ctx_keys.append(key)
+        cells[(pairs[(u, j)], ctxs[key])] = float(rng.integers(1, 6))
+    order = sorted(cells)
+    return {"n_users": n_users, "n_items": n_items, "n_conds": n_conds, "ui_user": ui_user, "ui_item": ui_item, "ctx_keys": ctx_keys,
+            "cells": [[ui, c, cells[(ui, c)]] for ui, c in order]}
+
+
+MODELS = {
+    "BiasedMF": ("alg/baseline/cf/BiasedMF.java",), "PMF": ("alg/baseline/cf/PMF.java",),
+    "CAMF_C": ("alg/cars/adaptation/dependent/dev/CAMF_C.java", "alg/cars/adaptation/dependent/CAMF.java", "generic/ContextRecommender.java"),
+    "CAMF_CI": ("alg/cars/adaptation/dependent/dev/CAMF_CI.java", "alg/cars/adaptation/dependent/CAMF.java", "generic/ContextRecommender.java"),
+    "CAMF_CU": ("alg/cars/adaptation/dependent/dev/CAMF_CU.java", "alg/cars/adaptation/dependent/CAMF.java", "generic/ContextRecommender.java"),
+    "CAMF_CUCI": ("alg/cars/adaptation/dependent/dev/CAMF_CUCI.java", "generic/ContextRecommender.java"),
+}
+STATE = {"BiasedMF": ("userBias", "itemBias"), "PMF": (), "CAMF_C": ("userBias", "itemBias", "condBias"), "CAMF_CI": ("userBias", "icBias"),
+         "CAMF_CU": ("itemBias", "ucBias"), "CAMF_CUCI": ("ucBias", "icBias")}
+
+
+def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3, bold=True):
+    vm = VM(os.path.join(ref, "lib", "librec-v1.4-alpha.jar"))
+    rng = np.random.default_rng(seed)
+    nu, ni, nc = prob["n_users"], prob["n_items"], prob["n_conds"]
+    init = {"P": 0.1 * rng.standard_normal((nu, k)), "Q": 0.1 * rng.standard_normal((ni, k))}
+    shapes = {"userBias": (nu,), "itemBias": (ni,), "condBias": (nc,), "ucBias": (nu, nc), "icBias": (ni, nc)}
+    for name in STATE[model]:
+        init[name] = rng.random(shapes[name]) if name in ("ucBias", "icBias") and model != "CAMF_CUCI" else 0.1 * rng.standard_normal(shapes[name])
+    src = [os.path.join(ref, "src", "carskit", p) for p in MODELS[model]] + \
+          [os.path.join(ref, "src", "carskit", "generic", "IterativeRecommender.java"), os.path.join(ref, "src", "carskit", "generic", "Recommender.java")]
+    this = javasrc.This(vm, src, CLASS_MAP)
+    two_d = model in ("BiasedMF", "PMF")
+    cells = prob["cells"]
+    if two_d:   # DataDAO.toTraditionalSparseMatrix: users x items, the mean over contexts of every (user, item) pair
+        acc = {}
+        for ui, c, v in cells:
+            key = (prob["ui_user"][ui], prob["ui_item"][ui])
+            s, n = acc.get(key, (0.0, 0))
+            acc[key] = (s + v, n + 1)
+        cells2 = [[u, j, s / n] for (u, j), (s, n) in sorted(acc.items())]
+        train2 = sparse(vm, nu, ni, cells2)
+    train_ctx = sparse(vm, len(prob["ui_user"]), len(prob["ctx_keys"]), cells)
+    vals = [v for _, _, v in cells]
+    gm = 0.0
+    for v in vals:
+        gm += v
+    gm = gm / sum(1 for v in vals if v != 0.0)                 # SparseMatrix.getGlobalAvg over the contextual train matrix (Recommender.java:265)
+    F = this.fields
+    F.update({"P": dense(vm, init["P"]), "Q": dense(vm, init["Q"]), "numFactors": k, "numIters": iters, "numUsers": nu, "numItems": ni,
+              "numConditions": nc, "lRate": float(f32(lrate)), "initLRate": f32(lrate), "maxLRate": f32(-1.0), "decay": f32(-1.0),
+              "isBoldDriver": bool(bold), "regU": f32(reg), "regI": f32(reg), "regB": f32(reg), "regC": f32(reg_c),
+              "globalMean": gm, "loss": 0.0, "last_loss": 0.0, "measure": 0.0, "last_measure": 0.0, "earlyStopMeasure": None,
+              "verbose": False, "isResultsOut": False, "minRate": 1.0, "maxRate": 5.0, "isUserSplitting": False, "isItemSplitting": False,
+              "algoName": model, "foldInfo": "", "trainMatrix": train_ctx, "train": train2 if two_d else None,
+              "rateDao": RateDao(prob["ui_user"], prob["ui_item"], prob["ctx_keys"]), "__enums__": ("Measure",)})
+    for name in STATE[model]:
+        if model == "CAMF_CUCI":
+            t = BoxTable()
+            for r_ in range(init[name].shape[0]):
+                for c_ in range(init[name].shape[1]):
+                    t.put(r_, c_, init[name][r_, c_])
+            F[name] = t
+        else:
+            F[name] = dense(vm, init[name]) if init[name].ndim == 2 else vector(vm, init[name])
+    trace = []
+    this.hooks["isConverged"] = lambda th, args: trace.append((th.fields["loss"], th.fields["lRate"]))
+    this.call("buildModel", [])
+
+    def out_state(name):
+        o = F[name]
+        if isinstance(o, BoxTable):
+            a = np.array([[o.rows[Box(r_, "Integer")][Box(c_, "Integer")].v for c_ in range(init[name].shape[1])] for r_ in range(init[name].shape[0])])
+        else:
+            a = np.array(to_list(o.fields["data"]), dtype=np.float64)
+        return [hx(x) for x in a.ravel()]
+    rec = {"model": model, "k": k, "iters": iters, "bold_driver": bool(bold), "lrate": float(f32(lrate)), "regU": float(f32(reg)),
+           "regI": float(f32(reg)), "regB": float(f32(reg)), "regC": float(f32(reg_c)), "global_mean": hx(gm),
+           "problem": prob, "init": {n: [hx(x) for x in a.ravel()] for n, a in init.items()},
+           "final": {n: out_state(n) for n in init}, "epoch_loss": [hx(l) for l, _ in trace], "epoch_lrate": [hx(r) for _, r in trace],
+           "final_lrate": hx(F["lRate"]), "java_statements_executed": this.statements, "bytecode_instructions": vm.steps}
+    return rec
+
+
+def main():
+    ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    rng = np.random.default_rng(20260928)
+    out = {"source": "reference Java SOURCE (src/carskit/**) interpreted by oracle/jvm/javasrc.py over the librec jar's bytecode "
+                     "(oracle/jvm/interp.py); doubles are C99 hex strings", "cases": []}
+    for model in MODELS:
+        for (nu, ni, nd, cpd, n, k, iters) in ((7, 5, 2, 3, 60, 3, 4), (12, 9, 3, 2, 150, 10, 3)):
+            prob = problem(rng, nu, ni, nd, cpd, n)
+            rec = run_model(ref, model, prob, k, iters, seed=int(rng.integers(1 << 30)))
+            out["cases"].append(rec)
+            print("%-10s k=%-3d %d ratings, %d epochs: loss %s -> %s   (%d Java statements, %d bytecode instructions)"
+                  % (model, k, len(prob["cells"]), iters, float.fromhex(rec["epoch_loss"][0]), float.fromhex(rec["epoch_loss"][-1]),
+                     rec["java_statements_executed"], rec["bytecode_instructions"]), flush=True)
+    path = os.path.join(ROOT, "tests", "golden", "reference_src.json")
+    json.dump(out, open(path, "w"), indent=0)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+"""The oracle (and, on a GPU, the strict fp64 kernels) against the reference's OWN Java source, executed.
+
+tests/golden/reference_src.json was minted in the build container by oracle/mint_reference_src.py: for BiasedMF, PMF, CAMF_C, CAMF_CI,
+CAMF_CU and CAMF_CUCI the reference's `buildModel()` -- with its `predict`, `getConditions`, `isConverged`, `updateLRate` -- was run
+statement by statement from the text of src/carskit/**.java by the Java-subset interpreter oracle/jvm/javasrc.py, on top of the vendored
+librec jar's bytecode (oracle/jvm/interp.py).  The fixture holds inputs (rating cells, id maps, initial containers, hyper-parameters as
+the Java fields hold them) and outputs (every epoch's loss and learning rate, the final containers), doubles as hex.
+
+Bar: BIT-identical -- every loss, every bold-driver rate, every element of every container -- for the C oracle and the independent Python
+restatement (CPU) and for the GPU's strict fp64 serial kernels (`-m gpu`).  This pins the statement order, the reads-before-writes, the
+operator association and the CAMF_C loss quirk of the `src/carskit` loops against the reference's text itself rather than against a
+reading of it."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c
+from tests import util
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_src.json")))["cases"]
+SHAPES = lambda c: {"P": (c["problem"]["n_users"], c["k"]), "Q": (c["problem"]["n_items"], c["k"]),
+                    "userBias": (c["problem"]["n_users"],), "itemBias": (c["problem"]["n_items"],), "condBias": (c["problem"]["n_conds"],),
+                    "ucBias": (c["problem"]["n_users"], c["problem"]["n_conds"]), "icBias": (c["problem"]["n_items"], c["problem"]["n_conds"])}
+
+
+def fx(v):
+    return float.fromhex(v)
+
+
+def _inputs(c):
+    p = c["problem"]
+    cells = p["cells"]
+    two_d = c["model"] in util.TWO_D
+    if two_d:   # the 2-D train matrix: mean over contexts per (user, item), CRS order (DataDAO.toTraditionalSparseMatrix)
+        acc = {}
+        for ui, _, v in cells:
+            key = (p["ui_user"][ui], p["ui_item"][ui])
+            s, n = acc.get(key, (0.0, 0))
+            acc[key] = (s + v, n + 1)
+        keys = sorted(acc)
+        u = np.array([k[0] for k in keys], np.int32)
+        j = np.array([k[1] for k in keys], np.int32)
+        ctx = np.zeros(len(keys), np.int32)
+        r = np.array([acc[k][0] / acc[k][1] for k in keys])
+    else:
+        u = np.array([p["ui_user"][ui] for ui, _, _ in cells], np.int32)
+        j = np.array([p["ui_item"][ui] for ui, _, _ in cells], np.int32)
+        ctx = np.array([cc for _, cc, _ in cells], np.int32)
+        r = np.array([v for _, _, v in cells])
+    conds = [[int(x) for x in key.split(",")] for key in p["ctx_keys"]]
+    ctx_ptr = np.cumsum([0] + [len(x) for x in conds]).astype(np.int32)
+    ctx_conds = np.array([x for cs in conds for x in cs], np.int32)
+    shapes = SHAPES(c)
+    state = {n: np.array([fx(x) for x in v]).reshape(shapes[n]) for n, v in c["init"].items()}
+    return u, j, ctx, r, ctx_ptr, ctx_conds, state
+
+
+def _check(c, losses, lrates, state):
+    assert [float(x).hex() for x in losses] == c["epoch_loss"]
+    assert [float(x).hex() for x in lrates] == c["epoch_lrate"]
+    for n, want in c["final"].items():
+        got = [float(x).hex() for x in np.asarray(state[n], dtype=np.float64).ravel()]
+        assert got == want, n
+
+
+@pytest.mark.parametrize("case", GOLD, ids=lambda c: "%s-k%d" % (c["model"], c["k"]))
+def test_c_oracle_reproduces_the_interpreted_reference_source_bit_for_bit(case):
+    u, j, ctx, r, ctx_ptr, ctx_conds, state = _inputs(case)
+    p = case["problem"]
+    gm = fx(case["global_mean"])
+    orc = oracle_c.Oracle(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], u, j, ctx, r, ctx_ptr, ctx_conds, state, gm,
+                          case["regU"], case["regI"], case["regB"], case["regC"])
+    losses, lrates, _ = orc.build_model(case["iters"], case["lrate"], bold_driver=case["bold_driver"])
+    _check(case, losses, lrates, orc.state)
+    # the global mean the hosts compute from the contextual train matrix
+    assert oracle_c.global_mean(np.array([v for _, _, v in p["cells"]])) == gm
+
+
+@pytest.mark.parametrize("case", GOLD, ids=lambda c: "%s-k%d" % (c["model"], c["k"]))
+def test_python_restatement_reproduces_it_too(case):
+    from oracle import oracle_np
+    u, j, ctx, r, ctx_ptr, ctx_conds, state = _inputs(case)
+    p = case["problem"]
+    conds = [ctx_conds[ctx_ptr[x]:ctx_ptr[x + 1]].tolist() for x in range(len(ctx_ptr) - 1)]
+    m = oracle_np.MODELS[case["model"]](case["k"], p["n_users"], p["n_items"], p["n_conds"], conds, fx(case["global_mean"]), case["regU"],
+                                        case["regI"], case["regB"], case["regC"])
+    for n, a in state.items():
+        setattr(m, n, a.tolist())
+    lr, last, losses, lrates = case["lrate"], 0.0, [], []
+    for it in range(1, case["iters"] + 1):
+        lrates.append(lr)
+        loss = m.epoch(list(zip(u.tolist(), j.tolist(), ctx.tolist(), r.tolist())), lr)
+        losses.append(loss)
+        if it > 1:                                   # IterativeRecommender.updateLRate, bold driver
+            lr = lr * 1.05 if abs(last) > abs(loss) else lr * 0.5
+        last = loss
+    _check(case, losses, lrates, {n: np.array(getattr(m, n)) for n in case["final"]})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GOLD, ids=lambda c: "%s-k%d" % (c["model"], c["k"]))
+def test_gpu_strict_fp64_reproduces_the_interpreted_reference_source_bit_for_bit(case):
+    """The PRODUCT path against the reference's own statements: STATE_F64 | SCHED_SERIAL | STRICT -- model, losses and bold-driver rates."""
+    from carskit_amd import capi
+    u, j, ctx, r, ctx_ptr, ctx_conds, state = _inputs(case)
+    p = case["problem"]
+    inst = capi.Instance(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"],
+                         flags=capi.FLAG_STATE_F64 | capi.FLAG_SCHED_SERIAL | capi.FLAG_STRICT)
+    inst.set_hparams(case["regU"], case["regI"], case["regB"], case["regC"], fx(case["global_mean"]))
+    if case["model"] in util.TWO_D:
+        inst.set_ratings(u, j, None, r)
+    else:
+        inst.set_ratings(u, j, ctx, r, ctx_ptr, ctx_conds)
+    inst.set_states(state)
+    losses, lrates = inst.train(case["iters"], case["lrate"], bold_driver=case["bold_driver"])
+    _check(case, losses, lrates, inst.get_states())
+    # and the order-exact LEVEL schedule (the production schedule family): same model bits, loss to rounding
+    if case["model"] != "CAMF_C":
+        lv = capi.Instance(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], flags=capi.FLAG_STATE_F64 | capi.FLAG_STRICT)
+        lv.set_hparams(case["regU"], case["regI"], case["regB"], case["regC"], fx(case["global_mean"]))
+        if case["model"] in util.TWO_D:
+            lv.set_ratings(u, j, None, r)
+        else:
+            lv.set_ratings(u, j, ctx, r, ctx_ptr, ctx_conds)
+        lv.set_states(state)
+        l2, r2 = lv.train(case["iters"], case["lrate"], bold_driver=case["bold_driver"])
+        np.testing.assert_allclose(l2, [fx(x) for x in case["epoch_loss"]], rtol=1e-12)
+        assert [float(x).hex() for x in r2] == case["epoch_lrate"]
+        for n, want in case["final"].items():
+            assert [float(x).hex() for x in lv.get_state(n).ravel()] == want, n
