@@ -572,7 +572,7 @@ class JCollection:
             self.items.append(args[0])
             return 1
         if name == "get":
-            return self.items[args[0]]
+            return self.items[args[0].v if isinstance(args[0], Box) else args[0]]
         if name == "isEmpty":
             return int(not self.items)
         if name == "contains":
@@ -627,6 +627,12 @@ class GuavaTable:
             return old
         if name == "size":
             return sum(len(r) for r in self.rows.values())
+        if name == "contains":
+            return int(args[0] in self.rows and args[1] in self.rows[args[0]])
+        if name == "get":
+            return self.rows.get(args[0], {}).get(args[1])
+        if name == "remove":
+            return self.rows.get(args[0], {}).pop(args[1], None)
         if name == "cellSet":
             return JCollection([Cell(r, c, v) for r, cols in self.rows.items() for c, v in cols.items()])
         if name == "row":

@@ -761,7 +761,7 @@ class Env:
         if k == "new":
             return self.new(n[1], [self.eval(a) for a in n[2]])
         if k == "newarray":
-            return [None] * unbox(self.eval(n[2]))
+            return [{"double": 0.0, "int": 0, "float": f32(0.0), "boolean": False, "long": JLong(0)}.get(n[1])] * unbox(self.eval(n[2]))
         raise NotImplementedError(k)
 
     def get_name(self, name):
@@ -1035,11 +1035,17 @@ STATIC_CALLS = {
     ("Integer", "parseInt"): lambda x: int(x),
     ("Double", "valueOf"): lambda x: Box(float(x), "Double"),
     ("String", "format"): lambda *a: "<formatted>",
+    ("HashBasedTable", "create"): lambda: _guava_table(),
     ("Logs", "debug"): lambda *a: None,
     ("Logs", "info"): lambda *a: None,
     ("Logs", "error"): lambda *a: None,
     ("Logs", "warn"): lambda *a: None,
 }
+
+
+def _guava_table():
+    from .interp import GuavaTable
+    return GuavaTable()
 
 
 def _exit(code):

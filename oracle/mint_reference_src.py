@@ -3,7 +3,8 @@
 
     python oracle/mint_reference_src.py [/root/reference]
 
-For every level-schedulable recommender of the path -- BiasedMF, PMF, CAMF_C, CAMF_CI, CAMF_CU, CAMF_CUCI -- the reference's
+For every SGD recommender of the path -- BiasedMF, PMF, CAMF_C, CAMF_CI, CAMF_CU, CAMF_CUCI and SVD++, CAMF_ICS, CAMF_LCS,
+CAMF_MCS -- the reference's
 `buildModel()` is run, statement by statement, from the text of its .java files (src/carskit/alg/**, src/carskit/generic/**) by
 oracle/jvm/javasrc.py: `predict(u, j, c, bound)`, the model's own `predict`, `getConditions`, `isConverged` and `updateLRate` are the
 reference's methods too (resolved through the class chain like Java's virtual dispatch), and every `P.get / P.add / rowMult / userBias.add
@@ -113,9 +114,32 @@ MODELS = {
     "CAMF_CI": ("alg/cars/adaptation/dependent/dev/CAMF_CI.java", "alg/cars/adaptation/dependent/CAMF.java", "generic/ContextRecommender.java"),
     "CAMF_CU": ("alg/cars/adaptation/dependent/dev/CAMF_CU.java", "alg/cars/adaptation/dependent/CAMF.java", "generic/ContextRecommender.java"),
     "CAMF_CUCI": ("alg/cars/adaptation/dependent/dev/CAMF_CUCI.java", "generic/ContextRecommender.java"),
+    # the remaining SGD recommenders of the family
+    "SVD++": ("alg/baseline/cf/SVDPlusPlus.java", "alg/baseline/cf/BiasedMF.java"),
+    "CAMF_ICS": ("alg/cars/adaptation/dependent/sim/CAMF_ICS.java", "alg/cars/adaptation/dependent/CAMF.java", "generic/ContextRecommender.java"),
+    "CAMF_LCS": ("alg/cars/adaptation/dependent/sim/CAMF_LCS.java", "alg/cars/adaptation/dependent/CAMF.java", "generic/ContextRecommender.java"),
+    "CAMF_MCS": ("alg/cars/adaptation/dependent/sim/CAMF_MCS.java", "alg/cars/adaptation/dependent/CAMF.java", "generic/ContextRecommender.java"),
 }
 STATE = {"BiasedMF": ("userBias", "itemBias"), "PMF": (), "CAMF_C": ("userBias", "itemBias", "condBias"), "CAMF_CI": ("userBias", "icBias"),
-         "CAMF_CU": ("itemBias", "ucBias"), "CAMF_CUCI": ("ucBias", "icBias")}
+         "CAMF_CU": ("itemBias", "ucBias"), "CAMF_CUCI": ("ucBias", "icBias"),
+         "SVD++": ("userBias", "itemBias", "Y"), "CAMF_ICS": ("ccMatrix",), "CAMF_LCS": ("cfMatrix",), "CAMF_MCS": ("cVector",)}
+NUM_F = 4   # `-f` of CAMF_LCS (CAMF_LCS.java:37)
+JAVA_FIELD = {"ccMatrix": "ccMatrix_ICS", "cfMatrix": "cfMatrix_LCS", "cVector": "cVector_MCS"}
+
+
+class UserItemsCache:
+    """train.rowColumnsCache(cacheSpec) (SVDPlusPlus.java:52): user -> the items of the user's row of the 2-D train matrix, ascending"""
+
+    def __init__(self, cells2, n_users):
+        self.items = [[] for _ in range(n_users)]
+        for u, j, _ in cells2:
+            self.items[u].append(j)
+
+    def jcall(self, vm, name, desc, args):
+        from oracle.jvm.interp import JCollection
+        if name == "get":
+            return JCollection([Box(j, "Integer") for j in self.items[args[0].v if isinstance(args[0], Box) else args[0]]])
+        raise KeyError("userItemsCache." + name)
 
 
 def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3, bold=True):
@@ -123,13 +147,26 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
     rng = np.random.default_rng(seed)
     nu, ni, nc = prob["n_users"], prob["n_items"], prob["n_conds"]
     init = {"P": 0.1 * rng.standard_normal((nu, k)), "Q": 0.1 * rng.standard_normal((ni, k))}
-    shapes = {"userBias": (nu,), "itemBias": (ni,), "condBias": (nc,), "ucBias": (nu, nc), "icBias": (ni, nc)}
+    shapes = {"userBias": (nu,), "itemBias": (ni,), "condBias": (nc,), "ucBias": (nu, nc), "icBias": (ni, nc), "Y": (ni, k),
+              "ccMatrix": (nc, nc), "cfMatrix": (nc, NUM_F), "cVector": (nc,)}
+    n_dims = len(prob["ctx_keys"][0].split(","))
+    upbound = float(1.0 / np.sqrt(float(n_dims)))     # CAMF_MCS.java:44
     for name in STATE[model]:
-        init[name] = rng.random(shapes[name]) if name in ("ucBias", "icBias") and model != "CAMF_CUCI" else 0.1 * rng.standard_normal(shapes[name])
+        if name == "ccMatrix":                        # symmetric, near 1 (CAMF_ICS.java:45-49 starts at exactly 1)
+            a = 1.0 + 0.05 * rng.standard_normal(shapes[name])
+            init[name] = (a + a.T) / 2
+        elif name == "cfMatrix":
+            init[name] = rng.random(shapes[name])
+        elif name == "cVector":
+            init[name] = rng.random(shapes[name]) * upbound
+        else:
+            init[name] = rng.random(shapes[name]) if name in ("ucBias", "icBias") and model != "CAMF_CUCI" else 0.1 * rng.standard_normal(shapes[name])
+    if model in ("CAMF_ICS", "CAMF_LCS", "CAMF_MCS"):  # isRankingPred: P and Q start uniform (CAMF_ICS.java:36-41); any values do for the pin
+        init["P"], init["Q"] = rng.random((nu, k)), rng.random((ni, k))
     src = [os.path.join(ref, "src", "carskit", p) for p in MODELS[model]] + \
           [os.path.join(ref, "src", "carskit", "generic", "IterativeRecommender.java"), os.path.join(ref, "src", "carskit", "generic", "Recommender.java")]
     this = javasrc.This(vm, src, CLASS_MAP)
-    two_d = model in ("BiasedMF", "PMF")
+    two_d = model in ("BiasedMF", "PMF", "SVD++")
     cells = prob["cells"]
     if two_d:   # DataDAO.toTraditionalSparseMatrix: users x items, the mean over contexts of every (user, item) pair
         acc = {}
@@ -153,7 +190,26 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
               "verbose": False, "isResultsOut": False, "minRate": 1.0, "maxRate": 5.0, "isUserSplitting": False, "isItemSplitting": False,
               "algoName": model, "foldInfo": "", "trainMatrix": train_ctx, "train": train2 if two_d else None,
               "rateDao": RateDao(prob["ui_user"], prob["ui_item"], prob["ctx_keys"]), "__enums__": ("Measure",)})
+    # EmptyContextConditions: one ":na" condition per dimension, in header order (ContextRecommender.java:43) -- here the first of each
+    conds_per_dim = nc // n_dims
+    from oracle.jvm.interp import JCollection
+    empty = [d * conds_per_dim for d in range(n_dims)]
+    F.update({"EmptyContextConditions": JCollection([Box(e, "Integer") for e in empty]), "upbound": upbound, "lowbound": 1.0 / (10.0 ** 100),
+              "isRankingPred": model.startswith("CAMF_") and model.endswith("CS"), "numF": NUM_F})
+    if model == "SVD++":
+        F["userItemsCache"] = UserItemsCache(cells2, nu)
     for name in STATE[model]:
+        if name == "ccMatrix":
+            sm = vm.new_object("librec/data/SymmMatrix")
+            vm.call("librec/data/SymmMatrix", "<init>", "(I)V", [sm, nc])
+            for a_ in range(nc):
+                for b_ in range(a_, nc):
+                    vm.call("librec/data/SymmMatrix", "set", "(IID)V", [sm, a_, b_, float(init[name][a_, b_])])
+            F[JAVA_FIELD[name]] = sm
+            continue
+        if name in JAVA_FIELD:
+            F[JAVA_FIELD[name]] = dense(vm, init[name]) if init[name].ndim == 2 else vector(vm, init[name])
+            continue
         if model == "CAMF_CUCI":
             t = BoxTable()
             for r_ in range(init[name].shape[0]):
@@ -167,7 +223,10 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
     this.call("buildModel", [])
 
     def out_state(name):
-        o = F[name]
+        o = F[JAVA_FIELD.get(name, name)]
+        if name == "ccMatrix":
+            a = np.array([[vm.call("librec/data/SymmMatrix", "get", "(II)D", [o, a_, b_]) for b_ in range(nc)] for a_ in range(nc)])
+            return [hx(x) for x in a.ravel()]
         if isinstance(o, BoxTable):
             a = np.array([[o.rows[Box(r_, "Integer")][Box(c_, "Integer")].v for c_ in range(init[name].shape[1])] for r_ in range(init[name].shape[0])])
         else:
@@ -175,6 +234,7 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
         return [hx(x) for x in a.ravel()]
     rec = {"model": model, "k": k, "iters": iters, "bold_driver": bool(bold), "lrate": float(f32(lrate)), "regU": float(f32(reg)),
            "regI": float(f32(reg)), "regB": float(f32(reg)), "regC": float(f32(reg_c)), "global_mean": hx(gm),
+           "empty_conds": empty, "n_ctx_dims": n_dims, "num_f": NUM_F,
            "problem": prob, "init": {n: [hx(x) for x in a.ravel()] for n, a in init.items()},
            "final": {n: out_state(n) for n in init}, "epoch_loss": [hx(l) for l, _ in trace], "epoch_lrate": [hx(r) for _, r in trace],
            "final_lrate": hx(F["lRate"]), "java_statements_executed": this.statements, "bytecode_instructions": vm.steps}

@@ -19,10 +19,15 @@ import pytest
 from oracle import oracle_c
 from tests import util
 
-GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_src.json")))["cases"]
+ALL = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_src.json")))["cases"]
+SIM = ("SVD++", "CAMF_ICS", "CAMF_LCS", "CAMF_MCS")          # oracle/carskit_oracle_sim.c
+GOLD = [c for c in ALL if c["model"] not in SIM]
+GOLD_SIM = [c for c in ALL if c["model"] in SIM]
 SHAPES = lambda c: {"P": (c["problem"]["n_users"], c["k"]), "Q": (c["problem"]["n_items"], c["k"]),
                     "userBias": (c["problem"]["n_users"],), "itemBias": (c["problem"]["n_items"],), "condBias": (c["problem"]["n_conds"],),
-                    "ucBias": (c["problem"]["n_users"], c["problem"]["n_conds"]), "icBias": (c["problem"]["n_items"], c["problem"]["n_conds"])}
+                    "ucBias": (c["problem"]["n_users"], c["problem"]["n_conds"]), "icBias": (c["problem"]["n_items"], c["problem"]["n_conds"]),
+                    "Y": (c["problem"]["n_items"], c["k"]), "ccMatrix": (c["problem"]["n_conds"], c["problem"]["n_conds"]),
+                    "cfMatrix": (c["problem"]["n_conds"], c.get("num_f", 0)), "cVector": (c["problem"]["n_conds"],)}
 
 
 def fx(v):
@@ -32,7 +37,7 @@ def fx(v):
 def _inputs(c):
     p = c["problem"]
     cells = p["cells"]
-    two_d = c["model"] in util.TWO_D
+    two_d = c["model"] in util.TWO_D or c["model"] == "SVD++"
     if two_d:   # the 2-D train matrix: mean over contexts per (user, item), CRS order (DataDAO.toTraditionalSparseMatrix)
         acc = {}
         for ui, _, v in cells:
@@ -130,3 +135,46 @@ def test_gpu_strict_fp64_reproduces_the_interpreted_reference_source_bit_for_bit
         assert [float(x).hex() for x in r2] == case["epoch_lrate"]
         for n, want in case["final"].items():
             assert [float(x).hex() for x in lv.get_state(n).ravel()] == want, n
+
+
+def _bold_loop(epoch, case):
+    lr, last, losses, lrates = case["lrate"], 0.0, [], []
+    for it in range(1, case["iters"] + 1):
+        lrates.append(lr)
+        loss = epoch(lr)
+        losses.append(loss)
+        if it > 1:
+            lr = lr * 1.05 if abs(last) > abs(loss) else lr * 0.5
+        last = loss
+    return losses, lrates
+
+
+@pytest.mark.parametrize("case", GOLD_SIM, ids=lambda c: "%s-k%d" % (c["model"], c["k"]))
+def test_sim_oracle_reproduces_the_interpreted_reference_source_bit_for_bit(case):
+    """SVD++ / CAMF_ICS / CAMF_LCS / CAMF_MCS (oracle/carskit_oracle_sim.c) against SVDPlusPlus.java / sim/CAMF_*.java, executed."""
+    u, j, ctx, r, ctx_ptr, ctx_conds, state = _inputs(case)
+    p = case["problem"]
+    orc = oracle_c.SimOracle(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], u, j, ctx, r, ctx_ptr, ctx_conds,
+                             np.array(case["empty_conds"], np.int32), state, fx(case["global_mean"]), case["regU"], case["regI"], case["regB"],
+                             case["regC"], n_ctx_dims=case["n_ctx_dims"])
+    losses, lrates = _bold_loop(orc.epoch, case)
+    _check(case, losses, lrates, orc.state)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GOLD_SIM, ids=lambda c: "%s-k%d" % (c["model"], c["k"]))
+def test_gpu_strict_fp64_sim_models_reproduce_the_interpreted_reference_source(case):
+    from carskit_amd import capi
+    u, j, ctx, r, ctx_ptr, ctx_conds, state = _inputs(case)
+    p = case["problem"]
+    inst = capi.Instance(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"],
+                         flags=capi.FLAG_STATE_F64 | capi.FLAG_SCHED_SERIAL | capi.FLAG_STRICT)
+    inst.set_hparams(case["regU"], case["regI"], case["regB"], case["regC"], fx(case["global_mean"]))
+    if case["model"] != "SVD++":
+        inst.set_sim_params(case["num_f"], case["n_ctx_dims"], case["empty_conds"])
+        inst.set_ratings(u, j, ctx, r, ctx_ptr, ctx_conds)
+    else:
+        inst.set_ratings(u, j, None, r)
+    inst.set_states(state)
+    losses, lrates = inst.train(case["iters"], case["lrate"], bold_driver=case["bold_driver"])
+    _check(case, losses, lrates, inst.get_states())
