@@ -266,7 +266,9 @@ __global__ __launch_bounds__(256) void fm_w0_reduce2(FmArgs a, const double *scr
 // w0 phase, apply: w0' = -part[0]/(size + regLw); err_i += w0' - w0   (FM.java:153-169)
 __global__ __launch_bounds__(256) void fm_w0_apply(FmArgs a) {
     const double w0 = *a.w0;
-    const double upd = 0.0 - a.part[0] / ((double)a.global_size + a.regLw);
+    // `size + regLw` is int + float in the reference (FM.java:47,161): Java's binary numeric promotion makes it a FLOAT sum (at C4's
+    // 25 M ratings regLw vanishes in it) -- found by executing the reference's source, tests/test_reference_src_golden.py
+    const double upd = 0.0 - a.part[0] / (double)((float)(int)a.global_size + (float)a.regLw);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256)
         a.R[i].x = fm_err(a, i, a.j[i], a.ctx[i]) + upd - w0;
     if (blockIdx.x == 0 && threadIdx.x == 0) a.part[2] = upd; // committed to *w0 by fm_w0_commit after all blocks read w0

@@ -88,7 +88,9 @@ double orc_fm_sweep(orc_fm *m) {
         update_w0 += err - m->w0;
         loss += err * err;
     }
-    update_w0 = update_w0 / ((double)size + regLw);
+    /* FM.java:161 `update_w0/(size + regLw)`: size is an int and regLw a float FIELD (FM.java:47), so Java's binary numeric promotion
+     * computes the sum in FLOAT -- found by executing the reference's source (oracle/mint_reference_src.py), not by reading it */
+    update_w0 = update_w0 / (double)((float)(int)size + (float)regLw);
     update_w0 = 0 - update_w0;
     for (int64_t i = 0; i < size; ++i) m->errors[i] = m->errors[i] + update_w0 - m->w0;
     loss += regLw * m->w0 * m->w0;

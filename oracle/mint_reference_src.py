@@ -52,6 +52,8 @@ class RateDao:
             return int(self.ui_item[a[0]])
         if name == "getContextId":
             return JString(self.ctx_keys[a[0]])
+        if name == "numContextDims":
+            return len(self.ctx_keys[0].split(","))
         raise KeyError("rateDao." + name)
 
 
@@ -241,6 +243,36 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
     return rec
 
 
+def run_fm(ref, prob, k, iters, seed, reg_lw=0.01, reg_lf=0.02):
+    """FM.buildModel (FM.java:115-220: the dense ALS / coordinate-descent sweep) from source; state = (w0, w, V)"""
+    vm = VM(os.path.join(ref, "lib", "librec-v1.4-alpha.jar"))
+    rng = np.random.default_rng(seed)
+    nu, ni, nc = prob["n_users"], prob["n_items"], prob["n_conds"]
+    p = nu + ni + nc
+    size = len(prob["cells"])
+    w, V = rng.random(p), 0.1 * rng.standard_normal((p, k))
+    src = [os.path.join(ref, "src", "carskit", q) for q in ("alg/cars/adaptation/dependent/FM.java", "generic/ContextRecommender.java",
+                                                              "generic/IterativeRecommender.java", "generic/Recommender.java")]
+    this = javasrc.This(vm, src, CLASS_MAP)
+    F = this.fields
+    F.update({"w0": 0.0, "p": p, "k": k, "size": size, "w": vector(vm, w), "V": dense(vm, V), "Q": dense(vm, np.zeros((size, k))),
+              "regLw": f32(reg_lw), "regLf": f32(reg_lf), "numFactors": k, "numIters": iters, "numUsers": nu, "numItems": ni,
+              "numConditions": nc, "loss": 0.0, "trainMatrix": sparse(vm, len(prob["ui_user"]), len(prob["ctx_keys"]), prob["cells"]),
+              "rateDao": RateDao(prob["ui_user"], prob["ui_item"], prob["ctx_keys"]), "verbose": False})
+    this.call("buildModel", [])
+    preds = []
+    for ui, c, _ in prob["cells"][:12]:
+        u_, j_ = prob["ui_user"][ui], prob["ui_item"][ui]
+        preds.append([u_, j_, c, hx(this.call("predict", [u_, j_, c]))])
+    return {"model": "FM", "k": k, "iters": iters, "regLw": float(f32(reg_lw)), "regLf": float(f32(reg_lf)), "problem": prob,
+            "n_ctx_dims": len(prob["ctx_keys"][0].split(",")),
+            "init": {"w": [hx(x) for x in w], "V": [hx(x) for x in V.ravel()]},
+            "final": {"w0": hx(F["w0"]), "w": [hx(x) for x in to_list(F["w"].fields["data"])],
+                      "V": [hx(x) for row in to_list(F["V"].fields["data"]) for x in row]},
+            "final_loss": hx(F["loss"]), "predictions": preds,
+            "java_statements_executed": this.statements, "bytecode_instructions": vm.steps}
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     rng = np.random.default_rng(20260928)
@@ -254,6 +286,13 @@ def main():
             print("%-10s k=%-3d %d ratings, %d epochs: loss %s -> %s   (%d Java statements, %d bytecode instructions)"
                   % (model, k, len(prob["cells"]), iters, float.fromhex(rec["epoch_loss"][0]), float.fromhex(rec["epoch_loss"][-1]),
                      rec["java_statements_executed"], rec["bytecode_instructions"]), flush=True)
+    out["fm_cases"] = []
+    for (nu, ni, nd, cpd, n, k, iters) in ((4, 3, 2, 2, 14, 2, 2), (5, 4, 2, 3, 24, 3, 2)):
+        prob = problem(rng, nu, ni, nd, cpd, n)
+        rec = run_fm(ref, prob, k, iters, seed=int(rng.integers(1 << 30)))
+        out["fm_cases"].append(rec)
+        print("FM         k=%-3d %d ratings, %d sweeps   (%d Java statements, %d bytecode instructions)"
+              % (k, len(prob["cells"]), iters, rec["java_statements_executed"], rec["bytecode_instructions"]), flush=True)
     path = os.path.join(ROOT, "tests", "golden", "reference_src.json")
     json.dump(out, open(path, "w"), indent=0)
     print("wrote", path)

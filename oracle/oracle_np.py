@@ -65,6 +65,11 @@ def fdlibm_log(x):
     return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f)
 
 
+def _f32(x):
+    """round to binary32 (Java float arithmetic: the operands and the result of a float operation)"""
+    return struct.unpack("f", struct.pack("f", x))[0]
+
+
 class JavaRandom:
     """java.util.Random from its published algorithm."""
 
@@ -371,7 +376,8 @@ class FM:
         for i in range(self.size):
             upd += self.errors[i] - self.w0
             loss += self.errors[i] * self.errors[i]
-        upd = 0 - upd / (self.size + self.regLw)
+        # `size + regLw` is int + float in the reference (FM.java:47,161): a FLOAT sum (executed source: oracle/mint_reference_src.py)
+        upd = 0 - upd / _f32(_f32(float(self.size)) + _f32(self.regLw))
         for i in range(self.size):
             self.errors[i] = self.errors[i] + upd - self.w0
         loss += self.regLw * self.w0 * self.w0

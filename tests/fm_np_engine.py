@@ -68,7 +68,7 @@ class NumpyFMEngine:
         field, f = self._decode(ph)
         t = self.phase_tensor(ph).numpy()
         if field < 0:
-            upd = 0.0 - t[0] / (self.size + self.regLw)
+            upd = 0.0 - t[0] / float(np.float32(self.size) + np.float32(self.regLw))   # int + float: a float sum (FM.java:161)
             self.err = self.err + upd - self.w0
             self.w0 = upd
             return

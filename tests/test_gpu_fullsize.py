@@ -252,7 +252,7 @@ def test_c4_fm_share_full_size():
         sl = slice(b0, min(data.n, b0 + step))
         err[sl] = data.r[sl] - _fm_predict_np(0.0, w_init, V_init, nu, ni, nc, data.n_dims, u[sl], j[sl], c[sl])
     size = float(data.n)
-    upd = 0.0 - (err - w0).sum() / (size + regw)
+    upd = 0.0 - (err - w0).sum() / float(np.float32(size) + np.float32(regw))   # int + float: a float sum (FM.java:161)
     err += upd - w0
     w0 = upd
     fields = ((u, np.ones(data.n), None, 0, nu), (j, np.ones(data.n), None, nu, ni), (cc, np.full(data.n, xc), has, nu + ni, nc))

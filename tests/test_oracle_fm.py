@@ -61,7 +61,8 @@ def test_fm_error_bookkeeping_matches_predictions():
     lin = w0 + X @ w
     pair = 0.5 * ((X @ V) ** 2 - (X ** 2) @ (V ** 2)).sum(axis=1)
     np.testing.assert_allclose(c.errors, data.r - (lin + pair), rtol=0, atol=1e-13)
-    # the w0 step in closed form: w0' = -(sum(err) - n*w0)/(n + regLw) with w0 = 0
+    # the w0 step in closed form: w0' = -(sum(err) - n*w0)/(n + regLw) with w0 = 0 -- `n + regLw` is int + float in the reference
+    # (FM.java:47,161), i.e. a FLOAT sum (found by executing the reference's source, tests/test_reference_src_golden.py)
     err0 = c.errors.copy()
     c.sweep()
-    assert abs(c.w0 - (-(err0.sum()) / (data.n + REGLW))) < 1e-12
+    assert abs(c.w0 - (-(err0.sum()) / float(np.float32(data.n) + np.float32(REGLW)))) < 1e-12

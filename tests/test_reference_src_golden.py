@@ -178,3 +178,59 @@ def test_gpu_strict_fp64_sim_models_reproduce_the_interpreted_reference_source(c
     inst.set_states(state)
     losses, lrates = inst.train(case["iters"], case["lrate"], bold_driver=case["bold_driver"])
     _check(case, losses, lrates, inst.get_states())
+
+
+FM_GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_src.json")))["fm_cases"]
+
+
+def _fm_inputs(c):
+    p = c["problem"]
+    u = np.array([p["ui_user"][ui] for ui, _, _ in p["cells"]], np.int32)
+    j = np.array([p["ui_item"][ui] for ui, _, _ in p["cells"]], np.int32)
+    ctx = np.array([cc for _, cc, _ in p["cells"]], np.int32)
+    r = np.array([v for _, _, v in p["cells"]])
+    pp = p["n_users"] + p["n_items"] + p["n_conds"]
+    w = np.array([fx(x) for x in c["init"]["w"]])
+    V = np.array([fx(x) for x in c["init"]["V"]]).reshape(pp, c["k"])
+    return u, j, ctx, r, w, V
+
+
+@pytest.mark.parametrize("case", FM_GOLD, ids=lambda c: "FM-k%d" % c["k"])
+def test_fm_oracle_reproduces_the_interpreted_fm_source_bit_for_bit(case):
+    """FM.java:115-220 (the dense ALS / coordinate-descent sweep, its pre-pass, its predict with the context-index quirk) executed from
+    source against oracle/carskit_oracle_fm.c: w0, w, V after the sweeps and the predictions, bit for bit."""
+    u, j, ctx, r, w, V = _fm_inputs(case)
+    p = case["problem"]
+    orc = oracle_c.FMOracle(case["k"], p["n_users"], p["n_items"], p["n_conds"], case["n_ctx_dims"], u, j, ctx, r, 0.0, w, V,
+                            case["regLw"], case["regLf"])
+    orc.init()
+    loss = 0.0
+    for _ in range(case["iters"]):
+        loss = orc.sweep()
+    assert float(orc.w0).hex() == case["final"]["w0"]
+    assert [float(x).hex() for x in orc.w] == case["final"]["w"]
+    assert [float(x).hex() for x in orc.V.ravel()] == case["final"]["V"]
+    for uu, jj, cc, want in case["predictions"]:
+        assert float(orc.predict(uu, jj, cc)).hex() == want
+    assert float(loss).hex() == case["final_loss"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FM_GOLD, ids=lambda c: "FM-k%d" % c["k"])
+def test_gpu_fm_matches_the_interpreted_fm_source(case):
+    """The GPU's sparse, exactly-equivalent formulation (tree-reduced sums, size * reg instead of one add per rating): 1e-8 relative on the
+    model, 1e-9 on the predictions -- the bar of tests/test_gpu_fm.py, here against the reference's own statements."""
+    from carskit_amd import capi
+    u, j, ctx, r, w, V = _fm_inputs(case)
+    p = case["problem"]
+    g = capi.FMInstance(case["k"], p["n_users"], p["n_items"], p["n_conds"], case["n_ctx_dims"])
+    g.set_hparams(case["regLw"], case["regLf"])
+    g.set_ratings(u, j, ctx, r)
+    g.set_model(0.0, w, V)
+    g.init()
+    for _ in range(case["iters"]):
+        g.sweep()
+    w0, gw, gV = g.get_model()
+    assert abs(w0 - fx(case["final"]["w0"])) <= 1e-8 * max(1.0, abs(w0))
+    np.testing.assert_allclose(gw, [fx(x) for x in case["final"]["w"]], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(gV.ravel(), [fx(x) for x in case["final"]["V"]], rtol=1e-6, atol=1e-9)
