@@ -955,12 +955,42 @@ class Env:
         simple = ty.split(".")[-1]
         if simple in ("ArrayList", "LinkedList"):
             return JCollection()
+        if simple in ("HashMap", "LinkedHashMap"):
+            return JMap()
         jar_cls = self.this.class_map.get(simple)
         if jar_cls is None:
             raise KeyError("new %s" % ty)
         o = self.this.vm.new_object(jar_cls)
         vm_call(self.this.vm, o, jar_cls, "<init>", args, static=False)
         return o
+
+
+class JMap:
+    """java.util.Map as the evaluated sources use it (put / get / containsKey / size); keys: enum constants, boxes, strings"""
+    JAVA_TYPES = ("java/util/Map",)
+
+    def __init__(self):
+        self.d = {}
+
+    def jcall(self, vm, name, desc, args):
+        if name == "put":
+            old = self.d.get(args[0])
+            self.d[args[0]] = args[1]
+            return old
+        if name == "get":
+            return self.d.get(args[0])
+        if name == "containsKey":
+            return args[0] in self.d
+        if name == "size":
+            return len(self.d)
+        raise KeyError("Map." + name)
+
+
+def _java_round(x):
+    """Math.round(double): floor(x + 0.5) as a long (NaN -> 0)"""
+    if x != x:
+        return JLong(0)
+    return JLong(max(-2 ** 63, min(2 ** 63 - 1, math.floor(x + 0.5))))
 
 
 def to_host(v):
@@ -1028,6 +1058,7 @@ STATIC_CALLS = {
     ("Math", "max"): lambda a, b: max(a, b),
     ("Math", "min"): lambda a, b: min(a, b),
     ("Math", "exp"): math.exp,
+    ("Math", "round"): _java_round,
     ("Math", "log"): math.log,
     ("Double", "isNaN"): lambda x: x != x,
     ("Double", "isInfinite"): lambda x: math.isinf(x),

@@ -144,7 +144,7 @@ class UserItemsCache:
         raise KeyError("userItemsCache." + name)
 
 
-def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3, bold=True):
+def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3, bold=True, test_cells=None):
     vm = VM(os.path.join(ref, "lib", "librec-v1.4-alpha.jar"))
     rng = np.random.default_rng(seed)
     nu, ni, nc = prob["n_users"], prob["n_items"], prob["n_conds"]
@@ -223,6 +223,12 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
     trace = []
     this.hooks["isConverged"] = lambda th, args: trace.append((th.fields["loss"], th.fields["lRate"]))
     this.call("buildModel", [])
+    evals = None
+    if test_cells:   # Recommender.evalRatings (Recommender.java:504-594) over a held-out testMatrix, from source as well
+        F["testMatrix"] = sparse(vm, len(prob["ui_user"]), len(prob["ctx_keys"]), test_cells)
+        F["workingPath"] = ""
+        m = this.call("evalRatings", [])
+        evals = {key.name: hx(val.v if isinstance(val, Box) else val) for key, val in m.d.items()}
 
     def out_state(name):
         o = F[JAVA_FIELD.get(name, name)]
@@ -239,7 +245,7 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
            "empty_conds": empty, "n_ctx_dims": n_dims, "num_f": NUM_F,
            "problem": prob, "init": {n: [hx(x) for x in a.ravel()] for n, a in init.items()},
            "final": {n: out_state(n) for n in init}, "epoch_loss": [hx(l) for l, _ in trace], "epoch_lrate": [hx(r) for _, r in trace],
-           "final_lrate": hx(F["lRate"]), "java_statements_executed": this.statements, "bytecode_instructions": vm.steps}
+           "final_lrate": hx(F["lRate"]), "test_cells": test_cells, "eval_ratings": evals, "java_statements_executed": this.statements, "bytecode_instructions": vm.steps}
     return rec
 
 
@@ -280,8 +286,10 @@ def main():
                      "(oracle/jvm/interp.py); doubles are C99 hex strings", "cases": []}
     for model in MODELS:
         for (nu, ni, nd, cpd, n, k, iters) in ((7, 5, 2, 3, 60, 3, 4), (12, 9, 3, 2, 150, 10, 3)):
-            prob = problem(rng, nu, ni, nd, cpd, n)
-            rec = run_model(ref, model, prob, k, iters, seed=int(rng.integers(1 << 30)))
+            prob = problem(rng, nu, ni, nd, cpd, n + n // 4)
+            held = [c for i, c in enumerate(prob["cells"]) if i % 5 == 4]           # every fifth cell is test data
+            prob["cells"] = [c for i, c in enumerate(prob["cells"]) if i % 5 != 4]
+            rec = run_model(ref, model, prob, k, iters, seed=int(rng.integers(1 << 30)), test_cells=held)
             out["cases"].append(rec)
             print("%-10s k=%-3d %d ratings, %d epochs: loss %s -> %s   (%d Java statements, %d bytecode instructions)"
                   % (model, k, len(prob["cells"]), iters, float.fromhex(rec["epoch_loss"][0]), float.fromhex(rec["epoch_loss"][-1]),

@@ -62,6 +62,13 @@ def _inputs(c):
     return u, j, ctx, r, ctx_ptr, ctx_conds, state
 
 
+def _test_tuples(c):
+    p = c["problem"]
+    t = c["test_cells"]
+    return (np.array([p["ui_user"][ui] for ui, _, _ in t], np.int32), np.array([p["ui_item"][ui] for ui, _, _ in t], np.int32),
+            np.array([cc for _, cc, _ in t], np.int32), np.array([v for _, _, v in t]))
+
+
 def _check(c, losses, lrates, state):
     assert [float(x).hex() for x in losses] == c["epoch_loss"]
     assert [float(x).hex() for x in lrates] == c["epoch_lrate"]
@@ -79,6 +86,12 @@ def test_c_oracle_reproduces_the_interpreted_reference_source_bit_for_bit(case):
                           case["regU"], case["regI"], case["regB"], case["regC"])
     losses, lrates, _ = orc.build_model(case["iters"], case["lrate"], bold_driver=case["bold_driver"])
     _check(case, losses, lrates, orc.state)
+    # Recommender.evalRatings (Recommender.java:504-594), executed from source over the held-out cells: MAE, RMSE, NMAE, rMAE, rRMSE
+    tu, tj, tc, tr = _test_tuples(case)
+    ev = orc.eval_ratings(tu, tj, tc, tr, 1.0, 5.0)
+    for name in ("MAE", "RMSE", "NMAE", "rMAE", "rRMSE"):
+        assert float(ev[name]).hex() == case["eval_ratings"][name], name
+    assert fx(case["eval_ratings"]["MPE"]) == 0.0
     # the global mean the hosts compute from the contextual train matrix
     assert oracle_c.global_mean(np.array([v for _, _, v in p["cells"]])) == gm
 
@@ -121,6 +134,10 @@ def test_gpu_strict_fp64_reproduces_the_interpreted_reference_source_bit_for_bit
     inst.set_states(state)
     losses, lrates = inst.train(case["iters"], case["lrate"], bold_driver=case["bold_driver"])
     _check(case, losses, lrates, inst.get_states())
+    tu, tj, tc, tr = _test_tuples(case)
+    ev = inst.eval_ratings(tu, tj, None if case["model"] in util.TWO_D else tc, tr, 1.0, 5.0)
+    for name in ("MAE", "RMSE", "NMAE", "rMAE", "rRMSE"):           # cmi_eval_ratings: tree-reduced dot and error sums, hence 1e-12
+        assert abs(ev[name] - fx(case["eval_ratings"][name])) <= 1e-12, name
     # and the order-exact LEVEL schedule (the production schedule family): same model bits, loss to rounding
     if case["model"] != "CAMF_C":
         lv = capi.Instance(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], flags=capi.FLAG_STATE_F64 | capi.FLAG_STRICT)
