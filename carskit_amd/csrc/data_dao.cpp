@@ -685,22 +685,22 @@ struct Conditions {
     }
 };
 
-// CARSKit.validateDataFormat (src/carskit/main/CARSKit.java:179-215): 1 binary, 2 loose, 3 compact
+// CARSKit.validateDataFormat (src/carskit/main/CARSKit.java:179-215): 1 binary, 2 loose, 3 compact; 0 where the reference THROWS
+// (no data line: NullPointerException; a one-column header or a data line shorter than the header: ArrayIndexOutOfBounds; a value under
+// a "dim:cond" column that Integer.valueOf refuses -- text, padding: NumberFormatException).  Statement order as in the reference: the
+// `:` test short-circuits before the value is parsed, and isBinaryNumber (CARSKit.java:177) looks at the decimal digits with Java's
+// truncating %, so every negative number passes (pinned against the interpreted source: tests/golden/reference_transform.json).
 int validate_format(const std::vector<std::string> &lines) {
     if (lines.size() < 2) return 0;
     const std::vector<std::string> sh = split_keep(lines[0], ','), sd = split_keep(lines[1], ',');
-    if (sh.size() >= 2 && jlower(jtrim(sh[sh.size() - 2])) == "dimension" && jlower(jtrim(sh.back())) == "condition") return 2;
+    if (sh.size() < 2) return 0;
+    if (jlower(jtrim(sh[sh.size() - 2])) == "dimension" && jlower(jtrim(sh.back())) == "condition") return 2;
     for (size_t i = 3; i < sh.size(); ++i) {
+        if (sh[i].find(':') == std::string::npos) return 3;
         int32_t v = 0;
-        bool binary_number = i < sd.size() && jparse_int(sd[i], v); // Integer.valueOf: no trim here (NumberFormatException otherwise)
-        if (binary_number) {
-            int32_t c = v < 0 ? -v : v;
-            while (c != 0) {
-                if (c % 10 > 1) binary_number = false;
-                c /= 10;
-            }
-        }
-        if (sh[i].find(':') == std::string::npos || !binary_number) return 3;
+        if (i >= sd.size() || !jparse_int(sd[i], v)) return 0; // Integer.valueOf: no trim here
+        for (int32_t c = v; c != 0; c /= 10)
+            if (c % 10 > 1) return 3;
     }
     return 1;
 }
@@ -910,7 +910,7 @@ extern "C" int cmi_transform(const char *train_in, const char *train_out, const 
     if (!read_lines(train_in, tr, g_dao_err)) return CMI_E_INVALID;
     const int ftr = validate_format(tr);
     if (ftr == 0) {
-        g_dao_err = "transform: training file has no data line";
+        g_dao_err = "transform: the training file is not a rating file validateDataFormat accepts (no data line, a short line, or a non-integer under a dim:cond column)";
         return CMI_E_INVALID;
     }
     bool tree = false;
@@ -928,7 +928,7 @@ extern "C" int cmi_transform(const char *train_in, const char *train_out, const 
     if (!read_lines(test_in, te, g_dao_err)) return CMI_E_INVALID;
     const int fte = validate_format(te);
     if (fte == 0) {
-        g_dao_err = "transform: test file has no data line";
+        g_dao_err = "transform: the test file is not a rating file validateDataFormat accepts (no data line, a short line, or a non-integer under a dim:cond column)";
         return CMI_E_INVALID;
     }
     Conditions merged;

@@ -446,7 +446,8 @@ int cmi_java_hashmap_order(int64_t n, const char *const *keys, int64_t *position
  * (src/carskit/data/processor/DataTransformer.java:231-259,266-329,155-163): rewrites a compact-format file
  * (user,item,rating,dim1,dim2,...) as the binary-format train.csv, rows in the reference's HashMap order. */
 int cmi_transform_compact_to_binary(const char *in_path, const char *out_path, int *treeified);
-/* CARSKit.validateDataFormat (src/carskit/main/CARSKit.java:179-215): 1 binary, 2 loose, 3 compact, 0 no data line */
+/* CARSKit.validateDataFormat (src/carskit/main/CARSKit.java:179-215): 1 binary, 2 loose, 3 compact; 0 where the reference throws
+ * (no data line, a one-column header, a data line shorter than the header, a value Integer.valueOf refuses under a dim:cond column) */
 int cmi_validate_data_format(const char *path);
 /* DataTransformer.run() (DataTransformer.java:331-396) for binary / loose / compact input.  test_in == NULL: only the
  * training file (binary is copied).  With a test file, both are rewritten against the merged, SORTED condition set

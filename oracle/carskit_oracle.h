@@ -2,10 +2,18 @@
  * carskit_oracle.h -- CPU restatement (fp64, single thread, order-exact) of the CARSKit
  * SGD training path.  TEST INFRASTRUCTURE ONLY.
  *
- * PARITY UNPINNED: the reference (irecsys/CARSKit v0.4.0, Java) ships no tests, golden vectors
- * or expected-output files for this path and there is no JVM in the build container, so the
- * restatement cannot be checked against the reference itself.  It is pinned instead by
- *   (i)  an independently written NumPy restatement (oracle/oracle_np.py) that must agree
+ * PARITY: the reference (irecsys/CARSKit v0.4.0, Java) ships no tests, golden vectors or
+ * expected-output files for this path and there is no JVM in the build container.  Rounds 1-2
+ * ran "parity unpinned"; since round 3 the restatement is pinned by INTERPRETED EXECUTION of the
+ * reference itself -- not by a JVM run:
+ *   (a) librec's DenseMatrix / SparseMatrix / Randoms executed from the vendored jar's bytecode
+ *       (oracle/jvm/interp.py -> tests/golden/librec_l0.json, tests/test_librec_l0.py),
+ *   (b) buildModel / predict / isConverged / updateLRate / evalRatings of all ten SGD recommenders
+ *       and FM executed from the reference's Java source (oracle/jvm/javasrc.py ->
+ *       tests/golden/reference_src.json; tests/test_reference_src_golden.py holds this library to
+ *       it bit for bit).  JDK / guava classes are stand-ins written from their specifications.
+ * The earlier anchors remain:
+ *   (i)  an independently written second restatement (oracle/oracle_np.py) that must agree
  *        bit-for-bit on random small problems,
  *   (ii) hand-computed single-update known answers (tests/test_oracle_known_answers.py),
  *   (iii) java.util.Random known answers from the public algorithm.

@@ -58,6 +58,12 @@ def read_lines(path):
     return lines
 
 
+def jdouble(s):
+    """Double.valueOf(String): whitespace trimmed, an optional f/F/d/D suffix (DataDAO.java:228)"""
+    t = jtrim(s)
+    return float(t[:-1] if t[-1:] in "dDfF" else t)
+
+
 def read_data(path):
     lines = read_lines(path)
     header = jsplit(jtrim(lines[0]), r"[\t,]+")
@@ -75,7 +81,7 @@ def read_data(path):
     table, scale, n_lines = {}, set(), 0
     for line in lines[1:]:
         data = jsplit(jtrim(line), ",", -1)
-        user, item, rate = data[0], data[1], float(jtrim(data[2]).rstrip("dDfF") if jtrim(data[2])[-1:] in "dDfF" else data[2])
+        user, item, rate = data[0], data[1], jdouble(data[2])
         scale.add(rate)
         n_lines += 1
         row = users.setdefault(user, len(users))
@@ -194,16 +200,22 @@ def compact_to_binary(in_path):
 # ---- the remaining DataTransformer paths (loose, binary->binary, merged conditions) and the shared-map test DAO -------
 
 def validate_format(lines):
-    """CARSKit.validateDataFormat (src/carskit/main/CARSKit.java:179-215)."""
+    """CARSKit.validateDataFormat (src/carskit/main/CARSKit.java:179-215); 0 where the reference throws (NullPointerException on a
+    missing data line, ArrayIndexOutOfBounds on a one-column header or a short data line, NumberFormatException from Integer.valueOf)."""
     if len(lines) < 2:
         return 0
     sh, sd = jsplit(lines[0], ",", -1), jsplit(lines[1], ",", -1)
-    if len(sh) >= 2 and jtrim(sh[-2]).lower() == "dimension" and jtrim(sh[-1]).lower() == "condition":
+    if len(sh) < 2:
+        return 0
+    if jtrim(sh[-2]).lower() == "dimension" and jtrim(sh[-1]).lower() == "condition":
         return 2
     for i in range(3, len(sh)):
-        tok = sd[i] if i < len(sd) else ""
-        ok = re.fullmatch(r"[+-]?\d+", tok) is not None and set(tok.lstrip("+-")) <= set("01")
-        if ":" not in sh[i] or not ok:
+        if ":" not in sh[i]:
+            return 3
+        if i >= len(sd) or re.fullmatch(r"[+-]?\d+", sd[i]) is None or not -2 ** 31 <= int(sd[i]) < 2 ** 31:
+            return 0
+        v = int(sd[i])
+        if v > 0 and any(ch > "1" for ch in str(v)):      # isBinaryNumber: Java's % keeps the sign, so a negative number always passes
             return 3
     return 1
 
@@ -351,7 +363,7 @@ def read_data_shared(train_path, test_path):
     table, n_lines = {}, 0
     for line in lines[1:]:
         data = jsplit(jtrim(line), ",", -1)
-        rate = float(data[2])
+        rate = jdouble(data[2])
         n_lines += 1
         row = users.setdefault(data[0], len(users))
         col = items.setdefault(data[1], len(items))

@@ -514,6 +514,12 @@ class JString:
     def __repr__(self):
         return repr(self.s)
 
+    def __eq__(self, o):        # String.equals / hashCode semantics when a string is a key of a host collection
+        return isinstance(o, JString) and o.s == self.s
+
+    def __hash__(self):
+        return hash(self.s)
+
 
 class Box:
     """java.lang.Integer / Double (Number)"""

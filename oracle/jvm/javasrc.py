@@ -19,6 +19,7 @@ What is executed is the reference's text, read where it lies under /root/referen
 repository -- the fixtures hold numbers only (oracle/mint_reference_src.py).
 """
 import math
+import os
 import re
 
 from .interp import Box, JArray, JCollection, JFloat, JLong, JObject, JString, f32, i32
@@ -185,12 +186,15 @@ class Parser:
     def try_local_decl(self):
         save = self.p
         ty = self.try_type()
-        if ty is None or self.peek()[0] != "id" or self.peek()[1] in KEYWORDS or self.peek(1)[1] not in ("=", ";", ",", ":"):
+        c_style = ty is not None and self.peek()[0] == "id" and self.peek(1)[1] == "[" and self.peek(2)[1] == "]"   # `String strs[] = ...`
+        if ty is None or self.peek()[0] != "id" or self.peek()[1] in KEYWORDS or (self.peek(1)[1] not in ("=", ";", ",", ":") and not c_style):
             self.p = save
             return None
         decls = []
         while True:
             name = self.eat()[1]
+            if self.at("[") and self.at("]", 1):
+                self.eat(), self.eat()
             init = None
             if self.at("="):
                 self.eat()
@@ -441,6 +445,7 @@ def find_methods(src):
             j = i + 2
             params, cur = [], []
             d = 1
+            angle = 0          # commas inside a generic parameter type (Multimap<String, String> conditions) do not separate parameters
             while d > 0:
                 t = toks[j]
                 if t[1] == "(":
@@ -449,7 +454,13 @@ def find_methods(src):
                     d -= 1
                     if d == 0:
                         break
-                if t[1] == "," and d == 1:
+                elif t[1] == "<":
+                    angle += 1
+                elif t[1] == ">":
+                    angle -= 1
+                elif t[1] == ">>":
+                    angle -= 2
+                if t[1] == "," and d == 1 and angle == 0:
                     params.append(cur)
                     cur = []
                 else:
@@ -640,7 +651,7 @@ class Env:
                 self.scopes.append({})
                 self.types.append({})
                 try:
-                    self.declare(node[2], coerce(ty, v) if ty in PRIMS else v, ty)
+                    self.declare(node[2], coerce(ty, v) if ty in PRIMS else from_host(v), ty)
                     self.exec(node[4])
                 except Continue:
                     pass
@@ -954,8 +965,14 @@ class Env:
     def new(self, ty, args):
         simple = ty.split(".")[-1]
         if simple in ("ArrayList", "LinkedList"):
+            if args and hasattr(args[0], "items"):
+                return JCollection(list(args[0].items))
             return JCollection()
-        if simple in ("HashMap", "LinkedHashMap"):
+        if simple == "StringBuilder":
+            return JStringBuilder(args[0] if args and isinstance(args[0], str) else "")
+        if simple == "HashMap":
+            return JHashMap()
+        if simple == "LinkedHashMap":
             return JMap()
         jar_cls = self.this.class_map.get(simple)
         if jar_cls is None:
@@ -983,7 +1000,118 @@ class JMap:
             return args[0] in self.d
         if name == "size":
             return len(self.d)
+        if name == "keySet":
+            return JCollection(list(self.d.keys()))
+        if name == "values":
+            return JCollection(list(self.d.values()))
+        if name == "inverse":
+            m = JMap()
+            m.d = {v: k for k, v in self.d.items()}
+            return m
         raise KeyError("Map." + name)
+
+
+def _java_hash(k):
+    """Object.hashCode() of the key kinds the evaluated sources put into a java.util.HashMap"""
+    if isinstance(k, JString):
+        return string_method(k.s, "hashCode", []) & 0xFFFFFFFF
+    if isinstance(k, Box) and k.kind == "Integer":
+        return int(k.v) & 0xFFFFFFFF
+    if isinstance(k, Box) and k.kind == "Double":
+        import struct
+        b = struct.unpack("<Q", struct.pack("<d", float(k.v)))[0]
+        return (b ^ (b >> 32)) & 0xFFFFFFFF
+    if isinstance(k, EnumConst):
+        return hash(k.name) & 0xFFFFFFFF        # identity hash in Java: iteration order over enum keys is not defined, and not used
+    raise KeyError("hashCode of %r" % (k,))
+
+
+class JHashMap(JMap):
+    """java.util.HashMap (JDK 8+) with its ITERATION ORDER: keySet() / values() walk the bin table by index, a bin in insertion order.
+    The table starts at 16 bins and doubles whenever size exceeds 0.75 x capacity (resize splits a bin preserving order, so the order is a
+    function of the final capacity and the insertion sequence).  The JDK itself is not part of the reference tree, so this is a SIMULATION
+    of its documented implementation; bins that would have been treeified (>= 8 entries at capacity >= 64) are refused."""
+
+    def _ordered(self):
+        cap = 16
+        while len(self.d) > cap * 3 // 4:
+            cap *= 2
+        bins = {}
+        for pos, k in enumerate(self.d):
+            h = _java_hash(k)
+            bins.setdefault((h ^ (h >> 16)) & (cap - 1), []).append(k)
+        if any(len(b) >= 8 for b in bins.values()):
+            raise RuntimeError("a HashMap bin of 8+ entries: tree bins are not simulated")
+        return [k for idx in sorted(bins) for k in bins[idx]]
+
+    def jcall(self, vm, name, desc, args):
+        if name == "keySet":
+            return JCollection(self._ordered())
+        if name == "values":
+            return JCollection([self.d[k] for k in self._ordered()])
+        return super().jcall(vm, name, desc, args)
+
+
+class JSetMultimap:
+    """guava TreeMultimap (sorted=True: keys and each key's values in natural order) or LinkedHashMultimap (insertion order)"""
+
+    def __init__(self, sorted_):
+        self.sorted, self.d = sorted_, {}
+
+    def _vals(self, k):
+        v = self.d.get(k, [])
+        return sorted(v, key=lambda x: x.s) if self.sorted else list(v)
+
+    def jcall(self, vm, name, desc, args):
+        if name == "put":
+            v = self.d.setdefault(args[0], [])
+            if args[1] in v:
+                return False
+            v.append(args[1])
+            return True
+        if name == "keySet":
+            ks = list(self.d)
+            return JCollection(sorted(ks, key=lambda x: x.s) if self.sorted else ks)
+        if name == "get":
+            return JCollection(self._vals(args[0]))
+        if name == "size":
+            return sum(len(v) for v in self.d.values())
+        raise KeyError("Multimap." + name)
+
+
+class JWriter:
+    """java.io.BufferedWriter over a file: write / flush / close"""
+
+    def __init__(self, path):
+        self.fh = open(path, "w", newline="")
+
+    def jcall(self, vm, name, desc, args):
+        if name == "write":
+            self.fh.write(from_host(args[0]))
+            return None
+        if name == "flush":
+            self.fh.flush()
+            return None
+        if name == "close":
+            self.fh.close()
+            return None
+        raise KeyError("BufferedWriter." + name)
+
+
+def _copy_file(a, b):
+    import shutil
+    shutil.copyfile(a, b)
+
+
+class JBiMap(JMap):
+    """guava HashBiMap: put(k, v) with v already bound to another key throws (BiMap.put's contract)"""
+
+    def jcall(self, vm, name, desc, args):
+        if name == "put":
+            for k2, v2 in self.d.items():
+                if v2 == args[1] and k2 != args[0]:
+                    raise RuntimeError("IllegalArgumentException: value already present: %r" % (args[1],))
+        return super().jcall(vm, name, desc, args)
 
 
 def _java_round(x):
@@ -1027,22 +1155,121 @@ def java_str(v):
 def string_method(s, name, args):
     a = [unbox(x) for x in args]
     if name == "split":
-        sep = a[0]
-        parts = s.split(sep) if sep not in (".", "|") else re.split(re.escape(sep), s)
-        while parts and parts[-1] == "":        # String.split(regex) drops trailing empty strings
-            parts.pop()
+        # String.split(regex[, limit]): a regex; limit 0 (default) drops trailing empty strings, a negative limit keeps them
+        limit = a[1] if len(a) > 1 else 0
+        parts = re.split(a[0], s)
+        if limit == 0:
+            while len(parts) > 1 and parts[-1] == "":
+                parts.pop()
+            if parts == [""] and s != "":
+                parts = []
         return parts
     if name == "trim":
-        return s.strip(" \t\n\r\f\v")
+        return s.strip("".join(chr(c) for c in range(0x21)))      # String.trim(): code points <= U+0020
     if name == "equals":
         return s == a[0]
+    if name == "endsWith":
+        return s.endswith(a[0])
+    if name == "startsWith":
+        return s.startswith(a[0])
+    if name == "contains":
+        return a[0] in s
+    if name == "indexOf":
+        return s.find(a[0])
     if name == "length":
         return len(s)
     if name == "toLowerCase":
         return s.lower()
     if name == "isEmpty":
         return s == ""
+    if name == "hashCode":
+        h = 0
+        for ch in s:
+            h = i32(31 * h + ord(ch))
+        return h
     raise KeyError("String." + name)
+
+
+class JStringBuilder:
+    def __init__(self, s=""):
+        self.s = s
+
+    def jcall(self, vm, name, desc, args):
+        if name == "append":
+            self.s += java_str(unbox(from_host(args[0])))
+            return self
+        if name == "length":
+            return len(self.s)
+        if name == "toString":
+            return JString(self.s)
+        raise KeyError("StringBuilder." + name)
+
+
+class JMultiset:
+    """guava Multiset<Double> (HashMultiset): add / size / elementSet"""
+
+    def __init__(self):
+        self.items = []
+
+    def jcall(self, vm, name, desc, args):
+        if name == "add":
+            self.items.append(args[0])
+            return True
+        if name == "size":
+            return len(self.items)
+        if name == "elementSet":
+            seen, out = set(), []
+            for x in self.items:
+                if x not in seen:
+                    seen.add(x)
+                    out.append(x)
+            return JCollection(out)
+        raise KeyError("Multiset." + name)
+
+
+class JReader:
+    """java.io.BufferedReader over a text file: readLine() without the line terminator, null at the end"""
+
+    def __init__(self, path):
+        self.lines = open(path, newline="").read().split("\n")
+        if self.lines and self.lines[-1] == "":
+            self.lines.pop()
+        self.lines = [ln[:-1] if ln.endswith("\r") else ln for ln in self.lines]
+        self.i = 0
+
+    def jcall(self, vm, name, desc, args):
+        if name == "readLine":
+            if self.i >= len(self.lines):
+                return None
+            self.i += 1
+            return JString(self.lines[self.i - 1])
+        if name == "close":
+            return None
+        raise KeyError("BufferedReader." + name)
+
+
+def _parse_int(x):
+    if isinstance(x, str):
+        if not re.fullmatch(r"[+-]?\d+", x):
+            raise RuntimeError("NumberFormatException: For input string: %r" % x)
+        return int(x)
+    return int(x)
+
+
+_JAVA_DOUBLE = re.compile(r"[+-]?(NaN|Infinity|((\d+\.?\d*|\.\d+)([eE][+-]?\d+)?)[fFdD]?)")
+
+
+def _parse_double(x):
+    """Double.valueOf(String) (FloatingDecimal.readJavaFormatString): whitespace trimmed, decimal literal with an optional f/F/d/D
+    suffix, NaN / Infinity; anything else is a NumberFormatException.  (Hex floating literals are not handled here.)"""
+    if isinstance(x, str):
+        t = x.strip("".join(chr(c) for c in range(0x21)))
+        if not _JAVA_DOUBLE.fullmatch(t):
+            raise RuntimeError("NumberFormatException: For input string: %r" % x)
+        if t[-1] in "fFdD":
+            t = t[:-1]
+        return float(t.replace("Infinity", "inf").replace("NaN", "nan"))
+    return float(x)
 
 
 def _math_pow(x, y):
@@ -1062,11 +1289,24 @@ STATIC_CALLS = {
     ("Math", "log"): math.log,
     ("Double", "isNaN"): lambda x: x != x,
     ("Double", "isInfinite"): lambda x: math.isinf(x),
-    ("Integer", "valueOf"): lambda x: Box(int(x), "Integer"),
+    ("Integer", "valueOf"): lambda x: Box(_parse_int(x), "Integer"),
     ("Integer", "parseInt"): lambda x: int(x),
-    ("Double", "valueOf"): lambda x: Box(float(x), "Double"),
+    ("Double", "valueOf"): lambda x: Box(_parse_double(x), "Double"),
     ("String", "format"): lambda *a: "<formatted>",
     ("HashBasedTable", "create"): lambda: _guava_table(),
+    ("HashMultimap", "create"): lambda: _guava_multimap(),
+    ("String", "format"): lambda *a: "",
+    ("TreeMultimap", "create"): lambda: JSetMultimap(True),
+    ("LinkedHashMultimap", "create"): lambda: JSetMultimap(False),
+    ("FileIO", "getWriter"): lambda path: JWriter(path),
+    ("FileIO", "exist"): lambda path: os.path.exists(path),
+    ("FileIO", "copyFile"): _copy_file,
+    ("Integer", "parseInt"): lambda x: _parse_int(x),
+    ("HashBiMap", "create"): lambda: JMap(),
+    ("HashMultiset", "create"): lambda: JMultiset(),
+    ("FileIO", "getReader"): lambda path: JReader(path),
+    ("Strings", "last"): lambda s_, n_: s_[-n_:],
+    ("Collections", "sort"): lambda coll: coll.items.sort(key=lambda b: b.v),
     ("Logs", "debug"): lambda *a: None,
     ("Logs", "info"): lambda *a: None,
     ("Logs", "error"): lambda *a: None,
@@ -1079,12 +1319,17 @@ def _guava_table():
     return GuavaTable()
 
 
+def _guava_multimap():
+    from .interp import GuavaMultimap
+    return GuavaMultimap()
+
+
 def _exit(code):
     raise JavaExit("System.exit(%r)" % (code,))
 
 
 STATIC_CALLS[("System", "exit")] = _exit
-STATIC_FIELDS = {("Double", "MAX_VALUE"): 1.7976931348623157e308, ("Integer", "MAX_VALUE"): 2 ** 31 - 1}
+STATIC_FIELDS = {("Double", "MAX_VALUE"): 1.7976931348623157e308, ("Integer", "MAX_VALUE"): 2 ** 31 - 1, ("CARSKit", "isMeasuresOnly"): False}
 
 
 def vm_call(vm, obj, cls, name, args, static):
