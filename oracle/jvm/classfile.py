@@ -131,17 +131,23 @@ class ClassFile:
 
 
 class Jar:
+    """one jar, or several searched in order (a class path)"""
+
     def __init__(self, path):
-        self.zip = zipfile.ZipFile(path)
-        self.names = set(self.zip.namelist())
+        paths = [path] if isinstance(path, str) else list(path)
+        self.zips = [zipfile.ZipFile(q) for q in paths]
+        self.where = {}
+        for z in reversed(self.zips):
+            for n in z.namelist():
+                self.where[n] = z
         self.cache = {}
 
     def has(self, cls):
-        return cls + ".class" in self.names
+        return cls + ".class" in self.where
 
     def load(self, cls):
         if cls not in self.cache:
-            self.cache[cls] = ClassFile(self.zip.read(cls + ".class"))
+            self.cache[cls] = ClassFile(self.where[cls + ".class"].read(cls + ".class"))
         return self.cache[cls]
 
 

@@ -537,6 +537,16 @@ class Box:
             return int(isinstance(args[0], Box) and args[0].v == self.v)
         if name == "hashCode":
             return i32(int(self.v))
+        if name == "compareTo":            # Integer.compareTo / Double.compareTo (Double: -0.0 < 0.0, NaN greatest -- by bits when equal)
+            a, b = self.v, args[0].v
+            if self.kind == "Double" and (a != a or b != b or (a == b == 0.0)):
+                import struct
+                ka = (a != a, struct.unpack("<q", struct.pack("<d", a))[0] if a == a else 0)
+                kb = (b != b, struct.unpack("<q", struct.pack("<d", b))[0] if b == b else 0)
+                return (ka > kb) - (ka < kb)
+            return (a > b) - (a < b)
+        if name == "floatValue":
+            return JFloat(f32(float(self.v)))
         raise KeyError("%s.%s" % (self.kind, name))
 
     def __hash__(self):
@@ -583,7 +593,21 @@ class JCollection:
             return int(not self.items)
         if name == "contains":
             return int(args[0] in self.items)
-        if name == "<init>":
+        if name == "indexOf":
+            return self.items.index(args[0]) if args[0] in self.items else -1
+        if name == "remove":               # Collection.remove(Object): the boxed-key form the evaluated code uses
+            if args[0] in self.items:
+                self.items.remove(args[0])
+                return 1
+            return 0
+        if name == "subList":
+            return JCollection(self.items[int(args[0].v if isinstance(args[0], Box) else args[0]):int(args[1].v if isinstance(args[1], Box) else args[1])])
+        if name == "clear":
+            self.items.clear()
+            return None
+        if name == "<init>":               # ArrayList() / ArrayList(int capacity) / ArrayList(Collection)
+            if args and hasattr(args[0], "items"):
+                self.items = list(args[0].items)
             return None
         raise KeyError("Collection." + name)
 
@@ -604,6 +628,34 @@ class JMapView:
         if name == "values":
             return JCollection(self.d.values())
         raise KeyError("Map." + name)
+
+
+class HostHashMap:
+    """java.util.HashMap as jar bytecode uses it (put / get / containsKey / size / keySet): lookups only matter, the iteration order of
+    keySet() is insertion order here -- callers that depend on HashMap's order use javasrc.JHashMap"""
+    JAVA_TYPES = ("java/util/Map", "java/util/HashMap")
+
+    def __init__(self):
+        self.d = {}
+
+    def jcall(self, vm, name, desc, args):
+        if name == "<init>":
+            return None
+        if name == "put":
+            old = self.d.get(args[0])
+            self.d[args[0]] = args[1]
+            return old
+        if name == "get":
+            return self.d.get(args[0])
+        if name == "containsKey":
+            return int(args[0] in self.d)
+        if name == "size":
+            return len(self.d)
+        if name == "keySet":
+            return JCollection(self.d.keys())
+        if name == "values":
+            return JCollection(self.d.values())
+        raise KeyError("HashMap." + name)
 
 
 class Cell:
@@ -673,6 +725,17 @@ class GuavaMultimap:
         raise KeyError("Multimap." + name)
 
 
+def _fdlibm_log(x):
+    from oracle.oracle_np import fdlibm_log
+    return fdlibm_log(x)
+
+
+def _java_pow(a, b):
+    if b == 2.0:
+        return a * a
+    raise KeyError("Math.pow(%r, %r): only the square is pinned" % (a, b))
+
+
 class HostRandom:
     """java.util.Random via oracle/oracle_np.JavaRandom (the Python restatement of the published algorithm: 48-bit LCG, polar
     nextGaussian over fdlibm's log; known answers in tests/test_java_random.py)"""
@@ -731,6 +794,7 @@ class HostThrowable:
 HOST_CLASSES = {
     "java/util/Random": HostRandom,
     "java/util/ArrayList": JCollection,
+    "java/util/HashMap": HostHashMap,
     "java/lang/StringBuilder": HostStringBuilder,
     "java/lang/AssertionError": lambda: HostThrowable("java/lang/AssertionError"),
     "java/lang/IllegalArgumentException": lambda: HostThrowable("java/lang/IllegalArgumentException"),
@@ -758,7 +822,52 @@ def _binary_search(vm, arr, lo, hi, key):
     return -(a + 1)
 
 
+def _collections_sort(vm, lst, cmp=None):
+    """java.util.Collections.sort(List[, Comparator]): a stable merge sort -- the result of ANY stable sort under a consistent comparator
+    is the same list, so Python's stable sort with the comparator's own compare() stands in"""
+    import functools
+    if cmp is None:
+        lst.items.sort(key=functools.cmp_to_key(lambda a, b: a.jcall(vm, "compareTo", "", [b])))
+        return None
+    owner = cmp.cls_name
+
+    def call(a, b):
+        return vm.invoke("virtual", owner, "compare", "(Ljava/lang/Object;Ljava/lang/Object;)I", [cmp, a, b])
+    lst.items.sort(key=functools.cmp_to_key(call))
+    return None
+
+
+class HostEntry:
+    """java.util.AbstractMap.SimpleImmutableEntry"""
+    JAVA_TYPES = ("java/util/Map$Entry",)
+
+    def __init__(self, k=None, v=None):
+        self.k, self.v = k, v
+
+    def jcall(self, vm, name, desc, args):
+        if name == "getKey":
+            return self.k
+        if name == "getValue":
+            return self.v
+        if name == "<init>":
+            self.k, self.v = args
+            return None
+        raise KeyError("Entry." + name)
+
+
+def _arraycopy(vm, src, sp, dst, dp, n):
+    dst.data[dp:dp + n] = src.data[sp:sp + n]
+
+
 HOST_STATICS = {
+    ("java/lang/System", "arraycopy"): _arraycopy,
+    ("java/lang/Math", "ceil"): lambda vm, v: float(math.ceil(v)) if math.isfinite(v) else v,
+    ("java/lang/Math", "floor"): lambda vm, v: float(math.floor(v)) if math.isfinite(v) else v,
+    ("java/util/Collections", "sort"): _collections_sort,
+    ("java/lang/Math", "log"): lambda vm, v: _fdlibm_log(v),
+    ("java/lang/Math", "min", "(II)I"): lambda vm, a, b: min(a, b),
+    ("java/lang/Math", "max", "(II)I"): lambda vm, a, b: max(a, b),
+    ("java/lang/Math", "pow"): lambda vm, a, b: _java_pow(a, b),
     ("java/lang/System", "currentTimeMillis"): lambda vm: JLong(0),
     ("java/lang/Integer", "valueOf", "(I)Ljava/lang/Integer;"): lambda vm, v: Box(v, "Integer"),
     ("java/lang/Double", "valueOf", "(D)Ljava/lang/Double;"): lambda vm, v: Box(v, "Double"),

@@ -329,6 +329,13 @@ class Parser:
         while True:
             if self.at("."):
                 self.eat()
+                if self.at("<"):            # explicit type arguments of a generic method call: HashMultimap.<Integer, Integer>create()
+                    depth = 0
+                    while True:
+                        t = self.eat()[1]
+                        depth += {"<": 1, ">": -1, ">>": -2}.get(t, 0)
+                        if depth == 0:
+                            break
                 name = self.eat()[1]
                 if self.at("("):
                     e = ("call", e, name, self.args())
@@ -538,28 +545,48 @@ class This:
         self.fields = {}
         self.host = {}          # name -> python callable(*args): methods of `this` outside the interpreted sources
         self.hooks = {}         # name -> python callable(this, args): runs before the source method of that name
-        self.class_map = class_map   # simple class name -> jar class (for static calls / new)
+        self.class_map = class_map   # simple class name -> jar class (for static calls / new), or a This of static methods
+        self.static_super = None     # jar class whose static methods an interpreted class of statics inherits
         self.statements = 0
 
-    def find(self, name, nargs, after=None):
+    def find(self, name, nargs, after=None, args=None):
         start = 0
         if after is not None:
             start = [c for c, _ in self.chain].index(after) + 1
         for cls, methods in self.chain[start:]:
-            for rec in methods.get(name, []):
-                if len(rec[0]) == nargs:
-                    if rec[2][0] == "lazy":
-                        p = Parser(rec[2][1])
-                        p.p = rec[2][2]
-                        rec[2] = p.block()
-                    return cls, rec[0], rec[1], rec[2]
+            cands = [rec for rec in methods.get(name, []) if len(rec[0]) == nargs]
+            if len(cands) > 1 and args is not None:      # overloads of one arity: the declared parameter types decide
+                def fits(rec):
+                    score = 0
+                    for t, a in zip(rec[1], args):
+                        t, a = t.split()[-1] if t else "", unbox(a)
+                        if t == "String":
+                            score += 2 if isinstance(a, str) else -9
+                        elif t in ("int", "Integer"):
+                            score += 2 if isinstance(a, int) and not isinstance(a, bool) else -9
+                        elif t in ("double", "Double"):
+                            score += 2 if isinstance(a, float) else (1 if isinstance(a, int) and not isinstance(a, bool) else -9)
+                        elif t == "boolean":
+                            score += 2 if isinstance(a, bool) else -9
+                        elif isinstance(a, (str, int, float, bool)):
+                            score -= 9
+                    return score
+                cands.sort(key=fits, reverse=True)
+            for rec in cands[:1]:
+                if rec[2][0] == "lazy":
+                    p = Parser(rec[2][1])
+                    p.p = rec[2][2]
+                    rec[2] = p.block()
+                return cls, rec[0], rec[1], rec[2]
         return None
 
     def call(self, name, args, after=None):
-        m = self.find(name, len(args), after)
+        m = self.find(name, len(args), after, args)
         if m is None:
             if name in self.host:
                 return self.host[name](*args)
+            if self.static_super is not None:
+                return vm_call(self.vm, None, self.static_super, name, args, static=True)
             raise KeyError("no source or host method %s/%d on %s" % (name, len(args), self.chain[0][0]))
         if name in self.hooks and after is None:
             self.hooks[name](self, args)
@@ -931,6 +958,8 @@ class Env:
             return self.static_call(obj[1], name, args)
         if obj is None:
             raise RuntimeError("NullPointerException: .%s() on null" % name)
+        if isinstance(obj, This):       # another object whose class is interpreted from source (rateDao)
+            return obj.call(name, args)
         if isinstance(obj, JObject):
             return vm_call(vm, obj, obj.cls_name, name, args, static=False)
         if isinstance(obj, str):
@@ -956,6 +985,10 @@ class Env:
         if key in STATIC_CALLS:
             return STATIC_CALLS[key](*a)
         jar_cls = self.this.class_map.get(cls)
+        if isinstance(jar_cls, This):   # a class of static methods interpreted from source; what it inherits comes from its `static_super`
+            if jar_cls.find(name, len(args)) is not None:
+                return jar_cls.call(name, args)
+            jar_cls = jar_cls.static_super
         if jar_cls is not None:
             return vm_call(self.this.vm, None, jar_cls, name, args, static=True)
         if cls in ("Logs",):
@@ -972,6 +1005,11 @@ class Env:
             return JStringBuilder(args[0] if args and isinstance(args[0], str) else "")
         if simple == "HashMap":
             return JHashMap()
+        if simple == "HashSet":
+            return JHashSet()
+        if simple == "SimpleImmutableEntry":
+            from .interp import HostEntry
+            return HostEntry(to_host(args[0]), to_host(args[1]))
         if simple == "LinkedHashMap":
             return JMap()
         jar_cls = self.this.class_map.get(simple)
@@ -1033,16 +1071,7 @@ class JHashMap(JMap):
     of its documented implementation; bins that would have been treeified (>= 8 entries at capacity >= 64) are refused."""
 
     def _ordered(self):
-        cap = 16
-        while len(self.d) > cap * 3 // 4:
-            cap *= 2
-        bins = {}
-        for pos, k in enumerate(self.d):
-            h = _java_hash(k)
-            bins.setdefault((h ^ (h >> 16)) & (cap - 1), []).append(k)
-        if any(len(b) >= 8 for b in bins.values()):
-            raise RuntimeError("a HashMap bin of 8+ entries: tree bins are not simulated")
-        return [k for idx in sorted(bins) for k in bins[idx]]
+        return _hash_order(list(self.d))
 
     def jcall(self, vm, name, desc, args):
         if name == "keySet":
@@ -1050,6 +1079,85 @@ class JHashMap(JMap):
         if name == "values":
             return JCollection([self.d[k] for k in self._ordered()])
         return super().jcall(vm, name, desc, args)
+
+
+def _hash_order(keys):
+    """iteration order of a java.util.HashMap / HashSet holding `keys` (given in insertion order): see JHashMap"""
+    cap = 16
+    while len(keys) > cap * 3 // 4:
+        cap *= 2
+    bins = {}
+    for k in keys:
+        h = _java_hash(k)
+        bins.setdefault((h ^ (h >> 16)) & (cap - 1), []).append(k)
+    if any(len(b) >= 8 for b in bins.values()):
+        raise RuntimeError("a HashMap bin of 8+ entries: tree bins are not simulated")
+    return [k for idx in sorted(bins) for k in bins[idx]]
+
+
+class JHashSet(JCollection):
+    """java.util.HashSet: add() ignores duplicates; iteration in HashMap order.  `items` is kept in that order after every change so the
+    for-each of the evaluator and the iterator() of jar bytecode see it.  (A set that shrinks keeps its table in Java; the sets the
+    evaluated code removes from -- candItems with -numIgnore -- are refused below once that would matter.)"""
+
+    def __init__(self, items=None):
+        super().__init__()
+        self.inserted, self.peak = [], 0
+        for x in items or []:
+            self.jcall(None, "add", "", [x])
+
+    def _reorder(self):
+        self.peak = max(self.peak, len(self.inserted))
+        cap, pcap = 16, 16
+        while len(self.inserted) > cap * 3 // 4:
+            cap *= 2
+        while self.peak > pcap * 3 // 4:
+            pcap *= 2
+        if cap != pcap:
+            raise RuntimeError("HashSet shrank below a resize boundary: its iteration order depends on the table it grew to")
+        self.items = _hash_order(self.inserted)
+
+    def jcall(self, vm, name, desc, args):
+        if name == "add":
+            if args[0] in self.inserted:
+                return 0
+            self.inserted.append(args[0])
+            self._reorder()
+            return 1
+        if name == "remove":
+            if args[0] in self.inserted:
+                self.inserted.remove(args[0])
+                self._reorder()
+                return 1
+            return 0
+        return super().jcall(vm, name, desc, args)
+
+
+class JHashMultimap:
+    """guava HashMultimap<K, V> = HashMap<K, HashSet<V>>: keySet() and get(k) iterate in java.util.HashMap order"""
+    JAVA_TYPES = ("com/google/common/collect/Multimap",)
+
+    def __init__(self):
+        self.d = JHashMap()
+
+    def put(self, k, v):
+        return self.jcall(None, "put", "", [Box(k, "Integer"), Box(v, "Integer")])
+
+    def jcall(self, vm, name, desc, args):
+        if name == "put":
+            s = self.d.d.get(args[0])
+            if s is None:
+                s = self.d.d[args[0]] = JHashSet()
+            return s.jcall(vm, "add", "", [args[1]])
+        if name == "get":
+            return self.d.d.get(args[0]) or JHashSet()
+        if name == "containsKey":
+            return args[0] in self.d.d
+        if name == "keySet":
+            return JCollection(self.d._ordered())
+        if name == "size":
+            return sum(len(v.items) for v in self.d.d.values())
+        raise KeyError("HashMultimap." + name)
 
 
 class JSetMultimap:
@@ -1307,6 +1415,7 @@ STATIC_CALLS = {
     ("FileIO", "getReader"): lambda path: JReader(path),
     ("Strings", "last"): lambda s_, n_: s_[-n_:],
     ("Collections", "sort"): lambda coll: coll.items.sort(key=lambda b: b.v),
+    ("Arrays", "asList"): lambda *a: JCollection([to_host(x) for x in a]),
     ("Logs", "debug"): lambda *a: None,
     ("Logs", "info"): lambda *a: None,
     ("Logs", "error"): lambda *a: None,
@@ -1320,8 +1429,7 @@ def _guava_table():
 
 
 def _guava_multimap():
-    from .interp import GuavaMultimap
-    return GuavaMultimap()
+    return JHashMultimap()
 
 
 def _exit(code):

@@ -144,8 +144,29 @@ class UserItemsCache:
         raise KeyError("userItemsCache." + name)
 
 
-def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3, bold=True, test_cells=None):
-    vm = VM(os.path.join(ref, "lib", "librec-v1.4-alpha.jar"))
+def source_dao(ref, vm, prob):
+    """rateDao as a carskit.data.processor.DataDAO whose METHODS are interpreted from DataDAO.java (getUserCtxList, getItemList,
+    getRatingCountByItem, getUserIdFromUI, getContextId ...); the maps readData() would have filled are built here from the problem"""
+    dao = javasrc.This(vm, [os.path.join(ref, "src", "carskit", "data", "processor", "DataDAO.java")], {})
+    ui_u, ui_i, ctx, u_rated, i_rated = javasrc.JHashMap(), javasrc.JHashMap(), javasrc.JBiMap(), javasrc.JHashMultimap(), javasrc.JHashMultimap()
+    for ui, (u, j) in enumerate(zip(prob["ui_user"], prob["ui_item"])):
+        ui_u.d[Box(ui, "Integer")] = Box(u, "Integer")
+        ui_i.d[Box(ui, "Integer")] = Box(j, "Integer")
+        u_rated.put(u, ui)
+        i_rated.put(j, ui)
+    for c, key in enumerate(prob["ctx_keys"]):
+        ctx.d[JString(key)] = Box(c, "Integer")
+    dim_ids = javasrc.JBiMap()
+    for d in range(len(prob["ctx_keys"][0].split(","))):
+        dim_ids.d[JString("dim%d" % d)] = Box(d, "Integer")
+    dao.fields.update({"uiUserIds": ui_u, "uiItemIds": ui_i, "ctxIds": ctx, "idCtx": None, "uRatedList": u_rated, "iRatedList": i_rated,
+                       "dimIds": dim_ids})
+    return dao
+
+
+def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3, bold=True, test_cells=None, rank=None):
+    vm = VM([os.path.join(ref, "lib", "librec-v1.4-alpha.jar"), os.path.join(ref, "lib", "happy.coding.utils-1.2.6.jar")] if rank else
+            os.path.join(ref, "lib", "librec-v1.4-alpha.jar"))
     rng = np.random.default_rng(seed)
     nu, ni, nc = prob["n_users"], prob["n_items"], prob["n_conds"]
     init = {"P": 0.1 * rng.standard_normal((nu, k)), "Q": 0.1 * rng.standard_normal((ni, k))}
@@ -230,6 +251,21 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
         m = this.call("evalRatings", [])
         evals = {key.name: hx(val.v if isinstance(val, Box) else val) for key, val in m.d.items()}
 
+    ranks = None
+    if rank:         # Recommender.evalRankings (Recommender.java:672-955) from source, with carskit.eval.Measures from source over
+        #              happy.coding.math.Measures / io.Lists / math.Stats from the happy.coding.utils jar's bytecode
+        measures_cls = javasrc.This(vm, [os.path.join(ref, "src", "carskit", "eval", "Measures.java")], {})
+        measures_cls.static_super = "happy/coding/math/Measures"
+        this.class_map = dict(this.class_map, Measures=measures_cls, Lists="happy/coding/io/Lists", Stats="happy/coding/math/Stats")
+        F["rateDao"] = source_dao(ref, vm, prob)
+        F["testMatrix"] = sparse(vm, len(prob["ui_user"]), len(prob["ctx_keys"]), rank["test_cells"])
+        F.update({"binThold": float(rank["bin_thold"]), "numRecs": int(rank["num_recs"]), "numIgnore": int(rank["num_ignore"]),
+                  "isDiverseUsed": False, "evalStrategy": rank["strategy"], "workingPath": ""})
+        before = this.statements
+        m = this.call("evalRankings", [])
+        ranks = {"measures": {key.name: hx(val.v if isinstance(val, Box) else val) for key, val in m.d.items()},
+                 "statements": this.statements - before}
+
     def out_state(name):
         o = F[JAVA_FIELD.get(name, name)]
         if name == "ccMatrix":
@@ -245,7 +281,7 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
            "empty_conds": empty, "n_ctx_dims": n_dims, "num_f": NUM_F,
            "problem": prob, "init": {n: [hx(x) for x in a.ravel()] for n, a in init.items()},
            "final": {n: out_state(n) for n in init}, "epoch_loss": [hx(l) for l, _ in trace], "epoch_lrate": [hx(r) for _, r in trace],
-           "final_lrate": hx(F["lRate"]), "test_cells": test_cells, "eval_ratings": evals, "java_statements_executed": this.statements, "bytecode_instructions": vm.steps}
+           "final_lrate": hx(F["lRate"]), "test_cells": test_cells, "eval_ratings": evals, "rank": rank, "eval_rankings": ranks, "java_statements_executed": this.statements, "bytecode_instructions": vm.steps}
     return rec
 
 

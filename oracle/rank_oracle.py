@@ -153,9 +153,12 @@ def eval_rankings(predict, train, test, bin_thold=-1.0, num_recs=10, strategy="u
     cand_set = set(cand)
     lists = {m: [] for m in MEASURES}
     tops = {}
-    for u in order_u:
+    # uciList is a HashMap<Integer, HashMultimap<Integer, Integer>>: users, and a user's contexts, are visited in java.util.HashMap order
+    # (Recommender.java:738, 770) -- which fixes the summation order of the means below
+    for u in java_int_hashset_order(order_u):
         c_lists = {m: [] for m in MEASURES}
-        for c, pos_items in uci[u].items():
+        for c in java_int_hashset_order(list(uci[u])):
+            pos_items = uci[u][c]
             num_cands = len(cand)
             correct = [j for j in pos_items if j in cand_set]
             if not correct:

@@ -1,0 +1,73 @@
+"""the top-N evaluation against the reference's OWN `Recommender.evalRankings`, executed from its Java source
+(oracle/mint_reference_rank.py -> tests/golden/reference_rank.json; carskit.eval.Measures from source, happy.coding's Measures / Lists /
+Stats from the happy.coding.utils jar's bytecode, HashMap / HashSet / HashMultimap iteration in JDK 8 order).
+
+CPU: oracle/rank_oracle.py (scoring with the C oracle's `predict` on the interpreted model) must reproduce all 18 measures.
+GPU (`-m gpu`): the product's cmi_eval_rankings on the same model state, fp64 strict scoring: measures within 1e-12."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c, rank_oracle
+from tests import util
+from tests.test_reference_src_golden import _inputs, fx, SHAPES
+
+CASES = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_rank.json")))["cases"]
+
+
+def _cells_to_tuples(p, cells):
+    return [(p["ui_user"][ui], p["ui_item"][ui], c, v) for ui, c, v in cells]
+
+
+def _final_state(case):
+    shapes = SHAPES(case)
+    return {n: np.array([fx(x) for x in v]).reshape(shapes[n]) for n, v in case["final"].items()}
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s-%s-top%d" % (c["model"], c["rank"]["strategy"], c["rank"]["num_recs"]))
+def test_rank_oracle_reproduces_the_interpreted_evalrankings(case):
+    u, j, ctx, r, ctx_ptr, ctx_conds, _ = _inputs(case)
+    p, rk = case["problem"], case["rank"]
+    assert case["eval_rankings"]["statements"] > 3000
+    orc = oracle_c.Oracle(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], u, j, ctx, r, ctx_ptr, ctx_conds,
+                          _final_state(case), fx(case["global_mean"]), case["regU"], case["regI"], case["regB"], case["regC"])
+    got, _ = rank_oracle.eval_rankings(lambda a, b, c: orc.predict(a, b, c), _cells_to_tuples(p, p["cells"]),
+                                       _cells_to_tuples(p, rk["test_cells"]), bin_thold=rk["bin_thold"], num_recs=rk["num_recs"],
+                                       strategy=rk["strategy"], num_ignore=rk["num_ignore"])
+    want = {m: fx(v) for m, v in case["eval_rankings"]["measures"].items()}
+    assert set(rank_oracle.MEASURES) | {"D5", "D10", "DN"} == set(want)
+    for m in rank_oracle.MEASURES:
+        if m.startswith("NDCG"):
+            # nDCG divides by Math.log, which Java specifies only to 1 ulp (HotSpot's intrinsic, not StrictMath): the golden was minted
+            # with fdlibm's log, the restatement uses libm's -- the one measure held to a few ulps instead of to the bit
+            assert abs(got[m] - want[m]) <= 4 * math.ulp(want[m]), (m, got[m], want[m])
+            continue
+        assert (math.isnan(got[m]) and math.isnan(want[m])) or float(got[m]).hex() == float(want[m]).hex(), (m, got[m], want[m])
+    assert want["D5"] == want["D10"] == want["DN"] == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s-%s-top%d" % (c["model"], c["rank"]["strategy"], c["rank"]["num_recs"]))
+def test_gpu_eval_rankings_reproduces_the_interpreted_evalrankings(case):
+    from carskit_amd import capi
+    u, j, ctx, r, ctx_ptr, ctx_conds, _ = _inputs(case)
+    p, rk = case["problem"], case["rank"]
+    inst = capi.Instance(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], flags=capi.FLAG_STATE_F64 | capi.FLAG_STRICT)
+    inst.set_hparams(case["regU"], case["regI"], case["regB"], case["regC"], fx(case["global_mean"]))
+    if case["model"] in util.TWO_D:
+        inst.set_ratings(u, j, None, r)
+    else:
+        inst.set_ratings(u, j, ctx, r, ctx_ptr, ctx_conds)
+    inst.set_states(_final_state(case))
+    tr = _cells_to_tuples(p, p["cells"])
+    te = _cells_to_tuples(p, rk["test_cells"])
+    arr = lambda t: (np.array([x[0] for x in t], np.int32), np.array([x[1] for x in t], np.int32), np.array([x[2] for x in t], np.int32),
+                     np.array([x[3] for x in t]))
+    res = inst.eval_rankings(arr(tr), arr(te), bin_thold=rk["bin_thold"], num_recs=rk["num_recs"], num_ignore=rk["num_ignore"],
+                             strategy=rk["strategy"])
+    want = {m: fx(v) for m, v in case["eval_rankings"]["measures"].items()}
+    for m in rank_oracle.MEASURES:
+        assert (math.isnan(res[m]) and math.isnan(want[m])) or abs(res[m] - want[m]) <= 1e-12, (m, res[m], want[m])
