@@ -209,7 +209,15 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--flags") && i + 1 < argc) flags = (unsigned)std::strtoul(argv[++i], nullptr, 0);
         else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = std::atoi(argv[++i]);
         else if (!strcmp(argv[i], "--precise")) precise = true;
-        else if (!strcmp(argv[i], "--load-model")) load_model = true; // evaluate the models `--save-model` left in the workspace instead of training
+        else if (!strcmp(argv[i], "--print-folds") && i + 3 < argc) {
+            // test hook (no GPU, no config): the fold label of every matrix entry in CRS order, as DataSplitter.splitFolds assigns them
+            int nf = 0;
+            const std::vector<int> lab = carskit::split_folds(std::atoll(argv[i + 1]), std::atoi(argv[i + 2]), std::atoll(argv[i + 3]), &nf);
+            printf("%d", nf);
+            for (int v : lab) printf(" %d", v);
+            printf("\n");
+            return 0;
+        } else if (!strcmp(argv[i], "--load-model")) load_model = true; // evaluate the models `--save-model` left in the workspace instead of training
         else {
             fprintf(stderr, "usage: carskit-mi355x -c setting.conf [-c more.conf] [--flags N] [--iters N] [--precise] [--load-model]\n");
             return 2;

@@ -162,6 +162,14 @@ class Parser:
             if v == "final":
                 self.eat()
                 return self.statement()
+            if v == "assert":               # assertions are off in a JVM started without -ea: parsed, never evaluated
+                self.eat()
+                self.expr()
+                if self.at(":"):
+                    self.eat()
+                    self.expr()
+                self.eat(";")
+                return ("block", [])
             if v == "try":
                 self.eat()
                 body = self.block()
@@ -394,6 +402,16 @@ class Parser:
             if v == "new":
                 self.eat()
                 ty = self.try_type_for_new()
+                if self.at("[") and self.at("]", 1):      # new T[] { a, b, ... }
+                    self.eat(), self.eat()
+                    self.eat("{")
+                    items = []
+                    while not self.at("}"):
+                        items.append(self.expr_no_comma())
+                        if self.at(","):
+                            self.eat()
+                    self.eat("}")
+                    return ("arraylit", ty, items)
                 if self.at("["):
                     self.eat()
                     n = self.expr()
@@ -544,6 +562,7 @@ class This:
             self.chain.append((cls, methods))
         self.fields = {}
         self.host = {}          # name -> python callable(*args): methods of `this` outside the interpreted sources
+        self.override = {}      # name -> python callable(*args) that REPLACES a source method (logging / debug output only)
         self.hooks = {}         # name -> python callable(this, args): runs before the source method of that name
         self.class_map = class_map   # simple class name -> jar class (for static calls / new), or a This of static methods
         self.static_super = None     # jar class whose static methods an interpreted class of statics inherits
@@ -581,6 +600,8 @@ class This:
         return None
 
     def call(self, name, args, after=None):
+        if name in self.override and after is None:
+            return self.override[name](*args)
         m = self.find(name, len(args), after, args)
         if m is None:
             if name in self.host:
@@ -798,6 +819,8 @@ class Env:
             return self.call(n[1], n[2], [self.eval(a) for a in n[3]])
         if k == "new":
             return self.new(n[1], [self.eval(a) for a in n[2]])
+        if k == "arraylit":
+            return [self.eval(x) for x in n[2]]
         if k == "newarray":
             return [{"double": 0.0, "int": 0, "float": f32(0.0), "boolean": False, "long": JLong(0)}.get(n[1])] * unbox(self.eval(n[2]))
         raise NotImplementedError(k)
@@ -1469,6 +1492,9 @@ def vm_call(vm, obj, cls, name, args, static):
                     score += 2
                 elif t == "J" and isinstance(a, int) and not isinstance(a, bool):
                     conv.append(JLong(a))
+                    score += 1
+                elif t[0] == "[" and isinstance(a, list):      # an array of the evaluator: the SAME list, so in-place changes are seen
+                    conv.append(JArray(t[1:], a))
                     score += 1
                 elif t[0] in "L[" and (a is None or isinstance(a, (JObject, JArray)) or hasattr(a, "jcall")):
                     conv.append(a)

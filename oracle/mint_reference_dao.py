@@ -105,6 +105,43 @@ def run_transform(ref, vm, f_train, p_train, f_test, p_test, outdir):
     return out
 
 
+def mint_splitter(ref, vm_unused, golden):
+    """DataSplitter.splitFolds + getKthFold (DataSplitter.java:68-133) from source; happy.coding.math.Randoms (seed, uniform) and
+    Sortor.quickSort from the happy.coding.utils jar's bytecode, SparseMatrix copy / set / reshape from the librec jar's"""
+    vm = VM([os.path.join(ref, "lib", "librec-v1.4-alpha.jar"), os.path.join(ref, "lib", "happy.coding.utils-1.2.6.jar")])
+    src = os.path.join(ref, "src", "carskit", "data", "processor", "DataSplitter.java")
+    cmap = {"SparseMatrix": SM, "Randoms": "happy/coding/math/Randoms", "Sortor": "happy/coding/math/Sortor"}
+    cases = []
+    for (n_rows, n_cols, n_cells, kfold, seed) in ((6, 5, 17, 5, 1), (9, 4, 23, 3, 42), (4, 3, 4, 10, 7), (12, 6, 50, 5, 20260928)):
+        rng = random.Random(seed * 7 + 1)
+        cells = {}
+        while len(cells) < n_cells:
+            cells[(rng.randrange(n_rows), rng.randrange(n_cols))] = float(rng.randrange(1, 6))
+        cells = [[r, c, v] for (r, c), v in sorted(cells.items())]
+        from oracle.mint_reference_src import sparse
+        mat = sparse(vm, n_rows, n_cols, cells)
+        this = javasrc.This(vm, [src], cmap)
+        this.fields.update({"rateMatrix": mat, "assignMatrix": None, "numFold": 0})
+        this.override["debugInfo"] = lambda *a: None
+        javasrc.vm_call(vm, None, "happy/coding/math/Randoms", "seed", [javasrc.JLong(seed)], static=True)
+        this.call("splitFolds", [kfold])
+        am = this.fields["assignMatrix"]
+        rp, ci, rd = (am.fields[x].data for x in ("rowPtr", "colInd", "rowData"))
+        labels = [int(rd[p]) for r in range(n_rows) for p in range(rp[r], rp[r + 1])]
+        folds = []
+        for f in range(1, this.fields["numFold"] + 1):
+            tr, te = this.call("getKthFold", [f])
+            def crs(m):
+                a, b, d = (m.fields[x].data for x in ("rowPtr", "colInd", "rowData"))
+                return [[r, int(b[p]), float(d[p]).hex()] for r in range(n_rows) for p in range(a[r], a[r + 1])]
+            folds.append({"train": crs(tr), "test": crs(te)})
+        cases.append({"name": "split_%d_of_%d_seed_%d" % (kfold, n_cells, seed), "n_rows": n_rows, "n_cols": n_cols, "cells": cells,
+                      "kfold": kfold, "seed": seed, "num_fold": this.fields["numFold"], "labels": labels, "folds": folds,
+                      "statements": this.statements})
+        print("splitter", cases[-1]["name"], "numFold", this.fields["numFold"], labels[:12], flush=True)
+    return cases
+
+
 VALIDATE_TEXTS = {
     "binary_plain": "User,Item,Rating,time:na,time:weekend\nu,i,3,1,0\n",
     "binary_digits_10": "User,Item,Rating,time:na,time:weekend\nu,i,3,10,11\n",          # isBinaryNumber looks at decimal digits
@@ -258,13 +295,14 @@ def main():
         cases.append({"name": "pair_%d%s" % (seed, "_messy" if messy else ""), "after_text": a, "text": b, "expect": exp_b})
         print("pair", seed, exp_a["counts"], "->", exp_b["counts"], flush=True)
     os.unlink(tmp)
+    scases = mint_splitter(ref, vm, golden)
     vcases = mint_validate(ref, vm, golden)
     tcases = mint_transform(ref, vm, golden)
     out = os.path.join(golden, "reference_transform.json")
     with open(out, "w") as fh:
         json.dump({"note": "minted by oracle/mint_reference_dao.py: DataTransformer.run of the reference, interpreted from its Java source "
                            "(java.util.HashMap's iteration order simulated: the JDK is not in the reference tree); validate = "
-                           "CARSKit.validateDataFormat", "cases": tcases, "validate": vcases}, fh,
+                           "CARSKit.validateDataFormat", "cases": tcases, "validate": vcases, "splitter": scases}, fh,
                   separators=(",", ":"))
     print("wrote", out, os.path.getsize(out), "bytes")
     out = os.path.join(golden, "reference_dao.json")

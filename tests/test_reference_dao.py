@@ -106,3 +106,28 @@ def test_validate_data_format_matches_the_interpreted_reference(tmp_path, case):
     assert ("throws" in case["expect"]) == (want == 0)
     assert dao.validate_data_format(path) == want
     assert dao_oracle.validate_format(dao_oracle.read_lines(path)) == want
+
+
+# ---- DataSplitter.splitFolds / getKthFold, interpreted from source over happy.coding's Randoms + Sortor bytecode
+SCASES = json.load(open(os.path.join(GOLDEN, "reference_transform.json")))["splitter"]
+DRIVER = os.path.join(os.path.dirname(GOLDEN), "..", "carskit_amd", "bin", "carskit-mi355x")
+
+
+@pytest.mark.parametrize("case", SCASES, ids=lambda c: c["name"])
+def test_fold_assignment_matches_the_interpreted_reference(case):
+    """The fold label of every matrix entry (CRS order) and the train / test cells of every fold: the C++ driver's split_folds
+    (`--print-folds`, no GPU involved) and the host mirror's, against DataSplitter.java executed."""
+    import subprocess
+    from tests.hostmirror import splitter
+    n = len(case["cells"])
+    assert case["statements"] > 50
+    out = subprocess.run([DRIVER, "--print-folds", str(n), str(case["kfold"]), str(case["seed"])], capture_output=True, text=True, check=True)
+    got = [int(x) for x in out.stdout.split()]
+    assert got[0] == case["num_fold"] and got[1:] == case["labels"]
+    labels, nf = splitter.split_folds(n, case["kfold"], case["seed"])
+    assert nf == case["num_fold"] and labels.tolist() == case["labels"]
+    # getKthFold: fold f's entries are the TEST matrix, the rest the training matrix, both in CRS order
+    for f, fold in enumerate(case["folds"], start=1):
+        test = [[r, c, float(v).hex()] for (r, c, v), lab in zip(case["cells"], case["labels"]) if lab == f]
+        train = [[r, c, float(v).hex()] for (r, c, v), lab in zip(case["cells"], case["labels"]) if lab != f]
+        assert fold["test"] == test and fold["train"] == train
