@@ -2,7 +2,9 @@
 // (inherited); buildModel() runs on the GPU through GpuSupport.buildModel, evalRatings() reads the device model while training
 // is in progress (so `--early-stop MAE|RMSE` sees the live model, IterativeRecommender.java:156-161).  Registered in the reference's
 // factory switch next to "camf_cuci" (src/carskit/main/CARSKit.java:706) as "camf_cuci_gpu".
-// Source only (no JDK in this image): NOT compiled or run here; tests/test_java_binding_text.py checks the NativeMF calls as text.
+// No JDK in this image: not compiled by javac here.  EXECUTED under the Java-source interpreter over the reference's own class chain
+// (oracle/check_java_binding.py, tests/test_java_binding_exec.py: bit-identical to the reference's buildModel()); the NativeMF calls are
+// also checked as text (tests/test_java_binding_text.py).
 package carskit.alg.gpu;
 
 import carskit.alg.cars.adaptation.dependent.dev.CAMF_CUCI;

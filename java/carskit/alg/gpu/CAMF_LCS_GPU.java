@@ -4,7 +4,9 @@
 // the reference's operation sequence (bit-identical to the Java arithmetic with FLAG_STATE_F64 | FLAG_STRICT); a GPU is the wrong
 // machine for such a chain -- the class exists so that the name resolves to the same library with the same parity guarantees.
 // Registered in the reference's factory switch next to "camf_lcs" (src/carskit/main/CARSKit.java:710) as "camf_lcs_gpu".
-// Source only (no JDK in this image): NOT compiled or run here; tests/test_java_binding_text.py checks the NativeMF calls as text.
+// No JDK in this image: not compiled by javac here.  EXECUTED under the Java-source interpreter over the reference's own class chain
+// (oracle/check_java_binding.py, tests/test_java_binding_exec.py: bit-identical to the reference's buildModel()); the NativeMF calls are
+// also checked as text (tests/test_java_binding_text.py).
 package carskit.alg.gpu;
 
 import carskit.alg.cars.adaptation.dependent.sim.CAMF_LCS;

@@ -1,6 +1,6 @@
 // Dev.java -- where a model container goes: the single instance behind a cmi_handle, or the sharded group behind a
 // cmi_group_handle (-Dcarskit.shards=N).  GpuSupport hands the *_GPU classes a group as the NEGATED handle (native addresses are
-// positive), so that their copyIn / copyOut stay one line per container.  Source only: NOT compiled or run here.
+// positive), so that their copyIn / copyOut stay one line per container.  No JDK here: not compiled by javac; executed under the Java-source interpreter (tests/test_java_binding_exec.py).
 package carskit.alg.gpu;
 
 final class Dev {

@@ -4,7 +4,8 @@
 // (FM.java:57-74, minus the size x k cache `Q`, which only buildModel() uses), trains with cmi_fm_train (the pre-pass + numIters
 // ALS sweeps of FM.java:115-220) and predicts with the model equation in its pairwise form over the <= 3 non-zero features
 // of a rating (FM.java:76-113 builds the dense p-vector and loops over it: same value, O(k) instead of O(p k)).
-// Source only (no JDK in this image): NOT compiled or run here.
+// No JDK in this image: not compiled by javac here.  EXECUTED under the Java-source interpreter (oracle/check_java_binding.py,
+// tests/test_java_binding_exec.py: buildModel() bit-identical to FM.buildModel(), predict() within 1e-12 of FM.predict()).
 package carskit.alg.gpu;
 
 import carskit.data.structure.SparseMatrix;

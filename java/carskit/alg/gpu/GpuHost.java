@@ -1,7 +1,7 @@
 // GpuHost.java -- what GpuSupport.buildModel needs from a *_GPU recommender.  The reference keeps its model containers and
 // hyper-parameters in PROTECTED fields of carskit.generic.Recommender / IterativeRecommender / ContextRecommender, and every
 // drop-in must extend a different reference class (CAMF_CI, CAMF_CU, ..., to inherit its initModel/predict), so the shared
-// flow lives in GpuSupport and reaches those fields through this interface.  Source only: NOT compiled or run here.
+// flow lives in GpuSupport and reaches those fields through this interface.  No JDK here: not compiled by javac; executed under the Java-source interpreter (tests/test_java_binding_exec.py).
 package carskit.alg.gpu;
 
 import carskit.data.structure.SparseMatrix;

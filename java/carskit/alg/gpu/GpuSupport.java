@@ -1,6 +1,6 @@
 // GpuSupport.java -- the part of buildModel()/evalRatings() every *_GPU recommender shares.  Only marshalling and the
 // reference's own control flow (the epoch loop with isConverged()); all arithmetic is behind NativeMF.
-// Source only: NOT compiled or run here (no JDK in the build image).
+// No JDK in the build image: not compiled by javac here; executed under the Java-source interpreter (tests/test_java_binding_exec.py).
 package carskit.alg.gpu;
 
 import carskit.data.processor.DataDAO;

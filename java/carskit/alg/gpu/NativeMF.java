@@ -1,5 +1,6 @@
 // NativeMF.java -- Java side of the JNI binding to libcarskit_mi355x.so (include/carskit_mi355x.h).
-// Source only: the build image and the GPU box have no JDK, so this file is NOT compiled or run here (see INTEGRATION.md);
+// The build image and the GPU box have no JDK, so this file is not compiled by javac here (see INTEGRATION.md; the classes that call it
+// are executed under the Java-source interpreter with these natives bound to a stand-in: tests/test_java_binding_exec.py);
 // tests/test_java_binding_text.py checks, as text, that every native below has exactly one
 // Java_carskit_alg_gpu_NativeMF_<name> definition in jni/carskit_jni.cpp with the matching JNI type signature.
 // One static native method per C-ABI entry point a Java host needs, same argument meaning; no logic.

@@ -1,6 +1,6 @@
 // Rows.java -- live row arrays of a librec DenseMatrix (row(i,false) is a shallow view, SURVEY 8b), and the dense image of the
 // guava Table<Integer,Integer,Double> CAMF_CUCI keeps its context-bias tables in (CAMF_CUCI.java:43-66: every (row, condition)
-// cell is present).  Source only: NOT compiled or run here.
+// cell is present).  No JDK here: not compiled by javac; executed under the Java-source interpreter (tests/test_java_binding_exec.py).
 package carskit.alg.gpu;
 
 import com.google.common.collect.Table;

@@ -605,6 +605,9 @@ class JCollection:
         if name == "clear":
             self.items.clear()
             return None
+        if name == "addAll":
+            self.items.extend(args[0].items)
+            return int(bool(args[0].items))
         if name == "<init>":               # ArrayList() / ArrayList(int capacity) / ArrayList(Collection)
             if args and hasattr(args[0], "items"):
                 self.items = list(args[0].items)

@@ -170,7 +170,7 @@ class Parser:
                     self.expr()
                 self.eat(";")
                 return ("block", [])
-            if v == "try":
+            if v == "try":               # catch clauses are parsed and ignored (a Java exception ends the run); finally IS executed
                 self.eat()
                 body = self.block()
                 while self.at("catch"):
@@ -179,10 +179,11 @@ class Parser:
                         self.eat()
                     self.eat(")")
                     self.block()
+                fin = None
                 if self.at("finally"):
                     self.eat()
-                    self.block()
-                return body
+                    fin = self.block()
+                return ("try", body, fin) if fin is not None else body
         decl = self.try_local_decl()
         if decl is not None:
             self.eat(";")
@@ -402,8 +403,9 @@ class Parser:
             if v == "new":
                 self.eat()
                 ty = self.try_type_for_new()
-                if self.at("[") and self.at("]", 1):      # new T[] { a, b, ... }
-                    self.eat(), self.eat()
+                if self.at("[") and self.at("]", 1):      # new T[] { a, b, ... } / new T[][] { a, b }
+                    while self.at("[") and self.at("]", 1):
+                        self.eat(), self.eat()
                     self.eat("{")
                     items = []
                     while not self.at("}"):
@@ -416,6 +418,11 @@ class Parser:
                     self.eat()
                     n = self.expr()
                     self.eat("]")
+                    if self.at("["):                      # new T[n][m] / new T[n][]
+                        self.eat()
+                        m = None if self.at("]") else self.expr()
+                        self.eat("]")
+                        return ("newarray2", ty, n, m)
                     return ("newarray", ty, n)
                 a = self.args()
                 if self.at("{"):  # anonymous class body: not on this path
@@ -654,6 +661,11 @@ class Env:
     def exec(self, node):
         self.this.statements += 1
         k = node[0]
+        if k == "try":
+            try:
+                return self.exec(node[1])
+            finally:
+                self.exec(node[2])
         if k == "block":
             self.scopes.append({})
             self.types.append({})
@@ -821,6 +833,11 @@ class Env:
             return self.new(n[1], [self.eval(a) for a in n[2]])
         if k == "arraylit":
             return [self.eval(x) for x in n[2]]
+        if k == "newarray2":
+            zero = {"double": 0.0, "int": 0, "float": f32(0.0), "boolean": False, "long": JLong(0)}.get(n[1])
+            rows = unbox(self.eval(n[2]))
+            cols = None if n[3] is None else unbox(self.eval(n[3]))
+            return [None if cols is None else [zero] * cols for _ in range(rows)]
         if k == "newarray":
             return [{"double": 0.0, "int": 0, "float": f32(0.0), "boolean": False, "long": JLong(0)}.get(n[1])] * unbox(self.eval(n[2]))
         raise NotImplementedError(k)
@@ -842,6 +859,9 @@ class Env:
                 return EnumConst(obj[1], name)
             if (obj[1], name) in STATIC_FIELDS:
                 return STATIC_FIELDS[(obj[1], name)]
+            holder = self.this.class_map.get(obj[1])
+            if holder is not None and hasattr(holder, "consts") and name in holder.consts:
+                return holder.consts[name]
             return EnumConst(obj[1], name)
         if obj is self.this:
             return self.this.fields[name]
@@ -876,6 +896,7 @@ class Env:
             return
         if target[0] == "index":
             a, i = self.eval(target[1]), unbox(self.eval(target[2]))
+            v = unbox(v) if isinstance(v, Box) else v       # int[] / double[] elements: auto-unboxing on the way in
             if isinstance(a, list):
                 a[i] = v
             else:
@@ -1008,6 +1029,8 @@ class Env:
         if key in STATIC_CALLS:
             return STATIC_CALLS[key](*a)
         jar_cls = self.this.class_map.get(cls)
+        if hasattr(jar_cls, "jstatic"):  # a class whose static (native) methods are provided by the harness
+            return jar_cls.jstatic(name, args)
         if isinstance(jar_cls, This):   # a class of static methods interpreted from source; what it inherits comes from its `static_super`
             if jar_cls.find(name, len(args)) is not None:
                 return jar_cls.call(name, args)
@@ -1438,6 +1461,10 @@ STATIC_CALLS = {
     ("FileIO", "getReader"): lambda path: JReader(path),
     ("Strings", "last"): lambda s_, n_: s_[-n_:],
     ("Collections", "sort"): lambda coll: coll.items.sort(key=lambda b: b.v),
+    ("Integer", "getInteger"): lambda name, dflt: Box(int(dflt), "Integer"),      # no -D properties are set in the evaluated runs
+    ("System", "getProperty"): lambda name, dflt=None: dflt,
+    ("Double", "parseDouble"): lambda x: _parse_double(x),
+    ("Double", "toString"): lambda x: java_str(float(x)),
     ("Arrays", "asList"): lambda *a: JCollection([to_host(x) for x in a]),
     ("Logs", "debug"): lambda *a: None,
     ("Logs", "info"): lambda *a: None,

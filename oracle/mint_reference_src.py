@@ -164,7 +164,11 @@ def source_dao(ref, vm, prob):
     return dao
 
 
-def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3, bold=True, test_cells=None, rank=None):
+def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3, bold=True, test_cells=None, rank=None, drop_in=None,
+              init_override=None):
+    """drop_in: (path of a *_GPU.java drop-in class of THIS repository, {simple class name: This / natives object}, make(vm) that fills
+    that map) -- the drop-in is put in front of the reference's class chain, so its buildModel() override runs
+    (oracle/check_java_binding.py); init_override: the initial containers of a minted case instead of fresh draws"""
     vm = VM([os.path.join(ref, "lib", "librec-v1.4-alpha.jar"), os.path.join(ref, "lib", "happy.coding.utils-1.2.6.jar")] if rank else
             os.path.join(ref, "lib", "librec-v1.4-alpha.jar"))
     rng = np.random.default_rng(seed)
@@ -188,7 +192,12 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
         init["P"], init["Q"] = rng.random((nu, k)), rng.random((ni, k))
     src = [os.path.join(ref, "src", "carskit", p) for p in MODELS[model]] + \
           [os.path.join(ref, "src", "carskit", "generic", "IterativeRecommender.java"), os.path.join(ref, "src", "carskit", "generic", "Recommender.java")]
-    this = javasrc.This(vm, src, CLASS_MAP)
+    if init_override:
+        init = {n: np.array(a, dtype=np.float64).reshape(init[n].shape) for n, a in init_override.items()}
+    if drop_in:
+        src = [drop_in[0]] + src
+        drop_in[2](vm)
+    this = javasrc.This(vm, src, dict(CLASS_MAP, **(drop_in[1] if drop_in else {})))
     two_d = model in ("BiasedMF", "PMF", "SVD++")
     cells = prob["cells"]
     if two_d:   # DataDAO.toTraditionalSparseMatrix: users x items, the mean over contexts of every (user, item) pair
@@ -243,6 +252,9 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
             F[name] = dense(vm, init[name]) if init[name].ndim == 2 else vector(vm, init[name])
     trace = []
     this.hooks["isConverged"] = lambda th, args: trace.append((th.fields["loss"], th.fields["lRate"]))
+    if drop_in:
+        F.update({"gpuHandle": javasrc.JLong(0), "fold": 1})
+        javasrc.STATIC_FIELDS[("Recommender", "rateDao")] = F["rateDao"]
     this.call("buildModel", [])
     evals = None
     if test_cells:   # Recommender.evalRatings (Recommender.java:504-594) over a held-out testMatrix, from source as well
