@@ -55,7 +55,7 @@ def test_gpu_eval_rankings_reproduces_the_interpreted_evalrankings(case):
     from carskit_amd import capi
     u, j, ctx, r, ctx_ptr, ctx_conds, _ = _inputs(case)
     p, rk = case["problem"], case["rank"]
-    inst = capi.Instance(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], flags=capi.FLAG_STATE_F64 | capi.FLAG_STRICT)
+    inst = capi.Instance(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], flags=capi.FLAG_STATE_F64 | capi.FLAG_STRICT | (capi.FLAG_SCHED_SERIAL if case["model"] == "CAMF_C" else 0))
     inst.set_hparams(case["regU"], case["regI"], case["regB"], case["regC"], fx(case["global_mean"]))
     if case["model"] in util.TWO_D:
         inst.set_ratings(u, j, None, r)
