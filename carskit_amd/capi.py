@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcarskit_mi355x.so")
+LIB_PATH = os.environ.get("CMI_LIB_PATH") or os.path.join(_HERE, "lib", "libcarskit_mi355x.so")   # CMI_LIB_PATH: experiments with variant builds
 
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NUMERIC, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 

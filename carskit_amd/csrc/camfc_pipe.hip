@@ -1,0 +1,328 @@
+// camfc_pipe.hip -- CAMF_C (src/carskit/alg/cars/adaptation/dependent/dev/CAMF_C.java:79-131) as ONE software-pipelined wave.
+//
+// CAMF_C's shared condBias vector makes every tuple depend on the one before it: the epoch is a single dependency chain and the only
+// lever is the latency of one link.  sgd_serial_fast (mf_sgd_kernels.hip) requests the rows of tuple t+1 while it computes tuple t, so
+// every link still waits most of a memory round trip (0.62 us per tuple measured on DePaulMovie and on the Frappe shape -- one CPU core
+// does a k = 64 link in 0.095 us).  This kernel requests the rows of tuple t+D (D = 8 for one-instruction rows) while it computes
+// tuple t, so the round trip is hidden behind D links and a link costs what its arithmetic chain costs:
+//   * lane l owns the MAXC consecutive factors [l*MAXC, (l+1)*MAXC) of P[u] and Q[j] -- one 4/8/16-byte load or store per row;
+//   * a ring of D register slots receives the requested rows; the loop body is unrolled D times so every slot is a fixed register;
+//   * a requested row is STALE when one of the D tuples processed since the request wrote it.  The ids of the last D tuples sit in
+//     one VGPR (lane s = ring slot s): one v_cmp + ballot per side says whether any of them is this tuple's user / item -- if so the
+//     freshest copy is taken from an LDS ring that every tuple writes its updated rows to (the previous tuple's rows are simply
+//     still in registers: consecutive CRS tuples share their user).  Writers further back than D tuples had issued their stores before
+//     the request; a wave's stores and later loads of one address stay ordered in the vector-memory pipeline;
+//   * condBias lives in a register (lane c owns condBias[c], n_conds <= 64): reading an entry is a v_readlane, no LDS round trip;
+//   * a tuple's condition ids travel as one packed 64-bit word per tuple (<= 8 dimensions, 8 bits each), staged 64 tuples at a time
+//     in registers, the next chunk's ids requested a chunk ahead;
+//   * no memory operation sits under a branch in the steady state, so the compiler counts outstanding requests exactly
+//     (s_waitcnt vmcnt(N), never a drain) -- the lesson of the hub-chain kernel.
+// Arithmetic per element is the expression every other non-strict kernel uses; the dot is a DPP tree sum, the deviations are added
+// one by one in condition order like the reference.  The last n mod 64 tuples take a plain loop (requests after stores).
+#include "mf_sgd_kernels.hpp"
+#include "sgd_device.hpp"
+
+#include <cstdlib>
+
+namespace cmi {
+namespace {
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float pdpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double pdpp(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int prl(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+__device__ __forceinline__ float prl(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+__device__ __forceinline__ double prl(double x, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+__device__ __forceinline__ unsigned long long prl(unsigned long long x, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// lane `slot` (a constant after unrolling) of x := v (wave-uniform): one v_cndmask under a loop-invariant lane mask
+template <typename V>
+__device__ __forceinline__ V pwl(V x, V v, int slot, int lane) { return lane == slot ? v : x; }
+template <typename T>
+__device__ __forceinline__ T pwave_sum(T x) { // fixed tree, result uniform
+    x += pdpp<0x128, 0xf>(x);
+    x += pdpp<0x124, 0xf>(x);
+    x += pdpp<0x122, 0xf>(x);
+    x += pdpp<0x121, 0xf>(x);
+    x += pdpp<0x142, 0xa>(x);
+    x += pdpp<0x143, 0xc>(x);
+    return prl(x, 63);
+}
+
+template <typename T, int MAXC>
+struct alignas(sizeof(T) * MAXC) RowVec { T v[MAXC]; };
+
+// FULL: k == 64 * MAXC, one aligned vector access per row; otherwise element-wise with a mask (k < 64 * MAXC)
+template <typename T, int MAXC, bool FULL>
+__device__ __forceinline__ RowVec<T, MAXC> load_row(const T *tab, int row, int k, int lane) {
+    RowVec<T, MAXC> r;
+    if (FULL) {
+        r = *reinterpret_cast<const RowVec<T, MAXC> *>(tab + (size_t)row * k + (size_t)lane * MAXC);
+    } else {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int f = lane * MAXC + c;
+            r.v[c] = tab[(size_t)row * k + (f < k ? f : 0)];
+            if (f >= k) r.v[c] = (T)0;
+        }
+    }
+    return r;
+}
+template <typename T, int MAXC, bool FULL>
+__device__ __forceinline__ void store_row(T *tab, int row, int k, int lane, const RowVec<T, MAXC> &r) {
+    if (FULL) {
+        *reinterpret_cast<RowVec<T, MAXC> *>(tab + (size_t)row * k + (size_t)lane * MAXC) = r;
+    } else {
+        // a store under a lane mask is a memory operation under control flow, and the compiler then stops counting outstanding
+        // requests exactly; so the lanes past k store too -- the row's LAST element, with the value its owner stores (same word, same
+        // value: harmless, like the all-lane bias stores)
+        const int lo = (k - 1) / MAXC, co = (k - 1) % MAXC;
+        T last = prl(r.v[0], lo);
+#pragma unroll
+        for (int c = 1; c < MAXC; ++c)
+            if (co == c) last = prl(r.v[c], lo);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int f = lane * MAXC + c;
+            tab[(size_t)row * k + (f < k ? f : k - 1)] = f < k ? r.v[c] : last;
+        }
+    }
+}
+
+template <typename T>
+struct PipeConst {
+    T lr, regU, regI, regB, regC, gm;
+};
+
+// one CAMF_C update on rows held in registers; returns the tuple's loss terms that are uniform, adds the lane-wise ones to acc_*
+template <typename T, int MAXC>
+__device__ __forceinline__ double camfc_step(RowVec<T, MAXC> &p, RowVec<T, MAXC> &q, T &bu, T &bj, T &bcreg, const T rr,
+                                             const unsigned long long pc, const int dmax, const int lane, const PipeConst<T> &h,
+                                             double &acc_reg, double &acc_ctx) {
+    T part = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) part += p.v[c] * q.v[c];
+    const T dot = pwave_sum(part);
+    T pred = h.gm;
+    pred += bu;
+    pred += bj;
+    pred += dot;
+    bool mine = false;
+    for (int d = 0; d < dmax; ++d) { // the reference adds the deviations one by one, in condition order (CAMF_C.java:98-101)
+        const int cond = (int)((pc >> (8 * d)) & 0xffull);
+        if (cond != 0xff) {
+            pred += prl(bcreg, cond);
+            mine = mine || (lane == cond);
+        }
+    }
+    const T e = rr - pred;
+    double l = (double)(e * e);
+    {
+        const T nb = bu + h.lr * (e - h.regB * bu);
+        l += (double)((h.regB * bu) * bu);
+        bu = nb;
+    }
+    {
+        const T nb = bj + h.lr * (e - h.regB * bj);
+        l += (double)((h.regB * bj) * bj);
+        bj = nb;
+    }
+    if (mine) {
+        const T bc = bcreg;
+        bcreg = bc + h.lr * (e - h.regC * bc);
+        acc_ctx += (double)bc; // plain sum, weighted by regB at the end (reference quirk, CAMF_C.java:110,115)
+    }
+    T reg_part = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const T pv = p.v[c], qv = q.v[c];
+        p.v[c] = pv + h.lr * (e * qv - h.regU * pv);
+        q.v[c] = qv + h.lr * (e * pv - h.regI * qv);
+        reg_part += (h.regU * pv) * pv + (h.regI * qv) * qv;
+    }
+    acc_reg += (double)reg_part;
+    return l;
+}
+
+template <typename T, int MAXC, bool FULL, int D>
+__global__ __launch_bounds__(64) void sgd_camfc_pipe(SgdArgs<T> a, int64_t n, double *loss_out) {
+    __shared__ RowVec<T, MAXC> h_p[D][64], h_q[D][64]; // the updated rows of the last D tuples (slot = t mod D)
+    const int lane = threadIdx.x;
+    const int k = a.k, dmax = a.dmax;
+    const HParams hp = *a.hp;
+    const PipeConst<T> h = {(T)hp.lr, (T)hp.regU, (T)hp.regI, (T)hp.regB, (T)hp.regC, (T)hp.gm};
+    T bcreg = lane < a.n_conds ? a.condBias[lane] : (T)0;
+    double loss = 0.0, acc_reg = 0.0, acc_ctx = 0.0;
+    const int64_t n_main = n & ~(int64_t)63;
+
+    // chunk staging: lane l holds tuple base + l
+    auto load_ids = [&](int64_t base, int &mu, int &mj, T &mr, unsigned long long &mc) {
+        mu = a.su[base + lane];
+        mj = a.sj[base + lane];
+        mr = a.sr[base + lane];
+        unsigned long long w = 0;
+        for (int d = 0; d < dmax; ++d) {
+            const int c = a.sconds[(base + lane) * dmax + d];
+            w |= (unsigned long long)(c < 0 ? 0xff : (c & 0xff)) << (8 * d);
+        }
+        mc = w;
+    };
+
+    if (n_main > 0) {
+        int mu, mj, mu2, mj2;
+        T mr, mr2;
+        unsigned long long mc, mc2;
+        load_ids(0, mu, mj, mr, mc);
+        RowVec<T, MAXC> pn[D], qn[D];
+        T bun[D], bjn[D];
+#pragma unroll
+        for (int s = 0; s < D; ++s) { // requests of the first D tuples
+            const int u0 = prl(mu, s), j0 = prl(mj, s);
+            pn[s] = load_row<T, MAXC, FULL>(a.P, u0, k, lane);
+            qn[s] = load_row<T, MAXC, FULL>(a.Q, j0, k, lane);
+            bun[s] = a.userBias[u0];
+            bjn[s] = a.itemBias[j0];
+        }
+        RowVec<T, MAXC> p, q;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) p.v[c] = q.v[c] = (T)0;
+        T bu = 0, bj = 0;
+        int cu = -1, cj = -1;
+        int hist_u = -1, hist_j = -1; // lane s: user / item of the tuple last processed in ring slot s
+        T hist_bu = 0, hist_bj = 0;   // lane s: its updated scalar biases
+        for (int64_t base = 0; base < n_main; base += 64) {
+            // the next chunk's ids, requested a chunk ahead and unconditionally (the last chunk re-requests itself: its look-ahead past
+            // the end then re-requests rows of this chunk, which are never used)
+            load_ids(base + 64 < n_main ? base + 64 : base, mu2, mj2, mr2, mc2);
+            auto stage = [&](const int i, const int s, const int nu, const int nj) __attribute__((always_inline)) {
+                const int uu = prl(mu, i), jj = prl(mj, i);
+                const T rr = prl(mr, i);
+                const unsigned long long pc = prl(mc, i);
+                // ---- the rows requested D tuples ago, then the request for tuple t + D into the same slot
+                const RowVec<T, MAXC> cand_p = pn[s], cand_q = qn[s];
+                const T cand_bu = bun[s], cand_bj = bjn[s];
+                pn[s] = load_row<T, MAXC, FULL>(a.P, nu, k, lane);
+                qn[s] = load_row<T, MAXC, FULL>(a.Q, nj, k, lane);
+                bun[s] = a.userBias[nu];
+                bjn[s] = a.itemBias[nj];
+                // ---- which copy is current: registers (same row as the previous tuple), the LDS ring (written by one of the last D
+                // tuples), or the requested one
+                if (uu != cu) {
+                    const unsigned long long m = __ballot(hist_u == uu) & ((1ull << D) - 1);
+                    if (m) { // newest writer: ages 1..D <-> slots s-1, s-2, ..., s-D (mod D)
+                        int slot = 0;
+#pragma unroll
+                        for (int age = D; age >= 1; --age) {
+                            const int sl = ((s - age) % D + D) % D;
+                            if ((m >> sl) & 1ull) slot = sl;
+                        }
+                        p = h_p[slot][lane];
+                        bu = prl(hist_bu, slot);
+                    } else {
+                        p = cand_p;
+                        bu = cand_bu;
+                    }
+                }
+                if (jj != cj) {
+                    const unsigned long long m = __ballot(hist_j == jj) & ((1ull << D) - 1);
+                    if (m) {
+                        int slot = 0;
+#pragma unroll
+                        for (int age = D; age >= 1; --age) {
+                            const int sl = ((s - age) % D + D) % D;
+                            if ((m >> sl) & 1ull) slot = sl;
+                        }
+                        q = h_q[slot][lane];
+                        bj = prl(hist_bj, slot);
+                    } else {
+                        q = cand_q;
+                        bj = cand_bj;
+                    }
+                }
+                cu = uu;
+                cj = jj;
+                loss += camfc_step<T, MAXC>(p, q, bu, bj, bcreg, rr, pc, dmax, lane, h, acc_reg, acc_ctx);
+                // ---- publish: HBM, the LDS ring, the id / bias history
+                store_row<T, MAXC, FULL>(a.P, uu, k, lane, p);
+                store_row<T, MAXC, FULL>(a.Q, jj, k, lane, q);
+                a.userBias[uu] = bu; // every lane stores the same value to the same word: no branch in the loop
+                a.itemBias[jj] = bj;
+                h_p[s][lane] = p;
+                h_q[s][lane] = q;
+                hist_u = pwl(hist_u, uu, s, lane);
+                hist_j = pwl(hist_j, jj, s, lane);
+                hist_bu = pwl(hist_bu, bu, s, lane);
+                hist_bj = pwl(hist_bj, bj, s, lane);
+
+            };
+            // rounds of D tuples; all but the last round of a chunk look ahead inside the chunk, the last one into the next chunk's ids
+            // (peeled, so that the next chunk's id request is first touched 64 - D tuples after it was issued)
+            for (int i0 = 0; i0 < 64 - D; i0 += D) {
+#pragma unroll
+                for (int s = 0; s < D; ++s) stage(i0 + s, s, prl(mu, i0 + s + D), prl(mj, i0 + s + D));
+            }
+#pragma unroll
+            for (int s = 0; s < D; ++s) stage(64 - D + s, s, prl(mu2, s), prl(mj2, s));
+            mu = mu2;
+            mj = mj2;
+            mr = mr2;
+            mc = mc2;
+        }
+    }
+    // ---- the last n mod 64 tuples: request after the previous tuple's stores, one by one
+    for (int64_t t = n_main; t < n; ++t) {
+        const int uu = a.su[t], jj = a.sj[t];
+        const T rr = a.sr[t];
+        unsigned long long pc = 0;
+        for (int d = 0; d < dmax; ++d) {
+            const int c = a.sconds[t * dmax + d];
+            pc |= (unsigned long long)(c < 0 ? 0xff : (c & 0xff)) << (8 * d);
+        }
+        RowVec<T, MAXC> p = load_row<T, MAXC, FULL>(a.P, uu, k, lane), q = load_row<T, MAXC, FULL>(a.Q, jj, k, lane);
+        T bu = a.userBias[uu], bj = a.itemBias[jj];
+        loss += camfc_step<T, MAXC>(p, q, bu, bj, bcreg, rr, pc, dmax, lane, h, acc_reg, acc_ctx);
+        store_row<T, MAXC, FULL>(a.P, uu, k, lane, p);
+        store_row<T, MAXC, FULL>(a.Q, jj, k, lane, q);
+        a.userBias[uu] = bu;
+        a.itemBias[jj] = bj;
+    }
+    if (lane < a.n_conds) a.condBias[lane] = bcreg;
+    loss += pwave_sum(acc_reg) + (double)h.regB * pwave_sum(acc_ctx);
+    if (lane == 0) loss_out[0] = loss * 0.5;
+}
+
+} // namespace
+
+// <= 64 conditions (one per lane), <= 8 context dimensions (one byte each in the packed word), k <= 256
+bool camfc_pipe_supported(int k, int n_conds, int dmax) { return k >= 1 && k <= 256 && n_conds <= 64 && dmax <= 8 && !getenv("CMI_NO_CAMFC_PIPE"); }
+
+template <typename T>
+hipError_t launch_camfc_pipe(const SgdArgs<T> &a, int64_t n, double *loss_out, hipStream_t s) {
+    const int k = a.k;
+    // ring depth: the requests of tuple t are the oldest of 4 * rowops + ... outstanding operations when they are consumed; the
+    // hardware counts 64 of them, so D * (2 * rowops + 2) * 2 stays below that
+    // (D divides the 64-tuple chunk)
+    if (k == 64) hipLaunchKernelGGL((sgd_camfc_pipe<T, 1, true, 8>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else if (k == 128) hipLaunchKernelGGL((sgd_camfc_pipe<T, 2, true, 8>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else if (k == 256) hipLaunchKernelGGL((sgd_camfc_pipe<T, 4, true, sizeof(T) == 8 ? 4 : 8>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else if (k < 64) hipLaunchKernelGGL((sgd_camfc_pipe<T, 1, false, 8>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else if (k < 128) hipLaunchKernelGGL((sgd_camfc_pipe<T, 2, false, 4>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else hipLaunchKernelGGL((sgd_camfc_pipe<T, 4, false, 2>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    return hipGetLastError();
+}
+template hipError_t launch_camfc_pipe<float>(const SgdArgs<float> &, int64_t, double *, hipStream_t);
+template hipError_t launch_camfc_pipe<double>(const SgdArgs<double> &, int64_t, double *, hipStream_t);
+
+} // namespace cmi

@@ -1637,7 +1637,11 @@ __device__ __forceinline__ double group_sum_t(double x) {
 template <int W>
 __device__ __forceinline__ float group_sum_t(float x) { return group_sum<W>(x); }
 
-template <typename T, int NV>
+// RC ("register chain", n_conds <= 64 and dmax <= 8): phase B without an LDS round trip per link -- lane c of wave 0 owns condBias[c],
+// lane t holds tuple t's base, rating and its condition ids packed one byte each; a link is readlanes, adds and one masked update
+// (0.34 -> 0.1x us per tuple at 28-56 tuples per block, tools/camfc_paths_bench.py).  RC also requests the NEXT block's tuple ids while
+// this block's updates are written, so phase A starts with the row gather instead of a dependent id load.
+template <typename T, int NV, bool RC>
 __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int32_t *__restrict__ blk_off, int n_blocks,
                                                          double *loss_out) {
     extern __shared__ unsigned char smem_raw[];
@@ -1651,8 +1655,30 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
     const HParams hp = *a.hp;
     const T lr = (T)hp.lr, regU = (T)hp.regU, regI = (T)hp.regI, regB = (T)hp.regB, regC = (T)hp.regC, gm = (T)hp.gm;
     for (int c = tid; c < a.n_conds; c += 1024) s_bc[c] = a.condBias[c];
+    T bcreg = (RC && tid < a.n_conds) ? a.condBias[tid] : (T)0; // RC: wave 0, lane c = condBias[c]
     double gloss = 0.0;  // groups: e^2-free parts (biases, factors); wave 0 lane 0: e^2 and the condBias term
     int b0 = blk_off[0];
+    // RC: ids of the block about to run, requested one block ahead (group g: its tuple's user / item; wave 0 lane t: rating + conditions)
+    int uu_n = 0, jj_n = 0;
+    T r_n = 0;
+    unsigned long long pc_n = 0;
+    auto request_ids = [&](int lo, int hi) {
+        if (g < hi - lo) {
+            uu_n = a.su[(int64_t)lo + g];
+            jj_n = a.sj[(int64_t)lo + g];
+        }
+        if (tid < hi - lo) {
+            const int64_t t = (int64_t)lo + tid;
+            r_n = a.sr[t];
+            unsigned long long w = 0;
+            for (int d = 0; d < dmax; ++d) {
+                const int c = a.sconds[t * dmax + d];
+                w |= (unsigned long long)(c < 0 ? 0xff : (c & 0xff)) << (8 * d);
+            }
+            pc_n = w;
+        }
+    };
+    if (RC && n_blocks > 0) request_ids(b0, blk_off[1]);
     __syncthreads();
     for (int blk = 0; blk < n_blocks; ++blk) {
         const int b1 = blk_off[blk + 1];
@@ -1663,12 +1689,19 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
         T p[NV], q[NV], bu = 0, bj = 0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) p[i] = q[i] = 0;
+        const T my_r = r_n;                    // RC, wave 0: lane t = tuple t of this block
+        const unsigned long long my_pc = pc_n;
         if (live) {
             const int64_t t = (int64_t)b0 + g;
-            uu = a.su[t];
-            jj = a.sj[t];
-            if (l16 < dmax) s_conds[g * dmax + l16] = a.sconds[t * dmax + l16];
-            if (l16 == 0) s_r[g] = a.sr[t];
+            if (RC) {
+                uu = uu_n;
+                jj = jj_n;
+            } else {
+                uu = a.su[t];
+                jj = a.sj[t];
+                if (l16 < dmax) s_conds[g * dmax + l16] = a.sconds[t * dmax + l16];
+                if (l16 == 0) s_r[g] = a.sr[t];
+            }
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int f = l16 + 16 * i;
@@ -1686,7 +1719,37 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
         const T dot = group_sum_t<16>(part);
         if (live && l16 == 0) s_base[g] = ((gm + bu) + bj) + dot;
         __syncthreads();
-        // ---- B: the scalar chain, wave 0, CRS order; lane d owns the tuple's d-th condition
+        // ---- B: the scalar chain, wave 0, CRS order
+        if (RC) {
+            if (tid < 64) {
+                const T vbase = tid < cnt ? s_base[tid] : (T)0;
+                T ve = 0;
+                double lacc = 0.0;
+                for (int t = 0; t < cnt; ++t) {
+                    T pred = rl(vbase, t);
+                    const unsigned long long pc = ((unsigned long long)(unsigned)rl((int)(unsigned)(my_pc >> 32), t) << 32) |
+                                                  (unsigned)rl((int)(unsigned)my_pc, t);
+                    T bc_sum = 0;
+                    bool mine = false;
+                    for (int d = 0; d < dmax; ++d) { // the reference adds the deviations one by one, in condition order
+                        const int cond = (int)((pc >> (8 * d)) & 0xffull);
+                        if (cond != 0xff) {
+                            const T v = rl(bcreg, cond);
+                            pred += v;
+                            bc_sum += v; // plain sum, weighted by regB: reference quirk (CAMF_C.java:110,115)
+                            mine = mine || (tid == cond);
+                        }
+                    }
+                    const T e = rl(my_r, t) - pred;
+                    if (mine) bcreg = bcreg + lr * (e - regC * bcreg);
+                    if (tid == t) ve = e;
+                    lacc += (double)(e * e) + (double)(regB * bc_sum);
+                }
+                if (tid < cnt) s_base[tid] = ve; // base_t is consumed: the slot now carries e_t for phase C
+                if (tid == 0) gloss += lacc;
+            }
+        } else
+        // (LDS chain) lane d owns the tuple's d-th condition
         if (tid < 64) {
             double l = 0.0;
             for (int t = 0; t < cnt; ++t) {
@@ -1732,12 +1795,16 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
                 gloss += (double)((regB * bu) * bu) + (double)((regB * bj) * bj) + (double)reg_sum;
             }
         }
+        if (RC && blk + 1 < n_blocks) request_ids(b1, blk_off[blk + 2]);
         b0 = b1;
         __syncthreads(); // this block's rows are visible (workgroup scope) before the next block gathers
     }
     if (l16 == 0) s_loss[g] = gloss;
     __syncthreads();
-    for (int c = tid; c < a.n_conds; c += 1024) a.condBias[c] = s_bc[c];
+    if (RC) {
+        if (tid < a.n_conds) a.condBias[tid] = bcreg;
+    } else
+        for (int c = tid; c < a.n_conds; c += 1024) a.condBias[c] = s_bc[c];
     if (tid == 0) {
         double sum = 0.0;
         for (int i = 0; i < 64; ++i) sum += s_loss[i];
@@ -1752,9 +1819,15 @@ size_t camfc_blocks_lds(int n_conds, int dmax, size_t esize) {
 template <typename T>
 hipError_t launch_camfc_blocks(const SgdArgs<T> &a, const int32_t *blk_off, int n_blocks, double *loss_out, hipStream_t s) {
     const size_t lds = camfc_blocks_lds(a.n_conds, a.dmax, sizeof(T));
-    if (a.k <= 64) hipLaunchKernelGGL((sgd_camfc_blocks<T, 4>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
-    else if (a.k <= 128) hipLaunchKernelGGL((sgd_camfc_blocks<T, 8>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
-    else hipLaunchKernelGGL((sgd_camfc_blocks<T, 16>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
+    if (a.n_conds <= 64 && a.dmax <= 8 && !getenv("CMI_CAMFC_LDS_CHAIN")) {
+        if (a.k <= 64) hipLaunchKernelGGL((sgd_camfc_blocks<T, 4, true>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
+        else if (a.k <= 128) hipLaunchKernelGGL((sgd_camfc_blocks<T, 8, true>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
+        else hipLaunchKernelGGL((sgd_camfc_blocks<T, 16, true>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
+        return hipGetLastError();
+    }
+    if (a.k <= 64) hipLaunchKernelGGL((sgd_camfc_blocks<T, 4, false>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
+    else if (a.k <= 128) hipLaunchKernelGGL((sgd_camfc_blocks<T, 8, false>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
+    else hipLaunchKernelGGL((sgd_camfc_blocks<T, 16, false>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
     return hipGetLastError();
 }
 template hipError_t launch_camfc_blocks<float>(const SgdArgs<float> &, const int32_t *, int, double *, hipStream_t);
@@ -1766,6 +1839,8 @@ static hipError_t launch_serial_model(const SgdArgs<T> &a, const LaunchCfg &cfg,
     const size_t lds = (MODEL == CAMF_C ? (size_t)a.n_conds * sizeof(T) : 0) + (size_t)64 * a.dmax * sizeof(int32_t) + 16;
     if (cfg.strict)
         hipLaunchKernelGGL((sgd_serial<T, MODEL, true>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else if (MODEL == CAMF_C && camfc_pipe_supported(a.k, a.n_conds, a.dmax))
+        return launch_camfc_pipe<T>(a, n, loss_out, s);
     else if (a.k <= 256 && lds <= 64 * 1024 && !getenv("CMI_SERIAL_GENERIC")) {
         if (a.k == 64) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 1, true>), dim3(1), dim3(64), lds, s, a, n, loss_out);
         else if (a.k == 128) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 2, true>), dim3(1), dim3(64), lds, s, a, n, loss_out);

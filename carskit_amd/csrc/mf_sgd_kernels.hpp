@@ -42,6 +42,11 @@ hipError_t launch_arena_scatter(const T *table, T *arena, const int32_t *first_p
 template <typename T>
 hipError_t launch_arena_gather(T *table, const T *arena, const int32_t *first_pos, int64_t n_rows, int k, hipStream_t s);
 
+// CAMF_C as one software-pipelined wave (camfc_pipe.hip): rows of tuple t + D requested while tuple t is computed
+bool camfc_pipe_supported(int k, int n_conds, int dmax);
+template <typename T>
+hipError_t launch_camfc_pipe(const SgdArgs<T> &a, int64_t n, double *loss_out, hipStream_t s);
+
 struct LaunchCfg {
     int model;
     bool strict; // left-to-right dot (DenseMatrix.rowMult order) + reference loss order

@@ -1,0 +1,96 @@
+"""CAMF_C as one software-pipelined wave (carskit_amd/csrc/camfc_pipe.hip): rows requested D tuples ahead, stale requests replaced from
+an LDS ring of the last D tuples' rows.  Order-exact like every CAMF_C path; the dot is a tree sum, so fp64 state agrees with the
+sequential oracle to rounding and fp32 state within the north_star tolerance.  The cases force what the pipeline has to get right:
+hazards (few items / few users: a requested row rewritten by one of the D tuples in between), user-sorted input (forwarding from
+registers), n not a multiple of the 64-tuple chunk, n < 64, every k bucket (masked and full rows), missing conditions."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+
+from carskit_amd import capi, synth
+from tests import util
+from tests.test_gpu_parity import assert_state_equal, make_pair
+
+pytestmark = pytest.mark.gpu
+SERIAL, F64 = capi.FLAG_SCHED_SERIAL, capi.FLAG_STATE_F64
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _run(data, k, flags, epochs=4):
+    # CMI_NO_CAMFC_BLOCKS: the conflict-free-block path would take over on unsorted data; here the serial wave is under test
+    def go():
+        orc, inst = make_pair("CAMF_C", data, k, SERIAL | flags)
+        assert inst.schedule_info()["flow_blocks"] == 0
+        o_losses, o_lrs, _ = orc.build_model(epochs, util.LR, bold_driver=True)
+        g_losses, g_lrs = inst.train(epochs, util.LR, bold_driver=True)
+        return orc, inst, o_losses, o_lrs, g_losses, g_lrs
+    return _with_env({"CMI_NO_CAMFC_BLOCKS": "1", "CMI_NO_CAMFC_PIPE": None}, go)
+
+
+@pytest.mark.parametrize("k", [1, 10, 63, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("flags", [0, F64])
+def test_pipe_matches_the_sequential_oracle(k, flags):
+    data = util.small_data(n_users=300, n_items=120, n_dims=3, conds_per_dim=4, n=5000 + k, seed=40 + k)
+    orc, inst, o_losses, o_lrs, g_losses, g_lrs = _run(data, k, flags)
+    assert g_lrs.tolist() == o_lrs.tolist()
+    np.testing.assert_allclose(g_losses, o_losses, rtol=1e-11 if flags else 3e-5)
+    assert_state_equal(orc, inst, exact=False, atol=1e-10 if flags else 3e-4)
+
+
+@pytest.mark.parametrize("n_users,n_items,n", [(5, 4, 3000), (3, 200, 2500), (200, 3, 2500), (64, 64, 4096), (2, 2, 700)])
+def test_hazards_a_requested_row_rewritten_before_it_is_used(n_users, n_items, n):
+    """few users / items: almost every tuple's row was written by one of the D tuples since its request went out"""
+    data = util.small_data(n_users=n_users, n_items=n_items, n_dims=2, conds_per_dim=3, n=n, seed=7 + n_users)
+    for flags in (F64, 0):
+        orc, inst, o_losses, o_lrs, g_losses, g_lrs = _run(data, 64, flags, epochs=3)
+        np.testing.assert_allclose(g_losses, o_losses, rtol=1e-11 if flags else 3e-5)
+        assert_state_equal(orc, inst, exact=False, atol=1e-10 if flags else 3e-4)
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 127, 128, 200])
+def test_chunk_boundaries(n):
+    data = util.small_data(n_users=30, n_items=20, n_dims=2, conds_per_dim=3, n=n, seed=90 + n)
+    orc, inst, o_losses, _, g_losses, _ = _run(data, 16, F64, epochs=3)
+    np.testing.assert_allclose(g_losses, o_losses, rtol=1e-11)
+    assert_state_equal(orc, inst, exact=False, atol=1e-11)
+
+
+def test_user_sorted_input_and_missing_conditions():
+    data = util.small_data(n_users=40, n_items=300, n_dims=4, conds_per_dim=3, n=3000, seed=34)
+    order = np.lexsort((data.j, data.u))
+    srt = dataclasses.replace(data, u=data.u[order], j=data.j[order], ctx=data.ctx[order], r=data.r[order])
+    orc, inst, o_losses, _, g_losses, _ = _run(srt, 128, F64, epochs=3)
+    np.testing.assert_allclose(g_losses, o_losses, rtol=1e-11)
+    assert_state_equal(orc, inst, exact=False, atol=1e-10)
+
+
+def test_pipe_and_the_one_ahead_wave_agree():
+    """same data through sgd_serial_fast (CMI_NO_CAMFC_PIPE): both are tree-sum kernels over the same order"""
+    data = util.small_data(n_users=150, n_items=60, n_dims=3, conds_per_dim=3, n=4000, seed=3)
+    _, a, _, _, la, _ = _run(data, 64, 0, epochs=3)
+
+    def old():
+        orc, inst = make_pair("CAMF_C", data, 64, SERIAL)
+        return inst, inst.train(3, util.LR, bold_driver=True)[0]
+    b, lb = _with_env({"CMI_NO_CAMFC_BLOCKS": "1", "CMI_NO_CAMFC_PIPE": "1"}, old)
+    np.testing.assert_allclose(la, lb, rtol=2e-5)
+    for name, x in a.get_states().items():
+        assert np.max(np.abs(x - b.get_state(name))) <= 2e-4, name
