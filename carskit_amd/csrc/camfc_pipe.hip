@@ -106,11 +106,14 @@ struct PipeConst {
     T lr, regU, regI, regB, regC, gm;
 };
 
-// one CAMF_C update on rows held in registers; returns the tuple's loss terms that are uniform, adds the lane-wise ones to acc_*
-template <typename T, int MAXC>
-__device__ __forceinline__ double camfc_step(RowVec<T, MAXC> &p, RowVec<T, MAXC> &q, T &bu, T &bj, T &bcreg, const T rr,
-                                             const unsigned long long pc, const int dmax, const int lane, const PipeConst<T> &h,
-                                             double &acc_reg, double &acc_ctx) {
+// One CAMF_C update on rows held in registers.  On ONE wave a link costs what its dependent instructions cost -- about 8-10 cycles per
+// dependent VALU operation, 20 per v_readlane and per taken branch (tools/micro/one_wave_clock.hip) -- so DM, the number of context
+// dimensions, is a template parameter (no inner loop; an absent condition, 0xff, contributes an exact +0) and the tuple's uniform loss
+// terms are returned as ONE float that the caller parks in a lane; they are summed in double once per 64 tuples.
+template <typename T, int MAXC, int DM>
+__device__ __forceinline__ T camfc_step_dm(RowVec<T, MAXC> &p, RowVec<T, MAXC> &q, T &bu, T &bj, T &bcreg, const T rr,
+                                           const unsigned long long pc, const int lane, const PipeConst<T> &h, double &acc_reg,
+                                           double &acc_ctx) {
     T part = 0;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) part += p.v[c] * q.v[c];
@@ -119,30 +122,32 @@ __device__ __forceinline__ double camfc_step(RowVec<T, MAXC> &p, RowVec<T, MAXC>
     pred += bu;
     pred += bj;
     pred += dot;
+    const unsigned lo = (unsigned)pc, hi = (unsigned)(pc >> 32);
+    const T decay = h.regC * bcreg;
     bool mine = false;
-    for (int d = 0; d < dmax; ++d) { // the reference adds the deviations one by one, in condition order (CAMF_C.java:98-101)
-        const int cond = (int)((pc >> (8 * d)) & 0xffull);
-        if (cond != 0xff) {
-            pred += prl(bcreg, cond);
-            mine = mine || (lane == cond);
-        }
+#pragma unroll
+    for (int d = 0; d < DM; ++d) { // the reference adds the deviations one by one, in condition order (CAMF_C.java:98-101)
+        const unsigned cond = (d < 4 ? lo >> (8 * d) : hi >> (8 * (d - 4))) & 0xffu;
+        const bool present = cond != 0xffu;
+        const T got = prl(bcreg, (int)(cond & 63u));
+        pred += present ? got : (T)0;
+        mine = mine || (present && lane == (int)cond);
     }
     const T e = rr - pred;
-    double l = (double)(e * e);
+    T l = e * e;
     {
         const T nb = bu + h.lr * (e - h.regB * bu);
-        l += (double)((h.regB * bu) * bu);
+        l += (h.regB * bu) * bu;
         bu = nb;
     }
     {
         const T nb = bj + h.lr * (e - h.regB * bj);
-        l += (double)((h.regB * bj) * bj);
+        l += (h.regB * bj) * bj;
         bj = nb;
     }
     if (mine) {
-        const T bc = bcreg;
-        bcreg = bc + h.lr * (e - h.regC * bc);
-        acc_ctx += (double)bc; // plain sum, weighted by regB at the end (reference quirk, CAMF_C.java:110,115)
+        acc_ctx += (double)bcreg; // plain sum, weighted by regB at the end (reference quirk, CAMF_C.java:110,115)
+        bcreg = bcreg + h.lr * (e - decay);
     }
     T reg_part = 0;
 #pragma unroll
@@ -154,6 +159,21 @@ __device__ __forceinline__ double camfc_step(RowVec<T, MAXC> &p, RowVec<T, MAXC>
     }
     acc_reg += (double)reg_part;
     return l;
+}
+template <typename T, int MAXC>
+__device__ __forceinline__ T camfc_step(RowVec<T, MAXC> &p, RowVec<T, MAXC> &q, T &bu, T &bj, T &bcreg, const T rr,
+                                        const unsigned long long pc, const int dmax, const int lane, const PipeConst<T> &h,
+                                        double &acc_reg, double &acc_ctx) {
+    switch (dmax) {
+    case 1: return camfc_step_dm<T, MAXC, 1>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
+    case 2: return camfc_step_dm<T, MAXC, 2>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
+    case 3: return camfc_step_dm<T, MAXC, 3>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
+    case 4: return camfc_step_dm<T, MAXC, 4>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
+    case 5: return camfc_step_dm<T, MAXC, 5>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
+    case 6: return camfc_step_dm<T, MAXC, 6>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
+    case 7: return camfc_step_dm<T, MAXC, 7>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
+    default: return camfc_step_dm<T, MAXC, 8>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
+    }
 }
 
 template <typename T, int MAXC, bool FULL, int D>
@@ -206,6 +226,7 @@ __global__ __launch_bounds__(64) void sgd_camfc_pipe(SgdArgs<T> a, int64_t n, do
             // the next chunk's ids, requested a chunk ahead and unconditionally (the last chunk re-requests itself: its look-ahead past
             // the end then re-requests rows of this chunk, which are never used)
             load_ids(base + 64 < n_main ? base + 64 : base, mu2, mj2, mr2, mc2);
+            T vl = 0; // lane i: the uniform loss terms of the chunk's tuple i
             auto stage = [&](const int i, const int s, const int nu, const int nj) __attribute__((always_inline)) {
                 const int uu = prl(mu, i), jj = prl(mj, i);
                 const T rr = prl(mr, i);
@@ -253,7 +274,8 @@ __global__ __launch_bounds__(64) void sgd_camfc_pipe(SgdArgs<T> a, int64_t n, do
                 }
                 cu = uu;
                 cj = jj;
-                loss += camfc_step<T, MAXC>(p, q, bu, bj, bcreg, rr, pc, dmax, lane, h, acc_reg, acc_ctx);
+                const T l_t = camfc_step<T, MAXC>(p, q, bu, bj, bcreg, rr, pc, dmax, lane, h, acc_reg, acc_ctx);
+                vl = lane == i ? l_t : vl;
                 // ---- publish: HBM, the LDS ring, the id / bias history
                 store_row<T, MAXC, FULL>(a.P, uu, k, lane, p);
                 store_row<T, MAXC, FULL>(a.Q, jj, k, lane, q);
@@ -275,6 +297,7 @@ __global__ __launch_bounds__(64) void sgd_camfc_pipe(SgdArgs<T> a, int64_t n, do
             }
 #pragma unroll
             for (int s = 0; s < D; ++s) stage(64 - D + s, s, prl(mu2, s), prl(mj2, s));
+            loss += pwave_sum((double)vl);
             mu = mu2;
             mj = mj2;
             mr = mr2;
@@ -292,7 +315,7 @@ __global__ __launch_bounds__(64) void sgd_camfc_pipe(SgdArgs<T> a, int64_t n, do
         }
         RowVec<T, MAXC> p = load_row<T, MAXC, FULL>(a.P, uu, k, lane), q = load_row<T, MAXC, FULL>(a.Q, jj, k, lane);
         T bu = a.userBias[uu], bj = a.itemBias[jj];
-        loss += camfc_step<T, MAXC>(p, q, bu, bj, bcreg, rr, pc, dmax, lane, h, acc_reg, acc_ctx);
+        loss += (double)camfc_step<T, MAXC>(p, q, bu, bj, bcreg, rr, pc, dmax, lane, h, acc_reg, acc_ctx);
         store_row<T, MAXC, FULL>(a.P, uu, k, lane, p);
         store_row<T, MAXC, FULL>(a.Q, jj, k, lane, q);
         a.userBias[uu] = bu;

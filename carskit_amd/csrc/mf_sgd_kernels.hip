@@ -1637,6 +1637,41 @@ __device__ __forceinline__ double group_sum_t(double x) {
 template <int W>
 __device__ __forceinline__ float group_sum_t(float x) { return group_sum<W>(x); }
 
+// One link of CAMF_C's condBias chain costs what its dependent instructions cost on ONE wave: about 8-10 cycles per dependent VALU
+// operation, 20 per v_readlane and per taken branch (tools/micro/one_wave_clock.hip: 2.39 GHz, 40 cycles for two dependent VALU ops + the
+// loop branch).  So the link is written with as few of each as the arithmetic allows: DM (the number of context dimensions) is a template
+// parameter -- no inner loop --, absent conditions (0xff) contribute an exact +0, and the loss terms are left in lanes (ve, vbs) and summed
+// once per block.
+template <typename T, int DM>
+__device__ __forceinline__ void camfc_rc_chain(const int cnt, const int tid, const T vbase, const T my_r, const unsigned long long my_pc,
+                                               T &bcreg, T &ve, T &vbs, const T lr, const T regC) {
+    const int pc_lo = (int)(unsigned)my_pc, pc_hi = (int)(unsigned)(my_pc >> 32);
+    for (int t = 0; t < cnt; ++t) {
+        T pred = rl(vbase, t);
+        const T rr = rl(my_r, t);
+        const unsigned lo = (unsigned)rl(pc_lo, t), hi = DM > 4 ? (unsigned)rl(pc_hi, t) : 0u;
+        const T decay = regC * bcreg; // does not depend on this link's error
+        T bc_sum = 0;
+        bool mine = false;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) { // the reference adds the deviations one by one, in condition order
+            const unsigned cond = ((d < 4 ? lo >> (8 * d) : hi >> (8 * (d - 4))) & 0xffu);
+            const bool present = cond != 0xffu;
+            const T got = rl(bcreg, (int)(cond & 63u));
+            const T v = present ? got : (T)0;
+            pred += v;
+            bc_sum += v;
+            mine = mine || (present && tid == (int)cond);
+        }
+        const T e = rr - pred;
+        if (mine) bcreg = bcreg + lr * (e - decay);
+        if (tid == t) {
+            ve = e;
+            vbs = bc_sum;
+        }
+    }
+}
+
 // RC ("register chain", n_conds <= 64 and dmax <= 8): phase B without an LDS round trip per link -- lane c of wave 0 owns condBias[c],
 // lane t holds tuple t's base, rating and its condition ids packed one byte each; a link is readlanes, adds and one masked update
 // (0.34 -> 0.1x us per tuple at 28-56 tuples per block, tools/camfc_paths_bench.py).  RC also requests the NEXT block's tuple ids while
@@ -1723,30 +1758,21 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
         if (RC) {
             if (tid < 64) {
                 const T vbase = tid < cnt ? s_base[tid] : (T)0;
-                T ve = 0;
-                double lacc = 0.0;
-                for (int t = 0; t < cnt; ++t) {
-                    T pred = rl(vbase, t);
-                    const unsigned long long pc = ((unsigned long long)(unsigned)rl((int)(unsigned)(my_pc >> 32), t) << 32) |
-                                                  (unsigned)rl((int)(unsigned)my_pc, t);
-                    T bc_sum = 0;
-                    bool mine = false;
-                    for (int d = 0; d < dmax; ++d) { // the reference adds the deviations one by one, in condition order
-                        const int cond = (int)((pc >> (8 * d)) & 0xffull);
-                        if (cond != 0xff) {
-                            const T v = rl(bcreg, cond);
-                            pred += v;
-                            bc_sum += v; // plain sum, weighted by regB: reference quirk (CAMF_C.java:110,115)
-                            mine = mine || (tid == cond);
-                        }
-                    }
-                    const T e = rl(my_r, t) - pred;
-                    if (mine) bcreg = bcreg + lr * (e - regC * bcreg);
-                    if (tid == t) ve = e;
-                    lacc += (double)(e * e) + (double)(regB * bc_sum);
+                T ve = 0, vbs = 0; // lane t: e_t and the plain sum of tuple t's condBias entries (reference quirk, CAMF_C.java:110,115)
+                switch (dmax) {
+                case 1: camfc_rc_chain<T, 1>(cnt, tid, vbase, my_r, my_pc, bcreg, ve, vbs, lr, regC); break;
+                case 2: camfc_rc_chain<T, 2>(cnt, tid, vbase, my_r, my_pc, bcreg, ve, vbs, lr, regC); break;
+                case 3: camfc_rc_chain<T, 3>(cnt, tid, vbase, my_r, my_pc, bcreg, ve, vbs, lr, regC); break;
+                case 4: camfc_rc_chain<T, 4>(cnt, tid, vbase, my_r, my_pc, bcreg, ve, vbs, lr, regC); break;
+                case 5: camfc_rc_chain<T, 5>(cnt, tid, vbase, my_r, my_pc, bcreg, ve, vbs, lr, regC); break;
+                case 6: camfc_rc_chain<T, 6>(cnt, tid, vbase, my_r, my_pc, bcreg, ve, vbs, lr, regC); break;
+                case 7: camfc_rc_chain<T, 7>(cnt, tid, vbase, my_r, my_pc, bcreg, ve, vbs, lr, regC); break;
+                default: camfc_rc_chain<T, 8>(cnt, tid, vbase, my_r, my_pc, bcreg, ve, vbs, lr, regC); break;
                 }
                 if (tid < cnt) s_base[tid] = ve; // base_t is consumed: the slot now carries e_t for phase C
-                if (tid == 0) gloss += lacc;
+                // the block's loss terms, once per block instead of once per link
+                const double lsum = wave_sum_dpp(tid < cnt ? (double)(ve * ve) + (double)(regB * vbs) : 0.0);
+                if (tid == 0) gloss += lsum;
             }
         } else
         // (LDS chain) lane d owns the tuple's d-th condition
