@@ -1672,11 +1672,43 @@ __device__ __forceinline__ void camfc_rc_chain(const int cnt, const int tid, con
     }
 }
 
+// The same link with condBias in LDS (any number of conditions; Frappe: 343): lane d reads the entry of the tuple's d-th condition
+// (ONE ds_read, 56 cycles of round trip), the entries are taken to the scalar side with DM readlanes issued back to back and added in
+// condition order; the tuple's condition ids were staged in LDS by phase A and the next tuple's are read one link ahead.
+template <typename T, int DM>
+__device__ __forceinline__ void camfc_lds_chain(const int cnt, const int tid, const T vbase, const T my_r, const int32_t *s_conds, T *s_bc,
+                                                T &ve, T &vbs, const T lr, const T regC) {
+    int cond_next = (tid < DM && cnt > 0) ? s_conds[tid] : -1;
+    for (int t = 0; t < cnt; ++t) {
+        const int cond = cond_next;
+        const int tn = t + 1 < cnt ? t + 1 : t;
+        cond_next = tid < DM ? s_conds[tn * DM + tid] : -1;
+        const T bc = cond >= 0 ? s_bc[cond] : (T)0;
+        T pred = rl(vbase, t);
+        const T rr = rl(my_r, t);
+        T got[DM];
+#pragma unroll
+        for (int d = 0; d < DM; ++d) got[d] = rl(bc, d); // an absent condition left 0 in its lane: an exact +0 below
+        T bc_sum = 0;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) { // the reference adds the deviations one by one, in condition order
+            pred += got[d];
+            bc_sum += got[d];
+        }
+        const T e = rr - pred;
+        if (cond >= 0) s_bc[cond] = bc + lr * (e - regC * bc);
+        if (tid == t) {
+            ve = e;
+            vbs = bc_sum;
+        }
+    }
+}
+
 // RC ("register chain", n_conds <= 64 and dmax <= 8): phase B without an LDS round trip per link -- lane c of wave 0 owns condBias[c],
 // lane t holds tuple t's base, rating and its condition ids packed one byte each; a link is readlanes, adds and one masked update
 // (0.34 -> 0.1x us per tuple at 28-56 tuples per block, tools/camfc_paths_bench.py).  RC also requests the NEXT block's tuple ids while
 // this block's updates are written, so phase A starts with the row gather instead of a dependent id load.
-template <typename T, int NV, bool RC>
+template <typename T, int NV, int CH> // CH: 0 = the round-2 LDS chain, 1 = register chain (RC), 2 = lean LDS chain (any n_conds, dmax <= 8)
 __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int32_t *__restrict__ blk_off, int n_blocks,
                                                          double *loss_out) {
     extern __shared__ unsigned char smem_raw[];
@@ -1690,6 +1722,7 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
     const HParams hp = *a.hp;
     const T lr = (T)hp.lr, regU = (T)hp.regU, regI = (T)hp.regI, regB = (T)hp.regB, regC = (T)hp.regC, gm = (T)hp.gm;
     for (int c = tid; c < a.n_conds; c += 1024) s_bc[c] = a.condBias[c];
+    constexpr bool RC = CH == 1, AHEAD = CH >= 1;
     T bcreg = (RC && tid < a.n_conds) ? a.condBias[tid] : (T)0; // RC: wave 0, lane c = condBias[c]
     double gloss = 0.0;  // groups: e^2-free parts (biases, factors); wave 0 lane 0: e^2 and the condBias term
     int b0 = blk_off[0];
@@ -1705,15 +1738,17 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
         if (tid < hi - lo) {
             const int64_t t = (int64_t)lo + tid;
             r_n = a.sr[t];
-            unsigned long long w = 0;
-            for (int d = 0; d < dmax; ++d) {
-                const int c = a.sconds[t * dmax + d];
-                w |= (unsigned long long)(c < 0 ? 0xff : (c & 0xff)) << (8 * d);
+            if (RC) {
+                unsigned long long w = 0;
+                for (int d = 0; d < dmax; ++d) {
+                    const int c = a.sconds[t * dmax + d];
+                    w |= (unsigned long long)(c < 0 ? 0xff : (c & 0xff)) << (8 * d);
+                }
+                pc_n = w;
             }
-            pc_n = w;
         }
     };
-    if (RC && n_blocks > 0) request_ids(b0, blk_off[1]);
+    if (AHEAD && n_blocks > 0) request_ids(b0, blk_off[1]);
     __syncthreads();
     for (int blk = 0; blk < n_blocks; ++blk) {
         const int b1 = blk_off[blk + 1];
@@ -1728,9 +1763,10 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
         const unsigned long long my_pc = pc_n;
         if (live) {
             const int64_t t = (int64_t)b0 + g;
-            if (RC) {
+            if (AHEAD) {
                 uu = uu_n;
                 jj = jj_n;
+                if (!RC && l16 < dmax) s_conds[g * dmax + l16] = a.sconds[t * dmax + l16];
             } else {
                 uu = a.su[t];
                 jj = a.sj[t];
@@ -1774,8 +1810,26 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
                 const double lsum = wave_sum_dpp(tid < cnt ? (double)(ve * ve) + (double)(regB * vbs) : 0.0);
                 if (tid == 0) gloss += lsum;
             }
+        } else if (CH == 2) {
+            if (tid < 64) {
+                const T vbase = tid < cnt ? s_base[tid] : (T)0;
+                T ve = 0, vbs = 0;
+                switch (dmax) {
+                case 1: camfc_lds_chain<T, 1>(cnt, tid, vbase, my_r, s_conds, s_bc, ve, vbs, lr, regC); break;
+                case 2: camfc_lds_chain<T, 2>(cnt, tid, vbase, my_r, s_conds, s_bc, ve, vbs, lr, regC); break;
+                case 3: camfc_lds_chain<T, 3>(cnt, tid, vbase, my_r, s_conds, s_bc, ve, vbs, lr, regC); break;
+                case 4: camfc_lds_chain<T, 4>(cnt, tid, vbase, my_r, s_conds, s_bc, ve, vbs, lr, regC); break;
+                case 5: camfc_lds_chain<T, 5>(cnt, tid, vbase, my_r, s_conds, s_bc, ve, vbs, lr, regC); break;
+                case 6: camfc_lds_chain<T, 6>(cnt, tid, vbase, my_r, s_conds, s_bc, ve, vbs, lr, regC); break;
+                case 7: camfc_lds_chain<T, 7>(cnt, tid, vbase, my_r, s_conds, s_bc, ve, vbs, lr, regC); break;
+                default: camfc_lds_chain<T, 8>(cnt, tid, vbase, my_r, s_conds, s_bc, ve, vbs, lr, regC); break;
+                }
+                if (tid < cnt) s_base[tid] = ve;
+                const double lsum = wave_sum_dpp(tid < cnt ? (double)(ve * ve) + (double)(regB * vbs) : 0.0);
+                if (tid == 0) gloss += lsum;
+            }
         } else
-        // (LDS chain) lane d owns the tuple's d-th condition
+        // (round-2 LDS chain) lane d owns the tuple's d-th condition
         if (tid < 64) {
             double l = 0.0;
             for (int t = 0; t < cnt; ++t) {
@@ -1821,7 +1875,7 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
                 gloss += (double)((regB * bu) * bu) + (double)((regB * bj) * bj) + (double)reg_sum;
             }
         }
-        if (RC && blk + 1 < n_blocks) request_ids(b1, blk_off[blk + 2]);
+        if (AHEAD && blk + 1 < n_blocks) request_ids(b1, blk_off[blk + 2]);
         b0 = b1;
         __syncthreads(); // this block's rows are visible (workgroup scope) before the next block gathers
     }
@@ -1845,15 +1899,19 @@ size_t camfc_blocks_lds(int n_conds, int dmax, size_t esize) {
 template <typename T>
 hipError_t launch_camfc_blocks(const SgdArgs<T> &a, const int32_t *blk_off, int n_blocks, double *loss_out, hipStream_t s) {
     const size_t lds = camfc_blocks_lds(a.n_conds, a.dmax, sizeof(T));
-    if (a.n_conds <= 64 && a.dmax <= 8 && !getenv("CMI_CAMFC_LDS_CHAIN")) {
-        if (a.k <= 64) hipLaunchKernelGGL((sgd_camfc_blocks<T, 4, true>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
-        else if (a.k <= 128) hipLaunchKernelGGL((sgd_camfc_blocks<T, 8, true>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
-        else hipLaunchKernelGGL((sgd_camfc_blocks<T, 16, true>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
-        return hipGetLastError();
-    }
-    if (a.k <= 64) hipLaunchKernelGGL((sgd_camfc_blocks<T, 4, false>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
-    else if (a.k <= 128) hipLaunchKernelGGL((sgd_camfc_blocks<T, 8, false>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
-    else hipLaunchKernelGGL((sgd_camfc_blocks<T, 16, false>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);
+    // chain form: 1 = condBias in a register (<= 64 conditions), 2 = lean LDS chain (any number), 0 = the round-2 LDS chain (dmax > 8, or
+    // CMI_CAMFC_LDS_CHAIN=1 for A/B runs)
+    const int ch = (a.dmax > 8 || getenv("CMI_CAMFC_LDS_CHAIN")) ? 0 : (a.n_conds <= 64 && !getenv("CMI_CAMFC_NO_RC")) ? 1 : 2;
+#define CMI_CAMFC_LAUNCH(NV)                                                                                                              \
+    do {                                                                                                                                  \
+        if (ch == 1) hipLaunchKernelGGL((sgd_camfc_blocks<T, NV, 1>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);      \
+        else if (ch == 2) hipLaunchKernelGGL((sgd_camfc_blocks<T, NV, 2>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out); \
+        else hipLaunchKernelGGL((sgd_camfc_blocks<T, NV, 0>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);              \
+    } while (0)
+    if (a.k <= 64) CMI_CAMFC_LAUNCH(4);
+    else if (a.k <= 128) CMI_CAMFC_LAUNCH(8);
+    else CMI_CAMFC_LAUNCH(16);
+#undef CMI_CAMFC_LAUNCH
     return hipGetLastError();
 }
 template hipError_t launch_camfc_blocks<float>(const SgdArgs<float> &, const int32_t *, int, double *, hipStream_t);

@@ -7,7 +7,7 @@ from carskit_amd import capi, synth
 from tests import util
 
 def run(data, k, env):
-    old = {n: os.environ.get(n) for n in ("CMI_NO_CAMFC_BLOCKS", "CMI_NO_CAMFC_PIPE")}
+    old = {n: os.environ.get(n) for n in ("CMI_NO_CAMFC_BLOCKS", "CMI_NO_CAMFC_PIPE", "CMI_CAMFC_LDS_CHAIN", "CMI_CAMFC_NO_RC")}
     for n in old:
         os.environ.pop(n, None)
     os.environ.update(env)
@@ -42,3 +42,12 @@ for (nu, ni, n, srt) in ((2000, 1500, 60000, False), (2000, 1500, 60000, True), 
         c, _ = run(data, k, {"CMI_NO_CAMFC_BLOCKS": "1", "CMI_NO_CAMFC_PIPE": "1"})
         print("users %d items %d n %d %s k %d: default %.3f us/tuple (blocks %d, %.1f tuples/block) | pipe %.3f | one-ahead %.3f" %
               (nu, ni, data.n, "user-sorted" if srt else "random order", k, a / data.n * 1e6, nb, data.n / nb if nb else 0, b / data.n * 1e6, c / data.n * 1e6), flush=True)
+
+# Frappe shape (BASELINE configs[1]): 957 users x 4 082 items, 8 dimensions / 344 conditions, 96 K ratings -- condBias does not fit a register
+data = util.small_data(n_users=957, n_items=4082, n_dims=8, conds_per_dim=43, n=96000, seed=12)
+for k in (10, 64, 128, 256):
+    a, nb = run(data, k, {})
+    b, _ = run(data, k, {"CMI_CAMFC_LDS_CHAIN": "1"})
+    c, _ = run(data, k, {"CMI_NO_CAMFC_BLOCKS": "1"})
+    print("Frappe shape n %d k %d: lean LDS chain %.3f us/tuple = %.2f M updates/s (blocks %d, %.1f tuples/block) | round-2 LDS chain %.3f | serial wave %.3f" %
+          (data.n, k, a / data.n * 1e6, data.n / a / 1e6, nb, data.n / nb if nb else 0, b / data.n * 1e6, c / data.n * 1e6), flush=True)
