@@ -1784,6 +1784,8 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
             bu = a.userBias[uu];
             bj = a.itemBias[jj];
         }
+        // the NEXT block's ids: requested now, a whole block (gather, chain, updates) before they are used
+        if (AHEAD && blk + 1 < n_blocks) request_ids(b1, blk_off[blk + 2]);
         T part = 0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) part += p[i] * q[i];
@@ -1875,7 +1877,6 @@ __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int
                 gloss += (double)((regB * bu) * bu) + (double)((regB * bj) * bj) + (double)reg_sum;
             }
         }
-        if (AHEAD && blk + 1 < n_blocks) request_ids(b1, blk_off[blk + 2]);
         b0 = b1;
         __syncthreads(); // this block's rows are visible (workgroup scope) before the next block gathers
     }
