@@ -497,6 +497,7 @@ template hipError_t launch_ext_rank_queries<double>(const ExtEvalArgs<double> &,
 template <typename T, int MODEL>
 static hipError_t launch_ext_model(const ExtArgs<T> &a, bool strict, int64_t n, double *loss_out, hipStream_t s) {
     if (strict) hipLaunchKernelGGL((ext_serial_strict<T, MODEL>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else if (MODEL == SVDPP && svdpp_team_supported(a.k)) return launch_svdpp_team<T>(a, n, loss_out, s);
     else hipLaunchKernelGGL((ext_serial_wave<T, MODEL>), dim3(1), dim3(64), 0, s, a, n, loss_out);
     return hipGetLastError();
 }

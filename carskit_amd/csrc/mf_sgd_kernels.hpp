@@ -165,6 +165,10 @@ struct ExtArgs {
 };
 template <typename T>
 hipError_t launch_ext_serial(const ExtArgs<T> &a, int model, bool strict, int64_t n, double *loss_out, hipStream_t s);
+// SVD++ with a workgroup per chain link, the user's rows resident in LDS (svdpp_team.hip)
+bool svdpp_team_supported(int k);
+template <typename T>
+hipError_t launch_svdpp_team(const ExtArgs<T> &a, int64_t n, double *loss_out, hipStream_t s);
 
 template <typename T>
 struct ExtEvalArgs {
