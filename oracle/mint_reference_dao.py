@@ -214,7 +214,8 @@ def mint_transform(ref, vm, golden):
         out = run_transform(ref, vm, flag[tr], os.path.join(golden, "train_%s.csv" % tr), flag[te], os.path.join(golden, "test_%s.csv" % te), td)
         cases.append({"name": "sample_%s_with_test_%s" % (tr, te), "train_file": "train_%s.csv" % tr, "train_format": flag[tr],
                       "test_file": "test_%s.csv" % te, "test_format": flag[te], "expect": out})
-    for seed, kind, messy in ((11, "loose", False), (12, "loose", True), (13, "compact", False), (14, "compact", True)):
+    for seed, kind, messy in ((11, "loose", False), (12, "loose", True), (13, "compact", False), (14, "compact", True), (21, "loose", True),
+                              (22, "compact", True), (23, "loose", False), (24, "compact", False), (25, "compact", True), (26, "loose", True)):
         rng = random.Random(seed)
         a = (gen_loose if kind == "loose" else gen_compact)(rng, 40, messy)
         b = (gen_loose if kind == "loose" else gen_compact)(rng, 15, messy)
@@ -269,8 +270,9 @@ def main():
         assert "IllegalArgumentException" in str(e)
         cases.append({"name": "sample_test_after_train", "file": "test_binary.csv", "after_file": "train_binary.csv", "throws": str(e)})
     tmp = os.path.join("/tmp", "mint_dao_%d.csv" % os.getpid())
-    for seed, messy, n_lines, nu, ni, dims in ((1, False, 60, 9, 7, (3, 2)), (2, True, 80, 8, 6, (2, 3, 2)), (3, True, 40, 5, 5, (4,)),
-                                               (4, False, 120, 20, 10, (2, 2, 2))):
+    more = [(100 + i, bool(i % 2), 20 + 7 * i, 3 + i % 9, 2 + (i * 5) % 11, tuple(2 + (i + d) % 3 for d in range(1 + i % 4))) for i in range(16)]
+    for seed, messy, n_lines, nu, ni, dims in [(1, False, 60, 9, 7, (3, 2)), (2, True, 80, 8, 6, (2, 3, 2)), (3, True, 40, 5, 5, (4,)),
+                                               (4, False, 120, 20, 10, (2, 2, 2))] + more:
         text = gen_file(random.Random(seed), n_lines, nu, ni, dims, messy)
         with open(tmp, "w", newline="") as fh:
             fh.write(text)
