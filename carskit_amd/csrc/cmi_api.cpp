@@ -655,7 +655,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
                 build_conflict_free_blocks(n, u, j, h->n_users, h->n_items, 64, off);
                 // shorter runs: the serial wave is faster -- the pipelined one (camfc_pipe.hip, 0.55-0.63 us per tuple at any run length)
                 // breaks even with the block kernel (about 1.3 us per block + 0.28 us per tuple) near 5 tuples per block, the one-ahead
-                // wave near 3 (tools/camfc_paths_bench.py)
+                // wave near 3 (tests/tools/bench_camfc_paths.py)
                 const double min_run = camfc_pipe_supported(h->k, h->n_conds, dmax) ? 5.0 : 3.0;
                 if ((double)n / (double)(off.size() - 1) >= min_run) h->blk_off.swap(off);
             }

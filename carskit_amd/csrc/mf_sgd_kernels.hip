@@ -1706,7 +1706,7 @@ __device__ __forceinline__ void camfc_lds_chain(const int cnt, const int tid, co
 
 // RC ("register chain", n_conds <= 64 and dmax <= 8): phase B without an LDS round trip per link -- lane c of wave 0 owns condBias[c],
 // lane t holds tuple t's base, rating and its condition ids packed one byte each; a link is readlanes, adds and one masked update
-// (0.34 -> 0.1x us per tuple at 28-56 tuples per block, tools/camfc_paths_bench.py).  RC also requests the NEXT block's tuple ids while
+// (0.34 -> 0.1x us per tuple at 28-56 tuples per block, tests/tools/bench_camfc_paths.py).  RC also requests the NEXT block's tuple ids while
 // this block's updates are written, so phase A starts with the row gather instead of a dependent id load.
 template <typename T, int NV, int CH> // CH: 0 = the round-2 LDS chain, 1 = register chain (RC), 2 = lean LDS chain (any n_conds, dmax <= 8)
 __global__ __launch_bounds__(1024) void sgd_camfc_blocks(SgdArgs<T> a, const int32_t *__restrict__ blk_off, int n_blocks,

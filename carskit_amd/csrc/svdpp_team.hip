@@ -4,7 +4,7 @@
 // them: no two ratings commute, the epoch is one chain in the 2-D train matrix's row-major order, and a link is O(|N(u)| k) work.
 // ext_serial_wave (ext_kernels.hip) walks that work with one wave and a dependent global access per row: 18 / 18 / 27 us per rating at
 // k = 10 / 64 / 128 on a 60 K-rating set with |N(u)| = 30 (one CPU core: 0.34 / 2.2 / 4.8 us); this kernel: 2.9 / 3.8 / 5.1 us
-// (tools/ext_models_bench.py).  What the order leaves to exploit:
+// (tests/tools/bench_ext_models.py).  What the order leaves to exploit:
 //   * the ratings of one user are consecutive (row-major order) and all of them touch the SAME rows Y[N(u)] and P[u]: the rows are loaded
 //     into LDS once per user, updated there by every rating of the user, and written back once;
 //   * inside a link everything is wide: |N(u)| dot products <Y[i], Q[j]> (one 16-lane group per row, DPP row sums), the per-factor column

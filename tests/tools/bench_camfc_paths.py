@@ -1,5 +1,5 @@
 """CAMF_C: the conflict-free-block kernel against the pipelined serial wave (and the one-ahead serial wave) on the same data.
-usage (GPU box): python tools/camfc_paths_bench.py"""
+usage (GPU box): python tests/tools/bench_camfc_paths.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())

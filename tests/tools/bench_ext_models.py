@@ -1,5 +1,5 @@
 """SVD++ / CAMF_ICS / CAMF_LCS / CAMF_MCS: the serial GPU kernels against the C oracle on the host, same data.
-usage (GPU box): python tools/ext_models_bench.py"""
+usage (GPU box): python tests/tools/bench_ext_models.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
