@@ -112,6 +112,15 @@ class Natives:
                                            rb, rc)
         return d["orc"]
 
+    def n_setEvalRatings(self, h, u, j, ctx, r):
+        self.h[int(h)]["eval"] = (arr(u, np.int32), arr(j, np.int32), None if ctx is None else arr(ctx, np.int32), arr(r, np.float64))
+
+    def n_evalResident(self, h, min_rate, max_rate):
+        d = self.h[int(h)]
+        u, j, ctx, r = d["eval"]
+        ev = self._oracle(d).eval_ratings(u, j, ctx if ctx is not None else np.zeros(len(u), np.int32), r, float(min_rate), float(max_rate))
+        return JArray("D", [float(ev[n]) for n in ("MAE", "RMSE", "NMAE", "rMAE", "rRMSE")])
+
     def n_trainEpoch(self, h, lrate):
         return float(self._oracle(self.h[int(h)]).epoch(float(lrate)))
 
@@ -234,6 +243,29 @@ def check(ref, case):
     return nat.calls, same, rec["java_statements_executed"]
 
 
+def check_early_stop(ref, case, measure="RMSE"):
+    """`--early-stop RMSE`: the reference's isConverged() calls evalRatings() after every epoch; the drop-in's override answers from the
+    live native model (GpuSupport.evalResident) -- setEvalRatings / tuples() / evaluatesDuringTraining() / the handle bookkeeping.  The
+    reference's own run with the same setting (interpreted, no drop-in) must stop at the same epoch with the same model."""
+    model = case["model"]
+    init = {n: [float.fromhex(x) for x in v] for n, v in case["init"].items()}
+    kw = dict(seed=0, lrate=case["lrate"], bold=case["bold_driver"], init_override=init, test_cells=case["test_cells"], early_stop=measure)
+    want = M.run_model(ref, model, case["problem"], case["k"], case["iters"], **kw)
+    want.pop("eval_ratings", None)
+    nat = Natives()
+    cmap = {"NativeMF": nat}
+
+    def make(vm):
+        for n in ("GpuSupport", "Dev", "Rows"):
+            cmap[n] = static_class(vm, n, cmap)
+    got = M.run_model(ref, model, case["problem"], case["k"], case["iters"], drop_in=(os.path.join(JAVA, DROP_IN[model] + ".java"), cmap, make), **kw)
+    same = {n: got["final"][n] == want["final"][n] for n in want["final"]}
+    for key in ("epoch_loss", "epoch_lrate", "epochs_run", "last_measure"):
+        same[key] = got[key] == want[key]
+    assert nat.live == 0
+    return nat.calls, same
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     cases = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_src.json")))["cases"]
@@ -250,6 +282,11 @@ def main():
         ok = ok and all(same.values())
         print("%-10s %-14s %s  (%d natives, %d statements)" % (case["model"], DROP_IN[case["model"]], "bit-identical" if all(same.values())
               else "DIFFERS: %s" % [n for n, v in same.items() if not v], len(calls), stmts), flush=True)
+    es_case = [c for c in cases if c["model"] == "CAMF_CU"][0]
+    calls, same = check_early_stop(ref, es_case)
+    out["early_stop_rmse"] = {"model": "CAMF_CU", "native_calls": calls, "bit_identical": same}
+    ok = ok and all(same.values())
+    print("early stop on RMSE (CAMF_CU_GPU):", "bit-identical" if all(same.values()) else "DIFFERS %s" % same, "natives:", sorted(set(calls)), flush=True)
     fm_case = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_src.json")))["fm_cases"][0]
     calls, same, stmts = check_fm(ref, fm_case)
     out["models"]["FM"] = {"drop_in": "FM_GPU", "native_calls": calls, "bit_identical": same, "java_statements_executed": stmts}

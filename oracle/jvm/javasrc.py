@@ -799,6 +799,8 @@ class Env:
                 return not self.truth(v)
             return i32(~v)
         if k == "cast":
+            if n[1][1] > 0:            # a cast to an array type ((int[]) t[0]): a reference conversion, the value is unchanged
+                return self.eval(n[2])
             v = unbox(self.eval(n[2]))
             ty = n[1][0]
             if ty == "float":

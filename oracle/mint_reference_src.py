@@ -165,7 +165,7 @@ def source_dao(ref, vm, prob):
 
 
 def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3, bold=True, test_cells=None, rank=None, drop_in=None,
-              init_override=None):
+              init_override=None, early_stop=None):
     """drop_in: (path of a *_GPU.java drop-in class of THIS repository, {simple class name: This / natives object}, make(vm) that fills
     that map) -- the drop-in is put in front of the reference's class chain, so its buildModel() override runs
     (oracle/check_java_binding.py); init_override: the initial containers of a minted case instead of fresh draws"""
@@ -252,6 +252,10 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
             F[name] = dense(vm, init[name]) if init[name].ndim == 2 else vector(vm, init[name])
     trace = []
     this.hooks["isConverged"] = lambda th, args: trace.append((th.fields["loss"], th.fields["lRate"]))
+    if early_stop:   # `--early-stop RMSE|MAE`: isConverged() scores testMatrix after every epoch (IterativeRecommender.java:149-161)
+        F["earlyStopMeasure"] = javasrc.EnumConst("Measure", early_stop)
+        F["testMatrix"] = sparse(vm, len(prob["ui_user"]), len(prob["ctx_keys"]), test_cells)
+        F["workingPath"] = ""
     if drop_in:
         F.update({"gpuHandle": javasrc.JLong(0), "fold": 1})
         javasrc.STATIC_FIELDS[("Recommender", "rateDao")] = F["rateDao"]
@@ -293,7 +297,7 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
            "empty_conds": empty, "n_ctx_dims": n_dims, "num_f": NUM_F,
            "problem": prob, "init": {n: [hx(x) for x in a.ravel()] for n, a in init.items()},
            "final": {n: out_state(n) for n in init}, "epoch_loss": [hx(l) for l, _ in trace], "epoch_lrate": [hx(r) for _, r in trace],
-           "final_lrate": hx(F["lRate"]), "test_cells": test_cells, "eval_ratings": evals, "rank": rank, "eval_rankings": ranks, "java_statements_executed": this.statements, "bytecode_instructions": vm.steps}
+           "final_lrate": hx(F["lRate"]), "epochs_run": len(trace), "last_measure": hx(javasrc.unbox(F["last_measure"])), "test_cells": test_cells, "eval_ratings": evals, "rank": rank, "eval_rankings": ranks, "java_statements_executed": this.statements, "bytecode_instructions": vm.steps}
     return rec
 
 

@@ -14,7 +14,8 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CHECK = json.load(open(os.path.join(ROOT, "tests", "golden", "java_binding_check.json")))["models"]
+_ALL = json.load(open(os.path.join(ROOT, "tests", "golden", "java_binding_check.json")))
+CHECK = _ALL["models"]
 REF = os.environ.get("CARSKIT_REFERENCE", "/root/reference")
 
 
@@ -49,6 +50,17 @@ def test_native_call_sequence_is_what_the_jni_shim_exports():
         assert not any(c.startswith("set") for c in calls[first_epoch:])
 
 
+def test_committed_early_stop_run_is_bit_identical_and_scores_the_live_model():
+    """`--early-stop RMSE`: the reference's isConverged() calls evalRatings() every epoch; the drop-in answers from the native model"""
+    rec = _ALL["early_stop_rmse"]
+    assert all(rec["bit_identical"].values()), rec["bit_identical"]
+    calls = rec["native_calls"]
+    assert "setEvalRatings" in calls[:calls.index("trainEpoch")]
+    assert calls.count("evalResident") == calls.count("trainEpoch")          # one score per epoch
+    for a, b in zip(calls, calls[1:]):
+        assert not (a == "trainEpoch" and b == "trainEpoch")                 # ... taken between the epochs, not after the loop
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "carskit")), reason="needs the reference tree (build container only)")
 def test_drop_ins_execute_bit_identically_to_the_reference_buildmodel():
     from oracle import check_java_binding as chk
@@ -66,3 +78,5 @@ def test_drop_ins_execute_bit_identically_to_the_reference_buildmodel():
     fm = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_src.json")))["fm_cases"][0]
     calls, same, _ = chk.check_fm(REF, fm)
     assert all(same.values()) and calls == CHECK["FM"]["native_calls"]
+    calls, same = chk.check_early_stop(REF, [c for c in cases if c["model"] == "CAMF_CU"][0])
+    assert all(same.values()) and calls == _ALL["early_stop_rmse"]["native_calls"]
