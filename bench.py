@@ -284,6 +284,27 @@ def bench_rank(args):
     return out
 
 
+def box_state():
+    """What the box reports about itself (rocm-smi), kept beside the numbers: the same library measures 41.6 ms per C5 epoch on one
+    MI355X box and 50.5 ms on another, so a line says which kind of box it ran on.  Never fails the bench."""
+    import re
+    import subprocess
+    try:
+        txt = subprocess.run(["rocm-smi", "--showtemp", "--showclocks", "--showpower", "--showmemuse"], capture_output=True, text=True,
+                             timeout=20).stdout
+    except Exception as e:
+        return {"error": repr(e)}
+    out = {}
+    for key, pat in (("mclk_MHz", r"GPU\[0\].*mclk clock level: \d+: \((\d+)Mhz\)"), ("sclk_MHz", r"GPU\[0\].*sclk clock level: \d+: \((\d+)Mhz\)"),
+                     ("fclk_MHz", r"GPU\[0\].*fclk clock level: \d+: \((\d+)Mhz\)"),
+                     ("temp_junction_C", r"GPU\[0\].*Sensor junction\) \(C\): ([0-9.]+)"), ("temp_memory_C", r"GPU\[0\].*Sensor memory\) \(C\): ([0-9.]+)"),
+                     ("power_W", r"GPU\[0\].*Package Power \(W\): ([0-9.]+)")):
+        m = re.search(pat, txt)
+        if m:
+            out[key] = float(m.group(1))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -516,6 +537,8 @@ def main():
                         raise
                     except Exception as e:
                         out[key] = {"value": None, "error": repr(e)}
+        if world == 1:
+            out["box"] = box_state()     # read right after the timed work, clocks still up
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
