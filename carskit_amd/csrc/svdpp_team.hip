@@ -2,8 +2,8 @@
 //
 // Every rating (u, j) of SVD++ reads the implicit-feedback rows Y[i] of ALL items i in N(u) (the items u rated), and writes every one of
 // them: no two ratings commute, the epoch is one chain in the 2-D train matrix's row-major order, and a link is O(|N(u)| k) work.
-// ext_serial_wave (ext_kernels.hip) walks that work with one wave and a dependent global access per row: 18 / 18 / 27 us per rating at
-// k = 10 / 64 / 128 on a 60 K-rating set with |N(u)| = 30 (one CPU core: 0.34 / 2.2 / 4.8 us); this kernel: 2.9 / 3.8 / 5.1 us
+// ext_serial_wave (ext_kernels.hip) walks that work with one wave and a dependent global access per row: 17.6 / 16.5 / 25.7 us per rating at
+// k = 10 / 64 / 128 on a 59 K-rating train matrix with |N(u)| = 30 (one CPU core: 0.31 / 2.1 / 4.7 us); this kernel: 1.5 / 1.9 / 2.6 us
 // (tests/tools/bench_ext_models.py).  What the order leaves to exploit:
 //   * the ratings of one user are consecutive (row-major order) and all of them touch the SAME rows Y[N(u)] and P[u]: the rows are loaded
 //     into LDS once per user, updated there by every rating of the user, and written back once;
@@ -140,7 +140,17 @@ __global__ __launch_bounds__(NT) void svdpp_team(ExtArgs<T> a, int64_t n, int ma
             while (t_end < n && a.su[t_end] == uu) ++t_end;
         }
         const int run = (int)(t_end - t);
-        if (cnt > max_rows || cnt <= 0 || run > max_rows) { // rows do not fit: wave 0 walks the run through HBM
+        // a row listed twice in N(u) (a (user, item) pair given twice: not a train matrix, but the C ABI takes any tuple list) is updated
+        // twice per rating by the sequential loop, the second time from the first result: two LDS copies cannot do that
+        bool twice = false;
+        if (cnt > 0 && cnt <= max_rows) {
+            for (int x = tid; x < cnt; x += NT) s_items[x] = a.ui_items[b + x];
+            __syncthreads();
+            bool mine = false;
+            for (int x = tid; x + 1 < cnt; x += NT) mine = mine || s_items[x] == s_items[x + 1];
+            twice = __syncthreads_or(mine);
+        }
+        if (cnt > max_rows || cnt <= 0 || run > max_rows || twice) { // rows do not fit (or repeat): wave 0 walks the run through HBM
             if (wave == 0) {
                 double l0 = 0.0;
                 for (int64_t x = t; x < t_end; ++x) svdpp_link_wave<T>(a, x, lane, lr, regU, regI, regB, gm, l0, lpart);
@@ -163,7 +173,6 @@ __global__ __launch_bounds__(NT) void svdpp_team(ExtArgs<T> a, int64_t n, int ma
                 }
             }
         }
-        for (int x = tid; x < cnt; x += NT) s_items[x] = a.ui_items[b + x];
         for (int x = tid; x < run; x += NT) {
             s_j[x] = a.sj[t + x];
             s_rr[x] = a.sr[t + x];
@@ -181,8 +190,11 @@ __global__ __launch_bounds__(NT) void svdpp_team(ExtArgs<T> a, int64_t n, int ma
             const T rr = s_rr[x], bj = bj_next;
             // ---- P1: Q[j] into LDS, the next rating's row requested
             if (tid < k) s_q[tid] = q_next;
-            {
-                const int jn = s_j[x + 1 < run ? x + 1 : x];
+            // (a stream that repeats one (user, item) pair back to back -- not a train matrix, but the C ABI takes any tuple list -- would
+            // make this request stale: it is then issued after this rating's stores instead)
+            const int jn = s_j[x + 1 < run ? x + 1 : x];
+            const bool repeat = jn == jj && x + 1 < run;
+            if (!repeat) {
                 if (tid < k) q_next = a.Q[(size_t)jn * k + tid];
                 bj_next = a.itemBias[jn];
             }
@@ -240,6 +252,11 @@ __global__ __launch_bounds__(NT) void svdpp_team(ExtArgs<T> a, int64_t n, int ma
                     if (f >= k) f -= k;
                 }
             }
+            if (repeat) {
+                __syncthreads(); // drains this rating's stores: the row below is the updated one
+                if (tid < k) q_next = a.Q[(size_t)jn * k + tid];
+                bj_next = a.itemBias[jn];
+            }
             lds_barrier(); // s_q and s_part are rewritten by the next rating; s_Y / s_p updates are visible
         }
         // ---- write the user's rows back
@@ -281,8 +298,8 @@ hipError_t launch_svdpp_team(const ExtArgs<T> &a, int64_t n, double *loss_out, h
     size_t rows = (budget - fixed) / per_row;
     if (rows > 4096) rows = 4096;
     const size_t lds = fixed + rows * per_row + 16;
-    // team size: 1024 threads measured fastest (k = 10 / 64 / 128, |N(u)| = 30: 2.9 / 3.8 / 5.1 us per rating against 3.2 / 5.7 / 9.1 with 256
-    // threads) although a link is only ~375 instructions per wave: the wide parts (|N(u)| k element updates, one group per row) win more
+    // team size: 1024 threads measured fastest (measured on a stream of one-rating runs: 2.9 / 3.8 / 5.1 us per rating at k = 10 / 64 / 128 against 3.2 / 5.7 / 9.1 with
+    // 256 threads) although a link is only ~375 instructions per wave: the wide parts (|N(u)| k element updates, one group per row) win more
     // from 16 waves than the uniform part loses; CMI_SVDPP_THREADS=256|512 for A/B runs
     const char *env = getenv("CMI_SVDPP_THREADS");
     int nt = env ? atoi(env) : 1024;

@@ -13,7 +13,11 @@ for model in ("SVD++", "CAMF_ICS", "CAMF_LCS", "CAMF_MCS"):
     for k in (10, 64, 128):
         st = synth.init_state(model, data, k, seed=1)
         gm = float(data.r.sum() / np.count_nonzero(data.r))
-        u, j, ctx, r = util.tuples_for(model, data)
+        if model == "SVD++":      # the 2-D train matrix (users x items, mean over contexts), row-major: what SVDPlusPlus.java iterates
+            u, j, r = synth.to_2d(data)
+            ctx = None
+        else:
+            u, j, ctx, r = util.tuples_for(model, data)
         inst = capi.Instance(model, k, data.n_users, data.n_items, data.n_conds, flags=capi.FLAG_SCHED_SERIAL)
         inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, gm)
         if model == "SVD++":
