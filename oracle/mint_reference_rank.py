@@ -29,7 +29,10 @@ def main():
     out = {"source": "Recommender.evalRankings of the reference, interpreted from source (see oracle/mint_reference_rank.py)", "cases": []}
     grid = (("CAMF_CU", 9, 14, 2, 2, 110, 4, 2, 10, -1.0, "ucu", 0), ("CAMF_CI", 9, 14, 2, 2, 110, 4, 2, 10, 3.0, "uc", 0),
             ("BiasedMF", 8, 16, 2, 2, 100, 3, 2, 10, -1.0, "ucu", 2), ("CAMF_C", 10, 25, 1, 3, 160, 3, 1, 12, 2.0, "ucu", 0),
-            ("PMF", 8, 16, 2, 2, 100, 3, 2, 5, -1.0, "uc", 0), ("CAMF_CUCI", 9, 14, 2, 2, 110, 3, 1, 10, -1.0, "ucu", 1))
+            ("PMF", 8, 16, 2, 2, 100, 3, 2, 5, -1.0, "uc", 0), ("CAMF_CUCI", 9, 14, 2, 2, 110, 3, 1, 10, -1.0, "ucu", 1),
+            # the similarity models are top-N recommenders by construction (isRankingPred), SVD++ by configuration
+            ("CAMF_ICS", 9, 14, 2, 3, 110, 3, 2, 10, -1.0, "ucu", 0), ("CAMF_MCS", 9, 14, 2, 3, 110, 3, 2, 10, -1.0, "uc", 0),
+            ("CAMF_LCS", 8, 12, 2, 3, 100, 3, 2, 10, -1.0, "ucu", 0), ("SVD++", 8, 16, 2, 2, 100, 3, 2, 10, -1.0, "ucu", 0))
     for (model, nu, ni, nd, cpd, n, k, iters, num_recs, thold, strategy, ignore) in grid:
         prob = M.problem(rng, nu, ni, nd, cpd, n)
         held = [c for i, c in enumerate(prob["cells"]) if i % 4 == 3]

@@ -15,6 +15,7 @@ from oracle import oracle_c, rank_oracle
 from tests import util
 from tests.test_reference_src_golden import _inputs, fx, SHAPES
 
+SIM = ("SVD++", "CAMF_ICS", "CAMF_LCS", "CAMF_MCS")
 CASES = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_rank.json")))["cases"]
 
 
@@ -32,8 +33,13 @@ def test_rank_oracle_reproduces_the_interpreted_evalrankings(case):
     u, j, ctx, r, ctx_ptr, ctx_conds, _ = _inputs(case)
     p, rk = case["problem"], case["rank"]
     assert case["eval_rankings"]["statements"] > 3000
-    orc = oracle_c.Oracle(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], u, j, ctx, r, ctx_ptr, ctx_conds,
-                          _final_state(case), fx(case["global_mean"]), case["regU"], case["regI"], case["regB"], case["regC"])
+    if case["model"] in SIM:     # oracle/carskit_oracle_sim.c
+        orc = oracle_c.SimOracle(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], u, j, ctx, r, ctx_ptr, ctx_conds,
+                                 np.array(case["empty_conds"], np.int32), _final_state(case), fx(case["global_mean"]), case["regU"],
+                                 case["regI"], case["regB"], case["regC"], n_ctx_dims=case["n_ctx_dims"])
+    else:
+        orc = oracle_c.Oracle(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], u, j, ctx, r, ctx_ptr, ctx_conds,
+                              _final_state(case), fx(case["global_mean"]), case["regU"], case["regI"], case["regB"], case["regC"])
     got, _ = rank_oracle.eval_rankings(lambda a, b, c: orc.predict(a, b, c), _cells_to_tuples(p, p["cells"]),
                                        _cells_to_tuples(p, rk["test_cells"]), bin_thold=rk["bin_thold"], num_recs=rk["num_recs"],
                                        strategy=rk["strategy"], num_ignore=rk["num_ignore"])
@@ -55,9 +61,13 @@ def test_gpu_eval_rankings_reproduces_the_interpreted_evalrankings(case):
     from carskit_amd import capi
     u, j, ctx, r, ctx_ptr, ctx_conds, _ = _inputs(case)
     p, rk = case["problem"], case["rank"]
-    inst = capi.Instance(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"], flags=capi.FLAG_STATE_F64 | capi.FLAG_STRICT | (capi.FLAG_SCHED_SERIAL if case["model"] == "CAMF_C" else 0))
+    serial = case["model"] == "CAMF_C" or case["model"] in SIM
+    inst = capi.Instance(case["model"], case["k"], p["n_users"], p["n_items"], p["n_conds"],
+                         flags=capi.FLAG_STATE_F64 | capi.FLAG_STRICT | (capi.FLAG_SCHED_SERIAL if serial else 0))
     inst.set_hparams(case["regU"], case["regI"], case["regB"], case["regC"], fx(case["global_mean"]))
-    if case["model"] in util.TWO_D:
+    if case["model"] in SIM and case["model"] != "SVD++":
+        inst.set_sim_params(case["num_f"], case["n_ctx_dims"], case["empty_conds"])
+    if case["model"] in util.TWO_D or case["model"] == "SVD++":
         inst.set_ratings(u, j, None, r)
     else:
         inst.set_ratings(u, j, ctx, r, ctx_ptr, ctx_conds)
