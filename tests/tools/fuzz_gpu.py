@@ -57,6 +57,21 @@ def main():
             os.environ["CMI_OWNER_TEAM"] = str(rng.choice(["all", "0"]))      # every owner a team of three wavefronts / none
             owned += 1
         state = synth.init_state(model, data, k, seed=int(rng.integers(1 << 30)))
+        # CAMF_C (round 3): the pipelined serial wave, the register chain and the lean LDS chain of the block kernel, picked at random
+        for knob in ("CMI_NO_CAMFC_BLOCKS", "CMI_NO_CAMFC_PIPE", "CMI_CAMFC_NO_RC", "CMI_CAMFC_LDS_CHAIN"):
+            os.environ.pop(knob, None)
+        if model == "CAMF_C":
+            pick = int(rng.integers(5))
+            if pick == 1:
+                os.environ["CMI_NO_CAMFC_BLOCKS"] = "1"                                   # the pipelined wave on any order
+            elif pick == 2:
+                os.environ["CMI_CAMFC_NO_RC"] = "1"                                       # lean LDS chain
+            elif pick == 3:
+                os.environ["CMI_NO_CAMFC_BLOCKS"], os.environ["CMI_NO_CAMFC_PIPE"] = "1", "1"   # the one-ahead wave
+            if rng.random() < 0.3:                                                        # user-sorted input: runs of one
+                import dataclasses
+                o = np.lexsort((data.j, data.u))
+                data = dataclasses.replace(data, u=data.u[o], j=data.j[o], ctx=data.ctx[o], r=data.r[o])
         gm = oracle_c.global_mean(data.r)
         orc = util.c_oracle(model, data, k, state, gm)
         u, j, ctx, r = util.tuples_for(model, data)
