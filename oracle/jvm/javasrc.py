@@ -17,6 +17,14 @@ Numeric model: int -> Python int (32-bit wrap on + - *, truncating / and %), dou
 float-typed result rounded to binary32), boolean -> bool.  Math.pow(x, 2) is x * x (what fdlibm's and HotSpot's pow return for y == 2).
 What is executed is the reference's text, read where it lies under /root/reference at minting time; nothing of it is copied into this
 repository -- the fixtures hold numbers only (oracle/mint_reference_src.py).
+
+Round 3 grew it from the SGD loops to everything either side of them (oracle/mint_reference_rank.py, oracle/mint_reference_dao.py,
+oracle/check_java_binding.py): try / finally, array literals and casts, 2-D arrays, generic-method call syntax, overloads picked by
+parameter type, objects whose class is itself interpreted (rateDao as DataDAO.java) and classes of static methods interpreted from source
+on top of a jar class (carskit.eval.Measures over happy.coding.math.Measures), harness-provided native methods (NativeMF), and host
+stand-ins written from the JDK / guava specifications: HashMap / HashSet / HashMultimap WITH java.util.HashMap's iteration order (JDK 8
+bin table, resize at 0.75; tree bins refused), HashBiMap with its "value already present" refusal, Tree/LinkedHashMultimap, Multiset,
+BufferedReader / Writer, String.split with Java's regex and limit rules, Integer.valueOf / Double.valueOf with their grammars.
 """
 import math
 import os
