@@ -395,7 +395,7 @@ class Parser:
             return ("lit", bytes(v[1:-1], "utf-8").decode("unicode_escape"))
         if kind == "chr":
             self.eat()
-            return ("lit", ord(bytes(v[1:-1], "utf-8").decode("unicode_escape")))
+            return ("lit", JChar(ord(bytes(v[1:-1], "utf-8").decode("unicode_escape"))))
         if kind == "op" and v == "(":
             self.eat()
             e = self.expr()
@@ -990,6 +990,8 @@ class Env:
             return wrap(x << (y & 31))
         if op == ">>":
             return wrap(x >> (y & 31))
+        if op == ">>>":
+            return wrap((x & 0xFFFFFFFF) >> (y & 31))
         if op == "&":
             return wrap(x & y)
         if op == "|":
@@ -1304,9 +1306,15 @@ def from_host(v):
     return v
 
 
+class JChar(int):
+    """a char value: an int in arithmetic (the results are plain ints), its character in a string concatenation"""
+
+
 def java_str(v):
     if isinstance(v, str):
         return v
+    if isinstance(v, JChar):
+        return chr(v)
     if v is None:
         return "null"
     if isinstance(v, bool):
