@@ -243,6 +243,135 @@ def check(ref, case):
     return nat.calls, same, rec["java_statements_executed"]
 
 
+class GroupNatives(Natives):
+    """the group* natives (cmi_group_*): W user shards, each an order-exact CPU oracle; after every epoch the item-side containers become
+    start + mean of the shards' moves, the local rate is lRate x the scale set by groupSetLrScale"""
+    USER_SIDE = ("P", "userBias", "ucBias")
+
+    def n_groupCreate(self, model, k, nu, ni, nc, n_shards, devices, flags):
+        self.live += 1
+        gid = 5000 + len(self.h)
+        self.h[gid] = {"model": MODEL_NAMES[int(model)], "k": int(k), "nu": int(nu), "ni": int(ni), "nc": int(nc), "W": int(n_shards),
+                       "state": {}, "scale": 1.0, "shards": None}
+        assert devices is None
+        return javasrc.JLong(gid)
+
+    def n_groupDestroy(self, g):
+        self.live -= 1
+
+    def n_groupSetHparams(self, g, ru, ri, rb, rc, gm):
+        self.n_setHparams(g, ru, ri, rb, rc, gm)
+
+    def n_groupSetRatingsCsr(self, g, *a):
+        self.n_setRatingsCsr(g, *a)
+
+    def n_groupSetRatings2D(self, g, *a):
+        self.n_setRatings2D(g, *a)
+
+    def n_groupSetMatrix(self, g, which, rows):
+        self.n_setMatrix(g, which, rows)
+
+    def n_groupSetVector(self, g, which, v):
+        self.n_setVector(g, which, v)
+
+    def n_groupSetLrScale(self, g, scale):
+        self.h[int(g)]["scale"] = float(scale)
+
+    def _shards(self, d):
+        if d["shards"] is None:
+            from carskit_amd import dist as cdist
+            from carskit_amd.synth import RatingData
+            u, j, ctx, r, ctx_ptr, ctx_conds = d["tuples"]
+            data = RatingData(d["nu"], d["ni"], d["nc"], 1, u.astype(np.int32), j.astype(np.int32), ctx.astype(np.int32), r, ctx_ptr, ctx_conds)
+            ru, ri, rb, rc, gm = d["hp"]
+            d["shards"] = []
+            for rank in range(d["W"]):
+                sh, (lo, hi) = cdist.shard_by_user(data, rank, d["W"])
+                st = {n: (a[lo:hi].copy() if n in self.USER_SIDE else a.copy()) for n, a in d["state"].items()}
+                orc = oracle_c.Oracle(d["model"], d["k"], hi - lo, d["ni"], d["nc"], sh.u, sh.j, sh.ctx, sh.r, ctx_ptr, ctx_conds, st, gm, ru, ri,
+                                      rb, rc)
+                d["shards"].append((orc, lo, hi))
+        return d["shards"]
+
+    def n_groupTrainEpoch(self, g, lrate):
+        d = self.h[int(g)]
+        shards = self._shards(d)
+        names = [n for n in d["state"] if n not in self.USER_SIDE]
+        start = {n: shards[0][0].state[n].copy() for n in names}
+        loss = 0.0
+        for orc, _, _ in shards:
+            loss += float(orc.epoch(float(lrate) * d["scale"]))
+        for n in names:
+            merged = start[n] + sum(o.state[n] - start[n] for o, _, _ in shards) / float(d["W"])
+            for o, _, _ in shards:
+                o.state[n][...] = merged
+        return loss
+
+    def _gather(self, g, which):
+        d = self.h[int(g)]
+        name = STATE_NAMES[int(which)]
+        if d["shards"] is None:
+            return d["state"][name]
+        if name in self.USER_SIDE:
+            return np.concatenate([np.asarray(o.state[name]).reshape(hi - lo, -1) for o, lo, hi in d["shards"]]).reshape(d["state"][name].shape)
+        return d["shards"][0][0].state[name]
+
+    def n_groupGetMatrix(self, g, which, rows):
+        a = np.asarray(self._gather(g, which), dtype=np.float64).reshape(len(rows), -1)
+        for row, src in zip(rows, a):
+            (row.data if isinstance(row, JArray) else row)[:] = [float(x) for x in src]
+
+    def n_groupGetVector(self, g, which, v):
+        (v.data if isinstance(v, JArray) else v)[:] = [float(x) for x in np.asarray(self._gather(g, which)).ravel()]
+
+
+def check_group(ref, case, n_shards=2):
+    """-Dcarskit.shards=N: GpuSupport.buildModelSharded -- groupCreate / groupSet* / Dev.ofGroup routing of copyIn and copyOut (negative
+    handles) / groupSetLrScale(sqrt(N)) / the epoch loop over groupTrainEpoch with the reference's isConverged() steering the base rate.
+    Expected: the same natives driven by a few lines of Python in the intended order, with IterativeRecommender's bold driver restated."""
+    model = case["model"]
+    init = {n: np.array([float.fromhex(x) for x in v]) for n, v in case["init"].items()}
+    nat = GroupNatives()
+    cmap = {"NativeMF": nat}
+
+    def make(vm):
+        for n in ("GpuSupport", "Dev", "Rows"):
+            cmap[n] = static_class(vm, n, cmap)
+    javasrc.SYSTEM_PROPERTIES["carskit.shards"] = str(n_shards)
+    try:
+        got = M.run_model(ref, model, case["problem"], case["k"], case["iters"], seed=0, lrate=case["lrate"], bold=case["bold_driver"],
+                          drop_in=(os.path.join(JAVA, DROP_IN[model] + ".java"), cmap, make),
+                          init_override={n: a.tolist() for n, a in init.items()})
+    finally:
+        javasrc.SYSTEM_PROPERTIES.pop("carskit.shards", None)
+    assert nat.live == 0
+    # the intended flow, in Python, over a second set of the same stand-ins
+    ref_nat = GroupNatives()
+    first = [h for h in nat.h.values()][0]
+    p = case["problem"]
+    shapes = {"P": (p["n_users"], case["k"]), "Q": (p["n_items"], case["k"]), "userBias": (p["n_users"],), "itemBias": (p["n_items"],),
+              "ucBias": (p["n_users"], p["n_conds"]), "icBias": (p["n_items"], p["n_conds"])}
+    g = ref_nat.n_groupCreate({v: k_ for k_, v in MODEL_NAMES.items()}[model], case["k"], p["n_users"], p["n_items"], p["n_conds"], n_shards, None, 0)
+    ref_nat.h[int(g)]["hp"] = first["hp"]
+    ref_nat.h[int(g)]["tuples"] = first["tuples"]
+    ref_nat.h[int(g)]["state"] = {n: init[n].reshape(shapes[n]).copy() for n in init}
+    ref_nat.n_groupSetLrScale(g, float(np.sqrt(float(n_shards))))
+    lr, last, losses, lrates = case["lrate"], 0.0, [], []
+    for it in range(1, case["iters"] + 1):
+        lrates.append(lr)
+        loss = ref_nat.n_groupTrainEpoch(g, lr)
+        losses.append(loss)
+        if it > 1:                                   # IterativeRecommender.updateLRate, bold driver (IterativeRecommender.java:216-229)
+            lr = lr * 1.05 if abs(last) > abs(loss) else lr * 0.5
+        last = loss
+    same = {"epoch_loss": got["epoch_loss"] == [M.hx(x) for x in losses], "epoch_lrate": got["epoch_lrate"] == [M.hx(x) for x in lrates]}
+    which = {v: k_ for k_, v in STATE_NAMES.items()}
+    for n in case["final"]:
+        want = np.asarray(ref_nat._gather(g, which[n]), dtype=np.float64).ravel()
+        same[n] = got["final"][n] == [M.hx(x) for x in want]
+    return nat.calls, same
+
+
 def check_early_stop(ref, case, measure="RMSE"):
     """`--early-stop RMSE`: the reference's isConverged() calls evalRatings() after every epoch; the drop-in's override answers from the
     live native model (GpuSupport.evalResident) -- setEvalRatings / tuples() / evaluatesDuringTraining() / the handle bookkeeping.  The
@@ -287,6 +416,11 @@ def main():
     out["early_stop_rmse"] = {"model": "CAMF_CU", "native_calls": calls, "bit_identical": same}
     ok = ok and all(same.values())
     print("early stop on RMSE (CAMF_CU_GPU):", "bit-identical" if all(same.values()) else "DIFFERS %s" % same, "natives:", sorted(set(calls)), flush=True)
+    gr_case = [c for c in cases if c["model"] == "CAMF_CI"][0]
+    calls, same = check_group(ref, gr_case)
+    out["shards_2"] = {"model": "CAMF_CI", "native_calls": calls, "bit_identical": same}
+    ok = ok and all(same.values())
+    print("-Dcarskit.shards=2 (CAMF_CI_GPU):", "as intended, bit for bit" if all(same.values()) else "DIFFERS %s" % same, "natives:", sorted(set(calls)), flush=True)
     fm_case = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_src.json")))["fm_cases"][0]
     calls, same, stmts = check_fm(ref, fm_case)
     out["models"]["FM"] = {"drop_in": "FM_GPU", "native_calls": calls, "bit_identical": same, "java_statements_executed": stmts}

@@ -1450,6 +1450,9 @@ def _math_pow(x, y):
     return math.pow(x, y)
 
 
+SYSTEM_PROPERTIES = {}   # -Dname=value of the evaluated run (strings), set by the harness
+
+
 STATIC_CALLS = {
     ("Math", "pow"): _math_pow,
     ("Math", "abs"): lambda x: abs(x),
@@ -1479,8 +1482,8 @@ STATIC_CALLS = {
     ("FileIO", "getReader"): lambda path: JReader(path),
     ("Strings", "last"): lambda s_, n_: s_[-n_:],
     ("Collections", "sort"): lambda coll: coll.items.sort(key=lambda b: b.v),
-    ("Integer", "getInteger"): lambda name, dflt: Box(int(dflt), "Integer"),      # no -D properties are set in the evaluated runs
-    ("System", "getProperty"): lambda name, dflt=None: dflt,
+    ("Integer", "getInteger"): lambda name, dflt: Box(int(SYSTEM_PROPERTIES.get(name, dflt)), "Integer"),
+    ("System", "getProperty"): lambda name, dflt=None: SYSTEM_PROPERTIES.get(name, dflt),
     ("Double", "parseDouble"): lambda x: _parse_double(x),
     ("Double", "toString"): lambda x: java_str(float(x)),
     ("Arrays", "asList"): lambda *a: JCollection([to_host(x) for x in a]),

@@ -61,6 +61,19 @@ def test_committed_early_stop_run_is_bit_identical_and_scores_the_live_model():
         assert not (a == "trainEpoch" and b == "trainEpoch")                 # ... taken between the epochs, not after the loop
 
 
+def test_committed_sharded_run_uses_the_group_natives_only():
+    """-Dcarskit.shards=2: GpuSupport.buildModelSharded, containers routed through Dev.ofGroup's negative handles"""
+    rec = _ALL["shards_2"]
+    assert all(rec["bit_identical"].values()), rec["bit_identical"]
+    calls = rec["native_calls"]
+    assert calls[0] == "groupCreate" and calls[-1] == "groupDestroy" and all(c.startswith("group") for c in calls)
+    first = calls.index("groupTrainEpoch")
+    assert {"groupSetHparams", "groupSetRatingsCsr", "groupSetMatrix", "groupSetLrScale"} <= set(calls[:first])
+    jni = open(os.path.join(ROOT, "jni", "carskit_jni.cpp")).read()
+    for name in set(calls):
+        assert re.search(r"Java_carskit_alg_gpu_NativeMF_%s\b" % name, jni), name
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "carskit")), reason="needs the reference tree (build container only)")
 def test_drop_ins_execute_bit_identically_to_the_reference_buildmodel():
     from oracle import check_java_binding as chk
@@ -80,3 +93,5 @@ def test_drop_ins_execute_bit_identically_to_the_reference_buildmodel():
     assert all(same.values()) and calls == CHECK["FM"]["native_calls"]
     calls, same = chk.check_early_stop(REF, [c for c in cases if c["model"] == "CAMF_CU"][0])
     assert all(same.values()) and calls == _ALL["early_stop_rmse"]["native_calls"]
+    calls, same = chk.check_group(REF, [c for c in cases if c["model"] == "CAMF_CI"][0])
+    assert all(same.values()) and calls == _ALL["shards_2"]["native_calls"]
