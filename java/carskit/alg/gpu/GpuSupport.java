@@ -77,19 +77,7 @@ final class GpuSupport {
         long h = NativeMF.create(r.modelId(), r.factors(), r.users(), r.items(), r.conditions(), deviceFor(r.foldId()), r.createFlags());
         try {
             DataDAO dao = Recommender.rateDao;
-            SparseMatrix tm = r.contextualTrain();
-            r.prepare(h);
-            if (twoD) {
-                librec.data.SparseMatrix t2 = r.train2D();
-                NativeMF.setRatings2D(h, t2.getRowPointers(), t2.getColumnIndices(), t2.getData());
-            } else {
-                int[][] ui = pairMaps(dao, tm.numRows());
-                int[][] ct = contextTable(r, tm.numColumns());
-                NativeMF.setRatingsCsr(h, tm.getRowPointers(), tm.getColumnIndices(), tm.getData(), ui[0], ui[1], ct[0], ct[1]);
-            }
-            double[] reg = r.regularizers();
-            NativeMF.setHparams(h, reg[0], reg[1], reg[2], reg[3], r.mean());
-            r.copyIn(h);
+            upload(r, h, twoD);
             if (r.evaluatesDuringTraining() && r.contextualTest() != null) {
                 // `--early-stop MAE|RMSE`: isConverged() scores the test set after EVERY epoch; the Java-side containers are
                 // stale until copyOut, so evalRatings() of the drop-in reads the device model instead (evalResident below)
@@ -104,6 +92,47 @@ final class GpuSupport {
             r.copyOut(h);   // predict() / evalRatings() / evalRankings() / saveModel() keep working unchanged afterwards
         } finally {
             r.handle(0L);
+            NativeMF.destroy(h);
+        }
+    }
+
+    /** everything a native call needs before it can train or score: sim params, the rating matrix (and with it the context table),
+     *  hyper-parameters, the model containers */
+    static void upload(GpuHost r, long h, boolean twoD) {
+        DataDAO dao = Recommender.rateDao;
+        SparseMatrix tm = r.contextualTrain();
+        r.prepare(h);
+        if (twoD) {
+            librec.data.SparseMatrix t2 = r.train2D();
+            NativeMF.setRatings2D(h, t2.getRowPointers(), t2.getColumnIndices(), t2.getData());
+        } else {
+            int[][] ui = pairMaps(dao, tm.numRows());
+            int[][] ct = contextTable(r, tm.numColumns());
+            NativeMF.setRatingsCsr(h, tm.getRowPointers(), tm.getColumnIndices(), tm.getData(), ui[0], ui[1], ct[0], ct[1]);
+        }
+        double[] reg = r.regularizers();
+        NativeMF.setHparams(h, reg[0], reg[1], reg[2], reg[3], r.mean());
+        r.copyIn(h);
+    }
+
+    /** -Dcarskit.gpu.rank=true: evalRankings() of the drop-ins scores on the GPU (cmi_eval_rankings) instead of walking
+     *  candidates x queries in Java (Recommender.java:672-955); off by default, `-diverse` stays on the Java path. */
+    static boolean rankOnGpu() { return Boolean.getBoolean("carskit.gpu.rank"); }
+
+    /** evalRankings() on the native side: the model as it stands in the Java object is uploaded to a fresh handle, the train and test
+     *  matrices go over as (u, j, ctx, rate) tuples, the 21 measures come back in Recommender.Measure order. */
+    static Map<Measure, Double> evalRankings(GpuHost r, double binThold, int numRecs, int numIgnore, String evalStrategy) throws Exception {
+        boolean twoD = r.modelId() == NativeMF.BIASEDMF || r.modelId() == NativeMF.PMF || r.modelId() == NativeMF.SVDPP;
+        long h = NativeMF.create(r.modelId(), r.factors(), r.users(), r.items(), r.conditions(), deviceFor(r.foldId()), r.createFlags());
+        try {
+            upload(r, h, twoD);
+            DataDAO dao = Recommender.rateDao;
+            Object[] tr = tuples(r.contextualTrain(), dao), te = tuples(r.contextualTest(), dao);
+            double[] out = NativeMF.evalRankings(h, (int[]) tr[0], (int[]) tr[1], (int[]) tr[2], (double[]) tr[3],
+                                                 (int[]) te[0], (int[]) te[1], (int[]) te[2], (double[]) te[3], binThold, numRecs, numIgnore,
+                                                 evalStrategy.equals("uc") ? NativeMF.RANK_UC : NativeMF.RANK_UCU);
+            return rankingMeasures(out);
+        } finally {
             NativeMF.destroy(h);
         }
     }

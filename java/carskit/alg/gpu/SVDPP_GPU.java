@@ -33,6 +33,12 @@ public class SVDPP_GPU extends SVDPlusPlus implements GpuHost {
         return GpuSupport.evalResident(gpuHandle, minRate, maxRate);           // during buildModel(): the model on the device
     }
 
+    @Override
+    protected Map<Measure, Double> evalRankings() throws Exception {
+        if (!GpuSupport.rankOnGpu() || isDiverseUsed) return super.evalRankings();   // the reference's loop (Recommender.java:672-955)
+        return GpuSupport.evalRankings(this, binThold, numRecs, numIgnore, evalStrategy);   // -Dcarskit.gpu.rank=true: cmi_eval_rankings
+    }
+
     // ---- GpuHost: the protected members of the reference classes GpuSupport needs ----
     public int modelId() { return NativeMF.SVDPP; }
     public int createFlags() { return NativeMF.FLAG_SCHED_SERIAL | NativeMF.FLAG_STATE_F64 | NativeMF.FLAG_STRICT; }

@@ -121,6 +121,20 @@ class Natives:
         ev = self._oracle(d).eval_ratings(u, j, ctx if ctx is not None else np.zeros(len(u), np.int32), r, float(min_rate), float(max_rate))
         return JArray("D", [float(ev[n]) for n in ("MAE", "RMSE", "NMAE", "rMAE", "rRMSE")])
 
+    def n_evalRankings(self, h, tu, tj, tctx, tr, su, sj, sctx, sr, bin_thold, num_recs, num_ignore, strategy):
+        """cmi_eval_rankings: (train tuples, test tuples, threshold, topN, numIgnore, strategy) -> the 21 measures in the order
+        GpuSupport.rankingMeasures unpacks them"""
+        from oracle import rank_oracle
+        d = self.h[int(h)]
+        orc = self._oracle(d)
+        tup = lambda u, j, c, r: list(zip(arr(u, np.int32).tolist(), arr(j, np.int32).tolist(), arr(c, np.int32).tolist(), arr(r, np.float64).tolist()))
+        got, _ = rank_oracle.eval_rankings(lambda a_, b_, c_: orc.predict(a_, b_, c_), tup(tu, tj, tctx, tr), tup(su, sj, sctx, sr),
+                                           bin_thold=float(bin_thold), num_recs=int(num_recs), num_ignore=int(num_ignore),
+                                           strategy="uc" if int(strategy) == self.consts["RANK_UC"] else "ucu")
+        order = ("Pre5", "Pre10", "PreN", "Rec5", "Rec10", "RecN", "AUC5", "AUC10", "AUCN", "MAP5", "MAP10", "MAPN", "NDCG5", "NDCG10", "NDCGN",
+                 "MRR5", "MRR10", "MRRN", "D5", "D10", "DN")
+        return JArray("D", [float(got[m]) for m in order])
+
     def n_trainEpoch(self, h, lrate):
         return float(self._oracle(self.h[int(h)]).epoch(float(lrate)))
 
@@ -372,6 +386,33 @@ def check_group(ref, case, n_shards=2):
     return nat.calls, same
 
 
+def check_rank(ref, case):
+    """-Dcarskit.gpu.rank=true: the drop-in's evalRankings() -> GpuSupport.evalRankings (fresh handle, upload, tuples of the train and test
+    matrices, NativeMF.evalRankings, rankingMeasures) against the reference's own evalRankings() of the same model
+    (tests/golden/reference_rank.json); nDCG within 4 ulp (Math.log), everything else bit for bit."""
+    import math
+    model = case["model"]
+    init = {n: [float.fromhex(x) for x in v] for n, v in case["init"].items()}
+    nat = Natives()
+    cmap = {"NativeMF": nat}
+
+    def make(vm):
+        for n in ("GpuSupport", "Dev", "Rows"):
+            cmap[n] = static_class(vm, n, cmap)
+    javasrc.SYSTEM_PROPERTIES["carskit.gpu.rank"] = "true"
+    try:
+        got = M.run_model(ref, model, case["problem"], case["k"], case["iters"], seed=0, lrate=case["lrate"], bold=case["bold_driver"],
+                          drop_in=(os.path.join(JAVA, DROP_IN[model] + ".java"), cmap, make), init_override=init, rank=case["rank"])
+    finally:
+        javasrc.SYSTEM_PROPERTIES.pop("carskit.gpu.rank", None)
+    assert nat.live == 0
+    same = {}
+    for m, want in case["eval_rankings"]["measures"].items():
+        a, b = float.fromhex(got["eval_rankings"]["measures"][m]), float.fromhex(want)
+        same[m] = (a == b) or (math.isnan(a) and math.isnan(b)) or (m.startswith("NDCG") and abs(a - b) <= 4 * math.ulp(b))
+    return nat.calls, same
+
+
 def check_early_stop(ref, case, measure="RMSE"):
     """`--early-stop RMSE`: the reference's isConverged() calls evalRatings() after every epoch; the drop-in's override answers from the
     live native model (GpuSupport.evalResident) -- setEvalRatings / tuples() / evaluatesDuringTraining() / the handle bookkeeping.  The
@@ -416,6 +457,13 @@ def main():
     out["early_stop_rmse"] = {"model": "CAMF_CU", "native_calls": calls, "bit_identical": same}
     ok = ok and all(same.values())
     print("early stop on RMSE (CAMF_CU_GPU):", "bit-identical" if all(same.values()) else "DIFFERS %s" % same, "natives:", sorted(set(calls)), flush=True)
+    rank_cases = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_rank.json")))["cases"]
+    out["rank_on_gpu"] = {}
+    for rc in rank_cases:
+        calls, same = check_rank(ref, rc)
+        out["rank_on_gpu"][rc["model"]] = {"native_calls": calls, "same_measures": same}
+        ok = ok and all(same.values())
+        print("-Dcarskit.gpu.rank (%s):" % DROP_IN[rc["model"]], "the reference's measures" if all(same.values()) else "DIFFERS %s" % [m for m, v in same.items() if not v], flush=True)
     gr_case = [c for c in cases if c["model"] == "CAMF_CI"][0]
     calls, same = check_group(ref, gr_case)
     out["shards_2"] = {"model": "CAMF_CI", "native_calls": calls, "bit_identical": same}

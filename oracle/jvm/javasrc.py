@@ -215,7 +215,17 @@ class Parser:
             init = None
             if self.at("="):
                 self.eat()
-                init = self.expr_no_comma()
+                if self.at("{"):            # T[] a = {x, y, ...};
+                    self.eat()
+                    items = []
+                    while not self.at("}"):
+                        items.append(self.expr_no_comma())
+                        if self.at(","):
+                            self.eat()
+                    self.eat("}")
+                    init = ("arraylit", ty, items)
+                else:
+                    init = self.expr_no_comma()
             decls.append((name, init))
             if self.at(","):
                 self.eat()
@@ -1484,6 +1494,7 @@ STATIC_CALLS = {
     ("Collections", "sort"): lambda coll: coll.items.sort(key=lambda b: b.v),
     ("Integer", "getInteger"): lambda name, dflt: Box(int(SYSTEM_PROPERTIES.get(name, dflt)), "Integer"),
     ("System", "getProperty"): lambda name, dflt=None: SYSTEM_PROPERTIES.get(name, dflt),
+    ("Boolean", "getBoolean"): lambda name: str(SYSTEM_PROPERTIES.get(name, "false")).lower() == "true",
     ("Double", "parseDouble"): lambda x: _parse_double(x),
     ("Double", "toString"): lambda x: java_str(float(x)),
     ("Arrays", "asList"): lambda *a: JCollection([to_host(x) for x in a]),

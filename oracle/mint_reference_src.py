@@ -274,6 +274,7 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
         measures_cls.static_super = "happy/coding/math/Measures"
         this.class_map = dict(this.class_map, Measures=measures_cls, Lists="happy/coding/io/Lists", Stats="happy/coding/math/Stats")
         F["rateDao"] = source_dao(ref, vm, prob)
+        javasrc.STATIC_FIELDS[("Recommender", "rateDao")] = F["rateDao"]
         F["testMatrix"] = sparse(vm, len(prob["ui_user"]), len(prob["ctx_keys"]), rank["test_cells"])
         F.update({"binThold": float(rank["bin_thold"]), "numRecs": int(rank["num_recs"]), "numIgnore": int(rank["num_ignore"]),
                   "isDiverseUsed": False, "evalStrategy": rank["strategy"], "workingPath": ""})

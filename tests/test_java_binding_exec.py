@@ -74,6 +74,18 @@ def test_committed_sharded_run_uses_the_group_natives_only():
         assert re.search(r"Java_carskit_alg_gpu_NativeMF_%s\b" % name, jni), name
 
 
+def test_committed_gpu_ranking_runs_give_the_reference_measures():
+    """-Dcarskit.gpu.rank=true: evalRankings() of every drop-in through GpuSupport.evalRankings -> NativeMF.evalRankings"""
+    assert set(_ALL["rank_on_gpu"]) == {"BiasedMF", "PMF", "CAMF_C", "CAMF_CI", "CAMF_CU", "CAMF_CUCI", "SVD++", "CAMF_ICS", "CAMF_LCS", "CAMF_MCS"}
+    for model, rec in _ALL["rank_on_gpu"].items():
+        assert len(rec["same_measures"]) == 21 and all(rec["same_measures"].values()), model
+        calls = rec["native_calls"]
+        tail = calls[len(calls) - 1 - calls[::-1].index("create"):]          # the evaluation's own handle
+        assert tail[0] == "create" and tail[-1] == "destroy" and tail[-2] == "evalRankings", (model, tail)
+        assert "setHparams" in tail and any(c.startswith("setRatings") for c in tail) and "setMatrix" in tail
+        assert "trainEpoch" not in tail
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "carskit")), reason="needs the reference tree (build container only)")
 def test_drop_ins_execute_bit_identically_to_the_reference_buildmodel():
     from oracle import check_java_binding as chk
@@ -93,5 +105,8 @@ def test_drop_ins_execute_bit_identically_to_the_reference_buildmodel():
     assert all(same.values()) and calls == CHECK["FM"]["native_calls"]
     calls, same = chk.check_early_stop(REF, [c for c in cases if c["model"] == "CAMF_CU"][0])
     assert all(same.values()) and calls == _ALL["early_stop_rmse"]["native_calls"]
+    rank_case = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_rank.json")))["cases"][0]
+    calls, same = chk.check_rank(REF, rank_case)
+    assert all(same.values()) and calls == _ALL["rank_on_gpu"][rank_case["model"]]["native_calls"]
     calls, same = chk.check_group(REF, [c for c in cases if c["model"] == "CAMF_CI"][0])
     assert all(same.values()) and calls == _ALL["shards_2"]["native_calls"]
