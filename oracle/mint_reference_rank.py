@@ -44,6 +44,17 @@ def main():
         print("%-10s topN=%d thold=%s %s ignore=%d: Pre10 %.4f  MAP10 %.4f  AUC10 %.4f  NDCG10 %.4f  (%d statements)"
               % (model, num_recs, thold, strategy, ignore, float.fromhex(ms["Pre10"]), float.fromhex(ms["MAP10"]), float.fromhex(ms["AUC10"]),
                  float.fromhex(ms["NDCG10"]), rec["eval_rankings"]["statements"]), flush=True)
+    # FM.predict as the scorer (FM.java:76-113) -- the reference's evalRankings() is the same method for every recommender
+    out["fm_cases"] = []
+    for (nu, ni, nd, cpd, n, k, iters, thold) in ((6, 9, 2, 2, 60, 3, 2, -5.0),):
+        prob = M.problem(rng, nu, ni, nd, cpd, n)
+        held = [c for i, c in enumerate(prob["cells"]) if i % 4 == 3]
+        prob["cells"] = [c for i, c in enumerate(prob["cells"]) if i % 4 != 3]
+        rec = M.run_fm(ref, prob, k, iters, seed=int(rng.integers(1 << 30)),
+                       rank={"test_cells": held, "bin_thold": thold, "num_recs": 10, "num_ignore": 0, "strategy": "ucu"})
+        out["fm_cases"].append(rec)
+        ms = rec["eval_rankings"]["measures"]
+        print("FM         topN=10: Pre10 %.4f  MAP10 %.4f  AUC10 %.4f  NDCG10 %.4f" % tuple(float.fromhex(ms[x]) for x in ("Pre10", "MAP10", "AUC10", "NDCG10")), flush=True)
     path = os.path.join(ROOT, "tests", "golden", "reference_rank.json")
     json.dump(out, open(path, "w"), indent=0)
     print("wrote", path)

@@ -302,9 +302,11 @@ def run_model(ref, model, prob, k, iters, seed, lrate=0.02, reg=1e-4, reg_c=1e-3
     return rec
 
 
-def run_fm(ref, prob, k, iters, seed, reg_lw=0.01, reg_lf=0.02):
-    """FM.buildModel (FM.java:115-220: the dense ALS / coordinate-descent sweep) from source; state = (w0, w, V)"""
-    vm = VM(os.path.join(ref, "lib", "librec-v1.4-alpha.jar"))
+def run_fm(ref, prob, k, iters, seed, reg_lw=0.01, reg_lf=0.02, rank=None):
+    """FM.buildModel (FM.java:115-220: the dense ALS / coordinate-descent sweep) from source; state = (w0, w, V); rank: also
+    Recommender.evalRankings() with FM.predict as the scorer"""
+    vm = VM([os.path.join(ref, "lib", "librec-v1.4-alpha.jar"), os.path.join(ref, "lib", "happy.coding.utils-1.2.6.jar")] if rank else
+            os.path.join(ref, "lib", "librec-v1.4-alpha.jar"))
     rng = np.random.default_rng(seed)
     nu, ni, nc = prob["n_users"], prob["n_items"], prob["n_conds"]
     p = nu + ni + nc
@@ -319,6 +321,18 @@ def run_fm(ref, prob, k, iters, seed, reg_lw=0.01, reg_lf=0.02):
               "numConditions": nc, "loss": 0.0, "trainMatrix": sparse(vm, len(prob["ui_user"]), len(prob["ctx_keys"]), prob["cells"]),
               "rateDao": RateDao(prob["ui_user"], prob["ui_item"], prob["ctx_keys"]), "verbose": False})
     this.call("buildModel", [])
+    ranks = None
+    if rank:
+        measures_cls = javasrc.This(vm, [os.path.join(ref, "src", "carskit", "eval", "Measures.java")], {})
+        measures_cls.static_super = "happy/coding/math/Measures"
+        this.class_map = dict(this.class_map, Measures=measures_cls, Lists="happy/coding/io/Lists", Stats="happy/coding/math/Stats")
+        F["rateDao"] = source_dao(ref, vm, prob)
+        F.update({"testMatrix": sparse(vm, len(prob["ui_user"]), len(prob["ctx_keys"]), rank["test_cells"]), "binThold": float(rank["bin_thold"]),
+                  "numRecs": int(rank["num_recs"]), "numIgnore": int(rank["num_ignore"]), "isDiverseUsed": False, "evalStrategy": rank["strategy"],
+                  "workingPath": "", "isResultsOut": False, "isUserSplitting": False, "isItemSplitting": False, "algoName": "FM", "foldInfo": "",
+                  "__enums__": ("Measure",)})
+        m = this.call("evalRankings", [])
+        ranks = {"measures": {key.name: hx(val.v if isinstance(val, Box) else val) for key, val in m.d.items()}}
     preds = []
     for ui, c, _ in prob["cells"][:12]:
         u_, j_ = prob["ui_user"][ui], prob["ui_item"][ui]
@@ -328,7 +342,7 @@ def run_fm(ref, prob, k, iters, seed, reg_lw=0.01, reg_lf=0.02):
             "init": {"w": [hx(x) for x in w], "V": [hx(x) for x in V.ravel()]},
             "final": {"w0": hx(F["w0"]), "w": [hx(x) for x in to_list(F["w"].fields["data"])],
                       "V": [hx(x) for row in to_list(F["V"].fields["data"]) for x in row]},
-            "final_loss": hx(F["loss"]), "predictions": preds,
+            "final_loss": hx(F["loss"]), "predictions": preds, "rank": rank, "eval_rankings": ranks,
             "java_statements_executed": this.statements, "bytecode_instructions": vm.steps}
 
 

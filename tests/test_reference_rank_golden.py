@@ -81,3 +81,56 @@ def test_gpu_eval_rankings_reproduces_the_interpreted_evalrankings(case):
     want = {m: fx(v) for m, v in case["eval_rankings"]["measures"].items()}
     for m in rank_oracle.MEASURES:
         assert (math.isnan(res[m]) and math.isnan(want[m])) or abs(res[m] - want[m]) <= 1e-12, (m, res[m], want[m])
+
+
+# ---- FM.predict as the scorer: the reference's evalRankings() is one method for every recommender
+FM_CASES = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_rank.json")))["fm_cases"]
+
+
+def _fm_trained_oracle(case):
+    from tests.test_reference_src_golden import _fm_inputs
+    u, j, ctx, r, w, V = _fm_inputs(case)
+    p = case["problem"]
+    orc = oracle_c.FMOracle(case["k"], p["n_users"], p["n_items"], p["n_conds"], case["n_ctx_dims"], u, j, ctx, r, 0.0, w, V, case["regLw"],
+                            case["regLf"])
+    orc.init()
+    for _ in range(case["iters"]):
+        orc.sweep()
+    assert [float(x).hex() for x in orc.V.ravel()] == case["final"]["V"]      # the model the reference ranked with
+    return orc, (u, j, ctx, r)
+
+
+@pytest.mark.parametrize("case", FM_CASES, ids=lambda c: "FM-k%d" % c["k"])
+def test_fm_rank_oracle_reproduces_the_interpreted_evalrankings(case):
+    orc, _ = _fm_trained_oracle(case)
+    p, rk = case["problem"], case["rank"]
+    got, _ = rank_oracle.eval_rankings(lambda a, b, c: orc.predict(a, b, c), _cells_to_tuples(p, p["cells"]), _cells_to_tuples(p, rk["test_cells"]),
+                                       bin_thold=rk["bin_thold"], num_recs=rk["num_recs"], strategy=rk["strategy"], num_ignore=rk["num_ignore"])
+    for m in rank_oracle.MEASURES:
+        want = fx(case["eval_rankings"]["measures"][m])
+        if m.startswith("NDCG"):
+            assert abs(got[m] - want) <= 4 * math.ulp(want), m
+        else:
+            assert (math.isnan(got[m]) and math.isnan(want)) or float(got[m]).hex() == float(want).hex(), (m, got[m], want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FM_CASES, ids=lambda c: "FM-k%d" % c["k"])
+def test_gpu_fm_eval_rankings_reproduces_the_interpreted_evalrankings(case):
+    """cmi_fm_eval_rankings on the reference's final FM model (set directly: the ALS kernels are held to 1e-7 elsewhere)"""
+    from carskit_amd import capi
+    p, rk = case["problem"], case["rank"]
+    pp = p["n_users"] + p["n_items"] + p["n_conds"]
+    g = capi.FMInstance(case["k"], p["n_users"], p["n_items"], p["n_conds"], case["n_ctx_dims"])
+    g.set_hparams(case["regLw"], case["regLf"])
+    tr = _cells_to_tuples(p, p["cells"])
+    te = _cells_to_tuples(p, rk["test_cells"])
+    arr = lambda t: (np.array([x[0] for x in t], np.int32), np.array([x[1] for x in t], np.int32), np.array([x[2] for x in t], np.int32),
+                     np.array([x[3] for x in t]))
+    g.set_ratings(*arr(tr))
+    g.set_model(fx(case["final"]["w0"]), np.array([fx(x) for x in case["final"]["w"]]),
+                np.array([fx(x) for x in case["final"]["V"]]).reshape(pp, case["k"]))
+    res = g.eval_rankings(arr(tr), arr(te), bin_thold=rk["bin_thold"], num_recs=rk["num_recs"], num_ignore=rk["num_ignore"], strategy=rk["strategy"])
+    for m in rank_oracle.MEASURES:
+        want = fx(case["eval_rankings"]["measures"][m])
+        assert (math.isnan(res[m]) and math.isnan(want)) or abs(res[m] - want) <= 1e-9, (m, res[m], want)
