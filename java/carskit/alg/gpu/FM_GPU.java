@@ -12,6 +12,7 @@ import carskit.data.structure.SparseMatrix;
 import carskit.generic.ContextRecommender;
 import librec.data.DenseMatrix;
 import librec.data.DenseVector;
+import java.util.Map;
 
 public class FM_GPU extends ContextRecommender {
     private double w0;
@@ -50,6 +51,25 @@ public class FM_GPU extends ContextRecommender {
             NativeMF.fmSetModel(h, w0, w.getData(), Rows.of(V));
             NativeMF.fmTrain(h, numIters);                       // replaces FM.java:115-220 (no early stop there either)
             w0 = NativeMF.fmGetModel(h, w.getData(), Rows.of(V));
+        } finally {
+            NativeMF.fmDestroy(h);
+        }
+    }
+
+    @Override
+    protected Map<Measure, Double> evalRankings() throws Exception {
+        if (!GpuSupport.rankOnGpu() || isDiverseUsed) return super.evalRankings();   // the reference's loop (Recommender.java:672-955)
+        long h = NativeMF.fmCreate(k, numUsers, numItems, numConditions, rateDao.numContextDims(), GpuSupport.deviceFor(fold), 0);
+        try {                                                                         // -Dcarskit.gpu.rank=true: cmi_fm_eval_rankings
+            int[][] ui = GpuSupport.pairMaps(rateDao, trainMatrix.numRows());
+            NativeMF.fmSetHparams(h, regLw, regLf, trainMatrix.size());
+            NativeMF.fmSetRatingsCsr(h, trainMatrix.getRowPointers(), trainMatrix.getColumnIndices(), trainMatrix.getData(), ui[0], ui[1]);
+            NativeMF.fmSetModel(h, w0, w.getData(), Rows.of(V));
+            Object[] tr = GpuSupport.tuples(trainMatrix, rateDao), te = GpuSupport.tuples(testMatrix, rateDao);
+            double[] out = NativeMF.fmEvalRankings(h, (int[]) tr[0], (int[]) tr[1], (int[]) tr[2], (double[]) tr[3],
+                                                   (int[]) te[0], (int[]) te[1], (int[]) te[2], (double[]) te[3], binThold, numRecs, numIgnore,
+                                                   evalStrategy.equals("uc") ? NativeMF.RANK_UC : NativeMF.RANK_UCU);
+            return GpuSupport.rankingMeasures(out);
         } finally {
             NativeMF.fmDestroy(h);
         }

@@ -191,12 +191,64 @@ class FMNatives(Natives):
             orc.sweep()
         d["orc"] = orc
 
+    def n_fmEvalRankings(self, h, tu, tj, tctx, tr, su, sj, sctx, sr, bin_thold, num_recs, num_ignore, strategy):
+        from oracle import rank_oracle
+        d = self.h[int(h)]
+        u, j, ctx, r = d["tuples"]
+        w0, w, V = d["model"]
+        orc = oracle_c.FMOracle(d["k"], d["nu"], d["ni"], d["nc"], d["dims"], u, j, ctx, r, w0, w, V, d["hp"][0], d["hp"][1])
+        tup = lambda a_, b_, c_, r_: list(zip(arr(a_, np.int32).tolist(), arr(b_, np.int32).tolist(), arr(c_, np.int32).tolist(), arr(r_, np.float64).tolist()))
+        got, _ = rank_oracle.eval_rankings(lambda a_, b_, c_: orc.predict(a_, b_, c_), tup(tu, tj, tctx, tr), tup(su, sj, sctx, sr),
+                                           bin_thold=float(bin_thold), num_recs=int(num_recs), num_ignore=int(num_ignore),
+                                           strategy="uc" if int(strategy) == self.consts["RANK_UC"] else "ucu")
+        order = ("Pre5", "Pre10", "PreN", "Rec5", "Rec10", "RecN", "AUC5", "AUC10", "AUCN", "MAP5", "MAP10", "MAPN", "NDCG5", "NDCG10", "NDCGN",
+                 "MRR5", "MRR10", "MRRN", "D5", "D10", "DN")
+        return JArray("D", [float(got[m]) for m in order])
+
     def n_fmGetModel(self, h, w, v_rows):
         orc = self.h[int(h)]["orc"]
         (w.data if isinstance(w, JArray) else w)[:] = [float(x) for x in orc.w]
         for row, src in zip(v_rows, orc.V):
             (row.data if isinstance(row, JArray) else row)[:] = [float(x) for x in src]
         return float(orc.w0)
+
+
+def check_fm_rank(ref, case):
+    """FM_GPU.evalRankings() with -Dcarskit.gpu.rank=true on the reference's trained FM model, against the reference's own evalRankings()"""
+    import math
+    from oracle.jvm.interp import VM
+    vm = VM([os.path.join(ref, "lib", "librec-v1.4-alpha.jar"), os.path.join(ref, "lib", "happy.coding.utils-1.2.6.jar")])
+    prob, k, rk = case["problem"], case["k"], case["rank"]
+    nu, ni, nc = prob["n_users"], prob["n_items"], prob["n_conds"]
+    nat = FMNatives()
+    cmap = dict(M.CLASS_MAP, NativeMF=nat)
+    for n in ("GpuSupport", "Dev", "Rows"):
+        cmap[n] = static_class(vm, n, cmap)
+    src = [os.path.join(JAVA, "FM_GPU.java")] + [os.path.join(ref, "src", "carskit", "generic", q) for q in
+                                                   ("ContextRecommender.java", "IterativeRecommender.java", "Recommender.java")]
+    this = javasrc.This(vm, src, cmap)
+    fin = case["final"]
+    V = np.array([float.fromhex(x) for x in fin["V"]]).reshape(nu + ni + nc, k)
+    dao = M.source_dao(ref, vm, prob)
+    javasrc.STATIC_FIELDS[("Recommender", "rateDao")] = dao
+    this.fields.update({"w0": float.fromhex(fin["w0"]), "p": nu + ni + nc, "k": k, "w": M.vector(vm, [float.fromhex(x) for x in fin["w"]]),
+                        "V": M.dense(vm, V), "regLw": M.f32(case["regLw"]), "regLf": M.f32(case["regLf"]), "numFactors": k, "numUsers": nu,
+                        "numItems": ni, "numConditions": nc, "fold": 1, "rateDao": dao, "isDiverseUsed": False,
+                        "trainMatrix": M.sparse(vm, len(prob["ui_user"]), len(prob["ctx_keys"]), prob["cells"]),
+                        "testMatrix": M.sparse(vm, len(prob["ui_user"]), len(prob["ctx_keys"]), rk["test_cells"]),
+                        "binThold": float(rk["bin_thold"]), "numRecs": int(rk["num_recs"]), "numIgnore": int(rk["num_ignore"]),
+                        "evalStrategy": rk["strategy"], "__enums__": ("Measure",)})
+    javasrc.SYSTEM_PROPERTIES["carskit.gpu.rank"] = "true"
+    try:
+        m = this.call("evalRankings", [])
+    finally:
+        javasrc.SYSTEM_PROPERTIES.pop("carskit.gpu.rank", None)
+    assert nat.live == 0
+    same = {}
+    for key, val in m.d.items():
+        a, b = float(javasrc.unbox(val)), float.fromhex(case["eval_rankings"]["measures"][key.name])
+        same[key.name] = (a == b) or (math.isnan(a) and math.isnan(b)) or (key.name.startswith("NDCG") and abs(a - b) <= 4 * math.ulp(b))
+    return nat.calls, same
 
 
 def check_fm(ref, case):
@@ -464,6 +516,11 @@ def main():
         out["rank_on_gpu"][rc["model"]] = {"native_calls": calls, "same_measures": same}
         ok = ok and all(same.values())
         print("-Dcarskit.gpu.rank (%s):" % DROP_IN[rc["model"]], "the reference's measures" if all(same.values()) else "DIFFERS %s" % [m for m, v in same.items() if not v], flush=True)
+    fm_rank_case = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_rank.json")))["fm_cases"][0]
+    calls, same = check_fm_rank(ref, fm_rank_case)
+    out["rank_on_gpu"]["FM"] = {"native_calls": calls, "same_measures": same}
+    ok = ok and all(same.values())
+    print("-Dcarskit.gpu.rank (FM_GPU):", "the reference's measures" if all(same.values()) else "DIFFERS %s" % [m for m, v in same.items() if not v], flush=True)
     gr_case = [c for c in cases if c["model"] == "CAMF_CI"][0]
     calls, same = check_group(ref, gr_case)
     out["shards_2"] = {"model": "CAMF_CI", "native_calls": calls, "bit_identical": same}

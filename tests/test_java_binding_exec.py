@@ -76,10 +76,14 @@ def test_committed_sharded_run_uses_the_group_natives_only():
 
 def test_committed_gpu_ranking_runs_give_the_reference_measures():
     """-Dcarskit.gpu.rank=true: evalRankings() of every drop-in through GpuSupport.evalRankings -> NativeMF.evalRankings"""
-    assert set(_ALL["rank_on_gpu"]) == {"BiasedMF", "PMF", "CAMF_C", "CAMF_CI", "CAMF_CU", "CAMF_CUCI", "SVD++", "CAMF_ICS", "CAMF_LCS", "CAMF_MCS"}
+    assert set(_ALL["rank_on_gpu"]) == {"BiasedMF", "PMF", "CAMF_C", "CAMF_CI", "CAMF_CU", "CAMF_CUCI", "SVD++", "CAMF_ICS", "CAMF_LCS", "CAMF_MCS",
+                                         "FM"}
     for model, rec in _ALL["rank_on_gpu"].items():
         assert len(rec["same_measures"]) == 21 and all(rec["same_measures"].values()), model
         calls = rec["native_calls"]
+        if model == "FM":
+            assert calls == ["fmCreate", "fmSetHparams", "fmSetRatingsCsr", "fmSetModel", "fmEvalRankings", "fmDestroy"]
+            continue
         tail = calls[len(calls) - 1 - calls[::-1].index("create"):]          # the evaluation's own handle
         assert tail[0] == "create" and tail[-1] == "destroy" and tail[-2] == "evalRankings", (model, tail)
         assert "setHparams" in tail and any(c.startswith("setRatings") for c in tail) and "setMatrix" in tail
@@ -108,5 +112,7 @@ def test_drop_ins_execute_bit_identically_to_the_reference_buildmodel():
     rank_case = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_rank.json")))["cases"][0]
     calls, same = chk.check_rank(REF, rank_case)
     assert all(same.values()) and calls == _ALL["rank_on_gpu"][rank_case["model"]]["native_calls"]
+    calls, same = chk.check_fm_rank(REF, json.load(open(os.path.join(ROOT, "tests", "golden", "reference_rank.json")))["fm_cases"][0])
+    assert all(same.values()) and calls == _ALL["rank_on_gpu"]["FM"]["native_calls"]
     calls, same = chk.check_group(REF, [c for c in cases if c["model"] == "CAMF_CI"][0])
     assert all(same.values()) and calls == _ALL["shards_2"]["native_calls"]
