@@ -329,7 +329,9 @@ __global__ __launch_bounds__(64) void sgd_camfc_pipe(SgdArgs<T> a, int64_t n, do
 } // namespace
 
 // <= 64 conditions (one per lane), <= 8 context dimensions (one byte each in the packed word), k <= 256
-bool camfc_pipe_supported(int k, int n_conds, int dmax) { return k >= 1 && k <= 256 && n_conds <= 64 && dmax <= 8 && !getenv("CMI_NO_CAMFC_PIPE"); }
+bool camfc_pipe_supported(int k, int n_conds, int dmax) {
+    return k >= 1 && k <= 256 && n_conds <= 64 && dmax >= 1 && dmax <= 8 && !getenv("CMI_NO_CAMFC_PIPE");
+}
 
 template <typename T>
 hipError_t launch_camfc_pipe(const SgdArgs<T> &a, int64_t n, double *loss_out, hipStream_t s) {

@@ -1902,7 +1902,7 @@ hipError_t launch_camfc_blocks(const SgdArgs<T> &a, const int32_t *blk_off, int 
     const size_t lds = camfc_blocks_lds(a.n_conds, a.dmax, sizeof(T));
     // chain form: 1 = condBias in a register (<= 64 conditions), 2 = lean LDS chain (any number), 0 = the round-2 LDS chain (dmax > 8, or
     // CMI_CAMFC_LDS_CHAIN=1 for A/B runs)
-    const int ch = (a.dmax > 8 || getenv("CMI_CAMFC_LDS_CHAIN")) ? 0 : (a.n_conds <= 64 && !getenv("CMI_CAMFC_NO_RC")) ? 1 : 2;
+    const int ch = (a.dmax > 8 || a.dmax < 1 || getenv("CMI_CAMFC_LDS_CHAIN")) ? 0 : (a.n_conds <= 64 && !getenv("CMI_CAMFC_NO_RC")) ? 1 : 2;
 #define CMI_CAMFC_LAUNCH(NV)                                                                                                              \
     do {                                                                                                                                  \
         if (ch == 1) hipLaunchKernelGGL((sgd_camfc_blocks<T, NV, 1>), dim3(1), dim3(1024), lds, s, a, blk_off, n_blocks, loss_out);      \

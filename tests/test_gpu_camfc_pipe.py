@@ -94,3 +94,27 @@ def test_pipe_and_the_one_ahead_wave_agree():
     np.testing.assert_allclose(la, lb, rtol=2e-5)
     for name, x in a.get_states().items():
         assert np.max(np.abs(x - b.get_state(name))) <= 2e-4, name
+
+
+def test_camf_c_without_context_dimensions_takes_the_general_paths():
+    """dmax = 0 (every rating in the one context that has no condition): the dimension-specialised chains do not apply; = the oracle"""
+    from oracle import oracle_c
+    rng = np.random.default_rng(5)
+    nu, ni, n, k = 50, 40, 900, 16
+    u, j = rng.integers(nu, size=n).astype(np.int32), rng.integers(ni, size=n).astype(np.int32)
+    ctx, r = np.zeros(n, np.int32), rng.integers(1, 6, size=n).astype(np.float64)
+    ctx_ptr, ctx_conds = np.zeros(2, np.int32), np.zeros(0, np.int32)
+    for flags in (F64, 0):
+        st = {"P": 0.1 * rng.standard_normal((nu, k)), "Q": 0.1 * rng.standard_normal((ni, k)), "userBias": 0.1 * rng.standard_normal(nu),
+              "itemBias": 0.1 * rng.standard_normal(ni), "condBias": 0.1 * rng.standard_normal(1)}
+        gm = float(r.mean())
+        orc = oracle_c.Oracle("CAMF_C", k, nu, ni, 1, u, j, ctx, r, ctx_ptr, ctx_conds, {a_: b_.copy() for a_, b_ in st.items()}, gm, util.REG,
+                              util.REG, util.REG, util.REGC)
+        inst = capi.Instance("CAMF_C", k, nu, ni, 1, flags=SERIAL | flags)
+        inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, gm)
+        inst.set_ratings(u, j, ctx, r, ctx_ptr, ctx_conds)
+        inst.set_states(st)
+        for _ in range(2):
+            lo, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
+            assert abs(lo - lg) <= (1e-11 if flags else 3e-5) * abs(lo)
+        assert_state_equal(orc, inst, exact=False, atol=1e-10 if flags else 3e-4)
