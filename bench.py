@@ -220,25 +220,33 @@ def bench_fm(args):
     g.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     phases = 4 + 3 * k
-    # the REFERENCE algorithm's compulsory traffic per rating and sweep: every phase reads and writes errors[],
-    # every factor phase also one Q column entry.  This implementation does not store Q at all and moves far fewer bytes; what
-    # bounds it is the rate of random 16-byte gathers of the item / context phases (one per rating and factor), not HBM bandwidth.
+    lay = g.layout()
+    # the dominant kernel: the reduce launch of a factor's user / item phase (64 + 64 of the ~455 launches of a sweep, 80 % of its time),
+    # timed with HIP events on the instance's stream (it only writes scratch).  Bytes = what THIS implementation has to move per
+    # launch (cmi_fm_layout: 16-byte records streamed once, piece offsets, chunk table, partial sums, one L2 fill of every table
+    # slice per XCD) -- not the reference algorithm's errors[] + Q traffic, which it never generates.
+    ku, ki = g.time_reduce(4 + 3 * (k // 2) + 0, 10) * 1e-3, g.time_reduce(4 + 3 * (k // 2) + 1, 10) * 1e-3
+    bytes_launch = 0.5 * (lay["bytes_reduce_user"] + lay["bytes_reduce_item"])
+    kern = 0.5 * (ku + ki)
+    sweep_bytes = lay["bytes_per_factor"] * (k + 1)
     ref_bytes = 16 * (3 + 3 * k) + 16 * 3 * k
-    gathers = data.n * (1 + 2 * k)        # item + context phases gather {error, V[user][f]} per rating (the user phase streams)
     out = {"metric": "FM ALS rating-sweeps/sec, k=%d" % k, "value": data.n / dt, "unit": "rating-sweeps/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
            "config": {"workload": "c4 share: FM k=%d, %d users x %d items x %d conditions, %d ratings (one GPU of BASELINE configs[3])"
                                   % (k, data.n_users, data.n_items, data.n_conds, data.n), "phases_per_sweep": phases},
-           "roofline": {"bound": "hbm", "achieved": data.n * ref_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": data.n * ref_bytes / dt / 1e9 / HBM_PEAK_GBS,
-                        "bytes_model": "the reference ALGORITHM's compulsory traffic (errors[] r+w per phase, one Q entry r+w per factor phase): "
-                                       "%d B per rating-sweep; this implementation never stores Q, so its real traffic is far lower" % ref_bytes,
-                        "limiter": "random 16-byte gather rate of the item / context phases",
-                        "gathers_per_s": gathers / dt, "gather_rate_ceiling_per_s": 54e9,
-                        "gather_frac": gathers / dt / 54e9,
-                        "gather_ceiling_source": "tools/micro/atomic_f64.hip, tools/micro/gather_window.hip (53-56 G random 16-B gathers/s on this part)",
-                        "kernel": "fm_field_phase (item / context field), fm_user_phase", "avg_phase_us": dt * 1e6 / phases}}
+           "roofline": {"bound": "hbm", "achieved": bytes_launch / kern / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_launch / kern / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "fm_reduce_kernel<0|1,false> (one factor's user / item phase)",
+                        "kernel_us": {"user_field": ku * 1e6, "item_field": ki * 1e6}, "bytes_per_launch": bytes_launch,
+                        "bytes_per_rating_phase": bytes_launch / data.n,
+                        "bytes_model": "this implementation's own traffic per reduce launch (cmi_fm_layout): records 16 B x %d, piece offsets, chunk "
+                                       "table, partial sums, table-slice fills; the reference ALGORITHM's errors[] + Q traffic would be %d B per "
+                                       "rating-sweep (never generated here)" % (data.n, ref_bytes),
+                        "whole_sweep_GBps": sweep_bytes / dt / 1e9, "whole_sweep_frac": sweep_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                        "limiter": "L2 request rate of the 16-byte table gathers (one per rating and phase, L2 hits by construction): with the "
+                                   "gathers pointed at one cache line the same launch takes ~80 us = 5 TB/s of streaming (DESIGN.md 5)",
+                        "layout": lay, "avg_phase_us": dt * 1e6 / phases}}
     g.close()
     return out
 

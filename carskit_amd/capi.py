@@ -155,6 +155,8 @@ SYMBOLS = [
     ("cmi_fm_phase_buffer", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64)]),
     ("cmi_fm_phase_apply", C.c_int, [_vp, C.c_int]),
     ("cmi_fm_phase_run", C.c_int, [_vp, C.c_int]),
+    ("cmi_fm_layout", C.c_int, [_vp, _vp]),
+    ("cmi_fm_time_reduce", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_dbl)]),
 ]
 
 _LIB = None
@@ -812,6 +814,19 @@ class FMInstance:
 
     def synchronize(self):
         self._chk(self.L.cmi_fm_synchronize(self.h))
+
+    def layout(self):
+        out = np.zeros(12, np.int64)
+        self._chk(self.L.cmi_fm_layout(self.h, _p(out)))
+        keys = ("slices_user_order", "slices_item_order", "records_user_order", "records_item_order", "records_ctx_order",
+                "chunks_user_order", "chunks_item_order", "bytes_per_factor", "bytes_reduce_user", "bytes_reduce_item",
+                "slice_entries", "p")
+        return dict(zip(keys, out.tolist()))
+
+    def time_reduce(self, phase, reps=10):
+        ms = _dbl()
+        self._chk(self.L.cmi_fm_time_reduce(self.h, phase, reps, C.byref(ms)))
+        return ms.value
 
     def stream_ptr(self):
         p = _vp()

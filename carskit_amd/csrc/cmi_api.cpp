@@ -30,6 +30,7 @@ static thread_local std::string g_create_err;
 // cannot be opened the epoch still runs, and its waits stay bounded.
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 struct OwnerDeviceLock {
     static constexpr int MAX_DEV = 64;
@@ -44,13 +45,27 @@ struct OwnerDeviceLock {
         if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", dev);
         for (char *c = bus; *c; ++c)
             if (*c == ':' || *c == '/' || *c == '.') *c = '_';
-        const char *dir = getenv("TMPDIR");
-        char path[256];
-        snprintf(path, sizeof path, "%s/cmi_owner_epoch_%s.lock", dir && *dir ? dir : "/tmp", bus);
-        fd = open(path, O_CREAT | O_RDWR, 0666);
-        if (fd >= 0 && flock(fd, LOCK_EX) != 0) {
-            close(fd);
-            fd = -1;
+        // a per-uid directory (0700) under $TMPDIR, so the lock file is neither world-writable nor at a path another user can plant
+        // a symlink on; O_NOFOLLOW refuses a planted link anyway, O_CLOEXEC keeps the descriptor out of forked children
+        const char *tmp = getenv("TMPDIR");
+        char dir[200], path[300];
+        snprintf(dir, sizeof dir, "%s/cmi_locks_%u", tmp && *tmp ? tmp : "/tmp", (unsigned)getuid());
+        (void)mkdir(dir, 0700);
+        snprintf(path, sizeof path, "%s/owner_epoch_%s.lock", dir, bus);
+        fd = open(path, O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600);
+        // bounded wait: a stopped or hung peer holding the lock must not block this process for ever.  An owner epoch
+        // lasts well under a second; after ~20 s of polling the epoch proceeds without the cross-process lock -- its device-side
+        // waits are bounded too, so the worst case is a slow epoch, not a hang.
+        if (fd >= 0) {
+            bool got = false;
+            for (int tries = 0; tries < 2000 && !got; ++tries) {
+                if (flock(fd, LOCK_EX | LOCK_NB) == 0) got = true;
+                else usleep(10000);
+            }
+            if (!got) {
+                close(fd);
+                fd = -1;
+            }
         }
     }
     ~OwnerDeviceLock() {
@@ -283,6 +298,7 @@ extern "C" int cmi_set_sim_params(cmi_handle h, int num_f, int n_ctx_dims, const
     CMI_HIP(h, hipSetDevice(h->device));
     CMI_HIP(h, hipStreamSynchronize(h->stream));
     h->n_ctx_dims = n_ctx_dims;
+    h->sim_params_set = true;
     h->empty_conds.assign(empty_conds, empty_conds + n_empty);
     if (h->d_empty) hipFree(h->d_empty);
     h->d_empty = nullptr;
@@ -382,7 +398,12 @@ extern "C" int cmi_get_state(cmi_handle h, int which, void *dst, int64_t count, 
 extern "C" int cmi_state_device_ptr(cmi_handle h, int which, void **ptr, int64_t *count, int *dtype) {
     if (!h || which < 0 || which >= CMI_STATE_COUNT) return CMI_E_INVALID;
     if (!cmi_model_has(h->model, which)) CMI_FAIL(h, CMI_E_INVALID, "state %d does not exist in model %d", which, h->model);
-    if (int rc = cmi_sync_table_from_arena(h)) return rc; // (spoke arena: the table is current as of this call only)
+    if (int rc = cmi_sync_table_from_arena(h)) return rc;
+    // The header documents this pointer for the host's in-place epoch-boundary exchange, i.e. the host may WRITE the table.  With
+    // the spoke arena holding the live rows of this container, such a write would be lost (the next epoch reads the arena and the
+    // following gather overwrites the table), so handing the pointer out makes the table the master copy: the next epoch
+    // re-scatters it into the arena (one streaming pass; only paid by hosts that ask for the pointer of the arena's container).
+    if (h->arena_on && which == h->arena_which) h->arena_valid = false;
     if (ptr) *ptr = h->state[which];
     if (count) *count = h->state_count[which];
     if (dtype) *dtype = h->f64 ? CMI_DTYPE_F64 : CMI_DTYPE_F32;

@@ -77,6 +77,7 @@ struct cmi_instance {
     std::vector<int64_t> x_off;     // their element offsets (16-byte aligned segments)
     // SVD++ / CAMF_*CS (ext_kernels.hip)
     int num_f = 0, n_ctx_dims = 1;
+    bool sim_params_set = false; // cmi_set_sim_params has run (an EMPTY EmptyContextConditions list is a valid setting)
     std::vector<int32_t> empty_conds;
     int32_t *d_empty = nullptr, *d_ui_ptr = nullptr, *d_ui_items = nullptr;
     float last_rank_ms = 0.f;    // device time of the most recent cmi_eval_rankings scoring loop (HIP events)

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -15,20 +16,30 @@
 
 using namespace cmi;
 
+// one field's stream on the device (fm_kernels.hpp FmOrder) and what owns it
+struct FmOrderDev {
+    FmRec *rec = nullptr;
+    int32_t *piece_off = nullptr, *xoff = nullptr;
+    FmChunk *chunks = nullptr;
+    double2 *partial = nullptr;
+    int32_t n_chunks = 0, count = 0, S = 1, n_x = 0;
+    int64_t n_rec = 0;
+};
+
 struct cmi_fm_instance {
     int k = 0, n_users = 0, n_items = 0, n_conds = 0, n_ctx_dims = 1, device = 0;
     int64_t p = 0, n = 0, global_size = 0;
     std::string err;
     hipStream_t stream = nullptr;
-    double *d_w0 = nullptr, *d_w = nullptr, *d_V = nullptr;
+    double *d_w0 = nullptr, *d_d0 = nullptr, *d_w = nullptr, *d_V = nullptr, *d_Vt = nullptr;
+    bool v_valid = true, vt_valid = false; // which of V (p x k) / Vt (k x p) holds the current factors
     double *d_r = nullptr, *d_part = nullptr, *d_scratch = nullptr;
-    double2 *d_R = nullptr, *d_tab = nullptr;
-    int32_t *d_u = nullptr, *d_j = nullptr, *d_ctx = nullptr, *d_sup[3] = {}, *d_sup_a[3] = {}, *d_sup_b[3] = {};
-    bool pend_j_set = false, pend_c_set = false; // item / context deltas not yet folded into errors[]
-    int col_f = -1;                               // factor whose column is loaded in d_tab[].x
-    int uval_f = -1;                              // factor whose user entries are in d_R[].y
-    int64_t *d_off[3] = {};
+    double2 *d_tab = nullptr;
+    int32_t *d_u = nullptr, *d_j = nullptr, *d_ctx = nullptr, *d_i2u = nullptr, *d_c2u = nullptr;
+    FmOrderDev ord[3];
+    int col_f = -1; // factor whose column is loaded in d_tab[].x
     int64_t part_count = 0;
+    int64_t slice_entries = 131072; // table entries (16 bytes each) a slice of the other field may gather: 2 MB stays L2-resident (measured best of 16 K .. 256 K)
     double regLw = 0, regLf = 0;
     bool have_ratings = false, have_model = false, initialised = false;
     int last_phase = -1;
@@ -52,18 +63,17 @@ static thread_local std::string g_fm_create_err;
 extern "C" const char *cmi_fm_last_error(cmi_fm_handle h) { return h ? h->err.c_str() : g_fm_create_err.c_str(); }
 
 static void fm_free_ratings(cmi_fm_instance *h) {
-    void *ptrs[] = {h->d_R, h->d_r, h->d_u, h->d_j, h->d_ctx, h->d_sup[1], h->d_sup[2], h->d_sup_a[1], h->d_sup_a[2],
-                    h->d_sup_b[1], h->d_sup_b[2], h->d_off[0], h->d_off[1], h->d_off[2]};
+    void *ptrs[] = {h->d_r, h->d_u, h->d_j, h->d_ctx, h->d_i2u, h->d_c2u};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    h->d_R = nullptr;
     h->d_r = nullptr;
-    h->d_u = h->d_j = h->d_ctx = nullptr;
-    for (int f = 0; f < 3; ++f) {
-        h->d_sup[f] = h->d_sup_a[f] = h->d_sup_b[f] = nullptr;
-        h->d_off[f] = nullptr;
+    h->d_u = h->d_j = h->d_ctx = h->d_i2u = h->d_c2u = nullptr;
+    for (FmOrderDev &o : h->ord) {
+        void *q[] = {o.rec, o.piece_off, o.xoff, o.chunks, o.partial};
+        for (void *p : q)
+            if (p) (void)hipFree(p);
+        o = FmOrderDev();
     }
-    h->pend_j_set = h->pend_c_set = false;
     h->have_ratings = h->initialised = false;
     h->n = 0;
 }
@@ -73,7 +83,7 @@ extern "C" int cmi_fm_destroy(cmi_fm_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     fm_free_ratings(h);
-    void *ptrs[] = {h->d_w0, h->d_w, h->d_V, h->d_part, h->d_scratch, h->d_tab};
+    void *ptrs[] = {h->d_w0, h->d_d0, h->d_w, h->d_V, h->d_Vt, h->d_part, h->d_scratch, h->d_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -99,6 +109,7 @@ extern "C" int cmi_fm_create(int k, int n_users, int n_items, int n_conds, int n
         return CMI_E_INVALID;
     }
     cmi_fm_instance *h = new cmi_fm_instance();
+    if (const char *v = getenv("CMI_FM_SLICE")) h->slice_entries = atoll(v); // experiment knob: 0 = one slice
     h->k = k;
     h->n_users = n_users;
     h->n_items = n_items;
@@ -110,12 +121,15 @@ extern "C" int cmi_fm_create(int k, int n_users, int n_items, int n_conds, int n
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_w0, sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_d0, sizeof(double));
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_d0, 0, sizeof(double), h->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_w, (size_t)h->p * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_V, (size_t)h->p * k * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_Vt, (size_t)h->p * k * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_part, (size_t)h->part_count * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_scratch, 256 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_tab, (size_t)h->p * sizeof(double2));
-    if (e == hipSuccess) e = hipMemsetAsync(h->d_tab, 0, (size_t)h->p * sizeof(double2), h->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_tab, (size_t)(h->p + 1) * sizeof(double2)); // + 1: fm_rec_eval's dummy gather
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_tab, 0, (size_t)(h->p + 1) * sizeof(double2), h->stream);
     if (e != hipSuccess) {
         g_fm_create_err = std::string("cmi_fm_create: ") + hipGetErrorString(e);
         cmi_fm_destroy(h);
@@ -143,12 +157,29 @@ extern "C" int cmi_fm_set_model(cmi_fm_handle h, double w0, const double *w, con
     h->have_model = true;
     h->initialised = false;
     h->col_f = -1;
+    h->v_valid = true;
+    h->vt_valid = false;
+    return CMI_OK;
+}
+
+// the sweeps keep the factors column-major (Vt); everything else reads V
+static int fm_sync_V(cmi_fm_instance *h) {
+    if (h->v_valid) return CMI_OK;
+    FM_HIP(h, fm_launch_transpose(h->d_Vt, h->d_V, h->k, h->p, h->stream));
+    h->v_valid = true;
+    return CMI_OK;
+}
+static int fm_sync_Vt(cmi_fm_instance *h) {
+    if (h->vt_valid) return CMI_OK;
+    FM_HIP(h, fm_launch_transpose(h->d_V, h->d_Vt, h->p, h->k, h->stream));
+    h->vt_valid = true;
     return CMI_OK;
 }
 
 extern "C" int cmi_fm_get_model(cmi_fm_handle h, double *w0, double *w, double *V) {
     if (!h) return CMI_E_INVALID;
     FM_HIP(h, hipSetDevice(h->device));
+    if (int rc = fm_sync_V(h)) return rc;
     if (w0) FM_HIP(h, hipMemcpyAsync(w0, h->d_w0, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (w) FM_HIP(h, hipMemcpyAsync(w, h->d_w, (size_t)h->p * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (V) FM_HIP(h, hipMemcpyAsync(V, h->d_V, (size_t)h->p * h->k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -165,6 +196,89 @@ static hipError_t up(T **dst, const std::vector<T> &v, hipStream_t s) {
     return hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
 }
 
+// ---- the three streams (fm_kernels.hpp FmOrder), built once per cmi_fm_set_ratings ------------------------------------
+struct FmOrderHost {
+    std::vector<FmRec> rec;      // err0 is filled by cmi_fm_init on the device
+    std::vector<int32_t> piece_off, xoff, src; // src[pos] = index of the rating in the caller's arrays
+    std::vector<FmChunk> chunks;
+    int S = 1, count = 0, n_x = 0;
+};
+
+// key[t]: this field's coordinate of rating t (or < 0: the rating is not in this field's support); other[t]: the id whose
+// table entries the stream gathers -- the order is sorted by (slice of other, key), stable in the caller's order; third[t]:
+// the record's second id.
+static void fm_build_order(int64_t n, const int32_t *key, const int32_t *other, const int32_t *third, int count, int other_count,
+                           int64_t slice_entries, FmOrderHost &o) {
+    int64_t in_support = 0;
+    for (int64_t t = 0; t < n; ++t) in_support += key[t] >= 0;
+    // as many slices as keep the gathered table entries L2-resident, but never so many that the pieces shrink below ~4 records
+    int64_t S = slice_entries > 0 ? (other_count + slice_entries - 1) / slice_entries : 1;
+    const int64_t avg = count > 0 ? in_support / count : 0;
+    S = std::max<int64_t>(1, std::min<int64_t>(S, avg / 4));
+    while (S > 1 && S * (int64_t)count >= ((int64_t)1 << 31) - 1) --S;
+    const int64_t slice_len = (other_count + S - 1) / S;
+    o.S = (int)S;
+    o.count = count;
+    const int64_t P = S * (int64_t)count;
+    o.piece_off.assign((size_t)P + 1, 0);
+    auto piece = [&](int64_t t) { return (int64_t)(other[t] / slice_len) * count + key[t]; };
+    for (int64_t t = 0; t < n; ++t)
+        if (key[t] >= 0) o.piece_off[(size_t)piece(t) + 1]++;
+    for (int64_t p = 0; p < P; ++p) o.piece_off[(size_t)p + 1] += o.piece_off[(size_t)p];
+    o.rec.resize((size_t)in_support);
+    o.src.resize((size_t)in_support);
+    {
+        std::vector<int32_t> cur(o.piece_off.begin(), o.piece_off.end() - 1);
+        for (int64_t t = 0; t < n; ++t) {
+            if (key[t] < 0) continue;
+            const int32_t pos = cur[(size_t)piece(t)]++;
+            o.rec[(size_t)pos] = FmRec{0.0, other[t], third[t]};
+            o.src[(size_t)pos] = (int32_t)t;
+        }
+    }
+    // chunks, in storage (slice-major) order.  Runs of pieces without records produce no chunk: their partial slots
+    // stay at the zero they were allocated with.
+    std::vector<int32_t> xcount((size_t)count + 1, 0);
+    const std::vector<int32_t> &off = o.piece_off;
+    for (int64_t p = 0; p < P;) {
+        const int32_t len = off[(size_t)p + 1] - off[(size_t)p];
+        if (len > FM_SHORT) {
+            for (int32_t r0 = off[(size_t)p]; r0 < off[(size_t)p + 1]; r0 += FM_VECTOR) {
+                o.chunks.push_back(FmChunk{(int32_t)p, -1, r0, std::min<int32_t>(r0 + FM_VECTOR, off[(size_t)p + 1])});
+                xcount[(size_t)(p % count) + 1]++;
+            }
+            ++p;
+            continue;
+        }
+        const int64_t p0 = p;
+        const int32_t rec0 = off[(size_t)p];
+        while (p < P && p - p0 < 64 && off[(size_t)p + 1] - off[(size_t)p] <= FM_SHORT && off[(size_t)p + 1] - rec0 <= FM_CHUNK) ++p;
+        if (off[(size_t)p] > rec0) o.chunks.push_back(FmChunk{(int32_t)p0, (int32_t)(p - p0), rec0, off[(size_t)p]});
+    }
+    for (int l = 0; l < count; ++l) xcount[(size_t)l + 1] += xcount[(size_t)l];
+    o.xoff = xcount;
+    o.n_x = xcount[(size_t)count];
+    std::vector<int32_t> cur(xcount.begin(), xcount.end() - 1);
+    for (FmChunk &c : o.chunks)
+        if (c.n < 0) c.n = -(cur[(size_t)(c.piece0 % count)]++) - 1;
+}
+
+static hipError_t fm_upload_order(const FmOrderHost &o, FmOrderDev &d, hipStream_t s) {
+    d.count = o.count;
+    d.S = o.S;
+    d.n_x = o.n_x;
+    d.n_chunks = (int32_t)o.chunks.size();
+    d.n_rec = (int64_t)o.rec.size();
+    hipError_t e = up(&d.rec, o.rec, s);
+    if (e == hipSuccess) e = up(&d.piece_off, o.piece_off, s);
+    if (e == hipSuccess) e = up(&d.xoff, o.xoff, s);
+    if (e == hipSuccess) e = up(&d.chunks, o.chunks, s);
+    const size_t slots = (size_t)o.S * o.count + o.n_x;
+    if (e == hipSuccess && slots > 0) e = hipMalloc((void **)&d.partial, slots * sizeof(double2));
+    if (e == hipSuccess && slots > 0) e = hipMemsetAsync(d.partial, 0, slots * sizeof(double2), s);
+    return e;
+}
+
 extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                                   const double *r) {
     if (!h) return CMI_E_INVALID;
@@ -176,61 +290,37 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
     FM_HIP(h, hipSetDevice(h->device));
     FM_HIP(h, hipStreamSynchronize(h->stream));
     fm_free_ratings(h);
-    // storage order: stable sort by user (counting sort) -> user supports are contiguous ranges
-    std::vector<int64_t> uoff((size_t)h->n_users + 1, 0), joff((size_t)h->n_items + 1, 0), coff((size_t)h->n_conds + 1, 0);
-    for (int64_t t = 0; t < n; ++t) uoff[(size_t)u[t] + 1]++;
-    for (int l = 0; l < h->n_users; ++l) uoff[(size_t)l + 1] += uoff[(size_t)l];
-    std::vector<int32_t> su((size_t)n), sj((size_t)n), sc((size_t)n);
+    FmOrderHost ou, oi, oc;
+    fm_build_order(n, u, j, ctx, h->n_users, h->n_items, h->slice_entries, ou);
+    fm_build_order(n, j, u, ctx, h->n_items, h->n_users, h->slice_entries, oi);
+    {
+        // context features: only ratings whose context-combination id is < numConditions have one (FM.java:81-86)
+        std::vector<int32_t> ckey((size_t)n);
+        for (int64_t t = 0; t < n; ++t) ckey[(size_t)t] = ctx[t] < h->n_conds ? ctx[t] : -1;
+        fm_build_order(n, ckey.data(), u, j, h->n_conds, h->n_users, 0, oc);
+    }
+    // the ratings as plain arrays in user order (cmi_fm_init), and where the other orders find their err0
+    std::vector<int32_t> su((size_t)n), sj((size_t)n), sc((size_t)n), inv((size_t)n), i2u((size_t)n), c2u(oc.src.size());
     std::vector<double> sr((size_t)n);
-    {
-        std::vector<int64_t> cur(uoff.begin(), uoff.end() - 1);
-        for (int64_t t = 0; t < n; ++t) {
-            const int64_t s = cur[(size_t)u[t]]++;
-            su[(size_t)s] = u[t];
-            sj[(size_t)s] = j[t];
-            sc[(size_t)s] = ctx[t];
-            sr[(size_t)s] = r[t];
-        }
+    for (int64_t pos = 0; pos < n; ++pos) {
+        const int32_t t = ou.src[(size_t)pos];
+        su[(size_t)pos] = u[t];
+        sj[(size_t)pos] = j[t];
+        sc[(size_t)pos] = ctx[t];
+        sr[(size_t)pos] = r[t];
+        inv[(size_t)t] = (int32_t)pos;
     }
-    // item and context-feature supports (lists of storage positions)
-    for (int64_t s = 0; s < n; ++s) {
-        joff[(size_t)sj[(size_t)s] + 1]++;
-        if (sc[(size_t)s] < h->n_conds) coff[(size_t)sc[(size_t)s] + 1]++;
-    }
-    for (int l = 0; l < h->n_items; ++l) joff[(size_t)l + 1] += joff[(size_t)l];
-    for (int l = 0; l < h->n_conds; ++l) coff[(size_t)l + 1] += coff[(size_t)l];
-    // each entry carries the rating's other two feature ids, so a reduce pass gathers nothing but errors[]
-    const size_t ncs = (size_t)coff[(size_t)h->n_conds];
-    std::vector<int32_t> jsup((size_t)n), jsup_u((size_t)n), jsup_c((size_t)n), csup(ncs), csup_u(ncs), csup_j(ncs);
-    {
-        std::vector<int64_t> cj(joff.begin(), joff.end() - 1), cc(coff.begin(), coff.end() - 1);
-        for (int64_t s = 0; s < n; ++s) {
-            const size_t pj = (size_t)cj[(size_t)sj[(size_t)s]]++;
-            jsup[pj] = (int32_t)s;
-            jsup_u[pj] = su[(size_t)s];
-            jsup_c[pj] = sc[(size_t)s];
-            if (sc[(size_t)s] < h->n_conds) {
-                const size_t pc = (size_t)cc[(size_t)sc[(size_t)s]]++;
-                csup[pc] = (int32_t)s;
-                csup_u[pc] = su[(size_t)s];
-                csup_j[pc] = sj[(size_t)s];
-            }
-        }
-    }
+    for (int64_t pos = 0; pos < n; ++pos) i2u[(size_t)pos] = inv[(size_t)oi.src[(size_t)pos]];
+    for (size_t pos = 0; pos < oc.src.size(); ++pos) c2u[pos] = inv[(size_t)oc.src[pos]];
     hipError_t e = up(&h->d_u, su, h->stream);
     if (e == hipSuccess) e = up(&h->d_j, sj, h->stream);
     if (e == hipSuccess) e = up(&h->d_ctx, sc, h->stream);
     if (e == hipSuccess) e = up(&h->d_r, sr, h->stream);
-    if (e == hipSuccess) e = up(&h->d_sup[1], jsup, h->stream);
-    if (e == hipSuccess) e = up(&h->d_sup[2], csup, h->stream);
-    if (e == hipSuccess) e = up(&h->d_sup_a[1], jsup_u, h->stream);
-    if (e == hipSuccess) e = up(&h->d_sup_b[1], jsup_c, h->stream);
-    if (e == hipSuccess) e = up(&h->d_sup_a[2], csup_u, h->stream);
-    if (e == hipSuccess) e = up(&h->d_sup_b[2], csup_j, h->stream);
-    if (e == hipSuccess) e = up(&h->d_off[0], uoff, h->stream);
-    if (e == hipSuccess) e = up(&h->d_off[1], joff, h->stream);
-    if (e == hipSuccess) e = up(&h->d_off[2], coff, h->stream);
-    if (e == hipSuccess && n > 0) e = hipMalloc((void **)&h->d_R, (size_t)n * sizeof(double2));
+    if (e == hipSuccess) e = up(&h->d_i2u, i2u, h->stream);
+    if (e == hipSuccess) e = up(&h->d_c2u, c2u, h->stream);
+    if (e == hipSuccess) e = fm_upload_order(ou, h->ord[0], h->stream);
+    if (e == hipSuccess) e = fm_upload_order(oi, h->ord[1], h->stream);
+    if (e == hipSuccess) e = fm_upload_order(oc, h->ord[2], h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         fm_free_ratings(h);
@@ -244,25 +334,22 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
 static FmArgs fm_args(cmi_fm_instance *h) {
     FmArgs a;
     a.w0 = h->d_w0;
+    a.d0 = h->d_d0;
     a.w = h->d_w;
     a.V = h->d_V;
-    a.R = h->d_R;
+    a.Vt = h->d_Vt;
     a.tab = h->d_tab;
-    a.pending = (h->pend_j_set ? 1 : 0) | (h->pend_c_set ? 2 : 0);
+    for (int f = 0; f < 3; ++f) {
+        const FmOrderDev &d = h->ord[f];
+        a.ord[f] = FmOrder{d.rec, d.piece_off, d.chunks, d.xoff, d.partial, d.n_chunks, d.count, d.S, d.n_x, d.n_rec};
+    }
+    a.part = h->d_part;
     a.u = h->d_u;
     a.j = h->d_j;
     a.ctx = h->d_ctx;
     a.r = h->d_r;
-    for (int f = 0; f < 3; ++f) {
-        a.sup[f] = h->d_sup[f];
-        a.sup_a[f] = h->d_sup_a[f];
-        a.sup_b[f] = h->d_sup_b[f];
-    }
-    for (int f = 0; f < 3; ++f) a.sup_off[f] = h->d_off[f];
-    a.field_count[0] = h->n_users;
-    a.field_count[1] = h->n_items;
-    a.field_count[2] = h->n_conds;
-    a.part = h->d_part;
+    a.i2u = h->d_i2u;
+    a.c2u = h->d_c2u;
     a.n = h->n;
     a.global_size = h->global_size > 0 ? h->global_size : h->n;
     a.k = h->k;
@@ -286,8 +373,8 @@ static int fm_ready(cmi_fm_instance *h, bool need_init) {
 extern "C" int cmi_fm_init(cmi_fm_handle h) {
     if (!h) return CMI_E_INVALID;
     if (int rc = fm_ready(h, false)) return rc;
-    h->pend_j_set = h->pend_c_set = false;
-    h->col_f = h->uval_f = -1;
+    if (int rc = fm_sync_V(h)) return rc;
+    h->col_f = -1;
     FM_HIP(h, fm_launch_init(fm_args(h), h->stream));
     FM_HIP(h, hipStreamSynchronize(h->stream));
     h->initialised = true;
@@ -312,31 +399,15 @@ static bool phase_decode(cmi_fm_instance *h, int phase, int *field, int *f) {
     return true;
 }
 
-// ---- phase driver: keeps the lazy-error bookkeeping consistent for any call order ---------------------------------
-// Usual order (w0, then per factor: users, items, contexts): the user phase and the w0 phase fold the pending item /
-// context deltas into errors[] on their own sequential pass, so no extra pass is ever launched.
-static int fm_before_phase(cmi_fm_instance *h, int field, int f) {
+// ---- phase driver.  Errors are never stored (fm_kernels.hip header), so the phases may be driven in any order; the
+// only state between them is which column of V sits in tab[].x.
+static int fm_before_phase(cmi_fm_instance *h, int f) {
+    if (f >= 0)
+        if (int rc = fm_sync_Vt(h)) return rc;
     if (f >= 0 && h->col_f != f) {
         FM_HIP(h, fm_launch_col_load(fm_args(h), f, h->stream));
         h->col_f = f;
     }
-    if (f >= 0 && field != 0 && h->uval_f != f) { // only when driven out of order: the user phase of f leaves them there
-        FM_HIP(h, fm_launch_uval(fm_args(h), h->stream));
-        h->uval_f = f;
-    }
-    // an item phase overwrites pend_j and a context phase pend_c: fold first if they still hold deltas
-    if ((field == 1 && (h->pend_j_set || h->pend_c_set)) || (field == 2 && h->pend_c_set)) {
-        FM_HIP(h, fm_launch_flush(fm_args(h), h->stream));
-        h->pend_j_set = h->pend_c_set = false;
-    }
-    return CMI_OK;
-}
-
-static int fm_after_apply(cmi_fm_instance *h, int field, int f = -1) {
-    if (field == 0 && f >= 0) h->uval_f = f;
-    if (field <= 0) h->pend_j_set = h->pend_c_set = false; // w0 (-1) and user (0) passes rewrote errors[] with the deltas folded in
-    else if (field == 1) h->pend_j_set = true;
-    else h->pend_c_set = true;
     return CMI_OK;
 }
 
@@ -345,10 +416,14 @@ extern "C" int cmi_fm_phase_reduce(cmi_fm_handle h, int phase) {
     if (int rc = fm_ready(h, true)) return rc;
     int field, f;
     if (!phase_decode(h, phase, &field, &f)) FM_FAIL(h, CMI_E_INVALID, "fm: bad phase %d", phase);
-    if (int rc = fm_before_phase(h, field, f)) return rc;
+    if (int rc = fm_before_phase(h, f)) return rc;
     const FmArgs a = fm_args(h);
-    if (phase == 0) FM_HIP(h, fm_launch_w0_reduce(a, h->d_scratch, h->stream));
-    else FM_HIP(h, fm_launch_field(a, field, f, 0, h->stream));
+    if (phase == 0) {
+        FM_HIP(h, fm_launch_w0_reduce(a, h->d_scratch, h->stream));
+    } else {
+        FM_HIP(h, fm_launch_reduce(a, field, f, h->stream));
+        FM_HIP(h, fm_launch_finish(a, field, f, 0, h->stream));
+    }
     h->last_phase = phase;
     return CMI_OK;
 }
@@ -370,40 +445,100 @@ extern "C" int cmi_fm_phase_apply(cmi_fm_handle h, int phase) {
     if (h->last_phase != phase) FM_FAIL(h, CMI_E_INVALID, "fm: phase_apply(%d) without the matching phase_reduce", phase);
     const FmArgs a = fm_args(h);
     if (phase == 0) FM_HIP(h, fm_launch_w0_apply(a, h->stream));
-    else FM_HIP(h, fm_launch_field(a, field, f, 1, h->stream));
-    return fm_after_apply(h, field, f);
+    else FM_HIP(h, fm_launch_finish(a, field, f, 1, h->stream));
+    if (f >= 0) h->v_valid = false;
+    h->last_phase = -1;
+    return CMI_OK;
 }
 
-// one phase, reduce + update fused (no exchange point): what cmi_fm_sweep runs per phase; a multi-GPU host uses it for the
+// one phase, reduce + update with no exchange point: what cmi_fm_sweep runs per phase; a multi-GPU host uses it for the
 // phases whose coordinates live on one rank only (the user field of user-sharded ratings)
 extern "C" int cmi_fm_phase_run(cmi_fm_handle h, int phase) {
     if (!h) return CMI_E_INVALID;
     if (int rc = fm_ready(h, true)) return rc;
     int field, f;
     if (!phase_decode(h, phase, &field, &f)) FM_FAIL(h, CMI_E_INVALID, "fm: bad phase %d", phase);
-    if (int rc = fm_before_phase(h, field, f)) return rc;
+    if (int rc = fm_before_phase(h, f)) return rc;
+    const FmArgs a = fm_args(h);
     if (phase == 0) {
-        FM_HIP(h, fm_launch_w0_reduce(fm_args(h), h->d_scratch, h->stream));
-        FM_HIP(h, fm_launch_w0_apply(fm_args(h), h->stream));
+        FM_HIP(h, fm_launch_w0_reduce(a, h->d_scratch, h->stream));
+        FM_HIP(h, fm_launch_w0_apply(a, h->stream));
     } else {
-        FM_HIP(h, fm_launch_field(fm_args(h), field, f, 2, h->stream));
+        FM_HIP(h, fm_launch_reduce(a, field, f, h->stream));
+        FM_HIP(h, fm_launch_finish(a, field, f, 2, h->stream));
+        if (f >= 0) h->v_valid = false;
     }
     h->last_phase = -1;
-    return fm_after_apply(h, field, f);
+    return CMI_OK;
 }
 
 extern "C" int cmi_fm_sweep(cmi_fm_handle h) {
     if (!h) return CMI_E_INVALID;
+    const int np = cmi_fm_num_phases(h);
+    for (int ph = 0; ph < np; ++ph)
+        if (int rc = cmi_fm_phase_run(h, ph)) return rc;
+    return CMI_OK;
+}
+
+
+// ---- measurement helpers (bench.py) ---------------------------------------------------------------------------------
+// out[0..1] slices of the user / item order, [2..4] records of the three orders, [5..6] chunks of the user / item order,
+// [7] HBM bytes one factor (3 phases + the column load) has to move with this layout, [8] the same for the reduce launch of
+// the user field alone, [9] of the item field alone, [10] slice entries, [11] p.
+extern "C" int cmi_fm_layout(cmi_fm_handle h, int64_t out[12]) {
+    if (!h || !out) return CMI_E_INVALID;
+    if (!h->have_ratings) FM_FAIL(h, CMI_E_INVALID, "fm: call cmi_fm_set_ratings first");
+    int64_t factor = 0, red[3] = {0, 0, 0};
+    for (int f = 0; f < 3; ++f) {
+        const FmOrderDev &o = h->ord[f];
+        const int64_t slots = (int64_t)o.S * o.count + o.n_x;
+        // reduce: the records, the piece offsets, the chunk table, the owners' table entries, one partial per slot written;
+        // the gathered table entries are L2-resident by construction and are charged once per XCD and slice below
+        red[f] = o.n_rec * 16 + ((int64_t)o.S * o.count + 1) * 4 + (int64_t)o.n_chunks * 16 + (int64_t)o.count * 16 + slots * 16;
+        const int64_t other = f == 0 ? h->n_items : f == 1 ? h->n_users : (int64_t)h->n_users + h->n_items;
+        red[f] += 8 * other * 16; // every XCD's L2 fills each slice of the gathered table once
+        // finish: the partials read back, the coordinate's table entry read and written, its Vt entry written
+        factor += red[f] + slots * 16 + (int64_t)o.count * (16 + 16 + 8);
+    }
+    factor += h->p * (8 + 16 + 16); // column load: Vt row read, table entries read-modify-written
+    out[0] = h->ord[0].S;
+    out[1] = h->ord[1].S;
+    out[2] = h->ord[0].n_rec;
+    out[3] = h->ord[1].n_rec;
+    out[4] = h->ord[2].n_rec;
+    out[5] = h->ord[0].n_chunks;
+    out[6] = h->ord[1].n_chunks;
+    out[7] = factor;
+    out[8] = red[0];
+    out[9] = red[1];
+    out[10] = h->slice_entries;
+    out[11] = h->p;
+    return CMI_OK;
+}
+
+// Average duration (HIP events on the instance's stream) of `reps` launches of the REDUCE kernel of one phase -- it only
+// writes the partial-sum scratch, so the model is untouched.
+extern "C" int cmi_fm_time_reduce(cmi_fm_handle h, int phase, int reps, double *avg_ms) {
+    if (!h || !avg_ms || reps < 1) return CMI_E_INVALID;
     if (int rc = fm_ready(h, true)) return rc;
-    FM_HIP(h, fm_launch_w0_reduce(fm_args(h), h->d_scratch, h->stream));
-    FM_HIP(h, fm_launch_w0_apply(fm_args(h), h->stream));
-    fm_after_apply(h, -1);
-    for (int f = -1; f < h->k; ++f)
-        for (int field = 0; field < 3; ++field) {
-            if (int rc = fm_before_phase(h, field, f)) return rc;
-            FM_HIP(h, fm_launch_field(fm_args(h), field, f, 2, h->stream));
-            fm_after_apply(h, field, f);
-        }
+    int field, f;
+    if (!phase_decode(h, phase, &field, &f) || phase == 0) FM_FAIL(h, CMI_E_INVALID, "fm: bad phase %d", phase);
+    if (int rc = fm_before_phase(h, f)) return rc;
+    const FmArgs a = fm_args(h);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    FM_HIP(h, hipEventCreate(&e0));
+    FM_HIP(h, hipEventCreate(&e1));
+    hipError_t e = fm_launch_reduce(a, field, f, h->stream); // warm
+    if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
+    for (int i = 0; i < reps && e == hipSuccess; ++i) e = fm_launch_reduce(a, field, f, h->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    FM_HIP(h, e);
+    *avg_ms = (double)ms / reps;
     return CMI_OK;
 }
 
@@ -439,6 +574,7 @@ extern "C" int cmi_fm_predict_batch(cmi_fm_handle h, int64_t n, const int32_t *u
             FM_FAIL(h, CMI_E_INVALID, "fm_predict: id out of range at tuple %lld", (long long)t);
     if (n == 0) return CMI_OK;
     FM_HIP(h, hipSetDevice(h->device));
+    if (int rc = fm_sync_V(h)) return rc;
     int32_t *du = nullptr, *dj = nullptr, *dc = nullptr;
     double *dout = nullptr;
     hipError_t e = hipMalloc((void **)&du, (size_t)n * 4);
@@ -481,6 +617,7 @@ extern "C" int cmi_fm_eval_rankings(cmi_fm_handle h, int64_t n_train, const int3
                 FM_FAIL(h, CMI_E_INVALID, "fm_eval_rankings: id out of range at %s tuple %lld", pass ? "test" : "train", (long long)t);
     }
     FM_HIP(h, hipSetDevice(h->device));
+    if (int rc = fm_sync_V(h)) return rc;
     if (n_queries) *n_queries = 0;
     RankPlan plan;
     rank_build_plan(h->n_users, h->n_items, RankTuples{n_train, tu, tj, tctx, tr}, RankTuples{n_test, su, sj, sctx, sr}, bin_thold,

@@ -7,25 +7,34 @@
 // (the reference's index quirk, FM.java:81-86), feature numUsers+numItems+c with value 1/numContextDims.
 // Rows whose feature l is zero contribute exactly 0 to the numerator and exactly `reg` to the denominator of
 // coordinate l and are not touched by its error update.  So
-//   * a coordinate only needs the ratings in its support (CSR lists per field, built once on the host);
+//   * a coordinate only needs the ratings in its support;
 //   * the coordinates of one FIELD (all users / all items / all context features) have pairwise disjoint
 //     supports, so their sequential updates commute exactly and run in parallel;
 //   * the denominator is sum_{support} h^2 + size*reg.
 // One sweep = 1 (w0) + 3 (w: users, items, contexts) + 3k (V, per factor) phases.
 //
-// HBM traffic is what bounds a sweep, so the per-rating state is kept to ONE fp64 array:
-//   * the reference's cache Q[i][f] = sum_l V[l][f] x_il (FM.java:134-146, 209-210) is not stored (k*size*8 bytes,
-//     re-read and re-written by every factor phase): with three features per rating it is V[u][f] + V[item][f] +
-//     xc*V[ctx][f], gathered from a dense copy of column f (`col`, p doubles: L2/MALL resident).  Same value up to
-//     rounding (the reference accumulates deltas into Q; RMSE holds 1e-9 against the order-exact oracle).
-//   * storage order = sorted by user, so the user field streams errors[] sequentially (wave per user, fused
-//     reduce + apply);
-//   * the item / context fields only GATHER errors[] (their CSR carries the other two feature ids) and leave their
-//     coordinate deltas next to the column entries (tab[].y); the next user phase (or the w0 phase of the next sweep) folds them into
-//     errors[] on its sequential pass.  No random write ever happens.
-// fp64 throughout (the reference's precision); sums are tree-reduced.  Gather/stream work: no MFMA.
+// What bounds a phase is HBM / fabric traffic per rating, so a sweep WRITES NO PER-RATING DATA AT ALL (round 4):
+//   * errors[i] (FM.java:133-136, rewritten by every coordinate update :165,188,208) is not stored.  Each update adds
+//     delta_l * x_il to the errors of its support, so  errors[i] = err0[i] + d0 + D[user] + D[item] + xc*D[ctx feature]
+//     with err0 from cmi_fm_init and D[l] the running sum of coordinate l's deltas -- one fp64 per COORDINATE, kept beside
+//     the column entry in tab[l] = {V[l][f], D[l]} (16 bytes, one gather serves both).  Equal to the reference's errors up
+//     to the association of the additions (1e-16 relative; the tests hold the model to 1e-8 against the dense oracle).
+//   * the reference's cache Q[i][f] = sum_l V[l][f] x_il (FM.java:134-146, 209-210) is not stored either: with three
+//     features per rating it is V[u][f] + V[item][f] + xc*V[ctx][f], the same gathers.
+//   * every field STREAMS its own copy of the ratings (16-byte records {err0, other id, ctx id}): the user field in user
+//     order, the item field in item order.  Nothing is gathered from per-rating arrays (round 3 did: 68 bytes fetched per
+//     16 useful in the item phase).
+//   * the only gathers left are the other field's table entries (8-10 MB tables at BASELINE C4's share: they miss L2 and
+//     every miss fetches a 64-byte sector for 16 bytes).  Each order is therefore sorted by (SLICE of the other id, own
+//     coordinate): while a slice streams, the table entries it gathers (<= 1 MB) stay L2-resident in every XCD.  A
+//     coordinate's support becomes S contiguous pieces whose partial sums the finishing kernel adds in slice order.
+// Reduction: CSR-stream.  A wave takes a chunk of <= 256 consecutive records = <= 64 whole pieces, evaluates every
+// record once (coalesced 16-byte loads, 4 per lane), parks {e', h} in LDS, and one lane per piece sums its records left
+// to right -- deterministic, independent of the chunking.  Pieces longer than 64 records (hot coordinates) are split
+// into vector chunks that all 64 lanes reduce (fixed butterfly).  fp64 throughout; gather / stream work: no MFMA.
 //
-// Split reduce/apply modes exist so a multi-GPU host can all-reduce (num, den) between them.
+// reduce (-> partial) and finish (partial -> [num | den] -> update) are separate launches, so a multi-GPU host can
+// all-reduce (num, den) between them; the fused sweep runs the identical arithmetic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -48,209 +57,233 @@ __device__ __forceinline__ double block_sum(double x, double *lds) {
     return s;
 }
 
-// true error of storage position i (pending item / context deltas folded in)
-__device__ __forceinline__ double fm_err(const FmArgs &a, int64_t i, int jj, int c) {
-    double e = a.R[i].x;
-    if (a.pending & 1) e += a.tab[a.n_users + jj].y;
-    if ((a.pending & 2) && c < a.n_conds) e += a.xc * a.tab[(int64_t)a.n_users + a.n_items + c].y;
-    return e;
+__device__ __forceinline__ int64_t fm_base(const FmArgs &a, int field) {
+    return field == 0 ? 0 : (field == 1 ? (int64_t)a.n_users : (int64_t)a.n_users + a.n_items);
 }
 
-// supporting rating s of coordinate l of FIELD -> true error et and h = x_il * (sum of the OTHER features' column
-// entries times their values) = x*Q[i][f] - x*x*theta of FM.java:178,198.  One 16-byte gather per table touched:
-// tab[] pairs a coordinate's column entry with its pending delta, R[] pairs a rating's error with its user's entry.
-template <int FIELD>
-__device__ __forceinline__ void fm_row(const FmArgs &a, int f, int64_t l, int64_t s, double x, double &et, double &h) {
+__device__ __forceinline__ FmRec fm_load_rec(const FmRec *rec, int64_t i) {
+    // streamed once per phase: non-temporal, so the table slice keeps its place in L2
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d v = __builtin_nontemporal_load((const v2d *)rec + i);
+    FmRec r;
+    r.err0 = v.x;
+    r.a = __double2loint(v.y);
+    r.c = __double2hiint(v.y);
+    return r;
+}
+
+
+// One record of FIELD's stream -> e' = its error without the own coordinate's D (the owner adds it) and
+// h = x_il * (sum of the OTHER features' column entries times their values) = x*Q[i][f] - x*x*theta of FM.java:178,198
+// (h = x for the linear weights).  One 16-byte gather per table touched.  N records at a time: all main gathers are
+// issued before anything waits on one, and the context gathers sit behind ONE wave-uniform branch (context features
+// are rare: only combination ids < numConditions have one), so the common case is one gather per record.
+template <int FIELD, int N>
+__device__ __forceinline__ void fm_rec_eval(const FmArgs &a, int f, const FmRec (&r)[N], double d0, double (&ep)[N], double (&h)[N]) {
     const int64_t jbase = a.n_users, cbase = (int64_t)a.n_users + a.n_items;
-    double other = 0.0;
-    if (FIELD == 0) {
-        const int jj = a.j[s], c = a.ctx[s];
-        const double2 t = a.tab[jbase + jj];
-        et = a.R[s].x;
-        if (a.pending & 1) et += t.y;
-        other = t.x;
-        if (c < a.n_conds) {
-            const double2 tc = a.tab[cbase + c];
-            if (a.pending & 2) et += a.xc * tc.y;
-            other += a.xc * tc.x;
-        }
-    } else if (FIELD == 1) { // pending deltas are always folded before an item phase
-        const double2 r = a.R[a.sup[1][s]];
-        const int c = a.sup_b[1][s];
-        et = r.x;
-        other = r.y;
-        if (c < a.n_conds) other += a.xc * a.tab[cbase + c].x;
-    } else {
-        const double2 r = a.R[a.sup[2][s]];
-        const double2 t = a.tab[jbase + a.sup_b[2][s]];
-        et = r.x;
-        if (a.pending & 1) et += t.y;
-        other = r.y + t.x;
-    }
-    h = f < 0 ? x : x * other;
-}
-
-// MODE 0: reduce only (writes part[l], part[count+l]); MODE 1: apply only (reads part); MODE 2: fused.
-// f < 0: linear weights w; f >= 0: factor column f of V (working copy in a.tab[].x).
-// h_i = x_il * (sum of the OTHER features' column entries times their values) = x*Q[i][f] - x*x*theta of FM.java:178,198.
-template <int BLOCK, int MODE, int FIELD>
-__global__ __launch_bounds__(BLOCK) void fm_field_kernel(FmArgs a, int f) {
-    __shared__ double lds[BLOCK / 64 + 2];
-    const int l = blockIdx.x; // coordinate within the field
-    const int64_t b = a.sup_off[FIELD][l], e = a.sup_off[FIELD][l + 1];
-    const int64_t ubase = 0, jbase = a.n_users, cbase = (int64_t)a.n_users + a.n_items;
-    const int64_t base = FIELD == 0 ? ubase : (FIELD == 1 ? jbase : cbase);
-    const double theta = f < 0 ? a.w[base + l] : a.tab[base + l].x;
-    const double x = FIELD == 2 ? a.xc : 1.0;
-    double num = 0.0, den = 0.0;
-    if (MODE != 1) {
-        for (int64_t s = b + threadIdx.x; s < e; s += BLOCK) {
-            double et, h;
-            fm_row<FIELD>(a, f, l, s, x, et, h);
-            num += (et - theta * h) * h;
-            den += h * h;
-        }
-        num = block_sum<BLOCK>(num, lds);
-        den = block_sum<BLOCK>(den, lds);
-        if (MODE == 0) {
-            if (threadIdx.x == 0) {
-                a.part[l] = num;
-                a.part[a.field_count[FIELD] + l] = den;
-            }
-            return;
-        }
-    } else {
-        num = a.part[l];
-        den = a.part[a.field_count[FIELD] + l];
-    }
-    const double reg = f < 0 ? a.regLw : a.regLf;
-    const double upd = 0.0 - num / (den + (double)a.global_size * reg);
-    const double delta = upd - theta;
-    if (FIELD == 0) { // the sequential field: errors[] are rewritten here, pending deltas folded in
-        for (int64_t s = b + threadIdx.x; s < e; s += BLOCK)
-            a.R[s] = make_double2(fm_err(a, s, a.j[s], a.ctx[s]) + delta * x, f < 0 ? 0.0 : upd);
-        if (BLOCK > 64) __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        // errors[i] += delta * x of an item / context coordinate is applied lazily by the next sequential pass
-        if (f < 0) {
-            a.w[base + l] = upd;
-            if (FIELD != 0) a.tab[base + l].y = delta;
-        } else {
-            a.tab[base + l] = make_double2(upd, FIELD == 0 ? 0.0 : delta);
-            a.V[(size_t)(base + l) * a.k + f] = upd;
-        }
-    }
-}
-
-// Short supports (the usual case: a user's or an item's ratings): LANES-wide lane groups, 64/LANES coordinates per
-// wave, up to 4*LANES supporting ratings held in registers -- one pass over the support instead of two, and a quarter
-// of the waves.  A phase over short supports is bound by the per-wave chain of dependent loads (offsets -> ids /
-// errors -> column gathers), not by bytes, so fewer, fuller waves and a shorter chain are what count.  Coordinates
-// with more than 4*LANES ratings take the two-loop path inside the same kernel.
-template <int LANES, int MODE, int FIELD>
-__global__ __launch_bounds__(256) void fm_field_sub(FmArgs a, int f) {
-    constexpr int CH = 4;
-    const int sub = threadIdx.x % LANES;
-    const int64_t l = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LANES; // coordinate within the field
-    const bool live = l < a.field_count[FIELD];
-    const int64_t b = live ? a.sup_off[FIELD][l] : 0, e = live ? a.sup_off[FIELD][l + 1] : 0;
-    const int64_t ubase = 0, jbase = a.n_users, cbase = (int64_t)a.n_users + a.n_items;
-    const int64_t base = FIELD == 0 ? ubase : (FIELD == 1 ? jbase : cbase);
-    const double theta = !live ? 0.0 : (f < 0 ? a.w[base + l] : a.tab[base + l].x);
-    const double x = FIELD == 2 ? a.xc : 1.0;
-    const bool small = (e - b) <= CH * LANES;
-    double et[CH], num = 0.0, den = 0.0;
-    if (MODE != 1) {
-        if (small) {
+    if (FIELD == 2) {
+        double2 tu[N], tj[N];
 #pragma unroll
-            for (int c4 = 0; c4 < CH; ++c4) {
-                const int64_t s = b + c4 * LANES + sub;
-                et[c4] = 0.0;
-                if (s < e) {
-                    double h;
-                    fm_row<FIELD>(a, f, l, s, x, et[c4], h);
-                    num += (et[c4] - theta * h) * h;
-                    den += h * h;
+        for (int q = 0; q < N; ++q) {
+            tu[q] = a.tab[r[q].a];
+            tj[q] = a.tab[jbase + r[q].c];
+        }
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            ep[q] = ((r[q].err0 + d0) + tu[q].y) + tj[q].y;
+            h[q] = f < 0 ? a.xc : a.xc * (tu[q].x + tj[q].x);
+        }
+    } else {
+        double2 t[N];
+        bool any_c = false;
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            t[q] = a.tab[(FIELD == 0 ? jbase : 0) + r[q].a];
+            any_c |= r[q].c < a.n_conds;
+        }
+        double other[N];
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            ep[q] = (r[q].err0 + d0) + t[q].y;
+            other[q] = t[q].x;
+        }
+        if (__builtin_amdgcn_ballot_w64(any_c) != 0) {
+#pragma unroll
+            for (int q = 0; q < N; ++q) {
+                const bool has_c = r[q].c < a.n_conds;
+                const double2 tc = a.tab[cbase + (has_c ? r[q].c : 0)]; // tab has p + 1 entries: in bounds even with no conditions
+                if (has_c) {
+                    ep[q] += a.xc * tc.y;
+                    other[q] += a.xc * tc.x;
                 }
             }
-        } else {
-            for (int64_t s = b + sub; s < e; s += LANES) {
-                double e1, h;
-                fm_row<FIELD>(a, f, l, s, x, e1, h);
-                num += (e1 - theta * h) * h;
-                den += h * h;
+        }
+#pragma unroll
+        for (int q = 0; q < N; ++q) h[q] = f < 0 ? 1.0 : other[q];
+    }
+}
+
+// W0: the w0 phase's sum over the user order: partial.x = sum(err_i - w0) per piece (FM.java:153-158).
+template <int FIELD, bool W0>
+__global__ __launch_bounds__(256) void fm_reduce_kernel(FmArgs a, int f) {
+    __shared__ double2 lds[4][FM_CHUNK];
+    const FmOrder &o = a.ord[FIELD];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ci = blockIdx.x * 4 + wave;
+    if (ci >= o.n_chunks) return; // waves are independent: no workgroup barrier below
+    const FmChunk ch = o.chunks[ci];
+    const double d0 = *a.d0;
+    const int64_t base = fm_base(a, FIELD);
+    if (ch.n >= 0) {
+        const bool own = lane < ch.n;
+        int b = 0, e = 0;
+        double theta = 0.0, dl = 0.0;
+        if (own) {
+            b = o.piece_off[ch.piece0 + lane];
+            e = o.piece_off[ch.piece0 + lane + 1];
+            const int l = (ch.piece0 + lane) % o.count;
+            const double2 t = a.tab[base + l];
+            theta = W0 ? *a.w0 : (f < 0 ? a.w[base + l] : t.x);
+            dl = FIELD == 2 ? a.xc * t.y : t.y; // the support's errors moved by delta * x_il
+        }
+        // all four record loads first (clamped, so no branch splits them), then the gathers, then LDS
+        FmRec rr[FM_CHUNK / 64];
+#pragma unroll
+        for (int r4 = 0; r4 < FM_CHUNK / 64; ++r4) {
+            const int i = ch.rec0 + r4 * 64 + lane;
+            rr[r4] = fm_load_rec(o.rec, i < ch.rec1 ? i : ch.rec1 - 1);
+        }
+        double ep[FM_CHUNK / 64], hh[FM_CHUNK / 64];
+        fm_rec_eval<FIELD>(a, f, rr, d0, ep, hh);
+#pragma unroll
+        for (int r4 = 0; r4 < FM_CHUNK / 64; ++r4)
+            if (ch.rec0 + r4 * 64 + lane < ch.rec1) lds[wave][r4 * 64 + lane] = make_double2(ep[r4], hh[r4]);
+        // the wave reads what its own lanes wrote: LDS operations of one wave complete in order, the compiler must not move them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (own) {
+            double num = 0.0, den = 0.0;
+            for (int i = b; i < e; ++i) {
+                const double2 v = lds[wave][i - ch.rec0];
+                const double et = v.x + dl;
+                if (W0) {
+                    num += et - theta;
+                } else {
+                    num += (et - theta * v.y) * v.y;
+                    den += v.y * v.y;
+                }
+            }
+            o.partial[ch.piece0 + lane] = make_double2(num, den);
+        }
+    } else {
+        const int l = ch.piece0 % o.count;
+        const double2 t = a.tab[base + l];
+        const double theta = W0 ? *a.w0 : (f < 0 ? a.w[base + l] : t.x), dl = FIELD == 2 ? a.xc * t.y : t.y;
+        double num = 0.0, den = 0.0;
+        for (int i0 = ch.rec0; i0 < ch.rec1; i0 += 4 * 64) { // a lane sums its records (stride 64) in order
+            FmRec rr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * 64 + lane;
+                rr[q] = fm_load_rec(o.rec, i < ch.rec1 ? i : ch.rec1 - 1);
+            }
+            double ep[4], hh[4];
+            fm_rec_eval<FIELD>(a, f, rr, d0, ep, hh);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (i0 + q * 64 + lane >= ch.rec1) continue;
+                const double et = ep[q] + dl;
+                if (W0) {
+                    num += et - theta;
+                } else {
+                    num += (et - theta * hh[q]) * hh[q];
+                    den += hh[q] * hh[q];
+                }
             }
         }
 #pragma unroll
-        for (int m = LANES / 2; m >= 1; m >>= 1) {
+        for (int m = 32; m >= 1; m >>= 1) {
             num += __shfl_xor(num, m, 64);
             den += __shfl_xor(den, m, 64);
         }
-        if (MODE == 0) {
-            if (live && sub == 0) {
-                a.part[l] = num;
-                a.part[a.field_count[FIELD] + l] = den;
-            }
+        if (lane == 0) o.partial[(int64_t)o.S * o.count + (-ch.n - 1)] = make_double2(num, den);
+    }
+}
+
+// mode 0: partial -> part (num | den); 1: part -> coordinate update; 2: both.  The update (FM.java:181-190, 201-211):
+// theta' = -num / (den + size*reg); D[l] += theta' - theta (the errors of the support move by delta * x_il, folded in
+// wherever errors are read).
+template <int FIELD>
+__global__ __launch_bounds__(256) void fm_finish_kernel(FmArgs a, int f, int mode) {
+    const FmOrder &o = a.ord[FIELD];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= o.count) return;
+    double num, den;
+    if (mode != 1) {
+        num = 0.0;
+        den = 0.0;
+        for (int s = 0; s < o.S; ++s) {
+            const double2 p = o.partial[(int64_t)s * o.count + l];
+            num += p.x;
+            den += p.y;
+        }
+        const int64_t grid = (int64_t)o.S * o.count;
+        for (int x = o.xoff[l]; x < o.xoff[l + 1]; ++x) {
+            const double2 p = o.partial[grid + x];
+            num += p.x;
+            den += p.y;
+        }
+        if (mode == 0) {
+            a.part[l] = num;
+            a.part[o.count + l] = den;
             return;
         }
-    } else if (live) {
+    } else {
         num = a.part[l];
-        den = a.part[a.field_count[FIELD] + l];
+        den = a.part[o.count + l];
     }
-    if (!live) return;
+    const int64_t base = fm_base(a, FIELD);
+    const double2 t = a.tab[base + l];
+    const double theta = f < 0 ? a.w[base + l] : t.x;
     const double reg = f < 0 ? a.regLw : a.regLf;
     const double upd = 0.0 - num / (den + (double)a.global_size * reg);
     const double delta = upd - theta;
-    if (FIELD == 0) { // the sequential field rewrites errors[] with the pending deltas folded in
-        if (MODE == 2 && small) {
-#pragma unroll
-            for (int c4 = 0; c4 < CH; ++c4) {
-                const int64_t s = b + c4 * LANES + sub;
-                if (s < e) a.R[s] = make_double2(et[c4] + delta * x, f < 0 ? 0.0 : upd);
-            }
-        } else {
-            for (int64_t s = b + sub; s < e; s += LANES)
-                a.R[s] = make_double2(fm_err(a, s, a.j[s], a.ctx[s]) + delta * x, f < 0 ? 0.0 : upd);
-        }
-    }
-    if (sub == 0) {
-        // errors[i] += delta * x of an item / context coordinate is applied lazily by the next sequential pass
-        if (f < 0) {
-            a.w[base + l] = upd;
-            if (FIELD != 0) a.tab[base + l].y = delta;
-        } else {
-            a.tab[base + l] = make_double2(upd, FIELD == 0 ? 0.0 : delta);
-            a.V[(size_t)(base + l) * a.k + f] = upd;
-        }
+    if (f < 0) {
+        a.w[base + l] = upd;
+        a.tab[base + l].y = t.y + delta;
+    } else {
+        a.tab[base + l] = make_double2(upd, t.y + delta);
+        a.Vt[(size_t)f * (size_t)((int64_t)a.n_users + a.n_items + a.n_conds) + (size_t)(base + l)] = upd;
     }
 }
 
 __global__ __launch_bounds__(256) void fm_col_load(FmArgs a, int f, int64_t p) {
     for (int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x; l < p; l += (int64_t)gridDim.x * 256)
-        a.tab[l].x = a.V[(size_t)l * a.k + f]; // .y (a pending delta of the previous factor's phase) is kept
+        a.tab[l].x = a.Vt[(size_t)f * (size_t)p + (size_t)l]; // .y (the coordinate's running delta sum) is kept
 }
 
-// R[i].y = column entry of the rating's user (only needed when an item / context phase of factor f is driven without
-// the user phase of f right before it)
-__global__ __launch_bounds__(256) void fm_uval_kernel(FmArgs a) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) a.R[i].y = a.tab[a.u[i]].x;
+// dst[c][r] = src[r][c] (V <-> Vt), 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void fm_transpose_kernel(const double *src, double *dst, int64_t rows, int64_t cols) {
+    __shared__ double tile[32][33];
+    const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = src[(size_t)(r0 + i) * cols + (size_t)(c0 + tx)];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) dst[(size_t)(c0 + i) * rows + (size_t)(r0 + tx)] = tile[tx][i];
 }
 
-// errors[i] += pending deltas (only needed when phases are driven out of the usual order)
-__global__ __launch_bounds__(256) void fm_flush_kernel(FmArgs a) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256)
-        a.R[i].x = fm_err(a, i, a.j[i], a.ctx[i]);
-}
-
-// w0 phase, reduce: part[0] = sum(err_i - w0) over the local ratings (fixed two-stage tree)
+// w0 phase, reduce: part[0] = sum over the pieces' sums of (err_i - w0) (fixed two-stage tree)
 __global__ __launch_bounds__(256) void fm_w0_reduce1(FmArgs a, double *scratch) {
     __shared__ double lds[6];
-    const int64_t chunk = (a.n + gridDim.x - 1) / gridDim.x;
-    const int64_t b = (int64_t)blockIdx.x * chunk, e = (b + chunk) < a.n ? (b + chunk) : a.n;
-    const double w0 = *a.w0;
+    const FmOrder &o = a.ord[0];
+    const int64_t slots = (int64_t)o.S * o.count + o.n_x;
+    const int64_t chunk = (slots + gridDim.x - 1) / gridDim.x;
+    const int64_t b = (int64_t)blockIdx.x * chunk, e = (b + chunk) < slots ? (b + chunk) : slots;
     double s = 0.0;
-    for (int64_t i = b + threadIdx.x; i < e; i += 256) s += fm_err(a, i, a.j[i], a.ctx[i]) - w0;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) s += o.partial[i].x;
     s = block_sum<256>(s, lds);
     if (threadIdx.x == 0) scratch[blockIdx.x] = s;
 }
@@ -263,22 +296,22 @@ __global__ __launch_bounds__(256) void fm_w0_reduce2(FmArgs a, const double *scr
         a.part[1] = 0.0;
     }
 }
-// w0 phase, apply: w0' = -part[0]/(size + regLw); err_i += w0' - w0   (FM.java:153-169)
-__global__ __launch_bounds__(256) void fm_w0_apply(FmArgs a) {
+// w0 phase, apply: w0' = -part[0]/(size + regLw); every error moves by w0' - w0 (FM.java:153-169): d0 takes it
+__global__ void fm_w0_apply(FmArgs a) {
     const double w0 = *a.w0;
     // `size + regLw` is int + float in the reference (FM.java:47,161): Java's binary numeric promotion makes it a FLOAT sum (at C4's
     // 25 M ratings regLw vanishes in it) -- found by executing the reference's source, tests/test_reference_src_golden.py
     const double upd = 0.0 - a.part[0] / (double)((float)(int)a.global_size + (float)a.regLw);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256)
-        a.R[i].x = fm_err(a, i, a.j[i], a.ctx[i]) + upd - w0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.part[2] = upd; // committed to *w0 by fm_w0_commit after all blocks read w0
+    *a.d0 = *a.d0 + (upd - w0);
+    *a.w0 = upd;
 }
-__global__ void fm_w0_commit(FmArgs a) { *a.w0 = a.part[2]; }
 
-// pre-pass (FM.java:117-146): errors[i] = r_i - predict(i) (Q is not materialised, see the header).  One wave per rating.
+// pre-pass (FM.java:117-146): err0[i] = r_i - predict(i) into the user-order records (Q is not materialised, see the
+// header); the running delta sums start at zero.  One wave per rating.
 __global__ __launch_bounds__(256) void fm_init_kernel(FmArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * 4;
+    FmRec *rec = const_cast<FmRec *>(a.ord[0].rec);
     for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < a.n; i += stride) {
         const int u = a.u[i], j = a.j[i], c = a.ctx[i];
         const bool has_c = c >= 0 && c < a.n_conds;
@@ -302,9 +335,22 @@ __global__ __launch_bounds__(256) void fm_init_kernel(FmArgs a) {
             double pred = *a.w0 + a.w[u];
             pred += a.w[a.n_users + j];
             if (has_c) pred += a.w[a.n_users + a.n_items + c] * a.xc;
-            a.R[i] = make_double2(a.r[i] - (pred + 0.5 * pair), 0.0);
+            rec[i].err0 = a.r[i] - (pred + 0.5 * pair);
         }
     }
+}
+// the other two orders copy their err0 from the user order, so the three copies are the same numbers
+__global__ __launch_bounds__(256) void fm_init_spread(FmArgs a) {
+    FmRec *ri = const_cast<FmRec *>(a.ord[1].rec), *rc = const_cast<FmRec *>(a.ord[2].rec);
+    const FmRec *ru = a.ord[0].rec;
+    const int64_t n2 = a.ord[2].n_rec, p = (int64_t)a.n_users + a.n_items + a.n_conds;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        ri[i].err0 = ru[a.i2u[i]].err0;
+        if (i < n2) rc[i].err0 = ru[a.c2u[i]].err0;
+        if (i < p) a.tab[i].y = 0.0;
+    }
+    for (int64_t i = a.n + (int64_t)blockIdx.x * 256 + threadIdx.x; i < p; i += (int64_t)gridDim.x * 256) a.tab[i].y = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.d0 = 0.0;
 }
 
 // FM.predict (FM.java:93-113) for arbitrary tuples; one wave per tuple
@@ -342,37 +388,32 @@ __global__ __launch_bounds__(256) void fm_predict_kernel(FmArgs a, int64_t n, co
 
 // ---- launchers ------------------------------------------------------------------------------------------
 
-template <int MODE, int FIELD>
-static hipError_t launch_field_mode(const FmArgs &a, int f, int64_t avg_support, hipStream_t s) {
-    const int count = a.field_count[FIELD];
-    if (count <= 0) return hipSuccess;
-    if (avg_support > 2048) // few coordinates with very long supports: a whole 1024-thread workgroup each
-        hipLaunchKernelGGL((fm_field_kernel<1024, MODE, FIELD>), dim3(count), dim3(1024), 0, s, a, f);
-    else if (avg_support > 192)
-        hipLaunchKernelGGL((fm_field_kernel<256, MODE, FIELD>), dim3(count), dim3(256), 0, s, a, f);
-    else if (avg_support > 48) // 64/LANES coordinates per wave
-        hipLaunchKernelGGL((fm_field_sub<32, MODE, FIELD>), dim3((count + 7) / 8), dim3(256), 0, s, a, f);
-    else
-        hipLaunchKernelGGL((fm_field_sub<16, MODE, FIELD>), dim3((count + 15) / 16), dim3(256), 0, s, a, f);
+template <int FIELD, bool W0>
+static hipError_t launch_reduce(const FmArgs &a, int f, hipStream_t s) {
+    const int nc = a.ord[FIELD].n_chunks;
+    if (nc <= 0) return hipSuccess;
+    hipLaunchKernelGGL((fm_reduce_kernel<FIELD, W0>), dim3((nc + 3) / 4), dim3(256), 0, s, a, f);
     return hipGetLastError();
 }
 
-template <int MODE>
-static hipError_t launch_field(const FmArgs &a, int field, int f, hipStream_t s) {
-    const int64_t avg = a.field_count[field] > 0 ? a.n / a.field_count[field] : 0; // context supports are a subset: fine
+hipError_t fm_launch_reduce(const FmArgs &a, int field, int f, hipStream_t s) {
     switch (field) {
-    case 0: return launch_field_mode<MODE, 0>(a, f, avg, s);
-    case 1: return launch_field_mode<MODE, 1>(a, f, avg, s);
-    default: return launch_field_mode<MODE, 2>(a, f, avg, s);
+    case 0: return launch_reduce<0, false>(a, f, s);
+    case 1: return launch_reduce<1, false>(a, f, s);
+    default: return launch_reduce<2, false>(a, f, s);
     }
 }
 
-hipError_t fm_launch_field(const FmArgs &a, int field, int f, int mode, hipStream_t s) {
-    switch (mode) {
-    case 0: return launch_field<0>(a, field, f, s);
-    case 1: return launch_field<1>(a, field, f, s);
-    default: return launch_field<2>(a, field, f, s);
+hipError_t fm_launch_finish(const FmArgs &a, int field, int f, int mode, hipStream_t s) {
+    const int count = a.ord[field].count;
+    if (count <= 0) return hipSuccess;
+    const dim3 grid((count + 255) / 256), block(256);
+    switch (field) {
+    case 0: hipLaunchKernelGGL(fm_finish_kernel<0>, grid, block, 0, s, a, f, mode); break;
+    case 1: hipLaunchKernelGGL(fm_finish_kernel<1>, grid, block, 0, s, a, f, mode); break;
+    default: hipLaunchKernelGGL(fm_finish_kernel<2>, grid, block, 0, s, a, f, mode); break;
     }
+    return hipGetLastError();
 }
 
 hipError_t fm_launch_col_load(const FmArgs &a, int f, hipStream_t s) {
@@ -383,24 +424,17 @@ hipError_t fm_launch_col_load(const FmArgs &a, int f, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t fm_launch_uval(const FmArgs &a, hipStream_t s) {
-    if (a.n <= 0) return hipSuccess;
-    int64_t blocks = (a.n + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(fm_uval_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t fm_launch_flush(const FmArgs &a, hipStream_t s) {
-    if (a.n <= 0) return hipSuccess;
-    int64_t blocks = (a.n + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(fm_flush_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+hipError_t fm_launch_transpose(const double *src, double *dst, int64_t rows, int64_t cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fm_transpose_kernel, dim3((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32)), dim3(256), 0, s, src, dst,
+                       rows, cols);
     return hipGetLastError();
 }
 
 hipError_t fm_launch_w0_reduce(const FmArgs &a, double *scratch, hipStream_t s) {
-    int nblk = (int)((a.n + 65535) / 65536);
+    if (hipError_t e = launch_reduce<0, true>(a, -1, s)) return e;
+    const int64_t slots = (int64_t)a.ord[0].S * a.ord[0].count + a.ord[0].n_x;
+    int nblk = (int)((slots + 65535) / 65536);
     if (nblk < 1) nblk = 1;
     if (nblk > 256) nblk = 256;
     hipLaunchKernelGGL(fm_w0_reduce1, dim3(nblk), dim3(256), 0, s, a, scratch);
@@ -409,19 +443,21 @@ hipError_t fm_launch_w0_reduce(const FmArgs &a, double *scratch, hipStream_t s) 
 }
 
 hipError_t fm_launch_w0_apply(const FmArgs &a, hipStream_t s) {
-    int64_t blocks = (a.n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(fm_w0_apply, dim3((unsigned)blocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(fm_w0_commit, dim3(1), dim3(1), 0, s, a);
+    hipLaunchKernelGGL(fm_w0_apply, dim3(1), dim3(1), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t fm_launch_init(const FmArgs &a, hipStream_t s) {
-    if (a.n <= 0) return hipSuccess;
-    int64_t blocks = (a.n + 3) / 4;
+    const int64_t p = (int64_t)a.n_users + a.n_items + a.n_conds;
+    if (a.n > 0) {
+        int64_t blocks = (a.n + 3) / 4;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(fm_init_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    }
+    int64_t blocks = ((a.n > p ? a.n : p) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(fm_init_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fm_init_spread, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -161,10 +161,19 @@ extern "C" int cmi_load_model(cmi_handle h, const char *path, double *lrate, dou
         if (!r.ok || ne > (uint32_t)h->n_conds + 1024u) LOAD_FAIL("load_model: %s is truncated or corrupt (sim-parameter block)", path);
         f_empty.resize(ne);
         if (ne) r.get(f_empty.data(), (size_t)ne * 4);
-        if (!h->empty_conds.empty() && (f_empty != h->empty_conds || (int)f_numf != h->num_f || (int)f_dims != h->n_ctx_dims))
+        if (h->sim_params_set && (f_empty != h->empty_conds || (int)f_numf != h->num_f || (int)f_dims != h->n_ctx_dims))
             LOAD_FAIL("load_model: %s was trained with other EmptyContextConditions / numF / context dimensions than this handle has "
                       "(cmi_set_sim_params)", path);
     }
+    // a version-2 file carries the sim parameters: a handle that has none yet takes them from the file -- also when the list of
+    // empty conditions is EMPTY (the restore used to be skipped then, and CAMF_LCS's cfMatrix failed its count check
+    // after P and Q had already been overwritten)
+    const bool sim_model = h->model == CMI_MODEL_CAMF_ICS || h->model == CMI_MODEL_CAMF_LCS || h->model == CMI_MODEL_CAMF_MCS;
+    const bool restore_sim = version >= 2 && sim_model && !h->sim_params_set;
+    if (restore_sim && (f_dims < 1 || (h->model == CMI_MODEL_CAMF_LCS && f_numf < 1)))
+        LOAD_FAIL("load_model: %s holds invalid sim parameters (numF %u, %u context dimensions)", path, f_numf, f_dims);
+    for (int32_t c : f_empty)
+        if (c < 0 || c >= h->n_conds) LOAD_FAIL("load_model: %s lists an empty condition id out of range", path);
     std::vector<std::vector<double>> tabs(CMI_STATE_COUNT);
     std::vector<bool> seen(CMI_STATE_COUNT, false);
     for (uint32_t i = 0; i < nc && r.ok; ++i) {
@@ -173,7 +182,7 @@ extern "C" int cmi_load_model(cmi_handle h, const char *path, double *lrate, dou
         const uint64_t count = r.u64();
         // a handle without sim params yet gets them from the file (below): its cfMatrix then has n_conds x numF elements
         int64_t expect = which < CMI_STATE_COUNT ? h->state_count[which] : -1;
-        if (which == CMI_STATE_CF_MATRIX && version >= 2 && h->empty_conds.empty()) expect = (int64_t)h->n_conds * (int64_t)f_numf;
+        if (which == CMI_STATE_CF_MATRIX && restore_sim) expect = (int64_t)h->n_conds * (int64_t)f_numf;
         if (!r.ok || which >= CMI_STATE_COUNT || !cmi_model_has(h->model, (int)which) || (int64_t)count != expect || seen[which])
             LOAD_FAIL("load_model: unexpected container %u (count %llu) in %s", which, (unsigned long long)count, path);
         seen[which] = true;
@@ -188,9 +197,11 @@ extern "C" int cmi_load_model(cmi_handle h, const char *path, double *lrate, dou
         if (cmi_model_has(h->model, c) && !seen[c]) LOAD_FAIL("load_model: container %d missing in %s", c, path);
 #undef LOAD_FAIL
     fclose(f);
-    // only now touch the handle: a bad file leaves the model as it was
-    if (version >= 2 && h->empty_conds.empty() && !f_empty.empty())
-        if (int rc = cmi_set_sim_params(h, (int)f_numf, (int)f_dims, f_empty.data(), (int)f_empty.size())) return rc;
+    // only now touch the handle: a bad file leaves the model as it was.  Every count was validated above against the sizes the
+    // handle has AFTER the sim-parameter restore, and the restore's own arguments were checked, so what can still fail below is a
+    // HIP call, not the file.
+    if (restore_sim)
+        if (int rc = cmi_set_sim_params(h, (int)f_numf, (int)f_dims, f_empty.empty() ? nullptr : f_empty.data(), (int)f_empty.size())) return rc;
     for (int c = 0; c < CMI_STATE_COUNT; ++c)
         if (seen[c] && !tabs[c].empty())
             if (int rc = cmi_set_state(h, c, tabs[c].data(), (int64_t)tabs[c].size(), CMI_DTYPE_F64)) return rc;

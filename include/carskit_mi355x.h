@@ -258,7 +258,9 @@ int cmi_rank_list_measures(const int32_t *ranked, int len, const int32_t *truth_
 int cmi_java_int_hashset_order(int64_t n, const int32_t *values, int32_t *out, int64_t *n_out);
 
 /* device pointer of a state container (element type per CMI_FLAG_STATE_F64), so the host can run its
- * epoch-boundary exchange (RCCL all-reduce of item-side deltas) in place */
+ * epoch-boundary exchange (RCCL all-reduce of item-side deltas) in place.  The table behind the pointer is current
+ * when the call returns and host writes through it are honoured by the next epoch (a container whose live rows sit
+ * in the spoke arena is re-read from the table); call it again after every training call before touching the memory. */
 int cmi_state_device_ptr(cmi_handle h, int which, void **ptr, int64_t *count, int *dtype);
 /* the HIP stream (hipStream_t) all of this handle's work is enqueued on */
 int cmi_stream(cmi_handle h, void **stream);
@@ -359,8 +361,10 @@ int cmi_group_member(cmi_group_handle g, int shard, cmi_handle *out);
  * device (the reference's precision).  The reference's quirks are kept: the context feature of a rating is
  * index numUsers+numItems+c with c the CONTEXT-COMBINATION id and value 1/numContextDims, present only if
  * c < numConditions (FM.java:81-86); denominators add the regulariser once per rating (FM.java:181,201); the
- * error/Q update of a factor uses x_il (FM.java:209-210).  Sums are tree-reduced (not the Java's sequential
- * order): model within ~1e-12 of the reference arithmetic, RMSE within 1e-9.  `loss` (FM.java:218) is never
+ * error/Q update of a factor uses x_il (FM.java:209-210).  errors[] and Q[][] are not stored: an error is
+ * err0 + the running delta sums of its three coordinates (fm_kernels.hip), and a coordinate's sums are added per
+ * slice of its support (not the Java's sequential order): model within ~1e-8 relative of the reference
+ * arithmetic, RMSE within 1e-9.  `loss` (FM.java:218) is never
  * read by the reference and is not computed. */
 typedef struct cmi_fm_instance *cmi_fm_handle;
 
@@ -407,6 +411,12 @@ int cmi_fm_phase_buffer(cmi_fm_handle h, int phase, void **dev_ptr, int64_t *cou
 int cmi_fm_phase_apply(cmi_fm_handle h, int phase);
 /* reduce + apply of one phase fused (no exchange point), for phases whose coordinates are local to the rank */
 int cmi_fm_phase_run(cmi_fm_handle h, int phase);
+/* measurement (no reference counterpart): the layout cmi_fm_set_ratings built -- out[0..1] slices of the user / item order,
+ * [2..4] records of the three orders, [5..6] chunks, [7] HBM bytes one factor has to move, [8..9] of that the reduce launch of
+ * the user / item field, [10] slice entries, [11] p -- and the HIP-event duration of one phase's reduce kernel (it writes only
+ * scratch, the model is untouched) */
+int cmi_fm_layout(cmi_fm_handle h, int64_t out[12]);
+int cmi_fm_time_reduce(cmi_fm_handle h, int phase, int reps, double *avg_ms);
 
 /* ---- data side of the path (host-only, no GPU): DataDAO id-mapper and the compact->binary rewrite -------------
  * Integer / string work that must be BIT-EXACT with the reference (north_star: "integer id mapping bit-exact"). */

@@ -265,3 +265,30 @@ def test_spoke_arena_with_the_item_side_in_the_arena_through_the_exchange():
         assert ga.train_epoch(util.LR) == gr.train_epoch(util.LR)
     for name, x in gr.get_states(np.float32).items():
         assert np.array_equal(x, ga.get_state(name, np.float32)), name
+
+
+@pytest.mark.parametrize("hub,name", [("user", "Q"), ("item", "P")])
+def test_spoke_arena_honours_host_writes_through_the_device_pointer(hub, name):
+    """cmi_state_device_ptr is documented for the host's in-place epoch-boundary exchange, i.e. the host WRITES the table behind
+    it.  With the container's live rows in the spoke arena such a write used to be lost (the next epoch read the arena, the following
+    gather overwrote the table).  Writing through the pointer must equal the cmi_set_state path bit for bit."""
+    import torch
+    from carskit_amd.dist import _DevArray
+    model, k = "CAMF_CU", 64
+    data = util.small_data(n_users=900, n_items=220, n_dims=3, conds_per_dim=3, n=16000, seed=49)
+    _, a = _with_hub(hub, lambda: make_pair(model, data, k, CHAIN | ARENA))
+    _, b = _with_hub(hub, lambda: make_pair(model, data, k, CHAIN | ARENA))
+    assert a.schedule_traffic()["spoke_arena"]
+    for ep in range(3):
+        la, lb = a.train_epoch(util.LR), b.train_epoch(util.LR)
+        assert la == lb
+        new = (a.get_state(name) * 0.75).astype(np.float32)
+        a.set_state(name, new)                                          # the path that always worked
+        ptr, cnt, dt = b.state_device_ptr(name)                         # the documented in-place path
+        view = torch.as_tensor(_DevArray(ptr, cnt, dt), device=torch.device("cuda", 0))
+        view.copy_(torch.from_numpy(new.reshape(-1)).to(view.device))
+        torch.cuda.synchronize()
+    a.train_epoch(util.LR)
+    b.train_epoch(util.LR)
+    for n_, x in a.get_states().items():
+        assert np.array_equal(x, b.get_state(n_)), n_

@@ -118,3 +118,19 @@ def test_sim_params_travel_with_the_file_and_are_verified(tmp_path):
     c = make([1, 3])                                 # other EmptyContextConditions: refused
     with pytest.raises(capi.CmiError, match="EmptyContextConditions"):
         c.load_model(p)
+    # a model trained with an EMPTY list of empty conditions (no ':na' columns) restores into a fresh handle too --
+    # the restore used to be skipped, cfMatrix then failed its count check after P and Q had been overwritten
+    d = make([])
+    d.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+    d.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
+    d.set_state("cfMatrix", np.random.default_rng(2).random((data.n_conds, 4)))
+    d.train_epoch(util.LR)
+    q = tmp_path / "lcs_noempty.cmi"
+    d.save_model(q)
+    e = make(None)
+    e.load_model(q)
+    e.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
+    assert np.array_equal(d.predict(data.u[:20], data.j[:20], data.ctx[:20]), e.predict(data.u[:20], data.j[:20], data.ctx[:20]))
+    assert np.array_equal(d.get_state("cfMatrix"), e.get_state("cfMatrix"))
+    with pytest.raises(capi.CmiError, match="EmptyContextConditions"):     # a handle configured with an empty list refuses a file with [0, 3]
+        make([]).load_model(p)
