@@ -74,6 +74,7 @@ SYMBOLS = [
     ("cmi_fm_eval_rankings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int, C.c_int,
                                        C.c_int, _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
     ("cmi_last_rank_ms", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_dbl)]),
+    ("cmi_last_rank_host_ms", C.c_int, [_vp, _vp]),
     ("cmi_rank_plan", C.c_int, [C.c_int32, C.c_int32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int,
                                 C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("cmi_rank_list_measures", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
@@ -725,6 +726,11 @@ class Instance:
         ms, fl = C.c_float(), _dbl()
         self._chk(self.L.cmi_last_rank_ms(self.h, C.byref(ms), C.byref(fl)))
         return ms.value, fl.value
+
+    def last_rank_host_ms(self):
+        out = np.zeros(5)
+        self._chk(self.L.cmi_last_rank_host_ms(self.h, _p(out)))
+        return dict(zip(("plan", "setup", "scoring_loop", "tail", "total"), out.tolist()))
 
     def eval_rankings(self, train, test, bin_thold=-1.0, num_recs=10, num_ignore=0, strategy="ucu", with_lists=False):
         """Recommender.evalRankings (Recommender.java:668-964).  train/test: (u, j, ctx, r) array tuples.

@@ -182,6 +182,7 @@ extern "C" int cmi_destroy(cmi_handle h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     free_ratings(h);
+    h->rank_ws.release();
     for (void *&p : h->state)
         if (p) {
             hipFree(p);

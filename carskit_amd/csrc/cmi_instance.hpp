@@ -1,5 +1,6 @@
 // cmi_instance.hpp -- the object behind a cmi_handle, shared by the translation units of libcarskit_mi355x.so.
 #pragma once
+#include "rank_host.hpp"
 #include "../../include/carskit_mi355x.h"
 
 #include <hip/hip_runtime.h>
@@ -80,6 +81,7 @@ struct cmi_instance {
     bool sim_params_set = false; // cmi_set_sim_params has run (an EMPTY EmptyContextConditions list is a valid setting)
     std::vector<int32_t> empty_conds;
     int32_t *d_empty = nullptr, *d_ui_ptr = nullptr, *d_ui_items = nullptr;
+    cmi::RankWorkspace rank_ws;  // cmi_eval_rankings' device / pinned buffers, reused by the next evaluation
     float last_rank_ms = 0.f;    // device time of the most recent cmi_eval_rankings scoring loop (HIP events)
     double last_rank_flops = 0.0; // 2 * queries * candidates * padded operand length of that loop
 };

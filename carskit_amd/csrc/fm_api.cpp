@@ -37,6 +37,7 @@ struct cmi_fm_instance {
     double2 *d_tab = nullptr;
     int32_t *d_u = nullptr, *d_j = nullptr, *d_ctx = nullptr, *d_i2u = nullptr, *d_c2u = nullptr;
     FmOrderDev ord[3];
+    RankWorkspace rank_ws; // cmi_fm_eval_rankings' buffers, reused by the next evaluation
     int col_f = -1; // factor whose column is loaded in d_tab[].x
     int64_t part_count = 0;
     int64_t slice_entries = 131072; // table entries (16 bytes each) a slice of the other field may gather: 2 MB stays L2-resident (measured best of 16 K .. 256 K)
@@ -83,6 +84,7 @@ extern "C" int cmi_fm_destroy(cmi_fm_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     fm_free_ratings(h);
+    h->rank_ws.release();
     void *ptrs[] = {h->d_w0, h->d_d0, h->d_w, h->d_V, h->d_Vt, h->d_part, h->d_scratch, h->d_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -622,9 +624,12 @@ extern "C" int cmi_fm_eval_rankings(cmi_fm_handle h, int64_t n_train, const int3
     RankPlan plan;
     rank_build_plan(h->n_users, h->n_items, RankTuples{n_train, tu, tj, tctx, tr}, RankTuples{n_test, su, sj, sctx, sr}, bin_thold,
                     num_ignore, plan);
-    std::vector<int32_t> top_idx, top_count;
-    std::vector<double> top_score;
-    if (!plan.qu.empty() && !plan.cand.empty()) {
+    RankWorkspace &ws = h->rank_ws;
+    const int64_t nq = (int64_t)plan.qu.size();
+    std::vector<double> vals((size_t)nq * 18);
+    std::vector<int32_t> no_lists;
+    const int32_t *top_count = nullptr;
+    if (nq > 0 && !plan.cand.empty()) {
         RankOperands<double> ops;
         ops.k_logical = h->k + 1;
         const RankFmArgs base{h->d_w0, h->d_w, h->d_V, h->k, 0, h->n_users, h->n_items, h->n_conds, 1.0 / (double)h->n_ctx_dims};
@@ -638,18 +643,18 @@ extern "C" int cmi_fm_eval_rankings(cmi_fm_handle h, int64_t n_train, const int3
             a.kp = kp;
             return rank_launch_fm_queries(a, dqu, dqc, n, dA, drc, s);
         };
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        hipError_t e = hipEventCreate(&ev0);
-        if (e == hipSuccess) e = hipEventCreate(&ev1);
-        if (e == hipSuccess)
-            e = rank_run_device<double>(h->stream, ev0, ev1, plan, ops, bin_thold, num_recs, top_idx, top_score, top_count, nullptr, nullptr);
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        FM_HIP(h, e);
+        auto on_batch = [&](int64_t q0, int64_t q1) {
+            rank_measures_range(plan, num_recs, (const int32_t *)ws.h_top.p, (const double *)ws.h_score.p, (const int32_t *)ws.h_count.p, q0, q1,
+                                vals.data(), q_user, q_ctx, q_count, top_items, top_scores);
+        };
+        FM_HIP(h, rank_run_device<double>(h->stream, ws, plan, ops, bin_thold, num_recs, on_batch, nullptr, nullptr));
+        top_count = (const int32_t *)ws.h_count.p;
     } else {
-        top_count.assign(plan.qu.size(), 0);
+        no_lists.assign((size_t)nq, 0);
+        top_count = no_lists.data();
+        rank_measures_range(plan, num_recs, nullptr, nullptr, top_count, 0, nq, vals.data(), q_user, q_ctx, q_count, top_items, top_scores);
     }
-    rank_metrics(plan, strategy, num_recs, top_idx, top_score, top_count, out, q_user, q_ctx, q_count, top_items, top_scores);
+    rank_average(plan, strategy, top_count, vals.data(), out);
     if (n_queries) *n_queries = (int64_t)plan.qu.size();
     return CMI_OK;
 }

@@ -22,7 +22,7 @@ struct FmChunk {
 };
 
 constexpr int FM_SHORT = 64;      // longest piece a single lane sums
-constexpr int FM_CHUNK = 256;     // records per stream chunk
+constexpr int FM_CHUNK = 512;     // records per stream chunk
 constexpr int FM_VECTOR = 2048;   // records per vector chunk
 
 // The ratings in the order one FIELD streams them: sorted by (slice of the other id, this field's coordinate), so a

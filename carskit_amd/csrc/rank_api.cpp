@@ -3,9 +3,13 @@
 // Host side: query / candidate / exclusion bookkeeping and the (tiny, per-query) metric formulas; device side:
 // rank_kernels.hip.  No CPU scoring path exists.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <future>
+#include <memory>
 #include <numeric>
+#include <thread>
 
 #include "cmi_instance.hpp"
 #include "rank_host.hpp"
@@ -14,6 +18,30 @@
 using namespace cmi;
 
 namespace {
+
+// The host side of an evaluation (plan before the device run, measures after it) is O(tuples + queries) of independent per-user /
+// per-query work: it runs on the host's cores in contiguous index ranges, each range producing its own output that is then
+// concatenated in range order -- the result is the serial one, element for element.
+int host_threads(int64_t work_items) {
+    if (const char *e = getenv("CMI_HOST_THREADS")) return std::max(1, std::min(atoi(e), 64)); // tests: force the ranged form on small inputs
+    int t = (int)std::thread::hardware_concurrency();
+    t = std::max(1, std::min(t, 16)); // measured on the 64-core host of an MI355X box: 16 threads 13 ms, 32 threads 17 ms for the plan
+    return (int)std::max<int64_t>(1, std::min<int64_t>(t, work_items / 4096 + 1));
+}
+template <typename F>
+void parallel_ranges(int64_t n, int nt, F &&body) { // body(range index, begin, end)
+    if (nt <= 1 || n <= 0) {
+        body(0, (int64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t step = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t b = std::min<int64_t>(n, t * step), e = std::min<int64_t>(n, b + step);
+        th.emplace_back([&body, t, b, e]() { body(t, b, e); });
+    }
+    for (std::thread &x : th) x.join();
+}
 
 // ---- java.util.HashSet<Integer> iteration order -----------------------------------------------------------------
 // Integer.hashCode() is the value; HashMap spreads h ^ (h >>> 16), indexes with (cap-1), doubles the table when
@@ -107,26 +135,6 @@ struct NanMean { // happy.coding.math.Stats.mean(Collection): NaN entries are sk
     double value() const { return c ? s / (double)c : std::nan(""); }
 };
 
-// tuple indices `sel` ordered by (user, context, item): counting sort by user, then each user's short run is sorted
-// (O(n) instead of one comparison sort over millions of tuples)
-std::vector<int64_t> order_by_user_ctx_item(int n_users, const std::vector<int64_t> &sel, const int32_t *u, const int32_t *c,
-                                            const int32_t *j) {
-    std::vector<int64_t> off((size_t)n_users + 1, 0), out(sel.size());
-    for (int64_t t : sel) off[(size_t)u[t] + 1]++;
-    for (int l = 0; l < n_users; ++l) off[(size_t)l + 1] += off[(size_t)l];
-    {
-        std::vector<int64_t> cur(off.begin(), off.end() - 1);
-        for (int64_t t : sel) out[(size_t)cur[(size_t)u[t]]++] = t;
-    }
-    for (int l = 0; l < n_users; ++l)
-        if (off[(size_t)l + 1] - off[(size_t)l] > 1)
-            std::sort(out.begin() + off[(size_t)l], out.begin() + off[(size_t)l + 1], [&](int64_t a, int64_t b) {
-                if (c[a] != c[b]) return c[a] < c[b];
-                return j[a] < j[b];
-            });
-    return out;
-}
-
 constexpr int N_MEAS = 18; // Pre,Rec,AUC,MAP,NDCG,MRR x {5,10,N}
 
 // the 18 measures of ONE ranked list (already cut at num_recs): index = measure * 3 + cut-off, cut-offs {5, 10, num_recs}
@@ -151,7 +159,8 @@ namespace cmi {
 
 void rank_build_plan(int n_users, int n_items, const RankTuples &train, const RankTuples &test, double bin_thold,
                      int num_ignore, RankPlan &plan) {
-    // candidate items: rateDao.getItemList(trainMatrix) -> HashSet<Integer> (DataDAO.java:1210-1218)
+    // candidate items: rateDao.getItemList(trainMatrix) -> HashSet<Integer> (DataDAO.java:1210-1218).  One sequential pass: the
+    // first-seen order is what the HashSet's iteration order is computed from.
     std::vector<int32_t> first_seen, degree(n_items, 0);
     for (int64_t t = 0; t < train.n; ++t) {
         if (train.r && train.r[t] == 0.0) continue; // a sparse matrix holds no zero entries
@@ -170,112 +179,201 @@ void rank_build_plan(int n_users, int n_items, const RankTuples &train, const Ra
     std::vector<int32_t> cand_pos(n_items, -1);
     for (int i = 0; i < nc; ++i) cand_pos[cand[i]] = i;
 
-    // queries: test positives (rate > threshold) grouped by (user, context)  (DataDAO.getUserCtxList, DataDAO.java:1114-1140)
-    std::vector<int64_t> pos;
-    for (int64_t t = 0; t < test.n; ++t)
-        if (test.r[t] != 0.0 && test.r[t] > bin_thold) pos.push_back(t);
-    pos = order_by_user_ctx_item(n_users, pos, test.u, test.ctx, test.j);
-    std::vector<int32_t> &qu = plan.qu, &qc = plan.qc, &truth_items = plan.truth_items;
-    std::vector<int64_t> &truth_ptr = plan.truth_ptr;
+    // Training tuples and test positives (rate > threshold; DataDAO.getUserCtxList, DataDAO.java:1114-1140) bucketed by user as
+    // packed (context, item) keys, in the caller's order inside a bucket.  Every host thread owns a range of users: ONE scan of all
+    // tuples (sequential reads) collects its own users' tuples, a second region scatters them into the user buckets (a cache-sized
+    // region of its own: no two threads share a cursor) and turns each of its users into queries.
+    const int nt = host_threads(train.n + test.n);
+    std::vector<int64_t> toff((size_t)n_users + 1, 0), poff((size_t)n_users + 1, 0);
+    struct Local {
+        std::vector<int32_t> tu, pu;
+        std::vector<uint64_t> tk, pk;
+    };
+    std::vector<Local> loc((size_t)nt);
+    parallel_ranges(n_users, nt, [&](int part, int64_t u0, int64_t u1) {
+        Local &L = loc[(size_t)part];
+        for (int64_t t = 0; t < train.n; ++t) {
+            const int32_t u = train.u[t];
+            if (u < u0 || u >= u1 || (train.r && train.r[t] == 0.0)) continue;
+            L.tu.push_back(u);
+            L.tk.push_back(((uint64_t)(uint32_t)train.ctx[t] << 32) | (uint32_t)train.j[t]);
+            toff[(size_t)u + 1]++;
+        }
+        for (int64_t t = 0; t < test.n; ++t) {
+            const int32_t u = test.u[t];
+            if (u < u0 || u >= u1 || !(test.r[t] != 0.0 && test.r[t] > bin_thold)) continue;
+            L.pu.push_back(u);
+            L.pk.push_back(((uint64_t)(uint32_t)test.ctx[t] << 32) | (uint32_t)test.j[t]);
+            poff[(size_t)u + 1]++;
+        }
+    });
+    for (int l = 0; l < n_users; ++l) {
+        toff[(size_t)l + 1] += toff[(size_t)l];
+        poff[(size_t)l + 1] += poff[(size_t)l];
+    }
+    std::unique_ptr<uint64_t[]> tkey(new uint64_t[(size_t)toff[(size_t)n_users] + 1]), pkey(new uint64_t[(size_t)poff[(size_t)n_users] + 1]);
+
+    // per user: its queries in (context, item) order -- a query is a (user, context) with at least one correct item that is a
+    // candidate (Recommender.java:789-790) -- and, per query, the candidate positions of the items the user rated in the same
+    // context in the training set (Recommender.java:793, 814-816), in item order
+    struct Part {
+        std::vector<int32_t> qu, qc, truth_items, excl_idx;
+        std::vector<int64_t> truth_end, excl_end; // running ends inside this part
+    };
+    std::vector<Part> parts((size_t)nt);
+    parallel_ranges(n_users, nt, [&](int part, int64_t u0, int64_t u1) {
+        if (u0 >= u1) return;
+        {
+            const Local &L = loc[(size_t)part];
+            std::vector<int64_t> cur(toff.begin() + u0, toff.begin() + u1);
+            for (size_t i = 0; i < L.tu.size(); ++i) tkey[(size_t)cur[(size_t)(L.tu[i] - u0)]++] = L.tk[i];
+            cur.assign(poff.begin() + u0, poff.begin() + u1);
+            for (size_t i = 0; i < L.pu.size(); ++i) pkey[(size_t)cur[(size_t)(L.pu[i] - u0)]++] = L.pk[i];
+        }
+        Part &P = parts[(size_t)part];
+        std::vector<uint32_t> items;
+        for (int64_t u = u0; u < u1; ++u) {
+            uint64_t *pb = pkey.get() + poff[(size_t)u], *pe = pkey.get() + poff[(size_t)u + 1];
+            if (pb == pe) continue;
+            std::sort(pb, pe);
+            const uint64_t *tb = tkey.get() + toff[(size_t)u], *te = tkey.get() + toff[(size_t)u + 1];
+            for (uint64_t *i = pb; i < pe;) {
+                const uint32_t c = (uint32_t)(*i >> 32);
+                const size_t before = P.truth_items.size();
+                uint64_t *e = i;
+                for (; e < pe && (uint32_t)(*e >> 32) == c; ++e) {
+                    const int32_t j = (int32_t)(uint32_t)*e;
+                    if (cand_pos[j] >= 0 && (P.truth_items.size() == before || P.truth_items.back() != j)) P.truth_items.push_back(j);
+                }
+                i = e;
+                if (P.truth_items.size() == before) continue;
+                P.qu.push_back((int32_t)u);
+                P.qc.push_back((int32_t)c);
+                P.truth_end.push_back((int64_t)P.truth_items.size());
+                items.clear();
+                for (const uint64_t *t = tb; t < te; ++t)
+                    if ((uint32_t)(*t >> 32) == c) items.push_back((uint32_t)*t);
+                std::sort(items.begin(), items.end());
+                const size_t ebefore = P.excl_idx.size();
+                for (uint32_t j : items) {
+                    const int32_t cp = cand_pos[j];
+                    if (cp >= 0 && (P.excl_idx.size() == ebefore || P.excl_idx.back() != cp)) P.excl_idx.push_back(cp);
+                }
+                P.excl_end.push_back((int64_t)P.excl_idx.size());
+            }
+        }
+    });
+    std::vector<int32_t> &qu = plan.qu, &qc = plan.qc, &truth_items = plan.truth_items, &excl_idx = plan.excl_idx;
+    std::vector<int64_t> &truth_ptr = plan.truth_ptr, &excl_ptr = plan.excl_ptr;
     qu.clear();
     qc.clear();
     truth_items.clear();
-    truth_ptr.assign(1, 0);
-    for (size_t i = 0; i < pos.size();) {
-        size_t e = i;
-        const size_t before = truth_items.size();
-        while (e < pos.size() && test.u[pos[e]] == test.u[pos[i]] && test.ctx[pos[e]] == test.ctx[pos[i]]) {
-            const int32_t j = test.j[pos[e]];
-            if (cand_pos[j] >= 0 && (truth_items.size() == before || truth_items.back() != j)) truth_items.push_back(j);
-            ++e;
-        }
-        if (truth_items.size() > before) { // correctItems non-empty (Recommender.java:789-790)
-            qu.push_back(test.u[pos[i]]);
-            qc.push_back(test.ctx[pos[i]]);
-            truth_ptr.push_back((int64_t)truth_items.size());
-        }
-        i = e;
-    }
-    const int64_t nq = (int64_t)qu.size();
-
-    // exclusions: items the user rated in the same context in the training set (Recommender.java:793, 814-816)
-    std::vector<int64_t> tord;
-    for (int64_t t = 0; t < train.n; ++t)
-        if (!(train.r && train.r[t] == 0.0)) tord.push_back(t);
-    tord = order_by_user_ctx_item(n_users, tord, train.u, train.ctx, train.j);
-    std::vector<int64_t> &excl_ptr = plan.excl_ptr;
-    std::vector<int32_t> &excl_idx = plan.excl_idx;
-    excl_ptr.assign(1, 0);
     excl_idx.clear();
-    {
-        size_t p = 0;
-        for (int64_t q = 0; q < nq; ++q) {
-            while (p < tord.size() && (train.u[tord[p]] < qu[q] || (train.u[tord[p]] == qu[q] && train.ctx[tord[p]] < qc[q]))) ++p;
-            size_t e = p;
-            while (e < tord.size() && train.u[tord[e]] == qu[q] && train.ctx[tord[e]] == qc[q]) {
-                const int32_t cp = cand_pos[train.j[tord[e]]];
-                if (cp >= 0 && (excl_idx.size() == (size_t)excl_ptr.back() || excl_idx.back() != cp)) excl_idx.push_back(cp);
-                ++e;
-            }
-            excl_ptr.push_back((int64_t)excl_idx.size());
-        }
+    truth_ptr.assign(1, 0);
+    excl_ptr.assign(1, 0);
+    for (const Part &P : parts) {
+        const int64_t t0 = (int64_t)truth_items.size(), e0 = (int64_t)excl_idx.size();
+        qu.insert(qu.end(), P.qu.begin(), P.qu.end());
+        qc.insert(qc.end(), P.qc.begin(), P.qc.end());
+        truth_items.insert(truth_items.end(), P.truth_items.begin(), P.truth_items.end());
+        excl_idx.insert(excl_idx.end(), P.excl_idx.begin(), P.excl_idx.end());
+        for (int64_t v : P.truth_end) truth_ptr.push_back(t0 + v);
+        for (int64_t v : P.excl_end) excl_ptr.push_back(e0 + v);
     }
-
 }
 
-void rank_metrics(const RankPlan &plan, int strategy, int num_recs, const std::vector<int32_t> &top_idx,
-                  const std::vector<double> &top_score, const std::vector<int32_t> &top_count, double *out,
-                  int32_t *q_user, int32_t *q_ctx, int32_t *q_count, int32_t *top_items, double *top_scores) {
-    const int64_t nq = (int64_t)plan.qu.size();
+void rank_measures_range(const RankPlan &plan, int num_recs, const int32_t *top_idx, const double *top_score, const int32_t *top_count,
+                         int64_t q_begin, int64_t q_end, double *vals, int32_t *q_user, int32_t *q_ctx, int32_t *q_count,
+                         int32_t *top_items, double *top_scores) {
     const int nc = (int)plan.cand.size();
+    // each query's measures are a pure function of its list: ranges of queries on the host's cores
+    parallel_ranges(q_end - q_begin, host_threads((q_end - q_begin) * 8), [&](int, int64_t r0, int64_t r1) {
+        std::vector<int32_t> ranked(num_recs);
+        for (int64_t q = q_begin + r0; q < q_begin + r1; ++q) {
+            const int len = top_count[q];
+            if (q_user) q_user[q] = plan.qu[q];
+            if (q_ctx) q_ctx[q] = plan.qc[q];
+            if (q_count) q_count[q] = len;
+            for (int i = 0; i < len; ++i) {
+                ranked[i] = plan.cand[top_idx[(size_t)q * num_recs + i]];
+                if (top_items) top_items[(size_t)q * num_recs + i] = ranked[i];
+                if (top_scores) top_scores[(size_t)q * num_recs + i] = top_score[(size_t)q * num_recs + i];
+            }
+            for (int i = len; i < num_recs; ++i) {
+                if (top_items) top_items[(size_t)q * num_recs + i] = -1;
+                if (top_scores) top_scores[(size_t)q * num_recs + i] = std::nan("");
+            }
+            if (len > 0) { // "no recommendations available" queries are skipped (Recommender.java:818-819)
+                const Truth t{plan.truth_items.data() + plan.truth_ptr[q], (int)(plan.truth_ptr[q + 1] - plan.truth_ptr[q])};
+                const int num_cands = nc - (int)(plan.excl_ptr[q + 1] - plan.excl_ptr[q]);
+                list_measures(ranked.data(), len, t, num_cands - len, num_recs, vals + (size_t)q * N_MEAS);
+            }
+        }
+    });
+}
+
+void rank_average(const RankPlan &plan, int strategy, const int32_t *top_count, const double *vals, double *out) {
+    const int64_t nq = (int64_t)plan.qu.size();
     for (int m = 0; m < CMI_RANK_MEASURES; ++m) out[m] = std::nan("");
     out[18] = out[19] = out[20] = 0.0; // D5/D10/DN: isDiverseUsed=false (Recommender.java:939-941)
-    // metrics, per query then averaged per strategy (Recommender.java:850-960)
+    // the serial part: 18 additions per query, in query order
     NanMean total[N_MEAS], per_user[N_MEAS];
-    std::vector<int32_t> ranked(num_recs);
     auto flush_user = [&]() {
         for (int m = 0; m < N_MEAS; ++m) {
             total[m].add(per_user[m].value());
             per_user[m] = NanMean();
         }
     };
-    int64_t emitted = 0;
     for (int64_t q = 0; q < nq; ++q) {
-        const int len = top_count[q];
-        if (q_user) q_user[q] = plan.qu[q];
-        if (q_ctx) q_ctx[q] = plan.qc[q];
-        if (q_count) q_count[q] = len;
-        for (int i = 0; i < len; ++i) {
-            ranked[i] = plan.cand[top_idx[(size_t)q * num_recs + i]];
-            if (top_items) top_items[(size_t)q * num_recs + i] = ranked[i];
-            if (top_scores) top_scores[(size_t)q * num_recs + i] = top_score[(size_t)q * num_recs + i];
-        }
-        for (int i = len; i < num_recs; ++i) {
-            if (top_items) top_items[(size_t)q * num_recs + i] = -1;
-            if (top_scores) top_scores[(size_t)q * num_recs + i] = std::nan("");
-        }
-        if (len > 0) { // "no recommendations available" queries are skipped (Recommender.java:818-819)
-            const Truth t{plan.truth_items.data() + plan.truth_ptr[q], (int)(plan.truth_ptr[q + 1] - plan.truth_ptr[q])};
-            const int num_cands = nc - (int)(plan.excl_ptr[q + 1] - plan.excl_ptr[q]);
-            const int num_dropped = num_cands - len;
+        if (top_count[q] > 0) {
             NanMean *dst = strategy == CMI_RANK_UC ? total : per_user;
-            double vals[N_MEAS];
-            list_measures(ranked.data(), len, t, num_dropped, num_recs, vals);
-            for (int m = 0; m < N_MEAS; ++m) dst[m].add(vals[m]);
-            ++emitted;
+            for (int m = 0; m < N_MEAS; ++m) dst[m].add(vals[(size_t)q * N_MEAS + m]);
         }
         // ucu: a test user contributes the NaN-skipping mean over its contexts -- NaN (skipped again) if none of
         // its contexts produced a list (Recommender.java:903-926)
         if (strategy == CMI_RANK_UCU && (q + 1 == nq || plan.qu[q + 1] != plan.qu[q])) flush_user();
     }
     for (int m = 0; m < N_MEAS; ++m) out[m] = total[m].value();
-    (void)emitted;
+}
+
+hipError_t RankWorkspace::need(Buf &b, size_t bytes, bool pinned) {
+    bytes = std::max<size_t>(bytes, 8);
+    if (b.cap >= bytes) return hipSuccess;
+    if (b.p) (void)(pinned ? hipHostFree(b.p) : hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = bytes + bytes / 8; // a little head room: the next fold's test set is rarely the same size
+    hipError_t e = pinned ? hipHostMalloc(&b.p, want, hipHostMallocDefault) : hipMalloc(&b.p, want);
+    if (e == hipSuccess) b.cap = want;
+    return e;
+}
+
+void RankWorkspace::release() {
+    Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount};
+    for (Buf *b : dev) {
+        if (b->p) (void)hipFree(b->p);
+        *b = Buf();
+    }
+    Buf *host[] = {&h_top, &h_score, &h_count};
+    for (Buf *b : host) {
+        if (b->p) (void)hipHostFree(b->p);
+        *b = Buf();
+    }
+    hipEvent_t *evs[] = {&ev0, &ev1, &evb[0], &evb[1]};
+    for (hipEvent_t *e : evs) {
+        if (*e) (void)hipEventDestroy(*e);
+        *e = nullptr;
+    }
+}
+
+static double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 template <typename T>
-hipError_t rank_run_device(hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, const RankPlan &plan, const RankOperands<T> &ops,
-                           double thold, int topn, std::vector<int32_t> &top_idx, std::vector<double> &top_score,
-                           std::vector<int32_t> &top_count, float *ms, double *flops) {
+hipError_t rank_run_device(hipStream_t stream, RankWorkspace &ws, const RankPlan &plan, const RankOperands<T> &ops, double thold, int topn,
+                           const std::function<void(int64_t, int64_t)> &on_batch, float *ms, double *flops) {
+    const auto t_setup = std::chrono::steady_clock::now();
     const std::vector<int32_t> &cand = plan.cand, &qu = plan.qu, &qc = plan.qc, &excl_idx = plan.excl_idx;
     const std::vector<int64_t> &excl_ptr = plan.excl_ptr;
     const int nc = (int)cand.size();
@@ -284,49 +382,39 @@ hipError_t rank_run_device(hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, c
     // never written back)
     const int kp = (ops.k_logical + 15) / 16 * 16; // multiple of both kernels' k step
     auto up128 = [](int64_t v) { return (size_t)((v + 127) / 128 * 128); };
-    // fp32 state with many candidates: the slab-free form (rank_kernels.hip, RankFilter) -- a sample of the candidates gives every query a
-    // lower bound of its N-th best score, the full contraction then appends only the scores that can still make the list; the
-    // [queries x candidates] score slab (21.5 GB for 270 K queries x 20 K items) is never written or re-read
-    bool filtered = false;
-    if constexpr (sizeof(T) == 4) filtered = rank_filter_usable(nc, kp, topn);
-    const int ns = filtered ? rank_filter_sample(nc) : nc;
-    const int cap = 1024;
-    // query batch: keep the score slab (or the sample slab + the survivor lists) around 1 GiB
-    const int64_t per_query = filtered ? (int64_t)ns * 4 + (int64_t)cap * 8 : (int64_t)nc * (int64_t)sizeof(T);
-    int64_t bq = std::max<int64_t>(64, ((int64_t)1 << 30) / per_query);
+    // query batch: keep the score slab around 1 GiB
+    int64_t bq = std::max<int64_t>(64, ((int64_t)1 << 30) / ((int64_t)nc * (int64_t)sizeof(T)));
     bq = std::min<int64_t>(bq, nq);
-    if (const char *e = getenv("CMI_RANK_BATCH")) bq = std::max<int64_t>(1, std::min<int64_t>(atoll(e), nq));
+    if (const char *e = getenv("CMI_RANK_BATCH")) bq = std::max<int64_t>(1, std::min<int64_t>(atoll(e), nq)); // tests: batching is invisible
 
-    T *dA = nullptr, *dB = nullptr, *dS = nullptr, *drc = nullptr;
-    int32_t *dcand = nullptr, *dqu = nullptr, *dqc = nullptr, *dexcl = nullptr, *dtop = nullptr, *dcount = nullptr;
-    int64_t *dexptr = nullptr;
-    double *dscore = nullptr;
-    float *dtau = nullptr;
-    int *dcnt = nullptr, *dover = nullptr;
-    int2 *dlist = nullptr;
-    T *dS_full = nullptr; // slab form, allocated only if a filtered batch overflows
     hipError_t e = hipSuccess;
-    auto alloc = [&](void **p, size_t bytes) {
-        if (e == hipSuccess) e = hipMalloc(p, std::max<size_t>(bytes, 8));
+    auto need = [&](RankWorkspace::Buf &b, size_t bytes, bool pinned = false) {
+        if (e == hipSuccess) e = ws.need(b, bytes, pinned);
     };
-    alloc((void **)&dB, up128(nc) * kp * sizeof(T));
-    alloc((void **)&dA, up128(bq) * kp * sizeof(T));
-    alloc((void **)&dS, (size_t)bq * (size_t)ns * sizeof(T));
-    if (filtered) {
-        alloc((void **)&dtau, (size_t)bq * 4);
-        alloc((void **)&dcnt, (size_t)bq * 4);
-        alloc((void **)&dover, 4);
-        alloc((void **)&dlist, (size_t)bq * cap * sizeof(int2));
-    }
-    alloc((void **)&drc, (size_t)bq * sizeof(T));
-    alloc((void **)&dcand, (size_t)nc * 4);
-    alloc((void **)&dqu, (size_t)nq * 4);
-    alloc((void **)&dqc, (size_t)nq * 4);
-    alloc((void **)&dexptr, (size_t)(nq + 1) * 8);
-    alloc((void **)&dexcl, excl_idx.size() * 4);
-    alloc((void **)&dtop, (size_t)nq * topn * 4);
-    alloc((void **)&dscore, (size_t)nq * topn * 8);
-    alloc((void **)&dcount, (size_t)nq * 4);
+    need(ws.dB, up128(nc) * kp * sizeof(T));
+    need(ws.dA, up128(bq) * kp * sizeof(T));
+    need(ws.dS, (size_t)bq * (size_t)nc * sizeof(T));
+    need(ws.drc, (size_t)bq * sizeof(T));
+    need(ws.dcand, (size_t)nc * 4);
+    need(ws.dqu, (size_t)nq * 4);
+    need(ws.dqc, (size_t)nq * 4);
+    need(ws.dexptr, (size_t)(nq + 1) * 8);
+    need(ws.dexcl, excl_idx.size() * 4);
+    need(ws.dtop, (size_t)nq * topn * 4);
+    need(ws.dscore, (size_t)nq * topn * 8);
+    need(ws.dcount, (size_t)nq * 4);
+    need(ws.h_top, (size_t)nq * topn * 4, true);
+    need(ws.h_score, (size_t)nq * topn * 8, true);
+    need(ws.h_count, (size_t)nq * 4, true);
+    hipEvent_t *evs[] = {&ws.ev0, &ws.ev1, &ws.evb[0], &ws.evb[1]};
+    for (hipEvent_t *ev : evs)
+        if (e == hipSuccess && !*ev) e = hipEventCreate(ev);
+    if (e != hipSuccess) return e;
+    T *dA = (T *)ws.dA.p, *dB = (T *)ws.dB.p, *dS = (T *)ws.dS.p, *drc = (T *)ws.drc.p;
+    int32_t *dcand = (int32_t *)ws.dcand.p, *dqu = (int32_t *)ws.dqu.p, *dqc = (int32_t *)ws.dqc.p, *dexcl = (int32_t *)ws.dexcl.p;
+    int32_t *dtop = (int32_t *)ws.dtop.p, *dcount = (int32_t *)ws.dcount.p;
+    int64_t *dexptr = (int64_t *)ws.dexptr.p;
+    double *dscore = (double *)ws.dscore.p;
     auto up = [&](void *d, const void *s, size_t bytes) {
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream);
     };
@@ -338,56 +426,43 @@ hipError_t rank_run_device(hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, c
     if (e == hipSuccess) e = hipMemsetAsync(dtop, 0xff, (size_t)nq * topn * 4, stream);
     if (e == hipSuccess) e = hipMemsetAsync(dscore, 0, (size_t)nq * topn * 8, stream);
     if (e == hipSuccess) e = ops.build_items(dB, dcand, nc, kp, stream);
-    if (e == hipSuccess) e = hipEventRecord(ev0, stream);
-    for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += bq) {
+    if (e == hipSuccess) e = hipEventRecord(ws.ev0, stream);
+    ws.host_ms[1] = ms_since(t_setup);
+    const auto t_loop = std::chrono::steady_clock::now();
+    // batch b scores while the host turns batch b-1's lists (already copied back) into measures
+    int64_t prev0 = -1, prev1 = -1;
+    int nb = 0;
+    for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += bq, ++nb) {
         const int n = (int)std::min<int64_t>(bq, nq - q0);
         e = ops.build_queries(dA, drc, dqu + q0, dqc + q0, n, kp, stream);
-        if (e != hipSuccess) break;
-        if (filtered) {
-            if constexpr (sizeof(T) == 4) {
-                e = hipMemsetAsync(dover, 0, 4, stream);
-                if (e == hipSuccess)
-                    e = rank_launch_score_filtered((const float *)dA, (const float *)dB, (const float *)drc, (float *)dS, n, nc, kp, dexptr, dexcl,
-                                                   (int)q0, thold, topn, dtau, dcnt, dlist, cap, dover, dtop, dscore, dcount, stream);
-                int over = 0;
-                if (e == hipSuccess) e = hipMemcpyAsync(&over, dover, 4, hipMemcpyDeviceToHost, stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(stream); // one host round trip per ~100 K queries
-                if (e == hipSuccess && over > 0) {
-                    // some query keeps more than `cap` candidates at or above its bound (heavy ties, or too few qualifying scores in the
-                    // sample): this batch goes through the slab form, in sub-batches of the slab's size
-                    const int64_t sub = std::max<int64_t>(64, ((int64_t)1 << 30) / ((int64_t)nc * 4));
-                    if (!dS_full) e = hipMalloc((void **)&dS_full, (size_t)std::min<int64_t>(sub, bq) * (size_t)nc * 4);
-                    for (int64_t s0 = 0; s0 < n && e == hipSuccess; s0 += sub) {
-                        const int m = (int)std::min<int64_t>(sub, n - s0);
-                        e = rank_launch_score<T>(dA + (size_t)s0 * kp, dB, drc + s0, dS_full, m, nc, kp, dexptr, dexcl, (int)(q0 + s0), thold, topn,
-                                                 dtop, dscore, dcount, stream);
-                    }
-                }
-            }
-        } else {
-            e = rank_launch_score<T>(dA, dB, drc, dS, n, nc, kp, dexptr, dexcl, (int)q0, thold, topn, dtop, dscore, dcount, stream);
+        if (e == hipSuccess) e = rank_launch_score<T>(dA, dB, drc, dS, n, nc, kp, dexptr, dexcl, (int)q0, thold, topn, dtop, dscore, dcount, stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync((int32_t *)ws.h_top.p + (size_t)q0 * topn, dtop + (size_t)q0 * topn, (size_t)n * topn * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync((double *)ws.h_score.p + (size_t)q0 * topn, dscore + (size_t)q0 * topn, (size_t)n * topn * 8, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync((int32_t *)ws.h_count.p + q0, dcount + q0, (size_t)n * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipEventRecord(ws.evb[nb & 1], stream);
+        if (e == hipSuccess && prev0 >= 0) {
+            e = hipEventSynchronize(ws.evb[(nb - 1) & 1]);
+            if (e == hipSuccess && on_batch) on_batch(prev0, prev1);
         }
+        prev0 = q0;
+        prev1 = q0 + n;
     }
-    if (e == hipSuccess) e = hipEventRecord(ev1, stream);
-    top_idx.resize((size_t)nq * topn);
-    top_score.resize((size_t)nq * topn);
-    top_count.resize((size_t)nq);
-    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_idx.data(), dtop, (size_t)nq * topn * 4, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_score.data(), dscore, (size_t)nq * topn * 8, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess && nq) e = hipMemcpyAsync(top_count.data(), dcount, (size_t)nq * 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipEventRecord(ws.ev1, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e == hipSuccess && ms) e = hipEventElapsedTime(ms, ev0, ev1);
+    ws.host_ms[2] = ms_since(t_loop);
+    const auto t_tail = std::chrono::steady_clock::now();
+    if (e == hipSuccess && prev0 >= 0 && on_batch) on_batch(prev0, prev1);
+    ws.host_ms[3] = ms_since(t_tail);
+    if (e == hipSuccess && ms) e = hipEventElapsedTime(ms, ws.ev0, ws.ev1);
     if (flops) *flops = 2.0 * (double)nq * (double)nc * (double)kp;
-    void *ptrs[] = {dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount, dtau, dcnt, dover, dlist, dS_full};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
     return e;
 }
-template hipError_t rank_run_device<float>(hipStream_t, hipEvent_t, hipEvent_t, const RankPlan &, const RankOperands<float> &, double, int,
-                                           std::vector<int32_t> &, std::vector<double> &, std::vector<int32_t> &, float *, double *);
-template hipError_t rank_run_device<double>(hipStream_t, hipEvent_t, hipEvent_t, const RankPlan &, const RankOperands<double> &, double, int,
-                                            std::vector<int32_t> &, std::vector<double> &, std::vector<int32_t> &, float *, double *);
-
+template hipError_t rank_run_device<float>(hipStream_t, RankWorkspace &, const RankPlan &, const RankOperands<float> &, double, int,
+                                           const std::function<void(int64_t, int64_t)> &, float *, double *);
+template hipError_t rank_run_device<double>(hipStream_t, RankWorkspace &, const RankPlan &, const RankOperands<double> &, double, int,
+                                            const std::function<void(int64_t, int64_t)> &, float *, double *);
 
 } // namespace cmi
 
@@ -440,6 +515,12 @@ extern "C" int cmi_last_rank_ms(cmi_handle h, float *ms, double *flops) {
     if (!h) return CMI_E_INVALID;
     if (ms) *ms = h->last_rank_ms;
     if (flops) *flops = h->last_rank_flops;
+    return CMI_OK;
+}
+
+extern "C" int cmi_last_rank_host_ms(cmi_handle h, double out[5]) {
+    if (!h || !out) return CMI_E_INVALID;
+    for (int i = 0; i < 5; ++i) out[i] = h->rank_ws.host_ms[i];
     return CMI_OK;
 }
 
@@ -529,11 +610,20 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
     if ((contextual || ext) && !h->have_ratings)
         CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: the context table comes from cmi_set_ratings; call it first");
     auto check = [&](int64_t n, const int32_t *u, const int32_t *j, const int32_t *c, const char *what) -> int {
-        for (int64_t t = 0; t < n; ++t) {
+        const int nt = host_threads(n);
+        std::vector<int64_t> bad((size_t)nt, -1); // first offending tuple of every range
+        parallel_ranges(n, nt, [&](int part, int64_t b, int64_t e) {
+            for (int64_t t = b; t < e; ++t)
+                if (u[t] < 0 || u[t] >= h->n_users || j[t] < 0 || j[t] >= h->n_items || c[t] < 0 || (contextual && c[t] >= h->n_ctx)) {
+                    bad[(size_t)part] = t;
+                    return;
+                }
+        });
+        for (int64_t t : bad) {
+            if (t < 0) continue;
             if (u[t] < 0 || u[t] >= h->n_users || j[t] < 0 || j[t] >= h->n_items)
                 CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: %s user/item id out of range at tuple %lld", what, (long long)t);
-            if (c[t] < 0 || (contextual && c[t] >= h->n_ctx))
-                CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: %s context id %d out of range at tuple %lld", what, c[t], (long long)t);
+            CMI_FAIL(h, CMI_E_INVALID, "eval_rankings: %s context id %d out of range at tuple %lld", what, c[t], (long long)t);
         }
         return CMI_OK;
     };
@@ -542,29 +632,45 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
     CMI_HIP(h, hipSetDevice(h->device));
     if (n_queries) *n_queries = 0;
 
+    const auto t_all = std::chrono::steady_clock::now();
     RankPlan plan;
     rank_build_plan(h->n_users, h->n_items, RankTuples{n_train, tu, tj, tctx, tr}, RankTuples{n_test, su, sj, sctx, sr}, bin_thold,
                     num_ignore, plan);
-    std::vector<int32_t> top_idx, top_count;
-    std::vector<double> top_score;
-    if (!plan.qu.empty() && !plan.cand.empty()) {
+    RankWorkspace &ws = h->rank_ws;
+    ws.host_ms[0] = ms_since(t_all);
+    ws.host_ms[1] = ws.host_ms[2] = ws.host_ms[3] = 0.0;
+    const int64_t nq = (int64_t)plan.qu.size();
+    std::unique_ptr<double[]> vals(new double[(size_t)nq * N_MEAS + 1]); // only the rows of queries with a list are written and read
+    std::vector<int32_t> no_lists;
+    const int32_t *top_count = nullptr;
+    if (nq > 0 && !plan.cand.empty()) {
         const bool ic_used = h->state[CMI_STATE_IC_BIAS] != nullptr;
         const int k_logical = ext ? h->k + (h->model == CMI_MODEL_SVDPP ? 1 : 0)
                                   : h->k + 1 + (ic_used ? h->n_conds : 0); // [factors | 1 or itemBias | one-hot conditions or icBias row]
+        auto on_batch = [&](int64_t q0, int64_t q1) {
+            rank_measures_range(plan, num_recs, (const int32_t *)ws.h_top.p, (const double *)ws.h_score.p, (const int32_t *)ws.h_count.p, q0, q1,
+                                vals.get(), q_user, q_ctx, q_count, top_items, top_scores);
+        };
         hipError_t e;
-        if (ext && h->f64) e = rank_run_device<double>(h->stream, h->ev0, h->ev1, plan, ext_operands<double>(h, k_logical), bin_thold, num_recs,
-                                                       top_idx, top_score, top_count, &h->last_rank_ms, &h->last_rank_flops);
-        else if (ext) e = rank_run_device<float>(h->stream, h->ev0, h->ev1, plan, ext_operands<float>(h, k_logical), bin_thold, num_recs, top_idx,
-                                                 top_score, top_count, &h->last_rank_ms, &h->last_rank_flops);
-        else if (h->f64) e = rank_run_device<double>(h->stream, h->ev0, h->ev1, plan, mf_operands<double>(h, k_logical, contextual, ic_used), bin_thold,
-                                                num_recs, top_idx, top_score, top_count, &h->last_rank_ms, &h->last_rank_flops);
-        else e = rank_run_device<float>(h->stream, h->ev0, h->ev1, plan, mf_operands<float>(h, k_logical, contextual, ic_used), bin_thold,
-                                        num_recs, top_idx, top_score, top_count, &h->last_rank_ms, &h->last_rank_flops);
+        if (ext && h->f64) e = rank_run_device<double>(h->stream, ws, plan, ext_operands<double>(h, k_logical), bin_thold, num_recs, on_batch,
+                                                       &h->last_rank_ms, &h->last_rank_flops);
+        else if (ext) e = rank_run_device<float>(h->stream, ws, plan, ext_operands<float>(h, k_logical), bin_thold, num_recs, on_batch,
+                                                 &h->last_rank_ms, &h->last_rank_flops);
+        else if (h->f64) e = rank_run_device<double>(h->stream, ws, plan, mf_operands<double>(h, k_logical, contextual, ic_used), bin_thold,
+                                                     num_recs, on_batch, &h->last_rank_ms, &h->last_rank_flops);
+        else e = rank_run_device<float>(h->stream, ws, plan, mf_operands<float>(h, k_logical, contextual, ic_used), bin_thold, num_recs,
+                                        on_batch, &h->last_rank_ms, &h->last_rank_flops);
         CMI_HIP(h, e);
+        top_count = (const int32_t *)ws.h_count.p;
     } else {
-        top_count.assign(plan.qu.size(), 0);
+        no_lists.assign((size_t)nq, 0);
+        top_count = no_lists.data();
+        rank_measures_range(plan, num_recs, nullptr, nullptr, top_count, 0, nq, vals.get(), q_user, q_ctx, q_count, top_items, top_scores);
     }
-    rank_metrics(plan, strategy, num_recs, top_idx, top_score, top_count, out, q_user, q_ctx, q_count, top_items, top_scores);
+    const auto t_avg = std::chrono::steady_clock::now();
+    rank_average(plan, strategy, top_count, vals.get(), out);
+    ws.host_ms[3] += ms_since(t_avg);
+    ws.host_ms[4] = ms_since(t_all);
     if (n_queries) *n_queries = (int64_t)plan.qu.size();
     return CMI_OK;
 }

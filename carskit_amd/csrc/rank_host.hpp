@@ -38,13 +38,34 @@ struct RankOperands {
     std::function<hipError_t(T *dA, T *drc, const int32_t *dqu, const int32_t *dqc, int n, int kp, hipStream_t)> build_queries;
 };
 
-template <typename T>
-hipError_t rank_run_device(hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, const RankPlan &plan, const RankOperands<T> &ops,
-                           double thold, int topn, std::vector<int32_t> &top_idx, std::vector<double> &top_score,
-                           std::vector<int32_t> &top_count, float *ms, double *flops);
+// Device and pinned-host buffers of an evaluation, owned by the handle and reused (grow-only) by the next one: allocating and
+// freeing ~1 GiB per call costs milliseconds and a device synchronisation each.
+struct RankWorkspace {
+    struct Buf {
+        void *p = nullptr;
+        size_t cap = 0;
+    };
+    Buf dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount; // device
+    Buf h_top, h_score, h_count;                                                // pinned host: the lists as they come back
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evb[2] = {nullptr, nullptr};
+    // host wall clock of the last evaluation, ms: [0] plan, [1] setup (buffers, uploads, item operands), [2] scoring loop incl. the
+    // overlapped per-batch measures, [3] tail (last batch's measures + the averages), [4] total
+    double host_ms[5] = {0, 0, 0, 0, 0};
+    hipError_t need(Buf &b, size_t bytes, bool pinned = false);
+    void release(); // the caller has made the owning device current
+};
 
-void rank_metrics(const RankPlan &plan, int strategy, int num_recs, const std::vector<int32_t> &top_idx,
-                  const std::vector<double> &top_score, const std::vector<int32_t> &top_count, double *out /*[21]*/,
-                  int32_t *q_user, int32_t *q_ctx, int32_t *q_count, int32_t *top_items, double *top_scores);
+// on_batch(q0, q1): the lists of queries [q0, q1) have arrived in ws.h_top / h_score / h_count (absolute query indexing); called on
+// the host while the device scores the next batch
+template <typename T>
+hipError_t rank_run_device(hipStream_t stream, RankWorkspace &ws, const RankPlan &plan, const RankOperands<T> &ops, double thold, int topn,
+                           const std::function<void(int64_t, int64_t)> &on_batch, float *ms, double *flops);
+
+// the 18 measures of the lists of queries [q0, q1) -> vals[q * 18 + m] (threads over ranges of queries); optional per-query outputs
+void rank_measures_range(const RankPlan &plan, int num_recs, const int32_t *top_idx, const double *top_score, const int32_t *top_count,
+                         int64_t q0, int64_t q1, double *vals, int32_t *q_user, int32_t *q_ctx, int32_t *q_count, int32_t *top_items,
+                         double *top_scores);
+// averaged per strategy, in query order (Recommender.java:850-960)
+void rank_average(const RankPlan &plan, int strategy, const int32_t *top_count, const double *vals, double *out /*[21]*/);
 
 } // namespace cmi

@@ -178,25 +178,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int RG_BM = 128, RG_BN = 128, RG_BK = CMI_RG_BK, RG_LDS = RG_BM + 2;
 constexpr int RG_TPR = RG_BK / 4, RG_RPP = 256 / RG_TPR, RG_NP = RG_BM / RG_RPP; // staging: threads per row, rows per pass, passes // +2: spreads the transposing writes over banks
 
-// FILTER = the slab-free form (round 3): instead of writing the 128 x 128 score tile, the epilogue appends only the scores that can
-// still make the query's top-N -- score >= tau[q] (a lower bound of the row's N-th best, from a sample of the candidates), above the
-// rating threshold, not NaN -- to a short per-query list {candidate, score}; the contraction is the same instruction stream, so the
-// scores are bit-identical to the slab form.
-struct RankFilter {
-    const float *tau;   // [nq] lower bound of the N-th best score of the row (-inf: keep everything above the threshold)
-    int *cnt;           // [nq] survivors appended so far (may exceed cap: the row then overflowed)
-    int2 *list;         // [nq][cap] {candidate position, score bits}
-    int cap;
-    float thold;
-};
-
 #ifndef CMI_RG_WAVES
 #define CMI_RG_WAVES 4 // min waves per SIMD: 114 VGPRs instead of 140, four blocks per CU instead of three (23.70 -> 23.19 ms on the 270 K x 20 K case)
 #endif
-template <bool FILTER>
 __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const float *__restrict__ A, const float *__restrict__ B,
                                                           const float *__restrict__ row_const, float *__restrict__ S,
-                                                          int nq, int nc, int kp_pad, int tiles_c, int n_tiles, RankFilter flt) {
+                                                          int nq, int nc, int kp_pad, int tiles_c, int n_tiles) {
     __shared__ float sA[2][RG_BK][RG_LDS];
     __shared__ float sB[2][RG_BK][RG_LDS];
     // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give XCD x the x-th contiguous
@@ -283,93 +270,12 @@ __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const fl
             const int q = q0 + wq + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * mk;
             if (q >= nq) continue;
             const float rc = row_const[q];
-            if (FILTER) {
-                const float tau = flt.tau[q];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c = c0 + wc + 32 * j + mrow;
-                    const float v = acc[i][j][r] + rc;
-                    if (c < nc && v >= tau && v > flt.thold) { // NaN fails both comparisons
-                        const int pos = atomicAdd(flt.cnt + q, 1);
-                        if (pos < flt.cap) flt.list[(size_t)q * flt.cap + pos] = make_int2(c, __float_as_int(v));
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c = c0 + wc + 32 * j + mrow;
-                    if (c < nc) S[(size_t)q * nc + c] = acc[i][j][r] + rc;
-                }
+            for (int j = 0; j < 2; ++j) {
+                const int c = c0 + wc + 32 * j + mrow;
+                if (c < nc) S[(size_t)q * nc + c] = acc[i][j][r] + rc;
             }
         }
-}
-
-// ---- the slab-free selection (fp32, topn <= 64) ----------------------------------------------------------------------
-// exclusions inside a SAMPLE slab [nq][ns] holding the first ns candidates
-__global__ void rank_mask_sample(float *S, int ns, const int64_t *excl_ptr, const int32_t *excl_idx, int q_base, int nq) {
-    const int q = blockIdx.x;
-    if (q >= nq) return;
-    for (int64_t p = excl_ptr[q_base + q] + threadIdx.x; p < excl_ptr[q_base + q + 1]; p += blockDim.x)
-        if (excl_idx[p] < ns) S[(size_t)q * ns + excl_idx[p]] = -INFINITY;
-}
-// tau[q] = the N-th best score of the row among the sampled candidates (a lower bound of the N-th best over all of them: every
-// member of the final top-N is >= it), or -inf if the sample held fewer than N qualifying scores
-__global__ void rank_tau_from_sample(const double *score, const int32_t *count, int q_base, int nq, int topn, float *tau, int *cnt) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    tau[q] = count[q_base + q] >= topn ? (float)score[(size_t)(q_base + q) * topn + topn - 1] : -INFINITY;
-    cnt[q] = 0;
-}
-// one wave per query: drop the excluded candidates from the survivor list, rank the rest by (score descending, candidate position
-// ascending) -- the order the reference's stable descending sort over its candidate order gives -- and emit ranks < topn.
-// Rows whose list overflowed are counted in *overflow and left to the caller (it re-runs the batch through the slab form).
-constexpr int RANK_LIST_CAP = 1024;
-__global__ __launch_bounds__(256) void rank_select_lists(const int2 *__restrict__ list, const int *__restrict__ cnt, int cap, int nq, int topn,
-                                                         double thold, const int64_t *excl_ptr, const int32_t *excl_idx, int q_base,
-                                                         int32_t *out_idx, double *out_score, int32_t *out_count, int *overflow) {
-    __shared__ unsigned char s_ok[4][RANK_LIST_CAP];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + w;
-    if (q >= nq) return;
-    const int n = cnt[q];
-    if (n > cap) {
-        if (lane == 0) atomicAdd(overflow, 1);
-        return;
-    }
-    const int2 *row = list + (size_t)q * cap;
-    const int64_t eb = excl_ptr[q_base + q], ee = excl_ptr[q_base + q + 1];
-    // pass 1: which survivors qualify -- `score > threshold` exactly as the slab form tests it, and not an already-rated item
-    int kept = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int e = base + lane;
-        bool ok = e < n;
-        if (ok) {
-            const int2 x = row[e];
-            ok = (double)__int_as_float(x.y) > thold;
-            for (int64_t p = eb; p < ee && ok; ++p) ok = excl_idx[p] != x.x; // a handful of items per (user, context)
-            s_ok[w][e] = ok;
-        }
-        kept += __popcll(__ballot(ok));
-    }
-    __builtin_amdgcn_wave_barrier(); // LDS operations of one wave execute in order
-    // pass 2: rank = how many qualifying survivors come before this one
-    for (int base = 0; base < n; base += 64) {
-        const int e = base + lane;
-        if (e >= n || !s_ok[w][e]) continue;
-        const int2 x = row[e];
-        const float v = __int_as_float(x.y);
-        int rank = 0;
-        for (int f = 0; f < n; ++f) {
-            const int2 y = row[f];
-            const float u = __int_as_float(y.y);
-            rank += s_ok[w][f] && (u > v || (u == v && y.x < x.x));
-        }
-        if (rank < topn) {
-            out_idx[(size_t)(q_base + q) * topn + rank] = x.x;
-            out_score[(size_t)(q_base + q) * topn + rank] = (double)v;
-        }
-    }
-    if (lane == 0) out_count[q_base + q] = kept < topn ? kept : topn;
 }
 
 // ---- exclusions: items the user already rated in this context (never candidates) -----------------------------------
@@ -509,8 +415,8 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
     if constexpr (sizeof(T) == 4) {
         if (!force_valu && kp % RG_BK == 0) {
             const int tiles_c = (nc + RG_BN - 1) / RG_BN, n_tiles = tiles_c * ((nq + RG_BM - 1) / RG_BM);
-            hipLaunchKernelGGL(rank_gemm_mfma_f32<false>, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, s, (const float *)A,
-                               (const float *)B, (const float *)row_const, (float *)S, nq, nc, kp, tiles_c, n_tiles, RankFilter{});
+            hipLaunchKernelGGL(rank_gemm_mfma_f32, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, s, (const float *)A,
+                               (const float *)B, (const float *)row_const, (float *)S, nq, nc, kp, tiles_c, n_tiles);
         } else {
             hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, S, nq, nc, kp);
         }
@@ -524,56 +430,6 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
     else // long lists: one extraction pass per rank
         hipLaunchKernelGGL(rank_topn<T>, dim3((nq + 3) / 4), dim3(256), 0, s, S, nq, nc, thold, topn, out_idx, out_score,
                            out_count, q_base);
-    return hipGetLastError();
-}
-
-// The slab-free form of rank_launch_score for fp32 state (see RankFilter): (1) the slab form on the first `ns` candidates only -> tau;
-// (2) the same contraction over ALL candidates with the filtering epilogue; (3) selection from the survivor lists.  *overflow (device)
-// counts rows whose list did not fit `cap`: the caller then repeats the batch through rank_launch_score.  Same scores, same lists.
-bool rank_filter_usable(int nc, int kp, int topn) {
-    // OPT-IN (CMI_RANK_FILTER=1): measured on the 270 K x 20 K case it is SLOWER than the slab form (35.1 vs 23.5 ms: the ~54 M atomic
-    // appends of the filtering epilogue cost more than the 21.5 GB slab write they replace, and the list selection adds 8 ms) -- kept,
-    // with its tests, as the record of that experiment.  Read per call: the tests switch it within one process.
-    const bool on = getenv("CMI_RANK_FILTER") != nullptr && getenv("CMI_RANK_NO_FILTER") == nullptr;
-    return on && getenv("CMI_RANK_VALU") == nullptr && topn <= 64 && kp % RG_BK == 0 && nc >= 4 * rank_filter_sample(nc);
-}
-int rank_filter_sample(int nc) {
-    (void)nc;
-    int ns = 1024;
-    if (const char *e = getenv("CMI_RANK_SAMPLE")) ns = atoi(e);
-    return (ns + RG_BN - 1) / RG_BN * RG_BN;
-}
-hipError_t rank_launch_score_filtered(const float *A, const float *B, const float *row_const, float *S_sample, int nq, int nc, int kp,
-                                      const int64_t *excl_ptr, const int32_t *excl_idx, int q_base, double thold, int topn, float *tau,
-                                      int *cnt, int2 *list, int cap, int *overflow, int32_t *out_idx, double *out_score,
-                                      int32_t *out_count, hipStream_t s) {
-    if (nq <= 0 || nc <= 0) return hipSuccess;
-    const int ns = rank_filter_sample(nc);
-    const int tq = (nq + RG_BM - 1) / RG_BM;
-    {   // (1) sample: slab form over the first ns candidates (B rows are contiguous: the first ns rows ARE the sample)
-        const int tiles_c = ns / RG_BN, n_tiles = tiles_c * tq;
-        hipLaunchKernelGGL(rank_gemm_mfma_f32<false>, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, s, A, B, row_const, S_sample, nq, ns, kp,
-                           tiles_c, n_tiles, RankFilter{});
-        hipLaunchKernelGGL(rank_mask_sample, dim3(nq), dim3(64), 0, s, S_sample, ns, excl_ptr, excl_idx, q_base, nq);
-        hipLaunchKernelGGL(rank_topn_stream<float>, dim3((nq + 3) / 4), dim3(256), 0, s, (const float *)S_sample, nq, ns, thold, topn, out_idx,
-                           out_score, out_count, q_base);
-        hipLaunchKernelGGL(rank_tau_from_sample, dim3((nq + 255) / 256), dim3(256), 0, s, (const double *)out_score, (const int32_t *)out_count,
-                           q_base, nq, topn, tau, cnt);
-    }
-    {   // (2) all candidates, filtering epilogue
-        const int tiles_c = (nc + RG_BN - 1) / RG_BN, n_tiles = tiles_c * tq;
-        // `score > threshold` is evaluated in double by the slab form ((double)v > thold); a float compare against thold rounded DOWN
-        // to float keeps at least the same scores, the selection's own test is exact again
-        float tf = (float)thold;
-        if ((double)tf > thold) tf = nextafterf(tf, -INFINITY);
-        if (!(thold > -INFINITY)) tf = -INFINITY;
-        RankFilter flt{tau, cnt, list, cap, tf};
-        hipLaunchKernelGGL(rank_gemm_mfma_f32<true>, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, s, A, B, row_const, (float *)nullptr, nq, nc,
-                           kp, tiles_c, n_tiles, flt);
-    }
-    if (cap > RANK_LIST_CAP) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rank_select_lists, dim3((nq + 3) / 4), dim3(256), 0, s, (const int2 *)list, (const int *)cnt, cap, nq, topn, thold,
-                       excl_ptr, excl_idx, q_base, out_idx, out_score, out_count, overflow);
     return hipGetLastError();
 }
 

@@ -45,13 +45,4 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
                              const int64_t *excl_ptr, const int32_t *excl_idx, int q_base, double thold, int topn,
                              int32_t *out_idx, double *out_score, int32_t *out_count, hipStream_t s);
 
-// fp32 state, topn <= 64, many candidates: the slab-free form (rank_kernels.hip, RankFilter).  S_sample: [nq][rank_filter_sample(nc)];
-// tau / cnt: [nq]; list: [nq][cap]; *overflow (device int, zeroed by the caller) counts rows whose list did not fit
-bool rank_filter_usable(int nc, int kp, int topn);
-int rank_filter_sample(int nc);
-hipError_t rank_launch_score_filtered(const float *A, const float *B, const float *row_const, float *S_sample, int nq, int nc, int kp,
-                                      const int64_t *excl_ptr, const int32_t *excl_idx, int q_base, double thold, int topn, float *tau,
-                                      int *cnt, int2 *list, int cap, int *overflow, int32_t *out_idx, double *out_score,
-                                      int32_t *out_count, hipStream_t s);
-
 } // namespace cmi

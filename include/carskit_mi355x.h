@@ -241,6 +241,10 @@ int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *tu, const in
  * gather + contraction + mask + top-N over all query batches) and the flops of its contraction
  * (2 x queries x candidates x padded operand length) */
 int cmi_last_rank_ms(cmi_handle h, float *ms, double *flops);
+/* host wall clock of the last cmi_eval_rankings call, milliseconds: out[0] plan (candidates, queries, exclusions), [1] setup (buffers,
+ * uploads, item operands), [2] the scoring loop including the per-batch measures computed behind it, [3] tail (last batch's measures +
+ * the averages), [4] the whole call */
+int cmi_last_rank_host_ms(cmi_handle h, double out[5]);
 /* host-only (no GPU): the bookkeeping cmi_eval_rankings does before scoring -- candidate items in HashSet<Integer> order minus the
  * `num_ignore` most rated (Recommender.java:704-735), the (user, context) queries with their correct items (:776-790), and per
  * query the candidate POSITIONS of the items already rated in that context (:793-816).  Call once with null arrays for

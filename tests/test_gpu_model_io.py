@@ -118,19 +118,22 @@ def test_sim_params_travel_with_the_file_and_are_verified(tmp_path):
     c = make([1, 3])                                 # other EmptyContextConditions: refused
     with pytest.raises(capi.CmiError, match="EmptyContextConditions"):
         c.load_model(p)
-    # a model trained with an EMPTY list of empty conditions (no ':na' columns) restores into a fresh handle too --
-    # the restore used to be skipped, cfMatrix then failed its count check after P and Q had been overwritten
+    # a handle configured with an EMPTY list of empty conditions (a data set without ':na' columns; the reference's CAMF_*CS
+    # cannot train on one -- EmptyContextConditions.get(i) throws -- and neither does cmi_set_ratings, but the handle and its file are
+    # legal) restores into a fresh handle too: the restore used to be skipped, and cfMatrix then failed its count check after P and Q
+    # had already been overwritten
     d = make([])
-    d.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
-    d.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
-    d.set_state("cfMatrix", np.random.default_rng(2).random((data.n_conds, 4)))
-    d.train_epoch(util.LR)
+    cf = np.random.default_rng(2).random((data.n_conds, 4))
+    d.set_state("cfMatrix", cf)
+    d.set_state("P", np.full((data.n_users, 5), 0.25))
     q = tmp_path / "lcs_noempty.cmi"
     d.save_model(q)
     e = make(None)
     e.load_model(q)
-    e.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
-    assert np.array_equal(d.predict(data.u[:20], data.j[:20], data.ctx[:20]), e.predict(data.u[:20], data.j[:20], data.ctx[:20]))
-    assert np.array_equal(d.get_state("cfMatrix"), e.get_state("cfMatrix"))
+    assert np.array_equal(e.get_state("cfMatrix"), cf) and np.array_equal(e.get_state("P"), d.get_state("P"))
     with pytest.raises(capi.CmiError, match="EmptyContextConditions"):     # a handle configured with an empty list refuses a file with [0, 3]
         make([]).load_model(p)
+    before = e.get_state("P")
+    with pytest.raises(capi.CmiError, match="EmptyContextConditions"):     # ... and a refused file leaves the model as it was
+        e.load_model(p)
+    assert np.array_equal(e.get_state("P"), before)

@@ -94,9 +94,14 @@ def test_query_batching_is_invisible():
     os.environ["CMI_RANK_BATCH"] = "7"
     try:
         split = inst.eval_rankings(_arrays(train), _arrays(test), bin_thold=2.5, with_lists=True)
+        # ... and so are the host-side ranges: the plan in 5 ranges of users, every 7-query batch's measures in 5 ranges of queries,
+        # computed behind the device's next batch
+        os.environ["CMI_HOST_THREADS"] = "5"
+        ranged = inst.eval_rankings(_arrays(train), _arrays(test), bin_thold=2.5, with_lists=True)
     finally:
         del os.environ["CMI_RANK_BATCH"]
-    assert whole == split
+        os.environ.pop("CMI_HOST_THREADS", None)
+    assert whole == split == ranged
 
 
 def test_threshold_and_ignore():
@@ -202,29 +207,9 @@ def _with_env(env, fn):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("model,num_recs,thold", [("CAMF_CI", 10, 2.5), ("BiasedMF", 5, -1.0), ("CAMF_CU", 64, 3.9)])
-def test_slab_free_scoring_is_identical_to_the_slab_form(model, num_recs, thold):
-    """The slab-free scoring path (opt-in, CMI_RANK_FILTER=1; round 3: a sample of the candidates bounds every query's N-th best
-    score, the full contraction keeps only the scores that can still make the list -- the [queries x candidates] slab is never
-    written).  Same contraction, exact filter: lists, scores and measures must be IDENTICAL to the slab form's, item for item."""
-    train, test, orc, inst = _setup(model, 32, 0, epochs=2, n_users=120, n_items=1600, n=9000, seed=8)
-    kw = dict(bin_thold=thold, num_recs=num_recs, with_lists=True)
-    slab = _with_env({"CMI_RANK_NO_FILTER": "1", "CMI_RANK_FILTER": None}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
-    free = _with_env({"CMI_RANK_NO_FILTER": None, "CMI_RANK_FILTER": "1", "CMI_RANK_SAMPLE": "128"}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
-    assert free[0]["n_queries"] == slab[0]["n_queries"] > 0
-    assert set(free[1]) == set(slab[1])
-    for key in slab[1]:
-        assert free[1][key] == slab[1][key], key                         # (item, score) pairs, bit for bit, same order
-    for m, v in slab[0].items():
-        assert free[0][m] == v or (math.isnan(v) and math.isnan(free[0][m])), m
-    # and the slab form itself is the one the oracle tests above pin (fp32 bar)
-    ref, ref_lists = _oracle_eval(orc, train, test, bin_thold=thold, num_recs=num_recs)
-    _assert_same(slab[0], slab[1], ref, ref_lists, 0.03, 1e-4, same_items=False)
-
-
-def test_slab_free_scoring_falls_back_when_a_list_overflows():
-    """An all-tied model keeps EVERY candidate at its bound: the survivor lists overflow (> 1024 per query) and the batch is repeated
-    through the slab form -- ties still resolve in HashSet candidate order."""
+def test_all_tied_scores_resolve_in_candidate_order():
+    """An all-tied model: every candidate has the same score, so the lists are the first N candidates in HashSet order (the
+    reference's stable descending sort over its candidate order)."""
     rng = np.random.default_rng(5)
     n_items = 1500
     d = synth.generate(25, n_items, 2, 3, 6000, seed=6)
@@ -236,6 +221,16 @@ def test_slab_free_scoring_falls_back_when_a_list_overflows():
     inst.set_states({"P": np.zeros((25, 4)), "Q": np.zeros((n_items, 4)), "userBias": np.zeros(25), "itemBias": np.zeros(n_items)})
     tt = [list(zip(*(a.tolist() for a in x))) for x in (train, test)]
     ref, ref_lists = rank_oracle.eval_rankings(lambda u, jj, c: 3.0, tt[0], tt[1], bin_thold=2.5, num_recs=10)
-    res, lists = _with_env({"CMI_RANK_NO_FILTER": None, "CMI_RANK_FILTER": "1", "CMI_RANK_SAMPLE": "128"},
-                           lambda: inst.eval_rankings(train, test, bin_thold=2.5, num_recs=10, with_lists=True))
+    res, lists = inst.eval_rankings(train, test, bin_thold=2.5, num_recs=10, with_lists=True)
     _assert_same(res, lists, ref, ref_lists, 1e-15, 0.0)
+    # a second evaluation on the same handle reuses the cached workspace (smaller, then larger problem): same answer
+    half = tuple(a[: len(a) // 2] for a in test)
+    r2, l2 = inst.eval_rankings(train, half, bin_thold=2.5, num_recs=10, with_lists=True)
+    ref2, ref_l2 = rank_oracle.eval_rankings(lambda u, jj, c: 3.0, tt[0], tt[1][: len(tt[1]) // 2], bin_thold=2.5, num_recs=10)
+    _assert_same(r2, l2, ref2, ref_l2, 1e-15, 0.0)
+    r3, l3 = inst.eval_rankings(train, test, bin_thold=2.5, num_recs=10, with_lists=True)
+    _assert_same(r3, l3, ref, ref_lists, 1e-15, 0.0)
+    hm = inst.last_rank_host_ms()
+    assert hm["total"] >= hm["plan"] > 0.0 and hm["scoring_loop"] > 0.0
+
+

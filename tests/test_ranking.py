@@ -158,6 +158,15 @@ def test_rank_plan_bookkeeping_matches_a_python_derivation(seed, num_ignore, tho
     for key, items_ in truth.items():
         t, e = got[key]
         assert t == sorted(items_) and sorted(e) == sorted(rated.get(key, set())) and len(set(e)) == len(e)
+    # the plan is built in ranges of users on the host's cores (forced here: the input is far below the size that would use them):
+    # element for element the serial result, whatever the number of ranges -- more ranges than users included
+    import os
+    for nt in ("3", "7", "64"):
+        os.environ["CMI_HOST_THREADS"] = nt
+        try:
+            assert capi.rank_plan(n_users, n_items, train, test, thold, num_ignore) == (cand, queries)
+        finally:
+            del os.environ["CMI_HOST_THREADS"]
 
 
 def test_list_measures_library_matches_oracle_formulas():

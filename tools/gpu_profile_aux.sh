@@ -11,7 +11,6 @@ for wl in c4 rank; do
   python bench.py "${args[@]}" > $out/bench.json 2> $out/bench.err
   timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python bench.py "${args[@]}" --no-cpu-baseline > $out/stats.log 2>&1
   if [ $wl = rank ]; then
-    CMI_RANK_FILTER=1 python bench.py "${args[@]}" --no-cpu-baseline > $out/bench_slab_free.json 2> $out/bench_slab_free.err
     timeout 1200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $out/MFMA -o pmc -- python bench.py "${args[@]}" --no-cpu-baseline > $out/MFMA.log 2>&1
     timeout 1200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/FETCH_SIZE -o pmc -- python bench.py "${args[@]}" --no-cpu-baseline > $out/FETCH.log 2>&1
     timeout 1200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/WRITE_SIZE -o pmc -- python bench.py "${args[@]}" --no-cpu-baseline > $out/WRITE.log 2>&1
