@@ -251,6 +251,56 @@ def bench_fm(args):
     return out
 
 
+def bench_group(args):
+    """python bench.py --gpus N (no torchrun): one host process, one cmi_group over N GPUs (user-sharded; the library cuts the ratings,
+    runs the shards' epochs concurrently and merges the item-side moves with RCCL reduce-scatter + all-gather).  Weak scaling: every
+    GPU gets the workload's tuple count over its own users; items and contexts are shared."""
+    model, k, n_users, n_items, n_dims, cpd, n_ratings = WORKLOADS[args.workload]
+    if args.k > 0:
+        k = args.k
+    if args.model:
+        model = args.model
+    W = args.gpus
+    if capi.device_count() < W:
+        raise SystemExit("--gpus %d: only %d device(s) visible" % (W, capi.device_count()))
+    parts = [synth.generate_fast(n_users, n_items, n_dims, cpd, n_ratings, seed=synth.DEFAULT_SEED + 1000 * r) for r in range(W)]
+    u = np.concatenate([p.u + r * n_users for r, p in enumerate(parts)]).astype(np.int32)
+    j, ctx, r_ = (np.concatenate([getattr(p, a) for p in parts]) for a in ("j", "ctx", "r"))
+    base = parts[0]
+    gm = float(r_.sum() / np.count_nonzero(r_))
+    regs = (synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-3))
+    lr = synth.java_float(0.02)
+    g = capi.Group(model, k, n_users * W, n_items, base.n_conds, W, devices=list(range(W)), flags=args.flags)
+    g.set_hparams(*regs, gm)
+    t0 = time.perf_counter()
+    g.set_ratings(u, j, ctx, r_, base.ctx_ptr, base.ctx_conds)
+    log("group of %d: schedules + upload in %.1fs" % (W, time.perf_counter() - t0))
+    state = synth.init_state(model, base, k, seed=synth.DEFAULT_SEED + 2, dtype=np.float32)
+    rng_u = np.random.default_rng(synth.DEFAULT_SEED + 7)
+    for name in ("P", "userBias", "ucBias"):              # user-side containers cover all W x n_users users
+        if name in state:
+            shape = (n_users * W,) + state[name].shape[1:]
+            state[name] = (rng_u.random(shape) if name == "ucBias" else 0.1 * rng_u.standard_normal(shape)).astype(np.float32)
+    g.set_states(state)
+    losses = [g.train_epoch(lr) for _ in range(args.warmup)]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(g.train_epoch(lr))                 # returns after the global loss is on the host: every shard's stream is done
+    elapsed = time.perf_counter() - t0
+    if not np.all(np.isfinite(losses)) or (len(losses) > 1 and losses[-1] > losses[0]):
+        raise SystemExit("bench: training diverged (epoch losses %s)" % losses)
+    info = [g.shard_info(s) for s in range(W)]
+    out = {"metric": "SGD rating-updates/sec, %s k=%d" % (model, k), "value": float(len(r_)) * args.steps / elapsed, "unit": "rating-updates/s",
+           "n_gpus": W, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%s: %s k=%d, %d users x %d items per GPU, %d ratings per GPU" % (args.workload, model, k, n_users, n_items, n_ratings),
+                      "parallelism": "one process, cmi_group over %d GPUs (user-sharded; exchange: %s)" % (W, info[0]["exchange"]),
+                      "shards": info},
+           "first_loss": losses[0], "final_loss": losses[-1]}
+    g.close()
+    return out
+
+
 def bench_rank(args):
     """--workload rank: Recommender.evalRankings (Recommender.java:668-964) for CAMF_CI k=128: every test (user, context) query scores
     ALL candidate items -- the one GEMM-shaped operation of this code base (f32 matrix cores).  A step = one whole evaluation."""
@@ -356,8 +406,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one rank per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node %d ..." % (args.gpus, args.gpus))
+            # not under torch.distributed.run: ONE process drives all N GPUs through cmi_group_* -- the form the Java / C++ hosts use
+            # (-Dcarskit.shards=N).  Same weak-scaling workload, same exchange function (group_api.cpp exchange_collective) as the
+            # one-process-per-GPU form below.
+            print(json.dumps(bench_group(args)), flush=True)
+            return
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
 
     import torch

@@ -75,6 +75,12 @@ SYMBOLS = [
                                        C.c_int, _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
     ("cmi_last_rank_ms", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_dbl)]),
     ("cmi_last_rank_host_ms", C.c_int, [_vp, _vp]),
+    ("cmi_group_set_eval_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    ("cmi_group_eval_resident", C.c_int, [_vp, _dbl, _dbl, _vp, C.POINTER(_i64)]),
+    ("cmi_comm_unique_id", C.c_int, [_vp]),
+    ("cmi_comm_init", C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    ("cmi_comm_exchange", C.c_int, [_vp, _dbl]),
+    ("cmi_comm_train_epoch", C.c_int, [_vp, _dbl, _dbl, C.POINTER(_dbl)]),
     ("cmi_rank_plan", C.c_int, [C.c_int32, C.c_int32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int,
                                 C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("cmi_rank_list_measures", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
@@ -157,6 +163,8 @@ SYMBOLS = [
     ("cmi_fm_phase_apply", C.c_int, [_vp, C.c_int]),
     ("cmi_fm_phase_run", C.c_int, [_vp, C.c_int]),
     ("cmi_fm_layout", C.c_int, [_vp, _vp]),
+    ("cmi_fm_comm_init", C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    ("cmi_fm_comm_sweep", C.c_int, [_vp]),
     ("cmi_fm_time_reduce", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_dbl)]),
 ]
 
@@ -232,6 +240,18 @@ def rank_plan(n_users, n_items, train, test, bin_thold=-1.0, num_ignore=0):
         raise CmiError(rc, "cmi_rank_plan")
     queries = [(int(qu[q]), int(qc[q]), ti[tp[q]:tp[q + 1]].tolist(), ei[ep[q]:ep[q + 1]].tolist()) for q in range(nq)]
     return cand[:nc].tolist(), queries
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """cmi_comm_unique_id: the RCCL unique id (bytes) rank 0 creates for a one-process-per-GPU job."""
+    buf = (C.c_char * COMM_ID_BYTES)()
+    rc = lib().cmi_comm_unique_id(buf)
+    if rc:
+        raise CmiError(rc, "cmi_comm_unique_id")
+    return bytes(buf)
 
 
 class CmiError(RuntimeError):
@@ -490,6 +510,20 @@ class Group:
         res["n"] = cnt.value
         return res
 
+    def set_eval_ratings(self, u, j, ctx, r):
+        """Test tuples routed once to the shards that own their users and kept on the devices (`--early-stop MAE|RMSE`)."""
+        c32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        u, j, ctx = c32(u), c32(j), c32(ctx)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        self._chk(self.L.cmi_group_set_eval_ratings(self.h, len(r), _p(u), _p(j), _p(ctx), _p(r)))
+
+    def eval_resident(self, min_rate, max_rate):
+        out, cnt = np.zeros(5), _i64()
+        self._chk(self.L.cmi_group_eval_resident(self.h, min_rate, max_rate, _p(out), C.byref(cnt)))
+        res = dict(zip(("MAE", "RMSE", "NMAE", "rMAE", "rRMSE"), out.tolist()))
+        res["n"] = cnt.value
+        return res
+
     def predict_batch(self, u, j, ctx, bound=False, lo=0.0, hi=0.0):
         c32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
         u, j, ctx = c32(u), c32(j), c32(ctx)
@@ -664,6 +698,8 @@ class Instance:
         """-> (lrate, last_loss, epochs_done) stored with the model"""
         lr, ll, ep = C.c_double(), C.c_double(), C.c_int()
         self._chk(self.L.cmi_load_model(self.h, str(path).encode(), C.byref(lr), C.byref(ll), C.byref(ep)))
+        if self.model == "CAMF_LCS" and self.n_conds > 0:      # a file may have restored numF into a handle that had none
+            self.num_f = self.state_device_ptr("cfMatrix")[1] // self.n_conds
         return lr.value, ll.value, ep.value
 
     def exchange_setup(self, pad_to=1):
@@ -682,6 +718,20 @@ class Instance:
         p = _vp()
         self._chk(self.L.cmi_loss_device_ptr(self.h, C.byref(p)))
         return p.value
+
+    # -- the library's own exchange for one-process-per-GPU jobs (cmi_comm_*: the function cmi_group_* uses) ------------------
+    def comm_init(self, unique_id, rank, world):
+        """unique_id: COMM_ID_BYTES bytes from comm_unique_id() on rank 0, handed to every rank by the host's rendezvous."""
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._chk(self.L.cmi_comm_init(self.h, buf, int(rank), int(world)))
+
+    def comm_exchange(self, scale):
+        self._chk(self.L.cmi_comm_exchange(self.h, float(scale)))
+
+    def comm_train_epoch(self, lrate, scale):
+        loss = _dbl()
+        self._chk(self.L.cmi_comm_train_epoch(self.h, float(lrate), float(scale), C.byref(loss)))
+        return loss.value
 
     def state_device_ptr(self, name):
         ptr, cnt, dt = _vp(), _i64(), C.c_int()
@@ -820,6 +870,13 @@ class FMInstance:
 
     def synchronize(self):
         self._chk(self.L.cmi_fm_synchronize(self.h))
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._chk(self.L.cmi_fm_comm_init(self.h, buf, int(rank), int(world)))
+
+    def comm_sweep(self):
+        self._chk(self.L.cmi_fm_comm_sweep(self.h))
 
     def layout(self):
         out = np.zeros(12, np.int64)

@@ -182,6 +182,7 @@ extern "C" int cmi_destroy(cmi_handle h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     free_ratings(h);
+    cmi_comm_release(h);
     h->rank_ws.release();
     for (void *&p : h->state)
         if (p) {
@@ -1648,8 +1649,7 @@ extern "C" int cmi_set_eval_ratings(cmi_handle h, int64_t n, const int32_t *u, c
     return CMI_OK;
 }
 
-extern "C" int cmi_eval_resident(cmi_handle h, double min_rate, double max_rate, double out[5], int64_t *count) {
-    if (!h || !out) return CMI_E_INVALID;
+int cmi_eval_resident_sums(cmi_instance *h, double min_rate, double max_rate, double sums[5]) {
     if (h->n_eval <= 0) CMI_FAIL(h, CMI_E_INVALID, "eval_resident: call cmi_set_eval_ratings first");
     CMI_HIP(h, hipSetDevice(h->device));
     if (int rc = cmi_sync_table_from_arena(h)) return rc;
@@ -1661,9 +1661,16 @@ extern "C" int cmi_eval_resident(cmi_handle h, double min_rate, double max_rate,
     if (e == hipSuccess) e = hipMemcpyAsync(part.data(), h->d_epart, part.size() * 8, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     CMI_HIP(h, e);
-    double sums[5] = {0, 0, 0, 0, 0};
+    for (int c = 0; c < 5; ++c) sums[c] = 0.0;
     for (int b = 0; b < blocks; ++b)
         for (int c = 0; c < 5; ++c) sums[c] += part[(size_t)b * 5 + c];
+    return CMI_OK;
+}
+
+extern "C" int cmi_eval_resident(cmi_handle h, double min_rate, double max_rate, double out[5], int64_t *count) {
+    if (!h || !out) return CMI_E_INVALID;
+    double sums[5];
+    if (int rc = cmi_eval_resident_sums(h, min_rate, max_rate, sums)) return rc;
     const double cnt = sums[4];
     const double mae = sums[0] / cnt;
     out[0] = mae;

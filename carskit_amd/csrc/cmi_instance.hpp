@@ -81,6 +81,8 @@ struct cmi_instance {
     bool sim_params_set = false; // cmi_set_sim_params has run (an EMPTY EmptyContextConditions list is a valid setting)
     std::vector<int32_t> empty_conds;
     int32_t *d_empty = nullptr, *d_ui_ptr = nullptr, *d_ui_items = nullptr;
+    void *comm = nullptr;        // ncclComm_t of cmi_comm_init (one-process-per-GPU jobs); group_api.cpp owns the type
+    int comm_rank = 0, comm_world = 0;
     cmi::RankWorkspace rank_ws;  // cmi_eval_rankings' device / pinned buffers, reused by the next evaluation
     float last_rank_ms = 0.f;    // device time of the most recent cmi_eval_rankings scoring loop (HIP events)
     double last_rank_flops = 0.0; // 2 * queries * candidates * padded operand length of that loop
@@ -112,6 +114,11 @@ int cmi_train_loop(const std::function<int(double, double *)> &epoch, std::strin
                    int *iters_run, double *final_lrate);
 int cmi_eval_sums(cmi_instance *h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r, double min_rate,
                   double max_rate, double sums[5]);
+
+// the sums of cmi_eval_resident before they are turned into measures (a group adds them over its shards)
+int cmi_eval_resident_sums(cmi_instance *h, double min_rate, double max_rate, double sums[5]);
+// cmi_comm_* (group_api.cpp, which owns the RCCL types): destroy the handle's communicator, if any
+void cmi_comm_release(cmi_instance *h);
 
 // spoke arena (cmi_api.cpp): make the model table current (gather from the arena) / say that the table was rewritten (arena stale)
 int cmi_sync_table_from_arena(cmi_instance *h);

@@ -2,10 +2,12 @@
 #include "../../include/carskit_mi355x.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -38,6 +40,8 @@ struct cmi_fm_instance {
     int32_t *d_u = nullptr, *d_j = nullptr, *d_ctx = nullptr, *d_i2u = nullptr, *d_c2u = nullptr;
     FmOrderDev ord[3];
     RankWorkspace rank_ws; // cmi_fm_eval_rankings' buffers, reused by the next evaluation
+    ncclComm_t comm = nullptr; // cmi_fm_comm_init: ratings sharded by user over one process per GPU
+    int comm_world = 0;
     int col_f = -1; // factor whose column is loaded in d_tab[].x
     int64_t part_count = 0;
     int64_t slice_entries = 131072; // table entries (16 bytes each) a slice of the other field may gather: 2 MB stays L2-resident (measured best of 16 K .. 256 K)
@@ -84,6 +88,8 @@ extern "C" int cmi_fm_destroy(cmi_fm_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     fm_free_ratings(h);
+    if (h->comm) (void)ncclCommDestroy(h->comm);
+    h->comm = nullptr;
     h->rank_ws.release();
     void *ptrs[] = {h->d_w0, h->d_d0, h->d_w, h->d_V, h->d_Vt, h->d_part, h->d_scratch, h->d_tab};
     for (void *p : ptrs)
@@ -541,6 +547,48 @@ extern "C" int cmi_fm_time_reduce(cmi_fm_handle h, int phase, int reps, double *
     (void)hipEventDestroy(e1);
     FM_HIP(h, e);
     *avg_ms = (double)ms / reps;
+    return CMI_OK;
+}
+
+
+// ---- ratings sharded by user over one process per GPU (BASELINE configs[3]): the sweep with its per-phase exchange issued by the
+// library itself.  User phases are rank-local (a user's ratings live on one rank) and run fused; the w0 / item / context phases
+// all-reduce their [num | den] buffer between reduce and apply on the instance's stream -- ~130 small collectives per sweep with no
+// host code between them (driven from Python they cost more than the phases).  Every rank then applies the same update, so the
+// replicated item / context part of the model stays identical.  cmi_fm_set_hparams' global_size must be the ratings of ALL ranks.
+extern "C" int cmi_fm_comm_init(cmi_fm_handle h, const void *id, int rank, int world) {
+    if (!h || !id || world < 1 || rank < 0 || rank >= world) return CMI_E_INVALID;
+    static_assert(sizeof(ncclUniqueId) == CMI_COMM_ID_BYTES, "CMI_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+    FM_HIP(h, hipSetDevice(h->device));
+    if (h->comm) (void)ncclCommDestroy(h->comm);
+    h->comm = nullptr;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    const ncclResult_t r = ncclCommInitRank(&h->comm, world, u, rank);
+    if (r != ncclSuccess) FM_FAIL(h, CMI_E_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    h->comm_world = world;
+    return CMI_OK;
+}
+
+extern "C" int cmi_fm_comm_sweep(cmi_fm_handle h) {
+    if (!h) return CMI_E_INVALID;
+    if (!h->comm) FM_FAIL(h, CMI_E_INVALID, "fm_comm_sweep: call cmi_fm_comm_init first");
+    const int np = cmi_fm_num_phases(h);
+    for (int ph = 0; ph < np; ++ph) {
+        int field, f;
+        phase_decode(h, ph, &field, &f);
+        if (field == 0) { // users: local to this rank
+            if (int rc = cmi_fm_phase_run(h, ph)) return rc;
+            continue;
+        }
+        if (int rc = cmi_fm_phase_reduce(h, ph)) return rc;
+        void *buf = nullptr;
+        int64_t cnt = 0;
+        if (int rc = cmi_fm_phase_buffer(h, ph, &buf, &cnt)) return rc;
+        const ncclResult_t r = ncclAllReduce(buf, buf, (size_t)cnt, ncclDouble, ncclSum, h->comm, h->stream);
+        if (r != ncclSuccess) FM_FAIL(h, CMI_E_HIP, "ncclAllReduce (phase %d) failed: %s", ph, ncclGetErrorString(r));
+        if (int rc = cmi_fm_phase_apply(h, ph)) return rc;
+    }
     return CMI_OK;
 }
 

@@ -78,6 +78,28 @@ static thread_local std::string g_group_create_err;
         if (rc_ != CMI_OK) GRP_FAIL(g, rc_, "shard %d (device %d): %s", (int)(i), (g)->dev[(size_t)(i)], cmi_last_error((g)->inst[(size_t)(i)])); \
     } while (0)
 
+// THE exchange, one implementation for both hosts: the single-process group (cmi_group_*: ncclCommInitAll, one
+// communicator per shard, grouped calls) and the one-process-per-GPU job (cmi_comm_*: ncclCommInitRank, carskit_amd/dist.py and
+// bench.py --gpus N) issue exactly these three collectives on the instance's stream:
+//   phase 0  reduce-scatter (sum) of the bucket of item-side moves: rank r receives slice r      |  xGMI is point to point: each rank's
+//   phase 1  all-gather of the summed slices, in place                                           |  slice goes straight to its owner and
+//   phase 2  all-reduce (sum) of the fp64 epoch loss                                             |  back, 2 x S/W per link pair, where a
+//                                                                                                   ring all-reduce is bound by one link
+// (CMI_DIST_ALLREDUCE=1: phase 0 = one all-reduce, phase 1 nothing -- the A/B of SURVEY 8e.)  In place: rank r's slice of its own
+// bucket is the reduce-scatter output and the all-gather input.
+static ncclResult_t exchange_collective(int phase, ncclComm_t comm, void *bucket, int64_t count, int world, int rank, bool f64, double *dloss,
+                                        hipStream_t st) {
+    static const bool allreduce = getenv("CMI_DIST_ALLREDUCE") != nullptr;
+    const size_t es = f64 ? 8 : 4, chunk = (size_t)(count / world);
+    const ncclDataType_t dt = f64 ? ncclDouble : ncclFloat;
+    char *mine = (char *)bucket + (size_t)rank * chunk * es;
+    switch (phase) {
+    case 0: return allreduce ? ncclAllReduce(bucket, bucket, (size_t)count, dt, ncclSum, comm, st) : ncclReduceScatter(bucket, mine, chunk, dt, ncclSum, comm, st);
+    case 1: return allreduce ? ncclSuccess : ncclAllGather(mine, bucket, chunk, dt, comm, st);
+    default: return ncclAllReduce(dloss, dloss, 1, ncclDouble, ncclSum, comm, st);
+    }
+}
+
 static bool user_side(int which) { return which == CMI_STATE_P || which == CMI_STATE_USER_BIAS || which == CMI_STATE_UC_BIAS; }
 
 template <typename T>
@@ -333,29 +355,18 @@ static int group_exchange(cmi_group *g) {
         GRP_MEMBER(g, s, cmi_loss_device_ptr(g->inst[(size_t)s], (void **)&dl[(size_t)s]));
     }
     if (g->rccl) {
-        // xGMI is point to point: reduce-scatter + all-gather moves 2 x S/W per link pair on the fully connected mesh where a ring
-        // all-reduce is bound by one link; in place: shard s's slice of its own bucket is the reduce-scatter output and the
-        // all-gather input
-        const size_t chunk = (size_t)(g->x_count / W);
-        const ncclDataType_t dt = g->f64 ? ncclDouble : ncclFloat;
-        const bool allreduce = getenv("CMI_DIST_ALLREDUCE") != nullptr;
-        if (allreduce) {
+        // every collective of the exchange is one grouped call over all communicators of this process
+        for (int phase = 0; phase < 3; ++phase) {
             GRP_NCCL(g, ncclGroupStart());
-            for (int s = 0; s < W; ++s) GRP_NCCL(g, ncclAllReduce(g->bucket[(size_t)s], g->bucket[(size_t)s], (size_t)g->x_count, dt, ncclSum, g->comm[(size_t)s], st[(size_t)s]));
-            GRP_NCCL(g, ncclGroupEnd());
-        } else {
-            GRP_NCCL(g, ncclGroupStart());
-            for (int s = 0; s < W; ++s)
-                GRP_NCCL(g, ncclReduceScatter(g->bucket[(size_t)s], (char *)g->bucket[(size_t)s] + (size_t)s * chunk * es, chunk, dt, ncclSum, g->comm[(size_t)s], st[(size_t)s]));
-            GRP_NCCL(g, ncclGroupEnd());
-            GRP_NCCL(g, ncclGroupStart());
-            for (int s = 0; s < W; ++s)
-                GRP_NCCL(g, ncclAllGather((char *)g->bucket[(size_t)s] + (size_t)s * chunk * es, g->bucket[(size_t)s], chunk, dt, g->comm[(size_t)s], st[(size_t)s]));
+            for (int s = 0; s < W; ++s) {
+                const ncclResult_t r = exchange_collective(phase, g->comm[(size_t)s], g->bucket[(size_t)s], g->x_count, W, s, g->f64, dl[(size_t)s], st[(size_t)s]);
+                if (r != ncclSuccess) {
+                    (void)ncclGroupEnd();
+                    GRP_FAIL(g, CMI_E_HIP, "exchange (phase %d, shard %d) failed: %s", phase, s, ncclGetErrorString(r));
+                }
+            }
             GRP_NCCL(g, ncclGroupEnd());
         }
-        GRP_NCCL(g, ncclGroupStart());
-        for (int s = 0; s < W; ++s) GRP_NCCL(g, ncclAllReduce(dl[(size_t)s], dl[(size_t)s], 1, ncclDouble, ncclSum, g->comm[(size_t)s], st[(size_t)s]));
-        GRP_NCCL(g, ncclGroupEnd());
     } else {
         // in-process: shard 0's stream waits for every shard's pack, sums the buckets (and the losses) in shard order, the others copy
         // the sums back on their own streams
@@ -516,5 +527,113 @@ extern "C" int cmi_group_member(cmi_group_handle g, int shard, cmi_handle *out) 
     if (int rc = need_ratings(g, "group_member")) return rc;
     if (shard < 0 || shard >= (int)g->inst.size()) GRP_FAIL(g, CMI_E_INVALID, "group_member: shard %d out of range", shard);
     *out = g->inst[(size_t)shard];
+    return CMI_OK;
+}
+
+// ---- early stop on a measure for a sharded recommender (IterativeRecommender.java:149-161: isConverged() scores the test set after
+// every epoch): the test tuples go to the shard that owns their user ONCE and stay on its device ----------------------------------------
+extern "C" int cmi_group_set_eval_ratings(cmi_group_handle g, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r) {
+    if (!g) return CMI_E_INVALID;
+    if (int rc = need_ratings(g, "group_set_eval_ratings")) return rc;
+    if (n < 0 || (n > 0 && (!u || !j || !r))) GRP_FAIL(g, CMI_E_INVALID, "group_set_eval_ratings: null argument");
+    Routed ro;
+    if (int rc = route(g, n, u, j, ctx, r, ro)) return rc;
+    for (size_t s = 0; s < g->inst.size(); ++s)
+        GRP_MEMBER(g, s, cmi_set_eval_ratings(g->inst[s], (int64_t)ro.u[s].size(), ro.u[s].data(), ro.j[s].data(), ctx ? ro.c[s].data() : nullptr,
+                                              ro.r[s].data()));
+    return CMI_OK;
+}
+
+extern "C" int cmi_group_eval_resident(cmi_group_handle g, double min_rate, double max_rate, double out[5], int64_t *count) {
+    if (!g || !out) return CMI_E_INVALID;
+    if (int rc = need_ratings(g, "group_eval_resident")) return rc;
+    double tot[5] = {0, 0, 0, 0, 0};
+    for (size_t s = 0; s < g->inst.size(); ++s) { // sums in shard order: deterministic
+        if (g->inst[s]->n_eval <= 0) continue;    // a shard that owns none of the test users
+        double sums[5];
+        GRP_MEMBER(g, s, cmi_eval_resident_sums(g->inst[s], min_rate, max_rate, sums));
+        for (int c = 0; c < 5; ++c) tot[c] += sums[c];
+    }
+    if (!(tot[4] > 0)) GRP_FAIL(g, CMI_E_INVALID, "group_eval_resident: call cmi_group_set_eval_ratings first");
+    const double cnt = tot[4], mae = tot[0] / cnt;
+    out[0] = mae;
+    out[1] = std::sqrt(tot[1] / cnt);
+    out[2] = mae / (max_rate - min_rate);
+    out[3] = tot[2] / cnt;
+    out[4] = std::sqrt(tot[3] / cnt);
+    if (count) *count = (int64_t)cnt;
+    return CMI_OK;
+}
+
+// ---- cmi_comm_*: the same exchange for the one-process-per-GPU form (carskit_amd/dist.py, bench.py --gpus N under
+// torch.distributed.run).  The host ranks only have to share 128 bytes once (the RCCL unique id: rank 0 makes it, the host's own
+// rendezvous -- torch.distributed, MPI, a file -- hands it to the others); from then on every epoch's exchange is issued by this
+// library on the instance's stream, through exchange_collective above. -----------------------------------------------------------------
+static_assert(sizeof(ncclUniqueId) == CMI_COMM_ID_BYTES, "CMI_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+
+extern "C" int cmi_comm_unique_id(void *id) {
+    if (!id) return CMI_E_INVALID;
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return CMI_E_HIP;
+    memcpy(id, &u, sizeof u);
+    return CMI_OK;
+}
+
+void cmi_comm_release(cmi_instance *h) {
+    if (h->comm) {
+        (void)hipSetDevice(h->device);
+        (void)ncclCommDestroy((ncclComm_t)h->comm);
+        h->comm = nullptr;
+    }
+    h->comm_world = 0;
+}
+
+#define COMM_NCCL(h, expr)                                                                                \
+    do {                                                                                                  \
+        ncclResult_t r_ = (expr);                                                                         \
+        if (r_ != ncclSuccess) CMI_FAIL(h, CMI_E_HIP, "%s failed: %s", #expr, ncclGetErrorString(r_));   \
+    } while (0)
+
+extern "C" int cmi_comm_init(cmi_handle h, const void *id, int rank, int world) {
+    if (!h || !id || world < 1 || rank < 0 || rank >= world) return CMI_E_INVALID;
+    cmi_comm_release(h);
+    CMI_HIP(h, hipSetDevice(h->device));
+    void *bucket = nullptr;
+    int64_t cnt = 0;
+    if (int rc = cmi_exchange_setup(h, world, &bucket, &cnt)) return rc; // also snapshots the item-side state
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclComm_t c = nullptr;
+    COMM_NCCL(h, ncclCommInitRank(&c, world, u, rank));
+    h->comm = c;
+    h->comm_rank = rank;
+    h->comm_world = world;
+    return CMI_OK;
+}
+
+// pack -> reduce-scatter -> all-gather -> apply(scale) -> loss all-reduce, all on the instance's stream (no host synchronisation)
+extern "C" int cmi_comm_exchange(cmi_handle h, double scale) {
+    if (!h) return CMI_E_INVALID;
+    if (!h->comm) CMI_FAIL(h, CMI_E_INVALID, "comm_exchange: call cmi_comm_init first");
+    if (int rc = cmi_exchange_pack(h)) return rc;
+    double *dl = nullptr;
+    if (int rc = cmi_loss_device_ptr(h, (void **)&dl)) return rc;
+    for (int phase = 0; phase < 2; ++phase)
+        COMM_NCCL(h, exchange_collective(phase, (ncclComm_t)h->comm, h->d_xbucket, h->x_count, h->comm_world, h->comm_rank, h->f64, dl, h->stream));
+    if (int rc = cmi_exchange_apply(h, scale)) return rc;
+    COMM_NCCL(h, exchange_collective(2, (ncclComm_t)h->comm, h->d_xbucket, h->x_count, h->comm_world, h->comm_rank, h->f64, dl, h->stream));
+    return CMI_OK;
+}
+
+// one global epoch of this rank: local epoch at `lrate`, the exchange with scale (1/W = the mean of the ranks' moves), the GLOBAL loss
+// back -- the one host synchronisation of the epoch
+extern "C" int cmi_comm_train_epoch(cmi_handle h, double lrate, double scale, double *global_loss) {
+    if (!h) return CMI_E_INVALID;
+    if (!h->comm) CMI_FAIL(h, CMI_E_INVALID, "comm_train_epoch: call cmi_comm_init first");
+    if (int rc = cmi_train_epoch_async(h, lrate)) return rc;
+    if (int rc = cmi_comm_exchange(h, scale)) return rc;
+    double loss = 0.0;
+    if (int rc = cmi_last_loss(h, &loss)) return rc;
+    if (global_loss) *global_loss = loss;
     return CMI_OK;
 }

@@ -41,15 +41,31 @@ class _DevArray:
 
 class GpuEngine:
     """Engine over one capi.Instance.  The exchange runs entirely on the instance's HIP stream: two hand-written elementwise
-    kernels (cmi_exchange_pack / cmi_exchange_apply) around the collective, which torch issues with that stream as its current
-    stream (torch.cuda.ExternalStream) -- local epoch -> pack -> reduce-scatter + all-gather -> apply -> loss all-reduce are
-    ordered on the device, and the host synchronises once per epoch, when it reads the loss it needs for isConverged()."""
+    kernels (cmi_exchange_pack / cmi_exchange_apply) around the collective -- local epoch -> pack -> reduce-scatter + all-gather ->
+    apply -> loss all-reduce are ordered on the device, and the host synchronises once per epoch, when it reads the loss it needs
+    for isConverged().
 
-    def __init__(self, inst, device_index, world=1):
+    Who issues the collective: with the `nccl` backend (RCCL; a real multi-GPU job) the LIBRARY does, through cmi_comm_* -- the one
+    exchange implementation the single-process hosts use too (cmi_group_*, group_api.cpp exchange_collective); torch.distributed
+    only hands the 128-byte RCCL unique id from rank 0 to the other ranks (`lib_comm`).  With `gloo` (the CPU / shared-GPU tests) torch
+    issues it on the bucket tensor, with the instance's stream made current."""
+
+    def __init__(self, inst, device_index, world=1, dist=None, group=None):
         import torch
         self.inst = inst
         self.torch = torch
         self.device = torch.device("cuda", device_index)
+        self.lib_comm = False
+        if dist is not None and dist.is_initialized() and dist.get_backend(group) == "nccl":
+            rank = dist.get_rank(group)
+            idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=self.device)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+            if dist.get_world_size(group) > 1:
+                dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            inst.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, dist.get_world_size(group))   # also snapshots the item-side state
+            self.lib_comm = True
+            return
         ptr, cnt, dt = inst.exchange_setup(pad_to=max(1, world))   # also snapshots the item-side state
         self.bucket = torch.as_tensor(_DevArray(ptr, cnt, dt), device=self.device)
         self.loss = torch.as_tensor(_DevArray(inst.loss_device_ptr(), 1, np.float64), device=self.device)
@@ -60,6 +76,11 @@ class GpuEngine:
 
     def local_loss(self):
         return self.inst.last_loss()          # synchronises the instance stream
+
+    def comm_epoch_tail(self, scale):
+        """lib_comm: the exchange behind the epoch start_epoch() enqueued, and the global loss (the epoch's one host sync)."""
+        self.inst.comm_exchange(scale)
+        return self.inst.last_loss()
 
     def exchange_stream(self):
         return self.torch.cuda.stream(self.ext)
@@ -150,7 +171,7 @@ class ShardedEpochRunner:
         if isinstance(engine_or_inst, capi.Instance):
             if device_index is None:
                 device_index = torch.cuda.current_device()
-            engine_or_inst = GpuEngine(engine_or_inst, device_index, self.world)
+            engine_or_inst = GpuEngine(engine_or_inst, device_index, self.world, dist, group)
         self.engine = engine_or_inst
         if hasattr(self.engine, "_setup_exchange"):
             self.engine._setup_exchange(self.world)
@@ -169,6 +190,8 @@ class ShardedEpochRunner:
         if self.world == 1 and not self.always_exchange:
             return eng.local_loss()
         scale = 1.0 / self.world if self.merge == "mean" else 1.0
+        if getattr(eng, "lib_comm", False):      # RCCL: the library issues the collectives itself (cmi_comm_*)
+            return eng.comm_epoch_tail(scale)
         with eng.exchange_stream():
             bucket = eng.pack()
             if self.rs_ag:
@@ -283,9 +306,26 @@ class ShardedFMRunner:
         self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
         # tests: run the exchange path (collective included) even at world size 1
         self.always_exchange = always_exchange and dist is not None and dist.is_initialized()
+        # RCCL (a real multi-GPU job): the library issues the ~130 per-phase all-reduces of a sweep itself (cmi_fm_comm_sweep) -- no
+        # Python between the phases; torch.distributed only hands the RCCL unique id to the ranks.  gloo (tests): torch issues them.
+        self.lib_comm = False
+        if (isinstance(engine, GpuFMEngine) and dist is not None and dist.is_initialized() and dist.get_backend(group) == "nccl"
+                and (self.world > 1 or self.always_exchange)):
+            import torch
+            rank = dist.get_rank(group)
+            idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=engine.device)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+            if self.world > 1:
+                dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            engine.inst.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, self.world)
+            self.lib_comm = True
 
     def sweep(self):
         eng, dist = self.engine, self.dist
+        if self.lib_comm:
+            eng.inst.comm_sweep()
+            return
         for ph in range(eng.num_phases()):
             exchange = (self.world > 1 or self.always_exchange) and fm_phase_field(ph) != 0
             if not exchange and hasattr(eng, "phase_run"):

@@ -358,6 +358,25 @@ int cmi_group_predict_batch(cmi_group_handle g, int64_t n, const int32_t *u, con
 int cmi_group_shard_info(cmi_group_handle g, int shard, int64_t info[6]);
 /* the shard's instance (owned by the group), e.g. for cmi_schedule_info / cmi_last_epoch_ms */
 int cmi_group_member(cmi_group_handle g, int shard, cmi_handle *out);
+/* `--early-stop MAE|RMSE` for a sharded recommender (IterativeRecommender.java:149-161: isConverged() scores the test set after every
+ * epoch): the test tuples are routed ONCE to the shard that owns their user and stay on its device (cmi_set_eval_ratings per shard);
+ * cmi_group_eval_resident adds the shards' sums in shard order -> out = {MAE, RMSE, NMAE, rMAE, rRMSE} as cmi_eval_resident */
+int cmi_group_set_eval_ratings(cmi_group_handle g, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r);
+int cmi_group_eval_resident(cmi_group_handle g, double min_rate, double max_rate, double out[5], int64_t *count);
+
+/* ---- the same exchange for a one-process-per-GPU job (carskit_amd/dist.py, bench.py --gpus N under torch.distributed.run) ------------
+ * ONE implementation serves both hosts: cmi_group_* (one process, ncclCommInitAll) and cmi_comm_* (ncclCommInitRank) issue the same
+ * three collectives from the same function (group_api.cpp, exchange_collective).  The host ranks share CMI_COMM_ID_BYTES bytes once
+ * (rank 0 calls cmi_comm_unique_id, the host's own rendezvous hands the bytes to the other ranks), every rank calls cmi_comm_init
+ * on its handle (after cmi_set_ratings / cmi_set_state: it snapshots the item-side containers), then per epoch
+ *   cmi_comm_train_epoch(h, lrate, scale, &loss) = local epoch -> pack -> reduce-scatter + all-gather -> apply(scale) -> loss all-reduce
+ * with scale = 1/world (the mean of the ranks' moves); `loss` is the GLOBAL loss, the epoch's one host
+ * synchronisation.  cmi_comm_exchange alone is the exchange without the epoch (everything enqueued on cmi_stream()). */
+#define CMI_COMM_ID_BYTES 128
+int cmi_comm_unique_id(void *id /* CMI_COMM_ID_BYTES */);
+int cmi_comm_init(cmi_handle h, const void *id, int rank, int world);
+int cmi_comm_exchange(cmi_handle h, double scale);
+int cmi_comm_train_epoch(cmi_handle h, double lrate, double scale, double *global_loss);
 
 /* ---- FM: src/carskit/alg/cars/adaptation/dependent/FM.java (ALS / coordinate-descent sweep, not SGD) ---------
  * Separate handle type: the state is (w0, w[p], V[p x k]) with p = numUsers+numItems+numConditions
@@ -419,6 +438,11 @@ int cmi_fm_phase_run(cmi_fm_handle h, int phase);
  * [2..4] records of the three orders, [5..6] chunks, [7] HBM bytes one factor has to move, [8..9] of that the reduce launch of
  * the user / item field, [10] slice entries, [11] p -- and the HIP-event duration of one phase's reduce kernel (it writes only
  * scratch, the model is untouched) */
+/* ratings sharded by user over one process per GPU: the sweep with its per-phase exchange (all-reduce of [num | den] for the w0 /
+ * item / context phases; user phases are rank-local) issued by the library on the instance's stream.  `id`: CMI_COMM_ID_BYTES bytes of
+ * cmi_comm_unique_id() from rank 0; cmi_fm_set_hparams' global_size = the ratings of ALL ranks. */
+int cmi_fm_comm_init(cmi_fm_handle h, const void *id, int rank, int world);
+int cmi_fm_comm_sweep(cmi_fm_handle h);
 int cmi_fm_layout(cmi_fm_handle h, int64_t out[12]);
 int cmi_fm_time_reduce(cmi_fm_handle h, int phase, int reps, double *avg_ms);
 

@@ -138,11 +138,10 @@ final class GpuSupport {
     }
 
     /** The same flow over a cmi_group: the library shards the CSR arrays by user, every epoch returns the GLOBAL loss, so the
-     *  unchanged isConverged() steers all shards.  `--early-stop MAE|RMSE` would need the live model per epoch on the host side:
-     *  not wired for groups (use --early-stop loss, or one GPU). */
+     *  unchanged isConverged() steers all shards.  `--early-stop MAE|RMSE`: the test tuples are routed once to the shards that own
+     *  their users and stay on the devices (cmi_group_set_eval_ratings); isConverged()'s evalRatings() reads the shards' sums
+     *  (cmi_group_eval_resident) through the drop-in's live handle, exactly as on one GPU. */
     static void buildModelSharded(GpuHost r, int nShards) throws Exception {
-        if (r.evaluatesDuringTraining())
-            throw new UnsupportedOperationException("-Dcarskit.shards > 1 supports --early-stop loss only");
         boolean twoD = r.modelId() == NativeMF.BIASEDMF || r.modelId() == NativeMF.PMF;
         long g = NativeMF.groupCreate(r.modelId(), r.factors(), r.users(), r.items(), r.conditions(), nShards, null, r.createFlags());
         try {
@@ -162,12 +161,18 @@ final class GpuSupport {
             // the mean merge slows convergence per epoch (1.2x / 1.4x / 1.6x at 2 / 4 / 8 shards); sqrt(N) on the LOCAL rate recovers
             // it to <= 1.2x while isConverged()'s bold driver keeps steering the base rate (DESIGN.md section 7); -Dcarskit.shards.lrscale=1 opts out
             NativeMF.groupSetLrScale(g, Double.parseDouble(System.getProperty("carskit.shards.lrscale", Double.toString(Math.sqrt(nShards)))));
+            if (r.evaluatesDuringTraining() && r.contextualTest() != null) {
+                Object[] t = tuples(r.contextualTest(), dao);
+                NativeMF.groupSetEvalRatings(g, (int[]) t[0], (int[]) t[1], twoD ? null : (int[]) t[2], (double[]) t[3]);
+                r.handle(-g);   // a drop-in's live handle < 0 = a cmi_group (native handles are user-space addresses: positive)
+            }
             for (int iter = 1; iter <= r.iterations(); iter++) {
                 double loss = NativeMF.groupTrainEpoch(g, r.learnRate());
                 if (r.epochDone(iter, loss)) break;
             }
             r.copyOut(Dev.ofGroup(g));
         } finally {
+            r.handle(0L);
             NativeMF.groupDestroy(g);
         }
     }
@@ -175,7 +180,7 @@ final class GpuSupport {
     /** evalRatings() while the native handle is live: the same measures the reference computes (Recommender.java:504-594),
      *  from the model on the device. */
     static Map<Measure, Double> evalResident(long h, double minRate, double maxRate) {
-        double[] m = NativeMF.evalResident(h, minRate, maxRate);
+        double[] m = h < 0 ? NativeMF.groupEvalResident(-h, minRate, maxRate) : NativeMF.evalResident(h, minRate, maxRate);
         Map<Measure, Double> out = new HashMap<Measure, Double>();
         out.put(Measure.MAE, m[0]);
         out.put(Measure.RMSE, m[1]);

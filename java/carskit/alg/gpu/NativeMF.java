@@ -87,6 +87,10 @@ public final class NativeMF {
     public static native double groupTrainEpoch(long g, double lRate);
     /** cmi_group_eval_ratings: {MAE, RMSE, NMAE, rMAE, rRMSE, count}, test tuples routed to the shard that owns their user */
     public static native double[] groupEvalRatings(long g, int[] u, int[] j, int[] ctx, double[] r, double minRate, double maxRate);
+    /** cmi_group_set_eval_ratings + cmi_group_eval_resident: `--early-stop MAE|RMSE` with -Dcarskit.shards=N -- the test tuples go to
+     *  the shards that own their users once and stay on the devices; {MAE, RMSE, NMAE, rMAE, rRMSE, count} */
+    public static native void groupSetEvalRatings(long g, int[] u, int[] j, int[] ctx, double[] r);
+    public static native double[] groupEvalResident(long g, double minRate, double maxRate);
 
     // ---- FM (src/carskit/alg/cars/adaptation/dependent/FM.java) --------------------------------------------------
     public static native long fmCreate(int k, int nUsers, int nItems, int nConds, int nCtxDims, int device, int flags);

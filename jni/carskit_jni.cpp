@@ -487,4 +487,25 @@ JNIEXPORT jdoubleArray JNICALL Java_carskit_alg_gpu_NativeMF_groupEvalRatings(JN
     return to_java(env, out, 6);
 }
 
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_groupSetEvalRatings(JNIEnv *env, jclass, jlong g, jintArray u, jintArray j, jintArray ctx,
+                                                                         jdoubleArray r) {
+    const std::vector<int32_t> pu = ints(env, u), pj = ints(env, j), pc = ints(env, ctx);
+    const std::vector<double> pr = doubles(env, r);
+    if (bad_tuples(env, pu.size(), pj.size(), ctx != nullptr, pc.size(), true, pr.size())) return;
+    throw_group(env, (cmi_group_handle)g,
+                cmi_group_set_eval_ratings((cmi_group_handle)g, (int64_t)pu.size(), pu.data(), pj.data(), ctx ? pc.data() : nullptr, pr.data()));
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_carskit_alg_gpu_NativeMF_groupEvalResident(JNIEnv *env, jclass, jlong g, jdouble minRate, jdouble maxRate) {
+    double out[6] = {0, 0, 0, 0, 0, 0};
+    int64_t cnt = 0;
+    const int rc = cmi_group_eval_resident((cmi_group_handle)g, minRate, maxRate, out, &cnt);
+    out[5] = (double)cnt;
+    if (rc != CMI_OK) {
+        throw_group(env, (cmi_group_handle)g, rc);
+        return nullptr;
+    }
+    return to_java(env, out, 6);
+}
+
 } // extern "C"

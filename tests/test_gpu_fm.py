@@ -1,6 +1,7 @@
-"""FM (reference FM.java ALS sweep) on the GPU vs the dense CPU oracle.  fp64 on both sides; the GPU
-tree-reduces the per-coordinate sums and uses size*reg for the denominator's regulariser instead of the
-Java's one-add-per-rating, so equality is to rounding: model 1e-10, predictions/RMSE 1e-9."""
+"""FM (reference FM.java ALS sweep) on the GPU vs the dense CPU oracle.  fp64 on both sides; the GPU never
+stores errors[] / Q[][] (an error is err0 + the running delta sums of its coordinates), adds a coordinate's sums per
+piece of its support and uses size*reg for the denominator's regulariser instead of the Java's one-add-per-rating,
+so equality is to rounding: model 1e-8 relative, predictions/RMSE 1e-9."""
 import numpy as np
 import pytest
 
@@ -110,9 +111,8 @@ def test_fm_sharded_runner_gpu_engine_and_phase_buffer_alias():
 
 
 def test_fm_phases_in_any_order_match_the_numpy_engine():
-    """The lazy error bookkeeping (item / context deltas folded by the next sequential pass, per-rating user entries
-    left by the user phase) must be invisible: drive reduce+apply phases in an order the sweep never uses and compare
-    with the dense NumPy phase engine after every step."""
+    """Errors are never stored (err0 + running delta sums per coordinate), so the phases may be driven in ANY order: drive
+    reduce+apply phases in an order the sweep never uses and compare with the dense NumPy phase engine after every step."""
     from tests.fm_np_engine import NumpyFMEngine
     data = util.small_data(n_users=45, n_items=14, n_dims=2, conds_per_dim=3, n=650, seed=55)
     k = 3
@@ -142,12 +142,15 @@ def test_fm_phases_in_any_order_match_the_numpy_engine():
 
 
 @pytest.mark.parametrize("n_users,n_items,n,zipf", [(3, 40, 1500, None), (1, 30, 900, None), (400, 2, 1200, None),
-                                                     (300, 25, 3000, 1.3), (2, 2, 60, None)])
+                                                     (300, 25, 3000, 1.3), (2, 2, 60, None), (1, 40, 6000, None)])
 def test_fm_support_length_paths(n_users, n_items, n, zipf):
-    """Every kernel path by support length: 16/32-lane groups with the in-register and the two-loop variant (hot
-    coordinates), 256- and 1024-thread workgroups per coordinate (few users or items with very long supports)."""
-    data = util.small_data(n_users=n_users, n_items=n_items, n_dims=3, conds_per_dim=4, n=n, seed=56, item_zipf=zipf)
+    """Every reduction path by support length: stream chunks (a lane per piece of <= 64 records), vector chunks (a hot coordinate's
+    piece, all 64 lanes), a piece longer than one vector chunk (> 2048 records: several partial slots per coordinate), coordinates
+    without any rating."""
+    data = util.small_data(n_users=n_users, n_items=n_items, n_dims=3, conds_per_dim=6 if n >= 6000 else 4, n=n, seed=56, item_zipf=zipf)
     orc, g = make_fm(data, 5, 6)
+    if n >= 6000:
+        assert np.bincount(data.u).max() > 2048
     orc.init()
     g.init()
     for _ in range(2):
@@ -157,6 +160,37 @@ def test_fm_support_length_paths(n_users, n_items, n, zipf):
     np.testing.assert_allclose(w0, orc.w0, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(w, orc.w, rtol=1e-8, atol=1e-11)
     np.testing.assert_allclose(V, orc.V.reshape(V.shape), rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("slice_entries", [8, 16, 1000000])
+def test_fm_l2_sliced_orders_match_the_oracle(slice_entries):
+    """The streams are sorted by (slice of the gathered table, own coordinate) so that the gathers stay L2-resident: a coordinate's
+    support is then S pieces whose partial sums the finishing kernel adds.  Forced here with tiny slices (CMI_FM_SLICE; at BASELINE
+    C4's share the default of 128 K entries gives 4 and 5 slices): same model as the dense oracle, whatever the slicing."""
+    import os
+    data = util.small_data(n_users=60, n_items=40, n_dims=2, conds_per_dim=3, n=3000, seed=58)
+    os.environ["CMI_FM_SLICE"] = str(slice_entries)
+    try:
+        orc, g = make_fm(data, 6, 7)
+    finally:
+        del os.environ["CMI_FM_SLICE"]
+    lay = g.layout()
+    if slice_entries < 100:
+        assert lay["slices_user_order"] > 1 and lay["slices_item_order"] > 1
+    else:
+        assert lay["slices_user_order"] == lay["slices_item_order"] == 1
+    assert lay["records_user_order"] == lay["records_item_order"] == data.n and lay["records_ctx_order"] == int((data.ctx < data.n_conds).sum())
+    orc.init()
+    g.init()
+    for _ in range(3):
+        orc.sweep()
+        g.sweep()
+    w0, w, V = g.get_model()
+    np.testing.assert_allclose(w0, orc.w0, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(w, orc.w, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(V, orc.V.reshape(V.shape), rtol=1e-8, atol=1e-11)
+    assert g.time_reduce(4, 2) > 0.0        # the bench's HIP-event timer of one reduce launch: leaves the model alone
+    assert np.array_equal(g.get_model()[2], V)
 
 
 def test_fm_runner_exchange_path_on_the_instance_stream_with_rccl():
@@ -183,6 +217,7 @@ def test_fm_runner_exchange_path_on_the_instance_stream_with_rccl():
         eng = cdist.GpuFMEngine(a, 0)
         assert eng.ext is not None
         run = cdist.ShardedFMRunner(eng, tdist, always_exchange=True)
+        assert run.lib_comm                        # RCCL: the library issues the per-phase all-reduces itself (cmi_fm_comm_sweep)
         for _ in range(3):
             run.sweep()
             b.sweep()

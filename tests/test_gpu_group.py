@@ -115,6 +115,12 @@ def test_group_on_one_device_equals_manual_exchange_bitwise(model, world):
     assert abs(e["MAE"] - sums[0] / cnt) < 1e-12 and abs(e["RMSE"] - np.sqrt(sums[1] / cnt)) < 1e-12
     p = g.predict_batch(test.u[:50], test.j[:50], test.ctx[:50], bound=True, lo=1.0, hi=5.0)
     assert p.shape == (50,) and np.all((p >= 1.0) & (p <= 5.0))
+    # `--early-stop MAE|RMSE` for a sharded recommender: the test tuples are routed to their owners ONCE and stay on the devices;
+    # the resident evaluation equals the per-call one, before and after a further epoch
+    g.set_eval_ratings(test.u, test.j, test.ctx, test.r)
+    assert g.eval_resident(1.0, 5.0) == e
+    g.train_epoch(util.LR)
+    assert g.eval_resident(1.0, 5.0) == g.eval_ratings(test.u, test.j, test.ctx, test.r, 1.0, 5.0) != e
 
 
 def test_group_of_one_is_the_plain_instance_and_matches_the_oracle():

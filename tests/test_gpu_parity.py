@@ -344,6 +344,7 @@ def test_dist_gpu_engine_aliases_device_state_and_exchange_is_identity_at_world1
     try:
         runner = cdist.ShardedEpochRunner(a, tdist, device_index=0, always_exchange=True)
         assert runner.rs_ag                                # RCCL: in-place reduce-scatter + all-gather of the bucket
+        assert runner.engine.lib_comm                      # ... issued by the LIBRARY (cmi_comm_*: the function cmi_group_* uses), not torch
         for _ in range(3):
             la, lb = runner.epoch(util.LR), b.train_epoch(util.LR)
             assert abs(la - lb) <= 1e-6 * abs(lb)
