@@ -543,7 +543,8 @@ def main():
                        "levels_per_epoch": info["levels"], "first_loss": losses[0], "final_loss": losses[-1],
                        "concurrent_folds": args.folds,
                        "parallelism": "1 GPU" if world == 1 else
-                       "user-sharded x%d + RCCL reduce-scatter/all-gather of item-side moves (%s merge)" % (world, args.merge)},
+                       "user-sharded x%d + RCCL reduce-scatter/all-gather of item-side moves (%s merge); exchange issued by: %s"
+                       % (world, args.merge, getattr(trainer.engine, "exchange_path", "torch.distributed"))},
             "roofline": roofline(model, k, n_dims, data.n, info, sched, kern_ms, es, args.workload),
         }
         for o in extra:

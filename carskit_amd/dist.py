@@ -56,6 +56,7 @@ class GpuEngine:
         self.torch = torch
         self.device = torch.device("cuda", device_index)
         self.lib_comm = False
+        self.exchange_path = "torch.distributed collectives on the instance's stream"
         if dist is not None and dist.is_initialized() and dist.get_backend(group) == "nccl":
             rank = dist.get_rank(group)
             idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=self.device)
@@ -63,9 +64,23 @@ class GpuEngine:
                 idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
             if dist.get_world_size(group) > 1:
                 dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            inst.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, dist.get_world_size(group))   # also snapshots the item-side state
-            self.lib_comm = True
-            return
+            # every rank reaches this point together (ncclCommInitRank is a collective).  If the library's communicator cannot be
+            # created on some rank, ALL ranks fall back to the torch-issued form of the same exchange (agreed through an all-reduce) --
+            # said loudly on stderr and recorded in `exchange_path`, never silently.
+            ok = torch.ones(1, device=self.device)
+            try:
+                inst.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, dist.get_world_size(group))   # also snapshots the item-side state
+            except Exception as e:   # noqa: BLE001
+                import sys
+                print("carskit_amd.dist: cmi_comm_init failed on rank %d (%s); falling back to torch.distributed collectives" % (rank, e),
+                      file=sys.stderr, flush=True)
+                ok.zero_()
+            if dist.get_world_size(group) > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if float(ok.item()) > 0:
+                self.lib_comm = True
+                self.exchange_path = "library (cmi_comm_*: RCCL reduce-scatter + all-gather issued by libcarskit_mi355x)"
+                return
         ptr, cnt, dt = inst.exchange_setup(pad_to=max(1, world))   # also snapshots the item-side state
         self.bucket = torch.as_tensor(_DevArray(ptr, cnt, dt), device=self.device)
         self.loss = torch.as_tensor(_DevArray(inst.loss_device_ptr(), 1, np.float64), device=self.device)
