@@ -37,8 +37,6 @@ FLAG_STATE_F64 = 0x1
 FLAG_SCHED_SERIAL = 0x2
 FLAG_STRICT = 0x4
 FLAG_NO_GRAPH = 0x10
-FLAG_SCHED_FLOW = 0x20
-FLAG_TWO_LANE = 0x40
 FLAG_SCHED_CHAIN = 0x80
 FLAG_NO_CHAIN = 0x100
 FLAG_SCHED_OWNER = 0x200
@@ -126,8 +124,6 @@ SYMBOLS = [
     ("cmi_owner_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(C.c_int)]),
     ("cmi_chain_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _i64, C.POINTER(_i64),
                                      C.POINTER(_i64), C.POINTER(C.c_int)]),
-    ("cmi_split_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
-    ("cmi_flow_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     ("cmi_dao_read", C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     ("cmi_dao_read_shared", C.c_int, [C.c_char_p, _vp, C.POINTER(_vp)]),
     ("cmi_dao_destroy", C.c_int, [_vp]),
@@ -355,40 +351,6 @@ def arena_positions(spoke, n_spokes):
     if rc != OK:
         raise CmiError(rc, "cmi_arena_positions")
     return nxt, first
-
-
-def split_schedule(u, j, n_users, n_items):
-    """Host-only: (perm, level_off, split) of the two-lane level schedule (see cmi_split_schedule)."""
-    u = np.ascontiguousarray(u, dtype=np.int32)
-    j = np.ascontiguousarray(j, dtype=np.int32)
-    nl = _i64()
-    rc = lib().cmi_split_schedule(len(u), _p(u), _p(j), n_users, n_items, None, None, None, 0, C.byref(nl))
-    if rc != OK:
-        raise CmiError(rc, "cmi_split_schedule")
-    perm = np.empty(len(u), dtype=np.int32)
-    off, split = np.empty(nl.value + 1, dtype=np.int64), np.empty(max(1, nl.value), dtype=np.int64)
-    rc = lib().cmi_split_schedule(len(u), _p(u), _p(j), n_users, n_items, _p(perm), _p(off), _p(split), len(off),
-                                  C.byref(nl))
-    if rc != OK:
-        raise CmiError(rc, "cmi_split_schedule")
-    return perm, off, split[:nl.value]
-
-
-def flow_schedule(u, j, n_users, n_items):
-    """Host-only: (perm with -1 padding, seq_u, seq_j) of the dataflow schedule (see cmi_flow_schedule)."""
-    u = np.ascontiguousarray(u, dtype=np.int32)
-    j = np.ascontiguousarray(j, dtype=np.int32)
-    ns = _i64()
-    rc = lib().cmi_flow_schedule(len(u), _p(u), _p(j), n_users, n_items, None, None, None, 0, C.byref(ns))
-    if rc != OK:
-        raise CmiError(rc, "cmi_flow_schedule")
-    perm = np.empty(ns.value, dtype=np.int32)
-    su, sj = np.empty(ns.value, dtype=np.uint32), np.empty(ns.value, dtype=np.uint32)
-    rc = lib().cmi_flow_schedule(len(u), _p(u), _p(j), n_users, n_items, _p(perm), _p(su), _p(sj), ns.value,
-                                 C.byref(ns))
-    if rc != OK:
-        raise CmiError(rc, "cmi_flow_schedule")
-    return perm, su, sj
 
 
 def _eval_rankings(fn, chk, h, train, test, bin_thold=-1.0, num_recs=10, num_ignore=0, strategy="ucu", with_lists=False):

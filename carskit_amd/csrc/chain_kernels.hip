@@ -377,67 +377,6 @@ __global__ __launch_bounds__(256) void sgd_chain_level(SgdArgs<T> a, const int32
     }
 }
 
-// Narrow runs of chain levels (heavy-tailed degrees: the hot rows' chains force hundreds of thousands of levels holding a few dozen
-// units each).  ONE 1024-thread workgroup = 64 groups walks a whole run of levels with <= 64 units each: group g takes unit g of
-// every level, a workgroup barrier separates levels (all waves share the CU's L1 and its XCD's L2: workgroup-scope ordering is all
-// the coherence needed, as in sgd_tail_fast_f32).  Bounds and ids do not depend on the updates: the bounds of level l+2 and the ids
-// of level l+1 are loaded while level l computes, so a level's critical path is ONE dependent round trip (its rows) + its chain.
-// Same per-tuple code as sgd_chain_level, hence the same bits.
-template <typename T, int MODEL, int NV, bool RAGGED, bool HUB_ITEM>
-__global__ __launch_bounds__(1024) void sgd_chain_tail(SgdArgs<T> a, const int32_t *__restrict__ unit_off, const int64_t *__restrict__ lvl_off,
-                                                       int n_levels, int64_t slot) {
-    using M = Traits<MODEL>;
-    constexpr int E = Vec16<T>::E;
-    constexpr bool HC = HUB_ITEM ? M::has_ic : M::has_uc;
-    extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
-    __shared__ double s_loss[64];
-    const int tid = threadIdx.x, l16 = tid & 15, gib = tid >> 4;
-    const int K = RAGGED ? a.k : NV * 16 * E;
-    const int dmax = M::has_ctx ? a.dmax : 0;
-    unsigned char *gbase = chain_smem + (size_t)gib * chain_group_lds(HC ? a.n_conds : 0, dmax, sizeof(T));
-    double gloss = 0.0;
-    const HParams hpd = *a.hp;
-    const ChainHp<T> hp{(T)hpd.lr, (T)hpd.regU, (T)hpd.regI, (T)hpd.regB, (T)hpd.regC, (T)hpd.gm};
-
-    // software pipeline over levels: `nb` = unit bounds of the next level, `pre` = ids of the current level
-    int64_t lo = lvl_off[0], hi = lvl_off[1];
-    bool have = lo + gib < hi;
-    ChainPre<T> pre;
-    pre.len = 0;
-    if (have) pre = chain_prefetch_ids<T, M::has_ctx, HUB_ITEM>(a, unit_off[lo + gib], unit_off[lo + gib + 1], l16, dmax);
-    int64_t nlo = hi, nhi = n_levels > 1 ? lvl_off[2] : hi;
-    bool nhave = n_levels > 1 && nlo + gib < nhi;
-    int32_t nb0 = 0, nb1 = 0;
-    if (nhave) {
-        nb0 = unit_off[nlo + gib];
-        nb1 = unit_off[nlo + gib + 1];
-    }
-    for (int l = 0; l < n_levels; ++l) {
-        const ChainPre<T> cur = pre;
-        const bool cur_have = have;
-        // ids of level l+1 (its bounds arrived during level l-1), bounds of level l+2
-        have = nhave;
-        if (nhave) pre = chain_prefetch_ids<T, M::has_ctx, HUB_ITEM>(a, nb0, nb1, l16, dmax);
-        const int64_t n2lo = nhi, n2hi = l + 3 <= n_levels ? lvl_off[l + 3] : nhi;
-        nhave = l + 2 < n_levels && n2lo + gib < n2hi;
-        if (nhave) {
-            nb0 = unit_off[n2lo + gib];
-            nb1 = unit_off[n2lo + gib + 1];
-        }
-        nlo = n2lo;
-        nhi = n2hi;
-        if (cur_have) chain_unit<T, MODEL, NV, RAGGED, HUB_ITEM>(a, hp, cur, gbase, l16, K, dmax, gloss);
-        __syncthreads(); // release/acquire at workgroup scope: the next level sees this level's rows
-    }
-    if (l16 == 0) s_loss[gib] = gloss;
-    __syncthreads();
-    if (tid == 0) {
-        double sum = 0.0;
-        for (int g = 0; g < 64; ++g) sum += s_loss[g];
-        a.loss_part[slot] = sum;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // small k (fp32 state, k < 64: the reference's default num.factors is 10): LPT = 4, 8 or 16 lanes per unit
 // ---------------------------------------------------------------------------------------------
@@ -725,49 +664,42 @@ int chain_level_blocks(int k, int dmax, bool f64, int count) {
     return (count + g - 1) / g;
 }
 
-// a narrow-run launch keeps 64 groups' LDS in one workgroup
-bool has_chain_tail(int model, int k, int n_conds, int dmax, bool f64) {
-    if (!f64 && k < 64) return false; // the small-k kernel has no multi-level form
-    return 4 * chain_lds_bytes(model, n_conds, dmax, f64, true) <= 64 * 1024 && 4 * chain_lds_bytes(model, n_conds, dmax, f64, false) <= 64 * 1024;
-}
-
 template <typename T, int MODEL, int NV, bool RAGGED>
-static void *chain_kernel_hub(bool hub_is_item, bool tail) {
-    if (tail) return hub_is_item ? (void *)sgd_chain_tail<T, MODEL, NV, RAGGED, true> : (void *)sgd_chain_tail<T, MODEL, NV, RAGGED, false>;
+static void *chain_kernel_hub(bool hub_is_item) {
     return hub_is_item ? (void *)sgd_chain_level<T, MODEL, NV, RAGGED, true> : (void *)sgd_chain_level<T, MODEL, NV, RAGGED, false>;
 }
 
 template <typename T, int MODEL>
-static void *chain_kernel_k(int k, bool hub_is_item, bool tail) {
+static void *chain_kernel_k(int k, bool hub_is_item) {
     constexpr int E = Vec16<T>::E;
     const int per = 16 * E; // factors one vector slot covers across the group
     if (k % per == 0) {
         switch (k / per) {
-        case 1: return chain_kernel_hub<T, MODEL, 1, false>(hub_is_item, tail);
-        case 2: return chain_kernel_hub<T, MODEL, 2, false>(hub_is_item, tail);
-        case 4: return chain_kernel_hub<T, MODEL, 4, false>(hub_is_item, tail);
-        case 8: if (E == 2) return chain_kernel_hub<T, MODEL, 8, false>(hub_is_item, tail); break;
+        case 1: return chain_kernel_hub<T, MODEL, 1, false>(hub_is_item);
+        case 2: return chain_kernel_hub<T, MODEL, 2, false>(hub_is_item);
+        case 4: return chain_kernel_hub<T, MODEL, 4, false>(hub_is_item);
+        case 8: if (E == 2) return chain_kernel_hub<T, MODEL, 8, false>(hub_is_item); break;
         }
     }
     const int nv = (k + per - 1) / per; // masked vector slots past k
-    if (nv <= 2) return chain_kernel_hub<T, MODEL, 2, true>(hub_is_item, tail);
-    if (nv <= 3) return chain_kernel_hub<T, MODEL, 3, true>(hub_is_item, tail);
-    if (nv <= 4) return chain_kernel_hub<T, MODEL, 4, true>(hub_is_item, tail);
+    if (nv <= 2) return chain_kernel_hub<T, MODEL, 2, true>(hub_is_item);
+    if (nv <= 3) return chain_kernel_hub<T, MODEL, 3, true>(hub_is_item);
+    if (nv <= 4) return chain_kernel_hub<T, MODEL, 4, true>(hub_is_item);
     if (E == 2) {
-        if (nv <= 6) return chain_kernel_hub<T, MODEL, 6, true>(hub_is_item, tail);
-        if (nv <= 8) return chain_kernel_hub<T, MODEL, 8, true>(hub_is_item, tail);
+        if (nv <= 6) return chain_kernel_hub<T, MODEL, 6, true>(hub_is_item);
+        if (nv <= 8) return chain_kernel_hub<T, MODEL, 8, true>(hub_is_item);
     }
     return nullptr;
 }
 
 template <typename T>
-static void *chain_kernel_ptr(int model, int k, bool hub_is_item, bool tail) {
+static void *chain_kernel_ptr(int model, int k, bool hub_is_item) {
     switch (model) {
-    case BIASEDMF: return chain_kernel_k<T, BIASEDMF>(k, hub_is_item, tail);
-    case PMF: return chain_kernel_k<T, PMF>(k, hub_is_item, tail);
-    case CAMF_CI: return chain_kernel_k<T, CAMF_CI>(k, hub_is_item, tail);
-    case CAMF_CU: return chain_kernel_k<T, CAMF_CU>(k, hub_is_item, tail);
-    case CAMF_CUCI: return chain_kernel_k<T, CAMF_CUCI>(k, hub_is_item, tail);
+    case BIASEDMF: return chain_kernel_k<T, BIASEDMF>(k, hub_is_item);
+    case PMF: return chain_kernel_k<T, PMF>(k, hub_is_item);
+    case CAMF_CI: return chain_kernel_k<T, CAMF_CI>(k, hub_is_item);
+    case CAMF_CU: return chain_kernel_k<T, CAMF_CU>(k, hub_is_item);
+    case CAMF_CUCI: return chain_kernel_k<T, CAMF_CUCI>(k, hub_is_item);
     }
     return nullptr;
 }
@@ -801,29 +733,13 @@ hipError_t launch_chain_level(const SgdArgs<T> &a, const LaunchCfg &cfg, bool hu
     if (count <= 0) return hipSuccess;
     const bool f64 = sizeof(T) == 8;
     const int groups = chain_groups_per_block(a.k, a.dmax, f64);
-    void *fn = (!f64 && a.k < 64) ? chain_small_ptr(cfg.model, 256 / groups, hub_is_item) : chain_kernel_ptr<T>(cfg.model, a.k, hub_is_item, false);
+    void *fn = (!f64 && a.k < 64) ? chain_small_ptr(cfg.model, 256 / groups, hub_is_item) : chain_kernel_ptr<T>(cfg.model, a.k, hub_is_item);
     if (!fn) return hipErrorInvalidValue;
     SgdArgs<T> args = a;
     void *params[] = {&args, &unit_off, &ubegin, &count, &slot0};
     const size_t lds = (size_t)groups * (chain_lds_bytes(cfg.model, a.n_conds, a.dmax, f64, hub_is_item) / 16);
     return hipLaunchKernel(fn, dim3((unsigned)chain_level_blocks(a.k, a.dmax, f64, count)), dim3(256), params, lds, s);
 }
-template <typename T>
-hipError_t launch_chain_tail(const SgdArgs<T> &a, const LaunchCfg &cfg, bool hub_is_item, const int32_t *unit_off, const int64_t *lvl_off,
-                             int n_levels, int64_t slot, hipStream_t s) {
-    if (n_levels <= 0) return hipSuccess;
-    void *fn = chain_kernel_ptr<T>(cfg.model, a.k, hub_is_item, true);
-    if (!fn) return hipErrorInvalidValue;
-    SgdArgs<T> args = a;
-    void *params[] = {&args, &unit_off, &lvl_off, &n_levels, &slot};
-    const size_t lds = 4 * chain_lds_bytes(cfg.model, a.n_conds, a.dmax, sizeof(T) == 8, hub_is_item);
-    return hipLaunchKernel(fn, dim3(1), dim3(1024), params, lds, s);
-}
-template hipError_t launch_chain_tail<float>(const SgdArgs<float> &, const LaunchCfg &, bool, const int32_t *, const int64_t *, int, int64_t,
-                                             hipStream_t);
-template hipError_t launch_chain_tail<double>(const SgdArgs<double> &, const LaunchCfg &, bool, const int32_t *, const int64_t *, int, int64_t,
-                                              hipStream_t);
-
 template hipError_t launch_chain_level<float>(const SgdArgs<float> &, const LaunchCfg &, bool, const int32_t *, int64_t, int, int64_t,
                                               hipStream_t);
 template hipError_t launch_chain_level<double>(const SgdArgs<double> &, const LaunchCfg &, bool, const int32_t *, int64_t, int, int64_t,

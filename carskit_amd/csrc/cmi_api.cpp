@@ -149,7 +149,7 @@ static void free_ratings(cmi_instance *h) {
         h->graph_exec = nullptr;
     }
     void *ptrs[] = {h->d_su, h->d_sj, h->d_sconds, h->d_ctx_ptr, h->d_ctx_conds, h->d_sr, h->d_loss_part,
-                    h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->d_tail_off, h->d_blk_off, h->d_unit_off,
+                    h->d_flow_err, h->d_tail_off, h->d_blk_off, h->d_unit_off,
                     h->d_ui_ptr, h->d_ui_items, h->d_own_recs, h->d_own_off, h->d_tagged};
     h->d_own_recs = nullptr;
     h->d_own_off = nullptr;
@@ -160,7 +160,6 @@ static void free_ratings(cmi_instance *h) {
     for (void *p : ptrs)
         if (p) hipFree(p);
     h->d_su = h->d_sj = h->d_sconds = h->d_ctx_ptr = h->d_ctx_conds = nullptr;
-    h->d_seq_u = h->d_seq_j = h->d_ver_u = h->d_ver_j = nullptr;
     h->d_flow_err = nullptr;
     h->d_tail_off = nullptr;
     h->d_blk_off = nullptr;
@@ -170,7 +169,6 @@ static void free_ratings(cmi_instance *h) {
     h->blk_off.clear();
     h->n_launches = h->n_tail = 0;
     h->tail_len.clear();
-    h->flow = false;
     h->d_sr = nullptr;
     h->d_loss_part = nullptr;
     h->have_ratings = false;
@@ -243,8 +241,6 @@ extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_cond
     h->serial = flags & CMI_FLAG_SCHED_SERIAL;
     h->strict = flags & CMI_FLAG_STRICT;
     h->use_graph = !(flags & CMI_FLAG_NO_GRAPH);
-    h->want_flow = flags & CMI_FLAG_SCHED_FLOW;
-    h->want_two_lane = flags & CMI_FLAG_TWO_LANE;
     h->want_owner = flags & CMI_FLAG_SCHED_OWNER;
     const char *step = "";
     hipError_t e = hipSuccess;
@@ -464,7 +460,7 @@ static bool try_chain(cmi_instance *h, int64_t n, const int32_t *u, const int32_
     // Narrow levels (heavy-tailed degrees, tiny data) keep the plain levels and their narrow-run launches: measured on C3-size
     // Zipf(0.8) items, the chain schedule has 2.5x fewer levels (434 K vs 1.10 M) but a narrow chain level is latency-bound on
     // the HBM round trip of EVERY spoke row of its longest unit (one row in flight per group), 3.77 s per epoch against 2.61 s for
-    // the plain narrow-run walk.  Forced (CMI_FLAG_SCHED_CHAIN) it still runs, runs of narrow levels sharing a launch (sgd_chain_tail).
+    // the plain narrow-run walk.  Forced (CMI_FLAG_SCHED_CHAIN) it still runs, one launch per level.
     if (!forced && csch.n_units() < min_width * csch.n_levels()) return false;
     h->chain = true;
     h->chain_hub_item = csch.hub_is_item != 0;
@@ -518,41 +514,27 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
 
     // schedule
     LevelSchedule sch;
-    FlowSchedule fsch;
     ChainSchedule csch;
     OwnerSchedule osch;
-    const bool chain_ok = !h->serial && !h->want_flow && !h->want_two_lane && !h->want_owner && !(h->flags & CMI_FLAG_NO_CHAIN) &&
+    const bool chain_ok = !h->serial && !h->want_owner && !(h->flags & CMI_FLAG_NO_CHAIN) &&
                           has_chain_path(h->model, h->k, dmax, h->n_conds, h->f64, h->strict) && !getenv("CMI_NO_CHAIN");
     if ((h->flags & CMI_FLAG_SCHED_CHAIN) && !chain_ok)
         CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: CMI_FLAG_SCHED_CHAIN: no hub-chain kernel for model %d, k=%d, %s state%s (or another "
                  "schedule flag is set)", h->model, h->k, h->f64 ? "fp64" : "fp32", h->strict ? ", strict" : "");
-    h->flow = false;
-    h->flow_blocks = 0;
-    const bool tables_fit_raw_buffer = (int64_t)h->n_users * h->k * 4 < ((int64_t)1 << 32) &&
-                                       (int64_t)h->n_items * h->k * 4 < ((int64_t)1 << 32);
-    const bool exact_k = h->k == 64 || h->k == 128 || h->k == 256; // the experimental schedules only exist for these
-    if (h->want_flow && h->fast && exact_k && n > 0 && tables_fit_raw_buffer) {
-        h->flow_blocks = flow_grid_blocks(h->device, h->k);
-        if (h->flow_blocks > 0) {
-            if (!build_flow_schedule(n, u, j, h->n_users, h->n_items, fsch))
-                CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: dataflow schedule construction failed");
-            h->flow = true;
-        }
-    }
     h->owner = false;
     h->owner_stalled = false;
-    if (h->want_owner && (h->serial || h->want_flow || h->want_two_lane || !has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict)))
+    if (h->want_owner && (h->serial || !has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict)))
         CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: CMI_FLAG_SCHED_OWNER: no owner kernel for model %d, k=%d, %d conditions, %s state%s (or "
                  "another schedule flag is set)", h->model, h->k, h->n_conds, h->f64 ? "fp64" : "fp32", h->strict ? ", strict" : "");
     // the hub-chain levels first: wide data is theirs
-    const bool use_chain = !h->flow && !h->serial && chain_ok && n > 0 && try_chain(h, n, u, j, csch);
+    const bool use_chain = !h->serial && chain_ok && n > 0 && try_chain(h, n, u, j, csch);
     bool use_owner = h->want_owner;
     h->sched_note.clear();
-    if (!use_owner && !use_chain && !h->flow && !h->serial && !h->want_two_lane && n >= ((int64_t)1 << 16) &&
+    if (!use_owner && !use_chain && !h->serial && n >= ((int64_t)1 << 16) &&
         !has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict) && !(h->flags & CMI_FLAG_NO_OWNER))
         h->sched_note = "narrow dependency levels on a large data set (heavy-tailed degrees?) and no owner kernel for this configuration "
                         "(limits: <= 384 conditions, k <= 256 (fp64: 128)): the level walk runs -- order-exact, roughly 10x slower on such data";
-    if (!use_owner && !use_chain && !h->flow && !h->serial && !h->want_two_lane && !(h->flags & (CMI_FLAG_SCHED_CHAIN | CMI_FLAG_NO_OWNER)) &&
+    if (!use_owner && !use_chain && !h->serial && !(h->flags & (CMI_FLAG_SCHED_CHAIN | CMI_FLAG_NO_OWNER)) &&
         !getenv("CMI_NO_OWNER") && has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict)) {
         // Narrow levels on a large data set = heavy-tailed degrees: every level costs a kernel boundary or a workgroup barrier (>= 2 us),
         // and there are at least as many levels as the hottest row has tuples.  The owner epoch pays ~0.3 us per tuple of the hottest
@@ -656,17 +638,8 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         h->slot_off = {0, (int64_t)h->n_owners};
         h->n_slots = h->n_owners;
         h->sched_levels = 1;
-        h->two_lane = false;
         sch.perm.swap(osch.perm);
-    } else if (h->flow) {
-        h->level_off = {0, (int64_t)fsch.perm.size()};
-        h->max_level = fsch.max_level;
-        h->n_chunks = fsch.n_chunks();
-        h->slot_off = {0, (int64_t)h->flow_blocks * 4};
-        h->n_slots = (int64_t)h->flow_blocks * 4;
-        h->sched_levels = fsch.n_levels;
     } else {
-        h->two_lane = false;
         if (h->serial) {
             sch.level_off = {0, n};
             sch.max_level = n;
@@ -687,15 +660,6 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             sch.perm.swap(csch.perm);
             sch.level_off = csch.level_off;
             sch.max_level = csch.max_level_units;
-        } else if (h->fast && exact_k && h->use_graph && h->want_two_lane && n > 0) {
-            SplitSchedule ss;
-            if (!build_split_schedule(n, u, j, h->n_users, h->n_items, ss))
-                CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: schedule construction failed");
-            sch.perm.swap(ss.perm);
-            sch.level_off = ss.level_off;
-            sch.max_level = ss.max_level;
-            h->split_off = ss.split;
-            h->two_lane = true;
         } else {
             int order = LEVEL_ORDER_CRS;
             if (const char *env = getenv("CMI_LEVEL_ORDER")) {
@@ -726,9 +690,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         // tuples each is walked by ONE single-workgroup launch instead of one launch per level
         h->tail_len.assign((size_t)n_levels, 0);
         h->n_launches = 0;
-        if (!h->serial && !h->two_lane && !h->chain && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 256, 16, h->tail_len);
-        // chain levels: a run of >= 16 consecutive levels with <= 64 UNITS each is walked by one 64-group workgroup (sgd_chain_tail)
-        if (h->chain && has_chain_tail(h->model, h->k, h->n_conds, dmax, h->f64) && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 64, 16, h->tail_len);
+        if (!h->serial && !h->chain && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 256, 16, h->tail_len);
         h->slot_off.assign((size_t)n_levels + 1, 0);
         for (int64_t l = 0; l < n_levels; ++l) {
             const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
@@ -737,10 +699,6 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
                          : h->fast ? level_blocks_f32_fast(h->k, cnt)
                          : h->small ? level_blocks_small(h->k, dmax, cnt)
                                     : level_blocks_generic(cnt);
-            if (h->two_lane) { // head and tail are separate launches with their own workgroup numbering
-                const int head = (int)(h->split_off[(size_t)l] - h->level_off[(size_t)l]);
-                blocks = level_blocks_f32_fast(h->k, head) + level_blocks_f32_fast(h->k, cnt - head);
-            }
             if (h->tail_len[(size_t)l] > 0) blocks = 1;       // a narrow run owns one loss slot ...
             else if (h->tail_len[(size_t)l] < 0) blocks = 0;  // ... at its first level
             if (h->tail_len[(size_t)l] >= 0) ++h->n_launches;
@@ -753,15 +711,15 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     }
 
     // tuple stream in schedule order, conditions pre-expanded to [n x dmax] (-1 padded) so the kernels
-    // need no ctx -> condition-list indirection.  The dataflow schedule has padding slots (user id -1).
-    const int64_t ns = h->flow ? (int64_t)fsch.perm.size() : n;
+    // need no ctx -> condition-list indirection.
+    const int64_t ns = n;
     std::vector<int32_t> su((size_t)ns), sj((size_t)ns), sconds((size_t)ns * (size_t)dmax);
     std::vector<float> sr32;
     std::vector<double> sr64;
     if (h->f64) sr64.resize((size_t)ns);
     else sr32.resize((size_t)ns);
     for (int64_t s = 0; s < ns; ++s) {
-        const int64_t t = h->flow ? fsch.perm[(size_t)s] : (h->serial ? s : sch.perm[(size_t)s]);
+        const int64_t t = h->serial ? s : sch.perm[(size_t)s];
         int32_t *row = dmax > 0 ? &sconds[(size_t)s * (size_t)dmax] : nullptr;
         if (t < 0) { // padding slot
             su[(size_t)s] = -1;
@@ -784,14 +742,6 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     if (e == hipSuccess) e = upload((void **)&h->d_sj, sj, h->stream);
     if (e == hipSuccess) e = upload((void **)&h->d_sconds, sconds, h->stream);
     if (e == hipSuccess) e = h->f64 ? upload(&h->d_sr, sr64, h->stream) : upload(&h->d_sr, sr32, h->stream);
-    if (e == hipSuccess && h->flow) {
-        e = upload((void **)&h->d_seq_u, fsch.seq_u, h->stream);
-        if (e == hipSuccess) e = upload((void **)&h->d_seq_j, fsch.seq_j, h->stream);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_ver_u, (size_t)h->n_users * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_ver_j, (size_t)h->n_items * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_flow_err, 16);
-        if (e == hipSuccess) e = hipMemsetAsync(h->d_flow_err, 0, 16, h->stream);
-    }
     if (e == hipSuccess && contextual) {
         std::vector<int32_t> cp(ctx_ptr, ctx_ptr + n_ctx + 1), cc(ctx_conds, ctx_conds + ctx_ptr[n_ctx]);
         h->ctx_nnz = (int64_t)cc.size();
@@ -928,7 +878,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     }
     h->n = n;
     h->tuple_bytes = h->owner ? (ns + (int64_t)h->n_owners * 2 * owner_depth()) * (int64_t)owner_rec_bytes(owner_mask_words(h->model, h->n_conds))
-                              : ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + (h->flow ? 8 : 0)) + (h->chain ? 4 * (h->n_units + 1) : 0) + (h->arena_on ? 4 * ns : 0);
+                              : ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + 0) + (h->chain ? 4 * (h->n_units + 1) : 0) + (h->arena_on ? 4 * ns : 0);
     h->have_ratings = true;
     return CMI_OK;
 }
@@ -944,8 +894,8 @@ extern "C" int cmi_schedule_info(cmi_handle h, int64_t info[8]) {
     for (int w = 0; w < CMI_STATE_COUNT; ++w) sb += h->state_count[w] * (int64_t)esize(h);
     info[4] = sb;
     info[5] = h->tuple_bytes;
-    info[6] = h->owner ? (h->owner_hub_item ? 6 : 7) : h->flow ? 2 : (h->serial ? 1 : (h->two_lane ? 3 : (h->chain ? (h->chain_hub_item ? 4 : 5) : 0)));
-    info[7] = h->owner ? ((int64_t)h->n_owners | ((int64_t)h->n_team << 32)) : h->flow ? h->flow_blocks : (h->chain ? h->n_units : (h->d_blk_off ? (int64_t)h->blk_off.size() - 1 : 0));
+    info[6] = h->owner ? (h->owner_hub_item ? 6 : 7) : (h->serial ? 1 : (h->chain ? (h->chain_hub_item ? 4 : 5) : 0));
+    info[7] = h->owner ? ((int64_t)h->n_owners | ((int64_t)h->n_team << 32)) : (h->chain ? h->n_units : (h->d_blk_off ? (int64_t)h->blk_off.size() - 1 : 0));
     return CMI_OK;
 }
 
@@ -1111,23 +1061,8 @@ static hipError_t enqueue_levels(cmi_instance *h) {
         }
         return e;
     }
-    if (h->flow) {
-        FlowArgs fa{h->d_seq_u, h->d_seq_j, h->d_ver_u, h->d_ver_j, h->d_flow_err, h->n_chunks, getenv("CMI_FLOW_STATS") ? 1 : 0};
-        e = hipMemsetAsync(h->d_ver_u, 0, (size_t)h->n_users * 4, h->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(h->d_ver_j, 0, (size_t)h->n_items * 4, h->stream);
-        if (e == hipSuccess) e = launch_flow_f32(make_args<float>(h), fa, cfg, h->flow_blocks, h->stream);
-        if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);
-        return e;
-    }
     if (h->chain) {
         for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l) {
-            const int32_t run = h->tail_len.empty() ? 0 : h->tail_len[(size_t)l];
-            if (run > 0) {
-                e = h->f64 ? launch_chain_tail<double>(make_args<double>(h), cfg, h->chain_hub_item, h->d_unit_off, h->d_tail_off + l, run, h->slot_off[(size_t)l], h->stream)
-                           : launch_chain_tail<float>(make_args<float>(h), cfg, h->chain_hub_item, h->d_unit_off, h->d_tail_off + l, run, h->slot_off[(size_t)l], h->stream);
-                l += run - 1;
-                continue;
-            }
             const int64_t b = h->level_off[(size_t)l];
             const int cnt = (int)(h->level_off[(size_t)l + 1] - b);
             e = h->f64 ? launch_chain_level<double>(make_args<double>(h), cfg, h->chain_hub_item, h->d_unit_off, b, cnt, h->slot_off[(size_t)l], h->stream)
@@ -1177,44 +1112,7 @@ static int enqueue_epoch(cmi_instance *h, double lrate) {
         return CMI_OK;
     }
     // a graph of several hundred thousand kernel nodes is neither instantiable in reasonable time nor useful
-    const bool graph = h->use_graph && !h->serial && !h->flow && !h->owner && (h->n_tail > 0 ? h->n_launches : (int64_t)h->level_off.size() - 1) <= 65536;
-    if (graph && !h->graph_exec && h->two_lane) {
-        // explicit DAG: head(l) <- head(l-1), tail(l-2) ; tail(l) <- tail(l-1), head(l-1)
-        hipGraph_t g = nullptr;
-        CMI_HIP(h, hipGraphCreate(&g, 0));
-        const SgdArgs<float> a = make_args<float>(h);
-        LaunchCfg cfg{h->model, h->strict};
-        const int64_t n_levels = (int64_t)h->level_off.size() - 1;
-        std::vector<hipGraphNode_t> head((size_t)n_levels), tail((size_t)n_levels);
-        hipError_t e = hipSuccess;
-        for (int64_t l = 0; l < n_levels && e == hipSuccess; ++l) {
-            const int64_t b = h->level_off[(size_t)l], m = h->split_off[(size_t)l], en = h->level_off[(size_t)l + 1];
-            const int64_t s0 = h->slot_off[(size_t)l];
-            hipGraphNode_t deps[2];
-            size_t nd = 0;
-            if (l >= 1) deps[nd++] = head[(size_t)l - 1];
-            if (l >= 2) deps[nd++] = tail[(size_t)l - 2];
-            e = graph_add_level_fast_f32(g, &head[(size_t)l], deps, nd, a, cfg, b, (int)(m - b), s0);
-            if (e != hipSuccess) break;
-            nd = 0;
-            if (l >= 1) {
-                deps[nd++] = tail[(size_t)l - 1];
-                deps[nd++] = head[(size_t)l - 1];
-            }
-            e = graph_add_level_fast_f32(g, &tail[(size_t)l], deps, nd, a, cfg, m, (int)(en - m),
-                                         s0 + level_blocks_f32_fast(h->k, (int)(m - b)));
-        }
-        if (e == hipSuccess) {
-            hipGraphNode_t deps[2] = {head[(size_t)n_levels - 1], tail[(size_t)n_levels - 1]};
-            e = graph_add_reduce_loss(g, deps, 2, h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss);
-        }
-        if (e == hipSuccess) e = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
-        hipGraphDestroy(g);
-        if (e != hipSuccess) {
-            h->graph_exec = nullptr;
-            CMI_FAIL(h, CMI_E_HIP, "two-lane graph construction failed: %s", hipGetErrorString(e));
-        }
-    }
+    const bool graph = h->use_graph && !h->serial && !h->owner && (h->n_tail > 0 ? h->n_launches : (int64_t)h->level_off.size() - 1) <= 65536;
     if (graph && !h->graph_exec) {
         hipGraph_t g = nullptr;
         CMI_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -1259,19 +1157,16 @@ extern "C" int cmi_last_loss(cmi_handle h, double *loss_out) {
     CMI_HIP(h, hipSetDevice(h->device));
     CMI_HIP(h, hipMemcpyAsync(h->h_loss, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     int32_t flow_stat[4] = {0, 0, 0, 0};
-    if (h->flow || h->owner) CMI_HIP(h, hipMemcpyAsync(flow_stat, h->d_flow_err, 16, hipMemcpyDeviceToHost, h->stream));
+    if (h->owner) CMI_HIP(h, hipMemcpyAsync(flow_stat, h->d_flow_err, 16, hipMemcpyDeviceToHost, h->stream));
     CMI_HIP(h, hipStreamSynchronize(h->stream));
     const int32_t flow_err = flow_stat[0];
-    if (h->flow && getenv("CMI_FLOW_STATS"))
-        fprintf(stderr, "[cmi] flow: cumulative slow-path entries %d, polls spent waiting %d (of %lld wave-steps per epoch)\n",
-                flow_stat[1], flow_stat[2], (long long)h->n_chunks * 4);
     if (h->owner && h->n_team > 0 && getenv("CMI_OWNER_STATS"))
         fprintf(stderr, "[cmi] owner teams: %d; cumulative, busiest owner: compute wave found the ring empty %d times, loader found it full %d times\n",
                 h->n_team, flow_stat[1], flow_stat[2]);
     else if (h->owner && getenv("CMI_OWNER_STATS"))
         fprintf(stderr, "[cmi] owner: cumulative -- busiest owner (%lld tuples per epoch) found %d records not ready and polled %d times; all owners: %d "
                 "records not ready (of %lld tuples per epoch)\n", (long long)h->max_level, flow_stat[1], flow_stat[2], flow_stat[3], (long long)h->n);
-    if (flow_err) CMI_FAIL(h, CMI_E_HIP, "dataflow epoch stalled: a tuple waited past its bound for a predecessor (model state is invalid)");
+    if (flow_err) CMI_FAIL(h, CMI_E_HIP, "owner epoch stalled: a tuple waited past its bound for a predecessor (model state is invalid)");
     h->last_loss = *h->h_loss;
     *loss_out = h->last_loss;
     return CMI_OK;
@@ -1736,24 +1631,6 @@ extern "C" int cmi_owner_schedule(int64_t n, const int32_t *u, const int32_t *j,
     return CMI_OK;
 }
 
-extern "C" int cmi_flow_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
-                                 int32_t *perm, uint32_t *seq_u, uint32_t *seq_j, int64_t cap, int64_t *n_slots) {
-    if (n < 0 || (n > 0 && (!u || !j)) || n_users <= 0 || n_items <= 0 || !n_slots) return CMI_E_INVALID;
-    for (int64_t t = 0; t < n; ++t)
-        if (u[t] < 0 || u[t] >= n_users || j[t] < 0 || j[t] >= n_items) return CMI_E_INVALID;
-    FlowSchedule f;
-    if (!build_flow_schedule(n, u, j, n_users, n_items, f)) return CMI_E_UNSUPPORTED;
-    *n_slots = (int64_t)f.perm.size();
-    if (!perm) return CMI_OK;
-    if (cap < *n_slots || !seq_u || !seq_j) return CMI_E_INVALID;
-    for (size_t s = 0; s < f.perm.size(); ++s) {
-        perm[s] = f.perm[s];
-        seq_u[s] = f.seq_u[s];
-        seq_j[s] = f.seq_j[s];
-    }
-    return CMI_OK;
-}
-
 // host-only views of the two schedule post-passes (tests): narrow runs of a level schedule, conflict-free CRS blocks
 extern "C" int cmi_narrow_runs(int64_t n_levels, const int64_t *level_off, int64_t max_tuples, int64_t min_levels,
                                int32_t *run_len, int64_t *n_launches) {
@@ -1777,22 +1654,5 @@ extern "C" int cmi_conflict_free_blocks(int64_t n, const int32_t *u, const int32
     if (!off) return CMI_OK;
     if (off_cap < (int64_t)o.size()) return CMI_E_INVALID;
     std::copy(o.begin(), o.end(), off);
-    return CMI_OK;
-}
-
-extern "C" int cmi_split_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
-                                  int32_t *perm, int64_t *level_off, int64_t *split, int64_t level_cap,
-                                  int64_t *n_levels) {
-    if (n < 0 || (n > 0 && (!u || !j)) || n_users <= 0 || n_items <= 0 || !n_levels) return CMI_E_INVALID;
-    for (int64_t t = 0; t < n; ++t)
-        if (u[t] < 0 || u[t] >= n_users || j[t] < 0 || j[t] >= n_items) return CMI_E_INVALID;
-    SplitSchedule ss;
-    if (!build_split_schedule(n, u, j, n_users, n_items, ss)) return CMI_E_UNSUPPORTED;
-    *n_levels = ss.n_levels();
-    if (!perm) return CMI_OK;
-    if (level_cap < ss.n_levels() + 1 || !level_off || !split) return CMI_E_INVALID;
-    for (size_t i = 0; i < ss.level_off.size(); ++i) level_off[i] = ss.level_off[i];
-    for (size_t i = 0; i < ss.split.size(); ++i) split[i] = ss.split[i];
-    for (int64_t s = 0; s < n; ++s) perm[s] = ss.perm[(size_t)s];
     return CMI_OK;
 }

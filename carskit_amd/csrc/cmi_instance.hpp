@@ -15,8 +15,7 @@
 struct cmi_instance {
     int model = 0, k = 0, n_users = 0, n_items = 0, n_conds = 0, device = 0;
     unsigned flags = 0;
-    bool f64 = false, serial = false, strict = false, use_graph = true, fast = false, small = false, want_flow = false, flow = false,
-         want_two_lane = false, two_lane = false;
+    bool f64 = false, serial = false, strict = false, use_graph = true, fast = false, small = false;
     bool chain = false, chain_hub_item = true; // hub-chain level schedule: level_off holds UNIT indices, d_unit_off the units
     int32_t *d_unit_off = nullptr;
     int64_t n_units = 0;
@@ -35,7 +34,6 @@ struct cmi_instance {
     int64_t *d_own_off = nullptr;
     void *d_tagged = nullptr;
     int64_t own_stride = 0;
-    std::vector<int64_t> split_off; // two-lane schedule: first tail position of every level
     std::string err;
     std::string sched_note; // why a slower schedule than the data calls for is running (cmi_schedule_note); empty = nothing to say
     hipStream_t stream = nullptr;
@@ -47,10 +45,7 @@ struct cmi_instance {
     int32_t n_ctx = 0;
     int32_t *d_su = nullptr, *d_sj = nullptr, *d_sconds = nullptr, *d_ctx_ptr = nullptr, *d_ctx_conds = nullptr;
     void *d_sr = nullptr;
-    uint32_t *d_seq_u = nullptr, *d_seq_j = nullptr, *d_ver_u = nullptr, *d_ver_j = nullptr;
-    int32_t *d_flow_err = nullptr;
-    int64_t n_chunks = 0;
-    int flow_blocks = 0;
+    int32_t *d_flow_err = nullptr; // owner epoch: stall flag + counters
     int64_t ctx_nnz = 0;
     std::vector<int64_t> level_off, slot_off;
     int64_t n_launches = 0, n_tail = 0; // launches per epoch; levels that live inside narrow runs

@@ -90,152 +90,6 @@ bool build_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t
     return true;
 }
 
-// Dataflow schedule.  Same levels, but consumed by ONE persistent kernel per epoch instead of one launch
-// per level: a tuple may start as soon as ITS OWN two predecessors (previous tuple of its user, previous
-// tuple of its item) have retired, which the kernel checks through per-row version counters
-// (seq_u / seq_j = the counter value the tuple must observe).  Two host-side measures keep waiting rare and
-// the protocol deadlock-free:
-//   * every level is padded to a multiple of 16 slots (one workgroup iteration = 16 tuples), so tuples
-//     that are processed together never depend on each other;
-//   * inside a level tuples are sorted by the schedule position of their later predecessor, so a tuple
-//     at relative offset x of level L+1 has its predecessor near relative offset x of level L or earlier:
-//     the dependency distance stays about one whole level, far beyond the window of tuples in flight.
-// Positions are handed out to workgroups in increasing order, so the oldest unfinished slot can always
-// run (its predecessors have smaller positions): no cycle, no deadlock.
-bool build_flow_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
-                         FlowSchedule &out) {
-    out = FlowSchedule();
-    if (n <= 0) return true;
-    if (n >= (int64_t)1 << 30) return false;
-    std::vector<int32_t> last_lu((size_t)n_users, 0), last_lj((size_t)n_items, 0);   // level of last tuple
-    std::vector<int32_t> last_tu((size_t)n_users, -1), last_tj((size_t)n_items, -1);  // index of last tuple
-    std::vector<uint32_t> cnt_u((size_t)n_users, 0), cnt_j((size_t)n_items, 0);
-    std::vector<int32_t> level((size_t)n), pred_u((size_t)n), pred_j((size_t)n);
-    std::vector<uint32_t> sq_u((size_t)n), sq_j((size_t)n);
-    int32_t n_levels = 0;
-    for (int64_t t = 0; t < n; ++t) {
-        const size_t uu = (size_t)u[t], jj = (size_t)j[t];
-        const int32_t l = std::max(last_lu[uu], last_lj[jj]) + 1;
-        last_lu[uu] = last_lj[jj] = l;
-        level[(size_t)t] = l;
-        pred_u[(size_t)t] = last_tu[uu];
-        pred_j[(size_t)t] = last_tj[jj];
-        last_tu[uu] = last_tj[jj] = (int32_t)t;
-        sq_u[(size_t)t] = cnt_u[uu]++;
-        sq_j[(size_t)t] = cnt_j[jj]++;
-        n_levels = std::max(n_levels, l);
-    }
-    std::vector<int64_t> off((size_t)n_levels + 1, 0);
-    for (int64_t t = 0; t < n; ++t) off[(size_t)level[(size_t)t]]++;
-    for (int32_t l = 1; l <= n_levels; ++l) {
-        out.max_level = std::max(out.max_level, off[(size_t)l]);
-        off[(size_t)l] += off[(size_t)l - 1];
-    }
-    std::vector<int32_t> by_level((size_t)n);
-    {
-        std::vector<int64_t> cur(off.begin(), off.end() - 1);
-        for (int64_t t = 0; t < n; ++t) by_level[(size_t)cur[(size_t)level[(size_t)t] - 1]++] = (int32_t)t;
-    }
-    std::vector<int32_t> pos_of((size_t)n, -1); // final padded position of each tuple
-    std::vector<std::pair<int32_t, int32_t>> keyed;
-    out.perm.reserve((size_t)n + (size_t)n_levels * 16);
-    for (int32_t l = 0; l < n_levels; ++l) {
-        const int64_t b = off[(size_t)l], e = off[(size_t)l + 1];
-        keyed.clear();
-        for (int64_t q = b; q < e; ++q) {
-            const int32_t t = by_level[(size_t)q];
-            const int32_t pu = pred_u[(size_t)t] >= 0 ? pos_of[(size_t)pred_u[(size_t)t]] : -1;
-            const int32_t pj = pred_j[(size_t)t] >= 0 ? pos_of[(size_t)pred_j[(size_t)t]] : -1;
-            keyed.emplace_back(std::max(pu, pj), t);
-        }
-        std::sort(keyed.begin(), keyed.end());
-        for (auto &kt : keyed) {
-            pos_of[(size_t)kt.second] = (int32_t)out.perm.size();
-            out.perm.push_back(kt.second);
-        }
-        while (out.perm.size() % 16) out.perm.push_back(-1);
-    }
-    out.n_levels = n_levels;
-    out.seq_u.assign(out.perm.size(), 0);
-    out.seq_j.assign(out.perm.size(), 0);
-    for (size_t p = 0; p < out.perm.size(); ++p)
-        if (out.perm[p] >= 0) {
-            out.seq_u[p] = sq_u[(size_t)out.perm[p]];
-            out.seq_j[p] = sq_j[(size_t)out.perm[p]];
-        }
-    return true;
-}
-
-// Two-lane level schedule.  Same levels as build_level_schedule.  Inside a level the tuples are sorted by the
-// schedule position of their later predecessor (free: tuples of a level commute).  The level is then cut at
-// split[l]: the HEAD holds tuples whose predecessors all lie before split[l-1] (i.e. in levels <= l-2 or in the
-// head of level l-1), at most half of the level; the TAIL holds the rest.  Dependencies between kernels:
-//     head(l) <- head(l-1), tail(l-2)            tail(l) <- tail(l-1), head(l-1)
-// so head(l) never waits for tail(l-1): the two run side by side.  They cannot conflict: a tuple of head(l)
-// sharing a user or item with a tuple s of tail(l-1) would have s (or something after it) as predecessor,
-// i.e. a predecessor position >= split[l-1], contradicting its membership in the head.  The result is the
-// same, bit for bit, as running the levels one after another.
-bool build_split_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
-                          SplitSchedule &out) {
-    out = SplitSchedule();
-    out.level_off.push_back(0);
-    if (n <= 0) return true;
-    if (n >= (int64_t)1 << 31) return false;
-    std::vector<int32_t> last_lu((size_t)n_users, 0), last_lj((size_t)n_items, 0);
-    std::vector<int32_t> last_tu((size_t)n_users, -1), last_tj((size_t)n_items, -1);
-    std::vector<int32_t> level((size_t)n), pred_u((size_t)n), pred_j((size_t)n);
-    int32_t n_levels = 0;
-    for (int64_t t = 0; t < n; ++t) {
-        const size_t uu = (size_t)u[t], jj = (size_t)j[t];
-        const int32_t l = std::max(last_lu[uu], last_lj[jj]) + 1;
-        last_lu[uu] = last_lj[jj] = l;
-        level[(size_t)t] = l;
-        pred_u[(size_t)t] = last_tu[uu];
-        pred_j[(size_t)t] = last_tj[jj];
-        last_tu[uu] = last_tj[jj] = (int32_t)t;
-        n_levels = std::max(n_levels, l);
-    }
-    std::vector<int64_t> off((size_t)n_levels + 1, 0);
-    for (int64_t t = 0; t < n; ++t) off[(size_t)level[(size_t)t]]++;
-    for (int32_t l = 1; l <= n_levels; ++l) {
-        out.max_level = std::max(out.max_level, off[(size_t)l]);
-        off[(size_t)l] += off[(size_t)l - 1];
-    }
-    std::vector<int32_t> by_level((size_t)n);
-    {
-        std::vector<int64_t> cur(off.begin(), off.end() - 1);
-        for (int64_t t = 0; t < n; ++t) by_level[(size_t)cur[(size_t)level[(size_t)t] - 1]++] = (int32_t)t;
-    }
-    std::vector<int32_t> pos_of((size_t)n, -1);
-    std::vector<std::pair<int32_t, int32_t>> keyed;
-    out.perm.resize((size_t)n);
-    out.level_off.assign(off.begin(), off.end());
-    out.split.assign((size_t)n_levels, 0);
-    int64_t prev_split = 0; // split of the previous level (positions < prev_split are "early")
-    for (int32_t l = 0; l < n_levels; ++l) {
-        const int64_t b = off[(size_t)l], e = off[(size_t)l + 1];
-        keyed.clear();
-        for (int64_t q = b; q < e; ++q) {
-            const int32_t t = by_level[(size_t)q];
-            const int32_t pu = pred_u[(size_t)t] >= 0 ? pos_of[(size_t)pred_u[(size_t)t]] : -1;
-            const int32_t pj = pred_j[(size_t)t] >= 0 ? pos_of[(size_t)pred_j[(size_t)t]] : -1;
-            keyed.emplace_back(std::max(pu, pj), t);
-        }
-        std::sort(keyed.begin(), keyed.end());
-        int64_t allowed = 0;
-        for (size_t q = 0; q < keyed.size(); ++q) {
-            pos_of[(size_t)keyed[q].second] = (int32_t)(b + (int64_t)q);
-            out.perm[(size_t)(b + (int64_t)q)] = keyed[q].second;
-            if ((int64_t)keyed[q].first < prev_split) allowed = (int64_t)q + 1; // sorted by key: a prefix
-        }
-        const int64_t half = (e - b + 1) / 2;
-        prev_split = b + std::min(allowed, half);
-        out.split[(size_t)l] = prev_split;
-    }
-    return true;
-}
-
-
 int64_t build_narrow_runs(const std::vector<int64_t> &level_off, int64_t max_tuples, int64_t min_levels, std::vector<int32_t> &run_len) {
     const int64_t n_levels = (int64_t)level_off.size() - 1;
     run_len.assign((size_t)(n_levels > 0 ? n_levels : 0), 0);

@@ -15,30 +15,6 @@ struct LevelSchedule {
     int64_t n_levels() const { return (int64_t)level_off.size() - 1; }
 };
 
-// Dataflow variant of the same schedule (see build_flow_schedule in level_schedule.cpp).
-struct FlowSchedule {
-    std::vector<int32_t> perm;   // padded schedule position -> CRS tuple index, -1 = padding slot
-    std::vector<uint32_t> seq_u; // per position: how many earlier tuples of the epoch share its user
-    std::vector<uint32_t> seq_j; // ... its item
-    int64_t n_levels = 0, max_level = 0;
-    int64_t n_chunks() const { return (int64_t)perm.size() / 16; }
-};
-bool build_flow_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
-                         FlowSchedule &out);
-
-// Two-lane variant of the level schedule (see build_split_schedule): every level is cut into a head and a tail so
-// that the head of level l depends only on the head of level l-1 and on levels <= l-2.  Head(l) and Tail(l-1) can
-// then run CONCURRENTLY (two kernels in flight), which hides each launch's ramp-up and drain.
-struct SplitSchedule {
-    std::vector<int32_t> perm;      // schedule position -> CRS tuple index
-    std::vector<int64_t> level_off; // n_levels+1
-    std::vector<int64_t> split;     // n_levels: first position of the tail of each level (level_off[l] <= split[l] <= level_off[l+1])
-    int64_t max_level = 0;
-    int64_t n_levels() const { return (int64_t)level_off.size() - 1; }
-};
-bool build_split_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
-                          SplitSchedule &out);
-
 // false if n does not fit the int32 permutation
 bool build_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
                           int within_level_order, LevelSchedule &out);

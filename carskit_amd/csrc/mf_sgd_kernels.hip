@@ -270,8 +270,6 @@ __global__ __launch_bounds__(256) void sgd_level_fast_f32(SgdArgs<float> a, int6
 }
 
 // ---------------------------------------------------------------------------------------------
-// dataflow path: one persistent launch per epoch, levels overlap (fp32 state, K = 64*VPL)
-// ---------------------------------------------------------------------------------------------
 // small-k fast path (fp32 state, any k <= 64 that is not 64: the reference's default num.factors is 10)
 // ---------------------------------------------------------------------------------------------
 // LPT lanes per tuple (4, 8 or 16 -> 16, 8 or 4 tuples per wave64), lane l owns factors l, l+LPT, l+2*LPT, l+3*LPT
@@ -412,244 +410,6 @@ __global__ __launch_bounds__(256) void sgd_level_small_f32(SgdArgs<float> a, int
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-//
-// Same arithmetic and lane layout as sgd_level_fast_f32, but instead of a kernel boundary after every
-// dependency level each tuple waits for exactly its own two predecessors: ver_u[u] / ver_j[j] count the
-// tuples of that user / item retired so far in this epoch, and the tuple at schedule position p may run
-// once they equal seq_u[p] / seq_j[p].  Because model rows now travel between workgroups (and XCDs, whose
-// L2s are not coherent with each other) INSIDE a launch, every access to model state is device-coherent:
-//   * row loads/stores are `buffer_load/store_dwordx4 ... sc0 sc1` (L1 bypass + write-through),
-//   * the producer drains its stores (`s_waitcnt vmcnt(0)`) before publishing the new version with a
-//     relaxed agent-scope store; the consumer polls the version with relaxed agent-scope loads and only
-//     then issues its row loads.
-// The tuple stream itself is read-only and uses plain loads.  Waves never synchronise with each other
-// (no __syncthreads): a wave owns 4 tuples of one level per step and accumulates its loss in registers.
-// Every spin is bounded; on overflow the kernel raises *error and carries on (the host reports it).
-
-#define CMI_FLOW_SPIN_LIMIT (1u << 22)
-
-// One 16-lane group's view of a schedule slot.
-struct FlowTuple {
-    int uu, jj, cond;
-    float rr;
-    uint32_t want_u, want_j;
-    bool live;
-};
-
-template <int MODEL>
-__device__ __forceinline__ FlowTuple flow_load_tuple(const SgdArgs<float> &a, const FlowArgs &fa, int64_t chunk,
-                                                     int gib, int l16) {
-    FlowTuple t;
-    t.uu = -1;
-    t.jj = 0;
-    t.cond = -1;
-    t.rr = 0.f;
-    t.want_u = t.want_j = 0;
-    t.live = false;
-    if (chunk < fa.n_chunks) {
-        // every field is loaded unconditionally (padding slots hold valid dummies): no load depends on another,
-        // so the whole tuple costs one round trip and can be issued two steps ahead
-        const int64_t pos = chunk * 16 + gib;
-        t.uu = a.su[pos];
-        t.jj = a.sj[pos];
-        t.rr = a.sr[pos];
-        t.want_u = fa.seq_u[pos];
-        t.want_j = fa.seq_j[pos];
-        if (Traits<MODEL>::has_ctx && l16 < a.dmax) t.cond = a.sconds[pos * a.dmax + l16];
-        t.live = t.uu >= 0;
-    }
-    return t;
-}
-
-__device__ __forceinline__ void flow_publish(const FlowArgs &fa, const FlowTuple &t, int l16) {
-    if (t.live && l16 == 0) {
-        __hip_atomic_store(fa.ver_u + t.uu, t.want_u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(fa.ver_j + t.jj, t.want_j + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// Software-pipelined wave loop.  While the rows of step i are in flight the wave has already issued the version
-// poll of step i+1 and the tuple loads of step i+2, and the versions of step i-1 are published only once the
-// rows of step i have arrived: vector memory operations of a wave complete in issue order, so by then the
-// write-through stores of step i-1 (issued before those row loads) are done -- no separate store drain.
-// A step therefore costs one memory round trip (the row gather) instead of four (tuple, poll, rows, drain).
-template <int MODEL, int VPL>
-__global__ __launch_bounds__(256) void sgd_flow_f32(SgdArgs<float> a, FlowArgs fa) {
-    using M = Traits<MODEL>;
-    static_assert(MODEL != CAMF_C, "CAMF_C has no level schedule (shared condBias)");
-    constexpr int K = 64 * VPL;
-    const int tid = threadIdx.x;
-    const int l16 = tid & 15;
-    const int gib = tid >> 4;
-    const int wave = tid >> 6;
-    double wloss = 0.0; // this wave's loss over all its tuples (fixed order: static chunk assignment)
-    const __amdgpu_buffer_rsrc_t rsP = table_rsrc(a.P), rsQ = table_rsrc(a.Q);
-
-    const HParams hp = *a.hp;
-    const float lr = (float)hp.lr, regU = (float)hp.regU, regI = (float)hp.regI, regB = (float)hp.regB,
-                regC = (float)hp.regC, gm = (float)hp.gm;
-    const int64_t G = gridDim.x;
-
-    FlowTuple cur = flow_load_tuple<MODEL>(a, fa, blockIdx.x, gib, l16);
-    FlowTuple nxt = flow_load_tuple<MODEL>(a, fa, blockIdx.x + G, gib, l16);
-    FlowTuple pend; // retired but not yet published
-    pend.live = false;
-    pend.uu = pend.jj = 0;
-    pend.want_u = pend.want_j = 0;
-    // version poll of `cur`, issued one step ahead
-    uint32_t vu = 0, vj = 0;
-    if (cur.live) {
-        vu = __hip_atomic_load(fa.ver_u + cur.uu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        vj = __hip_atomic_load(fa.ver_j + cur.jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
-    for (int64_t chunk = blockIdx.x; chunk < fa.n_chunks; chunk += G) {
-        // ---- confirm the predecessors of `cur` have retired (normally the early poll already says so)
-        bool ready = !cur.live || ((vu == cur.want_u) && (vj == cur.want_j));
-        if (!__all(ready)) {
-            // slow path: first make our own finished work visible (someone may be waiting for it), then spin
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            flow_publish(fa, pend, l16);
-            pend.live = false;
-            unsigned spins = 0;
-            if (fa.stats && (tid & 63) == 0) atomicAdd(fa.error + 1, 1); // statistics: slow-path entries
-            while (true) {
-                if (!ready) {
-                    vu = __hip_atomic_load(fa.ver_u + cur.uu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vj = __hip_atomic_load(fa.ver_j + cur.jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ready = (vu == cur.want_u) && (vj == cur.want_j);
-                }
-                if (__all(ready)) break;
-                if (++spins > CMI_FLOW_SPIN_LIMIT) {
-                    if ((tid & 63) == 0) atomicExch(fa.error, 1);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (fa.stats && (tid & 63) == 0) atomicAdd(fa.error + 2, (int)spins); // statistics: polls spent waiting
-        }
-
-        // ---- gather the rows of `cur`
-        const uint32_t poff = (uint32_t)(cur.live ? cur.uu : 0) * (K * 4) + l16 * 16;
-        const uint32_t qoff = (uint32_t)cur.jj * (K * 4) + l16 * 16;
-        f32x4 p[VPL], q[VPL];
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) p[v] = ld_row_coherent(rsP, poff + v * 256);
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) q[v] = ld_row_coherent(rsQ, qoff + v * 256);
-        float bu = 0.f, bj = 0.f, bic = 0.f, buc = 0.f;
-        float *pic = nullptr, *puc = nullptr;
-        if (cur.live) {
-            if (M::has_bu) bu = ld_f32_coherent(a.userBias + cur.uu);
-            if (M::has_bj) bj = ld_f32_coherent(a.itemBias + cur.jj);
-            if (cur.cond >= 0) {
-                if (M::has_ic) {
-                    pic = a.icBias + (size_t)cur.jj * a.n_conds + cur.cond;
-                    bic = ld_f32_coherent(pic);
-                }
-                if (M::has_uc) {
-                    puc = a.ucBias + (size_t)cur.uu * a.n_conds + cur.cond;
-                    buc = ld_f32_coherent(puc);
-                }
-            }
-        }
-        // ---- run ahead: poll the versions of `nxt`, fetch the tuple after it
-        uint32_t nvu = 0, nvj = 0;
-        if (nxt.live) {
-            nvu = __hip_atomic_load(fa.ver_u + nxt.uu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            nvj = __hip_atomic_load(fa.ver_j + nxt.jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const FlowTuple nxt2 = flow_load_tuple<MODEL>(a, fa, chunk + 2 * G, gib, l16);
-
-        // ---- rows of `cur` have arrived => the stores of the previous step are complete: publish it.
-        // The empty asm consumes the first row register (placing the compiler's wait before it) and is a
-        // compiler barrier for the version stores that follow.
-        asm volatile("" : "+v"(p[0])::"memory");
-        flow_publish(fa, pend, l16);
-
-        double gloss = 0.0;
-        if (cur.live) {
-            float part = 0.f;
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) {
-                part += p[v].x * q[v].x;
-                part += p[v].y * q[v].y;
-                part += p[v].z * q[v].z;
-                part += p[v].w * q[v].w;
-            }
-            const float dot = row_sum16(part);
-
-            float pred = gm;
-            if (M::has_bu) pred += bu;
-            if (M::has_bj) pred += bj;
-            pred += dot;
-            if (Traits<MODEL>::has_ctx) {
-                float term = 0.f;
-                if (M::has_ic && M::has_uc) term = bic + buc;
-                else if (M::has_ic) term = bic;
-                else if (M::has_uc) term = buc;
-                pred += row_sum16(term);
-            }
-            const float e = cur.rr - pred;
-
-            if (l16 == 0) {
-                if (M::has_bu) st_f32_coherent(a.userBias + cur.uu, bu + lr * (e - regB * bu));
-                if (M::has_bj) st_f32_coherent(a.itemBias + cur.jj, bj + lr * (e - regB * bj));
-            }
-            float ctx_loss = 0.f;
-            if (cur.cond >= 0) {
-                if (M::has_ic) {
-                    st_f32_coherent(pic, bic + lr * (e - regC * bic));
-                    ctx_loss += bic * bic;
-                }
-                if (M::has_uc) {
-                    st_f32_coherent(puc, buc + lr * (e - regC * buc));
-                    ctx_loss += buc * buc;
-                }
-            }
-
-            float lsum = 0.f;
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) {
-                f32x4 pn, qn;
-#define CMI_UPD(c)                                                                                       \
-    pn.c = p[v].c + lr * (e * q[v].c - regU * p[v].c);                                                   \
-    qn.c = q[v].c + lr * (e * p[v].c - regI * q[v].c);                                                   \
-    lsum += (regU * p[v].c) * p[v].c + (regI * q[v].c) * q[v].c;
-                CMI_UPD(x) CMI_UPD(y) CMI_UPD(z) CMI_UPD(w)
-#undef CMI_UPD
-                st_row_coherent(rsP, poff + v * 256, pn);
-                st_row_coherent(rsQ, qoff + v * 256, qn);
-            }
-
-            const float reg_loss = row_sum16(lsum);
-            const float ctx_sum = (Traits<MODEL>::has_ctx) ? row_sum16(ctx_loss) : 0.f;
-            if (l16 == 0) {
-                double l = (double)e * (double)e;
-                if (M::has_bu) l += (double)regB * bu * bu;
-                if (M::has_bj) l += (double)regB * bj * bj;
-                if (Traits<MODEL>::has_ctx) l += (double)regC * ctx_sum;
-                gloss = l + (double)reg_loss;
-            }
-        }
-        // the four tuple losses of this wave, fixed order
-        const double g0 = __shfl(gloss, 0, 64), g1 = __shfl(gloss, 16, 64), g2 = __shfl(gloss, 32, 64),
-                     g3 = __shfl(gloss, 48, 64);
-        wloss += ((g0 + g1) + g2) + g3;
-
-        pend = cur;
-        cur = nxt;
-        nxt = nxt2;
-        vu = nvu;
-        vj = nvj;
-    }
-    // retire the last step
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    flow_publish(fa, pend, l16);
-    if ((tid & 63) == 0) a.loss_part[(int64_t)blockIdx.x * 4 + wave] = wloss;
-}
 
 // ---------------------------------------------------------------------------------------------
 // generic path: one wave64 per tuple, any k, T in {float,double}, optional strict order
@@ -1407,55 +1167,6 @@ static void *fast_kernel_ptr_model(int k) {
     }
 }
 
-hipError_t graph_add_level_fast_f32(hipGraph_t g, hipGraphNode_t *node, const hipGraphNode_t *deps, size_t ndeps,
-                                    const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,
-                                    int64_t slot0) {
-    if (count <= 0) return hipGraphAddEmptyNode(node, g, deps, ndeps);
-    void *fn = nullptr;
-    switch (cfg.model) {
-    case BIASEDMF: fn = fast_kernel_ptr_model<BIASEDMF>(a.k); break;
-    case PMF: fn = fast_kernel_ptr_model<PMF>(a.k); break;
-    case CAMF_CI: fn = fast_kernel_ptr_model<CAMF_CI>(a.k); break;
-    case CAMF_CU: fn = fast_kernel_ptr_model<CAMF_CU>(a.k); break;
-    case CAMF_CUCI: fn = fast_kernel_ptr_model<CAMF_CUCI>(a.k); break;
-    }
-    if (!fn) return hipErrorInvalidValue;
-    SgdArgs<float> args = a;
-    void *params[] = {&args, &begin, &count, &slot0};
-    hipKernelNodeParams kp;
-    memset(&kp, 0, sizeof kp);
-    kp.func = fn;
-    kp.gridDim = dim3((unsigned)level_blocks_f32_fast(a.k, count));
-    kp.blockDim = dim3(256);
-    kp.sharedMemBytes = 0;
-    kp.kernelParams = params;
-    kp.extra = nullptr;
-    return hipGraphAddKernelNode(node, g, deps, ndeps, &kp);
-}
-
-hipError_t graph_add_reduce_loss(hipGraph_t g, const hipGraphNode_t *deps, size_t ndeps, const double *loss_part,
-                                 int64_t n_slots, double *scratch, double *loss_out) {
-    int nblk = (int)((n_slots + 4095) / 4096);
-    if (nblk < 1) nblk = 1;
-    if (nblk > 256) nblk = 256;
-    hipGraphNode_t n1, n2;
-    hipKernelNodeParams kp;
-    memset(&kp, 0, sizeof kp);
-    void *p1[] = {&loss_part, &n_slots, &scratch};
-    kp.func = (void *)reduce_loss_stage1;
-    kp.gridDim = dim3(nblk);
-    kp.blockDim = dim3(256);
-    kp.kernelParams = p1;
-    hipError_t e = hipGraphAddKernelNode(&n1, g, deps, ndeps, &kp);
-    if (e != hipSuccess) return e;
-    const double *sc = scratch;
-    void *p2[] = {&sc, &nblk, &loss_out};
-    kp.func = (void *)reduce_loss_stage2;
-    kp.gridDim = dim3(1);
-    kp.kernelParams = p2;
-    return hipGraphAddKernelNode(&n2, g, &n1, 1, &kp);
-}
-
 hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,
                                  int64_t slot0, hipStream_t s) {
     if (count <= 0) return hipSuccess;
@@ -1469,53 +1180,6 @@ hipError_t launch_level_fast_f32(const SgdArgs<float> &a, const LaunchCfg &cfg, 
     return hipErrorInvalidValue;
 }
 
-
-template <int MODEL>
-static hipError_t launch_flow_model(const SgdArgs<float> &a, const FlowArgs &fa, int grid_blocks, hipStream_t s) {
-    const dim3 grid(grid_blocks), block(256);
-    switch (a.k) {
-    case 64: hipLaunchKernelGGL((sgd_flow_f32<MODEL, 1>), grid, block, 0, s, a, fa); break;
-    case 128: hipLaunchKernelGGL((sgd_flow_f32<MODEL, 2>), grid, block, 0, s, a, fa); break;
-    case 256: hipLaunchKernelGGL((sgd_flow_f32<MODEL, 4>), grid, block, 0, s, a, fa); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_flow_f32(const SgdArgs<float> &a, const FlowArgs &fa, const LaunchCfg &cfg, int grid_blocks,
-                           hipStream_t s) {
-    if (fa.n_chunks <= 0) return hipSuccess;
-    switch (cfg.model) {
-    case BIASEDMF: return launch_flow_model<BIASEDMF>(a, fa, grid_blocks, s);
-    case PMF: return launch_flow_model<PMF>(a, fa, grid_blocks, s);
-    case CAMF_CI: return launch_flow_model<CAMF_CI>(a, fa, grid_blocks, s);
-    case CAMF_CU: return launch_flow_model<CAMF_CU>(a, fa, grid_blocks, s);
-    case CAMF_CUCI: return launch_flow_model<CAMF_CUCI>(a, fa, grid_blocks, s);
-    }
-    return hipErrorInvalidValue;
-}
-
-// The flow kernel needs every workgroup co-resident (waiting workgroups must not keep runnable ones off the
-// chip).  Size the grid from the occupancy query with a safety margin (MI355X_MICROARCH.md: the API can
-// over-report by one block per CU for SGPR-heavy kernels) and never above 4 blocks per CU: 4 x 16 tuples x
-// 256 CUs x ~2 KB in flight already exceeds what the HBM latency-bandwidth product needs.
-int flow_grid_blocks(int device, int k) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-    int per_cu = 0;
-    hipError_t e = hipErrorInvalidValue;
-    if (k == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_flow_f32<CAMF_CUCI, 1>, 256, 0);
-    if (k == 128) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_flow_f32<CAMF_CUCI, 2>, 256, 0);
-    if (k == 256) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgd_flow_f32<CAMF_CUCI, 4>, 256, 0);
-    if (e != hipSuccess || per_cu < 2) return 0;
-    int use = per_cu - 1;
-    if (use > 4) use = 4;
-    if (const char *env = getenv("CMI_FLOW_BLOCKS_PER_CU")) {
-        const int v = atoi(env);
-        if (v >= 1 && v < per_cu) use = v;
-    }
-    return use * prop.multiProcessorCount;
-}
 
 template <typename T, int MODEL>
 static hipError_t launch_generic_model(const SgdArgs<T> &a, const LaunchCfg &cfg, int64_t begin, int count,

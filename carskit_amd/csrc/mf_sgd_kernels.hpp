@@ -83,12 +83,6 @@ hipError_t launch_level_generic(const SgdArgs<T> &a, const LaunchCfg &cfg, int64
                                 hipStream_t s);
 // Explicit hipGraph nodes (the two-lane schedule needs a DAG, not a linear capture): one fast-path level segment,
 // and the two-stage loss reduction.  count == 0 adds an empty node so dependency chains stay uniform.
-hipError_t graph_add_level_fast_f32(hipGraph_t g, hipGraphNode_t *node, const hipGraphNode_t *deps, size_t ndeps,
-                                    const SgdArgs<float> &a, const LaunchCfg &cfg, int64_t begin, int count,
-                                    int64_t slot0);
-hipError_t graph_add_reduce_loss(hipGraph_t g, const hipGraphNode_t *deps, size_t ndeps, const double *loss_part,
-                                 int64_t n_slots, double *scratch, double *loss_out);
-
 // Hub-chain level kernel (chain_kernels.hip): one 16-lane group walks a unit of the chain schedule with the hub row on chip.
 // units [ubegin, ubegin+count) of unit_off (n_units+1 device offsets into the tuple stream) form one level.
 bool has_chain_path(int model, int k, int dmax, int n_conds, bool f64, bool strict);
@@ -97,25 +91,9 @@ int chain_groups_per_block(int k, int dmax, bool f64);   // units per 256-thread
 int chain_level_blocks(int k, int dmax, bool f64, int count);
 // a run of n_levels narrow chain levels (<= 64 units each) walked by ONE workgroup; lvl_off = device offsets (unit indices) of the
 // run's levels, n_levels + 1 entries
-bool has_chain_tail(int model, int k, int n_conds, int dmax, bool f64);
-template <typename T>
-hipError_t launch_chain_tail(const SgdArgs<T> &a, const LaunchCfg &cfg, bool hub_is_item, const int32_t *unit_off, const int64_t *lvl_off,
-                             int n_levels, int64_t slot, hipStream_t s);
 template <typename T>
 hipError_t launch_chain_level(const SgdArgs<T> &a, const LaunchCfg &cfg, bool hub_is_item, const int32_t *unit_off, int64_t ubegin,
                               int count, int64_t slot0, hipStream_t s);
-
-// Dataflow epoch: ONE persistent launch walks the padded schedule; tuples wait on per-row version counters.
-struct FlowArgs {
-    const uint32_t *seq_u, *seq_j; // per padded position: version the tuple must observe
-    uint32_t *ver_u, *ver_j;       // per user / per item: tuples retired this epoch (zeroed before the launch)
-    int32_t *error;                // set to 1 if a wait exceeded its bound (schedule stalled)
-    int64_t n_chunks;              // padded positions / 16
-    int32_t stats;                 // CMI_FLOW_STATS: count slow-path entries / waiting polls in error[1], error[2]
-};
-int flow_grid_blocks(int device, int k);       // fully co-resident grid size for the flow kernel (0 = unsupported)
-hipError_t launch_flow_f32(const SgdArgs<float> &a, const FlowArgs &fa, const LaunchCfg &cfg, int grid_blocks,
-                           hipStream_t s);
 
 // one wavefront walks tuples [0, n) in order (the reference's sequential semantics); loss -> loss_out[0] (already *0.5)
 template <typename T>

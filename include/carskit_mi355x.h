@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define CMI_ABI_VERSION 2 /* 2: round-2/3 additions (models 6-9, states 7-10, owner/chain flags, mean merge, cmi_group_*) */
+#define CMI_ABI_VERSION 3 /* 3: round 4 -- cmi_comm_*, cmi_fm_comm_*, group resident evaluation, FM layout / timing, ranking host
+                             clock; REMOVED: CMI_FLAG_SCHED_FLOW, CMI_FLAG_TWO_LANE, cmi_flow_schedule, cmi_split_schedule */
 
 /* status codes */
 #define CMI_OK 0
@@ -85,15 +86,8 @@ extern "C" {
                                       order) and, under SCHED_SERIAL, the reference's running-sum order for `loss`:
                                       with STATE_F64 the model (and under SERIAL the loss) is bit-identical to the
                                       Java arithmetic */
-#define CMI_FLAG_SCHED_FLOW 0x20u /* same dependency levels, but ONE persistent launch per epoch in which every tuple
-                                      waits only for its own two predecessors (per-row version counters, device-coherent
-                                      row traffic): adjacent levels overlap.  Same result as the level schedule, bit for
-                                      bit.  EXPERIMENTAL (round 1: correct but slower than the level launches, see
-                                      DESIGN.md); fp32 state, k in {64,128}; silently falls back to the level schedule
-                                      otherwise (cmi_schedule_info reports which one runs) */
-#define CMI_FLAG_TWO_LANE 0x40u /* fast path only, EXPERIMENTAL: a two-lane hipGraph in which the head of level l runs
-                                      beside the tail of level l-1 (identical result).  Measured slower than the plain
-                                      level launches in round 1 (the lanes stay in lock-step); see DESIGN.md */
+/* 0x20u, 0x40u: CMI_FLAG_SCHED_FLOW / CMI_FLAG_TWO_LANE of ABI 2 (round-1 experiments, measured slower than the level launches)
+ * were removed in ABI 3; the bits are reserved */
 #define CMI_FLAG_SCHED_CHAIN 0x80u /* force the hub-chain level schedule (the default whenever its levels are wide enough):
                                       consecutive tuples of one item (or user) whose other row is already final run back to
                                       back in one 16-lane group with the shared row, its bias and its context-bias row kept on
@@ -532,20 +526,6 @@ int cmi_conflict_free_blocks(int64_t n, const int32_t *u, const int32_t *j, int3
  * spoke row taken over in registers, bit 4 spoke record stored. */
 int cmi_owner_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int n_owners, int depth,
                        int32_t *perm, int64_t *own_off, uint32_t *want, uint32_t *flags, int *hub_used);
-
-/* The two-lane form behind CMI_FLAG_TWO_LANE (level_schedule.cpp, build_split_schedule): same levels,
- * tuples inside a level sorted by the position of their later predecessor, and split[l] = first position of the
- * level's TAIL; the HEAD [level_off[l], split[l]) only depends on positions < split[l-1], so head(l) and tail(l-1)
- * run concurrently.  level_off: *n_levels+1 entries, split: *n_levels entries (pass perm = NULL to only count). */
-int cmi_split_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int32_t *perm,
-                       int64_t *level_off, int64_t *split, int64_t level_cap, int64_t *n_levels);
-
-/* The padded dataflow form of the same schedule (CMI_FLAG_SCHED_FLOW; level_schedule.cpp): call with
- * perm = NULL to get *n_slots, then with arrays of that capacity.  perm[s] = CRS tuple index or -1 for a
- * padding slot (every level is padded to a multiple of 16 slots); seq_u[s] / seq_j[s] = number of earlier
- * tuples (CRS order) with the same user / item = the row version the tuple waits for. */
-int cmi_flow_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items,
-                      int32_t *perm, uint32_t *seq_u, uint32_t *seq_j, int64_t cap, int64_t *n_slots);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SETTING = """dataset.ratings.lins=%(path)s
 ratings.setup=-threshold -1 -datatransformation 1 -fullstat -1
 recommender=camf_c
-evaluation.setup=cv -k 5 -p off --rand-seed 1 --test-view all
+evaluation.setup=cv -k %(folds)d -p off --rand-seed 1 --test-view all
 item.ranking=off -topN 10
 output.setup=-folder CARSKit.Workspace -verbose off
 num.factors=64
@@ -22,6 +22,7 @@ reg.lambda=0.0001 -c 0.001
 
 
 def write_ratings(tmp_path, scale="raw"):
+    os.makedirs(str(tmp_path), exist_ok=True)
     text = gzip.open(os.path.join(GOLDEN, "frappe_compact.csv.gz"), "rb").read().decode("utf-8")
     if scale == "log":
         lines = text.split("\n")
@@ -39,8 +40,8 @@ def write_ratings(tmp_path, scale="raw"):
     return path
 
 
-def write_conf(tmp_path, scale="raw", lr="2e-2"):
+def write_conf(tmp_path, scale="raw", lr="2e-2", folds=5):
     path = write_ratings(tmp_path, scale)
-    conf = os.path.join(str(tmp_path), "setting.conf")
-    open(conf, "w").write(SETTING % {"path": path, "lr": lr})
+    conf = os.path.join(str(tmp_path), "setting_%s_%d.conf" % (scale, folds))
+    open(conf, "w").write(SETTING % {"path": path, "lr": lr, "folds": folds})
     return conf

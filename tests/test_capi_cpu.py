@@ -21,7 +21,7 @@ def test_header_symbols_all_exported():
     L = capi.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.cmi_abi_version() == 2
+    assert L.cmi_abi_version() == 3
 
 
 def test_no_cpu_fallback():
@@ -75,136 +75,6 @@ def _check_schedule(u, j, nu, ni, order):
         assert level_of[t] == want
         lu[int(u[t])] = lj[int(j[t])] = want
     return perm, off
-
-
-@pytest.mark.parametrize("order", [0, 1, 2])
-def test_level_schedule_small(order):
-    d = synth.generate(37, 13, 2, 3, 600, seed=order + 1)
-    perm, off = _check_schedule(d.u, d.j, d.n_users, d.n_items, order)
-    if order == 0:  # CRS order kept inside a level
-        for l in range(len(off) - 1):
-            assert np.all(np.diff(perm[off[l]:off[l + 1]]) > 0)
-
-
-@settings(max_examples=40, deadline=None)
-@given(nu=st.integers(1, 9), ni=st.integers(1, 9), n=st.integers(0, 80), seed=st.integers(0, 1000),
-       order=st.integers(0, 2))
-def test_level_schedule_property(nu, ni, n, seed, order):
-    rng = np.random.default_rng(seed)
-    u = rng.integers(0, nu, n).astype(np.int32)
-    j = rng.integers(0, ni, n).astype(np.int32)
-    _check_schedule(u, j, nu, ni, order)
-
-
-def test_level_schedule_rejects_bad_ids():
-    with pytest.raises(capi.CmiError):
-        capi.level_schedule(np.array([0, 5], np.int32), np.array([0, 0], np.int32), 3, 2)
-
-
-def test_level_schedule_zipf_chain():
-    """A hot item serialises its tuples: #levels >= its degree."""
-    d = synth.generate(200, 50, 1, 2, 3000, seed=4, item_zipf=1.3)
-    _, off = capi.level_schedule(d.u, d.j, d.n_users, d.n_items)
-    assert len(off) - 1 >= np.bincount(d.j).max()
-
-
-def _check_flow(u, j, nu, ni):
-    perm, su, sj = capi.flow_schedule(u, j, nu, ni)
-    n = len(u)
-    assert len(perm) % 16 == 0
-    live = perm[perm >= 0]
-    assert sorted(live.tolist()) == list(range(n))
-    pos = np.empty(n, dtype=np.int64)
-    pos[live] = np.flatnonzero(perm >= 0)
-    # seq = number of earlier tuples (CRS order) of the same user / item; predecessors sit at smaller positions
-    cu, cj, last_u, last_j = {}, {}, {}, {}
-    for t in range(n):
-        a, b = int(u[t]), int(j[t])
-        assert su[pos[t]] == cu.get(a, 0) and sj[pos[t]] == cj.get(b, 0)
-        for last, key in ((last_u, a), (last_j, b)):
-            if key in last:
-                assert pos[last[key]] < pos[t]
-                assert pos[last[key]] // 16 != pos[t] // 16      # never in the same 16-slot step
-            last[key] = t
-        cu[a] = cu.get(a, 0) + 1
-        cj[b] = cj.get(b, 0) + 1
-    # a 16-slot step (what one workgroup processes at once) holds pairwise independent tuples
-    for c in range(len(perm) // 16):
-        seg = perm[c * 16:(c + 1) * 16]
-        seg = seg[seg >= 0]
-        assert len(set(u[seg].tolist())) == len(seg) and len(set(j[seg].tolist())) == len(seg)
-    return perm, pos
-
-
-@settings(max_examples=30, deadline=None)
-@given(nu=st.integers(1, 9), ni=st.integers(1, 9), n=st.integers(0, 90), seed=st.integers(0, 1000))
-def test_flow_schedule_property(nu, ni, n, seed):
-    rng = np.random.default_rng(seed)
-    _check_flow(rng.integers(0, nu, n).astype(np.int32), rng.integers(0, ni, n).astype(np.int32), nu, ni)
-
-
-def test_flow_schedule_keeps_dependency_distance_about_one_level():
-    d = synth.generate(20000, 2000, 2, 3, 400000, seed=9)
-    perm, pos = None, None
-    perm, su, sj = capi.flow_schedule(d.u, d.j, d.n_users, d.n_items)
-    live = perm >= 0
-    pos = np.empty(d.n, dtype=np.int64)
-    pos[perm[live]] = np.flatnonzero(live)
-    # distance to the later predecessor
-    last_u = np.full(d.n_users, -1, np.int64)
-    last_j = np.full(d.n_items, -1, np.int64)
-    dist = []
-    for t in range(d.n):
-        p = max(last_u[d.u[t]], last_j[d.j[t]])
-        if p >= 0:
-            dist.append(pos[t] - p)
-        last_u[d.u[t]] = last_j[d.j[t]] = pos[t]
-    dist = np.array(dist)
-    _, off = capi.level_schedule(d.u, d.j, d.n_users, d.n_items)
-    median_level = np.median(np.diff(off))
-    # the within-level sort keeps almost every dependency at least ~half a typical level away
-    assert np.percentile(dist, 1) > 0.4 * median_level, (np.percentile(dist, [0.1, 1, 10, 50]), median_level)
-
-
-def _check_split(u, j, nu, ni):
-    perm, off, split = capi.split_schedule(u, j, nu, ni)
-    perm0, off0 = capi.level_schedule(u, j, nu, ni)
-    n = len(u)
-    assert off.tolist() == off0.tolist()                        # same levels as the plain schedule
-    assert sorted(perm.tolist()) == list(range(n))
-    pos = np.empty(n, dtype=np.int64)
-    pos[perm] = np.arange(n)
-    for l in range(len(off) - 1):
-        assert sorted(perm[off[l]:off[l + 1]].tolist()) == sorted(perm0[off0[l]:off0[l + 1]].tolist())
-        assert off[l] <= split[l] <= off[l + 1]
-        assert split[l] - off[l] <= (off[l + 1] - off[l] + 1) // 2   # the head is at most half of the level
-    # head(l) only depends on positions before split[l-1]; every tuple's predecessors are in earlier levels
-    last_u, last_j = {}, {}
-    level_of = np.searchsorted(off, pos, side="right") - 1
-    for t in range(n):
-        pred = max(last_u.get(int(u[t]), -1), last_j.get(int(j[t]), -1))
-        l = level_of[t]
-        if pred >= 0:
-            assert pred < off[l]
-            if pos[t] < split[l]:                                 # tuple is in the head of its level
-                assert l >= 1 and pred < split[l - 1]
-        last_u[int(u[t])] = last_j[int(j[t])] = pos[t]
-    return perm, off, split
-
-
-@settings(max_examples=30, deadline=None)
-@given(nu=st.integers(1, 9), ni=st.integers(1, 9), n=st.integers(0, 90), seed=st.integers(0, 1000))
-def test_split_schedule_property(nu, ni, n, seed):
-    rng = np.random.default_rng(seed)
-    _check_split(rng.integers(0, nu, n).astype(np.int32), rng.integers(0, ni, n).astype(np.int32), nu, ni)
-
-
-def test_split_schedule_heads_are_about_half_on_uniform_data():
-    d = synth.generate(20000, 2000, 2, 3, 400000, seed=9)
-    perm, off, split = _check_split(d.u, d.j, d.n_users, d.n_items)
-    sizes, heads = np.diff(off), split - off[:-1]
-    big = sizes > 500
-    assert np.median(heads[big] / sizes[big]) > 0.4             # the head really is ~half: two balanced lanes
 
 
 def test_narrow_runs_properties():

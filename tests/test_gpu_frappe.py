@@ -40,9 +40,12 @@ def test_c2_camf_c_k64_fp32_on_frappe(tmp_path):
 
 
 def test_c2_frappe_strict_fp64_bit_exact(tmp_path):
-    conf = frappe.write_conf(tmp_path, "log")
-    _, gpu, _ = main.run(conf, log=lambda *a: None, conf_overrides={"flags": STRICT})
-    _, cpu, _ = main.run(conf, engine_factory=util.OracleEngine, log=lambda *a: None)
+    # (the strict serial wave walks one tuple at a time in the reference's summation order, ~8 us per tuple at k = 64: two folds x
+    # four epochs keep this test at a few seconds; the fp32 test above runs the full 5 x 15)
+    conf = frappe.write_conf(tmp_path, "log", folds=2)
+    _, gpu, _ = main.run(conf, log=lambda *a: None, conf_overrides={"flags": STRICT, "num_iters": 4})
+    _, cpu, _ = main.run(conf, engine_factory=util.OracleEngine, log=lambda *a: None, conf_overrides={"num_iters": 4})
+    assert len(gpu) == 2
     for a, b in zip(gpu, cpu):
         assert a.losses == b.losses and a.lrates == b.lrates
         for name, arr in a.state.items():
@@ -55,9 +58,10 @@ def test_c2_frappe_raw_counts(tmp_path):
     conf = frappe.write_conf(tmp_path, "raw")
     with pytest.raises(FloatingPointError, match="Loss = NaN or Infinity"):     # IterativeRecommender.java:181-184
         main.run(conf, log=lambda *a: None)
-    over = {"init_lrate": 1e-6, "flags": STRICT}
+    conf = frappe.write_conf(tmp_path, "raw", folds=2)
+    over = {"init_lrate": 1e-6, "flags": STRICT, "num_iters": 4}
     _, gpu, _ = main.run(conf, log=lambda *a: None, conf_overrides=over)
-    _, cpu, _ = main.run(conf, engine_factory=util.OracleEngine, log=lambda *a: None, conf_overrides={"init_lrate": 1e-6})
+    _, cpu, _ = main.run(conf, engine_factory=util.OracleEngine, log=lambda *a: None, conf_overrides={"init_lrate": 1e-6, "num_iters": 4})
     for a, b in zip(gpu, cpu):
         assert a.losses == b.losses and a.lrates == b.lrates and np.isfinite(a.losses).all()
         for name, arr in a.state.items():
@@ -67,13 +71,15 @@ def test_c2_frappe_raw_counts(tmp_path):
 def test_c2_frappe_through_the_cpp_host(tmp_path):
     from tests.test_host_layer import EXE, expected_from_oracle
     conf = frappe.write_conf(tmp_path, "log")
-    want = expected_from_oracle(conf, "camf_c", 15)
-    p = subprocess.run([EXE, "-c", conf, "--flags", str(STRICT), "--precise"], capture_output=True, text=True)
+    strict_conf = frappe.write_conf(tmp_path / "strict", "log", folds=2)
+    want2 = expected_from_oracle(strict_conf, "camf_c", 4)
+    p = subprocess.run([EXE, "-c", strict_conf, "--iters", "4", "--flags", str(STRICT), "--precise"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
-    m = re.search(r"PRECISE CAMF_C folds=5 MAE=(\S+) RMSE=(\S+)", p.stdout)
+    m = re.search(r"PRECISE CAMF_C folds=2 MAE=(\S+) RMSE=(\S+)", p.stdout)
     assert m, p.stdout[-500:]
-    assert abs(float(m.group(1)) - want["MAE"]) <= 1e-12 and abs(float(m.group(2)) - want["RMSE"]) <= 1e-12
-    p32 = subprocess.run([EXE, "-c", conf, "--precise"], capture_output=True, text=True)      # the config's dtype: fp32 state
+    assert abs(float(m.group(1)) - want2["MAE"]) <= 1e-12 and abs(float(m.group(2)) - want2["RMSE"]) <= 1e-12
+    want = expected_from_oracle(conf, "camf_c", 15)
+    p32 = subprocess.run([EXE, "-c", conf, "--precise"], capture_output=True, text=True)      # the config's dtype: fp32 state, 5 folds x 15 epochs
     m32 = re.search(r"PRECISE CAMF_C folds=5 MAE=(\S+) RMSE=(\S+)", p32.stdout)
     assert m32, p32.stdout[-500:] + p32.stderr
     assert abs(float(m32.group(1)) - want["MAE"]) <= 1e-5 and abs(float(m32.group(2)) - want["RMSE"]) <= 1e-5

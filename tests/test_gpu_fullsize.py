@@ -78,7 +78,7 @@ def test_c3_lr_zero_is_idempotent_and_loss_is_consistent(c3):
 
 def test_c3_schedules_agree_bit_for_bit(c3):
     outs = []
-    for flags in (0, capi.FLAG_NO_CHAIN, capi.FLAG_NO_CHAIN | capi.FLAG_NO_GRAPH, capi.FLAG_TWO_LANE):
+    for flags in (0, capi.FLAG_NO_CHAIN, capi.FLAG_NO_CHAIN | capi.FLAG_NO_GRAPH):
         inst = _inst(c3, flags)
         losses = [inst.train_epoch(util.LR) for _ in range(2)]
         outs.append((losses, inst.get_state("P", np.float32), inst.get_state("Q", np.float32),
