@@ -188,7 +188,9 @@ def secondary_workload(name, steps, warmup, device, flags, regs, lr):
     losses, el, kern_ms = timed_epochs(inst, lr, steps, warmup)
     if not np.all(np.isfinite(losses)) or losses[-1] > losses[0]:
         raise SystemExit("bench: %s diverged (epoch losses %s)" % (name, losses))
-    out = {"workload": "%s: %s k=%d, %d users x %d items x %d conditions (%d dims), %d ratings, order-exact %s schedule"
+    info, sched = inst.schedule_info(), inst.schedule_traffic()      # (the first epoch may have chosen table vs arena for this box)
+    out = {"schedule_note": inst.schedule_note(),
+           "workload": "%s: %s k=%d, %d users x %d items x %d conditions (%d dims), %d ratings, order-exact %s schedule"
                        % (name, model, k, data.n_users, n_items, data.n_conds, n_dims, data.n,
                           "hub-chain level" if info["kind"].startswith("chain") else "owner (dataflow)" if info["kind"].startswith("owner")
                           else "dependency-level"),
@@ -501,6 +503,10 @@ def main():
     for _ in range(args.warmup):
         losses.append(step())
     barrier()
+    # the first training call may have chosen between the table and the arena form of the spoke rows for THIS box (spoke tables of
+    # 256 MiB .. 2 GiB: cmi_api.cpp arena_probe): price the roofline at the form that runs
+    if args.warmup > 0:
+        info, sched = inst.schedule_info(), inst.schedule_traffic()
     t0 = time.perf_counter()
     gpu_ms = []
     for _ in range(args.steps):

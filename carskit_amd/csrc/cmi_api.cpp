@@ -142,6 +142,7 @@ static void free_ratings(cmi_instance *h) {
             *p = nullptr;
         }
     h->arena_on = h->arena_valid = false;
+    h->arena_probe = false;
     h->table_valid = true;
     free_eval_set(h);
     if (h->graph_exec) {
@@ -759,7 +760,15 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const bool forced = (h->flags & CMI_FLAG_SPOKE_ARENA) || getenv("CMI_ARENA");
-        if (forced || (table_bytes >= ((size_t)2 << 30) && (double)arena_bytes <= 0.6 * (double)free_b)) {
+        const bool large = table_bytes >= ((size_t)2 << 30) && (double)arena_bytes <= 0.6 * (double)free_b;
+        // In between (spoke tables of 256 MiB .. 2 GiB: BASELINE C5's share has a 1-GiB Q) the better form depends on the BOX: the same
+        // library measures the arena 9 % faster on some MI355X boxes of the pool and 4 % slower on others.  There
+        // the arena is built and the first training call times one epoch of each form at learning rate 0 (which leaves every parameter
+        // as it is) and keeps the faster one (arena_probe below).  CMI_ARENA_PROBE=1 forces the probe at any size (tests), =0 disables it.
+        const char *pe = getenv("CMI_ARENA_PROBE");
+        const bool probe = !forced && !large && (pe ? atoi(pe) != 0 : (table_bytes >= ((size_t)256 << 20) && (double)arena_bytes <= 0.3 * (double)free_b));
+        h->arena_probe = false;
+        if (forced || large || probe) {
             // next_pos[p] = stream position of the next tuple of the same spoke row (its tuples sit in ascending levels, hence ascending
             // positions); the last one wraps to the first: that is where the row waits for the next epoch
             std::vector<int32_t> nxt((size_t)n), first((size_t)spokes, -1);
@@ -774,6 +783,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
                 h->arena_valid = false;
                 h->table_valid = true;
                 h->arena_which = h->chain_hub_item ? CMI_STATE_P : CMI_STATE_Q;
+                h->arena_probe = probe;
             } else if (!forced) { // not enough memory after all: run without
                 (void)hipGetLastError();
                 for (void **q : {(void **)&h->d_arena, (void **)&h->d_next, (void **)&h->d_first})
@@ -1101,9 +1111,13 @@ static hipError_t enqueue_levels(cmi_instance *h) {
     return e;
 }
 
-static int enqueue_epoch(cmi_instance *h, double lrate) {
+static int arena_probe(cmi_instance *h);
+
+static int enqueue_epoch(cmi_instance *h, double lrate, bool probing = false) {
     if (!h->have_ratings) CMI_FAIL(h, CMI_E_INVALID, "train: call cmi_set_ratings first");
     CMI_HIP(h, hipSetDevice(h->device));
+    if (h->arena_probe && !probing)
+        if (int rc = arena_probe(h)) return rc;
     h->hp.lr = lrate;
     CMI_HIP(h, launch_set_hparams(h->d_hp, h->hp, h->stream));
     if (h->n == 0) {
@@ -1144,6 +1158,43 @@ static int enqueue_epoch(cmi_instance *h, double lrate) {
     }
     CMI_HIP(h, hipEventRecord(h->ev1, h->stream));
     h->epoch_timed = true;
+    return CMI_OK;
+}
+
+// Table or arena for the spoke rows of this box (see cmi_set_ratings): one timed epoch of each form at learning rate 0 -- every update
+// is then x + 0 * (...) = x, so the model is what it was (to the sign of an exact zero) -- after one untimed epoch that also builds the
+// form's graph.  The arena stays if it is at least 3 % faster; otherwise its memory is released.
+static int arena_probe(cmi_instance *h) {
+    h->arena_probe = false;
+    float ms[2] = {0.f, 0.f};
+    for (int form = 0; form < 2; ++form) {
+        h->arena_on = form == 1;
+        if (h->graph_exec) {
+            hipGraphExecDestroy(h->graph_exec);
+            h->graph_exec = nullptr;
+        }
+        for (int rep = 0; rep < 2; ++rep)
+            if (int rc = enqueue_epoch(h, 0.0, true)) return rc;
+        CMI_HIP(h, hipStreamSynchronize(h->stream));
+        CMI_HIP(h, hipEventElapsedTime(&ms[form], h->ev0, h->ev1));
+        if (form == 1)
+            if (int rc = cmi_sync_table_from_arena(h)) return rc; // the tables are the masters again, whichever form wins
+    }
+    const bool keep = ms[1] < 0.97f * ms[0];
+    char note[200];
+    snprintf(note, sizeof note, "spoke arena probe: table %.2f ms, arena %.2f ms per epoch -> %s", ms[0], ms[1], keep ? "arena" : "table");
+    h->sched_note = h->sched_note.empty() ? note : h->sched_note + "; " + note;
+    if (!keep) {
+        hipGraphExecDestroy(h->graph_exec); // captured in the arena form
+        h->graph_exec = nullptr;
+        h->arena_on = h->arena_valid = false;
+        h->table_valid = true;
+        for (void **q : {(void **)&h->d_arena, (void **)&h->d_next, (void **)&h->d_first})
+            if (*q) {
+                hipFree(*q);
+                *q = nullptr;
+            }
+    }
     return CMI_OK;
 }
 

@@ -23,6 +23,7 @@ struct cmi_instance {
     // every spoke row with tuples sits in the slot of its FIRST tuple; the model table (state[arena_which]) is only current while
     // table_valid -- every reader of the table goes through cmi_sync_table_from_arena first
     bool arena_on = false, arena_valid = false, table_valid = true;
+    bool arena_probe = false;        // the first training call still has to choose between table and arena (cmi_api.cpp arena_probe)
     int arena_which = 0;             // CMI_STATE_P (hub = item) or CMI_STATE_Q (hub = user)
     void *d_arena = nullptr;
     int32_t *d_next = nullptr, *d_first = nullptr;

@@ -209,10 +209,16 @@ def test_spoke_arena_is_bit_identical_and_every_reader_sees_the_live_rows(model,
                                   arena.predict(test.u[:64], test.j[:64], None if tctx is None else tctx[:64]))
         if ep == 2:      # a container rewritten from the host between epochs (both the arena-backed one and the other side)
             st = ref.get_states()
-            for name in ("P", "Q"):
+            # (round 4: the arena slots also carry the spoke row's scalar bias -- userBias / itemBias are arena-backed containers too:
+            # rewriting ONE of the two must not lose the other's live values)
+            for name in ("userBias", "P", "itemBias", "Q"):
+                if name not in st:
+                    continue
                 new = (st[name] * 0.5).astype(st[name].dtype)
                 ref.set_state(name, new)
                 arena.set_state(name, new)
+                for other, a in ref.get_states().items():
+                    assert np.array_equal(a, arena.get_state(other)), (name, other)
     for name, a in ref.get_states().items():
         assert np.array_equal(a, arena.get_state(name)), name
 
@@ -288,3 +294,31 @@ def test_spoke_arena_honours_host_writes_through_the_device_pointer(hub, name):
     b.train_epoch(util.LR)
     for n_, x in a.get_states().items():
         assert np.array_equal(x, b.get_state(n_)), n_
+
+
+@pytest.mark.parametrize("hub", ["item", "user"])
+def test_arena_probe_times_both_forms_at_rate_zero_and_leaves_the_model_alone(hub):
+    """Spoke tables of 256 MiB .. 2 GiB (BASELINE C5's share): table or arena is the BOX's choice, so the first training call times
+    one epoch of each form at learning rate 0 -- x + 0 * (...) = x: nothing moves -- and keeps the faster (forced on this small set
+    with CMI_ARENA_PROBE=1).  Whatever it picks, the model equals the table-resident run bit for bit, epoch by epoch, and the
+    schedule note says what was measured."""
+    import os
+    model, k = "CAMF_CU", 64
+    data = util.small_data(n_users=900, n_items=220, n_dims=3, conds_per_dim=3, n=16000, seed=53)
+    _, ref = _with_hub(hub, lambda: make_pair(model, data, k, CHAIN | capi.FLAG_NO_ARENA))
+    os.environ["CMI_ARENA_PROBE"] = "1"
+    try:
+        _, prb = _with_hub(hub, lambda: make_pair(model, data, k, CHAIN))
+    finally:
+        del os.environ["CMI_ARENA_PROBE"]
+    assert prb.schedule_traffic()["spoke_arena"]                 # built, choice pending
+    before = prb.get_states()
+    for ep in range(3):
+        assert ref.train_epoch(util.LR) == prb.train_epoch(util.LR)
+        if ep == 0:
+            note = prb.schedule_note()
+            assert "spoke arena probe: table " in note and (note.endswith("-> arena") or note.endswith("-> table"))
+            assert prb.schedule_traffic()["spoke_arena"] == note.endswith("-> arena")
+    for name, a in ref.get_states().items():
+        assert np.array_equal(a, prb.get_state(name)), name
+    assert any(not np.array_equal(before[n], prb.get_state(n)) for n in before)     # (and it did train)
