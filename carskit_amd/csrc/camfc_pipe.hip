@@ -110,10 +110,14 @@ struct PipeConst {
 // dependent VALU operation, 20 per v_readlane and per taken branch (tools/micro/one_wave_clock.hip) -- so DM, the number of context
 // dimensions, is a template parameter (no inner loop; an absent condition, 0xff, contributes an exact +0) and the tuple's uniform loss
 // terms are returned as ONE float that the caller parks in a lane; they are summed in double once per 64 tuples.
-template <typename T, int MAXC, int DM>
-__device__ __forceinline__ T camfc_step_dm(RowVec<T, MAXC> &p, RowVec<T, MAXC> &q, T &bu, T &bj, T &bcreg, const T rr,
-                                           const unsigned long long pc, const int lane, const PipeConst<T> &h, double &acc_reg,
-                                           double &acc_ctx) {
+// BCL: condBias lives in LDS (s_bc, more than 64 conditions -- the Frappe file has 343) instead of in lane c of one register.  The tuple's
+// condition ids then travel as 16-bit fields of TWO packed words (pc: dimensions 0-3, pc2: 4-7; 0xffff = absent); lane d < DM reads and
+// later rewrites s_bc[its condition] -- one ds_read / ds_write for all dimensions, ordered after the previous tuple's write by the wave's
+// in-order LDS queue -- and the values reach the uniform sum through v_readlane, added one by one like in the register form.
+template <typename T, int MAXC, int DM, bool BCL>
+__device__ __forceinline__ T camfc_step_dm(RowVec<T, MAXC> &p, RowVec<T, MAXC> &q, T &bu, T &bj, T &bcreg, T *s_bc, const T rr,
+                                           const unsigned long long pc, const unsigned long long pc2, const int lane,
+                                           const PipeConst<T> &h, double &acc_reg, double &acc_ctx) {
     T part = 0;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) part += p.v[c] * q.v[c];
@@ -123,16 +127,28 @@ __device__ __forceinline__ T camfc_step_dm(RowVec<T, MAXC> &p, RowVec<T, MAXC> &
     pred += bj;
     pred += dot;
     const unsigned lo = (unsigned)pc, hi = (unsigned)(pc >> 32);
-    const T decay = h.regC * bcreg;
     bool mine = false;
+    unsigned mycond = 0;
+    if (BCL) {
+        const unsigned lo2 = (unsigned)pc2, hi2 = (unsigned)(pc2 >> 32);
+        // lane d's own condition: 16-bit field d of (pc, pc2)
+        const unsigned w = lane < 2 ? lo : lane < 4 ? hi : lane < 6 ? lo2 : hi2;
+        mycond = (w >> (16 * (lane & 1))) & 0xffffu;
+        mine = lane < DM && mycond != 0xffffu;
+        bcreg = mine ? s_bc[mycond] : (T)0; // here bcreg is a per-tuple temporary: lane d holds the d-th deviation
 #pragma unroll
-    for (int d = 0; d < DM; ++d) { // the reference adds the deviations one by one, in condition order (CAMF_C.java:98-101)
-        const unsigned cond = (d < 4 ? lo >> (8 * d) : hi >> (8 * (d - 4))) & 0xffu;
-        const bool present = cond != 0xffu;
-        const T got = prl(bcreg, (int)(cond & 63u));
-        pred += present ? got : (T)0;
-        mine = mine || (present && lane == (int)cond);
+        for (int d = 0; d < DM; ++d) pred += prl(bcreg, d); // absent dimensions contribute an exact +0
+    } else {
+#pragma unroll
+        for (int d = 0; d < DM; ++d) { // the reference adds the deviations one by one, in condition order (CAMF_C.java:98-101)
+            const unsigned cond = (d < 4 ? lo >> (8 * d) : hi >> (8 * (d - 4))) & 0xffu;
+            const bool present = cond != 0xffu;
+            const T got = prl(bcreg, (int)(cond & 63u));
+            pred += present ? got : (T)0;
+            mine = mine || (present && lane == (int)cond);
+        }
     }
+    const T decay = h.regC * bcreg;
     const T e = rr - pred;
     T l = e * e;
     {
@@ -148,6 +164,7 @@ __device__ __forceinline__ T camfc_step_dm(RowVec<T, MAXC> &p, RowVec<T, MAXC> &
     if (mine) {
         acc_ctx += (double)bcreg; // plain sum, weighted by regB at the end (reference quirk, CAMF_C.java:110,115)
         bcreg = bcreg + h.lr * (e - decay);
+        if (BCL) s_bc[mycond] = bcreg;
     }
     T reg_part = 0;
 #pragma unroll
@@ -160,51 +177,68 @@ __device__ __forceinline__ T camfc_step_dm(RowVec<T, MAXC> &p, RowVec<T, MAXC> &
     acc_reg += (double)reg_part;
     return l;
 }
-template <typename T, int MAXC>
-__device__ __forceinline__ T camfc_step(RowVec<T, MAXC> &p, RowVec<T, MAXC> &q, T &bu, T &bj, T &bcreg, const T rr,
-                                        const unsigned long long pc, const int dmax, const int lane, const PipeConst<T> &h,
-                                        double &acc_reg, double &acc_ctx) {
+template <typename T, int MAXC, bool BCL>
+__device__ __forceinline__ T camfc_step(RowVec<T, MAXC> &p, RowVec<T, MAXC> &q, T &bu, T &bj, T &bcreg, T *s_bc, const T rr,
+                                        const unsigned long long pc, const unsigned long long pc2, const int dmax, const int lane,
+                                        const PipeConst<T> &h, double &acc_reg, double &acc_ctx) {
     switch (dmax) {
-    case 1: return camfc_step_dm<T, MAXC, 1>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
-    case 2: return camfc_step_dm<T, MAXC, 2>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
-    case 3: return camfc_step_dm<T, MAXC, 3>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
-    case 4: return camfc_step_dm<T, MAXC, 4>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
-    case 5: return camfc_step_dm<T, MAXC, 5>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
-    case 6: return camfc_step_dm<T, MAXC, 6>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
-    case 7: return camfc_step_dm<T, MAXC, 7>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
-    default: return camfc_step_dm<T, MAXC, 8>(p, q, bu, bj, bcreg, rr, pc, lane, h, acc_reg, acc_ctx);
+    case 1: return camfc_step_dm<T, MAXC, 1, BCL>(p, q, bu, bj, bcreg, s_bc, rr, pc, pc2, lane, h, acc_reg, acc_ctx);
+    case 2: return camfc_step_dm<T, MAXC, 2, BCL>(p, q, bu, bj, bcreg, s_bc, rr, pc, pc2, lane, h, acc_reg, acc_ctx);
+    case 3: return camfc_step_dm<T, MAXC, 3, BCL>(p, q, bu, bj, bcreg, s_bc, rr, pc, pc2, lane, h, acc_reg, acc_ctx);
+    case 4: return camfc_step_dm<T, MAXC, 4, BCL>(p, q, bu, bj, bcreg, s_bc, rr, pc, pc2, lane, h, acc_reg, acc_ctx);
+    case 5: return camfc_step_dm<T, MAXC, 5, BCL>(p, q, bu, bj, bcreg, s_bc, rr, pc, pc2, lane, h, acc_reg, acc_ctx);
+    case 6: return camfc_step_dm<T, MAXC, 6, BCL>(p, q, bu, bj, bcreg, s_bc, rr, pc, pc2, lane, h, acc_reg, acc_ctx);
+    case 7: return camfc_step_dm<T, MAXC, 7, BCL>(p, q, bu, bj, bcreg, s_bc, rr, pc, pc2, lane, h, acc_reg, acc_ctx);
+    default: return camfc_step_dm<T, MAXC, 8, BCL>(p, q, bu, bj, bcreg, s_bc, rr, pc, pc2, lane, h, acc_reg, acc_ctx);
     }
 }
 
-template <typename T, int MAXC, bool FULL, int D>
+constexpr int CAMFC_PIPE_MAX_CONDS = 1024; // LDS form of condBias
+
+template <typename T, int MAXC, bool FULL, int D, bool BCL>
 __global__ __launch_bounds__(64) void sgd_camfc_pipe(SgdArgs<T> a, int64_t n, double *loss_out) {
     __shared__ RowVec<T, MAXC> h_p[D][64], h_q[D][64]; // the updated rows of the last D tuples (slot = t mod D)
+    __shared__ T s_bc[BCL ? CAMFC_PIPE_MAX_CONDS : 1];
     const int lane = threadIdx.x;
     const int k = a.k, dmax = a.dmax;
     const HParams hp = *a.hp;
     const PipeConst<T> h = {(T)hp.lr, (T)hp.regU, (T)hp.regI, (T)hp.regB, (T)hp.regC, (T)hp.gm};
-    T bcreg = lane < a.n_conds ? a.condBias[lane] : (T)0;
+    T bcreg = (!BCL && lane < a.n_conds) ? a.condBias[lane] : (T)0;
+    if (BCL)
+        for (int c = lane; c < a.n_conds; c += 64) s_bc[c] = a.condBias[c];
     double loss = 0.0, acc_reg = 0.0, acc_ctx = 0.0;
     const int64_t n_main = n & ~(int64_t)63;
 
     // chunk staging: lane l holds tuple base + l
-    auto load_ids = [&](int64_t base, int &mu, int &mj, T &mr, unsigned long long &mc) {
+    // packed condition ids of tuple t: 8-bit fields of one word (register form), 16-bit fields of two words (LDS form)
+    auto pack_ids = [&](int64_t t, unsigned long long &w, unsigned long long &w2) {
+        w = 0;
+        w2 = BCL ? ~0ull : 0ull;
+        if (BCL) w = ~0ull;
+        for (int d = 0; d < dmax; ++d) {
+            const int c = a.sconds[t * dmax + d];
+            if (BCL) {
+                const unsigned long long f = (unsigned long long)(c < 0 ? 0xffff : (c & 0xffff)) << (16 * (d & 3));
+                const unsigned long long m = ~(0xffffull << (16 * (d & 3)));
+                if (d < 4) w = (w & m) | f;
+                else w2 = (w2 & m) | f;
+            } else {
+                w |= (unsigned long long)(c < 0 ? 0xff : (c & 0xff)) << (8 * d);
+            }
+        }
+    };
+    auto load_ids = [&](int64_t base, int &mu, int &mj, T &mr, unsigned long long &mc, unsigned long long &mcb) {
         mu = a.su[base + lane];
         mj = a.sj[base + lane];
         mr = a.sr[base + lane];
-        unsigned long long w = 0;
-        for (int d = 0; d < dmax; ++d) {
-            const int c = a.sconds[(base + lane) * dmax + d];
-            w |= (unsigned long long)(c < 0 ? 0xff : (c & 0xff)) << (8 * d);
-        }
-        mc = w;
+        pack_ids(base + lane, mc, mcb);
     };
 
     if (n_main > 0) {
         int mu, mj, mu2, mj2;
         T mr, mr2;
-        unsigned long long mc, mc2;
-        load_ids(0, mu, mj, mr, mc);
+        unsigned long long mc, mc2, mcb = 0, mcb2 = 0;
+        load_ids(0, mu, mj, mr, mc, mcb);
         RowVec<T, MAXC> pn[D], qn[D];
         T bun[D], bjn[D];
 #pragma unroll
@@ -225,12 +259,12 @@ __global__ __launch_bounds__(64) void sgd_camfc_pipe(SgdArgs<T> a, int64_t n, do
         for (int64_t base = 0; base < n_main; base += 64) {
             // the next chunk's ids, requested a chunk ahead and unconditionally (the last chunk re-requests itself: its look-ahead past
             // the end then re-requests rows of this chunk, which are never used)
-            load_ids(base + 64 < n_main ? base + 64 : base, mu2, mj2, mr2, mc2);
+            load_ids(base + 64 < n_main ? base + 64 : base, mu2, mj2, mr2, mc2, mcb2);
             T vl = 0; // lane i: the uniform loss terms of the chunk's tuple i
             auto stage = [&](const int i, const int s, const int nu, const int nj) __attribute__((always_inline)) {
                 const int uu = prl(mu, i), jj = prl(mj, i);
                 const T rr = prl(mr, i);
-                const unsigned long long pc = prl(mc, i);
+                const unsigned long long pc = prl(mc, i), pcb = BCL ? prl(mcb, i) : 0ull;
                 // ---- the rows requested D tuples ago, then the request for tuple t + D into the same slot
                 const RowVec<T, MAXC> cand_p = pn[s], cand_q = qn[s];
                 const T cand_bu = bun[s], cand_bj = bjn[s];
@@ -274,7 +308,7 @@ __global__ __launch_bounds__(64) void sgd_camfc_pipe(SgdArgs<T> a, int64_t n, do
                 }
                 cu = uu;
                 cj = jj;
-                const T l_t = camfc_step<T, MAXC>(p, q, bu, bj, bcreg, rr, pc, dmax, lane, h, acc_reg, acc_ctx);
+                const T l_t = camfc_step<T, MAXC, BCL>(p, q, bu, bj, bcreg, s_bc, rr, pc, pcb, dmax, lane, h, acc_reg, acc_ctx);
                 vl = lane == i ? l_t : vl;
                 // ---- publish: HBM, the LDS ring, the id / bias history
                 store_row<T, MAXC, FULL>(a.P, uu, k, lane, p);
@@ -302,50 +336,57 @@ __global__ __launch_bounds__(64) void sgd_camfc_pipe(SgdArgs<T> a, int64_t n, do
             mj = mj2;
             mr = mr2;
             mc = mc2;
+            mcb = mcb2;
         }
     }
     // ---- the last n mod 64 tuples: request after the previous tuple's stores, one by one
     for (int64_t t = n_main; t < n; ++t) {
         const int uu = a.su[t], jj = a.sj[t];
         const T rr = a.sr[t];
-        unsigned long long pc = 0;
-        for (int d = 0; d < dmax; ++d) {
-            const int c = a.sconds[t * dmax + d];
-            pc |= (unsigned long long)(c < 0 ? 0xff : (c & 0xff)) << (8 * d);
-        }
+        unsigned long long pc, pcb;
+        pack_ids(t, pc, pcb);
         RowVec<T, MAXC> p = load_row<T, MAXC, FULL>(a.P, uu, k, lane), q = load_row<T, MAXC, FULL>(a.Q, jj, k, lane);
         T bu = a.userBias[uu], bj = a.itemBias[jj];
-        loss += (double)camfc_step<T, MAXC>(p, q, bu, bj, bcreg, rr, pc, dmax, lane, h, acc_reg, acc_ctx);
+        loss += (double)camfc_step<T, MAXC, BCL>(p, q, bu, bj, bcreg, s_bc, rr, pc, pcb, dmax, lane, h, acc_reg, acc_ctx);
         store_row<T, MAXC, FULL>(a.P, uu, k, lane, p);
         store_row<T, MAXC, FULL>(a.Q, jj, k, lane, q);
         a.userBias[uu] = bu;
         a.itemBias[jj] = bj;
     }
-    if (lane < a.n_conds) a.condBias[lane] = bcreg;
+    if (BCL) {
+        for (int c = lane; c < a.n_conds; c += 64) a.condBias[c] = s_bc[c];
+    } else if (lane < a.n_conds) {
+        a.condBias[lane] = bcreg;
+    }
     loss += pwave_sum(acc_reg) + (double)h.regB * pwave_sum(acc_ctx);
     if (lane == 0) loss_out[0] = loss * 0.5;
 }
 
 } // namespace
 
-// <= 64 conditions (one per lane), <= 8 context dimensions (one byte each in the packed word), k <= 256
+// <= 8 context dimensions, k <= 256; <= 64 conditions: condBias in a register (one per lane, one byte per id); <= 1024: condBias in LDS
+// (round 4: the real Frappe file has 343)
 bool camfc_pipe_supported(int k, int n_conds, int dmax) {
-    return k >= 1 && k <= 256 && n_conds <= 64 && dmax >= 1 && dmax <= 8 && !getenv("CMI_NO_CAMFC_PIPE");
+    return k >= 1 && k <= 256 && n_conds <= CAMFC_PIPE_MAX_CONDS && dmax >= 1 && dmax <= 8 && !getenv("CMI_NO_CAMFC_PIPE");
 }
 
-template <typename T>
-hipError_t launch_camfc_pipe(const SgdArgs<T> &a, int64_t n, double *loss_out, hipStream_t s) {
+template <typename T, bool BCL>
+static hipError_t launch_camfc_pipe_bc(const SgdArgs<T> &a, int64_t n, double *loss_out, hipStream_t s) {
     const int k = a.k;
     // ring depth: the requests of tuple t are the oldest of 4 * rowops + ... outstanding operations when they are consumed; the
     // hardware counts 64 of them, so D * (2 * rowops + 2) * 2 stays below that
     // (D divides the 64-tuple chunk)
-    if (k == 64) hipLaunchKernelGGL((sgd_camfc_pipe<T, 1, true, 8>), dim3(1), dim3(64), 0, s, a, n, loss_out);
-    else if (k == 128) hipLaunchKernelGGL((sgd_camfc_pipe<T, 2, true, 8>), dim3(1), dim3(64), 0, s, a, n, loss_out);
-    else if (k == 256) hipLaunchKernelGGL((sgd_camfc_pipe<T, 4, true, sizeof(T) == 8 ? 4 : 8>), dim3(1), dim3(64), 0, s, a, n, loss_out);
-    else if (k < 64) hipLaunchKernelGGL((sgd_camfc_pipe<T, 1, false, 8>), dim3(1), dim3(64), 0, s, a, n, loss_out);
-    else if (k < 128) hipLaunchKernelGGL((sgd_camfc_pipe<T, 2, false, 4>), dim3(1), dim3(64), 0, s, a, n, loss_out);
-    else hipLaunchKernelGGL((sgd_camfc_pipe<T, 4, false, 2>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    if (k == 64) hipLaunchKernelGGL((sgd_camfc_pipe<T, 1, true, 8, BCL>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else if (k == 128) hipLaunchKernelGGL((sgd_camfc_pipe<T, 2, true, 8, BCL>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else if (k == 256) hipLaunchKernelGGL((sgd_camfc_pipe<T, 4, true, sizeof(T) == 8 ? 4 : 8, BCL>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else if (k < 64) hipLaunchKernelGGL((sgd_camfc_pipe<T, 1, false, 8, BCL>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else if (k < 128) hipLaunchKernelGGL((sgd_camfc_pipe<T, 2, false, 4, BCL>), dim3(1), dim3(64), 0, s, a, n, loss_out);
+    else hipLaunchKernelGGL((sgd_camfc_pipe<T, 4, false, 2, BCL>), dim3(1), dim3(64), 0, s, a, n, loss_out);
     return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_camfc_pipe(const SgdArgs<T> &a, int64_t n, double *loss_out, hipStream_t s) {
+    return a.n_conds <= 64 ? launch_camfc_pipe_bc<T, false>(a, n, loss_out, s) : launch_camfc_pipe_bc<T, true>(a, n, loss_out, s);
 }
 template hipError_t launch_camfc_pipe<float>(const SgdArgs<float> &, int64_t, double *, hipStream_t);
 template hipError_t launch_camfc_pipe<double>(const SgdArgs<double> &, int64_t, double *, hipStream_t);

@@ -77,6 +77,37 @@ def _check_schedule(u, j, nu, ni, order):
     return perm, off
 
 
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_level_schedule_small(order):
+    d = synth.generate(37, 13, 2, 3, 600, seed=order + 1)
+    perm, off = _check_schedule(d.u, d.j, d.n_users, d.n_items, order)
+    if order == 0:  # CRS order kept inside a level
+        for l in range(len(off) - 1):
+            assert np.all(np.diff(perm[off[l]:off[l + 1]]) > 0)
+
+
+@settings(max_examples=40, deadline=None)
+@given(nu=st.integers(1, 9), ni=st.integers(1, 9), n=st.integers(0, 80), seed=st.integers(0, 1000),
+       order=st.integers(0, 2))
+def test_level_schedule_property(nu, ni, n, seed, order):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, nu, n).astype(np.int32)
+    j = rng.integers(0, ni, n).astype(np.int32)
+    _check_schedule(u, j, nu, ni, order)
+
+
+def test_level_schedule_rejects_bad_ids():
+    with pytest.raises(capi.CmiError):
+        capi.level_schedule(np.array([0, 5], np.int32), np.array([0, 0], np.int32), 3, 2)
+
+
+def test_level_schedule_zipf_chain():
+    """A hot item serialises its tuples: #levels >= its degree."""
+    d = synth.generate(200, 50, 1, 2, 3000, seed=4, item_zipf=1.3)
+    _, off = capi.level_schedule(d.u, d.j, d.n_users, d.n_items)
+    assert len(off) - 1 >= np.bincount(d.j).max()
+
+
 def test_narrow_runs_properties():
     """Runs partition the levels: every run has >= min_levels levels, all <= max_tuples; levels outside runs are either
     wide or sit in a too-short narrow stretch; launches = runs + lone levels."""

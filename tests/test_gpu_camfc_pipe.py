@@ -118,3 +118,34 @@ def test_camf_c_without_context_dimensions_takes_the_general_paths():
             lo, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
             assert abs(lo - lg) <= (1e-11 if flags else 3e-5) * abs(lo)
         assert_state_equal(orc, inst, exact=False, atol=1e-10 if flags else 3e-4)
+
+
+@pytest.mark.parametrize("k,n_dims,cpd,flags", [(64, 8, 43, 0), (64, 8, 43, F64), (10, 3, 30, F64), (128, 5, 100, 0), (256, 8, 120, F64), (100, 2, 40, 0)])
+def test_pipe_with_more_than_64_conditions_keeps_condbias_in_lds(k, n_dims, cpd, flags):
+    """Round 4: the real Frappe file has 343 conditions in 8 dimensions -- beyond the one-condition-per-lane register form.  There condBias
+    sits in LDS, the ids travel as 16-bit fields of two packed words, lane d reads / rewrites the d-th condition's entry.  Same order-exact
+    chain: = the sequential oracle (fp64: to rounding; fp32: the north_star tolerance)."""
+    data = util.small_data(n_users=200, n_items=150, n_dims=n_dims, conds_per_dim=cpd, n=4000 + k, seed=60 + k)
+    assert 64 < data.n_conds <= 1024
+    orc, inst, o_losses, o_lrs, g_losses, g_lrs = _run(data, k, flags)
+    assert g_lrs.tolist() == o_lrs.tolist()
+    np.testing.assert_allclose(g_losses, o_losses, rtol=1e-11 if flags else 3e-5)
+    assert_state_equal(orc, inst, exact=False, atol=1e-10 if flags else 3e-4)
+
+
+def test_lds_condbias_form_with_hazards_missing_conditions_and_odd_sizes():
+    """few users (every requested row rewritten inside the look-ahead), ragged contexts (some dimensions absent), n not a multiple of 64"""
+    base = util.small_data(n_users=4, n_items=90, n_dims=6, conds_per_dim=20, n=2777, seed=77)
+    # drop the last condition of every third context: ragged condition lists
+    ptr, conds = [0], []
+    for c in range(base.n_ctx):
+        row = base.ctx_conds[base.ctx_ptr[c]:base.ctx_ptr[c + 1]].tolist()
+        if c % 3 == 0:
+            row = row[:-1]
+        conds += row
+        ptr.append(len(conds))
+    data = dataclasses.replace(base, ctx_ptr=np.asarray(ptr, np.int32), ctx_conds=np.asarray(conds, np.int32))
+    for flags in (F64, 0):
+        orc, inst, o_losses, _, g_losses, _ = _run(data, 64, flags, epochs=3)
+        np.testing.assert_allclose(g_losses, o_losses, rtol=1e-11 if flags else 3e-5)
+        assert_state_equal(orc, inst, exact=False, atol=1e-10 if flags else 3e-4)
