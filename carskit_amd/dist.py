@@ -57,7 +57,9 @@ class GpuEngine:
         self.device = torch.device("cuda", device_index)
         self.lib_comm = False
         self.exchange_path = "torch.distributed collectives on the instance's stream"
-        if dist is not None and dist.is_initialized() and dist.get_backend(group) == "nccl":
+        import os
+        if dist is not None and dist.is_initialized() and dist.get_backend(group) == "nccl" and not os.environ.get("CMI_DIST_TORCH"):
+            # (CMI_DIST_TORCH=1: let torch issue the collectives even under RCCL -- the A/B of the two issuers of the same exchange)
             rank = dist.get_rank(group)
             idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=self.device)
             if rank == 0:
