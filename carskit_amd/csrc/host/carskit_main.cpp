@@ -89,7 +89,7 @@ static std::string evalInfo(const Measures &m, const Conf &conf) { // Recommende
     return buf;
 }
 
-static int run(const std::string &config, unsigned flags, int iters_override, bool precise, bool load_model) {
+static int run(const std::string &config, unsigned flags, int iters_override, bool precise, bool load_model, int shards, double shards_lrscale) {
     Logger log = [](const std::string &s) { std::cout << s << std::endl; };
     FileConfiger cf(config);
     Conf conf(cf);
@@ -105,6 +105,8 @@ static int run(const std::string &config, unsigned flags, int iters_override, bo
     log("WorkingPath: " + work);
     conf.workingPath = work;
     conf.loadModel = load_model;
+    conf.shards = shards;
+    conf.shardsLrScale = shards_lrscale;
     LineConfiger ev = cf.getParamOptions("evaluation.setup");
     const std::string mode = lower(ev.getMainParam());
     const std::string testFile = mode == "test-set" ? ev.getString("-f") : "";
@@ -204,6 +206,8 @@ int main(int argc, char **argv) {
     unsigned flags = 0;
     int iters = 0;
     bool precise = false, load_model = false;
+    int shards = 1;
+    double shards_lrscale = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-c") && i + 1 < argc) configs.push_back(argv[++i]);
         else if (!strcmp(argv[i], "--flags") && i + 1 < argc) flags = (unsigned)std::strtoul(argv[++i], nullptr, 0);
@@ -217,15 +221,17 @@ int main(int argc, char **argv) {
             for (int v : lab) printf(" %d", v);
             printf("\n");
             return 0;
-        } else if (!strcmp(argv[i], "--load-model")) load_model = true; // evaluate the models `--save-model` left in the workspace instead of training
+        } else if (!strcmp(argv[i], "--shards") && i + 1 < argc) shards = std::max(1, std::atoi(argv[++i])); // one recommender over N GPUs (cmi_group_*)
+        else if (!strcmp(argv[i], "--shards-lrscale") && i + 1 < argc) shards_lrscale = std::atof(argv[++i]);
+        else if (!strcmp(argv[i], "--load-model")) load_model = true; // evaluate the models `--save-model` left in the workspace instead of training
         else {
-            fprintf(stderr, "usage: carskit-mi355x -c setting.conf [-c more.conf] [--flags N] [--iters N] [--precise] [--load-model]\n");
+            fprintf(stderr, "usage: carskit-mi355x -c setting.conf [-c more.conf] [--flags N] [--iters N] [--precise] [--load-model] [--shards N [--shards-lrscale X]]\n");
             return 2;
         }
     }
     if (configs.empty()) configs.push_back("setting.conf");
     try {
-        for (const std::string &c : configs) run(c, flags, iters, precise, load_model);
+        for (const std::string &c : configs) run(c, flags, iters, precise, load_model, shards, shards_lrscale);
     } catch (const std::exception &e) { // the reference logs e.getMessage() and a stack trace (CARSKit.java:96-101)
         fprintf(stderr, "ERROR: %s\n", e.what());
         return 1;

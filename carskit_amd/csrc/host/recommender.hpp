@@ -141,6 +141,8 @@ struct Conf {
     int64_t randSeed = 1;
     unsigned flags = 0;
     int device = 0;
+    int shards = 1;            // --shards N: ONE recommender sharded by user over N GPUs (cmi_group_*; the Java host's -Dcarskit.shards)
+    double shardsLrScale = 0;  // local learning-rate scale of a sharded run; 0 = sqrt(shards)
     // item.ranking / ratings.setup -threshold / eval.strategy (Recommender.java:211-217,242; CARSKit.java:262)
     bool isRankingPred = false;
     int numRecs = 10, numIgnore = -1;
@@ -223,6 +225,7 @@ class IterativeRecommender {
         globalMean = cnt ? s / (double)cnt : std::nan("");
     }
     virtual ~IterativeRecommender() {
+        if (g_) cmi_group_destroy(g_);
         if (h_) cmi_destroy(h_);
     }
 
@@ -286,9 +289,54 @@ class IterativeRecommender {
         }
     }
 
+    // --shards N (N > 1, models whose ratings commute): the epochs run on a cmi_group -- the library cuts the ratings by user, runs the
+    // shards' epochs concurrently and merges the item-side moves (RCCL reduce-scatter + all-gather, or in-process when shards share a
+    // device) -- steered by the unchanged isConverged(); `--early-stop MAE|RMSE` scores the shards' resident test tuples.  Afterwards the
+    // model is copied back and lives on in a plain handle, so evaluation / ranking / --save-model are the single-GPU code below.
+    void trainSharded(unsigned flags) {
+        auto gcheck = [&](int rc, const char *what) {
+            if (rc != CMI_OK) throw std::runtime_error(std::string(what) + ": " + cmi_group_last_error(g_));
+        };
+        int rc = cmi_group_create(model_, conf_.numFactors, trainMatrix.n_users, trainMatrix.n_items, trainMatrix.n_conds, conf_.shards, nullptr,
+                                  flags, &g_);
+        if (rc != CMI_OK) throw std::runtime_error(std::string("cmi_group_create: ") + cmi_group_last_error(nullptr));
+        gcheck(cmi_group_set_hparams(g_, conf_.regU, conf_.regI, conf_.regB, conf_.regC, globalMean), "cmi_group_set_hparams");
+        if (isCARS_) {
+            gcheck(cmi_group_set_ratings(g_, trainMatrix.n(), trainMatrix.u.data(), trainMatrix.j.data(), trainMatrix.ctx.data(),
+                                         trainMatrix.r.data(), (int32_t)trainMatrix.ctx_ptr.size() - 1, trainMatrix.ctx_ptr.data(),
+                                         trainMatrix.ctx_conds.data()),
+                   "cmi_group_set_ratings");
+        } else {
+            std::vector<int32_t> u2, j2;
+            std::vector<double> r2;
+            to2d(trainMatrix, u2, j2, r2);
+            gcheck(cmi_group_set_ratings(g_, (int64_t)r2.size(), u2.data(), j2.data(), nullptr, r2.data(), 0, nullptr, nullptr), "cmi_group_set_ratings");
+        }
+        for (auto &kv : state) gcheck(cmi_group_set_state(g_, kv.first, kv.second.data(), (int64_t)kv.second.size(), CMI_DTYPE_F64), "cmi_group_set_state");
+        gcheck(cmi_group_set_lr_scale(g_, conf_.shardsLrScale > 0 ? conf_.shardsLrScale : std::sqrt((double)conf_.shards)), "cmi_group_set_lr_scale");
+        if (conf_.earlyStop == "MAE" || conf_.earlyStop == "RMSE") {
+            gcheck(cmi_group_set_eval_ratings(g_, testMatrix.n(), testMatrix.u.data(), testMatrix.j.data(), isCARS_ ? testMatrix.ctx.data() : nullptr,
+                                              testMatrix.r.data()),
+                   "cmi_group_set_eval_ratings");
+            evalResident_ = testMatrix.n() > 0;
+        }
+        for (int iter = 1; iter <= conf_.numIters; ++iter) {
+            gcheck(cmi_group_train_epoch(g_, lRate, &loss), "cmi_group_train_epoch");
+            losses.push_back(loss);
+            itersDone = iter;
+            if (isConverged(iter)) break;
+        }
+        for (auto &kv : state) gcheck(cmi_group_get_state(g_, kv.first, kv.second.data(), (int64_t)kv.second.size(), CMI_DTYPE_F64), "cmi_group_get_state");
+        cmi_group_destroy(g_);
+        g_ = nullptr;
+        evalResident_ = false;
+    }
+
     virtual void buildModel() {
         const bool chained = model_ == CMI_MODEL_CAMF_C || (model_ >= CMI_MODEL_SVDPP && model_ <= CMI_MODEL_CAMF_MCS);
         unsigned flags = conf_.flags | (chained ? CMI_FLAG_SCHED_SERIAL : 0u); // one dependent chain in CRS order
+        const bool sharded = conf_.shards > 1 && !chained && !conf_.loadModel;
+        if (sharded) trainSharded(flags);
         int rc = cmi_create(model_, conf_.numFactors, trainMatrix.n_users, trainMatrix.n_items, trainMatrix.n_conds,
                             conf_.device, flags, &h_);
         if (rc != CMI_OK) throw std::runtime_error(std::string("cmi_create: ") + cmi_last_error(nullptr));
@@ -312,7 +360,7 @@ class IterativeRecommender {
         if (*cmi_schedule_note(h_) && log_) log_(std::string("note: ") + cmi_schedule_note(h_));
         for (auto &kv : state) // copy-in
             check(cmi_set_state(h_, kv.first, kv.second.data(), (int64_t)kv.second.size(), CMI_DTYPE_F64), h_, "cmi_set_state");
-        if (conf_.earlyStop == "MAE" || conf_.earlyStop == "RMSE") { // evaluated after every epoch: keep the test tuples on the device
+        if (!sharded && (conf_.earlyStop == "MAE" || conf_.earlyStop == "RMSE")) { // evaluated after every epoch: keep the test tuples on the device
             check(cmi_set_eval_ratings(h_, testMatrix.n(), testMatrix.u.data(), testMatrix.j.data(),
                                        isCARS_ ? testMatrix.ctx.data() : nullptr, testMatrix.r.data()),
                   h_, "cmi_set_eval_ratings");
@@ -323,7 +371,7 @@ class IterativeRecommender {
             check(cmi_load_model(h_, modelPath().c_str(), &lRate, &last_loss, &done), h_, "cmi_load_model");
             itersDone = done;
             if (log_) log_("A recommender model is loaded from " + modelPath());
-        } else {
+        } else if (!sharded) {
             for (int iter = 1; iter <= conf_.numIters; ++iter) {
                 check(cmi_train_epoch(h_, lRate, &loss), h_, "cmi_train_epoch"); // the for(MatrixEntry me : trainMatrix) body
                 losses.push_back(loss);
@@ -338,7 +386,10 @@ class IterativeRecommender {
     virtual Measures evalRatings() { // Recommender.java:504-594 (numeric part)
         double out[5] = {0, 0, 0, 0, 0};
         int64_t cnt = 0;
-        if (evalResident_)
+        if (evalResident_ && g_) {
+            if (cmi_group_eval_resident(g_, trainMatrix.min_rate, trainMatrix.max_rate, out, &cnt) != CMI_OK)
+                throw std::runtime_error(std::string("cmi_group_eval_resident: ") + cmi_group_last_error(g_));
+        } else if (evalResident_)
             check(cmi_eval_resident(h_, trainMatrix.min_rate, trainMatrix.max_rate, out, &cnt), h_, "cmi_eval_resident");
         else
         check(cmi_eval_ratings(h_, testMatrix.n(), testMatrix.u.data(), testMatrix.j.data(),
@@ -457,6 +508,7 @@ class IterativeRecommender {
     Conf conf_;
     Logger log_;
     cmi_handle h_ = nullptr;
+    cmi_group_handle g_ = nullptr; // live only inside trainSharded()
 };
 
 #define CARSKIT_MODEL(cls, id, cars) CARSKIT_NAMED_MODEL(cls, #cls, id, cars)

@@ -185,3 +185,58 @@ def test_group_rejects_serial_chain_models_and_bad_calls():
         g.set_state("Q", np.zeros((20, 8)))
     with pytest.raises(capi.CmiError):
         capi.Group("CAMF_CI", 8, 100, 20, 6, 2, devices=[0, 99])
+
+
+@pytest.mark.parametrize("early", [None, "RMSE"])
+def test_cpp_host_shards_flag_runs_the_group_and_prints_its_numbers(tmp_path, early):
+    """`carskit-mi355x -c setting.conf --shards 2`: the product host trains ONE recommender over a cmi_group (on this box both shards share
+    the GPU: the in-process exchange), steered by its unchanged isConverged() -- with `--early-stop RMSE` through the shards' resident test
+    tuples -- then evaluates the copied-back model.  Expected numbers: the same folds and C++ init stream through capi.Group behind the
+    Python host mirror (local rate x sqrt(2), the hosts' rule)."""
+    import re
+    import subprocess
+    from tests.test_host_layer import EXE, _depaul_conf, expected_from_oracle
+
+    class GroupEngine:
+        def __init__(self, model, k, data, tuples, hp, flags=0, device=0):
+            u, j, ctx, r = tuples
+            self.g = capi.Group(model, k, data.n_users, data.n_items, data.n_conds, 2, devices=[0, 0], flags=flags)
+            self.g.set_hparams(hp["regU"], hp["regI"], hp["regB"], hp["regC"], hp["gm"])
+            self.g.set_ratings(u, j, ctx, r, data.ctx_ptr, data.ctx_conds)
+            self.g.set_lr_scale(np.sqrt(2.0))
+
+        def set_states(self, st):
+            self.g.set_states(st)
+
+        def get_states(self):
+            return self.g.get_states()
+
+        def epoch(self, lr):
+            return self.g.train_epoch(lr)
+
+        def eval_ratings(self, u, j, ctx, r, lo, hi):
+            return self.g.eval_ratings(u, j, ctx, r, lo, hi)
+
+        def set_eval_ratings(self, u, j, ctx, r):
+            self.g.set_eval_ratings(u, j, ctx, r)
+            self.eval_resident_ready = len(r) > 0
+
+        def eval_resident(self, lo, hi):
+            return self.g.eval_resident(lo, hi)
+
+    conf = _depaul_conf(tmp_path)
+    txt = open(conf).read().replace("recommender=biasedmf", "recommender=camf_ci")
+    if early:
+        txt = txt.replace("--test-view all", "--test-view all --early-stop " + early)
+    open(conf, "w").write(txt)
+    flags = capi.FLAG_STATE_F64
+    want = expected_from_oracle(conf, "camf_ci", 12, engine_factory=lambda *a, **kw: GroupEngine(*a, **dict(kw, flags=flags)))
+    p = subprocess.run([EXE, "-c", conf, "--iters", "12", "--flags", str(flags), "--precise", "--shards", "2"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    m = re.search(r"PRECISE CAMF_CI folds=5 MAE=(\S+) RMSE=(\S+)", p.stdout)
+    assert m, p.stdout[-400:] + p.stderr
+    assert abs(float(m.group(1)) - want["MAE"]) <= 1e-9 and abs(float(m.group(2)) - want["RMSE"]) <= 1e-9
+    # and it is NOT the single-GPU run: the merged two-shard model differs from the sequential one
+    q = subprocess.run([EXE, "-c", conf, "--iters", "12", "--flags", str(flags), "--precise"], capture_output=True, text=True)
+    m1 = re.search(r"PRECISE CAMF_CI folds=5 MAE=(\S+) RMSE=(\S+)", q.stdout)
+    assert m1 and abs(float(m1.group(2)) - float(m.group(2))) > 1e-6

@@ -232,9 +232,9 @@ def _cpp_init(model, train, k, seed):
     return st
 
 
-def expected_from_oracle(conf_path, model_cls_name, iters):
+def expected_from_oracle(conf_path, model_cls_name, iters, engine_factory=None):
     """What the C++ driver must print for a cv run: same transformer/DAO/fold assignment (shared C ABI + the Python
-    splitter, itself checked against the recipe), the C++ init stream, the oracle as the engine."""
+    splitter, itself checked against the recipe), the C++ init stream, the oracle as the engine (or `engine_factory`)."""
     class Cls(recommender.RECOMMENDERS[model_cls_name]):
         def initModel(self):
             self.trainMatrix.meta["num_f"] = self.conf.num_f
@@ -242,7 +242,7 @@ def expected_from_oracle(conf_path, model_cls_name, iters):
     saved = recommender.RECOMMENDERS[model_cls_name]
     recommender.RECOMMENDERS[model_cls_name] = Cls
     try:
-        avg, _, _ = main.run(conf_path, engine_factory=util.OracleEngine, log=lambda *a: None,
+        avg, _, _ = main.run(conf_path, engine_factory=engine_factory or util.OracleEngine, log=lambda *a: None,
                              conf_overrides={"num_iters": iters})
     finally:
         recommender.RECOMMENDERS[model_cls_name] = saved
