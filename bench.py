@@ -303,6 +303,18 @@ def bench_group(args):
     return out
 
 
+def rank_roofline(train, nq, n_cand, dev, flops, k, n_conds):
+    n_users_q = None
+    slab1 = lambda ng: 2.0 * ng * n_cand * 4            # S1 written + read once
+    ng = flops and max(1.0, flops / (2.0 * n_cand * ((k + 1 + 15) // 16 * 16)))   # upper estimate of the distinct query users from the flop count
+    hbm = slab1(ng)
+    cache = 2.0 * nq * n_cand * 4                        # every query streams one S1 row and one S2 row
+    return {"achieved": hbm / dev / 1e9, "frac": hbm / dev / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "bytes_model": "S1 slab (distinct query users x candidates x 4 B) written by the contraction and read by the selection",
+            "cache_traffic_GBps": cache / dev / 1e9, "contraction_flops": flops, "contraction_TFLOPs_over_whole_loop": flops / dev / 1e12,
+            "kernel": "rank_topn_split<float> (2/3 of the loop) + rank_gemm_mfma_f32 (v_mfma_f32_32x32x2_f32)"}
+
+
 def bench_rank(args):
     """--workload rank: Recommender.evalRankings (Recommender.java:668-964) for CAMF_CI k=128: every test (user, context) query scores
     ALL candidate items -- the one GEMM-shaped operation of this code base (f32 matrix cores).  A step = one whole evaluation."""
@@ -327,6 +339,7 @@ def bench_rank(args):
     dev = float(np.mean(ms)) * 1e-3
     wall = float(np.mean(walls))
     nq = res["n_queries"]
+    n_cand = int(len(np.unique(train.j)))
     # value = queries / WALL time of the whole cmi_eval_rankings call (plan + uploads + scoring + lists back + measures), timed
     # around the C-ABI call on the host; the roofline object prices the device scoring loop (HIP events) against the f32 MFMA peak
     out = {"metric": "evalRankings queries/sec, %s k=%d" % (model, k), "value": nq / wall, "unit": "queries/s", "n_gpus": 1,
@@ -338,9 +351,12 @@ def bench_rank(args):
                       "host_ms_breakdown_last_step": inst.last_rank_host_ms(),
                       "note": "value = queries / host wall clock of the whole call: the plan (candidates, queries, exclusions; host threads), "
                               "uploads, the device scoring loop, and the per-query measures computed batch by batch behind the device"},
-           "roofline": {"bound": "mfma", "achieved": flops / dev / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / dev / 1e12 / 157.3,
-                        "flops_model": "2 x queries x candidates x padded operand length of the contraction, over the WHOLE scoring loop "
-                                       "(operand gather + contraction + selection)", "kernel": "rank_gemm_mfma_f32 (v_mfma_f32_32x32x2_f32)"},
+           # The MF family in fp32 runs the SPLIT form (S1 per distinct query user + S2 per distinct context, added by the selection): 7x fewer
+           # matrix-core flops than one dot product per query, and the loop is bound by the selection's row streaming, not by the
+           # contraction.  `achieved` = the HBM-compulsory bytes of the loop (the S1 slab written by the contraction and read by the
+           # selection, the S2 slab, the operands) / device time; the selection additionally re-reads S1 / S2 rows out of L2 / Infinity
+           # Cache once per QUERY (`cache_traffic_GBps`).  The contraction's own rate rides along as `contraction_flops`.
+           "roofline": dict(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", **rank_roofline(train, nq, n_cand, dev, flops, k, train.n_conds)),
            "AUC10": res["AUC10"]}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, k, train, state, float(train.r.mean()), (1e-4, 1e-4, 1e-4, 1e-3), 0.0, 0, rank_queries=(test, 200))

@@ -349,7 +349,7 @@ hipError_t RankWorkspace::need(Buf &b, size_t bytes, bool pinned) {
 }
 
 void RankWorkspace::release() {
-    Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount};
+    Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount, &dB2, &dA2, &dS2, &dqg, &dqd, &dgu, &ddc, &dscr};
     for (Buf *b : dev) {
         if (b->p) (void)hipFree(b->p);
         *b = Buf();
@@ -459,6 +459,169 @@ hipError_t rank_run_device(hipStream_t stream, RankWorkspace &ws, const RankPlan
     if (flops) *flops = 2.0 * (double)nq * (double)nc * (double)kp;
     return e;
 }
+
+// ---- the split form (MF family, fp32 state): see rank_kernels.hip "the split form" ---------------------------------------------------------
+namespace {
+// distinct contexts of the queries (ascending context id) and the dense index of every query's context: O(queries + contexts)
+void distinct_contexts(const std::vector<int32_t> &qc, std::vector<int32_t> &dctx, std::vector<int32_t> &qd) {
+    int32_t mx = -1;
+    for (int32_t c : qc) mx = std::max(mx, c);
+    std::vector<int32_t> idx((size_t)mx + 2, -1);
+    for (int32_t c : qc) idx[(size_t)c] = 0;
+    dctx.clear();
+    for (int32_t c = 0; c <= mx; ++c)
+        if (idx[(size_t)c] == 0) {
+            idx[(size_t)c] = (int32_t)dctx.size();
+            dctx.push_back(c);
+        }
+    qd.resize(qc.size());
+    for (size_t i = 0; i < qc.size(); ++i) qd[i] = idx[(size_t)qc[i]];
+}
+} // namespace
+
+bool rank_split_usable(const RankPlan &plan, int topn) {
+    if (topn > 64 || plan.qu.empty() || plan.cand.empty() || getenv("CMI_RANK_NO_SPLIT")) return false;
+    // S2 = distinct contexts x candidates x 4 bytes must stay small (it is re-read by every query of the context)
+    std::vector<int32_t> dctx, qd;
+    distinct_contexts(plan.qc, dctx, qd);
+    return (int64_t)dctx.size() * (int64_t)plan.cand.size() * 4 <= ((int64_t)512 << 20);
+}
+
+hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const RankPlan &plan, RankSplitArgs a, double thold, int topn,
+                                 const std::function<void(int64_t, int64_t)> &on_batch, float *ms, double *flops) {
+    const auto t_setup = std::chrono::steady_clock::now();
+    const int nc = (int)plan.cand.size();
+    const int64_t nq = (int64_t)plan.qu.size();
+    // query groups = runs of one user (the plan orders the queries by user, then context)
+    std::vector<int32_t> gu, qg((size_t)nq), gq0; // group -> user; query -> group; group -> first query
+    for (int64_t q = 0; q < nq; ++q) {
+        if (q == 0 || plan.qu[(size_t)q] != plan.qu[(size_t)q - 1]) {
+            gu.push_back(plan.qu[(size_t)q]);
+            gq0.push_back((int32_t)q);
+        }
+        qg[(size_t)q] = (int32_t)gu.size() - 1;
+    }
+    gq0.push_back((int32_t)nq);
+    const int64_t ng = (int64_t)gu.size();
+    std::vector<int32_t> dctx, qd;
+    const bool ic = a.icBias != nullptr;
+    if (ic) distinct_contexts(plan.qc, dctx, qd);
+    const int n_dc = (int)dctx.size();
+    a.kp1 = (a.k + 1 + 15) / 16 * 16;
+    a.kp2 = ic ? (a.n_conds + 15) / 16 * 16 : 16;
+    a.nc = nc;
+    a.nq = (int)nq;
+    a.n_dctx = n_dc;
+    auto up128 = [](int64_t v) { return (size_t)((v + 127) / 128 * 128); };
+    // user groups per batch: an S1 slab of about 1 GiB (256-MiB batches were measured slower: 15.3 against 10.7 ms for the loop)
+    int64_t bg = std::max<int64_t>(64, ((int64_t)1 << 30) / ((int64_t)nc * 4));
+    bg = std::min<int64_t>(bg, ng);
+    if (const char *e = getenv("CMI_RANK_BATCH")) bg = std::max<int64_t>(1, std::min<int64_t>(atoll(e), ng)); // tests: batching is invisible
+
+    hipError_t e = hipSuccess;
+    auto need = [&](RankWorkspace::Buf &b, size_t bytes, bool pinned = false) {
+        if (e == hipSuccess) e = ws.need(b, bytes, pinned);
+    };
+    need(ws.dB, up128(nc) * a.kp1 * 4);
+    need(ws.dA, up128(bg) * a.kp1 * 4);
+    need(ws.dS, (size_t)bg * (size_t)nc * 4);
+    need(ws.dscr, std::max<size_t>(up128(bg), up128(n_dc)) * 4);
+    need(ws.drc, (size_t)nq * 4);
+    if (ic) {
+        need(ws.dB2, up128(nc) * a.kp2 * 4);
+        need(ws.dA2, up128(n_dc) * a.kp2 * 4);
+        need(ws.dS2, (size_t)n_dc * (size_t)nc * 4);
+        need(ws.ddc, (size_t)n_dc * 4);
+        need(ws.dqd, (size_t)nq * 4);
+    }
+    need(ws.dcand, (size_t)nc * 4);
+    need(ws.dqu, (size_t)nq * 4);
+    need(ws.dqc, (size_t)nq * 4);
+    need(ws.dqg, (size_t)nq * 4);
+    need(ws.dgu, (size_t)ng * 4);
+    need(ws.dexptr, (size_t)(nq + 1) * 8);
+    need(ws.dexcl, plan.excl_idx.size() * 4);
+    need(ws.dtop, (size_t)nq * topn * 4);
+    need(ws.dscore, (size_t)nq * topn * 8);
+    need(ws.dcount, (size_t)nq * 4);
+    need(ws.h_top, (size_t)nq * topn * 4, true);
+    need(ws.h_score, (size_t)nq * topn * 8, true);
+    need(ws.h_count, (size_t)nq * 4, true);
+    hipEvent_t *evs[] = {&ws.ev0, &ws.ev1, &ws.evb[0], &ws.evb[1]};
+    for (hipEvent_t *ev : evs)
+        if (e == hipSuccess && !*ev) e = hipEventCreate(ev);
+    if (e != hipSuccess) return e;
+    auto up = [&](void *d, const void *s, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream);
+    };
+    up(ws.dcand.p, plan.cand.data(), (size_t)nc * 4);
+    up(ws.dqu.p, plan.qu.data(), (size_t)nq * 4);
+    up(ws.dqc.p, plan.qc.data(), (size_t)nq * 4);
+    up(ws.dqg.p, qg.data(), (size_t)nq * 4);
+    up(ws.dgu.p, gu.data(), (size_t)ng * 4);
+    up(ws.dexptr.p, plan.excl_ptr.data(), (size_t)(nq + 1) * 8);
+    up(ws.dexcl.p, plan.excl_idx.data(), plan.excl_idx.size() * 4);
+    if (ic) {
+        up(ws.ddc.p, dctx.data(), (size_t)n_dc * 4);
+        up(ws.dqd.p, qd.data(), (size_t)nq * 4);
+    }
+    int32_t *dtop = (int32_t *)ws.dtop.p, *dcount = (int32_t *)ws.dcount.p;
+    double *dscore = (double *)ws.dscore.p;
+    if (e == hipSuccess) e = hipMemsetAsync(dtop, 0xff, (size_t)nq * topn * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dscore, 0, (size_t)nq * topn * 8, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ws.dscr.p, 0, std::max<size_t>(up128(bg), up128(n_dc)) * 4, stream);
+    a.cand = (const int32_t *)ws.dcand.p;
+    a.qu = (const int32_t *)ws.dqu.p;
+    a.qc = (const int32_t *)ws.dqc.p;
+    a.dctx = (const int32_t *)ws.ddc.p;
+    a.B1 = (float *)ws.dB.p;
+    a.B2 = (float *)ws.dB2.p;
+    a.A2 = (float *)ws.dA2.p;
+    a.rc = (float *)ws.drc.p;
+    if (e == hipSuccess) e = rank_launch_split_operands(a, stream);
+    if (e == hipSuccess) e = hipEventRecord(ws.ev0, stream);
+    // S2: once per evaluation (row constant = the zeroed scratch)
+    if (e == hipSuccess && ic) e = rank_launch_gemm<float>(a.A2, a.B2, (const float *)ws.dscr.p, (float *)ws.dS2.p, n_dc, nc, a.kp2, stream);
+    ws.host_ms[1] = ms_since(t_setup);
+    const auto t_loop = std::chrono::steady_clock::now();
+    int64_t prev0 = -1, prev1 = -1;
+    int nb = 0;
+    for (int64_t g0 = 0; g0 < ng && e == hipSuccess; g0 += bg, ++nb) {
+        const int n = (int)std::min<int64_t>(bg, ng - g0);
+        const int64_t q0 = gq0[(size_t)g0], q1 = gq0[(size_t)(g0 + n)];
+        // (the builder leaves its per-row constant -- zero here -- in the scratch the contraction then reads as its row constant)
+        e = rank_launch_split_users(a, (const int32_t *)ws.dgu.p + g0, n, (float *)ws.dA.p, (float *)ws.dscr.p, stream);
+        if (e == hipSuccess) e = rank_launch_gemm<float>((const float *)ws.dA.p, a.B1, (const float *)ws.dscr.p, (float *)ws.dS.p, n, nc, a.kp1, stream);
+        if (e == hipSuccess)
+            e = rank_launch_split_select((const float *)ws.dS.p, ic ? (const float *)ws.dS2.p : nullptr, a, (const int32_t *)ws.dqg.p,
+                                         (const int32_t *)ws.dqd.p, (int)g0, (int)q0, (int)(q1 - q0), (const int64_t *)ws.dexptr.p,
+                                         (const int32_t *)ws.dexcl.p, thold, topn, dtop, dscore, dcount, stream);
+        const size_t nqb = (size_t)(q1 - q0);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync((int32_t *)ws.h_top.p + (size_t)q0 * topn, dtop + (size_t)q0 * topn, nqb * topn * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync((double *)ws.h_score.p + (size_t)q0 * topn, dscore + (size_t)q0 * topn, nqb * topn * 8, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync((int32_t *)ws.h_count.p + q0, dcount + q0, nqb * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipEventRecord(ws.evb[nb & 1], stream);
+        if (e == hipSuccess && prev0 >= 0) {
+            e = hipEventSynchronize(ws.evb[(nb - 1) & 1]);
+            if (e == hipSuccess && on_batch) on_batch(prev0, prev1);
+        }
+        prev0 = q0;
+        prev1 = q1;
+    }
+    if (e == hipSuccess) e = hipEventRecord(ws.ev1, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    ws.host_ms[2] = ms_since(t_loop);
+    const auto t_tail = std::chrono::steady_clock::now();
+    if (e == hipSuccess && prev0 >= 0 && on_batch) on_batch(prev0, prev1);
+    ws.host_ms[3] = ms_since(t_tail);
+    if (e == hipSuccess && ms) e = hipEventElapsedTime(ms, ws.ev0, ws.ev1);
+    // flops of THIS form: the two contractions it actually runs
+    if (flops) *flops = 2.0 * (double)ng * (double)nc * (double)a.kp1 + (ic ? 2.0 * (double)n_dc * (double)nc * (double)a.kp2 : 0.0);
+    return e;
+}
+
 template hipError_t rank_run_device<float>(hipStream_t, RankWorkspace &, const RankPlan &, const RankOperands<float> &, double, int,
                                            const std::function<void(int64_t, int64_t)> &, float *, double *);
 template hipError_t rank_run_device<double>(hipStream_t, RankWorkspace &, const RankPlan &, const RankOperands<double> &, double, int,
@@ -658,8 +821,23 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
                                                  &h->last_rank_ms, &h->last_rank_flops);
         else if (h->f64) e = rank_run_device<double>(h->stream, ws, plan, mf_operands<double>(h, k_logical, contextual, ic_used), bin_thold,
                                                      num_recs, on_batch, &h->last_rank_ms, &h->last_rank_flops);
-        else e = rank_run_device<float>(h->stream, ws, plan, mf_operands<float>(h, k_logical, contextual, ic_used), bin_thold, num_recs,
-                                        on_batch, &h->last_rank_ms, &h->last_rank_flops);
+        else if (rank_split_usable(plan, num_recs)) {
+            RankSplitArgs sa{};
+            sa.P = (const float *)h->state[CMI_STATE_P];
+            sa.Q = (const float *)h->state[CMI_STATE_Q];
+            sa.userBias = (const float *)h->state[CMI_STATE_USER_BIAS];
+            sa.itemBias = (const float *)h->state[CMI_STATE_ITEM_BIAS];
+            sa.ucBias = (const float *)h->state[CMI_STATE_UC_BIAS];
+            sa.icBias = ic_used ? (const float *)h->state[CMI_STATE_IC_BIAS] : nullptr;
+            sa.condBias = (const float *)h->state[CMI_STATE_COND_BIAS];
+            sa.ctx_ptr = contextual ? h->d_ctx_ptr : nullptr;
+            sa.ctx_conds = contextual ? h->d_ctx_conds : nullptr;
+            sa.gm = h->hp.gm;
+            sa.k = h->k;
+            sa.n_conds = h->n_conds;
+            e = rank_run_device_split(h->stream, ws, plan, sa, bin_thold, num_recs, on_batch, &h->last_rank_ms, &h->last_rank_flops);
+        } else e = rank_run_device<float>(h->stream, ws, plan, mf_operands<float>(h, k_logical, contextual, ic_used), bin_thold, num_recs,
+                                          on_batch, &h->last_rank_ms, &h->last_rank_flops);
         CMI_HIP(h, e);
         top_count = (const int32_t *)ws.h_count.p;
     } else {

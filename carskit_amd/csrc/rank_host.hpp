@@ -46,6 +46,7 @@ struct RankWorkspace {
         size_t cap = 0;
     };
     Buf dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount; // device
+    Buf dB2, dA2, dS2, dqg, dqd, dgu, ddc, dscr;                                // device, split form (rank_run_device_split)
     Buf h_top, h_score, h_count;                                                // pinned host: the lists as they come back
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evb[2] = {nullptr, nullptr};
     // host wall clock of the last evaluation, ms: [0] plan, [1] setup (buffers, uploads, item operands), [2] scoring loop incl. the
@@ -60,6 +61,13 @@ struct RankWorkspace {
 template <typename T>
 hipError_t rank_run_device(hipStream_t stream, RankWorkspace &ws, const RankPlan &plan, const RankOperands<T> &ops, double thold, int topn,
                            const std::function<void(int64_t, int64_t)> &on_batch, float *ms, double *flops);
+
+// The split form for the MF family in fp32 (rank_kernels.hip): S1 per distinct query user, S2 per distinct context, added by the selection.
+struct RankSplitArgs;
+hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const RankPlan &plan, RankSplitArgs base, double thold, int topn,
+                                 const std::function<void(int64_t, int64_t)> &on_batch, float *ms, double *flops);
+// whether the split form applies: S2 must stay small (distinct contexts x candidates) and the lists must fit the register selection
+bool rank_split_usable(const RankPlan &plan, int topn);
 
 // the 18 measures of the lists of queries [q0, q1) -> vals[q * 18 + m] (threads over ranges of queries); optional per-query outputs
 void rank_measures_range(const RankPlan &plan, int num_recs, const int32_t *top_idx, const double *top_score, const int32_t *top_count,

@@ -392,6 +392,122 @@ __global__ __launch_bounds__(256) void rank_topn_stream(const T *__restrict__ S,
     if (lane == 0) out_count[q_base + q] = count;
 }
 
+
+// ---- the split form of the MF family's scores (round 4; fp32 state) ----------------------------------------------------------------------
+// For BiasedMF / PMF / CAMF_C / CAMF_CI / CAMF_CU / CAMF_CUCI the item-dependent part of predict(u, j, c) is a SUM of a part that
+// depends on (user, item) only and a part that depends on (context, item) only:
+//     score[q][j] = ( <P[u_q], Q[j]> + itemBias[j] )  +  sum_{cond in c_q} icBias[j][cond]  +  row_const[q]
+//                 =        S1[u_q][j]               +          S2[c_q][j]                  +  rc[q]
+// A test user appears in several contexts (5.4 queries per user in the bench's case) and far fewer distinct contexts exist than queries,
+// so contracting per QUERY repeats the k-long user part once per context.  The split form contracts S1 once per distinct query USER
+// (operand length k + 1) and S2 once per distinct CONTEXT (operand length n_conds), and the selection adds the two rows while it streams
+// them: 7x fewer matrix-core flops and a 5x smaller slab in the bench's case.  fp32 only (a different association of the same sum than
+// the per-query dot product: inside the fp32 tolerance of the ranking tests; the fp64 verification path keeps the per-query contraction).
+template <typename T>
+__global__ void rank_build_ic_items(const T *__restrict__ icBias, const int32_t *__restrict__ cand, T *__restrict__ B2, int n_conds, int kp2) {
+    const int c = blockIdx.x, j = cand[c];
+    for (int f = threadIdx.x; f < kp2; f += blockDim.x) B2[(size_t)c * kp2 + f] = f < n_conds ? icBias[(size_t)j * n_conds + f] : (T)0;
+}
+// one-hot rows of the distinct contexts' condition lists
+template <typename T>
+__global__ void rank_build_ctx_rows(const int32_t *__restrict__ ctx_ptr, const int32_t *__restrict__ ctx_conds, const int32_t *__restrict__ dctx,
+                                    T *__restrict__ A2, int kp2) {
+    const int r = blockIdx.x, c = dctx[r];
+    for (int f = threadIdx.x; f < kp2; f += blockDim.x) A2[(size_t)r * kp2 + f] = (T)0;
+    __syncthreads();
+    for (int p = ctx_ptr[c] + threadIdx.x; p < ctx_ptr[c + 1]; p += blockDim.x) A2[(size_t)r * kp2 + ctx_conds[p]] = (T)1;
+}
+// rc[q]: every predict() term that does not depend on the item (as rank_build_queries computes it)
+template <typename T>
+__global__ void rank_query_consts(RankQueryArgs<T> a, int nq) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int u = a.qu[q], c = a.qc[q];
+    T rc = (T)a.gm;
+    if (a.userBias) rc += a.userBias[u];
+    if (a.ctx_ptr)
+        for (int p = a.ctx_ptr[c]; p < a.ctx_ptr[c + 1]; ++p) {
+            const int cond = a.ctx_conds[p];
+            if (a.ucBias) rc += a.ucBias[(size_t)u * a.n_conds + cond];
+            if (a.condBias) rc += a.condBias[cond];
+        }
+    a.row_const[q] = rc;
+}
+
+// top-N of query q over  S1[group of q] + S2[context of q] + rc[q]  with the query's exclusion list (ascending candidate positions)
+// skipped on the fly -- the slab rows are shared between queries, so nothing is masked in place.  Same list discipline as
+// rank_topn_stream (lane r = rank r, an equal score never overtakes an earlier one).
+template <typename T>
+__global__ __launch_bounds__(256) void rank_topn_split(const T *__restrict__ S1, const T *__restrict__ S2, const T *__restrict__ rc,
+                                                       const int32_t *__restrict__ q_group, const int32_t *__restrict__ q_dctx, int g_base, int q0,
+                                                       int nq, int nc, const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_idx,
+                                                       double thold, int topn, int32_t *out_idx, double *out_score, int32_t *out_count) {
+    const int lane = threadIdx.x & 63;
+    const int q = q0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= q0 + nq) return;
+    const T *row1 = S1 + (size_t)(q_group[q] - g_base) * nc;
+    const T *row2 = S2 ? S2 + (size_t)q_dctx[q] * nc : nullptr;
+    const T c0 = rc[q];
+    int64_t ep = excl_ptr[q];
+    const int64_t ee = excl_ptr[q + 1];
+    int next_excl = ep < ee ? excl_idx[ep] : 0x7fffffff;
+    T lv = -INFINITY;
+    int li = -1;
+    int count = 0;
+    T t = -INFINITY;
+    for (int base = 0; base < nc; base += 64 * RT_U) {
+        T v[RT_U];
+#pragma unroll
+        for (int u = 0; u < RT_U; ++u) {
+            const int c = base + u * 64 + lane;
+            T x = -INFINITY;
+            if (c < nc) {
+                x = row1[c];
+                if (row2) x += row2[c];
+                x += c0;
+            }
+            v[u] = x;
+        }
+        // the (few) already-rated items of this query that fall into this step's 64 * RT_U candidates: wave-uniform walk
+        while (next_excl < base + 64 * RT_U) {
+            const int off = next_excl - base;
+#pragma unroll
+            for (int u = 0; u < RT_U; ++u)
+                if (off >= u * 64 && off < (u + 1) * 64 && lane == off - u * 64) v[u] = -INFINITY;
+            ++ep;
+            next_excl = ep < ee ? excl_idx[ep] : 0x7fffffff;
+        }
+#pragma unroll
+        for (int u = 0; u < RT_U; ++u) {
+            unsigned long long m = __ballot((double)v[u] > thold && v[u] > -INFINITY && (count < topn || v[u] > t));
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const T cv = lane_bcast(v[u], l);
+                if (count == topn && !(cv > t)) continue;
+                const int pos = __popcll(__ballot(lane < count && lv >= cv));
+                const T uv = __shfl_up(lv, 1, 64);
+                const int ui = __shfl_up(li, 1, 64);
+                if (lane > pos) {
+                    lv = uv;
+                    li = ui;
+                }
+                if (lane == pos) {
+                    lv = cv;
+                    li = base + u * 64 + l;
+                }
+                if (count < topn) ++count;
+                if (count == topn) t = lane_bcast(lv, topn - 1);
+            }
+        }
+    }
+    if (lane < count) {
+        out_idx[(size_t)q * topn + lane] = li;
+        out_score[(size_t)q * topn + lane] = (double)lv;
+    }
+    if (lane == 0) out_count[q] = count;
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------------
 
 template <typename T>
@@ -407,9 +523,7 @@ hipError_t rank_launch_build_queries(const RankQueryArgs<T> &a, int nq, hipStrea
     return hipGetLastError();
 }
 template <typename T>
-hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp,
-                             const int64_t *excl_ptr, const int32_t *excl_idx, int q_base, double thold, int topn,
-                             int32_t *out_idx, double *out_score, int32_t *out_count, hipStream_t s) {
+hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s) {
     if (nq <= 0 || nc <= 0) return hipSuccess;
     static const bool force_valu = getenv("CMI_RANK_VALU") != nullptr; // A/B experiments only
     if constexpr (sizeof(T) == 4) {
@@ -417,12 +531,18 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
             const int tiles_c = (nc + RG_BN - 1) / RG_BN, n_tiles = tiles_c * ((nq + RG_BM - 1) / RG_BM);
             hipLaunchKernelGGL(rank_gemm_mfma_f32, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, s, (const float *)A,
                                (const float *)B, (const float *)row_const, (float *)S, nq, nc, kp, tiles_c, n_tiles);
-        } else {
-            hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, S, nq, nc, kp);
+            return hipGetLastError();
         }
-    } else {
-        hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, S, nq, nc, kp);
     }
+    hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, S, nq, nc, kp);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp,
+                             const int64_t *excl_ptr, const int32_t *excl_idx, int q_base, double thold, int topn,
+                             int32_t *out_idx, double *out_score, int32_t *out_count, hipStream_t s) {
+    if (nq <= 0 || nc <= 0) return hipSuccess;
+    if (hipError_t e = rank_launch_gemm<T>(A, B, row_const, S, nq, nc, kp, s)) return e;
     hipLaunchKernelGGL(rank_mask<T>, dim3(nq), dim3(64), 0, s, S, nc, excl_ptr, excl_idx, q_base, nq);
     if (topn <= 64)
         hipLaunchKernelGGL(rank_topn_stream<T>, dim3((nq + 3) / 4), dim3(256), 0, s, (const T *)S, nq, nc, thold, topn, out_idx,
@@ -433,9 +553,37 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
     return hipGetLastError();
 }
 
+
+hipError_t rank_launch_split_operands(const RankSplitArgs &a, hipStream_t s) {
+    // B1 = [Q[j] | itemBias[j] or 0] for the candidates
+    RankItemsArgs<float> ia{a.Q, a.itemBias, nullptr, a.cand, a.B1, a.nc, a.k, a.kp1, 0};
+    if (hipError_t e = rank_launch_build_items<float>(ia, s)) return e;
+    if (a.icBias) {
+        hipLaunchKernelGGL(rank_build_ic_items<float>, dim3(a.nc), dim3(64), 0, s, a.icBias, a.cand, a.B2, a.n_conds, a.kp2);
+        hipLaunchKernelGGL(rank_build_ctx_rows<float>, dim3(a.n_dctx), dim3(64), 0, s, a.ctx_ptr, a.ctx_conds, a.dctx, a.A2, a.kp2);
+    }
+    RankQueryArgs<float> qa{nullptr, a.userBias, a.ucBias, a.condBias, a.qu, a.qc, a.ctx_ptr, a.ctx_conds, nullptr, a.rc, a.gm, a.k, a.kp1, a.n_conds, 0};
+    hipLaunchKernelGGL(rank_query_consts<float>, dim3((a.nq + 255) / 256), dim3(256), 0, s, qa, a.nq);
+    return hipGetLastError();
+}
+// A1 rows = [P[u] | 1] of the distinct query users [g0, g0 + n) (scratch_rc receives the builder's per-row constant, unused here)
+hipError_t rank_launch_split_users(const RankSplitArgs &a, const int32_t *d_group_user, int n, float *A1, float *scratch_rc, hipStream_t s) {
+    RankQueryArgs<float> qa{a.P, nullptr, nullptr, nullptr, d_group_user, d_group_user, nullptr, nullptr, A1, scratch_rc, 0.0, a.k, a.kp1, a.n_conds, 0};
+    return rank_launch_build_queries<float>(qa, n, s);
+}
+hipError_t rank_launch_split_select(const float *S1, const float *S2, const RankSplitArgs &a, const int32_t *q_group, const int32_t *q_dctx, int g_base,
+                                    int q0, int nq, const int64_t *excl_ptr, const int32_t *excl_idx, double thold, int topn, int32_t *out_idx,
+                                    double *out_score, int32_t *out_count, hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rank_topn_split<float>, dim3((nq + 3) / 4), dim3(256), 0, s, S1, S2, (const float *)a.rc, q_group, q_dctx, g_base, q0, nq, a.nc,
+                       excl_ptr, excl_idx, thold, topn, out_idx, out_score, out_count);
+    return hipGetLastError();
+}
+
 #define CMI_INST(T)                                                                                                    \
     template hipError_t rank_launch_build_items<T>(const RankItemsArgs<T> &, hipStream_t);                             \
     template hipError_t rank_launch_build_queries<T>(const RankQueryArgs<T> &, int, hipStream_t);                      \
+    template hipError_t rank_launch_gemm<T>(const T *, const T *, const T *, T *, int, int, int, hipStream_t);        \
     template hipError_t rank_launch_score<T>(const T *, const T *, const T *, T *, int, int, int, const int64_t *,     \
                                              const int32_t *, int, double, int, int32_t *, double *, int32_t *, hipStream_t);
 CMI_INST(float)

@@ -45,4 +45,23 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
                              const int64_t *excl_ptr, const int32_t *excl_idx, int q_base, double thold, int topn,
                              int32_t *out_idx, double *out_score, int32_t *out_count, hipStream_t s);
 
+
+// the split form of the MF family's scores (rank_kernels.hip, "the split form"): fp32 state
+struct RankSplitArgs {
+    const float *P, *Q, *userBias, *itemBias, *ucBias, *icBias, *condBias; // optional containers null
+    const int32_t *ctx_ptr, *ctx_conds;                                    // null for the 2-D models
+    const int32_t *cand, *qu, *qc, *dctx;                                  // candidates; per query user / context; distinct contexts
+    float *B1, *B2, *A2, *rc;                                              // operands built once per evaluation
+    double gm;
+    int k, kp1, kp2, n_conds, nc, nq, n_dctx;
+};
+hipError_t rank_launch_split_operands(const RankSplitArgs &a, hipStream_t s);
+hipError_t rank_launch_split_users(const RankSplitArgs &a, const int32_t *d_group_user, int n, float *A1, float *scratch_rc, hipStream_t s);
+hipError_t rank_launch_split_select(const float *S1, const float *S2, const RankSplitArgs &a, const int32_t *q_group, const int32_t *q_dctx, int g_base,
+                                    int q0, int nq, const int64_t *excl_ptr, const int32_t *excl_idx, double thold, int topn, int32_t *out_idx,
+                                    double *out_score, int32_t *out_count, hipStream_t s);
+// S = A.B^T + row_const (the contraction alone)
+template <typename T>
+hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s);
+
 } // namespace cmi

@@ -234,3 +234,25 @@ def test_all_tied_scores_resolve_in_candidate_order():
     assert hm["total"] >= hm["plan"] > 0.0 and hm["scoring_loop"] > 0.0
 
 
+
+
+@pytest.mark.parametrize("model", ["CAMF_CI", "CAMF_CUCI", "CAMF_CU", "CAMF_C", "BiasedMF", "PMF"])
+def test_split_form_agrees_with_the_per_query_contraction(model):
+    """Round 4: for the MF family in fp32 the scores are contracted as S1[user] + S2[context] (rank_kernels.hip "the split form") instead
+    of one dot product per query.  Same sum, another association: the lists of the two forms agree except at fp32 near-ties, scores to
+    1e-5, measures to 0.01; exclusions (walked on the fly in the split form, masked in the slab in the other) give the same counts."""
+    train, test, orc, inst = _setup(model, 32, 0, epochs=2, n_users=150, n_items=900, n=12000, seed=9)
+    kw = dict(bin_thold=2.5, num_recs=10, with_lists=True)
+    split = _with_env({"CMI_RANK_NO_SPLIT": None, "CMI_RANK_BATCH": "17"}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
+    whole = _with_env({"CMI_RANK_NO_SPLIT": "1"}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
+    assert split[0]["n_queries"] == whole[0]["n_queries"] > 0 and set(split[1]) == set(whole[1])
+    same = 0
+    for key, lst in whole[1].items():
+        other = split[1][key]
+        assert len(other) == len(lst)
+        same += [i for i, _ in lst] == [i for i, _ in other]
+        for (ia, sa), (ib, sb) in zip(lst, other):
+            assert abs(sa - sb) <= 1e-5 * max(1.0, abs(sa))
+    assert same >= 0.95 * len(whole[1])
+    for m, v in whole[0].items():
+        assert (math.isnan(v) and math.isnan(split[0][m])) or abs(split[0][m] - v) <= 0.01, m
