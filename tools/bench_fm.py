@@ -32,12 +32,13 @@ def main():
         g.sweep()
     dt = (time.perf_counter() - t0) / sweeps
     phases = 4 + 3 * k
-    # algorithmic bytes per rating per sweep (SURVEY 8d, fp64 here): (3+3k) passes over errors (8 B r + 8 B w) and, for the
-    # 3k factor passes, one Q column entry (8 B r + 8 B w)
-    bytes_per_rating = 16 * (3 + 3 * k) + 16 * 3 * k   # the REFERENCE algorithm's compulsory traffic (errors[] + one Q column entry per phase)
-    print("sweep %.1f ms (%d phases, %.1f us/phase): %.1f M rating-sweeps/s, %.0f GB/s algorithmic (fp64) = %.1f%% of 8 TB/s"
-          % (dt * 1e3, phases, dt * 1e6 / phases, data.n / dt / 1e6, data.n * bytes_per_rating / dt / 1e9,
-             100 * data.n * bytes_per_rating / dt / 8e12))
+    lay = g.layout()
+    red_u, red_i = g.time_reduce(4 + 3 * (k // 2)) * 1e-3, g.time_reduce(4 + 3 * (k // 2) + 1) * 1e-3
+    print("sweep %.1f ms (%d phases, %.1f us/phase): %.1f M rating-sweeps/s; reduce launch %.1f / %.1f us (user / item field) at %.1f B fetched per "
+          "rating-phase by the layout's own count (%d / %d slices); whole sweep %.0f GB/s of implementation bytes = %.1f%% of 8 TB/s"
+          % (dt * 1e3, phases, dt * 1e6 / phases, data.n / dt / 1e6, red_u * 1e6, red_i * 1e6,
+             0.5 * (lay["bytes_reduce_user"] + lay["bytes_reduce_item"]) / data.n, lay["slices_user_order"], lay["slices_item_order"],
+             lay["bytes_per_factor"] * (k + 1) / dt / 1e9, 100 * lay["bytes_per_factor"] * (k + 1) / dt / 8e12))
 
 
 if __name__ == "__main__":
