@@ -5,11 +5,15 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
 #include <cstring>
 #include <future>
 #include <memory>
 #include <numeric>
 #include <thread>
+
+#include <unistd.h>
 
 #include "cmi_instance.hpp"
 #include "rank_host.hpp"
@@ -19,27 +23,91 @@ using namespace cmi;
 
 namespace {
 
-// The host side of an evaluation (plan before the device run, measures after it) is O(tuples + queries) of independent per-user /
-// per-query work: it runs on the host's cores in contiguous index ranges, each range producing its own output that is then
-// concatenated in range order -- the result is the serial one, element for element.
+// The host side of an evaluation (plan before the device run, measures after it) is O(tuples + queries) of independent per-range
+// work: it runs on the host's cores in contiguous index ranges, each range producing its own output that is then concatenated in
+// range order -- the result is the serial one, element for element.
 int host_threads(int64_t work_items) {
     if (const char *e = getenv("CMI_HOST_THREADS")) return std::max(1, std::min(atoi(e), 64)); // tests: force the ranged form on small inputs
     int t = (int)std::thread::hardware_concurrency();
     t = std::max(1, std::min(t, 16)); // measured on the 64-core host of an MI355X box: 16 threads 13 ms, 32 threads 17 ms for the plan
     return (int)std::max<int64_t>(1, std::min<int64_t>(t, work_items / 4096 + 1));
 }
+
+// Worker threads that outlive the call: an evaluation runs five ranged phases of about a millisecond each, and creating 16 threads costs
+// about as much as one of them.  One job at a time; a caller that finds the pool busy (another fold's evaluation on another host thread)
+// or is itself a worker creates its own threads as before.  The pool is never destroyed (workers sleep on the condition variable until
+// the process ends).
+class HostPool {
+  public:
+    static HostPool &get() {
+        static HostPool *p = new HostPool();
+        return *p;
+    }
+    bool try_run(int nt, const std::function<void(int)> &fn) { // fn(0) runs on the caller
+        std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
+        if (!job.owns_lock()) return false;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (pid_ != getpid()) { // a forked child has no workers
+                workers_ = 0;
+                pid_ = getpid();
+            }
+            while (workers_ < nt - 1) {
+                std::thread(&HostPool::work, this, workers_ + 1, gen_).detach(); // gen_: the job posted below is the worker's first
+                ++workers_;
+            }
+            fn_ = &fn;
+            want_ = nt;
+            left_ = nt - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [&] { return left_ == 0; });
+        fn_ = nullptr;
+        return true;
+    }
+
+  private:
+    void work(int id, uint64_t seen) {
+        for (;;) {
+            const std::function<void(int)> *fn;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (id >= want_) continue;
+                fn = fn_;
+            }
+            (*fn)(id);
+            std::lock_guard<std::mutex> g(mu_);
+            if (--left_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int workers_ = 0, want_ = 0, left_ = 0;
+    uint64_t gen_ = 0;
+    pid_t pid_ = getpid();
+};
+
 template <typename F>
 void parallel_ranges(int64_t n, int nt, F &&body) { // body(range index, begin, end)
     if (nt <= 1 || n <= 0) {
         body(0, (int64_t)0, n);
         return;
     }
-    std::vector<std::thread> th;
     const int64_t step = (n + nt - 1) / nt;
-    for (int t = 0; t < nt; ++t) {
+    const std::function<void(int)> one = [&](int t) {
         const int64_t b = std::min<int64_t>(n, t * step), e = std::min<int64_t>(n, b + step);
-        th.emplace_back([&body, t, b, e]() { body(t, b, e); });
-    }
+        body(t, b, e);
+    };
+    if (HostPool::get().try_run(nt, one)) return;
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back([&one, t]() { one(t); });
+    one(0);
     for (std::thread &x : th) x.join();
 }
 
@@ -70,86 +138,94 @@ struct Truth {
     }
 };
 
-int hits_at(const int32_t *ranked, int len, const Truth &t, int n) { // Measures.HitsAt over the FULL ranked list
+// The measures below see a list through its membership flags rel[i] = "ranked[i] is a correct item" (one binary search per list
+// entry, done once per list: every formula of happy.coding.math.Measures asks only that question about an entry).
+int hits_at(const bool *rel, int len, int n) { // Measures.HitsAt over the FULL ranked list
     int hits = 0;
     for (int i = 0; i < len; ++i)
-        if (t.has(ranked[i])) {
+        if (rel[i]) {
             if (i >= n) break;
             ++hits;
         }
     return hits;
 }
 
-double auc(const int32_t *ranked, int len, const Truth &t, int num_dropped) {
+double auc(const bool *rel, int len, int n_truth, int num_dropped) {
     int num_rele = 0; // Lists.overlapSize(groundTruth, rankedList)
-    for (int i = 0; i < len; ++i) num_rele += t.has(ranked[i]);
+    for (int i = 0; i < len; ++i) num_rele += rel[i];
     const long num_eval_items = (long)len + num_dropped;
     const long num_eval_pairs = (num_eval_items - num_rele) * num_rele;
     if (num_eval_pairs == 0) return 0.5;
     long correct = 0, hits = 0;
     for (int i = 0; i < len; ++i) {
-        if (!t.has(ranked[i])) correct += hits;
+        if (!rel[i]) correct += hits;
         else ++hits;
     }
-    const long num_miss = t.n - num_rele; // Lists.exceptSize(groundTruth, rankedList)
+    const long num_miss = n_truth - num_rele; // Lists.exceptSize(groundTruth, rankedList)
     correct += hits * ((long)num_dropped - num_miss);
     return (double)correct / (double)num_eval_pairs;
 }
 
-double ap(const int32_t *ranked, int len, const Truth &t) {
+double ap(const bool *rel, int len, int n_truth) {
     int hits = 0;
     double s = 0.0;
     for (int i = 0; i < len; ++i)
-        if (t.has(ranked[i])) {
+        if (rel[i]) {
             ++hits;
             s += hits / (i + 1.0);
         }
-    return hits > 0 ? s / t.n : 0.0;
+    return hits > 0 ? s / n_truth : 0.0;
 }
 
 inline double log2j(double x) { return std::log(x) / std::log(2.0); } // Maths.log(x, 2)
+// 1 / log2(i + 2) for the first positions: the same expression evaluated once instead of once per list entry
+struct InvLog2 {
+    static constexpr int N = 1024;
+    double v[N];
+    InvLog2() {
+        for (int i = 0; i < N; ++i) v[i] = 1.0 / log2j(i + 2);
+    }
+    double operator()(int i) const { return i < N ? v[i] : 1.0 / log2j(i + 2); }
+};
+const InvLog2 inv_log2;
 
-double ndcg(const int32_t *ranked, int len, const Truth &t) {
+double ndcg(const bool *rel, int len, int n_truth) {
     double dcg = 0.0, idcg = 0.0;
     for (int i = 0; i < len; ++i)
-        if (t.has(ranked[i])) dcg += 1.0 / log2j(i + 2);
-    for (int i = 0; i < t.n; ++i) idcg += 1.0 / log2j(i + 2);
+        if (rel[i]) dcg += inv_log2(i);
+    for (int i = 0; i < n_truth; ++i) idcg += inv_log2(i);
     return dcg / idcg;
 }
 
-double rr(const int32_t *ranked, int len, const Truth &t) {
+double rr(const bool *rel, int len) {
     for (int i = 0; i < len; ++i)
-        if (t.has(ranked[i])) return 1.0 / (i + 1.0);
+        if (rel[i]) return 1.0 / (i + 1.0);
     return 0.0;
 }
-
-struct NanMean { // happy.coding.math.Stats.mean(Collection): NaN entries are skipped; empty -> 0/0 = NaN
-    double s = 0.0;
-    long c = 0;
-    void add(double x) {
-        if (!std::isnan(x)) {
-            s += x;
-            ++c;
-        }
-    }
-    double value() const { return c ? s / (double)c : std::nan(""); }
-};
 
 constexpr int N_MEAS = 18; // Pre,Rec,AUC,MAP,NDCG,MRR x {5,10,N}
 
 // the 18 measures of ONE ranked list (already cut at num_recs): index = measure * 3 + cut-off, cut-offs {5, 10, num_recs}
 // (Recommender.java:852-858 through carskit.eval.Measures.*At)
 void list_measures(const int32_t *ranked, int len, const Truth &t, int num_dropped, int num_recs, double vals[N_MEAS]) {
+    bool rel_small[64];
+    std::unique_ptr<bool[]> rel_big;
+    bool *rel = rel_small;
+    if (len > 64) {
+        rel_big.reset(new bool[(size_t)len]);
+        rel = rel_big.get();
+    }
+    for (int i = 0; i < len; ++i) rel[i] = t.has(ranked[i]);
     const int cut[3] = {5, 10, num_recs};
     for (int c = 0; c < 3; ++c) {
         const int n = cut[c], tl = std::min(n, len);
-        const int hits = hits_at(ranked, len, t, n);
+        const int hits = hits_at(rel, len, n);
         vals[0 + c] = hits / (n + 0.0);
         vals[3 + c] = hits / (t.n + 0.0);
-        vals[6 + c] = auc(ranked, tl, t, num_dropped);
-        vals[9 + c] = ap(ranked, tl, t);
-        vals[12 + c] = ndcg(ranked, tl, t);
-        vals[15 + c] = rr(ranked, tl, t);
+        vals[6 + c] = auc(rel, tl, t.n, num_dropped);
+        vals[9 + c] = ap(rel, tl, t.n);
+        vals[12 + c] = ndcg(rel, tl, t.n);
+        vals[15 + c] = rr(rel, tl);
     }
 }
 
@@ -157,15 +233,112 @@ void list_measures(const int32_t *ranked, int len, const Truth &t, int num_dropp
 
 namespace cmi {
 
+namespace {
+// Host scratch of rank_build_plan, kept between evaluations: the plan moves tens of megabytes through per-thread lists, and a fresh
+// allocation pays a page fault per 4 KB touched -- from 16 threads inside one address space those serialise in the kernel and cost more
+// than the work itself (measured on an MI355X box: the tuple passes ran at 14 ns per tuple).  One cached instance; a concurrent
+// evaluation (another fold on another host thread) builds its own and drops it.
+struct PlanUK {
+    uint32_t u, c, j;
+};
+struct PlanPart {
+    std::vector<int32_t> qu, qc, truth_items, excl_idx;
+    std::vector<int64_t> truth_end, excl_end; // running ends inside this part
+    void clear() {
+        qu.clear();
+        qc.clear();
+        truth_items.clear();
+        excl_idx.clear();
+        truth_end.clear();
+        excl_end.clear();
+    }
+};
+template <typename T>
+struct RawBuf { // uninitialised, grow-only
+    std::unique_ptr<T[]> p;
+    size_t cap = 0;
+    T *need(size_t n) {
+        if (n > cap) {
+            p.reset(new T[n + n / 8]);
+            cap = n + n / 8;
+        }
+        return p.get();
+    }
+};
+struct PlanScratch {
+    std::vector<std::vector<int32_t>> lfirst, ldeg;
+    std::vector<std::vector<PlanUK>> tl, pl;
+    std::vector<PlanPart> parts;
+    RawBuf<uint64_t> tkey, pkey;
+    RawBuf<int64_t> toff, poff;
+    size_t bytes() const {
+        size_t b = (tkey.cap + pkey.cap + toff.cap + poff.cap) * 8;
+        for (const auto &v : tl) b += v.capacity() * sizeof(PlanUK);
+        for (const auto &v : pl) b += v.capacity() * sizeof(PlanUK);
+        for (const auto &v : ldeg) b += v.capacity() * 4;
+        return b;
+    }
+};
+std::mutex plan_scratch_mu;
+PlanScratch *plan_scratch_cached = nullptr;
+struct PlanScratchLease {
+    PlanScratch *s;
+    PlanScratchLease() {
+        std::lock_guard<std::mutex> g(plan_scratch_mu);
+        s = plan_scratch_cached;
+        plan_scratch_cached = nullptr;
+        if (!s) s = new PlanScratch();
+    }
+    ~PlanScratchLease() {
+        std::lock_guard<std::mutex> g(plan_scratch_mu);
+        if (!plan_scratch_cached && s->bytes() <= ((size_t)1 << 30)) plan_scratch_cached = s;
+        else delete s;
+    }
+};
+} // namespace
+
 void rank_build_plan(int n_users, int n_items, const RankTuples &train, const RankTuples &test, double bin_thold,
                      int num_ignore, RankPlan &plan) {
-    // candidate items: rateDao.getItemList(trainMatrix) -> HashSet<Integer> (DataDAO.java:1210-1218).  One sequential pass: the
-    // first-seen order is what the HashSet's iteration order is computed from.
+    const int nt = host_threads(train.n + test.n);
+    const bool TT = getenv("CMI_PLAN_TIMES") != nullptr; auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) { if (TT) { auto n = std::chrono::steady_clock::now(); fprintf(stderr, "plan %s %.3f ms\n", w, std::chrono::duration<double, std::milli>(n - T0).count()); T0 = n; } };
+    auto range_of = [](int64_t n, int parts, int p, int64_t &b, int64_t &e) {
+        const int64_t step = (n + parts - 1) / parts;
+        b = std::min<int64_t>(n, p * step);
+        e = std::min<int64_t>(n, b + step);
+    };
+    // candidate items: rateDao.getItemList(trainMatrix) -> HashSet<Integer> (DataDAO.java:1210-1218); the HashSet's iteration order is
+    // computed from the first-seen order of the items.  Ranges of training tuples keep their own first-seen list and degrees; an
+    // item's global first occurrence lies in the earliest range that holds it, so walking the ranges in order and keeping the items
+    // not seen before reproduces the sequential pass.
+    PlanScratchLease lease;
+    PlanScratch &S = *lease.s;
     std::vector<int32_t> first_seen, degree(n_items, 0);
-    for (int64_t t = 0; t < train.n; ++t) {
-        if (train.r && train.r[t] == 0.0) continue; // a sparse matrix holds no zero entries
-        if (degree[train.j[t]]++ == 0) first_seen.push_back(train.j[t]);
+    {
+        const int np = (int)std::max<int64_t>(1, std::min<int64_t>(nt, ((int64_t)16 << 20) / std::max(n_items, 1)));
+        std::vector<std::vector<int32_t>> &lfirst = S.lfirst, &ldeg = S.ldeg;
+        if (lfirst.size() < (size_t)np) lfirst.resize((size_t)np);
+        if (ldeg.size() < (size_t)np) ldeg.resize((size_t)np);
+        parallel_ranges(np, np, [&](int, int64_t p0, int64_t p1) {
+            for (int64_t p = p0; p < p1; ++p) {
+                int64_t b, e;
+                range_of(train.n, np, (int)p, b, e);
+                std::vector<int32_t> &deg = ldeg[(size_t)p], &fs = lfirst[(size_t)p];
+                deg.assign((size_t)n_items, 0);
+                fs.clear();
+                for (int64_t t = b; t < e; ++t) {
+                    if (train.r && train.r[t] == 0.0) continue; // a sparse matrix holds no zero entries
+                    if (deg[train.j[t]]++ == 0) fs.push_back(train.j[t]);
+                }
+            }
+        });
+        for (int p = 0; p < np; ++p)
+            for (int32_t j : lfirst[(size_t)p]) {
+                if (degree[j] == 0) first_seen.push_back(j);
+                degree[j] += ldeg[(size_t)p][j];
+            }
     }
+    lap("first_seen");
     std::vector<int32_t> &cand = plan.cand;
     cand = java_int_hashset_order(first_seen);
     if (num_ignore > 0) { // drop the most popular items (Recommender.java:720-735): stable sort by degree, descending
@@ -179,64 +352,86 @@ void rank_build_plan(int n_users, int n_items, const RankTuples &train, const Ra
     std::vector<int32_t> cand_pos(n_items, -1);
     for (int i = 0; i < nc; ++i) cand_pos[cand[i]] = i;
 
+    lap("cand");
     // Training tuples and test positives (rate > threshold; DataDAO.getUserCtxList, DataDAO.java:1114-1140) bucketed by user as
-    // packed (context, item) keys, in the caller's order inside a bucket.  Every host thread owns a range of users: ONE scan of all
-    // tuples (sequential reads) collects its own users' tuples, a second region scatters them into the user buckets (a cache-sized
-    // region of its own: no two threads share a cursor) and turns each of its users into queries.
-    const int nt = host_threads(train.n + test.n);
-    std::vector<int64_t> toff((size_t)n_users + 1, 0), poff((size_t)n_users + 1, 0);
-    struct Local {
-        std::vector<int32_t> tu, pu;
-        std::vector<uint64_t> tk, pk;
-    };
-    std::vector<Local> loc((size_t)nt);
-    parallel_ranges(n_users, nt, [&](int part, int64_t u0, int64_t u1) {
-        Local &L = loc[(size_t)part];
-        for (int64_t t = 0; t < train.n; ++t) {
-            const int32_t u = train.u[t];
-            if (u < u0 || u >= u1 || (train.r && train.r[t] == 0.0)) continue;
-            L.tu.push_back(u);
-            L.tk.push_back(((uint64_t)(uint32_t)train.ctx[t] << 32) | (uint32_t)train.j[t]);
-            toff[(size_t)u + 1]++;
-        }
-        for (int64_t t = 0; t < test.n; ++t) {
-            const int32_t u = test.u[t];
-            if (u < u0 || u >= u1 || !(test.r[t] != 0.0 && test.r[t] > bin_thold)) continue;
-            L.pu.push_back(u);
-            L.pk.push_back(((uint64_t)(uint32_t)test.ctx[t] << 32) | (uint32_t)test.j[t]);
-            poff[(size_t)u + 1]++;
+    // packed (context, item) keys, in the caller's order inside a bucket.  Two passes, both cache-friendly: (1) every RANGE OF TUPLES
+    // is split by one thread into nt sequential lists, one per range of users; (2) every RANGE OF USERS walks its lists in tuple-range
+    // order (that keeps the caller's order), counts, and places the keys inside its own region of the key array (a region and its
+    // cursors fit the core's cache; no two threads share a cursor).
+    const size_t nu = (size_t)n_users;
+    const int64_t ustep = ((int64_t)n_users + nt - 1) / nt; // the user ranges of parallel_ranges(n_users, nt, ...)
+    using UK = PlanUK;
+    std::vector<std::vector<UK>> &tl = S.tl, &pl = S.pl; // [tuple range][user range]
+    if (tl.size() < (size_t)nt * nt) tl.resize((size_t)nt * nt);
+    if (pl.size() < (size_t)nt * nt) pl.resize((size_t)nt * nt);
+    auto positive = [&](int64_t t) { return test.r[t] != 0.0 && test.r[t] > bin_thold; };
+    parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
+        for (int64_t p = p0; p < p1; ++p) {
+            std::vector<UK> *tp = &tl[(size_t)p * nt], *pp = &pl[(size_t)p * nt];
+            int64_t b, e;
+            range_of(train.n, nt, (int)p, b, e);
+            for (int q = 0; q < nt; ++q) {
+                tp[q].clear();
+                pp[q].clear();
+                tp[q].reserve((size_t)((e - b) / nt + (e - b) / (4 * nt) + 16));
+            }
+            for (int64_t t = b; t < e; ++t)
+                if (!(train.r && train.r[t] == 0.0)) tp[train.u[t] / ustep].push_back(UK{(uint32_t)train.u[t], (uint32_t)train.ctx[t], (uint32_t)train.j[t]});
+            range_of(test.n, nt, (int)p, b, e);
+            for (int64_t t = b; t < e; ++t)
+                if (positive(t)) pp[test.u[t] / ustep].push_back(UK{(uint32_t)test.u[t], (uint32_t)test.ctx[t], (uint32_t)test.j[t]});
         }
     });
-    for (int l = 0; l < n_users; ++l) {
-        toff[(size_t)l + 1] += toff[(size_t)l];
-        poff[(size_t)l + 1] += poff[(size_t)l];
+    lap("split");
+    std::vector<int64_t> tbase((size_t)nt + 1, 0), pbase((size_t)nt + 1, 0); // first key of every user range
+    for (int q = 0; q < nt; ++q) {
+        int64_t ts = 0, ps = 0;
+        for (int p = 0; p < nt; ++p) {
+            ts += (int64_t)tl[(size_t)p * nt + q].size();
+            ps += (int64_t)pl[(size_t)p * nt + q].size();
+        }
+        tbase[(size_t)q + 1] = tbase[(size_t)q] + ts;
+        pbase[(size_t)q + 1] = pbase[(size_t)q] + ps;
     }
-    std::unique_ptr<uint64_t[]> tkey(new uint64_t[(size_t)toff[(size_t)n_users] + 1]), pkey(new uint64_t[(size_t)poff[(size_t)n_users] + 1]);
-
+    int64_t *toff = S.toff.need(nu + 1), *poff = S.poff.need(nu + 1);
+    toff[nu] = tbase[(size_t)nt];
+    poff[nu] = pbase[(size_t)nt];
+    uint64_t *tkey = S.tkey.need((size_t)toff[nu] + 1), *pkey = S.pkey.need((size_t)poff[nu] + 1);
+    parallel_ranges(n_users, nt, [&](int part, int64_t u0, int64_t u1) {
+        if (u0 >= u1) return;
+        auto place = [&](const std::vector<std::vector<UK>> &lists, int64_t base, int64_t *off, uint64_t *key) {
+            std::vector<int64_t> cur((size_t)(u1 - u0) + 1, 0);
+            for (int p = 0; p < nt; ++p)
+                for (const UK &x : lists[(size_t)p * nt + part]) cur[(size_t)(x.u - u0) + 1]++;
+            int64_t run = base;
+            for (int64_t u = u0; u < u1; ++u) {
+                off[(size_t)u] = run;
+                const int64_t n = cur[(size_t)(u - u0) + 1];
+                cur[(size_t)(u - u0)] = run;
+                run += n;
+            }
+            for (int p = 0; p < nt; ++p)
+                for (const UK &x : lists[(size_t)p * nt + part]) key[(size_t)cur[(size_t)(x.u - u0)]++] = ((uint64_t)x.c << 32) | x.j;
+        };
+        place(tl, tbase[(size_t)part], toff, tkey);
+        place(pl, pbase[(size_t)part], poff, pkey);
+    });
+    lap("place");
     // per user: its queries in (context, item) order -- a query is a (user, context) with at least one correct item that is a
     // candidate (Recommender.java:789-790) -- and, per query, the candidate positions of the items the user rated in the same
     // context in the training set (Recommender.java:793, 814-816), in item order
-    struct Part {
-        std::vector<int32_t> qu, qc, truth_items, excl_idx;
-        std::vector<int64_t> truth_end, excl_end; // running ends inside this part
-    };
-    std::vector<Part> parts((size_t)nt);
+    using Part = PlanPart;
+    std::vector<Part> &parts = S.parts;
+    if (parts.size() < (size_t)nt) parts.resize((size_t)nt);
+    for (Part &P : parts) P.clear();
     parallel_ranges(n_users, nt, [&](int part, int64_t u0, int64_t u1) {
-        if (u0 >= u1) return;
-        {
-            const Local &L = loc[(size_t)part];
-            std::vector<int64_t> cur(toff.begin() + u0, toff.begin() + u1);
-            for (size_t i = 0; i < L.tu.size(); ++i) tkey[(size_t)cur[(size_t)(L.tu[i] - u0)]++] = L.tk[i];
-            cur.assign(poff.begin() + u0, poff.begin() + u1);
-            for (size_t i = 0; i < L.pu.size(); ++i) pkey[(size_t)cur[(size_t)(L.pu[i] - u0)]++] = L.pk[i];
-        }
         Part &P = parts[(size_t)part];
         std::vector<uint32_t> items;
         for (int64_t u = u0; u < u1; ++u) {
-            uint64_t *pb = pkey.get() + poff[(size_t)u], *pe = pkey.get() + poff[(size_t)u + 1];
+            uint64_t *pb = pkey + poff[(size_t)u], *pe = pkey + poff[(size_t)u + 1];
             if (pb == pe) continue;
             std::sort(pb, pe);
-            const uint64_t *tb = tkey.get() + toff[(size_t)u], *te = tkey.get() + toff[(size_t)u + 1];
+            const uint64_t *tb = tkey + toff[(size_t)u], *te = tkey + toff[(size_t)u + 1];
             for (uint64_t *i = pb; i < pe;) {
                 const uint32_t c = (uint32_t)(*i >> 32);
                 const size_t before = P.truth_items.size();
@@ -250,11 +445,11 @@ void rank_build_plan(int n_users, int n_items, const RankTuples &train, const Ra
                 P.qu.push_back((int32_t)u);
                 P.qc.push_back((int32_t)c);
                 P.truth_end.push_back((int64_t)P.truth_items.size());
-                items.clear();
+                const size_t ebefore = P.excl_idx.size();
+                items.clear(); // the user's training items in this context, ascending (users hold tens of tuples: a scan per query)
                 for (const uint64_t *t = tb; t < te; ++t)
                     if ((uint32_t)(*t >> 32) == c) items.push_back((uint32_t)*t);
                 std::sort(items.begin(), items.end());
-                const size_t ebefore = P.excl_idx.size();
                 for (uint32_t j : items) {
                     const int32_t cp = cand_pos[j];
                     if (cp >= 0 && (P.excl_idx.size() == ebefore || P.excl_idx.back() != cp)) P.excl_idx.push_back(cp);
@@ -263,23 +458,35 @@ void rank_build_plan(int n_users, int n_items, const RankTuples &train, const Ra
             }
         }
     });
-    std::vector<int32_t> &qu = plan.qu, &qc = plan.qc, &truth_items = plan.truth_items, &excl_idx = plan.excl_idx;
-    std::vector<int64_t> &truth_ptr = plan.truth_ptr, &excl_ptr = plan.excl_ptr;
-    qu.clear();
-    qc.clear();
-    truth_items.clear();
-    excl_idx.clear();
-    truth_ptr.assign(1, 0);
-    excl_ptr.assign(1, 0);
-    for (const Part &P : parts) {
-        const int64_t t0 = (int64_t)truth_items.size(), e0 = (int64_t)excl_idx.size();
-        qu.insert(qu.end(), P.qu.begin(), P.qu.end());
-        qc.insert(qc.end(), P.qc.begin(), P.qc.end());
-        truth_items.insert(truth_items.end(), P.truth_items.begin(), P.truth_items.end());
-        excl_idx.insert(excl_idx.end(), P.excl_idx.begin(), P.excl_idx.end());
-        for (int64_t v : P.truth_end) truth_ptr.push_back(t0 + v);
-        for (int64_t v : P.excl_end) excl_ptr.push_back(e0 + v);
+    lap("per_user");
+    // the parts, in range order
+    std::vector<int64_t> q0((size_t)nt + 1, 0), t0((size_t)nt + 1, 0), e0((size_t)nt + 1, 0);
+    for (int p = 0; p < nt; ++p) {
+        q0[(size_t)p + 1] = q0[(size_t)p] + (int64_t)parts[(size_t)p].qu.size();
+        t0[(size_t)p + 1] = t0[(size_t)p] + (int64_t)parts[(size_t)p].truth_items.size();
+        e0[(size_t)p + 1] = e0[(size_t)p] + (int64_t)parts[(size_t)p].excl_idx.size();
     }
+    plan.qu.resize((size_t)q0[(size_t)nt]);
+    plan.qc.resize((size_t)q0[(size_t)nt]);
+    plan.truth_ptr.resize((size_t)q0[(size_t)nt] + 1);
+    plan.excl_ptr.resize((size_t)q0[(size_t)nt] + 1);
+    plan.truth_items.resize((size_t)t0[(size_t)nt]);
+    plan.excl_idx.resize((size_t)e0[(size_t)nt]);
+    plan.truth_ptr[0] = plan.excl_ptr[0] = 0;
+    parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
+        for (int64_t p = p0; p < p1; ++p) {
+            const Part &P = parts[(size_t)p];
+            std::copy(P.qu.begin(), P.qu.end(), plan.qu.begin() + q0[(size_t)p]);
+            std::copy(P.qc.begin(), P.qc.end(), plan.qc.begin() + q0[(size_t)p]);
+            std::copy(P.truth_items.begin(), P.truth_items.end(), plan.truth_items.begin() + t0[(size_t)p]);
+            std::copy(P.excl_idx.begin(), P.excl_idx.end(), plan.excl_idx.begin() + e0[(size_t)p]);
+            for (size_t i = 0; i < P.truth_end.size(); ++i) {
+                plan.truth_ptr[(size_t)q0[(size_t)p] + i + 1] = t0[(size_t)p] + P.truth_end[i];
+                plan.excl_ptr[(size_t)q0[(size_t)p] + i + 1] = e0[(size_t)p] + P.excl_end[i];
+            }
+        }
+    });
+    lap("concat");
 }
 
 void rank_measures_range(const RankPlan &plan, int num_recs, const int32_t *top_idx, const double *top_score, const int32_t *top_count,
@@ -316,24 +523,64 @@ void rank_average(const RankPlan &plan, int strategy, const int32_t *top_count, 
     const int64_t nq = (int64_t)plan.qu.size();
     for (int m = 0; m < CMI_RANK_MEASURES; ++m) out[m] = std::nan("");
     out[18] = out[19] = out[20] = 0.0; // D5/D10/DN: isDiverseUsed=false (Recommender.java:939-941)
-    // the serial part: 18 additions per query, in query order
-    NanMean total[N_MEAS], per_user[N_MEAS];
-    auto flush_user = [&]() {
-        for (int m = 0; m < N_MEAS; ++m) {
-            total[m].add(per_user[m].value());
-            per_user[m] = NanMean();
+    // Every addition is a happy.coding.math.Stats.mean step (NaN entries are skipped; an empty mean is 0/0 = NaN), in query order.  The
+    // 18 chains are independent of each other, so they advance side by side without branches: a skipped entry adds +0.0 (the sums are
+    // never -0.0: they start at +0.0 and +0.0 + -0.0 = +0.0) and counts 0.
+    struct Acc {
+        double s[N_MEAS];
+        int64_t c[N_MEAS];
+        Acc() {
+            for (int m = 0; m < N_MEAS; ++m) {
+                s[m] = 0.0;
+                c[m] = 0;
+            }
+        }
+        void add(const double *v) {
+            for (int m = 0; m < N_MEAS; ++m) {
+                const bool ok = v[m] == v[m];
+                s[m] += ok ? v[m] : 0.0;
+                c[m] += ok;
+            }
+        }
+        void mean(double *o) const {
+            for (int m = 0; m < N_MEAS; ++m) o[m] = c[m] ? s[m] / (double)c[m] : std::nan("");
         }
     };
-    for (int64_t q = 0; q < nq; ++q) {
-        if (top_count[q] > 0) {
-            NanMean *dst = strategy == CMI_RANK_UC ? total : per_user;
-            for (int m = 0; m < N_MEAS; ++m) dst[m].add(vals[(size_t)q * N_MEAS + m]);
+    Acc total;
+    if (strategy == CMI_RANK_UC) {
+        for (int64_t q = 0; q < nq; ++q)
+            if (top_count[q] > 0) total.add(vals + (size_t)q * N_MEAS);
+    } else {
+        // ucu: a test user contributes the NaN-skipping mean over its contexts -- NaN (skipped again) if none of its contexts produced
+        // a list (Recommender.java:903-926).  The users' means do not depend on each other: ranges of whole users on the host's cores
+        // write them down; only the sum over the users, in user order, is the serial part.
+        const int nt = host_threads(nq * 4);
+        std::vector<int64_t> cut((size_t)nt + 1, nq);
+        cut[0] = 0;
+        for (int t = 1; t < nt; ++t) {
+            int64_t b = std::min<int64_t>(nq, (nq + nt - 1) / nt * t);
+            while (b > 0 && b < nq && plan.qu[(size_t)b] == plan.qu[(size_t)b - 1]) ++b; // to the next user's first query
+            cut[(size_t)t] = std::max(b, cut[(size_t)t - 1]);
         }
-        // ucu: a test user contributes the NaN-skipping mean over its contexts -- NaN (skipped again) if none of
-        // its contexts produced a list (Recommender.java:903-926)
-        if (strategy == CMI_RANK_UCU && (q + 1 == nq || plan.qu[q + 1] != plan.qu[q])) flush_user();
+        std::vector<std::vector<double>> means((size_t)nt);
+        parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
+            for (int64_t p = p0; p < p1; ++p) {
+                std::vector<double> &mv = means[(size_t)p];
+                Acc user;
+                for (int64_t q = cut[(size_t)p]; q < cut[(size_t)p + 1]; ++q) {
+                    if (top_count[q] > 0) user.add(vals + (size_t)q * N_MEAS);
+                    if (q + 1 == nq || plan.qu[(size_t)q + 1] != plan.qu[(size_t)q]) {
+                        mv.resize(mv.size() + N_MEAS);
+                        user.mean(mv.data() + mv.size() - N_MEAS);
+                        user = Acc();
+                    }
+                }
+            }
+        });
+        for (const std::vector<double> &mv : means)
+            for (size_t i = 0; i + N_MEAS <= mv.size(); i += N_MEAS) total.add(mv.data() + i);
     }
-    for (int m = 0; m < N_MEAS; ++m) out[m] = total[m].value();
+    total.mean(out);
 }
 
 hipError_t RankWorkspace::need(Buf &b, size_t bytes, bool pinned) {
@@ -359,11 +606,38 @@ void RankWorkspace::release() {
         if (b->p) (void)hipHostFree(b->p);
         *b = Buf();
     }
-    hipEvent_t *evs[] = {&ev0, &ev1, &evb[0], &evb[1]};
+    hipEvent_t *evs[] = {&ev0, &ev1};
     for (hipEvent_t *e : evs) {
         if (*e) (void)hipEventDestroy(*e);
         *e = nullptr;
     }
+    for (hipEvent_t e : evb)
+        if (e) (void)hipEventDestroy(e);
+    evb.clear();
+}
+
+hipError_t RankWorkspace::batch_event(size_t b, hipStream_t stream) {
+    while (evb.size() <= b) {
+        hipEvent_t ev = nullptr;
+        if (hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) return e;
+        evb.push_back(ev);
+    }
+    return hipEventRecord(evb[b], stream);
+}
+
+hipError_t RankWorkspace::consume_batches(hipError_t e, const std::vector<std::pair<int64_t, int64_t>> &batches,
+                                          const std::function<void(int64_t, int64_t)> &on_batch,
+                                          std::chrono::steady_clock::time_point t_loop) {
+    for (size_t b = 0; b + 1 < batches.size() && e == hipSuccess; ++b) {
+        e = hipEventSynchronize(evb[b]);
+        if (e == hipSuccess && on_batch) on_batch(batches[b].first, batches[b].second);
+    }
+    if (e == hipSuccess) e = hipEventSynchronize(ev1); // recorded behind the last batch's copies
+    host_ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
+    const auto t_tail = std::chrono::steady_clock::now();
+    if (e == hipSuccess && !batches.empty() && on_batch) on_batch(batches.back().first, batches.back().second);
+    host_ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tail).count();
+    return e;
 }
 
 static double ms_since(std::chrono::steady_clock::time_point t0) {
@@ -406,7 +680,7 @@ hipError_t rank_run_device(hipStream_t stream, RankWorkspace &ws, const RankPlan
     need(ws.h_top, (size_t)nq * topn * 4, true);
     need(ws.h_score, (size_t)nq * topn * 8, true);
     need(ws.h_count, (size_t)nq * 4, true);
-    hipEvent_t *evs[] = {&ws.ev0, &ws.ev1, &ws.evb[0], &ws.evb[1]};
+    hipEvent_t *evs[] = {&ws.ev0, &ws.ev1};
     for (hipEvent_t *ev : evs)
         if (e == hipSuccess && !*ev) e = hipEventCreate(ev);
     if (e != hipSuccess) return e;
@@ -429,10 +703,11 @@ hipError_t rank_run_device(hipStream_t stream, RankWorkspace &ws, const RankPlan
     if (e == hipSuccess) e = hipEventRecord(ws.ev0, stream);
     ws.host_ms[1] = ms_since(t_setup);
     const auto t_loop = std::chrono::steady_clock::now();
-    // batch b scores while the host turns batch b-1's lists (already copied back) into measures
-    int64_t prev0 = -1, prev1 = -1;
-    int nb = 0;
-    for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += bq, ++nb) {
+    // Every batch is enqueued before the host waits for anything (the stream orders a batch's contraction behind the previous
+    // batch's selection, which reads the same slab); the host then turns the lists into measures batch by batch as their copies land,
+    // behind the device, and can never hold the device up.
+    std::vector<std::pair<int64_t, int64_t>> batches;
+    for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += bq) {
         const int n = (int)std::min<int64_t>(bq, nq - q0);
         e = ops.build_queries(dA, drc, dqu + q0, dqc + q0, n, kp, stream);
         if (e == hipSuccess) e = rank_launch_score<T>(dA, dB, drc, dS, n, nc, kp, dexptr, dexcl, (int)q0, thold, topn, dtop, dscore, dcount, stream);
@@ -441,20 +716,11 @@ hipError_t rank_run_device(hipStream_t stream, RankWorkspace &ws, const RankPlan
         if (e == hipSuccess)
             e = hipMemcpyAsync((double *)ws.h_score.p + (size_t)q0 * topn, dscore + (size_t)q0 * topn, (size_t)n * topn * 8, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipMemcpyAsync((int32_t *)ws.h_count.p + q0, dcount + q0, (size_t)n * 4, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipEventRecord(ws.evb[nb & 1], stream);
-        if (e == hipSuccess && prev0 >= 0) {
-            e = hipEventSynchronize(ws.evb[(nb - 1) & 1]);
-            if (e == hipSuccess && on_batch) on_batch(prev0, prev1);
-        }
-        prev0 = q0;
-        prev1 = q0 + n;
+        if (e == hipSuccess) e = ws.batch_event(batches.size(), stream);
+        batches.emplace_back(q0, q0 + n);
     }
     if (e == hipSuccess) e = hipEventRecord(ws.ev1, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    ws.host_ms[2] = ms_since(t_loop);
-    const auto t_tail = std::chrono::steady_clock::now();
-    if (e == hipSuccess && prev0 >= 0 && on_batch) on_batch(prev0, prev1);
-    ws.host_ms[3] = ms_since(t_tail);
+    e = ws.consume_batches(e, batches, on_batch, t_loop);
     if (e == hipSuccess && ms) e = hipEventElapsedTime(ms, ws.ev0, ws.ev1);
     if (flops) *flops = 2.0 * (double)nq * (double)nc * (double)kp;
     return e;
@@ -547,7 +813,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     need(ws.h_top, (size_t)nq * topn * 4, true);
     need(ws.h_score, (size_t)nq * topn * 8, true);
     need(ws.h_count, (size_t)nq * 4, true);
-    hipEvent_t *evs[] = {&ws.ev0, &ws.ev1, &ws.evb[0], &ws.evb[1]};
+    hipEvent_t *evs[] = {&ws.ev0, &ws.ev1};
     for (hipEvent_t *ev : evs)
         if (e == hipSuccess && !*ev) e = hipEventCreate(ev);
     if (e != hipSuccess) return e;
@@ -584,9 +850,8 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     if (e == hipSuccess && ic) e = rank_launch_gemm<float>(a.A2, a.B2, (const float *)ws.dscr.p, (float *)ws.dS2.p, n_dc, nc, a.kp2, stream);
     ws.host_ms[1] = ms_since(t_setup);
     const auto t_loop = std::chrono::steady_clock::now();
-    int64_t prev0 = -1, prev1 = -1;
-    int nb = 0;
-    for (int64_t g0 = 0; g0 < ng && e == hipSuccess; g0 += bg, ++nb) {
+    std::vector<std::pair<int64_t, int64_t>> batches; // all enqueued first, consumed behind the device (see rank_run_device)
+    for (int64_t g0 = 0; g0 < ng && e == hipSuccess; g0 += bg) {
         const int n = (int)std::min<int64_t>(bg, ng - g0);
         const int64_t q0 = gq0[(size_t)g0], q1 = gq0[(size_t)(g0 + n)];
         // (the builder leaves its per-row constant -- zero here -- in the scratch the contraction then reads as its row constant)
@@ -602,20 +867,11 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
         if (e == hipSuccess)
             e = hipMemcpyAsync((double *)ws.h_score.p + (size_t)q0 * topn, dscore + (size_t)q0 * topn, nqb * topn * 8, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipMemcpyAsync((int32_t *)ws.h_count.p + q0, dcount + q0, nqb * 4, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipEventRecord(ws.evb[nb & 1], stream);
-        if (e == hipSuccess && prev0 >= 0) {
-            e = hipEventSynchronize(ws.evb[(nb - 1) & 1]);
-            if (e == hipSuccess && on_batch) on_batch(prev0, prev1);
-        }
-        prev0 = q0;
-        prev1 = q1;
+        if (e == hipSuccess) e = ws.batch_event(batches.size(), stream);
+        batches.emplace_back(q0, q1);
     }
     if (e == hipSuccess) e = hipEventRecord(ws.ev1, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    ws.host_ms[2] = ms_since(t_loop);
-    const auto t_tail = std::chrono::steady_clock::now();
-    if (e == hipSuccess && prev0 >= 0 && on_batch) on_batch(prev0, prev1);
-    ws.host_ms[3] = ms_since(t_tail);
+    e = ws.consume_batches(e, batches, on_batch, t_loop);
     if (e == hipSuccess && ms) e = hipEventElapsedTime(ms, ws.ev0, ws.ev1);
     // flops of THIS form: the two contractions it actually runs
     if (flops) *flops = 2.0 * (double)ng * (double)nc * (double)a.kp1 + (ic ? 2.0 * (double)n_dc * (double)nc * (double)a.kp2 : 0.0);
@@ -796,14 +1052,14 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
     if (n_queries) *n_queries = 0;
 
     const auto t_all = std::chrono::steady_clock::now();
-    RankPlan plan;
+    RankWorkspace &ws = h->rank_ws;
+    RankPlan &plan = ws.plan; // its arrays keep their capacity between evaluations
     rank_build_plan(h->n_users, h->n_items, RankTuples{n_train, tu, tj, tctx, tr}, RankTuples{n_test, su, sj, sctx, sr}, bin_thold,
                     num_ignore, plan);
-    RankWorkspace &ws = h->rank_ws;
     ws.host_ms[0] = ms_since(t_all);
     ws.host_ms[1] = ws.host_ms[2] = ws.host_ms[3] = 0.0;
     const int64_t nq = (int64_t)plan.qu.size();
-    std::unique_ptr<double[]> vals(new double[(size_t)nq * N_MEAS + 1]); // only the rows of queries with a list are written and read
+    double *vals = ws.vals.need((size_t)nq * N_MEAS + 1); // only the rows of queries with a list are written and read
     std::vector<int32_t> no_lists;
     const int32_t *top_count = nullptr;
     if (nq > 0 && !plan.cand.empty()) {
@@ -812,7 +1068,7 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
                                   : h->k + 1 + (ic_used ? h->n_conds : 0); // [factors | 1 or itemBias | one-hot conditions or icBias row]
         auto on_batch = [&](int64_t q0, int64_t q1) {
             rank_measures_range(plan, num_recs, (const int32_t *)ws.h_top.p, (const double *)ws.h_score.p, (const int32_t *)ws.h_count.p, q0, q1,
-                                vals.get(), q_user, q_ctx, q_count, top_items, top_scores);
+                                vals, q_user, q_ctx, q_count, top_items, top_scores);
         };
         hipError_t e;
         if (ext && h->f64) e = rank_run_device<double>(h->stream, ws, plan, ext_operands<double>(h, k_logical), bin_thold, num_recs, on_batch,
@@ -843,10 +1099,10 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
     } else {
         no_lists.assign((size_t)nq, 0);
         top_count = no_lists.data();
-        rank_measures_range(plan, num_recs, nullptr, nullptr, top_count, 0, nq, vals.get(), q_user, q_ctx, q_count, top_items, top_scores);
+        rank_measures_range(plan, num_recs, nullptr, nullptr, top_count, 0, nq, vals, q_user, q_ctx, q_count, top_items, top_scores);
     }
     const auto t_avg = std::chrono::steady_clock::now();
-    rank_average(plan, strategy, top_count, vals.get(), out);
+    rank_average(plan, strategy, top_count, vals, out);
     ws.host_ms[3] += ms_since(t_avg);
     ws.host_ms[4] = ms_since(t_all);
     if (n_queries) *n_queries = (int64_t)plan.qu.size();

@@ -5,8 +5,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <chrono>
 #include <functional>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace cmi {
@@ -48,12 +51,29 @@ struct RankWorkspace {
     Buf dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount; // device
     Buf dB2, dA2, dS2, dqg, dqd, dgu, ddc, dscr;                                // device, split form (rank_run_device_split)
     Buf h_top, h_score, h_count;                                                // pinned host: the lists as they come back
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evb[2] = {nullptr, nullptr};
+    RankPlan plan;                                                              // the last evaluation's plan (capacity is reused)
+    struct HostVals { // per-query measures, uninitialised and grow-only (38 MB for 270 K queries: not re-faulted per call)
+        std::unique_ptr<double[]> p;
+        size_t cap = 0;
+        double *need(size_t n) {
+            if (n > cap) {
+                p.reset(new double[n + n / 8]);
+                cap = n + n / 8;
+            }
+            return p.get();
+        }
+    } vals;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; // around the device loop (timing)
+    std::vector<hipEvent_t> evb;              // one per batch: its lists have arrived on the host
     // host wall clock of the last evaluation, ms: [0] plan, [1] setup (buffers, uploads, item operands), [2] scoring loop incl. the
     // overlapped per-batch measures, [3] tail (last batch's measures + the averages), [4] total
     double host_ms[5] = {0, 0, 0, 0, 0};
     hipError_t need(Buf &b, size_t bytes, bool pinned = false);
     void release(); // the caller has made the owning device current
+    hipError_t batch_event(size_t b, hipStream_t stream);
+    // waits for the batches in order and hands each to on_batch while the device works on the later ones; fills host_ms[2], [3]
+    hipError_t consume_batches(hipError_t e, const std::vector<std::pair<int64_t, int64_t>> &batches,
+                               const std::function<void(int64_t, int64_t)> &on_batch, std::chrono::steady_clock::time_point t_loop);
 };
 
 // on_batch(q0, q1): the lists of queries [q0, q1) have arrived in ws.h_top / h_score / h_count (absolute query indexing); called on

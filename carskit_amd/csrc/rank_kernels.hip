@@ -441,7 +441,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void rank_topn_split(const T *__restrict__ S1, const T *__restrict__ S2, const T *__restrict__ rc,
                                                        const int32_t *__restrict__ q_group, const int32_t *__restrict__ q_dctx, int g_base, int q0,
                                                        int nq, int nc, const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_idx,
-                                                       double thold, int topn, int32_t *out_idx, double *out_score, int32_t *out_count) {
+                                                       T tf, int topn, int32_t *out_idx, double *out_score, int32_t *out_count) {
+    // tf = the largest T <= the rating threshold: (double)x > threshold  <=>  x > tf, for every x of type T
     const int lane = threadIdx.x & 63;
     const int q = q0 + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= q0 + nq) return;
@@ -455,6 +456,10 @@ __global__ __launch_bounds__(256) void rank_topn_split(const T *__restrict__ S1,
     int li = -1;
     int count = 0;
     T t = -INFINITY;
+    // ONE comparison per score: `x > thr` with thr = tf while the list fills and the N-th best once it is full (every list entry is
+    // > tf, so max(tf, t) = t) -- false for NaN, for masked / out-of-range entries (-inf) and for `score > threshold` failing
+    // (Recommender.java:808-812)
+    T thr = tf;
     for (int base = 0; base < nc; base += 64 * RT_U) {
         T v[RT_U];
 #pragma unroll
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(256) void rank_topn_split(const T *__restrict__ S1,
         }
 #pragma unroll
         for (int u = 0; u < RT_U; ++u) {
-            unsigned long long m = __ballot((double)v[u] > thold && v[u] > -INFINITY && (count < topn || v[u] > t));
+            unsigned long long m = __ballot(v[u] > thr);
             while (m) {
                 const int l = __ffsll((long long)m) - 1;
                 m &= m - 1;
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(256) void rank_topn_split(const T *__restrict__ S1,
                     li = base + u * 64 + l;
                 }
                 if (count < topn) ++count;
-                if (count == topn) t = lane_bcast(lv, topn - 1);
+                if (count == topn) thr = t = lane_bcast(lv, topn - 1);
             }
         }
     }
@@ -575,8 +580,10 @@ hipError_t rank_launch_split_select(const float *S1, const float *S2, const Rank
                                     int q0, int nq, const int64_t *excl_ptr, const int32_t *excl_idx, double thold, int topn, int32_t *out_idx,
                                     double *out_score, int32_t *out_count, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
+    float tf = (float)thold; // round to nearest, then down to the largest float <= thold (NaN stays NaN: nothing passes, as before)
+    if ((double)tf > thold) tf = nextafterf(tf, -INFINITY);
     hipLaunchKernelGGL(rank_topn_split<float>, dim3((nq + 3) / 4), dim3(256), 0, s, S1, S2, (const float *)a.rc, q_group, q_dctx, g_base, q0, nq, a.nc,
-                       excl_ptr, excl_idx, thold, topn, out_idx, out_score, out_count);
+                       excl_ptr, excl_idx, tf, topn, out_idx, out_score, out_count);
     return hipGetLastError();
 }
 
