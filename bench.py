@@ -303,16 +303,25 @@ def bench_group(args):
     return out
 
 
-def rank_roofline(train, nq, n_cand, dev, flops, k, n_conds):
-    n_users_q = None
-    slab1 = lambda ng: 2.0 * ng * n_cand * 4            # S1 written + read once
-    ng = flops and max(1.0, flops / (2.0 * n_cand * ((k + 1 + 15) // 16 * 16)))   # upper estimate of the distinct query users from the flop count
-    hbm = slab1(ng)
-    cache = 2.0 * nq * n_cand * 4                        # every query streams one S1 row and one S2 row
-    return {"achieved": hbm / dev / 1e9, "frac": hbm / dev / 1e9 / HBM_PEAK_GBS, "traffic": None,
-            "bytes_model": "S1 slab (distinct query users x candidates x 4 B) written by the contraction and read by the selection",
-            "cache_traffic_GBps": cache / dev / 1e9, "contraction_flops": flops, "contraction_TFLOPs_over_whole_loop": flops / dev / 1e12,
-            "kernel": "rank_topn_split<float> (2/3 of the loop) + rank_gemm_mfma_f32 (v_mfma_f32_32x32x2_f32)"}
+F32_MFMA_PEAK_TFLOPS = 157.3     # dense fp32 matrix peak (MI355X_MICROARCH.md): v_mfma_f32_32x32x2_f32
+
+
+def rank_roofline(nq, n_cand, dev, flops, kern_ms):
+    """The evaluation's device loop is two kernels.  `roofline` prices the CONTRACTION (rank_gemm_mfma_f32: S1 = [P[u] | 1] x [Q[j] | b_j]^T
+    over the distinct query users) against the f32 matrix peak, by HIP events around its launches inside the loop.  The SELECTION
+    (rank_topn_split) streams one S1 row and one S2 row per QUERY out of L2 / Infinity Cache (the S1 slab is written and read through HBM
+    once): its rate rides along as `selection`."""
+    g, t = kern_ms["contraction"] * 1e-3, kern_ms["selection"] * 1e-3
+    out = {"bound": "mfma", "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "achieved": flops / g / 1e12 if g else None,
+           "frac": flops / g / 1e12 / F32_MFMA_PEAK_TFLOPS if g else None, "traffic": None,
+           "kernel": "rank_gemm_mfma_f32 (v_mfma_f32_32x32x2_f32)", "flops": flops, "kernel_ms": g * 1e3,
+           "timing": "HIP events around the contraction's launches on the instance stream, summed over the batches of one evaluation",
+           "selection": {"kernel": "rank_topn_split<float>", "kernel_ms": t * 1e3,
+                         "bytes_streamed": 2.0 * nq * n_cand * 4,
+                         "GBps_through_L2": 2.0 * nq * n_cand * 4 / t / 1e9 if t else None,
+                         "note": "one S1 row (shared by the user's queries: L2) and one S2 row (Infinity Cache) per query"},
+           "contraction_TFLOPs_over_whole_loop": flops / dev / 1e12}
+    return out
 
 
 def bench_rank(args):
@@ -336,6 +345,7 @@ def bench_rank(args):
         walls.append(time.perf_counter() - t0)
         dev_ms, flops = inst.last_rank_ms()
         ms.append(dev_ms)
+        kern = inst.last_rank_kernel_ms()
     dev = float(np.mean(ms)) * 1e-3
     wall = float(np.mean(walls))
     nq = res["n_queries"]
@@ -351,12 +361,7 @@ def bench_rank(args):
                       "host_ms_breakdown_last_step": inst.last_rank_host_ms(),
                       "note": "value = queries / host wall clock of the whole call: the plan (candidates, queries, exclusions; host threads), "
                               "uploads, the device scoring loop, and the per-query measures computed batch by batch behind the device"},
-           # The MF family in fp32 runs the SPLIT form (S1 per distinct query user + S2 per distinct context, added by the selection): 7x fewer
-           # matrix-core flops than one dot product per query, and the loop is bound by the selection's row streaming, not by the
-           # contraction.  `achieved` = the HBM-compulsory bytes of the loop (the S1 slab written by the contraction and read by the
-           # selection, the S2 slab, the operands) / device time; the selection additionally re-reads S1 / S2 rows out of L2 / Infinity
-           # Cache once per QUERY (`cache_traffic_GBps`).  The contraction's own rate rides along as `contraction_flops`.
-           "roofline": dict(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", **rank_roofline(train, nq, n_cand, dev, flops, k, train.n_conds)),
+           "roofline": rank_roofline(nq, n_cand, dev, flops, kern),
            "AUC10": res["AUC10"]}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, k, train, state, float(train.r.mean()), (1e-4, 1e-4, 1e-4, 1e-3), 0.0, 0, rank_queries=(test, 200))

@@ -73,6 +73,7 @@ SYMBOLS = [
                                        C.c_int, _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
     ("cmi_last_rank_ms", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_dbl)]),
     ("cmi_last_rank_host_ms", C.c_int, [_vp, _vp]),
+    ("cmi_last_rank_kernel_ms", C.c_int, [_vp, _vp]),
     ("cmi_group_set_eval_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     ("cmi_group_eval_resident", C.c_int, [_vp, _dbl, _dbl, _vp, C.POINTER(_i64)]),
     ("cmi_comm_unique_id", C.c_int, [_vp]),
@@ -743,6 +744,11 @@ class Instance:
         out = np.zeros(5)
         self._chk(self.L.cmi_last_rank_host_ms(self.h, _p(out)))
         return dict(zip(("plan", "setup", "scoring_loop", "tail", "total"), out.tolist()))
+
+    def last_rank_kernel_ms(self):
+        out = np.zeros(2)
+        self._chk(self.L.cmi_last_rank_kernel_ms(self.h, _p(out)))
+        return dict(zip(("contraction", "selection"), out.tolist()))
 
     def eval_rankings(self, train, test, bin_thold=-1.0, num_recs=10, num_ignore=0, strategy="ucu", with_lists=False):
         """Recommender.evalRankings (Recommender.java:668-964).  train/test: (u, j, ctx, r) array tuples.

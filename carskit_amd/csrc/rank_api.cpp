@@ -300,44 +300,101 @@ struct PlanScratchLease {
 void rank_build_plan(int n_users, int n_items, const RankTuples &train, const RankTuples &test, double bin_thold,
                      int num_ignore, RankPlan &plan) {
     const int nt = host_threads(train.n + test.n);
-    const bool TT = getenv("CMI_PLAN_TIMES") != nullptr; auto T0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char *w) { if (TT) { auto n = std::chrono::steady_clock::now(); fprintf(stderr, "plan %s %.3f ms\n", w, std::chrono::duration<double, std::milli>(n - T0).count()); T0 = n; } };
+    const bool times = getenv("CMI_PLAN_TIMES") != nullptr; // tools/exp/rank_plan_time.py
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) {
+        if (!times) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "plan %s %.3f ms\n", w, std::chrono::duration<double, std::milli>(n - T0).count());
+        T0 = n;
+    };
     auto range_of = [](int64_t n, int parts, int p, int64_t &b, int64_t &e) {
         const int64_t step = (n + parts - 1) / parts;
         b = std::min<int64_t>(n, p * step);
         e = std::min<int64_t>(n, b + step);
     };
-    // candidate items: rateDao.getItemList(trainMatrix) -> HashSet<Integer> (DataDAO.java:1210-1218); the HashSet's iteration order is
-    // computed from the first-seen order of the items.  Ranges of training tuples keep their own first-seen list and degrees; an
-    // item's global first occurrence lies in the earliest range that holds it, so walking the ranges in order and keeping the items
-    // not seen before reproduces the sequential pass.
     PlanScratchLease lease;
     PlanScratch &S = *lease.s;
-    std::vector<int32_t> first_seen, degree(n_items, 0);
-    {
-        const int np = (int)std::max<int64_t>(1, std::min<int64_t>(nt, ((int64_t)16 << 20) / std::max(n_items, 1)));
-        std::vector<std::vector<int32_t>> &lfirst = S.lfirst, &ldeg = S.ldeg;
-        if (lfirst.size() < (size_t)np) lfirst.resize((size_t)np);
-        if (ldeg.size() < (size_t)np) ldeg.resize((size_t)np);
+    const size_t nu = (size_t)n_users;
+    // users fall into at most 256 BUCKETS of 2^sh consecutive ids (a shift per tuple, not a division)
+    int sh = 0;
+    // (256 buckets measured best on an MI355X box's host: 3.7 ms for the 2 M tuples of the bench against 4.1 / 5.1 with 64 / 16)
+    while ((((int64_t)n_users - 1) >> sh) >= 256) ++sh;
+    const int nbk = (int)(((int64_t)n_users - 1) >> sh) + 1;
+    using UK = PlanUK;
+    std::vector<std::vector<UK>> &tl = S.tl, &pl = S.pl; // [tuple range][user bucket]
+    if (tl.size() < (size_t)nt * nbk) tl.resize((size_t)nt * nbk);
+    if (pl.size() < (size_t)nt * nbk) pl.resize((size_t)nt * nbk);
+    int np = (int)std::max<int64_t>(1, std::min<int64_t>(nt, ((int64_t)16 << 20) / std::max(n_items, 1)));
+    if (const char *e = getenv("CMI_PLAN_DEG_RANGES")) np = std::max(1, std::min(atoi(e), nt)); // tests: the huge-catalogue form on small inputs
+    std::vector<std::vector<int32_t>> &lfirst = S.lfirst, &ldeg = S.ldeg;
+    if (lfirst.size() < (size_t)nt) lfirst.resize((size_t)nt);
+    if (ldeg.size() < (size_t)nt) ldeg.resize((size_t)nt);
+    auto positive = [&](int64_t t) { return test.r[t] != 0.0 && test.r[t] > bin_thold; };
+
+    // ONE pass over the tuples, in ranges of tuples.  Per range: (a) the items in first-seen order with their degrees (candidates:
+    // rateDao.getItemList(trainMatrix) -> HashSet<Integer>, DataDAO.java:1210-1218, whose iteration order is computed from the
+    // first-seen order); (b) the training tuples and the test positives (rate > threshold; DataDAO.getUserCtxList,
+    // DataDAO.java:1114-1140) appended to one sequential list per user bucket.
+    parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
+        for (int64_t p = p0; p < p1; ++p) {
+            std::vector<UK> *tp = &tl[(size_t)p * nbk], *pp = &pl[(size_t)p * nbk];
+            std::vector<int32_t> &deg = ldeg[(size_t)p], &fs = lfirst[(size_t)p];
+            fs.clear();
+            int64_t b, e;
+            range_of(train.n, nt, (int)p, b, e);
+            for (int q = 0; q < nbk; ++q) {
+                tp[q].clear();
+                pp[q].clear();
+                tp[q].reserve((size_t)((e - b) / nbk + (e - b) / (4 * nbk) + 16));
+            }
+            const bool fused = np == nt; // every tuple range records its own degrees: no second pass over the items
+            if (fused) deg.assign((size_t)n_items, 0);
+            for (int64_t t = b; t < e; ++t) {
+                if (train.r && train.r[t] == 0.0) continue; // a sparse matrix holds no zero entries
+                const uint32_t u = (uint32_t)train.u[t];
+                const int32_t j = train.j[t];
+                tp[u >> sh].push_back(UK{u, (uint32_t)train.ctx[t], (uint32_t)j});
+                if (fused && deg[j]++ == 0) fs.push_back(j);
+            }
+            range_of(test.n, nt, (int)p, b, e);
+            for (int64_t t = b; t < e; ++t)
+                if (positive(t)) {
+                    const uint32_t u = (uint32_t)test.u[t];
+                    pp[u >> sh].push_back(UK{u, (uint32_t)test.ctx[t], (uint32_t)test.j[t]});
+                }
+        }
+    });
+    if (np != nt) // a huge catalogue: per-range degrees cost n_items ints each, so fewer (larger) ranges record them
         parallel_ranges(np, np, [&](int, int64_t p0, int64_t p1) {
             for (int64_t p = p0; p < p1; ++p) {
-                int64_t b, e;
-                range_of(train.n, np, (int)p, b, e);
                 std::vector<int32_t> &deg = ldeg[(size_t)p], &fs = lfirst[(size_t)p];
                 deg.assign((size_t)n_items, 0);
-                fs.clear();
+                int64_t b, e;
+                range_of(train.n, np, (int)p, b, e);
                 for (int64_t t = b; t < e; ++t) {
-                    if (train.r && train.r[t] == 0.0) continue; // a sparse matrix holds no zero entries
+                    if (train.r && train.r[t] == 0.0) continue;
                     if (deg[train.j[t]]++ == 0) fs.push_back(train.j[t]);
                 }
             }
         });
-        for (int p = 0; p < np; ++p)
-            for (int32_t j : lfirst[(size_t)p]) {
-                if (degree[j] == 0) first_seen.push_back(j);
-                degree[j] += ldeg[(size_t)p][j];
-            }
-    }
+    lap("tuples");
+    // An item's global first occurrence lies in the EARLIEST range that holds it: per item the earliest range and the total degree
+    // (ranges of items), then every range keeps the items it saw first (in its own order), and the ranges follow each other.
+    std::vector<int32_t> first_seen, degree(n_items, 0), pmin(n_items, -1);
+    parallel_ranges(n_items, np, [&](int, int64_t j0, int64_t j1) {
+        for (int p = 0; p < np; ++p) {
+            const int32_t *d = ldeg[(size_t)p].data();
+            for (int64_t j = j0; j < j1; ++j)
+                if (d[j]) {
+                    if (pmin[(size_t)j] < 0) pmin[(size_t)j] = p;
+                    degree[(size_t)j] += d[j];
+                }
+        }
+    });
+    for (int p = 0; p < np; ++p)
+        for (int32_t j : lfirst[(size_t)p])
+            if (pmin[(size_t)j] == p) first_seen.push_back(j);
     lap("first_seen");
     std::vector<int32_t> &cand = plan.cand;
     cand = java_int_hashset_order(first_seen);
@@ -351,129 +408,102 @@ void rank_build_plan(int n_users, int n_items, const RankTuples &train, const Ra
     const int nc = (int)cand.size();
     std::vector<int32_t> cand_pos(n_items, -1);
     for (int i = 0; i < nc; ++i) cand_pos[cand[i]] = i;
-
     lap("cand");
-    // Training tuples and test positives (rate > threshold; DataDAO.getUserCtxList, DataDAO.java:1114-1140) bucketed by user as
-    // packed (context, item) keys, in the caller's order inside a bucket.  Two passes, both cache-friendly: (1) every RANGE OF TUPLES
-    // is split by one thread into nt sequential lists, one per range of users; (2) every RANGE OF USERS walks its lists in tuple-range
-    // order (that keeps the caller's order), counts, and places the keys inside its own region of the key array (a region and its
-    // cursors fit the core's cache; no two threads share a cursor).
-    const size_t nu = (size_t)n_users;
-    const int64_t ustep = ((int64_t)n_users + nt - 1) / nt; // the user ranges of parallel_ranges(n_users, nt, ...)
-    using UK = PlanUK;
-    std::vector<std::vector<UK>> &tl = S.tl, &pl = S.pl; // [tuple range][user range]
-    if (tl.size() < (size_t)nt * nt) tl.resize((size_t)nt * nt);
-    if (pl.size() < (size_t)nt * nt) pl.resize((size_t)nt * nt);
-    auto positive = [&](int64_t t) { return test.r[t] != 0.0 && test.r[t] > bin_thold; };
-    parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
-        for (int64_t p = p0; p < p1; ++p) {
-            std::vector<UK> *tp = &tl[(size_t)p * nt], *pp = &pl[(size_t)p * nt];
-            int64_t b, e;
-            range_of(train.n, nt, (int)p, b, e);
-            for (int q = 0; q < nt; ++q) {
-                tp[q].clear();
-                pp[q].clear();
-                tp[q].reserve((size_t)((e - b) / nt + (e - b) / (4 * nt) + 16));
-            }
-            for (int64_t t = b; t < e; ++t)
-                if (!(train.r && train.r[t] == 0.0)) tp[train.u[t] / ustep].push_back(UK{(uint32_t)train.u[t], (uint32_t)train.ctx[t], (uint32_t)train.j[t]});
-            range_of(test.n, nt, (int)p, b, e);
-            for (int64_t t = b; t < e; ++t)
-                if (positive(t)) pp[test.u[t] / ustep].push_back(UK{(uint32_t)test.u[t], (uint32_t)test.ctx[t], (uint32_t)test.j[t]});
-        }
-    });
-    lap("split");
-    std::vector<int64_t> tbase((size_t)nt + 1, 0), pbase((size_t)nt + 1, 0); // first key of every user range
-    for (int q = 0; q < nt; ++q) {
+
+    // Every user BUCKET walks its lists in tuple-range order (that keeps the caller's order inside a user), counts, and places the
+    // packed (context, item) keys inside its own region of the key array (a region and its cursors fit the core's cache; no two
+    // threads share a cursor).
+    std::vector<int64_t> tbase((size_t)nbk + 1, 0), pbase((size_t)nbk + 1, 0); // first key of every bucket
+    for (int q = 0; q < nbk; ++q) {
         int64_t ts = 0, ps = 0;
         for (int p = 0; p < nt; ++p) {
-            ts += (int64_t)tl[(size_t)p * nt + q].size();
-            ps += (int64_t)pl[(size_t)p * nt + q].size();
+            ts += (int64_t)tl[(size_t)p * nbk + q].size();
+            ps += (int64_t)pl[(size_t)p * nbk + q].size();
         }
         tbase[(size_t)q + 1] = tbase[(size_t)q] + ts;
         pbase[(size_t)q + 1] = pbase[(size_t)q] + ps;
     }
     int64_t *toff = S.toff.need(nu + 1), *poff = S.poff.need(nu + 1);
-    toff[nu] = tbase[(size_t)nt];
-    poff[nu] = pbase[(size_t)nt];
+    toff[nu] = tbase[(size_t)nbk];
+    poff[nu] = pbase[(size_t)nbk];
     uint64_t *tkey = S.tkey.need((size_t)toff[nu] + 1), *pkey = S.pkey.need((size_t)poff[nu] + 1);
-    parallel_ranges(n_users, nt, [&](int part, int64_t u0, int64_t u1) {
-        if (u0 >= u1) return;
-        auto place = [&](const std::vector<std::vector<UK>> &lists, int64_t base, int64_t *off, uint64_t *key) {
-            std::vector<int64_t> cur((size_t)(u1 - u0) + 1, 0);
-            for (int p = 0; p < nt; ++p)
-                for (const UK &x : lists[(size_t)p * nt + part]) cur[(size_t)(x.u - u0) + 1]++;
-            int64_t run = base;
-            for (int64_t u = u0; u < u1; ++u) {
-                off[(size_t)u] = run;
-                const int64_t n = cur[(size_t)(u - u0) + 1];
-                cur[(size_t)(u - u0)] = run;
-                run += n;
-            }
-            for (int p = 0; p < nt; ++p)
-                for (const UK &x : lists[(size_t)p * nt + part]) key[(size_t)cur[(size_t)(x.u - u0)]++] = ((uint64_t)x.c << 32) | x.j;
-        };
-        place(tl, tbase[(size_t)part], toff, tkey);
-        place(pl, pbase[(size_t)part], poff, pkey);
-    });
-    lap("place");
     // per user: its queries in (context, item) order -- a query is a (user, context) with at least one correct item that is a
     // candidate (Recommender.java:789-790) -- and, per query, the candidate positions of the items the user rated in the same
-    // context in the training set (Recommender.java:793, 814-816), in item order
+    // context in the training set (Recommender.java:793, 814-816), in item order.  One part per bucket.
     using Part = PlanPart;
     std::vector<Part> &parts = S.parts;
-    if (parts.size() < (size_t)nt) parts.resize((size_t)nt);
-    for (Part &P : parts) P.clear();
-    parallel_ranges(n_users, nt, [&](int part, int64_t u0, int64_t u1) {
-        Part &P = parts[(size_t)part];
+    if (parts.size() < (size_t)nbk) parts.resize((size_t)nbk);
+    parallel_ranges(nbk, nt, [&](int, int64_t k0, int64_t k1) {
+        std::vector<int64_t> cur;
         std::vector<uint32_t> items;
-        for (int64_t u = u0; u < u1; ++u) {
-            uint64_t *pb = pkey + poff[(size_t)u], *pe = pkey + poff[(size_t)u + 1];
-            if (pb == pe) continue;
-            std::sort(pb, pe);
-            const uint64_t *tb = tkey + toff[(size_t)u], *te = tkey + toff[(size_t)u + 1];
-            for (uint64_t *i = pb; i < pe;) {
-                const uint32_t c = (uint32_t)(*i >> 32);
-                const size_t before = P.truth_items.size();
-                uint64_t *e = i;
-                for (; e < pe && (uint32_t)(*e >> 32) == c; ++e) {
-                    const int32_t j = (int32_t)(uint32_t)*e;
-                    if (cand_pos[j] >= 0 && (P.truth_items.size() == before || P.truth_items.back() != j)) P.truth_items.push_back(j);
+        for (int64_t k = k0; k < k1; ++k) {
+            const int64_t u0 = k << sh, u1 = std::min<int64_t>(n_users, (k + 1) << sh);
+            auto place = [&](const std::vector<std::vector<UK>> &lists, int64_t base, int64_t *off, uint64_t *key) {
+                cur.assign((size_t)(u1 - u0) + 1, 0);
+                for (int p = 0; p < nt; ++p)
+                    for (const UK &x : lists[(size_t)p * nbk + (size_t)k]) cur[(size_t)(x.u - u0) + 1]++;
+                int64_t run = base;
+                for (int64_t u = u0; u < u1; ++u) {
+                    off[(size_t)u] = run;
+                    const int64_t n = cur[(size_t)(u - u0) + 1];
+                    cur[(size_t)(u - u0)] = run;
+                    run += n;
                 }
-                i = e;
-                if (P.truth_items.size() == before) continue;
-                P.qu.push_back((int32_t)u);
-                P.qc.push_back((int32_t)c);
-                P.truth_end.push_back((int64_t)P.truth_items.size());
-                const size_t ebefore = P.excl_idx.size();
-                items.clear(); // the user's training items in this context, ascending (users hold tens of tuples: a scan per query)
-                for (const uint64_t *t = tb; t < te; ++t)
-                    if ((uint32_t)(*t >> 32) == c) items.push_back((uint32_t)*t);
-                std::sort(items.begin(), items.end());
-                for (uint32_t j : items) {
-                    const int32_t cp = cand_pos[j];
-                    if (cp >= 0 && (P.excl_idx.size() == ebefore || P.excl_idx.back() != cp)) P.excl_idx.push_back(cp);
+                for (int p = 0; p < nt; ++p)
+                    for (const UK &x : lists[(size_t)p * nbk + (size_t)k]) key[(size_t)cur[(size_t)(x.u - u0)]++] = ((uint64_t)x.c << 32) | x.j;
+            };
+            place(tl, tbase[(size_t)k], toff, tkey);
+            place(pl, pbase[(size_t)k], poff, pkey);
+            Part &P = parts[(size_t)k];
+            P.clear();
+            for (int64_t u = u0; u < u1; ++u) {
+                uint64_t *pb = pkey + poff[(size_t)u], *pe = u + 1 < u1 ? pkey + poff[(size_t)u + 1] : pkey + pbase[(size_t)k + 1];
+                if (pb == pe) continue;
+                std::sort(pb, pe);
+                const uint64_t *tb = tkey + toff[(size_t)u], *te = u + 1 < u1 ? tkey + toff[(size_t)u + 1] : tkey + tbase[(size_t)k + 1];
+                for (uint64_t *i = pb; i < pe;) {
+                    const uint32_t c = (uint32_t)(*i >> 32);
+                    const size_t before = P.truth_items.size();
+                    uint64_t *e = i;
+                    for (; e < pe && (uint32_t)(*e >> 32) == c; ++e) {
+                        const int32_t j = (int32_t)(uint32_t)*e;
+                        if (cand_pos[j] >= 0 && (P.truth_items.size() == before || P.truth_items.back() != j)) P.truth_items.push_back(j);
+                    }
+                    i = e;
+                    if (P.truth_items.size() == before) continue;
+                    P.qu.push_back((int32_t)u);
+                    P.qc.push_back((int32_t)c);
+                    P.truth_end.push_back((int64_t)P.truth_items.size());
+                    const size_t ebefore = P.excl_idx.size();
+                    items.clear(); // the user's training items in this context, ascending (users hold tens of tuples: a scan per query)
+                    for (const uint64_t *t = tb; t < te; ++t)
+                        if ((uint32_t)(*t >> 32) == c) items.push_back((uint32_t)*t);
+                    std::sort(items.begin(), items.end());
+                    for (uint32_t j : items) {
+                        const int32_t cp = cand_pos[j];
+                        if (cp >= 0 && (P.excl_idx.size() == ebefore || P.excl_idx.back() != cp)) P.excl_idx.push_back(cp);
+                    }
+                    P.excl_end.push_back((int64_t)P.excl_idx.size());
                 }
-                P.excl_end.push_back((int64_t)P.excl_idx.size());
             }
         }
     });
-    lap("per_user");
-    // the parts, in range order
-    std::vector<int64_t> q0((size_t)nt + 1, 0), t0((size_t)nt + 1, 0), e0((size_t)nt + 1, 0);
-    for (int p = 0; p < nt; ++p) {
+    lap("users");
+    // the parts, in bucket order
+    std::vector<int64_t> q0((size_t)nbk + 1, 0), t0((size_t)nbk + 1, 0), e0((size_t)nbk + 1, 0);
+    for (int p = 0; p < nbk; ++p) {
         q0[(size_t)p + 1] = q0[(size_t)p] + (int64_t)parts[(size_t)p].qu.size();
         t0[(size_t)p + 1] = t0[(size_t)p] + (int64_t)parts[(size_t)p].truth_items.size();
         e0[(size_t)p + 1] = e0[(size_t)p] + (int64_t)parts[(size_t)p].excl_idx.size();
     }
-    plan.qu.resize((size_t)q0[(size_t)nt]);
-    plan.qc.resize((size_t)q0[(size_t)nt]);
-    plan.truth_ptr.resize((size_t)q0[(size_t)nt] + 1);
-    plan.excl_ptr.resize((size_t)q0[(size_t)nt] + 1);
-    plan.truth_items.resize((size_t)t0[(size_t)nt]);
-    plan.excl_idx.resize((size_t)e0[(size_t)nt]);
+    plan.qu.resize((size_t)q0[(size_t)nbk]);
+    plan.qc.resize((size_t)q0[(size_t)nbk]);
+    plan.truth_ptr.resize((size_t)q0[(size_t)nbk] + 1);
+    plan.excl_ptr.resize((size_t)q0[(size_t)nbk] + 1);
+    plan.truth_items.resize((size_t)t0[(size_t)nbk]);
+    plan.excl_idx.resize((size_t)e0[(size_t)nbk]);
     plan.truth_ptr[0] = plan.excl_ptr[0] = 0;
-    parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
+    parallel_ranges(nbk, nt, [&](int, int64_t p0, int64_t p1) {
         for (int64_t p = p0; p < p1; ++p) {
             const Part &P = parts[(size_t)p];
             std::copy(P.qu.begin(), P.qu.end(), plan.qu.begin() + q0[(size_t)p]);
@@ -614,6 +644,18 @@ void RankWorkspace::release() {
     for (hipEvent_t e : evb)
         if (e) (void)hipEventDestroy(e);
     evb.clear();
+    for (hipEvent_t e : evk)
+        if (e) (void)hipEventDestroy(e);
+    evk.clear();
+}
+
+hipError_t RankWorkspace::kernel_event(size_t i, hipStream_t stream) {
+    while (evk.size() <= i) {
+        hipEvent_t ev = nullptr;
+        if (hipError_t e = hipEventCreate(&ev)) return e;
+        evk.push_back(ev);
+    }
+    return hipEventRecord(evk[i], stream);
 }
 
 hipError_t RankWorkspace::batch_event(size_t b, hipStream_t stream) {
@@ -642,6 +684,17 @@ hipError_t RankWorkspace::consume_batches(hipError_t e, const std::vector<std::p
 
 static double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Batch boundaries over n units of at most b: the FINAL batch is kept short (b / 16), because its lists are the only ones the host
+// turns into measures with the device already idle.
+static std::vector<int64_t> batch_cuts(int64_t n, int64_t b) {
+    std::vector<int64_t> cuts;
+    for (int64_t x = 0; x < n; x += b) cuts.push_back(x);
+    cuts.push_back(n);
+    const int64_t small = std::max<int64_t>(64, b / 16);
+    if (cuts.size() >= 2 && n - cuts[cuts.size() - 2] > 2 * small) cuts.insert(cuts.end() - 1, n - small);
+    return cuts;
 }
 
 template <typename T>
@@ -707,8 +760,10 @@ hipError_t rank_run_device(hipStream_t stream, RankWorkspace &ws, const RankPlan
     // batch's selection, which reads the same slab); the host then turns the lists into measures batch by batch as their copies land,
     // behind the device, and can never hold the device up.
     std::vector<std::pair<int64_t, int64_t>> batches;
-    for (int64_t q0 = 0; q0 < nq && e == hipSuccess; q0 += bq) {
-        const int n = (int)std::min<int64_t>(bq, nq - q0);
+    const std::vector<int64_t> cuts = batch_cuts(nq, bq);
+    for (size_t b = 0; b + 1 < cuts.size() && e == hipSuccess; ++b) {
+        const int64_t q0 = cuts[b];
+        const int n = (int)(cuts[b + 1] - q0);
         e = ops.build_queries(dA, drc, dqu + q0, dqc + q0, n, kp, stream);
         if (e == hipSuccess) e = rank_launch_score<T>(dA, dB, drc, dS, n, nc, kp, dexptr, dexcl, (int)q0, thold, topn, dtop, dscore, dcount, stream);
         if (e == hipSuccess)
@@ -771,7 +826,8 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     const int64_t ng = (int64_t)gu.size();
     std::vector<int32_t> dctx, qd;
     const bool ic = a.icBias != nullptr;
-    if (ic) distinct_contexts(plan.qc, dctx, qd);
+    const bool s2 = ic; // the context part as a slab of its own (distinct contexts x candidates)
+    if (s2) distinct_contexts(plan.qc, dctx, qd);
     const int n_dc = (int)dctx.size();
     a.kp1 = (a.k + 1 + 15) / 16 * 16;
     a.kp2 = ic ? (a.n_conds + 15) / 16 * 16 : 16;
@@ -793,7 +849,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     need(ws.dS, (size_t)bg * (size_t)nc * 4);
     need(ws.dscr, std::max<size_t>(up128(bg), up128(n_dc)) * 4);
     need(ws.drc, (size_t)nq * 4);
-    if (ic) {
+    if (s2) {
         need(ws.dB2, up128(nc) * a.kp2 * 4);
         need(ws.dA2, up128(n_dc) * a.kp2 * 4);
         need(ws.dS2, (size_t)n_dc * (size_t)nc * 4);
@@ -827,7 +883,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     up(ws.dgu.p, gu.data(), (size_t)ng * 4);
     up(ws.dexptr.p, plan.excl_ptr.data(), (size_t)(nq + 1) * 8);
     up(ws.dexcl.p, plan.excl_idx.data(), plan.excl_idx.size() * 4);
-    if (ic) {
+    if (s2) {
         up(ws.ddc.p, dctx.data(), (size_t)n_dc * 4);
         up(ws.dqd.p, qd.data(), (size_t)nq * 4);
     }
@@ -847,20 +903,25 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     if (e == hipSuccess) e = rank_launch_split_operands(a, stream);
     if (e == hipSuccess) e = hipEventRecord(ws.ev0, stream);
     // S2: once per evaluation (row constant = the zeroed scratch)
-    if (e == hipSuccess && ic) e = rank_launch_gemm<float>(a.A2, a.B2, (const float *)ws.dscr.p, (float *)ws.dS2.p, n_dc, nc, a.kp2, stream);
+    if (e == hipSuccess && s2) e = rank_launch_gemm<float>(a.A2, a.B2, (const float *)ws.dscr.p, (float *)ws.dS2.p, n_dc, nc, a.kp2, stream);
     ws.host_ms[1] = ms_since(t_setup);
     const auto t_loop = std::chrono::steady_clock::now();
     std::vector<std::pair<int64_t, int64_t>> batches; // all enqueued first, consumed behind the device (see rank_run_device)
-    for (int64_t g0 = 0; g0 < ng && e == hipSuccess; g0 += bg) {
-        const int n = (int)std::min<int64_t>(bg, ng - g0);
+    const std::vector<int64_t> cuts = batch_cuts(ng, bg);
+    for (size_t b = 0; b + 1 < cuts.size() && e == hipSuccess; ++b) {
+        const int64_t g0 = cuts[b];
+        const int n = (int)(cuts[b + 1] - g0);
         const int64_t q0 = gq0[(size_t)g0], q1 = gq0[(size_t)(g0 + n)];
         // (the builder leaves its per-row constant -- zero here -- in the scratch the contraction then reads as its row constant)
         e = rank_launch_split_users(a, (const int32_t *)ws.dgu.p + g0, n, (float *)ws.dA.p, (float *)ws.dscr.p, stream);
+        if (e == hipSuccess) e = ws.kernel_event(3 * b, stream);
         if (e == hipSuccess) e = rank_launch_gemm<float>((const float *)ws.dA.p, a.B1, (const float *)ws.dscr.p, (float *)ws.dS.p, n, nc, a.kp1, stream);
+        if (e == hipSuccess) e = ws.kernel_event(3 * b + 1, stream);
         if (e == hipSuccess)
-            e = rank_launch_split_select((const float *)ws.dS.p, ic ? (const float *)ws.dS2.p : nullptr, a, (const int32_t *)ws.dqg.p,
+            e = rank_launch_split_select((const float *)ws.dS.p, s2 ? (const float *)ws.dS2.p : nullptr, a, (const int32_t *)ws.dqg.p,
                                          (const int32_t *)ws.dqd.p, (int)g0, (int)q0, (int)(q1 - q0), (const int64_t *)ws.dexptr.p,
                                          (const int32_t *)ws.dexcl.p, thold, topn, dtop, dscore, dcount, stream);
+        if (e == hipSuccess) e = ws.kernel_event(3 * b + 2, stream);
         const size_t nqb = (size_t)(q1 - q0);
         if (e == hipSuccess)
             e = hipMemcpyAsync((int32_t *)ws.h_top.p + (size_t)q0 * topn, dtop + (size_t)q0 * topn, nqb * topn * 4, hipMemcpyDeviceToHost, stream);
@@ -873,8 +934,15 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     if (e == hipSuccess) e = hipEventRecord(ws.ev1, stream);
     e = ws.consume_batches(e, batches, on_batch, t_loop);
     if (e == hipSuccess && ms) e = hipEventElapsedTime(ms, ws.ev0, ws.ev1);
+    for (size_t b = 0; b < batches.size() && e == hipSuccess; ++b) {
+        float g = 0.f, t = 0.f;
+        e = hipEventElapsedTime(&g, ws.evk[3 * b], ws.evk[3 * b + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, ws.evk[3 * b + 1], ws.evk[3 * b + 2]);
+        ws.kernel_ms[0] += g;
+        ws.kernel_ms[1] += t;
+    }
     // flops of THIS form: the two contractions it actually runs
-    if (flops) *flops = 2.0 * (double)ng * (double)nc * (double)a.kp1 + (ic ? 2.0 * (double)n_dc * (double)nc * (double)a.kp2 : 0.0);
+    if (flops) *flops = 2.0 * (double)ng * (double)nc * (double)a.kp1 + (s2 ? 2.0 * (double)n_dc * (double)nc * (double)a.kp2 : 0.0);
     return e;
 }
 
@@ -934,6 +1002,13 @@ extern "C" int cmi_last_rank_ms(cmi_handle h, float *ms, double *flops) {
     if (!h) return CMI_E_INVALID;
     if (ms) *ms = h->last_rank_ms;
     if (flops) *flops = h->last_rank_flops;
+    return CMI_OK;
+}
+
+extern "C" int cmi_last_rank_kernel_ms(cmi_handle h, double out[2]) {
+    if (!h || !out) return CMI_E_INVALID;
+    out[0] = h->rank_ws.kernel_ms[0];
+    out[1] = h->rank_ws.kernel_ms[1];
     return CMI_OK;
 }
 
@@ -1058,6 +1133,7 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
                     num_ignore, plan);
     ws.host_ms[0] = ms_since(t_all);
     ws.host_ms[1] = ws.host_ms[2] = ws.host_ms[3] = 0.0;
+    ws.kernel_ms[0] = ws.kernel_ms[1] = 0.0;
     const int64_t nq = (int64_t)plan.qu.size();
     double *vals = ws.vals.need((size_t)nq * N_MEAS + 1); // only the rows of queries with a list are written and read
     std::vector<int32_t> no_lists;

@@ -65,6 +65,9 @@ struct RankWorkspace {
     } vals;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; // around the device loop (timing)
     std::vector<hipEvent_t> evb;              // one per batch: its lists have arrived on the host
+    std::vector<hipEvent_t> evk;              // three per batch of the split form: before / after the contraction, after the selection
+    double kernel_ms[2] = {0, 0};             // last evaluation: contraction, selection (summed over the batches)
+    hipError_t kernel_event(size_t i, hipStream_t stream);
     // host wall clock of the last evaluation, ms: [0] plan, [1] setup (buffers, uploads, item operands), [2] scoring loop incl. the
     // overlapped per-batch measures, [3] tail (last batch's measures + the averages), [4] total
     double host_ms[5] = {0, 0, 0, 0, 0};

@@ -239,6 +239,10 @@ int cmi_last_rank_ms(cmi_handle h, float *ms, double *flops);
  * uploads, item operands), [2] the scoring loop including the per-batch measures computed behind it, [3] tail (last batch's measures +
  * the averages), [4] the whole call */
 int cmi_last_rank_host_ms(cmi_handle h, double out[5]);
+/* GPU time of the last evaluation's two kernels, by HIP events around their launches inside the scoring loop, milliseconds summed over
+ * the batches: out[0] the contraction (rank_gemm_mfma_f32), out[1] the selection (rank_topn_split); both 0 when the evaluation did not
+ * run the split form (fp64 state, SVD++ / CAMF_ICS / LCS / MCS) */
+int cmi_last_rank_kernel_ms(cmi_handle h, double out[2]);
 /* host-only (no GPU): the bookkeeping cmi_eval_rankings does before scoring -- candidate items in HashSet<Integer> order minus the
  * `num_ignore` most rated (Recommender.java:704-735), the (user, context) queries with their correct items (:776-790), and per
  * query the candidate POSITIONS of the items already rated in that context (:793-816).  Call once with null arrays for

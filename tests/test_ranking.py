@@ -161,12 +161,15 @@ def test_rank_plan_bookkeeping_matches_a_python_derivation(seed, num_ignore, tho
     # the plan is built in ranges of users on the host's cores (forced here: the input is far below the size that would use them):
     # element for element the serial result, whatever the number of ranges -- more ranges than users included
     import os
-    for nt in ("3", "7", "64"):
+    for nt, deg_ranges in (("3", None), ("7", None), ("64", None), ("7", "2"), ("5", "1")):
         os.environ["CMI_HOST_THREADS"] = nt
+        if deg_ranges:      # the form for huge catalogues: fewer, larger ranges record the item degrees in a pass of their own
+            os.environ["CMI_PLAN_DEG_RANGES"] = deg_ranges
         try:
             assert capi.rank_plan(n_users, n_items, train, test, thold, num_ignore) == (cand, queries)
         finally:
             del os.environ["CMI_HOST_THREADS"]
+            os.environ.pop("CMI_PLAN_DEG_RANGES", None)
 
 
 def test_list_measures_library_matches_oracle_formulas():
