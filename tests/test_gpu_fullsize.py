@@ -150,18 +150,23 @@ def test_big_shapes_full_size_properties_and_prefix_oracle(name):
         e2 += float(np.sum((data.r[sl] - inst.predict(data.u[sl], data.j[sl], data.ctx[sl])) ** 2))
     assert abs(loss0 - 0.5 * (e2 + _reg_terms(model, data, state))) <= 2e-6 * loss0
 
-    # (2) schedule independence at full size: hub-chain levels == plain level launches, bit for bit
-    l1 = inst.train_epoch(util.LR)
-    got = {n_: inst.get_state(n_, np.float32) for n_ in state}
-    del inst
-    plain = _big_inst(model, k, data, state, gm, flags=capi.FLAG_NO_CHAIN)
-    assert plain.schedule_info()["kind"] == "level"
-    plain.train_epoch(0.0)
-    l2 = plain.train_epoch(util.LR)
-    assert abs(l1 - l2) <= 1e-12 * abs(l2)
-    for n_ in state:
-        assert np.array_equal(plain.get_state(n_, np.float32), got[n_]), n_
-    del plain, got
+    # (2) schedule independence at full size: hub-chain levels == plain level launches, bit for bit.  (On the C5 share and, in
+    # test_c3_schedules_agree_bit_for_bit, on C3; the north_star shape would spend a minute building a second 200 M-tuple schedule
+    # for the same statement.)
+    if name == "c5":
+        l1 = inst.train_epoch(util.LR)
+        got = {n_: inst.get_state(n_, np.float32) for n_ in state}
+        del inst
+        plain = _big_inst(model, k, data, state, gm, flags=capi.FLAG_NO_CHAIN)
+        assert plain.schedule_info()["kind"] == "level"
+        plain.train_epoch(0.0)
+        l2 = plain.train_epoch(util.LR)
+        assert abs(l1 - l2) <= 1e-12 * abs(l2)
+        for n_ in state:
+            assert np.array_equal(plain.get_state(n_, np.float32), got[n_]), n_
+        del plain, got
+    else:
+        del inst
 
     # (3) one epoch over the first 5 M tuples (full-size tables on the GPU) against the CPU oracle.  The oracle's arithmetic does
     # not depend on the id values, so it runs on the users / items the prefix touches (compacted ids) -- same tuples, same rows.
