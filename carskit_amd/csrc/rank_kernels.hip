@@ -460,19 +460,36 @@ __global__ __launch_bounds__(256) void rank_topn_split(const T *__restrict__ S1,
     // > tf, so max(tf, t) = t) -- false for NaN, for masked / out-of-range entries (-inf) and for `score > threshold` failing
     // (Recommender.java:808-812)
     T thr = tf;
+    T n1[RT_U], n2[RT_U];
+    auto request = [&](int base) {
+        if (base + 64 * RT_U <= nc) { // a whole step
+#pragma unroll
+            for (int u = 0; u < RT_U; ++u) n1[u] = row1[base + u * 64 + lane];
+            if (row2) {
+#pragma unroll
+                for (int u = 0; u < RT_U; ++u) n2[u] = row2[base + u * 64 + lane];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < RT_U; ++u) {
+                const int c = base + u * 64 + lane;
+                n1[u] = c < nc ? row1[c] : (T)-INFINITY;
+                n2[u] = c < nc && row2 ? row2[c] : (T)0;
+            }
+        }
+    };
     for (int base = 0; base < nc; base += 64 * RT_U) {
         T v[RT_U];
+        request(base);
+        if (row2) {
 #pragma unroll
-        for (int u = 0; u < RT_U; ++u) {
-            const int c = base + u * 64 + lane;
-            T x = -INFINITY;
-            if (c < nc) {
-                x = row1[c];
-                if (row2) x += row2[c];
-                x += c0;
-            }
-            v[u] = x;
+            for (int u = 0; u < RT_U; ++u) v[u] = (n1[u] + n2[u]) + c0;
+        } else {
+#pragma unroll
+            for (int u = 0; u < RT_U; ++u) v[u] = n1[u] + c0;
         }
+        // (requesting the next step's rows here, behind this step's arithmetic, was measured: 4.4 against 4.3 ms -- no gain, the kernel
+        // waits on the memory system's throughput, not on a single request's latency; profiles/r04_rank_selection_forms.txt)
         // the (few) already-rated items of this query that fall into this step's 64 * RT_U candidates: wave-uniform walk
         while (next_excl < base + 64 * RT_U) {
             const int off = next_excl - base;
