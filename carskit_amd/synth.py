@@ -152,13 +152,33 @@ def _distinct_indices(n, domain, seed):
             left, right = right, left ^ (_mix64(right, k) & mask)
         return (left << hb) | right
 
-    with np.errstate(over="ignore"):
-        v = perm(np.arange(n, dtype=np.uint64))
-        bad = np.flatnonzero(v >= np.uint64(domain))
-        while len(bad):
-            v[bad] = perm(v[bad])
-            bad = bad[v[bad] >= np.uint64(domain)]
-    return v.astype(np.int64)
+    def walk(lo, hi):        # every index's value is a pure function of the index: ranges are independent
+        with np.errstate(over="ignore"):
+            v = perm(np.arange(lo, hi, dtype=np.uint64))
+            bad = np.flatnonzero(v >= np.uint64(domain))
+            while len(bad):
+                v[bad] = perm(v[bad])
+                bad = bad[v[bad] >= np.uint64(domain)]
+        out[lo:hi] = v.astype(np.int64)
+
+    out = np.empty(n, dtype=np.int64)
+    _ranges(n, 1 << 22, walk)
+    return out
+
+
+def _ranges(n, step, fn):
+    """fn(lo, hi) over [0, n) in ranges of `step` on a few host threads (NumPy releases the GIL inside its loops).  Used only where
+    the result does not depend on the split."""
+    import concurrent.futures
+    import os
+    spans = [(lo, min(n, lo + step)) for lo in range(0, n, step)]
+    workers = min(len(spans), max(1, min(16, (os.cpu_count() or 2) // 2)))
+    if workers <= 1:
+        for lo, hi in spans:
+            fn(lo, hi)
+        return
+    with concurrent.futures.ThreadPoolExecutor(workers) as ex:
+        list(ex.map(lambda sp: fn(*sp), spans))
 
 
 def _first_seen_dense(raw, size):
@@ -194,12 +214,20 @@ def generate_fast(n_users, n_items, n_dims, conds_per_dim, n_ratings, seed=DEFAU
     r = np.empty(n, dtype=np.float64)
     step = 1 << 22
     inv = np.float32(1.0 / np.sqrt(latent_k))
+    # the noise comes out of ONE generator stream, range after range (the values every earlier round generated); the gathers and the
+    # arithmetic of a range are independent of the other ranges and run on a few host threads
+    eps = np.empty(n, dtype=np.float32)
     for s in range(0, n, step):
         e = min(n, s + step)
+        eps[s:e] = rng.standard_normal(e - s, dtype=np.float32)
+
+    def rate(s, e):
         dot = np.einsum("nk,nk->n", zu[raw_u[s:e]], zi[raw_i[s:e]]) * inv
-        val = 3.0 + dot + zc[ckey[s:e]] + noise * rng.standard_normal(e - s, dtype=np.float32)
+        val = 3.0 + dot + zc[ckey[s:e]] + noise * eps[s:e]
         r[s:e] = np.clip(np.rint(val), 1, 5)
-    del zu, zi
+
+    _ranges(n, step, rate)
+    del zu, zi, eps
 
     u, nu, _ = _first_seen_dense(raw_u, n_users)
     i, ni, _ = _first_seen_dense(raw_i, n_items)
