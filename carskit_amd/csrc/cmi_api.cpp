@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "cmi_instance.hpp"
+#include "host_pool.hpp"
 #include "level_schedule.hpp"
 #include "mf_sgd_kernels.hpp"
 
@@ -420,18 +421,45 @@ static hipError_t upload(void **dst, const std::vector<V> &v, hipStream_t s) {
     return hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice, s);
 }
 
+template <typename V>
+static hipError_t upload(void **dst, const V *v, size_t count, hipStream_t s) {
+    *dst = nullptr;
+    if (!count) return hipSuccess;
+    hipError_t e = hipMalloc(dst, count * sizeof(V));
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(*dst, v, count * sizeof(V), hipMemcpyHostToDevice, s);
+}
+// a host array that is written once, in ranges, before it is read: not zero-filled first (5.6 GB for the north_star tuple stream)
+template <typename V>
+struct HostBuf {
+    std::unique_ptr<V[]> p;
+    size_t n = 0;
+    explicit HostBuf(size_t count = 0) : p(count ? new V[count] : nullptr), n(count) {}
+    V *data() { return p.get(); }
+    const V *data() const { return p.get(); }
+    V &operator[](size_t i) { return p[i]; }
+    const V &operator[](size_t i) const { return p[i]; }
+};
+template <typename V>
+static hipError_t upload(void **dst, const HostBuf<V> &v, hipStream_t s) {
+    return upload(dst, v.data(), v.n, s);
+}
+
 // Spoke arena bookkeeping: next[p] = stream position of the next tuple of the same spoke row (a row's tuples sit in ascending levels,
 // hence ascending positions); the row's last tuple wraps to its first -- that is where the row waits for the next epoch.
 // first[row] = position of the row's first tuple, -1 for a row without tuples.
 static void arena_positions(int64_t n, const int32_t *spoke, int64_t n_spokes, int32_t *next, int32_t *first) {
     for (int64_t r = 0; r < n_spokes; ++r) first[r] = -1;
-    for (int64_t p = n - 1; p >= 0; --p) {
+    for (int64_t p = n - 1; p >= 0; --p) { // sequential in p; the rows' entries (40 MB for 10 M users) are requested 24 tuples ahead
+        if (p >= 24) __builtin_prefetch(&first[spoke[p - 24]], 1);
         const int32_t r = spoke[p];
         next[p] = first[r]; // -1 for the row's last tuple: patched below
         first[r] = (int32_t)p;
     }
-    for (int64_t p = 0; p < n; ++p)
-        if (next[p] < 0) next[p] = first[spoke[p]];
+    parallel_ranges(n, host_threads(n), [&](int, int64_t b, int64_t e) {
+        for (int64_t p = b; p < e; ++p)
+            if (next[p] < 0) next[p] = first[spoke[p]];
+    });
 }
 // host-only export of the same (tests/test_chain_schedule.py)
 extern "C" int cmi_arena_positions(int64_t n, const int32_t *spoke, int32_t n_spokes, int32_t *next, int32_t *first) {
@@ -499,10 +527,22 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             if (ctx_conds[q] < 0 || ctx_conds[q] >= h->n_conds)
                 CMI_FAIL(h, CMI_E_INVALID, "set_ratings: condition id %d out of range [0,%d)", ctx_conds[q], h->n_conds);
     }
-    for (int64_t t = 0; t < n; ++t) {
-        if (u[t] < 0 || u[t] >= h->n_users) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: user id %d out of range at tuple %lld", u[t], (long long)t);
-        if (j[t] < 0 || j[t] >= h->n_items) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: item id %d out of range at tuple %lld", j[t], (long long)t);
-        if (contextual && (ctx[t] < 0 || ctx[t] >= n_ctx)) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: context id %d out of range at tuple %lld", ctx[t], (long long)t);
+    {
+        const int nt = host_threads(n);
+        std::vector<int64_t> bad((size_t)nt, -1); // first offending tuple of every range; the earliest is reported, as a sequential scan would
+        parallel_ranges(n, nt, [&](int part, int64_t b, int64_t e) {
+            for (int64_t t = b; t < e; ++t)
+                if (u[t] < 0 || u[t] >= h->n_users || j[t] < 0 || j[t] >= h->n_items || (contextual && (ctx[t] < 0 || ctx[t] >= n_ctx))) {
+                    bad[(size_t)part] = t;
+                    return;
+                }
+        });
+        for (int64_t t : bad) {
+            if (t < 0) continue;
+            if (u[t] < 0 || u[t] >= h->n_users) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: user id %d out of range at tuple %lld", u[t], (long long)t);
+            if (j[t] < 0 || j[t] >= h->n_items) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: item id %d out of range at tuple %lld", j[t], (long long)t);
+            CMI_FAIL(h, CMI_E_INVALID, "set_ratings: context id %d out of range at tuple %lld", ctx[t], (long long)t);
+        }
     }
     if (n >= ((int64_t)1 << 31) - 1024) CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: more than 2^31-1025 tuples per instance");
 
@@ -714,31 +754,44 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     // tuple stream in schedule order, conditions pre-expanded to [n x dmax] (-1 padded) so the kernels
     // need no ctx -> condition-list indirection.
     const int64_t ns = n;
-    std::vector<int32_t> su((size_t)ns), sj((size_t)ns), sconds((size_t)ns * (size_t)dmax);
-    std::vector<float> sr32;
-    std::vector<double> sr64;
-    if (h->f64) sr64.resize((size_t)ns);
-    else sr32.resize((size_t)ns);
-    for (int64_t s = 0; s < ns; ++s) {
-        const int64_t t = h->serial ? s : sch.perm[(size_t)s];
-        int32_t *row = dmax > 0 ? &sconds[(size_t)s * (size_t)dmax] : nullptr;
-        if (t < 0) { // padding slot
-            su[(size_t)s] = -1;
-            sj[(size_t)s] = 0;
-            for (int d = 0; d < dmax; ++d) row[d] = -1;
-            continue;
+    HostBuf<int32_t> su((size_t)ns), sj((size_t)ns), sconds((size_t)ns * (size_t)dmax);
+    HostBuf<float> sr32(h->f64 ? 0 : (size_t)ns);
+    HostBuf<double> sr64(h->f64 ? (size_t)ns : 0);
+    // every stream slot is a gather through the schedule's permutation: ranges of slots on the host's cores, the tuple arrays' entries
+    // requested 16 slots ahead
+    parallel_ranges(ns, host_threads(ns), [&](int, int64_t s0, int64_t s1) {
+        for (int64_t s = s0; s < s1; ++s) {
+            if (!h->serial && s + 16 < s1) {
+                const int64_t tp = sch.perm[(size_t)s + 16];
+                if (tp >= 0) {
+                    __builtin_prefetch(&u[tp]);
+                    __builtin_prefetch(&j[tp]);
+                    __builtin_prefetch(&r[tp]);
+                    if (dmax > 0) __builtin_prefetch(&ctx[tp]);
+                }
+            }
+            const int64_t t = h->serial ? s : sch.perm[(size_t)s];
+            int32_t *row = dmax > 0 ? &sconds[(size_t)s * (size_t)dmax] : nullptr;
+            if (t < 0) { // padding slot
+                su[(size_t)s] = -1;
+                sj[(size_t)s] = 0;
+                if (h->f64) sr64[(size_t)s] = 0.0;
+                else sr32[(size_t)s] = 0.f;
+                for (int d = 0; d < dmax; ++d) row[d] = -1;
+                continue;
+            }
+            su[(size_t)s] = u[t];
+            sj[(size_t)s] = j[t];
+            if (h->f64) sr64[(size_t)s] = r[t];
+            else sr32[(size_t)s] = (float)r[t];
+            if (dmax > 0) {
+                const int32_t b = ctx_ptr[ctx[t]], e = ctx_ptr[ctx[t] + 1];
+                int d = 0;
+                for (int32_t q = b; q < e; ++q) row[d++] = ctx_conds[q];
+                for (; d < dmax; ++d) row[d] = -1;
+            }
         }
-        su[(size_t)s] = u[t];
-        sj[(size_t)s] = j[t];
-        if (h->f64) sr64[(size_t)s] = r[t];
-        else sr32[(size_t)s] = (float)r[t];
-        if (dmax > 0) {
-            const int32_t b = ctx_ptr[ctx[t]], e = ctx_ptr[ctx[t] + 1];
-            int d = 0;
-            for (int32_t q = b; q < e; ++q) row[d++] = ctx_conds[q];
-            for (; d < dmax; ++d) row[d] = -1;
-        }
-    }
+    });
     hipError_t e = upload((void **)&h->d_su, su, h->stream);
     if (e == hipSuccess) e = upload((void **)&h->d_sj, sj, h->stream);
     if (e == hipSuccess) e = upload((void **)&h->d_sconds, sconds, h->stream);
@@ -771,8 +824,8 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (forced || large || probe) {
             // next_pos[p] = stream position of the next tuple of the same spoke row (its tuples sit in ascending levels, hence ascending
             // positions); the last one wraps to the first: that is where the row waits for the next epoch
-            std::vector<int32_t> nxt((size_t)n), first((size_t)spokes, -1);
-            const std::vector<int32_t> &sp = h->chain_hub_item ? su : sj;
+            HostBuf<int32_t> nxt((size_t)n), first((size_t)spokes);
+            const HostBuf<int32_t> &sp = h->chain_hub_item ? su : sj;
             arena_positions(n, sp.data(), spokes, nxt.data(), first.data());
             e = upload((void **)&h->d_next, nxt, h->stream);
             if (e == hipSuccess) e = upload((void **)&h->d_first, first, h->stream);

@@ -16,6 +16,10 @@
 // CMI_FLAG_SCHED_SERIAL.)
 #include "level_schedule.hpp"
 
+#include <thread>
+
+#include "host_pool.hpp"
+
 #include <queue>
 #include <functional>
 #include <utility>
@@ -149,33 +153,49 @@ void build_conflict_free_blocks(int64_t n, const int32_t *u, const int32_t *j, i
 // level schedule, bit for bit at equal arithmetic.
 // Inside a level the units are sorted by length, longest first (free: they are independent): the 4 groups of a wave then
 // walk chains of similar length and the longest chains are dispatched first.
+// The recurrence is sequential in t, but what it costs is the cache miss on the rows' level entries (a 10 M-user table is 40 MB): the
+// entries of tuple t + 24 are requested while tuple t is processed, and a hub row's three fields share one 12-byte entry.
+namespace {
+struct HubEntry {
+    int32_t level; // level of the hub row's previous tuple
+    int32_t unit;  // its current unit
+    int32_t len;   // tuples in that unit so far
+};
+} // namespace
 static void chain_pass(int64_t n, const int32_t *hub, const int32_t *spoke, int32_t n_hub, int32_t n_spoke, int max_chain,
-                       std::vector<int32_t> *level_out, std::vector<int32_t> *unit_out, std::vector<int32_t> *unit_level,
+                       std::vector<int32_t> *unit_out, std::vector<uint8_t> *pos_out, std::vector<int32_t> *unit_level,
                        std::vector<uint8_t> *unit_len, int32_t &n_levels, int64_t &n_units) {
-    std::vector<int32_t> lh((size_t)n_hub, 0), ls((size_t)n_spoke, 0), cur((size_t)n_hub, -1);
-    std::vector<uint8_t> cl((size_t)n_hub, 0);
+    std::vector<HubEntry> hb((size_t)n_hub, HubEntry{0, -1, 0});
+    std::vector<int32_t> ls((size_t)n_spoke, 0);
     n_levels = 0;
     n_units = 0;
+    constexpr int64_t AHEAD = 24;
     for (int64_t t = 0; t < n; ++t) {
-        const size_t hh = (size_t)hub[t], ss = (size_t)spoke[t];
-        const int32_t A = lh[hh], B = ls[ss];
+        if (t + AHEAD < n) {
+            __builtin_prefetch(&hb[(size_t)hub[t + AHEAD]], 1);
+            __builtin_prefetch(&ls[(size_t)spoke[t + AHEAD]], 1);
+        }
+        HubEntry &h = hb[(size_t)hub[t]];
+        const size_t ss = (size_t)spoke[t];
+        const int32_t A = h.level, B = ls[ss];
         int32_t l;
-        if (A > B && cl[hh] < max_chain) {
+        if (A > B && h.len < max_chain) {
             l = A;
-            cl[hh]++;
-            if (unit_len) (*unit_len)[(size_t)cur[hh]]++;
+            if (pos_out) (*pos_out)[(size_t)t] = (uint8_t)h.len;
+            h.len++;
+            if (unit_len) (*unit_len)[(size_t)h.unit]++;
         } else {
             l = (A > B ? A : B) + 1;
-            cl[hh] = 1;
-            cur[hh] = (int32_t)n_units++;
+            h.len = 1;
+            h.unit = (int32_t)n_units++;
+            if (pos_out) (*pos_out)[(size_t)t] = 0;
             if (unit_level) {
                 unit_level->push_back(l);
                 unit_len->push_back(1);
             }
         }
-        lh[hh] = ls[ss] = l;
-        if (level_out) (*level_out)[(size_t)t] = l;
-        if (unit_out) (*unit_out)[(size_t)t] = cur[hh];
+        h.level = ls[ss] = l;
+        if (unit_out) (*unit_out)[(size_t)t] = h.unit;
         if (l > n_levels) n_levels = l;
     }
 }
@@ -295,21 +315,37 @@ bool build_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t
     out.hub_is_item = hub == 0 ? 0 : 1;
     if (n <= 0) return true;
     if (n >= (int64_t)1 << 31) return false;
-    int32_t nl = 0;
-    int64_t nu = 0;
+    struct Side {
+        std::vector<int32_t> unit_of, unit_level;
+        std::vector<uint8_t> pos, unit_len;
+        int32_t nl = 0;
+        int64_t nu = 0;
+    };
+    auto run_side = [&](int item_hub, Side &sd) {
+        sd.unit_of.resize((size_t)n);
+        sd.pos.resize((size_t)n);
+        if (item_hub) chain_pass(n, j, u, n_items, n_users, max_chain, &sd.unit_of, &sd.pos, &sd.unit_level, &sd.unit_len, sd.nl, sd.nu);
+        else chain_pass(n, u, j, n_users, n_items, max_chain, &sd.unit_of, &sd.pos, &sd.unit_level, &sd.unit_len, sd.nl, sd.nu);
+    };
+    Side side;
     if (hub < 0) { // fewer units = fewer hub-row round trips through HBM; -2 / -3: a preferred side wins up to 1.3x the other's units
-        int64_t units_item = 0, units_user = 0;
-        chain_pass(n, j, u, n_items, n_users, max_chain, nullptr, nullptr, nullptr, nullptr, nl, units_item);
-        chain_pass(n, u, j, n_users, n_items, max_chain, nullptr, nullptr, nullptr, nullptr, nl, units_user);
+        // both sides are walked at the same time, each with its full output; the loser's is dropped (before: two counting walks, then
+        // the winner's walk again -- three sequential passes over the tuples)
+        Side other;
+        std::thread th([&]() { run_side(0, other); });
+        run_side(1, side);
+        th.join();
+        const int64_t units_item = side.nu, units_user = other.nu;
         if (hub == -2) hub = (double)units_user <= 1.3 * (double)units_item ? 0 : 1;
         else if (hub == -3) hub = (double)units_item <= 1.3 * (double)units_user ? 1 : 0;
         else hub = units_item <= units_user ? 1 : 0;
-    }
+        if (!hub) std::swap(side, other);
+    } else run_side(hub ? 1 : 0, side);
     out.hub_is_item = hub ? 1 : 0;
-    std::vector<int32_t> unit_of((size_t)n), unit_level;
-    std::vector<uint8_t> unit_len;
-    if (hub) chain_pass(n, j, u, n_items, n_users, max_chain, nullptr, &unit_of, &unit_level, &unit_len, nl, nu);
-    else chain_pass(n, u, j, n_users, n_items, max_chain, nullptr, &unit_of, &unit_level, &unit_len, nl, nu);
+    const int32_t nl = side.nl;
+    const int64_t nu = side.nu;
+    const std::vector<int32_t> &unit_of = side.unit_of, &unit_level = side.unit_level;
+    const std::vector<uint8_t> &unit_len = side.unit_len, &pos = side.pos;
     // counting sort of the units by (level ascending, length descending), stable in unit id (= CRS order of the first tuple)
     const size_t nkeys = (size_t)nl * (size_t)max_chain;
     std::vector<int64_t> key_off(nkeys + 1, 0);
@@ -327,11 +363,12 @@ bool build_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t
     out.unit_off.assign((size_t)nu + 1, 0);
     for (int64_t q = 0; q < nu; ++q) out.unit_off[(size_t)rank[(size_t)q] + 1] = unit_len[(size_t)q];
     for (int64_t q = 0; q < nu; ++q) out.unit_off[(size_t)q + 1] += out.unit_off[(size_t)q];
+    // a tuple's place: its unit's first slot + its position inside the unit (recorded by the walk) -- independent per tuple
     out.perm.resize((size_t)n);
-    {
-        std::vector<int32_t> fill(out.unit_off.begin(), out.unit_off.end() - 1);
-        for (int64_t t = 0; t < n; ++t) out.perm[(size_t)fill[(size_t)rank[(size_t)unit_of[(size_t)t]]]++] = (int32_t)t;
-    }
+    parallel_ranges(n, host_threads(n), [&](int, int64_t b, int64_t e) {
+        for (int64_t t = b; t < e; ++t)
+            out.perm[(size_t)out.unit_off[(size_t)rank[(size_t)unit_of[(size_t)t]]] + pos[(size_t)t]] = (int32_t)t;
+    });
     return true;
 }
 

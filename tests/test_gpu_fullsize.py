@@ -111,44 +111,73 @@ def _big_inst(model, k, data, state, gm, flags=0, n=None):
 
 
 def _reg_terms(model, data, state):
-    """Regulariser part of the epoch loss at the given model: sum over tuples of regU|P[u]|^2 + regI|Q[j]|^2 + the bias terms."""
-    P, Q = state["P"].astype(np.float64), state["Q"].astype(np.float64)
-    np2, nq2 = (P * P).sum(axis=1), (Q * Q).sum(axis=1)
-    conds = data.ctx_conds.reshape(-1, data.n_dims)[data.ctx]
-    reg = util.REG * np.bincount(data.u, minlength=data.n_users).dot(np2) + util.REG * np.bincount(data.j, minlength=data.n_items).dot(nq2)
-    if model == "CAMF_CI":
-        bu, ic = state["userBias"].astype(np.float64), state["icBias"].astype(np.float64)
-        reg += util.REG * np.bincount(data.u, minlength=data.n_users).dot(bu ** 2)
+    """Regulariser part of the epoch loss at the given model: sum over tuples of regU|P[u]|^2 + regI|Q[j]|^2 + the bias terms.
+    Per-row squared norms first (ranges of rows), then the per-tuple gathers in ranges of tuples on a few host threads (fp64 partial
+    sums per range, added in range order)."""
+    P, Q = state["P"], state["Q"]
+    np2, nq2 = np.empty(len(P)), np.empty(len(Q))
+
+    def norms(dst, M):
+        def f(lo, hi):
+            x = M[lo:hi].astype(np.float64)
+            dst[lo:hi] = (x * x).sum(axis=1)
+        synth._ranges(len(M), 1 << 18, f)
+
+    norms(np2, P)
+    norms(nq2, Q)
+    ctab = data.ctx_conds.reshape(-1, data.n_dims)
+    ci = model == "CAMF_CI"
+    bias2 = (state["userBias"] if ci else state["itemBias"]).astype(np.float64) ** 2     # keyed by user (CAMF_CI) / item (CAMF_CU)
+    cb2 = (state["icBias"] if ci else state["ucBias"]).astype(np.float64) ** 2           # [item or user][condition]
+    step = 1 << 22
+    parts = np.zeros((data.n + step - 1) // step)
+
+    def tuples(lo, hi):
+        u, j = data.u[lo:hi], data.j[lo:hi]
+        conds = ctab[data.ctx[lo:hi]]
+        row = j if ci else u
+        acc = util.REG * (np2[u].sum() + nq2[j].sum() + bias2[u if ci else j].sum())
         for d in range(data.n_dims):
-            reg += util.REGC * (ic[data.j, conds[:, d]] ** 2).sum()
-    else:  # CAMF_CU
-        bj, uc = state["itemBias"].astype(np.float64), state["ucBias"].astype(np.float64)
-        reg += util.REG * np.bincount(data.j, minlength=data.n_items).dot(bj ** 2)
-        for d in range(data.n_dims):
-            reg += util.REGC * (uc[data.u, conds[:, d]] ** 2).sum()
-    return reg
+            acc += util.REGC * cb2[row, conds[:, d]].sum()
+        parts[lo // step] = acc
+
+    synth._ranges(data.n, step, tuples)
+    return float(parts.sum())
 
 
 @pytest.mark.parametrize("name", ["c5", "northstar"])
 def test_big_shapes_full_size_properties_and_prefix_oracle(name):
+    import os, sys, time
+    T = [time.time()]
+    def lap(w):
+        if os.environ.get("CMI_TEST_TIMES"):
+            print("LAP %s %s %.1f" % (name, w, time.time() - T[0]), file=sys.stderr, flush=True)
+        T[0] = time.time()
     model, k, nu, ni, nd, cpd, nr = BIG[name]
     data = synth.generate_fast(nu, ni, nd, cpd, nr)
+    lap("generate")
     state = synth.init_state(model, data, k, dtype=np.float32)
     gm = float(data.r.sum() / np.count_nonzero(data.r))
+    lap("init_state")
 
     # (1) lr = 0: nothing moves, and the epoch loss equals 0.5 * (sum e^2 + regularisers) at the initial model
     inst = _big_inst(model, k, data, state, gm)
+    lap("instance")
     info = inst.schedule_info()
     assert info["tuples"] == data.n and info["kind"].startswith("chain")
     loss0 = inst.train_epoch(0.0)
+    lap("epoch0")
     for n_, a in state.items():
         assert np.array_equal(inst.get_state(n_, np.float32), a), n_
+    lap("get_state")
     step = 1 << 24
     e2 = 0.0
     for b in range(0, data.n, step):
         sl = slice(b, min(data.n, b + step))
         e2 += float(np.sum((data.r[sl] - inst.predict(data.u[sl], data.j[sl], data.ctx[sl])) ** 2))
+    lap("predict")
     assert abs(loss0 - 0.5 * (e2 + _reg_terms(model, data, state))) <= 2e-6 * loss0
+    lap("reg_terms")
 
     # (2) schedule independence at full size: hub-chain levels == plain level launches, bit for bit.  (On the C5 share and, in
     # test_c3_schedules_agree_bit_for_bit, on C3; the north_star shape would spend a minute building a second 200 M-tuple schedule
@@ -168,6 +197,7 @@ def test_big_shapes_full_size_properties_and_prefix_oracle(name):
     else:
         del inst
 
+    lap("step2")
     # (3) one epoch over the first 5 M tuples (full-size tables on the GPU) against the CPU oracle.  The oracle's arithmetic does
     # not depend on the id values, so it runs on the users / items the prefix touches (compacted ids) -- same tuples, same rows.
     m = 5_000_000
@@ -189,6 +219,7 @@ def test_big_shapes_full_size_properties_and_prefix_oracle(name):
     ge = pre.eval_ratings(data.u[idx], data.j[idx], data.ctx[idx], data.r[idx], 1.0, 5.0)
     oe = orc.eval_ratings(sub.u[idx], sub.j[idx], sub.ctx[idx], sub.r[idx], 1.0, 5.0)
     assert abs(ge["RMSE"] - oe["RMSE"]) <= 1e-5 and abs(ge["MAE"] - oe["MAE"]) <= 1e-5
+    lap("prefix")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
