@@ -105,10 +105,11 @@ def generate(n_users, n_items, n_dims, conds_per_dim, n_ratings, seed=DEFAULT_SE
     n = len(r)
 
     # first-seen inner ids (over the de-duplicated stream; every id's first sight is a first-appearance line)
-    u, nu = _first_seen_ids(raw_u)
-    i, ni = _first_seen_ids(raw_i)
+    dense = lambda raw, size: _first_seen_dense(raw, size)[:2] if size <= (1 << 26) else _first_seen_ids(raw)   # same ids, no sort
+    u, nu = dense(raw_u, n_users)
+    i, ni = dense(raw_i, n_items)
     ui, n_ui = _first_seen_ids(raw_u * n_items + raw_i)
-    ctx, n_ctx = _first_seen_ids(ckey)
+    ctx, n_ctx = dense(ckey, n_ckeys)
 
     # condition ids: column d*conds_per_dim + c; the context key lists them in ascending column order
     ctx_first = np.empty(n_ctx, dtype=np.int64)
