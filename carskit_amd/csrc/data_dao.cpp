@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +24,11 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+#include "host_pool.hpp"
+
+using cmi::host_threads;
+using cmi::parallel_ranges;
 
 namespace {
 
@@ -126,6 +132,51 @@ bool read_spans(const char *path, std::string &all, std::vector<std::pair<size_t
     all.resize(got);
     size_t i = 0, b = 0;
     const size_t n = all.size();
+    size_t par_min = (size_t)16 << 20;
+    if (const char *e = getenv("CMI_DAO_PARALLEL_MIN_LINES")) par_min = (size_t)std::max(1ll, atoll(e)); // tests: small files through this path
+    const int nt = cmi::host_threads((int64_t)n / 64);
+    if (n >= par_min && nt > 1) {
+        // Large files: the line breaks are found in ranges of BYTES on the host's cores.  A break starts at every '\r' and at every '\n'
+        // that does not follow a '\r' (that one belongs to the break the '\r' started): a property of a byte and its predecessor, so
+        // the ranges need nothing from each other; a line's start is where the previous break ended.
+        struct Brk {
+            size_t at, next; // first byte of the break; first byte after it
+        };
+        std::vector<std::vector<Brk>> found((size_t)nt);
+        cmi::parallel_ranges((int64_t)n, nt, [&](int part, int64_t lo, int64_t hi) {
+            std::vector<Brk> &v = found[(size_t)part];
+            v.reserve((size_t)(hi - lo) / 32 + 16);
+            for (size_t x = (size_t)lo; x < (size_t)hi; ++x) {
+                const char c = all[x];
+                if (c == '\r') v.push_back(Brk{x, x + 1 < n && all[x + 1] == '\n' ? x + 2 : x + 1});
+                else if (c == '\n' && !(x > 0 && all[x - 1] == '\r')) v.push_back(Brk{x, x + 1});
+            }
+        });
+        std::vector<size_t> off((size_t)nt + 1, 0);
+        for (int t = 0; t < nt; ++t) off[(size_t)t + 1] = off[(size_t)t] + found[(size_t)t].size();
+        const size_t nb = off[(size_t)nt];
+        size_t last_next = 0;
+        for (int t = nt - 1; t >= 0 && last_next == 0; --t)
+            if (!found[(size_t)t].empty()) last_next = found[(size_t)t].back().next;
+        spans.resize(nb + (last_next < n ? 1 : 0));
+        cmi::parallel_ranges(nt, nt, [&](int, int64_t t0, int64_t t1) {
+            for (int64_t t = t0; t < t1; ++t) {
+                size_t start = 0; // where the line of this range's first break begins: the previous break's end
+                for (int64_t q = t - 1; q >= 0; --q)
+                    if (!found[(size_t)q].empty()) {
+                        start = found[(size_t)q].back().next;
+                        break;
+                    }
+                size_t k = off[(size_t)t];
+                for (const Brk &br : found[(size_t)t]) {
+                    spans[k++] = std::make_pair(start, br.at - start);
+                    start = br.next;
+                }
+            }
+        });
+        if (last_next < n) spans[nb] = std::make_pair(last_next, n - last_next);
+        return true;
+    }
     while (i < n) {
         const char c = all[i];
         if (c == '\n' || c == '\r') {
@@ -218,6 +269,19 @@ class StrIndex {
         slots_[i] = Slot{h, id};
         return id;
     }
+    int32_t find(const char *p, size_t n, const std::vector<std::string> &names) const { // -1: not present
+        if (slots_.empty()) return -1;
+        const uint64_t h = hash(p, n);
+        size_t i = (size_t)h & (slots_.size() - 1);
+        while (slots_[i].id >= 0) {
+            if (slots_[i].h == h) {
+                const std::string &s = names[(size_t)slots_[i].id];
+                if (s.size() == n && std::memcmp(s.data(), p, n) == 0) return slots_[i].id;
+            }
+            i = (i + 1) & (slots_.size() - 1);
+        }
+        return -1;
+    }
     void rebuild(const std::vector<std::string> &names) { // after the names were copied from another DAO
         slots_.clear();
         grow(names);
@@ -247,25 +311,19 @@ class StrIndex {
     std::vector<Slot> slots_;
 };
 
-// (user, item) pair -> ui id, first seen (the reference keys a HashMap by the string "<u>,<i>" of inner ids)
+// (user, item) pair -> ui id, first seen (the reference keys a HashMap by the string "<u>,<i>" of inner ids).  SHARDS independent open-
+// addressing tables selected by the key's hash: the ranged reader fills them side by side (one thread per shard), the sequential one
+// through find_or_add as before.
 class PairIndex {
   public:
-    // returns the id; *fresh tells whether the pair was new (then id == previous size)
-    int32_t find_or_add(uint64_t key, int32_t next_id, bool *fresh) {
-        if ((size_ + 1) * 2 > slots_.size()) grow();
-        size_t i = (size_t)mix(key) & (slots_.size() - 1);
-        while (slots_[i].id >= 0) {
-            if (slots_[i].key == key) {
-                *fresh = false;
-                return slots_[i].id;
-            }
-            i = (i + 1) & (slots_.size() - 1);
-        }
-        slots_[i] = Slot{key, next_id};
-        ++size_;
-        *fresh = true;
-        return next_id;
-    }
+    static constexpr int SHARDS = 16;
+    static int shard_of(uint64_t key) { return (int)(mix(key) >> 60); }
+    // returns the id; *fresh tells whether the pair was new (then id == next_id)
+    int32_t find_or_add(uint64_t key, int32_t next_id, bool *fresh) { return sub_[shard_of(key)].find_or_add(key, next_id, fresh); }
+    int32_t find(uint64_t key) const { return sub_[shard_of(key)].find(key); } // -1: not present
+    // one shard's table, for a thread that owns that shard
+    int32_t shard_find_or_add(int s, uint64_t key, int32_t id, bool *fresh) { return sub_[s].find_or_add(key, id, fresh); }
+    void shard_set(int s, uint64_t key, int32_t id) { sub_[s].set(key, id); }
 
   private:
     static uint64_t mix(uint64_t x) {
@@ -278,19 +336,52 @@ class PairIndex {
         uint64_t key;
         int32_t id;
     };
-    void grow() {
-        std::vector<Slot> old;
-        old.swap(slots_);
-        slots_.assign(old.empty() ? 1024 : old.size() * 2, Slot{0, -1});
-        for (const Slot &s : old)
-            if (s.id >= 0) {
-                size_t i = (size_t)mix(s.key) & (slots_.size() - 1);
-                while (slots_[i].id >= 0) i = (i + 1) & (slots_.size() - 1);
-                slots_[i] = s;
+    struct Sub {
+        int32_t find_or_add(uint64_t key, int32_t next_id, bool *fresh) {
+            if ((size_ + 1) * 2 > slots_.size()) grow();
+            size_t i = (size_t)mix(key) & (slots_.size() - 1);
+            while (slots_[i].id != EMPTY) {
+                if (slots_[i].key == key) {
+                    *fresh = false;
+                    return slots_[i].id;
+                }
+                i = (i + 1) & (slots_.size() - 1);
             }
-    }
-    std::vector<Slot> slots_;
-    size_t size_ = 0;
+            slots_[i] = Slot{key, next_id};
+            ++size_;
+            *fresh = true;
+            return next_id;
+        }
+        int32_t find(uint64_t key) const {
+            if (slots_.empty()) return -1;
+            size_t i = (size_t)mix(key) & (slots_.size() - 1);
+            while (slots_[i].id != EMPTY) {
+                if (slots_[i].key == key) return slots_[i].id;
+                i = (i + 1) & (slots_.size() - 1);
+            }
+            return -1;
+        }
+        void set(uint64_t key, int32_t id) { // the key is present
+            size_t i = (size_t)mix(key) & (slots_.size() - 1);
+            while (slots_[i].key != key || slots_[i].id == EMPTY) i = (i + 1) & (slots_.size() - 1);
+            slots_[i].id = id;
+        }
+        void grow() {
+            std::vector<Slot> old;
+            old.swap(slots_);
+            slots_.assign(old.empty() ? 256 : old.size() * 2, Slot{0, EMPTY});
+            for (const Slot &sl : old)
+                if (sl.id != EMPTY) {
+                    size_t i = (size_t)mix(sl.key) & (slots_.size() - 1);
+                    while (slots_[i].id != EMPTY) i = (i + 1) & (slots_.size() - 1);
+                    slots_[i] = sl;
+                }
+        }
+        static constexpr int32_t EMPTY = INT32_MIN; // (ids are >= 0; the ranged reader parks a negative placeholder for a moment)
+        std::vector<Slot> slots_;
+        size_t size_ = 0;
+    };
+    Sub sub_[SHARDS];
 };
 
 template <typename M>
@@ -336,9 +427,18 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
         g_dao_err = "cmi_dao_read: null argument";
         return CMI_E_INVALID;
     }
+    const bool times = getenv("CMI_DAO_TIMES") != nullptr; // tools/exp/dao_read_time.py
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) {
+        if (!times) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "dao %s %.3f s\n", w, std::chrono::duration<double>(n - T0).count());
+        T0 = n;
+    };
     std::string image;
     std::vector<std::pair<size_t, size_t>> lines; // spans into `image`
     if (!read_spans(path, image, lines, g_dao_err)) return CMI_E_INVALID;
+    lap("read+split");
     if (lines.empty()) {
         g_dao_err = "cmi_dao_read: empty file (the reference dereferences a null header line)";
         return CMI_E_INVALID;
@@ -395,11 +495,11 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
         double rate;
     };
     std::vector<Cell> cells;
-    cells.reserve(lines.size());
     std::vector<double> scale;
-    std::vector<int32_t> cond_list;
-    std::string ctx;
-    for (size_t ln = 1; ln < lines.size(); ++ln) {
+    // One line -> its three raw keys and its rating.  `ctx` receives the context key (the comma-joined indices of the columns that
+    // hold 1), `cond_list` the indices.  Returns false with `err` set for what the reference would throw on.
+    auto parse_line = [&image, &lines, n_conds](size_t ln, const char *&ub, const char *&ue, const char *&ib, const char *&ie, double &rate,
+                                                std::string &ctx, std::vector<int32_t> &cond_list, std::string &err) -> bool {
         const char *const raw = image.data() + lines[ln].first;
         // line.trim(): strip chars <= ' ' at both ends
         size_t lb = 0, le = lines[ln].second;
@@ -415,14 +515,12 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
             p = fe + 1; // one past the comma; > end after the last field
             return true;
         };
-        const char *ub, *ue, *ib, *ie, *rb, *re;
+        const char *rb, *re;
         if (!next_field(ub, ue) || !next_field(ib, ie) || !next_field(rb, re)) {
-            d->err = "line " + std::to_string(ln + 1) + ": fewer than 3 fields (ArrayIndexOutOfBounds in the reference)";
-            g_dao_err = d->err;
-            delete d;
-            return CMI_E_INVALID;
+            err = "line " + std::to_string(ln + 1) + ": fewer than 3 fields (ArrayIndexOutOfBounds in the reference)";
+            return false;
         }
-        double rate = 0.0;
+        rate = 0.0;
         {
             bool simple = re > rb && re - rb <= 15; // [0-9]+ ( . [0-9]+ )? : exact in double for <= 15 digits
             int64_t ip = 0, fp = 0, fdig = 0;
@@ -437,10 +535,244 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
             }
             if (simple && c == re && fdig == 0) rate = (double)ip;
             else if (!jparse_double(std::string(rb, re), rate)) { // everything else: the Double.valueOf restatement
-                g_dao_err = "line " + std::to_string(ln + 1) + ": rating '" + std::string(rb, re) + "' is not a number (NumberFormatException)";
-                delete d;
-                return CMI_E_INVALID;
+                err = "line " + std::to_string(ln + 1) + ": rating '" + std::string(rb, re) + "' is not a number (NumberFormatException)";
+                return false;
             }
+        }
+        ctx.clear();
+        cond_list.clear();
+        const char *fb, *fe;
+        for (int32_t ci = 0; next_field(fb, fe); ++ci) {
+            int32_t value;
+            while (fb < fe && (unsigned char)*fb <= ' ') ++fb; // data[i].trim()
+            while (fe > fb && (unsigned char)fe[-1] <= ' ') --fe;
+            if (fe - fb == 1 && (*fb == '0' || *fb == '1')) value = *fb - '0';
+            else if (!jparse_int(std::string(fb, fe), value)) {
+                err = "line " + std::to_string(ln + 1) + ": condition flag '" + std::string(fb, fe) + "' is not an integer (NumberFormatException)";
+                return false;
+            }
+            if (value == 1) {
+                if (!ctx.empty()) ctx += ',';
+                char num[12];
+                int nd = 0, v = ci;
+                do num[nd++] = (char)('0' + v % 10); while ((v /= 10) > 0);
+                while (nd > 0) ctx += num[--nd];
+                cond_list.push_back(ci);
+            }
+        }
+        for (int32_t c : cond_list)
+            if (c >= n_conds) {
+                err = "line " + std::to_string(ln + 1) + ": more condition columns than the header declares";
+                return false;
+            }
+        return true;
+    };
+
+    // Large files: the lines are parsed in RANGES on the host's cores.  Ids are first-seen ranks, and a key's first occurrence lies in
+    // the earliest range that holds it: every range interns the keys it does not find in the tables it started with into tables of its
+    // own (first-seen order inside the range), the ranges' new keys are then entered into the shared tables range after range -- the
+    // order the sequential pass meets them -- and the lines are translated.  The same twice over for the (user, item) pairs, whose
+    // keys are made of the users' and items' final ids.  Any error: the sequential pass below runs instead and reports it.
+    size_t par_min = (size_t)1 << 16;
+    if (const char *e = getenv("CMI_DAO_PARALLEL_MIN_LINES")) par_min = (size_t)std::max(1ll, atoll(e)); // tests: small files through this path
+    const int64_t n_lines = (int64_t)lines.size() - 1;
+    const int nt = host_threads(n_lines);
+    bool parallel_done = false;
+    if ((size_t)n_lines >= par_min && nt > 1) {
+        struct Range {
+            StrIndex users_i, items_i, ctxs_i;
+            std::vector<std::string> users, items, ctxs;       // keys new to this range, first-seen
+            std::vector<std::vector<int32_t>> ctx_conds;        // per new context: its condition list
+            PairIndex pairs_i;
+            std::vector<uint64_t> pairs;                        // (user, item) pairs new to this range, first-seen
+            std::vector<int32_t> by_shard[PairIndex::SHARDS];   // their positions in `pairs`, per shard of the pair table
+            std::vector<uint8_t> fresh;                         // pair k is new to the whole file so far
+            std::vector<int32_t> rank;                          // number of fresh pairs before k in this range
+            int64_t first_id = 0;                               // ui id of the range's first fresh pair
+            std::vector<int32_t> tu, ti, tc;                    // new key -> final id
+            int64_t b = 0, e = 0;
+            bool bad = false;
+        };
+        std::vector<Range> rg((size_t)nt);
+        // per line: >= 0 = the range's own new key, < 0 = ~(id in the tables the read started with)
+        std::unique_ptr<int32_t[]> lu(new int32_t[(size_t)n_lines]), li(new int32_t[(size_t)n_lines]), lc(new int32_t[(size_t)n_lines]);
+        std::unique_ptr<double[]> lr(new double[(size_t)n_lines]);
+        const cmi_dao *dc = d; // read-only while the ranges run
+        parallel_ranges(n_lines, nt, [&](int part, int64_t b, int64_t e) {
+            Range &R = rg[(size_t)part];
+            R.b = b;
+            R.e = e;
+            std::string ctx, err;
+            std::vector<int32_t> cond_list;
+            for (int64_t x = b; x < e; ++x) {
+                const char *ub, *ue, *ib, *ie;
+                if (!parse_line((size_t)x + 1, ub, ue, ib, ie, lr[(size_t)x], ctx, cond_list, err)) {
+                    R.bad = true;
+                    return;
+                }
+                int32_t g = dc->user_ids.find(ub, (size_t)(ue - ub), dc->users); // NOT trimmed (DataDAO.java:226-227)
+                lu[(size_t)x] = g >= 0 ? ~g : R.users_i.find_or_add(ub, (size_t)(ue - ub), R.users);
+                g = dc->item_ids.find(ib, (size_t)(ie - ib), dc->items);
+                li[(size_t)x] = g >= 0 ? ~g : R.items_i.find_or_add(ib, (size_t)(ie - ib), R.items);
+                g = dc->ctx_ids.find(ctx.data(), ctx.size(), dc->ctxs);
+                if (g >= 0) lc[(size_t)x] = ~g;
+                else {
+                    const int32_t l = R.ctxs_i.find_or_add(ctx.data(), ctx.size(), R.ctxs);
+                    if ((size_t)l == R.ctx_conds.size()) R.ctx_conds.push_back(cond_list);
+                    lc[(size_t)x] = l;
+                }
+            }
+        });
+        bool bad = false;
+        for (const Range &R : rg) bad = bad || R.bad;
+        lap("parse");
+        if (!bad) {
+            for (Range &R : rg) { // the ranges' new keys, range after range
+                R.tu.resize(R.users.size());
+                R.ti.resize(R.items.size());
+                R.tc.resize(R.ctxs.size());
+                for (size_t k = 0; k < R.users.size(); ++k) R.tu[k] = d->user_ids.find_or_add(R.users[k].data(), R.users[k].size(), d->users);
+                for (size_t k = 0; k < R.items.size(); ++k) R.ti[k] = d->item_ids.find_or_add(R.items[k].data(), R.items[k].size(), d->items);
+                for (size_t k = 0; k < R.ctxs.size(); ++k) {
+                    const int32_t cc = d->ctx_ids.find_or_add(R.ctxs[k].data(), R.ctxs[k].size(), d->ctxs);
+                    R.tc[k] = cc;
+                    if ((size_t)cc == d->ctx_cond_list.size()) d->ctx_cond_list.push_back(R.ctx_conds[k]);
+                    else d->ctx_cond_list[(size_t)cc] = R.ctx_conds[k]; // (the same list by construction)
+                }
+            }
+            lap("merge keys");
+            // final user / item / context ids per line; the pairs new to each range
+            parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
+                for (int64_t p = p0; p < p1; ++p) {
+                    Range &R = rg[(size_t)p];
+                    for (int64_t x = R.b; x < R.e; ++x) {
+                        const int32_t row = lu[(size_t)x] < 0 ? ~lu[(size_t)x] : R.tu[(size_t)lu[(size_t)x]];
+                        const int32_t col = li[(size_t)x] < 0 ? ~li[(size_t)x] : R.ti[(size_t)li[(size_t)x]];
+                        lc[(size_t)x] = lc[(size_t)x] < 0 ? ~lc[(size_t)x] : R.tc[(size_t)lc[(size_t)x]];
+                        lu[(size_t)x] = row;
+                        li[(size_t)x] = col;
+                        const uint64_t uikey = ((uint64_t)(uint32_t)row << 32) | (uint32_t)col;
+                        if (dc->ui_ids.find(uikey) < 0) {
+                            bool fresh = false;
+                            R.pairs_i.find_or_add(uikey, (int32_t)R.pairs.size(), &fresh);
+                            if (fresh) {
+                                R.by_shard[PairIndex::shard_of(uikey)].push_back((int32_t)R.pairs.size());
+                                R.pairs.push_back(uikey);
+                            }
+                        }
+                    }
+                }
+            });
+            lap("translate");
+            // The ranges' pairs enter the pair table range after range, as the keys did -- but there is one pair per line, so this
+            // merge is done per SHARD of the table, all shards at once: a shard's thread walks the ranges in order and enters its
+            // shard's pairs (placeholder ids), noting which were new to the file; the ids are then the ranks of the new pairs in
+            // (range, first-seen) order -- a count per range, a scan over the ranges -- and a second sharded pass stores them.
+            for (Range &R : rg) R.fresh.assign(R.pairs.size(), 0);
+            parallel_ranges(PairIndex::SHARDS, std::min(nt, (int)PairIndex::SHARDS), [&](int, int64_t s0, int64_t s1) {
+                for (int64_t sh = s0; sh < s1; ++sh)
+                    for (Range &R : rg)
+                        for (int32_t k : R.by_shard[sh]) {
+                            bool fresh = false;
+                            d->ui_ids.shard_find_or_add((int)sh, R.pairs[(size_t)k], -1, &fresh);
+                            R.fresh[(size_t)k] = fresh ? 1 : 0;
+                        }
+            });
+            parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
+                for (int64_t p = p0; p < p1; ++p) {
+                    Range &R = rg[(size_t)p];
+                    R.rank.resize(R.pairs.size());
+                    int32_t run = 0;
+                    for (size_t k = 0; k < R.pairs.size(); ++k) {
+                        R.rank[k] = run;
+                        run += R.fresh[k];
+                    }
+                    R.first_id = run; // (count, turned into the first id below)
+                }
+            });
+            int64_t next_ui = (int64_t)d->ui_user.size();
+            for (Range &R : rg) {
+                const int64_t cnt = R.first_id;
+                R.first_id = next_ui;
+                next_ui += cnt;
+            }
+            d->ui_user.resize((size_t)next_ui);
+            d->ui_item.resize((size_t)next_ui);
+            parallel_ranges(PairIndex::SHARDS, std::min(nt, (int)PairIndex::SHARDS), [&](int, int64_t s0, int64_t s1) {
+                for (int64_t sh = s0; sh < s1; ++sh)
+                    for (Range &R : rg)
+                        for (int32_t k : R.by_shard[sh])
+                            if (R.fresh[(size_t)k]) {
+                                const uint64_t uikey = R.pairs[(size_t)k];
+                                const int64_t id = R.first_id + R.rank[(size_t)k];
+                                d->ui_ids.shard_set((int)sh, uikey, (int32_t)id);
+                                d->ui_user[(size_t)id] = (int32_t)(uikey >> 32);
+                                d->ui_item[(size_t)id] = (int32_t)(uikey & 0xffffffffu);
+                            }
+            });
+            lap("merge pairs");
+            cells.resize((size_t)n_lines);
+            parallel_ranges(n_lines, nt, [&](int, int64_t b, int64_t e) {
+                for (int64_t x = b; x < e; ++x) {
+                    const uint64_t uikey = ((uint64_t)(uint32_t)lu[(size_t)x] << 32) | (uint32_t)li[(size_t)x];
+                    cells[(size_t)x] = Cell{((uint64_t)(uint32_t)dc->ui_ids.find(uikey) << 32) | (uint32_t)lc[(size_t)x], lr[(size_t)x]};
+                }
+            });
+            // ratingScale candidates: the distinct values of every range
+            std::vector<std::vector<double>> sc((size_t)nt);
+            parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
+                for (int64_t p = p0; p < p1; ++p) {
+                    std::vector<double> &v = sc[(size_t)p];
+                    v.assign(lr.get() + rg[(size_t)p].b, lr.get() + rg[(size_t)p].e);
+                    std::sort(v.begin(), v.end());
+                    v.erase(std::unique(v.begin(), v.end()), v.end());
+                }
+            });
+            for (const std::vector<double> &v : sc) scale.insert(scale.end(), v.begin(), v.end());
+            d->num_ratings += n_lines;
+            lap("cells+scale");
+            // CRS order: every range sorted on its own (stable), then merged pairwise (std::merge takes from the earlier range on ties:
+            // the file order inside a cell survives)
+            std::vector<int64_t> cut;
+            for (const Range &R : rg) cut.push_back(R.b);
+            cut.push_back(n_lines);
+            parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
+                for (int64_t p = p0; p < p1; ++p)
+                    std::stable_sort(cells.begin() + cut[(size_t)p], cells.begin() + cut[(size_t)p + 1], [](const Cell &x, const Cell &y) { return x.key < y.key; });
+            });
+            std::vector<Cell> tmp(cells.size());
+            while (cut.size() > 2) {
+                const int64_t pairs = (int64_t)(cut.size() - 1) / 2;
+                parallel_ranges(pairs, (int)std::min<int64_t>(pairs, nt), [&](int, int64_t q0, int64_t q1) {
+                    for (int64_t q = q0; q < q1; ++q) {
+                        const int64_t a = cut[(size_t)(2 * q)], m = cut[(size_t)(2 * q + 1)], z = cut[(size_t)(2 * q + 2)];
+                        std::merge(cells.begin() + a, cells.begin() + m, cells.begin() + m, cells.begin() + z, tmp.begin() + a,
+                                   [](const Cell &x, const Cell &y) { return x.key < y.key; });
+                    }
+                });
+                if ((cut.size() - 1) % 2) // an odd range out: carried over as it is
+                    std::copy(cells.begin() + cut[cut.size() - 2], cells.begin() + cut[cut.size() - 1], tmp.begin() + cut[cut.size() - 2]);
+                cells.swap(tmp);
+                std::vector<int64_t> next;
+                for (size_t q = 0; q + 1 < cut.size(); q += 2) next.push_back(cut[q]);
+                next.push_back(n_lines);
+                cut.swap(next);
+            }
+            parallel_done = true;
+            lap("sort");
+        }
+    }
+    if (!parallel_done) {
+    cells.reserve(lines.size());
+    std::vector<int32_t> cond_list;
+    std::string ctx;
+    for (size_t ln = 1; ln < lines.size(); ++ln) {
+        const char *ub, *ue, *ib, *ie;
+        double rate = 0.0;
+        if (!parse_line(ln, ub, ue, ib, ie, rate, ctx, cond_list, d->err)) {
+            g_dao_err = d->err;
+            delete d;
+            return CMI_E_INVALID;
         }
         scale.push_back(rate);
         d->num_ratings++;
@@ -453,45 +785,18 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
             d->ui_user.push_back(row);
             d->ui_item.push_back(col);
         }
-        ctx.clear();
-        cond_list.clear();
-        const char *fb, *fe;
-        for (int32_t ci = 0; next_field(fb, fe); ++ci) {
-            int32_t value;
-            while (fb < fe && (unsigned char)*fb <= ' ') ++fb; // data[i].trim()
-            while (fe > fb && (unsigned char)fe[-1] <= ' ') --fe;
-            if (fe - fb == 1 && (*fb == '0' || *fb == '1')) value = *fb - '0';
-            else if (!jparse_int(std::string(fb, fe), value)) {
-                g_dao_err = "line " + std::to_string(ln + 1) + ": condition flag '" + std::string(fb, fe) + "' is not an integer (NumberFormatException)";
-                delete d;
-                return CMI_E_INVALID;
-            }
-            if (value == 1) {
-                if (!ctx.empty()) ctx += ',';
-                char num[12];
-                int nd = 0, v = ci;
-                do num[nd++] = (char)('0' + v % 10); while ((v /= 10) > 0);
-                while (nd > 0) ctx += num[--nd];
-                cond_list.push_back(ci);
-            }
-        }
         const int32_t cc = d->ctx_ids.find_or_add(ctx.data(), ctx.size(), d->ctxs);
         if ((size_t)cc == d->ctx_cond_list.size()) d->ctx_cond_list.push_back(cond_list);
         else d->ctx_cond_list[(size_t)cc] = cond_list; // contextConditionsList.put(cc, condList): same list by construction
-        for (int32_t c : cond_list)
-            if (c >= n_conds) {
-                g_dao_err = "line " + std::to_string(ln + 1) + ": more condition columns than the header declares";
-                delete d;
-                return CMI_E_INVALID;
-            }
         cells.push_back(Cell{((uint64_t)(uint32_t)uic << 32) | (uint32_t)cc, rate});
+    }
     }
     // ratingScale: sorted distinct values (DataDAO.java:348-350)
     std::sort(scale.begin(), scale.end());
     scale.erase(std::unique(scale.begin(), scale.end()), scale.end());
     d->rating_scale = scale;
     // CRS order; a stable sort keeps the file order inside a cell, whose LAST entry wins
-    std::stable_sort(cells.begin(), cells.end(), [](const Cell &x, const Cell &y) { return x.key < y.key; });
+    if (!parallel_done) std::stable_sort(cells.begin(), cells.end(), [](const Cell &x, const Cell &y) { return x.key < y.key; });
     d->m_ui.reserve(cells.size());
     for (size_t i = 0; i < cells.size(); ++i) {
         if (i + 1 < cells.size() && cells[i + 1].key == cells[i].key) continue;
@@ -499,6 +804,7 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
         d->m_ctx.push_back((int32_t)(cells[i].key & 0xffffffffu));
         d->m_r.push_back(cells[i].rate);
     }
+    lap("matrix");
     *out = d;
     return CMI_OK;
 }

@@ -79,6 +79,48 @@ def test_dao_matches_oracle_on_random_files(tmp_path_factory, seed, messy):
     assert_same(dao.DataDAO(p), dao_oracle.read_data(p))
 
 
+@pytest.mark.parametrize("threads", ["2", "5", "16"])
+def test_dao_ranged_reader_matches_oracle_and_the_sequential_reader(tmp_path, threads, monkeypatch):
+    """Files of 2^16 lines and more are parsed in ranges of lines on the host's cores (data_dao.cpp: per-range key tables, entered into
+    the shared tables range after range).  Forced here on small random files -- many duplicate cells (the last line wins), keys first
+    seen in any range, fewer lines than ranges, messy spacing -- and on a test file read over the training DAO's maps: the same ids,
+    strings and matrix as the oracle and as the sequential reader, and the same error for a bad line in a late range."""
+    monkeypatch.setenv("CMI_DAO_PARALLEL_MIN_LINES", "1")
+    monkeypatch.setenv("CMI_HOST_THREADS", threads)
+    rng = random.Random(int(threads))
+    for case in range(12):
+        p = str(tmp_path / ("r%d.csv" % case))
+        _write_random_binary(p, rng, rng.choice([1, 3, 17, 400, 2500]), rng.randrange(1, 40), rng.randrange(1, 12),
+                             [rng.randrange(1, 4) for _ in range(rng.randrange(0, 4))], messy=case % 3 == 0)
+        assert_same(dao.DataDAO(p), dao_oracle.read_data(p))
+    # `test-set`: the test DAO extends the training DAO's maps
+    tr, te = str(tmp_path / "tr.csv"), str(tmp_path / "te.csv")
+    _write_random_binary(tr, rng, 1500, 30, 9, [3, 2], messy=False)
+    _write_random_binary(te, rng, 900, 45, 14, [3, 2], messy=False)
+    d_tr = dao.DataDAO(tr)
+    d_te = dao.DataDAO(te, train=d_tr)
+    monkeypatch.setenv("CMI_DAO_PARALLEL_MIN_LINES", "1000000000")
+    s_tr = dao.DataDAO(tr)
+    s_te = dao.DataDAO(te, train=s_tr)
+    for a, b in ((d_tr, s_tr), (d_te, s_te)):
+        for kind in ("user", "item", "ui", "ctx", "cond", "dim"):
+            assert a.raw_ids(kind) == b.raw_ids(kind), kind
+        assert a.ui.tolist() == b.ui.tolist() and a.ctx.tolist() == b.ctx.tolist() and a.r.tolist() == b.r.tolist()
+        assert a.ui_user.tolist() == b.ui_user.tolist() and a.ctx_conds.tolist() == b.ctx_conds.tolist() and a.rating_scale == b.rating_scale
+        assert a.num_ratings == b.num_ratings
+    # a bad line in the last range: the sequential pass reports it, with its line number
+    monkeypatch.setenv("CMI_DAO_PARALLEL_MIN_LINES", "1")
+    bad = str(tmp_path / "bad.csv")
+    lines = open(tr).read().split("\n")
+    f = lines[1200].split(",")
+    f[2] = "abc"
+    lines[1200] = ",".join(f)
+    open(bad, "w").write("\n".join(lines))
+    with pytest.raises(Exception) as ei:
+        dao.DataDAO(bad)
+    assert "line 1201" in str(ei.value) and "not a number" in str(ei.value)
+
+
 def test_dao_errors():
     import tempfile
     with tempfile.TemporaryDirectory() as td:
