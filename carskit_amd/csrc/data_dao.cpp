@@ -797,12 +797,31 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
     d->rating_scale = scale;
     // CRS order; a stable sort keeps the file order inside a cell, whose LAST entry wins
     if (!parallel_done) std::stable_sort(cells.begin(), cells.end(), [](const Cell &x, const Cell &y) { return x.key < y.key; });
-    d->m_ui.reserve(cells.size());
-    for (size_t i = 0; i < cells.size(); ++i) {
-        if (i + 1 < cells.size() && cells[i + 1].key == cells[i].key) continue;
-        d->m_ui.push_back((int32_t)(cells[i].key >> 32));
-        d->m_ctx.push_back((int32_t)(cells[i].key & 0xffffffffu));
-        d->m_r.push_back(cells[i].rate);
+    // a cell keeps its LAST entry (the next entry holds another key): counted per range, placed per range
+    {
+        const int64_t nc = (int64_t)cells.size();
+        const int ntm = parallel_done ? host_threads(nc) : 1;
+        std::vector<int64_t> kept((size_t)ntm + 1, 0);
+        auto last_of_cell = [&](int64_t i) { return i + 1 >= nc || cells[(size_t)i + 1].key != cells[(size_t)i].key; };
+        parallel_ranges(nc, ntm, [&](int part, int64_t b, int64_t e) {
+            int64_t k = 0;
+            for (int64_t i = b; i < e; ++i) k += last_of_cell(i);
+            kept[(size_t)part + 1] = k;
+        });
+        for (int t = 0; t < ntm; ++t) kept[(size_t)t + 1] += kept[(size_t)t];
+        d->m_ui.resize((size_t)kept[(size_t)ntm]);
+        d->m_ctx.resize((size_t)kept[(size_t)ntm]);
+        d->m_r.resize((size_t)kept[(size_t)ntm]);
+        parallel_ranges(nc, ntm, [&](int part, int64_t b, int64_t e) {
+            int64_t k = kept[(size_t)part];
+            for (int64_t i = b; i < e; ++i)
+                if (last_of_cell(i)) {
+                    d->m_ui[(size_t)k] = (int32_t)(cells[(size_t)i].key >> 32);
+                    d->m_ctx[(size_t)k] = (int32_t)(cells[(size_t)i].key & 0xffffffffu);
+                    d->m_r[(size_t)k] = cells[(size_t)i].rate;
+                    ++k;
+                }
+        });
     }
     lap("matrix");
     *out = d;
