@@ -480,16 +480,23 @@ class IterativeRecommender {
     }
 
     static void to2d(const RatingData &d, std::vector<int32_t> &u2, std::vector<int32_t> &j2, std::vector<double> &r2) {
-        std::map<std::pair<int32_t, int32_t>, std::pair<double, double>> cell; // DataDAO.toTraditionalSparseMatrix
-        for (int64_t t = 0; t < d.n(); ++t) {
-            auto &c = cell[{d.u[(size_t)t], d.j[(size_t)t]}];
-            c.first += d.r[(size_t)t];
-            c.second += 1.0;
-        }
-        for (auto &kv : cell) {
-            u2.push_back(kv.first.first);
-            j2.push_back(kv.first.second);
-            r2.push_back(kv.second.first / kv.second.second);
+        // DataDAO.toTraditionalSparseMatrix: the mean of a (user, item) pair's ratings over its contexts, pairs in (user, item) order.
+        // (key, tuple) pairs sorted: a cell's ratings are then added in tuple order, as a map keyed by the pair would add them.
+        std::vector<std::pair<uint64_t, int64_t>> ord((size_t)d.n());
+        for (int64_t t = 0; t < d.n(); ++t)
+            ord[(size_t)t] = {((uint64_t)(uint32_t)d.u[(size_t)t] << 32) | (uint32_t)d.j[(size_t)t], t};
+        std::sort(ord.begin(), ord.end());
+        for (size_t a = 0; a < ord.size();) {
+            double sum = 0.0, cnt = 0.0;
+            size_t b = a;
+            for (; b < ord.size() && ord[b].first == ord[a].first; ++b) {
+                sum += d.r[(size_t)ord[b].second];
+                cnt += 1.0;
+            }
+            u2.push_back((int32_t)(ord[a].first >> 32));
+            j2.push_back((int32_t)(ord[a].first & 0xffffffffu));
+            r2.push_back(sum / cnt);
+            a = b;
         }
     }
 
