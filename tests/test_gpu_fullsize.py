@@ -26,7 +26,18 @@ def c3():
     data = synth.generate_fast(1_000_000, 100_000, 4, 8, 50_000_000)
     state = synth.init_state("CAMF_CI", data, K, dtype=np.float32)
     gm = float(data.r.sum() / np.count_nonzero(data.r))
+    # the CPU oracle's epoch over all 50 M tuples (about half a minute on one core) starts here, on a thread of its own, behind the
+    # other C3 tests; test_c3_one_epoch_matches_oracle (the last of them) waits for it
+    import threading
+    orc = util.c_oracle("CAMF_CI", data, K, {n: a.astype(np.float64) for n, a in state.items()}, gm)
+    _C3_ORACLE.clear()
+    _C3_ORACLE["orc"] = orc
+    _C3_ORACLE["thread"] = threading.Thread(target=lambda: _C3_ORACLE.__setitem__("loss", orc.epoch(util.LR)))
+    _C3_ORACLE["thread"].start()
     return data, state, gm
+
+
+_C3_ORACLE = {}
 
 
 def _inst(c3, flags=0):
@@ -36,25 +47,6 @@ def _inst(c3, flags=0):
     inst.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
     inst.set_states(state)
     return inst
-
-
-def test_c3_one_epoch_matches_oracle(c3):
-    data, state, gm = c3
-    inst = _inst(c3)
-    info = inst.schedule_info()
-    assert info["tuples"] == data.n and info["kind"] == "chain-item" and 200 < info["levels"] < 400
-    lg = inst.train_epoch(util.LR)
-    orc = util.c_oracle("CAMF_CI", data, K, {n: a.astype(np.float64) for n, a in state.items()}, gm)
-    lo = orc.epoch(util.LR)
-    assert abs(lg - lo) <= 1e-6 * abs(lo)                       # 50 M fp32 updates vs fp64, same order
-    for name in ("P", "Q", "userBias", "icBias"):
-        d = np.abs(inst.get_state(name, np.float64) - orc.state[name].reshape(inst.state_shape(name)))
-        assert d.max() <= 2e-5, (name, d.max())
-    # RMSE over a 2 M-tuple sample of the training set, clamped like evalRatings: the fp32 bar of the north star
-    idx = np.arange(0, data.n, 25)
-    ge = inst.eval_ratings(data.u[idx], data.j[idx], data.ctx[idx], data.r[idx], 1.0, 5.0)
-    oe = orc.eval_ratings(data.u[idx], data.j[idx], data.ctx[idx], data.r[idx], 1.0, 5.0)
-    assert abs(ge["RMSE"] - oe["RMSE"]) <= 1e-5 and abs(ge["MAE"] - oe["MAE"]) <= 1e-5
 
 
 def test_c3_lr_zero_is_idempotent_and_loss_is_consistent(c3):
@@ -88,6 +80,25 @@ def test_c3_schedules_agree_bit_for_bit(c3):
         np.testing.assert_allclose(other[0], outs[0][0], rtol=1e-12)
         for a, b in zip(outs[0][1:], other[1:]):
             assert np.array_equal(a, b)
+
+
+def test_c3_one_epoch_matches_oracle(c3):
+    data, state, gm = c3
+    inst = _inst(c3)
+    info = inst.schedule_info()
+    assert info["tuples"] == data.n and info["kind"] == "chain-item" and 200 < info["levels"] < 400
+    lg = inst.train_epoch(util.LR)
+    _C3_ORACLE["thread"].join()
+    orc, lo = _C3_ORACLE["orc"], _C3_ORACLE["loss"]
+    assert abs(lg - lo) <= 1e-6 * abs(lo)                       # 50 M fp32 updates vs fp64, same order
+    for name in ("P", "Q", "userBias", "icBias"):
+        d = np.abs(inst.get_state(name, np.float64) - orc.state[name].reshape(inst.state_shape(name)))
+        assert d.max() <= 2e-5, (name, d.max())
+    # RMSE over a 2 M-tuple sample of the training set, clamped like evalRatings: the fp32 bar of the north star
+    idx = np.arange(0, data.n, 25)
+    ge = inst.eval_ratings(data.u[idx], data.j[idx], data.ctx[idx], data.r[idx], 1.0, 5.0)
+    oe = orc.eval_ratings(data.u[idx], data.j[idx], data.ctx[idx], data.r[idx], 1.0, 5.0)
+    assert abs(ge["RMSE"] - oe["RMSE"]) <= 1e-5 and abs(ge["MAE"] - oe["MAE"]) <= 1e-5
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -159,6 +170,19 @@ def test_big_shapes_full_size_properties_and_prefix_oracle(name):
     state = synth.init_state(model, data, k, dtype=np.float32)
     gm = float(data.r.sum() / np.count_nonzero(data.r))
     lap("init_state")
+    # the CPU oracle's epoch over the 5 M-tuple prefix (step 3) takes seconds on one core: it runs on a thread of its own behind steps 1-2.
+    # Its arithmetic does not depend on the id values, so it runs on the users / items the prefix touches (compacted ids).
+    import threading
+    m = 5_000_000
+    uu, ui = np.unique(data.u[:m], return_inverse=True)
+    jj, ji = np.unique(data.j[:m], return_inverse=True)
+    sub = synth.RatingData(len(uu), len(jj), data.n_conds, data.n_dims, ui.astype(np.int32), ji.astype(np.int32), data.ctx[:m],
+                           data.r[:m], data.ctx_ptr, data.ctx_conds)
+    rows = {"P": uu, "userBias": uu, "ucBias": uu, "Q": jj, "itemBias": jj, "icBias": jj}
+    orc = util.c_oracle(model, sub, k, {n_: a[rows[n_]].astype(np.float64) for n_, a in state.items()}, gm)
+    orc_loss = []
+    orc_thread = threading.Thread(target=lambda: orc_loss.append(orc.epoch(util.LR)))
+    orc_thread.start()
 
     # (1) lr = 0: nothing moves, and the epoch loss equals 0.5 * (sum e^2 + regularisers) at the initial model
     inst = _big_inst(model, k, data, state, gm)
@@ -198,18 +222,11 @@ def test_big_shapes_full_size_properties_and_prefix_oracle(name):
         del inst
 
     lap("step2")
-    # (3) one epoch over the first 5 M tuples (full-size tables on the GPU) against the CPU oracle.  The oracle's arithmetic does
-    # not depend on the id values, so it runs on the users / items the prefix touches (compacted ids) -- same tuples, same rows.
-    m = 5_000_000
+    # (3) one epoch over the first 5 M tuples (full-size tables on the GPU) against the CPU oracle (started above) -- same tuples, same rows.
     pre = _big_inst(model, k, data, state, gm, n=m)
     lg = pre.train_epoch(util.LR)
-    uu, ui = np.unique(data.u[:m], return_inverse=True)
-    jj, ji = np.unique(data.j[:m], return_inverse=True)
-    sub = synth.RatingData(len(uu), len(jj), data.n_conds, data.n_dims, ui.astype(np.int32), ji.astype(np.int32), data.ctx[:m],
-                           data.r[:m], data.ctx_ptr, data.ctx_conds)
-    rows = {"P": uu, "userBias": uu, "ucBias": uu, "Q": jj, "itemBias": jj, "icBias": jj}
-    orc = util.c_oracle(model, sub, k, {n_: a[rows[n_]].astype(np.float64) for n_, a in state.items()}, gm)
-    lo = orc.epoch(util.LR)
+    orc_thread.join()
+    lo = orc_loss[0]
     assert abs(lg - lo) <= 1e-6 * abs(lo)
     for n_ in state:
         got_rows = pre.get_state(n_, np.float32)[rows[n_]].astype(np.float64)
