@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <functional>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -37,6 +38,7 @@ class HostPool {
     bool try_run(int nt, const std::function<void(int)> &fn) { // fn(0) runs on the caller
         std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
         if (!job.owns_lock()) return false;
+        int have = 0; // workers that take part in this job
         {
             std::lock_guard<std::mutex> g(mu_);
             if (pid_ != getpid()) { // a forked child has no workers
@@ -44,16 +46,22 @@ class HostPool {
                 pid_ = getpid();
             }
             while (workers_ < nt - 1) {
-                std::thread(&HostPool::work, this, workers_ + 1, gen_).detach(); // gen_: the job posted below is the worker's first
+                try {
+                    std::thread(&HostPool::work, this, workers_ + 1, gen_).detach(); // gen_: the job posted below is the worker's first
+                } catch (const std::system_error &) { // the process may not create more threads (a container's pid limit): fewer workers
+                    break;
+                }
                 ++workers_;
             }
+            have = std::min(workers_, nt - 1);
             fn_ = &fn;
-            want_ = nt;
-            left_ = nt - 1;
+            want_ = have + 1;
+            left_ = have;
             ++gen_;
         }
         cv_.notify_all();
         fn(0);
+        for (int id = have + 1; id < nt; ++id) fn(id); // the ranges no worker exists for
         std::unique_lock<std::mutex> g(mu_);
         done_.wait(g, [&] { return left_ == 0; });
         fn_ = nullptr;
@@ -97,8 +105,13 @@ inline void parallel_ranges(int64_t n, int nt, F &&body) { // body(range index, 
     };
     if (HostPool::get().try_run(nt, one)) return;
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back([&one, t]() { one(t); });
+    int started = 1;
+    try {
+        for (; started < nt; ++started) th.emplace_back([&one, started]() { one(started); });
+    } catch (const std::system_error &) { // no more threads: the caller takes the rest
+    }
     one(0);
+    for (int t = started; t < nt; ++t) one(t);
     for (std::thread &x : th) x.join();
 }
 

@@ -16,6 +16,7 @@
 // CMI_FLAG_SCHED_SERIAL.)
 #include "level_schedule.hpp"
 
+#include <system_error>
 #include <thread>
 
 #include "host_pool.hpp"
@@ -332,9 +333,16 @@ bool build_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t
         // both sides are walked at the same time, each with its full output; the loser's is dropped (before: two counting walks, then
         // the winner's walk again -- three sequential passes over the tuples)
         Side other;
-        std::thread th([&]() { run_side(0, other); });
+        bool threaded = true;
+        std::thread th;
+        try {
+            th = std::thread([&]() { run_side(0, other); });
+        } catch (const std::system_error &) { // the process may not create more threads: one side after the other
+            threaded = false;
+        }
         run_side(1, side);
-        th.join();
+        if (threaded) th.join();
+        else run_side(0, other);
         const int64_t units_item = side.nu, units_user = other.nu;
         if (hub == -2) hub = (double)units_user <= 1.3 * (double)units_item ? 0 : 1;
         else if (hub == -3) hub = (double)units_item <= 1.3 * (double)units_user ? 1 : 0;

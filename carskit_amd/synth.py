@@ -178,8 +178,19 @@ def _ranges(n, step, fn):
         for lo, hi in spans:
             fn(lo, hi)
         return
-    with concurrent.futures.ThreadPoolExecutor(workers) as ex:
-        list(ex.map(lambda sp: fn(*sp), spans))
+    done = set()
+
+    def one(sp):
+        fn(*sp)
+        done.add(sp)
+
+    try:
+        with concurrent.futures.ThreadPoolExecutor(workers) as ex:
+            list(ex.map(one, spans))
+    except RuntimeError:            # "can't start new thread" (a container's pid limit): the remaining ranges on this thread
+        for sp in spans:
+            if sp not in done:
+                fn(*sp)
 
 
 def _first_seen_dense(raw, size):
