@@ -702,7 +702,7 @@ extern "C" int cmi_fm_eval_rankings(cmi_fm_handle h, int64_t n_train, const int3
         top_count = no_lists.data();
         rank_measures_range(plan, num_recs, nullptr, nullptr, top_count, 0, nq, vals.data(), q_user, q_ctx, q_count, top_items, top_scores);
     }
-    rank_average(plan, strategy, top_count, vals.data(), out);
+    rank_average(plan, strategy, top_count, vals.data(), nullptr, RankFolded(), out);
     if (n_queries) *n_queries = (int64_t)plan.qu.size();
     return CMI_OK;
 }

@@ -462,66 +462,96 @@ void rank_measures_range(const RankPlan &plan, int num_recs, const int32_t *top_
     });
 }
 
-void rank_average(const RankPlan &plan, int strategy, const int32_t *top_count, const double *vals, double *out) {
+namespace {
+// Every addition of the averages is a happy.coding.math.Stats.mean step (NaN entries are skipped; an empty mean is 0/0 = NaN), in query
+// order.  The 18 chains are independent of each other, so they advance side by side without branches: a skipped entry adds +0.0 (the
+// sums are never -0.0: they start at +0.0 and +0.0 + -0.0 = +0.0) and counts 0.
+struct MeanAcc {
+    double s[N_MEAS];
+    int64_t c[N_MEAS];
+    MeanAcc() {
+        for (int m = 0; m < N_MEAS; ++m) {
+            s[m] = 0.0;
+            c[m] = 0;
+        }
+    }
+    void add(const double *v) {
+        for (int m = 0; m < N_MEAS; ++m) {
+            const bool ok = v[m] == v[m];
+            s[m] += ok ? v[m] : 0.0;
+            c[m] += ok;
+        }
+    }
+    void mean(double *o) const {
+        for (int m = 0; m < N_MEAS; ++m) o[m] = c[m] ? s[m] / (double)c[m] : std::nan("");
+    }
+};
+} // namespace
+
+// ucu: a test user contributes the NaN-skipping mean over its contexts -- NaN (skipped again) if none of its contexts produced a list
+// (Recommender.java:903-926).  The users' means do not depend on each other: ranges of whole users on the host's cores compute them and
+// write them, in user order, into `umeans` (18 doubles per user); only the sum over the users is serial (rank_average).  Users whose
+// queries all lie in [f.q, q_to) are folded (f.q is a user's first query); f advances to the first user that was not -- q_to itself when
+// `last`.
+void rank_fold_users(const RankPlan &plan, const int32_t *top_count, const double *vals, double *umeans, RankFolded &f, int64_t q_to, bool last) {
+    const int64_t nq = (int64_t)plan.qu.size(), q_from = f.q;
+    int64_t stop = std::min(q_to, nq);
+    if (!last && stop < nq)
+        while (stop > q_from && plan.qu[(size_t)stop] == plan.qu[(size_t)stop - 1]) --stop; // the user that straddles q_to waits
+    if (stop <= q_from) return;
+    const int64_t n = stop - q_from;
+    const int nt = host_threads(n * 4);
+    std::vector<int64_t> cut((size_t)nt + 1, stop), ubase((size_t)nt + 1, 0);
+    cut[0] = q_from;
+    for (int t = 1; t < nt; ++t) {
+        int64_t b = std::min<int64_t>(stop, q_from + (n + nt - 1) / nt * t);
+        while (b > q_from && b < stop && plan.qu[(size_t)b] == plan.qu[(size_t)b - 1]) ++b; // to the next user's first query
+        cut[(size_t)t] = std::max(b, cut[(size_t)t - 1]);
+    }
+    parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) { // users per range
+        for (int64_t p = p0; p < p1; ++p) {
+            int64_t c = 0;
+            for (int64_t q = cut[(size_t)p]; q < cut[(size_t)p + 1]; ++q) c += q + 1 == nq || plan.qu[(size_t)q + 1] != plan.qu[(size_t)q];
+            ubase[(size_t)p + 1] = c;
+        }
+    });
+    ubase[0] = f.u;
+    for (int t = 0; t < nt; ++t) ubase[(size_t)t + 1] += ubase[(size_t)t];
+    parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
+        for (int64_t p = p0; p < p1; ++p) {
+            MeanAcc user;
+            double *dst = umeans + (size_t)ubase[(size_t)p] * N_MEAS;
+            for (int64_t q = cut[(size_t)p]; q < cut[(size_t)p + 1]; ++q) {
+                if (top_count[q] > 0) user.add(vals + (size_t)q * N_MEAS);
+                if (q + 1 == nq || plan.qu[(size_t)q + 1] != plan.qu[(size_t)q]) {
+                    user.mean(dst);
+                    dst += N_MEAS;
+                    user = MeanAcc();
+                }
+            }
+        }
+    });
+    f.q = stop;
+    f.u = ubase[(size_t)nt];
+}
+
+void rank_average(const RankPlan &plan, int strategy, const int32_t *top_count, const double *vals, double *umeans, RankFolded f, double *out) {
     const int64_t nq = (int64_t)plan.qu.size();
     for (int m = 0; m < CMI_RANK_MEASURES; ++m) out[m] = std::nan("");
     out[18] = out[19] = out[20] = 0.0; // D5/D10/DN: isDiverseUsed=false (Recommender.java:939-941)
-    // Every addition is a happy.coding.math.Stats.mean step (NaN entries are skipped; an empty mean is 0/0 = NaN), in query order.  The
-    // 18 chains are independent of each other, so they advance side by side without branches: a skipped entry adds +0.0 (the sums are
-    // never -0.0: they start at +0.0 and +0.0 + -0.0 = +0.0) and counts 0.
-    struct Acc {
-        double s[N_MEAS];
-        int64_t c[N_MEAS];
-        Acc() {
-            for (int m = 0; m < N_MEAS; ++m) {
-                s[m] = 0.0;
-                c[m] = 0;
-            }
-        }
-        void add(const double *v) {
-            for (int m = 0; m < N_MEAS; ++m) {
-                const bool ok = v[m] == v[m];
-                s[m] += ok ? v[m] : 0.0;
-                c[m] += ok;
-            }
-        }
-        void mean(double *o) const {
-            for (int m = 0; m < N_MEAS; ++m) o[m] = c[m] ? s[m] / (double)c[m] : std::nan("");
-        }
-    };
-    Acc total;
+    MeanAcc total;
     if (strategy == CMI_RANK_UC) {
         for (int64_t q = 0; q < nq; ++q)
             if (top_count[q] > 0) total.add(vals + (size_t)q * N_MEAS);
     } else {
-        // ucu: a test user contributes the NaN-skipping mean over its contexts -- NaN (skipped again) if none of its contexts produced
-        // a list (Recommender.java:903-926).  The users' means do not depend on each other: ranges of whole users on the host's cores
-        // write them down; only the sum over the users, in user order, is the serial part.
-        const int nt = host_threads(nq * 4);
-        std::vector<int64_t> cut((size_t)nt + 1, nq);
-        cut[0] = 0;
-        for (int t = 1; t < nt; ++t) {
-            int64_t b = std::min<int64_t>(nq, (nq + nt - 1) / nt * t);
-            while (b > 0 && b < nq && plan.qu[(size_t)b] == plan.qu[(size_t)b - 1]) ++b; // to the next user's first query
-            cut[(size_t)t] = std::max(b, cut[(size_t)t - 1]);
+        std::unique_ptr<double[]> own;
+        if (!umeans) { // a caller without a workspace buffer: at most one user per query
+            own.reset(new double[(size_t)nq * N_MEAS + 1]);
+            umeans = own.get();
+            f = RankFolded();
         }
-        std::vector<std::vector<double>> means((size_t)nt);
-        parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
-            for (int64_t p = p0; p < p1; ++p) {
-                std::vector<double> &mv = means[(size_t)p];
-                Acc user;
-                for (int64_t q = cut[(size_t)p]; q < cut[(size_t)p + 1]; ++q) {
-                    if (top_count[q] > 0) user.add(vals + (size_t)q * N_MEAS);
-                    if (q + 1 == nq || plan.qu[(size_t)q + 1] != plan.qu[(size_t)q]) {
-                        mv.resize(mv.size() + N_MEAS);
-                        user.mean(mv.data() + mv.size() - N_MEAS);
-                        user = Acc();
-                    }
-                }
-            }
-        });
-        for (const std::vector<double> &mv : means)
-            for (size_t i = 0; i + N_MEAS <= mv.size(); i += N_MEAS) total.add(mv.data() + i);
+        if (f.q < nq) rank_fold_users(plan, top_count, vals, umeans, f, nq, true);
+        for (int64_t u = 0; u < f.u; ++u) total.add(umeans + (size_t)u * N_MEAS);
     }
     total.mean(out);
 }
@@ -1051,6 +1081,8 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
     double *vals = ws.vals.need((size_t)nq * N_MEAS + 1); // only the rows of queries with a list are written and read
     std::vector<int32_t> no_lists;
     const int32_t *top_count = nullptr;
+    RankFolded folded;  // ucu: queries / users whose means are already taken
+    double *umeans = ws.umeans.need((size_t)std::min<int64_t>(nq, h->n_users) * N_MEAS + 1);
     if (nq > 0 && !plan.cand.empty()) {
         const bool ic_used = h->state[CMI_STATE_IC_BIAS] != nullptr;
         const int k_logical = ext ? h->k + (h->model == CMI_MODEL_SVDPP ? 1 : 0)
@@ -1058,6 +1090,8 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
         auto on_batch = [&](int64_t q0, int64_t q1) {
             rank_measures_range(plan, num_recs, (const int32_t *)ws.h_top.p, (const double *)ws.h_score.p, (const int32_t *)ws.h_count.p, q0, q1,
                                 vals, q_user, q_ctx, q_count, top_items, top_scores);
+            // the batches arrive in query order: the users they complete are averaged here, behind the device
+            if (strategy == CMI_RANK_UCU) rank_fold_users(plan, (const int32_t *)ws.h_count.p, vals, umeans, folded, q1, q1 >= nq);
         };
         hipError_t e;
         if (ext && h->f64) e = rank_run_device<double>(h->stream, ws, plan, ext_operands<double>(h, k_logical), bin_thold, num_recs, on_batch,
@@ -1091,7 +1125,8 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
         rank_measures_range(plan, num_recs, nullptr, nullptr, top_count, 0, nq, vals, q_user, q_ctx, q_count, top_items, top_scores);
     }
     const auto t_avg = std::chrono::steady_clock::now();
-    rank_average(plan, strategy, top_count, vals, out);
+    rank_average(plan, strategy, top_count, vals, umeans, folded, out);
+    if (getenv("CMI_PLAN_TIMES")) fprintf(stderr, "rank last batch's measures %.3f ms, averages %.3f ms\n", ws.host_ms[3], ms_since(t_avg));
     ws.host_ms[3] += ms_since(t_avg);
     ws.host_ms[4] = ms_since(t_all);
     if (n_queries) *n_queries = (int64_t)plan.qu.size();

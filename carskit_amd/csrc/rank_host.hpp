@@ -62,7 +62,7 @@ struct RankWorkspace {
             }
             return p.get();
         }
-    } vals;
+    } vals, umeans; // umeans: per-user means of the ucu strategy (rank_fold_users)
     hipEvent_t ev0 = nullptr, ev1 = nullptr; // around the device loop (timing)
     std::vector<hipEvent_t> evb;              // one per batch: its lists have arrived on the host
     std::vector<hipEvent_t> evk;              // three per batch of the split form: before / after the contraction, after the selection
@@ -96,7 +96,14 @@ bool rank_split_usable(const RankPlan &plan, int topn);
 void rank_measures_range(const RankPlan &plan, int num_recs, const int32_t *top_idx, const double *top_score, const int32_t *top_count,
                          int64_t q0, int64_t q1, double *vals, int32_t *q_user, int32_t *q_ctx, int32_t *q_count, int32_t *top_items,
                          double *top_scores);
-// averaged per strategy, in query order (Recommender.java:850-960)
-void rank_average(const RankPlan &plan, int strategy, const int32_t *top_count, const double *vals, double *out /*[21]*/);
+// averaged per strategy, in query order (Recommender.java:850-960).  ucu: rank_fold_users writes every user's mean over its contexts
+// into `umeans` (18 doubles per user, user order) and may run batch by batch behind the device for the users a batch completes;
+// rank_average folds what is left and sums over the users (umeans == nullptr: it allocates its own and folds everything).
+struct RankFolded {
+    int64_t q = 0, u = 0; // first query not folded yet; users folded so far
+};
+void rank_fold_users(const RankPlan &plan, const int32_t *top_count, const double *vals, double *umeans, RankFolded &f, int64_t q_to, bool last);
+void rank_average(const RankPlan &plan, int strategy, const int32_t *top_count, const double *vals, double *umeans, RankFolded f,
+                  double *out /*[21]*/);
 
 } // namespace cmi
