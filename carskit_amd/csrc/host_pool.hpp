@@ -36,8 +36,13 @@ class HostPool {
         return *p;
     }
     bool try_run(int nt, const std::function<void(int)> &fn) { // fn(0) runs on the caller
+        if (in_job()) return false; // a ranged body that starts ranged work itself: its own threads (the job lock is not recursive)
         std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
         if (!job.owns_lock()) return false;
+        struct Busy {
+            Busy() { in_job() = true; }
+            ~Busy() { in_job() = false; }
+        } busy;
         int have = 0; // workers that take part in this job
         {
             std::lock_guard<std::mutex> g(mu_);
@@ -69,6 +74,10 @@ class HostPool {
     }
 
   private:
+    static bool &in_job() {
+        static thread_local bool b = false;
+        return b;
+    }
     void work(int id, uint64_t seen) {
         for (;;) {
             const std::function<void(int)> *fn;
@@ -79,7 +88,9 @@ class HostPool {
                 if (id >= want_) continue;
                 fn = fn_;
             }
+            in_job() = true;
             (*fn)(id);
+            in_job() = false;
             std::lock_guard<std::mutex> g(mu_);
             if (--left_ == 0) done_.notify_one();
         }
