@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -514,6 +515,14 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
     CMI_HIP(h, hipStreamSynchronize(h->stream));
     free_ratings(h);
 
+    const bool times = getenv("CMI_SETUP_TIMES") != nullptr; // per-phase wall times of this call on stderr
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) {
+        if (!times) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "set_ratings %s %.3f s\n", w, std::chrono::duration<double>(t - T0).count());
+        T0 = t;
+    };
     // validate ids (the reference would throw ArrayIndexOutOfBounds inside the loop)
     int dmax = 0;
     if (contextual) {
@@ -545,6 +554,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         }
     }
     if (n >= ((int64_t)1 << 31) - 1024) CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: more than 2^31-1025 tuples per instance");
+    lap("validate");
 
     h->n = n;
     h->n_ctx = contextual ? n_ctx : 0;
@@ -751,6 +761,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             if (t > 0) h->n_tail += t;
     }
 
+    lap("schedule");
     // tuple stream in schedule order, conditions pre-expanded to [n x dmax] (-1 padded) so the kernels
     // need no ctx -> condition-list indirection.
     const int64_t ns = n;
@@ -792,6 +803,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             }
         }
     });
+    lap("stream");
     hipError_t e = upload((void **)&h->d_su, su, h->stream);
     if (e == hipSuccess) e = upload((void **)&h->d_sj, sj, h->stream);
     if (e == hipSuccess) e = upload((void **)&h->d_sconds, sconds, h->stream);
@@ -804,6 +816,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // cp/cc are locals
     }
     if (e == hipSuccess && h->chain) e = upload((void **)&h->d_unit_off, csch.unit_off, h->stream);
+    lap("uploads");
     if (e == hipSuccess && h->chain && !(h->flags & CMI_FLAG_NO_ARENA) && !getenv("CMI_NO_ARENA") && h->k >= 64 && h->k % (h->f64 ? 2 : 4) == 0) {
         // Spoke arena (SgdArgs::arena): worth its memory when the spoke table is large -- random 512-B rows over >= 2 GiB run at ~0.5 of
         // the HBM peak (address-translation misses, DRAM page misses), sequential reads + random full-line writes at ~0.7
@@ -848,6 +861,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
             }
         }
     }
+    lap("arena");
     if (e == hipSuccess && h->owner) {
         const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
         h->own_stride = owner_record_stride(h->model, h->k, h->n_conds, h->f64, h->owner_hub_item);
