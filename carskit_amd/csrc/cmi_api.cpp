@@ -450,16 +450,62 @@ static hipError_t upload(void **dst, const HostBuf<V> &v, hipStream_t s) {
 // hence ascending positions); the row's last tuple wraps to its first -- that is where the row waits for the next epoch.
 // first[row] = position of the row's first tuple, -1 for a row without tuples.
 static void arena_positions(int64_t n, const int32_t *spoke, int64_t n_spokes, int32_t *next, int32_t *first) {
-    for (int64_t r = 0; r < n_spokes; ++r) first[r] = -1;
-    for (int64_t p = n - 1; p >= 0; --p) { // sequential in p; the rows' entries (40 MB for 10 M users) are requested 24 tuples ahead
-        if (p >= 24) __builtin_prefetch(&first[spoke[p - 24]], 1);
-        const int32_t r = spoke[p];
-        next[p] = first[r]; // -1 for the row's last tuple: patched below
-        first[r] = (int32_t)p;
-    }
-    parallel_ranges(n, host_threads(n), [&](int, int64_t b, int64_t e) {
-        for (int64_t p = b; p < e; ++p)
+    const int nt = host_threads(n);
+    if (n < ((int64_t)1 << 22) || nt < 2) { // small: one backward walk
+        for (int64_t r = 0; r < n_spokes; ++r) first[r] = -1;
+        for (int64_t p = n - 1; p >= 0; --p) {
+            const int32_t r = spoke[p];
+            next[p] = first[r]; // -1 for the row's last tuple: patched below
+            first[r] = (int32_t)p;
+        }
+        for (int64_t p = 0; p < n; ++p)
             if (next[p] < 0) next[p] = first[spoke[p]];
+        return;
+    }
+    // Large: the backward walk's state is one entry per spoke row, and the rows do not interact -- so the rows are split into BUCKETS
+    // of 2^sh consecutive ids whose entries fit a core's cache, and the walk runs per bucket.  (1) ranges of positions append
+    // (position, row) to one list per (range, bucket); (2) every bucket walks its lists backwards (ranges descending, a list from its
+    // end), leaves the answer in the list entry and patches the rows' last tuples once its rows' first positions are final; (3) every
+    // range of positions copies its lists' answers into its own part of `next` -- no two threads ever write the same cache line.
+    int sh = 0;
+    while (((n_spokes - 1) >> sh) >= 256) ++sh;
+    const int nbk = (int)((n_spokes - 1) >> sh) + 1;
+    struct PR {
+        int32_t p, r; // position and row; `r` becomes the answer in step (2)
+    };
+    std::vector<std::vector<PR>> lists((size_t)nt * (size_t)nbk);
+    std::vector<int64_t> lo((size_t)nt + 1, n);
+    const int64_t step = (n + nt - 1) / nt;
+    for (int t = 0; t <= nt; ++t) lo[(size_t)t] = std::min<int64_t>(n, (int64_t)t * step);
+    parallel_ranges(nt, nt, [&](int, int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; ++t) {
+            std::vector<PR> *L = &lists[(size_t)t * (size_t)nbk];
+            const int64_t b = lo[(size_t)t], e = lo[(size_t)t + 1];
+            for (int k = 0; k < nbk; ++k) L[k].reserve((size_t)((e - b) / nbk + (e - b) / (4 * nbk) + 16));
+            for (int64_t p = b; p < e; ++p) L[spoke[p] >> sh].push_back(PR{(int32_t)p, spoke[p]});
+        }
+    });
+    parallel_ranges(nbk, nt, [&](int, int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; ++k) {
+            const int64_t r0 = k << sh, r1 = std::min<int64_t>(n_spokes, (k + 1) << sh);
+            for (int64_t r = r0; r < r1; ++r) first[r] = -1;
+            for (int t = nt - 1; t >= 0; --t) {
+                std::vector<PR> &L = lists[(size_t)t * (size_t)nbk + (size_t)k];
+                for (size_t x = L.size(); x-- > 0;) {
+                    const int32_t r = L[x].r;
+                    L[x].r = first[r]; // -1 for the row's last tuple
+                    first[r] = L[x].p;
+                }
+            }
+            for (int t = 0; t < nt; ++t) // the rows' last tuples wrap to their first
+                for (PR &x : lists[(size_t)t * (size_t)nbk + (size_t)k])
+                    if (x.r < 0) x.r = first[spoke[x.p]];
+        }
+    });
+    parallel_ranges(nt, nt, [&](int, int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; ++t)
+            for (int k = 0; k < nbk; ++k)
+                for (const PR &x : lists[(size_t)t * (size_t)nbk + (size_t)k]) next[x.p] = x.r;
     });
 }
 // host-only export of the same (tests/test_chain_schedule.py)
