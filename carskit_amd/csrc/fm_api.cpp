@@ -10,9 +10,12 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "fm_kernels.hpp"
+#include "host_pool.hpp"
 #include "rank_host.hpp"
 #include "rank_kernels.hpp"
 
@@ -299,26 +302,51 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
     FM_HIP(h, hipStreamSynchronize(h->stream));
     fm_free_ratings(h);
     FmOrderHost ou, oi, oc;
-    fm_build_order(n, u, j, ctx, h->n_users, h->n_items, h->slice_entries, ou);
-    fm_build_order(n, j, u, ctx, h->n_items, h->n_users, h->slice_entries, oi);
     {
-        // context features: only ratings whose context-combination id is < numConditions have one (FM.java:81-86)
+        // the three orders do not depend on each other: the item and the context order are built on threads of their own beside the
+        // user order (each is two sequential passes over the ratings with scattered counters: a second of one core for 25 M ratings)
         std::vector<int32_t> ckey((size_t)n);
-        for (int64_t t = 0; t < n; ++t) ckey[(size_t)t] = ctx[t] < h->n_conds ? ctx[t] : -1;
-        fm_build_order(n, ckey.data(), u, j, h->n_conds, h->n_users, 0, oc);
+        auto item_order = [&]() { fm_build_order(n, j, u, ctx, h->n_items, h->n_users, h->slice_entries, oi); };
+        auto ctx_order = [&]() {
+            // context features: only ratings whose context-combination id is < numConditions have one (FM.java:81-86)
+            for (int64_t t = 0; t < n; ++t) ckey[(size_t)t] = ctx[t] < h->n_conds ? ctx[t] : -1;
+            fm_build_order(n, ckey.data(), u, j, h->n_conds, h->n_users, 0, oc);
+        };
+        std::thread ti, tc;
+        bool hi = true, hc = true;
+        try {
+            ti = std::thread(item_order);
+        } catch (const std::system_error &) { // the process may not create more threads: one after the other
+            hi = false;
+        }
+        try {
+            tc = std::thread(ctx_order);
+        } catch (const std::system_error &) {
+            hc = false;
+        }
+        fm_build_order(n, u, j, ctx, h->n_users, h->n_items, h->slice_entries, ou);
+        if (hi) ti.join();
+        else item_order();
+        if (hc) tc.join();
+        else ctx_order();
     }
-    // the ratings as plain arrays in user order (cmi_fm_init), and where the other orders find their err0
+    // the ratings as plain arrays in user order (cmi_fm_init), and where the other orders find their err0: gathers through the orders'
+    // permutations, in ranges on the host pool
     std::vector<int32_t> su((size_t)n), sj((size_t)n), sc((size_t)n), inv((size_t)n), i2u((size_t)n), c2u(oc.src.size());
     std::vector<double> sr((size_t)n);
-    for (int64_t pos = 0; pos < n; ++pos) {
-        const int32_t t = ou.src[(size_t)pos];
-        su[(size_t)pos] = u[t];
-        sj[(size_t)pos] = j[t];
-        sc[(size_t)pos] = ctx[t];
-        sr[(size_t)pos] = r[t];
-        inv[(size_t)t] = (int32_t)pos;
-    }
-    for (int64_t pos = 0; pos < n; ++pos) i2u[(size_t)pos] = inv[(size_t)oi.src[(size_t)pos]];
+    parallel_ranges(n, host_threads(n), [&](int, int64_t b, int64_t e) {
+        for (int64_t pos = b; pos < e; ++pos) {
+            const int32_t t = ou.src[(size_t)pos];
+            su[(size_t)pos] = u[t];
+            sj[(size_t)pos] = j[t];
+            sc[(size_t)pos] = ctx[t];
+            sr[(size_t)pos] = r[t];
+            inv[(size_t)t] = (int32_t)pos; // (a permutation: every t is written once)
+        }
+    });
+    parallel_ranges(n, host_threads(n), [&](int, int64_t b, int64_t e) {
+        for (int64_t pos = b; pos < e; ++pos) i2u[(size_t)pos] = inv[(size_t)oi.src[(size_t)pos]];
+    });
     for (size_t pos = 0; pos < oc.src.size(); ++pos) c2u[pos] = inv[(size_t)oc.src[pos]];
     hipError_t e = up(&h->d_u, su, h->stream);
     if (e == hipSuccess) e = up(&h->d_j, sj, h->stream);
