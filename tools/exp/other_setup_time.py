@@ -1,3 +1,5 @@
+"""usage (GPU box): python tools/exp/other_setup_time.py  -- wall time of cmi_fm_set_ratings (C4 share, 25 M ratings) + model upload + one sweep, and of
+cmi_set_ratings for a 2-D model (BiasedMF) on C3's tuples; CMI_SETUP_TIMES=1 prints cmi_set_ratings' phases."""
 import sys, time, numpy as np
 sys.path.insert(0,'.')
 from carskit_amd import capi, synth
