@@ -1087,7 +1087,17 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
         const bool ic_used = h->state[CMI_STATE_IC_BIAS] != nullptr;
         const int k_logical = ext ? h->k + (h->model == CMI_MODEL_SVDPP ? 1 : 0)
                                   : h->k + 1 + (ic_used ? h->n_conds : 0); // [factors | 1 or itemBias | one-hot conditions or icBias row]
+        const bool times = getenv("CMI_PLAN_TIMES") != nullptr;
         auto on_batch = [&](int64_t q0, int64_t q1) {
+            const auto tb = std::chrono::steady_clock::now();
+            struct Lap {
+                bool on;
+                std::chrono::steady_clock::time_point t0;
+                int64_t n;
+                ~Lap() {
+                    if (on) fprintf(stderr, "rank batch of %lld queries: measures + user means %.3f ms on the host\n", (long long)n, ms_since(t0));
+                }
+            } lap{times, tb, q1 - q0};
             rank_measures_range(plan, num_recs, (const int32_t *)ws.h_top.p, (const double *)ws.h_score.p, (const int32_t *)ws.h_count.p, q0, q1,
                                 vals, q_user, q_ctx, q_count, top_items, top_scores);
             // the batches arrive in query order: the users they complete are averaged here, behind the device
