@@ -25,6 +25,11 @@
 #include <unordered_map>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "host_pool.hpp"
 
 using cmi::host_threads;
@@ -116,20 +121,61 @@ bool read_lines(const char *path, std::vector<std::string> &lines, std::string &
     return true;
 }
 
-// the same line structure without one std::string per line: (offset, length) spans into the file image
-bool read_spans(const char *path, std::string &all, std::vector<std::pair<size_t, size_t>> &spans, std::string &err) {
-    FILE *f = std::fopen(path, "rb");
-    if (!f) {
-        err = std::string("cannot open ") + path;
-        return false;
+// The bytes of a rating file: mapped (large files: no copy, the page cache's pages) or read into a buffer.
+class FileImage {
+  public:
+    FileImage() = default;
+    FileImage(const FileImage &) = delete;
+    FileImage &operator=(const FileImage &) = delete;
+    ~FileImage() {
+        if (map_) munmap((void *)p_, n_);
     }
-    std::fseek(f, 0, SEEK_END);
-    const long sz = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    all.resize(sz > 0 ? (size_t)sz : 0);
-    const size_t got = all.empty() ? 0 : std::fread(&all[0], 1, all.size(), f);
-    std::fclose(f);
-    all.resize(got);
+    bool open(const char *path, std::string &err) {
+        const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+        if (fd < 0) {
+            err = std::string("cannot open ") + path;
+            return false;
+        }
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= ((off_t)16 << 20)) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                p_ = (const char *)m;
+                n_ = (size_t)st.st_size;
+                map_ = true;
+                ::close(fd);
+                return true;
+            }
+        }
+        std::string buf;
+        char tmp[1 << 16];
+        for (;;) {
+            const ssize_t got = ::read(fd, tmp, sizeof tmp);
+            if (got <= 0) break;
+            buf.append(tmp, (size_t)got);
+        }
+        ::close(fd);
+        own_.swap(buf);
+        p_ = own_.data();
+        n_ = own_.size();
+        return true;
+    }
+    const char *data() const { return p_; }
+    size_t size() const { return n_; }
+    char operator[](size_t i) const { return p_[i]; }
+    std::string substr(size_t b, size_t len) const { return std::string(p_ + b, std::min(len, n_ - b)); }
+
+  private:
+    const char *p_ = nullptr;
+    size_t n_ = 0;
+    bool map_ = false;
+    std::string own_;
+};
+
+// the same line structure without one std::string per line: (offset, length) spans into the file image
+bool read_spans(const char *path, FileImage &all, std::vector<std::pair<size_t, size_t>> &spans, std::string &err) {
+    if (!all.open(path, err)) return false;
     size_t i = 0, b = 0;
     const size_t n = all.size();
     size_t par_min = (size_t)16 << 20;
@@ -435,7 +481,7 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
         fprintf(stderr, "dao %s %.3f s\n", w, std::chrono::duration<double>(n - T0).count());
         T0 = n;
     };
-    std::string image;
+    FileImage image;
     std::vector<std::pair<size_t, size_t>> lines; // spans into `image`
     if (!read_spans(path, image, lines, g_dao_err)) return CMI_E_INVALID;
     lap("read+split");
