@@ -587,6 +587,39 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
         }
         ctx.clear();
         cond_list.clear();
+        auto add_cond = [&](int32_t ci) {
+            if (!ctx.empty()) ctx += ',';
+            char num[12];
+            int nd = 0, v = ci;
+            do num[nd++] = (char)('0' + v % 10); while ((v /= 10) > 0);
+            while (nd > 0) ctx += num[--nd];
+            cond_list.push_back(ci);
+        };
+        // the usual shape of the flag columns -- single characters 0 / 1 between commas -- is read byte by byte; anything else (spaces,
+        // other integers, empty fields) goes through the general field scan below from the start of the flags
+        bool plain = p <= end;
+        if (plain) {
+            const char *q = p;
+            int32_t ci = 0;
+            for (; q < end; q += 2, ++ci) {
+                if ((*q != '0' && *q != '1') || (q + 1 < end && q[1] != ',')) {
+                    plain = false;
+                    break;
+                }
+                if (q + 1 == end) { // the last flag
+                    if (*q == '1') add_cond(ci);
+                    q = end + 1;
+                    break;
+                }
+                if (*q == '1') add_cond(ci);
+            }
+            if (plain && q == end) plain = false; // an empty line tail or a trailing comma (an empty last field): the general scan
+            if (plain) p = end + 1;
+            else {
+                ctx.clear();
+                cond_list.clear();
+            }
+        }
         const char *fb, *fe;
         for (int32_t ci = 0; next_field(fb, fe); ++ci) {
             int32_t value;
@@ -597,14 +630,7 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
                 err = "line " + std::to_string(ln + 1) + ": condition flag '" + std::string(fb, fe) + "' is not an integer (NumberFormatException)";
                 return false;
             }
-            if (value == 1) {
-                if (!ctx.empty()) ctx += ',';
-                char num[12];
-                int nd = 0, v = ci;
-                do num[nd++] = (char)('0' + v % 10); while ((v /= 10) > 0);
-                while (nd > 0) ctx += num[--nd];
-                cond_list.push_back(ci);
-            }
+            if (value == 1) add_cond(ci);
         }
         for (int32_t c : cond_list)
             if (c >= n_conds) {
