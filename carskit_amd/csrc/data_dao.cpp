@@ -699,12 +699,44 @@ static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *
         for (const Range &R : rg) bad = bad || R.bad;
         lap("parse");
         if (!bad) {
-            for (Range &R : rg) { // the ranges' new keys, range after range
-                R.tu.resize(R.users.size());
-                R.ti.resize(R.items.size());
+            // The ranges' new keys enter the shared tables range after range.  For the users and the items (millions of keys, and with
+            // unordered data every range meets most of them) that order is produced by a TREE of pairwise merges first: merging table B
+            // into table A appends B's keys that A does not hold, in B's order -- an associative step, so ranges (0,1), (2,3), ... merge
+            // side by side, then (01, 23), ... and range 0's table ends up holding every new key in the sequential pass's order; those
+            // enter the shared table once, and every range looks its own keys up (in parallel).
+            {
+                std::vector<size_t> nu0((size_t)nt), ni0((size_t)nt);
+                for (int r = 0; r < nt; ++r) {
+                    nu0[(size_t)r] = rg[(size_t)r].users.size();
+                    ni0[(size_t)r] = rg[(size_t)r].items.size();
+                }
+                for (int stride = 1; stride < nt; stride *= 2) {
+                    const int64_t pairs = (nt + 2 * stride - 1) / (2 * stride);
+                    parallel_ranges(pairs, (int)std::min<int64_t>(pairs, nt), [&](int, int64_t q0, int64_t q1) {
+                        for (int64_t q = q0; q < q1; ++q) {
+                            const int64_t a = q * 2 * stride, b = a + stride;
+                            if (b >= nt) continue;
+                            Range &A = rg[(size_t)a];
+                            const Range &B = rg[(size_t)b];
+                            for (const std::string &k : B.users) A.users_i.find_or_add(k.data(), k.size(), A.users);
+                            for (const std::string &k : B.items) A.items_i.find_or_add(k.data(), k.size(), A.items);
+                        }
+                    });
+                }
+                for (const std::string &k : rg[0].users) d->user_ids.find_or_add(k.data(), k.size(), d->users);
+                for (const std::string &k : rg[0].items) d->item_ids.find_or_add(k.data(), k.size(), d->items);
+                parallel_ranges(nt, nt, [&](int, int64_t p0, int64_t p1) {
+                    for (int64_t p = p0; p < p1; ++p) {
+                        Range &R = rg[(size_t)p];
+                        R.tu.resize(nu0[(size_t)p]);
+                        R.ti.resize(ni0[(size_t)p]);
+                        for (size_t k = 0; k < R.tu.size(); ++k) R.tu[k] = dc->user_ids.find(R.users[k].data(), R.users[k].size(), dc->users);
+                        for (size_t k = 0; k < R.ti.size(); ++k) R.ti[k] = dc->item_ids.find(R.items[k].data(), R.items[k].size(), dc->items);
+                    }
+                });
+            }
+            for (Range &R : rg) { // the contexts (few): range after range
                 R.tc.resize(R.ctxs.size());
-                for (size_t k = 0; k < R.users.size(); ++k) R.tu[k] = d->user_ids.find_or_add(R.users[k].data(), R.users[k].size(), d->users);
-                for (size_t k = 0; k < R.items.size(); ++k) R.ti[k] = d->item_ids.find_or_add(R.items[k].data(), R.items[k].size(), d->items);
                 for (size_t k = 0; k < R.ctxs.size(); ++k) {
                     const int32_t cc = d->ctx_ids.find_or_add(R.ctxs[k].data(), R.ctxs[k].size(), d->ctxs);
                     R.tc[k] = cc;
