@@ -444,7 +444,12 @@ __global__ __launch_bounds__(256) void rank_topn_split(const T *__restrict__ S1,
                                                        T tf, int topn, int32_t *out_idx, double *out_score, int32_t *out_count) {
     // tf = the largest T <= the rating threshold: (double)x > threshold  <=>  x > tf, for every x of type T
     const int lane = threadIdx.x & 63;
-    const int q = q0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs, so XCD x takes the x-th contiguous eighth of the queries -- a
+    // user's queries (consecutive) then share one XCD's L2 for their S1 row instead of fetching it into two (A/B on one box, two runs
+    // each: 4.22 / 4.21 ms per evaluation with workgroup b on queries 4b .., 3.50 / 3.51 ms with this order)
+    const int per = (int)gridDim.x / 8; // (the grid is a multiple of 8 workgroups)
+    const int blk = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    const int q = q0 + blk * 4 + (threadIdx.x >> 6);
     if (q >= q0 + nq) return;
     const T *row1 = S1 + (size_t)(q_group[q] - g_base) * nc;
     const T *row2 = S2 ? S2 + (size_t)q_dctx[q] * nc : nullptr;
@@ -599,7 +604,8 @@ hipError_t rank_launch_split_select(const float *S1, const float *S2, const Rank
     if (nq <= 0) return hipSuccess;
     float tf = (float)thold; // round to nearest, then down to the largest float <= thold (NaN stays NaN: nothing passes, as before)
     if ((double)tf > thold) tf = nextafterf(tf, -INFINITY);
-    hipLaunchKernelGGL(rank_topn_split<float>, dim3((nq + 3) / 4), dim3(256), 0, s, S1, S2, (const float *)a.rc, q_group, q_dctx, g_base, q0, nq, a.nc,
+    const int nblk = (nq + 3) / 4;
+    hipLaunchKernelGGL(rank_topn_split<float>, dim3((nblk + 7) / 8 * 8), dim3(256), 0, s, S1, S2, (const float *)a.rc, q_group, q_dctx, g_base, q0, nq, a.nc,
                        excl_ptr, excl_idx, tf, topn, out_idx, out_score, out_count);
     return hipGetLastError();
 }
