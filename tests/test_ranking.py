@@ -192,3 +192,29 @@ def test_list_measures_library_matches_oracle_formulas():
     g = capi.rank_list_measures([3, 1, 4, 2, 5], [1, 5, 9], 10, 5)
     assert g["Pre5"] == 0.4 and g["MRR5"] == 0.5 and g["AUC5"] == pytest.approx(20 / 26, abs=1e-16)
     assert g["MAP5"] == pytest.approx((1 / 2 + 2 / 5) / 3, abs=1e-16)
+
+
+def test_rank_plan_is_the_same_for_any_number_of_host_threads_on_a_larger_input(monkeypatch):
+    """The plan's threaded form (tuple ranges -> user buckets -> queries; the candidates' first-seen order merged over ranges) on an input
+    large enough to fill every range and bucket: 6 000 users (more than 256 buckets' worth), sparse item ids (HashSet order != ascending),
+    duplicate (user, context, item) cells, zero ratings in the training set, -ignore: 1, 2, 7 and 16 ranges give the same arrays."""
+    rng = np.random.default_rng(12)
+    n_users, n_items, n = 6000, 5000, 120_000
+    items = rng.choice(n_items, size=1200, replace=False)
+    u = rng.integers(0, n_users, n).astype(np.int32)
+    j = items[rng.integers(0, len(items), n)].astype(np.int32)
+    c = rng.integers(0, 40, n).astype(np.int32)
+    r = rng.integers(0, 6, n).astype(np.float64)          # zeros included: a sparse matrix holds no zero entries
+    cut = int(0.8 * n)
+    train, test = (u[:cut], j[:cut], c[:cut], r[:cut]), (u[cut:], j[cut:], c[cut:], r[cut:])
+    ref = None
+    for nt in ("1", "2", "7", "16"):
+        monkeypatch.setenv("CMI_HOST_THREADS", nt)
+        for ignore in (0, 25):
+            got = capi.rank_plan(n_users, n_items, train, test, 2.5, ignore)
+            if ref is None or ignore not in ref:
+                ref = ref or {}
+                ref[ignore] = got
+                assert len(got[1]) > 5000
+            else:
+                assert got == ref[ignore], (nt, ignore)
