@@ -569,7 +569,7 @@ hipError_t RankWorkspace::need(Buf &b, size_t bytes, bool pinned) {
 }
 
 void RankWorkspace::release() {
-    Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount, &dB2, &dA2, &dS2, &dqg, &dqd, &dgu, &ddc, &dscr, &dcc};
+    Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount, &dB2, &dA2, &dS2, &dqg, &dqd, &dgu, &ddc, &dscr};
     for (Buf *b : dev) {
         if (b->p) (void)hipFree(b->p);
         *b = Buf();
@@ -772,8 +772,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     const bool s2 = ic; // the context part as a slab of its own (distinct contexts x candidates)
     if (s2) distinct_contexts(plan.qc, dctx, qd);
     const int n_dc = (int)dctx.size();
-    const bool bias_in_epilogue = a.k % 16 == 0 && !getenv("CMI_RANK_BIAS_COLUMN"); // (the variable: A/B of the two forms)
-    a.kp1 = bias_in_epilogue ? a.k : (a.k + 1 + 15) / 16 * 16;
+    a.kp1 = (a.k + 1 + 15) / 16 * 16;
     a.kp2 = ic ? (a.n_conds + 15) / 16 * 16 : 16;
     a.nc = nc;
     a.nq = (int)nq;
@@ -792,7 +791,6 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     need(ws.dA, up128(bg) * a.kp1 * 4);
     need(ws.dS, (size_t)bg * (size_t)nc * 4);
     need(ws.dscr, std::max<size_t>(up128(bg), up128(n_dc)) * 4);
-    need(ws.dcc, up128(nc) * 4);
     need(ws.drc, (size_t)nq * 4);
     if (s2) {
         need(ws.dB2, up128(nc) * a.kp2 * 4);
@@ -845,7 +843,6 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     a.B2 = (float *)ws.dB2.p;
     a.A2 = (float *)ws.dA2.p;
     a.rc = (float *)ws.drc.p;
-    a.cc1 = bias_in_epilogue ? (float *)ws.dcc.p : nullptr;
     if (e == hipSuccess) e = rank_launch_split_operands(a, stream);
     if (e == hipSuccess) e = hipEventRecord(ws.ev0, stream);
     // S2: once per evaluation (row constant = the zeroed scratch)
@@ -861,7 +858,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
         // (the builder leaves its per-row constant -- zero here -- in the scratch the contraction then reads as its row constant)
         e = rank_launch_split_users(a, (const int32_t *)ws.dgu.p + g0, n, (float *)ws.dA.p, (float *)ws.dscr.p, stream);
         if (e == hipSuccess) e = ws.kernel_event(3 * b, stream);
-        if (e == hipSuccess) e = rank_launch_gemm<float>((const float *)ws.dA.p, a.B1, (const float *)ws.dscr.p, (float *)ws.dS.p, n, nc, a.kp1, stream, a.cc1);
+        if (e == hipSuccess) e = rank_launch_gemm<float>((const float *)ws.dA.p, a.B1, (const float *)ws.dscr.p, (float *)ws.dS.p, n, nc, a.kp1, stream);
         if (e == hipSuccess) e = ws.kernel_event(3 * b + 1, stream);
         if (e == hipSuccess)
             e = rank_launch_split_select((const float *)ws.dS.p, s2 ? (const float *)ws.dS2.p : nullptr, a, (const int32_t *)ws.dqg.p,

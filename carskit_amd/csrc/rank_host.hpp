@@ -49,7 +49,7 @@ struct RankWorkspace {
         size_t cap = 0;
     };
     Buf dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount; // device
-    Buf dB2, dA2, dS2, dqg, dqd, dgu, ddc, dscr, dcc;                           // device, split form (rank_run_device_split)
+    Buf dB2, dA2, dS2, dqg, dqd, dgu, ddc, dscr;                                // device, split form (rank_run_device_split)
     Buf h_top, h_score, h_count;                                                // pinned host: the lists as they come back
     RankPlan plan;                                                              // the last evaluation's plan (capacity is reused)
     struct HostVals { // per-query measures, uninitialised and grow-only (38 MB for 270 K queries: not re-faulted per call)

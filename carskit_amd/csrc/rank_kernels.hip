@@ -121,7 +121,7 @@ hipError_t rank_launch_fm_queries(const RankFmArgs &a, const int32_t *qu, const 
 
 template <typename T>
 __global__ __launch_bounds__(256) void rank_gemm(const T *__restrict__ A, const T *__restrict__ B, const T *row_const,
-                                                 const T *col_const, T *__restrict__ S, int nq, int nc, int kp) {
+                                                 T *__restrict__ S, int nq, int nc, int kp) {
     constexpr int TM = 64, TN = 64, TK = 16;
     __shared__ T sA[TK][TM + 1];
     __shared__ T sB[TK][TN + 1];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void rank_gemm(const T *__restrict__ A, const 
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int c = c0 + tx * 4 + jj;
-            if (c < nc) S[(size_t)q * nc + c] = (col_const ? acc[i][jj] + col_const[c] : acc[i][jj]) + rc;
+            if (c < nc) S[(size_t)q * nc + c] = acc[i][jj] + rc;
         }
     }
 }
@@ -182,8 +182,8 @@ constexpr int RG_TPR = RG_BK / 4, RG_RPP = 256 / RG_TPR, RG_NP = RG_BM / RG_RPP;
 #define CMI_RG_WAVES 4 // min waves per SIMD: 114 VGPRs instead of 140, four blocks per CU instead of three (23.70 -> 23.19 ms on the 270 K x 20 K case)
 #endif
 __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const float *__restrict__ A, const float *__restrict__ B,
-                                                          const float *__restrict__ row_const, const float *__restrict__ col_const,
-                                                          float *__restrict__ S, int nq, int nc, int kp_pad, int tiles_c, int n_tiles) {
+                                                          const float *__restrict__ row_const, float *__restrict__ S,
+                                                          int nq, int nc, int kp_pad, int tiles_c, int n_tiles) {
     __shared__ float sA[2][RG_BK][RG_LDS];
     __shared__ float sB[2][RG_BK][RG_LDS];
     // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give XCD x the x-th contiguous
@@ -273,8 +273,7 @@ __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const fl
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int c = c0 + wc + 32 * j + mrow;
-                // (col_const: a per-candidate term that would otherwise be one more k step -- added where that step would add it)
-                if (c < nc) S[(size_t)q * nc + c] = (col_const ? acc[i][j][r] + col_const[c] : acc[i][j][r]) + rc;
+                if (c < nc) S[(size_t)q * nc + c] = acc[i][j][r] + rc;
             }
         }
 }
@@ -551,18 +550,18 @@ hipError_t rank_launch_build_queries(const RankQueryArgs<T> &a, int nq, hipStrea
     return hipGetLastError();
 }
 template <typename T>
-hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s, const T *col_const) {
+hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s) {
     if (nq <= 0 || nc <= 0) return hipSuccess;
     static const bool force_valu = getenv("CMI_RANK_VALU") != nullptr; // A/B experiments only
     if constexpr (sizeof(T) == 4) {
         if (!force_valu && kp % RG_BK == 0) {
             const int tiles_c = (nc + RG_BN - 1) / RG_BN, n_tiles = tiles_c * ((nq + RG_BM - 1) / RG_BM);
             hipLaunchKernelGGL(rank_gemm_mfma_f32, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, s, (const float *)A,
-                               (const float *)B, (const float *)row_const, (const float *)col_const, (float *)S, nq, nc, kp, tiles_c, n_tiles);
+                               (const float *)B, (const float *)row_const, (float *)S, nq, nc, kp, tiles_c, n_tiles);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, col_const, S, nq, nc, kp);
+    hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, S, nq, nc, kp);
     return hipGetLastError();
 }
 template <typename T>
@@ -570,7 +569,7 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
                              const int64_t *excl_ptr, const int32_t *excl_idx, int q_base, double thold, int topn,
                              int32_t *out_idx, double *out_score, int32_t *out_count, hipStream_t s) {
     if (nq <= 0 || nc <= 0) return hipSuccess;
-    if (hipError_t e = rank_launch_gemm<T>(A, B, row_const, S, nq, nc, kp, s, (const T *)nullptr)) return e;
+    if (hipError_t e = rank_launch_gemm<T>(A, B, row_const, S, nq, nc, kp, s)) return e;
     hipLaunchKernelGGL(rank_mask<T>, dim3(nq), dim3(64), 0, s, S, nc, excl_ptr, excl_idx, q_base, nq);
     if (topn <= 64)
         hipLaunchKernelGGL(rank_topn_stream<T>, dim3((nq + 3) / 4), dim3(256), 0, s, (const T *)S, nq, nc, thold, topn, out_idx,
@@ -582,18 +581,10 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
 }
 
 
-__global__ void rank_build_col_const(const float *__restrict__ itemBias, const int32_t *__restrict__ cand, float *__restrict__ cc, int nc) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < nc) cc[c] = itemBias ? itemBias[cand[c]] : 0.f;
-}
-
 hipError_t rank_launch_split_operands(const RankSplitArgs &a, hipStream_t s) {
-    // B1 = [Q[j] | itemBias[j] or 0] for the candidates; when k is a multiple of the contraction's k step the bias column would be a
-    // whole step of its own (144 against 128 at k = 128): it then leaves the operand (kp1 = k) and is added in the epilogue (cc1),
-    // where the last step would have added it
+    // B1 = [Q[j] | itemBias[j] or 0] for the candidates
     RankItemsArgs<float> ia{a.Q, a.itemBias, nullptr, a.cand, a.B1, a.nc, a.k, a.kp1, 0};
     if (hipError_t e = rank_launch_build_items<float>(ia, s)) return e;
-    if (a.cc1) hipLaunchKernelGGL(rank_build_col_const, dim3((a.nc + 255) / 256), dim3(256), 0, s, a.itemBias, a.cand, a.cc1, a.nc);
     if (a.icBias) {
         hipLaunchKernelGGL(rank_build_ic_items<float>, dim3(a.nc), dim3(64), 0, s, a.icBias, a.cand, a.B2, a.n_conds, a.kp2);
         hipLaunchKernelGGL(rank_build_ctx_rows<float>, dim3(a.n_dctx), dim3(64), 0, s, a.ctx_ptr, a.ctx_conds, a.dctx, a.A2, a.kp2);
@@ -622,7 +613,7 @@ hipError_t rank_launch_split_select(const float *S1, const float *S2, const Rank
 #define CMI_INST(T)                                                                                                    \
     template hipError_t rank_launch_build_items<T>(const RankItemsArgs<T> &, hipStream_t);                             \
     template hipError_t rank_launch_build_queries<T>(const RankQueryArgs<T> &, int, hipStream_t);                      \
-    template hipError_t rank_launch_gemm<T>(const T *, const T *, const T *, T *, int, int, int, hipStream_t, const T *); \
+    template hipError_t rank_launch_gemm<T>(const T *, const T *, const T *, T *, int, int, int, hipStream_t);        \
     template hipError_t rank_launch_score<T>(const T *, const T *, const T *, T *, int, int, int, const int64_t *,     \
                                              const int32_t *, int, double, int, int32_t *, double *, int32_t *, hipStream_t);
 CMI_INST(float)

@@ -52,7 +52,6 @@ struct RankSplitArgs {
     const int32_t *ctx_ptr, *ctx_conds;                                    // null for the 2-D models
     const int32_t *cand, *qu, *qc, *dctx;                                  // candidates; per query user / context; distinct contexts
     float *B1, *B2, *A2, *rc;                                              // operands built once per evaluation
-    float *cc1;                                                            // per-candidate constant of S1 (the item bias) when it is not an operand column
     double gm;
     int k, kp1, kp2, n_conds, nc, nq, n_dctx;
 };
@@ -63,6 +62,6 @@ hipError_t rank_launch_split_select(const float *S1, const float *S2, const Rank
                                     double *out_score, int32_t *out_count, hipStream_t s);
 // S = A.B^T + row_const (the contraction alone)
 template <typename T>
-hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s, const T *col_const = nullptr);
+hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s);
 
 } // namespace cmi
