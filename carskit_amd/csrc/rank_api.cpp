@@ -403,8 +403,17 @@ void rank_build_plan(int n_users, int n_items, const RankTuples &train, const Ra
     });
     lap("users");
     // the parts, in bucket order
-    std::vector<int64_t> q0((size_t)nbk + 1, 0), t0((size_t)nbk + 1, 0), e0((size_t)nbk + 1, 0);
+    std::vector<int64_t> q0((size_t)nbk + 1, 0), t0((size_t)nbk + 1, 0), e0((size_t)nbk + 1, 0), g0((size_t)nbk + 1, 0);
+    parallel_ranges(nbk, nt, [&](int, int64_t p0, int64_t p1) { // query groups (runs of one user) per part: users never straddle parts
+        for (int64_t p = p0; p < p1; ++p) {
+            const std::vector<int32_t> &qu = parts[(size_t)p].qu;
+            int64_t g = 0;
+            for (size_t i = 0; i < qu.size(); ++i) g += i == 0 || qu[i] != qu[i - 1];
+            g0[(size_t)p + 1] = g;
+        }
+    });
     for (int p = 0; p < nbk; ++p) {
+        g0[(size_t)p + 1] += g0[(size_t)p];
         q0[(size_t)p + 1] = q0[(size_t)p] + (int64_t)parts[(size_t)p].qu.size();
         t0[(size_t)p + 1] = t0[(size_t)p] + (int64_t)parts[(size_t)p].truth_items.size();
         e0[(size_t)p + 1] = e0[(size_t)p] + (int64_t)parts[(size_t)p].excl_idx.size();
@@ -416,9 +425,22 @@ void rank_build_plan(int n_users, int n_items, const RankTuples &train, const Ra
     plan.truth_items.resize((size_t)t0[(size_t)nbk]);
     plan.excl_idx.resize((size_t)e0[(size_t)nbk]);
     plan.truth_ptr[0] = plan.excl_ptr[0] = 0;
+    plan.qg.resize((size_t)q0[(size_t)nbk]);
+    plan.gu.resize((size_t)g0[(size_t)nbk]);
+    plan.gq0.resize((size_t)g0[(size_t)nbk] + 1);
+    plan.gq0[(size_t)g0[(size_t)nbk]] = (int32_t)q0[(size_t)nbk];
     parallel_ranges(nbk, nt, [&](int, int64_t p0, int64_t p1) {
         for (int64_t p = p0; p < p1; ++p) {
             const Part &P = parts[(size_t)p];
+            int64_t g = g0[(size_t)p] - 1;
+            for (size_t i = 0; i < P.qu.size(); ++i) {
+                if (i == 0 || P.qu[i] != P.qu[i - 1]) {
+                    ++g;
+                    plan.gu[(size_t)g] = P.qu[i];
+                    plan.gq0[(size_t)g] = (int32_t)(q0[(size_t)p] + (int64_t)i);
+                }
+                plan.qg[(size_t)q0[(size_t)p] + i] = (int32_t)g;
+            }
             std::copy(P.qu.begin(), P.qu.end(), plan.qu.begin() + q0[(size_t)p]);
             std::copy(P.qc.begin(), P.qc.end(), plan.qc.begin() + q0[(size_t)p]);
             std::copy(P.truth_items.begin(), P.truth_items.end(), plan.truth_items.begin() + t0[(size_t)p]);
@@ -743,35 +765,45 @@ void distinct_contexts(const std::vector<int32_t> &qc, std::vector<int32_t> &dct
 }
 } // namespace
 
-bool rank_split_usable(const RankPlan &plan, int topn) {
+bool rank_split_usable(const RankPlan &plan, int topn, RankWorkspace &ws) {
+    ws.ctx_ready = false;
     if (topn > 64 || plan.qu.empty() || plan.cand.empty() || getenv("CMI_RANK_NO_SPLIT")) return false;
-    // S2 = distinct contexts x candidates x 4 bytes must stay small (it is re-read by every query of the context)
-    std::vector<int32_t> dctx, qd;
-    distinct_contexts(plan.qc, dctx, qd);
-    return (int64_t)dctx.size() * (int64_t)plan.cand.size() * 4 <= ((int64_t)512 << 20);
+    // S2 = distinct contexts x candidates x 4 bytes must stay small (it is re-read by every query of the context); the index arrays
+    // computed for the answer are the ones rank_run_device_split uploads
+    distinct_contexts(plan.qc, ws.v_dctx, ws.v_qd);
+    ws.ctx_ready = true;
+    return (int64_t)ws.v_dctx.size() * (int64_t)plan.cand.size() * 4 <= ((int64_t)512 << 20);
 }
 
 hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const RankPlan &plan, RankSplitArgs a, double thold, int topn,
                                  const std::function<void(int64_t, int64_t)> &on_batch, float *ms, double *flops) {
     const auto t_setup = std::chrono::steady_clock::now();
+    const bool times = getenv("CMI_PLAN_TIMES") != nullptr;
+    auto tl = t_setup;
+    auto lap = [&](const char *w) {
+        if (!times) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "rank setup %s %.3f ms\n", w, std::chrono::duration<double, std::milli>(n - tl).count());
+        tl = n;
+    };
     const int nc = (int)plan.cand.size();
     const int64_t nq = (int64_t)plan.qu.size();
     // query groups = runs of one user (the plan orders the queries by user, then context)
-    std::vector<int32_t> gu, qg((size_t)nq), gq0; // group -> user; query -> group; group -> first query
-    for (int64_t q = 0; q < nq; ++q) {
-        if (q == 0 || plan.qu[(size_t)q] != plan.qu[(size_t)q - 1]) {
-            gu.push_back(plan.qu[(size_t)q]);
-            gq0.push_back((int32_t)q);
-        }
-        qg[(size_t)q] = (int32_t)gu.size() - 1;
-    }
-    gq0.push_back((int32_t)nq);
+    // (built by the plan's last phase, in ranges)
+    const std::vector<int32_t> &gu = plan.gu, &qg = plan.qg, &gq0 = plan.gq0; // group -> user; query -> group; group -> first query
     const int64_t ng = (int64_t)gu.size();
-    std::vector<int32_t> dctx, qd;
+    lap("groups");
+    std::vector<int32_t> &dctx = ws.v_dctx, &qd = ws.v_qd;
     const bool ic = a.icBias != nullptr;
     const bool s2 = ic; // the context part as a slab of its own (distinct contexts x candidates)
-    if (s2) distinct_contexts(plan.qc, dctx, qd);
+    if (s2 && !ws.ctx_ready) distinct_contexts(plan.qc, dctx, qd); // (normally left there by rank_split_usable)
+    if (!s2) {
+        dctx.clear();
+        qd.clear();
+    }
+    ws.ctx_ready = false;
     const int n_dc = (int)dctx.size();
+    lap("contexts");
     a.kp1 = (a.k + 1 + 15) / 16 * 16;
     a.kp2 = ic ? (a.n_conds + 15) / 16 * 16 : 16;
     a.nc = nc;
@@ -816,6 +848,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     for (hipEvent_t *ev : evs)
         if (e == hipSuccess && !*ev) e = hipEventCreate(ev);
     if (e != hipSuccess) return e;
+    lap("buffers");
     auto up = [&](void *d, const void *s, size_t bytes) {
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream);
     };
@@ -830,6 +863,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
         up(ws.ddc.p, dctx.data(), (size_t)n_dc * 4);
         up(ws.dqd.p, qd.data(), (size_t)nq * 4);
     }
+    lap("uploads");
     int32_t *dtop = (int32_t *)ws.dtop.p, *dcount = (int32_t *)ws.dcount.p;
     double *dscore = (double *)ws.dscore.p;
     if (e == hipSuccess) e = hipMemsetAsync(dtop, 0xff, (size_t)nq * topn * 4, stream);
@@ -847,6 +881,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     if (e == hipSuccess) e = hipEventRecord(ws.ev0, stream);
     // S2: once per evaluation (row constant = the zeroed scratch)
     if (e == hipSuccess && s2) e = rank_launch_gemm<float>(a.A2, a.B2, (const float *)ws.dscr.p, (float *)ws.dS2.p, n_dc, nc, a.kp2, stream);
+    lap("memsets + operand launches");
     ws.host_ms[1] = ms_since(t_setup);
     const auto t_loop = std::chrono::steady_clock::now();
     std::vector<std::pair<int64_t, int64_t>> batches; // all enqueued first, consumed behind the device (see rank_run_device)
@@ -1110,7 +1145,7 @@ extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *t
                                                  &h->last_rank_ms, &h->last_rank_flops);
         else if (h->f64) e = rank_run_device<double>(h->stream, ws, plan, mf_operands<double>(h, k_logical, contextual, ic_used), bin_thold,
                                                      num_recs, on_batch, &h->last_rank_ms, &h->last_rank_flops);
-        else if (rank_split_usable(plan, num_recs)) {
+        else if (rank_split_usable(plan, num_recs, ws)) {
             RankSplitArgs sa{};
             sa.P = (const float *)h->state[CMI_STATE_P];
             sa.Q = (const float *)h->state[CMI_STATE_Q];

@@ -17,6 +17,7 @@ namespace cmi {
 struct RankPlan {
     std::vector<int32_t> cand;            // candidate position -> item id (HashSet<Integer> order, minus ignored)
     std::vector<int32_t> qu, qc;          // query -> user, context
+    std::vector<int32_t> gu, qg, gq0;     // query groups = runs of one user: group -> user; query -> group; group -> first query (+ end)
     std::vector<int32_t> truth_items;     // per query: its positive test items that are candidates (sorted)
     std::vector<int64_t> truth_ptr;
     std::vector<int32_t> excl_idx;        // per query: candidate positions rated by the user in that context (training)
@@ -52,6 +53,8 @@ struct RankWorkspace {
     Buf dB2, dA2, dS2, dqg, dqd, dgu, ddc, dscr;                                // device, split form (rank_run_device_split)
     Buf h_top, h_score, h_count;                                                // pinned host: the lists as they come back
     RankPlan plan;                                                              // the last evaluation's plan (capacity is reused)
+    std::vector<int32_t> v_dctx, v_qd;                                          // split form: context index arrays (capacity is reused)
+    bool ctx_ready = false;                                                     // v_dctx / v_qd hold this evaluation's contexts (rank_split_usable)
     struct HostVals { // per-query measures, uninitialised and grow-only (38 MB for 270 K queries: not re-faulted per call)
         std::unique_ptr<double[]> p;
         size_t cap = 0;
@@ -90,7 +93,7 @@ struct RankSplitArgs;
 hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const RankPlan &plan, RankSplitArgs base, double thold, int topn,
                                  const std::function<void(int64_t, int64_t)> &on_batch, float *ms, double *flops);
 // whether the split form applies: S2 must stay small (distinct contexts x candidates) and the lists must fit the register selection
-bool rank_split_usable(const RankPlan &plan, int topn);
+bool rank_split_usable(const RankPlan &plan, int topn, RankWorkspace &ws);
 
 // the 18 measures of the lists of queries [q0, q1) -> vals[q * 18 + m] (threads over ranges of queries); optional per-query outputs
 void rank_measures_range(const RankPlan &plan, int num_recs, const int32_t *top_idx, const double *top_score, const int32_t *top_count,
