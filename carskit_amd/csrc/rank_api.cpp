@@ -342,7 +342,7 @@ void rank_build_plan(int n_users, int n_items, const RankTuples &train, const Ra
     uint64_t *tkey = S.tkey.need((size_t)toff[nu] + 1), *pkey = S.pkey.need((size_t)poff[nu] + 1);
     // per user: its queries in (context, item) order -- a query is a (user, context) with at least one correct item that is a
     // candidate (Recommender.java:789-790) -- and, per query, the candidate positions of the items the user rated in the same
-    // context in the training set (Recommender.java:793, 814-816), in item order.  One part per bucket.
+    // context in the training set (Recommender.java:793, 814-816), as ascending candidate positions.  One part per bucket.
     using Part = PlanPart;
     std::vector<Part> &parts = S.parts;
     if (parts.size() < (size_t)nbk) parts.resize((size_t)nbk);
@@ -388,14 +388,17 @@ void rank_build_plan(int n_users, int n_items, const RankTuples &train, const Ra
                     P.qc.push_back((int32_t)c);
                     P.truth_end.push_back((int64_t)P.truth_items.size());
                     const size_t ebefore = P.excl_idx.size();
-                    items.clear(); // the user's training items in this context, ascending (users hold tens of tuples: a scan per query)
+                    items.clear(); // the user's training items in this context (users hold tens of tuples: a scan per query) ...
                     for (const uint64_t *t = tb; t < te; ++t)
                         if ((uint32_t)(*t >> 32) == c) items.push_back((uint32_t)*t);
-                    std::sort(items.begin(), items.end());
+                    // ... as candidate POSITIONS in ascending order, each once: the selection walks the list beside the candidates
+                    // (with sparse item ids the candidates' HashSet order is not the order of the ids)
                     for (uint32_t j : items) {
                         const int32_t cp = cand_pos[j];
-                        if (cp >= 0 && (P.excl_idx.size() == ebefore || P.excl_idx.back() != cp)) P.excl_idx.push_back(cp);
+                        if (cp >= 0) P.excl_idx.push_back(cp);
                     }
+                    std::sort(P.excl_idx.begin() + (std::ptrdiff_t)ebefore, P.excl_idx.end());
+                    P.excl_idx.erase(std::unique(P.excl_idx.begin() + (std::ptrdiff_t)ebefore, P.excl_idx.end()), P.excl_idx.end());
                     P.excl_end.push_back((int64_t)P.excl_idx.size());
                 }
             }

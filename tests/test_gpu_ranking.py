@@ -256,3 +256,37 @@ def test_split_form_agrees_with_the_per_query_contraction(model):
     assert same >= 0.95 * len(whole[1])
     for m, v in whole[0].items():
         assert (math.isnan(v) and math.isnan(split[0][m])) or abs(split[0][m] - v) <= 0.01, m
+
+
+def test_split_form_exclusions_with_sparse_item_ids():
+    """The split form walks a query's exclusion list on the fly and needs it in ascending CANDIDATE POSITION; with sparse item ids the
+    HashSet order of the candidates is not the order of the ids.  Users that rated many items in the context of their test query, an
+    all-equal fp32 model (every score ties, so the list is the first num_recs non-excluded candidates: one missed exclusion shows): the
+    split form, the per-query form and the oracle agree on every list."""
+    rng = np.random.default_rng(21)
+    n_users, id_space, n_items = 40, 5000, 300
+    items = rng.choice(id_space, size=n_items, replace=False).astype(np.int32)
+    d = synth.generate(n_users, n_items, 2, 2, 9000, seed=8)        # 4 contexts: many training items per (user, context)
+    j = items[d.j]
+    mask = rng.random(len(j)) < 0.85
+    train = (d.u[mask], j[mask], d.ctx[mask], d.r[mask])
+    test = (d.u[~mask], j[~mask], d.ctx[~mask], d.r[~mask])
+    order = rank_oracle.java_int_hashset_order(train[1].tolist())
+    assert order != sorted(order)
+    inst = capi.Instance("CAMF_CI", 16, n_users, id_space, d.n_conds)            # fp32 state: the split form
+    inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+    inst.set_ratings(train[0], train[1], train[2], train[3], d.ctx_ptr, d.ctx_conds)
+    inst.set_states({"P": np.zeros((n_users, 16)), "Q": np.zeros((id_space, 16)), "userBias": np.zeros(n_users),
+                     "icBias": np.zeros((id_space, d.n_conds))})
+    tt = [list(zip(*(a.tolist() for a in x))) for x in (train, test)]
+    ref, ref_lists = rank_oracle.eval_rankings(lambda u, jj, c: 3.0, tt[0], tt[1], bin_thold=2.5, num_recs=10)
+    kw = dict(bin_thold=2.5, num_recs=10, with_lists=True)
+    split = inst.eval_rankings(train, test, **kw)
+    whole = _with_env({"CMI_RANK_NO_SPLIT": "1"}, lambda: inst.eval_rankings(train, test, **kw))
+    plan = capi.rank_plan(n_users, id_space, train, test, 2.5, 0)
+    assert max(len(e) for _, _, _, e in plan[1]) >= 20                            # long exclusion lists are in play
+    assert any(e != sorted(e) for _, _, _, e in plan[1]) is False                 # ascending candidate positions
+    for got in (split, whole):
+        assert set(got[1]) == set(ref_lists)
+        for key, lst in ref_lists.items():
+            assert [i for i, _ in got[1][key]] == [i for i, _ in lst], key
