@@ -139,3 +139,33 @@ def test_arena_positions_thread_every_row_through_its_tuples_in_order():
                 assert slot[int(first[r])] == (r, int(np.sum(spoke == r)))
     with pytest.raises(capi.CmiError):
         capi.arena_positions(np.array([0, 5], np.int32), 3)
+
+
+def test_arena_positions_large_form_matches_a_sorted_reference():
+    """From 2^22 tuples on, cmi_arena_positions walks backwards per BUCKET of rows (lists per (range, bucket), answers copied back per
+    range of positions) instead of once over all tuples: the same next / first arrays as a stable sort by row gives, for few and many
+    rows, with the host threads forced to 5 and left at their default."""
+    import ctypes as C
+    import os
+    from carskit_amd.capi import _p
+    L = capi.lib()
+    rng = np.random.default_rng(5)
+    for n, ns, threads in ((4_300_000, 300_000, "5"), (4_200_000 + 7, 9, None), (4_400_000, 1_500_000, "16")):
+        sp = rng.integers(0, ns, n).astype(np.int32)
+        nxt, first = np.empty(n, np.int32), np.empty(ns, np.int32)
+        if threads:
+            os.environ["CMI_HOST_THREADS"] = threads
+        try:
+            assert L.cmi_arena_positions(n, _p(sp), ns, _p(nxt), _p(first)) == 0
+        finally:
+            os.environ.pop("CMI_HOST_THREADS", None)
+        order = np.argsort(sp, kind="stable")
+        so = sp[order]
+        starts = np.r_[True, so[1:] != so[:-1]]
+        same_next = np.r_[so[1:] == so[:-1], False]
+        first_pos = order[starts]
+        want_next = np.empty(n, np.int64)
+        want_next[order] = np.where(same_next, np.r_[order[1:], 0], first_pos[np.cumsum(starts) - 1])
+        want_first = np.full(ns, -1, np.int64)
+        want_first[so[starts]] = first_pos
+        assert np.array_equal(nxt, want_next.astype(np.int32)) and np.array_equal(first, want_first.astype(np.int32)), (n, ns)
