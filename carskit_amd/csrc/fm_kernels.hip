@@ -129,7 +129,11 @@ __global__ __launch_bounds__(256) void fm_reduce_kernel(FmArgs a, int f) {
     __shared__ double2 lds[4][FM_CHUNK];
     const FmOrder &o = a.ord[FIELD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ci = blockIdx.x * 4 + wave;
+    // XCD x takes the x-th contiguous eighth of the chunks (workgroup ids are dealt round-robin to the XCDs): an XCD then stays inside one
+    // slice of the gathered table for an eighth of the launch instead of all eight XCDs sweeping every slice together (A/B on one box,
+    // two runs each: reduce launch 164.2 / 165.9 us -> 160.5 / 161.7 us, sweep 24.63 -> 24.14 ms)
+    const int per = (int)gridDim.x / 8; // (the grid is a multiple of 8 workgroups)
+    const int ci = (((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3)) * 4 + wave;
     if (ci >= o.n_chunks) return; // waves are independent: no workgroup barrier below
     const FmChunk ch = o.chunks[ci];
     const double d0 = *a.d0;
@@ -392,7 +396,7 @@ template <int FIELD, bool W0>
 static hipError_t launch_reduce(const FmArgs &a, int f, hipStream_t s) {
     const int nc = a.ord[FIELD].n_chunks;
     if (nc <= 0) return hipSuccess;
-    hipLaunchKernelGGL((fm_reduce_kernel<FIELD, W0>), dim3((nc + 3) / 4), dim3(256), 0, s, a, f);
+    hipLaunchKernelGGL((fm_reduce_kernel<FIELD, W0>), dim3(((nc + 3) / 4 + 7) / 8 * 8), dim3(256), 0, s, a, f);
     return hipGetLastError();
 }
 
