@@ -256,49 +256,88 @@ def bench_fm(args):
 def bench_group(args):
     """python bench.py --gpus N (no torchrun): one host process, one cmi_group over N GPUs (user-sharded; the library cuts the ratings,
     runs the shards' epochs concurrently and merges the item-side moves with RCCL reduce-scatter + all-gather).  Weak scaling: every
-    GPU gets the workload's tuple count over its own users; items and contexts are shared."""
+    GPU gets the workload's tuple count over its own users; items and contexts are shared (ONE context table: synth.merge_user_parts).
+    CMI_BENCH_SHARE_GPU=1 puts every shard on device 0 (the in-process exchange): the form tests/test_gpu_bench_group.py runs on a
+    one-GPU box -- a code-path check, never a measurement configuration (the line says so in config.parallelism)."""
     model, k, n_users, n_items, n_dims, cpd, n_ratings = WORKLOADS[args.workload]
     if args.k > 0:
         k = args.k
     if args.model:
         model = args.model
     W = args.gpus
-    if capi.device_count() < W:
+    share = bool(os.environ.get("CMI_BENCH_SHARE_GPU"))
+    if not share and capi.device_count() < W:
         raise SystemExit("--gpus %d: only %d device(s) visible" % (W, capi.device_count()))
-    parts = [synth.generate_fast(n_users, n_items, n_dims, cpd, n_ratings, seed=synth.DEFAULT_SEED + 1000 * r) for r in range(W)]
-    u = np.concatenate([p.u + r * n_users for r, p in enumerate(parts)]).astype(np.int32)
-    j, ctx, r_ = (np.concatenate([getattr(p, a) for p in parts]) for a in ("j", "ctx", "r"))
-    base = parts[0]
-    gm = float(r_.sum() / np.count_nonzero(r_))
+    t0 = time.perf_counter()
+    data = synth.merge_user_parts([synth.generate_fast(n_users, n_items, n_dims, cpd, n_ratings, seed=synth.DEFAULT_SEED + 1000 * r)
+                                   for r in range(W)])
+    log("group of %d: %d tuples (%d users, %d items, %d contexts in one table) generated in %.1fs"
+        % (W, data.n, data.n_users, data.n_items, data.n_ctx, time.perf_counter() - t0))
+    gm = float(data.r.sum() / np.count_nonzero(data.r))
     regs = (synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-3))
     lr = synth.java_float(0.02)
-    g = capi.Group(model, k, n_users * W, n_items, base.n_conds, W, devices=list(range(W)), flags=args.flags)
+    devices = [0] * W if share else list(range(W))
+    g = capi.Group(model, k, data.n_users, n_items, data.n_conds, W, devices=devices, flags=args.flags)
     g.set_hparams(*regs, gm)
     t0 = time.perf_counter()
-    g.set_ratings(u, j, ctx, r_, base.ctx_ptr, base.ctx_conds)
-    log("group of %d: schedules + upload in %.1fs" % (W, time.perf_counter() - t0))
-    state = synth.init_state(model, base, k, seed=synth.DEFAULT_SEED + 2, dtype=np.float32)
-    rng_u = np.random.default_rng(synth.DEFAULT_SEED + 7)
-    for name in ("P", "userBias", "ucBias"):              # user-side containers cover all W x n_users users
-        if name in state:
-            shape = (n_users * W,) + state[name].shape[1:]
-            state[name] = (rng_u.random(shape) if name == "ucBias" else 0.1 * rng_u.standard_normal(shape)).astype(np.float32)
+    g.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
+    setup_s = time.perf_counter() - t0
+    log("group of %d: schedules + upload in %.1fs" % (W, setup_s))
+    state = synth.init_state(model, data, k, seed=synth.DEFAULT_SEED + 2, dtype=np.float32)   # user-side containers cover all W x n_users users
     g.set_states(state)
+    del state
     losses = [g.train_epoch(lr) for _ in range(args.warmup)]
+    comp, exch = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses.append(g.train_epoch(lr))                 # returns after the global loss is on the host: every shard's stream is done
+        c, x = g.last_times()
+        comp.append(c)
+        exch.append(x)
     elapsed = time.perf_counter() - t0
     if not np.all(np.isfinite(losses)) or (len(losses) > 1 and losses[-1] > losses[0]):
         raise SystemExit("bench: training diverged (epoch losses %s)" % losses)
-    info = [g.shard_info(s) for s in range(W)]
-    out = {"metric": "SGD rating-updates/sec, %s k=%d" % (model, k), "value": float(len(r_)) * args.steps / elapsed, "unit": "rating-updates/s",
-           "n_gpus": W, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+    comp, exch = np.asarray(comp, dtype=np.float64), np.asarray(exch, dtype=np.float64)     # [steps, W] HIP-event ms
+    shards, bytes_epoch = [], 0.0
+    for s in range(W):
+        m = g.member(s)
+        si, info, sched = g.shard_info(s), m.schedule_info(), m.schedule_traffic()
+        bytes_epoch += sched["sector"]
+        si.update({"schedule": info["kind"], "launches_per_epoch": info["levels"], "compute_ms": float(comp[:, s].mean()),
+                   "exchange_ms": float(exch[:, s].mean()), "avg_launch_us": float(comp[:, s].mean()) * 1e3 / max(1, info["levels"]),
+                   "schedule_bytes_per_epoch": sched["sector"],
+                   "GBps": sched["sector"] / (float(comp[:, s].mean()) * 1e-3) / 1e9})
+        shards.append(si)
+    n_phys = len(set(devices))
+    compute_ms = float(comp.max(axis=1).mean())          # the slowest shard's local epoch
+    exchange_ms = float(exch.max(axis=1).mean())
+    step_ms = elapsed / args.steps * 1e3
+    peak = HBM_PEAK_GBS * n_phys
+    bpu = algorithmic_bytes(model, k, n_dims, 4)
+    rf = {"bound": "hbm", "achieved": bytes_epoch / (compute_ms * 1e-3) / 1e9, "peak": peak, "unit": "GB/s",
+          "frac": bytes_epoch / (compute_ms * 1e-3) / 1e9 / peak,
+          "bytes_model": "sum over the shards of the bytes their loaded schedule has to move per epoch (cmi_schedule_traffic) / the slowest "
+                         "shard's local epoch (HIP events on its stream) vs %d x %.0f GB/s" % (n_phys, HBM_PEAK_GBS),
+          "bytes_per_epoch": bytes_epoch, "bytes_per_update": bytes_epoch / data.n, "bytes_per_update_algorithmic": bpu,
+          "frac_algorithmic": data.n * bpu / (compute_ms * 1e-3) / 1e9 / peak,
+          # the same bytes over the WHOLE step (compute + exchange + host): what the aggregate updates/s is worth against N GPUs' HBM
+          "frac_whole_step": bytes_epoch / (step_ms * 1e-3) / 1e9 / peak,
+          "traffic": None, "kernel": "sgd_chain_level / sgd_level (per shard: config.shards[].schedule)",
+          "avg_launch_us": [sh["avg_launch_us"] for sh in shards]}
+    out = {"metric": "SGD rating-updates/sec, %s k=%d" % (model, k), "value": float(data.n) * args.steps / elapsed, "unit": "rating-updates/s",
+           "n_gpus": W, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "%s: %s k=%d, %d users x %d items per GPU, %d ratings per GPU" % (args.workload, model, k, n_users, n_items, n_ratings),
-                      "parallelism": "one process, cmi_group over %d GPUs (user-sharded; exchange: %s)" % (W, info[0]["exchange"]),
-                      "shards": info},
-           "first_loss": losses[0], "final_loss": losses[-1]}
+           "config": {"workload": "%s: %s k=%d, %d users x %d items per GPU, %d ratings per GPU, one context table of %d combinations"
+                                  % (args.workload, model, k, n_users, n_items, n_ratings, data.n_ctx),
+                      "parallelism": "one process, cmi_group over %d shards on %d physical GPU(s) (user-sharded; exchange: %s)%s"
+                                     % (W, n_phys, {"rccl": "RCCL reduce-scatter + all-gather over xGMI, ncclCommInitAll",
+                                                    "in-process": "in-process sums on shard 0's stream, no communicator",
+                                                    "none": "none"}[shards[0]["exchange"]],
+                                        " -- SHARED DEVICE: a code-path check (CMI_BENCH_SHARE_GPU), not a measurement" if share else ""),
+                      "setup_s": setup_s, "shards": shards},
+           "compute_ms": compute_ms, "exchange_ms": exchange_ms, "host_ms": max(0.0, step_ms - compute_ms - exchange_ms),
+           "exchange_bytes_per_shard": int(shards[0]["bucket_elems"]) * 4,
+           "roofline": rf, "first_loss": losses[0], "final_loss": losses[-1]}
     g.close()
     return out
 
@@ -490,8 +529,9 @@ def main():
 
     t0 = time.perf_counter()
     inst = make_instance(model, k, data, n_items, state, regs, gm, local_rank, args.flags)
+    setup_s = time.perf_counter() - t0     # cmi_create + cmi_set_ratings (schedule construction + tuple stream upload) + cmi_set_state
     info, sched = inst.schedule_info(), inst.schedule_traffic()
-    log("rank %d: schedule + upload in %.1fs: %s" % (rank, time.perf_counter() - t0, info))
+    log("rank %d: schedule + upload in %.1fs: %s" % (rank, setup_s, info))
 
     trainer = None
     if world > 1:
@@ -529,10 +569,13 @@ def main():
     if args.warmup > 0:
         info, sched = inst.schedule_info(), inst.schedule_traffic()
     t0 = time.perf_counter()
-    gpu_ms = []
+    gpu_ms, exch_ms = [], []
+    lib_comm = trainer is not None and getattr(trainer.engine, "lib_comm", False)
     for _ in range(args.steps):
         losses.append(step())
         gpu_ms.append(inst.last_epoch_ms())
+        if lib_comm:
+            exch_ms.append(inst.comm_last_exchange_ms())   # HIP events around pack .. loss all-reduce on the instance's stream
     barrier()
     elapsed = time.perf_counter() - t0
     # a diverging run is not a measurement: the loss must be finite and must not have grown over the run (one rate, no bold driver)
@@ -542,9 +585,15 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([float(data.n)], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(data.n), float(sched["sector"])], dtype=torch.float64, device="cuda")
         dist.all_reduce(tot)
-        total_tuples = float(tot.item())
+        total_tuples, total_sched_bytes = float(tot[0].item()), float(tot[1].item())
+        # the slowest rank's local epoch / exchange (HIP events on each rank's own stream), and every rank's launch time
+        tms = torch.tensor([float(np.mean(gpu_ms)), float(np.mean(exch_ms)) if exch_ms else -1.0], dtype=torch.float64, device="cuda")
+        allms = [torch.zeros_like(tms) for _ in range(world)]
+        dist.all_gather(allms, tms)
+        rank_compute_ms = [float(t[0].item()) for t in allms]
+        rank_exchange_ms = [float(t[1].item()) for t in allms]
     else:
         total_tuples = float(data.n) * args.folds
 
@@ -574,6 +623,21 @@ def main():
                        % (world, args.merge, getattr(trainer.engine, "exchange_path", "torch.distributed"))},
             "roofline": roofline(model, k, n_dims, data.n, info, sched, kern_ms, es, args.workload),
         }
+        out["config"]["setup_s"] = setup_s
+        if world > 1:
+            # N ranks: `roofline` above is rank 0's kernel against ONE GPU's peak; `roofline_aggregate` is the job -- all ranks' schedule
+            # bytes over the slowest rank's local epoch against N x 8 TB/s -- and the step splits into compute / exchange / host
+            step_ms = elapsed / args.steps * 1e3
+            cms, xms = max(rank_compute_ms), max(rank_exchange_ms)
+            out["compute_ms"], out["exchange_ms"] = cms, (xms if xms >= 0 else None)
+            out["host_ms"] = max(0.0, step_ms - cms - max(xms, 0.0))
+            out["rank_compute_ms"], out["rank_exchange_ms"] = rank_compute_ms, (rank_exchange_ms if xms >= 0 else None)
+            out["rank_avg_launch_us"] = [c * 1e3 / max(1, info["levels"]) for c in rank_compute_ms]
+            out["roofline_aggregate"] = {"bound": "hbm", "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                         "achieved": total_sched_bytes / (cms * 1e-3) / 1e9,
+                                         "frac": total_sched_bytes / (cms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+                                         "frac_whole_step": total_sched_bytes / (step_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+                                         "bytes_per_epoch_all_ranks": total_sched_bytes}
         for o in extra:
             o.close()
         if world == 1 and not args.no_calibration:

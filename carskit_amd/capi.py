@@ -80,6 +80,7 @@ SYMBOLS = [
     ("cmi_comm_init", C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     ("cmi_comm_exchange", C.c_int, [_vp, _dbl]),
     ("cmi_comm_train_epoch", C.c_int, [_vp, _dbl, _dbl, C.POINTER(_dbl)]),
+    ("cmi_comm_last_exchange_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("cmi_rank_plan", C.c_int, [C.c_int32, C.c_int32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _dbl, C.c_int,
                                 C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("cmi_rank_list_measures", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
@@ -116,6 +117,7 @@ SYMBOLS = [
     ("cmi_group_eval_ratings", C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, C.c_double, C.c_double, _vp, C.POINTER(_i64)]),
     ("cmi_group_predict_batch", C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, C.c_double, C.c_double, _vp]),
     ("cmi_group_shard_info", C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
+    ("cmi_group_last_times", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("cmi_group_member", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("cmi_exchange_pack", C.c_int, [_vp]),
     ("cmi_exchange_apply", C.c_int, [_vp, C.c_double]),
@@ -500,6 +502,13 @@ class Group:
         return {"user_lo": info[0], "user_hi": info[1], "tuples": info[2], "device": info[3],
                 "exchange": ("none", "rccl", "in-process")[info[4]], "bucket_elems": info[5]}
 
+    def last_times(self):
+        """(compute_ms, exchange_ms) per shard of the most recent epoch (HIP events on the shards' streams)."""
+        W = self.size()
+        c, x = (C.c_float * W)(), (C.c_float * W)()
+        self._chk(self.L.cmi_group_last_times(self.h, c, x))
+        return list(c), list(x)
+
     def member(self, shard):
         """The shard's instance as a borrowed capi.Instance (the group owns it: do not close)."""
         h = _vp()
@@ -687,6 +696,11 @@ class Instance:
         """unique_id: COMM_ID_BYTES bytes from comm_unique_id() on rank 0, handed to every rank by the host's rendezvous."""
         buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
         self._chk(self.L.cmi_comm_init(self.h, buf, int(rank), int(world)))
+
+    def comm_last_exchange_ms(self):
+        ms = C.c_float()
+        self._chk(self.L.cmi_comm_last_exchange_ms(self.h, C.byref(ms)))
+        return ms.value
 
     def comm_exchange(self, scale):
         self._chk(self.L.cmi_comm_exchange(self.h, float(scale)))

@@ -878,7 +878,9 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
         // the arena is built and the first training call times one epoch of each form at learning rate 0 (which leaves every parameter
         // as it is) and keeps the faster one (arena_probe below).  CMI_ARENA_PROBE=1 forces the probe at any size (tests), =0 disables it.
         const char *pe = getenv("CMI_ARENA_PROBE");
-        const bool probe = !forced && !large && (pe ? atoi(pe) != 0 : (table_bytes >= ((size_t)256 << 20) && (double)arena_bytes <= 0.3 * (double)free_b));
+        // (not under CMI_FLAG_STRICT unless asked for: the probe's rate-0 epochs turn a -0.0 parameter into +0.0, a bit-level drift the
+        // strict path promises not to have; strict instances in that range keep the table form)
+        const bool probe = !forced && !large && (pe ? atoi(pe) != 0 : (!h->strict && table_bytes >= ((size_t)256 << 20) && (double)arena_bytes <= 0.3 * (double)free_b));
         h->arena_probe = false;
         if (forced || large || probe) {
             // next_pos[p] = stream position of the next tuple of the same spoke row (its tuples sit in ascending levels, hence ascending
@@ -896,6 +898,7 @@ extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const 
                 h->table_valid = true;
                 h->arena_which = h->chain_hub_item ? CMI_STATE_P : CMI_STATE_Q;
                 h->arena_probe = probe;
+                h->arena_probe_table = pe && atoi(pe) < 0; // (CMI_ARENA_PROBE=-1: tests force the "table wins" verdict)
             } else if (!forced) { // not enough memory after all: run without
                 (void)hipGetLastError();
                 for (void **q : {(void **)&h->d_arena, (void **)&h->d_next, (void **)&h->d_first})
@@ -1293,13 +1296,15 @@ static int arena_probe(cmi_instance *h) {
         if (form == 1)
             if (int rc = cmi_sync_table_from_arena(h)) return rc; // the tables are the masters again, whichever form wins
     }
-    const bool keep = ms[1] < 0.97f * ms[0];
+    const bool keep = ms[1] < 0.97f * ms[0] && !h->arena_probe_table;
     char note[200];
     snprintf(note, sizeof note, "spoke arena probe: table %.2f ms, arena %.2f ms per epoch -> %s", ms[0], ms[1], keep ? "arena" : "table");
     h->sched_note = h->sched_note.empty() ? note : h->sched_note + "; " + note;
     if (!keep) {
-        hipGraphExecDestroy(h->graph_exec); // captured in the arena form
-        h->graph_exec = nullptr;
+        if (h->graph_exec) { // captured in the arena form (null when the epoch is not graph-captured: CMI_FLAG_NO_GRAPH, > 65536 launches)
+            hipGraphExecDestroy(h->graph_exec);
+            h->graph_exec = nullptr;
+        }
         h->arena_on = h->arena_valid = false;
         h->table_valid = true;
         for (void **q : {(void **)&h->d_arena, (void **)&h->d_next, (void **)&h->d_first})

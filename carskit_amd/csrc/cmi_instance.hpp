@@ -23,6 +23,7 @@ struct cmi_instance {
     // every spoke row with tuples sits in the slot of its FIRST tuple; the model table (state[arena_which]) is only current while
     // table_valid -- every reader of the table goes through cmi_sync_table_from_arena first
     bool arena_on = false, arena_valid = false, table_valid = true;
+    bool arena_probe_table = false;  // test hook: the probe's verdict is forced to "table"
     bool arena_probe = false;        // the first training call still has to choose between table and arena (cmi_api.cpp arena_probe)
     int arena_which = 0;             // CMI_STATE_P (hub = item) or CMI_STATE_Q (hub = user)
     void *d_arena = nullptr;
@@ -79,6 +80,8 @@ struct cmi_instance {
     int32_t *d_empty = nullptr, *d_ui_ptr = nullptr, *d_ui_items = nullptr;
     void *comm = nullptr;        // ncclComm_t of cmi_comm_init (one-process-per-GPU jobs); group_api.cpp owns the type
     int comm_rank = 0, comm_world = 0;
+    hipEvent_t evx0 = nullptr, evx1 = nullptr; // around the most recent cmi_comm_exchange (cmi_comm_last_exchange_ms)
+    bool exchange_timed = false;
     cmi::RankWorkspace rank_ws;  // cmi_eval_rankings' device / pinned buffers, reused by the next evaluation
     float last_rank_ms = 0.f;    // device time of the most recent cmi_eval_rankings scoring loop (HIP events)
     double last_rank_flops = 0.0; // 2 * queries * candidates * padded operand length of that loop

@@ -41,6 +41,8 @@ struct cmi_group {
     std::vector<int64_t> shard_n;    // tuples per shard
     std::vector<void *> bucket;
     std::vector<hipEvent_t> ev;      // per shard; ev[W] = shard 0's "sum ready"
+    std::vector<hipEvent_t> tx;      // timing: tx[2s] / tx[2s+1] on shard s's stream before its pack / after its apply
+    bool timed = false;
     int64_t x_count = 0;
     bool rccl = false;
     std::vector<ncclComm_t> comm;
@@ -126,6 +128,13 @@ static void group_free_instances(cmi_group *g) {
         hipFree(g->d_stage);
         g->d_stage = nullptr;
     }
+    for (size_t i = 0; i < g->tx.size(); ++i)
+        if (g->tx[i]) {
+            hipSetDevice(g->dev[i / 2]);
+            hipEventDestroy(g->tx[i]);
+        }
+    g->tx.clear();
+    g->timed = false;
     for (size_t i = 0; i < g->ev.size(); ++i)
         if (g->ev[i]) {
             hipSetDevice(g->dev[i + 1 == g->ev.size() ? 0 : i]);
@@ -280,6 +289,11 @@ extern "C" int cmi_group_set_ratings(cmi_group_handle g, int64_t n, const int32_
         GRP_HIP(g, hipSetDevice(g->dev[s == W ? 0 : (size_t)s]));
         GRP_HIP(g, hipEventCreateWithFlags(&g->ev[(size_t)s], hipEventDisableTiming));
     }
+    g->tx.assign((size_t)W * 2, nullptr);
+    for (int s = 0; s < 2 * W; ++s) {
+        GRP_HIP(g, hipSetDevice(g->dev[(size_t)s / 2]));
+        GRP_HIP(g, hipEventCreate(&g->tx[(size_t)s]));
+    }
     if (g->rccl) {
         g->comm.assign((size_t)W, nullptr);
         GRP_NCCL(g, ncclCommInitAll(g->comm.data(), W, g->dev.data()));
@@ -350,8 +364,10 @@ static int group_exchange(cmi_group *g) {
     std::vector<hipStream_t> st((size_t)W);
     std::vector<double *> dl((size_t)W);
     for (int s = 0; s < W; ++s) {
-        GRP_MEMBER(g, s, cmi_exchange_pack(g->inst[(size_t)s]));
         GRP_MEMBER(g, s, cmi_stream(g->inst[(size_t)s], (void **)&st[(size_t)s]));
+        GRP_HIP(g, hipSetDevice(g->dev[(size_t)s]));
+        GRP_HIP(g, hipEventRecord(g->tx[(size_t)2 * s], st[(size_t)s]));
+        GRP_MEMBER(g, s, cmi_exchange_pack(g->inst[(size_t)s]));
         GRP_MEMBER(g, s, cmi_loss_device_ptr(g->inst[(size_t)s], (void **)&dl[(size_t)s]));
     }
     if (g->rccl) {
@@ -400,7 +416,30 @@ static int group_exchange(cmi_group *g) {
         GRP_HIP(g, hipSetDevice(g->dev[0]));
         for (int s = 1; s < W; ++s) GRP_HIP(g, hipStreamWaitEvent(st[0], g->ev[(size_t)s], 0));
     }
-    for (int s = 0; s < W; ++s) GRP_MEMBER(g, s, cmi_exchange_apply(g->inst[(size_t)s], 1.0 / W));
+    for (int s = 0; s < W; ++s) {
+        GRP_MEMBER(g, s, cmi_exchange_apply(g->inst[(size_t)s], 1.0 / W));
+        GRP_HIP(g, hipSetDevice(g->dev[(size_t)s]));
+        GRP_HIP(g, hipEventRecord(g->tx[(size_t)2 * s + 1], st[(size_t)s]));
+    }
+    g->timed = true;
+    return CMI_OK;
+}
+
+// HIP-event times of the most recent epoch, per shard: the local epoch's launches (cmi_last_epoch_ms of the member) and the exchange
+// behind it (pack .. apply on the shard's stream: collectives or in-process sums, INCLUDING the wait for the slowest shard)
+extern "C" int cmi_group_last_times(cmi_group_handle g, float *compute_ms, float *exchange_ms) {
+    if (!g || !compute_ms || !exchange_ms) return CMI_E_INVALID;
+    if (int rc = need_ratings(g, "group_last_times")) return rc;
+    const int W = (int)g->inst.size();
+    for (int s = 0; s < W; ++s) {
+        GRP_MEMBER(g, s, cmi_last_epoch_ms(g->inst[(size_t)s], &compute_ms[s]));
+        exchange_ms[s] = 0.f;
+        if (W > 1 && g->timed) {
+            GRP_HIP(g, hipSetDevice(g->dev[(size_t)s]));
+            GRP_HIP(g, hipEventSynchronize(g->tx[(size_t)2 * s + 1]));
+            GRP_HIP(g, hipEventElapsedTime(&exchange_ms[s], g->tx[(size_t)2 * s], g->tx[(size_t)2 * s + 1]));
+        }
+    }
     return CMI_OK;
 }
 
@@ -580,6 +619,13 @@ extern "C" int cmi_comm_unique_id(void *id) {
 }
 
 void cmi_comm_release(cmi_instance *h) {
+    for (hipEvent_t *e : {&h->evx0, &h->evx1})
+        if (*e) {
+            (void)hipSetDevice(h->device);
+            (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
+    h->exchange_timed = false;
     if (h->comm) {
         (void)hipSetDevice(h->device);
         (void)ncclCommDestroy((ncclComm_t)h->comm);
@@ -615,6 +661,12 @@ extern "C" int cmi_comm_init(cmi_handle h, const void *id, int rank, int world) 
 extern "C" int cmi_comm_exchange(cmi_handle h, double scale) {
     if (!h) return CMI_E_INVALID;
     if (!h->comm) CMI_FAIL(h, CMI_E_INVALID, "comm_exchange: call cmi_comm_init first");
+    CMI_HIP(h, hipSetDevice(h->device));
+    if (!h->evx0) {
+        CMI_HIP(h, hipEventCreate(&h->evx0));
+        CMI_HIP(h, hipEventCreate(&h->evx1));
+    }
+    CMI_HIP(h, hipEventRecord(h->evx0, h->stream));
     if (int rc = cmi_exchange_pack(h)) return rc;
     double *dl = nullptr;
     if (int rc = cmi_loss_device_ptr(h, (void **)&dl)) return rc;
@@ -622,6 +674,18 @@ extern "C" int cmi_comm_exchange(cmi_handle h, double scale) {
         COMM_NCCL(h, exchange_collective(phase, (ncclComm_t)h->comm, h->d_xbucket, h->x_count, h->comm_world, h->comm_rank, h->f64, dl, h->stream));
     if (int rc = cmi_exchange_apply(h, scale)) return rc;
     COMM_NCCL(h, exchange_collective(2, (ncclComm_t)h->comm, h->d_xbucket, h->x_count, h->comm_world, h->comm_rank, h->f64, dl, h->stream));
+    CMI_HIP(h, hipEventRecord(h->evx1, h->stream));
+    h->exchange_timed = true;
+    return CMI_OK;
+}
+
+// HIP-event time of the most recent cmi_comm_exchange on the instance's stream (pack .. loss all-reduce; includes the wait for the slowest rank)
+extern "C" int cmi_comm_last_exchange_ms(cmi_handle h, float *ms) {
+    if (!h || !ms) return CMI_E_INVALID;
+    if (!h->exchange_timed) CMI_FAIL(h, CMI_E_INVALID, "comm_last_exchange_ms: no exchange has run");
+    CMI_HIP(h, hipSetDevice(h->device));
+    CMI_HIP(h, hipEventSynchronize(h->evx1));
+    CMI_HIP(h, hipEventElapsedTime(ms, h->evx0, h->evx1));
     return CMI_OK;
 }
 

@@ -317,3 +317,38 @@ def init_state(model, data, k, seed=DEFAULT_SEED + 2, dtype=np.float64):
     else:
         raise ValueError(model)
     return st
+
+
+def merge_user_parts(parts):
+    """One data set out of per-shard parts that each own their users: part r's users become [sum of the earlier parts' user counts, ...),
+    items keep their ids (the shared, replicated side), and the parts' CONTEXT ids -- each part numbers its context combinations in its
+    own first-seen order -- are re-mapped onto ONE table: combinations are identified by their condition lists and numbered in
+    first-seen order over the concatenated stream (what DataDAO would do with the concatenated file, DataDAO.java:281-290,330-333).
+    Tuples stay in part order, so the result is in CRS order."""
+    if not parts:
+        raise ValueError("no parts")
+    n_conds, n_dims = parts[0].n_conds, parts[0].n_dims
+    table, rows = {}, []
+    ctx_out, u_out, base = [], [], 0
+    for p in parts:
+        if p.n_conds != n_conds:
+            raise ValueError("parts disagree on the number of conditions")
+        ptr, conds = np.asarray(p.ctx_ptr, dtype=np.int64), np.asarray(p.ctx_conds, dtype=np.int32)
+        remap = np.empty(p.n_ctx, dtype=np.int32)
+        for c in range(p.n_ctx):               # the part's own ids ascend in ITS first-seen order: walking them in id order keeps that order
+            key = conds[ptr[c]:ptr[c + 1]].tobytes()
+            g = table.get(key)
+            if g is None:
+                g = table[key] = len(rows)
+                rows.append(conds[ptr[c]:ptr[c + 1]])
+            remap[c] = g
+        ctx_out.append(remap[p.ctx])
+        u_out.append(p.u.astype(np.int64) + base)
+        base += p.n_users
+    ctx_ptr = np.zeros(len(rows) + 1, dtype=np.int64)
+    ctx_ptr[1:] = np.cumsum([len(x) for x in rows])
+    cat = lambda name: np.concatenate([getattr(p, name) for p in parts])
+    return RatingData(int(base), max(p.n_items for p in parts), n_conds, n_dims, np.concatenate(u_out).astype(np.int32), cat("j"),
+                      np.concatenate(ctx_out).astype(np.int32), cat("r"), ctx_ptr.astype(np.int32),
+                      np.concatenate(rows).astype(np.int32) if rows else np.zeros(0, np.int32), parts[0].min_rate, parts[0].max_rate,
+                      {"merged_parts": len(parts), "part_users": [p.n_users for p in parts]}, parts[0].empty_conds)

@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define CMI_ABI_VERSION 3 /* 3: round 4 -- cmi_comm_*, cmi_fm_comm_*, group resident evaluation, FM layout / timing, ranking host
+#define CMI_ABI_VERSION 4 /* 4: round 5 -- ADDED cmi_group_last_times, cmi_comm_last_exchange_ms (exchange vs compute time of an epoch)
+                             3: round 4 -- cmi_comm_*, cmi_fm_comm_*, group resident evaluation, FM layout / timing, ranking host
                              clock; REMOVED: CMI_FLAG_SCHED_FLOW, CMI_FLAG_TWO_LANE, cmi_flow_schedule, cmi_split_schedule */
 
 /* status codes */
@@ -354,6 +355,11 @@ int cmi_group_predict_batch(cmi_group_handle g, int64_t n, const int32_t *u, con
 /* info[0..1] = [first, last) user of the shard, info[2] = its tuples, info[3] = its device, info[4] = exchange in use (0 none: one
  * shard, 1 RCCL, 2 in-process), info[5] = elements of the exchanged bucket */
 int cmi_group_shard_info(cmi_group_handle g, int shard, int64_t info[6]);
+/* measurement (no reference counterpart; the reference's fold threads are timed by Recommender.execute()'s wall clock,
+ * Recommender.java:284-297): HIP-event times of the most recent cmi_group_train_epoch, one float per shard -- compute_ms = the local
+ * epoch's launches, exchange_ms = pack .. apply on the shard's stream (the collectives or the in-process sums, including the wait for
+ * the slowest shard; 0 for a group of one) */
+int cmi_group_last_times(cmi_group_handle g, float *compute_ms, float *exchange_ms);
 /* the shard's instance (owned by the group), e.g. for cmi_schedule_info / cmi_last_epoch_ms */
 int cmi_group_member(cmi_group_handle g, int shard, cmi_handle *out);
 /* `--early-stop MAE|RMSE` for a sharded recommender (IterativeRecommender.java:149-161: isConverged() scores the test set after every
@@ -375,6 +381,9 @@ int cmi_comm_unique_id(void *id /* CMI_COMM_ID_BYTES */);
 int cmi_comm_init(cmi_handle h, const void *id, int rank, int world);
 int cmi_comm_exchange(cmi_handle h, double scale);
 int cmi_comm_train_epoch(cmi_handle h, double lrate, double scale, double *global_loss);
+/* HIP-event time of the most recent cmi_comm_exchange on the handle's stream (pack .. loss all-reduce, including the wait for the
+ * slowest rank); cmi_last_epoch_ms is the local epoch beside it */
+int cmi_comm_last_exchange_ms(cmi_handle h, float *ms);
 
 /* ---- FM: src/carskit/alg/cars/adaptation/dependent/FM.java (ALS / coordinate-descent sweep, not SGD) ---------
  * Separate handle type: the state is (w0, w[p], V[p x k]) with p = numUsers+numItems+numConditions

@@ -33,3 +33,7 @@ def test_bench_two_ranks_share_one_gpu(model):
     assert rec["config"]["parallelism"].startswith("user-sharded x2") and "mean merge" in rec["config"]["parallelism"]
     assert rec["config"]["final_loss"] < rec["config"]["first_loss"]            # the merged run converges
     assert "5000000 ratings per GPU" in rec["config"]["workload"]                # weak scaling: per-GPU work is fixed
+    # N > 1: the job's own roofline (all ranks' schedule bytes over the slowest rank's epoch vs N x 8 TB/s) and the step's split
+    assert rec["roofline_aggregate"]["peak"] == 16000.0 and 0 < rec["roofline_aggregate"]["frac_whole_step"] <= rec["roofline_aggregate"]["frac"]
+    assert rec["compute_ms"] > 0 and len(rec["rank_compute_ms"]) == 2 and len(rec["rank_avg_launch_us"]) == 2
+    assert rec["exchange_ms"] is None          # gloo: torch issues the collectives (the library times its own RCCL exchange only)

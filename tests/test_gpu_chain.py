@@ -296,19 +296,20 @@ def test_spoke_arena_honours_host_writes_through_the_device_pointer(hub, name):
         assert np.array_equal(x, b.get_state(n_)), n_
 
 
-@pytest.mark.parametrize("hub", ["item", "user"])
-def test_arena_probe_times_both_forms_at_rate_zero_and_leaves_the_model_alone(hub):
+@pytest.mark.parametrize("hub,extra,probe", [("item", 0, "1"), ("user", 0, "1"), ("item", capi.FLAG_NO_GRAPH, "-1"), ("item", 0, "-1")])
+def test_arena_probe_times_both_forms_at_rate_zero_and_leaves_the_model_alone(hub, extra, probe):
     """Spoke tables of 256 MiB .. 2 GiB (BASELINE C5's share): table or arena is the BOX's choice, so the first training call times
     one epoch of each form at learning rate 0 -- x + 0 * (...) = x: nothing moves -- and keeps the faster (forced on this small set
     with CMI_ARENA_PROBE=1).  Whatever it picks, the model equals the table-resident run bit for bit, epoch by epoch, and the
-    schedule note says what was measured."""
+    schedule note says what was measured.  probe "-1" forces the "table wins" verdict; with FLAG_NO_GRAPH there is then no captured graph
+    to drop (the unguarded hipGraphExecDestroy(nullptr) left a sticky error for the first real epoch)."""
     import os
     model, k = "CAMF_CU", 64
     data = util.small_data(n_users=900, n_items=220, n_dims=3, conds_per_dim=3, n=16000, seed=53)
-    _, ref = _with_hub(hub, lambda: make_pair(model, data, k, CHAIN | capi.FLAG_NO_ARENA))
-    os.environ["CMI_ARENA_PROBE"] = "1"
+    _, ref = _with_hub(hub, lambda: make_pair(model, data, k, CHAIN | capi.FLAG_NO_ARENA | extra))
+    os.environ["CMI_ARENA_PROBE"] = probe
     try:
-        _, prb = _with_hub(hub, lambda: make_pair(model, data, k, CHAIN))
+        _, prb = _with_hub(hub, lambda: make_pair(model, data, k, CHAIN | extra))
     finally:
         del os.environ["CMI_ARENA_PROBE"]
     assert prb.schedule_traffic()["spoke_arena"]                 # built, choice pending
@@ -319,6 +320,7 @@ def test_arena_probe_times_both_forms_at_rate_zero_and_leaves_the_model_alone(hu
             note = prb.schedule_note()
             assert "spoke arena probe: table " in note and (note.endswith("-> arena") or note.endswith("-> table"))
             assert prb.schedule_traffic()["spoke_arena"] == note.endswith("-> arena")
+            assert probe != "-1" or note.endswith("-> table")
     for name, a in ref.get_states().items():
         assert np.array_equal(a, prb.get_state(name)), name
     assert any(not np.array_equal(before[n], prb.get_state(n)) for n in before)     # (and it did train)
