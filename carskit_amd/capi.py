@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMI_LIB_PATH") or os.path.join(_HERE, "lib", "libcarskit_mi355x.so")   # CMI_LIB_PATH: experiments with variant builds
 
-OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NUMERIC, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NUMERIC, E_UNSUPPORTED, E_HOST = 0, -1, -2, -3, -4, -5, -6
 
 MODEL_IDS = {"BiasedMF": 0, "CAMF_C": 1, "CAMF_CI": 2, "CAMF_CU": 3, "CAMF_CUCI": 4, "PMF": 5,
              "SVD++": 6, "CAMF_ICS": 7, "CAMF_LCS": 8, "CAMF_MCS": 9}

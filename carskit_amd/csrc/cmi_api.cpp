@@ -544,9 +544,27 @@ static bool try_chain(cmi_instance *h, int64_t n, const int32_t *u, const int32_
     return true;
 }
 
+static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r, int32_t n_ctx,
+                            const int32_t *ctx_ptr, const int32_t *ctx_conds);
+
+// the exception barrier of the boundary: the schedule construction allocates O(tuples) host memory on the host pool's threads
+// (host_pool.hpp hands a range body's exception to the caller); nothing C++ may cross into a C / JNI / ctypes host
 extern "C" int cmi_set_ratings(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                                const double *r, int32_t n_ctx, const int32_t *ctx_ptr, const int32_t *ctx_conds) {
     if (!h) return CMI_E_INVALID;
+    try {
+        return set_ratings_impl(h, n, u, j, ctx, r, n_ctx, ctx_ptr, ctx_conds);
+    } catch (const std::exception &e) {
+        h->have_ratings = false;
+        CMI_FAIL(h, CMI_E_HOST, "set_ratings: host-side failure: %s", e.what());
+    } catch (...) {
+        h->have_ratings = false;
+        CMI_FAIL(h, CMI_E_HOST, "set_ratings: host-side failure (unknown exception)");
+    }
+}
+
+static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r, int32_t n_ctx,
+                            const int32_t *ctx_ptr, const int32_t *ctx_conds) {
     const bool contextual = !is_2d_model(h->model);
     if (n < 0 || (n > 0 && (!u || !j || !r))) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: null tuple arrays");
     if (is_ext_model(h->model) && h->model != CMI_MODEL_SVDPP && (h->empty_conds.empty() || (h->model == CMI_MODEL_CAMF_LCS && h->num_f < 1)))

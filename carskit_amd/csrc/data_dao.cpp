@@ -467,7 +467,21 @@ extern "C" int cmi_dao_destroy(cmi_dao_handle h) {
     return CMI_OK;
 }
 
-static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *out) {
+static int dao_read_body(const char *path, const cmi_dao *base, cmi_dao_handle *out);
+static int dao_read_impl(const char *path, const cmi_dao *base, cmi_dao_handle *out) { // exception barrier (ranged reader on the host pool)
+    try {
+        return dao_read_body(path, base, out);
+    } catch (const std::exception &e) {
+        if (out) *out = nullptr;
+        g_dao_err = std::string("cmi_dao_read: host-side failure: ") + e.what();
+        return CMI_E_HOST;
+    } catch (...) {
+        if (out) *out = nullptr;
+        g_dao_err = "cmi_dao_read: host-side failure (unknown exception)";
+        return CMI_E_HOST;
+    }
+}
+static int dao_read_body(const char *path, const cmi_dao *base, cmi_dao_handle *out) {
     if (out) *out = nullptr;
     if (!path || !out) {
         g_dao_err = "cmi_dao_read: null argument";

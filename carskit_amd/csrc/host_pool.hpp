@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <system_error>
@@ -65,11 +66,26 @@ class HostPool {
             ++gen_;
         }
         cv_.notify_all();
-        fn(0);
-        for (int id = have + 1; id < nt; ++id) fn(id); // the ranges no worker exists for
-        std::unique_lock<std::mutex> g(mu_);
-        done_.wait(g, [&] { return left_ == 0; });
-        fn_ = nullptr;
+        // A throwing body (std::bad_alloc of a range's vectors) must not unwind this frame while workers still hold `fn`: the caller's
+        // own ranges are caught, the workers are ALWAYS waited for, and the first exception of the job -- the caller's or a worker's,
+        // recorded in work() -- is rethrown to the caller once nobody references `fn` any more.
+        std::exception_ptr mine;
+        try {
+            fn(0);
+            for (int id = have + 1; id < nt; ++id) fn(id); // the ranges no worker exists for
+        } catch (...) {
+            mine = std::current_exception();
+        }
+        std::exception_ptr theirs;
+        {
+            std::unique_lock<std::mutex> g(mu_);
+            done_.wait(g, [&] { return left_ == 0; });
+            fn_ = nullptr;
+            theirs = err_;
+            err_ = nullptr;
+        }
+        if (mine) std::rethrow_exception(mine);
+        if (theirs) std::rethrow_exception(theirs);
         return true;
     }
 
@@ -89,15 +105,22 @@ class HostPool {
                 fn = fn_;
             }
             in_job() = true;
-            (*fn)(id);
+            std::exception_ptr e;
+            try {
+                (*fn)(id);
+            } catch (...) { // never std::terminate the host process from a detached worker: hand the exception to the job's caller
+                e = std::current_exception();
+            }
             in_job() = false;
             std::lock_guard<std::mutex> g(mu_);
+            if (e && !err_) err_ = e;
             if (--left_ == 0) done_.notify_one();
         }
     }
     std::mutex job_mu_, mu_;
     std::condition_variable cv_, done_;
     const std::function<void(int)> *fn_ = nullptr;
+    std::exception_ptr err_; // first exception a worker's range threw in the current job
     int workers_ = 0, want_ = 0, left_ = 0;
     uint64_t gen_ = 0;
     pid_t pid_ = getpid();
@@ -116,14 +139,25 @@ inline void parallel_ranges(int64_t n, int nt, F &&body) { // body(range index, 
     };
     if (HostPool::get().try_run(nt, one)) return;
     std::vector<std::thread> th;
+    std::mutex emu;
+    std::exception_ptr first;
+    auto guarded = [&](int t) {
+        try {
+            one(t);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(emu);
+            if (!first) first = std::current_exception();
+        }
+    };
     int started = 1;
     try {
-        for (; started < nt; ++started) th.emplace_back([&one, started]() { one(started); });
+        for (; started < nt; ++started) th.emplace_back([&guarded, started]() { guarded(started); });
     } catch (const std::system_error &) { // no more threads: the caller takes the rest
     }
-    one(0);
-    for (int t = started; t < nt; ++t) one(t);
+    guarded(0);
+    for (int t = started; t < nt; ++t) guarded(t);
     for (std::thread &x : th) x.join();
+    if (first) std::rethrow_exception(first);
 }
 
 } // namespace cmi

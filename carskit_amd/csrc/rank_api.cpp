@@ -1064,7 +1064,30 @@ extern "C" int cmi_java_int_hashset_order(int64_t n, const int32_t *values, int3
     return CMI_OK;
 }
 
+static int eval_rankings_impl(cmi_handle h, int64_t n_train, const int32_t *tu, const int32_t *tj,
+                                 const int32_t *tctx, const double *tr, int64_t n_test, const int32_t *su,
+                                 const int32_t *sj, const int32_t *sctx, const double *sr, double bin_thold,
+                                 int num_recs, int num_ignore, int strategy, double out[CMI_RANK_MEASURES],
+                                 int64_t *n_queries, int32_t *q_user, int32_t *q_ctx, int32_t *q_count,
+                                 int32_t *top_items, double *top_scores);
 extern "C" int cmi_eval_rankings(cmi_handle h, int64_t n_train, const int32_t *tu, const int32_t *tj,
+                                 const int32_t *tctx, const double *tr, int64_t n_test, const int32_t *su,
+                                 const int32_t *sj, const int32_t *sctx, const double *sr, double bin_thold,
+                                 int num_recs, int num_ignore, int strategy, double out[CMI_RANK_MEASURES],
+                                 int64_t *n_queries, int32_t *q_user, int32_t *q_ctx, int32_t *q_count,
+                                 int32_t *top_items, double *top_scores) {
+    if (!h) return CMI_E_INVALID;
+    try { // exception barrier: the plan and the measures allocate per-range vectors on the host pool
+        return eval_rankings_impl(h, n_train, tu, tj, tctx, tr, n_test, su, sj, sctx, sr, bin_thold, num_recs, num_ignore, strategy, out, n_queries,
+                                  q_user, q_ctx, q_count, top_items, top_scores);
+    } catch (const std::exception &e) {
+        CMI_FAIL(h, CMI_E_HOST, "eval_rankings: host-side failure: %s", e.what());
+    } catch (...) {
+        CMI_FAIL(h, CMI_E_HOST, "eval_rankings: host-side failure (unknown exception)");
+    }
+}
+
+static int eval_rankings_impl(cmi_handle h, int64_t n_train, const int32_t *tu, const int32_t *tj,
                                  const int32_t *tctx, const double *tr, int64_t n_test, const int32_t *su,
                                  const int32_t *sj, const int32_t *sctx, const double *sr, double bin_thold,
                                  int num_recs, int num_ignore, int strategy, double out[CMI_RANK_MEASURES],

@@ -66,20 +66,24 @@ class GpuEngine:
                 idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
             if dist.get_world_size(group) > 1:
                 dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            # every rank reaches this point together (ncclCommInitRank is a collective).  If the library's communicator cannot be
-            # created on some rank, ALL ranks fall back to the torch-issued form of the same exchange (agreed through an all-reduce) --
-            # said loudly on stderr and recorded in `exchange_path`, never silently.
+            # ncclCommInitRank is itself a collective: a rank that failed BEFORE it would leave the others blocked inside it.  So the
+            # part that can fail locally (cmi_exchange_setup: model not shardable, no memory for bucket + snapshot) runs first and the
+            # ranks vote on it (a cheap all-reduce); only if every rank is ready do ALL of them create the library's communicator,
+            # otherwise ALL use the torch-issued form of the same exchange -- said loudly on stderr and recorded in `exchange_path`.
             ok = torch.ones(1, device=self.device)
             try:
-                inst.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, dist.get_world_size(group))   # also snapshots the item-side state
+                inst.exchange_setup(pad_to=max(1, world))
             except Exception as e:   # noqa: BLE001
                 import sys
-                print("carskit_amd.dist: cmi_comm_init failed on rank %d (%s); falling back to torch.distributed collectives" % (rank, e),
+                print("carskit_amd.dist: cmi_exchange_setup failed on rank %d (%s); all ranks use torch.distributed collectives" % (rank, e),
                       file=sys.stderr, flush=True)
                 ok.zero_()
             if dist.get_world_size(group) > 1:
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
             if float(ok.item()) > 0:
+                # (a failure inside ncclCommInitRank itself is fatal for the job: RCCL's own timeout / abort ends it, there is no
+                # fallback a single rank could take without the others)
+                inst.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, dist.get_world_size(group))   # also snapshots the item-side state
                 self.lib_comm = True
                 self.exchange_path = "library (cmi_comm_*: RCCL reduce-scatter + all-gather issued by libcarskit_mi355x)"
                 return

@@ -38,6 +38,8 @@ extern "C" {
 #define CMI_E_HIP (-3)        /* a HIP runtime call failed */
 #define CMI_E_NUMERIC (-4)    /* loss became NaN/Inf (IterativeRecommender.java:181-184) */
 #define CMI_E_UNSUPPORTED (-5)
+#define CMI_E_HOST (-6)       /* a C++ exception (std::bad_alloc ...) reached the boundary: caught there, never thrown at the host;
+                                 the JNI shim turns it into a RuntimeException like every other status (Recommender.java:1162-1171) */
 
 /* recommender kinds = the `recommender=` names the reference's factory switch maps to the classes
  * this library accelerates (src/carskit/main/CARSKit.java:461,700-707) */
