@@ -864,7 +864,7 @@ class FMInstance:
         out = np.zeros(12, np.int64)
         self._chk(self.L.cmi_fm_layout(self.h, _p(out)))
         keys = ("slices_user_order", "slices_item_order", "records_user_order", "records_item_order", "records_ctx_order",
-                "chunks_user_order", "chunks_item_order", "bytes_per_factor", "bytes_reduce_user", "bytes_reduce_item",
+                "batches_user_order", "batches_item_order", "bytes_per_factor", "bytes_reduce_user", "bytes_reduce_item",
                 "slice_entries", "p")
         return dict(zip(keys, out.tolist()))
 

@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,6 +32,17 @@ struct FmOrderDev {
     int64_t n_rec = 0;
 };
 
+// fields 0 / 1: the cell stream on the device (fm_kernels.hpp FmCells)
+struct FmCellsDev {
+    double *err0 = nullptr, *partial3 = nullptr, *w0part = nullptr;
+    uint32_t *pk = nullptr;
+    int32_t *fo = nullptr, *fcx = nullptr, *flag0 = nullptr, *bat_off = nullptr, *slot_off = nullptr, *slot_coord = nullptr, *cplx = nullptr;
+    FmBatch *bat = nullptr;
+    uint16_t *poff = nullptr;
+    int32_t n_blocks = 0, n_slots = 0, n_cplx = 0, count = 0, S = 1, H = 1, n_batches = 0, n_flagged = 0;
+    int64_t n_rec = 0, poff_len = 0, slice_len = 0;
+};
+
 struct cmi_fm_instance {
     int k = 0, n_users = 0, n_items = 0, n_conds = 0, n_ctx_dims = 1, device = 0;
     int64_t p = 0, n = 0, global_size = 0;
@@ -38,16 +50,21 @@ struct cmi_fm_instance {
     hipStream_t stream = nullptr;
     double *d_w0 = nullptr, *d_d0 = nullptr, *d_w = nullptr, *d_V = nullptr, *d_Vt = nullptr;
     bool v_valid = true, vt_valid = false; // which of V (p x k) / Vt (k x p) holds the current factors
-    double *d_r = nullptr, *d_part = nullptr, *d_scratch = nullptr;
+    double *d_r = nullptr, *d_part = nullptr, *d_scratch = nullptr, *d_E = nullptr;
     double2 *d_tab = nullptr;
-    int32_t *d_u = nullptr, *d_j = nullptr, *d_ctx = nullptr, *d_i2u = nullptr, *d_c2u = nullptr;
-    FmOrderDev ord[3];
+    int32_t *d_u = nullptr, *d_j = nullptr, *d_ctx = nullptr, *d_src[3] = {nullptr, nullptr, nullptr};
+    FmOrderDev ord[3];   // [2] only: the context field keeps the per-wave chunk stream
+    FmCellsDev cell[2];  // users, items
+    int h_split = 0; // CMI_FM_HSPLIT: id-range parts per group (0 = chosen from the geometry)
+    int batch_cap = FMC_RCAP, slot_cap = FMC_SLOTS; // experiment / test knobs (CMI_FM_BATCH, CMI_FM_SLOTS): smaller batches and blocks on small data
     RankWorkspace rank_ws; // cmi_fm_eval_rankings' buffers, reused by the next evaluation
     ncclComm_t comm = nullptr; // cmi_fm_comm_init: ratings sharded by user over one process per GPU
     int comm_world = 0;
     int col_f = -1; // factor whose column is loaded in d_tab[].x
     int64_t part_count = 0;
-    int64_t slice_entries = 131072; // table entries (16 bytes each) a slice of the other field may gather: 2 MB stays L2-resident (measured best of 16 K .. 256 K)
+    // experiment / test knob (CMI_FM_SLICE): an upper bound on the table entries of a slice of the gathered field; 0 = the geometry's own
+    // choice (cells that fill a batch: fm_build_cells)
+    int64_t slice_entries = 0;
     double regLw = 0, regLf = 0;
     bool have_ratings = false, have_model = false, initialised = false;
     int last_phase = -1;
@@ -71,11 +88,17 @@ static thread_local std::string g_fm_create_err;
 extern "C" const char *cmi_fm_last_error(cmi_fm_handle h) { return h ? h->err.c_str() : g_fm_create_err.c_str(); }
 
 static void fm_free_ratings(cmi_fm_instance *h) {
-    void *ptrs[] = {h->d_r, h->d_u, h->d_j, h->d_ctx, h->d_i2u, h->d_c2u};
+    void *ptrs[] = {h->d_r, h->d_u, h->d_j, h->d_ctx, h->d_src[0], h->d_src[1], h->d_src[2], h->d_E};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    h->d_r = nullptr;
-    h->d_u = h->d_j = h->d_ctx = h->d_i2u = h->d_c2u = nullptr;
+    h->d_r = h->d_E = nullptr;
+    h->d_u = h->d_j = h->d_ctx = h->d_src[0] = h->d_src[1] = h->d_src[2] = nullptr;
+    for (FmCellsDev &c : h->cell) {
+        void *q[] = {c.err0, c.partial3, c.w0part, c.pk, c.fo, c.fcx, c.flag0, c.bat_off, c.slot_off, c.slot_coord, c.cplx, c.bat, c.poff};
+        for (void *p : q)
+            if (p) (void)hipFree(p);
+        c = FmCellsDev();
+    }
     for (FmOrderDev &o : h->ord) {
         void *q[] = {o.rec, o.piece_off, o.xoff, o.chunks, o.partial};
         for (void *p : q)
@@ -121,6 +144,9 @@ extern "C" int cmi_fm_create(int k, int n_users, int n_items, int n_conds, int n
     }
     cmi_fm_instance *h = new cmi_fm_instance();
     if (const char *v = getenv("CMI_FM_SLICE")) h->slice_entries = atoll(v); // experiment knob: 0 = one slice
+    if (const char *v = getenv("CMI_FM_BATCH")) h->batch_cap = std::max(1, std::min(atoi(v), FMC_RCAP));
+    if (const char *v = getenv("CMI_FM_SLOTS")) h->slot_cap = std::max((FMC_RCAP + FMC_RUN - 1) / FMC_RUN, std::min(atoi(v), FMC_SLOTS));
+    if (const char *v = getenv("CMI_FM_HSPLIT")) h->h_split = std::max(0, std::min(atoi(v), 8));
     h->k = k;
     h->n_users = n_users;
     h->n_items = n_items;
@@ -274,6 +300,298 @@ static void fm_build_order(int64_t n, const int32_t *key, const int32_t *other, 
         if (c.n < 0) c.n = -(cur[(size_t)(c.piece0 % count)]++) - 1;
 }
 
+// ---- the cell stream of fields 0 / 1 (fm_kernels.hpp FmCells), built once per cmi_fm_set_ratings -----------------------------------
+struct FmCellsHost {
+    std::vector<uint32_t> pk;
+    std::vector<int32_t> fo, fcx, flag0, src, bat_off, slot_off, slot_coord, cplx;
+    std::vector<FmBatch> bat;
+    std::vector<uint16_t> poff;
+    int n_blocks = 0, S = 1, H = 1, count = 0, n_flagged = 0;
+    int64_t slice_len = 0;
+};
+
+// key[t]: this field's coordinate of rating t; other[t]: the id whose table entries the stream gathers (table entry other_base +
+// other[t]); ctx[t]: the rating's context-combination id (a context feature exists iff ctx[t] < n_conds).
+//
+// Geometry.  GROUPS of consecutive coordinates with about the same number of records each and at most slot_cap accumulator slots (the
+// slots live in the registers of the workgroup that walks the group).  How many lanes of a wave instruction share a line of the
+// gathered table depends on the GROUP alone: a group holding n_G records puts 8 n_G / other_count of them on every 128-byte line, however
+// the table is sliced -- so groups are as large as the slots allow, and when that leaves fewer groups than the chip has CUs, every
+// group is walked by H workgroups, each taking the h-th part of every slice's id range (H id-range parts: more workgroups, the same
+// sharing; the parts' sums meet in fm_cplx_kernel).  A BLOCK = (group, part) = one workgroup; it walks sub-slices h, h + H, h + 2H, ...
+// of the gathered field; the records of (block, sub-slice) are a CELL, cut into batches of <= batch_cap records in gathered-id order
+// (records with a context feature last).
+static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, const int32_t *ctx, int count, int other_count, int other_base,
+                           int n_conds, int64_t slice_entries, int batch_cap, int slot_cap, int h_split, FmCellsHost &o) {
+    o.count = count;
+    const int max_vs = (batch_cap + FMC_RUN - 1) / FMC_RUN; // slots the longest possible run inside one batch needs
+    std::vector<int32_t> deg((size_t)count, 0), vs((size_t)count, 1);
+    for (int64_t t = 0; t < n; ++t) deg[(size_t)key[t]]++;
+    // groups: first a bound on the slots (one per coordinate, more for coordinates hot enough to have runs > FMC_RUN inside a batch --
+    // refined below once the sub-slices are known; a coordinate's records spread evenly over sub-slices only if the gathered ids do)
+    int64_t ng_min = std::max<int64_t>(1, (int64_t)std::ceil((double)count / (0.97 * (double)slot_cap)));
+    int64_t H = 1, NG = ng_min;
+    if (h_split > 0) H = h_split;
+    else if (ng_min < 256) {
+        while (H < 8 && ng_min * H * 2 <= 256 && n / (ng_min * H * 2) >= 2048) H *= 2; // fill the CUs, but keep blocks worth a launch
+    }
+    if (NG * H > 256) NG = (NG * H + 255) / 256 * 256 / H; // whole waves of 256 workgroups
+    else if (NG * H < 256 && h_split <= 0) NG = std::max<int64_t>(NG, std::min<int64_t>(256 / H, n / (2048 * H))); // small inputs: spread, blocks >= 2048 records
+    NG = std::max<int64_t>(1, std::min<int64_t>(NG, count));
+    const int64_t target = std::max<int64_t>(1, (n + NG - 1) / NG); // records per group
+    // sub-slices: a cell should fill a batch: n / (NG * H * S) <= 0.93 * batch_cap; 17 bits of id per sub-slice at most
+    int64_t S = std::max<int64_t>(1, (int64_t)std::ceil((double)n / ((double)NG * (double)H * 0.93 * (double)batch_cap)));
+    if (slice_entries > 0) S = std::max<int64_t>(S, ((int64_t)other_count + slice_entries * H - 1) / (slice_entries * H)); // experiment knob: force smaller slices
+    int64_t SS = S * H;
+    while (((int64_t)other_count + SS - 1) / SS > 131072) SS += H;
+    S = SS / H;
+    const int64_t sub_len = std::max<int64_t>(1, ((int64_t)other_count + SS - 1) / SS);
+    o.S = (int)S;
+    o.H = (int)H;
+    o.slice_len = sub_len;
+    {   // slots per coordinate from its hottest cell (a run inside a batch is at most the cell's count)
+        // (ratings with a context feature sit in one extra cell per block: counted per (coordinate, id-range part) in columns SS .. SS + H)
+        const int64_t W = SS + H;
+        std::vector<int32_t> cs((size_t)count * (size_t)W, 0);
+        for (int64_t t = 0; t < n; ++t) {
+            const int64_t ss = other[t] / sub_len;
+            cs[(size_t)key[t] * (size_t)W + (size_t)(ctx[t] < n_conds ? SS + ss % H : ss)]++;
+        }
+        parallel_ranges(count, host_threads(count), [&](int, int64_t b, int64_t e) {
+            for (int64_t l = b; l < e; ++l) {
+                int32_t m = 0;
+                for (int64_t s = 0; s < W; ++s) m = std::max(m, cs[(size_t)l * (size_t)W + (size_t)s]);
+                vs[(size_t)l] = std::max(1, std::min(max_vs, (m + FMC_RUN - 1) / FMC_RUN));
+            }
+        });
+    }
+    // a coordinate with more records than a group's target is cut by record rank into parts, each a group of its own
+    std::vector<int32_t> grp_of((size_t)count, 0), loc((size_t)count, 0); // first group of a coordinate, its first slot inside the group
+    std::vector<int32_t> grp_slots;
+    {
+        // a regular coordinate's group = where the running record count BEFORE it falls among NG equal shares: never more than NG groups
+        // (one more would be a second wave of workgroups for one or two blocks) unless a group's slots overflow (then it is cut in two)
+        // (the share weighs a coordinate by its records AND its slots, half each: ids are numbered in first-seen order, so late
+        // coordinates have fewer records, and shares of records alone overflow the slots of the late groups)
+        double n_reg = 0, s_reg = 0;
+        for (int l = 0; l < count; ++l)
+            if (!(deg[(size_t)l] > target && deg[(size_t)l] > 2 * (int64_t)batch_cap)) {
+                n_reg += (double)deg[(size_t)l];
+                s_reg += (double)vs[(size_t)l];
+            }
+        // the mix: as much weight on the records as keeps every share's slots within slot_cap (all weight on the slots always does)
+        double alpha = 0.5;
+        for (; alpha < 0.999; alpha += 0.1) {
+            double c2 = 0;
+            int64_t sh2 = 0, sl = 0, worst = 0;
+            for (int l = 0; l < count; ++l) {
+                if (deg[(size_t)l] > target && deg[(size_t)l] > 2 * (int64_t)batch_cap) continue;
+                const int64_t sh = std::min<int64_t>(NG - 1, (int64_t)(c2 * (double)NG));
+                if (sh != sh2) {
+                    worst = std::max(worst, sl);
+                    sl = 0;
+                    sh2 = sh;
+                }
+                sl += vs[(size_t)l];
+                c2 += (1.0 - alpha) * (n_reg > 0 ? (double)deg[(size_t)l] / n_reg : 0.0) + alpha * (double)vs[(size_t)l] / s_reg;
+            }
+            if (std::max(worst, sl) <= slot_cap) break;
+        }
+        alpha = std::min(alpha, 1.0);
+        double cum = 0;
+        int64_t share = -1;
+        int32_t slots = 0;
+        auto close = [&]() {
+            grp_slots.push_back(slots);
+            slots = 0;
+        };
+        for (int l = 0; l < count; ++l) {
+            const int64_t d = deg[(size_t)l];
+            if (d > target && d > 2 * (int64_t)batch_cap) { // giant: groups of its own
+                if (slots > 0) close();
+                grp_of[(size_t)l] = (int32_t)grp_slots.size();
+                loc[(size_t)l] = 0;
+                for (int64_t q = 0; q < (d + target - 1) / target; ++q) {
+                    slots = vs[(size_t)l];
+                    close();
+                }
+                continue;
+            }
+            const int64_t sh = std::min<int64_t>(NG - 1, (int64_t)(cum * (double)NG));
+            if (slots > 0 && (sh != share || slots + vs[(size_t)l] > slot_cap)) close();
+            share = sh;
+            grp_of[(size_t)l] = (int32_t)grp_slots.size();
+            loc[(size_t)l] = slots;
+            slots += vs[(size_t)l];
+            cum += (1.0 - alpha) * (n_reg > 0 ? (double)d / n_reg : 0.0) + alpha * (double)vs[(size_t)l] / s_reg;
+        }
+        if (slots > 0 || grp_slots.empty()) close();
+    }
+    auto giant = [&](int32_t l) { return deg[(size_t)l] > target && deg[(size_t)l] > 2 * (int64_t)batch_cap; };
+    const int64_t G = (int64_t)grp_slots.size(), NB = G * H; // block = group * H + part
+    o.n_blocks = (int)NB;
+    o.slot_off.assign((size_t)NB + 1, 0);
+    for (int64_t b = 0; b < NB; ++b) o.slot_off[(size_t)b + 1] = o.slot_off[(size_t)b] + grp_slots[(size_t)(b / H)];
+    o.slot_coord.assign((size_t)o.slot_off[(size_t)NB], 0);
+    for (int l = 0; l < count; ++l) {
+        const int64_t parts = giant(l) ? (deg[(size_t)l] + target - 1) / target : 1;
+        const int32_t v = vs[(size_t)l];
+        const bool cplx = parts * H * v > 1;
+        const int32_t first = o.slot_off[(size_t)((int64_t)grp_of[(size_t)l] * H)] + loc[(size_t)l];
+        const int32_t stride = grp_slots[(size_t)grp_of[(size_t)l]]; // (a giant's groups hold only its v slots: stride = v)
+        for (int64_t q = 0; q < parts * H; ++q)
+            for (int32_t x = 0; x < v; ++x) o.slot_coord[(size_t)(first + q * stride + x)] = l | (cplx ? (int32_t)0x80000000 : 0);
+        if (cplx) {
+            o.cplx.push_back(l);
+            o.cplx.push_back(first);
+            o.cplx.push_back((int32_t)(parts * H) | (v << 16));
+            o.cplx.push_back(stride);
+        }
+    }
+    // every record's cell = (block, sub-slice index inside the block's walk), ratings with a context feature in an extra cell at the
+    // block's end (index S); counting sort by cell, then gathered id inside the cell, stable in the caller's order
+    const int64_t S1 = S + 1, NC = NB * S1;
+    std::vector<int64_t> cell_off((size_t)NC + 1, 0);
+    std::vector<int32_t> rcell((size_t)n);
+    {
+        std::vector<int32_t> rank((size_t)count, 0);
+        for (int64_t t = 0; t < n; ++t) {
+            const int32_t l = key[t];
+            int64_t g = grp_of[(size_t)l];
+            if (giant(l)) g += rank[(size_t)l]++ / target;
+            const int64_t ss = other[t] / sub_len; // sub-slice: part ss % H, step ss / H of that part's walk
+            const int64_t cell = (g * H + ss % H) * S1 + (ctx[t] < n_conds ? S : ss / H);
+            rcell[(size_t)t] = (int32_t)cell;
+            cell_off[(size_t)cell + 1]++;
+        }
+    }
+    for (int64_t c = 0; c < NC; ++c) cell_off[(size_t)c + 1] += cell_off[(size_t)c];
+    o.src.resize((size_t)n);
+    {
+        std::vector<int64_t> cur(cell_off.begin(), cell_off.end() - 1);
+        for (int64_t t = 0; t < n; ++t) o.src[(size_t)cur[(size_t)rcell[(size_t)t]]++] = (int32_t)t;
+    }
+    std::vector<int32_t>().swap(rcell);
+    parallel_ranges(NC, host_threads(NC * 64), [&](int, int64_t cb, int64_t ce) {
+        for (int64_t c = cb; c < ce; ++c)
+            std::sort(o.src.begin() + cell_off[(size_t)c], o.src.begin() + cell_off[(size_t)c + 1],
+                      [&](int32_t x, int32_t y) { return other[x] != other[y] ? other[x] < other[y] : x < y; });
+    });
+    // batches (cells cut into <= batch_cap records), their slot boundaries and every record's parked position
+    o.bat_off.assign((size_t)NB + 1, 0);
+    std::vector<int64_t> bat_first((size_t)NB + 1, 0), poff_first((size_t)NB + 1, 0);
+    for (int64_t b = 0; b < NB; ++b) {
+        int64_t nbat = 0;
+        for (int64_t s = 0; s < S1; ++s) {
+            const int64_t len = cell_off[(size_t)(b * S1 + s) + 1] - cell_off[(size_t)(b * S1 + s)];
+            nbat += (len + batch_cap - 1) / batch_cap;
+        }
+        bat_first[(size_t)b + 1] = bat_first[(size_t)b] + nbat;
+        poff_first[(size_t)b + 1] = poff_first[(size_t)b] + nbat * ((int64_t)grp_slots[(size_t)(b / H)] + 1);
+        o.bat_off[(size_t)b + 1] = (int32_t)bat_first[(size_t)b + 1];
+    }
+    o.bat.resize((size_t)bat_first[(size_t)NB]);
+    o.poff.assign((size_t)poff_first[(size_t)NB], 0);
+    o.pk.resize((size_t)n);
+    o.flag0.assign((size_t)NB, 0);
+    // the side arrays of the ratings with a context feature: a block's entries are contiguous, in stream order
+    std::vector<int64_t> flag_first((size_t)NB + 1, 0);
+    for (int64_t b = 0; b < NB; ++b)
+        flag_first[(size_t)b + 1] = flag_first[(size_t)b] + (cell_off[(size_t)(b * S1 + S) + 1] - cell_off[(size_t)(b * S1 + S)]);
+    o.fo.resize((size_t)flag_first[(size_t)NB]);
+    o.fcx.resize((size_t)flag_first[(size_t)NB]);
+    o.n_flagged = (int)flag_first[(size_t)NB];
+    parallel_ranges(NB, host_threads(NB * 4096), [&](int, int64_t bb, int64_t be) {
+        std::vector<int32_t> run, cnt, cursor;
+        for (int64_t b = bb; b < be; ++b) {
+            const int32_t ns = grp_slots[(size_t)(b / H)];
+            const int64_t h = b % H;
+            int64_t bi = bat_first[(size_t)b], pf = poff_first[(size_t)b];
+            cnt.assign((size_t)ns + 1, 0);
+            cursor.assign((size_t)ns, 0);
+            int64_t ff = flag_first[(size_t)b];
+            for (int64_t s = 0; s < S1; ++s) {
+                const int64_t c0 = cell_off[(size_t)(b * S1 + s)], c1 = cell_off[(size_t)(b * S1 + s) + 1];
+                const bool fl = s == S;                              // the block's ratings with a context feature
+                const int64_t id0 = fl ? 0 : (s * H + h) * sub_len; // first gathered id of the cell's range
+                if (fl) o.flag0[(size_t)b] = (int32_t)bi;
+                for (int64_t r0 = c0; r0 < c1; r0 += batch_cap) {
+                    const int64_t r1 = std::min<int64_t>(c1, r0 + batch_cap);
+                    // slot of a record: the coordinate's first slot in the group + (its rank inside the batch's run) / FMC_RUN
+                    run.assign((size_t)ns, 0); // per FIRST slot of a coordinate: its records seen so far in this batch
+                    std::fill(cnt.begin(), cnt.end(), 0);
+                    for (int64_t r = r0; r < r1; ++r) {
+                        const int32_t first = loc[(size_t)key[o.src[(size_t)r]]];
+                        cnt[(size_t)(first + run[(size_t)first]++ / FMC_RUN) + 1]++;
+                    }
+                    for (int32_t q = 0; q < ns; ++q) cnt[(size_t)q + 1] += cnt[(size_t)q];
+                    uint16_t *po = o.poff.data() + pf;
+                    for (int32_t q = 0; q <= ns; ++q) po[q] = (uint16_t)cnt[(size_t)q];
+                    std::fill(run.begin(), run.end(), 0);
+                    std::copy(cnt.begin(), cnt.end() - 1, cursor.begin());
+                    const int64_t ff0 = ff;
+                    for (int64_t r = r0; r < r1; ++r) {
+                        const int32_t t = o.src[(size_t)r], first = loc[(size_t)key[t]];
+                        const uint32_t pos = (uint32_t)cursor[(size_t)(first + run[(size_t)first]++ / FMC_RUN)]++;
+                        o.pk[(size_t)r] = (fl ? 0u : (uint32_t)(other[t] - id0)) | (pos << 17);
+                        if (fl) {
+                            o.fo[(size_t)ff] = other[t];
+                            o.fcx[(size_t)ff++] = ctx[t];
+                        }
+                    }
+                    o.bat[(size_t)bi++] = FmBatch{(int32_t)r0, (int32_t)(r1 - r0), fl ? (int32_t)ff0 : (int32_t)(other_base + id0), (int32_t)pf,
+                                                  fl ? (int32_t)(r1 - r0) : 0, 0};
+                    pf += (int64_t)ns + 1;
+                }
+            }
+        }
+    });
+    if (getenv("CMI_FM_DEBUG")) {
+        int64_t maxcell = 0, maxblk = 0, minblk = n;
+        for (int64_t c = 0; c < NC; ++c) maxcell = std::max(maxcell, cell_off[(size_t)c + 1] - cell_off[(size_t)c]);
+        for (int64_t b = 0; b < NB; ++b) {
+            const int64_t r = cell_off[(size_t)((b + 1) * S1)] - cell_off[(size_t)(b * S1)];
+            maxblk = std::max(maxblk, r);
+            minblk = std::min(minblk, r);
+        }
+        int32_t maxslots = 0;
+        for (int32_t x : grp_slots) maxslots = std::max(maxslots, x);
+        fprintf(stderr, "[cmi fm] cells: count %d other %d n %lld: planned NG %lld H %lld S %lld sub_len %lld target %lld -> groups %lld blocks %lld batches %zu "
+                "max cell %lld block records %lld..%lld max slots %d complex %zu\n", count, other_count, (long long)n, (long long)NG, (long long)H, (long long)S,
+                (long long)sub_len, (long long)target, (long long)G, (long long)NB, o.bat.size(), (long long)maxcell, (long long)minblk, (long long)maxblk, maxslots,
+                o.cplx.size() / 4);
+    }
+}
+
+static hipError_t fm_upload_cells(const FmCellsHost &o, FmCellsDev &d, hipStream_t s) {
+    d.n_blocks = o.n_blocks;
+    d.n_slots = (int32_t)o.slot_coord.size();
+    d.n_cplx = (int32_t)(o.cplx.size() / 4);
+    d.H = o.H;
+    d.count = o.count;
+    d.S = o.S;
+    d.n_batches = (int32_t)o.bat.size();
+    d.n_flagged = o.n_flagged;
+    d.n_rec = (int64_t)o.pk.size();
+    d.poff_len = (int64_t)o.poff.size();
+    d.slice_len = o.slice_len;
+    hipError_t e = up(&d.pk, o.pk, s);
+    if (e == hipSuccess) e = up(&d.fo, o.fo, s);
+    if (e == hipSuccess) e = up(&d.fcx, o.fcx, s);
+    if (e == hipSuccess) e = up(&d.flag0, o.flag0, s);
+    if (e == hipSuccess) e = up(&d.bat, o.bat, s);
+    if (e == hipSuccess) e = up(&d.bat_off, o.bat_off, s);
+    if (e == hipSuccess) e = up(&d.poff, o.poff, s);
+    if (e == hipSuccess) e = up(&d.slot_off, o.slot_off, s);
+    if (e == hipSuccess) e = up(&d.slot_coord, o.slot_coord, s);
+    if (e == hipSuccess) e = up(&d.cplx, o.cplx, s);
+    if (e == hipSuccess && d.n_rec > 0) e = hipMalloc((void **)&d.err0, (size_t)d.n_rec * sizeof(double));
+    if (e == hipSuccess && d.n_rec > 0) e = hipMemsetAsync(d.err0, 0, (size_t)d.n_rec * sizeof(double), s);
+    if (e == hipSuccess && d.n_slots > 0) e = hipMalloc((void **)&d.partial3, (size_t)d.n_slots * 3 * sizeof(double));
+    if (e == hipSuccess && d.n_slots > 0) e = hipMalloc((void **)&d.w0part, (size_t)d.n_slots * sizeof(double));
+    return e;
+}
+
 static hipError_t fm_upload_order(const FmOrderHost &o, FmOrderDev &d, hipStream_t s) {
     d.count = o.count;
     d.S = o.S;
@@ -301,12 +619,15 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
     FM_HIP(h, hipSetDevice(h->device));
     FM_HIP(h, hipStreamSynchronize(h->stream));
     fm_free_ratings(h);
-    FmOrderHost ou, oi, oc;
+    FmCellsHost cu, ci;
+    FmOrderHost oc;
     {
-        // the three orders do not depend on each other: the item and the context order are built on threads of their own beside the
-        // user order (each is two sequential passes over the ratings with scattered counters: a second of one core for 25 M ratings)
+        // the three streams do not depend on each other: the item cells and the context order are built on threads of their own beside
+        // the user cells
         std::vector<int32_t> ckey((size_t)n);
-        auto item_order = [&]() { fm_build_order(n, j, u, ctx, h->n_items, h->n_users, h->slice_entries, oi); };
+        auto item_cells = [&]() {
+            fm_build_cells(n, j, u, ctx, h->n_items, h->n_users, 0, h->n_conds, h->slice_entries, h->batch_cap, h->slot_cap, h->h_split, ci);
+        };
         auto ctx_order = [&]() {
             // context features: only ratings whose context-combination id is < numConditions have one (FM.java:81-86)
             for (int64_t t = 0; t < n; ++t) ckey[(size_t)t] = ctx[t] < h->n_conds ? ctx[t] : -1;
@@ -315,7 +636,7 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
         std::thread ti, tc;
         bool hi = true, hc = true;
         try {
-            ti = std::thread(item_order);
+            ti = std::thread(item_cells);
         } catch (const std::system_error &) { // the process may not create more threads: one after the other
             hi = false;
         }
@@ -324,38 +645,29 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
         } catch (const std::system_error &) {
             hc = false;
         }
-        fm_build_order(n, u, j, ctx, h->n_users, h->n_items, h->slice_entries, ou);
+        fm_build_cells(n, u, j, ctx, h->n_users, h->n_items, h->n_users, h->n_conds, h->slice_entries, h->batch_cap, h->slot_cap, h->h_split, cu);
         if (hi) ti.join();
-        else item_order();
+        else item_cells();
         if (hc) tc.join();
         else ctx_order();
     }
-    // the ratings as plain arrays in user order (cmi_fm_init), and where the other orders find their err0: gathers through the orders'
-    // permutations, in ranges on the host pool
-    std::vector<int32_t> su((size_t)n), sj((size_t)n), sc((size_t)n), inv((size_t)n), i2u((size_t)n), c2u(oc.src.size());
-    std::vector<double> sr((size_t)n);
-    parallel_ranges(n, host_threads(n), [&](int, int64_t b, int64_t e) {
-        for (int64_t pos = b; pos < e; ++pos) {
-            const int32_t t = ou.src[(size_t)pos];
-            su[(size_t)pos] = u[t];
-            sj[(size_t)pos] = j[t];
-            sc[(size_t)pos] = ctx[t];
-            sr[(size_t)pos] = r[t];
-            inv[(size_t)t] = (int32_t)pos; // (a permutation: every t is written once)
-        }
-    });
-    parallel_ranges(n, host_threads(n), [&](int, int64_t b, int64_t e) {
-        for (int64_t pos = b; pos < e; ++pos) i2u[(size_t)pos] = inv[(size_t)oi.src[(size_t)pos]];
-    });
-    for (size_t pos = 0; pos < oc.src.size(); ++pos) c2u[pos] = inv[(size_t)oc.src[pos]];
-    hipError_t e = up(&h->d_u, su, h->stream);
-    if (e == hipSuccess) e = up(&h->d_j, sj, h->stream);
-    if (e == hipSuccess) e = up(&h->d_ctx, sc, h->stream);
-    if (e == hipSuccess) e = up(&h->d_r, sr, h->stream);
-    if (e == hipSuccess) e = up(&h->d_i2u, i2u, h->stream);
-    if (e == hipSuccess) e = up(&h->d_c2u, c2u, h->stream);
-    if (e == hipSuccess) e = fm_upload_order(ou, h->ord[0], h->stream);
-    if (e == hipSuccess) e = fm_upload_order(oi, h->ord[1], h->stream);
+    // the ratings as plain arrays in the caller's order (cmi_fm_init computes err0 there; every stream copies its err0 through `src`)
+    hipError_t e = hipSuccess;
+    {
+        std::vector<int32_t> tu(u, u + n), tj(j, j + n), tc(ctx, ctx + n);
+        std::vector<double> tr(r, r + n);
+        e = up(&h->d_u, tu, h->stream);
+        if (e == hipSuccess) e = up(&h->d_j, tj, h->stream);
+        if (e == hipSuccess) e = up(&h->d_ctx, tc, h->stream);
+        if (e == hipSuccess) e = up(&h->d_r, tr, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // the vectors are locals
+    }
+    if (e == hipSuccess && n > 0) e = hipMalloc((void **)&h->d_E, (size_t)n * sizeof(double));
+    if (e == hipSuccess) e = up(&h->d_src[0], cu.src, h->stream);
+    if (e == hipSuccess) e = up(&h->d_src[1], ci.src, h->stream);
+    if (e == hipSuccess) e = up(&h->d_src[2], oc.src, h->stream);
+    if (e == hipSuccess) e = fm_upload_cells(cu, h->cell[0], h->stream);
+    if (e == hipSuccess) e = fm_upload_cells(ci, h->cell[1], h->stream);
     if (e == hipSuccess) e = fm_upload_order(oc, h->ord[2], h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
@@ -379,13 +691,20 @@ static FmArgs fm_args(cmi_fm_instance *h) {
         const FmOrderDev &d = h->ord[f];
         a.ord[f] = FmOrder{d.rec, d.piece_off, d.chunks, d.xoff, d.partial, d.n_chunks, d.count, d.S, d.n_x, d.n_rec};
     }
+    a.ord[0].count = h->n_users; // (fields 0 / 1 stream cells; the apply kernel reads `count`)
+    a.ord[1].count = h->n_items;
+    for (int f = 0; f < 2; ++f) {
+        const FmCellsDev &c = h->cell[f];
+        a.cell[f] = FmCells{c.err0, c.pk, c.fo, c.fcx, c.bat, c.bat_off, c.flag0, c.poff, c.slot_off, c.slot_coord, c.partial3, c.w0part, c.cplx,
+                            c.n_blocks, c.n_slots, c.n_cplx, c.count, c.S, c.n_rec};
+    }
     a.part = h->d_part;
     a.u = h->d_u;
     a.j = h->d_j;
     a.ctx = h->d_ctx;
     a.r = h->d_r;
-    a.i2u = h->d_i2u;
-    a.c2u = h->d_c2u;
+    a.E = h->d_E;
+    for (int f = 0; f < 3; ++f) a.src[f] = h->d_src[f];
     a.n = h->n;
     a.global_size = h->global_size > 0 ? h->global_size : h->n;
     a.k = h->k;
@@ -457,8 +776,7 @@ extern "C" int cmi_fm_phase_reduce(cmi_fm_handle h, int phase) {
     if (phase == 0) {
         FM_HIP(h, fm_launch_w0_reduce(a, h->d_scratch, h->stream));
     } else {
-        FM_HIP(h, fm_launch_reduce(a, field, f, h->stream));
-        FM_HIP(h, fm_launch_finish(a, field, f, 0, h->stream));
+        FM_HIP(h, fm_launch_phase(a, field, f, 0, h->stream));
     }
     h->last_phase = phase;
     return CMI_OK;
@@ -481,7 +799,7 @@ extern "C" int cmi_fm_phase_apply(cmi_fm_handle h, int phase) {
     if (h->last_phase != phase) FM_FAIL(h, CMI_E_INVALID, "fm: phase_apply(%d) without the matching phase_reduce", phase);
     const FmArgs a = fm_args(h);
     if (phase == 0) FM_HIP(h, fm_launch_w0_apply(a, h->stream));
-    else FM_HIP(h, fm_launch_finish(a, field, f, 1, h->stream));
+    else FM_HIP(h, fm_launch_apply(a, field, f, h->stream));
     if (f >= 0) h->v_valid = false;
     h->last_phase = -1;
     return CMI_OK;
@@ -500,8 +818,7 @@ extern "C" int cmi_fm_phase_run(cmi_fm_handle h, int phase) {
         FM_HIP(h, fm_launch_w0_reduce(a, h->d_scratch, h->stream));
         FM_HIP(h, fm_launch_w0_apply(a, h->stream));
     } else {
-        FM_HIP(h, fm_launch_reduce(a, field, f, h->stream));
-        FM_HIP(h, fm_launch_finish(a, field, f, 2, h->stream));
+        FM_HIP(h, fm_launch_phase(a, field, f, 2, h->stream));
         if (f >= 0) h->v_valid = false;
     }
     h->last_phase = -1;
@@ -525,29 +842,36 @@ extern "C" int cmi_fm_layout(cmi_fm_handle h, int64_t out[12]) {
     if (!h || !out) return CMI_E_INVALID;
     if (!h->have_ratings) FM_FAIL(h, CMI_E_INVALID, "fm: call cmi_fm_set_ratings first");
     int64_t factor = 0, red[3] = {0, 0, 0};
-    for (int f = 0; f < 3; ++f) {
-        const FmOrderDev &o = h->ord[f];
+    for (int f = 0; f < 2; ++f) {
+        const FmCellsDev &c = h->cell[f];
+        // the launch of a user / item phase: the records (8-byte error + 4-byte packed word), a 64-byte sector per record with a context
+        // feature (its combination id), the batches' slot boundaries and descriptors, the slots' coordinates, every coordinate's table
+        // entry read and written and its Vt entry written (the update is part of the launch), complex coordinates' sums out and back in;
+        // the gathered table entries are L2-resident by construction and are charged once per XCD and slice
+        red[f] = c.n_rec * 12 + (int64_t)c.n_flagged * 8 + c.poff_len * 2 + (int64_t)c.n_batches * 16 + (int64_t)c.n_blocks * 16 +
+                 (int64_t)c.n_slots * 4 + (int64_t)c.count * (16 + 16 + 8) + (c.n_cplx > 0 ? (int64_t)c.n_slots * 2 * 24 + (int64_t)c.n_cplx * 16 : 0);
+        const int64_t other = f == 0 ? h->n_items : h->n_users;
+        red[f] += 8 * other * 16;
+        factor += red[f];
+    }
+    {
+        const FmOrderDev &o = h->ord[2];
         const int64_t slots = (int64_t)o.S * o.count + o.n_x;
-        // reduce: the records, the piece offsets, the chunk table, the owners' table entries, one partial per slot written;
-        // the gathered table entries are L2-resident by construction and are charged once per XCD and slice below
-        red[f] = o.n_rec * 16 + ((int64_t)o.S * o.count + 1) * 4 + (int64_t)o.n_chunks * 16 + (int64_t)o.count * 16 + slots * 16;
-        const int64_t other = f == 0 ? h->n_items : f == 1 ? h->n_users : (int64_t)h->n_users + h->n_items;
-        red[f] += 8 * other * 16; // every XCD's L2 fills each slice of the gathered table once
-        // finish: the partials read back, the coordinate's table entry read and written, its Vt entry written
-        factor += red[f] + slots * 16 + (int64_t)o.count * (16 + 16 + 8);
+        red[2] = o.n_rec * 16 + ((int64_t)o.S * o.count + 1) * 4 + (int64_t)o.n_chunks * 16 + (int64_t)o.count * 16 + slots * 16;
+        factor += red[2] + slots * 16 + (int64_t)o.count * (16 + 16 + 8);
     }
     factor += h->p * (8 + 16 + 16); // column load: Vt row read, table entries read-modify-written
-    out[0] = h->ord[0].S;
-    out[1] = h->ord[1].S;
-    out[2] = h->ord[0].n_rec;
-    out[3] = h->ord[1].n_rec;
+    out[0] = h->cell[0].S;
+    out[1] = h->cell[1].S;
+    out[2] = h->cell[0].n_rec;
+    out[3] = h->cell[1].n_rec;
     out[4] = h->ord[2].n_rec;
-    out[5] = h->ord[0].n_chunks;
-    out[6] = h->ord[1].n_chunks;
+    out[5] = h->cell[0].n_batches;
+    out[6] = h->cell[1].n_batches;
     out[7] = factor;
     out[8] = red[0];
     out[9] = red[1];
-    out[10] = h->slice_entries;
+    out[10] = h->cell[0].slice_len * h->cell[0].H;
     out[11] = h->p;
     return CMI_OK;
 }
@@ -564,9 +888,9 @@ extern "C" int cmi_fm_time_reduce(cmi_fm_handle h, int phase, int reps, double *
     hipEvent_t e0 = nullptr, e1 = nullptr;
     FM_HIP(h, hipEventCreate(&e0));
     FM_HIP(h, hipEventCreate(&e1));
-    hipError_t e = fm_launch_reduce(a, field, f, h->stream); // warm
+    hipError_t e = fm_launch_reduce_only(a, field, f, h->stream); // warm
     if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
-    for (int i = 0; i < reps && e == hipSuccess; ++i) e = fm_launch_reduce(a, field, f, h->stream);
+    for (int i = 0; i < reps && e == hipSuccess; ++i) e = fm_launch_reduce_only(a, field, f, h->stream);
     if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.f;

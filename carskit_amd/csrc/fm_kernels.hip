@@ -215,6 +215,204 @@ __global__ __launch_bounds__(256) void fm_reduce_kernel(FmArgs a, int f) {
     }
 }
 
+// ---- fields 0 / 1: the cell stream (fm_kernels.hpp) -------------------------------------------------------------------------------
+// One coordinate's result from its sums A = sum e'h, B = sum h, C = sum h^2 over its support (e' = the error without the coordinate's
+// own running delta D, h as in fm_rec_eval):  num = sum (e' + D - theta h) h = (A + D B) - theta C,  den = C   (FM.java:178-184, 198-204).
+// fused: the update itself (FM.java:181-190, 201-211): theta' = -num / (den + size*reg), D += theta' - theta; else [num | den] -> part.
+template <int FIELD>
+__device__ __forceinline__ void fm_coord_out(const FmArgs &a, int f, int l, double A, double B, double C, bool fused) {
+    const int64_t base = fm_base(a, FIELD);
+    const double2 t = a.tab[base + l];
+    const double theta = f < 0 ? a.w[base + l] : t.x;
+    const double num = (A + t.y * B) - theta * C, den = C;
+    if (!fused) {
+        a.part[l] = num;
+        a.part[a.ord[FIELD].count + l] = den;
+        return;
+    }
+    const double reg = f < 0 ? a.regLw : a.regLf;
+    const double upd = 0.0 - num / (den + (double)a.global_size * reg);
+    const double delta = upd - theta;
+    if (f < 0) {
+        a.w[base + l] = upd;
+        a.tab[base + l].y = t.y + delta;
+    } else {
+        a.tab[base + l] = make_double2(upd, t.y + delta);
+        a.Vt[(size_t)f * (size_t)((int64_t)a.n_users + a.n_items + a.n_conds) + (size_t)(base + l)] = upd;
+    }
+}
+
+constexpr int FMC_HQ = FMC_RCAP / FMC_THREADS / 2;                   // records per thread and HALF batch
+constexpr int FMC_NSL = (FMC_SLOTS + FMC_THREADS - 1) / FMC_THREADS; // slots per thread
+static_assert(FMC_RCAP % (2 * FMC_THREADS) == 0 && FMC_RCAP < 16384 && (FMC_RCAP + 1) * 16 <= 160 * 1024, "batch = whole rounds of the workgroup, 14-bit positions, LDS");
+
+// Half a batch's registers in flight: the records (8-byte error, packed word)
+struct FmcHalf {
+    double e0[FMC_HQ];
+    uint32_t pk[FMC_HQ];
+};
+
+// W0: the w0 phase (FM.java:153-158): per slot sum(err_i - w0) -> w0part.  FUSED: coordinates with ONE slot are updated by this launch.
+//
+// Software pipeline of a workgroup (one per CU: the parking area is most of the LDS), in HALF batches (half = rounds [0, HQ) / [HQ, 2 HQ) of
+// the workgroup over the batch's records), register sets X (first halves) and Y (second halves):
+//     park X(i)        <- waits for its gathers            |  a thread keeps <= 2 half batches of records and one of gathered entries:
+//     gathers Y(i)     <- waits for its records            |  what the register file holds at 16 waves per CU
+//     request X(i+1)
+//     park Y(i)
+//     barrier
+//     gathers X(i+1), request Y(i+1)
+//     add the runs of batch i out of LDS into the threads' REGISTER accumulators (a thread owns slots t, t + THREADS, ... of the block)
+//     barrier
+// so half a batch of gathers AND half a batch of record requests are in flight while the LDS phase and the barriers run.  The pipelined
+// batches are straight-line code: indices past a batch's end are clamped for the loads and parked into a dump slot.  Ratings with a
+// context feature (FM.java:81-86: rare, only combination ids < numConditions have one) are kept out of them: they form the block's last
+// batches (`flag0`), which carry their full ids in side arrays and are walked without the pipeline.
+template <int FIELD, bool W0, bool FUSED>
+__global__ __launch_bounds__(FMC_THREADS) void fm_cell_kernel(FmArgs a, int f) {
+    __shared__ double2 park[FMC_RCAP + 1];
+    const FmCells &c = a.cell[FIELD];
+    const int b = blockIdx.x;
+    const unsigned t = threadIdx.x;
+    const int s0 = c.slot_off[b], ns = c.slot_off[b + 1] - s0;
+    double A[FMC_NSL], B[FMC_NSL], C[FMC_NSL];
+#pragma unroll
+    for (int q = 0; q < FMC_NSL; ++q) A[q] = B[q] = C[q] = 0.0;
+    const double d0 = *a.d0;
+    const int b0 = c.bat_off[b], bf = c.flag0[b], be = c.bat_off[b + 1];
+    FmcHalf X, Y;
+    double2 tt[FMC_HQ];
+    uint32_t po[FMC_NSL];
+    const FmBatch none = FmBatch{0, 0, 0, 0, 0, 0};
+
+    // records of rounds [half * HQ, half * HQ + HQ) of batch d
+    auto load = [&](const FmBatch &d, int half, FmcHalf &r) {
+        const double *eb = c.err0 + d.rec0;
+        const uint32_t *pb = c.pk + d.rec0;
+        const unsigned last = d.n > 0 ? (unsigned)d.n - 1u : 0u;
+#pragma unroll
+        for (int q = 0; q < FMC_HQ; ++q) {
+            unsigned i = (unsigned)(half * FMC_HQ + q) * FMC_THREADS + t;
+            i = i < last ? i : last; // clamped: no branch splits the loads
+            r.e0[q] = __builtin_nontemporal_load(eb + i);
+            r.pk[q] = __builtin_nontemporal_load(pb + i);
+        }
+    };
+    auto gather = [&](const FmBatch &d, const FmcHalf &r) {
+        const double2 *tb = a.tab + d.tab0;
+#pragma unroll
+        for (int q = 0; q < FMC_HQ; ++q) tt[q] = tb[r.pk[q] & 0x1FFFFu];
+    };
+    auto eval_park = [&](const FmBatch &d, int half, const FmcHalf &r) {
+#pragma unroll
+        for (int q = 0; q < FMC_HQ; ++q) {
+            const unsigned i = (unsigned)(half * FMC_HQ + q) * FMC_THREADS + t;
+            const unsigned pos = i < (unsigned)d.n ? (r.pk[q] >> 17) & 0x3FFFu : (unsigned)FMC_RCAP; // past the end: the dump slot
+            park[pos] = make_double2((r.e0[q] + d0) + tt[q].y, f < 0 ? 1.0 : tt[q].x);
+        }
+    };
+    // the thread's slot boundaries of batch d, two 16-bit positions per slot in one (unaligned) 32-bit load
+    auto load_po = [&](const FmBatch &d) {
+        const uint16_t *pb = c.poff + d.poff0;
+#pragma unroll
+        for (int q = 0; q < FMC_NSL; ++q) {
+            const unsigned s = (unsigned)q * FMC_THREADS + t;
+            typedef uint32_t __attribute__((aligned(2))) u32_a2;
+            po[q] = *(const u32_a2 *)(pb + (s < (unsigned)ns ? s : 0u));
+        }
+    };
+    auto add_runs = [&]() {
+        // the thread's slots side by side: FMC_NSL independent LDS reads per step instead of one dependent chain per slot
+        int o[FMC_NSL], e[FMC_NSL], longest = 0;
+#pragma unroll
+        for (int q = 0; q < FMC_NSL; ++q) {
+            o[q] = (int)(po[q] & 0xFFFFu);
+            e[q] = (unsigned)q * FMC_THREADS + t < (unsigned)ns ? (int)(po[q] >> 16) : o[q];
+            longest = e[q] - o[q] > longest ? e[q] - o[q] : longest;
+        }
+        for (int step = 0; step < longest; ++step) {
+#pragma unroll
+            for (int q = 0; q < FMC_NSL; ++q)
+                if (o[q] + step < e[q]) {
+                    const double2 v = park[o[q] + step];
+                    A[q] += v.x * v.y;
+                    B[q] += v.y;
+                    C[q] += v.y * v.y;
+                }
+        }
+    };
+
+    FmBatch cur = b0 < bf ? c.bat[b0] : none;
+    load(cur, 0, X);
+    gather(cur, X);
+    load(cur, 1, Y);
+    for (int bi = b0; bi < bf; ++bi) {
+        const FmBatch nxt = bi + 1 < bf ? c.bat[bi + 1] : none;
+        load_po(cur);
+        eval_park(cur, 0, X);
+        gather(cur, Y);
+        load(nxt, 0, X);
+        eval_park(cur, 1, Y);
+        __syncthreads();
+        gather(nxt, X);
+        load(nxt, 1, Y);
+        add_runs();
+        __syncthreads();
+        cur = nxt;
+    }
+    // the block's ratings with a context feature: full ids from the side arrays, no pipeline
+    const int64_t obase = fm_base(a, 1 - FIELD), cbase = (int64_t)a.n_users + a.n_items;
+    for (int bi = bf; bi < be; ++bi) {
+        const FmBatch d = c.bat[bi];
+        load_po(d);
+        for (unsigned i = t; i < (unsigned)d.n; i += FMC_THREADS) {
+            const double e0 = c.err0[(int64_t)d.rec0 + i];
+            const uint32_t pk = c.pk[(int64_t)d.rec0 + i];
+            const double2 to = a.tab[obase + c.fo[(int64_t)d.tab0 + i]], tc = a.tab[cbase + c.fcx[(int64_t)d.tab0 + i]];
+            park[(pk >> 17) & 0x3FFFu] = make_double2(((e0 + d0) + to.y) + a.xc * tc.y, f < 0 ? 1.0 : to.x + a.xc * tc.x);
+        }
+        __syncthreads();
+        add_runs();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < FMC_NSL; ++q) {
+        const int s = q * FMC_THREADS + (int)t;
+        if (s >= ns) continue;
+        const int g = s0 + s, lc = c.slot_coord[g], l = lc & 0x7FFFFFFF;
+        if (W0) {
+            const double dl = a.tab[fm_base(a, FIELD) + l].y;
+            c.w0part[g] = (A[q] + dl * B[q]) - *a.w0 * B[q];
+        } else if (lc < 0) {
+            c.partial3[3 * (int64_t)g] = A[q];
+            c.partial3[3 * (int64_t)g + 1] = B[q];
+            c.partial3[3 * (int64_t)g + 2] = C[q];
+        } else {
+            fm_coord_out<FIELD>(a, f, l, A[q], B[q], C[q], FUSED);
+        }
+    }
+}
+
+// complex coordinates (several slots: a hot run spread over slots, a block's id-range parts, a giant's blocks): their slots' sums in
+// slot order, then the same output.  cplx[4 i ..] = coordinate, first slot, parts, stride between parts, slots per part is cplx_vs.
+template <int FIELD>
+__global__ __launch_bounds__(256) void fm_cplx_kernel(FmArgs a, int f, int fused) {
+    const FmCells &c = a.cell[FIELD];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c.n_cplx) return;
+    const int4 d = ((const int4 *)c.cplx)[i];
+    const int l = d.x, g0 = d.y, parts = d.z & 0xFFFF, vs = d.z >> 16, stride = d.w;
+    double A = 0.0, B = 0.0, C = 0.0;
+    for (int h = 0; h < parts; ++h)
+        for (int v = 0; v < vs; ++v) {
+            const int64_t g = (int64_t)g0 + (int64_t)h * stride + v;
+            A += c.partial3[3 * g];
+            B += c.partial3[3 * g + 1];
+            C += c.partial3[3 * g + 2];
+        }
+    fm_coord_out<FIELD>(a, f, l, A, B, C, fused != 0);
+}
+
 // mode 0: partial -> part (num | den); 1: part -> coordinate update; 2: both.  The update (FM.java:181-190, 201-211):
 // theta' = -num / (den + size*reg); D[l] += theta' - theta (the errors of the support move by delta * x_il, folded in
 // wherever errors are read).
@@ -282,12 +480,12 @@ __global__ __launch_bounds__(256) void fm_transpose_kernel(const double *src, do
 // w0 phase, reduce: part[0] = sum over the pieces' sums of (err_i - w0) (fixed two-stage tree)
 __global__ __launch_bounds__(256) void fm_w0_reduce1(FmArgs a, double *scratch) {
     __shared__ double lds[6];
-    const FmOrder &o = a.ord[0];
-    const int64_t slots = (int64_t)o.S * o.count + o.n_x;
+    const FmCells &o = a.cell[0];
+    const int64_t slots = o.n_slots;
     const int64_t chunk = (slots + gridDim.x - 1) / gridDim.x;
     const int64_t b = (int64_t)blockIdx.x * chunk, e = (b + chunk) < slots ? (b + chunk) : slots;
     double s = 0.0;
-    for (int64_t i = b + threadIdx.x; i < e; i += 256) s += o.partial[i].x;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) s += o.w0part[i];
     s = block_sum<256>(s, lds);
     if (threadIdx.x == 0) scratch[blockIdx.x] = s;
 }
@@ -310,12 +508,11 @@ __global__ void fm_w0_apply(FmArgs a) {
     *a.w0 = upd;
 }
 
-// pre-pass (FM.java:117-146): err0[i] = r_i - predict(i) into the user-order records (Q is not materialised, see the
+// pre-pass (FM.java:117-146): E[i] = err0[i] = r_i - predict(i) per rating, in the caller's order (Q is not materialised, see the
 // header); the running delta sums start at zero.  One wave per rating.
 __global__ __launch_bounds__(256) void fm_init_kernel(FmArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * 4;
-    FmRec *rec = const_cast<FmRec *>(a.ord[0].rec);
     for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < a.n; i += stride) {
         const int u = a.u[i], j = a.j[i], c = a.ctx[i];
         const bool has_c = c >= 0 && c < a.n_conds;
@@ -339,18 +536,18 @@ __global__ __launch_bounds__(256) void fm_init_kernel(FmArgs a) {
             double pred = *a.w0 + a.w[u];
             pred += a.w[a.n_users + j];
             if (has_c) pred += a.w[a.n_users + a.n_items + c] * a.xc;
-            rec[i].err0 = a.r[i] - (pred + 0.5 * pair);
+            a.E[i] = a.r[i] - (pred + 0.5 * pair);
         }
     }
 }
-// the other two orders copy their err0 from the user order, so the three copies are the same numbers
+// the three streams copy their err0 from E, so the three copies are the same numbers
 __global__ __launch_bounds__(256) void fm_init_spread(FmArgs a) {
-    FmRec *ri = const_cast<FmRec *>(a.ord[1].rec), *rc = const_cast<FmRec *>(a.ord[2].rec);
-    const FmRec *ru = a.ord[0].rec;
+    FmRec *rc = const_cast<FmRec *>(a.ord[2].rec);
     const int64_t n2 = a.ord[2].n_rec, p = (int64_t)a.n_users + a.n_items + a.n_conds;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
-        ri[i].err0 = ru[a.i2u[i]].err0;
-        if (i < n2) rc[i].err0 = ru[a.c2u[i]].err0;
+        a.cell[0].err0[i] = a.E[a.src[0][i]];
+        a.cell[1].err0[i] = a.E[a.src[1][i]];
+        if (i < n2) rc[i].err0 = a.E[a.src[2][i]];
         if (i < p) a.tab[i].y = 0.0;
     }
     for (int64_t i = a.n + (int64_t)blockIdx.x * 256 + threadIdx.x; i < p; i += (int64_t)gridDim.x * 256) a.tab[i].y = 0.0;
@@ -392,30 +589,59 @@ __global__ __launch_bounds__(256) void fm_predict_kernel(FmArgs a, int64_t n, co
 
 // ---- launchers ------------------------------------------------------------------------------------------
 
-template <int FIELD, bool W0>
-static hipError_t launch_reduce(const FmArgs &a, int f, hipStream_t s) {
-    const int nc = a.ord[FIELD].n_chunks;
+static hipError_t launch_reduce2(const FmArgs &a, int f, hipStream_t s) { // field 2: one wave per chunk
+    const int nc = a.ord[2].n_chunks;
     if (nc <= 0) return hipSuccess;
-    hipLaunchKernelGGL((fm_reduce_kernel<FIELD, W0>), dim3(((nc + 3) / 4 + 7) / 8 * 8), dim3(256), 0, s, a, f);
+    hipLaunchKernelGGL((fm_reduce_kernel<2, false>), dim3(((nc + 3) / 4 + 7) / 8 * 8), dim3(256), 0, s, a, f);
     return hipGetLastError();
 }
 
-hipError_t fm_launch_reduce(const FmArgs &a, int field, int f, hipStream_t s) {
+template <int FIELD, bool W0, bool FUSED>
+static hipError_t launch_cells(const FmArgs &a, int f, hipStream_t s) {
+    const FmCells &c = a.cell[FIELD];
+    if (c.n_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL((fm_cell_kernel<FIELD, W0, FUSED>), dim3(c.n_blocks), dim3(FMC_THREADS), 0, s, a, f);
+    if (!W0 && c.n_cplx > 0) {
+        if (FIELD == 0) hipLaunchKernelGGL(fm_cplx_kernel<0>, dim3((c.n_cplx + 255) / 256), dim3(256), 0, s, a, f, (int)FUSED);
+        else hipLaunchKernelGGL(fm_cplx_kernel<1>, dim3((c.n_cplx + 255) / 256), dim3(256), 0, s, a, f, (int)FUSED);
+    }
+    return hipGetLastError();
+}
+
+static hipError_t launch_finish2(const FmArgs &a, int f, int mode, hipStream_t s) {
+    const int count = a.ord[2].count;
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fm_finish_kernel<2>, dim3((count + 255) / 256), dim3(256), 0, s, a, f, mode);
+    return hipGetLastError();
+}
+
+hipError_t fm_launch_phase(const FmArgs &a, int field, int f, int mode, hipStream_t s) {
+    const bool fused = mode == 2;
     switch (field) {
-    case 0: return launch_reduce<0, false>(a, f, s);
-    case 1: return launch_reduce<1, false>(a, f, s);
-    default: return launch_reduce<2, false>(a, f, s);
+    case 0: return fused ? launch_cells<0, false, true>(a, f, s) : launch_cells<0, false, false>(a, f, s);
+    case 1: return fused ? launch_cells<1, false, true>(a, f, s) : launch_cells<1, false, false>(a, f, s);
+    default:
+        if (hipError_t e = launch_reduce2(a, f, s)) return e;
+        return launch_finish2(a, f, mode, s);
     }
 }
 
-hipError_t fm_launch_finish(const FmArgs &a, int field, int f, int mode, hipStream_t s) {
+hipError_t fm_launch_reduce_only(const FmArgs &a, int field, int f, hipStream_t s) {
+    switch (field) {
+    case 0: return launch_cells<0, false, false>(a, f, s);
+    case 1: return launch_cells<1, false, false>(a, f, s);
+    default: return launch_reduce2(a, f, s);
+    }
+}
+
+hipError_t fm_launch_apply(const FmArgs &a, int field, int f, hipStream_t s) {
     const int count = a.ord[field].count;
     if (count <= 0) return hipSuccess;
     const dim3 grid((count + 255) / 256), block(256);
     switch (field) {
-    case 0: hipLaunchKernelGGL(fm_finish_kernel<0>, grid, block, 0, s, a, f, mode); break;
-    case 1: hipLaunchKernelGGL(fm_finish_kernel<1>, grid, block, 0, s, a, f, mode); break;
-    default: hipLaunchKernelGGL(fm_finish_kernel<2>, grid, block, 0, s, a, f, mode); break;
+    case 0: hipLaunchKernelGGL(fm_finish_kernel<0>, grid, block, 0, s, a, f, 1); break;
+    case 1: hipLaunchKernelGGL(fm_finish_kernel<1>, grid, block, 0, s, a, f, 1); break;
+    default: hipLaunchKernelGGL(fm_finish_kernel<2>, grid, block, 0, s, a, f, 1); break;
     }
     return hipGetLastError();
 }
@@ -436,8 +662,8 @@ hipError_t fm_launch_transpose(const double *src, double *dst, int64_t rows, int
 }
 
 hipError_t fm_launch_w0_reduce(const FmArgs &a, double *scratch, hipStream_t s) {
-    if (hipError_t e = launch_reduce<0, true>(a, -1, s)) return e;
-    const int64_t slots = (int64_t)a.ord[0].S * a.ord[0].count + a.ord[0].n_x;
+    if (hipError_t e = launch_cells<0, true, false>(a, -1, s)) return e;
+    const int64_t slots = a.cell[0].n_slots;
     int nblk = (int)((slots + 65535) / 65536);
     if (nblk < 1) nblk = 1;
     if (nblk > 256) nblk = 256;

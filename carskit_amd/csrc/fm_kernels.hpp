@@ -38,6 +38,56 @@ struct FmOrder {
     int64_t n_rec;
 };
 
+// ---- fields 0 (users) and 1 (items): the CELL stream (round 5) -------------------------------------------------------------------
+// What bounded the reduce launch of round 4 was the L2 REQUEST rate of the table gathers: one 16-byte gather per record, every lane
+// of a wave in a line of its own (tools/micro/gather16.hip: 210 G such gathers/s on this part, 119 us for 25 M; the TCP sends ONE
+// request for the lanes of an instruction that fall into the same 128-byte line: two lanes per line 57 us, four 36 us).  So the
+// records a workgroup evaluates together are sorted BY THE GATHERED ID inside a slice small enough that 64 consecutive records span
+// few lines: a BLOCK of coordinates (~2 400 users, one 1 024-thread workgroup) walks the slices of the other field; the records of
+// (block, slice) -- a CELL -- are cut into BATCHES of <= FMC_RCAP records in gathered-id order.  The workgroup evaluates a batch in
+// that order (coalesced 8 + 4 byte streams, one gather per record), parks {e', h} in LDS at the record's position in COORDINATE order
+// (`pos`, 13 bits of the packed word), and a thread per coordinate slot adds its run left to right into accumulators that live in LDS
+// for the whole block: no per-piece partial sums go through memory at all, and a coordinate's update is applied by the same launch.
+// A run longer than FMC_RUN records inside a batch (hot coordinate) is spread over several slots; a coordinate with several slots --
+// or one whose records span blocks -- is COMPLEX: its slots' sums go to `partial3` and a small second kernel finishes it.
+#ifndef FMC_CONFIG
+#define FMC_CONFIG 0
+#endif
+#if FMC_CONFIG == 0
+constexpr int FMC_THREADS = 1024;
+constexpr int FMC_RCAP = 8192;  // records per batch: 128 KB of LDS parking
+#else
+constexpr int FMC_THREADS = 512;
+constexpr int FMC_RCAP = 6144;  // 96 KB
+#endif
+constexpr int FMC_SLOTS = 5120; // accumulator slots per block: kept in the threads' registers (3 doubles per slot)
+constexpr int FMC_RUN = 64;     // longest run one thread adds
+
+struct FmBatch {
+    int32_t rec0, n; // records [rec0, rec0 + n) of the stream, in gathered-id order
+    int32_t tab0;    // table entry (absolute index into FmArgs::tab) of the first id of the batch's id range; a batch of ratings WITH a
+                     // context feature (n_flag = n): first entry of the batch in the side arrays fo / fcx instead
+    int32_t poff0;   // poff[poff0 + s] .. poff[poff0 + s + 1]: parked positions of slot s (s local to the block)
+    int32_t n_flag, pad;
+};
+
+struct FmCells {
+    double *err0;           // n_rec: the error as computed by cmi_fm_init, stream order
+    const uint32_t *pk;     // n_rec: bits 0..16 gathered id - first id of the batch's range, bits 17..30 parked position
+    const int32_t *fo, *fcx; // ratings with a context feature only (compact, a block's are contiguous): gathered id, context-combination id
+    const FmBatch *bat;
+    const int32_t *bat_off;    // n_blocks + 1: a block's batches, the pipelined ones first
+    const int32_t *flag0;      // n_blocks: a block's first batch of ratings with a context feature (= bat_off[b + 1] if it has none)
+    const uint16_t *poff;
+    const int32_t *slot_off;   // n_blocks + 1
+    const int32_t *slot_coord; // n_slots: coordinate, bit 31 = complex
+    double *partial3;          // 3 x n_slots (complex slots only are written)
+    double *w0part;            // n_slots: the w0 phase's per-slot sums
+    const int32_t *cplx;       // 4 x n_cplx: coordinate, first slot, parts | slots per part << 16, stride between parts
+    int32_t n_blocks, n_slots, n_cplx, count, S;
+    int64_t n_rec;
+};
+
 struct FmArgs {
     // model (fp64, the reference's precision)
     double *w0;   // 1
@@ -50,12 +100,14 @@ struct FmArgs {
     //   err0[i] + d0 + D[user] + D[item] + xc * D[ctx feature]
     // so no phase ever writes per-rating data.
     double2 *tab;
-    FmOrder ord[3]; // field 0 users, 1 items, 2 context features
+    FmOrder ord[3]; // field 2 (context features): the per-wave chunk stream; fields 0 / 1: only `count` is set (the cell stream below)
+    FmCells cell[2]; // field 0 users, 1 items
     double *part;   // [num | den] of the phase's field, or w0 scratch
-    // the ratings in user order as plain arrays (init only)
+    // the ratings in the caller's order as plain arrays (init only); E = err0 per rating, spread into the three streams
     const int32_t *u, *j, *ctx;
     const double *r;
-    const int32_t *i2u, *c2u; // item-order / context-order record -> user-order record (init only)
+    double *E;
+    const int32_t *src[3]; // stream position -> rating, per field (init only)
     int64_t n, global_size;
     int32_t k, n_users, n_items, n_conds;
     double xc; // 1 / numContextDims
@@ -63,8 +115,10 @@ struct FmArgs {
 };
 
 // f < 0: linear weights w; f >= 0: column f of V (a.tab[].x must hold it).
-hipError_t fm_launch_reduce(const FmArgs &a, int field, int f, hipStream_t s);              // -> ord[field].partial
-hipError_t fm_launch_finish(const FmArgs &a, int field, int f, int mode, hipStream_t s);    // 0 partial -> part; 1 part -> update; 2 both
+// mode 0: reduce -> part ([num | den] per coordinate: the exchange point of a multi-GPU host); 2: reduce + update (no exchange point)
+hipError_t fm_launch_phase(const FmArgs &a, int field, int f, int mode, hipStream_t s);
+hipError_t fm_launch_apply(const FmArgs &a, int field, int f, hipStream_t s);               // part -> update
+hipError_t fm_launch_reduce_only(const FmArgs &a, int field, int f, hipStream_t s);         // the dominant kernel alone (timing; writes scratch only)
 hipError_t fm_launch_col_load(const FmArgs &a, int f, hipStream_t s);                       // tab[l].x = Vt[f][l]
 hipError_t fm_launch_transpose(const double *src, double *dst, int64_t rows, int64_t cols, hipStream_t s); // dst[c][r] = src[r][c]
 hipError_t fm_launch_w0_reduce(const FmArgs &a, double *scratch, hipStream_t s);            // part[0] = sum(err_i - w0)

@@ -144,8 +144,8 @@ def test_fm_phases_in_any_order_match_the_numpy_engine():
 @pytest.mark.parametrize("n_users,n_items,n,zipf", [(3, 40, 1500, None), (1, 30, 900, None), (400, 2, 1200, None),
                                                      (300, 25, 3000, 1.3), (2, 2, 60, None), (1, 40, 6000, None)])
 def test_fm_support_length_paths(n_users, n_items, n, zipf):
-    """Every reduction path by support length: stream chunks (a lane per piece of <= 64 records), vector chunks (a hot coordinate's
-    piece, all 64 lanes), a piece longer than one vector chunk (> 2048 records: several partial slots per coordinate), coordinates
+    """Every reduction path by support length: runs of <= 64 records (one slot, one thread), a hot coordinate's run spread over several
+    slots (a COMPLEX coordinate: fm_cplx_kernel adds its slots), a coordinate with more records than one batch holds, coordinates
     without any rating."""
     data = util.small_data(n_users=n_users, n_items=n_items, n_dims=3, conds_per_dim=6 if n >= 6000 else 4, n=n, seed=56, item_zipf=zipf)
     orc, g = make_fm(data, 5, 6)
@@ -164,9 +164,9 @@ def test_fm_support_length_paths(n_users, n_items, n, zipf):
 
 @pytest.mark.parametrize("slice_entries", [8, 16, 1000000])
 def test_fm_l2_sliced_orders_match_the_oracle(slice_entries):
-    """The streams are sorted by (slice of the gathered table, own coordinate) so that the gathers stay L2-resident: a coordinate's
-    support is then S pieces whose partial sums the finishing kernel adds.  Forced here with tiny slices (CMI_FM_SLICE; at BASELINE
-    C4's share the default of 128 K entries gives 4 and 5 slices): same model as the dense oracle, whatever the slicing."""
+    """A block of coordinates walks the SLICES of the gathered table (cells), so that the records a workgroup evaluates together are
+    consecutive in gathered-id order inside a small slice and lanes share L2 lines.  Forced here with tiny slices (CMI_FM_SLICE; at
+    BASELINE C4's share the default of 32 K entries gives 16 and 20 slices): same model as the dense oracle, whatever the slicing."""
     import os
     data = util.small_data(n_users=60, n_items=40, n_dims=2, conds_per_dim=3, n=3000, seed=58)
     os.environ["CMI_FM_SLICE"] = str(slice_entries)
@@ -227,3 +227,41 @@ def test_fm_runner_exchange_path_on_the_instance_stream_with_rccl():
             assert np.array_equal(np.asarray(x), np.asarray(y))
     finally:
         tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch,slots,slice_entries,shape", [(64, 96, 8, (60, 40, 3000, None)), (32, 96, 4, (300, 25, 3000, 1.3)),
+                                                             (128, 96, 16, (1, 40, 6000, None)), (64, 100, 0, (400, 2, 1200, None)),
+                                                             (16, 96, 5, (37, 11, 900, None))])
+def test_fm_cell_stream_blocks_batches_and_complex_coordinates(batch, slots, slice_entries, shape):
+    """The cell stream's structure, forced on small data (CMI_FM_BATCH = records per batch, CMI_FM_SLOTS = accumulator slots per block,
+    CMI_FM_SLICE): many blocks, cells cut into several batches, runs longer than 64 records inside a batch (several slots per
+    coordinate), coordinates with more records than a block's target (cut over blocks of their own) -- the same model as the dense
+    oracle (FM.java:148-218), and the split phases (reduce -> [num | den] -> apply) bit-identical to the fused sweep."""
+    import os
+    n_users, n_items, n, zipf = shape
+    data = util.small_data(n_users=n_users, n_items=n_items, n_dims=3, conds_per_dim=4, n=n, seed=59, item_zipf=zipf)
+    os.environ.update(CMI_FM_BATCH=str(batch), CMI_FM_SLOTS=str(slots), CMI_FM_SLICE=str(slice_entries))
+    try:
+        orc, g = make_fm(data, 5, 8)
+        _, g2 = make_fm(data, 5, 8)
+    finally:
+        for v in ("CMI_FM_BATCH", "CMI_FM_SLOTS", "CMI_FM_SLICE"):
+            del os.environ[v]
+    lay = g.layout()
+    assert lay["batches_user_order"] >= data.n // batch and lay["batches_item_order"] >= data.n // batch
+    assert lay["records_user_order"] == lay["records_item_order"] == data.n
+    orc.init()
+    g.init()
+    g2.init()
+    for _ in range(2):
+        orc.sweep()
+        g.sweep()
+        for ph in range(g2.num_phases()):
+            g2.phase_reduce(ph)
+            g2.phase_apply(ph)
+    w0, w, V = g.get_model()
+    np.testing.assert_allclose(w0, orc.w0, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(w, orc.w, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(V, orc.V.reshape(V.shape), rtol=1e-8, atol=1e-11)
+    for x, y in zip(g.get_model(), g2.get_model()):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
