@@ -223,10 +223,11 @@ def bench_fm(args):
     dt = (time.perf_counter() - t0) / args.steps
     phases = 4 + 3 * k
     lay = g.layout()
-    # the dominant kernel: the reduce launch of a factor's user / item phase (64 + 64 of the ~455 launches of a sweep, 80 % of its time),
-    # timed with HIP events on the instance's stream (it only writes scratch).  Bytes = what THIS implementation has to move per
-    # launch (cmi_fm_layout: 16-byte records streamed once, piece offsets, chunk table, partial sums, one L2 fill of every table
-    # slice per XCD) -- not the reference algorithm's errors[] + Q traffic, which it never generates.
+    # the dominant kernel: the launch of a factor's user / item phase (fm_cell_kernel: 65 + 65 of the ~390 launches of a sweep, 85 % of its
+    # time), timed with HIP events on the instance's stream (in its non-updating form: it only writes scratch).  Bytes = what THIS
+    # implementation has to move per launch (cmi_fm_layout: 12-byte records streamed once, the batches' slot boundaries, the
+    # coordinates' table entries and sums, one L2 fill of every table slice per XCD) -- not the reference algorithm's errors[] + Q
+    # traffic, which it never generates.
     ku, ki = g.time_reduce(4 + 3 * (k // 2) + 0, 10) * 1e-3, g.time_reduce(4 + 3 * (k // 2) + 1, 10) * 1e-3
     bytes_launch = 0.5 * (lay["bytes_reduce_user"] + lay["bytes_reduce_item"])
     kern = 0.5 * (ku + ki)
@@ -239,15 +240,17 @@ def bench_fm(args):
                                   % (k, data.n_users, data.n_items, data.n_conds, data.n), "phases_per_sweep": phases},
            "roofline": {"bound": "hbm", "achieved": bytes_launch / kern / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_launch / kern / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "fm_reduce_kernel<0|1,false> (one factor's user / item phase)",
+                        "kernel": "fm_cell_kernel<0|1> (one factor's user / item phase)",
                         "kernel_us": {"user_field": ku * 1e6, "item_field": ki * 1e6}, "bytes_per_launch": bytes_launch,
                         "bytes_per_rating_phase": bytes_launch / data.n,
-                        "bytes_model": "this implementation's own traffic per reduce launch (cmi_fm_layout): records 16 B x %d, piece offsets, chunk "
-                                       "table, partial sums, table-slice fills; the reference ALGORITHM's errors[] + Q traffic would be %d B per "
+                        "bytes_model": "this implementation's own traffic per launch (cmi_fm_layout): records 12 B x %d, slot boundaries per batch, "
+                                       "coordinate entries + sums, table-slice fills; the reference ALGORITHM's errors[] + Q traffic would be %d B per "
                                        "rating-sweep (never generated here)" % (data.n, ref_bytes),
                         "whole_sweep_GBps": sweep_bytes / dt / 1e9, "whole_sweep_frac": sweep_bytes / dt / 1e9 / HBM_PEAK_GBS,
-                        "limiter": "L2 request rate of the 16-byte table gathers (one per rating and phase, L2 hits by construction): with the "
-                                   "gathers pointed at one cache line the same launch takes ~80 us = 5 TB/s of streaming (DESIGN.md 5)",
+                        "limiter": "one 1024-thread workgroup per CU walks stream -> gather -> LDS parking -> run sums in lockstep: the record "
+                                   "stream alone is 44 us at the copy rate, the gathers 40 us at 3 lanes per L2 line (tools/micro/gather16.hip: "
+                                   "210 G lone 16-byte gathers/s, 119 us, was round 4's wall), the LDS phase 28 us, VALU issue 35 us -- they "
+                                   "overlap only in part (DESIGN.md 5)",
                         "layout": lay, "avg_phase_us": dt * 1e6 / phases}}
     g.close()
     return out

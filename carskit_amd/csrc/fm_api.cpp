@@ -60,7 +60,7 @@ struct cmi_fm_instance {
     RankWorkspace rank_ws; // cmi_fm_eval_rankings' buffers, reused by the next evaluation
     ncclComm_t comm = nullptr; // cmi_fm_comm_init: ratings sharded by user over one process per GPU
     int comm_world = 0;
-    int col_f = -1; // factor whose column is loaded in d_tab[].x
+    int col[3] = {-1, -1, -1}; // per field: the factor whose column sits in d_tab[].x of that field's coordinates (-1: none)
     int64_t part_count = 0;
     // experiment / test knob (CMI_FM_SLICE): an upper bound on the table entries of a slice of the gathered field; 0 = the geometry's own
     // choice (cells that fill a batch: fm_build_cells)
@@ -193,7 +193,7 @@ extern "C" int cmi_fm_set_model(cmi_fm_handle h, double w0, const double *w, con
     FM_HIP(h, hipStreamSynchronize(h->stream));
     h->have_model = true;
     h->initialised = false;
-    h->col_f = -1;
+    h->col[0] = h->col[1] = h->col[2] = -1;
     h->v_valid = true;
     h->vt_valid = false;
     return CMI_OK;
@@ -711,6 +711,7 @@ static FmArgs fm_args(cmi_fm_instance *h) {
     a.n_users = h->n_users;
     a.n_items = h->n_items;
     a.n_conds = h->n_conds;
+    a.xcol = -1;
     a.xc = 1.0 / (double)h->n_ctx_dims;
     a.regLw = h->regLw;
     a.regLf = h->regLf;
@@ -729,7 +730,7 @@ extern "C" int cmi_fm_init(cmi_fm_handle h) {
     if (!h) return CMI_E_INVALID;
     if (int rc = fm_ready(h, false)) return rc;
     if (int rc = fm_sync_V(h)) return rc;
-    h->col_f = -1;
+    h->col[0] = h->col[1] = h->col[2] = -1;
     FM_HIP(h, fm_launch_init(fm_args(h), h->stream));
     FM_HIP(h, hipStreamSynchronize(h->stream));
     h->initialised = true;
@@ -756,14 +757,29 @@ static bool phase_decode(cmi_fm_instance *h, int phase, int *field, int *f) {
 
 // ---- phase driver.  Errors are never stored (fm_kernels.hip header), so the phases may be driven in any order; the
 // only state between them is which column of V sits in tab[].x.
-static int fm_before_phase(cmi_fm_instance *h, int f) {
-    if (f >= 0)
-        if (int rc = fm_sync_Vt(h)) return rc;
-    if (f >= 0 && h->col_f != f) {
-        FM_HIP(h, fm_launch_col_load(fm_args(h), f, h->stream));
-        h->col_f = f;
+// the column an update of (field, f) leaves in tab[].x of the coordinates it updates (fm_kernels.hip fm_update)
+static int fm_xcol(const cmi_fm_instance *h, int field, int f) {
+    if (field == 0) return f;                // users: the column just written (-1: a linear-weight phase leaves .x alone)
+    return std::min(f + 1, h->k - 1);        // items / context features: the next factor's column
+}
+
+// What a phase's GATHERS need in tab[].x: the user phase of factor f gathers the items' (and the context features') column f, the item
+// phase the users' (and the context features'); the context phase reads its columns out of Vt.  In the order of a sweep the updates have
+// left exactly these columns (fm_update); phases driven in another order reload what is missing.
+static int fm_before_phase(cmi_fm_instance *h, int field, int f) {
+    if (int rc = fm_sync_Vt(h)) return rc;
+    if (f < 0 || field == 2) return CMI_OK;
+    for (int g = 0; g < 3; ++g) {
+        if (g == field || h->col[g] == f) continue;
+        FM_HIP(h, fm_launch_col_load(fm_args(h), g, f, h->stream));
+        h->col[g] = f;
     }
     return CMI_OK;
+}
+static void fm_after_update(cmi_fm_instance *h, int field, int f) {
+    const int x = fm_xcol(h, field, f);
+    if (x >= 0) h->col[field] = x;
+    if (f >= 0) h->v_valid = false;
 }
 
 extern "C" int cmi_fm_phase_reduce(cmi_fm_handle h, int phase) {
@@ -771,7 +787,7 @@ extern "C" int cmi_fm_phase_reduce(cmi_fm_handle h, int phase) {
     if (int rc = fm_ready(h, true)) return rc;
     int field, f;
     if (!phase_decode(h, phase, &field, &f)) FM_FAIL(h, CMI_E_INVALID, "fm: bad phase %d", phase);
-    if (int rc = fm_before_phase(h, f)) return rc;
+    if (int rc = fm_before_phase(h, field, f)) return rc;
     const FmArgs a = fm_args(h);
     if (phase == 0) {
         FM_HIP(h, fm_launch_w0_reduce(a, h->d_scratch, h->stream));
@@ -797,10 +813,13 @@ extern "C" int cmi_fm_phase_apply(cmi_fm_handle h, int phase) {
     int field, f;
     if (!phase_decode(h, phase, &field, &f)) FM_FAIL(h, CMI_E_INVALID, "fm: bad phase %d", phase);
     if (h->last_phase != phase) FM_FAIL(h, CMI_E_INVALID, "fm: phase_apply(%d) without the matching phase_reduce", phase);
-    const FmArgs a = fm_args(h);
+    FmArgs a = fm_args(h);
     if (phase == 0) FM_HIP(h, fm_launch_w0_apply(a, h->stream));
-    else FM_HIP(h, fm_launch_apply(a, field, f, h->stream));
-    if (f >= 0) h->v_valid = false;
+    else {
+        a.xcol = fm_xcol(h, field, f);
+        FM_HIP(h, fm_launch_apply(a, field, f, h->stream));
+        fm_after_update(h, field, f);
+    }
     h->last_phase = -1;
     return CMI_OK;
 }
@@ -812,14 +831,15 @@ extern "C" int cmi_fm_phase_run(cmi_fm_handle h, int phase) {
     if (int rc = fm_ready(h, true)) return rc;
     int field, f;
     if (!phase_decode(h, phase, &field, &f)) FM_FAIL(h, CMI_E_INVALID, "fm: bad phase %d", phase);
-    if (int rc = fm_before_phase(h, f)) return rc;
-    const FmArgs a = fm_args(h);
+    if (int rc = fm_before_phase(h, field, f)) return rc;
+    FmArgs a = fm_args(h);
     if (phase == 0) {
         FM_HIP(h, fm_launch_w0_reduce(a, h->d_scratch, h->stream));
         FM_HIP(h, fm_launch_w0_apply(a, h->stream));
     } else {
+        a.xcol = fm_xcol(h, field, f);
         FM_HIP(h, fm_launch_phase(a, field, f, 2, h->stream));
-        if (f >= 0) h->v_valid = false;
+        fm_after_update(h, field, f);
     }
     h->last_phase = -1;
     return CMI_OK;
@@ -883,7 +903,7 @@ extern "C" int cmi_fm_time_reduce(cmi_fm_handle h, int phase, int reps, double *
     if (int rc = fm_ready(h, true)) return rc;
     int field, f;
     if (!phase_decode(h, phase, &field, &f) || phase == 0) FM_FAIL(h, CMI_E_INVALID, "fm: bad phase %d", phase);
-    if (int rc = fm_before_phase(h, f)) return rc;
+    if (int rc = fm_before_phase(h, field, f)) return rc;
     const FmArgs a = fm_args(h);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     FM_HIP(h, hipEventCreate(&e0));

@@ -21,20 +21,24 @@
 //     to the association of the additions (1e-16 relative; the tests hold the model to 1e-8 against the dense oracle).
 //   * the reference's cache Q[i][f] = sum_l V[l][f] x_il (FM.java:134-146, 209-210) is not stored either: with three
 //     features per rating it is V[u][f] + V[item][f] + xc*V[ctx][f], the same gathers.
-//   * every field STREAMS its own copy of the ratings (16-byte records {err0, other id, ctx id}): the user field in user
-//     order, the item field in item order.  Nothing is gathered from per-rating arrays (round 3 did: 68 bytes fetched per
+//   * every field STREAMS its own copy of the ratings: nothing is gathered from per-rating arrays (round 3 did: 68 bytes fetched per
 //     16 useful in the item phase).
-//   * the only gathers left are the other field's table entries (8-10 MB tables at BASELINE C4's share: they miss L2 and
-//     every miss fetches a 64-byte sector for 16 bytes).  Each order is therefore sorted by (SLICE of the other id, own
-//     coordinate): while a slice streams, the table entries it gathers (<= 1 MB) stay L2-resident in every XCD.  A
-//     coordinate's support becomes S contiguous pieces whose partial sums the finishing kernel adds in slice order.
-// Reduction: CSR-stream.  A wave takes a chunk of <= 256 consecutive records = <= 64 whole pieces, evaluates every
-// record once (coalesced 16-byte loads, 4 per lane), parks {e', h} in LDS, and one lane per piece sums its records left
-// to right -- deterministic, independent of the chunking.  Pieces longer than 64 records (hot coordinates) are split
-// into vector chunks that all 64 lanes reduce (fixed butterfly).  fp64 throughout; gather / stream work: no MFMA.
+//   * the only gathers left are the OTHER field's table entries, one 16-byte gather per rating and phase, L2 hits by construction.
+//     Round 4 streamed 16-byte records sorted by (slice of the other id, own coordinate), a wave per 512 records: 160 us per launch,
+//     bound by the L2 REQUEST rate -- every lane's gather in a 128-byte line of its own (tools/micro/gather16.hip: 210 G such
+//     gathers/s on this part = 119 us for 25 M, whatever the slice size; the TCP sends one request for the lanes of an instruction
+//     that fall into one line: two lanes per line 57 us, four 36 us).  Round 5 (the CELL stream, fm_kernels.hpp): the user and the
+//     item field evaluate their records in GATHERED-ID order inside groups of ~4 900 coordinates (3 lanes per line at BASELINE C4's
+//     share), park {e', h} in LDS at the record's position in coordinate order, and add the runs into register accumulators that
+//     live for the whole group: 12-byte records, no per-piece partial sums through memory, the coordinate update in the same launch
+//     (or one small kernel where a coordinate's sums come from several workgroups).  122-136 us per launch box to box, 19.2 ms per sweep.
+//   * the context field (a few records in a thousand) keeps round 4's form: 16-byte records, a wave per chunk, CSR-stream reduction
+//     (a lane per piece out of LDS; pieces longer than 64 records are vector chunks that all 64 lanes reduce).
+// Deterministic: every sum is added in a fixed order that depends on the data layout alone.  fp64 throughout; gather / stream
+// work: no MFMA.
 //
-// reduce (-> partial) and finish (partial -> [num | den] -> update) are separate launches, so a multi-GPU host can
-// all-reduce (num, den) between them; the fused sweep runs the identical arithmetic.
+// reduce (-> [num | den] per coordinate) and apply are separable, so a multi-GPU host can all-reduce (num, den) between them; the
+// fused sweep runs the identical arithmetic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -59,6 +63,12 @@ __device__ __forceinline__ double block_sum(double x, double *lds) {
 
 __device__ __forceinline__ int64_t fm_base(const FmArgs &a, int field) {
     return field == 0 ? 0 : (field == 1 ? (int64_t)a.n_users : (int64_t)a.n_users + a.n_items);
+}
+
+// The coordinate's current value: the linear weight, or column f of V out of the sweeps' working copy Vt (NOT tab[].x: that holds
+// the column the GATHERS of the coming phases need, see fm_update).
+__device__ __forceinline__ double fm_theta(const FmArgs &a, int f, int64_t bl) {
+    return f < 0 ? a.w[bl] : a.Vt[(size_t)f * (size_t)((int64_t)a.n_users + a.n_items + a.n_conds) + (size_t)bl];
 }
 
 __device__ __forceinline__ FmRec fm_load_rec(const FmRec *rec, int64_t i) {
@@ -91,7 +101,8 @@ __device__ __forceinline__ void fm_rec_eval(const FmArgs &a, int f, const FmRec 
 #pragma unroll
         for (int q = 0; q < N; ++q) {
             ep[q] = ((r[q].err0 + d0) + tu[q].y) + tj[q].y;
-            h[q] = f < 0 ? a.xc : a.xc * (tu[q].x + tj[q].x);
+            // (the user's and the item's column entries out of Vt: tab[].x of the items already holds the next factor's column)
+            h[q] = f < 0 ? a.xc : a.xc * (fm_theta(a, f, r[q].a) + fm_theta(a, f, jbase + r[q].c));
         }
     } else {
         double2 t[N];
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256) void fm_reduce_kernel(FmArgs a, int f) {
             e = o.piece_off[ch.piece0 + lane + 1];
             const int l = (ch.piece0 + lane) % o.count;
             const double2 t = a.tab[base + l];
-            theta = W0 ? *a.w0 : (f < 0 ? a.w[base + l] : t.x);
+            theta = W0 ? *a.w0 : fm_theta(a, f, base + l);
             dl = FIELD == 2 ? a.xc * t.y : t.y; // the support's errors moved by delta * x_il
         }
         // all four record loads first (clamped, so no branch splits them), then the gathers, then LDS
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(256) void fm_reduce_kernel(FmArgs a, int f) {
     } else {
         const int l = ch.piece0 % o.count;
         const double2 t = a.tab[base + l];
-        const double theta = W0 ? *a.w0 : (f < 0 ? a.w[base + l] : t.x), dl = FIELD == 2 ? a.xc * t.y : t.y;
+        const double theta = W0 ? *a.w0 : fm_theta(a, f, base + l), dl = FIELD == 2 ? a.xc * t.y : t.y;
         double num = 0.0, den = 0.0;
         for (int i0 = ch.rec0; i0 < ch.rec1; i0 += 4 * 64) { // a lane sums its records (stride 64) in order
             FmRec rr[4];
@@ -215,6 +226,22 @@ __global__ __launch_bounds__(256) void fm_reduce_kernel(FmArgs a, int f) {
     }
 }
 
+// The update (FM.java:181-190, 201-211): theta' = -num / (den + size*reg); the errors of the support move by (theta' - theta) x_il,
+// which is folded into the coordinate's running delta D = tab[].y.  tab[].x is left holding column a.xcol: a user update leaves the
+// column it just wrote (the item phase of the same factor gathers it), an item / context update leaves the NEXT factor's column (the
+// next reader of those entries is the next factor's user phase) -- so a sweep never needs a pass that reloads the columns
+// (round 4's fm_col_load per factor: 9.5 us of a 290-us factor).
+__device__ __forceinline__ void fm_update(const FmArgs &a, int f, int64_t bl, double2 t, double theta, double num, double den) {
+    const double reg = f < 0 ? a.regLw : a.regLf;
+    const double upd = 0.0 - num / (den + (double)a.global_size * reg);
+    const double delta = upd - theta;
+    const size_t p = (size_t)((int64_t)a.n_users + a.n_items + a.n_conds);
+    if (f < 0) a.w[bl] = upd;
+    else a.Vt[(size_t)f * p + (size_t)bl] = upd;
+    const double x = a.xcol < 0 ? t.x : (a.xcol == f ? upd : a.Vt[(size_t)a.xcol * p + (size_t)bl]);
+    a.tab[bl] = make_double2(x, t.y + delta);
+}
+
 // ---- fields 0 / 1: the cell stream (fm_kernels.hpp) -------------------------------------------------------------------------------
 // One coordinate's result from its sums A = sum e'h, B = sum h, C = sum h^2 over its support (e' = the error without the coordinate's
 // own running delta D, h as in fm_rec_eval):  num = sum (e' + D - theta h) h = (A + D B) - theta C,  den = C   (FM.java:178-184, 198-204).
@@ -223,28 +250,19 @@ template <int FIELD>
 __device__ __forceinline__ void fm_coord_out(const FmArgs &a, int f, int l, double A, double B, double C, bool fused) {
     const int64_t base = fm_base(a, FIELD);
     const double2 t = a.tab[base + l];
-    const double theta = f < 0 ? a.w[base + l] : t.x;
+    const double theta = fm_theta(a, f, base + l);
     const double num = (A + t.y * B) - theta * C, den = C;
     if (!fused) {
         a.part[l] = num;
         a.part[a.ord[FIELD].count + l] = den;
         return;
     }
-    const double reg = f < 0 ? a.regLw : a.regLf;
-    const double upd = 0.0 - num / (den + (double)a.global_size * reg);
-    const double delta = upd - theta;
-    if (f < 0) {
-        a.w[base + l] = upd;
-        a.tab[base + l].y = t.y + delta;
-    } else {
-        a.tab[base + l] = make_double2(upd, t.y + delta);
-        a.Vt[(size_t)f * (size_t)((int64_t)a.n_users + a.n_items + a.n_conds) + (size_t)(base + l)] = upd;
-    }
+    fm_update(a, f, base + l, t, theta, num, den);
 }
 
 constexpr int FMC_HQ = FMC_RCAP / FMC_THREADS / 2;                   // records per thread and HALF batch
 constexpr int FMC_NSL = (FMC_SLOTS + FMC_THREADS - 1) / FMC_THREADS; // slots per thread
-static_assert(FMC_RCAP % (2 * FMC_THREADS) == 0 && FMC_RCAP < 16384 && (FMC_RCAP + 1) * 16 <= 160 * 1024, "batch = whole rounds of the workgroup, 14-bit positions, LDS");
+static_assert(FMC_RCAP % (2 * FMC_THREADS) == 0 && FMC_RCAP <= 16384 && FMC_RCAP * 16 <= 160 * 1024, "batch = whole rounds of the workgroup, 14-bit positions, LDS");
 
 // Half a batch's registers in flight: the records (8-byte error, packed word)
 struct FmcHalf {
@@ -265,12 +283,12 @@ struct FmcHalf {
 //     add the runs of batch i out of LDS into the threads' REGISTER accumulators (a thread owns slots t, t + THREADS, ... of the block)
 //     barrier
 // so half a batch of gathers AND half a batch of record requests are in flight while the LDS phase and the barriers run.  The pipelined
-// batches are straight-line code: indices past a batch's end are clamped for the loads and parked into a dump slot.  Ratings with a
+// batches are straight-line code: indices past a batch's end are clamped for the loads and parked at positions no record has.  Ratings with a
 // context feature (FM.java:81-86: rare, only combination ids < numConditions have one) are kept out of them: they form the block's last
 // batches (`flag0`), which carry their full ids in side arrays and are walked without the pipeline.
 template <int FIELD, bool W0, bool FUSED>
 __global__ __launch_bounds__(FMC_THREADS) void fm_cell_kernel(FmArgs a, int f) {
-    __shared__ double2 park[FMC_RCAP + 1];
+    __shared__ double2 park[FMC_RCAP];
     const FmCells &c = a.cell[FIELD];
     const int b = blockIdx.x;
     const unsigned t = threadIdx.x;
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(FMC_THREADS) void fm_cell_kernel(FmArgs a, int f) {
 #pragma unroll
         for (int q = 0; q < FMC_HQ; ++q) {
             const unsigned i = (unsigned)(half * FMC_HQ + q) * FMC_THREADS + t;
-            const unsigned pos = i < (unsigned)d.n ? (r.pk[q] >> 17) & 0x3FFFu : (unsigned)FMC_RCAP; // past the end: the dump slot
+            const unsigned pos = i < (unsigned)d.n ? (r.pk[q] >> 17) & 0x3FFFu : i; // past the end: its own index, a position no record of the batch has
             park[pos] = make_double2((r.e0[q] + d0) + tt[q].y, f < 0 ? 1.0 : tt[q].x);
         }
     };
@@ -446,22 +464,12 @@ __global__ __launch_bounds__(256) void fm_finish_kernel(FmArgs a, int f, int mod
         den = a.part[o.count + l];
     }
     const int64_t base = fm_base(a, FIELD);
-    const double2 t = a.tab[base + l];
-    const double theta = f < 0 ? a.w[base + l] : t.x;
-    const double reg = f < 0 ? a.regLw : a.regLf;
-    const double upd = 0.0 - num / (den + (double)a.global_size * reg);
-    const double delta = upd - theta;
-    if (f < 0) {
-        a.w[base + l] = upd;
-        a.tab[base + l].y = t.y + delta;
-    } else {
-        a.tab[base + l] = make_double2(upd, t.y + delta);
-        a.Vt[(size_t)f * (size_t)((int64_t)a.n_users + a.n_items + a.n_conds) + (size_t)(base + l)] = upd;
-    }
+    fm_update(a, f, base + l, a.tab[base + l], fm_theta(a, f, base + l), num, den);
 }
 
-__global__ __launch_bounds__(256) void fm_col_load(FmArgs a, int f, int64_t p) {
-    for (int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x; l < p; l += (int64_t)gridDim.x * 256)
+// tab[l].x = Vt[f][l] for entries [lo, hi): only when phases are driven out of the sweep's order (fm_update leaves the right columns)
+__global__ __launch_bounds__(256) void fm_col_load(FmArgs a, int f, int64_t lo, int64_t hi, int64_t p) {
+    for (int64_t l = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; l < hi; l += (int64_t)gridDim.x * 256)
         a.tab[l].x = a.Vt[(size_t)f * (size_t)p + (size_t)l]; // .y (the coordinate's running delta sum) is kept
 }
 
@@ -646,11 +654,14 @@ hipError_t fm_launch_apply(const FmArgs &a, int field, int f, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t fm_launch_col_load(const FmArgs &a, int f, hipStream_t s) {
+hipError_t fm_launch_col_load(const FmArgs &a, int field, int f, hipStream_t s) {
     const int64_t p = (int64_t)a.n_users + a.n_items + a.n_conds;
-    int64_t blocks = (p + 255) / 256;
+    const int64_t lo = field == 0 ? 0 : field == 1 ? a.n_users : (int64_t)a.n_users + a.n_items;
+    const int64_t hi = field == 0 ? a.n_users : field == 1 ? (int64_t)a.n_users + a.n_items : p;
+    if (hi <= lo) return hipSuccess;
+    int64_t blocks = (hi - lo + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(fm_col_load, dim3((unsigned)blocks), dim3(256), 0, s, a, f, p);
+    hipLaunchKernelGGL(fm_col_load, dim3((unsigned)blocks), dim3(256), 0, s, a, f, lo, hi, p);
     return hipGetLastError();
 }
 

@@ -55,7 +55,7 @@ struct FmOrder {
 #endif
 #if FMC_CONFIG == 0
 constexpr int FMC_THREADS = 1024;
-constexpr int FMC_RCAP = 8192;  // records per batch: 128 KB of LDS parking
+constexpr int FMC_RCAP = 8192;  // records per batch: 128 KB of LDS parking (10 240 = all of a CU's LDS measured the same)
 #else
 constexpr int FMC_THREADS = 512;
 constexpr int FMC_RCAP = 6144;  // 96 KB
@@ -110,6 +110,7 @@ struct FmArgs {
     const int32_t *src[3]; // stream position -> rating, per field (init only)
     int64_t n, global_size;
     int32_t k, n_users, n_items, n_conds;
+    int32_t xcol; // the column of V an UPDATE leaves in tab[].x of the coordinates it updates (-1: .x stays): see fm_update
     double xc; // 1 / numContextDims
     double regLw, regLf;
 };
@@ -119,7 +120,7 @@ struct FmArgs {
 hipError_t fm_launch_phase(const FmArgs &a, int field, int f, int mode, hipStream_t s);
 hipError_t fm_launch_apply(const FmArgs &a, int field, int f, hipStream_t s);               // part -> update
 hipError_t fm_launch_reduce_only(const FmArgs &a, int field, int f, hipStream_t s);         // the dominant kernel alone (timing; writes scratch only)
-hipError_t fm_launch_col_load(const FmArgs &a, int f, hipStream_t s);                       // tab[l].x = Vt[f][l]
+hipError_t fm_launch_col_load(const FmArgs &a, int field, int f, hipStream_t s);            // tab[l].x = Vt[f][l] for the coordinates of one field
 hipError_t fm_launch_transpose(const double *src, double *dst, int64_t rows, int64_t cols, hipStream_t s); // dst[c][r] = src[r][c]
 hipError_t fm_launch_w0_reduce(const FmArgs &a, double *scratch, hipStream_t s);            // part[0] = sum(err_i - w0)
 hipError_t fm_launch_w0_apply(const FmArgs &a, hipStream_t s);
