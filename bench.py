@@ -147,6 +147,7 @@ def roofline(model, k, n_dims, data_n, info, sched, kern_ms, esize, workload):
            "traffic": traffic, "traffic_source": src,
            "traffic_GBps": (traffic / avg_us / 1e3) if traffic else None,
            "traffic_over_model": (traffic * launches / sched["sector"]) if traffic else None,
+           "traffic_over_algorithmic": (traffic * launches / (data_n * bpu)) if traffic else None,
            "kernel": ("sgd_chain_level<%s,%s,hub=%s>" % (tname, model, info["kind"][6:]) if chain
                       else "sgd_owner<%s,%s,hub=%s> (latency-bound by the hottest row's chain, not by HBM)" % (tname, model, info["kind"][6:])
                       if info["kind"].startswith("owner") else "sgd_level_fast_f32<%s,%d>" % (model, k // 64) if esize == 4 else "sgd_level_generic<double,%s>" % model),
@@ -158,6 +159,35 @@ def roofline(model, k, n_dims, data_n, info, sched, kern_ms, esize, workload):
                          "more than 5 %% -- the roofline numerator is not trustworthy, fix the model or re-profile"
                          % (sched["sector"] / launches / 1e6, src, traffic / 1e6))
     return out
+
+
+_PEAK_MEASURED = {}
+
+
+def peak_measured(device):
+    """The part's measured ceilings beside the spec peak, once per run: a device-to-device copy and random 512-byte row read-modify-write
+    (cmi_measure_hbm over a 4 GiB scratch buffer, best of 3 after warm-up).  Every SGD object of the line carries them, so a fraction
+    can be read against the box's own pattern ceiling without opening profiles/."""
+    if device not in _PEAK_MEASURED:
+        try:
+            cp, rw = capi.measure_hbm(device, 4 << 30)
+            _PEAK_MEASURED[device] = {"copy_GBps": cp, "random_512B_row_rw_GBps": rw,
+                                      "method": "cmi_measure_hbm over a 4 GiB scratch buffer, best of 3 after warm-up"}
+        except Exception as e:
+            _PEAK_MEASURED[device] = {"error": repr(e)}
+    return _PEAK_MEASURED[device]
+
+
+def with_measured(rf, device, enabled=True):
+    """frac_of_measured_copy / _random_row: the same achieved GB/s against what this box's HBM delivers for a copy / for the row pattern."""
+    if not enabled:
+        return rf
+    pm = peak_measured(device)
+    rf["peak_measured"] = pm
+    if "copy_GBps" in pm:
+        rf["frac_of_measured_copy"] = rf["achieved"] / pm["copy_GBps"]
+        rf["frac_of_measured_random_row"] = rf["achieved"] / pm["random_512B_row_rw_GBps"]
+    return rf
 
 
 def timed_epochs(inst, lr, steps, warmup):
@@ -173,7 +203,7 @@ def timed_epochs(inst, lr, steps, warmup):
     return losses, time.perf_counter() - t0, float(np.mean(ms))
 
 
-def secondary_workload(name, steps, warmup, device, flags, regs, lr):
+def secondary_workload(name, steps, warmup, device, flags, regs, lr, calibrate=True):
     """Another workload of WORKLOADS in the same run (the `northstar` object of the N=1 line): generated, scheduled, uploaded and
     timed exactly like the primary one, with its own roofline."""
     model, k, n_users, n_items, n_dims, cpd, n_ratings = WORKLOADS[name]
@@ -181,9 +211,11 @@ def secondary_workload(name, steps, warmup, device, flags, regs, lr):
     data = synth.generate_fast(n_users, n_items, n_dims, cpd, n_ratings, seed=synth.DEFAULT_SEED)
     gm = float(data.r.sum() / np.count_nonzero(data.r))
     state = synth.init_state(model, data, k, seed=synth.DEFAULT_SEED + 2, dtype=np.float32)
+    t1 = time.perf_counter()
     inst = make_instance(model, k, data, n_items, state, regs, gm, device, flags)
+    setup_s = time.perf_counter() - t1     # cmi_create + cmi_set_ratings (schedule + tuple stream upload) + cmi_set_state
     info, sched = inst.schedule_info(), inst.schedule_traffic()
-    log("%s: %d tuples generated, scheduled and uploaded in %.1fs: %s" % (name, data.n, time.perf_counter() - t0, info))
+    log("%s: %d tuples generated in %.1fs, scheduled and uploaded in %.1fs: %s" % (name, data.n, t1 - t0, setup_s, info))
     del state
     losses, el, kern_ms = timed_epochs(inst, lr, steps, warmup)
     if not np.all(np.isfinite(losses)) or losses[-1] > losses[0]:
@@ -195,9 +227,10 @@ def secondary_workload(name, steps, warmup, device, flags, regs, lr):
                           "hub-chain level" if info["kind"].startswith("chain") else "owner (dataflow)" if info["kind"].startswith("owner")
                           else "dependency-level"),
            "dtype": "f32", "value": data.n * steps / el, "unit": "rating-updates/s", "steps": steps, "warmup": warmup,
-           "ms_per_step": el / steps * 1e3, "levels_per_epoch": info["levels"], "first_loss": losses[0], "final_loss": losses[-1],
+           "ms_per_step": el / steps * 1e3, "setup_s": setup_s, "levels_per_epoch": info["levels"], "first_loss": losses[0], "final_loss": losses[-1],
            "roofline": roofline(model, k, n_dims, data.n, info, sched, kern_ms, 4, name)}
     inst.close()
+    with_measured(out["roofline"], device, calibrate)
     return out
 
 
@@ -253,6 +286,122 @@ def bench_fm(args):
                                    "overlap only in part (DESIGN.md 5)",
                         "layout": lay, "avg_phase_us": dt * 1e6 / phases}}
     g.close()
+    return out
+
+
+def bench_frappe(args):
+    """--workload frappe: BASELINE configs[1]'s data set the way the reference runs it -- `cv -k F -p on`, F recommender instances side by
+    side (CARSKit.java:395-412: one Java thread per fold) -- on ONE GPU: F instances of --model (default CAMF_C, k=64) on F streams, each
+    training on the tuples outside its fold of the real Frappe file (tests/golden/frappe_compact.csv.gz through the product's DataTransformer
+    + DataDAO; rating = 1 + log10(count), the scale the tests train on).  value = aggregate updates/s of the F concurrent folds; cpu_baseline
+    = the C restatement on the same folds, one core and F threads.  These models are ONE dependent chain per instance (every rating updates
+    parameters every other rating reads): the bound is the chain's latency, not HBM -- the roofline object says so."""
+    import gzip
+    import math
+    import tempfile
+    from carskit_amd import dao
+    depaul = args.workload == "depaul"      # BASELINE configs[0]'s file (5 043 ratings, ':na' conditions: the similarity models can run on it;
+    #                                         on Frappe the reference's EmptyContextConditions.get(i) has nothing to return, CAMF_ICS.java:56)
+    model = args.model or ("CAMF_ICS" if depaul else "CAMF_C")
+    k = args.k if args.k > 0 else (10 if depaul else 64)
+    F = max(1, args.folds)
+    tmp = tempfile.mkdtemp(prefix="cmi_frappe_")
+    if depaul:
+        src = os.path.join(ROOT, "tests", "golden", "depaul_ratings_compact.csv")
+    else:
+        text = gzip.open(os.path.join(ROOT, "tests", "golden", "frappe_compact.csv.gz"), "rb").read().decode("utf-8").split("\n")
+        rows = [text[0]]
+        for ln in text[1:]:
+            if ln:
+                f_ = ln.split(",")
+                f_[2] = "%.6f" % (1.0 + math.log10(int(f_[2])))
+                ln = ",".join(f_)
+            rows.append(ln)
+        src = os.path.join(tmp, "frappe_log.csv")
+        open(src, "w", encoding="utf-8").write("\n".join(rows))
+    dao.transform(src, os.path.join(tmp, "train.csv"))
+    d = dao.DataDAO(os.path.join(tmp, "train.csv")).rating_data()
+    regs = (synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-4), synth.java_float(1e-3))
+    lr = synth.java_float(0.02) if model == "CAMF_C" else synth.java_float(0.02) / 8
+    sim = model in ("CAMF_ICS", "CAMF_LCS", "CAMF_MCS")
+    num_f = 10
+    folds = []
+    for f_ in range(F):
+        tr = d.subset(np.flatnonzero((np.arange(d.n) % max(F, 5)) != f_)) if F > 1 else d
+        tr.meta["num_f"] = num_f
+        st = synth.init_state(model, tr, k, seed=synth.DEFAULT_SEED + f_, dtype=np.float32)
+        if sim:
+            st["P"] = (0.3 * st["P"]).astype(np.float32)
+        gm = float(tr.r.sum() / np.count_nonzero(tr.r))
+        inst = capi.Instance(model, k, tr.n_users, tr.n_items, tr.n_conds, flags=args.flags | capi.FLAG_SCHED_SERIAL)
+        inst.set_hparams(*regs, gm)
+        if sim:
+            inst.set_sim_params(num_f, tr.n_dims, d.empty_conds)
+        inst.set_ratings(tr.u, tr.j, tr.ctx, tr.r, tr.ctx_ptr, tr.ctx_conds)
+        inst.set_states(st)
+        folds.append((inst, tr, st, gm))
+
+    def run(steps):
+        ths = [threading.Thread(target=lambda i=i: [i.train_epoch(lr) for _ in range(steps)]) for i, _, _, _ in folds]
+        t0 = time.perf_counter()
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        return time.perf_counter() - t0
+
+    run(max(1, args.warmup))
+    el = run(args.steps)
+    one_ms = float(np.mean([i.last_epoch_ms() for i, _, _, _ in folds]))
+    total = sum(tr.n for _, tr, _, _ in folds)
+    # one instance alone (no neighbours): what a fold costs when the GPU has nothing else to do
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        folds[0][0].train_epoch(lr)
+    alone = (time.perf_counter() - t0) / args.steps
+    bpu = algorithmic_bytes("CAMF_C", k, 8, 4)
+    out = {"metric": "SGD rating-updates/sec, %s k=%d, %d concurrent folds" % (model, k, F), "value": total * args.steps / el, "unit": "rating-updates/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32",
+           "data": "real (tests/golden/%s)" % ("depaul_ratings_compact.csv" if depaul else "frappe_compact.csv.gz, rating = 1 + log10(count)"),
+           "config": {"workload": "%s: %s k=%d on the %s file (%d users x %d items x %d conditions, %d ratings), %d folds trained "
+                                  "concurrently on one GPU, each on the tuples outside its fold (%d per fold)"
+                                  % (args.workload, model, k, "DePaulMovie" if depaul else "Frappe", d.n_users, d.n_items, d.n_conds, d.n, F, folds[0][1].n),
+                      "concurrent_folds": F, "schedule": folds[0][0].schedule_info()["kind"],
+                      "one_fold_alone_ms_per_epoch": alone * 1e3, "one_fold_alone_updates_per_s": folds[0][1].n / alone,
+                      "fold_epoch_ms_while_concurrent": one_ms},
+           "roofline": {"bound": "hbm", "achieved": total * args.steps * bpu / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": total * args.steps * bpu / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "one serial wave / conflict-free block chain per instance (camfc_pipe.hip, ext_kernels.hip)",
+                        "limiter": "latency of ONE dependent chain per instance (every rating updates parameters every other rating reads: "
+                                   "CAMF_C's condBias, the similarity models' shared tables); the whole model is a few MB and cache-resident, "
+                                   "HBM is idle -- the fraction is reported for form, the comparison that matters is cpu_baseline"}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle_c
+
+        def mk(tr, st, gm):
+            s64 = {n_: np.asarray(a, dtype=np.float64) for n_, a in st.items()}
+            if sim:
+                return oracle_c.SimOracle(model, k, tr.n_users, tr.n_items, tr.n_conds, tr.u, tr.j, tr.ctx, tr.r, tr.ctx_ptr, tr.ctx_conds,
+                                          d.empty_conds, s64, gm, *regs, n_ctx_dims=tr.n_dims)
+            return oracle_c.Oracle(model, k, tr.n_users, tr.n_items, tr.n_conds, tr.u, tr.j, tr.ctx, tr.r, tr.ctx_ptr, tr.ctx_conds, s64, gm, *regs)
+        orcs = [mk(tr, st, gm) for _, tr, st, gm in folds]
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            orcs[0].epoch(lr)
+        one = (time.perf_counter() - t0) / reps
+        ths = [threading.Thread(target=lambda o=o: [o.epoch(lr) for _ in range(reps)]) for o in orcs]      # the C call releases the GIL
+        t0 = time.perf_counter()
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        dtF = (time.perf_counter() - t0) / reps
+        out["cpu_baseline"] = {"value": folds[0][1].n / one, "unit": "rating-updates/s", "cores": 1, "kind": "port",
+                               "sample": "%d epochs of fold 0 (%d tuples), fp64 order-exact C restatement, single thread (host has %d cores)"
+                                         % (reps, folds[0][1].n, os.cpu_count() or 0),
+                               "five_fold": {"value": total / dtF, "cores": F, "seconds": dtF * reps,
+                                             "sample": "the same %d folds on %d threads, aggregate updates/s" % (F, F)}}
+        out["vs_cpu_folds"] = out["value"] / out["cpu_baseline"]["five_fold"]["value"]
+    for i, _, _, _ in folds:
+        i.close()
     return out
 
 
@@ -437,7 +586,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + ["c4", "rank"],
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + ["c4", "rank", "frappe", "depaul"],
                     help="c3 (default) / northstar / c5 / small: the SGD hot path; c4: one GPU's share of the FM configuration (ALS sweep); "
                          "rank: evalRankings (top-N scoring on the f32 matrix cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -461,10 +610,10 @@ def main():
                          "one thread per fold), each on its own stream; value then aggregates all of them")
     args = ap.parse_args()
 
-    if args.workload in ("c4", "rank"):
+    if args.workload in ("c4", "rank", "frappe", "depaul"):
         if args.gpus != 1:
             raise SystemExit("--workload %s is a single-GPU measurement (FM over ranks: carskit_amd.dist.ShardedFMRunner, tests/test_dist_fm_gloo.py)" % args.workload)
-        print(json.dumps(bench_fm(args) if args.workload == "c4" else bench_rank(args)), flush=True)
+        print(json.dumps({"c4": bench_fm, "rank": bench_rank, "frappe": bench_frappe, "depaul": bench_frappe}[args.workload](args)), flush=True)
         return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -644,13 +793,8 @@ def main():
         for o in extra:
             o.close()
         if world == 1 and not args.no_calibration:
-            try:
-                inst.synchronize()
-                cp, rw = capi.measure_hbm(local_rank, 4 << 30)
-                out["roofline"]["peak_measured"] = {"copy_GBps": cp, "random_512B_row_rw_GBps": rw,
-                                                    "method": "cmi_measure_hbm over a 4 GiB scratch buffer, best of 3 after warm-up"}
-            except Exception as e:
-                out["roofline"]["peak_measured"] = {"error": repr(e)}
+            inst.synchronize()
+            with_measured(out["roofline"], local_rank)
         if world == 1 and not args.no_f64 and args.folds == 1:
             # secondary line: the same workload with the model kept in fp64 on the GPU (the reference's precision)
             try:
@@ -664,6 +808,7 @@ def main():
                               "steps": args.f64_steps, "ms_per_step": el64 / args.f64_steps * 1e3, "final_loss": l64[-1],
                               "roofline": roofline(model, k, n_dims, data.n, info64, sched64, ms64, 8, args.workload)}
                 i64.close()
+                with_measured(out["f64"]["roofline"], local_rank, not args.no_calibration)
             except Exception as e:
                 out["f64"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
@@ -676,7 +821,8 @@ def main():
             try:
                 inst.close()
                 del data, state
-                out["northstar"] = secondary_workload("northstar", args.northstar_steps, args.warmup, local_rank, args.flags, regs, lr)
+                out["northstar"] = secondary_workload("northstar", args.northstar_steps, args.warmup, local_rank, args.flags, regs, lr,
+                                                      not args.no_calibration)
             except SystemExit:
                 raise
             except Exception as e:
@@ -689,11 +835,11 @@ def main():
                 small.steps, small.warmup, small.no_cpu_baseline = 3, 1, True
                 rk = copy.copy(small)
                 rk.steps, rk.warmup = 8, 2      # an evaluation is 15 ms of which a third is host work: more of them, so that one disturbed call weighs less
-                for key, fn in (("c5", lambda: secondary_workload("c5", 3, 1, local_rank, args.flags, regs, lr)),
+                for key, fn in (("c5", lambda: secondary_workload("c5", 3, 1, local_rank, args.flags, regs, lr, not args.no_calibration)),
                                 ("fm_c4", lambda: bench_fm(small)), ("rank", lambda: bench_rank(rk))):
                     try:
                         o = fn()
-                        out[key] = {kk: o[kk] for kk in ("metric", "workload", "value", "unit", "steps", "ms_per_step", "dtype", "roofline", "config")
+                        out[key] = {kk: o[kk] for kk in ("metric", "workload", "value", "unit", "steps", "ms_per_step", "setup_s", "dtype", "roofline", "config")
                                     if kk in o}
                     except SystemExit:
                         raise

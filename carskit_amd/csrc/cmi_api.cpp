@@ -567,11 +567,17 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
                             const int32_t *ctx_ptr, const int32_t *ctx_conds) {
     const bool contextual = !is_2d_model(h->model);
     if (n < 0 || (n > 0 && (!u || !j || !r))) CMI_FAIL(h, CMI_E_INVALID, "set_ratings: null tuple arrays");
-    if (is_ext_model(h->model) && h->model != CMI_MODEL_SVDPP && (h->empty_conds.empty() || (h->model == CMI_MODEL_CAMF_LCS && h->num_f < 1)))
+    if (is_ext_model(h->model) && h->model != CMI_MODEL_SVDPP && (!h->sim_params_set || (h->model == CMI_MODEL_CAMF_LCS && h->num_f < 1)))
         CMI_FAIL(h, CMI_E_INVALID, "set_ratings: call cmi_set_sim_params first (EmptyContextConditions%s)", h->model == CMI_MODEL_CAMF_LCS ? ", numF" : "");
     if (contextual && is_ext_model(h->model) && n_ctx > 0 && ctx_ptr) {
         for (int32_t c = 0; c < n_ctx; ++c)
             if (ctx_ptr[c + 1] - ctx_ptr[c] > 16) CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: more than 16 conditions per context");
+        // condition i of a context is paired with EmptyContextConditions.get(i) (CAMF_ICS.java:56,88: an IndexOutOfBoundsException in the
+        // reference when the data has fewer ':na' conditions than a context has conditions, e.g. Frappe, which has none)
+        for (int32_t c = 0; c < n_ctx; ++c)
+            if (ctx_ptr[c + 1] - ctx_ptr[c] > (int32_t)h->empty_conds.size())
+                CMI_FAIL(h, CMI_E_INVALID, "set_ratings: context %d has %d conditions but EmptyContextConditions has %d entries "
+                         "(IndexOutOfBoundsException in the reference, CAMF_ICS.java:88)", c, ctx_ptr[c + 1] - ctx_ptr[c], (int)h->empty_conds.size());
     }
     if (contextual && (n_ctx < 0 || !ctx_ptr || (n > 0 && !ctx) || (n_ctx > 0 && ctx_ptr[n_ctx] > 0 && !ctx_conds)))
         CMI_FAIL(h, CMI_E_INVALID, "set_ratings: context table required for model %d", h->model);
