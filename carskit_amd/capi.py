@@ -127,6 +127,8 @@ SYMBOLS = [
     ("cmi_owner_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(C.c_int)]),
     ("cmi_chain_schedule", C.c_int, [_i64, _vp, _vp, _i32, _i32, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _i64, C.POINTER(_i64),
                                      C.POINTER(_i64), C.POINTER(C.c_int)]),
+    ("cmi_chain_schedule_device", C.c_int, [C.c_int, _i64, _vp, _vp, _i32, _i32, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _i64, C.POINTER(_i64),
+                                     C.POINTER(_i64), C.POINTER(C.c_int)]),
     ("cmi_dao_read", C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     ("cmi_dao_read_shared", C.c_int, [C.c_char_p, _vp, C.POINTER(_vp)]),
     ("cmi_dao_destroy", C.c_int, [_vp]),
@@ -327,6 +329,26 @@ def chain_schedule(u, j, n_users, n_items, hub=-1, max_chain=16):
     if rc != OK:
         raise CmiError(rc, "cmi_chain_schedule")
     return perm, unit_off, level_off, bool(hub_used.value)
+
+
+def chain_schedule_device(u, j, n_users, n_items, hub=-1, max_chain=16, device=0):
+    """The same schedule built on the device (cmi_chain_schedule_device; what cmi_set_ratings uses for large sets)."""
+    u = np.ascontiguousarray(u, dtype=np.int32)
+    j = np.ascontiguousarray(j, dtype=np.int32)
+    n = len(u)
+    # (the device build has no count-only form: sized by the host's counts)
+    nu, nl, hub_used = _i64(), _i64(), C.c_int()
+    rc = lib().cmi_chain_schedule(n, _p(u), _p(j), n_users, n_items, hub, max_chain, None, None, 0, None, 0, C.byref(nu), C.byref(nl), C.byref(hub_used))
+    if rc != OK:
+        raise CmiError(rc, "cmi_chain_schedule")
+    perm = np.empty(n, dtype=np.int32)
+    unit_off = np.empty(nu.value + 1, dtype=np.int32)
+    level_off = np.empty(nl.value + 1, dtype=np.int64)
+    rc = lib().cmi_chain_schedule_device(device, n, _p(u), _p(j), n_users, n_items, hub, max_chain, _p(perm), _p(unit_off), len(unit_off),
+                                         _p(level_off), len(level_off), C.byref(nu), C.byref(nl), C.byref(hub_used))
+    if rc != OK:
+        raise CmiError(rc, "cmi_chain_schedule_device")
+    return perm, unit_off[:nu.value + 1], level_off[:nl.value + 1], bool(hub_used.value)
 
 
 def owner_schedule(u, j, n_users, n_items, n_owners, hub=-1, depth=8):

@@ -20,6 +20,7 @@
 #include "cmi_instance.hpp"
 #include "host_pool.hpp"
 #include "level_schedule.hpp"
+#include "sched_device.hpp"
 #include "mf_sgd_kernels.hpp"
 
 using namespace cmi;
@@ -524,12 +525,31 @@ static int chain_max_len() {
     if (const char *env = getenv("CMI_CHAIN_MAX")) v = atoi(env);
     return v < 1 ? 1 : (v > 16 ? 16 : v);
 }
-static bool try_chain(cmi_instance *h, int64_t n, const int32_t *u, const int32_t *j, ChainSchedule &csch) {
+static void free_keep(ChainDeviceKeep &keep) {
+    for (int32_t **q : {&keep.d_u, &keep.d_j, &keep.d_perm})
+        if (*q) {
+            (void)hipFree(*q);
+            *q = nullptr;
+        }
+}
+static bool try_chain(cmi_instance *h, int64_t n, const int32_t *u, const int32_t *j, ChainSchedule &csch, ChainDeviceKeep &keep) {
     // the side that carries the context-bias rows is preferred as the hub side (CAMF_CI: items, CAMF_CU: users): measured on the C5
     // share (CAMF_CU k=256, 128 conditions) 50.1 ms per epoch along users (36.4 M units) against 64.3 ms along items (31.9 M units)
     int hub = h->model == CMI_MODEL_CAMF_CU ? -2 : (h->model == CMI_MODEL_CAMF_CI ? -3 : -1);
     if (const char *env = getenv("CMI_CHAIN_HUB")) hub = !strcmp(env, "item") ? 1 : (!strcmp(env, "user") ? 0 : hub);
-    if (!build_chain_schedule(n, u, j, h->n_users, h->n_items, hub, chain_max_len(), csch)) return false;
+    // large sets: the schedule is built on the device (sched_device.hip: the same schedule, element for element; the host walk is
+    // 11 ns per tuple on one core).  CMI_SCHEDULE_DEVICE=0 / 1: never / at any size.
+    int64_t dev_min = (int64_t)1 << 21;
+    if (const char *env = getenv("CMI_SCHEDULE_DEVICE")) dev_min = atoi(env) ? 0 : INT64_MAX;
+    bool built = false;
+    if (n >= dev_min) {
+        built = build_chain_schedule_device(h->device, h->stream, n, u, j, h->n_users, h->n_items, hub, chain_max_len(), csch, &keep);
+        if (!built) {
+            (void)hipGetLastError();
+            free_keep(keep);
+        }
+    }
+    if (!built && !build_chain_schedule(n, u, j, h->n_users, h->n_items, hub, chain_max_len(), csch)) return false;
     int64_t min_width = 2048; // mean units per level
     if (const char *env = getenv("CMI_CHAIN_MIN_WIDTH")) min_width = atoll(env);
     const bool forced = h->flags & CMI_FLAG_SCHED_CHAIN;
@@ -537,7 +557,10 @@ static bool try_chain(cmi_instance *h, int64_t n, const int32_t *u, const int32_
     // Zipf(0.8) items, the chain schedule has 2.5x fewer levels (434 K vs 1.10 M) but a narrow chain level is latency-bound on
     // the HBM round trip of EVERY spoke row of its longest unit (one row in flight per group), 3.77 s per epoch against 2.61 s for
     // the plain narrow-run walk.  Forced (CMI_FLAG_SCHED_CHAIN) it still runs, one launch per level.
-    if (!forced && csch.n_units() < min_width * csch.n_levels()) return false;
+    if (!forced && csch.n_units() < min_width * csch.n_levels()) {
+        free_keep(keep);
+        return false;
+    }
     h->chain = true;
     h->chain_hub_item = csch.hub_is_item != 0;
     h->n_units = csch.n_units();
@@ -648,7 +671,49 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: CMI_FLAG_SCHED_OWNER: no owner kernel for model %d, k=%d, %d conditions, %s state%s (or "
                  "another schedule flag is set)", h->model, h->k, h->n_conds, h->f64 ? "fp64" : "fp32", h->strict ? ", strict" : "");
     // the hub-chain levels first: wide data is theirs
-    const bool use_chain = !h->serial && chain_ok && n > 0 && try_chain(h, n, u, j, csch);
+    // The spoke arena of a large set is tens of GB (north_star: 102 GB) and hipMalloc takes ~20 ms per GB: when the sizes say an arena is
+    // likely (a side's table >= 2 GiB, or it is forced), it is allocated on a thread of its own WHILE the schedule and the stream are
+    // built; the arena block below takes it over or frees it.
+    struct SpecArena {
+        std::thread th;
+        void *ptr = nullptr;
+        size_t bytes = 0;
+        hipError_t err = hipSuccess;
+        void *take(size_t want) {
+            if (th.joinable()) th.join();
+            if (ptr && bytes == want && err == hipSuccess) {
+                void *p = ptr;
+                ptr = nullptr;
+                return p;
+            }
+            return nullptr;
+        }
+        ~SpecArena() {
+            if (th.joinable()) th.join();
+            if (ptr) (void)hipFree(ptr);
+        }
+    } spec;
+    if (!h->serial && chain_ok && n >= ((int64_t)1 << 21) && !(h->flags & CMI_FLAG_NO_ARENA) && !getenv("CMI_NO_ARENA") && h->k >= 64 &&
+        h->k % (h->f64 ? 2 : 4) == 0) {
+        const size_t row = (size_t)h->k * esize(h), arena_bytes = (size_t)n * row;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const bool likely = (h->flags & CMI_FLAG_SPOKE_ARENA) || getenv("CMI_ARENA") || (size_t)std::max(h->n_users, h->n_items) * row >= ((size_t)2 << 30);
+        if (likely && (double)arena_bytes <= 0.6 * (double)free_b) {
+            spec.bytes = arena_bytes;
+            const int dev = h->device;
+            try {
+                spec.th = std::thread([&spec, dev]() {
+                    spec.err = hipSetDevice(dev);
+                    if (spec.err == hipSuccess) spec.err = hipMalloc(&spec.ptr, spec.bytes);
+                });
+            } catch (const std::system_error &) { // no thread: allocated in place below
+            }
+        }
+    }
+    ChainDeviceKeep keep; // device-built schedule: the tuple ids and the permutation stay on the device for the stream build
+    const bool use_chain = !h->serial && chain_ok && n > 0 && try_chain(h, n, u, j, csch, keep);
+    const bool dev_stream = use_chain && keep.d_perm != nullptr;
     bool use_owner = h->want_owner;
     h->sched_note.clear();
     if (!use_owner && !use_chain && !h->serial && n >= ((int64_t)1 << 16) &&
@@ -835,11 +900,13 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
     // tuple stream in schedule order, conditions pre-expanded to [n x dmax] (-1 padded) so the kernels
     // need no ctx -> condition-list indirection.
     const int64_t ns = n;
-    HostBuf<int32_t> su((size_t)ns), sj((size_t)ns), sconds((size_t)ns * (size_t)dmax);
-    HostBuf<float> sr32(h->f64 ? 0 : (size_t)ns);
-    HostBuf<double> sr64(h->f64 ? (size_t)ns : 0);
+    const int64_t hs = dev_stream ? 0 : ns; // (the device-built schedule builds the stream on the device too: no host copy of it)
+    HostBuf<int32_t> su((size_t)hs), sj((size_t)hs), sconds((size_t)hs * (size_t)dmax);
+    HostBuf<float> sr32(h->f64 ? 0 : (size_t)hs);
+    HostBuf<double> sr64(h->f64 ? (size_t)hs : 0);
     // every stream slot is a gather through the schedule's permutation: ranges of slots on the host's cores, the tuple arrays' entries
     // requested 16 slots ahead
+    if (!dev_stream)
     parallel_ranges(ns, host_threads(ns), [&](int, int64_t s0, int64_t s1) {
         for (int64_t s = s0; s < s1; ++s) {
             if (!h->serial && s + 16 < s1) {
@@ -874,10 +941,13 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         }
     });
     lap("stream");
-    hipError_t e = upload((void **)&h->d_su, su, h->stream);
-    if (e == hipSuccess) e = upload((void **)&h->d_sj, sj, h->stream);
-    if (e == hipSuccess) e = upload((void **)&h->d_sconds, sconds, h->stream);
-    if (e == hipSuccess) e = h->f64 ? upload(&h->d_sr, sr64, h->stream) : upload(&h->d_sr, sr32, h->stream);
+    hipError_t e = hipSuccess;
+    if (!dev_stream) {
+        e = upload((void **)&h->d_su, su, h->stream);
+        if (e == hipSuccess) e = upload((void **)&h->d_sj, sj, h->stream);
+        if (e == hipSuccess) e = upload((void **)&h->d_sconds, sconds, h->stream);
+        if (e == hipSuccess) e = h->f64 ? upload(&h->d_sr, sr64, h->stream) : upload(&h->d_sr, sr32, h->stream);
+    }
     if (e == hipSuccess && contextual) {
         std::vector<int32_t> cp(ctx_ptr, ctx_ptr + n_ctx + 1), cc(ctx_conds, ctx_conds + ctx_ptr[n_ctx]);
         h->ctx_nnz = (int64_t)cc.size();
@@ -885,6 +955,16 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         if (e == hipSuccess) e = upload((void **)&h->d_ctx_conds, cc, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // cp/cc are locals
     }
+    if (e == hipSuccess && dev_stream) {
+        e = hipMalloc((void **)&h->d_su, (size_t)ns * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_sj, (size_t)ns * 4);
+        if (e == hipSuccess && dmax > 0) e = hipMalloc((void **)&h->d_sconds, (size_t)ns * (size_t)dmax * 4);
+        if (e == hipSuccess) e = hipMalloc(&h->d_sr, (size_t)ns * esize(h));
+        if (e == hipSuccess)
+            e = (hipError_t)stream_build_device(h->stream, ns, keep.d_u, keep.d_j, keep.d_perm, ctx, r, h->d_ctx_ptr, h->d_ctx_conds, dmax, h->f64, h->d_su,
+                                                h->d_sj, h->d_sconds, h->d_sr);
+    }
+    free_keep(keep);
     if (e == hipSuccess && h->chain) e = upload((void **)&h->d_unit_off, csch.unit_off, h->stream);
     lap("uploads");
     if (e == hipSuccess && h->chain && !(h->flags & CMI_FLAG_NO_ARENA) && !getenv("CMI_NO_ARENA") && h->k >= 64 && h->k % (h->f64 ? 2 : 4) == 0) {
@@ -909,12 +989,26 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         if (forced || large || probe) {
             // next_pos[p] = stream position of the next tuple of the same spoke row (its tuples sit in ascending levels, hence ascending
             // positions); the last one wraps to the first: that is where the row waits for the next epoch
-            HostBuf<int32_t> nxt((size_t)n), first((size_t)spokes);
-            const HostBuf<int32_t> &sp = h->chain_hub_item ? su : sj;
-            arena_positions(n, sp.data(), spokes, nxt.data(), first.data());
-            e = upload((void **)&h->d_next, nxt, h->stream);
-            if (e == hipSuccess) e = upload((void **)&h->d_first, first, h->stream);
-            if (e == hipSuccess) e = hipMalloc(&h->d_arena, arena_bytes);
+            // on the device out of the uploaded stream (sched_device.hip arena_positions_device: a stable sort of the positions by spoke
+            // row); the host walk (0.5 s for C3's 50 M tuples) only if that fails
+            e = hipMalloc((void **)&h->d_next, (size_t)n * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&h->d_first, (size_t)spokes * 4);
+            if (e == hipSuccess && (hipError_t)arena_positions_device(h->stream, n, h->chain_hub_item ? h->d_su : h->d_sj, spokes, h->d_next, h->d_first) != hipSuccess) {
+                (void)hipGetLastError();
+                HostBuf<int32_t> nxt((size_t)n), first((size_t)spokes), back(dev_stream ? (size_t)n : 0);
+                if (dev_stream) { // the stream exists on the device only: the spoke ids come back for the host walk
+                    e = hipMemcpy(back.data(), h->chain_hub_item ? h->d_su : h->d_sj, (size_t)n * 4, hipMemcpyDeviceToHost);
+                }
+                const HostBuf<int32_t> &sp = dev_stream ? back : (h->chain_hub_item ? su : sj);
+                arena_positions(n, sp.data(), spokes, nxt.data(), first.data());
+                e = hipMemcpyAsync(h->d_next, nxt.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(h->d_first, first.data(), (size_t)spokes * 4, hipMemcpyHostToDevice, h->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // nxt / first are locals
+            }
+            if (e == hipSuccess) {
+                h->d_arena = spec.take(arena_bytes); // allocated beside the schedule build, if the sizes had announced it
+                if (!h->d_arena) e = hipMalloc(&h->d_arena, arena_bytes);
+            }
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // nxt / first are locals
             if (e == hipSuccess) {
                 h->arena_on = true;
@@ -1026,6 +1120,7 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         free_ratings(h);
         CMI_FAIL(h, CMI_E_HIP, "set_ratings: upload failed: %s", hipGetErrorString(e));
     }
+    lap("rest");
     h->n = n;
     h->tuple_bytes = h->owner ? (ns + (int64_t)h->n_owners * 2 * owner_depth()) * (int64_t)owner_rec_bytes(owner_mask_words(h->model, h->n_conds))
                               : ns * (8 + (int64_t)esize(h) + 4 * (int64_t)dmax + 0) + (h->chain ? 4 * (h->n_units + 1) : 0) + (h->arena_on ? 4 * ns : 0);
@@ -1797,6 +1892,31 @@ extern "C" int cmi_chain_schedule(int64_t n, const int32_t *u, const int32_t *j,
         if (u[t] < 0 || u[t] >= n_users || j[t] < 0 || j[t] >= n_items) return CMI_E_INVALID;
     ChainSchedule cs;
     if (!build_chain_schedule(n, u, j, n_users, n_items, hub, max_chain, cs)) return CMI_E_UNSUPPORTED;
+    *n_units = cs.n_units();
+    *n_levels = cs.n_levels();
+    if (hub_used) *hub_used = cs.hub_is_item;
+    if (!perm) return CMI_OK;
+    if (!unit_off || !level_off || unit_cap < cs.n_units() + 1 || level_cap < cs.n_levels() + 1) return CMI_E_INVALID;
+    std::copy(cs.perm.begin(), cs.perm.end(), perm);
+    std::copy(cs.unit_off.begin(), cs.unit_off.end(), unit_off);
+    std::copy(cs.level_off.begin(), cs.level_off.end(), level_off);
+    return CMI_OK;
+}
+
+// the same schedule built on the device (what cmi_set_ratings uses for large sets): tests compare the two element for element
+extern "C" int cmi_chain_schedule_device(int device, int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub,
+                                         int max_chain, int32_t *perm, int32_t *unit_off, int64_t unit_cap, int64_t *level_off,
+                                         int64_t level_cap, int64_t *n_units, int64_t *n_levels, int *hub_used) {
+    if (n < 0 || (n > 0 && (!u || !j)) || n_users <= 0 || n_items <= 0 || !n_units || !n_levels || max_chain < 1) return CMI_E_INVALID;
+    if (device < 0 || device >= cmi_device_count()) return CMI_E_NO_DEVICE;
+    for (int64_t t = 0; t < n; ++t)
+        if (u[t] < 0 || u[t] >= n_users || j[t] < 0 || j[t] >= n_items) return CMI_E_INVALID;
+    ChainSchedule cs;
+    hipStream_t st = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return CMI_E_HIP;
+    const bool ok = build_chain_schedule_device(device, st, n, u, j, n_users, n_items, hub, max_chain, cs);
+    (void)hipStreamDestroy(st);
+    if (!ok) return CMI_E_UNSUPPORTED;
     *n_units = cs.n_units();
     *n_levels = cs.n_levels();
     if (hub_used) *hub_used = cs.hub_is_item;

@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define CMI_ABI_VERSION 4 /* 4: round 5 -- ADDED cmi_group_last_times, cmi_comm_last_exchange_ms (exchange vs compute time of an epoch)
+#define CMI_ABI_VERSION 4 /* 4: round 5 -- ADDED cmi_group_last_times, cmi_comm_last_exchange_ms (exchange vs compute time of an epoch),
+                             cmi_chain_schedule_device; CMI_E_HOST; cmi_fm_layout's [5..6] are batches
                              3: round 4 -- cmi_comm_*, cmi_fm_comm_*, group resident evaluation, FM layout / timing, ranking host
                              clock; REMOVED: CMI_FLAG_SCHED_FLOW, CMI_FLAG_TWO_LANE, cmi_flow_schedule, cmi_split_schedule */
 
@@ -521,6 +522,12 @@ int cmi_level_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_
 int cmi_chain_schedule(int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int max_chain,
                        int32_t *perm, int32_t *unit_off, int64_t unit_cap, int64_t *level_off, int64_t level_cap,
                        int64_t *n_units, int64_t *n_levels, int *hub_used);
+/* the same schedule built on `device` (sched_device.hip: a lane per hub row walks the row's CRS chain, the spoke rows hand over through
+ * atomic words; sorts and scans around it) -- what cmi_set_ratings uses from 2 M tuples on; element for element the host's result, the
+ * order of librec's MatrixIterator restated, not changed.  CMI_E_UNSUPPORTED: not built (the caller uses cmi_chain_schedule). */
+int cmi_chain_schedule_device(int device, int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub, int max_chain,
+                              int32_t *perm, int32_t *unit_off, int64_t unit_cap, int64_t *level_off, int64_t level_cap,
+                              int64_t *n_units, int64_t *n_levels, int *hub_used);
 
 /* host-only views of two schedule post-passes (tests).  cmi_narrow_runs: run_len[l] > 0 = a run of that many consecutive
  * levels with <= max_tuples tuples each starts at level l and is walked by ONE launch (the library uses 256 / 16), -1 = inside
