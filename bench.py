@@ -72,11 +72,34 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(model, k, data, state, gm, regs, lr, budget_tuples, rank_queries=None):
+def cpu_baseline(model, k, data, state, gm, regs, lr, budget_tuples, rank_queries=None, fold_sets=None, sim=False):
     """The oracle (order-exact fp64 restatement of the Java loop, 1 thread) on a prefix of the same tuples; then five of them
     side by side = what the reference's `cv -k 5 -p on` (one Java thread per fold, CARSKit.java:395-412) gets out of the host.
     rank_queries = (test data, n): the evalRankings baseline instead -- the oracle's predict() per (query, candidate) pair + a stable sort."""
     from oracle import oracle_c
+    if fold_sets is not None:
+        # --workload frappe / depaul: the C restatement on the SAME folds -- fold 0 on one core, then all F folds on F threads
+        def mk(tr, st, gm_):
+            s64 = {n_: np.asarray(a, dtype=np.float64) for n_, a in st.items()}
+            if sim:
+                return oracle_c.SimOracle(model, k, tr.n_users, tr.n_items, tr.n_conds, tr.u, tr.j, tr.ctx, tr.r, tr.ctx_ptr, tr.ctx_conds,
+                                          data.empty_conds, s64, gm_, *regs, n_ctx_dims=tr.n_dims)
+            return oracle_c.Oracle(model, k, tr.n_users, tr.n_items, tr.n_conds, tr.u, tr.j, tr.ctx, tr.r, tr.ctx_ptr, tr.ctx_conds, s64, gm_, *regs)
+        orcs = [mk(*fs) for fs in fold_sets]
+        F, reps, n0 = len(orcs), 10, fold_sets[0][0].n
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            orcs[0].epoch(lr)
+        one = (time.perf_counter() - t0) / reps
+        ths = [threading.Thread(target=lambda o=o: [o.epoch(lr) for _ in range(reps)]) for o in orcs]      # the C call releases the GIL
+        t0 = time.perf_counter()
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        dtF = (time.perf_counter() - t0) / reps
+        return {"value": n0 / one, "unit": "rating-updates/s", "cores": 1, "kind": "port",
+                "sample": "%d epochs of fold 0 (%d tuples), fp64 order-exact C restatement, single thread (host has %d cores)" % (reps, n0, os.cpu_count() or 0),
+                "five_fold": {"value": sum(fs[0].n for fs in fold_sets) / dtF, "cores": F, "seconds": dtF * reps,
+                              "sample": "the same %d folds on %d threads, aggregate updates/s" % (F, F)}}
     if rank_queries is not None:
         test, nq = rank_queries
         orc = oracle_c.Oracle(model, k, data.n_users, data.n_items, data.n_conds, data.u, data.j, data.ctx, data.r, data.ctx_ptr,
@@ -375,30 +398,7 @@ def bench_frappe(args):
                                    "CAMF_C's condBias, the similarity models' shared tables); the whole model is a few MB and cache-resident, "
                                    "HBM is idle -- the fraction is reported for form, the comparison that matters is cpu_baseline"}}
     if not args.no_cpu_baseline:
-        from oracle import oracle_c
-
-        def mk(tr, st, gm):
-            s64 = {n_: np.asarray(a, dtype=np.float64) for n_, a in st.items()}
-            if sim:
-                return oracle_c.SimOracle(model, k, tr.n_users, tr.n_items, tr.n_conds, tr.u, tr.j, tr.ctx, tr.r, tr.ctx_ptr, tr.ctx_conds,
-                                          d.empty_conds, s64, gm, *regs, n_ctx_dims=tr.n_dims)
-            return oracle_c.Oracle(model, k, tr.n_users, tr.n_items, tr.n_conds, tr.u, tr.j, tr.ctx, tr.r, tr.ctx_ptr, tr.ctx_conds, s64, gm, *regs)
-        orcs = [mk(tr, st, gm) for _, tr, st, gm in folds]
-        reps = 10
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            orcs[0].epoch(lr)
-        one = (time.perf_counter() - t0) / reps
-        ths = [threading.Thread(target=lambda o=o: [o.epoch(lr) for _ in range(reps)]) for o in orcs]      # the C call releases the GIL
-        t0 = time.perf_counter()
-        [t.start() for t in ths]
-        [t.join() for t in ths]
-        dtF = (time.perf_counter() - t0) / reps
-        out["cpu_baseline"] = {"value": folds[0][1].n / one, "unit": "rating-updates/s", "cores": 1, "kind": "port",
-                               "sample": "%d epochs of fold 0 (%d tuples), fp64 order-exact C restatement, single thread (host has %d cores)"
-                                         % (reps, folds[0][1].n, os.cpu_count() or 0),
-                               "five_fold": {"value": total / dtF, "cores": F, "seconds": dtF * reps,
-                                             "sample": "the same %d folds on %d threads, aggregate updates/s" % (F, F)}}
+        out["cpu_baseline"] = cpu_baseline(model, k, d, None, 0.0, regs, lr, 0, fold_sets=[(tr, st, gm) for _, tr, st, gm in folds], sim=sim)
         out["vs_cpu_folds"] = out["value"] / out["cpu_baseline"]["five_fold"]["value"]
     for i, _, _, _ in folds:
         i.close()
