@@ -594,7 +594,15 @@ hipError_t RankWorkspace::need(Buf &b, size_t bytes, bool pinned) {
 }
 
 void RankWorkspace::release() {
-    Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount, &dB2, &dA2, &dS2, &dqg, &dqd, &dgu, &ddc, &dscr};
+    Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount, &dB2, &dA2, &dS2, &dqg, &dqd, &dgu, &ddc, &dscr, &dSb, &dAb};
+    if (sel_stream) (void)hipStreamDestroy(sel_stream);
+    sel_stream = nullptr;
+    for (std::vector<hipEvent_t> *v : {&evgemm, &evsel}) {
+        for (hipEvent_t ev : *v) (void)hipEventDestroy(ev);
+        v->clear();
+    }
+    plan_valid = false;
+    for (const void *&r : resident) r = nullptr;
     for (Buf *b : dev) {
         if (b->p) (void)hipFree(b->p);
         *b = Buf();
@@ -823,8 +831,17 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
         if (e == hipSuccess) e = ws.need(b, bytes, pinned);
     };
     need(ws.dB, up128(nc) * a.kp1 * 4);
+    // two streams: the selection of batch b runs beside the contraction of batch b + 1 (matrix pipe beside the L2 / memory pipes), each
+    // batch on the slab / operand buffer of its parity.  CMI_RANK_ONE_STREAM=1: the round-4 form, one stream, one slab (A/B)
+    static const bool one_stream = getenv("CMI_RANK_ONE_STREAM") != nullptr;
+    const bool two = !one_stream && ng > bg;
     need(ws.dA, up128(bg) * a.kp1 * 4);
     need(ws.dS, (size_t)bg * (size_t)nc * 4);
+    if (two) {
+        need(ws.dAb, up128(bg) * a.kp1 * 4);
+        need(ws.dSb, (size_t)bg * (size_t)nc * 4);
+        if (e == hipSuccess && !ws.sel_stream) e = hipStreamCreateWithFlags(&ws.sel_stream, hipStreamNonBlocking);
+    }
     need(ws.dscr, std::max<size_t>(up128(bg), up128(n_dc)) * 4);
     need(ws.drc, (size_t)nq * 4);
     if (s2) {
@@ -855,16 +872,24 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     auto up = [&](void *d, const void *s, size_t bytes) {
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, stream);
     };
-    up(ws.dcand.p, plan.cand.data(), (size_t)nc * 4);
-    up(ws.dqu.p, plan.qu.data(), (size_t)nq * 4);
-    up(ws.dqc.p, plan.qc.data(), (size_t)nq * 4);
-    up(ws.dqg.p, qg.data(), (size_t)nq * 4);
-    up(ws.dgu.p, gu.data(), (size_t)ng * 4);
-    up(ws.dexptr.p, plan.excl_ptr.data(), (size_t)(nq + 1) * 8);
-    up(ws.dexcl.p, plan.excl_idx.data(), plan.excl_idx.size() * 4);
-    if (s2) {
-        up(ws.ddc.p, dctx.data(), (size_t)n_dc * 4);
-        up(ws.dqd.p, qd.data(), (size_t)nq * 4);
+    // the plan's index arrays: already on the device when this is the plan of the previous evaluation (ws.plan_valid: same tuples, by
+    // content hash) and none of their buffers was re-allocated since
+    const void *now[9] = {ws.dcand.p, ws.dqu.p, ws.dqc.p, ws.dqg.p, ws.dgu.p, ws.dexptr.p, ws.dexcl.p, s2 ? ws.ddc.p : nullptr, s2 ? ws.dqd.p : nullptr};
+    bool resident = ws.plan_valid && ws.resident[0] != nullptr;
+    for (int i = 0; i < 9 && resident; ++i) resident = ws.resident[i] == now[i];
+    if (!resident) {
+        up(ws.dcand.p, plan.cand.data(), (size_t)nc * 4);
+        up(ws.dqu.p, plan.qu.data(), (size_t)nq * 4);
+        up(ws.dqc.p, plan.qc.data(), (size_t)nq * 4);
+        up(ws.dqg.p, qg.data(), (size_t)nq * 4);
+        up(ws.dgu.p, gu.data(), (size_t)ng * 4);
+        up(ws.dexptr.p, plan.excl_ptr.data(), (size_t)(nq + 1) * 8);
+        up(ws.dexcl.p, plan.excl_idx.data(), plan.excl_idx.size() * 4);
+        if (s2) {
+            up(ws.ddc.p, dctx.data(), (size_t)n_dc * 4);
+            up(ws.dqd.p, qd.data(), (size_t)nq * 4);
+        }
+        for (int i = 0; i < 9; ++i) ws.resident[i] = now[i];
     }
     lap("uploads");
     int32_t *dtop = (int32_t *)ws.dtop.p, *dcount = (int32_t *)ws.dcount.p;
@@ -889,36 +914,60 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     const auto t_loop = std::chrono::steady_clock::now();
     std::vector<std::pair<int64_t, int64_t>> batches; // all enqueued first, consumed behind the device (see rank_run_device)
     const std::vector<int64_t> cuts = batch_cuts(ng, bg);
+    auto ev_at = [&](std::vector<hipEvent_t> &v, size_t i) -> hipEvent_t {
+        while (v.size() <= i && e == hipSuccess) {
+            hipEvent_t ev = nullptr;
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) v.push_back(ev);
+        }
+        return i < v.size() ? v[i] : nullptr;
+    };
+    hipStream_t sel = two ? ws.sel_stream : stream;
     for (size_t b = 0; b + 1 < cuts.size() && e == hipSuccess; ++b) {
         const int64_t g0 = cuts[b];
         const int n = (int)(cuts[b + 1] - g0);
         const int64_t q0 = gq0[(size_t)g0], q1 = gq0[(size_t)(g0 + n)];
+        float *dAx = (float *)((two && (b & 1)) ? ws.dAb.p : ws.dA.p), *dSx = (float *)((two && (b & 1)) ? ws.dSb.p : ws.dS.p);
+        // the slab of this parity is free once the selection of batch b - 2 has read it
+        if (two && b >= 2 && e == hipSuccess) e = hipStreamWaitEvent(stream, ev_at(ws.evsel, b - 2), 0);
         // (the builder leaves its per-row constant -- zero here -- in the scratch the contraction then reads as its row constant)
-        e = rank_launch_split_users(a, (const int32_t *)ws.dgu.p + g0, n, (float *)ws.dA.p, (float *)ws.dscr.p, stream);
-        if (e == hipSuccess) e = ws.kernel_event(3 * b, stream);
-        if (e == hipSuccess) e = rank_launch_gemm<float>((const float *)ws.dA.p, a.B1, (const float *)ws.dscr.p, (float *)ws.dS.p, n, nc, a.kp1, stream);
-        if (e == hipSuccess) e = ws.kernel_event(3 * b + 1, stream);
+        if (e == hipSuccess) e = rank_launch_split_users(a, (const int32_t *)ws.dgu.p + g0, n, dAx, (float *)ws.dscr.p, stream);
+        if (e == hipSuccess) e = ws.kernel_event(4 * b, stream);
+        if (e == hipSuccess) e = rank_launch_gemm<float>(dAx, a.B1, (const float *)ws.dscr.p, dSx, n, nc, a.kp1, stream);
+        if (e == hipSuccess) e = ws.kernel_event(4 * b + 1, stream);
+        if (two && e == hipSuccess) {
+            hipEvent_t g = ev_at(ws.evgemm, b);
+            if (e == hipSuccess) e = hipEventRecord(g, stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(sel, g, 0);
+        }
+        if (e == hipSuccess) e = ws.kernel_event(4 * b + 2, sel);
         if (e == hipSuccess)
-            e = rank_launch_split_select((const float *)ws.dS.p, s2 ? (const float *)ws.dS2.p : nullptr, a, (const int32_t *)ws.dqg.p,
+            e = rank_launch_split_select(dSx, s2 ? (const float *)ws.dS2.p : nullptr, a, (const int32_t *)ws.dqg.p,
                                          (const int32_t *)ws.dqd.p, (int)g0, (int)q0, (int)(q1 - q0), (const int64_t *)ws.dexptr.p,
-                                         (const int32_t *)ws.dexcl.p, thold, topn, dtop, dscore, dcount, stream);
-        if (e == hipSuccess) e = ws.kernel_event(3 * b + 2, stream);
+                                         (const int32_t *)ws.dexcl.p, thold, topn, dtop, dscore, dcount, sel);
+        if (e == hipSuccess) e = ws.kernel_event(4 * b + 3, sel);
+        if (two && e == hipSuccess) {
+            hipEvent_t sd = ev_at(ws.evsel, b);
+            if (e == hipSuccess) e = hipEventRecord(sd, sel);
+        }
         const size_t nqb = (size_t)(q1 - q0);
         if (e == hipSuccess)
-            e = hipMemcpyAsync((int32_t *)ws.h_top.p + (size_t)q0 * topn, dtop + (size_t)q0 * topn, nqb * topn * 4, hipMemcpyDeviceToHost, stream);
+            e = hipMemcpyAsync((int32_t *)ws.h_top.p + (size_t)q0 * topn, dtop + (size_t)q0 * topn, nqb * topn * 4, hipMemcpyDeviceToHost, sel);
         if (e == hipSuccess)
-            e = hipMemcpyAsync((double *)ws.h_score.p + (size_t)q0 * topn, dscore + (size_t)q0 * topn, nqb * topn * 8, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync((int32_t *)ws.h_count.p + q0, dcount + q0, nqb * 4, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = ws.batch_event(batches.size(), stream);
+            e = hipMemcpyAsync((double *)ws.h_score.p + (size_t)q0 * topn, dscore + (size_t)q0 * topn, nqb * topn * 8, hipMemcpyDeviceToHost, sel);
+        if (e == hipSuccess) e = hipMemcpyAsync((int32_t *)ws.h_count.p + q0, dcount + q0, nqb * 4, hipMemcpyDeviceToHost, sel);
+        if (e == hipSuccess) e = ws.batch_event(batches.size(), sel);
         batches.emplace_back(q0, q1);
     }
+    // the loop ends when the last batch's lists are on the host: ev1 on the main stream, behind the selection stream's last event
+    if (two && e == hipSuccess && !batches.empty()) e = hipStreamWaitEvent(stream, ws.evb[batches.size() - 1], 0);
     if (e == hipSuccess) e = hipEventRecord(ws.ev1, stream);
     e = ws.consume_batches(e, batches, on_batch, t_loop);
     if (e == hipSuccess && ms) e = hipEventElapsedTime(ms, ws.ev0, ws.ev1);
-    for (size_t b = 0; b < batches.size() && e == hipSuccess; ++b) {
+    for (size_t b = 0; b < batches.size() && e == hipSuccess; ++b) { // (with two streams the two kernels' times overlap: their sum exceeds the loop)
         float g = 0.f, t = 0.f;
-        e = hipEventElapsedTime(&g, ws.evk[3 * b], ws.evk[3 * b + 1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&t, ws.evk[3 * b + 1], ws.evk[3 * b + 2]);
+        e = hipEventElapsedTime(&g, ws.evk[4 * b], ws.evk[4 * b + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, ws.evk[4 * b + 2], ws.evk[4 * b + 3]);
         ws.kernel_ms[0] += g;
         ws.kernel_ms[1] += t;
     }
@@ -1133,8 +1182,44 @@ static int eval_rankings_impl(cmi_handle h, int64_t n_train, const int32_t *tu, 
     const auto t_all = std::chrono::steady_clock::now();
     RankWorkspace &ws = h->rank_ws;
     RankPlan &plan = ws.plan; // its arrays keep their capacity between evaluations
-    rank_build_plan(h->n_users, h->n_items, RankTuples{n_train, tu, tj, tctx, tr}, RankTuples{n_test, su, sj, sctx, sr}, bin_thold,
-                    num_ignore, plan);
+    // the same tuples as the previous evaluation (an early-stop loop evaluates after every epoch): the plan is kept.  Identity = sizes +
+    // a 64-bit hash of the arrays' CONTENT (ranges on the host's cores: half a millisecond for 2.5 M tuples against 4 ms for the plan)
+    RankWorkspace::PlanKey key;
+    key.n_train = n_train, key.n_test = n_test, key.n_users = h->n_users, key.n_items = h->n_items, key.bin_thold = bin_thold, key.num_ignore = num_ignore;
+    {
+        struct Arr {
+            const void *p;
+            size_t bytes;
+        } arrs[] = {{tu, (size_t)n_train * 4}, {tj, (size_t)n_train * 4}, {tctx, (size_t)n_train * 4}, {tr, tr ? (size_t)n_train * 8 : 0},
+                    {su, (size_t)n_test * 4},  {sj, (size_t)n_test * 4},  {sctx, (size_t)n_test * 4},  {sr, (size_t)n_test * 8}};
+        uint64_t hsh = 0x9E3779B97F4A7C15ull;
+        for (const Arr &a : arrs) {
+            const int64_t words = (int64_t)(a.bytes / 4);
+            const int nt = host_threads(words / 4);
+            std::vector<uint64_t> part((size_t)nt, 0);
+            const uint32_t *w = (const uint32_t *)a.p;
+            parallel_ranges(words, nt, [&](int t, int64_t b, int64_t e) {
+                uint64_t x = 0xCBF29CE484222325ull ^ (uint64_t)b;
+                for (int64_t i = b; i < e; ++i) {
+                    x ^= w[i];
+                    x *= 0x100000001B3ull;
+                    x ^= x >> 29;
+                }
+                part[(size_t)t] = x;
+            });
+            for (uint64_t x : part) hsh = (hsh ^ x) * 0xFF51AFD7ED558CCDull + (hsh >> 31);
+            hsh ^= a.bytes + (a.p ? 1 : 0);
+        }
+        key.hash = hsh;
+    }
+    if (!(ws.plan_valid && ws.plan_key == key) || getenv("CMI_RANK_NO_PLAN_CACHE")) {
+        ws.plan_valid = false;
+        rank_build_plan(h->n_users, h->n_items, RankTuples{n_train, tu, tj, tctx, tr}, RankTuples{n_test, su, sj, sctx, sr}, bin_thold,
+                        num_ignore, plan);
+        ws.plan_key = key;
+        for (const void *&r : ws.resident) r = nullptr;
+        ws.plan_valid = true;
+    }
     ws.host_ms[0] = ms_since(t_all);
     ws.host_ms[1] = ws.host_ms[2] = ws.host_ms[3] = 0.0;
     ws.kernel_ms[0] = ws.kernel_ms[1] = 0.0;

@@ -51,10 +51,28 @@ struct RankWorkspace {
     };
     Buf dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount; // device
     Buf dB2, dA2, dS2, dqg, dqd, dgu, ddc, dscr;                                // device, split form (rank_run_device_split)
+    Buf dSb, dAb;                                                               // split form: the second slab / operand buffer (batch b + 1 is contracted while batch b is selected)
+    hipStream_t sel_stream = nullptr;                                           // split form: the selection's stream
+    std::vector<hipEvent_t> evgemm, evsel;                                           // per batch: contraction done (main stream), selection done (selection stream)
     Buf h_top, h_score, h_count;                                                // pinned host: the lists as they come back
     RankPlan plan;                                                              // the last evaluation's plan (capacity is reused)
     std::vector<int32_t> v_dctx, v_qd;                                          // split form: context index arrays (capacity is reused)
     bool ctx_ready = false;                                                     // v_dctx / v_qd hold this evaluation's contexts (rank_split_usable)
+    // Repeated evaluations of the same (train, test) tuples (`--early-stop` on a ranking measure evaluates after every epoch,
+    // IterativeRecommender.java:149-161): the plan depends on the tuples alone, so it is kept, keyed by their sizes and a 64-bit
+    // content hash, and so are the index arrays it put on the device.
+    struct PlanKey {
+        int64_t n_train = -1, n_test = -1, n_users = 0, n_items = 0;
+        double bin_thold = 0;
+        int num_ignore = 0;
+        uint64_t hash = 0;
+        bool operator==(const PlanKey &o) const {
+            return n_train == o.n_train && n_test == o.n_test && n_users == o.n_users && n_items == o.n_items && bin_thold == o.bin_thold &&
+                   num_ignore == o.num_ignore && hash == o.hash;
+        }
+    } plan_key;
+    bool plan_valid = false;      // `plan` belongs to plan_key
+    const void *resident[9] = {}; // split form: the device buffers that hold plan_key's index arrays (null: not uploaded)
     struct HostVals { // per-query measures, uninitialised and grow-only (38 MB for 270 K queries: not re-faulted per call)
         std::unique_ptr<double[]> p;
         size_t cap = 0;
