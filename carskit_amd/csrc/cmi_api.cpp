@@ -3,6 +3,7 @@
 // loop, predict/eval.  Compiled by hipcc together with mf_sgd_kernels.hip into libcarskit_mi355x.so.
 // There is deliberately no CPU code path for any compute entry point.
 #include "../../include/carskit_mi355x.h"
+#include "env_knobs.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -551,7 +552,7 @@ static bool try_chain(cmi_instance *h, int64_t n, const int32_t *u, const int32_
     }
     if (!built && !build_chain_schedule(n, u, j, h->n_users, h->n_items, hub, chain_max_len(), csch)) return false;
     int64_t min_width = 2048; // mean units per level
-    if (const char *env = getenv("CMI_CHAIN_MIN_WIDTH")) min_width = atoll(env);
+    if (const char *env = cmi_exp_env("CMI_CHAIN_MIN_WIDTH")) min_width = atoll(env);
     const bool forced = h->flags & CMI_FLAG_SCHED_CHAIN;
     // Narrow levels (heavy-tailed degrees, tiny data) keep the plain levels and their narrow-run launches: measured on C3-size
     // Zipf(0.8) items, the chain schedule has 2.5x fewer levels (434 K vs 1.10 M) but a narrow chain level is latency-bound on
@@ -661,7 +662,7 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
     ChainSchedule csch;
     OwnerSchedule osch;
     const bool chain_ok = !h->serial && !h->want_owner && !(h->flags & CMI_FLAG_NO_CHAIN) &&
-                          has_chain_path(h->model, h->k, dmax, h->n_conds, h->f64, h->strict) && !getenv("CMI_NO_CHAIN");
+                          has_chain_path(h->model, h->k, dmax, h->n_conds, h->f64, h->strict) && !cmi_exp_env("CMI_NO_CHAIN");
     if ((h->flags & CMI_FLAG_SCHED_CHAIN) && !chain_ok)
         CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: CMI_FLAG_SCHED_CHAIN: no hub-chain kernel for model %d, k=%d, %s state%s (or another "
                  "schedule flag is set)", h->model, h->k, h->f64 ? "fp64" : "fp32", h->strict ? ", strict" : "");
@@ -693,12 +694,12 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
             if (ptr) (void)hipFree(ptr);
         }
     } spec;
-    if (!h->serial && chain_ok && n >= ((int64_t)1 << 21) && !(h->flags & CMI_FLAG_NO_ARENA) && !getenv("CMI_NO_ARENA") && h->k >= 64 &&
+    if (!h->serial && chain_ok && n >= ((int64_t)1 << 21) && !(h->flags & CMI_FLAG_NO_ARENA) && !cmi_exp_env("CMI_NO_ARENA") && h->k >= 64 &&
         h->k % (h->f64 ? 2 : 4) == 0) {
         const size_t row = (size_t)h->k * esize(h), arena_bytes = (size_t)n * row;
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        const bool likely = (h->flags & CMI_FLAG_SPOKE_ARENA) || getenv("CMI_ARENA") || (size_t)std::max(h->n_users, h->n_items) * row >= ((size_t)2 << 30);
+        const bool likely = (h->flags & CMI_FLAG_SPOKE_ARENA) || cmi_exp_env("CMI_ARENA") || (size_t)std::max(h->n_users, h->n_items) * row >= ((size_t)2 << 30);
         if (likely && (double)arena_bytes <= 0.6 * (double)free_b) {
             spec.bytes = arena_bytes;
             const int dev = h->device;
@@ -721,14 +722,14 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         h->sched_note = "narrow dependency levels on a large data set (heavy-tailed degrees?) and no owner kernel for this configuration "
                         "(limits: <= 384 conditions, k <= 256 (fp64: 128)): the level walk runs -- order-exact, roughly 10x slower on such data";
     if (!use_owner && !use_chain && !h->serial && !(h->flags & (CMI_FLAG_SCHED_CHAIN | CMI_FLAG_NO_OWNER)) &&
-        !getenv("CMI_NO_OWNER") && has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict)) {
+        !cmi_exp_env("CMI_NO_OWNER") && has_owner_path(h->model, h->k, h->n_conds, h->f64, h->strict)) {
         // Narrow levels on a large data set = heavy-tailed degrees: every level costs a kernel boundary or a workgroup barrier (>= 2 us),
         // and there are at least as many levels as the hottest row has tuples.  The owner epoch pays ~0.3 us per tuple of the hottest
         // row it owns and a hand-off (0.86 us measured, tools/exp_owner_handoff.py) per tuple of the hottest row on the other side,
         // plus ~0.3 ms for the tag / untag passes and the launch.  Taken for heavy-tailed data when that is at least twice faster
         // (measured: 3.3-3.7x at 100 K - 800 K ratings with Zipf(1.1) items, tests/tools/bench_zipf_small.py).
         int64_t min_tuples = (int64_t)1 << 16;
-        if (const char *env = getenv("CMI_OWNER_MIN_TUPLES")) min_tuples = atoll(env);
+        if (const char *env = cmi_exp_env("CMI_OWNER_MIN_TUPLES")) min_tuples = atoll(env);
         if (n >= min_tuples) {
             std::vector<int32_t> du((size_t)h->n_users, 0), dj((size_t)h->n_items, 0);
             for (int64_t t = 0; t < n; ++t) {
@@ -857,7 +858,7 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
                 CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: schedule construction failed");
         }
 #ifdef CMI_TIMING_EXPERIMENTS // never in a release build: merging dependent levels gives WRONG results (boundary-cost timing only)
-        if (const char *env = getenv("CMI_DEBUG_MERGE_LEVELS")) {
+        if (const char *env = cmi_exp_env("CMI_DEBUG_MERGE_LEVELS")) {
             const int m = atoi(env);
             if (m > 1) {
                 fprintf(stderr, "[cmi] CMI_DEBUG_MERGE_LEVELS=%d: dependent levels merged, results are WRONG (timing experiment)\n", m);
@@ -876,7 +877,7 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         // tuples each is walked by ONE single-workgroup launch instead of one launch per level
         h->tail_len.assign((size_t)n_levels, 0);
         h->n_launches = 0;
-        if (!h->serial && !h->chain && !getenv("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 256, 16, h->tail_len);
+        if (!h->serial && !h->chain && !cmi_exp_env("CMI_NO_TAIL")) build_narrow_runs(h->level_off, 256, 16, h->tail_len);
         h->slot_off.assign((size_t)n_levels + 1, 0);
         for (int64_t l = 0; l < n_levels; ++l) {
             const int cnt = (int)(h->level_off[(size_t)l + 1] - h->level_off[(size_t)l]);
@@ -967,7 +968,7 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
     free_keep(keep);
     if (e == hipSuccess && h->chain) e = upload((void **)&h->d_unit_off, csch.unit_off, h->stream);
     lap("uploads");
-    if (e == hipSuccess && h->chain && !(h->flags & CMI_FLAG_NO_ARENA) && !getenv("CMI_NO_ARENA") && h->k >= 64 && h->k % (h->f64 ? 2 : 4) == 0) {
+    if (e == hipSuccess && h->chain && !(h->flags & CMI_FLAG_NO_ARENA) && !cmi_exp_env("CMI_NO_ARENA") && h->k >= 64 && h->k % (h->f64 ? 2 : 4) == 0) {
         // Spoke arena (SgdArgs::arena): worth its memory when the spoke table is large -- random 512-B rows over >= 2 GiB run at ~0.5 of
         // the HBM peak (address-translation misses, DRAM page misses), sequential reads + random full-line writes at ~0.7
         // (tools/micro/row_bias.hip: 4.10 vs 5.73 TB/s) -- and smaller tables gain nothing (5.58 vs 5.61).
@@ -975,7 +976,7 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         const size_t table_bytes = (size_t)spokes * (size_t)h->k * esize(h), arena_bytes = (size_t)n * (size_t)h->k * esize(h);
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        const bool forced = (h->flags & CMI_FLAG_SPOKE_ARENA) || getenv("CMI_ARENA");
+        const bool forced = (h->flags & CMI_FLAG_SPOKE_ARENA) || cmi_exp_env("CMI_ARENA");
         const bool large = table_bytes >= ((size_t)2 << 30) && (double)arena_bytes <= 0.6 * (double)free_b;
         // In between (spoke tables of 256 MiB .. 2 GiB: BASELINE C5's share has a 1-GiB Q) the better form depends on the BOX: the same
         // library measures the arena 9 % faster on some MI355X boxes of the pool and 4 % slower on others.  There

@@ -1,5 +1,6 @@
 // fm_api.cpp -- C ABI of the FM recommender (include/carskit_mi355x.h, cmi_fm_*).
 #include "../../include/carskit_mi355x.h"
+#include "env_knobs.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -146,7 +147,7 @@ extern "C" int cmi_fm_create(int k, int n_users, int n_items, int n_conds, int n
     if (const char *v = getenv("CMI_FM_SLICE")) h->slice_entries = atoll(v); // experiment knob: 0 = one slice
     if (const char *v = getenv("CMI_FM_BATCH")) h->batch_cap = std::max(1, std::min(atoi(v), FMC_RCAP));
     if (const char *v = getenv("CMI_FM_SLOTS")) h->slot_cap = std::max((FMC_RCAP + FMC_RUN - 1) / FMC_RUN, std::min(atoi(v), FMC_SLOTS));
-    if (const char *v = getenv("CMI_FM_HSPLIT")) h->h_split = std::max(0, std::min(atoi(v), 8));
+    if (const char *v = cmi_exp_env("CMI_FM_HSPLIT")) h->h_split = std::max(0, std::min(atoi(v), 8));
     h->k = k;
     h->n_users = n_users;
     h->n_items = n_items;

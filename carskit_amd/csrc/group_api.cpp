@@ -16,6 +16,7 @@
 // the in-process exchange instead: the buckets are summed in shard order on shard 0's stream and copied back (peer copies) --
 // the same arithmetic, no communicator.
 #include "../../include/carskit_mi355x.h"
+#include "env_knobs.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -283,7 +284,7 @@ extern "C" int cmi_group_set_ratings(cmi_group_handle g, int64_t n, const int32_
     bool distinct = true;
     for (int a = 0; a < W; ++a)
         for (int b = a + 1; b < W; ++b) distinct = distinct && g->dev[(size_t)a] != g->dev[(size_t)b];
-    g->rccl = distinct && !getenv("CMI_GROUP_NO_RCCL");
+    g->rccl = distinct && !cmi_exp_env("CMI_GROUP_NO_RCCL");
     g->ev.assign((size_t)W + 1, nullptr);
     for (int s = 0; s <= W; ++s) { // ev[W] belongs to shard 0's device
         GRP_HIP(g, hipSetDevice(g->dev[s == W ? 0 : (size_t)s]));

@@ -21,6 +21,7 @@
 // Built with -ffp-contract=off: the JVM never fuses a*b+c, and the strict fp64 path is bit-compared
 // with the CPU oracle.
 #include "mf_sgd_kernels.hpp"
+#include "env_knobs.hpp"
 #include "sgd_device.hpp"
 
 #include <cstdlib>
@@ -1052,14 +1053,14 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs<T> a, int64_t n) {
 // ---------------------------------------------------------------------------------------------
 
 static bool level_coherent() { // experiment: device-coherent model traffic in the level kernel (k = 128, tables < 4 GiB)
-    static const bool on = getenv("CMI_LEVEL_COHERENT") != nullptr;
+    static const bool on = cmi_exp_env("CMI_LEVEL_COHERENT") != nullptr;
     return on;
 }
 static int g_fast_tpg = -1;
 static int fast_tpg() { // tuples per 16-lane group (CMI_LEVEL_TPG overrides for experiments)
     if (g_fast_tpg < 0) {
         int v = 2;
-        if (const char *env = getenv("CMI_LEVEL_TPG")) v = atoi(env);
+        if (const char *env = cmi_exp_env("CMI_LEVEL_TPG")) v = atoi(env);
         g_fast_tpg = (v == 1 || v == 2 || v == 4) ? v : 2;
     }
     return g_fast_tpg;
@@ -1083,7 +1084,7 @@ int small_lpt(int k, int dmax) {
 }
 bool has_small_path(int k, int dmax, bool f64, const LaunchCfg &cfg) {
     if (f64 || cfg.strict || cfg.model == CAMF_C) return false;
-    if (getenv("CMI_NO_SMALL_K")) return false; // A/B experiments
+    if (cmi_exp_env("CMI_NO_SMALL_K")) return false; // A/B experiments
     return k < 64 && dmax <= 16;
 }
 constexpr int SMALL_TPG = 2;
@@ -1590,7 +1591,7 @@ static hipError_t launch_serial_model(const SgdArgs<T> &a, const LaunchCfg &cfg,
         hipLaunchKernelGGL((sgd_serial<T, MODEL, true>), dim3(1), dim3(64), 0, s, a, n, loss_out);
     else if (MODEL == CAMF_C && camfc_pipe_supported(a.k, a.n_conds, a.dmax))
         return launch_camfc_pipe<T>(a, n, loss_out, s);
-    else if (a.k <= 256 && lds <= 64 * 1024 && !getenv("CMI_SERIAL_GENERIC")) {
+    else if (a.k <= 256 && lds <= 64 * 1024 && !cmi_exp_env("CMI_SERIAL_GENERIC")) {
         if (a.k == 64) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 1, true>), dim3(1), dim3(64), lds, s, a, n, loss_out);
         else if (a.k == 128) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 2, true>), dim3(1), dim3(64), lds, s, a, n, loss_out);
         else if (a.k == 256) hipLaunchKernelGGL((sgd_serial_fast<T, MODEL, 4, true>), dim3(1), dim3(64), lds, s, a, n, loss_out);

@@ -21,6 +21,7 @@
 // workgroup per owner whose three wavefronts split the step (owner_team: loader -> LDS ring -> compute -> LDS ring -> storer).
 // With CMI_FLAG_STRICT (fp64) the step uses the reference's operation order throughout and the model is bit-identical to the oracle's.
 #include "sgd_device.hpp"
+#include "env_knobs.hpp"
 #include "level_schedule.hpp"
 
 #include <hip/hip_runtime.h>
@@ -969,7 +970,7 @@ int owner_grid_waves(int device, int model, int n_conds, int k, bool f64, bool h
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) return 0;
     if (per_cu > 1) per_cu = 1; // __launch_bounds__(256, 1): one owner per SIMD, the whole register file for its read-ahead
-    if (const char *env = getenv("CMI_OWNER_BLOCKS_PER_CU")) {
+    if (const char *env = cmi_exp_env("CMI_OWNER_BLOCKS_PER_CU")) {
         const int v = atoi(env);
         if (v >= 1 && v < per_cu) per_cu = v;
     }

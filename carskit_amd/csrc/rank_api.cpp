@@ -3,6 +3,7 @@
 // Host side: query / candidate / exclusion bookkeeping and the (tiny, per-query) metric formulas; device side:
 // rank_kernels.hip.  No CPU scoring path exists.
 #include <algorithm>
+#include "env_knobs.hpp"
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -833,7 +834,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     need(ws.dB, up128(nc) * a.kp1 * 4);
     // two streams: the selection of batch b runs beside the contraction of batch b + 1 (matrix pipe beside the L2 / memory pipes), each
     // batch on the slab / operand buffer of its parity.  CMI_RANK_ONE_STREAM=1: the round-4 form, one stream, one slab (A/B)
-    static const bool one_stream = getenv("CMI_RANK_ONE_STREAM") != nullptr;
+    static const bool one_stream = cmi_exp_env("CMI_RANK_ONE_STREAM") != nullptr;
     const bool two = !one_stream && ng > bg;
     need(ws.dA, up128(bg) * a.kp1 * 4);
     need(ws.dS, (size_t)bg * (size_t)nc * 4);
@@ -1212,7 +1213,7 @@ static int eval_rankings_impl(cmi_handle h, int64_t n_train, const int32_t *tu, 
         }
         key.hash = hsh;
     }
-    if (!(ws.plan_valid && ws.plan_key == key) || getenv("CMI_RANK_NO_PLAN_CACHE")) {
+    if (!(ws.plan_valid && ws.plan_key == key) || cmi_exp_env("CMI_RANK_NO_PLAN_CACHE")) {
         ws.plan_valid = false;
         rank_build_plan(h->n_users, h->n_items, RankTuples{n_train, tu, tj, tctx, tr}, RankTuples{n_test, su, sj, sctx, sr}, bin_thold,
                         num_ignore, plan);

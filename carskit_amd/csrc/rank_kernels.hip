@@ -14,6 +14,7 @@
 // Top-N: one wave64 per query row repeatedly extracts the row maximum (ties -> lowest candidate index, which
 // reproduces the reference's stable descending sort over its candidate iteration order).
 #include <hip/hip_runtime.h>
+#include "env_knobs.hpp"
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -552,7 +553,7 @@ hipError_t rank_launch_build_queries(const RankQueryArgs<T> &a, int nq, hipStrea
 template <typename T>
 hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s) {
     if (nq <= 0 || nc <= 0) return hipSuccess;
-    static const bool force_valu = getenv("CMI_RANK_VALU") != nullptr; // A/B experiments only
+    static const bool force_valu = cmi_exp_env("CMI_RANK_VALU") != nullptr; // A/B experiments only
     if constexpr (sizeof(T) == 4) {
         if (!force_valu && kp % RG_BK == 0) {
             const int tiles_c = (nc + RG_BN - 1) / RG_BN, n_tiles = tiles_c * ((nq + RG_BM - 1) / RG_BM);

@@ -15,6 +15,7 @@
 // Per element the expressions are ext_serial_wave's; dots and the prediction are tree sums.  A user whose rows do not fit the LDS budget
 // (or whose ratings do not arrive as one run) is walked by wave 0 with ext_serial_wave's code.
 #include "mf_sgd_kernels.hpp"
+#include "env_knobs.hpp"
 #include "sgd_device.hpp"
 
 #include <cmath>
@@ -301,7 +302,7 @@ hipError_t launch_svdpp_team(const ExtArgs<T> &a, int64_t n, double *loss_out, h
     // team size: 1024 threads measured fastest (measured on a stream of one-rating runs: 2.9 / 3.8 / 5.1 us per rating at k = 10 / 64 / 128 against 3.2 / 5.7 / 9.1 with
     // 256 threads) although a link is only ~375 instructions per wave: the wide parts (|N(u)| k element updates, one group per row) win more
     // from 16 waves than the uniform part loses; CMI_SVDPP_THREADS=256|512 for A/B runs
-    const char *env = getenv("CMI_SVDPP_THREADS");
+    const char *env = cmi_exp_env("CMI_SVDPP_THREADS");
     int nt = env ? atoi(env) : 1024;
     if (nt < a.k) nt = a.k <= 256 ? 256 : a.k <= 512 ? 512 : 1024;
 #define CMI_SVDPP_LAUNCH(NTV)                                                                                                             \
