@@ -26,10 +26,8 @@ using namespace cmi;
 // one field's stream on the device (fm_kernels.hpp FmOrder) and what owns it
 struct FmOrderDev {
     FmRec *rec = nullptr;
-    int32_t *piece_off = nullptr, *xoff = nullptr;
-    FmChunk *chunks = nullptr;
-    double2 *partial = nullptr;
-    int32_t n_chunks = 0, count = 0, S = 1, n_x = 0;
+    int32_t *piece_off = nullptr;
+    int32_t count = 0;
     int64_t n_rec = 0;
 };
 
@@ -54,7 +52,7 @@ struct cmi_fm_instance {
     double *d_r = nullptr, *d_part = nullptr, *d_scratch = nullptr, *d_E = nullptr;
     double2 *d_tab = nullptr;
     int32_t *d_u = nullptr, *d_j = nullptr, *d_ctx = nullptr, *d_src[3] = {nullptr, nullptr, nullptr};
-    FmOrderDev ord[3];   // [2] only: the context field keeps the per-wave chunk stream
+    FmOrderDev ord[3];   // [2] only: the context field (records sorted by feature, a wave per feature)
     FmCellsDev cell[2];  // users, items
     int h_split = 0; // CMI_FM_HSPLIT: id-range parts per group (0 = chosen from the geometry)
     int batch_cap = FMC_RCAP, slot_cap = FMC_SLOTS; // experiment / test knobs (CMI_FM_BATCH, CMI_FM_SLOTS): smaller batches and blocks on small data
@@ -101,7 +99,7 @@ static void fm_free_ratings(cmi_fm_instance *h) {
         c = FmCellsDev();
     }
     for (FmOrderDev &o : h->ord) {
-        void *q[] = {o.rec, o.piece_off, o.xoff, o.chunks, o.partial};
+        void *q[] = {o.rec, o.piece_off};
         for (void *p : q)
             if (p) (void)hipFree(p);
         o = FmOrderDev();
@@ -237,68 +235,28 @@ static hipError_t up(T **dst, const std::vector<T> &v, hipStream_t s) {
 // ---- the three streams (fm_kernels.hpp FmOrder), built once per cmi_fm_set_ratings ------------------------------------
 struct FmOrderHost {
     std::vector<FmRec> rec;      // err0 is filled by cmi_fm_init on the device
-    std::vector<int32_t> piece_off, xoff, src; // src[pos] = index of the rating in the caller's arrays
-    std::vector<FmChunk> chunks;
-    int S = 1, count = 0, n_x = 0;
+    std::vector<int32_t> piece_off, src; // src[pos] = index of the rating in the caller's arrays
+    int count = 0;
 };
 
-// key[t]: this field's coordinate of rating t (or < 0: the rating is not in this field's support); other[t]: the id whose
-// table entries the stream gathers -- the order is sorted by (slice of other, key), stable in the caller's order; third[t]:
-// the record's second id.
-static void fm_build_order(int64_t n, const int32_t *key, const int32_t *other, const int32_t *third, int count, int other_count,
-                           int64_t slice_entries, FmOrderHost &o) {
-    int64_t in_support = 0;
-    for (int64_t t = 0; t < n; ++t) in_support += key[t] >= 0;
-    // as many slices as keep the gathered table entries L2-resident, but never so many that the pieces shrink below ~4 records
-    int64_t S = slice_entries > 0 ? (other_count + slice_entries - 1) / slice_entries : 1;
-    const int64_t avg = count > 0 ? in_support / count : 0;
-    S = std::max<int64_t>(1, std::min<int64_t>(S, avg / 4));
-    while (S > 1 && S * (int64_t)count >= ((int64_t)1 << 31) - 1) --S;
-    const int64_t slice_len = (other_count + S - 1) / S;
-    o.S = (int)S;
+// The context field's stream: the ratings whose key[t] >= 0 (a context feature exists), sorted by key, stable in the caller's order;
+// a record carries the rating's user (a) and item (c).
+static void fm_build_order(int64_t n, const int32_t *key, const int32_t *a_id, const int32_t *c_id, int count, FmOrderHost &o) {
     o.count = count;
-    const int64_t P = S * (int64_t)count;
-    o.piece_off.assign((size_t)P + 1, 0);
-    auto piece = [&](int64_t t) { return (int64_t)(other[t] / slice_len) * count + key[t]; };
+    o.piece_off.assign((size_t)count + 1, 0);
     for (int64_t t = 0; t < n; ++t)
-        if (key[t] >= 0) o.piece_off[(size_t)piece(t) + 1]++;
-    for (int64_t p = 0; p < P; ++p) o.piece_off[(size_t)p + 1] += o.piece_off[(size_t)p];
-    o.rec.resize((size_t)in_support);
-    o.src.resize((size_t)in_support);
-    {
-        std::vector<int32_t> cur(o.piece_off.begin(), o.piece_off.end() - 1);
-        for (int64_t t = 0; t < n; ++t) {
-            if (key[t] < 0) continue;
-            const int32_t pos = cur[(size_t)piece(t)]++;
-            o.rec[(size_t)pos] = FmRec{0.0, other[t], third[t]};
-            o.src[(size_t)pos] = (int32_t)t;
-        }
+        if (key[t] >= 0) o.piece_off[(size_t)key[t] + 1]++;
+    for (int l = 0; l < count; ++l) o.piece_off[(size_t)l + 1] += o.piece_off[(size_t)l];
+    const size_t in_support = (size_t)o.piece_off[(size_t)count];
+    o.rec.resize(in_support);
+    o.src.resize(in_support);
+    std::vector<int32_t> cur(o.piece_off.begin(), o.piece_off.end() - 1);
+    for (int64_t t = 0; t < n; ++t) {
+        if (key[t] < 0) continue;
+        const int32_t pos = cur[(size_t)key[t]]++;
+        o.rec[pos] = FmRec{0.0, a_id[t], c_id[t]};
+        o.src[pos] = (int32_t)t;
     }
-    // chunks, in storage (slice-major) order.  Runs of pieces without records produce no chunk: their partial slots
-    // stay at the zero they were allocated with.
-    std::vector<int32_t> xcount((size_t)count + 1, 0);
-    const std::vector<int32_t> &off = o.piece_off;
-    for (int64_t p = 0; p < P;) {
-        const int32_t len = off[(size_t)p + 1] - off[(size_t)p];
-        if (len > FM_SHORT) {
-            for (int32_t r0 = off[(size_t)p]; r0 < off[(size_t)p + 1]; r0 += FM_VECTOR) {
-                o.chunks.push_back(FmChunk{(int32_t)p, -1, r0, std::min<int32_t>(r0 + FM_VECTOR, off[(size_t)p + 1])});
-                xcount[(size_t)(p % count) + 1]++;
-            }
-            ++p;
-            continue;
-        }
-        const int64_t p0 = p;
-        const int32_t rec0 = off[(size_t)p];
-        while (p < P && p - p0 < 64 && off[(size_t)p + 1] - off[(size_t)p] <= FM_SHORT && off[(size_t)p + 1] - rec0 <= FM_CHUNK) ++p;
-        if (off[(size_t)p] > rec0) o.chunks.push_back(FmChunk{(int32_t)p0, (int32_t)(p - p0), rec0, off[(size_t)p]});
-    }
-    for (int l = 0; l < count; ++l) xcount[(size_t)l + 1] += xcount[(size_t)l];
-    o.xoff = xcount;
-    o.n_x = xcount[(size_t)count];
-    std::vector<int32_t> cur(xcount.begin(), xcount.end() - 1);
-    for (FmChunk &c : o.chunks)
-        if (c.n < 0) c.n = -(cur[(size_t)(c.piece0 % count)]++) - 1;
 }
 
 // ---- the cell stream of fields 0 / 1 (fm_kernels.hpp FmCells), built once per cmi_fm_set_ratings -----------------------------------
@@ -595,17 +553,9 @@ static hipError_t fm_upload_cells(const FmCellsHost &o, FmCellsDev &d, hipStream
 
 static hipError_t fm_upload_order(const FmOrderHost &o, FmOrderDev &d, hipStream_t s) {
     d.count = o.count;
-    d.S = o.S;
-    d.n_x = o.n_x;
-    d.n_chunks = (int32_t)o.chunks.size();
     d.n_rec = (int64_t)o.rec.size();
     hipError_t e = up(&d.rec, o.rec, s);
     if (e == hipSuccess) e = up(&d.piece_off, o.piece_off, s);
-    if (e == hipSuccess) e = up(&d.xoff, o.xoff, s);
-    if (e == hipSuccess) e = up(&d.chunks, o.chunks, s);
-    const size_t slots = (size_t)o.S * o.count + o.n_x;
-    if (e == hipSuccess && slots > 0) e = hipMalloc((void **)&d.partial, slots * sizeof(double2));
-    if (e == hipSuccess && slots > 0) e = hipMemsetAsync(d.partial, 0, slots * sizeof(double2), s);
     return e;
 }
 
@@ -632,7 +582,7 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
         auto ctx_order = [&]() {
             // context features: only ratings whose context-combination id is < numConditions have one (FM.java:81-86)
             for (int64_t t = 0; t < n; ++t) ckey[(size_t)t] = ctx[t] < h->n_conds ? ctx[t] : -1;
-            fm_build_order(n, ckey.data(), u, j, h->n_conds, h->n_users, 0, oc);
+            fm_build_order(n, ckey.data(), u, j, h->n_conds, oc);
         };
         std::thread ti, tc;
         bool hi = true, hc = true;
@@ -690,7 +640,7 @@ static FmArgs fm_args(cmi_fm_instance *h) {
     a.tab = h->d_tab;
     for (int f = 0; f < 3; ++f) {
         const FmOrderDev &d = h->ord[f];
-        a.ord[f] = FmOrder{d.rec, d.piece_off, d.chunks, d.xoff, d.partial, d.n_chunks, d.count, d.S, d.n_x, d.n_rec};
+        a.ord[f] = FmOrder{d.rec, d.piece_off, d.count, d.n_rec};
     }
     a.ord[0].count = h->n_users; // (fields 0 / 1 stream cells; the apply kernel reads `count`)
     a.ord[1].count = h->n_items;
@@ -877,11 +827,9 @@ extern "C" int cmi_fm_layout(cmi_fm_handle h, int64_t out[12]) {
     }
     {
         const FmOrderDev &o = h->ord[2];
-        const int64_t slots = (int64_t)o.S * o.count + o.n_x;
-        red[2] = o.n_rec * 16 + ((int64_t)o.S * o.count + 1) * 4 + (int64_t)o.n_chunks * 16 + (int64_t)o.count * 16 + slots * 16;
-        factor += red[2] + slots * 16 + (int64_t)o.count * (16 + 16 + 8);
+        red[2] = o.n_rec * (16 + 2 * 16 + 2 * 8) + ((int64_t)o.count + 1) * 4 + (int64_t)o.count * (16 + 16 + 8 + 8); // records + their gathers, entries
+        factor += red[2];
     }
-    factor += h->p * (8 + 16 + 16); // column load: Vt row read, table entries read-modify-written
     out[0] = h->cell[0].S;
     out[1] = h->cell[1].S;
     out[2] = h->cell[0].n_rec;

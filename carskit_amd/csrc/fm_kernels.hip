@@ -32,8 +32,8 @@
 //     share), park {e', h} in LDS at the record's position in coordinate order, and add the runs into register accumulators that
 //     live for the whole group: 12-byte records, no per-piece partial sums through memory, the coordinate update in the same launch
 //     (or one small kernel where a coordinate's sums come from several workgroups).  122-136 us per launch box to box, 19.2 ms per sweep.
-//   * the context field (a few records in a thousand) keeps round 4's form: 16-byte records, a wave per chunk, CSR-stream reduction
-//     (a lane per piece out of LDS; pieces longer than 64 records are vector chunks that all 64 lanes reduce).
+//   * the context field (a few records in a thousand): 16-byte records sorted by feature, one wave per feature, reduce + update in one
+//     launch (fm_ctx_kernel).
 // Deterministic: every sum is added in a fixed order that depends on the data layout alone.  fp64 throughout; gather / stream
 // work: no MFMA.
 //
@@ -131,98 +131,6 @@ __device__ __forceinline__ void fm_rec_eval(const FmArgs &a, int f, const FmRec 
         }
 #pragma unroll
         for (int q = 0; q < N; ++q) h[q] = f < 0 ? 1.0 : other[q];
-    }
-}
-
-// W0: the w0 phase's sum over the user order: partial.x = sum(err_i - w0) per piece (FM.java:153-158).
-template <int FIELD, bool W0>
-__global__ __launch_bounds__(256) void fm_reduce_kernel(FmArgs a, int f) {
-    __shared__ double2 lds[4][FM_CHUNK];
-    const FmOrder &o = a.ord[FIELD];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // XCD x takes the x-th contiguous eighth of the chunks (workgroup ids are dealt round-robin to the XCDs): an XCD then stays inside one
-    // slice of the gathered table for an eighth of the launch instead of all eight XCDs sweeping every slice together (A/B on one box,
-    // two runs each: reduce launch 164.2 / 165.9 us -> 160.5 / 161.7 us, sweep 24.63 -> 24.14 ms)
-    const int per = (int)gridDim.x / 8; // (the grid is a multiple of 8 workgroups)
-    const int ci = (((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3)) * 4 + wave;
-    if (ci >= o.n_chunks) return; // waves are independent: no workgroup barrier below
-    const FmChunk ch = o.chunks[ci];
-    const double d0 = *a.d0;
-    const int64_t base = fm_base(a, FIELD);
-    if (ch.n >= 0) {
-        const bool own = lane < ch.n;
-        int b = 0, e = 0;
-        double theta = 0.0, dl = 0.0;
-        if (own) {
-            b = o.piece_off[ch.piece0 + lane];
-            e = o.piece_off[ch.piece0 + lane + 1];
-            const int l = (ch.piece0 + lane) % o.count;
-            const double2 t = a.tab[base + l];
-            theta = W0 ? *a.w0 : fm_theta(a, f, base + l);
-            dl = FIELD == 2 ? a.xc * t.y : t.y; // the support's errors moved by delta * x_il
-        }
-        // all four record loads first (clamped, so no branch splits them), then the gathers, then LDS
-        FmRec rr[FM_CHUNK / 64];
-#pragma unroll
-        for (int r4 = 0; r4 < FM_CHUNK / 64; ++r4) {
-            const int i = ch.rec0 + r4 * 64 + lane;
-            rr[r4] = fm_load_rec(o.rec, i < ch.rec1 ? i : ch.rec1 - 1);
-        }
-        double ep[FM_CHUNK / 64], hh[FM_CHUNK / 64];
-        fm_rec_eval<FIELD>(a, f, rr, d0, ep, hh);
-#pragma unroll
-        for (int r4 = 0; r4 < FM_CHUNK / 64; ++r4)
-            if (ch.rec0 + r4 * 64 + lane < ch.rec1) lds[wave][r4 * 64 + lane] = make_double2(ep[r4], hh[r4]);
-        // the wave reads what its own lanes wrote: LDS operations of one wave complete in order, the compiler must not move them
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (own) {
-            double num = 0.0, den = 0.0;
-            for (int i = b; i < e; ++i) {
-                const double2 v = lds[wave][i - ch.rec0];
-                const double et = v.x + dl;
-                if (W0) {
-                    num += et - theta;
-                } else {
-                    num += (et - theta * v.y) * v.y;
-                    den += v.y * v.y;
-                }
-            }
-            o.partial[ch.piece0 + lane] = make_double2(num, den);
-        }
-    } else {
-        const int l = ch.piece0 % o.count;
-        const double2 t = a.tab[base + l];
-        const double theta = W0 ? *a.w0 : fm_theta(a, f, base + l), dl = FIELD == 2 ? a.xc * t.y : t.y;
-        double num = 0.0, den = 0.0;
-        for (int i0 = ch.rec0; i0 < ch.rec1; i0 += 4 * 64) { // a lane sums its records (stride 64) in order
-            FmRec rr[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = i0 + q * 64 + lane;
-                rr[q] = fm_load_rec(o.rec, i < ch.rec1 ? i : ch.rec1 - 1);
-            }
-            double ep[4], hh[4];
-            fm_rec_eval<FIELD>(a, f, rr, d0, ep, hh);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (i0 + q * 64 + lane >= ch.rec1) continue;
-                const double et = ep[q] + dl;
-                if (W0) {
-                    num += et - theta;
-                } else {
-                    num += (et - theta * hh[q]) * hh[q];
-                    den += hh[q] * hh[q];
-                }
-            }
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            num += __shfl_xor(num, m, 64);
-            den += __shfl_xor(den, m, 64);
-        }
-        if (lane == 0) o.partial[(int64_t)o.S * o.count + (-ch.n - 1)] = make_double2(num, den);
     }
 }
 
@@ -431,40 +339,45 @@ __global__ __launch_bounds__(256) void fm_cplx_kernel(FmArgs a, int f, int fused
     fm_coord_out<FIELD>(a, f, l, A, B, C, fused != 0);
 }
 
-// mode 0: partial -> part (num | den); 1: part -> coordinate update; 2: both.  The update (FM.java:181-190, 201-211):
-// theta' = -num / (den + size*reg); D[l] += theta' - theta (the errors of the support move by delta * x_il, folded in
-// wherever errors are read).
+// part ([num | den] of the phase's field, all-reduced by a multi-GPU host) -> the coordinate update
 template <int FIELD>
-__global__ __launch_bounds__(256) void fm_finish_kernel(FmArgs a, int f, int mode) {
-    const FmOrder &o = a.ord[FIELD];
+__global__ __launch_bounds__(256) void fm_apply_kernel(FmArgs a, int f) {
     const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= o.count) return;
-    double num, den;
-    if (mode != 1) {
-        num = 0.0;
-        den = 0.0;
-        for (int s = 0; s < o.S; ++s) {
-            const double2 p = o.partial[(int64_t)s * o.count + l];
-            num += p.x;
-            den += p.y;
-        }
-        const int64_t grid = (int64_t)o.S * o.count;
-        for (int x = o.xoff[l]; x < o.xoff[l + 1]; ++x) {
-            const double2 p = o.partial[grid + x];
-            num += p.x;
-            den += p.y;
-        }
-        if (mode == 0) {
-            a.part[l] = num;
-            a.part[o.count + l] = den;
-            return;
-        }
-    } else {
-        num = a.part[l];
-        den = a.part[o.count + l];
-    }
+    const int count = a.ord[FIELD].count;
+    if (l >= count) return;
     const int64_t base = fm_base(a, FIELD);
-    fm_update(a, f, base + l, a.tab[base + l], fm_theta(a, f, base + l), num, den);
+    fm_update(a, f, base + l, a.tab[base + l], fm_theta(a, f, base + l), a.part[l], a.part[count + l]);
+}
+
+// The context field's phase: one wave per context feature adds its piece (lane-strided sums in record order, then a fixed butterfly)
+// and -- fused -- applies the update; else [num | den] -> part.  A few ratings in a thousand have such a feature (FM.java:81-86), so
+// this is a latency-bound launch of n_conds waves: one kernel instead of round 4's chunked reduce + finish pair (12 + 5 us -> 6 us).
+__global__ __launch_bounds__(64) void fm_ctx_kernel(FmArgs a, int f, int fused) {
+    const FmOrder &o = a.ord[2];
+    const int l = blockIdx.x, lane = threadIdx.x;
+    const int64_t base = fm_base(a, 2);
+    const double2 t = a.tab[base + l];
+    const double theta = fm_theta(a, f, base + l), dl = a.xc * t.y, d0 = *a.d0; // the support's errors moved by delta * x_il
+    double num = 0.0, den = 0.0;
+    for (int i = o.piece_off[l] + lane; i < o.piece_off[l + 1]; i += 64) {
+        FmRec rr[1] = {fm_load_rec(o.rec, i)};
+        double ep[1], hh[1];
+        fm_rec_eval<2>(a, f, rr, d0, ep, hh);
+        const double et = ep[0] + dl;
+        num += (et - theta * hh[0]) * hh[0];
+        den += hh[0] * hh[0];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        num += __shfl_xor(num, m, 64);
+        den += __shfl_xor(den, m, 64);
+    }
+    if (lane != 0) return;
+    if (fused) fm_update(a, f, base + l, t, theta, num, den);
+    else {
+        a.part[l] = num;
+        a.part[o.count + l] = den;
+    }
 }
 
 // tab[l].x = Vt[f][l] for entries [lo, hi): only when phases are driven out of the sweep's order (fm_update leaves the right columns)
@@ -597,10 +510,9 @@ __global__ __launch_bounds__(256) void fm_predict_kernel(FmArgs a, int64_t n, co
 
 // ---- launchers ------------------------------------------------------------------------------------------
 
-static hipError_t launch_reduce2(const FmArgs &a, int f, hipStream_t s) { // field 2: one wave per chunk
-    const int nc = a.ord[2].n_chunks;
-    if (nc <= 0) return hipSuccess;
-    hipLaunchKernelGGL((fm_reduce_kernel<2, false>), dim3(((nc + 3) / 4 + 7) / 8 * 8), dim3(256), 0, s, a, f);
+static hipError_t launch_ctx(const FmArgs &a, int f, int fused, hipStream_t s) {
+    if (a.ord[2].count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fm_ctx_kernel, dim3(a.ord[2].count), dim3(64), 0, s, a, f, fused);
     return hipGetLastError();
 }
 
@@ -616,21 +528,12 @@ static hipError_t launch_cells(const FmArgs &a, int f, hipStream_t s) {
     return hipGetLastError();
 }
 
-static hipError_t launch_finish2(const FmArgs &a, int f, int mode, hipStream_t s) {
-    const int count = a.ord[2].count;
-    if (count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fm_finish_kernel<2>, dim3((count + 255) / 256), dim3(256), 0, s, a, f, mode);
-    return hipGetLastError();
-}
-
 hipError_t fm_launch_phase(const FmArgs &a, int field, int f, int mode, hipStream_t s) {
     const bool fused = mode == 2;
     switch (field) {
     case 0: return fused ? launch_cells<0, false, true>(a, f, s) : launch_cells<0, false, false>(a, f, s);
     case 1: return fused ? launch_cells<1, false, true>(a, f, s) : launch_cells<1, false, false>(a, f, s);
-    default:
-        if (hipError_t e = launch_reduce2(a, f, s)) return e;
-        return launch_finish2(a, f, mode, s);
+    default: return launch_ctx(a, f, fused ? 1 : 0, s);
     }
 }
 
@@ -638,7 +541,7 @@ hipError_t fm_launch_reduce_only(const FmArgs &a, int field, int f, hipStream_t 
     switch (field) {
     case 0: return launch_cells<0, false, false>(a, f, s);
     case 1: return launch_cells<1, false, false>(a, f, s);
-    default: return launch_reduce2(a, f, s);
+    default: return launch_ctx(a, f, 0, s);
     }
 }
 
@@ -647,9 +550,9 @@ hipError_t fm_launch_apply(const FmArgs &a, int field, int f, hipStream_t s) {
     if (count <= 0) return hipSuccess;
     const dim3 grid((count + 255) / 256), block(256);
     switch (field) {
-    case 0: hipLaunchKernelGGL(fm_finish_kernel<0>, grid, block, 0, s, a, f, 1); break;
-    case 1: hipLaunchKernelGGL(fm_finish_kernel<1>, grid, block, 0, s, a, f, 1); break;
-    default: hipLaunchKernelGGL(fm_finish_kernel<2>, grid, block, 0, s, a, f, 1); break;
+    case 0: hipLaunchKernelGGL(fm_apply_kernel<0>, grid, block, 0, s, a, f); break;
+    case 1: hipLaunchKernelGGL(fm_apply_kernel<1>, grid, block, 0, s, a, f); break;
+    default: hipLaunchKernelGGL(fm_apply_kernel<2>, grid, block, 0, s, a, f); break;
     }
     return hipGetLastError();
 }

@@ -13,28 +13,12 @@ struct FmRec {
     int32_t a, c;
 };
 
-// How a chunk of the stream is reduced (one wave per chunk).
-//   stream chunk: pieces [piece0, piece0 + n) (n <= 64, every piece <= FM_SHORT records), records [rec0, rec1) (<= 256):
-//                 a lane per piece sums its records left to right out of LDS -> partial[piece]
-//   vector chunk: n < 0: records [rec0, rec1) of the ONE long piece piece0, all lanes -> partial[grid + (-n - 1)]
-struct FmChunk {
-    int32_t piece0, n, rec0, rec1;
-};
-
-constexpr int FM_SHORT = 64;      // longest piece a single lane sums
-constexpr int FM_CHUNK = 512;     // records per stream chunk
-constexpr int FM_VECTOR = 2048;   // records per vector chunk
-
-// The ratings in the order one FIELD streams them: sorted by (slice of the other id, this field's coordinate), so a
-// coordinate's support is S contiguous pieces and the table entries a slice gathers stay L2-resident.
-// piece p = slice * count + coordinate; piece_off[p] .. piece_off[p + 1] its records.
+// Field 2 (context features; a few ratings in a thousand have one): the ratings of the field's support sorted by feature, 16-byte records;
+// one wave per feature adds its piece (fm_ctx_kernel).  piece_off[l] .. piece_off[l + 1] = the records of feature l.
 struct FmOrder {
     const FmRec *rec;
-    const int32_t *piece_off; // S * count + 1
-    const FmChunk *chunks;
-    const int32_t *xoff; // count + 1: coordinate l's extra partial slots are grid + [xoff[l], xoff[l + 1])  (vector chunks)
-    double2 *partial;    // S * count + n_x
-    int32_t n_chunks, count, S, n_x;
+    const int32_t *piece_off; // count + 1
+    int32_t count;
     int64_t n_rec;
 };
 
@@ -42,24 +26,17 @@ struct FmOrder {
 // What bounded the reduce launch of round 4 was the L2 REQUEST rate of the table gathers: one 16-byte gather per record, every lane
 // of a wave in a line of its own (tools/micro/gather16.hip: 210 G such gathers/s on this part, 119 us for 25 M; the TCP sends ONE
 // request for the lanes of an instruction that fall into the same 128-byte line: two lanes per line 57 us, four 36 us).  So the
-// records a workgroup evaluates together are sorted BY THE GATHERED ID inside a slice small enough that 64 consecutive records span
-// few lines: a BLOCK of coordinates (~2 400 users, one 1 024-thread workgroup) walks the slices of the other field; the records of
-// (block, slice) -- a CELL -- are cut into BATCHES of <= FMC_RCAP records in gathered-id order.  The workgroup evaluates a batch in
-// that order (coalesced 8 + 4 byte streams, one gather per record), parks {e', h} in LDS at the record's position in COORDINATE order
-// (`pos`, 13 bits of the packed word), and a thread per coordinate slot adds its run left to right into accumulators that live in LDS
-// for the whole block: no per-piece partial sums go through memory at all, and a coordinate's update is applied by the same launch.
-// A run longer than FMC_RUN records inside a batch (hot coordinate) is spread over several slots; a coordinate with several slots --
-// or one whose records span blocks -- is COMPLEX: its slots' sums go to `partial3` and a small second kernel finishes it.
-#ifndef FMC_CONFIG
-#define FMC_CONFIG 0
-#endif
-#if FMC_CONFIG == 0
+// records a workgroup evaluates together are sorted BY THE GATHERED ID: a GROUP of coordinates (as many as a workgroup's register
+// accumulators hold: ~4 900 users at C4's share = 3 lanes per line) is walked by H workgroups, each taking alternate sub-slices of the
+// other field (fm_api.cpp fm_build_cells); the records of (group part, sub-slice) -- a CELL -- are cut into BATCHES of <= FMC_RCAP records
+// in gathered-id order.  The workgroup evaluates a batch in that order (coalesced 8 + 4 byte streams, one gather per record), parks
+// {e', h} in LDS at the record's position in COORDINATE order (`pos`, 14 bits of the packed word), and a thread per coordinate slot adds
+// its run left to right into accumulators that live in its REGISTERS for the whole block: no per-piece partial sums go through memory,
+// and a coordinate with one slot is updated by the same launch.  A run longer than FMC_RUN records inside a batch (hot coordinate) is
+// spread over several slots; a coordinate with several slots -- H > 1, a hot run, records spanning blocks -- is COMPLEX: its slots' sums
+// go to `partial3` and fm_cplx_kernel finishes it.
 constexpr int FMC_THREADS = 1024;
 constexpr int FMC_RCAP = 8192;  // records per batch: 128 KB of LDS parking (10 240 = all of a CU's LDS measured the same)
-#else
-constexpr int FMC_THREADS = 512;
-constexpr int FMC_RCAP = 6144;  // 96 KB
-#endif
 constexpr int FMC_SLOTS = 5120; // accumulator slots per block: kept in the threads' registers (3 doubles per slot)
 constexpr int FMC_RUN = 64;     // longest run one thread adds
 

@@ -834,7 +834,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     need(ws.dB, up128(nc) * a.kp1 * 4);
     // two streams: the selection of batch b runs beside the contraction of batch b + 1 (matrix pipe beside the L2 / memory pipes), each
     // batch on the slab / operand buffer of its parity.  CMI_RANK_ONE_STREAM=1: the round-4 form, one stream, one slab (A/B)
-    static const bool one_stream = cmi_exp_env("CMI_RANK_ONE_STREAM") != nullptr;
+    const bool one_stream = getenv("CMI_RANK_ONE_STREAM") != nullptr; // (read per call: bench.py times the two kernels on their own with it)
     const bool two = !one_stream && ng > bg;
     need(ws.dA, up128(bg) * a.kp1 * 4);
     need(ws.dS, (size_t)bg * (size_t)nc * 4);
