@@ -288,6 +288,18 @@ def bench_fm(args):
     bytes_launch = 0.5 * (lay["bytes_reduce_user"] + lay["bytes_reduce_item"])
     kern = 0.5 * (ku + ki)
     sweep_bytes = lay["bytes_per_factor"] * (k + 1)
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of tools/bench_fm.py (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r*_c4_pmc.json)
+    traffic, tsrc = None, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_pmc.json")), reverse=True):
+        try:
+            ks = json.load(open(path))["kernels"]
+            vals = [v["hbm_bytes_per_dispatch"] for kk, v in ks.items() if "fm_cell_kernel" in kk and "true>" in kk and "hbm_bytes_per_dispatch" in v]
+            if vals:
+                traffic, tsrc = float(np.mean(vals)), os.path.relpath(path, ROOT)
+                break
+        except Exception:
+            continue
     ref_bytes = 16 * (3 + 3 * k) + 16 * 3 * k
     out = {"metric": "FM ALS rating-sweeps/sec, k=%d" % k, "value": data.n / dt, "unit": "rating-sweeps/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
@@ -295,7 +307,8 @@ def bench_fm(args):
            "config": {"workload": "c4 share: FM k=%d, %d users x %d items x %d conditions, %d ratings (one GPU of BASELINE configs[3])"
                                   % (k, data.n_users, data.n_items, data.n_conds, data.n), "phases_per_sweep": phases},
            "roofline": {"bound": "hbm", "achieved": bytes_launch / kern / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": bytes_launch / kern / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": bytes_launch / kern / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                        "traffic_GBps": traffic / kern / 1e9 if traffic else None, "traffic_over_model": traffic / bytes_launch if traffic else None,
                         "kernel": "fm_cell_kernel<0|1> (one factor's user / item phase)",
                         "kernel_us": {"user_field": ku * 1e6, "item_field": ki * 1e6}, "bytes_per_launch": bytes_launch,
                         "bytes_per_rating_phase": bytes_launch / data.n,
