@@ -349,17 +349,18 @@ __global__ __launch_bounds__(256) void fm_apply_kernel(FmArgs a, int f) {
     fm_update(a, f, base + l, a.tab[base + l], fm_theta(a, f, base + l), a.part[l], a.part[count + l]);
 }
 
-// The context field's phase: one wave per context feature adds its piece (lane-strided sums in record order, then a fixed butterfly)
+// The context field's phase: one 256-thread workgroup per context feature adds its piece (thread-strided sums, a fixed butterfly per wave, the waves in order)
 // and -- fused -- applies the update; else [num | den] -> part.  A few ratings in a thousand have such a feature (FM.java:81-86), so
 // this is a latency-bound launch of n_conds waves: one kernel instead of round 4's chunked reduce + finish pair (12 + 5 us -> 6 us).
-__global__ __launch_bounds__(64) void fm_ctx_kernel(FmArgs a, int f, int fused) {
+__global__ __launch_bounds__(256) void fm_ctx_kernel(FmArgs a, int f, int fused) {
+    __shared__ double red[2][4];
     const FmOrder &o = a.ord[2];
-    const int l = blockIdx.x, lane = threadIdx.x;
+    const int l = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = fm_base(a, 2);
     const double2 t = a.tab[base + l];
     const double theta = fm_theta(a, f, base + l), dl = a.xc * t.y, d0 = *a.d0; // the support's errors moved by delta * x_il
     double num = 0.0, den = 0.0;
-    for (int i = o.piece_off[l] + lane; i < o.piece_off[l + 1]; i += 64) {
+    for (int i = o.piece_off[l] + tid; i < o.piece_off[l + 1]; i += 256) { // thread-strided sums in record order
         FmRec rr[1] = {fm_load_rec(o.rec, i)};
         double ep[1], hh[1];
         fm_rec_eval<2>(a, f, rr, d0, ep, hh);
@@ -368,11 +369,18 @@ __global__ __launch_bounds__(64) void fm_ctx_kernel(FmArgs a, int f, int fused) 
         den += hh[0] * hh[0];
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
+    for (int m = 32; m >= 1; m >>= 1) { // a fixed butterfly per wave, then the four waves in order
         num += __shfl_xor(num, m, 64);
         den += __shfl_xor(den, m, 64);
     }
-    if (lane != 0) return;
+    if (lane == 0) {
+        red[0][wave] = num;
+        red[1][wave] = den;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    num = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    den = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
     if (fused) fm_update(a, f, base + l, t, theta, num, den);
     else {
         a.part[l] = num;
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(256) void fm_predict_kernel(FmArgs a, int64_t n, co
 
 static hipError_t launch_ctx(const FmArgs &a, int f, int fused, hipStream_t s) {
     if (a.ord[2].count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fm_ctx_kernel, dim3(a.ord[2].count), dim3(64), 0, s, a, f, fused);
+    hipLaunchKernelGGL(fm_ctx_kernel, dim3(a.ord[2].count), dim3(256), 0, s, a, f, fused);
     return hipGetLastError();
 }
 
