@@ -43,6 +43,7 @@ FLAG_SCHED_OWNER = 0x200
 FLAG_NO_OWNER = 0x400
 FLAG_SPOKE_ARENA = 0x800
 FLAG_NO_ARENA = 0x1000
+FM_FLAG_DETERMINISTIC = 0x1
 OWN_HUB_FWD, OWN_HUB_LATE, OWN_HUB_STORE, OWN_SPK_FWD, OWN_SPK_STORE = 1, 2, 4, 8, 16
 
 # every symbol include/carskit_mi355x.h declares: (name, restype, argtypes)

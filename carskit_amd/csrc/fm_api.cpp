@@ -54,6 +54,7 @@ struct cmi_fm_instance {
     int32_t *d_u = nullptr, *d_j = nullptr, *d_ctx = nullptr, *d_src[3] = {nullptr, nullptr, nullptr};
     FmOrderDev ord[3];   // [2] only: the context field (records sorted by feature, a wave per feature)
     FmCellsDev cell[2];  // users, items
+    int atomic = 1;  // 0: CMI_FM_FLAG_DETERMINISTIC (fm_cell_kernel: parking + a fixed walk); 1: fm_cell_atomic_kernel (LDS atomics)
     int h_split = 0; // CMI_FM_HSPLIT: id-range parts per group (0 = chosen from the geometry)
     int batch_cap = FMC_RCAP, slot_cap = FMC_SLOTS; // experiment / test knobs (CMI_FM_BATCH, CMI_FM_SLOTS): smaller batches and blocks on small data
     RankWorkspace rank_ws; // cmi_fm_eval_rankings' buffers, reused by the next evaluation
@@ -126,7 +127,6 @@ extern "C" int cmi_fm_destroy(cmi_fm_handle h) {
 
 extern "C" int cmi_fm_create(int k, int n_users, int n_items, int n_conds, int n_ctx_dims, int device,
                              unsigned flags, cmi_fm_handle *out) {
-    (void)flags;
     if (out) *out = nullptr;
     if (!out || k <= 0 || n_users <= 0 || n_items <= 0 || n_conds < 0 || n_ctx_dims <= 0) {
         g_fm_create_err = "cmi_fm_create: invalid argument";
@@ -145,6 +145,7 @@ extern "C" int cmi_fm_create(int k, int n_users, int n_items, int n_conds, int n
     if (const char *v = getenv("CMI_FM_SLICE")) h->slice_entries = atoll(v); // experiment knob: 0 = one slice
     if (const char *v = getenv("CMI_FM_BATCH")) h->batch_cap = std::max(1, std::min(atoi(v), FMC_RCAP));
     if (const char *v = getenv("CMI_FM_SLOTS")) h->slot_cap = std::max((FMC_RCAP + FMC_RUN - 1) / FMC_RUN, std::min(atoi(v), FMC_SLOTS));
+    h->atomic = (flags & CMI_FM_FLAG_DETERMINISTIC) || getenv("CMI_FM_DETERMINISTIC") ? 0 : 1;
     if (const char *v = cmi_exp_env("CMI_FM_HSPLIT")) h->h_split = std::max(0, std::min(atoi(v), 8));
     h->k = k;
     h->n_users = n_users;
@@ -281,7 +282,7 @@ struct FmCellsHost {
 // of the gathered field; the records of (block, sub-slice) are a CELL, cut into batches of <= batch_cap records in gathered-id order
 // (records with a context feature last).
 static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, const int32_t *ctx, int count, int other_count, int other_base,
-                           int n_conds, int64_t slice_entries, int batch_cap, int slot_cap, int h_split, FmCellsHost &o) {
+                           int n_conds, int64_t slice_entries, int batch_cap, int slot_cap, int h_split, FmCellsHost &o, bool slot_in_word = false) {
     o.count = count;
     const int max_vs = (batch_cap + FMC_RUN - 1) / FMC_RUN; // slots the longest possible run inside one batch needs
     std::vector<int32_t> deg((size_t)count, 0), vs((size_t)count, 1);
@@ -491,7 +492,8 @@ static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, 
                     const int64_t ff0 = ff;
                     for (int64_t r = r0; r < r1; ++r) {
                         const int32_t t = o.src[(size_t)r], first = loc[(size_t)key[t]];
-                        const uint32_t pos = (uint32_t)cursor[(size_t)(first + run[(size_t)first]++ / FMC_RUN)]++;
+                        const int32_t the_slot = first + run[(size_t)first]++ / FMC_RUN;
+                        const uint32_t pos = slot_in_word ? (uint32_t)the_slot : (uint32_t)cursor[(size_t)the_slot]++;
                         o.pk[(size_t)r] = (fl ? 0u : (uint32_t)(other[t] - id0)) | (pos << 17);
                         if (fl) {
                             o.fo[(size_t)ff] = other[t];
@@ -577,7 +579,7 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
         // the user cells
         std::vector<int32_t> ckey((size_t)n);
         auto item_cells = [&]() {
-            fm_build_cells(n, j, u, ctx, h->n_items, h->n_users, 0, h->n_conds, h->slice_entries, h->batch_cap, h->slot_cap, h->h_split, ci);
+            fm_build_cells(n, j, u, ctx, h->n_items, h->n_users, 0, h->n_conds, h->slice_entries, h->batch_cap, h->slot_cap, h->h_split, ci, h->atomic != 0);
         };
         auto ctx_order = [&]() {
             // context features: only ratings whose context-combination id is < numConditions have one (FM.java:81-86)
@@ -596,7 +598,7 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
         } catch (const std::system_error &) {
             hc = false;
         }
-        fm_build_cells(n, u, j, ctx, h->n_users, h->n_items, h->n_users, h->n_conds, h->slice_entries, h->batch_cap, h->slot_cap, h->h_split, cu);
+        fm_build_cells(n, u, j, ctx, h->n_users, h->n_items, h->n_users, h->n_conds, h->slice_entries, h->batch_cap, h->slot_cap, h->h_split, cu, h->atomic != 0);
         if (hi) ti.join();
         else item_cells();
         if (hc) tc.join();
@@ -663,6 +665,7 @@ static FmArgs fm_args(cmi_fm_instance *h) {
     a.n_items = h->n_items;
     a.n_conds = h->n_conds;
     a.xcol = -1;
+    a.atomic = h->atomic;
     a.xc = 1.0 / (double)h->n_ctx_dims;
     a.regLw = h->regLw;
     a.regLf = h->regLf;
@@ -819,7 +822,7 @@ extern "C" int cmi_fm_layout(cmi_fm_handle h, int64_t out[12]) {
         // feature (its combination id), the batches' slot boundaries and descriptors, the slots' coordinates, every coordinate's table
         // entry read and written and its Vt entry written (the update is part of the launch), complex coordinates' sums out and back in;
         // the gathered table entries are L2-resident by construction and are charged once per XCD and slice
-        red[f] = c.n_rec * 12 + (int64_t)c.n_flagged * 8 + c.poff_len * 2 + (int64_t)c.n_batches * 16 + (int64_t)c.n_blocks * 16 +
+        red[f] = c.n_rec * 12 + (int64_t)c.n_flagged * 8 + (h->atomic ? 0 : c.poff_len * 2) + (int64_t)c.n_batches * 16 + (int64_t)c.n_blocks * 16 +
                  (int64_t)c.n_slots * 4 + (int64_t)c.count * (16 + 16 + 8) + (c.n_cplx > 0 ? (int64_t)c.n_slots * 2 * 24 + (int64_t)c.n_cplx * 16 : 0);
         const int64_t other = f == 0 ? h->n_items : h->n_users;
         red[f] += 8 * other * 16;

@@ -319,6 +319,95 @@ __global__ __launch_bounds__(FMC_THREADS) void fm_cell_kernel(FmArgs a, int f) {
     }
 }
 
+// ---- the default form (a.atomic): the same cell stream without parking -- every wave walks its own slice of each batch (records
+// requested one batch ahead) and adds the three products of a record straight into LDS accumulators with ds_add_f64 (the packed word's
+// 14-bit field holds the record's SLOT).  No barriers between batches, no second pass over LDS, no slot boundaries to stream: the
+// waves run independently, so stream, gathers, VALU and LDS overlap by themselves.  The order of the additions is not fixed: sums vary
+// in their last bits run to run (CMI_FM_FLAG_DETERMINISTIC selects fm_cell_kernel above).  118-121 us per launch against 135.
+template <int FIELD, bool W0, bool FUSED>
+__global__ __launch_bounds__(FMC_THREADS) void fm_cell_atomic_kernel(FmArgs a, int f) {
+    __shared__ double acc[3][FMC_SLOTS];
+    const FmCells &c = a.cell[FIELD];
+    const int b = blockIdx.x;
+    const unsigned t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int s0 = c.slot_off[b], ns = c.slot_off[b + 1] - s0;
+    for (int s = (int)t; s < FMC_SLOTS; s += FMC_THREADS) acc[0][s] = acc[1][s] = acc[2][s] = 0.0;
+    __syncthreads();
+    const double d0 = *a.d0;
+    const int b0 = c.bat_off[b], bf = c.flag0[b], be = c.bat_off[b + 1];
+    constexpr int PW = FMC_RCAP / 16 / 64; // records per lane and batch (a wave takes FMC_RCAP / 16 consecutive records of a batch)
+    const FmBatch none = FmBatch{0, 0, 0, 0, 0, 0};
+    double e0[2][PW];
+    uint32_t pk[2][PW];
+    auto load = [&](const FmBatch &d, int buf) {
+        const double *eb = c.err0 + d.rec0;
+        const uint32_t *pb = c.pk + d.rec0;
+        const unsigned last = d.n > 0 ? (unsigned)d.n - 1u : 0u;
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            unsigned i = wave * (FMC_RCAP / 16) + q * 64 + lane;
+            i = i < last ? i : last;
+            e0[buf][q] = __builtin_nontemporal_load(eb + i);
+            pk[buf][q] = __builtin_nontemporal_load(pb + i);
+        }
+    };
+    FmBatch cur = b0 < bf ? c.bat[b0] : none;
+    load(cur, 0);
+    for (int bi = b0; bi < bf; bi += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (bi + half >= bf) break;
+            const FmBatch nxt = bi + half + 1 < bf ? c.bat[bi + half + 1] : none;
+            double2 tt[PW];
+            const double2 *tb = a.tab + cur.tab0;
+#pragma unroll
+            for (int q = 0; q < PW; ++q) tt[q] = tb[pk[half][q] & 0x1FFFFu];
+            load(nxt, half ^ 1);
+#pragma unroll
+            for (int q = 0; q < PW; ++q) {
+                const unsigned i = wave * (FMC_RCAP / 16) + q * 64 + lane;
+                if (i < (unsigned)cur.n) {
+                    const double ep = (e0[half][q] + d0) + tt[q].y, hh = f < 0 ? 1.0 : tt[q].x;
+                    const unsigned sl = (pk[half][q] >> 17) & 0x3FFFu;
+                    __hip_atomic_fetch_add(&acc[0][sl], ep * hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&acc[1][sl], hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&acc[2][sl], hh * hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            cur = nxt;
+        }
+    }
+    const int64_t obase = fm_base(a, 1 - FIELD), cbase = (int64_t)a.n_users + a.n_items;
+    for (int bi = bf; bi < be; ++bi) { // ratings with a context feature
+        const FmBatch d = c.bat[bi];
+        for (unsigned r = t; r < (unsigned)d.n; r += FMC_THREADS) {
+            const double e = c.err0[(int64_t)d.rec0 + r];
+            const uint32_t w = c.pk[(int64_t)d.rec0 + r];
+            const double2 to = a.tab[obase + c.fo[(int64_t)d.tab0 + r]], tc = a.tab[cbase + c.fcx[(int64_t)d.tab0 + r]];
+            const double ep = ((e + d0) + to.y) + a.xc * tc.y, hh = f < 0 ? 1.0 : to.x + a.xc * tc.x;
+            const unsigned sl = (w >> 17) & 0x3FFFu;
+            __hip_atomic_fetch_add(&acc[0][sl], ep * hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&acc[1][sl], hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&acc[2][sl], hh * hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    for (int s = (int)t; s < ns; s += FMC_THREADS) {
+        const int g = s0 + s, lc = c.slot_coord[g], l = lc & 0x7FFFFFFF;
+        const double A = acc[0][s], B = acc[1][s], C = acc[2][s];
+        if (W0) {
+            const double dl = a.tab[fm_base(a, FIELD) + l].y;
+            c.w0part[g] = (A + dl * B) - *a.w0 * B;
+        } else if (lc < 0) {
+            c.partial3[3 * (int64_t)g] = A;
+            c.partial3[3 * (int64_t)g + 1] = B;
+            c.partial3[3 * (int64_t)g + 2] = C;
+        } else {
+            fm_coord_out<FIELD>(a, f, l, A, B, C, FUSED);
+        }
+    }
+}
+
 // complex coordinates (several slots: a hot run spread over slots, a block's id-range parts, a giant's blocks): their slots' sums in
 // slot order, then the same output.  cplx[4 i ..] = coordinate, first slot, parts, stride between parts, slots per part is cplx_vs.
 template <int FIELD>
@@ -528,7 +617,8 @@ template <int FIELD, bool W0, bool FUSED>
 static hipError_t launch_cells(const FmArgs &a, int f, hipStream_t s) {
     const FmCells &c = a.cell[FIELD];
     if (c.n_blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL((fm_cell_kernel<FIELD, W0, FUSED>), dim3(c.n_blocks), dim3(FMC_THREADS), 0, s, a, f);
+    if (a.atomic) hipLaunchKernelGGL((fm_cell_atomic_kernel<FIELD, W0, FUSED>), dim3(c.n_blocks), dim3(FMC_THREADS), 0, s, a, f);
+    else hipLaunchKernelGGL((fm_cell_kernel<FIELD, W0, FUSED>), dim3(c.n_blocks), dim3(FMC_THREADS), 0, s, a, f);
     if (!W0 && c.n_cplx > 0) {
         if (FIELD == 0) hipLaunchKernelGGL(fm_cplx_kernel<0>, dim3((c.n_cplx + 255) / 256), dim3(256), 0, s, a, f, (int)FUSED);
         else hipLaunchKernelGGL(fm_cplx_kernel<1>, dim3((c.n_cplx + 255) / 256), dim3(256), 0, s, a, f, (int)FUSED);

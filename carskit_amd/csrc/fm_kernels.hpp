@@ -50,7 +50,8 @@ struct FmBatch {
 
 struct FmCells {
     double *err0;           // n_rec: the error as computed by cmi_fm_init, stream order
-    const uint32_t *pk;     // n_rec: bits 0..16 gathered id - first id of the batch's range, bits 17..30 parked position
+    const uint32_t *pk;     // n_rec: bits 0..16 gathered id - first id of the batch's range, bits 17..30 parked position (deterministic form) or
+                            // the record's slot inside its block (atomic form)
     const int32_t *fo, *fcx; // ratings with a context feature only (compact, a block's are contiguous): gathered id, context-combination id
     const FmBatch *bat;
     const int32_t *bat_off;    // n_blocks + 1: a block's batches, the pipelined ones first
@@ -87,6 +88,7 @@ struct FmArgs {
     const int32_t *src[3]; // stream position -> rating, per field (init only)
     int64_t n, global_size;
     int32_t k, n_users, n_items, n_conds;
+    int32_t atomic; // 1 (default): the packed words hold SLOTS and fm_cell_atomic_kernel runs; 0: positions, fm_cell_kernel (deterministic)
     int32_t xcol; // the column of V an UPDATE leaves in tab[].x of the coordinates it updates (-1: .x stays): see fm_update
     double xc; // 1 / numContextDims
     double regLw, regLf;

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define CMI_ABI_VERSION 4 /* 4: round 5 -- ADDED cmi_group_last_times, cmi_comm_last_exchange_ms (exchange vs compute time of an epoch),
-                             cmi_chain_schedule_device; CMI_E_HOST; cmi_fm_layout's [5..6] are batches
+                             cmi_chain_schedule_device; CMI_E_HOST; CMI_FM_FLAG_DETERMINISTIC; cmi_fm_layout's [5..6] are batches
                              3: round 4 -- cmi_comm_*, cmi_fm_comm_*, group resident evaluation, FM layout / timing, ranking host
                              clock; REMOVED: CMI_FLAG_SCHED_FLOW, CMI_FLAG_TWO_LANE, cmi_flow_schedule, cmi_split_schedule */
 
@@ -401,7 +401,12 @@ int cmi_comm_last_exchange_ms(cmi_handle h, float *ms);
  * read by the reference and is not computed. */
 typedef struct cmi_fm_instance *cmi_fm_handle;
 
-/* new FM(train, test, fold) + initModel() allocation (FM.java:49-74) */
+/* new FM(train, test, fold) + initModel() allocation (FM.java:49-74).  flags: CMI_FM_FLAG_DETERMINISTIC -- every coordinate's sums are
+ * added in an order the data layout alone decides (LDS parking + a fixed walk): runs are bit-reproducible and the split phases
+ * (reduce / apply) equal the fused sweep bit for bit, at ~12 % more time per sweep.  Default: the records' products are added with LDS
+ * atomics as they are evaluated -- same sums to the last few bits (the order of fp64 additions varies run to run), within the 1e-8
+ * the FM path promises against the reference arithmetic either way. */
+#define CMI_FM_FLAG_DETERMINISTIC 0x1u
 int cmi_fm_create(int k, int n_users, int n_items, int n_conds, int n_ctx_dims, int device, unsigned flags,
                   cmi_fm_handle *out);
 int cmi_fm_destroy(cmi_fm_handle h);
