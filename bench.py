@@ -279,9 +279,9 @@ def bench_fm(args):
     dt = (time.perf_counter() - t0) / args.steps
     phases = 4 + 3 * k
     lay = g.layout()
-    # the dominant kernel: the launch of a factor's user / item phase (fm_cell_kernel: 65 + 65 of the ~390 launches of a sweep, 85 % of its
+    # the dominant kernel: the launch of a factor's user / item phase (fm_cell_atomic_kernel: 65 + 65 of the ~390 launches of a sweep, 85 % of its
     # time), timed with HIP events on the instance's stream (in its non-updating form: it only writes scratch).  Bytes = what THIS
-    # implementation has to move per launch (cmi_fm_layout: 12-byte records streamed once, the batches' slot boundaries, the
+    # implementation has to move per launch (cmi_fm_layout: 12-byte records streamed once, the
     # coordinates' table entries and sums, one L2 fill of every table slice per XCD) -- not the reference algorithm's errors[] + Q
     # traffic, which it never generates.
     ku, ki = g.time_reduce(4 + 3 * (k // 2) + 0, 10) * 1e-3, g.time_reduce(4 + 3 * (k // 2) + 1, 10) * 1e-3
@@ -294,7 +294,7 @@ def bench_fm(args):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_pmc.json")), reverse=True):
         try:
             ks = json.load(open(path))["kernels"]
-            vals = [v["hbm_bytes_per_dispatch"] for kk, v in ks.items() if "fm_cell_kernel" in kk and "true>" in kk and "hbm_bytes_per_dispatch" in v]
+            vals = [v["hbm_bytes_per_dispatch"] for kk, v in ks.items() if "fm_cell_atomic_kernel" in kk and "true>" in kk and "hbm_bytes_per_dispatch" in v]
             if vals:
                 traffic, tsrc = float(np.mean(vals)), os.path.relpath(path, ROOT)
                 break
@@ -309,17 +309,17 @@ def bench_fm(args):
            "roofline": {"bound": "hbm", "achieved": bytes_launch / kern / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_launch / kern / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                         "traffic_GBps": traffic / kern / 1e9 if traffic else None, "traffic_over_model": traffic / bytes_launch if traffic else None,
-                        "kernel": "fm_cell_kernel<0|1> (one factor's user / item phase)",
+                        "kernel": "fm_cell_atomic_kernel<0|1> (one factor's user / item phase; fm_cell_kernel under CMI_FM_FLAG_DETERMINISTIC)",
                         "kernel_us": {"user_field": ku * 1e6, "item_field": ki * 1e6}, "bytes_per_launch": bytes_launch,
                         "bytes_per_rating_phase": bytes_launch / data.n,
-                        "bytes_model": "this implementation's own traffic per launch (cmi_fm_layout): records 12 B x %d, slot boundaries per batch, "
+                        "bytes_model": "this implementation's own traffic per launch (cmi_fm_layout): records 12 B x %d, "
                                        "coordinate entries + sums, table-slice fills; the reference ALGORITHM's errors[] + Q traffic would be %d B per "
                                        "rating-sweep (never generated here)" % (data.n, ref_bytes),
                         "whole_sweep_GBps": sweep_bytes / dt / 1e9, "whole_sweep_frac": sweep_bytes / dt / 1e9 / HBM_PEAK_GBS,
-                        "limiter": "one 1024-thread workgroup per CU walks stream -> gather -> LDS parking -> run sums in lockstep: the record "
-                                   "stream alone is 44 us at the copy rate, the gathers 40 us at 3 lanes per L2 line (tools/micro/gather16.hip: "
-                                   "210 G lone 16-byte gathers/s, 119 us, was round 4's wall), the LDS phase 28 us, VALU issue 35 us -- they "
-                                   "overlap only in part (DESIGN.md 5)",
+                        "limiter": "one 1024-thread workgroup per CU (120 KB of LDS sums): a wave's chain stream -> gather -> fp64 LDS atomics is "
+                                   "latency its 15 neighbours only partly cover (SQ counters: 0.52 of wave-cycles waiting, LDS busy 48 us of the "
+                                   "launch, VALU 6.7 M instructions); the record stream alone is 44 us at the copy rate, the gathers 40 us at 3 "
+                                   "lanes per L2 line (tools/micro/gather16.hip; DESIGN.md 5)",
                         "layout": lay, "avg_phase_us": dt * 1e6 / phases}}
     g.close()
     return out

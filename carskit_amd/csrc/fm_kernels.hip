@@ -29,13 +29,15 @@
 //     gathers/s on this part = 119 us for 25 M, whatever the slice size; the TCP sends one request for the lanes of an instruction
 //     that fall into one line: two lanes per line 57 us, four 36 us).  Round 5 (the CELL stream, fm_kernels.hpp): the user and the
 //     item field evaluate their records in GATHERED-ID order inside groups of ~4 900 coordinates (3 lanes per line at BASELINE C4's
-//     share), park {e', h} in LDS at the record's position in coordinate order, and add the runs into register accumulators that
-//     live for the whole group: 12-byte records, no per-piece partial sums through memory, the coordinate update in the same launch
-//     (or one small kernel where a coordinate's sums come from several workgroups).  122-136 us per launch box to box, 19.2 ms per sweep.
+//     share) and add a record's products to its coordinate's sums, which live in the workgroup for the whole group: in LDS, added with
+//     workgroup-scope fp64 atomics (fm_cell_atomic_kernel, the default: 118-121 us per launch, 16.4 ms per sweep), or -- the
+//     DETERMINISTIC form, CMI_FM_FLAG_DETERMINISTIC -- parked in LDS at the record's position in coordinate order and added left to
+//     right into register accumulators (fm_cell_kernel: 135 us, 18.2 ms).  12-byte records, no per-piece partial sums through memory,
+//     the coordinate update in the same launch (or one small kernel where a coordinate's sums come from several workgroups).
 //   * the context field (a few records in a thousand): 16-byte records sorted by feature, one wave per feature, reduce + update in one
 //     launch (fm_ctx_kernel).
-// Deterministic: every sum is added in a fixed order that depends on the data layout alone.  fp64 throughout; gather / stream
-// work: no MFMA.
+// The deterministic form adds every sum in a fixed order that depends on the data layout alone; the default form's LDS atomics add a
+// slot's records in whatever order its waves arrive (equal to rounding).  fp64 throughout; gather / stream work: no MFMA.
 //
 // reduce (-> [num | den] per coordinate) and apply are separable, so a multi-GPU host can all-reduce (num, den) between them; the
 // fused sweep runs the identical arithmetic.
