@@ -316,10 +316,10 @@ def bench_fm(args):
                                        "coordinate entries + sums, table-slice fills; the reference ALGORITHM's errors[] + Q traffic would be %d B per "
                                        "rating-sweep (never generated here)" % (data.n, ref_bytes),
                         "whole_sweep_GBps": sweep_bytes / dt / 1e9, "whole_sweep_frac": sweep_bytes / dt / 1e9 / HBM_PEAK_GBS,
-                        "limiter": "one 1024-thread workgroup per CU (120 KB of LDS sums): a wave's chain stream -> gather -> fp64 LDS atomics is "
-                                   "latency its 15 neighbours only partly cover (SQ counters: 0.52 of wave-cycles waiting, LDS busy 48 us of the "
-                                   "launch, VALU 6.7 M instructions); the record stream alone is 44 us at the copy rate, the gathers 40 us at 3 "
-                                   "lanes per L2 line (tools/micro/gather16.hip; DESIGN.md 5)",
+                        "limiter": "the memory pattern: the same kernel without its LDS atomics runs the same 115-118 us (LDS 48 us busy per CU and "
+                                   "VALU are hidden).  2.3 M stream lines from HBM + 8.3 M gather lines from L2 per launch (3 lanes per line) against "
+                                   "~400 outstanding lines per CU: time ~ sum(lines x latency) / (256 x 400), which also gives the stream-only "
+                                   "(59 us) and lone-gather (119 us) microbenchmarks (tools/micro/gather16.hip; DESIGN.md 5)",
                         "layout": lay, "avg_phase_us": dt * 1e6 / phases}}
     g.close()
     return out

@@ -284,7 +284,9 @@ struct FmCellsHost {
 static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, const int32_t *ctx, int count, int other_count, int other_base,
                            int n_conds, int64_t slice_entries, int batch_cap, int slot_cap, int h_split, FmCellsHost &o, bool slot_in_word = false) {
     o.count = count;
-    const int max_vs = (batch_cap + FMC_RUN - 1) / FMC_RUN; // slots the longest possible run inside one batch needs
+    // atomic form: the geometry (sub-slices, groups) is the deterministic form's, but a cell is cut into chunks of <= FMC_CHUNK records
+    const int cut = slot_in_word ? std::min(batch_cap, FMC_CHUNK) : batch_cap;
+    const int max_vs = (cut + FMC_RUN - 1) / FMC_RUN; // slots the longest possible run inside one batch needs
     std::vector<int32_t> deg((size_t)count, 0), vs((size_t)count, 1);
     for (int64_t t = 0; t < n; ++t) deg[(size_t)key[t]]++;
     // groups: first a bound on the slots (one per coordinate, more for coordinates hot enough to have runs > FMC_RUN inside a batch --
@@ -444,10 +446,10 @@ static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, 
         int64_t nbat = 0;
         for (int64_t s = 0; s < S1; ++s) {
             const int64_t len = cell_off[(size_t)(b * S1 + s) + 1] - cell_off[(size_t)(b * S1 + s)];
-            nbat += (len + batch_cap - 1) / batch_cap;
+            nbat += (len + cut - 1) / cut;
         }
         bat_first[(size_t)b + 1] = bat_first[(size_t)b] + nbat;
-        poff_first[(size_t)b + 1] = poff_first[(size_t)b] + nbat * ((int64_t)grp_slots[(size_t)(b / H)] + 1);
+        poff_first[(size_t)b + 1] = poff_first[(size_t)b] + (slot_in_word ? 0 : nbat * ((int64_t)grp_slots[(size_t)(b / H)] + 1)); // no slot boundaries in the atomic form
         o.bat_off[(size_t)b + 1] = (int32_t)bat_first[(size_t)b + 1];
     }
     o.bat.resize((size_t)bat_first[(size_t)NB]);
@@ -475,8 +477,8 @@ static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, 
                 const bool fl = s == S;                              // the block's ratings with a context feature
                 const int64_t id0 = fl ? 0 : (s * H + h) * sub_len; // first gathered id of the cell's range
                 if (fl) o.flag0[(size_t)b] = (int32_t)bi;
-                for (int64_t r0 = c0; r0 < c1; r0 += batch_cap) {
-                    const int64_t r1 = std::min<int64_t>(c1, r0 + batch_cap);
+                for (int64_t r0 = c0; r0 < c1; r0 += cut) {
+                    const int64_t r1 = std::min<int64_t>(c1, r0 + cut);
                     // slot of a record: the coordinate's first slot in the group + (its rank inside the batch's run) / FMC_RUN
                     run.assign((size_t)ns, 0); // per FIRST slot of a coordinate: its records seen so far in this batch
                     std::fill(cnt.begin(), cnt.end(), 0);
@@ -485,8 +487,10 @@ static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, 
                         cnt[(size_t)(first + run[(size_t)first]++ / FMC_RUN) + 1]++;
                     }
                     for (int32_t q = 0; q < ns; ++q) cnt[(size_t)q + 1] += cnt[(size_t)q];
-                    uint16_t *po = o.poff.data() + pf;
-                    for (int32_t q = 0; q <= ns; ++q) po[q] = (uint16_t)cnt[(size_t)q];
+                    if (!slot_in_word) {
+                        uint16_t *po = o.poff.data() + pf;
+                        for (int32_t q = 0; q <= ns; ++q) po[q] = (uint16_t)cnt[(size_t)q];
+                    }
                     std::fill(run.begin(), run.end(), 0);
                     std::copy(cnt.begin(), cnt.end() - 1, cursor.begin());
                     const int64_t ff0 = ff;
@@ -502,7 +506,7 @@ static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, 
                     }
                     o.bat[(size_t)bi++] = FmBatch{(int32_t)r0, (int32_t)(r1 - r0), fl ? (int32_t)ff0 : (int32_t)(other_base + id0), (int32_t)pf,
                                                   fl ? (int32_t)(r1 - r0) : 0, 0};
-                    pf += (int64_t)ns + 1;
+                    if (!slot_in_word) pf += (int64_t)ns + 1;
                 }
             }
         }

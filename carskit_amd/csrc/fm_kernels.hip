@@ -331,52 +331,68 @@ __global__ __launch_bounds__(FMC_THREADS) void fm_cell_atomic_kernel(FmArgs a, i
     __shared__ double acc[3][FMC_SLOTS];
     const FmCells &c = a.cell[FIELD];
     const int b = blockIdx.x;
-    const unsigned t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned t = threadIdx.x, lane = t & 63;
     const int s0 = c.slot_off[b], ns = c.slot_off[b + 1] - s0;
     for (int s = (int)t; s < FMC_SLOTS; s += FMC_THREADS) acc[0][s] = acc[1][s] = acc[2][s] = 0.0;
     __syncthreads();
     const double d0 = *a.d0;
     const int b0 = c.bat_off[b], bf = c.flag0[b], be = c.bat_off[b + 1];
-    constexpr int PW = FMC_RCAP / 16 / 64; // records per lane and batch (a wave takes FMC_RCAP / 16 consecutive records of a batch)
+    constexpr int PW = FMC_CHUNK / 64; // records per lane and batch: in this form a batch is a CHUNK of <= FMC_CHUNK records, a wave's unit of work
     const FmBatch none = FmBatch{0, 0, 0, 0, 0, 0};
-    double e0[2][PW];
-    uint32_t pk[2][PW];
+    // wave w walks chunks b0 + w, b0 + w + 16, ... and never waits for another wave before the epilogue.  Three stages in flight per
+    // wave: the records of step s + 2 and the gathers of step s + 1 are outstanding while step s adds into LDS (the memory pipe and the
+    // LDS pipe of a CU are busy ~59 and ~48 us of a launch: with a wave's stages back to back, and the 16 waves in phase, they added up).
+    const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+    const int nst = bf - b0 - wv > 0 ? (bf - b0 - wv + 15) / 16 : 0;
+    auto desc = [&](int st) -> FmBatch { return st < nst ? c.bat[b0 + wv + 16 * st] : none; };
+    double e0[3][PW];
+    uint32_t pk[3][PW];
+    double2 tt[2][PW];
     auto load = [&](const FmBatch &d, int buf) {
         const double *eb = c.err0 + d.rec0;
         const uint32_t *pb = c.pk + d.rec0;
         const unsigned last = d.n > 0 ? (unsigned)d.n - 1u : 0u;
 #pragma unroll
         for (int q = 0; q < PW; ++q) {
-            unsigned i = wave * (FMC_RCAP / 16) + q * 64 + lane;
+            unsigned i = q * 64 + lane;
             i = i < last ? i : last;
             e0[buf][q] = __builtin_nontemporal_load(eb + i);
             pk[buf][q] = __builtin_nontemporal_load(pb + i);
         }
     };
-    FmBatch cur = b0 < bf ? c.bat[b0] : none;
-    load(cur, 0);
-    for (int bi = b0; bi < bf; bi += 2) {
+    auto gather = [&](const FmBatch &d, int buf, int tb) {
+        const double2 *base = a.tab + d.tab0;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (bi + half >= bf) break;
-            const FmBatch nxt = bi + half + 1 < bf ? c.bat[bi + half + 1] : none;
-            double2 tt[PW];
-            const double2 *tb = a.tab + cur.tab0;
+        for (int q = 0; q < PW; ++q) tt[tb][q] = base[pk[buf][q] & 0x1FFFFu];
+    };
+    auto add = [&](const FmBatch &d, int buf, int tb) {
 #pragma unroll
-            for (int q = 0; q < PW; ++q) tt[q] = tb[pk[half][q] & 0x1FFFFu];
-            load(nxt, half ^ 1);
-#pragma unroll
-            for (int q = 0; q < PW; ++q) {
-                const unsigned i = wave * (FMC_RCAP / 16) + q * 64 + lane;
-                if (i < (unsigned)cur.n) {
-                    const double ep = (e0[half][q] + d0) + tt[q].y, hh = f < 0 ? 1.0 : tt[q].x;
-                    const unsigned sl = (pk[half][q] >> 17) & 0x3FFFu;
-                    __hip_atomic_fetch_add(&acc[0][sl], ep * hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&acc[1][sl], hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&acc[2][sl], hh * hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+        for (int q = 0; q < PW; ++q) {
+            const unsigned i = q * 64 + lane;
+            if (i < (unsigned)d.n) {
+                const double ep = (e0[buf][q] + d0) + tt[tb][q].y, hh = f < 0 ? 1.0 : tt[tb][q].x;
+                const unsigned sl = (pk[buf][q] >> 17) & 0x3FFFu;
+                __hip_atomic_fetch_add(&acc[0][sl], ep * hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&acc[1][sl], hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&acc[2][sl], hh * hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            cur = nxt;
+        }
+    };
+    FmBatch dA = desc(0), dB = desc(1), dC = desc(2), dD = desc(3); // steps s, s + 1, s + 2, s + 3
+    load(dA, 0);
+    load(dB, 1);
+    gather(dA, 0, 0);
+    for (int st = 0; st < nst; st += 6) {
+#pragma unroll
+        for (int ph = 0; ph < 6; ++ph) {
+            if (st + ph >= nst) break;
+            load(dC, (ph + 2) % 3);
+            gather(dB, (ph + 1) % 3, (ph + 1) & 1);
+            add(dA, ph % 3, ph & 1);
+            dA = dB;
+            dB = dC;
+            dC = dD;
+            dD = desc(st + ph + 4);
         }
     }
     const int64_t obase = fm_base(a, 1 - FIELD), cbase = (int64_t)a.n_users + a.n_items;

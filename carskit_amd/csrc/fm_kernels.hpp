@@ -39,6 +39,7 @@ constexpr int FMC_THREADS = 1024;
 constexpr int FMC_RCAP = 8192;  // records per batch: 128 KB of LDS parking (10 240 = all of a CU's LDS measured the same)
 constexpr int FMC_SLOTS = 5120; // accumulator slots per block: kept in the threads' registers (3 doubles per slot)
 constexpr int FMC_RUN = 64;     // longest run one thread adds
+constexpr int FMC_CHUNK = 256;  // atomic form: a batch is a chunk of <= 256 records, the unit a WAVE takes (no barriers between chunks)
 
 struct FmBatch {
     int32_t rec0, n; // records [rec0, rec0 + n) of the stream, in gathered-id order
