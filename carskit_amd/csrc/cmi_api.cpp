@@ -672,17 +672,17 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         CMI_FAIL(h, CMI_E_UNSUPPORTED, "set_ratings: CMI_FLAG_SCHED_OWNER: no owner kernel for model %d, k=%d, %d conditions, %s state%s (or "
                  "another schedule flag is set)", h->model, h->k, h->n_conds, h->f64 ? "fp64" : "fp32", h->strict ? ", strict" : "");
     // the hub-chain levels first: wide data is theirs
-    // The spoke arena of a large set is tens of GB (north_star: 102 GB) and hipMalloc takes ~20 ms per GB: when the sizes say an arena is
-    // likely (a side's table >= 2 GiB, or it is forced), it is allocated on a thread of its own WHILE the schedule and the stream are
-    // built; the arena block below takes it over or frees it.
+    // The spoke arena of a large set is tens of GB (north_star: 102 GB).  hipMalloc hands out CLEAN device memory at once (0.001 s for
+    // 102 GB) but waits for the driver's wipe of blocks this process freed a moment ago (~30 ms per GB: tools/exp/hipmalloc_probe.py,
+    // tools/micro/alloc_time.hip), and the schedule build below frees GBs of temporaries.  So when the sizes say an arena is likely (a
+    // side's table >= 2 GiB, or it is forced) it is allocated HERE, before anything of this call has been freed; the arena block below
+    // takes it over or frees it.  (Round 5 first allocated it on a side thread beside the schedule build: 1.9 s for the same call, and
+    // every other HIP call of the build slowed down beside it.)
     struct SpecArena {
-        std::thread th;
         void *ptr = nullptr;
         size_t bytes = 0;
-        hipError_t err = hipSuccess;
         void *take(size_t want) {
-            if (th.joinable()) th.join();
-            if (ptr && bytes == want && err == hipSuccess) {
+            if (ptr && bytes == want) {
                 void *p = ptr;
                 ptr = nullptr;
                 return p;
@@ -690,7 +690,6 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
             return nullptr;
         }
         ~SpecArena() {
-            if (th.joinable()) th.join();
             if (ptr) (void)hipFree(ptr);
         }
     } spec;
@@ -701,17 +700,14 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         (void)hipMemGetInfo(&free_b, &total_b);
         const bool likely = (h->flags & CMI_FLAG_SPOKE_ARENA) || cmi_exp_env("CMI_ARENA") || (size_t)std::max(h->n_users, h->n_items) * row >= ((size_t)2 << 30);
         if (likely && (double)arena_bytes <= 0.6 * (double)free_b) {
-            spec.bytes = arena_bytes;
-            const int dev = h->device;
-            try {
-                spec.th = std::thread([&spec, dev]() {
-                    spec.err = hipSetDevice(dev);
-                    if (spec.err == hipSuccess) spec.err = hipMalloc(&spec.ptr, spec.bytes);
-                });
-            } catch (const std::system_error &) { // no thread: allocated in place below
+            if (hipMalloc(&spec.ptr, arena_bytes) == hipSuccess) spec.bytes = arena_bytes;
+            else {
+                spec.ptr = nullptr;
+                (void)hipGetLastError(); // the arena block decides again (and reports) with what is free then
             }
         }
     }
+    lap("arena allocation");
     ChainDeviceKeep keep; // device-built schedule: the tuple ids and the permutation stay on the device for the stream build
     const bool use_chain = !h->serial && chain_ok && n > 0 && try_chain(h, n, u, j, csch, keep);
     const bool dev_stream = use_chain && keep.d_perm != nullptr;
@@ -1007,7 +1003,7 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
                 if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // nxt / first are locals
             }
             if (e == hipSuccess) {
-                h->d_arena = spec.take(arena_bytes); // allocated beside the schedule build, if the sizes had announced it
+                h->d_arena = spec.take(arena_bytes); // allocated at the top of the call (clean memory), if the sizes had announced it
                 if (!h->d_arena) e = hipMalloc(&h->d_arena, arena_bytes);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // nxt / first are locals
