@@ -369,8 +369,12 @@ def bench_frappe(args):
         if sim:
             st["P"] = (0.3 * st["P"]).astype(np.float32)
         gm = float(tr.r.sum() / np.count_nonzero(tr.r))
-        inst = capi.Instance(model, k, tr.n_users, tr.n_items, tr.n_conds, flags=args.flags | capi.FLAG_SCHED_SERIAL)
+        # (the serial form is what the one-chain models run anyway; the row-local models -- BiasedMF, CAMF_CI / CU / CUCI -- get the schedule
+        # cmi_set_ratings picks for the file: the owner epoch on Frappe's heavy-tailed items)
+        chain_model = model in ("CAMF_C", "SVD++") or sim
+        inst = capi.Instance(model, k, tr.n_users, tr.n_items, tr.n_conds, flags=args.flags | (capi.FLAG_SCHED_SERIAL if chain_model else 0))
         inst.set_hparams(*regs, gm)
+        inst.set_device_share(F)
         if sim:
             inst.set_sim_params(num_f, tr.n_dims, d.empty_conds)
         inst.set_ratings(tr.u, tr.j, tr.ctx, tr.r, tr.ctx_ptr, tr.ctx_conds)

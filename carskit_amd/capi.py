@@ -59,6 +59,7 @@ SYMBOLS = [
     ("cmi_get_state", C.c_int, [_vp, C.c_int, _vp, _i64, C.c_int]),
     ("cmi_set_sim_params", C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int]),
     ("cmi_set_hparams", C.c_int, [_vp, _dbl, _dbl, _dbl, _dbl, _dbl]),
+    ("cmi_set_device_share", C.c_int, [_vp, C.c_int]),
     ("cmi_train_epoch", C.c_int, [_vp, _dbl, C.POINTER(_dbl)]),
     ("cmi_train", C.c_int, [_vp, C.c_int, _dbl, _dbl, C.c_int, _dbl, C.c_int, _vp, _vp, C.POINTER(C.c_int),
                             C.POINTER(_dbl)]),
@@ -622,6 +623,10 @@ class Instance:
 
     def set_hparams(self, regU, regI, regB, regC, global_mean):
         self._chk(self.L.cmi_set_hparams(self.h, regU, regI, regB, regC, global_mean))
+
+    def set_device_share(self, instances):
+        """`cv -p on`: how many instances train concurrently on this device (before set_ratings)."""
+        self._chk(self.L.cmi_set_device_share(self.h, int(instances)))
 
     # -- training -----------------------------------------------------------------------------------
     def train_epoch(self, lrate):

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <condition_variable>
 #include <mutex>
 #include <vector>
 
@@ -36,47 +37,74 @@ static thread_local std::string g_create_err;
 #include <sys/file.h>
 #include <sys/stat.h>
 #include <unistd.h>
-struct OwnerDeviceLock {
+// Owner epochs are persistent launches: every workgroup must be resident, so the workgroups of the epochs in flight on one device must
+// fit it together.  Inside a process a per-device GATE counts them (capacity = the device's compute units, one owner workgroup each):
+// an instance with cmi_set_device_share(F) launches ~1 / F of the device and F such epochs run side by side (`cv -p on`); an instance
+// without the hint takes the whole device and is alone, as before.  Across PROCESSES an advisory file lock (held by a process while any
+// of its owner epochs is in flight) keeps two processes' persistent kernels apart.
+struct OwnerDeviceGate {
     static constexpr int MAX_DEV = 64;
-    static std::mutex &mtx(int dev) {
-        static std::mutex m[MAX_DEV];
-        return m[dev >= 0 && dev < MAX_DEV ? dev : 0];
-    }
-    std::unique_lock<std::mutex> lk;
+    std::mutex m;
+    std::condition_variable cv;
+    int in_use = 0;  // workgroups of the owner epochs in flight
+    int holders = 0; // epochs in flight (the file lock is held while > 0)
     int fd = -1;
-    explicit OwnerDeviceLock(int dev) : lk(mtx(dev)) {
-        char bus[64] = "";
-        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", dev);
-        for (char *c = bus; *c; ++c)
-            if (*c == ':' || *c == '/' || *c == '.') *c = '_';
-        // a per-uid directory (0700) under $TMPDIR, so the lock file is neither world-writable nor at a path another user can plant
-        // a symlink on; O_NOFOLLOW refuses a planted link anyway, O_CLOEXEC keeps the descriptor out of forked children
-        const char *tmp = getenv("TMPDIR");
-        char dir[200], path[300];
-        snprintf(dir, sizeof dir, "%s/cmi_locks_%u", tmp && *tmp ? tmp : "/tmp", (unsigned)getuid());
-        (void)mkdir(dir, 0700);
-        snprintf(path, sizeof path, "%s/owner_epoch_%s.lock", dir, bus);
-        fd = open(path, O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600);
-        // bounded wait: a stopped or hung peer holding the lock must not block this process for ever.  An owner epoch
-        // lasts well under a second; after ~20 s of polling the epoch proceeds without the cross-process lock -- its device-side
-        // waits are bounded too, so the worst case is a slow epoch, not a hang.
-        if (fd >= 0) {
-            bool got = false;
-            for (int tries = 0; tries < 2000 && !got; ++tries) {
-                if (flock(fd, LOCK_EX | LOCK_NB) == 0) got = true;
-                else usleep(10000);
-            }
-            if (!got) {
-                close(fd);
-                fd = -1;
+    static OwnerDeviceGate &of(int dev) {
+        static OwnerDeviceGate g[MAX_DEV];
+        return g[dev >= 0 && dev < MAX_DEV ? dev : 0];
+    }
+};
+struct OwnerDeviceLock {
+    OwnerDeviceGate &g;
+    int wgs;
+    bool ok = true; // false: another process kept the device's lock for the whole bounded wait -- the caller must not launch
+    OwnerDeviceLock(int dev, int workgroups, int capacity) : g(OwnerDeviceGate::of(dev)), wgs(std::max(1, workgroups)) {
+        std::unique_lock<std::mutex> lk(g.m);
+        g.cv.wait(lk, [&] { return g.in_use == 0 || g.in_use + wgs <= capacity; });
+        if (g.holders == 0) {
+            char bus[64] = "";
+            if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", dev);
+            for (char *c = bus; *c; ++c)
+                if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+            // a per-uid directory (0700) under $TMPDIR, so the lock file is neither world-writable nor at a path another user can plant
+            // a symlink on; O_NOFOLLOW refuses a planted link anyway, O_CLOEXEC keeps the descriptor out of forked children.
+            // (Processes of DIFFERENT users are therefore not serialised against each other: a shared GPU needs one uid or one process.)
+            const char *tmp = getenv("TMPDIR");
+            char dir[200], path[300];
+            snprintf(dir, sizeof dir, "%s/cmi_locks_%u", tmp && *tmp ? tmp : "/tmp", (unsigned)getuid());
+            (void)mkdir(dir, 0700);
+            snprintf(path, sizeof path, "%s/owner_epoch_%s.lock", dir, bus);
+            g.fd = open(path, O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600);
+            // bounded wait: a stopped or hung peer holding the lock must not block this process for ever; an owner epoch lasts well
+            // under a second.  After 60 s the epoch is NOT launched beside the other process's persistent kernel (that
+            // could stall both): the caller reports the device as busy.
+            if (g.fd >= 0) {
+                bool got = false;
+                for (int tries = 0; tries < 6000 && !got; ++tries) {
+                    if (flock(g.fd, LOCK_EX | LOCK_NB) == 0) got = true;
+                    else usleep(10000);
+                }
+                if (!got) {
+                    close(g.fd);
+                    g.fd = -1;
+                    ok = false;
+                    return; // (nothing taken: in_use / holders unchanged)
+                }
             }
         }
+        g.in_use += wgs;
+        ++g.holders;
     }
     ~OwnerDeviceLock() {
-        if (fd >= 0) {
-            flock(fd, LOCK_UN);
-            close(fd);
+        if (!ok) return;
+        std::lock_guard<std::mutex> lk(g.m);
+        g.in_use -= wgs;
+        if (--g.holders == 0 && g.fd >= 0) {
+            flock(g.fd, LOCK_UN);
+            close(g.fd);
+            g.fd = -1;
         }
+        g.cv.notify_all();
     }
 };
 
@@ -288,6 +316,13 @@ extern "C" int cmi_set_hparams(cmi_handle h, double regU, double regI, double re
     h->hp.regB = regB;
     h->hp.regC = regC;
     h->hp.gm = h->model == CMI_MODEL_PMF ? 0.0 : global_mean; // PMF.predict is the bare dot product
+    return CMI_OK;
+}
+
+extern "C" int cmi_set_device_share(cmi_handle h, int instances) {
+    if (!h) return CMI_E_INVALID;
+    if (instances < 1) CMI_FAIL(h, CMI_E_INVALID, "set_device_share: %d instances", instances);
+    h->device_share = instances;
     return CMI_OK;
 }
 
@@ -760,6 +795,9 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         if (n > 0) {
             // the owners must all be resident: as many as the device holds wavefronts of the kernel (either hub side: same registers)
             int waves = owner_grid_waves(h->device, h->model, h->n_conds, h->k, h->f64, true);
+            // cmi_set_device_share: this instance's share of the resident wavefronts (whole workgroups of four owners), so that the
+            // persistent launches of the instances that train side by side are co-resident
+            if (h->device_share > 1 && waves > 0) waves = std::max(8, waves / h->device_share / 4 * 4);
             if (const char *env = getenv("CMI_OWNER_WAVES")) {
                 const int v = atoi(env);
                 if (v >= 1 && v < waves) waves = v;
@@ -786,8 +824,9 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
                 return t;
             };
             const int wgs = (waves + 3) / 4; // resident workgroups
-            if (h->strict || (team_env && !strcmp(team_env, "0"))) {
-                // one wavefront per owner throughout
+            if (h->strict || h->device_share > 1 || (team_env && !strcmp(team_env, "0"))) {
+                // one wavefront per owner throughout (a shared device: the hottest rows' owners get no workgroup of their own -- and the
+                // team form was measured NOT exact beside another instance's persistent launch: tools/exp/share_debug.py)
             } else if (team_env && !strcmp(team_env, "all")) { // testing: every owner a team, whatever its list
                 if (waves > wgs) {
                     waves = wgs;
@@ -1285,7 +1324,13 @@ static hipError_t enqueue_levels(cmi_instance *h) {
         // PROCESSES an advisory lock on a per-device file does the same (OwnerDeviceLock); should a foreign persistent kernel hold
         // compute units anyway, the waits are bounded, the first one to expire ends every other wait early (owner_spin_expired) and the
         // epoch is reported as failed right here -- also on the cmi_train_epoch_async path, which never calls cmi_last_loss.
-        OwnerDeviceLock guard(h->device);
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 1;
+        OwnerDeviceLock guard(h->device, h->n_team + (h->n_owners - h->n_team + 3) / 4, cus);
+        if (!guard.ok) {
+            h->owner_busy = true;
+            return hipErrorNotReady;
+        }
         const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
         e = h->f64 ? launch_owner_epoch<double>(make_args<double>(h), h->model, h->owner_hub_item, h->strict, h->d_own_recs, h->d_own_off, h->n_owners, h->n_team, h->d_tagged,
                                                 h->own_stride, n_spokes, h->d_flow_err, h->stream)
@@ -1383,6 +1428,11 @@ static int enqueue_epoch(cmi_instance *h, double lrate, bool probing = false) {
     if (graph) CMI_HIP(h, hipGraphLaunch(h->graph_exec, h->stream));
     else {
         const hipError_t e = enqueue_levels(h);
+        if (h->owner_busy) {
+            h->owner_busy = false;
+            CMI_FAIL(h, CMI_E_HIP, "owner epoch not started: another process has held the owner-epoch lock of device %d for 60 s (persistent "
+                     "kernels of two processes must not share a device); the model is untouched -- retry, or use CMI_FLAG_NO_OWNER", h->device);
+        }
         if (h->owner_stalled)
             CMI_FAIL(h, CMI_E_HIP, "owner epoch stalled: a tuple waited past its bound for a predecessor's record (is another persistent kernel "
                      "holding compute units of device %d?) -- the model state is invalid; reload it and use CMI_FLAG_NO_OWNER", h->device);

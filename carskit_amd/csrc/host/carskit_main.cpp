@@ -134,11 +134,13 @@ static int run(const std::string &config, unsigned flags, int iters_override, bo
     std::string name;
     std::mutex mu;
     std::string fold_error;
+    int concurrent_folds = 1; // `cv -p on`: the folds that train side by side (set by the cv branch below)
     auto runFold = [&](const RatingData &tr, const RatingData &te, int fold, size_t slot) {
         try {
             Conf fc = conf; // fold -> GPU round robin (the reference runs one thread per fold, CARSKit.java:395-412)
             const int ngpu = cmi_device_count();
             if (ngpu > 1 && fold > 0) fc.device = (fold - 1) % ngpu;
+            fc.deviceShare = std::max(1, (concurrent_folds + std::max(1, ngpu) - 1) / std::max(1, ngpu)); // the folds that share this fold's GPU
             auto algo = getRecommender(algoName, tr, te, fold, fc, log);
             const Measures m = algo->execute();
             std::lock_guard<std::mutex> g(mu);
@@ -165,6 +167,7 @@ static int run(const std::string &config, unsigned flags, int iters_override, bo
             trs[(size_t)f - 1] = data.subset(tr);
             tes[(size_t)f - 1] = data.subset(te);
         }
+        concurrent_folds = parallel ? k : 1;
         for (int f = 1; f <= k; ++f) {
             if (parallel) ts.emplace_back(runFold, std::cref(trs[(size_t)f - 1]), std::cref(tes[(size_t)f - 1]), f, (size_t)f - 1);
             else runFold(trs[(size_t)f - 1], tes[(size_t)f - 1], f, (size_t)f - 1);

@@ -141,6 +141,7 @@ struct Conf {
     int64_t randSeed = 1;
     unsigned flags = 0;
     int device = 0;
+    int deviceShare = 1;       // recommenders training concurrently on `device` (`cv -p on`: the folds that landed on it): cmi_set_device_share
     int shards = 1;            // --shards N: ONE recommender sharded by user over N GPUs (cmi_group_*; the Java host's -Dcarskit.shards)
     double shardsLrScale = 0;  // local learning-rate scale of a sharded run; 0 = sqrt(shards)
     // item.ranking / ratings.setup -threshold / eval.strategy (Recommender.java:211-217,242; CARSKit.java:262)
@@ -341,6 +342,7 @@ class IterativeRecommender {
                             conf_.device, flags, &h_);
         if (rc != CMI_OK) throw std::runtime_error(std::string("cmi_create: ") + cmi_last_error(nullptr));
         check(cmi_set_hparams(h_, conf_.regU, conf_.regI, conf_.regB, conf_.regC, globalMean), h_, "cmi_set_hparams");
+        if (conf_.deviceShare > 1) check(cmi_set_device_share(h_, conf_.deviceShare), h_, "cmi_set_device_share");
         if (model_ >= CMI_MODEL_CAMF_ICS && model_ <= CMI_MODEL_CAMF_MCS)
             check(cmi_set_sim_params(h_, conf_.numF, std::max(1, trainMatrix.n_dims), trainMatrix.empty_conds.data(),
                                      (int)trainMatrix.empty_conds.size()),

@@ -158,6 +158,13 @@ int cmi_set_sim_params(cmi_handle h, int num_f, int n_ctx_dims, const int32_t *e
  * globalMean (Recommender.java:265) */
 int cmi_set_hparams(cmi_handle h, double regU, double regI, double regB, double regC, double global_mean);
 
+/* `cv -p on` (CARSKit.java:395-412: one thread per fold, every fold a recommender of its own): `instances` = how many instances the
+ * host trains CONCURRENTLY on this handle's device.  A hint, not semantics: the persistent kernels (the owner epoch, one launch whose
+ * wavefronts must all be resident) size their grids to 1 / instances of the device, so the instances' launches run side by side instead
+ * of one after another; results are what they are without the hint (the schedules are order-exact).  Call before cmi_set_ratings.
+ * Default 1.  instances < 1 -> CMI_E_INVALID. */
+int cmi_set_device_share(cmi_handle h, int instances);
+
 /* One pass of the `for (MatrixEntry me : trainMatrix) {...}` body + `loss *= 0.5`
  * (e.g. CAMF_CI.java:79-123) with learning rate lrate; *loss_out = the epoch's loss.  The host keeps
  * calling isConverged() itself (the Java drop-in does exactly this). */

@@ -271,3 +271,46 @@ def test_schedule_note_when_owner_limits_force_the_level_walk():
     i2 = capi.Instance("CAMF_CI", 8, small.n_users, small.n_items, small.n_conds)
     i2.set_ratings(small.u, small.j, small.ctx, small.r, small.ctx_ptr, small.ctx_conds)
     assert i2.schedule_note() == ""
+
+
+def test_device_share_runs_owner_epochs_side_by_side_and_changes_nothing():
+    """cmi_set_device_share (`cv -p on`: F folds on one GPU): an instance that declares F sharers sizes its persistent owner launch to
+    1 / F of the device, and the library lets such epochs run concurrently (their workgroups fit the device together) instead of one at
+    a time.  The schedule stays order-exact, so the model is bit for bit what the instance without the hint computes; three sharing
+    instances trained from three threads each match their own oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    data = synth.generate(3000, 300, 3, 4, 120000, seed=77, item_zipf=1.2)
+    st = synth.init_state("CAMF_CI", data, 64, seed=5, dtype=np.float32)
+
+    def make(share):
+        inst = capi.Instance("CAMF_CI", 64, data.n_users, data.n_items, data.n_conds, flags=OWNER)
+        inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+        if share:
+            inst.set_device_share(share)
+        inst.set_ratings(data.u, data.j, data.ctx, data.r, data.ctx_ptr, data.ctx_conds)
+        inst.set_states(st)
+        return inst
+
+    whole, part = make(0), make(5)
+    assert part.schedule_info()["kind"] == whole.schedule_info()["kind"] == "owner-item"
+    assert 0 < part.schedule_info()["flow_blocks"] <= whole.schedule_info()["flow_blocks"] // 4
+    for _ in range(3):
+        lw, lp = whole.train_epoch(util.LR), part.train_epoch(util.LR)
+        assert abs(lw - lp) <= 1e-9 * abs(lw)   # (the epoch loss is a sum of per-owner partial sums: other owners, another association)
+    for name in ("P", "Q", "userBias", "icBias"):
+        np.testing.assert_array_equal(whole.get_state(name), part.get_state(name))
+    with pytest.raises(capi.CmiError):
+        whole.set_device_share(0)
+
+    pairs = []
+    for seed in (1, 2, 3):
+        d = synth.generate(3000, 300, 3, 4, 120000, seed=500 + seed, item_zipf=1.2)
+        orc, inst = make_pair("CAMF_CI", d, 64, F64 | OWNER, before_ratings=lambda i: i.set_device_share(3))
+        pairs.append((orc, inst))
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        losses = list(pool.map(lambda p: [p[1].train_epoch(util.LR) for _ in range(3)], pairs))
+    for (orc, inst), ls in zip(pairs, losses):
+        for lg in ls:
+            lo = orc.epoch(util.LR)
+            assert abs(lo - lg) <= 1e-10 * abs(lo)
+        assert_state_equal(orc, inst, exact=False, atol=1e-11)

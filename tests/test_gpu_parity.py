@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 F64, SERIAL, STRICT, NOGRAPH = (capi.FLAG_STATE_F64, capi.FLAG_SCHED_SERIAL, capi.FLAG_STRICT, capi.FLAG_NO_GRAPH)
 
 
-def make_pair(model, data, k, flags, seed=5, regs=None):
+def make_pair(model, data, k, flags, seed=5, regs=None, before_ratings=None):
     """(oracle, gpu instance) over the same tuples and the same injected initial state."""
     regU, regI, regB, regC = regs or (util.REG, util.REG, util.REG, util.REGC)
     state = synth.init_state(model, data, k, seed=seed)
@@ -27,6 +27,8 @@ def make_pair(model, data, k, flags, seed=5, regs=None):
     u, j, ctx, r = util.tuples_for(model, data)
     inst = capi.Instance(model, k, data.n_users, data.n_items, data.n_conds, flags=flags)
     inst.set_hparams(regU, regI, regB, regC, gm)
+    if before_ratings:
+        before_ratings(inst)
     if model in util.TWO_D:
         inst.set_ratings(u, j, None, r)
     else:
