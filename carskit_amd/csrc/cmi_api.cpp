@@ -824,9 +824,12 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
                 return t;
             };
             const int wgs = (waves + 3) / 4; // resident workgroups
-            if (h->strict || h->device_share > 1 || (team_env && !strcmp(team_env, "0"))) {
-                // one wavefront per owner throughout (a shared device: the hottest rows' owners get no workgroup of their own -- and the
-                // team form was measured NOT exact beside another instance's persistent launch: tools/exp/share_debug.py)
+            if (h->strict || (h->device_share > 1 && !cmi_exp_env("CMI_SHARE_DEBUG_TEAMS")) || (team_env && !strcmp(team_env, "0"))) {
+                // one wavefront per owner throughout.  (A shared device: the hottest rows' owners get no workgroup of their own -- and
+                // the team form was measured NOT exact, 1e-7 off the fp64 oracle now and then, when ANOTHER owner epoch is in flight
+                // beside it; exact alone and beside level / chain kernels, the one-wavefront form exact in every combination:
+                // tools/exp/share_debug.py, docs/history/r05.md 7.  Unexplained; an instance without the hint takes the whole gate,
+                // so its teams never meet another owner epoch of this process.)
             } else if (team_env && !strcmp(team_env, "all")) { // testing: every owner a team, whatever its list
                 if (waves > wgs) {
                     waves = wgs;
@@ -1332,10 +1335,13 @@ static hipError_t enqueue_levels(cmi_instance *h) {
             return hipErrorNotReady;
         }
         const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
+        // the epoch's tag base: an odd multiple of the sequence number mod 2^32 -- two epochs' tags of one row differ by far more than a
+        // row has updates, so a record copy from an earlier epoch cannot carry the tag a tuple of this epoch waits for
+        const uint32_t tag0 = (uint32_t)(++h->owner_epoch_seq) * 0x9E3779B1u;
         e = h->f64 ? launch_owner_epoch<double>(make_args<double>(h), h->model, h->owner_hub_item, h->strict, h->d_own_recs, h->d_own_off, h->n_owners, h->n_team, h->d_tagged,
-                                                h->own_stride, n_spokes, h->d_flow_err, h->stream)
+                                                h->own_stride, n_spokes, h->d_flow_err, tag0, h->stream)
                    : launch_owner_epoch<float>(make_args<float>(h), h->model, h->owner_hub_item, false, h->d_own_recs, h->d_own_off, h->n_owners, h->n_team, h->d_tagged,
-                                               h->own_stride, n_spokes, h->d_flow_err, h->stream);
+                                               h->own_stride, n_spokes, h->d_flow_err, tag0, h->stream);
         if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) {

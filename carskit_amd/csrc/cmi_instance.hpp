@@ -30,6 +30,7 @@ struct cmi_instance {
     int32_t *d_next = nullptr, *d_first = nullptr;
     // owner (dataflow) schedule: one persistent launch, d_own_recs = the owners' lists, d_tagged = the spoke side's tagged records
     bool want_owner = false, owner = false, owner_hub_item = true;
+    uint32_t owner_epoch_seq = 0; // owner epochs launched so far (the epoch's tag base derives from it)
     bool owner_busy = false; // the last owner epoch was not launched: another process held the device's owner-epoch lock
     int device_share = 1; // cmi_set_device_share: instances training concurrently on this device (sizes the persistent kernels' grids)
     int n_owners = 0, n_team = 0; // owners [0, n_team) run as teams of three wavefronts

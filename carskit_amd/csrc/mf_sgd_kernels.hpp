@@ -34,6 +34,9 @@ struct SgdArgs {
     // null: rows are read from / written to the model table itself
     T *arena = nullptr;
     const int32_t *next_pos = nullptr;
+    // owner epoch: the tag a spoke record carries when the epoch begins (a row's tag = tag0 + its updates so far this epoch).  A new
+    // value every epoch, so that a copy of a record left anywhere from an EARLIER epoch can never pass for the one a tuple waits for.
+    uint32_t owner_tag0 = 0;
 };
 
 // spoke arena <-> model table (n_rows rows of k elements; first_pos[row] = stream position of the row's first tuple, -1: none)
@@ -194,6 +197,6 @@ int owner_grid_waves(int device, int model, int n_conds, int k, bool f64, bool h
 template <typename T>
 // owners [0, n_team) run as teams of three wavefronts (one workgroup each), the rest four to a workgroup
 hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, bool strict, const void *recs, const int64_t *own_off,
-                              int n_owners, int n_team, void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s);
+                              int n_owners, int n_team, void *tagged, int64_t stride, int n_spokes, int *error, uint32_t tag0, hipStream_t s);
 
 } // namespace cmi

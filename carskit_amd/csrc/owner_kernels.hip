@@ -124,24 +124,24 @@ __device__ __forceinline__ double wave_total(double x) {
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool TO_RECORDS>
 __global__ __launch_bounds__(256) void owner_records(T *__restrict__ rows, T *__restrict__ ctx, T *__restrict__ bias, gran_t *__restrict__ tagged,
-                                                     int64_t stride, int n_spokes, int k, int ncs, int vpl, int ncw) {
+                                                     int64_t stride, int n_spokes, int k, int ncs, int vpl, int ncw, uint32_t tag0) {
     const int lane = threadIdx.x & 63;
     const int row_cap = 64 * vpl;
     const int64_t waves = (int64_t)gridDim.x * 4;
     for (int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < n_spokes; s += waves) {
         gran_t *rec = tagged + s * stride;
         for (int e = lane; e < row_cap; e += 64) {
-            if (TO_RECORDS) Tagged<T>::store_plain(rec, e, e < k ? rows[s * k + e] : (T)0, 0u);
+            if (TO_RECORDS) Tagged<T>::store_plain(rec, e, e < k ? rows[s * k + e] : (T)0, tag0);
             else if (e < k) rows[s * k + e] = Tagged<T>::value(Tagged<T>::load(rec, e));
         }
         if (ctx)
             for (int c = lane; c < 64 * ncw; c += 64) {
-                if (TO_RECORDS) Tagged<T>::store_plain(rec, row_cap + c, c < ncs ? ctx[s * ncs + c] : (T)0, 0u);
+                if (TO_RECORDS) Tagged<T>::store_plain(rec, row_cap + c, c < ncs ? ctx[s * ncs + c] : (T)0, tag0);
                 else if (c < ncs) ctx[s * ncs + c] = Tagged<T>::value(Tagged<T>::load(rec, row_cap + c));
             }
         if (bias && lane == 0) {
             const int e = row_cap + (ctx ? 64 * ncw : 0);
-            if (TO_RECORDS) Tagged<T>::store_plain(rec, e, bias[s], 0u);
+            if (TO_RECORDS) Tagged<T>::store_plain(rec, e, bias[s], tag0);
             else bias[s] = Tagged<T>::value(Tagged<T>::load(rec, e));
         }
     }
@@ -520,12 +520,12 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
                 T sbv[1];
                 sbv[0] = (T)0;
                 if (!(r.flags & OWN_SPK_FWD)) {
-                    if (__builtin_expect(!__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want)), 0)) {
+                    if (__builtin_expect(!__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want + a.owner_tag0)), 0)) {
                         unsigned spins = 0;
                         while (true) {
                             __builtin_amdgcn_s_sleep(4);
                             owner_load_spoke<T, MODEL, VPL, NCW, HUB_ITEM>(rs, (int)r.off, lane, s);
-                            if (__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want))) break;
+                            if (__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want + a.owner_tag0))) break;
                             if (owner_spin_expired(spins, error, lane)) break;
                         }
                     }
@@ -582,7 +582,7 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
                 if (S::SB) last = bv[0];
                 r_next = recs[c + 1 + team_after(last)];
             }
-            const uint32_t tag = r.want + 1u;
+            const uint32_t tag = r.want + a.owner_tag0 + 1u;
             uint32_t ow[VPL * NW * 2], oc[NW * 2], ob[NW * 2];
 #pragma unroll
             for (int v = 0; v < VPL; ++v) owner_pack(ow, v, xv[v], tag);
@@ -797,12 +797,12 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
         }
         // ---- spoke side: registers | the record read ahead, if every granule carries the tag | poll
         if (!(r.flags & OWN_SPK_FWD)) {
-            if (__builtin_expect(!__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want)), 0)) {
+            if (__builtin_expect(!__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want + a.owner_tag0)), 0)) {
                 unsigned spins = 0;
                 while (true) { // the predecessor has not written the record yet (or was in the middle of it)
                     __builtin_amdgcn_s_sleep(4);
                     owner_load_spoke<T, MODEL, VPL, NCW, HUB_ITEM>(rs, (int)r.off, lane, s);
-                    if (__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want))) break;
+                    if (__all(owner_spoke_ok<T, MODEL, VPL, NCW, HUB_ITEM>(s, r.want + a.owner_tag0))) break;
                     if (owner_spin_expired(spins, error, lane)) break;
                 }
                 n_late += 1; // statistics: records that were not ready when their step came, and the polls spent on them
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
         // ---- the spoke record goes back with the next tag (always: one store sequence per step); the hub side when the next
         //      step of the list does not take it over in registers
         {
-            const uint32_t tag = r.want + 1u;
+            const uint32_t tag = r.want + a.owner_tag0 + 1u;
             uint32_t ow[VPL * NW * 2], oc[NW * 2], ob[NW * 2];
 #pragma unroll
             for (int v = 0; v < VPL; ++v) owner_pack(ow, v, x[v], tag);
@@ -979,7 +979,7 @@ int owner_grid_waves(int device, int model, int n_conds, int k, bool f64, bool h
 
 template <typename T>
 hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, bool strict, const void *recs, const int64_t *own_off,
-                              int n_owners, int n_team, void *tagged, int64_t stride, int n_spokes, int *error, hipStream_t s) {
+                              int n_owners, int n_team, void *tagged, int64_t stride, int n_spokes, int *error, uint32_t tag0, hipStream_t s) {
     const OwnerKernel kn = owner_kernel<T>(model, a.n_conds, a.k, hub_is_item, strict);
     if (!kn.fn) return hipErrorInvalidValue;
     const bool has_ic = model == CAMF_CI || model == CAMF_CUCI, has_uc = model == CAMF_CU || model == CAMF_CUCI;
@@ -991,8 +991,9 @@ hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, 
     const int ncs = sc ? a.n_conds : 0, vpl = owner_vpl(a.k), ncw = owner_mask_words(model, a.n_conds);
     const int pass_blocks = (int)std::min<int64_t>(((int64_t)n_spokes + 3) / 4, 256 * 16);
     hipLaunchKernelGGL((owner_records<T, true>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl,
-                       ncw);
+                       ncw, tag0);
     SgdArgs<T> args = a;
+    args.owner_tag0 = tag0;
     gran_t *tg = (gran_t *)tagged;
     if (strict) n_team = 0;
     void *params[] = {&args, &recs, &own_off, &tg, &error, &n_owners, &n_team};
@@ -1001,12 +1002,12 @@ hipError_t launch_owner_epoch(const SgdArgs<T> &a, int model, bool hub_is_item, 
     hipError_t e = hipLaunchKernel(kn.fn, dim3((unsigned)(n_team + (n_owners - n_team + 3) / 4)), dim3(256), params, lds, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((owner_records<T, false>), dim3(pass_blocks), dim3(256), 0, s, rows, ctx, bias, (gran_t *)tagged, stride, n_spokes, a.k, ncs, vpl,
-                       ncw);
+                       ncw, tag0);
     return hipGetLastError();
 }
 template hipError_t launch_owner_epoch<float>(const SgdArgs<float> &, int, bool, bool, const void *, const int64_t *, int, int, void *, int64_t, int,
-                                              int *, hipStream_t);
+                                              int *, uint32_t, hipStream_t);
 template hipError_t launch_owner_epoch<double>(const SgdArgs<double> &, int, bool, bool, const void *, const int64_t *, int, int, void *, int64_t, int,
-                                               int *, hipStream_t);
+                                               int *, uint32_t, hipStream_t);
 
 } // namespace cmi
