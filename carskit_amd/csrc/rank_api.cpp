@@ -595,7 +595,7 @@ hipError_t RankWorkspace::need(Buf &b, size_t bytes, bool pinned) {
 }
 
 void RankWorkspace::release() {
-    Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount, &dB2, &dA2, &dS2, &dqg, &dqd, &dgu, &ddc, &dscr, &dSb, &dAb};
+    Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount, &dB2, &dA2, &dS2, &dqg, &dqd, &dgu, &ddc, &dscr, &dSb, &dAb, &dcolc};
     if (sel_stream) (void)hipStreamDestroy(sel_stream);
     sel_stream = nullptr;
     for (std::vector<hipEvent_t> *v : {&evgemm, &evsel}) {
@@ -816,7 +816,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     ws.ctx_ready = false;
     const int n_dc = (int)dctx.size();
     lap("contexts");
-    a.kp1 = (a.k + 1 + 15) / 16 * 16;
+    a.kp1 = (a.k + 15) / 16 * 16; // (the item bias is not a column: the contraction's epilogue adds it -- k = 128 costs 8 steps of 16, not 9)
     a.kp2 = ic ? (a.n_conds + 15) / 16 * 16 : 16;
     a.nc = nc;
     a.nq = (int)nq;
@@ -832,6 +832,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
         if (e == hipSuccess) e = ws.need(b, bytes, pinned);
     };
     need(ws.dB, up128(nc) * a.kp1 * 4);
+    need(ws.dcolc, up128(nc) * 4);
     // two streams: the selection of batch b runs beside the contraction of batch b + 1 (matrix pipe beside the L2 / memory pipes), each
     // batch on the slab / operand buffer of its parity.  CMI_RANK_ONE_STREAM=1: the round-4 form, one stream, one slab (A/B)
     const bool one_stream = getenv("CMI_RANK_ONE_STREAM") != nullptr; // (read per call: bench.py times the two kernels on their own with it)
@@ -903,6 +904,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     a.qc = (const int32_t *)ws.dqc.p;
     a.dctx = (const int32_t *)ws.ddc.p;
     a.B1 = (float *)ws.dB.p;
+    a.colc = (float *)ws.dcolc.p;
     a.B2 = (float *)ws.dB2.p;
     a.A2 = (float *)ws.dA2.p;
     a.rc = (float *)ws.drc.p;
@@ -934,7 +936,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
         // (the builder leaves its per-row constant -- zero here -- in the scratch the contraction then reads as its row constant)
         if (e == hipSuccess) e = rank_launch_split_users(a, (const int32_t *)ws.dgu.p + g0, n, dAx, (float *)ws.dscr.p, stream);
         if (e == hipSuccess) e = ws.kernel_event(4 * b, stream);
-        if (e == hipSuccess) e = rank_launch_gemm<float>(dAx, a.B1, (const float *)ws.dscr.p, dSx, n, nc, a.kp1, stream);
+        if (e == hipSuccess) e = rank_launch_gemm<float>(dAx, a.B1, (const float *)ws.dscr.p, dSx, n, nc, a.kp1, stream, a.colc);
         if (e == hipSuccess) e = ws.kernel_event(4 * b + 1, stream);
         if (two && e == hipSuccess) {
             hipEvent_t g = ev_at(ws.evgemm, b);

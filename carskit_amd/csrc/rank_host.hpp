@@ -51,6 +51,7 @@ struct RankWorkspace {
     };
     Buf dA, dB, dS, drc, dcand, dqu, dqc, dexptr, dexcl, dtop, dscore, dcount; // device
     Buf dB2, dA2, dS2, dqg, dqd, dgu, ddc, dscr;                                // device, split form (rank_run_device_split)
+    Buf dcolc;                                                                  // split form: itemBias of the candidates (the S1 contraction adds it at the end)
     Buf dSb, dAb;                                                               // split form: the second slab / operand buffer (batch b + 1 is contracted while batch b is selected)
     hipStream_t sel_stream = nullptr;                                           // split form: the selection's stream
     std::vector<hipEvent_t> evgemm, evsel;                                           // per batch: contraction done (main stream), selection done (selection stream)

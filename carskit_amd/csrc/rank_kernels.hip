@@ -32,10 +32,11 @@ __global__ void rank_build_items(RankItemsArgs<T> a) { // one block per candidat
     for (int f = threadIdx.x; f < a.kp; f += blockDim.x) {
         T v = 0;
         if (f < a.k) v = a.Q[(size_t)j * a.k + f];
-        else if (f == a.k) v = a.itemBias ? a.itemBias[j] : (T)0;
+        else if (f == a.k) v = a.itemBias && !a.bias_out ? a.itemBias[j] : (T)0;
         else if (f < a.k + 1 + a.n_conds) v = a.icBias ? a.icBias[(size_t)j * a.n_conds + (f - a.k - 1)] : (T)0;
         dst[f] = v;
     }
+    if (a.bias_out && threadIdx.x == 0) a.bias_out[c] = a.itemBias ? a.itemBias[j] : (T)0;
 }
 
 template <typename T>
@@ -122,7 +123,7 @@ hipError_t rank_launch_fm_queries(const RankFmArgs &a, const int32_t *qu, const 
 
 template <typename T>
 __global__ __launch_bounds__(256) void rank_gemm(const T *__restrict__ A, const T *__restrict__ B, const T *row_const,
-                                                 T *__restrict__ S, int nq, int nc, int kp) {
+                                                 T *__restrict__ S, int nq, int nc, int kp, const T *__restrict__ col_const) {
     constexpr int TM = 64, TN = 64, TK = 16;
     __shared__ T sA[TK][TM + 1];
     __shared__ T sB[TK][TN + 1];
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void rank_gemm(const T *__restrict__ A, const 
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int c = c0 + tx * 4 + jj;
-            if (c < nc) S[(size_t)q * nc + c] = acc[i][jj] + rc;
+            if (c < nc) S[(size_t)q * nc + c] = (col_const ? acc[i][jj] + col_const[c] : acc[i][jj]) + rc;
         }
     }
 }
@@ -184,7 +185,7 @@ constexpr int RG_TPR = RG_BK / 4, RG_RPP = 256 / RG_TPR, RG_NP = RG_BM / RG_RPP;
 #endif
 __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const float *__restrict__ A, const float *__restrict__ B,
                                                           const float *__restrict__ row_const, float *__restrict__ S,
-                                                          int nq, int nc, int kp_pad, int tiles_c, int n_tiles) {
+                                                          int nq, int nc, int kp_pad, int tiles_c, int n_tiles, const float *__restrict__ col_const) {
     __shared__ float sA[2][RG_BK][RG_LDS];
     __shared__ float sB[2][RG_BK][RG_LDS];
     // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give XCD x the x-th contiguous
@@ -264,6 +265,11 @@ __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const fl
         if (it + 1 < nk) __syncthreads(); // the other buffer was last read one barrier ago
     }
     // D layout of the 32x32 MFMA: column (B index) = lane & 31, row (A index) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float cc[2] = {0.f, 0.f};
+    if (col_const) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[j] = col_const[min(c0 + wc + 32 * j + mrow, nc - 1)];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const fl
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int c = c0 + wc + 32 * j + mrow;
-                if (c < nc) S[(size_t)q * nc + c] = acc[i][j][r] + rc;
+                if (c < nc) S[(size_t)q * nc + c] = (col_const ? acc[i][j][r] + cc[j] : acc[i][j][r]) + rc;
             }
         }
 }
@@ -551,18 +557,18 @@ hipError_t rank_launch_build_queries(const RankQueryArgs<T> &a, int nq, hipStrea
     return hipGetLastError();
 }
 template <typename T>
-hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s) {
+hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s, const T *col_const) {
     if (nq <= 0 || nc <= 0) return hipSuccess;
     static const bool force_valu = cmi_exp_env("CMI_RANK_VALU") != nullptr; // A/B experiments only
     if constexpr (sizeof(T) == 4) {
         if (!force_valu && kp % RG_BK == 0) {
             const int tiles_c = (nc + RG_BN - 1) / RG_BN, n_tiles = tiles_c * ((nq + RG_BM - 1) / RG_BM);
             hipLaunchKernelGGL(rank_gemm_mfma_f32, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, s, (const float *)A,
-                               (const float *)B, (const float *)row_const, (float *)S, nq, nc, kp, tiles_c, n_tiles);
+                               (const float *)B, (const float *)row_const, (float *)S, nq, nc, kp, tiles_c, n_tiles, (const float *)col_const);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, S, nq, nc, kp);
+    hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, S, nq, nc, kp, col_const);
     return hipGetLastError();
 }
 template <typename T>
@@ -570,7 +576,7 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
                              const int64_t *excl_ptr, const int32_t *excl_idx, int q_base, double thold, int topn,
                              int32_t *out_idx, double *out_score, int32_t *out_count, hipStream_t s) {
     if (nq <= 0 || nc <= 0) return hipSuccess;
-    if (hipError_t e = rank_launch_gemm<T>(A, B, row_const, S, nq, nc, kp, s)) return e;
+    if (hipError_t e = rank_launch_gemm<T>(A, B, row_const, S, nq, nc, kp, s, nullptr)) return e;
     hipLaunchKernelGGL(rank_mask<T>, dim3(nq), dim3(64), 0, s, S, nc, excl_ptr, excl_idx, q_base, nq);
     if (topn <= 64)
         hipLaunchKernelGGL(rank_topn_stream<T>, dim3((nq + 3) / 4), dim3(256), 0, s, (const T *)S, nq, nc, thold, topn, out_idx,
@@ -583,8 +589,8 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
 
 
 hipError_t rank_launch_split_operands(const RankSplitArgs &a, hipStream_t s) {
-    // B1 = [Q[j] | itemBias[j] or 0] for the candidates
-    RankItemsArgs<float> ia{a.Q, a.itemBias, nullptr, a.cand, a.B1, a.nc, a.k, a.kp1, 0};
+    // B1 = Q[j] for the candidates (k columns, zero-padded to kp1); itemBias[j] goes to colc: the contraction adds it at the end
+    RankItemsArgs<float> ia{a.Q, a.itemBias, nullptr, a.cand, a.B1, a.nc, a.k, a.kp1, 0, a.colc};
     if (hipError_t e = rank_launch_build_items<float>(ia, s)) return e;
     if (a.icBias) {
         hipLaunchKernelGGL(rank_build_ic_items<float>, dim3(a.nc), dim3(64), 0, s, a.icBias, a.cand, a.B2, a.n_conds, a.kp2);
@@ -614,7 +620,7 @@ hipError_t rank_launch_split_select(const float *S1, const float *S2, const Rank
 #define CMI_INST(T)                                                                                                    \
     template hipError_t rank_launch_build_items<T>(const RankItemsArgs<T> &, hipStream_t);                             \
     template hipError_t rank_launch_build_queries<T>(const RankQueryArgs<T> &, int, hipStream_t);                      \
-    template hipError_t rank_launch_gemm<T>(const T *, const T *, const T *, T *, int, int, int, hipStream_t);        \
+    template hipError_t rank_launch_gemm<T>(const T *, const T *, const T *, T *, int, int, int, hipStream_t, const T *);        \
     template hipError_t rank_launch_score<T>(const T *, const T *, const T *, T *, int, int, int, const int64_t *,     \
                                              const int32_t *, int, double, int, int32_t *, double *, int32_t *, hipStream_t);
 CMI_INST(float)

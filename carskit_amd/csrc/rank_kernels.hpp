@@ -11,6 +11,7 @@ struct RankItemsArgs {
     const int32_t *cand;            // candidate position -> item id
     T *B;                           // [n_cand][kp]
     int n_cand, k, kp, n_conds;
+    T *bias_out = nullptr;          // not null: itemBias[cand] goes HERE (a per-candidate constant the contraction adds at the end) and not into column k
 };
 
 template <typename T>
@@ -52,6 +53,7 @@ struct RankSplitArgs {
     const int32_t *ctx_ptr, *ctx_conds;                                    // null for the 2-D models
     const int32_t *cand, *qu, *qc, *dctx;                                  // candidates; per query user / context; distinct contexts
     float *B1, *B2, *A2, *rc;                                              // operands built once per evaluation
+    float *colc = nullptr;                                                 // [nc] itemBias of the candidates (added by the S1 contraction's epilogue)
     double gm;
     int k, kp1, kp2, n_conds, nc, nq, n_dctx;
 };
@@ -60,8 +62,9 @@ hipError_t rank_launch_split_users(const RankSplitArgs &a, const int32_t *d_grou
 hipError_t rank_launch_split_select(const float *S1, const float *S2, const RankSplitArgs &a, const int32_t *q_group, const int32_t *q_dctx, int g_base,
                                     int q0, int nq, const int64_t *excl_ptr, const int32_t *excl_idx, double thold, int topn, int32_t *out_idx,
                                     double *out_score, int32_t *out_count, hipStream_t s);
-// S = A.B^T + row_const (the contraction alone)
+// S = (A.B^T [+ col_const]) + row_const (the contraction alone).  col_const[c] is added to the finished dot product first: the same value
+// as one more column {1 | col_const[c]} at the end of the k-ordered chain (fma(1, b, acc) = acc + b), without the 16 padded columns it costs
 template <typename T>
-hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s);
+hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s, const T *col_const = nullptr);
 
 } // namespace cmi
