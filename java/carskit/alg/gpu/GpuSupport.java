@@ -101,6 +101,10 @@ final class GpuSupport {
     static void upload(GpuHost r, long h, boolean twoD) {
         DataDAO dao = Recommender.rateDao;
         SparseMatrix tm = r.contextualTrain();
+        // `cv -p on` (CARSKit.java:395-412): -Dcarskit.folds.per.gpu=F tells the library how many fold threads train side by side on this
+        // GPU (cmi_set_device_share: their persistent owner epochs then run concurrently instead of taking turns); default 1
+        int share = Math.max(1, Integer.getInteger("carskit.folds.per.gpu", 1));
+        if (share > 1) NativeMF.setDeviceShare(h, share);
         r.prepare(h);
         if (twoD) {
             librec.data.SparseMatrix t2 = r.train2D();

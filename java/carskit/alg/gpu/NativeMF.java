@@ -40,6 +40,8 @@ public final class NativeMF {
     public static native void setVector(long h, int which, double[] v);
     public static native void getVector(long h, int which, double[] v);
     public static native void setHparams(long h, double regU, double regI, double regB, double regC, double globalMean);
+    /** cmi_set_device_share: recommenders training concurrently on this handle's GPU (`cv -p on`); before setRatings*. */
+    public static native void setDeviceShare(long h, int instances);
     /** cmi_train_epoch: one pass of the for(MatrixEntry me : trainMatrix) body; returns loss (already *0.5). */
     public static native double trainEpoch(long h, double lRate);
     /** cmi_train: the whole buildModel() loop on the native side (isConverged/updateLRate included); returns the epochs run,

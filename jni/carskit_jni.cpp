@@ -177,6 +177,10 @@ JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setHparams(JNIEnv *env, jcl
     throw_cmi(env, (cmi_handle)h, cmi_set_hparams((cmi_handle)h, regU, regI, regB, regC, globalMean));
 }
 
+JNIEXPORT void JNICALL Java_carskit_alg_gpu_NativeMF_setDeviceShare(JNIEnv *env, jclass, jlong h, jint instances) {
+    throw_cmi(env, (cmi_handle)h, cmi_set_device_share((cmi_handle)h, (int)instances));
+}
+
 JNIEXPORT jdouble JNICALL Java_carskit_alg_gpu_NativeMF_trainEpoch(JNIEnv *env, jclass, jlong h, jdouble lRate) {
     double loss = 0;
     throw_cmi(env, (cmi_handle)h, cmi_train_epoch((cmi_handle)h, lRate, &loss));
