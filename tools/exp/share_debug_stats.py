@@ -1,0 +1,37 @@
+"""GPU box, `make EXP=1` library: python tools/exp/share_debug_stats.py [k] -- how often is an instance WITH teams, trained beside two
+other owner epochs (cmi_set_device_share(3)), not bit-identical to the one-wavefront form?  12 runs each in fp32 and fp64.
+Round 5: k = 64: fp32 0 / 12, fp64 12 / 12; k = 128: 0 / 12 and 0 / 12."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import numpy as np
+from concurrent.futures import ThreadPoolExecutor
+from carskit_amd import capi, synth
+from tests import util
+OWNER, F64 = capi.FLAG_SCHED_OWNER, capi.FLAG_STATE_F64
+os.environ["CMI_SHARE_DEBUG_TEAMS"] = "1"
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+def make(d, team, flags):
+    if team is None: os.environ.pop("CMI_OWNER_TEAM", None)
+    else: os.environ["CMI_OWNER_TEAM"] = team
+    st = synth.init_state("CAMF_CI", d, K, seed=5, dtype=np.float64 if flags & F64 else np.float32)
+    i = capi.Instance("CAMF_CI", K, d.n_users, d.n_items, d.n_conds, flags=OWNER | flags)
+    i.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+    i.set_device_share(3)
+    i.set_ratings(d.u, d.j, d.ctx, d.r, d.ctx_ptr, d.ctx_conds)
+    i.set_states(st)
+    return i
+ds = [synth.generate(3000, 300, 3, 4, 120000, seed=500 + s, item_zipf=1.2) for s in (1, 2, 3)]
+for flags in (0, F64):
+    ref = make(ds[0], "0", flags)
+    for _ in range(3): ref.train_epoch(util.LR)
+    a = ref.get_states()
+    bad = 0
+    for rep in range(12):
+        conc = [make(ds[0], None, flags), make(ds[1], "0", flags), make(ds[2], "0", flags)]
+        with ThreadPoolExecutor(max_workers=3) as pool:
+            list(pool.map(lambda i: [i.train_epoch(util.LR) for _ in range(3)], conc))
+        b = conc[0].get_states()
+        e = max(float(np.max(np.abs(a[n].astype(np.float64) - b[n].astype(np.float64)))) for n in a)
+        bad += e > 0
+        for c in conc: c.close()
+    print("k", K, "f64" if flags else "f32", "inexact runs", bad, "of 12")
