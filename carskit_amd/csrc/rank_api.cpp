@@ -1195,24 +1195,38 @@ static int eval_rankings_impl(cmi_handle h, int64_t n_train, const int32_t *tu, 
             size_t bytes;
         } arrs[] = {{tu, (size_t)n_train * 4}, {tj, (size_t)n_train * 4}, {tctx, (size_t)n_train * 4}, {tr, tr ? (size_t)n_train * 8 : 0},
                     {su, (size_t)n_test * 4},  {sj, (size_t)n_test * 4},  {sctx, (size_t)n_test * 4},  {sr, (size_t)n_test * 8}};
+        // one pass of the host's cores over all eight arrays as one run of 32-bit words; every thread keeps four independent chains
+        // (the multiply's latency is the pace of one)
         uint64_t hsh = 0x9E3779B97F4A7C15ull;
-        for (const Arr &a : arrs) {
-            const int64_t words = (int64_t)(a.bytes / 4);
-            const int nt = host_threads(words / 4);
-            std::vector<uint64_t> part((size_t)nt, 0);
-            const uint32_t *w = (const uint32_t *)a.p;
-            parallel_ranges(words, nt, [&](int t, int64_t b, int64_t e) {
-                uint64_t x = 0xCBF29CE484222325ull ^ (uint64_t)b;
-                for (int64_t i = b; i < e; ++i) {
-                    x ^= w[i];
-                    x *= 0x100000001B3ull;
-                    x ^= x >> 29;
+        int64_t first[9] = {0};
+        for (int i = 0; i < 8; ++i) first[i + 1] = first[i] + (int64_t)(arrs[i].bytes / 4);
+        const int64_t words = first[8];
+        const int nt = host_threads(words / 16);
+        std::vector<uint64_t> part((size_t)nt, 0);
+        parallel_ranges(words, nt, [&](int t, int64_t b, int64_t e) {
+            uint64_t x[4] = {0xCBF29CE484222325ull ^ (uint64_t)b, 0x84222325CBF29CE4ull, 0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full};
+            int ai = 0;
+            while (ai < 7 && first[ai + 1] <= b) ++ai;
+            for (int64_t i = b; i < e;) {
+                while (first[ai + 1] <= i) ++ai;
+                const uint32_t *w = (const uint32_t *)arrs[ai].p - first[ai];
+                const int64_t stop = std::min<int64_t>(e, first[ai + 1]);
+                for (; i + 4 <= stop; i += 4)
+                    for (int l = 0; l < 4; ++l) {
+                        x[l] ^= w[i + l];
+                        x[l] *= 0x100000001B3ull;
+                        x[l] ^= x[l] >> 29;
+                    }
+                for (; i < stop; ++i) {
+                    x[0] ^= w[i];
+                    x[0] *= 0x100000001B3ull;
+                    x[0] ^= x[0] >> 29;
                 }
-                part[(size_t)t] = x;
-            });
-            for (uint64_t x : part) hsh = (hsh ^ x) * 0xFF51AFD7ED558CCDull + (hsh >> 31);
-            hsh ^= a.bytes + (a.p ? 1 : 0);
-        }
+            }
+            part[(size_t)t] = ((x[0] * 0xFF51AFD7ED558CCDull ^ x[1]) * 0xFF51AFD7ED558CCDull ^ x[2]) * 0xFF51AFD7ED558CCDull ^ x[3];
+        });
+        for (uint64_t x : part) hsh = (hsh ^ x) * 0xFF51AFD7ED558CCDull + (hsh >> 31);
+        for (const Arr &a : arrs) hsh = (hsh ^ (a.bytes + (a.p ? 1 : 0))) * 0x100000001B3ull;
         key.hash = hsh;
     }
     if (!(ws.plan_valid && ws.plan_key == key) || cmi_exp_env("CMI_RANK_NO_PLAN_CACHE")) {
