@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -284,11 +285,21 @@ struct FmCellsHost {
 static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, const int32_t *ctx, int count, int other_count, int other_base,
                            int n_conds, int64_t slice_entries, int batch_cap, int slot_cap, int h_split, FmCellsHost &o, bool slot_in_word = false) {
     o.count = count;
+    const bool times = getenv("CMI_SETUP_TIMES") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) {
+        if (!times) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "fm cells (%d coordinates) %s %.3f s\n", count, w, std::chrono::duration<double>(t - T0).count());
+        T0 = t;
+    };
     // atomic form: the geometry (sub-slices, groups) is the deterministic form's, but a cell is cut into chunks of <= FMC_CHUNK records
     const int cut = slot_in_word ? std::min(batch_cap, FMC_CHUNK) : batch_cap;
     const int max_vs = (cut + FMC_RUN - 1) / FMC_RUN; // slots the longest possible run inside one batch needs
     std::vector<int32_t> deg((size_t)count, 0), vs((size_t)count, 1);
-    for (int64_t t = 0; t < n; ++t) deg[(size_t)key[t]]++;
+    parallel_ranges(n, host_threads(n), [&](int, int64_t b, int64_t e) { // (relaxed atomic increments: a count does not care about order)
+        for (int64_t t = b; t < e; ++t) __atomic_fetch_add(&deg[(size_t)key[t]], 1, __ATOMIC_RELAXED);
+    });
     // groups: first a bound on the slots (one per coordinate, more for coordinates hot enough to have runs > FMC_RUN inside a batch --
     // refined below once the sub-slices are known; a coordinate's records spread evenly over sub-slices only if the gathered ids do)
     int64_t ng_min = std::max<int64_t>(1, (int64_t)std::ceil((double)count / (0.97 * (double)slot_cap)));
@@ -315,10 +326,12 @@ static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, 
         // (ratings with a context feature sit in one extra cell per block: counted per (coordinate, id-range part) in columns SS .. SS + H)
         const int64_t W = SS + H;
         std::vector<int32_t> cs((size_t)count * (size_t)W, 0);
-        for (int64_t t = 0; t < n; ++t) {
-            const int64_t ss = other[t] / sub_len;
-            cs[(size_t)key[t] * (size_t)W + (size_t)(ctx[t] < n_conds ? SS + ss % H : ss)]++;
-        }
+        parallel_ranges(n, host_threads(n), [&](int, int64_t b, int64_t e) {
+            for (int64_t t = b; t < e; ++t) {
+                const int64_t ss = other[t] / sub_len;
+                __atomic_fetch_add(&cs[(size_t)key[t] * (size_t)W + (size_t)(ctx[t] < n_conds ? SS + ss % H : ss)], 1, __ATOMIC_RELAXED);
+            }
+        });
         parallel_ranges(count, host_threads(count), [&](int, int64_t b, int64_t e) {
             for (int64_t l = b; l < e; ++l) {
                 int32_t m = 0;
@@ -327,6 +340,7 @@ static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, 
             }
         });
     }
+    lap("degrees + slots per coordinate");
     // a coordinate with more records than a group's target is cut by record rank into parts, each a group of its own
     std::vector<int32_t> grp_of((size_t)count, 0), loc((size_t)count, 0); // first group of a coordinate, its first slot inside the group
     std::vector<int32_t> grp_slots;
@@ -410,12 +424,17 @@ static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, 
             o.cplx.push_back(stride);
         }
     }
+    lap("groups");
     // every record's cell = (block, sub-slice index inside the block's walk), ratings with a context feature in an extra cell at the
     // block's end (index S); counting sort by cell, then gathered id inside the cell, stable in the caller's order
     const int64_t S1 = S + 1, NC = NB * S1;
     std::vector<int64_t> cell_off((size_t)NC + 1, 0);
     std::vector<int32_t> rcell((size_t)n);
-    {
+    o.src.resize((size_t)n);
+    bool any_giant = false;
+    for (int l = 0; l < count && !any_giant; ++l) any_giant = giant(l);
+    const int nt_cells = any_giant ? 1 : host_threads(n);
+    if (nt_cells < 2) { // (a giant's records are dealt to its groups by their rank in the caller's order: one walk)
         std::vector<int32_t> rank((size_t)count, 0);
         for (int64_t t = 0; t < n; ++t) {
             const int32_t l = key[t];
@@ -426,19 +445,51 @@ static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, 
             rcell[(size_t)t] = (int32_t)cell;
             cell_off[(size_t)cell + 1]++;
         }
-    }
-    for (int64_t c = 0; c < NC; ++c) cell_off[(size_t)c + 1] += cell_off[(size_t)c];
-    o.src.resize((size_t)n);
-    {
+        for (int64_t c = 0; c < NC; ++c) cell_off[(size_t)c + 1] += cell_off[(size_t)c];
         std::vector<int64_t> cur(cell_off.begin(), cell_off.end() - 1);
         for (int64_t t = 0; t < n; ++t) o.src[(size_t)cur[(size_t)rcell[(size_t)t]]++] = (int32_t)t;
+    } else { // the same stable counting sort in ranges: per-range histograms, offsets in range order, every range scatters its own records
+        std::vector<std::vector<int64_t>> hist((size_t)nt_cells, std::vector<int64_t>((size_t)NC, 0));
+        parallel_ranges(n, nt_cells, [&](int th, int64_t b, int64_t e) {
+            std::vector<int64_t> &hh = hist[(size_t)th];
+            for (int64_t t = b; t < e; ++t) {
+                const int64_t g = grp_of[(size_t)key[t]];
+                const int64_t ss = other[t] / sub_len;
+                const int64_t cell = (g * H + ss % H) * S1 + (ctx[t] < n_conds ? S : ss / H);
+                rcell[(size_t)t] = (int32_t)cell;
+                hh[(size_t)cell]++;
+            }
+        });
+        for (int64_t c = 0; c < NC; ++c) {
+            int64_t run = cell_off[(size_t)c];
+            for (int th = 0; th < nt_cells; ++th) {
+                const int64_t cnt = hist[(size_t)th][(size_t)c];
+                hist[(size_t)th][(size_t)c] = run; // first position of range th's records of cell c
+                run += cnt;
+            }
+            cell_off[(size_t)c + 1] = run;
+        }
+        parallel_ranges(n, nt_cells, [&](int th, int64_t b, int64_t e) { // (the same ranges as above: parallel_ranges cuts [0, n) by nt alone)
+            std::vector<int64_t> &cur = hist[(size_t)th];
+            for (int64_t t = b; t < e; ++t) o.src[(size_t)cur[(size_t)rcell[(size_t)t]]++] = (int32_t)t;
+        });
     }
     std::vector<int32_t>().swap(rcell);
+    lap("cells: count + scatter");
     parallel_ranges(NC, host_threads(NC * 64), [&](int, int64_t cb, int64_t ce) {
-        for (int64_t c = cb; c < ce; ++c)
-            std::sort(o.src.begin() + cell_off[(size_t)c], o.src.begin() + cell_off[(size_t)c + 1],
-                      [&](int32_t x, int32_t y) { return other[x] != other[y] ? other[x] < other[y] : x < y; });
+        std::vector<uint64_t> keys; // {gathered id, rating}: one plain sort, no look-ups from the comparator
+        for (int64_t c = cb; c < ce; ++c) {
+            const int64_t c0 = cell_off[(size_t)c], len = cell_off[(size_t)c + 1] - c0;
+            keys.resize((size_t)len);
+            for (int64_t i = 0; i < len; ++i) {
+                const int32_t t = o.src[(size_t)(c0 + i)];
+                keys[(size_t)i] = ((uint64_t)(uint32_t)other[t] << 32) | (uint32_t)t;
+            }
+            std::sort(keys.begin(), keys.end());
+            for (int64_t i = 0; i < len; ++i) o.src[(size_t)(c0 + i)] = (int32_t)(uint32_t)keys[(size_t)i];
+        }
     });
+    lap("sort inside cells");
     // batches (cells cut into <= batch_cap records), their slot boundaries and every record's parked position
     o.bat_off.assign((size_t)NB + 1, 0);
     std::vector<int64_t> bat_first((size_t)NB + 1, 0), poff_first((size_t)NB + 1, 0);
@@ -480,6 +531,23 @@ static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, 
                 for (int64_t r0 = c0; r0 < c1; r0 += cut) {
                     const int64_t r1 = std::min<int64_t>(c1, r0 + cut);
                     // slot of a record: the coordinate's first slot in the group + (its rank inside the batch's run) / FMC_RUN
+                    if (slot_in_word) { // atomic form: no positions, no boundaries -- work proportional to the chunk, not to the group's slots
+                        if (run.size() < (size_t)ns) run.assign((size_t)ns, 0); // (all zero between chunks)
+                        const int64_t ff0 = ff;
+                        for (int64_t r = r0; r < r1; ++r) {
+                            const int32_t t = o.src[(size_t)r], first = loc[(size_t)key[t]];
+                            const uint32_t the_slot = (uint32_t)(first + run[(size_t)first]++ / FMC_RUN);
+                            o.pk[(size_t)r] = (fl ? 0u : (uint32_t)(other[t] - id0)) | (the_slot << 17);
+                            if (fl) {
+                                o.fo[(size_t)ff] = other[t];
+                                o.fcx[(size_t)ff++] = ctx[t];
+                            }
+                        }
+                        for (int64_t r = r0; r < r1; ++r) run[(size_t)loc[(size_t)key[o.src[(size_t)r]]]] = 0;
+                        o.bat[(size_t)bi++] = FmBatch{(int32_t)r0, (int32_t)(r1 - r0), fl ? (int32_t)ff0 : (int32_t)(other_base + id0), (int32_t)pf,
+                                                      fl ? (int32_t)(r1 - r0) : 0, 0};
+                        continue;
+                    }
                     run.assign((size_t)ns, 0); // per FIRST slot of a coordinate: its records seen so far in this batch
                     std::fill(cnt.begin(), cnt.end(), 0);
                     for (int64_t r = r0; r < r1; ++r) {
@@ -511,6 +579,7 @@ static void fm_build_cells(int64_t n, const int32_t *key, const int32_t *other, 
             }
         }
     });
+    lap("batches + packed words");
     if (getenv("CMI_FM_DEBUG")) {
         int64_t maxcell = 0, maxblk = 0, minblk = n;
         for (int64_t c = 0; c < NC; ++c) maxcell = std::max(maxcell, cell_off[(size_t)c + 1] - cell_off[(size_t)c]);
@@ -576,6 +645,15 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
     FM_HIP(h, hipSetDevice(h->device));
     FM_HIP(h, hipStreamSynchronize(h->stream));
     fm_free_ratings(h);
+    const bool times = getenv("CMI_SETUP_TIMES") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) {
+        if (!times) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "fm_set_ratings %s %.3f s\n", w, std::chrono::duration<double>(t - T0).count());
+        T0 = t;
+    };
+    lap("validate");
     FmCellsHost cu, ci;
     FmOrderHost oc;
     {
@@ -608,17 +686,24 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
         if (hc) tc.join();
         else ctx_order();
     }
+    lap("cells + context order (three threads)");
     // the ratings as plain arrays in the caller's order (cmi_fm_init computes err0 there; every stream copies its err0 through `src`)
     hipError_t e = hipSuccess;
     {
-        std::vector<int32_t> tu(u, u + n), tj(j, j + n), tc(ctx, ctx + n);
-        std::vector<double> tr(r, r + n);
-        e = up(&h->d_u, tu, h->stream);
-        if (e == hipSuccess) e = up(&h->d_j, tj, h->stream);
-        if (e == hipSuccess) e = up(&h->d_ctx, tc, h->stream);
-        if (e == hipSuccess) e = up(&h->d_r, tr, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // the vectors are locals
+        auto up_raw = [&](auto **dst, const auto *src) { // straight from the caller's arrays (they outlive the synchronize below)
+            *dst = nullptr;
+            if (n == 0) return hipSuccess;
+            hipError_t e2 = hipMalloc((void **)dst, (size_t)n * sizeof(**dst));
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(*dst, src, (size_t)n * sizeof(**dst), hipMemcpyHostToDevice, h->stream);
+            return e2;
+        };
+        e = up_raw(&h->d_u, u);
+        if (e == hipSuccess) e = up_raw(&h->d_j, j);
+        if (e == hipSuccess) e = up_raw(&h->d_ctx, ctx);
+        if (e == hipSuccess) e = up_raw(&h->d_r, r);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     }
+    lap("tuple upload");
     if (e == hipSuccess && n > 0) e = hipMalloc((void **)&h->d_E, (size_t)n * sizeof(double));
     if (e == hipSuccess) e = up(&h->d_src[0], cu.src, h->stream);
     if (e == hipSuccess) e = up(&h->d_src[1], ci.src, h->stream);
@@ -631,6 +716,7 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
         fm_free_ratings(h);
         FM_FAIL(h, CMI_E_HIP, "fm_set_ratings: upload failed: %s", hipGetErrorString(e));
     }
+    lap("stream upload");
     h->n = n;
     h->have_ratings = true;
     return CMI_OK;
