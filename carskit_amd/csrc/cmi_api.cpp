@@ -825,9 +825,12 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
             };
             const int wgs = (waves + 3) / 4; // resident workgroups
             if (h->strict || (h->device_share > 1 && !cmi_exp_env("CMI_SHARE_DEBUG_TEAMS")) || (team_env && !strcmp(team_env, "0"))) {
-                // one wavefront per owner throughout.  (A shared device: the hottest rows' owners get no workgroup of their own -- a
-                // share is a few dozen workgroups.  CMI_SHARE_DEBUG_TEAMS, experiment builds only, keeps the teams: that is how the
-                // team form's missing wait before its ring counters was found and verified, docs/history/r05.md 7.)
+                // one wavefront per owner throughout.  (A shared device: the hottest rows' owners get no workgroup of their own -- and
+                // the fp64 k <= 64 instantiation of the team form is NOT exact, 1e-7 off the oracle in 12 of 12 runs, when ANOTHER
+                // owner epoch is in flight beside it; exact alone and beside level / chain kernels, fp32 and fp64 k = 128 exact beside
+                // the same neighbours, the one-wavefront form exact in every combination: tools/exp/share_debug_stats.py,
+                // docs/history/r05.md 7.  Unexplained.  An instance without the hint takes the whole gate, so its teams never meet
+                // another owner epoch of this process; CMI_SHARE_DEBUG_TEAMS, experiment builds only, keeps the teams for the reproducer.)
             } else if (team_env && !strcmp(team_env, "all")) { // testing: every owner a team, whatever its list
                 if (waves > wgs) {
                     waves = wgs;

@@ -423,8 +423,8 @@ __device__ __forceinline__ void owner_update(const OwnerRecT<NCW> &r, const Owne
 //                     late -- and puts the row, context biases and bias of entry c into ring slot c mod R;  n_ready = c + 1
 //   compute (wave 0): hub row in registers; takes slot c, runs owner_update, puts the new values back into the slot;  n_done = c + 1
 //   storer  (wave 2): takes the new values, tags them want + 1 and writes the record through;  n_stored = c + 1 (the slot is free again)
-// The three counters live in LDS, each written by one wave, "data, then counter" with a wait for the wave's own LDS operations in
-// between (team_publish_wait: issue order alone was measured not to be enough), and the readers poll.  What is left on the compute wave is the arithmetic chain itself.  Any list is handled correctly (a hub
+// The three counters live in LDS, each written by one wave: LDS operations of a wave execute in order, so "data, then counter" needs no
+// fence, and the readers poll.  What is left on the compute wave is the arithmetic chain itself.  Any list is handled correctly (a hub
 // switch loads the hub row synchronously), but the form only pays for single-hub lists: cmi_set_ratings gives it to the longest ones.
 static const int OWNER_TEAM_RING = 32;
 
@@ -460,14 +460,6 @@ __device__ __forceinline__ void team_put(lds_u8 *p, const T (&v)[VPL]) {
     }
     *(volatile __attribute__((address_space(3))) V *)p = t;
 }
-
-// Before a ring counter is advanced: s_waitcnt lgkmcnt(0) -- every LDS operation this wave has issued (the slot's data it wrote, or the
-// slot it read) is COMPLETE, not merely issued ahead of the counter's write.  Rounds 2-4 relied on "the LDS operations of a wave execute
-// in order, so data-then-counter needs no wait".  That held in every run of an instance that had the device to itself; with another
-// owner epoch's workgroups on the same compute units (their ds_bpermute traffic in the same LDS) the fp64 k <= 64 team form was 1e-7 off
-// the oracle in 12 of 12 runs, and 0 of 12 with this wait (tools/exp/share_debug_stats.py, docs/history/r05.md 7).  Cost: 75.3 -> 76.7
-// ms per epoch on the Zipf(1.1) case whose hottest owners are teams.
-__device__ __forceinline__ void team_publish_wait() { __builtin_amdgcn_s_waitcnt(0xC07F); } // vmcnt(63) expcnt(7) lgkmcnt(0)
 
 // A zero the compiler cannot see through, derived from a value read from LDS: an index that adds it cannot be formed -- and the scalar
 // load that uses it cannot be issued -- before that LDS read has returned.  Scalar loads and LDS operations share one counter, which can
@@ -550,9 +542,8 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
                     }
                     if (S::SB) sbv[0] = owner_elem(s.bw, 0, (T)0);
                 }
-                if (lane == 0) { // the counter after the slot's data, and only once that data is in LDS (team_publish_wait)
+                if (lane == 0) { // the counter after the slot's data: LDS operations of a wave execute in order
                     if (S::SB && !(r.flags & OWN_SPK_FWD)) team_put<T, 1>(sl + OFF_SB, sbv);
-                    team_publish_wait();
                     ctr[0] = (uint32_t)c + 1u;
                 }
             }
@@ -607,8 +598,7 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
                 owner_pack(ob, 0, bv[0], tag);
                 owner_st_words(rs, (64 * VPL + (S::SC ? 64 * NCW : 0)) * NW * 8, (int)r.off, ob);
             }
-            team_publish_wait();
-            if (lane == 0) ctr[2] = (uint32_t)c + 1u; // after the reads of the slot have returned: the loader may refill it
+            if (lane == 0) ctr[2] = (uint32_t)c + 1u; // after the reads of the slot (in order): the loader may refill it
         }
         return;
     }
@@ -686,7 +676,6 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
                     one[0] = sb;
                     team_put<T, 1>(sl + OFF_SB, one);
                 }
-                team_publish_wait();
                 ctr[1] = (uint32_t)c + 1u;
             }
         }

@@ -31,7 +31,8 @@ for flags in (0, F64):
         with ThreadPoolExecutor(max_workers=3) as pool:
             list(pool.map(lambda i: [i.train_epoch(util.LR) for _ in range(3)], conc))
         b = conc[0].get_states()
+        teams = conc[0].schedule_info().get("teams")
         e = max(float(np.max(np.abs(a[n].astype(np.float64) - b[n].astype(np.float64)))) for n in a)
         bad += e > 0
         for c in conc: c.close()
-    print("k", K, "f64" if flags else "f32", "inexact runs", bad, "of 12")
+    print("k", K, "f64" if flags else "f32", "inexact runs", bad, "of 12", "(teams in the instance under test: %s -- 0 means the library was not built with EXP=1 and the run says nothing)" % teams)
