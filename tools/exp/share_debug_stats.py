@@ -10,6 +10,7 @@ from tests import util
 OWNER, F64 = capi.FLAG_SCHED_OWNER, capi.FLAG_STATE_F64
 os.environ["CMI_SHARE_DEBUG_TEAMS"] = "1"
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+TEAM = None if len(sys.argv) < 3 or sys.argv[2] == "default" else sys.argv[2]   # CMI_OWNER_TEAM of the instance under test
 def make(d, team, flags):
     if team is None: os.environ.pop("CMI_OWNER_TEAM", None)
     else: os.environ["CMI_OWNER_TEAM"] = team
@@ -27,7 +28,7 @@ for flags in (0, F64):
     a = ref.get_states()
     bad = 0
     for rep in range(12):
-        conc = [make(ds[0], None, flags), make(ds[1], "0", flags), make(ds[2], "0", flags)]
+        conc = [make(ds[0], TEAM, flags), make(ds[1], "0", flags), make(ds[2], "0", flags)]
         with ThreadPoolExecutor(max_workers=3) as pool:
             list(pool.map(lambda i: [i.train_epoch(util.LR) for _ in range(3)], conc))
         b = conc[0].get_states()
