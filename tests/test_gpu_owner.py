@@ -317,3 +317,38 @@ def test_device_share_runs_owner_epochs_side_by_side_and_changes_nothing():
             lo = orc.epoch(util.LR)
             assert abs(lo - lg) <= 1e-10 * abs(lo)
         assert_state_equal(orc, inst, exact=False, atol=1e-11)
+
+
+def test_owner_epochs_of_two_processes_on_one_gpu_take_turns_and_stay_exact():
+    """Two PROCESSES (two folds started as two programs) train owner-schedule instances on the same GPU.  Their persistent launches must
+    not be in flight together (each could hold part of the compute units and wait for the rest): the per-device file lock makes them take
+    turns, a process holding it while any of its owner epochs runs.  Both finish, both match their own oracle."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        from carskit_amd import capi, synth
+        from tests import util
+        from tests.test_gpu_parity import make_pair
+        seed = int(sys.argv[1])
+        d = synth.generate(3000, 300, 3, 4, 120000, seed=seed, item_zipf=1.2)
+        orc, inst = make_pair("CAMF_CI", d, 64, capi.FLAG_STATE_F64 | capi.FLAG_SCHED_OWNER)
+        assert inst.schedule_info()["kind"] == "owner-item"
+        worst = 0.0
+        for _ in range(6):
+            lo, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
+            worst = max(worst, abs(lo - lg) / abs(lo))
+        err = max(float(np.max(np.abs(orc.state[n].reshape(a.shape) - a))) for n, a in inst.get_states().items())
+        print("RESULT %%.3e %%.3e" %% (worst, err))
+    """ % root)
+    procs = [subprocess.Popen([sys.executable, "-c", prog, str(700 + i)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root)
+             for i in range(2)]
+    for p in procs:
+        out, errs = p.communicate(timeout=600)
+        assert p.returncode == 0, errs[-2000:]
+        line = [ln for ln in out.splitlines() if ln.startswith("RESULT")][-1].split()
+        assert float(line[1]) <= 1e-10 and float(line[2]) <= 1e-11, line
