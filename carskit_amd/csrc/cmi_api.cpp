@@ -842,7 +842,7 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
                 // (no automatic teams for fp64 at k <= 64: that instantiation of the team form's compute wave is the one measured inexact
                 // beside another owner epoch -- even with the ring carrying no data, while the one-wavefront body run on the same
                 // workgroups is exact: docs/history/r05.md 7.  CMI_OWNER_TEAM=all still forces it for the tests, which run it alone.)
-                int t = (h->f64 && h->k <= 64) ? 0 : leading_single_hub(osch, wgs / 2);
+                int t = (h->f64 && h->k <= 64 && !cmi_exp_env("CMI_SHARE_DEBUG_TEAMS")) ? 0 : leading_single_hub(osch, wgs / 2); // (the knob: the reproducer)
                 if (t > 0) {
                     const int fewer = waves - 3 * t;
                     if (fewer >= t + 1 && build_owner_schedule(n, u, j, h->n_users, h->n_items, hub, fewer, owner_depth(), osch)) {
