@@ -266,9 +266,16 @@ def bench_fm(args):
     rng = np.random.default_rng(1)
     g = capi.FMInstance(k, data.n_users, data.n_items, data.n_conds, data.n_dims)
     g.set_hparams(synth.java_float(0.01), synth.java_float(0.02))
+    t_set = time.perf_counter()
     g.set_ratings(data.u, data.j, data.ctx, data.r)
-    g.set_model(0.0, rng.random(p), 0.1 * rng.standard_normal((p, k)))
+    g.synchronize()
+    setup_s = time.perf_counter() - t_set          # cmi_fm_set_ratings: the cell streams of both fields + the context order + uploads
+    w_init, v_init = rng.random(p), 0.1 * rng.standard_normal((p, k))
+    t_set = time.perf_counter()
+    g.set_model(0.0, w_init, v_init)
     g.init()
+    g.synchronize()
+    model_s = time.perf_counter() - t_set          # cmi_fm_set_model + cmi_fm_init (the model's upload, err0 of every rating)
     for _ in range(args.warmup):
         g.sweep()
     g.synchronize()
@@ -305,7 +312,8 @@ def bench_fm(args):
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
            "config": {"workload": "c4 share: FM k=%d, %d users x %d items x %d conditions, %d ratings (one GPU of BASELINE configs[3])"
-                                  % (k, data.n_users, data.n_items, data.n_conds, data.n), "phases_per_sweep": phases},
+                                  % (k, data.n_users, data.n_items, data.n_conds, data.n), "phases_per_sweep": phases,
+                      "setup_s": setup_s, "set_model_and_init_s": model_s},
            "roofline": {"bound": "hbm", "achieved": bytes_launch / kern / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_launch / kern / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                         "traffic_GBps": traffic / kern / 1e9 if traffic else None, "traffic_over_model": traffic / bytes_launch if traffic else None,
