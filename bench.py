@@ -259,41 +259,50 @@ def secondary_workload(name, steps, warmup, device, flags, regs, lr, calibrate=T
 
 def bench_fm(args):
     """--workload c4: one GPU's share of BASELINE configs[3] (FM k=64, 5 M users x 500 K items x 64 conditions, 200 M ratings over
-    8 GPUs -> 625 K users / 25 M ratings per GPU).  A step = one ALS sweep (FM.java:148-218: 1 + 3 + 3k coordinate phases)."""
+    8 GPUs -> 625 K users / 25 M ratings per GPU).  A step = one ALS sweep (FM.java:148-218: 1 + 3 + 3k coordinate phases).  `value` is
+    the DEFAULT form (fixed-order sums: two runs are bit-identical, like the reference's sweep); `relaxed_sums` beside it is the opt-in
+    LDS-atomic form (CMI_FM_FLAG_RELAXED_SUMS)."""
     k, n_users, n_items, n = 64, 625_000, 500_000, 25_000_000
     data = synth.generate_fast(n_users, n_items, 4, 16, n)
     p = data.n_users + data.n_items + data.n_conds
     rng = np.random.default_rng(1)
-    g = capi.FMInstance(k, data.n_users, data.n_items, data.n_conds, data.n_dims)
-    g.set_hparams(synth.java_float(0.01), synth.java_float(0.02))
-    t_set = time.perf_counter()
-    g.set_ratings(data.u, data.j, data.ctx, data.r)
-    g.synchronize()
-    setup_s = time.perf_counter() - t_set          # cmi_fm_set_ratings: the cell streams of both fields + the context order + uploads
     w_init, v_init = rng.random(p), 0.1 * rng.standard_normal((p, k))
-    t_set = time.perf_counter()
-    g.set_model(0.0, w_init, v_init)
-    g.init()
-    g.synchronize()
-    model_s = time.perf_counter() - t_set          # cmi_fm_set_model + cmi_fm_init (the model's upload, err0 of every rating)
-    for _ in range(args.warmup):
-        g.sweep()
-    g.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        g.sweep()
-    g.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+
+    def timed(flags):
+        g = capi.FMInstance(k, data.n_users, data.n_items, data.n_conds, data.n_dims, flags=flags)
+        g.set_hparams(synth.java_float(0.01), synth.java_float(0.02))
+        t_set = time.perf_counter()
+        g.set_ratings(data.u, data.j, data.ctx, data.r)
+        g.synchronize()
+        setup_s = time.perf_counter() - t_set      # cmi_fm_set_ratings: the cell streams of both fields + the context order + uploads
+        t_set = time.perf_counter()
+        g.set_model(0.0, w_init, v_init)
+        g.init()
+        g.synchronize()
+        model_s = time.perf_counter() - t_set      # cmi_fm_set_model + cmi_fm_init (the model's upload, err0 of every rating)
+        for _ in range(args.warmup):
+            g.sweep()
+        g.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g.sweep()
+        g.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        # the dominant kernel: the launch of a factor's user / item phase (65 + 65 of the ~390 launches of a sweep, 85 % of its time), timed
+        # with HIP events on the instance's stream (in its non-updating form: it only writes scratch)
+        ku, ki = g.time_reduce(4 + 3 * (k // 2) + 0, 10) * 1e-3, g.time_reduce(4 + 3 * (k // 2) + 1, 10) * 1e-3
+        lay = g.layout()
+        g.close()
+        return dt, ku, ki, lay, setup_s, model_s
+
+    dt, ku, ki, lay, setup_s, model_s = timed(0)
+    rdt, rku, rki, rlay, _, _ = timed(capi.FM_FLAG_RELAXED_SUMS)
     phases = 4 + 3 * k
-    lay = g.layout()
-    # the dominant kernel: the launch of a factor's user / item phase (fm_cell_atomic_kernel: 65 + 65 of the ~390 launches of a sweep, 85 % of its
-    # time), timed with HIP events on the instance's stream (in its non-updating form: it only writes scratch).  Bytes = what THIS
-    # implementation has to move per launch (cmi_fm_layout: 12-byte records streamed once, the
-    # coordinates' table entries and sums, one L2 fill of every table slice per XCD) -- not the reference algorithm's errors[] + Q
-    # traffic, which it never generates.
-    ku, ki = g.time_reduce(4 + 3 * (k // 2) + 0, 10) * 1e-3, g.time_reduce(4 + 3 * (k // 2) + 1, 10) * 1e-3
+    # Bytes = what THIS implementation has to move per launch (cmi_fm_layout: 12-byte records streamed once, the coordinates' table entries
+    # and sums, one L2 fill of every table slice per XCD) -- not the reference algorithm's errors[] + Q traffic, which it never generates.
     bytes_launch = 0.5 * (lay["bytes_reduce_user"] + lay["bytes_reduce_item"])
-    kern = 0.5 * (ku + ki)
+    rbytes_launch = 0.5 * (rlay["bytes_reduce_user"] + rlay["bytes_reduce_item"])
+    kern, rkern = 0.5 * (ku + ki), 0.5 * (rku + rki)
     sweep_bytes = lay["bytes_per_factor"] * (k + 1)
     # HBM bytes per launch from the committed rocprofv3 PMC passes of tools/bench_fm.py (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r*_c4_pmc.json)
     traffic, tsrc = None, None
@@ -301,7 +310,7 @@ def bench_fm(args):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_pmc.json")), reverse=True):
         try:
             ks = json.load(open(path))["kernels"]
-            vals = [v["hbm_bytes_per_dispatch"] for kk, v in ks.items() if "fm_cell_atomic_kernel" in kk and "true>" in kk and "hbm_bytes_per_dispatch" in v]
+            vals = [v["hbm_bytes_per_dispatch"] for kk, v in ks.items() if "fm_cell_kernel" in kk and "true>" in kk and "hbm_bytes_per_dispatch" in v]
             if vals:
                 traffic, tsrc = float(np.mean(vals)), os.path.relpath(path, ROOT)
                 break
@@ -313,23 +322,28 @@ def bench_fm(args):
            "data": "synthetic",
            "config": {"workload": "c4 share: FM k=%d, %d users x %d items x %d conditions, %d ratings (one GPU of BASELINE configs[3])"
                                   % (k, data.n_users, data.n_items, data.n_conds, data.n), "phases_per_sweep": phases,
+                      "form": "default: fixed-order sums, bit-reproducible (fm_cell_kernel)",
                       "setup_s": setup_s, "set_model_and_init_s": model_s},
+           "relaxed_sums": {"form": "CMI_FM_FLAG_RELAXED_SUMS: LDS-atomic sums, last bits vary run to run (fm_cell_atomic_kernel)",
+                            "value": data.n / rdt, "unit": "rating-sweeps/s", "ms_per_step": rdt * 1e3,
+                            "kernel_us": {"user_field": rku * 1e6, "item_field": rki * 1e6},
+                            "frac": rbytes_launch / rkern / 1e9 / HBM_PEAK_GBS},
            "roofline": {"bound": "hbm", "achieved": bytes_launch / kern / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_launch / kern / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                         "traffic_GBps": traffic / kern / 1e9 if traffic else None, "traffic_over_model": traffic / bytes_launch if traffic else None,
-                        "kernel": "fm_cell_atomic_kernel<0|1> (one factor's user / item phase; fm_cell_kernel under CMI_FM_FLAG_DETERMINISTIC)",
+                        "kernel": "fm_cell_kernel<0|1> (one factor's user / item phase, the default fixed-order form; fm_cell_atomic_kernel under "
+                                  "CMI_FM_FLAG_RELAXED_SUMS: see relaxed_sums)",
                         "kernel_us": {"user_field": ku * 1e6, "item_field": ki * 1e6}, "bytes_per_launch": bytes_launch,
                         "bytes_per_rating_phase": bytes_launch / data.n,
                         "bytes_model": "this implementation's own traffic per launch (cmi_fm_layout): records 12 B x %d, "
                                        "coordinate entries + sums, table-slice fills; the reference ALGORITHM's errors[] + Q traffic would be %d B per "
                                        "rating-sweep (never generated here)" % (data.n, ref_bytes),
                         "whole_sweep_GBps": sweep_bytes / dt / 1e9, "whole_sweep_frac": sweep_bytes / dt / 1e9 / HBM_PEAK_GBS,
-                        "limiter": "the memory pattern: the same kernel without its LDS atomics runs the same 115-118 us (LDS 48 us busy per CU and "
-                                   "VALU are hidden).  2.3 M stream lines from HBM + 8.3 M gather lines from L2 per launch (3 lanes per line) against "
-                                   "~400 outstanding lines per CU: time ~ sum(lines x latency) / (256 x 400), which also gives the stream-only "
-                                   "(59 us) and lone-gather (119 us) microbenchmarks (tools/micro/gather16.hip; DESIGN.md 5)",
+                        "limiter": "the memory pattern: 2.3 M stream lines from HBM + 8.3 M gather lines from L2 per launch (3 lanes per line) "
+                                   "against ~400 outstanding lines per CU: time ~ sum(lines x latency) / (256 x 400), which also gives the "
+                                   "stream-only (59 us) and lone-gather (119 us) microbenchmarks (tools/micro/gather16.hip; DESIGN.md 5); the "
+                                   "fixed-order form adds the parking of a batch's products in LDS and its walk (+ ~11 %)",
                         "layout": lay, "avg_phase_us": dt * 1e6 / phases}}
-    g.close()
     return out
 
 

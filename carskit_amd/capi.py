@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMI_LIB_PATH") or os.path.join(_HERE, "lib", "libcarskit_mi355x.so")   # CMI_LIB_PATH: experiments with variant builds
 
-OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NUMERIC, E_UNSUPPORTED, E_HOST = 0, -1, -2, -3, -4, -5, -6
+OK, E_INVALID, E_NO_DEVICE, E_HIP, E_NUMERIC, E_UNSUPPORTED, E_HOST, E_BUSY = 0, -1, -2, -3, -4, -5, -6, -7
 
 MODEL_IDS = {"BiasedMF": 0, "CAMF_C": 1, "CAMF_CI": 2, "CAMF_CU": 3, "CAMF_CUCI": 4, "PMF": 5,
              "SVD++": 6, "CAMF_ICS": 7, "CAMF_LCS": 8, "CAMF_MCS": 9}
@@ -43,7 +43,8 @@ FLAG_SCHED_OWNER = 0x200
 FLAG_NO_OWNER = 0x400
 FLAG_SPOKE_ARENA = 0x800
 FLAG_NO_ARENA = 0x1000
-FM_FLAG_DETERMINISTIC = 0x1
+FM_FLAG_DETERMINISTIC = 0x1      # round-5 name of what is now the default (accepted, no effect)
+FM_FLAG_RELAXED_SUMS = 0x2       # opt into the LDS-atomic sums (faster, last bits vary run to run)
 OWN_HUB_FWD, OWN_HUB_LATE, OWN_HUB_STORE, OWN_SPK_FWD, OWN_SPK_STORE = 1, 2, 4, 8, 16
 
 # every symbol include/carskit_mi355x.h declares: (name, restype, argtypes)

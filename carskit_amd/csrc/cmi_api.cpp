@@ -29,26 +29,38 @@ using namespace cmi;
 
 static thread_local std::string g_create_err;
 
-// The owner epoch (one persistent launch whose workgroups wait for each other) needs its device to itself while it runs.  One
-// mutex per device orders the owner epochs of this process (folds on DIFFERENT devices no longer wait for each other: ADVICE r2);
-// an advisory flock() on a per-device file orders them across processes (two ranks sharing a GPU).  Best effort: if the lock file
-// cannot be opened the epoch still runs, and its waits stay bounded.
+// Owner epochs are persistent launches: every workgroup must be resident, so the workgroups of the epochs in flight on one device must
+// fit it together.  Inside a process a per-device GATE counts them (capacity = the device's compute units, one owner workgroup each):
+// an instance with cmi_set_device_share(F) launches ~1 / F of the device and F such epochs run side by side (`cv -p on`); an instance
+// without the hint takes the whole device and is alone.  Across PROCESSES an advisory flock() on a per-device file (held by a process
+// while any of its owner epochs is in flight) keeps two processes' persistent kernels apart.  (This is about RESIDENCY only.  Round 5
+// also kept the team form away from other owner epochs because it was measured inexact beside them; the cause was a store-data hazard
+// in the record stores, fixed in owner_kernels.hip owner_st_words, and those rules are gone: docs/history/r06.md 1.)
+//  * The file lock is polled WITHOUT the gate's mutex (a 60-s poll under the mutex blocked every other fold of the
+//    process); one thread acquires for the process, the others wait on the condition variable.
+//  * Fair hand-over: a process whose folds overlap their epochs never sees `holders` reach 0 by itself, and a lone fast process
+//    re-acquires microseconds after releasing.  A process that WAITS for the lock holds a shared flock on a second file (".waiters")
+//    while it polls; a holder that has kept the lock for 50 ms tests that file (one non-blocking exclusive attempt) and, if somebody
+//    waits, DRAINS: no new epoch is admitted, the last one out releases the lock, and the process stays away from it for 2 ms -- the
+//    waiting peer polls every 250 us.  Nobody waiting: no pause, nothing changes.
+//  * The lock file cannot be opened (read-only $TMPDIR ...): the epoch is refused (CMI_E_BUSY) instead of launched unprotected, unless
+//    CMI_OWNER_NO_LOCK=1 says this process is the device's only user.  The lock directory is per uid (0700), so processes of DIFFERENT
+//    users are not serialised against each other: a GPU shared across uids needs one process per GPU.
 #include <fcntl.h>
 #include <sys/file.h>
 #include <sys/stat.h>
 #include <unistd.h>
-// Owner epochs are persistent launches: every workgroup must be resident, so the workgroups of the epochs in flight on one device must
-// fit it together.  Inside a process a per-device GATE counts them (capacity = the device's compute units, one owner workgroup each):
-// an instance with cmi_set_device_share(F) launches ~1 / F of the device and F such epochs run side by side (`cv -p on`); an instance
-// without the hint takes the whole device and is alone, as before.  Across PROCESSES an advisory file lock (held by a process while any
-// of its owner epochs is in flight) keeps two processes' persistent kernels apart.
 struct OwnerDeviceGate {
     static constexpr int MAX_DEV = 64;
     std::mutex m;
     std::condition_variable cv;
-    int in_use = 0;  // workgroups of the owner epochs in flight
-    int holders = 0; // epochs in flight (the file lock is held while > 0)
-    int fd = -1;
+    int in_use = 0;          // workgroups of the owner epochs in flight
+    int holders = 0;         // epochs in flight (the file lock is held while > 0)
+    int fd = -1, fd_wait = -1; // the lock file and the waiters' file, opened once per process and device
+    bool locked = false;     // this process holds the flock
+    bool acquiring = false;  // one thread is polling the flock (without `m`)
+    bool draining = false;   // fairness: no admissions until the epochs in flight are done and the flock has been released
+    std::chrono::steady_clock::time_point since, not_before; // when the flock was taken; earliest re-acquisition after a fair release
     static OwnerDeviceGate &of(int dev) {
         static OwnerDeviceGate g[MAX_DEV];
         return g[dev >= 0 && dev < MAX_DEV ? dev : 0];
@@ -57,40 +69,64 @@ struct OwnerDeviceGate {
 struct OwnerDeviceLock {
     OwnerDeviceGate &g;
     int wgs;
-    bool ok = true; // false: another process kept the device's lock for the whole bounded wait -- the caller must not launch
+    bool ok = true;  // false: the epoch must not be launched (`why` says which of the two reasons)
+    const char *why = "";
     OwnerDeviceLock(int dev, int workgroups, int capacity) : g(OwnerDeviceGate::of(dev)), wgs(std::max(1, workgroups)) {
+        static const bool no_lock = getenv("CMI_OWNER_NO_LOCK") != nullptr;
         std::unique_lock<std::mutex> lk(g.m);
-        g.cv.wait(lk, [&] { return g.in_use == 0 || g.in_use + wgs <= capacity; });
-        if (g.holders == 0) {
-            char bus[64] = "";
-            if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", dev);
-            for (char *c = bus; *c; ++c)
-                if (*c == ':' || *c == '/' || *c == '.') *c = '_';
-            // a per-uid directory (0700) under $TMPDIR, so the lock file is neither world-writable nor at a path another user can plant
-            // a symlink on; O_NOFOLLOW refuses a planted link anyway, O_CLOEXEC keeps the descriptor out of forked children.
-            // (Processes of DIFFERENT users are therefore not serialised against each other: a shared GPU needs one uid or one process.)
-            const char *tmp = getenv("TMPDIR");
-            char dir[200], path[300];
-            snprintf(dir, sizeof dir, "%s/cmi_locks_%u", tmp && *tmp ? tmp : "/tmp", (unsigned)getuid());
-            (void)mkdir(dir, 0700);
-            snprintf(path, sizeof path, "%s/owner_epoch_%s.lock", dir, bus);
-            g.fd = open(path, O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600);
-            // bounded wait: a stopped or hung peer holding the lock must not block this process for ever; an owner epoch lasts well
-            // under a second.  After 60 s the epoch is NOT launched beside the other process's persistent kernel (that
-            // could stall both): the caller reports the device as busy.
-            if (g.fd >= 0) {
-                bool got = false;
-                for (int tries = 0; tries < 6000 && !got; ++tries) {
-                    if (flock(g.fd, LOCK_EX | LOCK_NB) == 0) got = true;
-                    else usleep(10000);
-                }
-                if (!got) {
-                    close(g.fd);
-                    g.fd = -1;
-                    ok = false;
-                    return; // (nothing taken: in_use / holders unchanged)
+        while (true) {
+            g.cv.wait(lk, [&] { return !g.acquiring && !g.draining && (g.in_use == 0 || g.in_use + wgs <= capacity); });
+            if (g.locked || no_lock) break;
+            // this thread takes the flock for the process; the mutex is NOT held while it polls
+            g.acquiring = true;
+            const auto not_before = g.not_before;
+            lk.unlock();
+            bool got = false, opened = true;
+            if (g.fd < 0) { // (only the acquiring thread touches fd)
+                char bus[64] = "";
+                if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", dev);
+                for (char *c = bus; *c; ++c)
+                    if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+                // a per-uid directory (0700) under $TMPDIR, so the lock file is neither world-writable nor at a path another user can
+                // plant a symlink on; O_NOFOLLOW refuses a planted link anyway, O_CLOEXEC keeps the descriptor out of forked children
+                const char *tmp = getenv("TMPDIR");
+                char dir[200], path[300];
+                snprintf(dir, sizeof dir, "%s/cmi_locks_%u", tmp && *tmp ? tmp : "/tmp", (unsigned)getuid());
+                (void)mkdir(dir, 0700);
+                snprintf(path, sizeof path, "%s/owner_epoch_%s.lock", dir, bus);
+                g.fd = open(path, O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600);
+                opened = g.fd >= 0;
+                if (opened) {
+                    snprintf(path, sizeof path, "%s/owner_epoch_%s.waiters", dir, bus);
+                    g.fd_wait = open(path, O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600); // (best effort: without it nobody sees us wait)
                 }
             }
+            if (opened) {
+                std::this_thread::sleep_until(not_before); // (a fair release just happened: let the waiting peer in first)
+                // bounded wait: a stopped or hung peer holding the lock must not block this process for ever; an owner epoch lasts well
+                // under a second.  After 60 s the epoch is NOT launched beside the other process's persistent kernel (that could stall both)
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(60);
+                bool announced = false;
+                while (!(got = flock(g.fd, LOCK_EX | LOCK_NB) == 0) && std::chrono::steady_clock::now() < deadline) {
+                    if (!announced && g.fd_wait >= 0) announced = flock(g.fd_wait, LOCK_SH | LOCK_NB) == 0; // "somebody waits"
+                    usleep(250);
+                }
+                if (announced) flock(g.fd_wait, LOCK_UN);
+            }
+            lk.lock();
+            g.acquiring = false;
+            if (!got) {
+                ok = false;
+                why = opened ? "another process has held the owner-epoch lock of the device for 60 s"
+                             : "the owner-epoch lock file under $TMPDIR/cmi_locks_<uid>/ cannot be opened (set CMI_OWNER_NO_LOCK=1 if this process is "
+                               "the only user of the GPU)";
+                g.cv.notify_all();
+                return; // (nothing taken: in_use / holders unchanged)
+            }
+            g.locked = true;
+            g.since = std::chrono::steady_clock::now();
+            g.cv.notify_all();
+            // (loop: the capacity predicate is re-evaluated under the mutex)
         }
         g.in_use += wgs;
         ++g.holders;
@@ -99,10 +135,18 @@ struct OwnerDeviceLock {
         if (!ok) return;
         std::lock_guard<std::mutex> lk(g.m);
         g.in_use -= wgs;
-        if (--g.holders == 0 && g.fd >= 0) {
+        --g.holders;
+        if (g.locked && !g.draining && g.fd_wait >= 0 && std::chrono::steady_clock::now() - g.since > std::chrono::milliseconds(50)) {
+            if (flock(g.fd_wait, LOCK_EX | LOCK_NB) == 0) { // nobody holds the shared lock: nobody waits
+                flock(g.fd_wait, LOCK_UN);
+                g.since = std::chrono::steady_clock::now();
+            } else g.draining = true;
+        }
+        if (g.holders == 0 && g.locked) {
             flock(g.fd, LOCK_UN);
-            close(g.fd);
-            g.fd = -1;
+            g.locked = false;
+            if (g.draining) g.not_before = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+            g.draining = false;
         }
         g.cv.notify_all();
     }
@@ -283,7 +327,18 @@ extern "C" int cmi_create(int model, int k, int n_users, int n_items, int n_cond
         e = (x);                                                                                        \
     }
     TRY(hipSetDevice(device));
-    TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    // experiment builds: CMI_STREAM_CUS="m:r0,r1,..." -- the instance's stream may only use the compute units whose index mod m is one of
+    // the residues (the driver deals consecutive mask bits round the XCDs, so m = 8 selects XCDs and m = 16 halves of every XCD)
+    if (const char *cus = cmi_exp_env("CMI_STREAM_CUS")) {
+        int m = atoi(cus), n_cu = 0;
+        uint32_t want = 0, mask[16] = {};
+        for (const char *p = strchr(cus, ':'); p && *p; p = strchr(p + 1, ',')) want |= 1u << (atoi(p + 1) & 31);
+        TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
+        for (int c = 0; c < n_cu && c < 512 && m > 0; ++c)
+            if (want >> (c % m) & 1) mask[c / 32] |= 1u << (c % 32);
+        TRY(hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)((n_cu + 31) / 32), mask));
+    } else
+        TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     TRY(hipEventCreate(&h->ev0));
     TRY(hipEventCreate(&h->ev1));
     for (int w = 0; w < CMI_STATE_COUNT; ++w) {
@@ -342,7 +397,10 @@ extern "C" int cmi_set_sim_params(cmi_handle h, int num_f, int n_ctx_dims, const
     h->d_empty = nullptr;
     if (n_empty > 0) {
         CMI_HIP(h, hipMalloc((void **)&h->d_empty, (size_t)n_empty * 4));
-        CMI_HIP(h, hipMemcpy(h->d_empty, empty_conds, (size_t)n_empty * 4, hipMemcpyHostToDevice));
+        // (never the legacy stream: a synchronous hipMemcpy / hipMemset fails with hipErrorStreamCaptureImplicit while ANOTHER fold's
+        //  thread is capturing its level graph -- found by tests/test_gpu_soak.py)
+        CMI_HIP(h, hipMemcpyAsync(h->d_empty, empty_conds, (size_t)n_empty * 4, hipMemcpyHostToDevice, h->stream));
+        CMI_HIP(h, hipStreamSynchronize(h->stream));
     }
     if (h->model == CMI_MODEL_CAMF_LCS && num_f != h->num_f) {
         if (h->state[CMI_STATE_CF_MATRIX]) hipFree(h->state[CMI_STATE_CF_MATRIX]);
@@ -352,7 +410,8 @@ extern "C" int cmi_set_sim_params(cmi_handle h, int num_f, int n_ctx_dims, const
         const size_t bytes = (size_t)h->state_count[CMI_STATE_CF_MATRIX] * esize(h);
         if (bytes) {
             CMI_HIP(h, hipMalloc(&h->state[CMI_STATE_CF_MATRIX], bytes));
-            CMI_HIP(h, hipMemset(h->state[CMI_STATE_CF_MATRIX], 0, bytes));
+            CMI_HIP(h, hipMemsetAsync(h->state[CMI_STATE_CF_MATRIX], 0, bytes, h->stream));
+            CMI_HIP(h, hipStreamSynchronize(h->stream));
         }
     }
     return CMI_OK;
@@ -561,13 +620,7 @@ static int chain_max_len() {
     if (const char *env = getenv("CMI_CHAIN_MAX")) v = atoi(env);
     return v < 1 ? 1 : (v > 16 ? 16 : v);
 }
-static void free_keep(ChainDeviceKeep &keep) {
-    for (int32_t **q : {&keep.d_u, &keep.d_j, &keep.d_perm})
-        if (*q) {
-            (void)hipFree(*q);
-            *q = nullptr;
-        }
-}
+static void free_keep(ChainDeviceKeep &keep) { keep.release(); } // (early: 12 bytes per tuple; the destructor covers every other exit)
 static bool try_chain(cmi_instance *h, int64_t n, const int32_t *u, const int32_t *j, ChainSchedule &csch, ChainDeviceKeep &keep) {
     // the side that carries the context-bias rows is preferred as the hub side (CAMF_CI: items, CAMF_CU: users): measured on the C5
     // share (CAMF_CU k=256, 128 conditions) 50.1 ms per epoch along users (36.4 M units) against 64.3 ms along items (31.9 M units)
@@ -824,13 +877,12 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
                 return t;
             };
             const int wgs = (waves + 3) / 4; // resident workgroups
-            if (h->strict || (h->device_share > 1 && !cmi_exp_env("CMI_SHARE_DEBUG_TEAMS")) || (team_env && !strcmp(team_env, "0"))) {
-                // one wavefront per owner throughout.  (A shared device: the hottest rows' owners get no workgroup of their own -- and
-                // the fp64 k <= 64 instantiation of the team form is NOT exact, 1e-7 off the oracle in 12 of 12 runs, when ANOTHER
-                // owner epoch is in flight beside it; exact alone and beside level / chain kernels, fp32 and fp64 k = 128 exact beside
-                // the same neighbours, the one-wavefront form exact in every combination: tools/exp/share_debug_stats.py,
-                // docs/history/r05.md 7.  Unexplained.  An instance without the hint takes the whole gate, so its teams never meet
-                // another owner epoch of this process; CMI_SHARE_DEBUG_TEAMS, experiment builds only, keeps the teams for the reproducer.)
+            if (h->strict || (team_env && !strcmp(team_env, "0"))) {
+                // one wavefront per owner throughout (the strict form has no team body; CMI_OWNER_TEAM=0: tests and A/B runs).
+                // (Round 5 also refused teams to sharing instances and to fp64 at k <= 64 because that form was measured inexact beside
+                // another owner epoch.  The cause was a store-data hazard in the record stores of BOTH bodies -- the compiler had merely
+                // happened to reuse the data registers at once only in that instantiation -- fixed in owner_kernels.hip owner_st_words;
+                // tests/test_gpu_soak.py holds every instantiation beside other owner epochs bit for bit.  docs/history/r06.md 1.)
             } else if (team_env && !strcmp(team_env, "all")) { // testing: every owner a team, whatever its list
                 if (waves > wgs) {
                     waves = wgs;
@@ -839,10 +891,7 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
                 }
                 h->n_team = waves;
             } else {
-                // (no automatic teams for fp64 at k <= 64: that instantiation of the team form's compute wave is the one measured inexact
-                // beside another owner epoch -- even with the ring carrying no data, while the one-wavefront body run on the same
-                // workgroups is exact: docs/history/r05.md 7.  CMI_OWNER_TEAM=all still forces it for the tests, which run it alone.)
-                int t = (h->f64 && h->k <= 64 && !cmi_exp_env("CMI_SHARE_DEBUG_TEAMS")) ? 0 : leading_single_hub(osch, wgs / 2); // (the knob: the reproducer)
+                int t = leading_single_hub(osch, wgs / 2);
                 if (t > 0) {
                     const int fewer = waves - 3 * t;
                     if (fewer >= t + 1 && build_owner_schedule(n, u, j, h->n_users, h->n_items, hub, fewer, owner_depth(), osch)) {
@@ -1018,6 +1067,10 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
         const size_t table_bytes = (size_t)spokes * (size_t)h->k * esize(h), arena_bytes = (size_t)n * (size_t)h->k * esize(h);
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
+        // the arena allocated at the top of the call is already OUT of free_b: count it back, or the 0.6 / 0.3 limits below would apply
+        // to (free - arena) and an arena between 0.375 and 0.6 of the free memory -- north_star's 102 GB on 288 GB is within 1 % of that
+        // edge -- would be allocated, judged too large, freed again and the run would silently take the table form
+        if (spec.ptr && spec.bytes == arena_bytes) free_b += spec.bytes;
         const bool forced = (h->flags & CMI_FLAG_SPOKE_ARENA) || cmi_exp_env("CMI_ARENA");
         const bool large = table_bytes >= ((size_t)2 << 30) && (double)arena_bytes <= 0.6 * (double)free_b;
         // In between (spoke tables of 256 MiB .. 2 GiB: BASELINE C5's share has a 1-GiB Q) the better form depends on the BOX: the same
@@ -1040,11 +1093,14 @@ static int set_ratings_impl(cmi_handle h, int64_t n, const int32_t *u, const int
                 (void)hipGetLastError();
                 HostBuf<int32_t> nxt((size_t)n), first((size_t)spokes), back(dev_stream ? (size_t)n : 0);
                 if (dev_stream) { // the stream exists on the device only: the spoke ids come back for the host walk
-                    e = hipMemcpy(back.data(), h->chain_hub_item ? h->d_su : h->d_sj, (size_t)n * 4, hipMemcpyDeviceToHost);
+                    e = hipMemcpyAsync(back.data(), h->chain_hub_item ? h->d_su : h->d_sj, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
                 }
-                const HostBuf<int32_t> &sp = dev_stream ? back : (h->chain_hub_item ? su : sj);
-                arena_positions(n, sp.data(), spokes, nxt.data(), first.data());
-                e = hipMemcpyAsync(h->d_next, nxt.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+                if (e == hipSuccess) { // (a failed copy-back must not be walked over, nor its error overwritten: ADVICE r5)
+                    const HostBuf<int32_t> &sp = dev_stream ? back : (h->chain_hub_item ? su : sj);
+                    arena_positions(n, sp.data(), spokes, nxt.data(), first.data());
+                    e = hipMemcpyAsync(h->d_next, nxt.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+                }
                 if (e == hipSuccess) e = hipMemcpyAsync(h->d_first, first.data(), (size_t)spokes * 4, hipMemcpyHostToDevice, h->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // nxt / first are locals
             }
@@ -1254,8 +1310,41 @@ static SgdArgs<T> make_args(cmi_instance *h) {
         a.arena = (T *)h->d_arena;
         a.next_pos = h->d_next;
     }
+#ifdef CMI_OWNER_TRACE
+    a.trace = h->d_trace;
+#endif
     return a;
 }
+
+#ifdef CMI_OWNER_TRACE
+// Debug builds only (make TRACE=1; tools/exp/owner_trace.py): owner epochs from now on record every tuple's inputs and outputs (12 rows of
+// 64 doubles per list position, owner_kernels.hip CMI_TR_ROWS); the dump writes the most recent epoch's trace to a file and stops tracing.
+extern "C" int cmi_debug_owner_trace(cmi_handle h) {
+    if (!h || !h->owner) return CMI_E_INVALID;
+    if (hipSetDevice(h->device) != hipSuccess) return CMI_E_HIP;
+    if (!h->d_trace) {
+        h->trace_doubles = ((size_t)h->n + (size_t)h->n_owners * 2 * (size_t)owner_depth()) * 12 * 64;
+        CMI_HIP(h, hipMalloc((void **)&h->d_trace, h->trace_doubles * 8));
+    }
+    CMI_HIP(h, hipMemsetAsync(h->d_trace, 0, h->trace_doubles * 8, h->stream));
+    CMI_HIP(h, hipStreamSynchronize(h->stream));
+    return CMI_OK;
+}
+extern "C" int cmi_debug_owner_trace_dump(cmi_handle h, const char *path) {
+    if (!h || !h->d_trace || !path) return CMI_E_INVALID;
+    if (hipSetDevice(h->device) != hipSuccess) return CMI_E_HIP;
+    std::vector<double> host(h->trace_doubles);
+    CMI_HIP(h, hipMemcpyAsync(host.data(), h->d_trace, h->trace_doubles * 8, hipMemcpyDeviceToHost, h->stream));
+    CMI_HIP(h, hipStreamSynchronize(h->stream));
+    FILE *f = fopen(path, "wb");
+    if (!f) CMI_FAIL(h, CMI_E_INVALID, "cannot open %s", path);
+    const size_t wrote = fwrite(host.data(), 8, host.size(), f);
+    fclose(f);
+    (void)hipFree(h->d_trace);
+    h->d_trace = nullptr;
+    return wrote == host.size() ? CMI_OK : CMI_E_INVALID;
+}
+#endif
 
 // ---- spoke arena <-> model table ------------------------------------------------------------------------------------------
 int cmi_sync_table_from_arena(cmi_instance *h) {
@@ -1324,18 +1413,19 @@ static hipError_t enqueue_levels(cmi_instance *h) {
         return launch_serial<float>(make_args<float>(h), cfg, h->n, h->d_loss, h->stream);
     }
     if (h->owner) {
-        // The owner epoch is a persistent launch whose workgroups wait for each other: every one of them has to be resident, i.e. it
-        // needs the device to itself.  Two of them in flight at once (two folds of `cv -p on` on one GPU, each on its own stream) could
-        // each hold part of the compute units and wait forever for the rest, so owner epochs of one process run one at a time: the lock
-        // is held from the launch until the stream has drained (cmi_train_epoch_async is synchronous for this schedule).  Across
-        // PROCESSES an advisory lock on a per-device file does the same (OwnerDeviceLock); should a foreign persistent kernel hold
-        // compute units anyway, the waits are bounded, the first one to expire ends every other wait early (owner_spin_expired) and the
-        // epoch is reported as failed right here -- also on the cmi_train_epoch_async path, which never calls cmi_last_loss.
+        // The owner epoch is a persistent launch whose workgroups wait for each other: every one of them has to be resident.  Two of
+        // them in flight at once (two folds of `cv -p on` on one GPU, each on its own stream) could each hold part of the compute units
+        // and wait forever for the rest, so the gate (OwnerDeviceLock) admits owner epochs of this process only while their workgroups
+        // fit the device together, and keeps another PROCESS's epochs away through an advisory file lock; it is held from the launch
+        // until the stream has drained (cmi_train_epoch_async is synchronous for this schedule).  Should a foreign persistent kernel
+        // hold compute units anyway, the waits are bounded, the first one to expire ends every other wait early (owner_spin_expired)
+        // and the epoch is reported as failed right here -- also on the cmi_train_epoch_async path, which never calls cmi_last_loss.
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 1;
         OwnerDeviceLock guard(h->device, h->n_team + (h->n_owners - h->n_team + 3) / 4, cus);
         if (!guard.ok) {
             h->owner_busy = true;
+            h->owner_busy_why = guard.why;
             return hipErrorNotReady;
         }
         const int32_t n_spokes = h->owner_hub_item ? h->n_users : h->n_items;
@@ -1347,11 +1437,11 @@ static hipError_t enqueue_levels(cmi_instance *h) {
                    : launch_owner_epoch<float>(make_args<float>(h), h->model, h->owner_hub_item, false, h->d_own_recs, h->d_own_off, h->n_owners, h->n_team, h->d_tagged,
                                                h->own_stride, n_spokes, h->d_flow_err, tag0, h->stream);
         if (e == hipSuccess) e = launch_reduce_loss(h->d_loss_part, h->n_slots, h->d_scratch, h->d_loss, h->stream);
+        int32_t stalled = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&stalled, h->d_flow_err, 4, hipMemcpyDeviceToHost, h->stream); // (the instance's stream, not the legacy one)
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) {
-            int32_t stalled = 0;
-            e = hipMemcpy(&stalled, h->d_flow_err, 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess && stalled) {
+            if (stalled) {
                 h->owner_stalled = true;
                 e = hipErrorLaunchFailure;
             }
@@ -1440,8 +1530,8 @@ static int enqueue_epoch(cmi_instance *h, double lrate, bool probing = false) {
         const hipError_t e = enqueue_levels(h);
         if (h->owner_busy) {
             h->owner_busy = false;
-            CMI_FAIL(h, CMI_E_HIP, "owner epoch not started: another process has held the owner-epoch lock of device %d for 60 s (persistent "
-                     "kernels of two processes must not share a device); the model is untouched -- retry, or use CMI_FLAG_NO_OWNER", h->device);
+            CMI_FAIL(h, CMI_E_BUSY, "owner epoch not started on device %d: %s (persistent kernels of two processes must not share a device); "
+                     "the model is untouched -- retry, or use CMI_FLAG_NO_OWNER", h->device, h->owner_busy_why);
         }
         if (h->owner_stalled)
             CMI_FAIL(h, CMI_E_HIP, "owner epoch stalled: a tuple waited past its bound for a predecessor's record (is another persistent kernel "

@@ -31,7 +31,8 @@ struct cmi_instance {
     // owner (dataflow) schedule: one persistent launch, d_own_recs = the owners' lists, d_tagged = the spoke side's tagged records
     bool want_owner = false, owner = false, owner_hub_item = true;
     uint32_t owner_epoch_seq = 0; // owner epochs launched so far (the epoch's tag base derives from it)
-    bool owner_busy = false; // the last owner epoch was not launched: another process held the device's owner-epoch lock
+    bool owner_busy = false; // the last owner epoch was not launched: the device's owner-epoch lock could not be taken (CMI_E_BUSY)
+    const char *owner_busy_why = "";
     int device_share = 1; // cmi_set_device_share: instances training concurrently on this device (sizes the persistent kernels' grids)
     int n_owners = 0, n_team = 0; // owners [0, n_team) run as teams of three wavefronts
     bool owner_stalled = false;   // an owner epoch hit its wait bound: the model state is invalid (sticky until cmi_set_ratings)
@@ -39,6 +40,10 @@ struct cmi_instance {
     int64_t *d_own_off = nullptr;
     void *d_tagged = nullptr;
     int64_t own_stride = 0;
+#ifdef CMI_OWNER_TRACE
+    double *d_trace = nullptr; // debug builds (make TRACE=1): cmi_debug_owner_trace / cmi_debug_owner_trace_dump
+    size_t trace_doubles = 0;
+#endif
     std::string err;
     std::string sched_note; // why a slower schedule than the data calls for is running (cmi_schedule_note); empty = nothing to say
     hipStream_t stream = nullptr;

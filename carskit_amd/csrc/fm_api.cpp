@@ -55,7 +55,7 @@ struct cmi_fm_instance {
     int32_t *d_u = nullptr, *d_j = nullptr, *d_ctx = nullptr, *d_src[3] = {nullptr, nullptr, nullptr};
     FmOrderDev ord[3];   // [2] only: the context field (records sorted by feature, a wave per feature)
     FmCellsDev cell[2];  // users, items
-    int atomic = 1;  // 0: CMI_FM_FLAG_DETERMINISTIC (fm_cell_kernel: parking + a fixed walk); 1: fm_cell_atomic_kernel (LDS atomics)
+    int atomic = 0;  // 0 (default): fm_cell_kernel, parking + a fixed walk, bit-reproducible; 1: CMI_FM_FLAG_RELAXED_SUMS, fm_cell_atomic_kernel (LDS atomics)
     int h_split = 0; // CMI_FM_HSPLIT: id-range parts per group (0 = chosen from the geometry)
     int batch_cap = FMC_RCAP, slot_cap = FMC_SLOTS; // experiment / test knobs (CMI_FM_BATCH, CMI_FM_SLOTS): smaller batches and blocks on small data
     RankWorkspace rank_ws; // cmi_fm_eval_rankings' buffers, reused by the next evaluation
@@ -146,7 +146,9 @@ extern "C" int cmi_fm_create(int k, int n_users, int n_items, int n_conds, int n
     if (const char *v = getenv("CMI_FM_SLICE")) h->slice_entries = atoll(v); // experiment knob: 0 = one slice
     if (const char *v = getenv("CMI_FM_BATCH")) h->batch_cap = std::max(1, std::min(atoi(v), FMC_RCAP));
     if (const char *v = getenv("CMI_FM_SLOTS")) h->slot_cap = std::max((FMC_RCAP + FMC_RUN - 1) / FMC_RUN, std::min(atoi(v), FMC_SLOTS));
-    h->atomic = (flags & CMI_FM_FLAG_DETERMINISTIC) || getenv("CMI_FM_DETERMINISTIC") ? 0 : 1;
+    // the reference's sweep is deterministic (FM.java:148-218): so is the default here; the relaxed (LDS-atomic) sums are an opt-in, and
+    // an explicit CMI_FM_FLAG_DETERMINISTIC / CMI_FM_DETERMINISTIC=1 wins over the environment's opt-in
+    h->atomic = ((flags & CMI_FM_FLAG_RELAXED_SUMS) || getenv("CMI_FM_RELAXED_SUMS")) && !(flags & CMI_FM_FLAG_DETERMINISTIC) && !getenv("CMI_FM_DETERMINISTIC") ? 1 : 0;
     if (const char *v = cmi_exp_env("CMI_FM_HSPLIT")) h->h_split = std::max(0, std::min(atoi(v), 8));
     h->k = k;
     h->n_users = n_users;
@@ -634,9 +636,26 @@ static hipError_t fm_upload_order(const FmOrderHost &o, FmOrderDev &d, hipStream
     return e;
 }
 
+static int fm_set_ratings_impl(cmi_fm_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r);
+
+// The exception barrier of the boundary: the cell streams allocate O(tuples) host memory, part of it on the host pool's
+// threads (host_pool.hpp hands a range body's exception to the caller) and on the two side threads below; nothing C++ may cross into a
+// C / JNI / ctypes host.
 extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx,
                                   const double *r) {
     if (!h) return CMI_E_INVALID;
+    try {
+        return fm_set_ratings_impl(h, n, u, j, ctx, r);
+    } catch (const std::exception &e) {
+        fm_free_ratings(h);
+        FM_FAIL(h, CMI_E_HOST, "fm_set_ratings: host-side failure: %s", e.what());
+    } catch (...) {
+        fm_free_ratings(h);
+        FM_FAIL(h, CMI_E_HOST, "fm_set_ratings: host-side failure (unknown exception)");
+    }
+}
+
+static int fm_set_ratings_impl(cmi_fm_handle h, int64_t n, const int32_t *u, const int32_t *j, const int32_t *ctx, const double *r) {
     if (n < 0 || (n > 0 && (!u || !j || !ctx || !r))) FM_FAIL(h, CMI_E_INVALID, "fm_set_ratings: null arrays");
     if (n >= ((int64_t)1 << 31)) FM_FAIL(h, CMI_E_UNSUPPORTED, "fm_set_ratings: more than 2^31-1 tuples");
     for (int64_t t = 0; t < n; ++t)
@@ -668,23 +687,42 @@ extern "C" int cmi_fm_set_ratings(cmi_fm_handle h, int64_t n, const int32_t *u, 
             for (int64_t t = 0; t < n; ++t) ckey[(size_t)t] = ctx[t] < h->n_conds ? ctx[t] : -1;
             fm_build_order(n, ckey.data(), u, j, h->n_conds, oc);
         };
+        // a side thread's exception (std::bad_alloc ...) is caught IN the thread and rethrown here after both have been joined: an
+        // exception escaping a std::thread body, or unwinding past a joinable std::thread, would be std::terminate
+        std::exception_ptr xi, xc, xu;
+        auto guarded = [](auto &body, std::exception_ptr &x) {
+            return [&body, &x]() {
+                try {
+                    body();
+                } catch (...) {
+                    x = std::current_exception();
+                }
+            };
+        };
         std::thread ti, tc;
         bool hi = true, hc = true;
         try {
-            ti = std::thread(item_cells);
+            ti = std::thread(guarded(item_cells, xi));
         } catch (const std::system_error &) { // the process may not create more threads: one after the other
             hi = false;
         }
         try {
-            tc = std::thread(ctx_order);
+            tc = std::thread(guarded(ctx_order, xc));
         } catch (const std::system_error &) {
             hc = false;
         }
-        fm_build_cells(n, u, j, ctx, h->n_users, h->n_items, h->n_users, h->n_conds, h->slice_entries, h->batch_cap, h->slot_cap, h->h_split, cu, h->atomic != 0);
+        try {
+            fm_build_cells(n, u, j, ctx, h->n_users, h->n_items, h->n_users, h->n_conds, h->slice_entries, h->batch_cap, h->slot_cap, h->h_split, cu, h->atomic != 0);
+        } catch (...) {
+            xu = std::current_exception();
+        }
         if (hi) ti.join();
-        else item_cells();
         if (hc) tc.join();
-        else ctx_order();
+        if (xu) std::rethrow_exception(xu);
+        if (xi) std::rethrow_exception(xi);
+        if (xc) std::rethrow_exception(xc);
+        if (!hi) item_cells();
+        if (!hc) ctx_order();
     }
     lap("cells + context order (three threads)");
     // the ratings as plain arrays in the caller's order (cmi_fm_init computes err0 there; every stream copies its err0 through `src`)

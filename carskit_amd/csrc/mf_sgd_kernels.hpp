@@ -37,6 +37,9 @@ struct SgdArgs {
     // owner epoch: the tag a spoke record carries when the epoch begins (a row's tag = tag0 + its updates so far this epoch).  A new
     // value every epoch, so that a copy of a record left anywhere from an EARLIER epoch can never pass for the one a tuple waits for.
     uint32_t owner_tag0 = 0;
+#ifdef CMI_OWNER_TRACE
+    double *trace = nullptr; // debug builds (make TRACE=1): per-tuple inputs and outputs of the owner epoch, owner_kernels.hip
+#endif
 };
 
 // spoke arena <-> model table (n_rows rows of k elements; first_pos[row] = stream position of the row's first tuple, -1: none)

@@ -162,6 +162,20 @@ __device__ __forceinline__ bool owner_spin_expired(unsigned &spins, int *error, 
     }
     return false;
 }
+#ifdef CMI_OWNER_TRACE
+// Debug builds only (make TRACE=1): every owner writes what it read and what it produced for every tuple into SgdArgs::trace -- per list
+// position CMI_TR_ROWS rows of 64 doubles (lane l = element l): 0 hub row in, 1 spoke row in, 2 hub context row in, 3 {spoke bias in, off,
+// hub, want, flags, 1, tag0}, 4-7 the same after the update (7: {spoke bias out}), 8 / 9 the team loader's view of the spoke row / bias,
+// 10 / 11 the team storer's.  tools/exp/owner_trace.py compares the trace of a lone run with that of a run beside other owner epochs.
+#define CMI_TR_ROWS 12
+template <typename T>
+__device__ __forceinline__ void tr_put(double *tr, int64_t pos, int row, int lane, T v) {
+    if (tr) tr[((size_t)pos * CMI_TR_ROWS + row) * 64 + lane] = (double)v;
+}
+#define CMI_TR(...) __VA_ARGS__
+#else
+#define CMI_TR(...)
+#endif
 static const int OWNER_DEPTH_MAX = 16; // every list is followed by OWNER_DEPTH_MAX + 1 inert entries (cmi_api.cpp), whatever D a kernel uses
 
 // Spoke records go through buffer instructions: one resource over the record table, the record's byte offset in the scalar offset
@@ -197,7 +211,28 @@ __device__ __forceinline__ void owner_st_words(__amdgpu_buffer_rsrc_t rs, int vo
         for (int i = 0; i < W / 4; ++i) {
             u32x4 t;
             t.x = w[4 * i], t.y = w[4 * i + 1], t.z = w[4 * i + 2], t.w = w[4 * i + 3];
+#if defined(CMI_VAR_STORE_B64)
+            u32x2 lo, hi; // experiment: the same 16 bytes as two 8-byte stores (no > 64-bit store data)
+            lo.x = t.x, lo.y = t.y, hi.x = t.z, hi.y = t.w;
+            __builtin_amdgcn_raw_buffer_store_b64(lo, rs, voff + 16 * i, soff, CMI_OWNER_CPOL);
+            __builtin_amdgcn_raw_buffer_store_b64(hi, rs, voff + 16 * i + 8, soff, CMI_OWNER_CPOL);
+#else
             __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff + 16 * i, soff, CMI_OWNER_CPOL);
+#if !defined(CMI_VAR_NO_STORE_NOP)
+            // STORE-DATA HAZARD (gfx9 family, "VMEM store of more than 64 bits followed by a VALU write of the VGPRs that hold its data"):
+            // the store reads its data registers AFTER it has issued, so a v_mov into one of them in the next one or two issue slots can
+            // reach the register first and the NEW value is stored.  The compiler's hazard recognizer inserts the wait states itself --
+            // except for buffer stores whose soffset is an SGPR (it takes the ISA manual's word that those are exempt), which is exactly
+            // this store (the record's byte offset travels in soffset).  Measured on gfx950 they are not exempt: with the data registers
+            // reused at once (the bias granules are packed into the row's registers: `buffer_store_dwordx4 v[2:5] ... ; v_mov_b32 v2, v74`)
+            // a record now and then went out with the right tags and the NEXT store's low word in 16 lanes -- only when another
+            // workgroup's memory instructions delayed the read, i.e. beside another owner epoch (docs/history/r06.md 1;
+            // tools/micro/store_data_hazard.hip reproduces it in isolation).  The asm below reads the store's data TUPLE (the same four registers: as four
+            // scalar operands the compiler found the values elsewhere and still rewrote the tuple before the asm), so they stay live --
+            // unwritten -- up to it, and s_nop 1 supplies the two wait states the manual asks for on gfx940+.
+            asm volatile("s_nop 1" : : "v"(t) : "memory");
+#endif
+#endif
         }
     }
 }
@@ -480,7 +515,7 @@ __host__ __device__ constexpr int team_slot_bytes() { // row | context biases | 
 
 template <typename T, int MODEL, int VPL, int NCW, int D, bool HUB_ITEM>
 __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<NCW> *__restrict__ recs, int len, int w, __amdgpu_buffer_rsrc_t rs,
-                                           const OwnerHp<T> &hp, int *error) {
+                                           const OwnerHp<T> &hp, int *error, int64_t pos0) {
     typedef OwnerRecT<NCW> OwnerRec;
     using S = Sides<MODEL, HUB_ITEM>;
     constexpr int NW = Tagged<T>::NW, R = OWNER_TEAM_RING;
@@ -533,6 +568,10 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
 #pragma unroll
                     for (int v = 0; v < VPL; ++v) xv[v] = owner_elem(s.xw, v, (T)0);
                     team_put<T, VPL>(sl + lane * (VPL * (int)sizeof(T)), xv);
+                    CMI_TR(if constexpr (VPL == 1 && NCW == 1) {
+                        tr_put(a.trace, pos0 + c, 8, lane, xv[0]);
+                        if (S::SB) tr_put(a.trace, pos0 + c, 9, lane, owner_elem(s.bw, 0, (T)0));
+                    })
                     if (S::SC) {
 #pragma unroll
                         for (int cw = 0; cw < NCW; ++cw) {
@@ -584,6 +623,10 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
             }
             const uint32_t tag = r.want + a.owner_tag0 + 1u;
             uint32_t ow[VPL * NW * 2], oc[NW * 2], ob[NW * 2];
+            CMI_TR(if constexpr (VPL == 1 && NCW == 1) {
+                tr_put(a.trace, pos0 + c, 10, lane, xv[0]);
+                if (S::SB) tr_put(a.trace, pos0 + c, 11, lane, bv[0]);
+            })
 #pragma unroll
             for (int v = 0; v < VPL; ++v) owner_pack(ow, v, xv[v], tag);
             owner_st_words(rs, lane * (VPL * NW * 8), (int)r.off, ow);
@@ -630,7 +673,22 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
             T hq[VPL], hcq[NCW], hbq = (T)0;
 #pragma unroll
             for (int cw = 0; cw < NCW; ++cw) hcq[cw] = (T)0;
+#ifdef CMI_VAR_HUB_COHERENT
+            { // experiment: the team's hub row through system-scope (sc0 sc1) loads
+                const T *row = (HUB_ITEM ? a.Q : a.P) + (size_t)r.hub * k;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) hq[v] = __hip_atomic_load(row + min(lane * VPL + v, k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (S::HC) {
+#pragma unroll
+                    for (int cw = 0; cw < NCW; ++cw)
+                        hcq[cw] = __hip_atomic_load((HUB_ITEM ? a.icBias : a.ucBias) + (size_t)r.hub * a.n_conds + min(lane + 64 * cw, a.n_conds - 1),
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (S::HB) hbq = __hip_atomic_load((HUB_ITEM ? a.itemBias : a.userBias) + r.hub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+#else
             owner_load_hub<T, MODEL, VPL, NCW, HUB_ITEM>(a, r.hub, lane, k, hq, hcq, hbq);
+#endif
 #pragma unroll
             for (int v = 0; v < VPL; ++v) h[v] = lane * VPL + v < k ? hq[v] : (T)0;
             if (S::HC) {
@@ -660,7 +718,21 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
             if (S::SB) last = sb;
             r_next = recs[c + 1 + team_after(last)];
         }
+        CMI_TR(if constexpr (VPL == 1 && NCW == 1) {
+            tr_put(a.trace, pos0 + c, 0, lane, h[0]);
+            tr_put(a.trace, pos0 + c, 1, lane, x[0]);
+            tr_put(a.trace, pos0 + c, 2, lane, hc[0]);
+            const double meta = lane == 0 ? (double)sb : lane == 1 ? (double)r.off : lane == 2 ? (double)r.hub : lane == 3 ? (double)r.want
+                              : lane == 4 ? (double)r.flags : lane == 5 ? 1.0 : lane == 6 ? (double)a.owner_tag0 : lane == 7 ? (double)hb : 0.0;
+            tr_put(a.trace, pos0 + c, 3, lane, meta);
+        })
         owner_update<T, MODEL, VPL, NCW, HUB_ITEM, false>(r, hp, k, h, hc, hb, x, sc, sb, sq_p, sq_q, sq_c, sq_e, sq_b);
+        CMI_TR(if constexpr (VPL == 1 && NCW == 1) {
+            tr_put(a.trace, pos0 + c, 4, lane, h[0]);
+            tr_put(a.trace, pos0 + c, 5, lane, x[0]);
+            tr_put(a.trace, pos0 + c, 6, lane, hc[0]);
+            tr_put(a.trace, pos0 + c, 7, lane, lane == 0 ? sb : lane == 7 ? hb : (T)0);
+        })
         {
             T one[1];
             team_put<T, VPL>(sl + lane * (VPL * (int)sizeof(T)), x);
@@ -681,15 +753,21 @@ __device__ __forceinline__ void owner_team(const SgdArgs<T> &a, const OwnerRecT<
         }
         if (__builtin_expect(r.flags & OWN_HUB_STORE, 0)) {
             T *row = (HUB_ITEM ? a.Q : a.P) + (size_t)r.hub * k;
+#ifdef CMI_VAR_HUB_COHERENT
+#define CMI_HUB_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#else
+#define CMI_HUB_ST(p, v) (*(p) = (v))
+#endif
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
-                if (lane * VPL + v < k) row[lane * VPL + v] = h[v];
+                if (lane * VPL + v < k) CMI_HUB_ST(row + lane * VPL + v, h[v]);
             if (S::HC) {
 #pragma unroll
                 for (int cw = 0; cw < NCW; ++cw)
-                    if (lane + 64 * cw < a.n_conds) (HUB_ITEM ? a.icBias : a.ucBias)[(size_t)r.hub * a.n_conds + lane + 64 * cw] = hc[cw];
+                    if (lane + 64 * cw < a.n_conds) CMI_HUB_ST((HUB_ITEM ? a.icBias : a.ucBias) + (size_t)r.hub * a.n_conds + lane + 64 * cw, hc[cw]);
             }
-            if (S::HB && lane == 0) (HUB_ITEM ? a.itemBias : a.userBias)[r.hub] = hb;
+            if (S::HB && lane == 0) CMI_HUB_ST((HUB_ITEM ? a.itemBias : a.userBias) + r.hub, hb);
+#undef CMI_HUB_ST
         }
         if ((c & 15) == 15) { // flush the float partial sums of squares into the double accumulator
             acc += (double)hp.regU * (double)sq_p + (double)hp.regI * (double)sq_q + (double)hp.regC * (double)sq_c;
@@ -739,7 +817,7 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
     recs += c0;
     if constexpr (!STRICT) {
         if (team) {
-            owner_team<T, MODEL, VPL, NCW, D, HUB_ITEM>(a, recs, len, w, rs, hp, error);
+            owner_team<T, MODEL, VPL, NCW, D, HUB_ITEM>(a, recs, len, w, rs, hp, error, c0);
             return;
         }
     }
@@ -817,7 +895,21 @@ __global__ __launch_bounds__(256, 1) void sgd_owner(SgdArgs<T> a, const OwnerRec
             if (S::SB) sb = owner_elem(s.bw, 0, (T)0);
         }
 
+        CMI_TR(if constexpr (VPL == 1 && NCW == 1) {
+            tr_put(a.trace, c0 + c, 0, lane, h[0]);
+            tr_put(a.trace, c0 + c, 1, lane, x[0]);
+            tr_put(a.trace, c0 + c, 2, lane, hc[0]);
+            const double meta = lane == 0 ? (double)sb : lane == 1 ? (double)r.off : lane == 2 ? (double)r.hub : lane == 3 ? (double)r.want
+                              : lane == 4 ? (double)r.flags : lane == 5 ? 1.0 : lane == 6 ? (double)a.owner_tag0 : lane == 7 ? (double)hb : 0.0;
+            tr_put(a.trace, c0 + c, 3, lane, meta);
+        })
         owner_update<T, MODEL, VPL, NCW, HUB_ITEM, STRICT>(r, hp, k, h, hc, hb, x, sc, sb, sq_p, sq_q, sq_c, sq_e, sq_b);
+        CMI_TR(if constexpr (VPL == 1 && NCW == 1) {
+            tr_put(a.trace, c0 + c, 4, lane, h[0]);
+            tr_put(a.trace, c0 + c, 5, lane, x[0]);
+            tr_put(a.trace, c0 + c, 6, lane, hc[0]);
+            tr_put(a.trace, c0 + c, 7, lane, lane == 0 ? sb : lane == 7 ? hb : (T)0);
+        })
         } // !OWN_NOP
 
         // ---- the spoke record goes back with the next tag (always: one store sequence per step); the hub side when the next

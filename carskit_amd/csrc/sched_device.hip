@@ -410,11 +410,6 @@ hipError_t walk(DevPool &pool, int device, hipStream_t s, const Sorted &hubs, co
             blocks = (unsigned)std::min<int64_t>(rb_used, ((int64_t)n_hub + (int64_t)256 * hmax - 1) / ((int64_t)256 * hmax));
             break;
         }
-        continue;
-        if ((int64_t)rb * 256 * hmax >= n_hub) {
-            blocks = (unsigned)std::min<int64_t>(rb, ((int64_t)n_hub + (int64_t)256 * hmax - 1) / ((int64_t)256 * hmax));
-            break;
-        }
     }
     if (getenv("CMI_SCHED_WALK_MEM")) blocks = 0; // tests: force the in-memory form
     if (!blocks) { // more hub rows than 16 per resident lane: the rows' state lives in memory
@@ -454,6 +449,14 @@ hipError_t walk(DevPool &pool, int device, hipStream_t s, const Sorted &hubs, co
 }
 
 } // namespace
+
+void ChainDeviceKeep::release() {
+    for (int32_t **q : {&d_u, &d_j, &d_perm})
+        if (*q) {
+            (void)hipFree(*q);
+            *q = nullptr;
+        }
+}
 
 bool build_chain_schedule_device(int device, void *stream, int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub,
                                  int max_chain, ChainSchedule &out, ChainDeviceKeep *keep) {

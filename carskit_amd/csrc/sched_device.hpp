@@ -10,8 +10,13 @@ namespace cmi {
 // (uploaded here).  false = not built (a HIP failure, more hub rows than the resident grid can own): the caller uses the host builder.
 // keep != nullptr: the uploaded tuple ids and the permutation STAY on the device for the caller (who frees them with hipFree) and
 // out.perm is left empty -- the tuple stream is then built on the device too (stream_build_device), nothing of size n goes back to the host.
-struct ChainDeviceKeep {
+struct ChainDeviceKeep { // owns the three device arrays: whatever path leaves cmi_set_ratings (error, exception), they are freed
     int32_t *d_u = nullptr, *d_j = nullptr, *d_perm = nullptr;
+    ChainDeviceKeep() = default;
+    ChainDeviceKeep(const ChainDeviceKeep &) = delete;
+    ChainDeviceKeep &operator=(const ChainDeviceKeep &) = delete;
+    void release();            // hipFree the arrays now (sched_device.hip)
+    ~ChainDeviceKeep() { release(); }
 };
 bool build_chain_schedule_device(int device, void *stream, int64_t n, const int32_t *u, const int32_t *j, int32_t n_users, int32_t n_items, int hub,
                                  int max_chain, ChainSchedule &out, ChainDeviceKeep *keep = nullptr);

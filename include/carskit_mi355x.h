@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define CMI_ABI_VERSION 4 /* 4: round 5 -- ADDED cmi_group_last_times, cmi_comm_last_exchange_ms (exchange vs compute time of an epoch),
+#define CMI_ABI_VERSION 5 /* 5: round 6 -- CMI_E_BUSY; FM: the fixed-order (bit-reproducible) sweep is the DEFAULT, CMI_FM_FLAG_RELAXED_SUMS opts into the
+                             LDS-atomic form (CMI_FM_FLAG_DETERMINISTIC is still accepted and now changes nothing)
+                             4: round 5 -- ADDED cmi_group_last_times, cmi_comm_last_exchange_ms (exchange vs compute time of an epoch),
                              cmi_chain_schedule_device; CMI_E_HOST; CMI_FM_FLAG_DETERMINISTIC; cmi_fm_layout's [5..6] are batches
                              3: round 4 -- cmi_comm_*, cmi_fm_comm_*, group resident evaluation, FM layout / timing, ranking host
                              clock; REMOVED: CMI_FLAG_SCHED_FLOW, CMI_FLAG_TWO_LANE, cmi_flow_schedule, cmi_split_schedule */
@@ -41,6 +43,8 @@ extern "C" {
 #define CMI_E_UNSUPPORTED (-5)
 #define CMI_E_HOST (-6)       /* a C++ exception (std::bad_alloc ...) reached the boundary: caught there, never thrown at the host;
                                  the JNI shim turns it into a RuntimeException like every other status (Recommender.java:1162-1171) */
+#define CMI_E_BUSY (-7)       /* an owner (persistent) epoch was NOT launched: another process held the device's owner-epoch lock for the
+                                 whole bounded wait, or the lock file cannot be opened (CMI_OWNER_NO_LOCK=1 waives it); model untouched */
 
 /* recommender kinds = the `recommender=` names the reference's factory switch maps to the classes
  * this library accelerates (src/carskit/main/CARSKit.java:461,700-707) */
@@ -408,12 +412,15 @@ int cmi_comm_last_exchange_ms(cmi_handle h, float *ms);
  * read by the reference and is not computed. */
 typedef struct cmi_fm_instance *cmi_fm_handle;
 
-/* new FM(train, test, fold) + initModel() allocation (FM.java:49-74).  flags: CMI_FM_FLAG_DETERMINISTIC -- every coordinate's sums are
- * added in an order the data layout alone decides (LDS parking + a fixed walk): runs are bit-reproducible and the split phases
- * (reduce / apply) equal the fused sweep bit for bit, at ~12 % more time per sweep.  Default: the records' products are added with LDS
- * atomics as they are evaluated -- same sums to the last few bits (the order of fp64 additions varies run to run), within the 1e-8
- * the FM path promises against the reference arithmetic either way. */
+/* new FM(train, test, fold) + initModel() allocation (FM.java:49-74).  Default (flags 0): every coordinate's sums are added in an order
+ * the data layout alone decides (LDS parking + a fixed walk) -- two runs on identical inputs give bit-identical models, as two runs of
+ * the reference's sweep do (FM.java:148-218), and the split phases (reduce / apply) equal the fused sweep bit for bit.
+ * CMI_FM_FLAG_RELAXED_SUMS (or env CMI_FM_RELAXED_SUMS=1): the records' products are added with LDS atomics as they are evaluated --
+ * ~11 % less time per sweep, same sums to the last few bits, but the order of the fp64 additions (so the last bits of the model, ~1e-12
+ * relative) varies from run to run.  Both forms are within the 1e-8 the FM path promises against the reference arithmetic.
+ * CMI_FM_FLAG_DETERMINISTIC: the round-5 name of what is now the default; accepted, no effect. */
 #define CMI_FM_FLAG_DETERMINISTIC 0x1u
+#define CMI_FM_FLAG_RELAXED_SUMS 0x2u
 int cmi_fm_create(int k, int n_users, int n_items, int n_conds, int n_ctx_dims, int device, unsigned flags,
                   cmi_fm_handle *out);
 int cmi_fm_destroy(cmi_fm_handle h);

@@ -21,7 +21,7 @@ def test_header_symbols_all_exported():
     L = capi.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.cmi_abi_version() == 4
+    assert L.cmi_abi_version() == 5
 
 
 def test_no_cpu_fallback():

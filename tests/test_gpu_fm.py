@@ -13,8 +13,9 @@ from tests.test_oracle_fm import REGLF, REGLW, fm_init_model
 pytestmark = pytest.mark.gpu
 
 
-DET = capi.FM_FLAG_DETERMINISTIC    # sums in an order the layout alone decides: what the bit-identity assertions below need
-FORM = 0                            # the form make_fm() builds: the default (LDS atomics) unless a test sets DET
+DET = 0                             # the DEFAULT since round 6: sums in an order the layout alone decides (bit-reproducible, FM.java:148-218)
+RELAXED = capi.FM_FLAG_RELAXED_SUMS # the opt-in: a record's products are added with LDS atomics as it is evaluated (order varies run to run)
+FORM = 0                            # the form make_fm() builds unless a test passes flags
 
 
 def make_fm(data, k, seed, flags=None):
@@ -28,7 +29,7 @@ def make_fm(data, k, seed, flags=None):
     return orc, g
 
 
-@pytest.mark.parametrize("flags", [0, DET])
+@pytest.mark.parametrize("flags", [DET, RELAXED])
 @pytest.mark.parametrize("k", [1, 4, 64, 70])
 def test_fm_sweeps_match_oracle(k, flags):
     data = util.small_data(n_users=40, n_items=15, n_dims=2, conds_per_dim=3, n=500, seed=51)
@@ -146,7 +147,7 @@ def test_fm_phases_in_any_order_match_the_numpy_engine():
     assert np.all(np.isfinite(p))
 
 
-@pytest.mark.parametrize("flags", [0, DET])
+@pytest.mark.parametrize("flags", [DET, RELAXED])
 @pytest.mark.parametrize("n_users,n_items,n,zipf", [(3, 40, 1500, None), (1, 30, 900, None), (400, 2, 1200, None),
                                                      (300, 25, 3000, 1.3), (2, 2, 60, None), (1, 40, 6000, None)])
 def test_fm_support_length_paths(n_users, n_items, n, zipf, flags):
@@ -199,22 +200,29 @@ def test_fm_l2_sliced_orders_match_the_oracle(slice_entries):
     assert np.array_equal(g.get_model()[2], V)
 
 
-def test_fm_default_form_is_the_deterministic_one_to_rounding():
-    """The default form adds a record's products with LDS atomics as it is evaluated (the order of the fp64 additions varies); the
-    CMI_FM_FLAG_DETERMINISTIC form parks and walks them in a fixed order.  Same sums to rounding: models within 1e-12 relative of each
-    other after three sweeps (both within 1e-8 of the reference arithmetic, tests above), and the deterministic form reproduces itself
-    bit for bit."""
+def test_fm_default_form_is_bit_reproducible_and_the_relaxed_form_equals_it_to_rounding():
+    """Two trainings on identical inputs give bit-identical models by default, as two runs of the reference's sweep do (FM.java:148-218):
+    the default form parks a batch's products in LDS and adds them in an order the layout alone decides.  CMI_FM_FLAG_RELAXED_SUMS adds
+    them with LDS atomics as they are evaluated (the order of the fp64 additions varies): same sums to rounding, models within 1e-11
+    relative of the default's after three sweeps (both within 1e-8 of the reference arithmetic, tests above).  The round-5 flag
+    CMI_FM_FLAG_DETERMINISTIC is still accepted and builds the default form, also next to the relaxed flag or the environment's opt-in."""
+    import os
     data = util.small_data(n_users=300, n_items=120, n_dims=2, conds_per_dim=3, n=20000, seed=61)
     runs = []
-    for flags in (0, DET, DET):
-        _, g = make_fm(data, 8, 3, flags)
-        g.init()
-        for _ in range(3):
-            g.sweep()
+    for flags, env in ((0, None), (0, None), (capi.FM_FLAG_DETERMINISTIC, None), (capi.FM_FLAG_DETERMINISTIC | RELAXED, None),
+                       (capi.FM_FLAG_DETERMINISTIC, "1"), (RELAXED, None), (0, "1")):
+        if env: os.environ["CMI_FM_RELAXED_SUMS"] = env
+        try:
+            _, g = make_fm(data, 8, 3, flags)
+        finally:
+            os.environ.pop("CMI_FM_RELAXED_SUMS", None)
+        g.train(3)          # cmi_fm_train: init + three sweeps
         runs.append(g.get_model())
-    assert runs[1][0] == runs[2][0] and np.array_equal(runs[1][1], runs[2][1]) and np.array_equal(runs[1][2], runs[2][2])
-    np.testing.assert_allclose(runs[0][1], runs[1][1], rtol=1e-11, atol=1e-13)
-    np.testing.assert_allclose(runs[0][2], runs[1][2], rtol=1e-11, atol=1e-13)
+    for other in runs[1:5]:          # default twice, and every spelling of "deterministic": bit for bit
+        assert runs[0][0] == other[0] and np.array_equal(runs[0][1], other[1]) and np.array_equal(runs[0][2], other[2])
+    for relaxed in runs[5:]:         # flag and environment opt-in
+        np.testing.assert_allclose(relaxed[1], runs[0][1], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(relaxed[2], runs[0][2], rtol=1e-11, atol=1e-13)
 
 
 def test_fm_runner_exchange_path_on_the_instance_stream_with_rccl():
@@ -256,7 +264,7 @@ def test_fm_runner_exchange_path_on_the_instance_stream_with_rccl():
 @pytest.mark.parametrize("batch,slots,slice_entries,shape", [(64, 96, 8, (60, 40, 3000, None)), (32, 96, 4, (300, 25, 3000, 1.3)),
                                                              (128, 96, 16, (1, 40, 6000, None)), (64, 100, 0, (400, 2, 1200, None)),
                                                              (16, 96, 5, (37, 11, 900, None))])
-@pytest.mark.parametrize("flags", [0, DET])
+@pytest.mark.parametrize("flags", [DET, RELAXED])
 def test_fm_cell_stream_blocks_batches_and_complex_coordinates(batch, slots, slice_entries, shape, flags):
     """The cell stream's structure, forced on small data (CMI_FM_BATCH = records per batch, CMI_FM_SLOTS = accumulator slots per block,
     CMI_FM_SLICE): many blocks, cells cut into several batches, runs longer than 64 records inside a batch (several slots per
@@ -289,7 +297,7 @@ def test_fm_cell_stream_blocks_batches_and_complex_coordinates(batch, slots, sli
     np.testing.assert_allclose(w, orc.w, rtol=1e-8, atol=1e-11)
     np.testing.assert_allclose(V, orc.V.reshape(V.shape), rtol=1e-8, atol=1e-11)
     for x, y in zip(g.get_model(), g2.get_model()):
-        if flags == DET:
+        if flags == DET:    # the default form: split phases == fused sweep bit for bit
             assert np.array_equal(np.asarray(x), np.asarray(y))
         else:
             np.testing.assert_allclose(np.asarray(x), np.asarray(y), rtol=1e-11, atol=1e-13)

@@ -81,7 +81,7 @@ def test_owner_f32_vs_oracle_north_star_bar(model, hub, k):
 
 @pytest.mark.parametrize("model", LEVEL_MODELS)
 @pytest.mark.parametrize("hub", ["item", "user"])
-@pytest.mark.parametrize("k,flags", [(10, F64), (128, F64), (64, 0), (200, 0)])
+@pytest.mark.parametrize("k,flags", [(10, F64), (64, F64), (128, F64), (64, 0), (200, 0)])
 def test_owner_team_form(model, hub, k, flags):
     """The team form (a workgroup of three wavefronts per owner: loader -> LDS ring -> compute -> LDS ring -> storer), which
     cmi_set_ratings gives to the hottest single-row owners, forced on EVERY owner here (CMI_OWNER_TEAM=all), lists with many rows
@@ -95,18 +95,22 @@ def test_owner_team_form(model, hub, k, flags):
 
 
 def test_owner_team_form_is_picked_for_the_hottest_rows():
-    """(k = 128: fp64 at k <= 64 gets no automatic teams since round 5 -- the instantiation measured inexact beside another owner epoch)"""
+    """Every instantiation gets automatic teams again (round 5 withheld them from fp64 at k <= 64, the instantiation measured inexact
+    beside another owner epoch; the cause -- a store-data hazard in the record stores -- is fixed, tests/test_gpu_soak.py)."""
     data = synth.generate(20000, 2000, 4, 8, 600000, seed=91, item_zipf=1.1)
-    for team, expect in ((None, True), ("0", False)):
-        orc, inst = _env(lambda: make_pair("CAMF_CI", data, 128, F64 | OWNER), CMI_OWNER_TEAM=team, CMI_OWNER_TEAM_MIN=4096)
-        info = inst.schedule_info()
-        assert info["kind"] == "owner-item" and (info["teams"] > 0) == expect, info
-        for _ in range(2):
-            lo, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
-            assert abs(lo - lg) <= 1e-10 * abs(lo)
-        assert_state_equal(orc, inst, exact=False, atol=1e-11)
-    orc, inst = _env(lambda: make_pair("CAMF_CI", data, 64, F64 | OWNER), CMI_OWNER_TEAM=None, CMI_OWNER_TEAM_MIN=4096)
-    assert inst.schedule_info()["teams"] == 0
+    for k in (128, 64):
+        for team, expect in ((None, True), ("0", False)):
+            orc, inst = _env(lambda: make_pair("CAMF_CI", data, k, F64 | OWNER), CMI_OWNER_TEAM=team, CMI_OWNER_TEAM_MIN=4096)
+            info = inst.schedule_info()
+            assert info["kind"] == "owner-item" and (info["teams"] > 0) == expect, info
+            for _ in range(2):
+                lo, lg = orc.epoch(util.LR), inst.train_epoch(util.LR)
+                assert abs(lo - lg) <= 1e-10 * abs(lo)
+            assert_state_equal(orc, inst, exact=False, atol=1e-11)
+    # an instance that shares its device (cmi_set_device_share) keeps its teams too
+    orc, inst = _env(lambda: make_pair("CAMF_CI", data, 64, F64 | OWNER, before_ratings=lambda i: i.set_device_share(2)), CMI_OWNER_TEAM=None,
+                     CMI_OWNER_TEAM_MIN=4096)
+    assert inst.schedule_info()["teams"] > 0
 
 
 @pytest.mark.parametrize("model", LEVEL_MODELS)
