@@ -520,11 +520,13 @@ def bench_group(args):
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%s: %s k=%d, %d users x %d items per GPU, %d ratings per GPU, one context table of %d combinations"
                                   % (args.workload, model, k, n_users, n_items, n_ratings, data.n_ctx),
+                      # the exchange the library really runs: RCCL after its pre-flight (one small exchange through RCCL and through the
+                      # in-process path, both bit-identical to the host's sums), or the in-process peer-copy exchange -- by design when
+                      # shards share a device, as the FALLBACK when RCCL failed to initialise or to pass the pre-flight on this node
                       "parallelism": "one process, cmi_group over %d shards on %d physical GPU(s) (user-sharded; exchange: %s)%s"
-                                     % (W, n_phys, {"rccl": "RCCL reduce-scatter + all-gather over xGMI, ncclCommInitAll",
-                                                    "in-process": "in-process sums on shard 0's stream, no communicator",
-                                                    "none": "none"}[shards[0]["exchange"]],
+                                     % (W, n_phys, g.exchange_path(),
                                         " -- SHARED DEVICE: a code-path check (CMI_BENCH_SHARE_GPU), not a measurement" if share else ""),
+                      "exchange": shards[0]["exchange"],
                       "setup_s": setup_s, "shards": shards},
            "compute_ms": compute_ms, "exchange_ms": exchange_ms, "host_ms": max(0.0, step_ms - compute_ms - exchange_ms),
            "exchange_bytes_per_shard": int(shards[0]["bucket_elems"]) * 4,
@@ -894,7 +896,7 @@ def main():
                                 ("fm_c4", lambda: bench_fm(small)), ("rank", lambda: bench_rank(rk))):
                     try:
                         o = fn()
-                        out[key] = {kk: o[kk] for kk in ("metric", "workload", "value", "unit", "steps", "ms_per_step", "setup_s", "dtype", "roofline", "config")
+                        out[key] = {kk: o[kk] for kk in ("metric", "workload", "value", "unit", "steps", "ms_per_step", "setup_s", "dtype", "roofline", "config", "relaxed_sums")
                                     if kk in o}
                     except SystemExit:
                         raise
@@ -902,6 +904,27 @@ def main():
                         out[key] = {"value": None, "error": repr(e)}
         if world == 1:
             out["box"] = box_state()     # read right after the timed work, clocks still up
+            # the driver's record keeps `config`, `roofline` and `cpu_baseline` and drops every other key of the line: the secondary
+            # workloads timed in this same run travel as five numbers each inside config; the full objects stay at
+            # the top level for whoever reads the line itself
+            sec = {}
+            for key in ("northstar", "c5", "f64", "fm_c4", "rank"):
+                o = out.get(key)
+                if not isinstance(o, dict) or o.get("value") is None:
+                    continue
+                rf = o.get("roofline") or {}
+                sec[key] = {"value": o["value"], "unit": o.get("unit"), "ms_per_step": o.get("ms_per_step"), "frac": rf.get("frac"),
+                            "traffic_over_model": rf.get("traffic_over_model")}
+                if key == "fm_c4" and isinstance(o.get("relaxed_sums"), dict):
+                    sec["fm_c4_relaxed_sums"] = {"value": o["relaxed_sums"]["value"], "unit": o["relaxed_sums"]["unit"],
+                                                 "ms_per_step": o["relaxed_sums"]["ms_per_step"], "frac": o["relaxed_sums"].get("frac"),
+                                                 "traffic_over_model": None}
+            if sec:
+                out["config"]["secondary"] = sec
+            out["roofline"]["note"] = ("frac = schedule-model bytes (what this schedule has to move: hub rows once per unit, spoke rows once per tuple) "
+                                       "/ HIP-event kernel time / 8 TB/s; SURVEY 8(d)'s zero-reuse bytes_per_update_algorithmic exceed what the "
+                                       "schedule moves (hub rows stay on chip for ~4.5 tuples), so frac_algorithmic may exceed 1 without any "
+                                       "update being skipped (tests/test_gpu_fullsize.py holds all updates of the epoch to the oracle)")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

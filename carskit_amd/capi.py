@@ -121,6 +121,7 @@ SYMBOLS = [
     ("cmi_group_predict_batch", C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, C.c_double, C.c_double, _vp]),
     ("cmi_group_shard_info", C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
     ("cmi_group_last_times", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("cmi_group_exchange_path", C.c_char_p, [_vp]),
     ("cmi_group_member", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("cmi_exchange_pack", C.c_int, [_vp]),
     ("cmi_exchange_apply", C.c_int, [_vp, C.c_double]),
@@ -526,6 +527,10 @@ class Group:
         self._chk(self.L.cmi_group_shard_info(self.h, shard, info))
         return {"user_lo": info[0], "user_hi": info[1], "tuples": info[2], "device": info[3],
                 "exchange": ("none", "rccl", "in-process")[info[4]], "bucket_elems": info[5]}
+
+    def exchange_path(self):
+        """Which exchange the group runs and why (RCCL after its pre-flight, or the in-process exchange: shared device / fallback)."""
+        return self.L.cmi_group_exchange_path(self.h).decode()
 
     def last_times(self):
         """(compute_ms, exchange_ms) per shard of the most recent epoch (HIP events on the shards' streams)."""

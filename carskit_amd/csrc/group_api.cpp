@@ -46,6 +46,7 @@ struct cmi_group {
     bool timed = false;
     int64_t x_count = 0;
     bool rccl = false;
+    std::string path_note;           // which exchange runs and why (cmi_group_exchange_path): RCCL verified by the pre-flight, or the fallback's reason
     std::vector<ncclComm_t> comm;
     void *d_stage = nullptr;         // in-process exchange: staging buffer on shard 0's device
     double lr_scale = 1.0;           // local learning rate = lrate x lr_scale (cmi_group_set_lr_scale)
@@ -117,6 +118,10 @@ static hipError_t group_add(void *acc, const void *x, int64_t n, bool f64, hipSt
     else hipLaunchKernelGGL(group_add_kernel<float>, dim3(blocks), dim3(256), 0, s, (float *)acc, (const float *)x, n);
     return hipGetLastError();
 }
+
+static int group_preflight(cmi_group *g);
+
+extern "C" const char *cmi_group_exchange_path(cmi_group_handle g) { return g ? g->path_note.c_str() : ""; }
 
 extern "C" const char *cmi_group_last_error(cmi_group_handle g) { return g ? g->err.c_str() : g_group_create_err.c_str(); }
 
@@ -284,7 +289,6 @@ extern "C" int cmi_group_set_ratings(cmi_group_handle g, int64_t n, const int32_
     bool distinct = true;
     for (int a = 0; a < W; ++a)
         for (int b = a + 1; b < W; ++b) distinct = distinct && g->dev[(size_t)a] != g->dev[(size_t)b];
-    g->rccl = distinct && !cmi_exp_env("CMI_GROUP_NO_RCCL");
     g->ev.assign((size_t)W + 1, nullptr);
     for (int s = 0; s <= W; ++s) { // ev[W] belongs to shard 0's device
         GRP_HIP(g, hipSetDevice(g->dev[s == W ? 0 : (size_t)s]));
@@ -295,24 +299,41 @@ extern "C" int cmi_group_set_ratings(cmi_group_handle g, int64_t n, const int32_
         GRP_HIP(g, hipSetDevice(g->dev[(size_t)s / 2]));
         GRP_HIP(g, hipEventCreate(&g->tx[(size_t)s]));
     }
-    if (g->rccl) {
-        g->comm.assign((size_t)W, nullptr);
-        GRP_NCCL(g, ncclCommInitAll(g->comm.data(), W, g->dev.data()));
-    } else {
-        GRP_HIP(g, hipSetDevice(g->dev[0]));
-        GRP_HIP(g, hipMalloc(&g->d_stage, (size_t)g->x_count * (g->f64 ? 8 : 4) + 8));
-        for (int s = 1; s < W; ++s)
-            if (g->dev[(size_t)s] != g->dev[0]) {
-                int can = 0;
-                hipDeviceCanAccessPeer(&can, g->dev[0], g->dev[(size_t)s]);
-                if (can) {
-                    hipSetDevice(g->dev[0]);
-                    hipDeviceEnablePeerAccess(g->dev[(size_t)s], 0); // already enabled is fine
-                    hipSetDevice(g->dev[(size_t)s]);
-                    hipDeviceEnablePeerAccess(g->dev[0], 0);
-                    (void)hipGetLastError();
-                }
+    // The in-process exchange (peer copies) is ALWAYS set up: it is what shards that share a device use, and what a group falls back
+    // to when RCCL cannot be initialised or does not pass the pre-flight on this node (the first N > 1 RCCL call
+    // ever executed must not be the timed one, and a failure must still leave a working trainer).
+    GRP_HIP(g, hipSetDevice(g->dev[0]));
+    GRP_HIP(g, hipMalloc(&g->d_stage, (size_t)g->x_count * (g->f64 ? 8 : 4) + 8));
+    for (int s = 1; s < W; ++s)
+        if (g->dev[(size_t)s] != g->dev[0]) {
+            int can = 0;
+            hipDeviceCanAccessPeer(&can, g->dev[0], g->dev[(size_t)s]);
+            if (can) {
+                hipSetDevice(g->dev[0]);
+                hipDeviceEnablePeerAccess(g->dev[(size_t)s], 0); // already enabled is fine
+                hipSetDevice(g->dev[(size_t)s]);
+                hipDeviceEnablePeerAccess(g->dev[0], 0);
+                (void)hipGetLastError();
             }
+        }
+    g->rccl = false;
+    g->path_note = "in-process exchange (sums on shard 0's stream, peer copies)";
+    // CMI_GROUP_TRY_RCCL=1 (test hook): attempt RCCL although shards share a device -- ncclCommInitAll refuses duplicate devices, which
+    // drives the fallback below on a single-GPU box (tests/test_gpu_bench_group.py)
+    const bool try_rccl = (distinct || getenv("CMI_GROUP_TRY_RCCL")) && !cmi_exp_env("CMI_GROUP_NO_RCCL");
+    if (!distinct && !try_rccl) g->path_note += ": shards share a device";
+    if (try_rccl) {
+        g->comm.assign((size_t)W, nullptr);
+        const ncclResult_t r = ncclCommInitAll(g->comm.data(), W, g->dev.data());
+        if (r != ncclSuccess) {
+            g->comm.clear();
+            (void)hipGetLastError();
+            g->path_note = std::string("in-process exchange (peer copies) -- FALLBACK: ncclCommInitAll failed: ") + ncclGetErrorString(r);
+            fprintf(stderr, "[cmi] group: %s\n", g->path_note.c_str());
+        } else {
+            g->rccl = true;
+            if (int rc = group_preflight(g)) return rc; // (may switch to the in-process exchange; only a HIP failure is an error)
+        }
     }
     return CMI_OK;
 }
@@ -358,25 +379,17 @@ extern "C" int cmi_group_get_state(cmi_group_handle g, int which, void *dst, int
     return CMI_OK;
 }
 
-// the epoch-boundary merge of the item-side containers + the global loss; everything enqueued on the shards' streams
-static int group_exchange(cmi_group *g) {
+// The collective part of the exchange over the first `count` elements of every shard's bucket (count: a multiple of W) and the fp64
+// loss words dl[s], enqueued on the shards' streams st[s]: through RCCL (grouped calls over the process's communicators) or in process.
+static int exchange_buckets(cmi_group *g, bool rccl, int64_t count, const std::vector<hipStream_t> &st, const std::vector<double *> &dl) {
     const int W = (int)g->inst.size();
     const size_t es = g->f64 ? 8 : 4;
-    std::vector<hipStream_t> st((size_t)W);
-    std::vector<double *> dl((size_t)W);
-    for (int s = 0; s < W; ++s) {
-        GRP_MEMBER(g, s, cmi_stream(g->inst[(size_t)s], (void **)&st[(size_t)s]));
-        GRP_HIP(g, hipSetDevice(g->dev[(size_t)s]));
-        GRP_HIP(g, hipEventRecord(g->tx[(size_t)2 * s], st[(size_t)s]));
-        GRP_MEMBER(g, s, cmi_exchange_pack(g->inst[(size_t)s]));
-        GRP_MEMBER(g, s, cmi_loss_device_ptr(g->inst[(size_t)s], (void **)&dl[(size_t)s]));
-    }
-    if (g->rccl) {
+    if (rccl) {
         // every collective of the exchange is one grouped call over all communicators of this process
         for (int phase = 0; phase < 3; ++phase) {
             GRP_NCCL(g, ncclGroupStart());
             for (int s = 0; s < W; ++s) {
-                const ncclResult_t r = exchange_collective(phase, g->comm[(size_t)s], g->bucket[(size_t)s], g->x_count, W, s, g->f64, dl[(size_t)s], st[(size_t)s]);
+                const ncclResult_t r = exchange_collective(phase, g->comm[(size_t)s], g->bucket[(size_t)s], count, W, s, g->f64, dl[(size_t)s], st[(size_t)s]);
                 if (r != ncclSuccess) {
                     (void)ncclGroupEnd();
                     GRP_FAIL(g, CMI_E_HIP, "exchange (phase %d, shard %d) failed: %s", phase, s, ncclGetErrorString(r));
@@ -392,31 +405,124 @@ static int group_exchange(cmi_group *g) {
             GRP_HIP(g, hipEventRecord(g->ev[(size_t)s], st[(size_t)s]));
         }
         GRP_HIP(g, hipSetDevice(g->dev[0]));
-        double *stage_loss = (double *)((char *)g->d_stage + (size_t)g->x_count * es);
+        double *stage_loss = (double *)((char *)g->d_stage + (size_t)count * es);
         for (int s = 1; s < W; ++s) {
             GRP_HIP(g, hipStreamWaitEvent(st[0], g->ev[(size_t)s], 0));
             const void *src = g->bucket[(size_t)s];
             if (g->dev[(size_t)s] != g->dev[0]) {
-                GRP_HIP(g, hipMemcpyPeerAsync(g->d_stage, g->dev[0], g->bucket[(size_t)s], g->dev[(size_t)s], (size_t)g->x_count * es, st[0]));
+                GRP_HIP(g, hipMemcpyPeerAsync(g->d_stage, g->dev[0], g->bucket[(size_t)s], g->dev[(size_t)s], (size_t)count * es, st[0]));
                 GRP_HIP(g, hipMemcpyPeerAsync(stage_loss, g->dev[0], dl[(size_t)s], g->dev[(size_t)s], 8, st[0]));
                 src = g->d_stage;
                 GRP_HIP(g, group_add(dl[0], stage_loss, 1, true, st[0]));
             } else {
                 GRP_HIP(g, group_add(dl[0], dl[(size_t)s], 1, true, st[0]));
             }
-            GRP_HIP(g, group_add(g->bucket[0], src, g->x_count, g->f64, st[0]));
+            GRP_HIP(g, group_add(g->bucket[0], src, count, g->f64, st[0]));
         }
         GRP_HIP(g, hipEventRecord(g->ev[(size_t)W], st[0]));
         for (int s = 1; s < W; ++s) {
             GRP_HIP(g, hipSetDevice(g->dev[(size_t)s]));
             GRP_HIP(g, hipStreamWaitEvent(st[(size_t)s], g->ev[(size_t)W], 0));
-            GRP_HIP(g, hipMemcpyPeerAsync(g->bucket[(size_t)s], g->dev[(size_t)s], g->bucket[0], g->dev[0], (size_t)g->x_count * es, st[(size_t)s]));
+            GRP_HIP(g, hipMemcpyPeerAsync(g->bucket[(size_t)s], g->dev[(size_t)s], g->bucket[0], g->dev[0], (size_t)count * es, st[(size_t)s]));
             GRP_HIP(g, hipMemcpyPeerAsync(dl[(size_t)s], g->dev[(size_t)s], dl[0], g->dev[0], 8, st[(size_t)s]));
             GRP_HIP(g, hipEventRecord(g->ev[(size_t)s], st[(size_t)s])); // shard 0 must not start its next pack before the copies have read bucket 0
         }
         GRP_HIP(g, hipSetDevice(g->dev[0]));
         for (int s = 1; s < W; ++s) GRP_HIP(g, hipStreamWaitEvent(st[0], g->ev[(size_t)s], 0));
     }
+    return CMI_OK;
+}
+
+// Pre-flight of a group that is about to use RCCL: one small exchange of exactly representable values (integers: any order of the
+// additions gives the same bits) through the RCCL path AND through the in-process path, each compared with the sums computed on the
+// host and so with each other, bit for bit.  It also takes RCCL's first-call cost (channel setup) out of the first timed epoch.  RCCL
+// returning an error or a wrong sum switches the group to the in-process exchange, says so on stderr and in cmi_group_exchange_path.
+static int group_preflight(cmi_group *g) {
+    const int W = (int)g->inst.size();
+    const size_t es = g->f64 ? 8 : 4;
+    const int64_t count = (int64_t)W * std::min<int64_t>(g->x_count / W, 16384);
+    if (count <= 0) return CMI_OK;
+    std::vector<hipStream_t> st((size_t)W);
+    std::vector<double *> dl((size_t)W);
+    for (int s = 0; s < W; ++s) {
+        GRP_MEMBER(g, s, cmi_stream(g->inst[(size_t)s], (void **)&st[(size_t)s]));
+        GRP_MEMBER(g, s, cmi_loss_device_ptr(g->inst[(size_t)s], (void **)&dl[(size_t)s]));
+    }
+    auto value = [](int64_t i, int s) { return (double)((i * 7 + (int64_t)s * 13) % 97 - 48); };
+    std::vector<double> want((size_t)count, 0.0);
+    for (int s = 0; s < W; ++s)
+        for (int64_t i = 0; i < count; ++i) want[(size_t)i] += value(i, s);
+    const double want_loss = 0.5 * W * (W + 1);
+    auto run = [&](bool rccl, std::string &why) -> int { // CMI_OK + why.empty(): verified; CMI_OK + why: this path is unusable
+        std::vector<char> host((size_t)count * es);
+        for (int s = 0; s < W; ++s) {
+            for (int64_t i = 0; i < count; ++i) {
+                if (g->f64) ((double *)host.data())[i] = value(i, s);
+                else ((float *)host.data())[i] = (float)value(i, s);
+            }
+            const double l = s + 1.0;
+            GRP_HIP(g, hipSetDevice(g->dev[(size_t)s]));
+            GRP_HIP(g, hipMemcpyAsync(g->bucket[(size_t)s], host.data(), (size_t)count * es, hipMemcpyHostToDevice, st[(size_t)s]));
+            GRP_HIP(g, hipMemcpyAsync(dl[(size_t)s], &l, 8, hipMemcpyHostToDevice, st[(size_t)s]));
+            GRP_HIP(g, hipStreamSynchronize(st[(size_t)s])); // (host and l are reused)
+        }
+        const std::string keep = g->err;
+        if (exchange_buckets(g, rccl, count, st, dl) != CMI_OK) {
+            why = g->err;
+            g->err = keep;
+            (void)hipGetLastError();
+            return CMI_OK;
+        }
+        for (int s = 0; s < W; ++s) {
+            double l = 0.0;
+            GRP_HIP(g, hipSetDevice(g->dev[(size_t)s]));
+            GRP_HIP(g, hipMemcpyAsync(host.data(), g->bucket[(size_t)s], (size_t)count * es, hipMemcpyDeviceToHost, st[(size_t)s]));
+            GRP_HIP(g, hipMemcpyAsync(&l, dl[(size_t)s], 8, hipMemcpyDeviceToHost, st[(size_t)s]));
+            GRP_HIP(g, hipStreamSynchronize(st[(size_t)s]));
+            for (int64_t i = 0; i < count && why.empty(); ++i) {
+                const double got = g->f64 ? ((double *)host.data())[i] : (double)((float *)host.data())[i];
+                if (got != want[(size_t)i]) {
+                    char buf[160];
+                    snprintf(buf, sizeof buf, "wrong sum on shard %d, element %lld: %.17g instead of %.17g", s, (long long)i, got, want[(size_t)i]);
+                    why = buf;
+                }
+            }
+            if (why.empty() && l != want_loss) why = "wrong loss sum";
+        }
+        return CMI_OK;
+    };
+    std::string why_rccl, why_local;
+    if (int rc = run(true, why_rccl)) return rc;
+    if (getenv("CMI_GROUP_PREFLIGHT_FAIL")) why_rccl = "forced by CMI_GROUP_PREFLIGHT_FAIL (test hook)";
+    if (int rc = run(false, why_local)) return rc;
+    if (!why_local.empty()) GRP_FAIL(g, CMI_E_HIP, "group: the in-process exchange failed its pre-flight: %s", why_local.c_str());
+    if (why_rccl.empty()) {
+        g->path_note = "RCCL (grouped ncclReduceScatter + ncclAllGather + loss ncclAllReduce over the process's communicators); pre-flight: "
+                       "bit-identical to the in-process exchange and to the host's sums";
+    } else {
+        for (ncclComm_t c : g->comm)
+            if (c) ncclCommAbort(c);
+        g->comm.clear();
+        g->rccl = false;
+        g->path_note = "in-process exchange (peer copies) -- FALLBACK: RCCL pre-flight: " + why_rccl;
+        fprintf(stderr, "[cmi] group: %s\n", g->path_note.c_str());
+    }
+    return CMI_OK;
+}
+
+// the epoch-boundary merge of the item-side containers + the global loss; everything enqueued on the shards' streams
+static int group_exchange(cmi_group *g) {
+    const int W = (int)g->inst.size();
+    std::vector<hipStream_t> st((size_t)W);
+    std::vector<double *> dl((size_t)W);
+    for (int s = 0; s < W; ++s) {
+        GRP_MEMBER(g, s, cmi_stream(g->inst[(size_t)s], (void **)&st[(size_t)s]));
+        GRP_HIP(g, hipSetDevice(g->dev[(size_t)s]));
+        GRP_HIP(g, hipEventRecord(g->tx[(size_t)2 * s], st[(size_t)s]));
+        GRP_MEMBER(g, s, cmi_exchange_pack(g->inst[(size_t)s]));
+        GRP_MEMBER(g, s, cmi_loss_device_ptr(g->inst[(size_t)s], (void **)&dl[(size_t)s]));
+    }
+    if (int rc = exchange_buckets(g, g->rccl, g->x_count, st, dl)) return rc;
     for (int s = 0; s < W; ++s) {
         GRP_MEMBER(g, s, cmi_exchange_apply(g->inst[(size_t)s], 1.0 / W));
         GRP_HIP(g, hipSetDevice(g->dev[(size_t)s]));

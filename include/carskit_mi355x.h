@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CMI_ABI_VERSION 5 /* 5: round 6 -- CMI_E_BUSY; FM: the fixed-order (bit-reproducible) sweep is the DEFAULT, CMI_FM_FLAG_RELAXED_SUMS opts into the
+#define CMI_ABI_VERSION 5 /* 5: round 6 -- CMI_E_BUSY; cmi_group_exchange_path (RCCL pre-flight + fallback); FM: the fixed-order (bit-reproducible) sweep is the DEFAULT, CMI_FM_FLAG_RELAXED_SUMS opts into the
                              LDS-atomic form (CMI_FM_FLAG_DETERMINISTIC is still accepted and now changes nothing)
                              4: round 5 -- ADDED cmi_group_last_times, cmi_comm_last_exchange_ms (exchange vs compute time of an epoch),
                              cmi_chain_schedule_device; CMI_E_HOST; CMI_FM_FLAG_DETERMINISTIC; cmi_fm_layout's [5..6] are batches
@@ -374,6 +374,12 @@ int cmi_group_shard_info(cmi_group_handle g, int shard, int64_t info[6]);
  * epoch's launches, exchange_ms = pack .. apply on the shard's stream (the collectives or the in-process sums, including the wait for
  * the slowest shard; 0 for a group of one) */
 int cmi_group_last_times(cmi_group_handle g, float *compute_ms, float *exchange_ms);
+/* Which exchange the group runs and why, as text (valid after cmi_group_set_ratings): RCCL -- after a pre-flight that ran one small
+ * exchange of integer values through RCCL and through the in-process path and found both bit-identical to the host's sums -- or the
+ * in-process exchange (peer copies): because shards share a device, or as the FALLBACK when ncclCommInitAll or the pre-flight failed
+ * on this node (the reason is in the text and on stderr; training works either way).  No reference counterpart (CARSKit.java:395-412
+ * has threads, not devices). */
+const char *cmi_group_exchange_path(cmi_group_handle g);
 /* the shard's instance (owned by the group), e.g. for cmi_schedule_info / cmi_last_epoch_ms */
 int cmi_group_member(cmi_group_handle g, int shard, cmi_handle *out);
 /* `--early-stop MAE|RMSE` for a sharded recommender (IterativeRecommender.java:149-161: isConverged() scores the test set after every
