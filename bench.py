@@ -743,7 +743,36 @@ def main():
     log("rank %d: schedule + upload in %.1fs: %s" % (rank, setup_s, info))
 
     trainer = None
+    preflight = None
     if world > 1:
+        # pre-flight: one epoch + exchange of a small problem through the exchange this job will use and through the
+        # torch-issued form, compared across ranks and with each other, BEFORE anything is timed; if the library-issued RCCL exchange is
+        # unusable on this node every rank switches to the torch-issued one (CMI_DIST_TORCH=1) and the line says so
+        tiny = synth.generate_fast(4000, 600, n_dims, cpd, 100_000, seed=synth.DEFAULT_SEED + 555 + 1000 * rank)
+        tiny_state = synth.init_state(model, tiny, k, seed=synth.DEFAULT_SEED + 3, dtype=np.float32)
+        tiny_insts = []
+
+        def make_runner(force_torch):
+            old = os.environ.pop("CMI_DIST_TORCH", None)
+            if force_torch:
+                os.environ["CMI_DIST_TORCH"] = "1"
+            try:
+                ti = make_instance(model, k, tiny, 600, tiny_state, regs, 3.0, local_rank, args.flags)
+                tiny_insts.append(ti)
+                return cdist.ShardedEpochRunner(ti, dist, device_index=local_rank, merge=args.merge)
+            finally:
+                os.environ.pop("CMI_DIST_TORCH", None)
+                if old is not None:
+                    os.environ["CMI_DIST_TORCH"] = old
+
+        t_pf = time.perf_counter()
+        preflight = cdist.preflight_exchange(make_runner, lambda run: {n: run.engine.inst.get_state(n) for n in cdist.ITEM_SIDE[model]}, dist, lr=lr)
+        preflight["seconds"] = time.perf_counter() - t_pf
+        for ti in tiny_insts:
+            ti.close()
+        if not preflight["ok"]:
+            log("rank %d: exchange pre-flight FAILED (%s): every rank uses the torch-issued exchange" % (rank, preflight["note"]))
+            os.environ["CMI_DIST_TORCH"] = "1"
         trainer = cdist.ShardedEpochRunner(inst, dist, device_index=local_rank, merge=args.merge)
     extra = []
     if args.folds > 1:
@@ -829,7 +858,10 @@ def main():
                        "concurrent_folds": args.folds,
                        "parallelism": "1 GPU" if world == 1 else
                        "user-sharded x%d + RCCL reduce-scatter/all-gather of item-side moves (%s merge); exchange issued by: %s"
-                       % (world, args.merge, getattr(trainer.engine, "exchange_path", "torch.distributed"))},
+                       % (world, args.merge, getattr(trainer.engine, "exchange_path", "torch.distributed"))
+                       + ("" if preflight is None else
+                          ("; pre-flight (%.1f s): identical on every rank and equal to the torch-issued exchange" % preflight["seconds"] if preflight["ok"]
+                           else "; pre-flight FAILED (%s): FALLBACK to the torch-issued exchange" % preflight["note"]))},
             "roofline": roofline(model, k, n_dims, data.n, info, sched, kern_ms, es, args.workload),
         }
         out["config"]["setup_s"] = setup_s

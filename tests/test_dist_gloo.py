@@ -149,3 +149,42 @@ def test_world1_runner_is_plain_epoch():
     for n, arr in b.state.items():
         if arr is not None:
             assert np.array_equal(arr, a.orc.state[n])
+
+
+def _preflight_worker(rank, world, port, tmpdir, break_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model, k = "CAMF_CI", 6
+        data = util.small_data(n_users=60, n_items=17, n_dims=2, conds_per_dim=3, n=900, seed=31)
+        gm = float(data.r.sum() / np.count_nonzero(data.r))
+        shard, lo, hi = _shard_for(model, data, rank, world)
+
+        def make_runner(force_torch):
+            eng = OracleEngine(model, shard, k, _shard_state(model, data, k, lo, hi), gm)
+            if break_rank == rank and not force_torch:   # an exchange that completes but leaves this rank with a different item side
+                real = eng.apply
+
+                def bad_apply(scale):
+                    real(scale)
+                    eng.item["Q"][0, 0] += 1.0
+                eng.apply = bad_apply
+            return cdist.ShardedEpochRunner(eng, tdist)
+
+        res = cdist.preflight_exchange(make_runner, lambda run: {n: t.numpy() for n, t in run.engine.item.items()}, tdist, lr=util.LR)
+        # every rank reports the same verdict, whichever rank the fault was on
+        assert res["ok"] == (break_rank < 0), res
+        if break_rank == 1:
+            assert "different item-side states" in res["note"] or "another rank" in res["note"], res
+        open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
+    finally:
+        tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("break_rank", [-1, 1])
+def test_exchange_preflight_votes_across_ranks(break_rank, tmp_path):
+    """carskit_amd.dist.preflight_exchange (what bench.py --gpus N runs before its timed epochs): a sound exchange passes on every rank;
+    an exchange that leaves ONE rank with a different item-side state fails on EVERY rank, so that all of them take the same fallback."""
+    mp.spawn(_preflight_worker, args=(2, _free_port(), str(tmp_path), break_rank), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(2))
