@@ -598,6 +598,10 @@ void RankWorkspace::release() {
     Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount, &dB2, &dA2, &dS2, &dqg, &dqd, &dgu, &ddc, &dscr, &dSb, &dAb, &dcolc};
     if (sel_stream) (void)hipStreamDestroy(sel_stream);
     sel_stream = nullptr;
+    if (gemm_stream) (void)hipStreamDestroy(gemm_stream);
+    gemm_stream = nullptr;
+    if (ev_gs) (void)hipEventDestroy(ev_gs);
+    ev_gs = nullptr;
     for (std::vector<hipEvent_t> *v : {&evgemm, &evsel}) {
         for (hipEvent_t ev : *v) (void)hipEventDestroy(ev);
         v->clear();
@@ -842,6 +846,20 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     if (two) {
         need(ws.dAb, up128(bg) * a.kp1 * 4);
         need(ws.dSb, (size_t)bg * (size_t)nc * 4);
+        // experiment builds, CMI_RANK_SEL_CUS=N: the selection's stream may only use N compute units of every XCD (of 32) and the
+        // contraction runs on a stream of its own masked to the others, so that the two kernels overlap instead of taking turns
+        // (docs/history/r06.md 3 has the sweep)
+        const char *cus = cmi_exp_env("CMI_RANK_SEL_CUS");
+        if (e == hipSuccess && !ws.sel_stream && cus && atoi(cus) > 0) {
+            const int nsel = atoi(cus);
+            int n_cu = 0;
+            e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0);
+            uint32_t msel[16] = {}, mgemm[16] = {};
+            for (int c = 0; c < n_cu && c < 512; ++c) ((c / 8 < nsel) ? msel : mgemm)[c / 32] |= 1u << (c % 32); // bit c: XCD c % 8, slot c / 8
+            if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ws.sel_stream, (uint32_t)((n_cu + 31) / 32), msel);
+            if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ws.gemm_stream, (uint32_t)((n_cu + 31) / 32), mgemm);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ws.ev_gs, hipEventDisableTiming);
+        }
         if (e == hipSuccess && !ws.sel_stream) e = hipStreamCreateWithFlags(&ws.sel_stream, hipStreamNonBlocking);
     }
     need(ws.dscr, std::max<size_t>(up128(bg), up128(n_dc)) * 4);
@@ -926,21 +944,26 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
         return i < v.size() ? v[i] : nullptr;
     };
     hipStream_t sel = two ? ws.sel_stream : stream;
+    hipStream_t gs = two && ws.gemm_stream ? ws.gemm_stream : stream; // (the contraction's stream: the instance's own, except in the CU-split experiment)
+    if (gs != stream && e == hipSuccess) {
+        e = hipEventRecord(ws.ev_gs, stream); // behind the operands and the S2 contraction
+        if (e == hipSuccess) e = hipStreamWaitEvent(gs, ws.ev_gs, 0);
+    }
     for (size_t b = 0; b + 1 < cuts.size() && e == hipSuccess; ++b) {
         const int64_t g0 = cuts[b];
         const int n = (int)(cuts[b + 1] - g0);
         const int64_t q0 = gq0[(size_t)g0], q1 = gq0[(size_t)(g0 + n)];
         float *dAx = (float *)((two && (b & 1)) ? ws.dAb.p : ws.dA.p), *dSx = (float *)((two && (b & 1)) ? ws.dSb.p : ws.dS.p);
         // the slab of this parity is free once the selection of batch b - 2 has read it
-        if (two && b >= 2 && e == hipSuccess) e = hipStreamWaitEvent(stream, ev_at(ws.evsel, b - 2), 0);
+        if (two && b >= 2 && e == hipSuccess) e = hipStreamWaitEvent(gs, ev_at(ws.evsel, b - 2), 0);
         // (the builder leaves its per-row constant -- zero here -- in the scratch the contraction then reads as its row constant)
-        if (e == hipSuccess) e = rank_launch_split_users(a, (const int32_t *)ws.dgu.p + g0, n, dAx, (float *)ws.dscr.p, stream);
-        if (e == hipSuccess) e = ws.kernel_event(4 * b, stream);
-        if (e == hipSuccess) e = rank_launch_gemm<float>(dAx, a.B1, (const float *)ws.dscr.p, dSx, n, nc, a.kp1, stream, a.colc);
-        if (e == hipSuccess) e = ws.kernel_event(4 * b + 1, stream);
+        if (e == hipSuccess) e = rank_launch_split_users(a, (const int32_t *)ws.dgu.p + g0, n, dAx, (float *)ws.dscr.p, gs);
+        if (e == hipSuccess) e = ws.kernel_event(4 * b, gs);
+        if (e == hipSuccess) e = rank_launch_gemm<float>(dAx, a.B1, (const float *)ws.dscr.p, dSx, n, nc, a.kp1, gs, a.colc);
+        if (e == hipSuccess) e = ws.kernel_event(4 * b + 1, gs);
         if (two && e == hipSuccess) {
             hipEvent_t g = ev_at(ws.evgemm, b);
-            if (e == hipSuccess) e = hipEventRecord(g, stream);
+            if (e == hipSuccess) e = hipEventRecord(g, gs);
             if (e == hipSuccess) e = hipStreamWaitEvent(sel, g, 0);
         }
         if (e == hipSuccess) e = ws.kernel_event(4 * b + 2, sel);

@@ -54,6 +54,8 @@ struct RankWorkspace {
     Buf dcolc;                                                                  // split form: itemBias of the candidates (the S1 contraction adds it at the end)
     Buf dSb, dAb;                                                               // split form: the second slab / operand buffer (batch b + 1 is contracted while batch b is selected)
     hipStream_t sel_stream = nullptr;                                           // split form: the selection's stream
+    hipStream_t gemm_stream = nullptr;                                          // experiment builds (CMI_RANK_SEL_CUS): the contraction on the compute units the selection's masked stream leaves
+    hipEvent_t ev_gs = nullptr;
     std::vector<hipEvent_t> evgemm, evsel;                                           // per batch: contraction done (main stream), selection done (selection stream)
     Buf h_top, h_score, h_count;                                                // pinned host: the lists as they come back
     RankPlan plan;                                                              // the last evaluation's plan (capacity is reused)
