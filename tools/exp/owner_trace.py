@@ -17,7 +17,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.join(HERE, "..", "..")
 sys.path.insert(0, ROOT)
 os.environ.setdefault("CMI_LIB_PATH", os.path.join(ROOT, "carskit_amd", "lib", "libcarskit_trace.so"))
-os.environ["CMI_SHARE_DEBUG_TEAMS"] = "1"
 import numpy as np
 from carskit_amd import capi, synth
 from tests import util

@@ -1,8 +1,9 @@
-"""GPU box, library built with `make EXP=1` (CMI_SHARE_DEBUG_TEAMS is an experiment knob: it lets sharing instances keep the team form):
+"""GPU box:
 python tools/exp/share_debug.py -- owner epochs of three instances in flight together (cmi_set_device_share(3)): which forms stay exact?
 Prints the largest deviation from the fp64 oracle per instance for combinations of team / one-wavefront instances.  Round 5: the
 one-wavefront form is exact in every combination; an instance with teams is ~2e-7 off in most runs when another owner epoch runs beside it
-(from its second epoch on, every row), exact alone, after another, and beside level / chain kernels."""
+(from its second epoch on, every row), exact alone, after another, and beside level / chain kernels.  Round 6: cause found and fixed
+(a store-data hazard in the record stores, docs/history/r06.md 1): every combination is exact."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
@@ -13,7 +14,6 @@ from tests.test_gpu_parity import make_pair
 OWNER, F64 = capi.FLAG_SCHED_OWNER, capi.FLAG_STATE_F64
 def err(orc, inst):
     return max(float(np.max(np.abs(orc.state[n].reshape(a.shape) - a))) for n, a in inst.get_states().items())
-os.environ["CMI_SHARE_DEBUG_TEAMS"] = "1"
 for teams in (("all", "0", "0"), (None, "0", "0"), (None, None, "0"), ("0", "0", "0"), (None, None, None)):
     pairs = []
     for seed, team in zip((1, 2, 3), teams):

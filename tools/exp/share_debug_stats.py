@@ -1,6 +1,7 @@
-"""GPU box, `make EXP=1` library: python tools/exp/share_debug_stats.py [k] -- how often is an instance WITH teams, trained beside two
-other owner epochs (cmi_set_device_share(3)), not bit-identical to the one-wavefront form?  12 runs each in fp32 and fp64.
-Round 5: k = 64: fp32 0 / 12, fp64 12 / 12; k = 128: 0 / 12 and 0 / 12."""
+"""GPU box: python tools/exp/share_debug_stats.py [k] [team] -- how often is an instance WITH teams, trained beside two other owner
+epochs (cmi_set_device_share(3)), not bit-identical to the one-wavefront form?  STATS_REPS (12) runs each in fp32 and fp64.
+Round 5: k = 64: fp32 0 / 12, fp64 12 / 12; k = 128: 0 / 12 and 0 / 12 -- cause unknown.  Round 6: a store-data hazard in the record
+stores (docs/history/r06.md 1): 23 / 24 on a library built without the wait states, 0 / 24 on the shipped one, every k and dtype."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
@@ -8,7 +9,6 @@ from concurrent.futures import ThreadPoolExecutor
 from carskit_amd import capi, synth
 from tests import util
 OWNER, F64 = capi.FLAG_SCHED_OWNER, capi.FLAG_STATE_F64
-os.environ["CMI_SHARE_DEBUG_TEAMS"] = "1"
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 TEAM = None if len(sys.argv) < 3 or sys.argv[2] == "default" else sys.argv[2]   # CMI_OWNER_TEAM of the instance under test
 # optional (experiment builds): STATS_CUS_TEST / STATS_CUS_NEIGH = CMI_STREAM_CUS of the instance under test / of its neighbours (compute
@@ -46,4 +46,4 @@ for flags in [f for f, n in ((0, "f32"), (F64, "f64")) if n in DTYPES]:
         e = max(float(np.max(np.abs(a[n].astype(np.float64) - b[n].astype(np.float64)))) for n in a)
         bad += e > 0
         for c in conc: c.close()
-    print("k", K, "f64" if flags else "f32", "inexact runs", bad, "of", REPS, "(teams in the instance under test: %s -- 0 means the library was not built with EXP=1 and the run says nothing)" % teams)
+    print("k", K, "f64" if flags else "f32", "inexact runs", bad, "of", REPS, "(teams in the instance under test: %s)" % teams)
