@@ -860,6 +860,13 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
             if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ws.gemm_stream, (uint32_t)((n_cu + 31) / 32), mgemm);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ws.ev_gs, hipEventDisableTiming);
         }
+        // experiment builds, CMI_RANK_SEL_PRIO=high|low: the selection's stream at the device's highest / lowest stream priority (the
+        // instance's own stream, which carries the contraction, has the default one)
+        if (const char *pr = cmi_exp_env("CMI_RANK_SEL_PRIO")) {
+            int least = 0, greatest = 0;
+            if (e == hipSuccess && !ws.sel_stream) e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (e == hipSuccess && !ws.sel_stream) e = hipStreamCreateWithPriority(&ws.sel_stream, hipStreamNonBlocking, !strcmp(pr, "high") ? greatest : least);
+        }
         if (e == hipSuccess && !ws.sel_stream) e = hipStreamCreateWithFlags(&ws.sel_stream, hipStreamNonBlocking);
     }
     need(ws.dscr, std::max<size_t>(up128(bg), up128(n_dc)) * 4);

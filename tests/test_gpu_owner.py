@@ -356,3 +356,40 @@ def test_owner_epochs_of_two_processes_on_one_gpu_take_turns_and_stay_exact():
         assert p.returncode == 0, errs[-2000:]
         line = [ln for ln in out.splitlines() if ln.startswith("RESULT")][-1].split()
         assert float(line[1]) <= 1e-10 and float(line[2]) <= 1e-11, line
+
+
+def test_owner_epoch_is_refused_when_the_lock_file_cannot_be_opened():
+    """The cross-process owner-epoch lock: a lock file that cannot be opened used to mean "launch unprotected"; since
+    round 6 the epoch is refused with CMI_E_BUSY (model untouched) unless CMI_OWNER_NO_LOCK=1 declares the process the GPU's only user.
+    Run in child processes: the gate caches the lock file's descriptor per process."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        from carskit_amd import capi, synth
+        from tests import util
+        d = synth.generate(1500, 200, 3, 4, 30000, seed=7, item_zipf=1.2)
+        st = synth.init_state("CAMF_CI", d, 16, seed=5, dtype=np.float32)
+        inst = capi.Instance("CAMF_CI", 16, d.n_users, d.n_items, d.n_conds, flags=capi.FLAG_SCHED_OWNER)
+        inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+        inst.set_ratings(d.u, d.j, d.ctx, d.r, d.ctx_ptr, d.ctx_conds)
+        inst.set_states(st)
+        try:
+            loss = inst.train_epoch(util.LR)
+            print("RESULT ok", np.isfinite(loss))
+        except capi.CmiError as e:
+            same = all(np.array_equal(a, st[n].reshape(a.shape)) for n, a in inst.get_states(np.float32).items())
+            print("RESULT error", e.code, "untouched" if same else "CHANGED", "|", e)
+    """ % root)
+    def run(**env):
+        p = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, cwd=root, timeout=600,
+                           env=dict(os.environ, TMPDIR="/proc/definitely/not/a/directory", **env))
+        assert p.returncode == 0, p.stderr[-2000:]
+        return [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1]
+    refused = run()
+    assert refused.startswith("RESULT error %d untouched" % capi.E_BUSY) and "cannot be opened" in refused, refused
+    assert run(CMI_OWNER_NO_LOCK="1") == "RESULT ok True"
