@@ -89,7 +89,8 @@ struct OwnerDeviceLock {
                     if (*c == ':' || *c == '/' || *c == '.') *c = '_';
                 // a per-uid directory (0700) under $TMPDIR, so the lock file is neither world-writable nor at a path another user can
                 // plant a symlink on; O_NOFOLLOW refuses a planted link anyway, O_CLOEXEC keeps the descriptor out of forked children
-                const char *tmp = getenv("TMPDIR");
+                const char *tmp = getenv("CMI_OWNER_LOCK_DIR"); // (where the lock files live, if not under $TMPDIR: every process that shares the GPU must agree)
+                if (!tmp || !*tmp) tmp = getenv("TMPDIR");
                 char dir[200], path[300];
                 snprintf(dir, sizeof dir, "%s/cmi_locks_%u", tmp && *tmp ? tmp : "/tmp", (unsigned)getuid());
                 (void)mkdir(dir, 0700);
@@ -118,8 +119,8 @@ struct OwnerDeviceLock {
             if (!got) {
                 ok = false;
                 why = opened ? "another process has held the owner-epoch lock of the device for 60 s"
-                             : "the owner-epoch lock file under $TMPDIR/cmi_locks_<uid>/ cannot be opened (set CMI_OWNER_NO_LOCK=1 if this process is "
-                               "the only user of the GPU)";
+                             : "the owner-epoch lock file under $CMI_OWNER_LOCK_DIR or $TMPDIR (/cmi_locks_<uid>/) cannot be opened (set CMI_OWNER_NO_LOCK=1 if this "
+                               "process is the only user of the GPU)";
                 g.cv.notify_all();
                 return; // (nothing taken: in_use / holders unchanged)
             }

@@ -29,15 +29,16 @@
 //     gathers/s on this part = 119 us for 25 M, whatever the slice size; the TCP sends one request for the lanes of an instruction
 //     that fall into one line: two lanes per line 57 us, four 36 us).  Round 5 (the CELL stream, fm_kernels.hpp): the user and the
 //     item field evaluate their records in GATHERED-ID order inside groups of ~4 900 coordinates (3 lanes per line at BASELINE C4's
-//     share) and add a record's products to its coordinate's sums, which live in the workgroup for the whole group: in LDS, added with
-//     workgroup-scope fp64 atomics (fm_cell_atomic_kernel, the default: 118-121 us per launch, 16.4 ms per sweep), or -- the
-//     DETERMINISTIC form, CMI_FM_FLAG_DETERMINISTIC -- parked in LDS at the record's position in coordinate order and added left to
-//     right into register accumulators (fm_cell_kernel: 135 us, 18.2 ms).  12-byte records, no per-piece partial sums through memory,
-//     the coordinate update in the same launch (or one small kernel where a coordinate's sums come from several workgroups).
+//     share) and add a record's products to its coordinate's sums, which live in the workgroup for the whole group: parked in LDS at
+//     the record's position in coordinate order and added left to right into register accumulators (fm_cell_kernel, the DEFAULT since
+//     round 6: a fixed order, bit-reproducible like the reference's sweep; 135 us per launch, 18.2-18.6 ms per sweep), or -- the opt-in
+//     CMI_FM_FLAG_RELAXED_SUMS -- in LDS, added with workgroup-scope fp64 atomics as the records are evaluated (fm_cell_atomic_kernel:
+//     116-119 us, 15.8-16.3 ms; the order of a slot's additions varies run to run).  12-byte records, no per-piece partial sums through
+//     memory, the coordinate update in the same launch (or one small kernel where a coordinate's sums come from several workgroups).
 //   * the context field (a few records in a thousand): 16-byte records sorted by feature, one wave per feature, reduce + update in one
 //     launch (fm_ctx_kernel).
-// The deterministic form adds every sum in a fixed order that depends on the data layout alone; the default form's LDS atomics add a
-// slot's records in whatever order its waves arrive (equal to rounding).  fp64 throughout; gather / stream work: no MFMA.
+// The default form adds every sum in a fixed order that depends on the data layout alone; the relaxed form's LDS atomics add a slot's
+// records in whatever order its waves arrive (equal to rounding).  fp64 throughout; gather / stream work: no MFMA.
 //
 // reduce (-> [num | den] per coordinate) and apply are separable, so a multi-GPU host can all-reduce (num, den) between them; the
 // fused sweep runs the identical arithmetic.
@@ -321,11 +322,11 @@ __global__ __launch_bounds__(FMC_THREADS) void fm_cell_kernel(FmArgs a, int f) {
     }
 }
 
-// ---- the default form (a.atomic): the same cell stream without parking -- every wave walks its own slice of each batch (records
+// ---- the relaxed form (a.atomic, CMI_FM_FLAG_RELAXED_SUMS; the default until round 6): the same cell stream without parking -- every wave walks its own slice of each batch (records
 // requested one batch ahead) and adds the three products of a record straight into LDS accumulators with ds_add_f64 (the packed word's
 // 14-bit field holds the record's SLOT).  No barriers between batches, no second pass over LDS, no slot boundaries to stream: the
 // waves run independently, so stream, gathers, VALU and LDS overlap by themselves.  The order of the additions is not fixed: sums vary
-// in their last bits run to run (CMI_FM_FLAG_DETERMINISTIC selects fm_cell_kernel above).  118-121 us per launch against 135.
+// in their last bits run to run (which is why fm_cell_kernel above is the default).  116-119 us per launch against 135.
 template <int FIELD, bool W0, bool FUSED>
 __global__ __launch_bounds__(FMC_THREADS) void fm_cell_atomic_kernel(FmArgs a, int f) {
     __shared__ double acc[3][FMC_SLOTS];

@@ -89,7 +89,7 @@ struct FmArgs {
     const int32_t *src[3]; // stream position -> rating, per field (init only)
     int64_t n, global_size;
     int32_t k, n_users, n_items, n_conds;
-    int32_t atomic; // 1 (default): the packed words hold SLOTS and fm_cell_atomic_kernel runs; 0: positions, fm_cell_kernel (deterministic)
+    int32_t atomic; // 0 (default): the packed words hold POSITIONS and fm_cell_kernel runs (fixed order); 1 (CMI_FM_FLAG_RELAXED_SUMS): slots, fm_cell_atomic_kernel
     int32_t xcol; // the column of V an UPDATE leaves in tab[].x of the coordinates it updates (-1: .x stays): see fm_update
     double xc; // 1 / numContextDims
     double regLw, regLf;

@@ -387,7 +387,7 @@ def test_owner_epoch_is_refused_when_the_lock_file_cannot_be_opened():
     """ % root)
     def run(**env):
         p = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, cwd=root, timeout=600,
-                           env=dict(os.environ, TMPDIR="/proc/definitely/not/a/directory", **env))
+                           env=dict(os.environ, CMI_OWNER_LOCK_DIR="/proc/definitely/not/a/directory", **env))
         assert p.returncode == 0, p.stderr[-2000:]
         return [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1]
     refused = run()
