@@ -860,8 +860,11 @@ def main():
                        "user-sharded x%d + RCCL reduce-scatter/all-gather of item-side moves (%s merge); exchange issued by: %s"
                        % (world, args.merge, getattr(trainer.engine, "exchange_path", "torch.distributed"))
                        + ("" if preflight is None else
-                          ("; pre-flight (%.1f s): identical on every rank and equal to the torch-issued exchange" % preflight["seconds"] if preflight["ok"]
-                           else "; pre-flight FAILED (%s): FALLBACK to the torch-issued exchange" % preflight["note"]))},
+                          ("; pre-flight FAILED (%s): FALLBACK to the torch-issued exchange" % preflight["note"] if not preflight["ok"] else
+                           "; pre-flight (%.1f s): identical on every rank and equal to the torch-issued exchange" % preflight["seconds"]
+                           if preflight["verified"] else
+                           "; pre-flight (%.1f s): identical on every rank; NOT verified against the torch-issued exchange (%s)"
+                           % (preflight["seconds"], preflight["note"])))},
             "roofline": roofline(model, k, n_dims, data.n, info, sched, kern_ms, es, args.workload),
         }
         out["config"]["setup_s"] = setup_s

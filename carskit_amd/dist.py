@@ -232,19 +232,29 @@ class ShardedEpochRunner:
 def preflight_exchange(make_runner, item_state, dist, group=None, lr=0.02, epochs=1):
     """Before a timed multi-rank run (bench.py --gpus N under torch.distributed.run): the first collective the job ever issues must not be
     a timed one, and a broken exchange must be noticed before it is measured.  `make_runner(force_torch)` builds a ShardedEpochRunner over
-    a SMALL problem from a fixed state -- force_torch False: the exchange the job would use (under the `nccl` backend the library's own
-    RCCL communicator, cmi_comm_*); True: the same exchange issued through torch.distributed on the bucket tensor -- and
+    a SMALL problem from a fixed state -- force_torch False: the PRIMARY exchange, the one the job would use (under the `nccl` backend the
+    library's own RCCL communicator, cmi_comm_*); True: the same exchange issued through torch.distributed on the bucket tensor -- and
     `item_state(runner)` returns {name: numpy array} of the replicated item-side containers.  One epoch + exchange through each, then:
       * every rank holds the SAME item-side state after the primary exchange (digests all-gathered): what a sum / all-gather guarantees;
       * primary == torch-issued: bit for bit at world 2 (a + b commutes, the mean scales both alike), to 1e-5 relative beyond (the
         association of W > 2 floating-point additions is the collective's own).
-    Any exception or mismatch on ANY rank makes ALL ranks report the primary path unusable (a vote: one all-reduce), and the caller runs
-    the torch-issued form (CMI_DIST_TORCH=1) and says so in its output.  A hang inside a collective cannot be caught here: RCCL's own
-    watchdog / timeout ends such a job.  Returns {"ok": bool, "note": str, "loss": float}."""
+    Verdicts are the same on every rank (votes: one all-reduce each).  Returns {"ok", "verified", "note", "loss"}:
+      ok False        the primary exchange raised somewhere, or left the ranks with different states: the caller runs the torch-issued
+                      form instead (CMI_DIST_TORCH=1) and says so;
+      ok True, verified False   the primary exchange is consistent across ranks but the torch-issued comparison could not be made or
+                      disagreed with it: the caller keeps the primary exchange and prints the note;
+      ok True, verified True    both agree.
+    A hang inside a collective cannot be caught here: RCCL's own watchdog / timeout ends such a job."""
     import hashlib
     import torch
     world = dist.get_world_size(group)
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+    def vote(good):
+        t = torch.tensor([1.0 if good else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return float(t.item()) == 1.0
+
     note, primary, loss = "", None, float("nan")
     try:
         run = make_runner(False)
@@ -253,36 +263,31 @@ def preflight_exchange(make_runner, item_state, dist, group=None, lr=0.02, epoch
         primary = {n: np.array(a, copy=True) for n, a in item_state(run).items()}
     except Exception as e:   # noqa: BLE001 -- whatever the exchange raised on this rank
         note = "primary exchange raised %r" % (e,)
-    ok = torch.tensor([0.0 if note else 1.0], device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-    if float(ok.item()) == 0.0:
-        return {"ok": False, "note": note or "the primary exchange failed on another rank", "loss": loss}
+    if not vote(not note):
+        return {"ok": False, "verified": False, "note": note or "the primary exchange failed on another rank", "loss": loss}
     digest = int.from_bytes(hashlib.sha256(b"".join(np.ascontiguousarray(primary[n]).tobytes() for n in sorted(primary))).digest()[:7], "little")
     mine = torch.tensor([digest], dtype=torch.int64, device=dev)
     every = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(every, mine, group=group)
-    if len({int(t.item()) for t in every}) != 1:
-        note = "ranks hold different item-side states after the exchange"
-    else:
-        try:
-            run_t = make_runner(True)
-            for _ in range(epochs):
-                loss_t = run_t.epoch(lr)
-            other = item_state(run_t)
-            for n in sorted(primary):
-                a, b = primary[n], np.asarray(other[n])
-                same = np.array_equal(a, b) if world <= 2 else np.allclose(a, b, rtol=1e-5, atol=1e-7)
-                if not same:
-                    note = "container %s differs from the torch-issued exchange (largest deviation %.3e)" % (n, float(np.max(np.abs(a - b))))
-                    break
-            if not note and not (loss == loss_t if world <= 2 else abs(loss - loss_t) <= 1e-9 * abs(loss_t)):
-                note = "global loss %r differs from the torch-issued exchange's %r" % (loss, loss_t)
-        except Exception as e:   # noqa: BLE001
-            note = "torch-issued comparison run raised %r" % (e,)
-    ok = torch.tensor([0.0 if note else 1.0], device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-    good = float(ok.item()) == 1.0
-    return {"ok": good, "note": note or ("" if good else "the comparison failed on another rank"), "loss": loss}
+    if len({int(t.item()) for t in every}) != 1:     # (the same list on every rank: no vote needed)
+        return {"ok": False, "verified": False, "note": "ranks hold different item-side states after the primary exchange", "loss": loss}
+    try:
+        run_t = make_runner(True)
+        for _ in range(epochs):
+            loss_t = run_t.epoch(lr)
+        other = item_state(run_t)
+        for n in sorted(primary):
+            a, b = primary[n], np.asarray(other[n])
+            same = np.array_equal(a, b) if world <= 2 else np.allclose(a, b, rtol=1e-5, atol=1e-7)
+            if not same:
+                note = "MISMATCH: container %s differs from the torch-issued exchange (largest deviation %.3e)" % (n, float(np.max(np.abs(a - b))))
+                break
+        if not note and not (loss == loss_t if world <= 2 else abs(loss - loss_t) <= 1e-9 * abs(loss_t)):
+            note = "MISMATCH: global loss %r differs from the torch-issued exchange's %r" % (loss, loss_t)
+    except Exception as e:   # noqa: BLE001
+        note = "torch-issued comparison run raised %r" % (e,)
+    verified = vote(not note)
+    return {"ok": True, "verified": verified, "note": note or ("" if verified else "the comparison failed on another rank"), "loss": loss}
 
 
 def shard_by_user(data, rank, world):
