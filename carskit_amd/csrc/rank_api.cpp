@@ -595,7 +595,7 @@ hipError_t RankWorkspace::need(Buf &b, size_t bytes, bool pinned) {
 }
 
 void RankWorkspace::release() {
-    Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount, &dB2, &dA2, &dS2, &dqg, &dqd, &dgu, &ddc, &dscr, &dSb, &dAb, &dcolc};
+    Buf *dev[] = {&dA, &dB, &dS, &drc, &dcand, &dqu, &dqc, &dexptr, &dexcl, &dtop, &dscore, &dcount, &dB2, &dA2, &dS2, &dqg, &dqd, &dgu, &ddc, &dscr, &dSb, &dAb, &dcolc, &dM1, &dM1b, &dM2};
     if (sel_stream) (void)hipStreamDestroy(sel_stream);
     sel_stream = nullptr;
     if (gemm_stream) (void)hipStreamDestroy(gemm_stream);
@@ -841,11 +841,17 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     // batch on the slab / operand buffer of its parity.  CMI_RANK_ONE_STREAM=1: the round-4 form, one stream, one slab (A/B)
     const bool one_stream = getenv("CMI_RANK_ONE_STREAM") != nullptr; // (read per call: bench.py times the two kernels on their own with it)
     const bool two = !one_stream && ng > bg;
+    // tile pruning (rank_topn_split_pruned): the contractions also write the rows' maxima over tiles of 64 candidates (0.8 % of the slab);
+    // CMI_RANK_NO_PRUNE=1: the plain selection (tests compare the two forms entry for entry)
+    const bool prune = getenv("CMI_RANK_NO_PRUNE") == nullptr;
+    const size_t nt64 = (size_t)(nc + 63) / 64;
     need(ws.dA, up128(bg) * a.kp1 * 4);
     need(ws.dS, (size_t)bg * (size_t)nc * 4);
+    if (prune) need(ws.dM1, (size_t)bg * nt64 * 4);
     if (two) {
         need(ws.dAb, up128(bg) * a.kp1 * 4);
         need(ws.dSb, (size_t)bg * (size_t)nc * 4);
+        if (prune) need(ws.dM1b, (size_t)bg * nt64 * 4);
         // experiment builds, CMI_RANK_SEL_CUS=N: the selection's stream may only use N compute units of every XCD (of 32) and the
         // contraction runs on a stream of its own masked to the others, so that the two kernels overlap instead of taking turns
         // (docs/history/r06.md 3 has the sweep)
@@ -875,6 +881,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
         need(ws.dB2, up128(nc) * a.kp2 * 4);
         need(ws.dA2, up128(n_dc) * a.kp2 * 4);
         need(ws.dS2, (size_t)n_dc * (size_t)nc * 4);
+        if (prune) need(ws.dM2, (size_t)n_dc * nt64 * 4);
         need(ws.ddc, (size_t)n_dc * 4);
         need(ws.dqd, (size_t)nq * 4);
     }
@@ -936,7 +943,8 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     if (e == hipSuccess) e = rank_launch_split_operands(a, stream);
     if (e == hipSuccess) e = hipEventRecord(ws.ev0, stream);
     // S2: once per evaluation (row constant = the zeroed scratch)
-    if (e == hipSuccess && s2) e = rank_launch_gemm<float>(a.A2, a.B2, (const float *)ws.dscr.p, (float *)ws.dS2.p, n_dc, nc, a.kp2, stream);
+    if (e == hipSuccess && s2)
+        e = rank_launch_gemm<float>(a.A2, a.B2, (const float *)ws.dscr.p, (float *)ws.dS2.p, n_dc, nc, a.kp2, stream, nullptr, prune ? (float *)ws.dM2.p : nullptr);
     lap("memsets + operand launches");
     ws.host_ms[1] = ms_since(t_setup);
     const auto t_loop = std::chrono::steady_clock::now();
@@ -951,6 +959,8 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
         return i < v.size() ? v[i] : nullptr;
     };
     hipStream_t sel = two ? ws.sel_stream : stream;
+    // (the contraction of batch b + 1 made to wait for the selection of batch b -- the kernels never side by side, only the lists' copies
+    // overlapped -- measured the same 6.3 ms as the overlapped form: docs/history/r06.md 3)
     hipStream_t gs = two && ws.gemm_stream ? ws.gemm_stream : stream; // (the contraction's stream: the instance's own, except in the CU-split experiment)
     if (gs != stream && e == hipSuccess) {
         e = hipEventRecord(ws.ev_gs, stream); // behind the operands and the S2 contraction
@@ -961,12 +971,13 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
         const int n = (int)(cuts[b + 1] - g0);
         const int64_t q0 = gq0[(size_t)g0], q1 = gq0[(size_t)(g0 + n)];
         float *dAx = (float *)((two && (b & 1)) ? ws.dAb.p : ws.dA.p), *dSx = (float *)((two && (b & 1)) ? ws.dSb.p : ws.dS.p);
+        float *dMx = prune ? (float *)((two && (b & 1)) ? ws.dM1b.p : ws.dM1.p) : nullptr;
         // the slab of this parity is free once the selection of batch b - 2 has read it
         if (two && b >= 2 && e == hipSuccess) e = hipStreamWaitEvent(gs, ev_at(ws.evsel, b - 2), 0);
         // (the builder leaves its per-row constant -- zero here -- in the scratch the contraction then reads as its row constant)
         if (e == hipSuccess) e = rank_launch_split_users(a, (const int32_t *)ws.dgu.p + g0, n, dAx, (float *)ws.dscr.p, gs);
         if (e == hipSuccess) e = ws.kernel_event(4 * b, gs);
-        if (e == hipSuccess) e = rank_launch_gemm<float>(dAx, a.B1, (const float *)ws.dscr.p, dSx, n, nc, a.kp1, gs, a.colc);
+        if (e == hipSuccess) e = rank_launch_gemm<float>(dAx, a.B1, (const float *)ws.dscr.p, dSx, n, nc, a.kp1, gs, a.colc, dMx);
         if (e == hipSuccess) e = ws.kernel_event(4 * b + 1, gs);
         if (two && e == hipSuccess) {
             hipEvent_t g = ev_at(ws.evgemm, b);
@@ -977,7 +988,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
         if (e == hipSuccess)
             e = rank_launch_split_select(dSx, s2 ? (const float *)ws.dS2.p : nullptr, a, (const int32_t *)ws.dqg.p,
                                          (const int32_t *)ws.dqd.p, (int)g0, (int)q0, (int)(q1 - q0), (const int64_t *)ws.dexptr.p,
-                                         (const int32_t *)ws.dexcl.p, thold, topn, dtop, dscore, dcount, sel);
+                                         (const int32_t *)ws.dexcl.p, thold, topn, dtop, dscore, dcount, sel, dMx, prune && s2 ? (const float *)ws.dM2.p : nullptr);
         if (e == hipSuccess) e = ws.kernel_event(4 * b + 3, sel);
         if (two && e == hipSuccess) {
             hipEvent_t sd = ev_at(ws.evsel, b);

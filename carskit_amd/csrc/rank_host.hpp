@@ -53,6 +53,7 @@ struct RankWorkspace {
     Buf dB2, dA2, dS2, dqg, dqd, dgu, ddc, dscr;                                // device, split form (rank_run_device_split)
     Buf dcolc;                                                                  // split form: itemBias of the candidates (the S1 contraction adds it at the end)
     Buf dSb, dAb;                                                               // split form: the second slab / operand buffer (batch b + 1 is contracted while batch b is selected)
+    Buf dM1, dM1b, dM2;                                                         // split form: per-row maxima of S1 (per slab) / S2 over tiles of 64 candidates (the selection's tile pruning)
     hipStream_t sel_stream = nullptr;                                           // split form: the selection's stream
     hipStream_t gemm_stream = nullptr;                                          // experiment builds (CMI_RANK_SEL_CUS): the contraction on the compute units the selection's masked stream leaves
     hipEvent_t ev_gs = nullptr;

@@ -183,9 +183,44 @@ constexpr int RG_TPR = RG_BK / 4, RG_RPP = 256 / RG_TPR, RG_NP = RG_BM / RG_RPP;
 #ifndef CMI_RG_WAVES
 #define CMI_RG_WAVES 4 // min waves per SIMD: 114 VGPRs instead of 140, four blocks per CU instead of three (23.70 -> 23.19 ms on the 270 K x 20 K case)
 #endif
+// tile_max (may be null): tile_max[q * nt64 + t] = the largest score the launch stored in row q among candidates [64 t, 64 t + 64)
+// (NaN scores ignored).  A wave's 64 x 64 patch IS one such tile: the maximum costs a few DPP row operations per accumulator row.
+// The selection uses it to skip tiles that cannot hold a candidate above a query's current N-th best (rank_topn_split_pruned).
+// Four independent maxima over lanes 0-31 (left in lanes 16-31) and lanes 32-63 (in lanes 48-63) at once: v_max_f32 with the DPP
+// operand on the instruction itself (row_ror 8 / 4 / 2 / 1: every lane of a 16-lane row holds the row's maximum; row_bcast:15 into
+// rows 1 and 3 adds the previous row's).  Written as one asm block because the compiler's fmaxf costs three instructions per step
+// (it quiets both operands first; the kernel runs in IEEE mode, where v_max_f32 already returns the non-NaN operand) -- 800
+// instructions per tile instead of 200.  The four chains are interleaved, so a result is read by its next DPP step three
+// instructions later (VALU write -> DPP read needs two wait states); s_nop 1 covers the values coming in.
+__device__ __forceinline__ void rg_max32x4(float &a, float &b, float &c, float &d) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %3, %3, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
 __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const float *__restrict__ A, const float *__restrict__ B,
                                                           const float *__restrict__ row_const, float *__restrict__ S,
-                                                          int nq, int nc, int kp_pad, int tiles_c, int n_tiles, const float *__restrict__ col_const) {
+                                                          int nq, int nc, int kp_pad, int tiles_c, int n_tiles, const float *__restrict__ col_const,
+                                                          float *__restrict__ tile_max, int nt64) {
     __shared__ float sA[2][RG_BK][RG_LDS];
     __shared__ float sB[2][RG_BK][RG_LDS];
     // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give XCD x the x-th contiguous
@@ -270,19 +305,56 @@ __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const fl
 #pragma unroll
         for (int j = 0; j < 2; ++j) cc[j] = col_const[min(c0 + wc + 32 * j + mrow, nc - 1)];
     }
+    float rowmax = -INFINITY; // lane l: the maximum of patch row l over the wave's 64 candidates (collected below, stored once)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = q0 + wq + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * mk;
-            if (q >= nq) continue;
-            const float rc = row_const[q];
+        for (int r4 = 0; r4 < 16; r4 += 4) {
+            float m[4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = c0 + wc + 32 * j + mrow;
-                if (c < nc) S[(size_t)q * nc + c] = (col_const ? acc[i][j][r] + cc[j] : acc[i][j][r]) + rc;
+            for (int d = 0; d < 4; ++d) {
+                const int r = r4 + d;
+                const int q = q0 + wq + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * mk;
+                const float rc = q < nq ? row_const[q] : 0.f;
+                m[d] = -INFINITY; // (no `continue` for rows past the end: the cross-lane maximum below needs every lane)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = c0 + wc + 32 * j + mrow;
+                    const float val = (col_const ? acc[i][j][r] + cc[j] : acc[i][j][r]) + rc;
+                    if (q < nq && c < nc) {
+                        S[(size_t)q * nc + c] = val;
+                        m[d] = val > m[d] ? val : m[d]; // (a NaN score is never taken: it cannot enter a list either)
+                    }
+                }
+            }
+            if (tile_max) { // wave-uniform
+                rg_max32x4(m[0], m[1], m[2], m[3]);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int r = r4 + d, row = 32 * i + (r & 3) + 8 * (r >> 2); // patch row of the lanes with mk = 0; mk = 1: + 4
+                    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m[d]), 31));
+                    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m[d]), 63));
+                    rowmax = lane == row ? lo : (lane == row + 4 ? hi : rowmax);
+                }
             }
         }
+    if (tile_max && q0 + wq + lane < nq && c0 + wc < nc) tile_max[(size_t)(q0 + wq + lane) * nt64 + ((c0 + wc) >> 6)] = rowmax;
+}
+
+// tile maxima of a finished score slab (only where the MFMA contraction did not produce them: the VALU fallback): a wave per (row, tile)
+template <typename T>
+__global__ __launch_bounds__(256) void rank_tile_max(const T *__restrict__ S, int nq, int nc, int nt64, T *__restrict__ tile_max) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (int64_t)nq * nt64) return;
+    const int q = (int)(w / nt64), t = (int)(w % nt64), c = t * 64 + (int)(threadIdx.x & 63);
+    T m = c < nc ? S[(size_t)q * nc + c] : (T)-INFINITY;
+    if (m != m) m = (T)-INFINITY; // NaN scores never enter a list
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const T x = __shfl_xor(m, o, 64);
+        m = x > m ? x : m;
+    }
+    if ((threadIdx.x & 63) == 0) tile_max[w] = m;
 }
 
 // ---- exclusions: items the user already rated in this context (never candidates) -----------------------------------
@@ -542,6 +614,118 @@ __global__ __launch_bounds__(256) void rank_topn_split(const T *__restrict__ S1,
     if (lane == 0) out_count[q] = count;
 }
 
+// The same selection with TILE PRUNING (round 6).  M1[g][t] / M2[c][t] = the largest S1 / S2 value of the row over candidates
+// [64 t, 64 t + 64) (written by the contractions' epilogues).  ub = (M1 + M2) + c0 is an upper bound of every score of the tile in the
+// SAME floating-point operations as the score itself -- n1 <= M1 and n2 <= M2 give fl(n1 + n2) <= fl(M1 + M2), and adding c0 keeps
+// the order (rounding is monotone) -- so a tile with !(ub > thr) cannot contain a candidate that passes `v > thr` and is neither
+// loaded nor scanned.  thr only rises while a row is walked, tiles are still visited in ascending order, lanes in ascending order
+// inside a tile: the lists are those of rank_topn_split, entry for entry (tests/test_gpu_ranking.py compares the two forms bit for bit).
+// A top-10 list's threshold sits ~3.3 sigma out, a 64-candidate tile's maximum ~2.4: on the bench's data 60 % of the tiles are skipped.
+// Lane l of a chunk holds the bound of tile tb + l; the tiles that pass are fetched PU at a time (2 PU loads in flight, as before).
+template <typename T>
+__global__ __launch_bounds__(256) void rank_topn_split_pruned(const T *__restrict__ S1, const T *__restrict__ S2, const T *__restrict__ M1,
+                                                              const T *__restrict__ M2, int nt64, const T *__restrict__ rc,
+                                                              const int32_t *__restrict__ q_group, const int32_t *__restrict__ q_dctx, int g_base, int q0,
+                                                              int nq, int nc, const int64_t *__restrict__ excl_ptr, const int32_t *__restrict__ excl_idx,
+                                                              T tf, int topn, int32_t *out_idx, double *out_score, int32_t *out_count) {
+#ifndef CMI_RT_PU
+#define CMI_RT_PU 8
+#endif
+    constexpr int PU = CMI_RT_PU;
+    const int lane = threadIdx.x & 63;
+    const int per = (int)gridDim.x / 8; // XCD-aware order, as in rank_topn_split
+    const int blk = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    const int q = q0 + blk * 4 + (threadIdx.x >> 6);
+    if (q >= q0 + nq) return;
+    const size_t g = (size_t)(q_group[q] - g_base);
+    const T *row1 = S1 + g * nc;
+    const T *row2 = S2 ? S2 + (size_t)q_dctx[q] * nc : nullptr;
+    const T *m1 = M1 + g * nt64;
+    const T *m2 = S2 ? M2 + (size_t)q_dctx[q] * nt64 : nullptr;
+    const T c0 = rc[q];
+    int64_t ep = excl_ptr[q];
+    const int64_t ee = excl_ptr[q + 1];
+    int next_excl = ep < ee ? excl_idx[ep] : 0x7fffffff;
+    T lv = -INFINITY;
+    int li = -1;
+    int count = 0;
+    T t = -INFINITY;
+    T thr = tf;
+    // Lane l holds the bound of tile tb + l of the current chunk of 64 tiles (the next chunk's bounds are requested a chunk ahead).  The
+    // chunk's tiles that pass are taken in ROUNDS of up to PU: all of a round's 2 PU loads are issued back to back before its first tile is
+    // scanned -- as many in flight per wave as the plain selection has.  Keep the round's fill loop free of other loads and loops: with
+    // the chunk advance inside it the compiler waited after every load (4.0 instead of 2.6 ms); two rounds in flight (the next round's
+    // loads issued before this one is scanned) cost 82 VGPRs and gained nothing (3.8 ms).
+    auto bounds = [&](int base) -> T {
+        T u = -INFINITY;
+        if (base + lane < nt64) u = m2 ? (m1[base + lane] + m2[base + lane]) + c0 : m1[base + lane] + c0;
+        return u;
+    };
+    T ubn = bounds(0);
+    for (int tb = 0; tb < nt64; tb += 64) {
+        const T ub = ubn;
+        ubn = bounds(tb + 64);
+        unsigned long long mask = __ballot(ub > thr);
+        while (mask) {
+            int tile[PU];
+            T n1[PU], n2[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) { // the next PU tiles that pass (wave-uniform), all their loads issued before the first is used
+                tile[u] = -1;
+                if (mask) {
+                    tile[u] = tb + __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const int c = tile[u] * 64 + lane;
+                    n1[u] = c < nc ? row1[c] : (T)-INFINITY;
+                    n2[u] = c < nc && row2 ? row2[c] : (T)0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                if (tile[u] < 0) continue;
+                if (!(lane_bcast(ub, tile[u] - tb) > thr)) continue; // the N-th best has risen past this tile's bound meanwhile (uniform)
+                const int base = tile[u] * 64;
+                T v = row2 ? (n1[u] + n2[u]) + c0 : n1[u] + c0;
+                while (next_excl < base) { // already-rated items inside skipped tiles
+                    ++ep;
+                    next_excl = ep < ee ? excl_idx[ep] : 0x7fffffff;
+                }
+                while (next_excl < base + 64) {
+                    if (lane == next_excl - base) v = -INFINITY;
+                    ++ep;
+                    next_excl = ep < ee ? excl_idx[ep] : 0x7fffffff;
+                }
+                unsigned long long m = __ballot(v > thr);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const T cv = lane_bcast(v, l);
+                    if (count == topn && !(cv > t)) continue;
+                    const int pos = __popcll(__ballot(lane < count && lv >= cv));
+                    const T uv = __shfl_up(lv, 1, 64);
+                    const int ui = __shfl_up(li, 1, 64);
+                    if (lane > pos) {
+                        lv = uv;
+                        li = ui;
+                    }
+                    if (lane == pos) {
+                        lv = cv;
+                        li = base + l;
+                    }
+                    if (count < topn) ++count;
+                    if (count == topn) thr = t = lane_bcast(lv, topn - 1);
+                }
+            }
+            mask &= __ballot(ub > thr); // drop the chunk's remaining tiles that no longer pass
+        }
+    }
+    if (lane < count) {
+        out_idx[(size_t)q * topn + lane] = li;
+        out_score[(size_t)q * topn + lane] = (double)lv;
+    }
+    if (lane == 0) out_count[q] = count;
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------------
 
 template <typename T>
@@ -557,18 +741,21 @@ hipError_t rank_launch_build_queries(const RankQueryArgs<T> &a, int nq, hipStrea
     return hipGetLastError();
 }
 template <typename T>
-hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s, const T *col_const) {
+hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s, const T *col_const, T *tile_max) {
     if (nq <= 0 || nc <= 0) return hipSuccess;
+    const int nt64 = (nc + 63) / 64;
     static const bool force_valu = cmi_exp_env("CMI_RANK_VALU") != nullptr; // A/B experiments only
     if constexpr (sizeof(T) == 4) {
         if (!force_valu && kp % RG_BK == 0) {
             const int tiles_c = (nc + RG_BN - 1) / RG_BN, n_tiles = tiles_c * ((nq + RG_BM - 1) / RG_BM);
             hipLaunchKernelGGL(rank_gemm_mfma_f32, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, s, (const float *)A,
-                               (const float *)B, (const float *)row_const, (float *)S, nq, nc, kp, tiles_c, n_tiles, (const float *)col_const);
+                               (const float *)B, (const float *)row_const, (float *)S, nq, nc, kp, tiles_c, n_tiles, (const float *)col_const,
+                               (float *)tile_max, nt64);
             return hipGetLastError();
         }
     }
     hipLaunchKernelGGL(rank_gemm<T>, dim3((nc + 63) / 64, (nq + 63) / 64), dim3(256), 0, s, A, B, row_const, S, nq, nc, kp, col_const);
+    if (tile_max) hipLaunchKernelGGL(rank_tile_max<T>, dim3((unsigned)(((int64_t)nq * nt64 + 3) / 4)), dim3(256), 0, s, (const T *)S, nq, nc, nt64, tile_max);
     return hipGetLastError();
 }
 template <typename T>
@@ -576,7 +763,7 @@ hipError_t rank_launch_score(const T *A, const T *B, const T *row_const, T *S, i
                              const int64_t *excl_ptr, const int32_t *excl_idx, int q_base, double thold, int topn,
                              int32_t *out_idx, double *out_score, int32_t *out_count, hipStream_t s) {
     if (nq <= 0 || nc <= 0) return hipSuccess;
-    if (hipError_t e = rank_launch_gemm<T>(A, B, row_const, S, nq, nc, kp, s, nullptr)) return e;
+    if (hipError_t e = rank_launch_gemm<T>(A, B, row_const, S, nq, nc, kp, s, nullptr, nullptr)) return e;
     hipLaunchKernelGGL(rank_mask<T>, dim3(nq), dim3(64), 0, s, S, nc, excl_ptr, excl_idx, q_base, nq);
     if (topn <= 64)
         hipLaunchKernelGGL(rank_topn_stream<T>, dim3((nq + 3) / 4), dim3(256), 0, s, (const T *)S, nq, nc, thold, topn, out_idx,
@@ -607,11 +794,16 @@ hipError_t rank_launch_split_users(const RankSplitArgs &a, const int32_t *d_grou
 }
 hipError_t rank_launch_split_select(const float *S1, const float *S2, const RankSplitArgs &a, const int32_t *q_group, const int32_t *q_dctx, int g_base,
                                     int q0, int nq, const int64_t *excl_ptr, const int32_t *excl_idx, double thold, int topn, int32_t *out_idx,
-                                    double *out_score, int32_t *out_count, hipStream_t s) {
+                                    double *out_score, int32_t *out_count, hipStream_t s, const float *M1, const float *M2) {
     if (nq <= 0) return hipSuccess;
     float tf = (float)thold; // round to nearest, then down to the largest float <= thold (NaN stays NaN: nothing passes, as before)
     if ((double)tf > thold) tf = nextafterf(tf, -INFINITY);
     const int nblk = (nq + 3) / 4;
+    if (M1 && (M2 || !S2)) { // the tile maxima are there: the pruning form
+        hipLaunchKernelGGL(rank_topn_split_pruned<float>, dim3((nblk + 7) / 8 * 8), dim3(256), 0, s, S1, S2, M1, M2, (a.nc + 63) / 64, (const float *)a.rc, q_group,
+                           q_dctx, g_base, q0, nq, a.nc, excl_ptr, excl_idx, tf, topn, out_idx, out_score, out_count);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(rank_topn_split<float>, dim3((nblk + 7) / 8 * 8), dim3(256), 0, s, S1, S2, (const float *)a.rc, q_group, q_dctx, g_base, q0, nq, a.nc,
                        excl_ptr, excl_idx, tf, topn, out_idx, out_score, out_count);
     return hipGetLastError();
@@ -620,7 +812,7 @@ hipError_t rank_launch_split_select(const float *S1, const float *S2, const Rank
 #define CMI_INST(T)                                                                                                    \
     template hipError_t rank_launch_build_items<T>(const RankItemsArgs<T> &, hipStream_t);                             \
     template hipError_t rank_launch_build_queries<T>(const RankQueryArgs<T> &, int, hipStream_t);                      \
-    template hipError_t rank_launch_gemm<T>(const T *, const T *, const T *, T *, int, int, int, hipStream_t, const T *);        \
+    template hipError_t rank_launch_gemm<T>(const T *, const T *, const T *, T *, int, int, int, hipStream_t, const T *, T *);   \
     template hipError_t rank_launch_score<T>(const T *, const T *, const T *, T *, int, int, int, const int64_t *,     \
                                              const int32_t *, int, double, int, int32_t *, double *, int32_t *, hipStream_t);
 CMI_INST(float)

@@ -61,10 +61,12 @@ hipError_t rank_launch_split_operands(const RankSplitArgs &a, hipStream_t s);
 hipError_t rank_launch_split_users(const RankSplitArgs &a, const int32_t *d_group_user, int n, float *A1, float *scratch_rc, hipStream_t s);
 hipError_t rank_launch_split_select(const float *S1, const float *S2, const RankSplitArgs &a, const int32_t *q_group, const int32_t *q_dctx, int g_base,
                                     int q0, int nq, const int64_t *excl_ptr, const int32_t *excl_idx, double thold, int topn, int32_t *out_idx,
-                                    double *out_score, int32_t *out_count, hipStream_t s);
+                                    double *out_score, int32_t *out_count, hipStream_t s, const float *M1 = nullptr, const float *M2 = nullptr);
 // S = (A.B^T [+ col_const]) + row_const (the contraction alone).  col_const[c] is added to the finished dot product first: the same value
 // as one more column {1 | col_const[c]} at the end of the k-ordered chain (fma(1, b, acc) = acc + b), without the 16 padded columns it costs
+// tile_max (may be null): [nq][(nc + 63) / 64] row maxima of S over tiles of 64 candidates, for the selection's tile pruning (M1 / M2 above)
 template <typename T>
-hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s, const T *col_const = nullptr);
+hipError_t rank_launch_gemm(const T *A, const T *B, const T *row_const, T *S, int nq, int nc, int kp, hipStream_t s, const T *col_const = nullptr,
+                            T *tile_max = nullptr);
 
 } // namespace cmi

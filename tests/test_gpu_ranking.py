@@ -290,3 +290,30 @@ def test_split_form_exclusions_with_sparse_item_ids():
         assert set(got[1]) == set(ref_lists)
         for key, lst in ref_lists.items():
             assert [i for i, _ in got[1][key]] == [i for i, _ in lst], key
+
+
+@pytest.mark.parametrize("model,k,n_items,num_recs", [("CAMF_CI", 32, 900, 10), ("CAMF_CI", 128, 9000, 10), ("CAMF_CU", 16, 5000, 25),
+                                                      ("BiasedMF", 8, 4500, 5), ("CAMF_CUCI", 32, 700, 64), ("PMF", 16, 130, 10)])
+def test_tile_pruned_selection_equals_the_plain_selection(model, k, n_items, num_recs):
+    """Round 6: the split form's selection skips tiles of 64 candidates whose bound (M1[user][tile] + M2[context][tile]) + c0 -- the row
+    maxima the contractions' epilogues write, combined in the score's own floating-point operations -- cannot beat the query's current
+    N-th best (rank_topn_split_pruned).  A bound, not an approximation: lists, scores, counts and measures equal the plain split
+    selection's (CMI_RANK_NO_PRUNE=1) ENTRY FOR ENTRY -- trained models, candidate counts across several 64-tile chunks (> 4 096), small
+    batches, lists as long as 64, all-tied models (every tile's bound equals the threshold: nothing may be skipped wrongly) and queries
+    with long exclusion lists inside skipped tiles."""
+    train, test, orc, inst = _setup(model, k, 0, epochs=2, n_users=120, n_items=n_items, n=14000, seed=13)
+    kw = dict(bin_thold=2.5, num_recs=num_recs, with_lists=True)
+    for batch in ("23", None):
+        pruned = _with_env({"CMI_RANK_NO_PRUNE": None, "CMI_RANK_BATCH": batch}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
+        plain = _with_env({"CMI_RANK_NO_PRUNE": "1", "CMI_RANK_BATCH": batch}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
+        assert pruned[0]["n_queries"] == plain[0]["n_queries"] > 0 and set(pruned[1]) == set(plain[1])
+        for key, lst in plain[1].items():
+            assert pruned[1][key] == lst, key          # (item, score) pairs: identical, in order
+        for m, v in plain[0].items():
+            assert (math.isnan(v) and math.isnan(pruned[0][m])) or pruned[0][m] == v, m
+    # an all-tied model (ties resolve in candidate order; with every bound EQUAL to the threshold the `>` must not skip a tile early)
+    st = {n: np.zeros_like(a) for n, a in inst.get_states(np.float32).items()}
+    inst.set_states(st)
+    pruned = _with_env({"CMI_RANK_NO_PRUNE": None}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
+    plain = _with_env({"CMI_RANK_NO_PRUNE": "1"}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
+    assert pruned[1] == plain[1] and all((math.isnan(v) and math.isnan(pruned[0][m])) or pruned[0][m] == v for m, v in plain[0].items())
