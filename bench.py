@@ -548,10 +548,11 @@ def rank_roofline(nq, n_cand, dev, flops, kern_ms):
            "frac": flops / g / 1e12 / F32_MFMA_PEAK_TFLOPS if g else None, "traffic": None,
            "kernel": "rank_gemm_mfma_f32 (v_mfma_f32_32x32x2_f32)", "flops": flops, "kernel_ms": g * 1e3,
            "timing": "HIP events around the contraction's launches on the instance stream, summed over the batches of one evaluation",
-           "selection": {"kernel": "rank_topn_split<float>", "kernel_ms": t * 1e3,
+           "selection": {"kernel": "rank_topn_split<float>" if os.environ.get("CMI_RANK_NO_PRUNE") else "rank_topn_split_pruned<float>", "kernel_ms": t * 1e3,
                          "bytes_streamed": 2.0 * nq * n_cand * 4,
                          "GBps_through_L2": 2.0 * nq * n_cand * 4 / t / 1e9 if t else None,
-                         "note": "one S1 row (shared by the user's queries: L2) and one S2 row (Infinity Cache) per query"},
+                         "note": "one S1 row (shared by the user's queries: L2) and one S2 row (Infinity Cache) per query; bytes_streamed / GBps_through_L2 "
+                                 "count EVERY candidate: the pruned selection skips the 64-candidate tiles whose bound cannot pass (~60 % here)"},
            "contraction_TFLOPs_over_whole_loop": flops / dev / 1e12}
     return out
 
