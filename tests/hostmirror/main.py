@@ -1,5 +1,5 @@
 """Host-flow MIRROR, test plumbing only (it lives under tests/): the product host is the C++ one (carskit_amd/csrc/host, built to
-carskit_amd/bin/carskit-mi355x; `python -m carskit_amd.main -c setting.conf` runs that binary).  run() below restates the same flow in
+carskit_amd/bin/carskit-mi355x).  run() below restates the same flow in
 Python for one reason: it takes an `engine_factory`, so the tests can put the CPU ORACLE behind the identical host logic (config parsing, splits,
 bold driver, early stop, measures) and compare the two hosts and the two engines line by line (tests/test_host_layer.py,
 tests/test_gpu_realdata.py).  It is test plumbing, not a second product.
