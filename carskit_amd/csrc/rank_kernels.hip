@@ -17,6 +17,7 @@
 #include "env_knobs.hpp"
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "rank_kernels.hpp"
 
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const fl
                                                           float *__restrict__ tile_max, int nt64) {
     __shared__ float sA[2][RG_BK][RG_LDS];
     __shared__ float sB[2][RG_BK][RG_LDS];
+    __shared__ float s_rc[RG_BM];
     // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give XCD x the x-th contiguous
     // eighth of the tile list (candidate tiles fastest): its L2 then sees one band of queries and sweeps the items.
     const int per = (n_tiles + 7) / 8;
@@ -259,6 +261,10 @@ __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const fl
             }
     };
     gload(0);
+    // the tile's 128 row constants go to LDS now (visible after the barrier below): the epilogue used to fetch each with a global load in
+    // front of the row's stores, and on this part a wait for a load is also a wait for every older store -- 32 dependent round trips
+    // per wavefront and tile, as long as the tile's whole matrix work (contraction 2.9 -> see profiles/r06_rank_epilogue.txt)
+    if (tid < RG_BM) s_rc[tid] = q0 + tid < nq ? row_const[q0 + tid] : 0.f;
     lstore(0);
     __syncthreads();
     const int nk = kp_pad / RG_BK;
@@ -306,38 +312,45 @@ __global__ __launch_bounds__(256, CMI_RG_WAVES) void rank_gemm_mfma_f32(const fl
         for (int j = 0; j < 2; ++j) cc[j] = col_const[min(c0 + wc + 32 * j + mrow, nc - 1)];
     }
     float rowmax = -INFINITY; // lane l: the maximum of patch row l over the wave's 64 candidates (collected below, stored once)
+    // FULL (block-uniform): the whole 128 x 128 tile lies inside the slab -- no per-element bounds, the 64 stores of a wavefront go out
+    // back to back; the edge tiles take the same code with the bounds
+    auto epilogue = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r4 = 0; r4 < 16; r4 += 4) {
-            float m[4];
+            for (int r4 = 0; r4 < 16; r4 += 4) {
+                float m[4];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int r = r4 + d;
-                const int q = q0 + wq + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * mk;
-                const float rc = q < nq ? row_const[q] : 0.f;
-                m[d] = -INFINITY; // (no `continue` for rows past the end: the cross-lane maximum below needs every lane)
+                for (int d = 0; d < 4; ++d) {
+                    const int r = r4 + d;
+                    const int ql = wq + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * mk, q = q0 + ql;
+                    const float rc = s_rc[ql]; // (0 for rows past the end)
+                    m[d] = -INFINITY; // (no `continue` for rows past the end: the cross-lane maximum below needs every lane)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c = c0 + wc + 32 * j + mrow;
-                    const float val = (col_const ? acc[i][j][r] + cc[j] : acc[i][j][r]) + rc;
-                    if (q < nq && c < nc) {
-                        S[(size_t)q * nc + c] = val;
-                        m[d] = val > m[d] ? val : m[d]; // (a NaN score is never taken: it cannot enter a list either)
+                    for (int j = 0; j < 2; ++j) {
+                        const int c = c0 + wc + 32 * j + mrow;
+                        const float val = (col_const ? acc[i][j][r] + cc[j] : acc[i][j][r]) + rc;
+                        if (FULL || (q < nq && c < nc)) {
+                            S[(size_t)q * nc + c] = val;
+                            m[d] = val > m[d] ? val : m[d]; // (a NaN score is never taken: it cannot enter a list either)
+                        }
+                    }
+                }
+                if (tile_max) { // wave-uniform
+                    rg_max32x4(m[0], m[1], m[2], m[3]);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int r = r4 + d, row = 32 * i + (r & 3) + 8 * (r >> 2); // patch row of the lanes with mk = 0; mk = 1: + 4
+                        const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m[d]), 31));
+                        const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m[d]), 63));
+                        rowmax = lane == row ? lo : (lane == row + 4 ? hi : rowmax);
                     }
                 }
             }
-            if (tile_max) { // wave-uniform
-                rg_max32x4(m[0], m[1], m[2], m[3]);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int r = r4 + d, row = 32 * i + (r & 3) + 8 * (r >> 2); // patch row of the lanes with mk = 0; mk = 1: + 4
-                    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m[d]), 31));
-                    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m[d]), 63));
-                    rowmax = lane == row ? lo : (lane == row + 4 ? hi : rowmax);
-                }
-            }
-        }
+    };
+    if (q0 + RG_BM <= nq && c0 + RG_BN <= nc) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     if (tile_max && q0 + wq + lane < nq && c0 + wc < nc) tile_max[(size_t)(q0 + wq + lane) * nt64 + ((c0 + wc) >> 6)] = rowmax;
 }
 
