@@ -635,6 +635,14 @@ __global__ __launch_bounds__(256) void rank_topn_split(const T *__restrict__ S1,
 // inside a tile: the lists are those of rank_topn_split, entry for entry (tests/test_gpu_ranking.py compares the two forms bit for bit).
 // A top-10 list's threshold sits ~3.3 sigma out, a 64-candidate tile's maximum ~2.4: on the bench's data 60 % of the tiles are skipped.
 // Lane l of a chunk holds the bound of tile tb + l; the tiles that pass are fetched PU at a time (2 PU loads in flight, as before).
+// v of lane l for a WAVE-UNIFORM l (v_readlane with the lane number in an SGPR; __shfl goes through LDS)
+__device__ __forceinline__ float lane_pick(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_pick(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void rank_topn_split_pruned(const T *__restrict__ S1, const T *__restrict__ S2, const T *__restrict__ M1,
                                                               const T *__restrict__ M2, int nt64, const T *__restrict__ rc,
@@ -648,7 +656,10 @@ __global__ __launch_bounds__(256) void rank_topn_split_pruned(const T *__restric
     const int lane = threadIdx.x & 63;
     const int per = (int)gridDim.x / 8; // XCD-aware order, as in rank_topn_split
     const int blk = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-    const int q = q0 + blk * 4 + (threadIdx.x >> 6);
+    // the wave's query index as a SCALAR (readfirstlane of the wave number): the row pointers, the exclusion cursor and its reads then live
+    // in SGPRs / scalar loads -- as VGPR values the compiler walked the exclusion list with vector loads and `s_waitcnt vmcnt(0)` in front
+    // of every tile (which also drains the round's tile loads), and broadcast the tile bound through LDS (ds_bpermute)
+    const int q = q0 + blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (q >= q0 + nq) return;
     const size_t g = (size_t)(q_group[q] - g_base);
     const T *row1 = S1 + g * nc;
@@ -696,7 +707,7 @@ __global__ __launch_bounds__(256) void rank_topn_split_pruned(const T *__restric
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 if (tile[u] < 0) continue;
-                if (!(lane_bcast(ub, tile[u] - tb) > thr)) continue; // the N-th best has risen past this tile's bound meanwhile (uniform)
+                if (!(lane_pick(ub, tile[u] - tb) > thr)) continue; // the N-th best has risen past this tile's bound meanwhile (uniform)
                 const int base = tile[u] * 64;
                 T v = row2 ? (n1[u] + n2[u]) + c0 : n1[u] + c0;
                 while (next_excl < base) { // already-rated items inside skipped tiles
@@ -712,7 +723,7 @@ __global__ __launch_bounds__(256) void rank_topn_split_pruned(const T *__restric
                 while (m) {
                     const int l = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    const T cv = lane_bcast(v, l);
+                    const T cv = lane_pick(v, l);
                     if (count == topn && !(cv > t)) continue;
                     const int pos = __popcll(__ballot(lane < count && lv >= cv));
                     const T uv = __shfl_up(lv, 1, 64);
@@ -726,7 +737,7 @@ __global__ __launch_bounds__(256) void rank_topn_split_pruned(const T *__restric
                         li = base + l;
                     }
                     if (count < topn) ++count;
-                    if (count == topn) thr = t = lane_bcast(lv, topn - 1);
+                    if (count == topn) thr = t = lane_pick(lv, topn - 1);
                 }
             }
             mask &= __ballot(ub > thr); // drop the chunk's remaining tiles that no longer pass
