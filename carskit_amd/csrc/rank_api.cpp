@@ -512,7 +512,22 @@ struct MeanAcc {
         for (int m = 0; m < N_MEAS; ++m) o[m] = c[m] ? s[m] / (double)c[m] : std::nan("");
     }
 };
+static_assert(N_MEAS == 18, "RankFolded::s / c (rank_host.hpp) hold one chain per measure");
+// the running sums of a RankFolded advance exactly as one MeanAcc over all rows would: same rows, same order, same operations
+inline void folded_add(RankFolded &f, const double *v) {
+    for (int m = 0; m < N_MEAS; ++m) {
+        const bool ok = v[m] == v[m];
+        f.s[m] += ok ? v[m] : 0.0;
+        f.c[m] += ok;
+    }
+}
 } // namespace
+
+void rank_sum_queries(const int32_t *top_count, const double *vals, RankFolded &f, int64_t q_to) {
+    for (int64_t q = f.summed; q < q_to; ++q)
+        if (top_count[q] > 0) folded_add(f, vals + (size_t)q * N_MEAS);
+    f.summed = std::max(f.summed, q_to);
+}
 
 // ucu: a test user contributes the NaN-skipping mean over its contexts -- NaN (skipped again) if none of its contexts produced a list
 // (Recommender.java:903-926).  The users' means do not depend on each other: ranges of whole users on the host's cores compute them and
@@ -559,16 +574,17 @@ void rank_fold_users(const RankPlan &plan, const int32_t *top_count, const doubl
     });
     f.q = stop;
     f.u = ubase[(size_t)nt];
+    // the sum over the users is serial (its order is the result's last bits): taken here, batch by batch, for the users just folded
+    for (int64_t u = f.summed; u < f.u; ++u) folded_add(f, umeans + (size_t)u * N_MEAS);
+    f.summed = f.u;
 }
 
 void rank_average(const RankPlan &plan, int strategy, const int32_t *top_count, const double *vals, double *umeans, RankFolded f, double *out) {
     const int64_t nq = (int64_t)plan.qu.size();
     for (int m = 0; m < CMI_RANK_MEASURES; ++m) out[m] = std::nan("");
     out[18] = out[19] = out[20] = 0.0; // D5/D10/DN: isDiverseUsed=false (Recommender.java:939-941)
-    MeanAcc total;
     if (strategy == CMI_RANK_UC) {
-        for (int64_t q = 0; q < nq; ++q)
-            if (top_count[q] > 0) total.add(vals + (size_t)q * N_MEAS);
+        rank_sum_queries(top_count, vals, f, nq); // (what the batches have not added yet)
     } else {
         std::unique_ptr<double[]> own;
         if (!umeans) { // a caller without a workspace buffer: at most one user per query
@@ -576,9 +592,10 @@ void rank_average(const RankPlan &plan, int strategy, const int32_t *top_count, 
             umeans = own.get();
             f = RankFolded();
         }
-        if (f.q < nq) rank_fold_users(plan, top_count, vals, umeans, f, nq, true);
-        for (int64_t u = 0; u < f.u; ++u) total.add(umeans + (size_t)u * N_MEAS);
+        if (f.q < nq) rank_fold_users(plan, top_count, vals, umeans, f, nq, true); // (also sums the users it folds)
     }
+    MeanAcc total;
+    for (int m = 0; m < N_MEAS; ++m) total.s[m] = f.s[m], total.c[m] = f.c[m];
     total.mean(out);
 }
 
@@ -1306,6 +1323,7 @@ static int eval_rankings_impl(cmi_handle h, int64_t n_train, const int32_t *tu, 
                                 vals, q_user, q_ctx, q_count, top_items, top_scores);
             // the batches arrive in query order: the users they complete are averaged here, behind the device
             if (strategy == CMI_RANK_UCU) rank_fold_users(plan, (const int32_t *)ws.h_count.p, vals, umeans, folded, q1, q1 >= nq);
+            else rank_sum_queries((const int32_t *)ws.h_count.p, vals, folded, q1); // uc: the serial sum over the queries, behind the device
         };
         hipError_t e;
         if (ext && h->f64) e = rank_run_device<double>(h->stream, ws, plan, ext_operands<double>(h, k_logical), bin_thold, num_recs, on_batch,

@@ -126,7 +126,13 @@ void rank_measures_range(const RankPlan &plan, int num_recs, const int32_t *top_
 // rank_average folds what is left and sums over the users (umeans == nullptr: it allocates its own and folds everything).
 struct RankFolded {
     int64_t q = 0, u = 0; // first query not folded yet; users folded so far
+    // the serial sum over users (ucu) / queries (uc), advanced batch by batch behind the device in the order rank_average would take
+    int64_t summed = 0;   // users (ucu) or queries (uc) already in s / c
+    double s[18] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int64_t c[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
+// uc: add the queries [f.summed, q_to) to the running sums (query order)
+void rank_sum_queries(const int32_t *top_count, const double *vals, RankFolded &f, int64_t q_to);
 void rank_fold_users(const RankPlan &plan, const int32_t *top_count, const double *vals, double *umeans, RankFolded &f, int64_t q_to, bool last);
 void rank_average(const RankPlan &plan, int strategy, const int32_t *top_count, const double *vals, double *umeans, RankFolded f,
                   double *out /*[21]*/);
