@@ -668,11 +668,17 @@ hipError_t RankWorkspace::batch_event(size_t b, hipStream_t stream) {
 hipError_t RankWorkspace::consume_batches(hipError_t e, const std::vector<std::pair<int64_t, int64_t>> &batches,
                                           const std::function<void(int64_t, int64_t)> &on_batch,
                                           std::chrono::steady_clock::time_point t_loop) {
+    const bool times = getenv("CMI_PLAN_TIMES") != nullptr;
+    auto at = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count(); };
+    if (times) fprintf(stderr, "rank loop: all batches enqueued at %.3f ms\n", at());
     for (size_t b = 0; b + 1 < batches.size() && e == hipSuccess; ++b) {
         e = hipEventSynchronize(evb[b]);
+        if (times) fprintf(stderr, "rank loop: batch %zu's lists on the host at %.3f ms\n", b, at());
         if (e == hipSuccess && on_batch) on_batch(batches[b].first, batches[b].second);
     }
+    if (times) fprintf(stderr, "rank loop: host done with all but the last batch at %.3f ms\n", at());
     if (e == hipSuccess) e = hipEventSynchronize(ev1); // recorded behind the last batch's copies
+    if (times) fprintf(stderr, "rank loop: last batch's lists on the host at %.3f ms\n", at());
     host_ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
     const auto t_tail = std::chrono::steady_clock::now();
     if (e == hipSuccess && !batches.empty() && on_batch) on_batch(batches.back().first, batches.back().second);
@@ -684,14 +690,28 @@ static double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-// Batch boundaries over n units of at most b: the FINAL batch is kept short (b / 16), because its lists are the only ones the host
-// turns into measures with the device already idle.
+// Batch boundaries over n units of at most b.  The host turns a batch's lists into measures while the device works on the batches
+// behind it, so the END of the sequence tapers: b / 3, b / 6, b / 12 -- every batch's host work (about half its device time on an
+// MI355X box) is covered by the device time of the batches that follow, and only the last, smallest batch's is exposed.  (Until round
+// 6 only the final batch was short, b / 16: the batch before it finished on the host 0.3-0.5 ms after the device had gone idle.)
+// In front of the taper: equal batches.
 static std::vector<int64_t> batch_cuts(int64_t n, int64_t b) {
+    std::vector<int64_t> tail;
+    int64_t left = n;
+    if (b / 12 >= 64)
+        for (int64_t s = b / 12; tail.size() < 3 && left > 2 * s; s *= 2) {
+            tail.push_back(s);
+            left -= s;
+        }
+    const int64_t m = std::max<int64_t>(1, (left + b - 1) / b);
     std::vector<int64_t> cuts;
-    for (int64_t x = 0; x < n; x += b) cuts.push_back(x);
+    for (int64_t i = 0; i < m; ++i) cuts.push_back(left * i / m); // (pieces of at most ceil(left / m) <= b)
+    int64_t x = left;
+    for (size_t i = tail.size(); i-- > 0;) {
+        cuts.push_back(x);
+        x += tail[i];
+    }
     cuts.push_back(n);
-    const int64_t small = std::max<int64_t>(64, b / 16);
-    if (cuts.size() >= 2 && n - cuts[cuts.size() - 2] > 2 * small) cuts.insert(cuts.end() - 1, n - small);
     return cuts;
 }
 
