@@ -883,11 +883,11 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     const bool prune = getenv("CMI_RANK_NO_PRUNE") == nullptr;
     const size_t nt64 = (size_t)(nc + 63) / 64;
     need(ws.dA, up128(bg) * a.kp1 * 4);
-    need(ws.dS, (size_t)bg * (size_t)nc * 4);
+    need(ws.dS, (size_t)bg * (size_t)nc * 4 + RANK_SLAB_SLACK);
     if (prune) need(ws.dM1, (size_t)bg * nt64 * 4);
     if (two) {
         need(ws.dAb, up128(bg) * a.kp1 * 4);
-        need(ws.dSb, (size_t)bg * (size_t)nc * 4);
+        need(ws.dSb, (size_t)bg * (size_t)nc * 4 + RANK_SLAB_SLACK);
         if (prune) need(ws.dM1b, (size_t)bg * nt64 * 4);
         // experiment builds, CMI_RANK_SEL_CUS=N: the selection's stream may only use N compute units of every XCD (of 32) and the
         // contraction runs on a stream of its own masked to the others, so that the two kernels overlap instead of taking turns
@@ -917,7 +917,7 @@ hipError_t rank_run_device_split(hipStream_t stream, RankWorkspace &ws, const Ra
     if (s2) {
         need(ws.dB2, up128(nc) * a.kp2 * 4);
         need(ws.dA2, up128(n_dc) * a.kp2 * 4);
-        need(ws.dS2, (size_t)n_dc * (size_t)nc * 4);
+        need(ws.dS2, (size_t)n_dc * (size_t)nc * 4 + RANK_SLAB_SLACK);
         if (prune) need(ws.dM2, (size_t)n_dc * nt64 * 4);
         need(ws.ddc, (size_t)n_dc * 4);
         need(ws.dqd, (size_t)nq * 4);

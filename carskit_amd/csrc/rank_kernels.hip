@@ -699,9 +699,11 @@ __global__ __launch_bounds__(256) void rank_topn_split_pruned(const T *__restric
                 if (mask) {
                     tile[u] = tb + __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
+                    // (no per-lane bounds around the loads -- as exec-masked branches they were half of the fill's instructions: the row's last
+                    // tile may read up to 63 elements past the row, which the slabs' allocations cover (RANK_SLAB_SLACK); the scan masks them)
                     const int c = tile[u] * 64 + lane;
-                    n1[u] = c < nc ? row1[c] : (T)-INFINITY;
-                    n2[u] = c < nc && row2 ? row2[c] : (T)0;
+                    n1[u] = row1[c];
+                    n2[u] = row2 ? row2[c] : (T)0;
                 }
             }
 #pragma unroll
@@ -710,6 +712,7 @@ __global__ __launch_bounds__(256) void rank_topn_split_pruned(const T *__restric
                 if (!(lane_pick(ub, tile[u] - tb) > thr)) continue; // the N-th best has risen past this tile's bound meanwhile (uniform)
                 const int base = tile[u] * 64;
                 T v = row2 ? (n1[u] + n2[u]) + c0 : n1[u] + c0;
+                if (base + 64 > nc) v = base + lane < nc ? v : (T)-INFINITY; // (wave-uniform test) the row's last, partial tile
                 while (next_excl < base) { // already-rated items inside skipped tiles
                     ++ep;
                     next_excl = ep < ee ? excl_idx[ep] : 0x7fffffff;

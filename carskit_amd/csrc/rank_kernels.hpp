@@ -5,6 +5,10 @@
 
 namespace cmi {
 
+// bytes the score slabs (S1, S2) are allocated beyond their last row: the pruned selection loads whole tiles of 64 candidates, and the
+// last tile of a row may reach up to 63 elements past it (into the next row, or past the slab's last row into this slack; never used)
+constexpr size_t RANK_SLAB_SLACK = 256;
+
 template <typename T>
 struct RankItemsArgs {
     const T *Q, *itemBias, *icBias; // itemBias / icBias may be null (model does not own them)
