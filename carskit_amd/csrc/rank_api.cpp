@@ -696,6 +696,7 @@ static double ms_since(std::chrono::steady_clock::time_point t0) {
 // 6 only the final batch was short, b / 16: the batch before it finished on the host 0.3-0.5 ms after the device had gone idle.)
 // In front of the taper: equal batches.
 static std::vector<int64_t> batch_cuts(int64_t n, int64_t b) {
+    if (n <= 0) return {0}; // (no batches)
     std::vector<int64_t> tail;
     int64_t left = n;
     if (b / 12 >= 64)
