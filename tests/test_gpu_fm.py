@@ -169,6 +169,32 @@ def test_fm_support_length_paths(n_users, n_items, n, zipf, flags):
     np.testing.assert_allclose(V, orc.V.reshape(V.shape), rtol=1e-8, atol=1e-11)
 
 
+def test_fm_mid_size_sweep_against_the_dense_oracle():
+    """The largest problem the DENSE oracle (O(size x p x k) per sweep: FM.java's own cost) finishes in seconds: 40 K ratings,
+    p = 2 512, k = 6 -- several groups of coordinates, id-range parts, full batches, complex coordinates with the DEFAULT geometry (no
+    test knob), held to the oracle itself rather than to a restatement.  Both forms of the sums."""
+    data = util.small_data(n_users=1500, n_items=1000, n_dims=3, conds_per_dim=4, n=40000, seed=77)
+    k = 6
+    w0, w, V = fm_init_model(data.n_users, data.n_items, data.n_conds, k, 5)
+    orc = oracle_c.FMOracle(k, data.n_users, data.n_items, data.n_conds, data.n_dims, data.u, data.j, data.ctx, data.r, w0, w, V, REGLW, REGLF)
+    orc.init()
+    orc.sweep()
+    want = np.array([orc.predict(int(u), int(j), int(c)) for u, j, c in zip(data.u[:4000], data.j[:4000], data.ctx[:4000])])
+    for flags in (DET, RELAXED):
+        g = capi.FMInstance(k, data.n_users, data.n_items, data.n_conds, data.n_dims, flags=flags)
+        g.set_hparams(REGLW, REGLF)
+        g.set_ratings(data.u, data.j, data.ctx, data.r)
+        g.set_model(w0, w, V)
+        g.init()
+        g.sweep()
+        gw0, gw, gV = g.get_model()
+        assert abs(gw0 - orc.w0) <= 1e-10 * max(1.0, abs(orc.w0))
+        np.testing.assert_allclose(gw, orc.w, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(gV, orc.V.reshape(gV.shape), rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(g.predict(data.u[:4000], data.j[:4000], data.ctx[:4000]), want, rtol=0, atol=1e-9)
+        g.close()
+
+
 @pytest.mark.parametrize("slice_entries", [8, 16, 1000000])
 def test_fm_l2_sliced_orders_match_the_oracle(slice_entries):
     """A block of coordinates walks the SLICES of the gathered table (cells), so that the records a workgroup evaluates together are
