@@ -258,6 +258,30 @@ def test_split_form_agrees_with_the_per_query_contraction(model):
         assert (math.isnan(v) and math.isnan(split[0][m])) or abs(split[0][m] - v) <= 0.01, m
 
 
+@pytest.mark.parametrize("model,n_items", [("CAMF_CI", 5000), ("BiasedMF", 4200)])
+def test_pruned_split_form_at_many_tiles_against_the_oracle(model, n_items):
+    """The product path of the fp32 MF family -- split contraction on the matrix cores, tile-pruning selection over several 64-tile
+    chunks, exclusions walked by the scalar cursor -- held to the ORACLE itself (rank_oracle over the C oracle's predict, fp64) at a
+    candidate count the other oracle comparisons do not reach (they rank 90 items).  fp32 state against fp64: lists agree except at
+    near-ties, scores to 1e-4, measures to 0.01."""
+    train, test, orc, inst = _setup(model, 16, 0, epochs=2, n_users=40, n_items=n_items, n=9000, seed=21)
+    kw = dict(bin_thold=2.5, num_recs=10)
+    ref, ref_lists = _oracle_eval(orc, train, test, **kw)
+    res, lists = inst.eval_rankings(_arrays(train), _arrays(test), with_lists=True, **kw)
+    assert set(lists) == set(ref_lists) and len(ref_lists) > 20
+    same = 0
+    for key, ref_l in ref_lists.items():
+        got = lists[key]
+        assert len(got) == len(ref_l), key
+        same += [i for i, _ in got] == [i for i, _ in ref_l]
+        for (_, a), (_, b) in zip(got, ref_l):
+            assert abs(a - b) <= 1e-4, (key, a, b)
+    assert same >= 0.9 * len(ref_lists), (same, len(ref_lists))
+    for m in rank_oracle.MEASURES:
+        a, b = res[m], ref[m]
+        assert (math.isnan(a) and math.isnan(b)) or abs(a - b) <= 0.01, (m, a, b)
+
+
 def test_split_form_exclusions_with_sparse_item_ids():
     """The split form walks a query's exclusion list on the fly and needs it in ascending CANDIDATE POSITION; with sparse item ids the
     HashSet order of the candidates is not the order of the ids.  Users that rated many items in the context of their test query, an
