@@ -341,3 +341,37 @@ def test_tile_pruned_selection_equals_the_plain_selection(model, k, n_items, num
     pruned = _with_env({"CMI_RANK_NO_PRUNE": None}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
     plain = _with_env({"CMI_RANK_NO_PRUNE": "1"}, lambda: inst.eval_rankings(_arrays(train), _arrays(test), **kw))
     assert pruned[1] == plain[1] and all((math.isnan(v) and math.isnan(pruned[0][m])) or pruned[0][m] == v for m, v in plain[0].items())
+
+
+def test_two_instances_evaluate_rankings_at_the_same_time():
+    """`cv -p on` evaluates the folds' rankings from one host thread per fold (CARSKit.java:395-412, Recommender.java:1162-1171): two
+    instances -- different models, different data, split form and per-query form -- evaluate concurrently, repeatedly, and every result
+    equals the instance's lone result entry for entry (per-instance workspace, streams and plan cache; the host's ranged work shares one
+    pool)."""
+    import threading
+    a = _setup("CAMF_CI", 32, 0, epochs=2, n_users=150, n_items=3000, n=15000, seed=31)
+    b = _setup("CAMF_CUCI", 10, F64 | STRICT, epochs=1, n_users=80, n_items=400, n=6000, seed=32)
+    kw = dict(bin_thold=2.5, num_recs=10, with_lists=True)
+    lone = [x[3].eval_rankings(_arrays(x[0]), _arrays(x[1]), **kw) for x in (a, b)]
+    errors, done = [], []
+
+    def work(x, want, batch):
+        try:
+            for rep in range(12):
+                os.environ["CMI_RANK_BATCH"] = batch          # (read per call; both threads set small batches: many launches interleave)
+                got = x[3].eval_rankings(_arrays(x[0]), _arrays(x[1]), **kw)
+                assert got[1] == want[1], rep
+                assert all((math.isnan(v) and math.isnan(got[0][m])) or got[0][m] == v for m, v in want[0].items()), rep
+            done.append(1)
+        except Exception as exc:                              # noqa: BLE001 -- surfaced below
+            errors.append(exc)
+    try:
+        ts = [threading.Thread(target=work, args=(x, w, "29")) for x, w in zip((a, b), lone)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+    finally:
+        os.environ.pop("CMI_RANK_BATCH", None)
+    assert not errors, errors
+    assert len(done) == 2
