@@ -357,7 +357,7 @@ def test_two_instances_evaluate_rankings_at_the_same_time():
 
     def work(x, want, batch):
         try:
-            for rep in range(12):
+            for rep in range(40):
                 os.environ["CMI_RANK_BATCH"] = batch          # (read per call; both threads set small batches: many launches interleave)
                 got = x[3].eval_rankings(_arrays(x[0]), _arrays(x[1]), **kw)
                 assert got[1] == want[1], rep
@@ -365,13 +365,36 @@ def test_two_instances_evaluate_rankings_at_the_same_time():
             done.append(1)
         except Exception as exc:                              # noqa: BLE001 -- surfaced below
             errors.append(exc)
+    stop = threading.Event()
+
+    def trainer():
+        # a third fold still TRAINING: fresh instances whose first epoch captures the level graph (thread-local capture) and whose
+        # set_ratings / close allocate and free device memory while the other two evaluate
+        try:
+            d = synth.generate(400, 120, 3, 3, 20000, seed=33)
+            st = synth.init_state("CAMF_CI", d, 64, seed=9, dtype=np.float32)
+            while not stop.is_set():
+                inst = capi.Instance("CAMF_CI", 64, d.n_users, d.n_items, d.n_conds, flags=capi.FLAG_SCHED_CHAIN)
+                inst.set_hparams(util.REG, util.REG, util.REG, util.REGC, 3.0)
+                inst.set_ratings(d.u, d.j, d.ctx, d.r, d.ctx_ptr, d.ctx_conds)
+                inst.set_states(st)
+                for _ in range(3):
+                    inst.train_epoch(util.LR)
+                inst.close()
+        except Exception as exc:                              # noqa: BLE001
+            errors.append(exc)
     try:
         ts = [threading.Thread(target=work, args=(x, w, "29")) for x, w in zip((a, b), lone)]
+        tr = threading.Thread(target=trainer)
+        tr.start()
         for t in ts:
             t.start()
         for t in ts:
             t.join(timeout=300)
+        stop.set()
+        tr.join(timeout=120)
     finally:
+        stop.set()
         os.environ.pop("CMI_RANK_BATCH", None)
     assert not errors, errors
     assert len(done) == 2
