@@ -888,6 +888,34 @@ def main():
         if world == 1 and not args.no_calibration:
             inst.synchronize()
             with_measured(out["roofline"], local_rank)
+        if world == 1 and args.folds == 1 and args.workload == "c3" and not args.no_extras and not args.item_zipf and trainer is None:
+            # secondary line: TWO independent models of the same workload side by side on this GPU (two instances, two streams, two host
+            # threads: the reference's `cv -p on`, CARSKit.java:395-412).  The second model fills the first one's level boundaries
+            # (285 dependent launches per epoch, each with its pipeline ramp and drain): what a lone model's order-exact schedule leaves idle
+            try:
+                other = make_instance(model, k, data, n_items, state, regs, gm, local_rank, args.flags)
+
+                def pair():
+                    th = threading.Thread(target=other.train_epoch, args=(lr,))
+                    th.start()
+                    inst.train_epoch(lr)
+                    th.join()
+                pair()
+                inst.synchronize()
+                other.synchronize()
+                t2 = time.perf_counter()
+                for _ in range(3):
+                    pair()
+                inst.synchronize()
+                other.synchronize()
+                el2 = time.perf_counter() - t2
+                rf2 = roofline(model, k, n_dims, data.n, info, sched, el2 / 3 * 1e3 / 2, 4, args.workload)
+                out["two_folds"] = {"value": 2 * data.n * 3 / el2, "unit": "rating-updates/s", "steps": 3, "ms_per_step": el2 / 3 * 1e3,
+                                    "note": "aggregate of two independent models trained side by side (ms_per_step = one epoch of BOTH)",
+                                    "roofline": {"frac": rf2["frac"], "achieved": rf2["achieved"], "peak": rf2["peak"], "unit": rf2["unit"]}}
+                other.close()
+            except Exception as e:
+                out["two_folds"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_f64 and args.folds == 1:
             # secondary line: the same workload with the model kept in fp64 on the GPU (the reference's precision)
             try:
@@ -944,7 +972,7 @@ def main():
             # workloads timed in this same run travel as five numbers each inside config; the full objects stay at
             # the top level for whoever reads the line itself
             sec = {}
-            for key in ("northstar", "c5", "f64", "fm_c4", "rank"):
+            for key in ("northstar", "c5", "f64", "two_folds", "fm_c4", "rank"):
                 o = out.get(key)
                 if not isinstance(o, dict) or o.get("value") is None:
                     continue
